@@ -1,0 +1,323 @@
+/* mi355x_nk.h — C ABI of libmi355x_nk.so: a MI355X (gfx950) Newton–Krylov inner loop that
+ * drops in behind SciML/NonlinearSolve.jl's first-order step path.
+ *
+ * Every entry point replaces one seam of the reference (paths relative to the reference tree):
+ *
+ *   seam 1  linsolve backend   lib/NonlinearSolveBase/ext/NonlinearSolveBaseLinearSolveExt.jl:16-32
+ *                              (LinearSolveJLCache functor → solve!(lincache)), tolerances pushed by
+ *                              lib/NonlinearSolveFirstOrder/src/eisenstat_walker.jl:50,77
+ *                              → nk_gmres_*                                     (GMRES(m) on device)
+ *   seam 2  jac/jvp/vjp        lib/SciMLJacobianOperators/src/SciMLJacobianOperators.jl:167-182,238-243
+ *                              (mul!(Jv, StatefulJacobianOperator, v)), f.jac at
+ *                              lib/NonlinearSolveBase/src/jacobian.jl:237-258
+ *                              → nk_residual / nk_jvp / nk_vjp / nk_jac_values / nk_spmv / nk_spmv_t
+ *   seam 3  whole solver       ext/NonlinearSolvePETScExt.jl:38-167 pattern (SciMLBase.__solve) over
+ *                              lib/NonlinearSolveFirstOrder/src/solve.jl:140-301 (init), :325-465 (step!)
+ *                              lib/NonlinearSolveBase/src/solve.jl:360-387 (run to completion)
+ *                              → nk_solver_init / _step / _solve / _reinit
+ *
+ * Conventions: C linkage, plain pointers and sizes, no C++ or torch types. All floating point data is
+ * IEEE binary64. Every function returns an nk_status (0 = ok, <0 = error); the message of the last error
+ * is available from nk_last_error(). Numerical non-convergence is a *retcode*, never an error status.
+ * Vector arguments carry an explicit memory space (NK_HOST / NK_DEVICE). Host arrays are only read or
+ * written during the call; device arrays must live on the context's device. Calls are asynchronous on the
+ * context's HIP stream unless documented otherwise (anything returning scalars to the host synchronises).
+ * A context is single-threaded. There is NO CPU fallback: without a HIP device nk_ctx_create fails.
+ */
+#ifndef MI355X_NK_H
+#define MI355X_NK_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NK_VERSION_MAJOR 0
+#define NK_VERSION_MINOR 1
+
+/* ---------------------------------------------------------------- status / enums */
+typedef enum {
+  NK_OK = 0,
+  NK_E_INVALID = -1,   /* bad argument */
+  NK_E_HIP = -2,       /* HIP runtime error (no device, launch failure, ...) */
+  NK_E_RCCL = -3,      /* RCCL error or librccl not loadable */
+  NK_E_NOMEM = -4,
+  NK_E_UNSUPPORTED = -5,
+  NK_E_CALLBACK = -6   /* a user callback returned non-zero */
+} nk_status;
+
+typedef enum { NK_HOST = 0, NK_DEVICE = 1 } nk_memspace;
+
+/* SciMLBase.ReturnCode values that the first-order path can produce
+ * (lib/NonlinearSolveFirstOrder/src/solve.jl:370,399,432; lib/NonlinearSolveBase/src/solve.jl:372-376,851;
+ *  lib/NonlinearSolveBase/src/termination_conditions.jl:262,270,283,303,332). */
+typedef enum {
+  NK_RET_DEFAULT = 0,
+  NK_RET_SUCCESS = 1,
+  NK_RET_MAXITERS = 2,
+  NK_RET_UNSTABLE = 3,
+  NK_RET_STALLED = 4,
+  NK_RET_INTERNAL_LINEAR_SOLVE_FAILED = 5,
+  NK_RET_SHRINK_THRESHOLD_EXCEEDED = 6,
+  NK_RET_MAXTIME = 7,
+  NK_RET_FAILURE = 8
+} nk_retcode;
+
+typedef enum {
+  NK_PROBLEM_QUADRATIC = 1,     /* f(u,p) = u.*u .- p          common/common_rootfind_testing.jl:15-17 */
+  NK_PROBLEM_BRATU2D = 2,       /* 5-point Bratu (not in the reference)                  */
+  NK_PROBLEM_BRUSSELATOR2D = 3, /* lib/NonlinearSolveFirstOrder/test/sparsity_tests__item1.jl:13-36     */
+  NK_PROBLEM_USER = 100         /* user callbacks (f, jvp, vjp, jac) — NonlinearFunction fields         */
+} nk_problem_kind;
+
+typedef enum { NK_ALG_NEWTON_RAPHSON = 0, NK_ALG_TRUST_REGION = 1 } nk_algorithm;
+
+/* which operator the Krylov solver sees as A (lib/NonlinearSolveBase/src/jacobian.jl:43-47,90-102) */
+typedef enum {
+  NK_LINSOLVE_GMRES_MATFREE = 0, /* StatefulJacobianOperator: fused device JVP                       */
+  NK_LINSOLVE_GMRES_CSR = 1,     /* concrete sparse J (values refilled every step) + CSR SpMV        */
+  NK_LINSOLVE_BANDED_LU = 2      /* concrete J, direct banded LU on device (config C2)                */
+} nk_linsolve;
+
+typedef enum {
+  NK_ORTHO_MGS = 0,  /* modified Gram–Schmidt: the structure Krylov.jl's gmres uses [EXT]            */
+  NK_ORTHO_CGS2 = 1, /* classical GS, always re-orthogonalised (2 fused passes)                       */
+  NK_ORTHO_CGS = 2   /* classical GS, re-orthogonalise only when ‖w'‖ < ‖w‖/√2 (DGKS)                 */
+} nk_ortho;
+
+typedef enum { NK_FORCING_NONE = 0, NK_FORCING_EISENSTAT_WALKER2 = 1 } nk_forcing;
+
+/* RadiusUpdateSchemes — lib/NonlinearSolveFirstOrder/src/trust_region.jl:59-147 */
+typedef enum {
+  NK_RUS_SIMPLE = 0, NK_RUS_NLSOLVE = 1, NK_RUS_NOCEDAL_WRIGHT = 2, NK_RUS_HEI = 3,
+  NK_RUS_YUAN = 4, NK_RUS_BASTIN = 5, NK_RUS_FAN = 6
+} nk_radius_update_scheme;
+
+typedef enum { NK_COMM_NONE = 0, NK_COMM_RCCL = 1, NK_COMM_CALLBACKS = 2 } nk_comm_kind;
+
+/* ---------------------------------------------------------------- opaque handles */
+typedef struct nk_ctx nk_ctx;         /* device, stream, communicator, scratch                     */
+typedef struct nk_csr nk_csr;         /* row-partitioned CSR (f64 values, i32 indices) + halo plan */
+typedef struct nk_problem nk_problem; /* residual / JVP / VJP / Jacobian provider                  */
+typedef struct nk_gmres nk_gmres;     /* GMRES(m) workspace (LinearSolve "LinearCache" analogue)    */
+typedef struct nk_solver nk_solver;   /* GeneralizedFirstOrderAlgorithmCache analogue               */
+
+/* ---------------------------------------------------------------- plain structs */
+
+/* NLStats (nf, njacs, nfactors, nsolve, nsteps) — incremented where the reference increments them
+ * (lib/NonlinearSolveBase/src/utils.jl:201, jacobian.jl:238, ext/...LinearSolveExt.jl:20,84,
+ *  lib/NonlinearSolveBase/src/solve.jl:844) — extended with device-side work counters. */
+typedef struct {
+  int64_t nf, njacs, nfactors, nsolve, nsteps;
+  int64_t gmres_iters;     /* total Arnoldi steps                        */
+  int64_t op_applies;      /* SpMV / JVP / VJP applications              */
+  int64_t allreduces;      /* collective calls issued                    */
+  int64_t halo_exchanges;
+} nk_stats;
+
+typedef struct {
+  int32_t iters;        /* Arnoldi steps performed                                    */
+  int32_t restarts;     /* completed restart cycles                                   */
+  int32_t converged;    /* 1: ‖r‖ ≤ atol + rtol‖r0‖ ; 0: iteration cap hit            */
+  int32_t failed;       /* 1: non-finite residual (maps to ReturnCode.Failure)        */
+  double  rnorm0;       /* ‖b − A x0‖₂                                                */
+  double  rnorm;        /* last (recurrence) residual norm estimate                   */
+} nk_gmres_info;
+
+/* One row per nonlinear step: the TraceMinimal fields (lib/NonlinearSolveBase/src/tracing.jl:259-309)
+ * plus the Krylov / forcing / trust-region scalars. */
+typedef struct {
+  int32_t iter;
+  int32_t gmres_iters;
+  int32_t accepted;      /* trust region: step accepted (always 1 for Newton) */
+  int32_t reserved;
+  double  fnorm_inf;     /* ‖f(u)‖∞ after the step                            */
+  double  step_norm2;    /* ‖δu‖₂                                             */
+  double  eta;           /* Krylov reltol used                                */
+  double  trust_region;  /* Δ after the update                                */
+  double  rho;
+} nk_trace_entry;
+
+typedef struct {
+  /* --- algorithm (raphson.jl:30-43, trust_region.jl:25-43) */
+  int32_t algorithm;            /* nk_algorithm                                                     */
+  int32_t linsolve;             /* nk_linsolve                                                      */
+  int32_t maxiters;             /* 1000  (FirstOrder/src/solve.jl:142)                              */
+  int32_t reserved0;
+  double  abstol;               /* ≤0 → 3.0e-13 (common_defaults.jl:44-48)                          */
+  double  reltol;               /* ≤0 → 3.0e-13; only forwarded to the linear solver                */
+  double  maxtime;              /* seconds, ≤0 → none (Base/src/solve.jl:846-856)                   */
+  /* --- Krylov protocol */
+  int32_t gmres_restart;        /* m; ≤0 → 30                                                       */
+  int32_t gmres_maxiters;       /* inner-iteration cap per linear solve; ≤0 → 300                   */
+  int32_t gmres_ortho;          /* nk_ortho                                                         */
+  int32_t gmres_fixed_iters;    /* >0: run exactly this many Arnoldi steps (fixed-work protocol)    */
+  double  lin_abstol;           /* <0 → forward the nonlinear abstol (FirstOrder/src/solve.jl:203)  */
+  double  lin_reltol;           /* <0 → forward the nonlinear reltol                                */
+  /* --- forcing (eisenstat_walker.jl:18-29) */
+  int32_t forcing;              /* nk_forcing                                                       */
+  int32_t ew_safeguard;         /* 1                                                                */
+  double  ew_eta0, ew_eta_max, ew_gamma, ew_alpha, ew_safeguard_threshold; /* .5 .9 .9 2 .1         */
+  /* --- trust region (trust_region.jl:25-33,320-384); 0 → the scheme's default */
+  int32_t radius_update_scheme; /* nk_radius_update_scheme                                          */
+  int32_t max_shrink_times;     /* 32                                                               */
+  double  max_trust_radius, initial_trust_radius, step_threshold, shrink_threshold,
+          expand_threshold, shrink_factor, expand_factor;
+  /* --- termination: AbsNormSafeBestTerminationMode(maximum∘abs; max_stalled_steps = 32)
+   *     (termination_conditions.jl:243-336,385-389); numeric defaults of the mode struct are [EXT] */
+  int32_t patience_steps;       /* 100                                                              */
+  int32_t max_stalled_steps;    /* 32; <0 disables the stall test                                   */
+  double  patience_objective_multiplier; /* 3                                                        */
+  double  min_max_factor;       /* 1.3                                                              */
+  double  protective_threshold; /* ≤0 → off                                                         */
+  /* --- tracing */
+  int32_t store_trace;          /* keep nk_trace_entry rows (costs one extra 2-norm per step)       */
+  int32_t reserved1;
+} nk_options;
+
+/* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
+ * (signatures pinned by lib/SciMLJacobianOperators/test/core_tests__item2.jl:38-40,62-67 and
+ *  lib/NonlinearSolveFirstOrder/test/rootfind_tests__item20.jl:17-32). All pointers are DEVICE pointers
+ *  of local length n; `stream` is the hipStream_t the work must be ordered on. Return 0 on success. */
+typedef int (*nk_residual_fn)(void *user, const double *u, double *f, void *stream);
+typedef int (*nk_jvp_fn)(void *user, const double *v, const double *u, double *Jv, void *stream);
+typedef int (*nk_vjp_fn)(void *user, const double *v, const double *u, double *vJ, void *stream);
+typedef int (*nk_jacvals_fn)(void *user, const double *u, double *csr_vals, void *stream);
+typedef struct {
+  nk_residual_fn residual; /* required */
+  nk_jvp_fn jvp;           /* required for NK_LINSOLVE_GMRES_MATFREE */
+  nk_vjp_fn vjp;           /* required for TrustRegion on the matrix-free path */
+  nk_jacvals_fn jac_values;/* required for concrete-J linsolves (pattern given at create) */
+} nk_user_callbacks;
+
+/* generic operator for nk_gmres: y = A x on device (an AbstractSciMLOperator / FunctionOperator) */
+typedef int (*nk_matvec_fn)(void *user, const double *x, double *y, void *stream);
+
+/* communicator callbacks (used for gloo/CPU-side collectives in tests, or any host transport).
+ * Buffers are DEVICE pointers; the callback must have completed the operation (device-visible) before
+ * it returns, after synchronising `stream` itself if it needs the data on the host. */
+typedef struct {
+  int (*allreduce)(void *user, double *buf, int count, int op /*0 sum, 1 max*/, void *stream);
+  /* exchange bytes with every peer: send_bytes[p] bytes at send+send_off[p] to peer p, receive likewise */
+  int (*alltoallv)(void *user, const void *send, const int64_t *send_off, const int64_t *send_bytes,
+                   void *recv, const int64_t *recv_off, const int64_t *recv_bytes, void *stream);
+  void *user;
+} nk_comm_callbacks;
+
+/* ---------------------------------------------------------------- library / context */
+const char *nk_version(void);
+const char *nk_last_error(void);              /* thread-local; never NULL */
+int nk_device_count(int *count);
+
+/* device_id: HIP ordinal. stream: a hipStream_t to enqueue on, or NULL for a private stream. */
+int nk_ctx_create(int device_id, void *stream, nk_ctx **out);
+int nk_ctx_destroy(nk_ctx *ctx);
+int nk_ctx_set_stream(nk_ctx *ctx, void *stream);
+int nk_ctx_synchronize(nk_ctx *ctx);
+/* deterministic=1 (default): fixed-order two-stage reductions, bitwise reproducible run to run. */
+int nk_ctx_set_deterministic(nk_ctx *ctx, int deterministic);
+
+/* One process per GPU. Rank 0 creates an id, the host language broadcasts the 128 bytes
+ * (torch.distributed / MPI.jl / Distributed.jl), every rank calls nk_ctx_comm_init_rccl. */
+int nk_comm_unique_id(char id_out[128]);
+int nk_ctx_comm_init_rccl(nk_ctx *ctx, int nranks, int rank, const char id[128]);
+int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, const nk_comm_callbacks *cb);
+int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank);
+
+/* contiguous row-range partition used everywhere: rank r owns [r*n/P, (r+1)*n/P) rounded down to a
+ * multiple of `granule` (a grid line for stencil problems). Pure host logic, no device needed. */
+int nk_partition_range(int64_t n_global, int64_t granule, int nranks, int rank,
+                       int64_t *row_begin, int64_t *row_end);
+
+/* ---------------------------------------------------------------- sparse matrices */
+/* Local rows [row_begin, row_begin+nrows_local) of a square n_global matrix, GLOBAL column ids.
+ * index_bits 32|64, index_base 0|1 (Julia). Copies (and for nranks>1 builds the halo plan — collective).
+ * vals may be NULL (pattern only; fill later with nk_csr_set_values / nk_jac_values). */
+int nk_csr_create(nk_ctx *ctx, int64_t nrows_local, int64_t n_global, int64_t row_begin, int64_t nnz,
+                  int index_bits, int index_base, const void *rowptr, const void *colind,
+                  const double *vals, int memspace, nk_csr **out);
+/* Julia's SparseMatrixCSC{Float64,Int} (colptr,rowval,nzval): converts CSC→CSR once on the host.
+ * Single-rank only. */
+int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
+                           const void *colptr, const void *rowval, const double *nzval, nk_csr **out);
+int nk_csr_destroy(nk_csr *A);
+int nk_csr_set_values(nk_csr *A, const double *vals, int memspace);
+int nk_csr_get_values(nk_csr *A, double *vals, int memspace);
+int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, int64_t *nnz, int64_t *n_halo);
+double *nk_csr_values_device(nk_csr *A);      /* device pointer of the local values (nnz doubles) */
+/* y = A x  (x, y local slices; halo exchanged internally).  nk_spmv_t: y = Aᵀ x. */
+int nk_spmv(nk_csr *A, const double *x, double *y, int memspace);
+int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace);
+
+/* ---------------------------------------------------------------- problems (seam 2) */
+/* params: QUADRATIC {n, p}; BRATU2D {n_side, lambda, scale (0 → h², i.e. h²F)};
+ *         BRUSSELATOR2D {N_g, A, B, alpha, dx}.  The problem partitions itself over the ctx's ranks. */
+int nk_problem_create(nk_ctx *ctx, int kind, const double *params, int nparams, nk_problem **out);
+/* csr pattern (local rows, global columns, 0-based int32/int64) is optional: NULL ⇒ no concrete J. */
+int nk_problem_create_user(nk_ctx *ctx, int64_t n_local, int64_t n_global, int64_t row_begin,
+                           const nk_user_callbacks *cb, void *user, nk_csr *jac_pattern,
+                           nk_problem **out);
+int nk_problem_destroy(nk_problem *P);
+int nk_problem_size(nk_problem *P, int64_t *n_local, int64_t *n_global, int64_t *row_begin);
+int nk_problem_set_params(nk_problem *P, const double *params, int nparams);  /* reinit!(cache; p) */
+int nk_problem_initial_guess(nk_problem *P, double *u0, int memspace);
+int nk_residual(nk_problem *P, const double *u, double *f, int memspace);
+int nk_jvp(nk_problem *P, const double *u, const double *v, double *Jv, int memspace);
+int nk_vjp(nk_problem *P, const double *u, const double *v, double *vJ, int memspace);
+/* concrete sparse Jacobian: pattern once, closed-form values per call (f.jac(J,u,p), jacobian.jl:241) */
+int nk_problem_jac_csr(nk_problem *P, nk_csr **out);
+int nk_jac_values(nk_problem *P, const double *u, int memspace, nk_csr *J);
+/* colour-compressed assembly: ncolors JVPs with seed vectors + decompression — the structure of
+ * DI.jacobian! with AutoSparse (jacobian.jl:244-247; colouring ext/...SparseMatrixColoringsExt.jl:13-28) */
+int nk_jac_values_colored(nk_problem *P, const double *u, int memspace, nk_csr *J, int *ncolors);
+
+/* ---------------------------------------------------------------- GMRES (seam 1) */
+int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int ortho, nk_gmres **out);
+int nk_gmres_destroy(nk_gmres *G);
+int nk_gmres_set_operator_csr(nk_gmres *G, nk_csr *A);                    /* cache.A = SparseMatrix   */
+int nk_gmres_set_operator_jvp(nk_gmres *G, nk_problem *P, const double *u, int memspace); /* Stateful… */
+int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);   /* AbstractSciMLOperator    */
+/* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
+int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
+/* Solve A x = b. use_x0 = 0 ⇒ zero initial guess (our protocol); 1 ⇒ x holds x0.
+ * Stop when ‖r‖₂ ≤ atol + rtol‖r0‖₂ or after maxiter Arnoldi steps; fixed_iters>0 overrides both. */
+int nk_gmres_solve(nk_gmres *G, const double *b, double *x, int memspace, int use_x0,
+                   double atol, double rtol, int maxiter, int fixed_iters, nk_gmres_info *info);
+
+/* ---------------------------------------------------------------- Newton / TrustRegion (seam 3) */
+int nk_options_default(nk_options *opts);
+int nk_solver_init(nk_problem *P, const double *u0, int memspace, const nk_options *opts,
+                   nk_solver **out);                       /* SciMLBase.__init */
+int nk_solver_destroy(nk_solver *S);
+int nk_solver_step(nk_solver *S);                          /* CommonSolve.step!  */
+int nk_solver_solve(nk_solver *S, int *retcode);           /* CommonSolve.solve! */
+int nk_solver_reinit(nk_solver *S, const double *u0, int memspace,
+                     const double *params, int nparams);   /* SciMLBase.reinit!(cache, u0; p) */
+int nk_solver_get_u(nk_solver *S, double *u, int memspace);
+int nk_solver_get_resid(nk_solver *S, double *f, int memspace);
+int nk_solver_get_stats(nk_solver *S, nk_stats *stats);
+int nk_solver_get_retcode(nk_solver *S, int *retcode, int *nsteps, int *force_stop);
+int nk_solver_get_scalars(nk_solver *S, double *fnorm_inf, double *trust_region, double *eta);
+int nk_solver_get_trace(nk_solver *S, nk_trace_entry *rows, int capacity, int *nrows);
+/* one call: init + solve + results (what SciMLBase.__solve of the extension algorithm does) */
+int nk_newton_solve(nk_problem *P, const double *u0, int memspace, const nk_options *opts,
+                    double *u_out, double *resid_out, nk_stats *stats, int *retcode);
+
+/* ---------------------------------------------------------------- BLAS-1 building blocks (exported for
+ * the bench / tests; all on the ctx stream, results of reductions are all-reduced over the ranks) */
+int nk_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *result);
+int nk_nrm2(nk_ctx *ctx, int64_t n, const double *x, double *result);
+int nk_norm_inf(nk_ctx *ctx, int64_t n, const double *x, double *result);
+int nk_axpy(nk_ctx *ctx, int64_t n, double a, const double *x, double *y);
+/* Krylov basis kernels: V is column-major n × nv with leading dimension ldv (device).
+ * h[j] = V[:,j]·w  and  w -= V h (returns ‖w‖² after the update in *wnorm2 if non-NULL). */
+int nk_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w, double *h_host);
+int nk_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *h_host,
+                 double *w, double *wnorm2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_NK_H */

@@ -1,0 +1,123 @@
+"""ctypes wrapper around oracle/libnk_oracle.so (C99 + OpenMP restatement). TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnk_oracle.so")
+_lib = None
+
+_d = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "nk_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libnk_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_dot.restype = C.c_double
+        L.orc_dot.argtypes = [C.c_int64, _d, _d]
+        L.orc_norm_inf.restype = C.c_double
+        L.orc_norm_inf.argtypes = [C.c_int64, _d]
+        L.orc_spmv.argtypes = [C.c_int64, _i, _i, _d, _d, _d]
+        L.orc_spmv_t.argtypes = [C.c_int64, C.c_int64, _i, _i, _d, _d, _d]
+        L.orc_bratu_residual.argtypes = [C.c_int64, C.c_double, C.c_double, _d, _d]
+        L.orc_bratu_jvp.argtypes = [C.c_int64, C.c_double, C.c_double, _d, _d, _d]
+        L.orc_bratu_nnz.restype = C.c_int64
+        L.orc_bratu_nnz.argtypes = [C.c_int64]
+        L.orc_bratu_pattern.argtypes = [C.c_int64, _i, _i]
+        L.orc_bratu_jac_values.argtypes = [C.c_int64, C.c_double, C.c_double, _d, _i, _d]
+        L.orc_brusselator_residual.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, _d, _d]
+        L.orc_gmres_csr.restype = C.c_int
+        L.orc_gmres_csr.argtypes = [C.c_int64, _i, _i, _d, _d, _d, C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_bratu_newton.restype = C.c_int
+        L.orc_bratu_newton.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_double, _d, _i, _d]
+        _lib = L
+    return _lib
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def set_num_threads(t):
+    lib().orc_set_num_threads(int(t))
+
+
+def spmv(rowptr, col, val, x):
+    y = np.empty(len(rowptr) - 1)
+    lib().orc_spmv(len(rowptr) - 1, rowptr, col, val, x, y)
+    return y
+
+
+def spmv_t(rowptr, col, val, x, ncols):
+    y = np.empty(ncols)
+    lib().orc_spmv_t(len(rowptr) - 1, ncols, rowptr, col, val, x, y)
+    return y
+
+
+def bratu_residual(ns, lam, scale, u):
+    f = np.empty_like(u)
+    lib().orc_bratu_residual(ns, lam, scale, u, f)
+    return f
+
+
+def bratu_jvp(ns, lam, scale, u, v):
+    jv = np.empty_like(u)
+    lib().orc_bratu_jvp(ns, lam, scale, u, v, jv)
+    return jv
+
+
+def bratu_pattern(ns):
+    nnz = lib().orc_bratu_nnz(ns)
+    rowptr = np.empty(ns * ns + 1, dtype=np.int32)
+    col = np.empty(nnz, dtype=np.int32)
+    lib().orc_bratu_pattern(ns, rowptr, col)
+    return rowptr, col
+
+
+def bratu_jac_values(ns, lam, scale, u, rowptr):
+    val = np.empty(int(rowptr[-1]))
+    lib().orc_bratu_jac_values(ns, lam, scale, u, rowptr, val)
+    return val
+
+
+def brusselator_residual(N, A, B, alpha, dx, u):
+    du = np.empty_like(u)
+    lib().orc_brusselator_residual(N, A, B, alpha, dx, u, du)
+    return du
+
+
+def gmres_csr(rowptr, col, val, b, atol=0.0, rtol=1e-8, m=30, itmax=300, fixed_iters=0):
+    x = np.empty_like(b)
+    conv, r0, r1 = C.c_int(0), C.c_double(0), C.c_double(0)
+    it = lib().orc_gmres_csr(len(b), rowptr, col, val, b, x, atol, rtol, m, itmax, fixed_iters,
+                             C.byref(conv), C.byref(r0), C.byref(r1))
+    return x, dict(iters=it, converged=bool(conv.value), rnorm0=r0.value, rnorm=r1.value)
+
+
+def bratu_newton(ns, lam, scale, u0, nsteps, use_csr=True, m=30, itmax=300, fixed_iters=0, forcing=True,
+                 rtol=1e-4):
+    u = np.array(u0, dtype=np.float64, copy=True)
+    fn = np.zeros(nsteps)
+    gi = np.zeros(nsteps, dtype=np.int32)
+    eta = np.zeros(nsteps)
+    lib().orc_bratu_newton(ns, lam, scale, u, nsteps, int(use_csr), m, itmax, fixed_iters, int(forcing), rtol,
+                           fn, gi, eta)
+    return u, fn, gi, eta

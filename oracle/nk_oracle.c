@@ -1,0 +1,331 @@
+/* CPU ORACLE (C99 + OpenMP) — TEST INFRASTRUCTURE ONLY. Never linked into or called by the product
+ * library; used by tests/ (checker), __graft_entry__.smoke() (checker) and bench.py's cpu_baseline leg.
+ *
+ * Restates, for speed at full problem sizes, the O(N) loops of the reference's Newton–Krylov step:
+ *   - A*x for a concrete sparse Jacobian (the SparseMatrixCSC mul! that Krylov calls; here CSR, int32)
+ *   - residual / JVP / Jacobian values of the 2-D Bratu problem and of the reference's
+ *     Brusselator kernel (lib/NonlinearSolveFirstOrder/test/sparsity_tests__item1.jl:13-36)
+ *   - restarted GMRES(m), MGS Arnoldi + Givens (Krylov.jl gmres, [EXT]: iterates parity-unpinned,
+ *     see oracle/reference_restatement.py header)
+ *   - NewtonDescent step `J δu = fu; δu *= -1; u += δu; fu = f(u)` with EisenstatWalkerForcing2 lag
+ *     (lib/NonlinearSolveBase/src/descent/newton.jl:121-138,
+ *      lib/NonlinearSolveFirstOrder/src/solve.jl:436-443, eisenstat_walker.jl:42-89)
+ * It is validated against oracle/reference_restatement.py (NumPy) in tests/test_oracle_pins.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void orc_set_num_threads(int t) {
+#ifdef _OPENMP
+  omp_set_num_threads(t);
+#else
+  (void)t;
+#endif
+}
+
+/* ------------------------------------------------------------------ BLAS-1 */
+static double dot(int64_t n, const double *x, const double *y) {
+  double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+  for (int64_t i = 0; i < n; ++i) s += x[i] * y[i];
+  return s;
+}
+static void axpy(int64_t n, double a, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
+}
+static double norm_inf(int64_t n, const double *x) {
+  double m = 0.0;
+#pragma omp parallel for reduction(max : m) schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    double a = fabs(x[i]);
+    if (a > m || a != a) m = a;
+  }
+  return m;
+}
+double orc_dot(int64_t n, const double *x, const double *y) { return dot(n, x, y); }
+double orc_norm_inf(int64_t n, const double *x) { return norm_inf(n, x); }
+
+/* ------------------------------------------------------------------ CSR SpMV / transpose */
+void orc_spmv(int64_t nrows, const int32_t *rowptr, const int32_t *col, const double *val,
+              const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < nrows; ++i) {
+    double s = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * x[col[k]];
+    y[i] = s;
+  }
+}
+void orc_spmv_t(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int32_t *col,
+                const double *val, const double *x, double *y) {
+  memset(y, 0, (size_t)ncols * sizeof(double));
+  for (int64_t i = 0; i < nrows; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) y[col[k]] += val[k] * x[i];
+}
+
+/* ------------------------------------------------------------------ 2-D Bratu */
+typedef struct { int64_t ns; double c_lap, c_exp; } bratu_t;
+static bratu_t bratu_make(int64_t ns, double lambda, double scale) {
+  bratu_t b;
+  double h = 1.0 / (double)(ns + 1);
+  double s = (scale == 0.0) ? h * h : scale;
+  b.ns = ns;
+  b.c_lap = s / (h * h);
+  b.c_exp = s * lambda;
+  return b;
+}
+static inline double lap5(const double *u, int64_t ns, int64_t i, int64_t j) {
+  int64_t k = j * ns + i;
+  double s = 4.0 * u[k];
+  if (i > 0) s -= u[k - 1];
+  if (i < ns - 1) s -= u[k + 1];
+  if (j > 0) s -= u[k - ns];
+  if (j < ns - 1) s -= u[k + ns];
+  return s;
+}
+void orc_bratu_residual(int64_t ns, double lambda, double scale, const double *u, double *f) {
+  bratu_t b = bratu_make(ns, lambda, scale);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < ns; ++j)
+    for (int64_t i = 0; i < ns; ++i)
+      f[j * ns + i] = b.c_lap * lap5(u, ns, i, j) - b.c_exp * exp(u[j * ns + i]);
+}
+void orc_bratu_jvp(int64_t ns, double lambda, double scale, const double *u, const double *v, double *jv) {
+  bratu_t b = bratu_make(ns, lambda, scale);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < ns; ++j)
+    for (int64_t i = 0; i < ns; ++i) {
+      int64_t k = j * ns + i;
+      jv[k] = b.c_lap * lap5(v, ns, i, j) - b.c_exp * exp(u[k]) * v[k];
+    }
+}
+/* CSR pattern: rows sorted, columns ascending (S, W, C, E, N), diagonal stored. nnz = 5N - 4ns. */
+int64_t orc_bratu_nnz(int64_t ns) { return 5 * ns * ns - 4 * ns; }
+void orc_bratu_pattern(int64_t ns, int32_t *rowptr, int32_t *col) {
+  int64_t p = 0;
+  for (int64_t j = 0; j < ns; ++j)
+    for (int64_t i = 0; i < ns; ++i) {
+      int64_t k = j * ns + i;
+      rowptr[k] = (int32_t)p;
+      if (j > 0) col[p++] = (int32_t)(k - ns);
+      if (i > 0) col[p++] = (int32_t)(k - 1);
+      col[p++] = (int32_t)k;
+      if (i < ns - 1) col[p++] = (int32_t)(k + 1);
+      if (j < ns - 1) col[p++] = (int32_t)(k + ns);
+    }
+  rowptr[ns * ns] = (int32_t)p;
+}
+void orc_bratu_jac_values(int64_t ns, double lambda, double scale, const double *u,
+                          const int32_t *rowptr, double *val) {
+  bratu_t b = bratu_make(ns, lambda, scale);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < ns; ++j)
+    for (int64_t i = 0; i < ns; ++i) {
+      int64_t k = j * ns + i;
+      int64_t p = rowptr[k];
+      if (j > 0) val[p++] = -b.c_lap;
+      if (i > 0) val[p++] = -b.c_lap;
+      val[p++] = 4.0 * b.c_lap - b.c_exp * exp(u[k]);
+      if (i < ns - 1) val[p++] = -b.c_lap;
+      if (j < ns - 1) val[p++] = -b.c_lap;
+    }
+}
+
+/* ------------------------------------------------------------------ Brusselator (reference kernel) */
+void orc_brusselator_residual(int64_t N, double A, double B, double alpha, double dx,
+                              const double *u, double *du) {
+  const double al = alpha / (dx * dx);
+  const int64_t NN = N * N;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < N; ++j)
+    for (int64_t i = 0; i < N; ++i) {
+      double x = (double)i / (double)(N - 1), y = (double)j / (double)(N - 1);
+      int64_t ip1 = (i + 1 == N) ? 0 : i + 1, im1 = (i == 0) ? N - 1 : i - 1;
+      int64_t jp1 = (j + 1 == N) ? 0 : j + 1, jm1 = (j == 0) ? N - 1 : j - 1;
+      int64_t k = i + N * j;
+      double uu = u[k], vv = u[NN + k];
+      double bf = (((x - 0.3) * (x - 0.3) + (y - 0.6) * (y - 0.6)) <= 0.1 * 0.1) ? 5.0 : 0.0;
+      du[k] = al * (u[im1 + N * j] + u[ip1 + N * j] + u[i + N * jp1] + u[i + N * jm1] - 4.0 * uu) + B +
+              uu * uu * vv - (A + 1.0) * uu + bf;
+      du[NN + k] = al * (u[NN + im1 + N * j] + u[NN + ip1 + N * j] + u[NN + i + N * jp1] +
+                         u[NN + i + N * jm1] - 4.0 * vv) + A * uu - uu * uu * vv;
+    }
+}
+
+/* ------------------------------------------------------------------ operator dispatch for GMRES */
+typedef struct {
+  int kind; /* 0 = CSR, 1 = Bratu matrix-free JVP at u */
+  int64_t n;
+  const int32_t *rowptr, *col;
+  const double *val;
+  int64_t ns;
+  double lambda, scale;
+  const double *u;
+} orc_op;
+
+static void op_apply(const orc_op *A, const double *x, double *y) {
+  if (A->kind == 0) orc_spmv(A->n, A->rowptr, A->col, A->val, x, y);
+  else orc_bratu_jvp(A->ns, A->lambda, A->scale, A->u, x, y);
+}
+
+/* GMRES(m), zero initial guess. Returns Arnoldi steps done; *converged, *rnorm0, *rnorm filled.
+ * fixed_iters>0: exactly that many steps. work: (m+2)*n doubles. */
+static int gmres_run(const orc_op *A, const double *b, double *x, double atol, double rtol, int m,
+                     int itmax, int fixed_iters, double *work, int *converged, double *rnorm0,
+                     double *rnorm_out) {
+  const int64_t n = A->n;
+  double *V = work;               /* (m+1) vectors */
+  double *w = work + (size_t)(m + 1) * n;
+  double *R = (double *)calloc((size_t)m * m, sizeof(double));
+  double *cs = (double *)calloc(m, sizeof(double)), *sn = (double *)calloc(m, sizeof(double));
+  double *g = (double *)calloc(m + 1, sizeof(double)), *h = (double *)calloc(m + 2, sizeof(double));
+  double *yv = (double *)calloc(m, sizeof(double));
+  memset(x, 0, (size_t)n * sizeof(double));
+  double beta = sqrt(dot(n, b, b));
+  *rnorm0 = *rnorm_out = beta;
+  *converged = 0;
+  int iters = 0;
+  const int cap = fixed_iters > 0 ? fixed_iters : itmax;
+  const double eps = fixed_iters > 0 ? -1.0 : atol + rtol * beta;
+  if (beta == 0.0 || (fixed_iters <= 0 && beta <= eps)) { *converged = 1; goto out; }
+  {
+    const double *r = b;
+    double *rbuf = NULL;
+    for (;;) {
+      double ib = 1.0 / beta;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) V[i] = r[i] * ib;
+      memset(g, 0, (size_t)(m + 1) * sizeof(double));
+      g[0] = beta;
+      int k = 0, done = 0;
+      while (k < m && iters < cap) {
+        op_apply(A, V + (size_t)k * n, w);
+        for (int i = 0; i <= k; ++i) { /* modified Gram–Schmidt */
+          h[i] = dot(n, V + (size_t)i * n, w);
+          axpy(n, -h[i], V + (size_t)i * n, w);
+        }
+        double hn = sqrt(dot(n, w, w));
+        h[k + 1] = hn;
+        for (int i = 0; i < k; ++i) {
+          double t = cs[i] * h[i] + sn[i] * h[i + 1];
+          h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+          h[i] = t;
+        }
+        double d = hypot(h[k], h[k + 1]);
+        if (d == 0.0) { cs[k] = 1.0; sn[k] = 0.0; } else { cs[k] = h[k] / d; sn[k] = h[k + 1] / d; }
+        for (int i = 0; i < k; ++i) R[(size_t)i * m + k] = h[i];
+        R[(size_t)k * m + k] = d;
+        g[k + 1] = -sn[k] * g[k];
+        g[k] = cs[k] * g[k];
+        ++iters; ++k;
+        *rnorm_out = fabs(g[k]);
+        if (!(*rnorm_out == *rnorm_out) || isinf(*rnorm_out)) { done = 2; break; }
+        if (fixed_iters <= 0 && *rnorm_out <= eps) { *converged = 1; done = 1; break; }
+        if (hn == 0.0) { *converged = 1; done = 1; break; }
+        double ih = 1.0 / hn;
+        double *vn = V + (size_t)k * n;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) vn[i] = w[i] * ih;
+      }
+      if (k > 0 && done != 2) {
+        for (int i = k - 1; i >= 0; --i) {
+          double s = g[i];
+          for (int j = i + 1; j < k; ++j) s -= R[(size_t)i * m + j] * yv[j];
+          yv[i] = s / R[(size_t)i * m + i];
+        }
+        for (int i = 0; i < k; ++i) axpy(n, yv[i], V + (size_t)i * n, x);
+      }
+      if (done || iters >= cap) { free(rbuf); break; }
+      if (!rbuf) rbuf = (double *)malloc((size_t)n * sizeof(double));
+      op_apply(A, x, w);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) rbuf[i] = b[i] - w[i];
+      r = rbuf;
+      beta = sqrt(dot(n, r, r));
+    }
+  }
+out:
+  free(R); free(cs); free(sn); free(g); free(h); free(yv);
+  return iters;
+}
+
+int orc_gmres_csr(int64_t n, const int32_t *rowptr, const int32_t *col, const double *val,
+                  const double *b, double *x, double atol, double rtol, int m, int itmax,
+                  int fixed_iters, int *converged, double *rnorm0, double *rnorm) {
+  orc_op A = {0, n, rowptr, col, val, 0, 0, 0, NULL};
+  double *work = (double *)malloc((size_t)(m + 2) * n * sizeof(double));
+  int it = gmres_run(&A, b, x, atol, rtol, m, itmax, fixed_iters, work, converged, rnorm0, rnorm);
+  free(work);
+  return it;
+}
+
+/* Newton–Krylov on Bratu: `nsteps` NewtonRaphson steps (no termination test inside — the caller
+ * decides), linsolve = GMRES(m) on the assembled CSR (use_csr=1, values refilled every step as f.jac
+ * does) or on the matrix-free JVP (use_csr=0). forcing=1: EisenstatWalkerForcing2 defaults with the
+ * reference's one-step lag; forcing=0: rtol fixed. fixed_iters>0: fixed-work protocol.
+ * Outputs per step: fnorm_inf[k] = ‖f(u_{k+1})‖∞, gmres_iters[k], eta[k]. u is updated in place. */
+int orc_bratu_newton(int64_t ns, double lambda, double scale, double *u, int nsteps, int use_csr,
+                     int m, int itmax, int fixed_iters, int forcing, double rtol, double *fnorm_inf,
+                     int32_t *gmres_iters, double *eta_out) {
+  const int64_t n = ns * ns;
+  double *f = (double *)malloc((size_t)n * sizeof(double));
+  double *dx = (double *)malloc((size_t)n * sizeof(double));
+  double *work = (double *)malloc((size_t)(m + 2) * n * sizeof(double));
+  int32_t *rowptr = NULL, *col = NULL;
+  double *val = NULL;
+  if (use_csr) {
+    int64_t nnz = orc_bratu_nnz(ns);
+    rowptr = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
+    col = (int32_t *)malloc((size_t)nnz * sizeof(int32_t));
+    val = (double *)malloc((size_t)nnz * sizeof(double));
+    orc_bratu_pattern(ns, rowptr, col);
+  }
+  orc_bratu_residual(ns, lambda, scale, u, f);
+  double eta = 0.5, rn = sqrt(dot(n, f, f)), rn_prev = rn;
+  const double gamma = 0.9, alpha = 2.0, eta_max = 0.9, sg_thr = 0.1;
+  for (int k = 0; k < nsteps; ++k) {
+    orc_op A;
+    if (use_csr) {
+      orc_bratu_jac_values(ns, lambda, scale, u, rowptr, val);
+      orc_op t = {0, n, rowptr, col, val, 0, 0, 0, NULL};
+      A = t;
+    } else {
+      orc_op t = {1, n, NULL, NULL, NULL, ns, lambda, scale, u};
+      A = t;
+    }
+    double tol = rtol;
+    if (forcing) {
+      if (k == 0) { eta = 0.5; rn = rn_prev = sqrt(dot(n, f, f)); }
+      else {
+        double eprev = eta;
+        eta = gamma * pow(rn / rn_prev, alpha);
+        double esg = gamma * pow(eprev, alpha);
+        if (esg > sg_thr && esg > eta) eta = esg;
+        if (eta < 0.0) eta = 0.0;
+        if (eta > eta_max) eta = eta_max;
+      }
+      tol = eta;
+    }
+    int conv; double r0, r1;
+    gmres_iters[k] = gmres_run(&A, f, dx, 0.0, tol, m, itmax, fixed_iters, work, &conv, &r0, &r1);
+    eta_out[k] = tol;
+    if (forcing) { rn_prev = rn; rn = sqrt(dot(n, f, f)); }
+    axpy(n, -1.0, dx, u);                       /* δu = -x ; u += δu */
+    orc_bratu_residual(ns, lambda, scale, u, f); /* fu = f(u) */
+    fnorm_inf[k] = norm_inf(n, f);
+  }
+  free(f); free(dx); free(work); free(rowptr); free(col); free(val);
+  return 0;
+}

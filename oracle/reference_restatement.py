@@ -1,0 +1,898 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+A NumPy/SciPy restatement of SciML/NonlinearSolve.jl's first-order step path, written to be read next
+to the Julia sources (paths relative to the reference tree, v4.27.0):
+
+  step!/init/driver   lib/NonlinearSolveFirstOrder/src/solve.jl:140-301,325-465
+                      lib/NonlinearSolveBase/src/solve.jl:360-387,835-859
+  NewtonRaphson       lib/NonlinearSolveFirstOrder/src/raphson.jl:30-43
+  TrustRegion         lib/NonlinearSolveFirstOrder/src/trust_region.jl:25-43,204-258,320-384,396-514
+  EisenstatWalker     lib/NonlinearSolveFirstOrder/src/eisenstat_walker.jl:42-107
+  NewtonDescent       lib/NonlinearSolveBase/src/descent/newton.jl:28-56,97-141
+  Dogleg / Steepest   lib/NonlinearSolveBase/src/descent/dogleg.jl:86-151, steepest.jl:57-80
+  termination         lib/NonlinearSolveBase/src/termination_conditions.jl:243-336,385-453
+  defaults / norms    lib/NonlinearSolveBase/src/common_defaults.jl:19-48
+  Jacobian operators  lib/SciMLJacobianOperators/src/SciMLJacobianOperators.jl:116-182,210-291
+
+PARITY PINNING.  The reference is Julia and Julia is not installed in the build container, so the
+reference itself cannot be executed; it also ships no golden vectors (every test is an outcome /
+tolerance test).  This oracle is therefore pinned against (tests/test_oracle_pins.py):
+  * every known-answer fixture the reference's own tests hold for this path (quadratic → sqrt(p),
+    tridiagonal N=40 `sol.u ≈ Wmat\\bvec`, custom-JVP N=100 `max|resid|<1e-6`, Brusselator N=32
+    `‖resid‖∞<1e-8`, JVP/VJP/JᵀJ vs the analytic Jacobian, newton_fails+TrustRegion, TR reinit rules),
+  * SciPy as an independent second opinion (scipy.sparse.linalg.gmres / spsolve, scipy.optimize.root).
+GMRES arithmetic lives in Krylov.jl (reached through LinearSolve.jl compat "5.4", version unpinned, source
+absent from /root/reference): its *iterates* are **parity unpinned**; `gmres()` below restates the published
+algorithm (Saad & Schultz restarted GMRES, modified Gram–Schmidt Arnoldi + Givens, stop on
+‖r‖ ≤ atol + rtol‖r0‖).  Defaults of SciMLBase's termination-mode struct (patience_steps=100,
+patience_objective_multiplier=3, min_max_factor=1.3) are from memory of SciMLBase [EXT].
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+# ----------------------------------------------------------------------------- return codes
+DEFAULT, SUCCESS, MAXITERS, UNSTABLE, STALLED, LINSOLVE_FAILED, SHRINK_EXCEEDED, MAXTIME, FAILURE = range(9)
+RETCODE_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalLinearSolveFailed",
+                 "ShrinkThresholdExceeded", "MaxTime", "Failure"]
+
+
+def L2_NORM(x):  # common_defaults.jl:19-30
+    x = np.asarray(x, dtype=np.float64).ravel()
+    return math.sqrt(float(np.dot(x, x)))
+
+
+def Linf_NORM(x):  # common_defaults.jl:32-33 / Base.Fix1(maximum, abs)
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.max(np.abs(x))) if x.size else 0.0
+
+
+DEFAULT_TOL = 3.0e-13  # common_defaults.jl:44-48 (Float64)
+
+
+# ----------------------------------------------------------------------------- problems
+class Problem:
+    """NonlinearProblem(NonlinearFunction(f; jvp, vjp, jac, jac_prototype), u0, p)."""
+
+    n: int
+
+    def f(self, u):
+        raise NotImplementedError
+
+    def jac(self, u) -> sp.csr_matrix:
+        raise NotImplementedError
+
+    def jvp(self, v, u):  # SciMLJacobianOperators.jl:373-431: f.jvp, else jac*v
+        return self.jac(u) @ v
+
+    def vjp(self, v, u):  # SciMLJacobianOperators.jl:296-362
+        return self.jac(u).T @ v
+
+    def u0(self):
+        raise NotImplementedError
+
+
+class Quadratic(Problem):
+    """quadratic_f(u, p) = u .* u .- p   (common/common_rootfind_testing.jl:15-17)."""
+
+    def __init__(self, n, p=2.0):
+        self.n, self.p = int(n), p
+
+    def f(self, u):
+        return u * u - self.p
+
+    def jac(self, u):
+        return sp.diags(2.0 * u, format="csr")
+
+    def jvp(self, v, u):
+        return 2.0 * u * v
+
+    def vjp(self, v, u):
+        return 2.0 * u * v
+
+    def u0(self):
+        return np.ones(self.n)
+
+
+class Bratu2D(Problem):
+    """2-D Bratu, 5-point stencil, homogeneous Dirichlet, lexicographic k = j*n + i (SURVEY.md §8d;
+    not present in the reference).  F_k = s*[(4u_k − u_W − u_E − u_S − u_N)/h² − λ exp(u_k)],
+    s = `scale` (None → h², the h²-scaled residual the convergence test uses)."""
+
+    def __init__(self, n, lam=6.0, scale=None):
+        self.ns = int(n)
+        self.n = self.ns * self.ns
+        self.lam = float(lam)
+        self.h = 1.0 / (self.ns + 1)
+        s = self.h * self.h if scale is None or scale == 0 else float(scale)
+        self.c_lap = s / (self.h * self.h)
+        self.c_exp = s * self.lam
+        self._L = None
+
+    def laplacian(self):
+        if self._L is None:
+            n = self.ns
+            T = sp.diags([-np.ones(n - 1), 4.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+            I = sp.identity(n)
+            S = sp.diags([-np.ones(n - 1), -np.ones(n - 1)], [-1, 1])
+            L = sp.kron(I, T) + sp.kron(S, I)
+            L = sp.csr_matrix(L)
+            L.sort_indices()
+            self._L = L
+        return self._L
+
+    def f(self, u):
+        return self.c_lap * (self.laplacian() @ u) - self.c_exp * np.exp(u)
+
+    def jac(self, u):
+        J = (self.c_lap * self.laplacian() - sp.diags(self.c_exp * np.exp(u))).tocsr()
+        J.sort_indices()
+        return J
+
+    def jvp(self, v, u):
+        return self.c_lap * (self.laplacian() @ v) - self.c_exp * np.exp(u) * v
+
+    def vjp(self, v, u):  # symmetric
+        return self.jvp(v, u)
+
+    def u0(self):
+        return np.zeros(self.n)
+
+
+class Brusselator2D(Problem):
+    """brusselator_2d_loop (lib/NonlinearSolveFirstOrder/test/sparsity_tests__item1.jl:13-36),
+    unknowns column-major (i, j, k): idx = i + N*j + N*N*k (0-based), periodic `limit`."""
+
+    def __init__(self, N, A=3.4, B=1.0, alpha=10.0, dx=None):
+        self.N = int(N)
+        self.n = 2 * self.N * self.N
+        self.A, self.B = float(A), float(B)
+        self.dx = float(dx) if dx is not None else 1.0 / (self.N - 1)  # step(range(0,1,length=N))
+        self.alpha = float(alpha) / (self.dx * self.dx)
+        xy = np.linspace(0.0, 1.0, self.N)
+        X, Y = np.meshgrid(xy, xy, indexing="ij")  # X[i,j] = x_i, Y[i,j] = y_j
+        self.forcing = (((X - 0.3) ** 2 + (Y - 0.6) ** 2) <= 0.1 ** 2) * 5.0
+        self._xy = xy
+        self._Lp = None
+
+    def _lap(self, w):  # periodic 5-point sum minus 4w on an (N,N) array indexed [i,j]
+        return (np.roll(w, 1, 0) + np.roll(w, -1, 0) + np.roll(w, 1, 1) + np.roll(w, -1, 1) - 4.0 * w)
+
+    def _split(self, u):
+        N = self.N
+        U = u.reshape(2, N, N)  # U[k, j, i]
+        return U[0].T, U[1].T  # [i, j]
+
+    def _join(self, a, b):
+        return np.concatenate([a.T.ravel(), b.T.ravel()])
+
+    def f(self, u):
+        uu, vv = self._split(u)
+        du = self.alpha * self._lap(uu) + self.B + uu * uu * vv - (self.A + 1.0) * uu + self.forcing
+        dv = self.alpha * self._lap(vv) + self.A * uu - uu * uu * vv
+        return self._join(du, dv)
+
+    def lap_matrix(self):
+        if self._Lp is None:
+            N = self.N
+            e = np.ones(N)
+            C = sp.diags([e[:-1], e[:-1]], [-1, 1], shape=(N, N)).tolil()
+            C[0, N - 1] = 1.0
+            C[N - 1, 0] = 1.0
+            C = sp.csr_matrix(C)
+            I = sp.identity(N)
+            self._Lp = sp.csr_matrix(sp.kron(I, C) + sp.kron(C, I) - 4.0 * sp.identity(N * N))
+        return self._Lp
+
+    def jac(self, u):
+        uu, vv = self._split(u)
+        uf, vf = uu.T.ravel(), vv.T.ravel()
+        Lp = self.alpha * self.lap_matrix()
+        J11 = Lp + sp.diags(2.0 * uf * vf - (self.A + 1.0))
+        J12 = sp.diags(uf * uf)
+        J21 = sp.diags(self.A - 2.0 * uf * vf)
+        J22 = Lp - sp.diags(uf * uf)
+        J = sp.bmat([[J11, J12], [J21, J22]], format="csr")
+        J.sort_indices()
+        return J
+
+    def jvp(self, v, u):
+        uu, vv = self._split(u)
+        a, b = self._split(v)
+        ja = self.alpha * self._lap(a) + (2.0 * uu * vv - (self.A + 1.0)) * a + uu * uu * b
+        jb = self.alpha * self._lap(b) + (self.A - 2.0 * uu * vv) * a - uu * uu * b
+        return self._join(ja, jb)
+
+    def vjp(self, v, u):
+        uu, vv = self._split(u)
+        a, b = self._split(v)
+        ja = self.alpha * self._lap(a) + (2.0 * uu * vv - (self.A + 1.0)) * a + (self.A - 2.0 * uu * vv) * b
+        jb = self.alpha * self._lap(b) + uu * uu * a - uu * uu * b
+        return self._join(ja, jb)
+
+    def u0(self):  # init_brusselator_2d, sparsity_tests__item1.jl:40-50
+        x = self._xy
+        X, Y = np.meshgrid(x, x, indexing="ij")
+        return self._join(22.0 * (Y * (1.0 - Y)) ** 1.5, 27.0 * (X * (1.0 - X)) ** 1.5)
+
+
+class FunctionProblem(Problem):
+    """Generic problem from Python callables (mirrors NonlinearFunction(f; jvp, vjp, jac))."""
+
+    def __init__(self, f, u0, jac=None, jvp=None, vjp=None):
+        self._f, self._u0 = f, np.asarray(u0, dtype=np.float64)
+        self._jac, self._jvp, self._vjp = jac, jvp, vjp
+        self.n = self._u0.size
+
+    def f(self, u):
+        return np.asarray(self._f(u), dtype=np.float64)
+
+    def jac(self, u):
+        if self._jac is None:
+            # forward differences, only for tiny fixtures (AutoFiniteDiff stand-in)
+            f0 = self.f(u)
+            J = np.zeros((f0.size, u.size))
+            for j in range(u.size):
+                e = np.zeros_like(u)
+                hh = math.sqrt(np.finfo(float).eps) * max(1.0, abs(u[j]))
+                e[j] = hh
+                J[:, j] = (self.f(u + e) - f0) / hh
+            return sp.csr_matrix(J)
+        return sp.csr_matrix(self._jac(u))
+
+    def jvp(self, v, u):
+        return self._jvp(v, u) if self._jvp is not None else self.jac(u) @ v
+
+    def vjp(self, v, u):
+        return self._vjp(v, u) if self._vjp is not None else self.jac(u).T @ v
+
+    def u0(self):
+        return self._u0.copy()
+
+
+# ----------------------------------------------------------------------------- GMRES (Krylov.jl restated)
+@dataclass
+class GmresInfo:
+    iters: int = 0
+    restarts: int = 0
+    converged: bool = False
+    failed: bool = False
+    rnorm0: float = 0.0
+    rnorm: float = 0.0
+    residuals: list = field(default_factory=list)
+
+
+def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0,
+          ortho="mgs", allreduce: Optional[Callable] = None):
+    """Restarted GMRES(m) with MGS Arnoldi and Givens rotations, right-hand side b, zero (or given)
+    initial guess.  Stop when the recurrence residual ≤ atol + rtol*‖r0‖ or after itmax Arnoldi steps.
+    fixed_iters>0: run exactly that many Arnoldi steps (tolerances ignored).
+    `allreduce(x)` (optional) sums partial inner products across ranks (distributed oracle, tests only)."""
+    ar = allreduce if allreduce is not None else (lambda z: z)
+    b = np.asarray(b, dtype=np.float64)
+    n = b.size
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    info = GmresInfo()
+    r = b - matvec(x) if x0 is not None and np.any(x) else b.copy()
+    beta = math.sqrt(float(ar(np.dot(r, r))))
+    info.rnorm0 = info.rnorm = beta
+    info.residuals.append(beta)
+    if not math.isfinite(beta):
+        info.failed = True
+        return x, info
+    if fixed_iters > 0:
+        eps_stop, cap = -1.0, int(fixed_iters)
+    else:
+        eps_stop, cap = atol + rtol * beta, int(itmax)
+    if beta == 0.0 or (fixed_iters <= 0 and beta <= eps_stop):
+        info.converged = True
+        return x, info
+    m = int(restart)
+    while True:
+        V = np.zeros((m + 1, n))
+        R = np.zeros((m, m))          # upper-triangular factor of the Hessenberg matrix
+        cs, sn, g = np.zeros(m), np.zeros(m), np.zeros(m + 1)
+        V[0] = r / beta
+        g[0] = beta
+        k = 0
+        done = False
+        while k < m and info.iters < cap:
+            w = matvec(V[k])
+            h = np.zeros(k + 2)
+            if ortho == "mgs":
+                for i in range(k + 1):
+                    h[i] = float(ar(np.dot(V[i], w)))
+                    w = w - h[i] * V[i]
+            else:  # classical Gram–Schmidt with one re-orthogonalisation (CGS2)
+                hh = ar(V[: k + 1] @ w)
+                w = w - V[: k + 1].T @ hh
+                h2 = ar(V[: k + 1] @ w)
+                w = w - V[: k + 1].T @ h2
+                h[: k + 1] = hh + h2
+            hn = math.sqrt(float(ar(np.dot(w, w))))
+            h[k + 1] = hn
+            for i in range(k):  # apply previous rotations
+                t = cs[i] * h[i] + sn[i] * h[i + 1]
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]
+                h[i] = t
+            d = math.hypot(h[k], h[k + 1])
+            if d == 0.0:
+                cs[k], sn[k] = 1.0, 0.0
+            else:
+                cs[k], sn[k] = h[k] / d, h[k + 1] / d
+            R[: k, k] = h[:k]
+            R[k, k] = d
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            info.iters += 1
+            k += 1
+            info.rnorm = abs(g[k])
+            info.residuals.append(info.rnorm)
+            if not math.isfinite(info.rnorm):
+                info.failed = True
+                done = True
+                break
+            if fixed_iters <= 0 and info.rnorm <= eps_stop:
+                info.converged = True
+                done = True
+                break
+            if hn == 0.0:  # happy breakdown
+                info.converged = True
+                done = True
+                break
+            V[k] = w / hn
+        if k > 0 and not info.failed:
+            y = np.linalg.solve(np.triu(R[:k, :k]), g[:k]) if k > 1 else np.array([g[0] / R[0, 0]])
+            x = x + V[:k].T @ y
+        if done or info.iters >= cap:
+            return x, info
+        info.restarts += 1
+        r = b - matvec(x)
+        beta = math.sqrt(float(ar(np.dot(r, r))))
+
+
+# ----------------------------------------------------------------------------- algorithm descriptors
+@dataclass
+class KrylovJL_GMRES:
+    """Krylov protocol of SURVEY.md §8d (GMRES(m), restart on, x0 = 0, no preconditioner)."""
+    gmres_restart: int = 30
+    maxiters: int = 300
+    ortho: str = "mgs"
+    fixed_iters: int = 0
+
+
+@dataclass
+class DirectSolve:
+    """linsolve = nothing on a sparse J: LinearSolve default sparse LU (KLU/UMFPACK [EXT]) → SuperLU."""
+
+
+@dataclass
+class EisenstatWalkerForcing2:  # eisenstat_walker.jl:18-29
+    eta0: float = 0.5
+    eta_max: float = 0.9
+    gamma: float = 0.9
+    alpha: float = 2.0
+    safeguard: bool = True
+    safeguard_threshold: float = 0.1
+
+
+@dataclass
+class NewtonRaphson:  # raphson.jl:30-43
+    linsolve: object = None
+    forcing: Optional[EisenstatWalkerForcing2] = None
+    concrete_jac: Optional[bool] = None
+    name: str = "NewtonRaphson"
+
+
+SIMPLE, NLSOLVE, NOCEDAL_WRIGHT, HEI, YUAN, BASTIN, FAN = range(7)
+
+
+@dataclass
+class TrustRegion:  # trust_region.jl:25-43 ; 0 means "scheme default" (trust_region.jl:320-328)
+    linsolve: object = None
+    radius_update_scheme: int = SIMPLE
+    max_trust_radius: float = 0.0
+    initial_trust_radius: float = 0.0
+    step_threshold: float = 1.0 / 10000
+    shrink_threshold: float = 1.0 / 4
+    expand_threshold: float = 3.0 / 4
+    shrink_factor: float = 1.0 / 4
+    expand_factor: float = 2.0
+    max_shrink_times: int = 32
+    concrete_jac: Optional[bool] = None
+    name: str = "TrustRegion"
+
+
+@dataclass
+class Stats:  # NLStats
+    nf: int = 0
+    njacs: int = 0
+    nfactors: int = 0
+    nsolve: int = 0
+    nsteps: int = 0
+    gmres_iters: int = 0
+
+
+@dataclass
+class Solution:
+    u: np.ndarray
+    resid: np.ndarray
+    retcode: int
+    stats: Stats
+    trace: list
+
+
+# ----------------------------------------------------------------------------- termination cache
+class TerminationCache:
+    """AbsNormSafeBestTerminationMode(maximum∘abs; max_stalled_steps = 32) functor —
+    termination_conditions.jl:243-336 (default mode :385-389)."""
+
+    def __init__(self, fu, u, abstol, patience_steps=100, patience_objective_multiplier=3.0,
+                 min_max_factor=1.3, max_stalled_steps=32, protective_threshold=None, leastsq=False):
+        self.abstol = abstol
+        self.patience_steps = patience_steps
+        self.pom = patience_objective_multiplier
+        self.min_max_factor = min_max_factor
+        self.max_stalled_steps = max_stalled_steps
+        self.protective_threshold = protective_threshold
+        self.leastsq = leastsq
+        self.reinit(fu, u)
+
+    def reinit(self, fu, u):
+        self.u = np.array(u, copy=True)
+        self.retcode = DEFAULT
+        self.nsteps = 0
+        self.initial_objective = Linf_NORM(fu)
+        self.best_objective_value = self.initial_objective
+        self.objectives_trace = np.zeros(self.patience_steps)
+        self.step_norm_trace = None if self.max_stalled_steps is None else np.zeros(self.max_stalled_steps)
+
+    def __call__(self, du, u, uprev):
+        objective = Linf_NORM(du)
+        criteria = self.abstol
+        if not math.isfinite(objective):
+            self.retcode = UNSTABLE
+            return True
+        if self.protective_threshold is not None and \
+                objective > self.initial_objective * self.protective_threshold * du.size:
+            self.retcode = UNSTABLE
+            return True
+        if objective < self.best_objective_value:
+            self.best_objective_value = objective
+            self.u[...] = u
+        if objective <= criteria:
+            self.retcode = SUCCESS
+            return True
+        self.nsteps += 1
+        L = len(self.objectives_trace)
+        self.objectives_trace[(self.nsteps - 1) % L] = objective  # mod1
+        if objective <= self.pom * criteria and self.nsteps > self.patience_steps:
+            tr = self.objectives_trace[: self.nsteps] if self.nsteps < L else self.objectives_trace
+            if tr.min() < self.min_max_factor * tr.max():
+                self.retcode = STALLED
+                return True
+        if self.step_norm_trace is not None:
+            du_norm = L2_NORM(u - uprev)
+            self.step_norm_trace[(self.nsteps - 1) % len(self.step_norm_trace)] = du_norm
+            if self.nsteps > self.max_stalled_steps:
+                if self.step_norm_trace.max() <= self.abstol:
+                    self.retcode = STALLED
+                    return True
+        self.retcode = FAILURE
+        return False
+
+
+# ----------------------------------------------------------------------------- the cache
+class FirstOrderCache:
+    """GeneralizedFirstOrderAlgorithmCache — `init`, `step!`, `solve!`, `reinit!`."""
+
+    def __init__(self, prob: Problem, alg, abstol=None, reltol=None, maxiters=1000, u0=None,
+                 termination_kwargs=None, store_trace=True, lin_x0_zero=True):
+        self.prob, self.alg = prob, alg
+        self.abstol = DEFAULT_TOL if abstol is None else float(abstol)
+        self.reltol = DEFAULT_TOL if reltol is None else float(reltol)
+        self.maxiters = int(maxiters)
+        self.termination_kwargs = termination_kwargs or {}
+        self.store_trace = store_trace
+        self.is_tr = isinstance(alg, TrustRegion)
+        ls = alg.linsolve
+        self.krylov = ls if isinstance(ls, KrylovJL_GMRES) else None
+        # jacobian.jl:43-47 — concrete J needed unless a Krylov method without concrete_jac
+        self.concrete = (self.krylov is None) or bool(alg.concrete_jac)
+        self._init(prob.u0() if u0 is None else np.asarray(u0, dtype=np.float64))
+
+    # -- SciMLBase.__init (FirstOrder/src/solve.jl:140-301)
+    def _init(self, u0):
+        prob = self.prob
+        self.u = np.array(u0, dtype=np.float64, copy=True)
+        self.fu = prob.f(self.u)
+        self.u_cache = self.u.copy()
+        self.stats = Stats()
+        self.nsteps = 0
+        self.retcode = DEFAULT
+        self.force_stop = False
+        self.make_new_jacobian = True
+        self.tc = TerminationCache(self.fu, self.u, self.abstol, **self.termination_kwargs)
+        self.J = None
+        if self.concrete:
+            self.J = prob.jac(self.u)  # jacobian.jl:104-118 (evaluated once "to get the type")
+            self.stats.njacs += 1
+        self.du = np.zeros_like(self.u)  # descent/newton.jl:34-36
+        self.trace = []
+        self.eta = float("nan")
+        forcing = getattr(self.alg, "forcing", None)
+        self.forcing = forcing if (forcing is not None and self.krylov is not None) else None
+        if self.forcing is not None:  # eisenstat_walker.jl:92-101
+            self.ew_eta = self.forcing.eta0
+            self.ew_rnorm = self.ew_rnorm_prev = L2_NORM(self.fu)
+        self.lin_reltol = self.reltol  # FirstOrder/src/solve.jl:203
+        self.lin_abstol = self.abstol
+        if self.is_tr:
+            self._tr_init(self.u, self.fu)
+
+    # -- trust_region.jl:204-258 (+ defaults :320-384)
+    def _tr_defaults(self):
+        a, m = self.alg, self.alg.radius_update_scheme
+        def pick(val, default):
+            return default if val == 0 else float(val)
+        self.step_threshold = pick(a.step_threshold, {HEI: 0.0, YUAN: 1e-3, BASTIN: 0.05}.get(m, 1e-4))
+        self.shrink_threshold = pick(a.shrink_threshold, {HEI: 0.0, NLSOLVE: 0.05, BASTIN: 0.05}.get(m, 0.25))
+        self.expand_threshold = pick(a.expand_threshold, {NLSOLVE: 0.9, HEI: 0.0, BASTIN: 0.9}.get(m, 0.75))
+        self.shrink_factor = pick(a.shrink_factor, {NLSOLVE: 0.5, HEI: 0.0, BASTIN: 0.05}.get(m, 0.25))
+        self.expand_factor = pick(a.expand_factor, 2.0)
+        self.p1, self.p2, self.p3, self.p4 = {
+            NLSOLVE: (0.5, 0.0, 0.0, 0.0), HEI: (5.0, 0.1, 0.15, 0.15), YUAN: (2.0, 1.0 / 6, 6.0, 0.0),
+            FAN: (0.1, 0.25, 12.0, 1e18), BASTIN: (2.5, 0.25, 0.0, 0.0)}.get(m, (0.0, 0.0, 0.0, 0.0))
+
+    def _tr_radii(self, u, fu):
+        a, m = self.alg, self.alg.radius_update_scheme
+        u0_norm, fu_norm = L2_NORM(u), L2_NORM(fu)
+        if a.max_trust_radius != 0:
+            mtr = float(a.max_trust_radius)
+        elif m in (SIMPLE, NOCEDAL_WRIGHT):
+            mtr = max(fu_norm, float(np.max(u) - np.min(u)))
+        else:
+            mtr = float("inf")
+        if a.initial_trust_radius != 0:
+            itr = float(a.initial_trust_radius)
+        elif m == NLSOLVE:
+            itr = u0_norm if u0_norm > 0 else 1.0
+        elif m in (HEI, BASTIN):
+            itr = 1.0
+        elif m == FAN:
+            itr = (fu_norm ** 0.99) / 10
+        else:
+            itr = mtr / 11
+        return mtr, itr
+
+    def _tr_init(self, u, fu):
+        self._tr_defaults()
+        self.max_trust_radius, self.initial_trust_radius = self._tr_radii(u, fu)
+        if self.alg.radius_update_scheme == YUAN:
+            self.initial_trust_radius = self.p1 * L2_NORM(self._apply_JT(fu, u))
+        self.trust_region = self.initial_trust_radius
+        self.rho = 0.0
+        self.shrink_counter = 0
+        self.last_step_accepted = False
+        self.tr_du_cache = np.zeros_like(u)
+
+    # -- operators (jacobian.jl:237-262, SciMLJacobianOperators.jl:238-243)
+    def _apply_J(self, v, u):
+        self.stats_op = getattr(self, "stats_op", 0) + 1
+        return (self.J @ v) if self.concrete else self.prob.jvp(v, u)
+
+    def _apply_JT(self, v, u):
+        return (self.J.T @ v) if self.concrete else self.prob.vjp(v, u)
+
+    # -- NewtonDescent.solve! (descent/newton.jl:97-141) through LinearSolveJLCache (ext:16-32)
+    def _newton_descent(self, new_jacobian):
+        self.stats.nsolve += 1
+        if self.krylov is not None:
+            kr = self.krylov
+            u_now = self.u
+            x, info = gmres(lambda v: self._apply_J(v, u_now), self.fu, None, atol=self.lin_abstol,
+                            rtol=self.lin_reltol, restart=kr.gmres_restart, itmax=kr.maxiters,
+                            fixed_iters=kr.fixed_iters, ortho=kr.ortho)
+            self.stats.gmres_iters += info.iters
+            self.last_gmres = info
+            if info.failed:
+                return None
+        else:
+            import scipy.sparse.linalg as spla
+            if new_jacobian or getattr(self, "_lu", None) is None:
+                self._lu = spla.splu(sp.csc_matrix(self.J))
+                self.stats.nfactors += 1
+            x = self._lu.solve(self.fu)
+            if not np.all(np.isfinite(x)):
+                return None
+        return -x  # @bb @. δu *= -1  (newton.jl:138)
+
+    # -- Dogleg.solve! (descent/dogleg.jl:86-151)
+    def _dogleg(self, new_jacobian, trust_region):
+        du_newton = self._newton_descent(new_jacobian)
+        if du_newton is None:
+            return None, float("nan")
+        if L2_NORM(du_newton) <= trust_region:
+            return du_newton.copy(), float("nan")
+        du_cauchy = -self._apply_JT(self.fu, self.u)  # steepest.jl:75-77
+        l_grad = L2_NORM(du_cauchy)
+        Jdc = self._apply_J(du_cauchy, self.u)
+        duJJdu = float(np.dot(Jdc, Jdc))
+        d_cauchy = (l_grad ** 3) / duJJdu
+        if d_cauchy >= trust_region:
+            lam = trust_region / l_grad
+            return lam * du_cauchy, lam * lam * duJJdu
+        c1 = (d_cauchy / l_grad) * du_cauchy
+        c2 = du_newton - c1
+        a = float(np.dot(c2, c2))
+        b = 2.0 * float(np.dot(c1, c2))
+        c = d_cauchy ** 2 - trust_region ** 2
+        aux = max(0.0, b * b - 4.0 * a * c)
+        tau = (-b + math.sqrt(aux)) / (2.0 * a)
+        return c1 + tau * c2, float("nan")
+
+    # -- GenericTrustRegionSchemeCache solve! (trust_region.jl:396-514)
+    def _tr_solve(self, du, duJJdu):
+        m = self.alg.radius_update_scheme
+        u_new = self.u + du
+        fu_new = self.prob.f(u_new)
+        self.stats.nf += 1
+        if math.isnan(duJJdu):
+            Jdu = self._apply_J(du, self.u)
+            duJJdu = float(np.dot(Jdu, Jdu))
+        JTfu = self._apply_JT(self.fu, self.u)
+        num = (L2_NORM(fu_new) ** 2 - L2_NORM(self.fu) ** 2) / 2.0
+        denom = float(np.dot(du, JTfu)) + duJJdu / 2.0
+        self.rho = num / denom if denom != 0 else float("nan")
+        rho = self.rho
+        self.last_step_accepted = bool(rho > self.step_threshold)
+        nd = L2_NORM(du)
+        if m == SIMPLE:
+            if rho < self.shrink_threshold:
+                self.trust_region *= self.shrink_factor
+                self.shrink_counter += 1
+            else:
+                self.shrink_counter = 0
+                if rho > self.expand_threshold and rho > self.step_threshold:
+                    self.trust_region = self.expand_factor * self.trust_region
+        elif m == NLSOLVE:
+            if rho < self.shrink_threshold:
+                self.trust_region *= self.shrink_factor
+                self.shrink_counter += 1
+            else:
+                self.shrink_counter = 0
+                if rho >= self.expand_threshold:
+                    self.trust_region = self.expand_factor * nd
+                elif rho >= self.p1:
+                    self.trust_region = max(self.trust_region, self.expand_factor * nd)
+        elif m == NOCEDAL_WRIGHT:
+            if rho < self.shrink_threshold:
+                self.trust_region = self.shrink_factor * nd
+                self.shrink_counter += 1
+            else:
+                self.shrink_counter = 0
+                if rho > self.expand_threshold and abs(nd - self.trust_region) < 1e-6 * self.trust_region:
+                    self.trust_region = self.expand_factor * self.trust_region
+        elif m == HEI:
+            r, c2, M, g1, g2, beta = rho, self.shrink_threshold, self.p1, self.p3, self.p4, self.p2
+            if r >= c2:
+                rf = (2 * (M - 1 - g2) * math.atan(r - c2) + (1 + g2)) / math.pi
+            else:
+                rf = (1 - g1 - beta) * (math.exp(r - c2) + beta / (1 - g1 - beta))
+            tr_new = rf * nd
+            if tr_new < self.trust_region:
+                self.shrink_counter += 1
+            else:
+                self.shrink_counter = 0
+            self.trust_region = tr_new
+        elif m == YUAN:
+            if rho < self.shrink_threshold:
+                self.p1 = self.p2 * self.p1
+                self.shrink_counter += 1
+            else:
+                if rho >= self.expand_threshold and 2 * nd > self.trust_region:
+                    self.p1 = self.p3 * self.p1
+                self.shrink_counter = 0
+            JTf_new = self.prob.vjp(fu_new, u_new)
+            self.trust_region = self.p1 * L2_NORM(JTf_new)
+        elif m == FAN:
+            if rho < self.shrink_threshold:
+                self.p1 *= self.p2
+                self.shrink_counter += 1
+            else:
+                self.shrink_counter = 0
+                if rho > self.expand_threshold:
+                    self.p1 = min(self.p1 * self.p3, self.p4)
+            self.trust_region = self.p1 * (L2_NORM(fu_new) ** 0.99)
+        elif m == BASTIN:
+            if rho > self.step_threshold:
+                Jdu2 = self.prob.jvp(self.tr_du_cache, u_new)
+                JTf2 = self.prob.vjp(fu_new, u_new)
+                denom_1 = float(np.dot(JTf2, JTf2))
+                JTJdu = self.prob.vjp(Jdu2, u_new)
+                denom_2 = float(np.dot(JTJdu, JTJdu))
+                rho2 = num / (denom_1 + denom_2 / 2.0)
+                if rho2 >= self.expand_threshold:
+                    self.trust_region = self.p1 * L2_NORM(self.tr_du_cache)
+                self.shrink_counter = 0
+            else:
+                self.trust_region *= self.p2
+                self.shrink_counter += 1
+        self.trust_region = min(self.trust_region, self.max_trust_radius)
+        return self.last_step_accepted, u_new, fu_new
+
+    # -- pre/post_step_forcing! (eisenstat_walker.jl:42-89)
+    def _pre_step_forcing(self, it):
+        p = self.forcing
+        if it == 0:
+            self.ew_eta = p.eta0
+            self.ew_rnorm = self.ew_rnorm_prev = L2_NORM(self.fu)
+        else:
+            eta_prev = self.ew_eta
+            self.ew_eta = p.gamma * (self.ew_rnorm / self.ew_rnorm_prev) ** p.alpha
+            if p.safeguard:
+                eta_sg = p.gamma * eta_prev ** p.alpha
+                if eta_sg > p.safeguard_threshold and eta_sg > self.ew_eta:
+                    self.ew_eta = eta_sg
+            self.ew_eta = min(max(self.ew_eta, 0.0), p.eta_max)
+        self.lin_reltol = self.ew_eta  # LinearSolve.update_tolerances!(…; reltol = η)
+
+    def _post_step_forcing(self):
+        self.ew_rnorm_prev = self.ew_rnorm
+        self.ew_rnorm = L2_NORM(self.fu)
+
+    # -- InternalAPI.step! (FirstOrder/src/solve.jl:325-465) + CommonSolve.step! (Base/src/solve.jl:835-859)
+    def step(self, recompute_jacobian=None):
+        if self.force_stop or self.nsteps >= self.maxiters:
+            return
+        self._internal_step(recompute_jacobian)
+        self.stats.nsteps += 1
+        self.nsteps += 1
+
+    def _internal_step(self, recompute_jacobian=None):
+        if (recompute_jacobian is None or recompute_jacobian) and self.make_new_jacobian:
+            if self.concrete:
+                self.J = self.prob.jac(self.u)
+                self.stats.njacs += 1
+            new_jacobian = True
+        else:
+            new_jacobian = False
+        if self.forcing is not None:
+            self._pre_step_forcing(self.nsteps)
+        if self.is_tr:
+            du, duJJdu = self._dogleg(new_jacobian, self.trust_region)
+        else:
+            du, duJJdu = self._newton_descent(new_jacobian), float("nan")
+        if du is None:  # linear solve failed
+            if new_jacobian:
+                self.retcode = LINSOLVE_FAILED
+                self.force_stop = True
+                return
+            self.make_new_jacobian = True
+            return self._internal_step(True)
+        self.du = du
+        if self.forcing is not None:
+            self._post_step_forcing()
+        self.make_new_jacobian = True
+        accepted = True
+        if self.is_tr:
+            self.tr_du_cache = du
+            accepted, u_new, fu_new = self._tr_solve(du, duJJdu)
+            if accepted:
+                self.u = u_new.copy()
+                self.fu = fu_new.copy()
+            else:
+                self.make_new_jacobian = False
+            if self.shrink_counter > self.alg.max_shrink_times:
+                self.retcode = SHRINK_EXCEEDED
+                self.force_stop = True
+        else:
+            self.u = self.u + du         # @bb axpy!(1, δu, cache.u)
+            self.fu = self.prob.f(self.u)  # Utils.evaluate_f!
+            self.stats.nf += 1
+        # check_and_update! (termination_conditions.jl:414-426)
+        if self.tc(self.fu, self.u, self.u_cache):
+            self.retcode = self.tc.retcode
+            self._rollback_to_best()
+            self.force_stop = True
+        if self.store_trace:
+            self.trace.append(dict(iter=self.nsteps + 1, fnorm_inf=Linf_NORM(self.fu), step_norm2=L2_NORM(du),
+                                   eta=self.lin_reltol if self.krylov is not None else float("nan"),
+                                   gmres_iters=self.last_gmres.iters if self.krylov is not None else 0,
+                                   accepted=bool(accepted),
+                                   trust_region=self.trust_region if self.is_tr else float("nan"),
+                                   rho=self.rho if self.is_tr else float("nan")))
+        self.u_cache = self.u.copy()
+
+    def _rollback_to_best(self):  # update_from_termination_cache! (termination_conditions.jl:440-453)
+        if np.array_equal(self.u, self.tc.u):
+            return
+        self.u = self.tc.u.copy()
+        self.fu = self.prob.f(self.u)
+        self.stats.nf += 1
+
+    # -- _run_cache_to_completion! (Base/src/solve.jl:360-387)
+    def solve(self):
+        while (not self.force_stop) and self.nsteps < self.maxiters:
+            self.step()
+        if self.retcode == DEFAULT:
+            self.retcode = MAXITERS if self.nsteps >= self.maxiters else SUCCESS
+        self._rollback_to_best()
+        return Solution(self.u.copy(), self.fu.copy(), self.retcode, self.stats, self.trace)
+
+    # -- reinit! (FirstOrder/src/solve.jl:108-133, trust_region.jl:292-317, eisenstat_walker.jl:104-107)
+    def reinit(self, u0=None, p=None):
+        if p is not None:
+            self.prob.p = p
+        u0 = self.u if u0 is None else np.asarray(u0, dtype=np.float64)
+        self.u = np.array(u0, copy=True)
+        self.fu = self.prob.f(self.u)
+        self.u_cache = self.u.copy()
+        self.stats = Stats()
+        self.nsteps = 0
+        self.force_stop = False
+        self.retcode = DEFAULT
+        self.make_new_jacobian = True
+        self.trace = []
+        self.tc.reinit(self.fu, self.u)
+        if self.forcing is not None:
+            self.ew_eta = self.forcing.eta0
+        self.lin_reltol = self.reltol
+        if self.is_tr:
+            self.max_trust_radius, self.initial_trust_radius = self._tr_radii(self.u, self.fu)
+            if self.alg.radius_update_scheme == YUAN:
+                self.initial_trust_radius = self.p1 * L2_NORM(self._apply_JT(self.fu, self.u))
+            self.last_step_accepted = False
+            self.trust_region = self.initial_trust_radius
+            self.shrink_counter = 0
+
+
+def init(prob, alg, **kw):
+    return FirstOrderCache(prob, alg, **kw)
+
+
+def solve(prob, alg, **kw):
+    return FirstOrderCache(prob, alg, **kw).solve()
+
+
+# ----------------------------------------------------------------------------- Jacobian operators (L2)
+class JacobianOperator:
+    """JacobianOperator / StatefulJacobianOperator / normal form — SciMLJacobianOperators.jl:86-291."""
+
+    def __init__(self, prob: Problem, mode="jvp"):
+        self.prob, self.mode = prob, mode
+
+    @property
+    def T(self):
+        return JacobianOperator(self.prob, "vjp" if self.mode == "jvp" else "jvp")
+
+    def __call__(self, v, u):
+        return self.prob.jvp(v, u) if self.mode == "jvp" else self.prob.vjp(v, u)
+
+
+class StatefulJacobianOperator:
+    def __init__(self, op: JacobianOperator, u):
+        self.op, self.u = op, np.asarray(u, dtype=np.float64)
+
+    @property
+    def T(self):
+        return StatefulJacobianOperator(self.op.T, self.u)
+
+    def __matmul__(self, v):
+        if isinstance(v, StatefulJacobianOperator):  # Jᵀ * J → normal form
+            left, right = self, v
+            return _NormalForm(left, right)
+        return self.op(np.asarray(v, dtype=np.float64), self.u)
+
+
+class _NormalForm:
+    def __init__(self, vjp_op, jvp_op):
+        self.vjp_op, self.jvp_op = vjp_op, jvp_op
+
+    def __matmul__(self, x):
+        return self.vjp_op @ (self.jvp_op @ x)
