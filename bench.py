@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py — Newton steps/s + SpMV GB/s vs the HBM roofline on 2-D Bratu (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (config C3 of BASELINE.md, the configuration the metric is quoted on): 2-D Bratu n = 1024²
+(N = 1 048 576 unknowns, nnz = 5 238 784, λ = 6, u0 = 0), NewtonRaphson with the *fixed-work* Krylov protocol
+of SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step, zero initial guess, CGS2
+orthogonalisation — on the assembled CSR Jacobian (values refilled every step, SpMV as the operator).
+A "step" is one such Newton step: Jacobian value fill + 30×(SpMV + CGS2 pass) + solution update + u += δu +
+residual + ‖·‖∞ + termination bookkeeping, everything resident in HBM.
+N > 1: weak scaling — every rank owns ≈1024² unknowns of a (1024·√N)² grid (row-range partition by grid
+lines, halo lines by RCCL send/recv, Krylov inner products by RCCL all-reduce).
+
+Extra objects on the JSON line: `roofline` (CSR SpMV kernel, HIP-event timed on the launch stream in a second,
+instrumented pass of the same K steps), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
+C/OpenMP restatement timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1024, help="grid side per GPU-equivalent (1024 ⇒ N = 1e6)")
+    ap.add_argument("--ortho", default="cgs2", choices=["cgs2", "cgs", "mgs"])
+    ap.add_argument("--arnoldi", type=int, default=30)
+    ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="Newton steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import nonlinearsolve_jl_amd as nls
+
+    ctx = nls.Context(device=local_rank)
+    nls.set_default_context(ctx)
+    comm = "none"
+    if world > 1:
+        # unique id from rank 0, broadcast as bytes over torch.distributed (RCCL); the library then owns its
+        # own communicator on the compute stream
+        if rank == 0:
+            uid = torch.tensor(list(nls.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        ctx.comm_init_rccl(world, rank, bytes(uid.cpu().tolist()))
+        comm = "rccl"
+
+    # weak scaling: grid side so that every rank owns ≈ n² unknowns; side must be ≥ world lines
+    ns = args.n if world == 1 else int(round(args.n * math.sqrt(world)))
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+    n_local = prob.device_problem.n_local
+    n_global = prob.device_problem.n_global
+    alg = nls.NewtonRaphson(
+        linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho,
+                                    fixed_iters=args.arnoldi),
+        concrete_jac=not args.matfree)
+    u0 = torch.zeros(n_local, dtype=torch.float64, device="cuda")
+    prob.u0 = u0
+    # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
+    cache = nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(k):
+        for _ in range(k):
+            cache.step()
+
+    run_steps(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    steps_per_s = args.steps / dt
+    stats = cache.stats
+    fnorm = cache.fnorm_inf
+
+    # ---- second, instrumented pass of the same K steps: HIP events on the launch stream around every
+    # kernel family (not part of `value`)
+    kernels = {}
+    if not args.no_profile_pass:
+        ctx.profile_enable(True)
+        run_steps(args.steps)
+        barrier()
+        kernels = ctx.profile_report()
+        ctx.profile_enable(False)
+    dom = "spmv" if not args.matfree else "jvp"
+    roof = None
+    if dom in kernels:
+        k = kernels[dom]
+        roof = {"kernel": "k_spmv_stream" if dom == "spmv" else "k_bratu_jvp", "bound": "hbm",
+                "achieved": round(k["gbps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(k["gbps"] / HBM_PEAK_GBS, 4), "frac_of_achievable_6.29TBs": round(k["gbps"] / HBM_ACHIEVABLE_GBS, 4),
+                "traffic": None, "launches": k["launches"], "avg_us": round(k["avg_us"], 2),
+                "algorithmic_bytes_per_launch": int(k["bytes"] / k["launches"])}
+    ksum = {name: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbps"], 1),
+                   "frac_of_8TBs": round(v["gbps"] / HBM_PEAK_GBS, 4), "share_of_step_time": None}
+            for name, v in kernels.items()}
+    tot = sum(v["total_ms"] for v in kernels.values()) or 1.0
+    for name, v in kernels.items():
+        ksum[name]["share_of_step_time"] = round(v["total_ms"] / tot, 4)
+
+    # ---- CPU baseline: the oracle's C/OpenMP restatement on this box's host cores, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        import numpy as np
+        from oracle import c_oracle as CO
+        CO.build()
+        cores = CO.num_threads()
+        tc = time.perf_counter()
+        CO.bratu_newton(ns, 6.0, 0.0, np.zeros(ns * ns), args.cpu_steps, use_csr=not args.matfree, m=args.arnoldi,
+                        itmax=args.arnoldi, fixed_iters=args.arnoldi, forcing=False)
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(args.cpu_steps / tcpu, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port",
+               "sample": f"{args.cpu_steps} fixed-work Newton steps (30 MGS-GMRES Arnoldi steps each) of the same "
+                         f"Bratu {ns}x{ns} workload, oracle/nk_oracle.c with OpenMP on {cores} threads, {tcpu:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "newton_steps_per_sec", "value": round(steps_per_s, 3), "unit": "newton_steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"bratu2d_{ns}x{ns}_newtonraphson_gmres{args.arnoldi}_fixedwork_"
+                                   f"{'matfree_jvp' if args.matfree else 'csr_spmv'}",
+                       "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
+                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho,
+                       "parallelism": f"row-range x{world}", "comm": comm},
+            "roofline": roof, "kernels": ksum, "cpu_baseline": cpu,
+            "gpu_vs_cpu": round(steps_per_s / cpu["value"], 1) if cpu else None,
+            "check": {"fnorm_inf_after_timed_steps": fnorm, "gmres_iters": stats.gmres_iters,
+                      "nsteps": stats.nsteps, "allreduces": stats.allreduces},
+        }
+        print(json.dumps(line))
+    cache.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

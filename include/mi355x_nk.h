@@ -211,13 +211,20 @@ const char *nk_version(void);
 const char *nk_last_error(void);              /* thread-local; never NULL */
 int nk_device_count(int *count);
 
-/* device_id: HIP ordinal. stream: a hipStream_t to enqueue on, or NULL for a private stream. */
+/* device_id: HIP ordinal. stream: the hipStream_t to enqueue on (NULL = the default/null stream). */
 int nk_ctx_create(int device_id, void *stream, nk_ctx **out);
 int nk_ctx_destroy(nk_ctx *ctx);
 int nk_ctx_set_stream(nk_ctx *ctx, void *stream);
 int nk_ctx_synchronize(nk_ctx *ctx);
 /* deterministic=1 (default): fixed-order two-stage reductions, bitwise reproducible run to run. */
 int nk_ctx_set_deterministic(nk_ctx *ctx, int deterministic);
+
+/* Per-kernel-family timing with HIP events recorded on the context's stream (bench.py's roofline numbers).
+ * Off by default; when on, every launch of a profiled family is bracketed by two events. */
+int nk_ctx_profile_enable(nk_ctx *ctx, int on);          /* on=1 also resets the accumulators */
+int nk_ctx_profile_kernel_count(void);
+int nk_ctx_profile_query(nk_ctx *ctx, int kernel_id, const char **name, int64_t *launches,
+                         double *total_ms, double *total_algorithmic_bytes);
 
 /* One process per GPU. Rank 0 creates an id, the host language broadcasts the 128 bytes
  * (torch.distributed / MPI.jl / Distributed.jl), every rank calls nk_ctx_comm_init_rccl. */

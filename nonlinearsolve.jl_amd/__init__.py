@@ -1,0 +1,15 @@
+"""nonlinearsolve.jl_amd — MI355X-native Newton–Krylov inner loop behind NonlinearSolve.jl's first-order
+step path. Import as `nonlinearsolve_jl_amd` (root-level shim; the directory name has a dot in it).
+
+Product code: csrc/ (HIP kernels + C ABI → lib/libmi355x_nk.so), _lib.py (ctypes), core.py (host mirror of
+the reference interface). Nothing here imports oracle/."""
+from ._lib import NKError, LIB_PATH, build  # noqa: F401
+from .core import (  # noqa: F401
+    Context, default_context, set_default_context, partition_range, comm_unique_id,
+    CSRMatrix, DeviceProblem, Quadratic, Bratu2D, Brusselator2D,
+    NonlinearFunction, NonlinearProblem,
+    KrylovJL_GMRES, EisenstatWalkerForcing2, RadiusUpdateSchemes, NewtonRaphson, TrustRegion,
+    NLStats, NonlinearSolution, FirstOrderCache, init, solve, step_, solve_, reinit_,
+    GMRES, JacobianOperator, JacVecOperator, VecJacOperator, StatefulJacobianOperator,
+    StatefulJacobianNormalFormOperator,
+)

@@ -1,0 +1,868 @@
+"""Host-side mirror of the reference's interface for the first-order step path, above the C ABI.
+
+The names, argument meaning and error behaviour follow NonlinearSolve.jl so that the parity tests read like
+the reference's own tests:
+
+    prob = NonlinearProblem(NonlinearFunction(f!; jvp = jvp!), u0, p)          # SciMLBase
+    sol  = solve(prob, NewtonRaphson(; linsolve = KrylovJL_GMRES(), forcing = EisenstatWalkerForcing2());
+                 abstol = 1e-8)                                                 # lib/NonlinearSolveFirstOrder
+    cache = init(prob, TrustRegion(; linsolve = KrylovJL_GMRES())); step!(cache); solve!(cache); reinit!(cache, u0; p)
+    J = StatefulJacobianOperator(JacobianOperator(prob, fu, u), u, p);  J * v;  J' * v   # lib/SciMLJacobianOperators
+
+Everything numerical happens in libmi355x_nk.so (HIP kernels); this file only marshals pointers. Vectors may
+be NumPy arrays (host; copied per call) or torch CUDA tensors (device; zero-copy). torch is used for device
+memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import NKError, check
+
+try:  # torch is plumbing: device buffers + current stream
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+# ------------------------------------------------------------------------------------------- pointers
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _ptr(x, n: Optional[int] = None):
+    """(address, memspace, keepalive) of a float64 vector."""
+    if _is_torch(x):
+        if x.dtype != torch.float64:
+            raise TypeError("device vectors must be float64")
+        if not x.is_contiguous():
+            raise ValueError("device vectors must be contiguous")
+        if n is not None and x.numel() != n:
+            raise ValueError(f"expected {n} elements, got {x.numel()}")
+        return C.c_void_p(x.data_ptr()), (L.DEVICE if x.is_cuda else L.HOST), x
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} elements, got {a.size}")
+    return C.c_void_p(a.ctypes.data), L.HOST, a
+
+
+def _like(x, n: int):
+    if _is_torch(x):
+        return torch.empty(n, dtype=torch.float64, device=x.device)
+    return np.empty(n, dtype=np.float64)
+
+
+class _DevView:
+    """Zero-copy torch view of a raw device pointer handed to a callback (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _view(ptr, n):
+    return torch.as_tensor(_DevView(ptr, n), device="cuda")
+
+
+# ------------------------------------------------------------------------------------------- context
+class Context:
+    """nk_ctx: one HIP device + stream (+ communicator). One process per GPU."""
+
+    def __init__(self, device: Optional[int] = None, stream: Optional[int] = None):
+        lib = L.lib()
+        if device is None:
+            device = torch.cuda.current_device() if (torch is not None and torch.cuda.is_available()) else 0
+        if stream is None and torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        check(lib.nk_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h, self.device = h, int(device)
+        self._keep = []
+
+    def synchronize(self):
+        check(L.lib().nk_ctx_synchronize(self._h))
+
+    def set_deterministic(self, flag: bool = True):
+        check(L.lib().nk_ctx_set_deterministic(self._h, int(bool(flag))))
+
+    # -- per-kernel-family HIP-event timing (bench.py roofline evidence)
+    def profile_enable(self, on: bool = True):
+        check(L.lib().nk_ctx_profile_enable(self._h, int(bool(on))))
+
+    def profile_report(self):
+        out = {}
+        for k in range(L.lib().nk_ctx_profile_kernel_count()):
+            name, cnt, ms, by = C.c_char_p(), C.c_int64(), C.c_double(), C.c_double()
+            check(L.lib().nk_ctx_profile_query(self._h, k, C.byref(name), C.byref(cnt), C.byref(ms), C.byref(by)))
+            if cnt.value:
+                out[name.value.decode()] = dict(launches=cnt.value, total_ms=ms.value, bytes=by.value,
+                                                avg_us=1e3 * ms.value / cnt.value,
+                                                gbps=by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0)
+        return out
+
+    # -- communicator
+    def comm_init_rccl(self, nranks: int, rank: int, unique_id: bytes):
+        check(L.lib().nk_ctx_comm_init_rccl(self._h, nranks, rank, unique_id))
+
+    def comm_init_callbacks(self, nranks: int, rank: int, allreduce: Callable, alltoallv: Callable):
+        cb = L.CommCallbacks(L.ALLREDUCE_FN(allreduce), L.ALLTOALLV_FN(alltoallv), None)
+        self._keep.append(cb)
+        check(L.lib().nk_ctx_comm_init_callbacks(self._h, nranks, rank, C.byref(cb)))
+
+    def comm_info(self):
+        k, n, r = C.c_int(), C.c_int(), C.c_int()
+        check(L.lib().nk_ctx_comm_info(self._h, C.byref(k), C.byref(n), C.byref(r)))
+        return k.value, n.value, r.value
+
+    def close(self):
+        if self._h:
+            L.lib().nk_ctx_destroy(self._h)
+            self._h = None
+
+    # -- BLAS-1 on device tensors
+    def dot(self, x, y):
+        r = C.c_double()
+        check(L.lib().nk_dot(self._h, x.numel(), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.byref(r)))
+        return r.value
+
+    def nrm2(self, x):
+        r = C.c_double()
+        check(L.lib().nk_nrm2(self._h, x.numel(), C.c_void_p(x.data_ptr()), C.byref(r)))
+        return r.value
+
+    def norm_inf(self, x):
+        r = C.c_double()
+        check(L.lib().nk_norm_inf(self._h, x.numel(), C.c_void_p(x.data_ptr()), C.byref(r)))
+        return r.value
+
+    def axpy(self, a, x, y):
+        check(L.lib().nk_axpy(self._h, x.numel(), float(a), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+
+    def multidot(self, V, w):
+        """V: (nv, ldv) row-major torch tensor = column-major n×nv basis; returns h[j] = V[j]·w."""
+        nv, ldv = V.shape
+        h = (C.c_double * nv)()
+        check(L.lib().nk_multidot(self._h, w.numel(), nv, C.c_void_p(V.data_ptr()), ldv, C.c_void_p(w.data_ptr()), h))
+        return np.array(h[:])
+
+    def multiaxpy(self, V, h, w, want_norm2=False):
+        nv, ldv = V.shape
+        hh = (C.c_double * nv)(*[float(t) for t in h])
+        r = C.c_double()
+        check(L.lib().nk_multiaxpy(self._h, w.numel(), nv, C.c_void_p(V.data_ptr()), ldv, hh,
+                                   C.c_void_p(w.data_ptr()), C.byref(r) if want_norm2 else None))
+        return r.value if want_norm2 else None
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def set_default_context(ctx: Optional[Context]):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+def partition_range(n_global: int, granule: int, nranks: int, rank: int):
+    b, e = C.c_int64(), C.c_int64()
+    check(L.lib().nk_partition_range(n_global, granule, nranks, rank, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(L.lib().nk_comm_unique_id(buf))
+    return buf.raw
+
+
+# ------------------------------------------------------------------------------------------- CSR
+class CSRMatrix:
+    """nk_csr: row-partitioned CSR with f64 values / i32 indices on the device (SparseMatrixCSC stand-in)."""
+
+    def __init__(self, handle, ctx: Context, owned=True):
+        self._h, self.ctx, self._owned = handle, ctx, owned
+
+    @classmethod
+    def from_arrays(cls, rowptr, colind, vals=None, n_global=None, row_begin=0, index_base=0, ctx=None):
+        ctx = ctx or default_context()
+        rowptr = np.ascontiguousarray(rowptr)
+        colind = np.ascontiguousarray(colind)
+        if rowptr.dtype not in (np.int32, np.int64):
+            rowptr = rowptr.astype(np.int64)
+        colind = colind.astype(rowptr.dtype, copy=False)
+        bits = 32 if rowptr.dtype == np.int32 else 64
+        nrows = rowptr.size - 1
+        nnz = int(colind.size)
+        if n_global is None:
+            n_global = nrows
+        v = None if vals is None else np.ascontiguousarray(vals, dtype=np.float64)
+        h = C.c_void_p()
+        check(L.lib().nk_csr_create(ctx._h, nrows, n_global, row_begin, nnz, bits, index_base,
+                                    C.c_void_p(rowptr.ctypes.data), C.c_void_p(colind.ctypes.data),
+                                    None if v is None else C.c_void_p(v.ctypes.data), L.HOST, C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def from_scipy(cls, A, ctx=None):
+        A = A.tocsr()
+        A.sort_indices()
+        return cls.from_arrays(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, ctx=ctx)
+
+    @classmethod
+    def from_csc(cls, colptr, rowval, nzval, index_base=1, ctx=None):
+        """Julia's SparseMatrixCSC fields (1-based Int64 by default)."""
+        ctx = ctx or default_context()
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+        nz = np.ascontiguousarray(nzval, dtype=np.float64)
+        h = C.c_void_p()
+        check(L.lib().nk_csr_create_from_csc(ctx._h, colptr.size - 1, rowval.size, 64, index_base,
+                                             C.c_void_p(colptr.ctypes.data), C.c_void_p(rowval.ctypes.data),
+                                             C.c_void_p(nz.ctypes.data), C.byref(h)))
+        return cls(h, ctx)
+
+    def info(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(L.lib().nk_csr_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(nrows_local=a.value, n_global=b.value, nnz=c.value, n_halo=d.value)
+
+    @property
+    def shape(self):
+        i = self.info()
+        return (i["nrows_local"], i["n_global"])
+
+    def set_values(self, vals):
+        p, ms, _k = _ptr(vals, self.info()["nnz"])
+        check(L.lib().nk_csr_set_values(self._h, p, ms))
+
+    def values(self):
+        out = np.empty(self.info()["nnz"])
+        check(L.lib().nk_csr_get_values(self._h, C.c_void_p(out.ctypes.data), L.HOST))
+        return out
+
+    def values_device(self):
+        return _view(L.lib().nk_csr_values_device(self._h), self.info()["nnz"])
+
+    def matvec(self, x, out=None):
+        n = self.info()["nrows_local"]
+        px, ms, _k = _ptr(x, n)
+        y = _like(x, n) if out is None else out
+        py, ms2, _k2 = _ptr(y, n)
+        if ms != ms2:
+            raise ValueError("x and out must live in the same memory space")
+        check(L.lib().nk_spmv(self._h, px, py, ms))
+        return y
+
+    def rmatvec(self, x, out=None):
+        n = self.info()["nrows_local"]
+        px, ms, _k = _ptr(x, n)
+        y = _like(x, n) if out is None else out
+        py, _ms2, _k2 = _ptr(y, n)
+        check(L.lib().nk_spmv_t(self._h, px, py, ms))
+        return y
+
+    __matmul__ = matvec
+
+    def close(self):
+        if self._h and self._owned:
+            L.lib().nk_csr_destroy(self._h)
+        self._h = None
+
+
+# ------------------------------------------------------------------------------------------- problems
+class DeviceProblem:
+    """nk_problem: residual / JVP / VJP / Jacobian provider living on the device."""
+
+    def __init__(self, handle, ctx: Context, keep=()):
+        self._h, self.ctx, self._keep = handle, ctx, list(keep)
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(L.lib().nk_problem_size(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.n_local, self.n_global, self.row_begin = a.value, b.value, c.value
+
+    def residual(self, u):
+        f = _like(u, self.n_local)
+        pu, ms, _a = _ptr(u, self.n_local)
+        pf, _m, _b = _ptr(f)
+        check(L.lib().nk_residual(self._h, pu, pf, ms))
+        return f
+
+    def _jv(self, fn, u, v):
+        out = _like(u, self.n_local)
+        pu, ms, _a = _ptr(u, self.n_local)
+        pv, ms2, _b = _ptr(v, self.n_local)
+        po, _m, _c = _ptr(out)
+        if ms != ms2:
+            raise ValueError("u and v must live in the same memory space")
+        check(fn(self._h, pu, pv, po, ms))
+        return out
+
+    def jvp(self, v, u):  # argument order of the reference: jvp(v, u, p)
+        return self._jv(L.lib().nk_jvp, u, v)
+
+    def vjp(self, v, u):
+        return self._jv(L.lib().nk_vjp, u, v)
+
+    def jac_csr(self) -> CSRMatrix:
+        h = C.c_void_p()
+        check(L.lib().nk_problem_jac_csr(self._h, C.byref(h)))
+        return CSRMatrix(h, self.ctx)
+
+    def jac_values(self, u, J: CSRMatrix, colored: bool = False):
+        pu, ms, _a = _ptr(u, self.n_local)
+        if colored:
+            nc = C.c_int()
+            check(L.lib().nk_jac_values_colored(self._h, pu, ms, J._h, C.byref(nc)))
+            return nc.value
+        check(L.lib().nk_jac_values(self._h, pu, ms, J._h))
+        return None
+
+    def initial_guess(self, device: bool = False):
+        u0 = torch.empty(self.n_local, dtype=torch.float64, device=f"cuda:{self.ctx.device}") if device \
+            else np.empty(self.n_local)
+        p, ms, _a = _ptr(u0)
+        check(L.lib().nk_problem_initial_guess(self._h, p, ms))
+        return u0
+
+    def set_params(self, params: Sequence[float]):
+        arr = (C.c_double * len(params))(*[float(x) for x in params])
+        check(L.lib().nk_problem_set_params(self._h, arr, len(params)))
+
+    def close(self):
+        if self._h:
+            L.lib().nk_problem_destroy(self._h)
+            self._h = None
+
+
+def _builtin(kind, params, ctx):
+    ctx = ctx or default_context()
+    arr = (C.c_double * len(params))(*[float(x) for x in params])
+    h = C.c_void_p()
+    check(L.lib().nk_problem_create(ctx._h, kind, arr, len(params), C.byref(h)))
+    return DeviceProblem(h, ctx)
+
+
+def Quadratic(n: int, p: float = 2.0, ctx=None) -> DeviceProblem:
+    """quadratic_f(u, p) = u .* u .- p   (common/common_rootfind_testing.jl:15-17)"""
+    P = _builtin(L.PROBLEM_QUADRATIC, [n, p], ctx)
+    P.params = [n, p]
+    return P
+
+
+def Bratu2D(n: int, lam: float = 6.0, scale: float = 0.0, ctx=None) -> DeviceProblem:
+    """2-D Bratu, 5-point stencil; scale = 0 → h²-scaled residual."""
+    P = _builtin(L.PROBLEM_BRATU2D, [n, lam, scale], ctx)
+    P.params = [n, lam, scale]
+    return P
+
+
+def Brusselator2D(N: int, A=3.4, B=1.0, alpha=10.0, dx=None, ctx=None) -> DeviceProblem:
+    """brusselator_2d_loop (lib/NonlinearSolveFirstOrder/test/sparsity_tests__item1.jl:13-36)"""
+    dx = 1.0 / (N - 1) if dx is None else dx
+    P = _builtin(L.PROBLEM_BRUSSELATOR2D, [N, A, B, alpha, dx], ctx)
+    P.params = [N, A, B, alpha, dx]
+    return P
+
+
+@dataclass
+class NonlinearFunction:
+    """NonlinearFunction{true}(f!; jvp, vjp, jac, jac_prototype) with torch-tensor callbacks on the device:
+    f(du, u, p), jvp(Jv, v, u, p), vjp(vJ, v, u, p), jac(nzval, u, p) (values of jac_prototype, a CSRMatrix)."""
+    f: Callable
+    jvp: Optional[Callable] = None
+    vjp: Optional[Callable] = None
+    jac: Optional[Callable] = None
+    jac_prototype: Optional[CSRMatrix] = None
+
+
+class NonlinearProblem:
+    """NonlinearProblem(f, u0, p). `f` is a built-in DeviceProblem or a NonlinearFunction of torch callbacks."""
+
+    def __init__(self, f, u0=None, p=None, ctx: Optional[Context] = None):
+        self.p = p
+        if isinstance(f, DeviceProblem):
+            self.device_problem = f
+            self.ctx = f.ctx
+            self.u0 = f.initial_guess() if u0 is None else u0
+            if p is not None:
+                self.set_p(p)
+            return
+        if not isinstance(f, NonlinearFunction):
+            f = NonlinearFunction(f)
+        if u0 is None:
+            raise ValueError("u0 is required for a NonlinearFunction problem")
+        self.ctx = ctx or default_context()
+        self.u0 = u0
+        n = int(u0.numel() if _is_torch(u0) else np.asarray(u0).size)
+        prob = self
+
+        def wrap(fn, nargs):
+            if fn is None:
+                return None
+
+            def cb(*a):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(a[-1])) if a[-1] else _nullctx():
+                        tensors = [_view(q, n) for q in a[1:-1]]
+                        if nargs == 2:      # residual(u, f) → f!(du, u, p)
+                            fn(tensors[1], tensors[0], prob.p)
+                        elif nargs == 3:    # (v, u, out) → jvp!(out, v, u, p)
+                            fn(tensors[2], tensors[0], tensors[1], prob.p)
+                    return 0
+                except Exception as e:  # pragma: no cover - surfaced as NK_E_CALLBACK
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return cb
+
+        def jac_cb(user, u_ptr, vals_ptr, stream):
+            try:
+                nnz = f.jac_prototype.info()["nnz"]
+                f.jac(_view(vals_ptr, nnz), _view(u_ptr, n), prob.p)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cbs = L.UserCallbacks(
+            L.RESIDUAL_FN(wrap(f.f, 2)),
+            L.JVP_FN(wrap(f.jvp, 3)) if f.jvp else L.JVP_FN(),
+            L.JVP_FN(wrap(f.vjp, 3)) if f.vjp else L.JVP_FN(),
+            L.JACVALS_FN(jac_cb) if (f.jac and f.jac_prototype is not None) else L.JACVALS_FN(),
+        )
+        h = C.c_void_p()
+        check(L.lib().nk_problem_create_user(self.ctx._h, n, n, 0, C.byref(cbs), None,
+                                             f.jac_prototype._h if f.jac_prototype is not None else None,
+                                             C.byref(h)))
+        self.device_problem = DeviceProblem(h, self.ctx, keep=[cbs, f])
+        self.f = f
+
+    def set_p(self, p):
+        self.p = p
+        dp = self.device_problem
+        if hasattr(dp, "params"):
+            params = list(dp.params)
+            if isinstance(p, (int, float)):
+                params[1] = float(p)           # quadratic p / Bratu λ
+            else:
+                params[1:1 + len(p)] = [float(x) for x in p]
+            dp.params = params
+            dp.set_params(params)
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+# ------------------------------------------------------------------------------------------- algorithms
+@dataclass
+class KrylovJL_GMRES:
+    """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
+    gmres_restart: int = 30
+    maxiters: int = 300
+    ortho: str = "cgs2"        # "mgs" (Krylov.jl's structure) | "cgs2" | "cgs"
+    fixed_iters: int = 0
+    abstol: Optional[float] = None   # None → the nonlinear tolerances are forwarded (FirstOrder/src/solve.jl:203)
+    reltol: Optional[float] = None
+
+
+@dataclass
+class EisenstatWalkerForcing2:  # eisenstat_walker.jl:18-29
+    eta0: float = 0.5
+    eta_max: float = 0.9
+    gamma: float = 0.9
+    alpha: float = 2.0
+    safeguard: bool = True
+    safeguard_threshold: float = 0.1
+
+
+class RadiusUpdateSchemes:  # trust_region.jl:59-147
+    Simple, NLsolve, NocedalWright, Hei, Yuan, Bastin, Fan = range(7)
+
+
+@dataclass
+class NewtonRaphson:  # raphson.jl:30-43
+    linsolve: Optional[KrylovJL_GMRES] = None
+    forcing: Optional[EisenstatWalkerForcing2] = None
+    concrete_jac: Optional[bool] = None
+    name: str = "NewtonRaphson"
+
+
+@dataclass
+class TrustRegion:  # trust_region.jl:25-43
+    linsolve: Optional[KrylovJL_GMRES] = None
+    radius_update_scheme: int = RadiusUpdateSchemes.Simple
+    max_trust_radius: float = 0.0
+    initial_trust_radius: float = 0.0
+    step_threshold: float = 1.0 / 10000
+    shrink_threshold: float = 1.0 / 4
+    expand_threshold: float = 3.0 / 4
+    shrink_factor: float = 1.0 / 4
+    expand_factor: float = 2.0
+    max_shrink_times: int = 32
+    concrete_jac: Optional[bool] = None
+    name: str = "TrustRegion"
+
+
+_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS}
+
+
+def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs) -> L.Options:
+    o = L.Options()
+    check(L.lib().nk_options_default(C.byref(o)))
+    ls = alg.linsolve
+    if ls is None:
+        raise NotImplementedError("linsolve = nothing (LinearSolve's default factorisation) is not built yet; "
+                                  "pass linsolve = KrylovJL_GMRES(...)")
+    o.algorithm = L.ALG_TRUST_REGION if isinstance(alg, TrustRegion) else L.ALG_NEWTON_RAPHSON
+    o.linsolve = L.LINSOLVE_GMRES_CSR if alg.concrete_jac else L.LINSOLVE_GMRES_MATFREE
+    o.maxiters = int(maxiters)
+    o.abstol = 0.0 if abstol is None else float(abstol)
+    o.reltol = 0.0 if reltol is None else float(reltol)
+    o.maxtime = 0.0 if maxtime is None else float(maxtime)
+    o.gmres_restart, o.gmres_maxiters = int(ls.gmres_restart), int(ls.maxiters)
+    o.gmres_ortho, o.gmres_fixed_iters = _ORTHO[ls.ortho], int(ls.fixed_iters)
+    o.lin_abstol = -1.0 if ls.abstol is None else float(ls.abstol)
+    o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
+    fo = getattr(alg, "forcing", None)
+    if fo is not None:
+        o.forcing = L.FORCING_EW2
+        o.ew_eta0, o.ew_eta_max, o.ew_gamma, o.ew_alpha = fo.eta0, fo.eta_max, fo.gamma, fo.alpha
+        o.ew_safeguard, o.ew_safeguard_threshold = int(fo.safeguard), fo.safeguard_threshold
+    if isinstance(alg, TrustRegion):
+        o.radius_update_scheme = int(alg.radius_update_scheme)
+        o.max_shrink_times = int(alg.max_shrink_times)
+        for k in ("max_trust_radius", "initial_trust_radius", "step_threshold", "shrink_threshold",
+                  "expand_threshold", "shrink_factor", "expand_factor"):
+            setattr(o, k, float(getattr(alg, k)))
+    for k, v in (termination_kwargs or {}).items():
+        setattr(o, k, v)
+    o.store_trace = int(bool(store_trace))
+    return o
+
+
+@dataclass
+class NLStats:
+    nf: int = 0
+    njacs: int = 0
+    nfactors: int = 0
+    nsolve: int = 0
+    nsteps: int = 0
+    gmres_iters: int = 0
+    op_applies: int = 0
+    allreduces: int = 0
+    halo_exchanges: int = 0
+
+
+@dataclass
+class NonlinearSolution:
+    u: object
+    resid: object
+    retcode: str
+    stats: NLStats
+    trace: list = field(default_factory=list)
+    alg: object = None
+
+    @property
+    def successful_retcode(self):  # SciMLBase.successful_retcode
+        return self.retcode == "Success"
+
+
+class FirstOrderCache:
+    """GeneralizedFirstOrderAlgorithmCache behind nk_solver: init / step! / solve! / reinit!."""
+
+    def __init__(self, prob: NonlinearProblem, alg, abstol=None, reltol=None, maxiters=1000, maxtime=None,
+                 store_trace=False, termination_kwargs=None):
+        self.prob, self.alg = prob, alg
+        self._opts = _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs)
+        self._u0_is_torch = _is_torch(prob.u0)
+        p, ms, _k = _ptr(prob.u0, prob.device_problem.n_local)
+        h = C.c_void_p()
+        check(L.lib().nk_solver_init(prob.device_problem._h, p, ms, C.byref(self._opts), C.byref(h)))
+        self._h = h
+        self.n = prob.device_problem.n_local
+
+    def _out(self, fn):
+        if self._u0_is_torch and self.prob.u0.is_cuda:
+            out = torch.empty(self.n, dtype=torch.float64, device=self.prob.u0.device)
+        else:
+            out = np.empty(self.n)
+        p, ms, _k = _ptr(out)
+        check(fn(self._h, p, ms))
+        return out
+
+    @property
+    def u(self):
+        return self._out(L.lib().nk_solver_get_u)
+
+    @property
+    def fu(self):
+        return self._out(L.lib().nk_solver_get_resid)
+
+    @property
+    def stats(self) -> NLStats:
+        s = L.Stats()
+        check(L.lib().nk_solver_get_stats(self._h, C.byref(s)))
+        return NLStats(**s.as_dict())
+
+    def _ret(self):
+        r, n, f = C.c_int(), C.c_int(), C.c_int()
+        check(L.lib().nk_solver_get_retcode(self._h, C.byref(r), C.byref(n), C.byref(f)))
+        return r.value, n.value, bool(f.value)
+
+    @property
+    def retcode(self):
+        return L.RET_NAMES[self._ret()[0]]
+
+    @property
+    def nsteps(self):
+        return self._ret()[1]
+
+    @property
+    def force_stop(self):
+        return self._ret()[2]
+
+    @property
+    def trust_region(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(L.lib().nk_solver_get_scalars(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return b.value
+
+    @property
+    def fnorm_inf(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(L.lib().nk_solver_get_scalars(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value
+
+    @property
+    def trace(self):
+        n = C.c_int()
+        check(L.lib().nk_solver_get_trace(self._h, None, 0, C.byref(n)))
+        rows = (L.TraceEntry * max(n.value, 1))()
+        check(L.lib().nk_solver_get_trace(self._h, rows, n.value, C.byref(n)))
+        return [dict(iter=r.iter, gmres_iters=r.gmres_iters, accepted=bool(r.accepted), fnorm_inf=r.fnorm_inf,
+                     step_norm2=r.step_norm2, eta=r.eta, trust_region=r.trust_region, rho=r.rho)
+                for r in rows[: n.value]]
+
+    def step(self):
+        check(L.lib().nk_solver_step(self._h))
+        return self
+
+    def solve(self) -> NonlinearSolution:
+        r = C.c_int()
+        check(L.lib().nk_solver_solve(self._h, C.byref(r)))
+        return NonlinearSolution(self.u, self.fu, L.RET_NAMES[r.value], self.stats,
+                                 self.trace if self._opts.store_trace else [], self.alg)
+
+    def reinit(self, u0=None, p=None):
+        params, npar = None, 0
+        if p is not None:
+            self.prob.set_p(p)  # built-ins push the new parameters to the device problem
+        if u0 is not None:
+            pu, ms, _k = _ptr(u0, self.n)
+        else:
+            pu, ms = None, L.HOST
+        check(L.lib().nk_solver_reinit(self._h, pu, ms, params, npar))
+        return self
+
+    def close(self):
+        if self._h:
+            L.lib().nk_solver_destroy(self._h)
+            self._h = None
+
+
+def init(prob: NonlinearProblem, alg, **kw) -> FirstOrderCache:
+    return FirstOrderCache(prob, alg, **kw)
+
+
+def solve(prob: NonlinearProblem, alg, **kw) -> NonlinearSolution:
+    cache = FirstOrderCache(prob, alg, **kw)
+    try:
+        return cache.solve()
+    finally:
+        cache.close()
+
+
+def step_(cache: FirstOrderCache):   # step!(cache)
+    return cache.step()
+
+
+def solve_(cache: FirstOrderCache):  # solve!(cache)
+    return cache.solve()
+
+
+def reinit_(cache: FirstOrderCache, u0=None, p=None):  # reinit!(cache, u0; p)
+    return cache.reinit(u0, p)
+
+
+# ------------------------------------------------------------------------------------------- linear solve seam
+class GMRES:
+    """nk_gmres: the LinearCache analogue NonlinearSolveBase drives (A, b, u, reltol; solve!)."""
+
+    def __init__(self, n: int, restart: int = 30, ortho: str = "cgs2", ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(L.lib().nk_gmres_create(self.ctx._h, n, restart, _ORTHO[ortho], C.byref(h)))
+        self._h, self.n, self._keep = h, n, []
+        self.abstol, self.reltol, self.maxiters = 0.0, 1e-8, 300
+
+    def set_operator(self, A, u=None):
+        """A: CSRMatrix (concrete J), StatefulJacobianOperator (matrix-free), or callable y = A(x) on tensors."""
+        self._keep = [A]
+        if isinstance(A, CSRMatrix):
+            check(L.lib().nk_gmres_set_operator_csr(self._h, A._h))
+        elif isinstance(A, StatefulJacobianOperator):
+            if A.mode != "jvp":
+                raise NotImplementedError("GMRES on a transposed operator")
+            p, ms, k = _ptr(A.u, self.n)
+            self._keep.append(k)
+            check(L.lib().nk_gmres_set_operator_jvp(self._h, A.jac_op.prob.device_problem._h, p, ms))
+        elif callable(A):
+            n = self.n
+
+            def cb(user, x, y, stream):
+                try:
+                    out = A(_view(x, n))
+                    _view(y, n).copy_(out)
+                    return 0
+                except Exception:  # pragma: no cover
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            fn = L.MATVEC_FN(cb)
+            self._keep.append(fn)
+            check(L.lib().nk_gmres_set_operator_fn(self._h, fn, None))
+        else:
+            raise TypeError(f"unsupported operator {type(A)}")
+        return self
+
+    def set_right_preconditioner(self, M: Optional[Callable]):
+        """precs hook (test/Core/core_tests__item21.jl): M(x) ≈ A⁻¹ x on device tensors."""
+        if M is None:
+            check(L.lib().nk_gmres_set_right_preconditioner(self._h, L.MATVEC_FN(), None))
+            return self
+        n = self.n
+
+        def cb(user, x, y, stream):
+            try:
+                _view(y, n).copy_(M(_view(x, n)))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = L.MATVEC_FN(cb)
+        self._keep.append(fn)
+        check(L.lib().nk_gmres_set_right_preconditioner(self._h, fn, None))
+        return self
+
+    def update_tolerances(self, abstol=None, reltol=None):  # LinearSolve.update_tolerances!
+        if abstol is not None:
+            self.abstol = float(abstol)
+        if reltol is not None:
+            self.reltol = float(reltol)
+
+    def solve(self, b, x0=None, abstol=None, reltol=None, maxiters=None, fixed_iters=0):
+        x = _like(b, self.n)
+        use_x0 = 0
+        if x0 is not None:
+            if _is_torch(x):
+                x.copy_(x0)
+            else:
+                x[...] = x0
+            use_x0 = 1
+        pb, ms, _a = _ptr(b, self.n)
+        px, _m, _b = _ptr(x)
+        info = L.GmresInfo()
+        check(L.lib().nk_gmres_solve(self._h, pb, px, ms, use_x0,
+                                     self.abstol if abstol is None else abstol,
+                                     self.reltol if reltol is None else reltol,
+                                     self.maxiters if maxiters is None else maxiters, fixed_iters, C.byref(info)))
+        return x, dict(iters=info.iters, restarts=info.restarts, converged=bool(info.converged),
+                       failed=bool(info.failed), rnorm0=info.rnorm0, rnorm=info.rnorm)
+
+    def close(self):
+        if self._h:
+            L.lib().nk_gmres_destroy(self._h)
+            self._h = None
+
+
+# ------------------------------------------------------------------------------------------- Jacobian operators
+class JacobianOperator:
+    """JacobianOperator(prob, fu, u): JVP by default, `.T` flips to VJP
+    (lib/SciMLJacobianOperators/src/SciMLJacobianOperators.jl:86-143)."""
+
+    def __init__(self, prob: NonlinearProblem, fu=None, u=None, mode: str = "jvp"):
+        self.prob, self.mode = prob, mode
+        n = prob.device_problem.n_local
+        self.size = (n, n)
+
+    @property
+    def T(self):
+        return JacobianOperator(self.prob, mode="vjp" if self.mode == "jvp" else "jvp")
+
+    adjoint = transpose = T
+
+    def __call__(self, v, u, p=None):  # (op::JacobianOperator)(v, u, p)
+        dp = self.prob.device_problem
+        return dp.jvp(v, u) if self.mode == "jvp" else dp.vjp(v, u)
+
+
+def JacVecOperator(prob, fu=None, u=None):
+    return JacobianOperator(prob, fu, u, "jvp")
+
+
+def VecJacOperator(prob, fu=None, u=None):
+    return JacobianOperator(prob, fu, u, "vjp")
+
+
+class StatefulJacobianOperator:
+    """StatefulJacobianOperator(jac_op, u, p) with `*` / mul! (SciMLJacobianOperators.jl:210-243)."""
+
+    def __init__(self, jac_op: JacobianOperator, u, p=None):
+        self.jac_op, self.u, self.p, self.mode = jac_op, u, p, jac_op.mode
+
+    @property
+    def T(self):
+        return StatefulJacobianOperator(self.jac_op.T, self.u, self.p)
+
+    def __matmul__(self, v):
+        if isinstance(v, StatefulJacobianOperator):
+            return StatefulJacobianNormalFormOperator(self, v)
+        return self.jac_op(v, self.u, self.p)
+
+    __mul__ = __matmul__
+
+    def mul_(self, out, v):  # mul!(Jv, J, v)
+        r = self @ v
+        if _is_torch(out):
+            out.copy_(r)
+        else:
+            out[...] = r
+        return out
+
+
+class StatefulJacobianNormalFormOperator:
+    """JᵀJ x via JVP then VJP (SciMLJacobianOperators.jl:252-291)."""
+
+    def __init__(self, vjp_op, jvp_op):
+        self.vjp_operator, self.jvp_operator = vjp_op, jvp_op
+
+    def __matmul__(self, x):
+        return self.vjp_operator @ (self.jvp_operator @ x)
+
+    __mul__ = __matmul__

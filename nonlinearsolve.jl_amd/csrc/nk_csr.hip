@@ -1,0 +1,405 @@
+// Row-partitioned CSR (f64 values, i32 local column ids) and the SpMV kernels.
+//
+// SpMV design ("CSR-stream", LDS-staged partial products): a 256-thread workgroup owns a contiguous range
+// of rows whose non-zeros fit one LDS tile. Phase 1 streams vals/colind of the whole tile with fully
+// coalesced lane-contiguous loads (no per-row divergence), gathers x, and parks val*x in LDS. Phase 2 gives
+// each lane one row and sums that row's products from LDS in CSR order — so the result is bit-identical
+// to a sequential CPU row sum, with no atomics. Row-block boundaries are computed once on the host.
+// The blockIdx→row-block map is XCD-aware: consecutive row blocks go to the same XCD (block b runs on
+// XCD b%8) so that the x gathers of neighbouring grid lines hit that XCD's private 4 MiB L2.
+//
+// Algorithmic bytes per launch: 12 nnz + 4 (nrows+1) + 8 nrows (y) + 8 nrows (x)  ≈ 80 N for 5-pt Bratu.
+#include <algorithm>
+#include <string.h>
+
+#include "nk_internal.h"
+
+constexpr int SPMV_TILE = 2048;   // non-zeros per workgroup tile (16 KiB of LDS)
+constexpr int NXCD = 8;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  // bijective for any nblk: XCD x gets the contiguous chunk [x*q + min(x,r), ...) of row blocks
+  const int q = nblk / NXCD, r = nblk % NXCD;
+  const int x = bid % NXCD, k = bid / NXCD;
+  return x * q + (x < r ? x : r) + k;
+}
+
+__global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
+    int nblk, const int32_t *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+    const double *__restrict__ xhalo, int32_t nlocal, double *__restrict__ y, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  __shared__ double prod[SPMV_TILE];
+  __shared__ double red[4];
+  const int b = xcd_remap(blockIdx.x, nblk);
+  const int r0 = rowblocks[b], r1 = rowblocks[b + 1];
+  const int p0 = rowptr[r0], p1 = rowptr[r1];
+  const int nnzb = p1 - p0;
+  if (nnzb <= SPMV_TILE) {
+    for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
+      const int c = col[p0 + k];
+      const double xv = (c < nlocal) ? x[c] : xhalo[c - nlocal];
+      prod[k] = val[p0 + k] * xv;
+    }
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += NK_BLOCK) {
+      const int a = rowptr[r] - p0, e = rowptr[r + 1] - p0;
+      double s = 0.0;
+      for (int k = a; k < e; ++k) s += prod[k];
+      y[r] = s;
+    }
+  } else {
+    // a single long row: the whole workgroup reduces it (fixed order → deterministic)
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
+      const int c = col[p0 + k];
+      const double xv = (c < nlocal) ? x[c] : xhalo[c - nlocal];
+      s += val[p0 + k] * xv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) y[r0] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+static void build_rowblocks(const std::vector<int32_t> &rowptr, std::vector<int32_t> &rb) {
+  const int64_t nrows = (int64_t)rowptr.size() - 1;
+  rb.clear();
+  rb.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t e = r;
+    const int64_t base = rowptr[r];
+    while (e < nrows && (rowptr[e + 1] - base) <= SPMV_TILE && (e - r) < 4 * NK_BLOCK) ++e;
+    if (e == r) e = r + 1;  // one row longer than a tile → long-row path
+    rb.push_back((int32_t)e);
+    r = e;
+  }
+}
+
+int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
+                        const std::vector<int32_t> &rowptr, const std::vector<int64_t> &gcol,
+                        const double *vals_host, nk_csr **out) {
+  const int64_t nnz = (int64_t)gcol.size();
+  NK_REQUIRE(nnz < (1ll << 31) && nrows < (1ll << 31), "local CSR too large for int32 indices");
+  nk_csr *A = new nk_csr();
+  A->ctx = ctx;
+  A->nrows = nrows;
+  A->n_global = n_global;
+  A->row_begin = row_begin;
+  A->nnz = nnz;
+  A->h_rowptr = rowptr;
+  A->h_col.resize(nnz);
+  // map global columns → local index space [owned | halo]
+  const int64_t lo = row_begin, hi = row_begin + nrows;
+  std::vector<int64_t> halo;
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t g = gcol[k];
+    if (g < 0 || g >= n_global) {
+      delete A;
+      NK_FAIL(NK_E_INVALID, "column index %lld out of range [0,%lld)", (long long)g, (long long)n_global);
+    }
+    if (g < lo || g >= hi) halo.push_back(g);
+  }
+  std::sort(halo.begin(), halo.end());
+  halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+  if (ctx->nranks == 1 && !halo.empty()) {
+    delete A;
+    NK_FAIL(NK_E_INVALID, "single-rank CSR must be square: column outside the local row range");
+  }
+  A->halo_gcols = halo;
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t g = gcol[k];
+    if (g >= lo && g < hi) A->h_col[k] = (int32_t)(g - lo);
+    else A->h_col[k] = (int32_t)(nrows + (std::lower_bound(halo.begin(), halo.end(), g) - halo.begin()));
+  }
+  std::vector<int32_t> rb;
+  build_rowblocks(rowptr, rb);
+  A->nblocks = (int)rb.size() - 1;
+  NK_TRY(nk_dev_alloc(&A->d_rowptr, (size_t)nrows + 1));
+  NK_TRY(nk_dev_alloc(&A->d_col, (size_t)nnz));
+  NK_TRY(nk_dev_alloc(&A->d_val, (size_t)nnz));
+  NK_TRY(nk_dev_alloc(&A->d_rowblocks, rb.size()));
+  NK_HIP(hipMemcpy(A->d_rowptr, rowptr.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nnz) NK_HIP(hipMemcpy(A->d_col, A->h_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(hipMemcpy(A->d_rowblocks, rb.data(), rb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (vals_host && nnz) NK_HIP(hipMemcpy(A->d_val, vals_host, nnz * sizeof(double), hipMemcpyHostToDevice));
+  else if (nnz) NK_HIP(hipMemset(A->d_val, 0, nnz * sizeof(double)));
+
+  // ---- halo plan (collective): tell every owner which of its entries we need
+  if (ctx->nranks > 1) {
+    const int P = ctx->nranks;
+    // 1. everyone learns all row ranges: all-reduce a zero vector with our begin in slot `rank`
+    std::vector<double> hb(P + 1, 0.0);
+    hb[ctx->rank] = (double)row_begin;
+    if (ctx->rank == P - 1) hb[P] = (double)(row_begin + nrows);
+    double *d_tmp = nullptr;
+    NK_TRY(nk_dev_alloc(&d_tmp, (size_t)P * P + P + 1));
+    NK_HIP(hipMemcpy(d_tmp, hb.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice));
+    NK_TRY(nk_comm_allreduce(ctx, d_tmp, P + 1, 0));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_HIP(hipMemcpy(hb.data(), d_tmp, (P + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<int64_t> begin(P + 1);
+    for (int p = 0; p <= P; ++p) begin[p] = (int64_t)hb[p];
+    // 2. needs per owner
+    std::vector<std::vector<int64_t>> need(P);
+    for (int64_t g : halo) {
+      int p = (int)(std::upper_bound(begin.begin(), begin.end(), g) - begin.begin()) - 1;
+      if (p < 0 || p >= P || p == ctx->rank) {
+        hipFree(d_tmp);
+        NK_FAIL(NK_E_INVALID, "halo column %lld has no owner", (long long)g);
+      }
+      need[p].push_back(g);
+    }
+    // 3. exchange counts: P×P matrix, row = requester, col = owner
+    std::vector<double> cnt((size_t)P * P, 0.0);
+    for (int p = 0; p < P; ++p) cnt[(size_t)ctx->rank * P + p] = (double)need[p].size();
+    NK_HIP(hipMemcpy(d_tmp, cnt.data(), (size_t)P * P * sizeof(double), hipMemcpyHostToDevice));
+    NK_TRY(nk_comm_allreduce(ctx, d_tmp, P * P, 0));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_HIP(hipMemcpy(cnt.data(), d_tmp, (size_t)P * P * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(d_tmp);
+    // 4. exchange index lists (int64 global ids) — what I need from p ↔ what p needs from me
+    std::vector<int64_t> soff(P, 0), sbytes(P, 0), roff(P, 0), rbytes(P, 0);
+    std::vector<int64_t> sendflat;
+    int64_t rtotal = 0;
+    for (int p = 0; p < P; ++p) {
+      soff[p] = (int64_t)sendflat.size() * 8;
+      sbytes[p] = (int64_t)need[p].size() * 8;
+      sendflat.insert(sendflat.end(), need[p].begin(), need[p].end());
+      roff[p] = rtotal * 8;
+      const int64_t c = (int64_t)cnt[(size_t)p * P + ctx->rank];
+      rbytes[p] = c * 8;
+      rtotal += c;
+    }
+    int64_t *d_s = nullptr, *d_r = nullptr;
+    NK_TRY(nk_dev_alloc(&d_s, sendflat.size() + 1));
+    NK_TRY(nk_dev_alloc(&d_r, (size_t)rtotal + 1));
+    if (!sendflat.empty())
+      NK_HIP(hipMemcpy(d_s, sendflat.data(), sendflat.size() * 8, hipMemcpyHostToDevice));
+    NK_TRY(nk_comm_alltoallv(ctx, d_s, soff.data(), sbytes.data(), d_r, roff.data(), rbytes.data()));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> wanted((size_t)rtotal);
+    if (rtotal) NK_HIP(hipMemcpy(wanted.data(), d_r, (size_t)rtotal * 8, hipMemcpyDeviceToHost));
+    hipFree(d_s);
+    hipFree(d_r);
+    std::vector<std::vector<int32_t>> send_idx(P);
+    std::vector<int64_t> recv_cnt(P, 0);
+    for (int p = 0; p < P; ++p) {
+      const int64_t c = rbytes[p] / 8, o = roff[p] / 8;
+      for (int64_t t = 0; t < c; ++t) {
+        const int64_t g = wanted[o + t];
+        if (g < lo || g >= hi) NK_FAIL(NK_E_INVALID, "peer %d asked for a row this rank does not own", p);
+        send_idx[p].push_back((int32_t)(g - lo));
+      }
+      recv_cnt[p] = (int64_t)need[p].size();
+    }
+    // halo slots are sorted by global id and owners are ordered by rank → recv layout == halo order
+    NK_TRY(nk_halo_setup(ctx, &A->halo, send_idx, recv_cnt));
+  }
+  *out = A;
+  return NK_OK;
+}
+
+template <typename I>
+static void widen_indices(const void *p, int64_t count, int base, std::vector<int64_t> &out) {
+  const I *q = (const I *)p;
+  out.resize(count);
+  for (int64_t i = 0; i < count; ++i) out[i] = (int64_t)q[i] - base;
+}
+
+extern "C" int nk_csr_create(nk_ctx *ctx, int64_t nrows_local, int64_t n_global, int64_t row_begin, int64_t nnz,
+                             int index_bits, int index_base, const void *rowptr, const void *colind,
+                             const double *vals, int memspace, nk_csr **out) {
+  NK_REQUIRE(ctx && rowptr && (colind || nnz == 0) && out, "NULL argument");
+  NK_REQUIRE(index_bits == 32 || index_bits == 64, "index_bits must be 32 or 64");
+  NK_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  NK_REQUIRE(nrows_local >= 0 && nnz >= 0 && row_begin >= 0 && row_begin + nrows_local <= n_global, "bad sizes");
+  NK_HIP(hipSetDevice(ctx->device));
+  const size_t isz = index_bits / 8;
+  std::vector<char> hrp((nrows_local + 1) * isz), hci(nnz * isz);
+  std::vector<double> hv;
+  const void *rp = rowptr, *ci = colind;
+  const double *vv = vals;
+  if (memspace == NK_DEVICE) {
+    NK_HIP(hipMemcpy(hrp.data(), rowptr, hrp.size(), hipMemcpyDeviceToHost));
+    if (nnz) NK_HIP(hipMemcpy(hci.data(), colind, hci.size(), hipMemcpyDeviceToHost));
+    rp = hrp.data();
+    ci = hci.data();
+    if (vals) {
+      hv.resize(nnz);
+      if (nnz) NK_HIP(hipMemcpy(hv.data(), vals, nnz * sizeof(double), hipMemcpyDeviceToHost));
+      vv = hv.data();
+    }
+  }
+  std::vector<int64_t> rp64, gc;
+  if (index_bits == 32) {
+    widen_indices<int32_t>(rp, nrows_local + 1, index_base, rp64);
+    widen_indices<int32_t>(ci, nnz, index_base, gc);
+  } else {
+    widen_indices<int64_t>(rp, nrows_local + 1, index_base, rp64);
+    widen_indices<int64_t>(ci, nnz, index_base, gc);
+  }
+  NK_REQUIRE(rp64[0] == 0 && rp64[nrows_local] == nnz, "rowptr does not span [0, nnz]");
+  std::vector<int32_t> rp32(nrows_local + 1);
+  for (int64_t i = 0; i <= nrows_local; ++i) {
+    if (i > 0) NK_REQUIRE(rp64[i] >= rp64[i - 1], "rowptr not monotone at row %lld", (long long)i);
+    rp32[i] = (int32_t)rp64[i];
+  }
+  return nk_csr_create_local(ctx, nrows_local, n_global, row_begin, rp32, gc, vv, out);
+}
+
+extern "C" int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
+                                      const void *colptr, const void *rowval, const double *nzval, nk_csr **out) {
+  NK_REQUIRE(ctx && colptr && rowval && out, "NULL argument");
+  NK_REQUIRE(ctx->nranks == 1, "nk_csr_create_from_csc is single-rank only");
+  NK_REQUIRE(index_bits == 32 || index_bits == 64, "index_bits must be 32 or 64");
+  std::vector<int64_t> cp, rv;
+  if (index_bits == 32) {
+    widen_indices<int32_t>(colptr, n + 1, index_base, cp);
+    widen_indices<int32_t>(rowval, nnz, index_base, rv);
+  } else {
+    widen_indices<int64_t>(colptr, n + 1, index_base, cp);
+    widen_indices<int64_t>(rowval, nnz, index_base, rv);
+  }
+  NK_REQUIRE(cp[0] == 0 && cp[n] == nnz, "colptr does not span [0, nnz]");
+  std::vector<int32_t> rp(n + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    NK_REQUIRE(rv[k] >= 0 && rv[k] < n, "row index out of range");
+    rp[rv[k] + 1]++;
+  }
+  for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+  std::vector<int64_t> gc(nnz);
+  std::vector<double> vals(nnz, 0.0);
+  std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+  for (int64_t c = 0; c < n; ++c)
+    for (int64_t k = cp[c]; k < cp[c + 1]; ++k) {
+      const int32_t pos = fill[rv[k]]++;
+      gc[pos] = c;  // columns ascend within each row because c ascends
+      if (nzval) vals[pos] = nzval[k];
+    }
+  return nk_csr_create_local(ctx, n, n, 0, rp, gc, nzval ? vals.data() : nullptr, out);
+}
+
+extern "C" int nk_csr_destroy(nk_csr *A) {
+  if (!A) return NK_OK;
+  hipFree(A->d_rowptr);
+  hipFree(A->d_col);
+  hipFree(A->d_val);
+  hipFree(A->d_rowblocks);
+  hipFree(A->d_tperm);
+  hipFree(A->d_xtmp);
+  hipFree(A->d_ytmp);
+  nk_halo_free(&A->halo);
+  if (A->T) nk_csr_destroy(A->T);
+  delete A;
+  return NK_OK;
+}
+extern "C" int nk_csr_set_values(nk_csr *A, const double *vals, int memspace) {
+  NK_REQUIRE(A && vals, "NULL argument");
+  NK_HIP(hipMemcpyAsync(A->d_val, vals, A->nnz * sizeof(double),
+                        memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, A->ctx->stream));
+  if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(A->ctx->stream));
+  A->t_values_stale = true;
+  return NK_OK;
+}
+extern "C" int nk_csr_get_values(nk_csr *A, double *vals, int memspace) {
+  NK_REQUIRE(A && vals, "NULL argument");
+  NK_HIP(hipMemcpyAsync(vals, A->d_val, A->nnz * sizeof(double),
+                        memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, A->ctx->stream));
+  NK_HIP(hipStreamSynchronize(A->ctx->stream));
+  return NK_OK;
+}
+extern "C" int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, int64_t *nnz, int64_t *n_halo) {
+  NK_REQUIRE(A, "NULL argument");
+  if (nrows_local) *nrows_local = A->nrows;
+  if (n_global) *n_global = A->n_global;
+  if (nnz) *nnz = A->nnz;
+  if (n_halo) *n_halo = (int64_t)A->halo_gcols.size();
+  return NK_OK;
+}
+extern "C" double *nk_csr_values_device(nk_csr *A) { return A ? A->d_val : nullptr; }
+
+int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip) {
+  nk_ctx *ctx = A->ctx;
+  if (A->halo.active()) NK_TRY(nk_halo_exchange(ctx, &A->halo, d_x));
+  ctx->stats.op_applies++;
+  nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
+  if (A->nblocks > 0)
+    hipLaunchKernelGGL(k_spmv_stream, dim3(A->nblocks), dim3(NK_BLOCK), 0, ctx->stream, A->nblocks, A->d_rowblocks,
+                       A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- transpose (single rank)
+__global__ __launch_bounds__(NK_BLOCK) void k_permute_vals(int64_t nnz, const int32_t *__restrict__ perm,
+                                                           const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < nnz) dst[i] = src[perm[i]];
+}
+
+static int build_transpose(nk_csr *A) {
+  NK_REQUIRE(A->ctx->nranks == 1, "transposed SpMV on an assembled CSR is single-rank only (use the matrix-free VJP)");
+  const int64_t n = A->nrows, nnz = A->nnz;
+  std::vector<int32_t> rp(n + 1, 0), perm(nnz);
+  std::vector<int64_t> gc(nnz);
+  for (int64_t k = 0; k < nnz; ++k) rp[A->h_col[k] + 1]++;
+  for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+  std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k) {
+      const int32_t pos = fill[A->h_col[k]]++;
+      gc[pos] = r;
+      perm[pos] = k;
+    }
+  NK_TRY(nk_csr_create_local(A->ctx, n, n, 0, rp, gc, nullptr, &A->T));
+  NK_TRY(nk_dev_alloc(&A->d_tperm, (size_t)nnz));
+  if (nnz) NK_HIP(hipMemcpy(A->d_tperm, perm.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  A->t_values_stale = true;
+  return NK_OK;
+}
+
+int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y) {
+  if (!A->T) NK_TRY(build_transpose(A));
+  if (A->t_values_stale && A->nnz) {
+    const int grid = (int)((A->nnz + NK_BLOCK - 1) / NK_BLOCK);
+    hipLaunchKernelGGL(k_permute_vals, dim3(grid), dim3(NK_BLOCK), 0, A->ctx->stream, A->nnz, A->d_tperm, A->d_val,
+                       A->T->d_val);
+    A->t_values_stale = false;
+  }
+  return nk_csr_spmv_dev(A->T, d_x, d_y, nullptr);
+}
+
+static int stage_in(nk_csr *A, const double *x, int memspace, const double **dx) {
+  if (memspace == NK_DEVICE) {
+    *dx = x;
+    return NK_OK;
+  }
+  if (!A->d_xtmp) NK_TRY(nk_dev_alloc(&A->d_xtmp, (size_t)A->nrows + 1));
+  NK_HIP(hipMemcpyAsync(A->d_xtmp, x, A->nrows * sizeof(double), hipMemcpyHostToDevice, A->ctx->stream));
+  *dx = A->d_xtmp;
+  return NK_OK;
+}
+
+static int spmv_any(nk_csr *A, const double *x, double *y, int memspace, bool transpose) {
+  NK_REQUIRE(A && x && y, "NULL argument");
+  NK_HIP(hipSetDevice(A->ctx->device));
+  const double *dx;
+  NK_TRY(stage_in(A, x, memspace, &dx));
+  double *dy = y;
+  if (memspace != NK_DEVICE) {
+    if (!A->d_ytmp) NK_TRY(nk_dev_alloc(&A->d_ytmp, (size_t)A->nrows + 1));
+    dy = A->d_ytmp;
+  }
+  NK_TRY(transpose ? nk_csr_spmv_t_dev(A, dx, dy) : nk_csr_spmv_dev(A, dx, dy, nullptr));
+  if (memspace != NK_DEVICE) {
+    NK_HIP(hipMemcpyAsync(y, dy, A->nrows * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
+    NK_HIP(hipStreamSynchronize(A->ctx->stream));
+  }
+  return NK_OK;
+}
+extern "C" int nk_spmv(nk_csr *A, const double *x, double *y, int memspace) { return spmv_any(A, x, y, memspace, false); }
+extern "C" int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace) { return spmv_any(A, x, y, memspace, true); }

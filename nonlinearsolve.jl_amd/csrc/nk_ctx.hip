@@ -1,0 +1,364 @@
+// Context, error reporting, communicator (RCCL over xGMI via dlopen, or host callbacks) and halo exchange.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "nk_internal.h"
+
+// ----------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+void nk_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *nk_last_error(void) { return g_err; }
+extern "C" const char *nk_version(void) { return "mi355x_nk 0.1 (gfx950)"; }
+
+extern "C" int nk_device_count(int *count) {
+  NK_REQUIRE(count, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    NK_FAIL(NK_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = c;
+  return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- context
+extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
+  NK_REQUIRE(out, "out is NULL");
+  *out = nullptr;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c == 0)
+    NK_FAIL(NK_E_HIP, "no HIP device available (%s); libmi355x_nk has no CPU fallback",
+            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  NK_REQUIRE(device_id >= 0 && device_id < c, "device_id %d out of range [0,%d)", device_id, c);
+  NK_HIP(hipSetDevice(device_id));
+  nk_ctx *ctx = new nk_ctx();
+  ctx->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  ctx->stream = (hipStream_t)stream;  // NULL = the device's default (null) stream, as in every HIP API
+  NK_TRY(nk_dev_alloc(&ctx->d_partials, (size_t)(NK_MAX_NV + 2) * NK_MAX_RED_BLOCKS));
+  NK_TRY(nk_dev_alloc(&ctx->d_scal, (size_t)4 * NK_MAX_NV));
+  NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV, hipHostMallocDefault));
+  *out = ctx;
+  return NK_OK;
+}
+
+extern "C" int nk_ctx_destroy(nk_ctx *ctx) {
+  if (!ctx) return NK_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  nk_comm_destroy(ctx);
+  hipFree(ctx->d_partials);
+  hipFree(ctx->d_scal);
+  hipHostFree(ctx->h_pinned);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return NK_OK;
+}
+extern "C" int nk_ctx_set_stream(nk_ctx *ctx, void *stream) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = (hipStream_t)stream;
+  return NK_OK;
+}
+extern "C" int nk_ctx_synchronize(nk_ctx *ctx) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  ctx->deterministic = d ? 1 : 0;
+  return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- kernel-family profiling
+static const char *k_names[NK_K_COUNT] = {"spmv", "multidot", "multiaxpy", "jvp", "residual", "scale",
+                                          "reduce_small", "jacfill", "newton_update", "other"};
+void nk_prof_begin(nk_ctx *ctx, int id, double bytes) {
+  nk_prof &p = ctx->prof;
+  if (p.used + 2 > p.ev.size()) {
+    if (p.ev.size() >= 16384) nk_prof_flush(ctx);
+    else {
+      const size_t old = p.ev.size();
+      p.ev.resize(old + 2048);
+      for (size_t i = old; i < p.ev.size(); ++i) hipEventCreate(&p.ev[i]);
+    }
+  }
+  p.ids.push_back(id);
+  p.nbytes.push_back(bytes);
+  hipEventRecord(p.ev[p.used], ctx->stream);
+}
+void nk_prof_end(nk_ctx *ctx) {
+  nk_prof &p = ctx->prof;
+  hipEventRecord(p.ev[p.used + 1], ctx->stream);
+  p.used += 2;
+}
+void nk_prof_flush(nk_ctx *ctx) {
+  nk_prof &p = ctx->prof;
+  if (p.used == 0) return;
+  hipStreamSynchronize(ctx->stream);
+  for (size_t r = 0; r < p.ids.size(); ++r) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[2 * r], p.ev[2 * r + 1]) == hipSuccess) {
+      p.ms[p.ids[r]] += ms;
+      p.bytes[p.ids[r]] += p.nbytes[r];
+      p.count[p.ids[r]]++;
+    }
+  }
+  p.ids.clear();
+  p.nbytes.clear();
+  p.used = 0;
+}
+extern "C" int nk_ctx_profile_enable(nk_ctx *ctx, int on) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  nk_prof_flush(ctx);
+  ctx->prof.on = on != 0;
+  if (on) {
+    for (int i = 0; i < NK_K_COUNT; ++i) { ctx->prof.ms[i] = 0; ctx->prof.bytes[i] = 0; ctx->prof.count[i] = 0; }
+  }
+  return NK_OK;
+}
+extern "C" int nk_ctx_profile_query(nk_ctx *ctx, int kernel_id, const char **name, int64_t *launches, double *ms,
+                                    double *bytes) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  NK_REQUIRE(kernel_id >= 0 && kernel_id < NK_K_COUNT, "kernel_id out of range");
+  nk_prof_flush(ctx);
+  if (name) *name = k_names[kernel_id];
+  if (launches) *launches = ctx->prof.count[kernel_id];
+  if (ms) *ms = ctx->prof.ms[kernel_id];
+  if (bytes) *bytes = ctx->prof.bytes[kernel_id];
+  return NK_OK;
+}
+extern "C" int nk_ctx_profile_kernel_count(void) { return NK_K_COUNT; }
+
+extern "C" int nk_partition_range(int64_t n_global, int64_t granule, int nranks, int rank,
+                                  int64_t *row_begin, int64_t *row_end) {
+  NK_REQUIRE(row_begin && row_end, "NULL output");
+  NK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
+  if (granule < 1) granule = 1;
+  NK_REQUIRE(n_global % granule == 0, "n_global %lld not a multiple of granule %lld",
+             (long long)n_global, (long long)granule);
+  int64_t units = n_global / granule;
+  *row_begin = (units * rank / nranks) * granule;
+  *row_end = (units * (rank + 1) / nranks) * granule;
+  return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- RCCL through dlopen
+// Only the handful of entry points the Krylov loop needs; resolved at run time so that single-GPU use
+// has no RCCL dependency and so that the process shares whichever librccl the host already loaded.
+typedef struct { char internal[128]; } rccl_uid;
+typedef int (*pfn_GetUniqueId)(rccl_uid *);
+typedef int (*pfn_CommInitRank)(void **, int, rccl_uid, int);
+typedef int (*pfn_CommDestroy)(void *);
+typedef int (*pfn_AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*pfn_Send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*pfn_Recv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*pfn_Group)(void);
+typedef const char *(*pfn_GetErrorString)(int);
+static struct {
+  void *h = nullptr;
+  pfn_GetUniqueId GetUniqueId;
+  pfn_CommInitRank CommInitRank;
+  pfn_CommDestroy CommDestroy;
+  pfn_AllReduce AllReduce;
+  pfn_Send Send;
+  pfn_Recv Recv;
+  pfn_Group GroupStart, GroupEnd;
+  pfn_GetErrorString GetErrorString;
+} R;
+enum { RCCL_INT8 = 0, RCCL_FLOAT64 = 8, RCCL_SUM = 0, RCCL_MAX = 2 };  // ncclDataType_t / ncclRedOp_t
+
+static int rccl_load() {
+  if (R.h) return NK_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *nm : names) {
+    R.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (R.h) break;
+  }
+  if (!R.h) NK_FAIL(NK_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+#define SYM(field, name)                                          \
+  R.field = (decltype(R.field))dlsym(R.h, name);                  \
+  if (!R.field) NK_FAIL(NK_E_RCCL, "librccl lacks symbol %s", name)
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(Send, "ncclSend");
+  SYM(Recv, "ncclRecv");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  return NK_OK;
+}
+#define NK_RCCL(call)                                                                        \
+  do {                                                                                       \
+    int r_ = (call);                                                                         \
+    if (r_ != 0) NK_FAIL(NK_E_RCCL, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, R.GetErrorString(r_)); \
+  } while (0)
+
+extern "C" int nk_comm_unique_id(char id_out[128]) {
+  NK_REQUIRE(id_out, "id_out is NULL");
+  NK_TRY(rccl_load());
+  rccl_uid id;
+  NK_RCCL(R.GetUniqueId(&id));
+  memcpy(id_out, id.internal, 128);
+  return NK_OK;
+}
+extern "C" int nk_ctx_comm_init_rccl(nk_ctx *ctx, int nranks, int rank, const char id[128]) {
+  NK_REQUIRE(ctx && id, "NULL argument");
+  NK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
+  NK_REQUIRE(ctx->comm_kind == NK_COMM_NONE, "communicator already initialised");
+  NK_TRY(rccl_load());
+  NK_HIP(hipSetDevice(ctx->device));
+  rccl_uid uid;
+  memcpy(uid.internal, id, 128);
+  NK_RCCL(R.CommInitRank(&ctx->rccl_comm, nranks, uid, rank));
+  ctx->comm_kind = NK_COMM_RCCL;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return NK_OK;
+}
+extern "C" int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, const nk_comm_callbacks *cb) {
+  NK_REQUIRE(ctx && cb && cb->allreduce && cb->alltoallv, "NULL argument / callback");
+  NK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
+  NK_REQUIRE(ctx->comm_kind == NK_COMM_NONE, "communicator already initialised");
+  ctx->cb = *cb;
+  ctx->comm_kind = NK_COMM_CALLBACKS;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return NK_OK;
+}
+extern "C" int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  if (kind) *kind = ctx->comm_kind;
+  if (nranks) *nranks = ctx->nranks;
+  if (rank) *rank = ctx->rank;
+  return NK_OK;
+}
+void nk_comm_destroy(nk_ctx *ctx) {
+  if (ctx->comm_kind == NK_COMM_RCCL && ctx->rccl_comm && R.CommDestroy) R.CommDestroy(ctx->rccl_comm);
+  ctx->rccl_comm = nullptr;
+  ctx->comm_kind = NK_COMM_NONE;
+  ctx->nranks = 1;
+  ctx->rank = 0;
+}
+
+int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op) {
+  if (ctx->nranks <= 1 || count <= 0) return NK_OK;
+  ctx->stats.allreduces++;
+  if (ctx->comm_kind == NK_COMM_RCCL) {
+    NK_RCCL(R.AllReduce(dbuf, dbuf, (size_t)count, RCCL_FLOAT64, op == 1 ? RCCL_MAX : RCCL_SUM,
+                        ctx->rccl_comm, ctx->stream));
+    return NK_OK;
+  }
+  if (ctx->comm_kind == NK_COMM_CALLBACKS) {
+    if (ctx->cb.allreduce(ctx->cb.user, dbuf, count, op, (void *)ctx->stream) != 0)
+      NK_FAIL(NK_E_CALLBACK, "allreduce callback failed");
+    return NK_OK;
+  }
+  NK_FAIL(NK_E_INVALID, "nranks>1 without a communicator");
+}
+
+int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
+                      void *recv, const int64_t *roff, const int64_t *rbytes) {
+  if (ctx->nranks <= 1) return NK_OK;
+  if (ctx->comm_kind == NK_COMM_RCCL) {
+    NK_RCCL(R.GroupStart());
+    for (int p = 0; p < ctx->nranks; ++p) {
+      if (p == ctx->rank) continue;
+      if (sbytes[p] > 0)
+        NK_RCCL(R.Send((const char *)send + soff[p], (size_t)sbytes[p], RCCL_INT8, p, ctx->rccl_comm, ctx->stream));
+      if (rbytes[p] > 0)
+        NK_RCCL(R.Recv((char *)recv + roff[p], (size_t)rbytes[p], RCCL_INT8, p, ctx->rccl_comm, ctx->stream));
+    }
+    NK_RCCL(R.GroupEnd());
+    return NK_OK;
+  }
+  if (ctx->comm_kind == NK_COMM_CALLBACKS) {
+    if (ctx->cb.alltoallv(ctx->cb.user, send, soff, sbytes, recv, roff, rbytes, (void *)ctx->stream) != 0)
+      NK_FAIL(NK_E_CALLBACK, "alltoallv callback failed");
+    return NK_OK;
+  }
+  NK_FAIL(NK_E_INVALID, "nranks>1 without a communicator");
+}
+
+// ----------------------------------------------------------------------------- halo exchange
+__global__ __launch_bounds__(NK_BLOCK) void k_gather(int64_t n, const int32_t *__restrict__ idx,
+                                                     const double *__restrict__ x, double *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) out[i] = x[idx[i]];
+}
+
+int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
+                  const std::vector<int64_t> &recv_cnt_per_peer) {
+  const int P = ctx->nranks;
+  H->send_off.assign(P, 0);
+  H->send_cnt.assign(P, 0);
+  H->recv_off.assign(P, 0);
+  H->recv_cnt.assign(P, 0);
+  std::vector<int32_t> flat;
+  int64_t so = 0, ro = 0;
+  for (int p = 0; p < P; ++p) {
+    H->send_off[p] = so;
+    H->send_cnt[p] = (int64_t)send_idx_per_peer[p].size();
+    flat.insert(flat.end(), send_idx_per_peer[p].begin(), send_idx_per_peer[p].end());
+    so += H->send_cnt[p];
+    H->recv_off[p] = ro;
+    H->recv_cnt[p] = recv_cnt_per_peer[p];
+    ro += H->recv_cnt[p];
+  }
+  H->n_send = so;
+  H->n_recv = ro;
+  NK_TRY(nk_dev_alloc(&H->d_send_idx, (size_t)so));
+  NK_TRY(nk_dev_alloc(&H->d_send, (size_t)so));
+  NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)ro));
+  if (so) NK_HIP(hipMemcpy(H->d_send_idx, flat.data(), so * sizeof(int32_t), hipMemcpyHostToDevice));
+  return NK_OK;
+}
+
+int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
+  if (!H->active()) return NK_OK;
+  const int P = ctx->nranks;
+  if (H->n_send) {
+    int grid = (int)((H->n_send + NK_BLOCK - 1) / NK_BLOCK);
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, H->n_send, H->d_send_idx,
+                       d_x_local, H->d_send);
+  }
+  // entries a rank "sends to itself" (periodic wrap on one rank) are a device copy
+  if (H->send_cnt[ctx->rank] > 0) {
+    NK_HIP(hipMemcpyAsync(H->d_recv + H->recv_off[ctx->rank], H->d_send + H->send_off[ctx->rank],
+                          H->send_cnt[ctx->rank] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (P > 1) {
+    std::vector<int64_t> so(P), sb(P), ro(P), rb(P);
+    for (int p = 0; p < P; ++p) {
+      so[p] = H->send_off[p] * 8;
+      sb[p] = (p == ctx->rank) ? 0 : H->send_cnt[p] * 8;
+      ro[p] = H->recv_off[p] * 8;
+      rb[p] = (p == ctx->rank) ? 0 : H->recv_cnt[p] * 8;
+    }
+    ctx->stats.halo_exchanges++;
+    NK_TRY(nk_comm_alltoallv(ctx, H->d_send, so.data(), sb.data(), H->d_recv, ro.data(), rb.data()));
+  }
+  return NK_OK;
+}
+
+void nk_halo_free(nk_halo *H) {
+  hipFree(H->d_send_idx);
+  hipFree(H->d_send);
+  hipFree(H->d_recv);
+  H->d_send_idx = nullptr;
+  H->d_send = H->d_recv = nullptr;
+  H->n_send = H->n_recv = 0;
+}

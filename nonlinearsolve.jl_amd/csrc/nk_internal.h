@@ -1,0 +1,215 @@
+// Internal declarations of libmi355x_nk.so (gfx950 only). Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "mi355x_nk.h"
+
+// ----------------------------------------------------------------------------- errors
+void nk_set_error(const char *fmt, ...);
+#define NK_FAIL(code, ...)        \
+  do {                            \
+    nk_set_error(__VA_ARGS__);    \
+    return (code);                \
+  } while (0)
+#define NK_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      NK_FAIL(NK_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+#define NK_TRY(call)            \
+  do {                          \
+    int s_ = (call);            \
+    if (s_ != NK_OK) return s_; \
+  } while (0)
+#define NK_REQUIRE(cond, ...) \
+  do {                        \
+    if (!(cond)) NK_FAIL(NK_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ----------------------------------------------------------------------------- context
+constexpr int NK_BLOCK = 256;          // 4 wavefronts of 64
+constexpr int NK_MAX_RED_BLOCKS = 1024; // stage-1 reduction blocks (4 per CU)
+constexpr int NK_MAX_NV = 64;          // max simultaneous dot products (restart m ≤ 63)
+
+// per-kernel-family timing with HIP events on the launch stream (bench/roofline evidence; off by default)
+enum nk_kernel_id {
+  NK_K_SPMV = 0, NK_K_MULTIDOT, NK_K_MULTIAXPY, NK_K_JVP, NK_K_RESIDUAL, NK_K_SCALE, NK_K_REDUCE_SMALL,
+  NK_K_JACFILL, NK_K_NEWTON_UPDATE, NK_K_OTHER, NK_K_COUNT
+};
+struct nk_prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;       // 2 per record
+  std::vector<int> ids;
+  std::vector<double> nbytes;
+  size_t used = 0;
+  double ms[NK_K_COUNT] = {0}, bytes[NK_K_COUNT] = {0};
+  int64_t count[NK_K_COUNT] = {0};
+};
+
+struct nk_ctx {
+  nk_prof prof;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int deterministic = 1;
+  int num_cus = 256;
+  // communicator
+  int comm_kind = NK_COMM_NONE, nranks = 1, rank = 0;
+  void *rccl_comm = nullptr;
+  nk_comm_callbacks cb{};
+  // scratch
+  double *d_partials = nullptr;  // NK_MAX_NV * NK_MAX_RED_BLOCKS doubles
+  double *d_scal = nullptr;      // 4*NK_MAX_NV doubles of device scalars
+  double *h_pinned = nullptr;    // 4*NK_MAX_NV doubles pinned host
+  nk_stats stats{};
+};
+
+void nk_prof_begin(nk_ctx *ctx, int id, double bytes);
+void nk_prof_end(nk_ctx *ctx);
+void nk_prof_flush(nk_ctx *ctx);
+struct nk_prof_scope {  // RAII: brackets the launches issued in its lifetime with two events
+  nk_ctx *c;
+  nk_prof_scope(nk_ctx *ctx, int id, double bytes) : c(ctx->prof.on ? ctx : nullptr) { if (c) nk_prof_begin(c, id, bytes); }
+  ~nk_prof_scope() { if (c) nk_prof_end(c); }
+};
+int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op /*0 sum,1 max*/);
+int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
+                      void *recv, const int64_t *roff, const int64_t *rbytes);
+void nk_comm_destroy(nk_ctx *ctx);
+
+// ----------------------------------------------------------------------------- halo plan
+// recv_buf holds the off-rank entries a kernel needs ("halo"), in the order defined by the plan's owner.
+struct nk_halo {
+  int64_t n_send = 0, n_recv = 0;
+  std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;  // per peer (size nranks), in elements
+  int32_t *d_send_idx = nullptr;  // local indices to gather (n_send)
+  double *d_send = nullptr, *d_recv = nullptr;
+  bool active() const { return n_send > 0 || n_recv > 0; }
+};
+int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
+                  const std::vector<int64_t> &recv_cnt_per_peer);
+int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local);  // result in H->d_recv
+void nk_halo_free(nk_halo *H);
+
+// ----------------------------------------------------------------------------- CSR
+struct nk_csr {
+  nk_ctx *ctx = nullptr;
+  int64_t nrows = 0, n_global = 0, row_begin = 0, nnz = 0;
+  int32_t *d_rowptr = nullptr, *d_col = nullptr;  // local columns: [0,nrows) owned, ≥ nrows → halo slot
+  double *d_val = nullptr;
+  int32_t *d_rowblocks = nullptr;
+  int nblocks = 0;
+  nk_halo halo;
+  std::vector<int64_t> halo_gcols;  // global column of each halo slot
+  // host copies of the pattern (needed for transpose / banded LU / colouring)
+  std::vector<int32_t> h_rowptr, h_col;
+  // lazily built transpose (single rank)
+  nk_csr *T = nullptr;
+  int32_t *d_tperm = nullptr;
+  bool t_values_stale = true;
+  double *d_xtmp = nullptr, *d_ytmp = nullptr;  // staging for host-memspace calls
+};
+int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip);
+int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
+int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
+                        const std::vector<int32_t> &rowptr, const std::vector<int64_t> &gcol,
+                        const double *vals_host, nk_csr **out);
+
+// ----------------------------------------------------------------------------- problems
+struct nk_problem {
+  nk_ctx *ctx = nullptr;
+  int kind = 0;
+  int64_t n_local = 0, n_global = 0, row_begin = 0;
+  double params[8] = {0};
+  int nparams = 0;
+  // grid problems
+  int64_t ns = 0;           // side length
+  int64_t j0 = 0, j1 = 0;   // owned grid lines [j0, j1)
+  double c_lap = 0, c_exp = 0;  // Bratu coefficients
+  nk_halo halo;             // grid-line halo (lower line(s) then upper line(s))
+  double *d_diag = nullptr; // Bratu: c_exp*exp(u) at the linearisation point
+  const double *d_u_lin = nullptr;
+  // user problem
+  nk_user_callbacks cb{};
+  void *user = nullptr;
+  nk_csr *user_pattern = nullptr;
+  // staging buffers for host-memspace calls
+  double *d_tmp[3] = {nullptr, nullptr, nullptr};
+};
+int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
+int nk_problem_jvp_prepare(nk_problem *P, const double *d_u);  // linearise at u (u must stay alive)
+int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip);
+int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
+int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
+
+// ----------------------------------------------------------------------------- BLAS-1 launchers (device)
+// reductions leave their (all-reduced) result in device memory at d_out
+int nk_blas_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *d_out);
+int nk_blas_sumsq(nk_ctx *ctx, int64_t n, const double *x, double *d_out);
+int nk_blas_norm_inf(nk_ctx *ctx, int64_t n, const double *x, double *d_out);
+int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w,
+                     double *d_h, bool with_self, const int *d_skip);
+int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
+                      double sign, double *w, double *d_sumsq /*nullable*/, const int *d_skip,
+                      const int *d_nv /*nullable: device count overrides nv*/);
+int nk_blas_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y);  // y = a x + b y
+int nk_blas_scale_to(nk_ctx *ctx, int64_t n, const double *d_scale, const double *x, double *y,
+                     const int *d_skip);  // y = (*d_scale) * x
+int nk_blas_copy(nk_ctx *ctx, int64_t n, const double *x, double *y);
+int nk_blas_fill(nk_ctx *ctx, int64_t n, double a, double *y);
+// z = a*x + b*y (three-operand)
+int nk_blas_lincomb(nk_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z);
+int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst);  // synchronises
+int nk_blas_minmax(nk_ctx *ctx, int64_t n, const double *x, double *d_out2 /*min,max*/);
+
+// ----------------------------------------------------------------------------- GMRES
+struct nk_gmres_ctl {  // lives in device memory, mirrored to pinned host memory
+  int done, k, converged, failed, need_reorth, pad0, pad1, pad2;
+  double tol, rnorm0, rnorm, inv_hn, hn, wnorm2_before, beta, r0;
+};
+struct nk_gmres {
+  nk_ctx *ctx = nullptr;
+  int64_t n = 0, ldv = 0;
+  int m = 30, ortho = NK_ORTHO_CGS2;
+  double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
+  double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
+         *d_g = nullptr, *d_y = nullptr, *d_ss = nullptr;
+  nk_gmres_ctl *d_ctl = nullptr, *h_ctl = nullptr;
+  // operator
+  int op_kind = 0;  // 0 none, 1 csr, 2 problem jvp, 3 fn
+  nk_csr *A = nullptr;
+  nk_problem *P = nullptr;
+  const double *d_u = nullptr;
+  double *d_u_own = nullptr;
+  nk_matvec_fn fn = nullptr;
+  void *fn_user = nullptr;
+  nk_matvec_fn prec = nullptr;
+  void *prec_user = nullptr;
+  double *d_b = nullptr, *d_x = nullptr;  // staging for host-memspace calls
+};
+int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
+                       int maxiter, int fixed_iters, nk_gmres_info *info);
+
+// ----------------------------------------------------------------------------- misc helpers
+template <typename T>
+static inline int nk_dev_alloc(T **p, size_t count) {
+  *p = nullptr;
+  if (count == 0) return NK_OK;
+  hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+  if (e != hipSuccess) {
+    nk_set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    return NK_E_NOMEM;
+  }
+  return NK_OK;
+}
+static inline int nk_grid_for(int64_t work_items, int per_block, int max_blocks) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}

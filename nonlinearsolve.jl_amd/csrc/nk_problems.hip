@@ -1,0 +1,723 @@
+// Residual / JVP / VJP / Jacobian-value kernels of the built-in problems and the nk_problem API (seam 2).
+//
+//   QUADRATIC      f = u.*u .- p                         common/common_rootfind_testing.jl:15-17
+//   BRATU2D        F_k = s[(4u_k − Σ nb)/h² − λ e^{u_k}]  SURVEY.md §8d (not in the reference)
+//   BRUSSELATOR2D  brusselator_2d_loop                   lib/NonlinearSolveFirstOrder/test/sparsity_tests__item1.jl:13-36
+//   USER           device callbacks (f!, jvp!, vjp!, jac!) = NonlinearFunction{true} fields
+//
+// Grid problems are partitioned by whole grid lines; a rank owns lines [j0, j1). Off-rank lines arrive in
+// the halo buffer (lower neighbour's line(s) first, then the upper neighbour's).
+// Algorithmic bytes: residual 16 n; matrix-free JVP 24 n (v, d = c_exp·e^u precomputed once per Newton
+// step, Jv); Jacobian value fill ≈ 8 nnz + 8 n.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "nk_internal.h"
+
+#define SKIP_GUARD(d_skip) \
+  if ((d_skip) != nullptr && *(d_skip) != 0) return;
+
+// ============================================================================ quadratic
+__global__ __launch_bounds__(NK_BLOCK) void k_quad_residual(int64_t n, double p, const double *__restrict__ u,
+                                                            double *__restrict__ f) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) f[i] = u[i] * u[i] - p;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_quad_jvp(int64_t n, const double *__restrict__ u,
+                                                       const double *__restrict__ v, double *__restrict__ jv,
+                                                       const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) jv[i] = 2.0 * u[i] * v[i];
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_quad_jac(int64_t n, const double *__restrict__ u,
+                                                       double *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) vals[i] = 2.0 * u[i];
+}
+
+// ============================================================================ Bratu 2-D
+// local point k = jl*ns + i, jl = j - j0. lo/hi: halo lines (nullptr at the physical boundary).
+__device__ __forceinline__ double bratu_lap(const double *__restrict__ u, const double *__restrict__ lo,
+                                            const double *__restrict__ hi, int64_t ns, int64_t nl, int64_t i,
+                                            int64_t jl, int64_t k) {
+  double s = 4.0 * u[k];
+  if (i > 0) s -= u[k - 1];
+  if (i < ns - 1) s -= u[k + 1];
+  if (jl > 0) s -= u[k - ns];
+  else if (lo) s -= lo[i];
+  if (jl < nl - 1) s -= u[k + ns];
+  else if (hi) s -= hi[i];
+  return s;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual(int64_t ns, int64_t nl, double c_lap, double c_exp,
+                                                             const double *__restrict__ u,
+                                                             const double *__restrict__ lo,
+                                                             const double *__restrict__ hi, double *__restrict__ f) {
+  const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= ns * nl) return;
+  const int64_t jl = k / ns, i = k - jl * ns;
+  f[k] = c_lap * bratu_lap(u, lo, hi, ns, nl, i, jl, k) - c_exp * exp(u[k]);
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_bratu_diag(int64_t n, double c_exp, const double *__restrict__ u,
+                                                         double *__restrict__ d) {
+  const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k < n) d[k] = c_exp * exp(u[k]);
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp(int64_t ns, int64_t nl, double c_lap,
+                                                        const double *__restrict__ d, const double *__restrict__ v,
+                                                        const double *__restrict__ lo, const double *__restrict__ hi,
+                                                        double *__restrict__ jv, const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= ns * nl) return;
+  const int64_t jl = k / ns, i = k - jl * ns;
+  jv[k] = c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * v[k];
+}
+// values in pattern order [S?][W?][C][E?][N?] (columns ascending); j = global grid line
+__global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
+                                                        double c_exp, const double *__restrict__ u,
+                                                        const int32_t *__restrict__ rowptr,
+                                                        double *__restrict__ vals) {
+  const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= ns * nl) return;
+  const int64_t jl = k / ns, i = k - jl * ns, j = j0 + jl;
+  int32_t p = rowptr[k];
+  if (j > 0) vals[p++] = -c_lap;
+  if (i > 0) vals[p++] = -c_lap;
+  vals[p++] = 4.0 * c_lap - c_exp * exp(u[k]);
+  if (i < ns - 1) vals[p++] = -c_lap;
+  if (j < ns - 1) vals[p++] = -c_lap;
+}
+
+// ============================================================================ Brusselator 2-D
+// local layout (i, jl, species): idx = i + N*jl + N*nl*s. lo/hi: [species0 line | species1 line] of the
+// periodic neighbours; nullptr → wrap inside the local slab (single rank).
+struct brus_par { int64_t N, nl, j0; double A, B, alpha; };
+
+__device__ __forceinline__ double brus_lap(const double *__restrict__ w, const double *__restrict__ lo,
+                                           const double *__restrict__ hi, const brus_par &q, int64_t i, int64_t jl) {
+  const int64_t N = q.N, nl = q.nl;
+  const int64_t ip1 = (i + 1 == N) ? 0 : i + 1, im1 = (i == 0) ? N - 1 : i - 1;
+  double s = w[im1 + N * jl] + w[ip1 + N * jl] - 4.0 * w[i + N * jl];
+  if (jl + 1 < nl) s += w[i + N * (jl + 1)];
+  else s += hi ? hi[i] : w[i];                      // wrap to local line 0
+  if (jl > 0) s += w[i + N * (jl - 1)];
+  else s += lo ? lo[i] : w[i + N * (nl - 1)];       // wrap to local last line
+  return s;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_brus_residual(brus_par q, const double *__restrict__ U,
+                                                            const double *__restrict__ lo,
+                                                            const double *__restrict__ hi, double *__restrict__ F) {
+  const int64_t t = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  const int64_t nn = q.N * q.nl;
+  if (t >= nn) return;
+  const int64_t jl = t / q.N, i = t - jl * q.N;
+  const double x = (double)i / (double)(q.N - 1), y = (double)(q.j0 + jl) / (double)(q.N - 1);
+  const double bf = (((x - 0.3) * (x - 0.3) + (y - 0.6) * (y - 0.6)) <= 0.1 * 0.1) ? 5.0 : 0.0;
+  const double uu = U[t], vv = U[nn + t];
+  const double *lo1 = lo ? lo + q.N : nullptr, *hi1 = hi ? hi + q.N : nullptr;
+  F[t] = q.alpha * brus_lap(U, lo, hi, q, i, jl) + q.B + uu * uu * vv - (q.A + 1.0) * uu + bf;
+  F[nn + t] = q.alpha * brus_lap(U + nn, lo1, hi1, q, i, jl) + q.A * uu - uu * uu * vv;
+}
+// transpose=0: J*v ; transpose=1: Jᵀ*v
+__global__ __launch_bounds__(NK_BLOCK) void k_brus_jvp(brus_par q, int transpose, const double *__restrict__ U,
+                                                       const double *__restrict__ V, const double *__restrict__ lo,
+                                                       const double *__restrict__ hi, double *__restrict__ JV,
+                                                       const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  const int64_t t = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  const int64_t nn = q.N * q.nl;
+  if (t >= nn) return;
+  const int64_t jl = t / q.N, i = t - jl * q.N;
+  const double uu = U[t], vv = U[nn + t], a = V[t], b = V[nn + t];
+  const double *lo1 = lo ? lo + q.N : nullptr, *hi1 = hi ? hi + q.N : nullptr;
+  const double la = q.alpha * brus_lap(V, lo, hi, q, i, jl), lb = q.alpha * brus_lap(V + nn, lo1, hi1, q, i, jl);
+  const double d11 = 2.0 * uu * vv - (q.A + 1.0), d12 = uu * uu, d21 = q.A - 2.0 * uu * vv, d22 = -uu * uu;
+  if (!transpose) {
+    JV[t] = la + d11 * a + d12 * b;
+    JV[nn + t] = lb + d21 * a + d22 * b;
+  } else {
+    JV[t] = la + d11 * a + d21 * b;
+    JV[nn + t] = lb + d12 * a + d22 * b;
+  }
+}
+// role per non-zero: 0 α (neighbour) · 1 ∂F1/∂u · 2 ∂F1/∂v · 3 ∂F2/∂v · 4 ∂F2/∂u
+__global__ __launch_bounds__(NK_BLOCK) void k_brus_jac(int64_t nnz, int64_t nn, double A, double alpha,
+                                                       const uint8_t *__restrict__ role,
+                                                       const int32_t *__restrict__ node, const double *__restrict__ U,
+                                                       double *__restrict__ vals) {
+  const int64_t p = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (p >= nnz) return;
+  const int32_t t = node[p];
+  const double uu = U[t], vv = U[nn + t];
+  double r;
+  switch (role[p]) {
+    case 0: r = alpha; break;
+    case 1: r = -4.0 * alpha + 2.0 * uu * vv - (A + 1.0); break;
+    case 2: r = uu * uu; break;
+    case 3: r = -4.0 * alpha - uu * uu; break;
+    default: r = A - 2.0 * uu * vv; break;
+  }
+  vals[p] = r;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_brus_u0(brus_par q, double *__restrict__ U) {
+  const int64_t t = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  const int64_t nn = q.N * q.nl;
+  if (t >= nn) return;
+  const int64_t jl = t / q.N, i = t - jl * q.N;
+  const double x = (double)i / (double)(q.N - 1), y = (double)(q.j0 + jl) / (double)(q.N - 1);
+  const double a = y * (1.0 - y), b = x * (1.0 - x);
+  U[t] = 22.0 * a * sqrt(a);        // 22 (y(1-y))^(3/2)   sparsity_tests__item1.jl:40-50
+  U[nn + t] = 27.0 * b * sqrt(b);
+}
+
+// ============================================================================ host side
+struct brus_extra {  // kept alongside the Jacobian CSR created by nk_problem_jac_csr
+  uint8_t *d_role = nullptr;
+  int32_t *d_node = nullptr;
+};
+static std::vector<std::pair<nk_csr *, brus_extra>> g_brus_extras;  // tiny registry (ctx is single-threaded)
+
+static inline int grid1(int64_t n) { return (int)((n + NK_BLOCK - 1) / NK_BLOCK); }
+
+static brus_par brus_params(const nk_problem *P) {
+  brus_par q;
+  q.N = P->ns;
+  q.nl = P->j1 - P->j0;
+  q.j0 = P->j0;
+  q.A = P->params[1];
+  q.B = P->params[2];
+  const double dx = P->params[4];
+  q.alpha = P->params[3] / (dx * dx);
+  return q;
+}
+
+static int setup_grid_partition(nk_problem *P, int64_t ns, int dof_per_node, bool periodic) {
+  nk_ctx *ctx = P->ctx;
+  const int R = ctx->nranks, r = ctx->rank;
+  NK_REQUIRE(ns >= R, "grid side %lld smaller than the number of ranks %d", (long long)ns, R);
+  int64_t b, e;
+  NK_TRY(nk_partition_range(ns, 1, R, r, &b, &e));
+  P->ns = ns;
+  P->j0 = b;
+  P->j1 = e;
+  const int64_t nl = e - b;
+  P->n_local = ns * nl * dof_per_node;
+  P->n_global = ns * ns * dof_per_node;
+  P->row_begin = ns * b * dof_per_node;
+  if (R == 1) return NK_OK;
+  // who needs what from me: my first line goes to the rank below (it is their "upper" line), my last line
+  // to the rank above. Receive order per peer: [their-lower-request][their-upper-request].
+  std::vector<std::vector<int32_t>> send(R);
+  std::vector<int64_t> recv(R, 0);
+  const int below = (r == 0) ? (periodic ? R - 1 : -1) : r - 1;
+  const int above = (r == R - 1) ? (periodic ? 0 : -1) : r + 1;
+  auto push_line = [&](std::vector<int32_t> &v, int64_t jl) {
+    for (int s = 0; s < dof_per_node; ++s)
+      for (int64_t i = 0; i < ns; ++i) v.push_back((int32_t)(i + ns * jl + ns * nl * s));
+  };
+  // A peer p receives from me first what serves as p's LOWER halo (my last line, if I am below p), then
+  // what serves as p's UPPER halo (my first line, if I am above p).
+  if (above >= 0) push_line(send[above], nl - 1);  // I am below `above`
+  if (below >= 0) push_line(send[below], 0);       // I am above `below`
+  if (below >= 0) recv[below] += ns * dof_per_node;
+  if (above >= 0) recv[above] += ns * dof_per_node;
+  return nk_halo_setup(ctx, &P->halo, send, recv);
+}
+
+// pointers to my lower / upper halo lines inside the receive buffer (nullptr if none)
+static void halo_lines(const nk_problem *P, int dof_per_node, bool periodic, const double **lo, const double **hi) {
+  *lo = *hi = nullptr;
+  const nk_ctx *ctx = P->ctx;
+  const int R = ctx->nranks, r = ctx->rank;
+  if (R == 1) return;
+  const int below = (r == 0) ? (periodic ? R - 1 : -1) : r - 1;
+  const int above = (r == R - 1) ? (periodic ? 0 : -1) : r + 1;
+  const int64_t line = P->ns * dof_per_node;
+  if (below >= 0) *lo = P->halo.d_recv + P->halo.recv_off[below];
+  if (above >= 0) {
+    // if the same peer is both below and above (R == 2, periodic) its block is [lower part][upper part]
+    const int64_t shift = (above == below) ? line : 0;
+    *hi = P->halo.d_recv + P->halo.recv_off[above] + shift;
+  }
+}
+
+extern "C" int nk_problem_create(nk_ctx *ctx, int kind, const double *params, int nparams, nk_problem **out) {
+  NK_REQUIRE(ctx && params && out, "NULL argument");
+  NK_REQUIRE(nparams >= 0 && nparams <= 8, "nparams out of range");
+  NK_HIP(hipSetDevice(ctx->device));
+  nk_problem *P = new nk_problem();
+  P->ctx = ctx;
+  P->kind = kind;
+  P->nparams = nparams;
+  for (int i = 0; i < nparams; ++i) P->params[i] = params[i];
+  int st = NK_OK;
+  if (kind == NK_PROBLEM_QUADRATIC) {
+    if (nparams < 2) { delete P; NK_FAIL(NK_E_INVALID, "QUADRATIC needs {n, p}"); }
+    const int64_t n = (int64_t)params[0];
+    int64_t b, e;
+    st = nk_partition_range(n, 1, ctx->nranks, ctx->rank, &b, &e);
+    P->n_global = n;
+    P->row_begin = b;
+    P->n_local = e - b;
+  } else if (kind == NK_PROBLEM_BRATU2D) {
+    if (nparams < 2) { delete P; NK_FAIL(NK_E_INVALID, "BRATU2D needs {n_side, lambda[, scale]}"); }
+    const int64_t ns = (int64_t)params[0];
+    const double lam = params[1], sc = nparams >= 3 ? params[2] : 0.0;
+    const double h = 1.0 / (double)(ns + 1);
+    const double s = (sc == 0.0) ? h * h : sc;
+    P->c_lap = s / (h * h);
+    P->c_exp = s * lam;
+    st = setup_grid_partition(P, ns, 1, false);
+  } else if (kind == NK_PROBLEM_BRUSSELATOR2D) {
+    if (nparams < 5) { delete P; NK_FAIL(NK_E_INVALID, "BRUSSELATOR2D needs {N, A, B, alpha, dx}"); }
+    const int64_t N = (int64_t)params[0];
+    if (N < 3) { delete P; NK_FAIL(NK_E_INVALID, "BRUSSELATOR2D needs N >= 3"); }
+    st = setup_grid_partition(P, N, 2, true);
+  } else {
+    delete P;
+    NK_FAIL(NK_E_INVALID, "unknown built-in problem kind %d", kind);
+  }
+  if (st != NK_OK) { delete P; return st; }
+  *out = P;
+  return NK_OK;
+}
+
+extern "C" int nk_problem_create_user(nk_ctx *ctx, int64_t n_local, int64_t n_global, int64_t row_begin,
+                                      const nk_user_callbacks *cb, void *user, nk_csr *jac_pattern,
+                                      nk_problem **out) {
+  NK_REQUIRE(ctx && cb && cb->residual && out, "NULL argument / residual callback");
+  nk_problem *P = new nk_problem();
+  P->ctx = ctx;
+  P->kind = NK_PROBLEM_USER;
+  P->n_local = n_local;
+  P->n_global = n_global;
+  P->row_begin = row_begin;
+  P->cb = *cb;
+  P->user = user;
+  P->user_pattern = jac_pattern;
+  *out = P;
+  return NK_OK;
+}
+
+extern "C" int nk_problem_destroy(nk_problem *P) {
+  if (!P) return NK_OK;
+  hipFree(P->d_diag);
+  for (double *&t : P->d_tmp) hipFree(t);
+  nk_halo_free(&P->halo);
+  delete P;
+  return NK_OK;
+}
+extern "C" int nk_problem_size(nk_problem *P, int64_t *n_local, int64_t *n_global, int64_t *row_begin) {
+  NK_REQUIRE(P, "NULL argument");
+  if (n_local) *n_local = P->n_local;
+  if (n_global) *n_global = P->n_global;
+  if (row_begin) *row_begin = P->row_begin;
+  return NK_OK;
+}
+extern "C" int nk_problem_set_params(nk_problem *P, const double *params, int nparams) {
+  NK_REQUIRE(P && params, "NULL argument");
+  NK_REQUIRE(nparams == P->nparams, "nparams mismatch (%d vs %d)", nparams, P->nparams);
+  if (P->kind == NK_PROBLEM_QUADRATIC) {
+    NK_REQUIRE((int64_t)params[0] == P->n_global, "cannot change the problem size");
+  } else if (P->kind == NK_PROBLEM_BRATU2D || P->kind == NK_PROBLEM_BRUSSELATOR2D) {
+    NK_REQUIRE((int64_t)params[0] == P->ns, "cannot change the grid size");
+  }
+  for (int i = 0; i < nparams; ++i) P->params[i] = params[i];
+  if (P->kind == NK_PROBLEM_BRATU2D) {
+    const double h = 1.0 / (double)(P->ns + 1);
+    const double sc = nparams >= 3 ? params[2] : 0.0, s = (sc == 0.0) ? h * h : sc;
+    P->c_lap = s / (h * h);
+    P->c_exp = s * params[1];
+  }
+  return NK_OK;
+}
+
+// ---------------------------------------------------------------------------- device-level operations
+int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f) {
+  nk_ctx *ctx = P->ctx;
+  const int64_t n = P->n_local;
+  if (n == 0) return NK_OK;
+  nk_prof_scope prof_(ctx, NK_K_RESIDUAL, 16.0 * (double)n);
+  switch (P->kind) {
+    case NK_PROBLEM_QUADRATIC:
+      hipLaunchKernelGGL(k_quad_residual, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, P->params[1], d_u, d_f);
+      break;
+    case NK_PROBLEM_BRATU2D: {
+      const double *lo, *hi;
+      NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
+      halo_lines(P, 1, false, &lo, &hi);
+      hipLaunchKernelGGL(k_bratu_residual, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0,
+                         P->c_lap, P->c_exp, d_u, lo, hi, d_f);
+      break;
+    }
+    case NK_PROBLEM_BRUSSELATOR2D: {
+      const double *lo, *hi;
+      NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
+      halo_lines(P, 2, true, &lo, &hi);
+      hipLaunchKernelGGL(k_brus_residual, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), d_u, lo,
+                         hi, d_f);
+      break;
+    }
+    case NK_PROBLEM_USER:
+      if (P->cb.residual(P->user, d_u, d_f, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "residual callback failed");
+      break;
+    default:
+      NK_FAIL(NK_E_INVALID, "bad problem kind");
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
+  P->d_u_lin = d_u;
+  if (P->kind == NK_PROBLEM_BRATU2D) {
+    if (!P->d_diag) NK_TRY(nk_dev_alloc(&P->d_diag, (size_t)P->n_local + 1));
+    if (P->n_local)
+      hipLaunchKernelGGL(k_bratu_diag, dim3(grid1(P->n_local)), dim3(NK_BLOCK), 0, P->ctx->stream, P->n_local,
+                         P->c_exp, d_u, P->d_diag);
+    NK_HIP(hipGetLastError());
+  }
+  return NK_OK;
+}
+
+int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip) {
+  nk_ctx *ctx = P->ctx;
+  const int64_t n = P->n_local;
+  ctx->stats.op_applies++;
+  if (n == 0) return NK_OK;
+  if (P->kind == NK_PROBLEM_BRATU2D && (P->d_u_lin != d_u || !P->d_diag)) NK_TRY(nk_problem_jvp_prepare(P, d_u));
+  nk_prof_scope prof_(ctx, NK_K_JVP, 24.0 * (double)n);
+  switch (P->kind) {
+    case NK_PROBLEM_QUADRATIC:
+      hipLaunchKernelGGL(k_quad_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_u, d_v, d_jv, d_skip);
+      break;
+    case NK_PROBLEM_BRATU2D: {
+      const double *lo, *hi;
+      NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
+      halo_lines(P, 1, false, &lo, &hi);
+      hipLaunchKernelGGL(k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0, P->c_lap,
+                         P->d_diag, d_v, lo, hi, d_jv, d_skip);
+      break;
+    }
+    case NK_PROBLEM_BRUSSELATOR2D: {
+      const double *lo, *hi;
+      NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
+      halo_lines(P, 2, true, &lo, &hi);
+      hipLaunchKernelGGL(k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), 0, d_u, d_v,
+                         lo, hi, d_jv, d_skip);
+      break;
+    }
+    case NK_PROBLEM_USER:
+      if (!P->cb.jvp) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no jvp callback");
+      if (P->cb.jvp(P->user, d_v, d_u, d_jv, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "jvp callback failed");
+      break;
+    default:
+      NK_FAIL(NK_E_INVALID, "bad problem kind");
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj) {
+  nk_ctx *ctx = P->ctx;
+  const int64_t n = P->n_local;
+  if (P->kind == NK_PROBLEM_QUADRATIC || P->kind == NK_PROBLEM_BRATU2D)  // symmetric Jacobians
+    return nk_problem_jvp_dev(P, d_u, d_v, d_vj, nullptr);
+  ctx->stats.op_applies++;
+  if (n == 0) return NK_OK;
+  if (P->kind == NK_PROBLEM_BRUSSELATOR2D) {
+    const double *lo, *hi;
+    NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
+    halo_lines(P, 2, true, &lo, &hi);
+    hipLaunchKernelGGL(k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), 1, d_u, d_v, lo,
+                       hi, d_vj, (const int *)nullptr);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
+  if (P->kind == NK_PROBLEM_USER) {
+    if (!P->cb.vjp) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no vjp callback");
+    if (P->cb.vjp(P->user, d_v, d_u, d_vj, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "vjp callback failed");
+    return NK_OK;
+  }
+  NK_FAIL(NK_E_INVALID, "bad problem kind");
+}
+
+// ---------------------------------------------------------------------------- Jacobian pattern / values
+// internal global index of grid node (i, j), species s for a line-partitioned problem
+static int64_t grid_gidx(int64_t ns, int dof, int R, int64_t i, int64_t j, int s) {
+  // owner of line j and its range
+  int p = (int)(((j + 1) * R - 1) / ns);  // initial guess, then fix up
+  if (p < 0) p = 0;
+  if (p >= R) p = R - 1;
+  for (;;) {
+    const int64_t b = ns * p / R, e = ns * (p + 1) / R;
+    if (j < b) --p;
+    else if (j >= e) ++p;
+    else {
+      const int64_t nl = e - b;
+      return ns * b * dof + i + ns * (j - b) + ns * nl * s;
+    }
+  }
+}
+
+extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
+  NK_REQUIRE(P && out, "NULL argument");
+  nk_ctx *ctx = P->ctx;
+  NK_HIP(hipSetDevice(ctx->device));
+  const int R = ctx->nranks;
+  std::vector<int32_t> rp;
+  std::vector<int64_t> gc;
+  if (P->kind == NK_PROBLEM_QUADRATIC) {
+    rp.resize(P->n_local + 1);
+    gc.resize(P->n_local);
+    for (int64_t i = 0; i < P->n_local; ++i) { rp[i] = (int32_t)i; gc[i] = P->row_begin + i; }
+    rp[P->n_local] = (int32_t)P->n_local;
+    return nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out);
+  }
+  if (P->kind == NK_PROBLEM_BRATU2D) {
+    const int64_t ns = P->ns;
+    rp.reserve(P->n_local + 1);
+    gc.reserve(5 * P->n_local);
+    for (int64_t j = P->j0; j < P->j1; ++j)
+      for (int64_t i = 0; i < ns; ++i) {
+        const int64_t k = j * ns + i;  // contiguous line partition ⇒ internal global index = lexicographic
+        rp.push_back((int32_t)gc.size());
+        if (j > 0) gc.push_back(k - ns);
+        if (i > 0) gc.push_back(k - 1);
+        gc.push_back(k);
+        if (i < ns - 1) gc.push_back(k + 1);
+        if (j < ns - 1) gc.push_back(k + ns);
+      }
+    rp.push_back((int32_t)gc.size());
+    return nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out);
+  }
+  if (P->kind == NK_PROBLEM_BRUSSELATOR2D) {
+    const int64_t N = P->ns, nl = P->j1 - P->j0, nn = N * nl;
+    std::vector<uint8_t> role;
+    std::vector<int32_t> node;
+    rp.reserve(P->n_local + 1);
+    struct ent { int64_t c; uint8_t role; };
+    for (int s = 0; s < 2; ++s)
+      for (int64_t jl = 0; jl < nl; ++jl)
+        for (int64_t i = 0; i < N; ++i) {
+          const int64_t j = P->j0 + jl;
+          const int64_t ip1 = (i + 1 == N) ? 0 : i + 1, im1 = (i == 0) ? N - 1 : i - 1;
+          const int64_t jp1 = (j + 1 == N) ? 0 : j + 1, jm1 = (j == 0) ? N - 1 : j - 1;
+          ent e[6] = {{grid_gidx(N, 2, R, im1, j, s), 0}, {grid_gidx(N, 2, R, ip1, j, s), 0},
+                      {grid_gidx(N, 2, R, i, jp1, s), 0}, {grid_gidx(N, 2, R, i, jm1, s), 0},
+                      {grid_gidx(N, 2, R, i, j, s), (uint8_t)(s == 0 ? 1 : 3)},
+                      {grid_gidx(N, 2, R, i, j, 1 - s), (uint8_t)(s == 0 ? 2 : 4)}};
+          std::sort(e, e + 6, [](const ent &a, const ent &b) { return a.c < b.c; });
+          rp.push_back((int32_t)gc.size());
+          for (int t = 0; t < 6; ++t) {
+            gc.push_back(e[t].c);
+            role.push_back(e[t].role);
+            node.push_back((int32_t)(i + N * jl));
+          }
+        }
+    rp.push_back((int32_t)gc.size());
+    NK_TRY(nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out));
+    brus_extra ex;
+    NK_TRY(nk_dev_alloc(&ex.d_role, role.size()));
+    NK_TRY(nk_dev_alloc(&ex.d_node, node.size()));
+    NK_HIP(hipMemcpy(ex.d_role, role.data(), role.size(), hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ex.d_node, node.data(), node.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    g_brus_extras.push_back({*out, ex});
+    (void)nn;
+    return NK_OK;
+  }
+  if (P->kind == NK_PROBLEM_USER) {
+    NK_REQUIRE(P->user_pattern, "user problem was created without a Jacobian pattern");
+    *out = P->user_pattern;
+    return NK_OK;
+  }
+  NK_FAIL(NK_E_INVALID, "bad problem kind");
+}
+
+int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
+  nk_ctx *ctx = P->ctx;
+  const int64_t n = P->n_local;
+  J->t_values_stale = true;
+  if (n == 0) return NK_OK;
+  nk_prof_scope prof_(ctx, NK_K_JACFILL, 8.0 * (double)J->nnz + 8.0 * (double)n);
+  switch (P->kind) {
+    case NK_PROBLEM_QUADRATIC:
+      hipLaunchKernelGGL(k_quad_jac, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_u, J->d_val);
+      break;
+    case NK_PROBLEM_BRATU2D:
+      hipLaunchKernelGGL(k_bratu_jac, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0, P->j0,
+                         P->c_lap, P->c_exp, d_u, J->d_rowptr, J->d_val);
+      break;
+    case NK_PROBLEM_BRUSSELATOR2D: {
+      brus_extra *ex = nullptr;
+      for (auto &pr : g_brus_extras)
+        if (pr.first == J) ex = &pr.second;
+      NK_REQUIRE(ex, "CSR was not created by nk_problem_jac_csr for a Brusselator problem");
+      const brus_par q = brus_params(P);
+      hipLaunchKernelGGL(k_brus_jac, dim3(grid1(J->nnz)), dim3(NK_BLOCK), 0, ctx->stream, J->nnz, q.N * q.nl, q.A,
+                         q.alpha, ex->d_role, ex->d_node, d_u, J->d_val);
+      break;
+    }
+    case NK_PROBLEM_USER:
+      if (!P->cb.jac_values) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no jac_values callback");
+      if (P->cb.jac_values(P->user, d_u, J->d_val, (void *)ctx->stream) != 0)
+        NK_FAIL(NK_E_CALLBACK, "jac_values callback failed");
+      break;
+    default:
+      NK_FAIL(NK_E_INVALID, "bad problem kind");
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+// ---------------------------------------------------------------------------- exported wrappers with memspace
+static int stage(nk_problem *P, int slot, const double *src, int memspace, const double **dst) {
+  if (memspace == NK_DEVICE) { *dst = src; return NK_OK; }
+  if (!P->d_tmp[slot]) NK_TRY(nk_dev_alloc(&P->d_tmp[slot], (size_t)P->n_local + 1));
+  NK_HIP(hipMemcpyAsync(P->d_tmp[slot], src, P->n_local * sizeof(double), hipMemcpyHostToDevice, P->ctx->stream));
+  *dst = P->d_tmp[slot];
+  return NK_OK;
+}
+static int out_begin(nk_problem *P, int slot, double *dst, int memspace, double **dev) {
+  if (memspace == NK_DEVICE) { *dev = dst; return NK_OK; }
+  if (!P->d_tmp[slot]) NK_TRY(nk_dev_alloc(&P->d_tmp[slot], (size_t)P->n_local + 1));
+  *dev = P->d_tmp[slot];
+  return NK_OK;
+}
+static int out_end(nk_problem *P, double *dst, int memspace, const double *dev) {
+  if (memspace == NK_DEVICE) return NK_OK;
+  NK_HIP(hipMemcpyAsync(dst, dev, P->n_local * sizeof(double), hipMemcpyDeviceToHost, P->ctx->stream));
+  NK_HIP(hipStreamSynchronize(P->ctx->stream));
+  return NK_OK;
+}
+
+extern "C" int nk_problem_initial_guess(nk_problem *P, double *u0, int memspace) {
+  NK_REQUIRE(P && u0, "NULL argument");
+  NK_HIP(hipSetDevice(P->ctx->device));
+  double *d;
+  NK_TRY(out_begin(P, 0, u0, memspace, &d));
+  switch (P->kind) {
+    case NK_PROBLEM_QUADRATIC: NK_TRY(nk_blas_fill(P->ctx, P->n_local, 1.0, d)); break;
+    case NK_PROBLEM_BRATU2D: NK_TRY(nk_blas_fill(P->ctx, P->n_local, 0.0, d)); break;
+    case NK_PROBLEM_BRUSSELATOR2D:
+      if (P->n_local)
+        hipLaunchKernelGGL(k_brus_u0, dim3(grid1(P->n_local / 2)), dim3(NK_BLOCK), 0, P->ctx->stream, brus_params(P), d);
+      NK_HIP(hipGetLastError());
+      break;
+    default: NK_FAIL(NK_E_UNSUPPORTED, "no built-in initial guess for this problem kind");
+  }
+  return out_end(P, u0, memspace, d);
+}
+extern "C" int nk_residual(nk_problem *P, const double *u, double *f, int memspace) {
+  NK_REQUIRE(P && u && f, "NULL argument");
+  NK_HIP(hipSetDevice(P->ctx->device));
+  const double *du;
+  double *df;
+  NK_TRY(stage(P, 0, u, memspace, &du));
+  NK_TRY(out_begin(P, 1, f, memspace, &df));
+  NK_TRY(nk_problem_residual_dev(P, du, df));
+  return out_end(P, f, memspace, df);
+}
+static int jvp_any(nk_problem *P, const double *u, const double *v, double *jv, int memspace, bool transpose) {
+  NK_REQUIRE(P && u && v && jv, "NULL argument");
+  NK_HIP(hipSetDevice(P->ctx->device));
+  const double *du, *dv;
+  double *dj;
+  NK_TRY(stage(P, 0, u, memspace, &du));
+  NK_TRY(stage(P, 1, v, memspace, &dv));
+  NK_TRY(out_begin(P, 2, jv, memspace, &dj));
+  P->d_u_lin = nullptr;  // force re-linearisation: the caller's u may have changed in place
+  NK_TRY(transpose ? nk_problem_vjp_dev(P, du, dv, dj) : nk_problem_jvp_dev(P, du, dv, dj, nullptr));
+  return out_end(P, jv, memspace, dj);
+}
+extern "C" int nk_jvp(nk_problem *P, const double *u, const double *v, double *Jv, int memspace) {
+  return jvp_any(P, u, v, Jv, memspace, false);
+}
+extern "C" int nk_vjp(nk_problem *P, const double *u, const double *v, double *vJ, int memspace) {
+  return jvp_any(P, u, v, vJ, memspace, true);
+}
+extern "C" int nk_jac_values(nk_problem *P, const double *u, int memspace, nk_csr *J) {
+  NK_REQUIRE(P && u && J, "NULL argument");
+  NK_HIP(hipSetDevice(P->ctx->device));
+  const double *du;
+  NK_TRY(stage(P, 0, u, memspace, &du));
+  NK_TRY(nk_problem_jac_values_dev(P, du, J));
+  if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(P->ctx->stream));
+  return NK_OK;
+}
+
+// ---------------------------------------------------------------------------- colour-compressed assembly
+// Column colouring by greedy distance-2 (structurally orthogonal columns), seeds s_c = 1 on colour c,
+// B[:,c] = J s_c by the matrix-free JVP, decompression vals[p] = B[row(p), colour(col(p))]. This is the
+// shape of DI.jacobian! with AutoSparse + column colouring (jacobian.jl:244-247).
+__global__ __launch_bounds__(NK_BLOCK) void k_seed(int64_t n, const int32_t *__restrict__ color, int c,
+                                                   double *__restrict__ s) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) s[i] = (color[i] == c) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_decompress(int64_t nrows, const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ colcolor_of_nnz, int c,
+                                                         const double *__restrict__ Bc, double *__restrict__ vals) {
+  const int64_t r = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (r >= nrows) return;
+  for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
+    if (colcolor_of_nnz[p] == c) vals[p] = Bc[r];
+}
+
+extern "C" int nk_jac_values_colored(nk_problem *P, const double *u, int memspace, nk_csr *J, int *ncolors_out) {
+  NK_REQUIRE(P && u && J, "NULL argument");
+  nk_ctx *ctx = P->ctx;
+  NK_REQUIRE(ctx->nranks == 1, "coloured assembly is single-rank in this round");
+  NK_HIP(hipSetDevice(ctx->device));
+  const int64_t n = J->nrows;
+  // greedy distance-2 column colouring on the host pattern (columns sharing a row get different colours)
+  std::vector<std::vector<int32_t>> rows_of_col(n);
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) rows_of_col[J->h_col[p]].push_back((int32_t)r);
+  std::vector<int32_t> color(n, -1), mark(n + 1, -1);
+  int ncolors = 0;
+  for (int64_t c = 0; c < n; ++c) {
+    for (int32_t r : rows_of_col[c])
+      for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) {
+        const int32_t oc = color[J->h_col[p]];
+        if (oc >= 0) mark[oc] = (int32_t)c;
+      }
+    int32_t k = 0;
+    while (mark[k] == (int32_t)c) ++k;
+    color[c] = k;
+    if (k + 1 > ncolors) ncolors = k + 1;
+  }
+  std::vector<int32_t> nnzcolor(J->nnz);
+  for (int64_t p = 0; p < J->nnz; ++p) nnzcolor[p] = color[J->h_col[p]];
+  int32_t *d_color = nullptr, *d_nnzcolor = nullptr;
+  double *d_seed = nullptr, *d_B = nullptr;
+  NK_TRY(nk_dev_alloc(&d_color, (size_t)n));
+  NK_TRY(nk_dev_alloc(&d_nnzcolor, (size_t)J->nnz));
+  NK_TRY(nk_dev_alloc(&d_seed, (size_t)n + 1));
+  NK_TRY(nk_dev_alloc(&d_B, (size_t)n + 1));
+  NK_HIP(hipMemcpy(d_color, color.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(hipMemcpy(d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  const double *du;
+  NK_TRY(stage(P, 0, u, memspace, &du));
+  P->d_u_lin = nullptr;
+  int st = NK_OK;
+  for (int c = 0; c < ncolors && st == NK_OK; ++c) {
+    hipLaunchKernelGGL(k_seed, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_color, c, d_seed);
+    st = nk_problem_jvp_dev(P, du, d_seed, d_B, nullptr);
+    if (st != NK_OK) break;
+    hipLaunchKernelGGL(k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, J->d_rowptr, d_nnzcolor, c, d_B,
+                       J->d_val);
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_color);
+  hipFree(d_nnzcolor);
+  hipFree(d_seed);
+  hipFree(d_B);
+  J->t_values_stale = true;
+  if (ncolors_out) *ncolors_out = ncolors;
+  return st;
+}

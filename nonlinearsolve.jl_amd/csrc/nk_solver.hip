@@ -1,0 +1,731 @@
+// Newton–Raphson / TrustRegion driver (seam 3): a host-side restatement of
+//   lib/NonlinearSolveFirstOrder/src/solve.jl:140-301 (init), :325-465 (step!), :108-133 (reinit!)
+//   lib/NonlinearSolveBase/src/solve.jl:360-387 (run to completion), :835-859 (step! bookkeeping)
+//   lib/NonlinearSolveBase/src/descent/newton.jl:97-141, dogleg.jl:86-151, steepest.jl:57-80
+//   lib/NonlinearSolveFirstOrder/src/trust_region.jl:204-258,292-317,320-384,396-514
+//   lib/NonlinearSolveFirstOrder/src/eisenstat_walker.jl:42-107
+//   lib/NonlinearSolveBase/src/termination_conditions.jl:243-336,414-453
+// All vectors stay in device memory; per nonlinear step the host reads back a handful of scalars.
+#include <math.h>
+#include <string.h>
+
+#include <chrono>
+
+#include "nk_internal.h"
+
+struct nk_solver {
+  nk_problem *P = nullptr;
+  nk_ctx *ctx = nullptr;
+  nk_options o{};
+  int64_t n = 0;
+  // vectors
+  double *u = nullptr, *fu = nullptr, *du = nullptr, *best_u = nullptr;
+  double *u_trial = nullptr, *fu_trial = nullptr, *du_newton = nullptr, *du_cauchy = nullptr, *Jdu = nullptr,
+         *JTfu = nullptr, *c1 = nullptr, *c2 = nullptr, *tr_du = nullptr, *stage = nullptr;
+  nk_gmres *G = nullptr;
+  nk_csr *J = nullptr;
+  bool own_J = false;
+  // driver state
+  int nsteps = 0, retcode = NK_RET_DEFAULT;
+  bool force_stop = false, make_new_jacobian = true;
+  nk_stats stats{};
+  double total_time = 0.0;
+  uint64_t u_version = 0, best_version = 0;
+  // termination cache
+  double abstol = 0, reltol = 0, best_obj = 0, initial_obj = 0, fnorm_inf = 0;
+  int tc_nsteps = 0, tc_retcode = NK_RET_DEFAULT;
+  std::vector<double> objectives_trace, step_norm_trace;
+  // forcing
+  double eta = 0, rnorm = 0, rnorm_prev = 0, lin_abstol = 0, lin_reltol = 0;
+  // trust region
+  double max_tr = 0, init_tr = 0, tr = 0, rho = 0, step_thr = 0, shrink_thr = 0, expand_thr = 0, shrink_f = 0,
+         expand_f = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+  int shrink_counter = 0;
+  bool last_accepted = false;
+  int last_gmres_iters = 0;
+  std::vector<nk_trace_entry> trace;
+};
+
+// u += du ; partial Σ (u_new − u_old)²  (the stall test's ‖u − uprev‖₂, termination_conditions.jl:311-316)
+__global__ __launch_bounds__(NK_BLOCK) void k_newton_update(int64_t n, const double *__restrict__ du,
+                                                            double *__restrict__ u, double *__restrict__ partials) {
+  __shared__ double sm[4];
+  double ss = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double uo = u[i], un = uo + du[i], d = un - uo;
+    u[i] = un;
+    ss += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_sum_partials(const double *__restrict__ partials, int nblk,
+                                                           double *__restrict__ out) {
+  __shared__ double sm[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) v += partials[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+extern "C" int nk_options_default(nk_options *o) {
+  NK_REQUIRE(o, "NULL argument");
+  memset(o, 0, sizeof(*o));
+  o->algorithm = NK_ALG_NEWTON_RAPHSON;
+  o->linsolve = NK_LINSOLVE_GMRES_MATFREE;
+  o->maxiters = 1000;
+  o->abstol = 0.0;
+  o->reltol = 0.0;
+  o->maxtime = 0.0;
+  o->gmres_restart = 30;
+  o->gmres_maxiters = 300;
+  o->gmres_ortho = NK_ORTHO_CGS2;
+  o->gmres_fixed_iters = 0;
+  o->lin_abstol = -1.0;
+  o->lin_reltol = -1.0;
+  o->forcing = NK_FORCING_NONE;
+  o->ew_safeguard = 1;
+  o->ew_eta0 = 0.5;
+  o->ew_eta_max = 0.9;
+  o->ew_gamma = 0.9;
+  o->ew_alpha = 2.0;
+  o->ew_safeguard_threshold = 0.1;
+  o->radius_update_scheme = NK_RUS_SIMPLE;
+  o->max_shrink_times = 32;
+  o->step_threshold = 1.0 / 10000;  // TrustRegion() constructor values (trust_region.jl:25-33)
+  o->shrink_threshold = 0.25;
+  o->expand_threshold = 0.75;
+  o->shrink_factor = 0.25;
+  o->expand_factor = 2.0;
+  o->patience_steps = 100;
+  o->max_stalled_steps = 32;
+  o->patience_objective_multiplier = 3.0;
+  o->min_max_factor = 1.3;
+  o->protective_threshold = 0.0;
+  o->store_trace = 0;
+  return NK_OK;
+}
+
+static const double DEFAULT_TOL = 3.0e-13;  // common_defaults.jl:44-48
+
+static bool is_tr(const nk_solver *S) { return S->o.algorithm == NK_ALG_TRUST_REGION; }
+static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE; }
+
+// ---- scalar helpers (device reductions → pinned host, one synchronisation)
+static int fetch(nk_solver *S, int count, double *out) { return nk_scalars_to_host(S->ctx, S->ctx->d_scal, count, out); }
+static double *slot(nk_solver *S, int i) { return S->ctx->d_scal + i; }
+
+static int apply_J(nk_solver *S, const double *v, double *out) {
+  if (concrete(S)) return nk_csr_spmv_dev(S->J, v, out, nullptr);
+  return nk_problem_jvp_dev(S->P, S->u, v, out, nullptr);
+}
+static int apply_JT(nk_solver *S, const double *u_at, const double *v, double *out) {
+  if (concrete(S) && u_at == S->u) return nk_csr_spmv_t_dev(S->J, v, out);
+  return nk_problem_vjp_dev(S->P, u_at, v, out);
+}
+
+// ---- trust-region defaults (trust_region.jl:320-384)
+static void tr_defaults(nk_solver *S) {
+  const int m = S->o.radius_update_scheme;
+  auto pick = [](double v, double d) { return v == 0.0 ? d : v; };
+  double d;
+  d = (m == NK_RUS_HEI) ? 0.0 : (m == NK_RUS_YUAN) ? 1e-3 : (m == NK_RUS_BASTIN) ? 0.05 : 1e-4;
+  S->step_thr = pick(S->o.step_threshold, d);
+  d = (m == NK_RUS_HEI) ? 0.0 : (m == NK_RUS_NLSOLVE || m == NK_RUS_BASTIN) ? 0.05 : 0.25;
+  S->shrink_thr = pick(S->o.shrink_threshold, d);
+  d = (m == NK_RUS_NLSOLVE || m == NK_RUS_BASTIN) ? 0.9 : (m == NK_RUS_HEI) ? 0.0 : 0.75;
+  S->expand_thr = pick(S->o.expand_threshold, d);
+  d = (m == NK_RUS_NLSOLVE) ? 0.5 : (m == NK_RUS_HEI) ? 0.0 : (m == NK_RUS_BASTIN) ? 0.05 : 0.25;
+  S->shrink_f = pick(S->o.shrink_factor, d);
+  S->expand_f = pick(S->o.expand_factor, 2.0);
+  S->p1 = S->p2 = S->p3 = S->p4 = 0.0;
+  switch (m) {
+    case NK_RUS_NLSOLVE: S->p1 = 0.5; break;
+    case NK_RUS_HEI: S->p1 = 5.0; S->p2 = 0.1; S->p3 = 0.15; S->p4 = 0.15; break;
+    case NK_RUS_YUAN: S->p1 = 2.0; S->p2 = 1.0 / 6; S->p3 = 6.0; break;
+    case NK_RUS_FAN: S->p1 = 0.1; S->p2 = 0.25; S->p3 = 12.0; S->p4 = 1e18; break;
+    case NK_RUS_BASTIN: S->p1 = 2.5; S->p2 = 0.25; break;
+    default: break;
+  }
+}
+static int tr_radii(nk_solver *S) {
+  const int m = S->o.radius_update_scheme;
+  nk_ctx *ctx = S->ctx;
+  NK_TRY(nk_blas_sumsq(ctx, S->n, S->u, slot(S, 0)));
+  NK_TRY(nk_blas_sumsq(ctx, S->n, S->fu, slot(S, 1)));
+  NK_TRY(nk_blas_minmax(ctx, S->n, S->u, slot(S, 2)));
+  double v[4];
+  NK_TRY(fetch(S, 4, v));
+  const double u0_norm = sqrt(v[0]), fu_norm = sqrt(v[1]), umax = v[2], umin = -v[3];
+  if (S->o.max_trust_radius != 0.0) S->max_tr = S->o.max_trust_radius;
+  else if (m == NK_RUS_SIMPLE || m == NK_RUS_NOCEDAL_WRIGHT) S->max_tr = fmax(fu_norm, umax - umin);
+  else S->max_tr = INFINITY;
+  if (S->o.initial_trust_radius != 0.0) S->init_tr = S->o.initial_trust_radius;
+  else if (m == NK_RUS_NLSOLVE) S->init_tr = u0_norm > 0 ? u0_norm : 1.0;
+  else if (m == NK_RUS_HEI || m == NK_RUS_BASTIN) S->init_tr = 1.0;
+  else if (m == NK_RUS_FAN) S->init_tr = pow(fu_norm, 0.99) / 10.0;
+  else S->init_tr = S->max_tr / 11.0;
+  if (m == NK_RUS_YUAN) {
+    NK_TRY(apply_JT(S, S->u, S->fu, S->JTfu));
+    NK_TRY(nk_blas_sumsq(ctx, S->n, S->JTfu, slot(S, 0)));
+    NK_TRY(fetch(S, 1, v));
+    S->init_tr = S->p1 * sqrt(v[0]);
+  }
+  return NK_OK;
+}
+
+// ---- termination cache (AbsNormSafeBest, termination_conditions.jl)
+static void tc_reinit(nk_solver *S, double fnorm_inf0) {
+  S->tc_retcode = NK_RET_DEFAULT;
+  S->tc_nsteps = 0;
+  S->initial_obj = fnorm_inf0;
+  S->best_obj = fnorm_inf0;
+  S->objectives_trace.assign(S->o.patience_steps > 0 ? S->o.patience_steps : 1, 0.0);
+  if (S->o.max_stalled_steps >= 0) S->step_norm_trace.assign(S->o.max_stalled_steps > 0 ? S->o.max_stalled_steps : 1, 0.0);
+  else S->step_norm_trace.clear();
+}
+// returns true when the solve must stop; step_norm = ‖u − uprev‖₂
+static int tc_check(nk_solver *S, double objective, double step_norm, bool *stop) {
+  *stop = false;
+  const double criteria = S->abstol;
+  if (!isfinite(objective)) { S->tc_retcode = NK_RET_UNSTABLE; *stop = true; return NK_OK; }
+  if (S->o.protective_threshold > 0.0 &&
+      objective > S->initial_obj * S->o.protective_threshold * (double)S->P->n_global) {
+    S->tc_retcode = NK_RET_UNSTABLE; *stop = true; return NK_OK;
+  }
+  if (objective < S->best_obj) {
+    S->best_obj = objective;
+    NK_TRY(nk_blas_copy(S->ctx, S->n, S->u, S->best_u));
+    S->best_version = S->u_version;
+  }
+  if (objective <= criteria) { S->tc_retcode = NK_RET_SUCCESS; *stop = true; return NK_OK; }
+  S->tc_nsteps += 1;
+  const int L = (int)S->objectives_trace.size();
+  S->objectives_trace[(S->tc_nsteps - 1) % L] = objective;
+  if (objective <= S->o.patience_objective_multiplier * criteria && S->tc_nsteps > S->o.patience_steps) {
+    const int cnt = S->tc_nsteps < L ? S->tc_nsteps : L;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < cnt; ++i) { mn = fmin(mn, S->objectives_trace[i]); mx = fmax(mx, S->objectives_trace[i]); }
+    if (mn < S->o.min_max_factor * mx) { S->tc_retcode = NK_RET_STALLED; *stop = true; return NK_OK; }
+  }
+  if (!S->step_norm_trace.empty()) {
+    const int L2 = (int)S->step_norm_trace.size();
+    S->step_norm_trace[(S->tc_nsteps - 1) % L2] = step_norm;
+    if (S->tc_nsteps > S->o.max_stalled_steps) {
+      double mx = -INFINITY;
+      for (double v : S->step_norm_trace) mx = fmax(mx, v);
+      if (mx <= S->abstol) { S->tc_retcode = NK_RET_STALLED; *stop = true; return NK_OK; }
+    }
+  }
+  S->tc_retcode = NK_RET_FAILURE;
+  return NK_OK;
+}
+// update_from_termination_cache! (termination_conditions.jl:440-453)
+static int rollback_to_best(nk_solver *S) {
+  if (S->best_version == S->u_version) return NK_OK;
+  NK_TRY(nk_blas_copy(S->ctx, S->n, S->best_u, S->u));
+  S->u_version++;
+  S->best_version = S->u_version;
+  NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
+  S->stats.nf++;
+  NK_TRY(nk_blas_norm_inf(S->ctx, S->n, S->fu, slot(S, 0)));
+  double v;
+  NK_TRY(fetch(S, 1, &v));
+  S->fnorm_inf = v;
+  return NK_OK;
+}
+
+// ---- init
+static int solver_start(nk_solver *S) {  // everything after u has been set
+  nk_ctx *ctx = S->ctx;
+  NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
+  S->stats = nk_stats{};
+  S->nsteps = 0;
+  S->retcode = NK_RET_DEFAULT;
+  S->force_stop = false;
+  S->make_new_jacobian = true;
+  S->total_time = 0.0;
+  S->trace.clear();
+  S->u_version++;
+  NK_TRY(nk_blas_copy(ctx, S->n, S->u, S->best_u));
+  S->best_version = S->u_version;
+  NK_TRY(nk_blas_norm_inf(ctx, S->n, S->fu, slot(S, 0)));
+  NK_TRY(nk_blas_sumsq(ctx, S->n, S->fu, slot(S, 1)));
+  double v[2];
+  NK_TRY(fetch(S, 2, v));
+  S->fnorm_inf = v[0];
+  tc_reinit(S, v[0]);
+  if (concrete(S)) {  // jacobian.jl:104-118 evaluates J once at init
+    NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
+    S->stats.njacs++;
+  }
+  NK_TRY(nk_blas_fill(ctx, S->n, 0.0, S->du));  // descent/newton.jl:34-36
+  S->eta = S->o.ew_eta0;
+  S->rnorm = S->rnorm_prev = sqrt(v[1]);
+  S->lin_abstol = S->o.lin_abstol >= 0.0 ? S->o.lin_abstol : S->abstol;  // FirstOrder/src/solve.jl:203
+  S->lin_reltol = S->o.lin_reltol >= 0.0 ? S->o.lin_reltol : S->reltol;
+  if (is_tr(S)) {
+    tr_defaults(S);
+    NK_TRY(tr_radii(S));
+    S->tr = S->init_tr;
+    S->rho = 0.0;
+    S->shrink_counter = 0;
+    S->last_accepted = false;
+  }
+  return NK_OK;
+}
+
+extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, const nk_options *opts, nk_solver **out) {
+  NK_REQUIRE(P && u0 && opts && out, "NULL argument");
+  nk_ctx *ctx = P->ctx;
+  NK_HIP(hipSetDevice(ctx->device));
+  NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION, "bad algorithm");
+  NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_MATFREE || opts->linsolve == NK_LINSOLVE_GMRES_CSR,
+             "linsolve %d not supported by this build", opts->linsolve);
+  NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->forcing != NK_FORCING_NONE),
+             "TrustRegion does not accept a forcing term (trust_region.jl:25-43)");
+  nk_solver *S = new nk_solver();
+  S->P = P;
+  S->ctx = ctx;
+  S->o = *opts;
+  if (S->o.maxiters <= 0) S->o.maxiters = 1000;
+  if (S->o.gmres_restart <= 0) S->o.gmres_restart = 30;
+  if (S->o.gmres_maxiters <= 0) S->o.gmres_maxiters = 300;
+  if (S->o.patience_steps <= 0) S->o.patience_steps = 100;
+  if (S->o.max_shrink_times <= 0) S->o.max_shrink_times = 32;
+  S->abstol = opts->abstol > 0.0 ? opts->abstol : DEFAULT_TOL;
+  S->reltol = opts->reltol > 0.0 ? opts->reltol : DEFAULT_TOL;
+  const int64_t n = S->n = P->n_local;
+  const size_t na = (size_t)n + 2;
+  NK_TRY(nk_dev_alloc(&S->u, na));
+  NK_TRY(nk_dev_alloc(&S->fu, na));
+  NK_TRY(nk_dev_alloc(&S->du, na));
+  NK_TRY(nk_dev_alloc(&S->best_u, na));
+  if (is_tr(S)) {
+    NK_TRY(nk_dev_alloc(&S->u_trial, na));
+    NK_TRY(nk_dev_alloc(&S->fu_trial, na));
+    NK_TRY(nk_dev_alloc(&S->du_newton, na));
+    NK_TRY(nk_dev_alloc(&S->du_cauchy, na));
+    NK_TRY(nk_dev_alloc(&S->Jdu, na));
+    NK_TRY(nk_dev_alloc(&S->JTfu, na));
+    NK_TRY(nk_dev_alloc(&S->c1, na));
+    NK_TRY(nk_dev_alloc(&S->c2, na));
+    NK_TRY(nk_dev_alloc(&S->tr_du, na));
+  }
+  if (concrete(S)) {
+    NK_TRY(nk_problem_jac_csr(P, &S->J));
+    S->own_J = (P->kind != NK_PROBLEM_USER);
+  }
+  NK_TRY(nk_gmres_create(ctx, n, S->o.gmres_restart, S->o.gmres_ortho, &S->G));
+  if (concrete(S)) NK_TRY(nk_gmres_set_operator_csr(S->G, S->J));
+  NK_HIP(hipMemcpyAsync(S->u, u0, n * sizeof(double),
+                        memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  int st = solver_start(S);
+  if (st != NK_OK) { nk_solver_destroy(S); return st; }
+  *out = S;
+  return NK_OK;
+}
+
+extern "C" int nk_solver_destroy(nk_solver *S) {
+  if (!S) return NK_OK;
+  hipStreamSynchronize(S->ctx->stream);
+  double *bufs[] = {S->u, S->fu, S->du, S->best_u, S->u_trial, S->fu_trial, S->du_newton, S->du_cauchy,
+                    S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage};
+  for (double *b : bufs) hipFree(b);
+  nk_gmres_destroy(S->G);
+  if (S->own_J) nk_csr_destroy(S->J);
+  delete S;
+  return NK_OK;
+}
+
+// ---- EisenstatWalkerForcing2 (eisenstat_walker.jl:42-89)
+static int pre_step_forcing(nk_solver *S, int iter) {
+  const nk_options &o = S->o;
+  if (iter == 0) {
+    S->eta = o.ew_eta0;
+    NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu, slot(S, 0)));
+    double v;
+    NK_TRY(fetch(S, 1, &v));
+    S->rnorm = S->rnorm_prev = sqrt(v);
+  } else {
+    const double eta_prev = S->eta;
+    S->eta = o.ew_gamma * pow(S->rnorm / S->rnorm_prev, o.ew_alpha);
+    if (o.ew_safeguard) {
+      const double eta_sg = o.ew_gamma * pow(eta_prev, o.ew_alpha);
+      if (eta_sg > o.ew_safeguard_threshold && eta_sg > S->eta) S->eta = eta_sg;
+    }
+    S->eta = fmin(fmax(S->eta, 0.0), o.ew_eta_max);
+  }
+  S->lin_reltol = S->eta;  // LinearSolve.update_tolerances!(lincache; reltol = η)
+  return NK_OK;
+}
+
+// ---- NewtonDescent.solve! : J δ = fu through GMRES, then δu = −δ  (newton.jl:121-138)
+static int newton_descent(nk_solver *S, double *du_out, bool *ok) {
+  S->stats.nsolve++;
+  nk_gmres_info info;
+  NK_TRY(nk_gmres_solve_dev(S->G, S->fu, du_out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
+                            S->o.gmres_fixed_iters, &info));
+  S->last_gmres_iters = info.iters;
+  S->stats.gmres_iters += info.iters;
+  *ok = !info.failed;
+  if (!*ok) return NK_OK;
+  return nk_blas_lincomb(S->ctx, S->n, -1.0, du_out, 0.0, du_out, du_out);
+}
+
+// ---- Dogleg.solve! (dogleg.jl:86-151). duJJdu = NaN ⇒ "not computed"
+static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out) {
+  nk_ctx *ctx = S->ctx;
+  const int64_t n = S->n;
+  *duJJdu_out = NAN;
+  NK_TRY(newton_descent(S, S->du_newton, ok));
+  if (!*ok) return NK_OK;
+  double v[4];
+  NK_TRY(nk_blas_sumsq(ctx, n, S->du_newton, slot(S, 0)));
+  NK_TRY(fetch(S, 1, v));
+  if (sqrt(v[0]) <= S->tr) return nk_blas_copy(ctx, n, S->du_newton, S->du);
+  // δu_cauchy = −Jᵀ fu (steepest.jl:75-77)
+  NK_TRY(apply_JT(S, S->u, S->fu, S->du_cauchy));
+  NK_TRY(nk_blas_lincomb(ctx, n, -1.0, S->du_cauchy, 0.0, S->du_cauchy, S->du_cauchy));
+  NK_TRY(apply_J(S, S->du_cauchy, S->Jdu));
+  NK_TRY(nk_blas_sumsq(ctx, n, S->du_cauchy, slot(S, 0)));
+  NK_TRY(nk_blas_sumsq(ctx, n, S->Jdu, slot(S, 1)));
+  NK_TRY(fetch(S, 2, v));
+  const double l_grad = sqrt(v[0]), dJJd = v[1];
+  const double d_cauchy = (l_grad * l_grad * l_grad) / dJJd;
+  if (d_cauchy >= S->tr) {
+    const double lam = S->tr / l_grad;
+    *duJJdu_out = lam * lam * dJJd;
+    return nk_blas_lincomb(ctx, n, lam, S->du_cauchy, 0.0, S->du_cauchy, S->du);
+  }
+  NK_TRY(nk_blas_lincomb(ctx, n, d_cauchy / l_grad, S->du_cauchy, 0.0, S->du_cauchy, S->c1));
+  NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->du_newton, -1.0, S->c1, S->c2));
+  NK_TRY(nk_blas_dot(ctx, n, S->c2, S->c2, slot(S, 0)));
+  NK_TRY(nk_blas_dot(ctx, n, S->c1, S->c2, slot(S, 1)));
+  NK_TRY(fetch(S, 2, v));
+  const double a = v[0], b = 2.0 * v[1], c = d_cauchy * d_cauchy - S->tr * S->tr;
+  const double aux = fmax(0.0, b * b - 4.0 * a * c);
+  const double tau = (-b + sqrt(aux)) / (2.0 * a);
+  return nk_blas_lincomb(ctx, n, 1.0, S->c1, tau, S->c2, S->du);
+}
+
+// ---- GenericTrustRegionSchemeCache solve! (trust_region.jl:396-514)
+static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
+  nk_ctx *ctx = S->ctx;
+  const int64_t n = S->n;
+  const int m = S->o.radius_update_scheme;
+  NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->u, 1.0, S->du, S->u_trial));
+  NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
+  S->stats.nf++;
+  const bool have = !isnan(duJJdu);
+  if (!have) {
+    NK_TRY(apply_J(S, S->du, S->Jdu));
+    NK_TRY(nk_blas_sumsq(ctx, n, S->Jdu, slot(S, 3)));
+  }
+  NK_TRY(apply_JT(S, S->u, S->fu, S->JTfu));
+  NK_TRY(nk_blas_sumsq(ctx, n, S->fu_trial, slot(S, 0)));
+  NK_TRY(nk_blas_sumsq(ctx, n, S->fu, slot(S, 1)));
+  NK_TRY(nk_blas_dot(ctx, n, S->du, S->JTfu, slot(S, 2)));
+  NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 4)));
+  NK_TRY(nk_blas_norm_inf(ctx, n, S->fu_trial, slot(S, 5)));
+  double v[6];
+  NK_TRY(fetch(S, 6, v));
+  if (!have) duJJdu = v[3];
+  const double fnew2 = v[0], f2 = v[1], nd = sqrt(v[4]);
+  const double num = (fnew2 - f2) / 2.0, denom = v[2] + duJJdu / 2.0;
+  S->rho = num / denom;
+  const double rho = S->rho;
+  S->last_accepted = rho > S->step_thr;
+  switch (m) {
+    case NK_RUS_SIMPLE:
+      if (rho < S->shrink_thr) { S->tr *= S->shrink_f; S->shrink_counter++; }
+      else {
+        S->shrink_counter = 0;
+        if (rho > S->expand_thr && rho > S->step_thr) S->tr = S->expand_f * S->tr;
+      }
+      break;
+    case NK_RUS_NLSOLVE:
+      if (rho < S->shrink_thr) { S->tr *= S->shrink_f; S->shrink_counter++; }
+      else {
+        S->shrink_counter = 0;
+        if (rho >= S->expand_thr) S->tr = S->expand_f * nd;
+        else if (rho >= S->p1) S->tr = fmax(S->tr, S->expand_f * nd);
+      }
+      break;
+    case NK_RUS_NOCEDAL_WRIGHT:
+      if (rho < S->shrink_thr) { S->tr = S->shrink_f * nd; S->shrink_counter++; }
+      else {
+        S->shrink_counter = 0;
+        if (rho > S->expand_thr && fabs(nd - S->tr) < 1e-6 * S->tr) S->tr = S->expand_f * S->tr;
+      }
+      break;
+    case NK_RUS_HEI: {
+      const double r = rho, c2 = S->shrink_thr, M = S->p1, g1 = S->p3, g2 = S->p4, beta = S->p2;
+      const double rf = (r >= c2) ? (2 * (M - 1 - g2) * atan(r - c2) + (1 + g2)) / M_PI
+                                  : (1 - g1 - beta) * (exp(r - c2) + beta / (1 - g1 - beta));
+      const double tr_new = rf * nd;
+      if (tr_new < S->tr) S->shrink_counter++;
+      else S->shrink_counter = 0;
+      S->tr = tr_new;
+      break;
+    }
+    case NK_RUS_YUAN: {
+      if (rho < S->shrink_thr) { S->p1 = S->p2 * S->p1; S->shrink_counter++; }
+      else {
+        if (rho >= S->expand_thr && 2 * nd > S->tr) S->p1 = S->p3 * S->p1;
+        S->shrink_counter = 0;
+      }
+      NK_TRY(apply_JT(S, S->u_trial, S->fu_trial, S->JTfu));
+      NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 0)));
+      double t;
+      NK_TRY(fetch(S, 1, &t));
+      S->tr = S->p1 * sqrt(t);
+      break;
+    }
+    case NK_RUS_FAN:
+      if (rho < S->shrink_thr) { S->p1 *= S->p2; S->shrink_counter++; }
+      else {
+        S->shrink_counter = 0;
+        if (rho > S->expand_thr) S->p1 = fmin(S->p1 * S->p3, S->p4);
+      }
+      S->tr = S->p1 * pow(sqrt(fnew2), 0.99);
+      break;
+    case NK_RUS_BASTIN:
+      if (rho > S->step_thr) {
+        // retrospective ratio with J at the trial point (trust_region.jl:490-504)
+        NK_TRY(nk_problem_jvp_dev(S->P, S->u_trial, S->tr_du, S->Jdu, nullptr));
+        NK_TRY(nk_problem_vjp_dev(S->P, S->u_trial, S->fu_trial, S->JTfu));
+        NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 0)));
+        NK_TRY(nk_problem_vjp_dev(S->P, S->u_trial, S->Jdu, S->JTfu));
+        NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 1)));
+        NK_TRY(nk_blas_sumsq(ctx, n, S->tr_du, slot(S, 2)));
+        double t[3];
+        NK_TRY(fetch(S, 3, t));
+        const double rho2 = num / (t[0] + t[1] / 2.0);
+        if (rho2 >= S->expand_thr) S->tr = S->p1 * sqrt(t[2]);
+        S->shrink_counter = 0;
+      } else {
+        S->tr *= S->p2;
+        S->shrink_counter++;
+      }
+      break;
+    default: NK_FAIL(NK_E_INVALID, "bad radius update scheme");
+  }
+  S->tr = fmin(S->tr, S->max_tr);
+  *accepted = S->last_accepted;
+  S->fnorm_inf = S->last_accepted ? v[5] : S->fnorm_inf;
+  return NK_OK;
+}
+
+// ---- InternalAPI.step! (FirstOrder/src/solve.jl:325-465)
+static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/) {
+  nk_ctx *ctx = S->ctx;
+  const int64_t n = S->n;
+  bool new_jacobian;
+  if ((recompute < 0 || recompute == 1) && S->make_new_jacobian) {
+    if (concrete(S)) {
+      NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
+      S->stats.njacs++;
+    } else {
+      NK_TRY(nk_gmres_set_operator_jvp(S->G, S->P, S->u, NK_DEVICE));  // StatefulJacobianOperator(J, u, p)
+    }
+    new_jacobian = true;
+  } else {
+    new_jacobian = false;
+  }
+  const bool has_forcing = S->o.forcing == NK_FORCING_EISENSTAT_WALKER2;
+  if (has_forcing) NK_TRY(pre_step_forcing(S, S->nsteps));
+
+  bool ok = true;
+  double duJJdu = NAN;
+  if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu));
+  else NK_TRY(newton_descent(S, S->du, &ok));
+  if (!ok) {
+    if (new_jacobian) {
+      S->retcode = NK_RET_INTERNAL_LINEAR_SOLVE_FAILED;
+      S->force_stop = true;
+      return NK_OK;
+    }
+    S->make_new_jacobian = true;
+    return internal_step(S, 1);
+  }
+  if (has_forcing) {  // post_step_forcing!: ‖fu‖ BEFORE u moves (one-step lag)
+    S->rnorm_prev = S->rnorm;
+    NK_TRY(nk_blas_sumsq(ctx, n, S->fu, slot(S, 0)));
+    double v;
+    NK_TRY(fetch(S, 1, &v));
+    S->rnorm = sqrt(v);
+  }
+  S->make_new_jacobian = true;
+  bool accepted = true;
+  double step_norm = 0.0, du_norm = NAN;
+  if (is_tr(S)) {
+    NK_TRY(nk_blas_copy(ctx, n, S->du, S->tr_du));
+    NK_TRY(tr_solve(S, duJJdu, &accepted));
+    if (accepted) {
+      // ‖u_new − u‖₂ for the stall test, then take the trial point
+      NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->u_trial, -1.0, S->u, S->c1));
+      NK_TRY(nk_blas_sumsq(ctx, n, S->c1, slot(S, 0)));
+      NK_TRY(nk_blas_copy(ctx, n, S->u_trial, S->u));
+      NK_TRY(nk_blas_copy(ctx, n, S->fu_trial, S->fu));
+      S->u_version++;
+      double v;
+      NK_TRY(fetch(S, 1, &v));
+      step_norm = sqrt(v);
+    } else {
+      S->make_new_jacobian = false;
+    }
+    if (S->shrink_counter > S->o.max_shrink_times) {
+      S->retcode = NK_RET_SHRINK_THRESHOLD_EXCEEDED;
+      S->force_stop = true;
+    }
+  } else {
+    const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+    {
+    nk_prof_scope prof_(ctx, NK_K_NEWTON_UPDATE, 24.0 * (double)n);
+    hipLaunchKernelGGL(k_newton_update, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, S->du, S->u, ctx->d_partials);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(NK_BLOCK), 0, ctx->stream, ctx->d_partials, grid, slot(S, 1));
+    }
+    NK_HIP(hipGetLastError());
+    NK_TRY(nk_comm_allreduce(ctx, slot(S, 1), 1, 0));
+    S->u_version++;
+    NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
+    S->stats.nf++;
+    NK_TRY(nk_blas_norm_inf(ctx, n, S->fu, slot(S, 0)));
+    int cnt = 2;
+    if (S->o.store_trace) { NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 2))); cnt = 3; }
+    double v[3];
+    NK_TRY(fetch(S, cnt, v));
+    S->fnorm_inf = v[0];
+    step_norm = sqrt(v[1]);
+    if (S->o.store_trace) du_norm = sqrt(v[2]);
+  }
+  bool stop = false;
+  NK_TRY(tc_check(S, S->fnorm_inf, step_norm, &stop));
+  if (stop) {
+    S->retcode = S->tc_retcode;
+    NK_TRY(rollback_to_best(S));
+    S->force_stop = true;
+  }
+  if (S->o.store_trace) {
+    nk_trace_entry e;
+    memset(&e, 0, sizeof(e));
+    e.iter = S->nsteps + 1;
+    e.gmres_iters = S->last_gmres_iters;
+    e.accepted = accepted ? 1 : 0;
+    e.fnorm_inf = S->fnorm_inf;
+    if (is_tr(S)) {
+      NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
+      double v;
+      NK_TRY(fetch(S, 1, &v));
+      du_norm = sqrt(v);
+    }
+    e.step_norm2 = du_norm;
+    e.eta = S->lin_reltol;
+    e.trust_region = is_tr(S) ? S->tr : NAN;
+    e.rho = is_tr(S) ? S->rho : NAN;
+    S->trace.push_back(e);
+  }
+  return NK_OK;
+}
+
+extern "C" int nk_solver_step(nk_solver *S) {  // CommonSolve.step! (Base/src/solve.jl:835-859)
+  NK_REQUIRE(S, "NULL argument");
+  NK_HIP(hipSetDevice(S->ctx->device));
+  if (S->force_stop || S->nsteps >= S->o.maxiters) return NK_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  NK_TRY(internal_step(S, -1));
+  S->stats.nsteps++;
+  S->nsteps++;
+  if (S->o.maxtime > 0.0) {
+    S->total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!S->force_stop && S->retcode == NK_RET_DEFAULT && S->total_time >= S->o.maxtime) {
+      S->retcode = NK_RET_MAXTIME;
+      S->force_stop = true;
+    }
+  }
+  return NK_OK;
+}
+
+extern "C" int nk_solver_solve(nk_solver *S, int *retcode) {  // _run_cache_to_completion!
+  NK_REQUIRE(S, "NULL argument");
+  while (!S->force_stop && S->nsteps < S->o.maxiters) NK_TRY(nk_solver_step(S));
+  if (S->retcode == NK_RET_DEFAULT) S->retcode = (S->nsteps >= S->o.maxiters) ? NK_RET_MAXITERS : NK_RET_SUCCESS;
+  NK_TRY(rollback_to_best(S));
+  NK_HIP(hipStreamSynchronize(S->ctx->stream));
+  if (retcode) *retcode = S->retcode;
+  return NK_OK;
+}
+
+extern "C" int nk_solver_reinit(nk_solver *S, const double *u0, int memspace, const double *params, int nparams) {
+  NK_REQUIRE(S, "NULL argument");
+  NK_HIP(hipSetDevice(S->ctx->device));
+  if (params) NK_TRY(nk_problem_set_params(S->P, params, nparams));
+  if (u0)
+    NK_HIP(hipMemcpyAsync(S->u, u0, S->n * sizeof(double),
+                          memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, S->ctx->stream));
+  return solver_start(S);
+}
+
+static int copy_out(nk_solver *S, const double *src, double *dst, int memspace) {
+  NK_HIP(hipMemcpyAsync(dst, src, S->n * sizeof(double),
+                        memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, S->ctx->stream));
+  NK_HIP(hipStreamSynchronize(S->ctx->stream));
+  return NK_OK;
+}
+extern "C" int nk_solver_get_u(nk_solver *S, double *u, int memspace) {
+  NK_REQUIRE(S && u, "NULL argument");
+  return copy_out(S, S->u, u, memspace);
+}
+extern "C" int nk_solver_get_resid(nk_solver *S, double *f, int memspace) {
+  NK_REQUIRE(S && f, "NULL argument");
+  return copy_out(S, S->fu, f, memspace);
+}
+extern "C" int nk_solver_get_stats(nk_solver *S, nk_stats *st) {
+  NK_REQUIRE(S && st, "NULL argument");
+  *st = S->stats;
+  st->op_applies = S->ctx->stats.op_applies;
+  st->allreduces = S->ctx->stats.allreduces;
+  st->halo_exchanges = S->ctx->stats.halo_exchanges;
+  return NK_OK;
+}
+extern "C" int nk_solver_get_retcode(nk_solver *S, int *retcode, int *nsteps, int *force_stop) {
+  NK_REQUIRE(S, "NULL argument");
+  if (retcode) *retcode = S->retcode;
+  if (nsteps) *nsteps = S->nsteps;
+  if (force_stop) *force_stop = S->force_stop ? 1 : 0;
+  return NK_OK;
+}
+extern "C" int nk_solver_get_scalars(nk_solver *S, double *fnorm_inf, double *trust_region, double *eta) {
+  NK_REQUIRE(S, "NULL argument");
+  if (fnorm_inf) *fnorm_inf = S->fnorm_inf;
+  if (trust_region) *trust_region = S->tr;
+  if (eta) *eta = S->eta;
+  return NK_OK;
+}
+extern "C" int nk_solver_get_trace(nk_solver *S, nk_trace_entry *rows, int capacity, int *nrows) {
+  NK_REQUIRE(S && nrows, "NULL argument");
+  *nrows = (int)S->trace.size();
+  if (rows)
+    for (int i = 0; i < capacity && i < *nrows; ++i) rows[i] = S->trace[i];
+  return NK_OK;
+}
+
+extern "C" int nk_newton_solve(nk_problem *P, const double *u0, int memspace, const nk_options *opts, double *u_out,
+                               double *resid_out, nk_stats *stats, int *retcode) {
+  nk_solver *S = nullptr;
+  NK_TRY(nk_solver_init(P, u0, memspace, opts, &S));
+  int st = nk_solver_solve(S, retcode);
+  if (st == NK_OK && u_out) st = nk_solver_get_u(S, u_out, memspace);
+  if (st == NK_OK && resid_out) st = nk_solver_get_resid(S, resid_out, memspace);
+  if (st == NK_OK && stats) st = nk_solver_get_stats(S, stats);
+  nk_solver_destroy(S);
+  return st;
+}

@@ -1,0 +1,248 @@
+"""GPU parity tests of GMRES / NewtonRaphson / TrustRegion against the oracle (through the C ABI).
+
+Stated tolerances:
+  GMRES vs oracle GMRES at equal (m, rtol): ‖x−x_ref‖₂ ≤ 10·rtol·‖x_ref‖₂
+  Newton/TR final u vs oracle:              ‖u−u_ref‖∞ ≤ 1e-8·max(1, ‖u_ref‖∞), both at ‖F‖∞ ≤ abstol
+  Newton step counts equal ±1 under the identical protocol."""
+import numpy as np
+import pytest
+
+from oracle import reference_restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+def uerr(u, uref):
+    return float(np.max(np.abs(np.asarray(u) - uref)) / max(1.0, np.max(np.abs(uref))))
+
+
+@pytest.mark.parametrize("ortho", ["mgs", "cgs2", "cgs"])
+@pytest.mark.parametrize("ns,rtol", [(16, 1e-10), (48, 1e-6)])
+def test_gmres_csr_vs_oracle(nls, ns, rtol, ortho):
+    p = R.Bratu2D(ns)
+    u = 0.2 * np.random.default_rng(0).standard_normal(p.n)
+    J = p.jac(u)
+    b = np.random.default_rng(1).standard_normal(p.n)
+    xref, iref = R.gmres(lambda z: J @ z, b, rtol=rtol, restart=30, itmax=5000)
+    G = nls.GMRES(p.n, restart=30, ortho=ortho).set_operator(nls.CSRMatrix.from_scipy(J))
+    x, info = G.solve(b, abstol=0.0, reltol=rtol, maxiters=5000)
+    assert info["converged"] and not info["failed"]
+    assert np.linalg.norm(x - xref) <= 10 * rtol * np.linalg.norm(xref)
+    assert np.linalg.norm(J @ x - b) <= 1.01 * rtol * np.linalg.norm(b) + 1e-12
+    assert abs(info["iters"] - iref.iters) <= max(3, iref.iters // 20)
+    assert abs(info["rnorm0"] - np.linalg.norm(b)) <= 1e-12 * np.linalg.norm(b)
+
+
+def test_gmres_first_cycle_matches_oracle_mgs(nls):
+    """With MGS the device Arnoldi process follows the oracle's arithmetic: recurrence residual after a
+    fixed number of steps agrees to rounding."""
+    p = R.Bratu2D(24)
+    J = p.jac(np.zeros(p.n))
+    b = np.random.default_rng(2).standard_normal(p.n)
+    for k in (1, 5, 30, 45):
+        xref, iref = R.gmres(lambda z: J @ z, b, restart=30, fixed_iters=k)
+        G = nls.GMRES(p.n, restart=30, ortho="mgs").set_operator(nls.CSRMatrix.from_scipy(J))
+        x, info = G.solve(b, fixed_iters=k)
+        assert info["iters"] == k == iref.iters
+        assert abs(info["rnorm"] - iref.rnorm) <= 1e-10 * iref.rnorm0
+        assert np.linalg.norm(x - xref) <= 1e-9 * np.linalg.norm(xref)
+
+
+def test_gmres_matrix_free_and_callable_operator(nls, dev):
+    import torch
+    ns = 32
+    p = R.Bratu2D(ns)
+    u = 0.1 * np.random.default_rng(3).standard_normal(p.n)
+    J = p.jac(u)
+    b = np.random.default_rng(4).standard_normal(p.n)
+    xref, _ = R.gmres(lambda z: J @ z, b, rtol=1e-9, itmax=3000)
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns))
+    op = nls.StatefulJacobianOperator(nls.JacobianOperator(prob), u)
+    G = nls.GMRES(p.n).set_operator(op)
+    x, info = G.solve(b, reltol=1e-9, maxiters=3000)
+    assert info["converged"] and np.linalg.norm(x - xref) <= 1e-7 * np.linalg.norm(xref)
+    # generic AbstractSciMLOperator-style callable on device tensors
+    Jd = torch.sparse_csr_tensor(torch.tensor(J.indptr, dtype=torch.int64), torch.tensor(J.indices, dtype=torch.int64),
+                                 torch.tensor(J.data), size=J.shape, device=dev)
+    G2 = nls.GMRES(p.n).set_operator(lambda z: Jd @ z)
+    x2, info2 = G2.solve(torch.tensor(b, device=dev), reltol=1e-9, maxiters=3000)
+    assert info2["converged"] and np.linalg.norm(x2.cpu().numpy() - xref) <= 1e-7 * np.linalg.norm(xref)
+
+
+def test_gmres_zero_rhs_and_warm_start(nls):
+    p = R.Bratu2D(8)
+    J = p.jac(np.zeros(p.n))
+    G = nls.GMRES(p.n).set_operator(nls.CSRMatrix.from_scipy(J))
+    x, info = G.solve(np.zeros(p.n))
+    assert info["converged"] and info["iters"] == 0 and np.all(x == 0)
+    b = np.ones(p.n)
+    xs, _ = G.solve(b, reltol=1e-12, maxiters=1000)
+    x2, info2 = G.solve(b, x0=xs, reltol=1e-6)
+    assert info2["iters"] == 0 and np.allclose(x2, xs)
+
+
+def test_gmres_nan_is_failure(nls):
+    p = R.Bratu2D(8)
+    J = p.jac(np.zeros(p.n))
+    G = nls.GMRES(p.n).set_operator(nls.CSRMatrix.from_scipy(J))
+    b = np.ones(p.n)
+    b[3] = np.nan
+    _, info = G.solve(b)
+    assert info["failed"]
+
+
+# ------------------------------------------------------------------ Newton–Raphson
+def test_quadratic_newton_gmres(nls):
+    """common/common_rootfind_testing.jl: quadratic_f, u0 = ones, p = 2 ⇒ sqrt(2), err < 1e-9."""
+    prob = nls.NonlinearProblem(nls.Quadratic(1000, 2.0))
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), abstol=1e-9)
+    assert sol.successful_retcode
+    assert np.max(np.abs(sol.u - np.sqrt(2.0))) < 1e-9
+    assert np.max(np.abs(sol.resid)) < 1e-9
+    ref = R.solve(R.Quadratic(1000), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES()), abstol=1e-9)
+    assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf
+
+
+@pytest.mark.parametrize("concrete", [False, True])
+@pytest.mark.parametrize("ortho", ["mgs", "cgs2"])
+def test_bratu_newton_ew_vs_oracle(nls, concrete, ortho):
+    ns = 48
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(ortho=ortho), forcing=nls.EisenstatWalkerForcing2(),
+                            concrete_jac=concrete)
+    sol = nls.solve(prob, alg, abstol=1e-8, maxiters=50, store_trace=True)
+    ref = R.solve(R.Bratu2D(ns), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2(),
+                                                 concrete_jac=concrete), abstol=1e-8, maxiters=50)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert np.max(np.abs(sol.resid)) <= 1e-8
+    assert uerr(sol.u, ref.u) <= 1e-8 * 50  # both are only converged to ‖F‖∞ ≤ 1e-8 with loose inner solves
+    assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
+    # forcing sequence (with the reference's one-step lag) matches the oracle's at the first steps
+    assert sol.trace[0]["eta"] == 0.5 and sol.trace[1]["eta"] == 0.9
+    assert abs(sol.trace[2]["eta"] - ref.trace[2]["eta"]) <= 1e-6
+
+
+def test_bratu_newton_tight_inner_matches_direct(nls):
+    """With near-exact linear solves Newton–Krylov reproduces Newton + sparse direct solve to 1e-8."""
+    ns = 32
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(maxiters=5000, reltol=1e-12, abstol=0.0))
+    sol = nls.solve(prob, alg, abstol=1e-10, maxiters=50)
+    ref = R.solve(R.Bratu2D(ns), R.NewtonRaphson(), abstol=1e-10, maxiters=50)
+    assert sol.retcode == "Success"
+    assert uerr(sol.u, ref.u) <= 1e-8
+    assert sol.stats.nsteps == ref.stats.nsteps
+
+
+def test_iterator_interface_and_reinit(nls):
+    """nlprob_iterator_interface (common_rootfind_testing.jl:47-57): reinit!(cache, u; p) + solve! ≈ sqrt.(p)."""
+    prob = nls.NonlinearProblem(nls.Quadratic(4, 1.0), u0=np.full(4, 0.5))
+    cache = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), maxiters=100, abstol=1e-10)
+    for p in np.linspace(1.0, 10.0, 12):
+        nls.reinit_(cache, cache.u, p=float(p))
+        sol = nls.solve_(cache)
+        assert sol.retcode == "Success"
+        assert np.allclose(sol.u, np.sqrt(p), atol=1e-9)
+    cache.close()
+
+
+def test_step_by_step(nls):
+    prob = nls.NonlinearProblem(nls.Quadratic(10, 2.0))
+    cache = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), abstol=1e-9)
+    oc = R.init(R.Quadratic(10), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES()), abstol=1e-9)
+    for _ in range(3):
+        nls.step_(cache)
+        oc.step()
+        assert np.allclose(cache.u, oc.u, rtol=1e-12)
+        assert cache.nsteps == oc.nsteps
+    cache.close()
+
+
+def test_maxiters_retcode(nls):
+    prob = nls.NonlinearProblem(nls.Bratu2D(32))
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=2)), abstol=1e-12, maxiters=3)
+    assert sol.retcode == "MaxIters" and sol.stats.nsteps == 3 and sol.stats.gmres_iters == 6
+
+
+def test_user_function_custom_jvp(nls, dev):
+    """rootfind_tests__item20.jl: F(u) = u + 0.1 u .* (Δ u) − p with an analytic JVP, N = 100, GMRES."""
+    import torch
+    N = 100
+    rng = np.random.default_rng(20)
+    u0 = rng.random(N)
+    D = (torch.diag(2 * torch.ones(N)) - torch.diag(torch.ones(N - 1), 1) - torch.diag(torch.ones(N - 1), -1)).to(
+        dev, torch.float64)
+    pvec = torch.tensor(u0, device=dev)
+
+    def F(du, u, p):
+        du.copy_(u + 0.1 * u * (D @ u) - p)
+
+    def JVP(out, v, u, p):
+        out.copy_(v + 0.1 * (u * (D @ v) + v * (D @ u)))
+
+    def VJP(out, v, u, p):
+        out.copy_(v + 0.1 * (D @ (u * v) + v * (D @ u)))
+
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(F, jvp=JVP, vjp=VJP), torch.tensor(u0, device=dev), pvec)
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), abstol=1e-13)
+    assert float(sol.resid.abs().max()) < 1e-6
+    sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES()), abstol=1e-13)
+    assert float(sol.resid.abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------ TrustRegion
+@pytest.mark.parametrize("scheme", list(range(7)))
+def test_trust_region_quadratic_all_schemes(nls, scheme):
+    """rootfind_tests__item8.jl: TrustRegion × radius update schemes × GMRES on quadratic_f (abstol 1e-6…1e-9)."""
+    prob = nls.NonlinearProblem(nls.Quadratic(12, 2.0))
+    sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(), radius_update_scheme=scheme), abstol=1e-9)
+    assert sol.retcode == "Success"
+    assert np.max(np.abs(sol.resid)) < 1e-9
+    ref = R.solve(R.Quadratic(12), R.TrustRegion(linsolve=R.KrylovJL_GMRES(), radius_update_scheme=scheme), abstol=1e-9)
+    assert sol.stats.nsteps == ref.stats.nsteps
+    assert uerr(sol.u, ref.u) <= 1e-9
+
+
+@pytest.mark.parametrize("concrete", [False, True])
+def test_trust_region_brusselator_vs_oracle(nls, concrete):
+    """Brusselator N = 32 (sparsity_tests__item1.jl), TrustRegion + GMRES, ‖resid‖∞ < 1e-8."""
+    N = 32
+    lin = dict(gmres_restart=30, maxiters=4000, reltol=1e-10, abstol=0.0)
+    prob = nls.NonlinearProblem(nls.Brusselator2D(N))
+    sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(**lin), concrete_jac=concrete), abstol=1e-8,
+                    store_trace=True)
+    rb = R.Brusselator2D(N)
+    ref = R.solve(rb, R.TrustRegion(), abstol=1e-8)
+    assert sol.retcode == "Success"
+    assert np.max(np.abs(sol.resid)) < 1e-8
+    assert uerr(sol.u, ref.u) <= 1e-8
+    assert sol.stats.nsteps == ref.stats.nsteps
+    for a, b in zip(sol.trace, ref.trace):
+        assert a["accepted"] == b["accepted"]
+        assert abs(a["trust_region"] - b["trust_region"]) <= 1e-6 * b["trust_region"]
+
+
+def test_trust_region_maxiters_sweep_matches_oracle(nls):
+    """rootfind_tests__item12.jl: TR iterates agree at maxiters ∈ {2,3,4,5} (here: device vs oracle)."""
+    for mi in (2, 3, 4, 5):
+        prob = nls.NonlinearProblem(nls.Quadratic(6, 2.0), u0=np.full(6, 3.0))
+        sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES()), maxiters=mi, abstol=1e-14)
+        ref = R.solve(R.Quadratic(6), R.TrustRegion(linsolve=R.KrylovJL_GMRES()), maxiters=mi, abstol=1e-14,
+                      u0=np.full(6, 3.0))
+        assert np.allclose(sol.u, ref.u, rtol=1e-10)
+
+
+def test_jacobian_operators(nls):
+    """core_tests__item2.jl: sop*v ≈ J v, sop'*v ≈ Jᵀ v, (sop'*sop)*v ≈ JᵀJ v (atol 1e-5) — Brusselator J."""
+    N = 8
+    b = R.Brusselator2D(N)
+    prob = nls.NonlinearProblem(nls.Brusselator2D(N))
+    jac_op = nls.JacobianOperator(prob)
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        u, v = b.u0() + rng.random(b.n), rng.random(b.n)
+        J = b.jac(u).toarray()
+        sop = nls.StatefulJacobianOperator(jac_op, u)
+        assert np.allclose(sop @ v, J @ v, atol=1e-5)
+        assert np.allclose(sop.T @ v, J.T @ v, atol=1e-5)
+        assert np.allclose((sop.T @ sop) @ v, J.T @ (J @ v), atol=1e-5, rtol=1e-10)
