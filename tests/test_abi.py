@@ -1,0 +1,111 @@
+"""CPU tests of the C-ABI boundary: the shared library loads, exports every symbol include/mi355x_nk.h declares,
+its host-only logic works without a GPU, and it fails loudly (no CPU fallback) when no HIP device exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi355x_nk.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nk_[a-z0-9_]+)\s*\(", src)) - {"nk_residual_fn", "nk_jvp_fn", "nk_vjp_fn",
+                                                                       "nk_jacvals_fn", "nk_matvec_fn"})
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nonlinearsolve_jl_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    names = _declared_functions()
+    assert len(names) >= 55
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/mi355x_nk.h but not exported: {missing}"
+
+
+def test_ctypes_table_covers_header(lib):
+    from nonlinearsolve_jl_amd import _lib
+    assert set(_declared_functions()) == set(_lib.SIGNATURES), set(_declared_functions()) ^ set(_lib.SIGNATURES)
+
+
+def test_struct_layouts_match_header():
+    """sizeof of the ctypes mirrors equals what a C compiler computes for the header's structs."""
+    import subprocess
+    import tempfile
+    from nonlinearsolve_jl_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include "mi355x_nk.h"
+int main(void){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(nk_options), sizeof(nk_stats), sizeof(nk_gmres_info),
+  sizeof(nk_trace_entry), sizeof(nk_user_callbacks), sizeof(nk_comm_callbacks)); return 0;}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    assert sizes == [C.sizeof(_lib.Options), C.sizeof(_lib.Stats), C.sizeof(_lib.GmresInfo), C.sizeof(_lib.TraceEntry),
+                     C.sizeof(_lib.UserCallbacks), C.sizeof(_lib.CommCallbacks)]
+
+
+def test_version_and_options_default(lib):
+    from nonlinearsolve_jl_amd import _lib
+    assert lib.nk_version().decode().startswith("mi355x_nk")
+    o = _lib.Options()
+    assert lib.nk_options_default(C.byref(o)) == 0
+    assert o.maxiters == 1000 and o.gmres_restart == 30 and o.gmres_maxiters == 300
+    assert (o.ew_eta0, o.ew_eta_max, o.ew_gamma, o.ew_alpha, o.ew_safeguard_threshold) == (0.5, 0.9, 0.9, 2.0, 0.1)
+    assert (o.step_threshold, o.shrink_threshold, o.expand_threshold, o.shrink_factor, o.expand_factor) == \
+        (1e-4, 0.25, 0.75, 0.25, 2.0)
+    assert o.max_shrink_times == 32 and o.patience_steps == 100 and o.max_stalled_steps == 32
+
+
+@pytest.mark.parametrize("n,g,P", [(1024, 1, 8), (1000, 1, 3), (4096 * 4096, 4096, 8), (10, 1, 10), (7, 1, 2)])
+def test_partition_range_host_logic(lib, n, g, P):
+    import nonlinearsolve_jl_amd as nls
+    ranges = [nls.partition_range(n, g, P, r) for r in range(P)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n
+    for (b0, e0), (b1, e1) in zip(ranges[:-1], ranges[1:]):
+        assert e0 == b1 and b0 <= e0
+    assert all(b % g == 0 and e % g == 0 for b, e in ranges)
+    sizes = [e - b for b, e in ranges]
+    assert max(sizes) - min(sizes) <= g
+
+
+def test_partition_range_errors(lib):
+    import nonlinearsolve_jl_amd as nls
+    with pytest.raises(nls.NKError):
+        nls.partition_range(10, 3, 2, 0)      # n not a multiple of the granule
+    with pytest.raises(nls.NKError):
+        nls.partition_range(10, 1, 2, 2)      # rank out of range
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """On a box without a HIP device every compute entry point is unreachable: context creation fails loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import nonlinearsolve_jl_amd as nls
+    with pytest.raises(nls.NKError, match="no HIP device|no CPU fallback|hip"):
+        nls.Context(device=0)
+    with pytest.raises(nls.NKError):
+        nls.Bratu2D(16)
+
+
+def test_product_never_imports_oracle():
+    """The product package and bench/entry 'value' path must not route through oracle/ (only the checker legs may)."""
+    pkg = os.path.join(ROOT, "nonlinearsolve.jl_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "nk_oracle" not in txt, f

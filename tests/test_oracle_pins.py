@@ -1,0 +1,263 @@
+"""CPU tests that pin the oracle (oracle/) — the checker every GPU parity test relies on.
+
+The reference is Julia (not installed) and holds no golden vectors; its own tests are outcome/tolerance tests.
+Each test below restates one of those known-answer tests for the path against the oracle, or
+cross-checks the oracle against SciPy as an independent second opinion."""
+import numpy as np
+import pytest
+import scipy.optimize
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import c_oracle as CO
+from oracle import reference_restatement as R
+
+GM = R.KrylovJL_GMRES
+
+
+# ---- common/common_rootfind_testing.jl:15-17,37-45 + rootfind_tests__item2.jl: quadratic_f → sqrt(p), err < 1e-9
+@pytest.mark.parametrize("alg", [R.NewtonRaphson(), R.NewtonRaphson(linsolve=GM()), R.TrustRegion(),
+                                 R.TrustRegion(linsolve=GM())])
+@pytest.mark.parametrize("n", [1, 2, 1000])
+def test_quadratic_known_answer(alg, n):
+    sol = R.solve(R.Quadratic(n, 2.0), alg, abstol=1e-9)
+    assert sol.retcode == R.SUCCESS
+    assert np.max(np.abs(sol.u - np.sqrt(2.0))) < 1e-9
+    assert np.max(np.abs(sol.resid)) < 1e-9
+
+
+# ---- config C1 (BASELINE.json configs[0]): u0 = ones(1000), dense J, default tolerance 3e-13
+def test_config_c1_default_tolerance():
+    sol = R.solve(R.Quadratic(1000, 2.0), R.NewtonRaphson())
+    assert sol.retcode == R.SUCCESS and sol.stats.nsteps <= 7
+    assert np.max(np.abs(sol.resid)) <= 3.0e-13
+
+
+# ---- rootfind_tests__item3.jl:4-6 — iterator interface over a parameter sweep ≈ sqrt.(p)
+def test_iterator_interface_parameter_sweep():
+    prob = R.Quadratic(1, 1.0)
+    cache = R.init(prob, R.NewtonRaphson(), abstol=1e-10, maxiters=100, u0=np.array([0.5]))
+    ps = np.linspace(1.0, 10.0, 200)
+    out = []
+    for p in ps:
+        cache.reinit(cache.u, p=p)
+        out.append(cache.solve().u[0])
+    assert np.allclose(out, np.sqrt(ps), atol=1e-9)
+
+
+# ---- operator_jacobian.jl:11-29 — linear residual W z − b, N = 40 tridiagonal, sol.u ≈ W \ b for GMRES and LU
+@pytest.mark.parametrize("lin", [GM(), None])
+def test_tridiagonal_linear_problem(lin):
+    N = 40
+    W = sp.diags([-np.ones(N - 1), 4.0 * np.ones(N), -np.ones(N - 1)], [-1, 0, 1], format="csr")
+    b = np.arange(1.0, N + 1)
+    prob = R.FunctionProblem(lambda z: W @ z - b, np.zeros(N), jac=lambda z: W, jvp=lambda v, z: W @ v)
+    sol = R.solve(prob, R.NewtonRaphson(linsolve=lin))
+    assert sol.retcode == R.SUCCESS
+    assert np.allclose(sol.u, spla.spsolve(W.tocsc(), b), rtol=1e-8)
+
+
+# ---- rootfind_tests__item20.jl — custom analytic JVP, N = 100, NR and TR with GMRES, max|resid| < 1e-6
+@pytest.mark.parametrize("alg", [R.NewtonRaphson(linsolve=GM()), R.TrustRegion(linsolve=GM())])
+def test_custom_jvp_problem(alg):
+    N = 100
+    D = sp.diags([-np.ones(N - 1), 2.0 * np.ones(N), -np.ones(N - 1)], [-1, 0, 1], format="csr")
+    u0 = np.random.default_rng(20).random(N)
+    prob = R.FunctionProblem(lambda u: u + 0.1 * u * (D @ u) - u0, u0,
+                             jvp=lambda v, u: v + 0.1 * (u * (D @ v) + v * (D @ u)),
+                             vjp=lambda v, u: v + 0.1 * (D @ (u * v) + v * (D @ u)))
+    sol = R.solve(prob, alg, abstol=1e-13)
+    assert np.max(np.abs(sol.resid)) < 1e-6
+
+
+# ---- sparsity_tests__item1.jl:7-55 — Brusselator N = 32, p = (3.4, 1, 10, 1/31), ‖resid‖∞ < 1e-8
+@pytest.mark.parametrize("alg", [R.NewtonRaphson(), R.TrustRegion()])
+def test_brusselator_n32(alg):
+    b = R.Brusselator2D(32)
+    sol = R.solve(b, alg, abstol=1e-8)
+    assert sol.retcode == R.SUCCESS
+    assert np.max(np.abs(sol.resid)) < 1e-8
+    # SciPy second opinion from the same u0 (hybr on the dense-ish system is too slow; Krylov root finder)
+    chk = scipy.optimize.root(b.f, b.u0(), method="krylov", options=dict(fatol=1e-9, maxiter=200))
+    assert np.max(np.abs(b.f(chk.x))) < 1e-6
+    assert np.max(np.abs(chk.x - sol.u)) < 1e-6
+
+
+def test_brusselator_kernel_matches_literal_loop():
+    """The vectorised restatement equals a literal transcription of brusselator_2d_loop (1-based → 0-based)."""
+    N, A, B, alpha = 7, 3.4, 1.0, 10.0
+    dx = 1.0 / (N - 1)
+    b = R.Brusselator2D(N)
+    u = np.random.default_rng(0).random(2 * N * N)
+    U = u.reshape(2, N, N).transpose(2, 1, 0)  # U[i, j, k]
+    du = np.zeros_like(U)
+    al = alpha / dx ** 2
+    xyd = np.linspace(0, 1, N)
+    lim = lambda a: 0 if a == N else (N - 1 if a == -1 else a)
+    for i in range(N):
+        for j in range(N):
+            x, y = xyd[i], xyd[j]
+            ip1, im1, jp1, jm1 = lim(i + 1), lim(i - 1), lim(j + 1), lim(j - 1)
+            bf = 5.0 if ((x - 0.3) ** 2 + (y - 0.6) ** 2) <= 0.1 ** 2 else 0.0
+            du[i, j, 0] = al * (U[im1, j, 0] + U[ip1, j, 0] + U[i, jp1, 0] + U[i, jm1, 0] - 4 * U[i, j, 0]) + B + \
+                U[i, j, 0] ** 2 * U[i, j, 1] - (A + 1) * U[i, j, 0] + bf
+            du[i, j, 1] = al * (U[im1, j, 1] + U[ip1, j, 1] + U[i, jp1, 1] + U[i, jm1, 1] - 4 * U[i, j, 1]) + \
+                A * U[i, j, 0] - U[i, j, 0] ** 2 * U[i, j, 1]
+    ref = du.transpose(2, 1, 0).ravel()
+    assert np.allclose(b.f(u), ref, rtol=1e-13, atol=1e-10)
+    assert np.allclose(CO.brusselator_residual(N, A, B, alpha, dx, u), ref, rtol=1e-13, atol=1e-10)
+
+
+# ---- lib/SciMLJacobianOperators/test/core_tests__item2.jl:30-59 — JVP / VJP / JᵀJ v vs analytic (atol 1e-5)
+def test_jacobian_operator_analytic():
+    f = lambda u: u ** 2 - 2.0 + u[1] * u[0]
+    jac = lambda u: np.array([[2 * u[0] + u[1], u[0]], [u[1], 2 * u[1] + u[0]]])
+    prob = R.FunctionProblem(f, np.array([1.0, 3.0]), jac=jac)
+    op = R.JacobianOperator(prob)
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        u, v = rng.random(2), rng.random(2)
+        sop = R.StatefulJacobianOperator(op, u)
+        assert np.allclose(sop @ v, jac(u) @ v, atol=1e-5)
+        assert np.allclose(sop.T @ v, jac(u).T @ v, atol=1e-5)
+        assert np.allclose((sop.T @ sop) @ v, jac(u).T @ jac(u) @ v, atol=1e-5)
+
+
+# ---- rootfind_tests__item10.jl — newton_fails (7 unknowns) converges with TrustRegion
+def test_newton_fails_converges_with_trust_region():
+    def newton_fails(u, p=0.0):
+        return 0.010000000000000002 + 10.000000000000002 / (1 + (0.21640425613334457 + 216.40425613334457 / (
+            1 + (0.21640425613334457 + 216.40425613334457 / (1 + 0.0006250000000000001 * (u ** 2.0))) ** 2.0)) ** 2.0) \
+            - 0.0011552453009332421 * u - p
+    u0 = np.array([-10.0, -1.0, 1.0, 2.0, 3.0, 4.0, 10.0])
+    prob = R.FunctionProblem(lambda u: newton_fails(u, np.zeros(7)), u0,
+                             jac=lambda u: sp.diags((newton_fails(u + 1e-7) - newton_fails(u - 1e-7)) / 2e-7))
+    sol = R.solve(prob, R.TrustRegion(), abstol=1e-9)
+    assert np.max(np.abs(sol.resid)) < 1e-9
+
+
+# ---- misc_tests__item3.jl:9-26 — TrustRegion radius after reinit!: back to the initial radius, counters reset
+def test_trust_region_reinit_resets_radius():
+    prob = R.Quadratic(3, 2.0)
+    c = R.init(prob, R.TrustRegion(initial_trust_radius=5.0), abstol=1e-9, u0=np.array([1.0, 2.0, 3.0]))
+    assert c.trust_region == 5.0
+    c.step(); c.step()
+    assert c.trust_region != 5.0
+    c.reinit(np.array([1.0, 2.0, 3.0]))
+    assert c.trust_region == 5.0 and c.shrink_counter == 0 and c.nsteps == 0
+    c2 = R.init(prob, R.TrustRegion(), u0=np.array([1.0, 2.0, 3.0]))
+    fu = prob.f(np.array([1.0, 2.0, 3.0]))
+    assert np.isclose(c2.max_trust_radius, max(np.linalg.norm(fu), 2.0))
+    assert np.isclose(c2.trust_region, c2.max_trust_radius / 11)
+
+
+# ---- misc_tests__item8.jl:23-37 — residual evaluations are counted once per step
+def test_residual_evaluation_count():
+    calls = [0]
+    def f(u):
+        calls[0] += 1
+        return u * u - 2.0
+    prob = R.FunctionProblem(f, np.ones(3), jac=lambda u: sp.diags(2 * u))
+    c = R.init(prob, R.NewtonRaphson(), abstol=1e-10)
+    base = calls[0]
+    for k in range(1, 4):
+        c.step()
+        assert calls[0] - base == k == c.stats.nf
+
+
+# ---- eisenstat_walker.jl:42-89 — the one-step lag: η₀ = 0.5, then exactly γ·1² = 0.9 at step 1
+def test_eisenstat_walker_lag():
+    s = R.solve(R.Bratu2D(24), R.NewtonRaphson(linsolve=GM(), forcing=R.EisenstatWalkerForcing2()), abstol=1e-8,
+                maxiters=50)
+    etas = [t["eta"] for t in s.trace]
+    assert etas[0] == 0.5 and etas[1] == 0.9
+    assert all(0.0 <= e <= 0.9 for e in etas)
+    f0 = np.linalg.norm(R.Bratu2D(24).f(np.zeros(24 * 24)))
+    # step 2 uses ‖f1‖/‖f0‖ (not ‖f2‖/‖f1‖): recompute it from the trace's first step
+    c = R.init(R.Bratu2D(24), R.NewtonRaphson(linsolve=GM(), forcing=R.EisenstatWalkerForcing2()), abstol=1e-8)
+    c.step()
+    f1 = np.linalg.norm(c.fu)
+    c.step(); c.step()
+    expected = min(max(max(0.9 * (f1 / f0) ** 2, 0.9 * 0.9 ** 2), 0.0), 0.9)
+    assert np.isclose(c.trace[2]["eta"], expected)
+
+
+# ---- termination_conditions.jl — retcodes of the safe-best mode
+def test_termination_retcodes():
+    assert R.solve(R.Bratu2D(16), R.NewtonRaphson(linsolve=GM(fixed_iters=1)), abstol=1e-12, maxiters=3).retcode == R.MAXITERS
+    # the first Newton step lands at u = 50.5 where the residual is NaN ⇒ protective break ⇒ Unstable
+    nanprob = R.FunctionProblem(lambda u: np.where(u > 5.0, np.nan, u * u - 100.0), np.ones(2),
+                                jac=lambda u: sp.diags(2.0 * u))
+    assert R.solve(nanprob, R.NewtonRaphson()).retcode == R.UNSTABLE
+    # best-iterate rollback: the returned u is the iterate with the smallest ‖f‖∞ seen
+    prob = R.Bratu2D(16)
+    s = R.solve(prob, R.NewtonRaphson(linsolve=GM(fixed_iters=3)), abstol=1e-14, maxiters=8)
+    assert np.isclose(np.max(np.abs(prob.f(s.u))), min(t["fnorm_inf"] for t in s.trace))
+
+
+# ---- GMRES restatement vs SciPy's GMRES and a direct solve
+@pytest.mark.parametrize("ns", [12, 40])
+def test_gmres_vs_scipy(ns):
+    p = R.Bratu2D(ns)
+    J = p.jac(0.2 * np.random.default_rng(0).standard_normal(p.n))
+    b = np.random.default_rng(1).standard_normal(p.n)
+    x, info = R.gmres(lambda z: J @ z, b, rtol=1e-10, restart=30, itmax=20000)
+    assert info.converged
+    xd = spla.spsolve(J.tocsc(), b)
+    assert np.linalg.norm(x - xd) <= 1e-7 * np.linalg.norm(xd)
+    xs, code = spla.gmres(J, b, rtol=1e-10, restart=30, maxiter=20000)
+    assert code == 0 and np.linalg.norm(x - xs) <= 1e-7 * np.linalg.norm(xs)
+    # the recurrence residual is the true residual (to rounding)
+    assert abs(np.linalg.norm(b - J @ x) - info.rnorm) <= 1e-8 * info.rnorm0
+    # CGS2 variant converges to the same solution
+    x2, info2 = R.gmres(lambda z: J @ z, b, rtol=1e-10, restart=30, itmax=20000, ortho="cgs2")
+    assert info2.converged and np.linalg.norm(x2 - xd) <= 1e-7 * np.linalg.norm(xd)
+
+
+# ---- the C/OpenMP restatement equals the NumPy restatement
+def test_c_oracle_matches_numpy_oracle():
+    ns = 40
+    p = R.Bratu2D(ns)
+    rng = np.random.default_rng(0)
+    u, v = 0.1 * rng.standard_normal(p.n), rng.standard_normal(p.n)
+    assert np.allclose(CO.bratu_residual(ns, 6.0, 0.0, u), p.f(u), rtol=1e-14, atol=1e-15)
+    assert np.allclose(CO.bratu_jvp(ns, 6.0, 0.0, u, v), p.jvp(v, u), rtol=1e-14, atol=1e-13)
+    rp, ci = CO.bratu_pattern(ns)
+    J = p.jac(u)
+    assert np.array_equal(rp, J.indptr) and np.array_equal(ci, J.indices)
+    val = CO.bratu_jac_values(ns, 6.0, 0.0, u, rp)
+    assert np.allclose(val, J.data, rtol=1e-15)
+    assert np.allclose(CO.spmv(rp, ci, val, v), J @ v, rtol=1e-14, atol=1e-12)
+    assert np.allclose(CO.spmv_t(rp, ci, val, v, p.n), J.T @ v, rtol=1e-14, atol=1e-12)
+    x, info = CO.gmres_csr(rp, ci, val, v, rtol=1e-8, itmax=5000)
+    x2, info2 = R.gmres(lambda z: J @ z, v, rtol=1e-8, itmax=5000)
+    assert info["converged"] and abs(info["iters"] - info2.iters) <= 2
+    assert np.linalg.norm(x - x2) <= 1e-6 * np.linalg.norm(x2)
+    uC, fn, gi, eta = CO.bratu_newton(ns, 6.0, 0.0, np.zeros(p.n), 8, use_csr=True)
+    s = R.solve(p, R.NewtonRaphson(linsolve=GM(), forcing=R.EisenstatWalkerForcing2(), concrete_jac=True),
+                abstol=1e-30, maxiters=8)
+    assert np.allclose(eta[:3], [t["eta"] for t in s.trace[:3]], rtol=1e-6)
+    assert np.max(np.abs(uC - s.u)) <= 1e-5
+
+
+# ---- Bratu definition sanity: Newton with a sparse direct solve, λ = 6 below the fold, max u ≈ 0.797
+def test_bratu_reference_solution():
+    for ns in (32, 64):
+        s = R.solve(R.Bratu2D(ns), R.NewtonRaphson(), abstol=1e-8, maxiters=50)
+        assert s.retcode == R.SUCCESS and s.stats.nsteps <= 6
+        assert 0.79 < s.u.max() < 0.80
+    # nnz = 5N − 4n
+    assert R.Bratu2D(64).jac(np.zeros(64 * 64)).nnz == 5 * 64 * 64 - 4 * 64
+
+
+def test_golden_fixtures_reproduce():
+    """tests/golden/*.npz were produced by tests/golden/make_golden.py from this oracle; they must keep
+    reproducing (guards the checker itself against silent drift)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+    s = R.solve(R.Bratu2D(16), R.NewtonRaphson(), abstol=1e-10, maxiters=50)
+    assert np.allclose(s.u, g["bratu16_u"], rtol=0, atol=1e-12)
+    s = R.solve(R.Brusselator2D(8), R.NewtonRaphson(), abstol=1e-10)
+    assert np.allclose(s.u, g["brus8_u"], rtol=1e-10, atol=1e-10)
+    p = R.Bratu2D(16)
+    assert np.allclose(p.jac(g["bratu16_u"]) @ g["v256"], g["bratu16_Jv"], rtol=1e-13)
