@@ -323,6 +323,9 @@ int nk_axpy(nk_ctx *ctx, int64_t n, double a, const double *x, double *y);
 int nk_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w, double *h_host);
 int nk_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *h_host,
                  double *w, double *wnorm2);
+/* fused CGS2 pass on a lazily-normalised basis (v_j = s_j ṽ_j): w -= V (h∘s); h2[j] = s_j ṽ_j·w (j<nv), h2[nv] = ‖w‖² */
+int nk_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *h_host,
+                      const double *s_host, double *w, double *h2_host);
 
 #ifdef __cplusplus
 }

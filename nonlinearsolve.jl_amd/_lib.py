@@ -151,6 +151,7 @@ SIGNATURES = {
     "nk_axpy": (_I, [_P, _L, _D, _P, _P]),
     "nk_multidot": (_I, [_P, _L, _I, _P, _L, _P, C.POINTER(_D)]),
     "nk_multiaxpy": (_I, [_P, _L, _I, _P, _L, C.POINTER(_D), _P, C.POINTER(_D)]),
+    "nk_fused_axpy_dot": (_I, [_P, _L, _I, _P, _L, C.POINTER(_D), C.POINTER(_D), _P, C.POINTER(_D)]),
 }
 
 _lib = None

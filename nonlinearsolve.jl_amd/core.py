@@ -158,6 +158,20 @@ class Context:
         return r.value if want_norm2 else None
 
 
+def _fused_axpy_dot(self, V, h, s, w):
+    """w -= V (h∘s); returns (h2, ‖w_new‖²) with h2[j] = s_j V[j]·w_new — the fused CGS2 pass."""
+    nv, ldv = V.shape
+    hh = (C.c_double * nv)(*[float(t) for t in h])
+    ss = (C.c_double * nv)(*[float(t) for t in s])
+    out = (C.c_double * (nv + 1))()
+    check(L.lib().nk_fused_axpy_dot(self._h, w.numel(), nv, C.c_void_p(V.data_ptr()), ldv, hh, ss,
+                                    C.c_void_p(w.data_ptr()), out))
+    arr = np.array(out[:])
+    return arr[:nv], float(arr[nv])
+
+
+Context.fused_axpy_dot = _fused_axpy_dot
+
 _default_ctx: Optional[Context] = None
 
 

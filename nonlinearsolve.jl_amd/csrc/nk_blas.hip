@@ -33,17 +33,41 @@ __device__ __forceinline__ double block_sum(double v, double *sm /*[4]*/) {
   return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// NV per-thread accumulators → NV block sums with ONE barrier: butterfly inside each wavefront, lane 0 parks the
+// wave's sums in LDS, then thread j adds the four wave sums (fixed order) and stores slot j's partial.
+template <int NV>
+__device__ __forceinline__ void block_sum_array_store(const double (&acc)[NV], int nvc, double *sm /*[4*NV]*/,
+                                                      double *__restrict__ partials, int slot0) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (j < nvc) {
+      const double v = wave_sum(acc[j]);
+      if (lane == 0) sm[wid * NV + j] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nvc) {
+    const int t = threadIdx.x;
+    partials[(size_t)(slot0 + t) * gridDim.x + blockIdx.x] = (sm[t] + sm[NV + t]) + (sm[2 * NV + t] + sm[3 * NV + t]);
+  }
+}
+
 // ----------------------------------------------------------------------------- stage-2 reducers
 // block s reduces partials[s*nblk .. s*nblk+nblk) in a fixed order
-__global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum(const double *__restrict__ partials, int nblk,
-                                                         double *__restrict__ out, const int *d_skip) {
+// optional per-slot scale (lagged normalisation of the Krylov basis: h_j = s_j · (ṽ_j·w)) for slots < nscaled
+__global__ __launch_bounds__(64) void k_reduce_sum(const double *__restrict__ partials, int nblk,
+                                                   double *__restrict__ out, const int *d_skip,
+                                                   const double *__restrict__ scales, int nscaled) {
   SKIP_GUARD(d_skip);
-  __shared__ double sm[4];
   const double *p = partials + (size_t)blockIdx.x * nblk;
   double v = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) v += p[i];
-  v = block_sum(v, sm);
-  if (threadIdx.x == 0) out[blockIdx.x] = v;
+  for (int i = threadIdx.x; i < nblk; i += 64) v += p[i];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) {
+    if (scales != nullptr && (int)blockIdx.x < nscaled) v *= scales[blockIdx.x];
+    out[blockIdx.x] = v;
+  }
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_reduce_nanmax(const double *__restrict__ partials, int nblk,
                                                             double *__restrict__ out, double sign) {
@@ -60,87 +84,88 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_nanmax(const double *__rest
 // ----------------------------------------------------------------------------- multidot
 // partial[(slot)*gridDim.x + blk] = Σ_{i in blk's stripes} V[:,jbase+slot][i] * w[i], slot < nvc
 // optional self slot (w·w) written to slot index `self_slot`.
+// NV is the EXACT number of columns (no per-column predicate: hipcc turns a dynamic `if (j < nv)` around each
+// load into load→s_waitcnt→use chains with a single load in flight per wave). NV = 0: only the self product.
 template <int NV>
 __global__ __launch_bounds__(NK_BLOCK) void k_multidot(int64_t n, const double *__restrict__ V, int64_t ldv,
-                                                       int jbase, int nvc, const double *__restrict__ w,
+                                                       int jbase, const double *__restrict__ w,
                                                        double *__restrict__ partials, int self_slot,
                                                        const int *d_skip) {
   SKIP_GUARD(d_skip);
-  __shared__ double sm[4];
-  double acc[NV];
+  constexpr int NA = NV > 0 ? NV : 1;
+  __shared__ double sm[4 * NA + 4];
+  double acc[NA];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+  for (int j = 0; j < NA; ++j) acc[j] = 0.0;
   double self = 0.0;
   const int64_t npair = n >> 1;
   const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
   const double2 *w2 = reinterpret_cast<const double2 *>(w);
   for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < npair; i += stride) {
     const double2 wv = w2[i];
-    if (self_slot >= 0) self += wv.x * wv.x + wv.y * wv.y;
+    double2 vv[NA];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      if (j < nvc) {
-        const double2 vv = reinterpret_cast<const double2 *>(V + (size_t)(jbase + j) * ldv)[i];
-        acc[j] += wv.x * vv.x + wv.y * vv.y;
-      }
-    }
+    for (int j = 0; j < NV; ++j) vv[j] = reinterpret_cast<const double2 *>(V + (size_t)(jbase + j) * ldv)[i];
+    self += wv.x * wv.x + wv.y * wv.y;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += wv.x * vv[j].x + wv.y * vv[j].y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail
     const double wv = w[n - 1];
-    if (self_slot >= 0) self += wv * wv;
+    self += wv * wv;
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-      if (j < nvc) acc[j] += wv * V[(size_t)(jbase + j) * ldv + n - 1];
+    for (int j = 0; j < NV; ++j) acc[j] += wv * V[(size_t)(jbase + j) * ldv + n - 1];
   }
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    if (j < nvc) {
-      const double s = block_sum(acc[j], sm);
-      if (threadIdx.x == 0) partials[(size_t)(jbase + j) * gridDim.x + blockIdx.x] = s;
-    }
-  }
+  if (NV > 0) block_sum_array_store<NA>(acc, NV, sm, partials, jbase);
   if (self_slot >= 0) {
-    const double s = block_sum(self, sm);
+    const double s = block_sum(self, sm + 4 * NA);
     if (threadIdx.x == 0) partials[(size_t)self_slot * gridDim.x + blockIdx.x] = s;
   }
 }
 
-int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w,
-                     double *d_h, bool with_self, const int *d_skip) {
-  NK_REQUIRE(nv >= 0 && nv <= NK_MAX_NV, "multidot: nv=%d out of range", nv);
-  const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
-  const int self_slot = with_self ? nv : -1;
-  constexpr int CH = 16;
-  int j = 0;
-  bool self_done = !with_self;
-  {
-  nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (nv + 1));
-  while (j < nv || !self_done) {
-    const int nvc = (nv - j) < CH ? (nv - j) : CH;
-    const int ss = self_done ? -1 : self_slot;
-    if (nvc > 8)
-      hipLaunchKernelGGL(k_multidot<16>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, j, nvc, w,
-                         ctx->d_partials, ss, d_skip);
-    else if (nvc > 4)
-      hipLaunchKernelGGL(k_multidot<8>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, j, nvc, w,
-                         ctx->d_partials, ss, d_skip);
-    else if (nvc > 1)
-      hipLaunchKernelGGL(k_multidot<4>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, j, nvc, w,
-                         ctx->d_partials, ss, d_skip);
-    else
-      hipLaunchKernelGGL(k_multidot<1>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, j, nvc, w,
-                         ctx->d_partials, ss, d_skip);
-    self_done = true;
-    j += nvc;
-    if (nvc == 0) break;
+#define NK_SWITCH_1_16(nvc, F)                                                                               \
+  switch (nvc) {                                                                                             \
+    case 1: F(1); break;   case 2: F(2); break;   case 3: F(3); break;   case 4: F(4); break;                \
+    case 5: F(5); break;   case 6: F(6); break;   case 7: F(7); break;   case 8: F(8); break;                \
+    case 9: F(9); break;   case 10: F(10); break; case 11: F(11); break; case 12: F(12); break;              \
+    case 13: F(13); break; case 14: F(14); break; case 15: F(15); break; case 16: F(16); break;              \
+    default: break;                                                                                          \
   }
+
+int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w,
+                     double *d_h, bool with_self, const int *d_skip, const double *d_scales) {
+  NK_REQUIRE(nv >= 0 && nv <= NK_MAX_NV, "multidot: nv=%d out of range", nv);
+  const int grid = nk_grid_for(n >> 1, NK_BLOCK * 4, NK_DOT_BLOCKS);
+  const int self_slot = with_self ? nv : -1;
+  {
+    nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (nv + 1));
+    // balanced chunks of ≤ 16 columns (e.g. 31 → 16 + 15); the self product rides on the first launch
+    const int nchunks = nv > 0 ? (nv + 15) / 16 : 0;
+    int j = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int nvc = (nv - j + (nchunks - c) - 1) / (nchunks - c);
+      const int ss = (c == 0) ? self_slot : -1;
+#define MD_LAUNCH(N)                                                                                         \
+  hipLaunchKernelGGL(k_multidot<N>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, j, w, ctx->d_partials, \
+                     ss, d_skip)
+      NK_SWITCH_1_16(nvc, MD_LAUNCH)
+      j += nvc;
+    }
+    if (nchunks == 0 && with_self) {
+      const int j0 = 0;
+      const int ss = self_slot;
+      (void)j0;
+      hipLaunchKernelGGL(k_multidot<0>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, 0, w, ctx->d_partials,
+                         ss, d_skip);
+    }
+#undef MD_LAUNCH
   }
   const int nslots = nv + (with_self ? 1 : 0);
   if (nslots == 0) return NK_OK;
   {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), 0, ctx->stream, ctx->d_partials, grid, d_h,
-                       d_skip);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(nslots), dim3(64), 0, ctx->stream, ctx->d_partials, grid, d_h,
+                       d_skip, d_scales, nv);
   }
   NK_HIP(hipGetLastError());
   return nk_comm_allreduce(ctx, d_h, nslots, 0);
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
                                                         int nv, const int *__restrict__ d_nv,
                                                         const double *__restrict__ h, double sign,
                                                         double *__restrict__ w, double *__restrict__ partials,
-                                                        const int *d_skip) {
+                                                        const int *d_skip, const double *__restrict__ sc) {
   SKIP_GUARD(d_skip);
   __shared__ double sm[4];
   if (d_nv) nv = *d_nv;
@@ -168,7 +193,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
       const double2 v1 = reinterpret_cast<const double2 *>(V + (size_t)(j + 1) * ldv)[i];
       const double2 v2 = reinterpret_cast<const double2 *>(V + (size_t)(j + 2) * ldv)[i];
       const double2 v3 = reinterpret_cast<const double2 *>(V + (size_t)(j + 3) * ldv)[i];
-      const double c0 = sign * h[j], c1 = sign * h[j + 1], c2 = sign * h[j + 2], c3 = sign * h[j + 3];
+      double c0 = sign * h[j], c1 = sign * h[j + 1], c2 = sign * h[j + 2], c3 = sign * h[j + 3];
+      if (sc) { c0 *= sc[j]; c1 *= sc[j + 1]; c2 *= sc[j + 2]; c3 *= sc[j + 3]; }
       a.x += c0 * v0.x; a.y += c0 * v0.y;
       a.x += c1 * v1.x; a.y += c1 * v1.y;
       a.x += c2 * v2.x; a.y += c2 * v2.y;
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
     }
     for (; j < nv; ++j) {
       const double2 v0 = reinterpret_cast<const double2 *>(V + (size_t)j * ldv)[i];
-      const double c0 = sign * h[j];
+      const double c0 = sign * h[j] * (sc ? sc[j] : 1.0);
       a.x += c0 * v0.x; a.y += c0 * v0.y;
     }
     w2[i] = a;
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double a = w[n - 1];
-    for (int j = 0; j < nv; ++j) a += sign * h[j] * V[(size_t)j * ldv + n - 1];
+    for (int j = 0; j < nv; ++j) a += sign * h[j] * (sc ? sc[j] : 1.0) * V[(size_t)j * ldv + n - 1];
     w[n - 1] = a;
     ss += a * a;
   }
@@ -195,22 +221,106 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
 }
 
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
-                      double sign, double *w, double *d_sumsq, const int *d_skip, const int *d_nv) {
+                      double sign, double *w, double *d_sumsq, const int *d_skip, const int *d_nv,
+                      const double *d_scales) {
   const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
   {
     nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2));
     hipLaunchKernelGGL(k_multiaxpy, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, nv, d_nv, d_h, sign,
-                       w, d_sumsq ? ctx->d_partials : nullptr, d_skip);
+                       w, d_sumsq ? ctx->d_partials_ss : nullptr, d_skip, d_scales);
+  }
+  if (d_sumsq == NK_SUMSQ_PARTIALS_ONLY) {  // consumer (k_givens) reduces ctx->d_partials[0..grid) itself
+    ctx->last_red_grid = grid;
+    NK_HIP(hipGetLastError());
+    return NK_OK;
   }
   if (d_sumsq) {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * grid);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(NK_BLOCK), 0, ctx->stream, ctx->d_partials, grid, d_sumsq,
-                       d_skip);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(64), 0, ctx->stream, ctx->d_partials_ss, grid, d_sumsq,
+                       d_skip, (const double *)nullptr, 0);
     NK_HIP(hipGetLastError());
     return nk_comm_allreduce(ctx, d_sumsq, 1, 0);
   }
   NK_HIP(hipGetLastError());
   return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- fused Gram–Schmidt pass
+// One pass over the basis does BOTH halves of a CGS2 step that touch V:
+//     w ← w − Σ_j (h_j s_j) ṽ_j           (first projection, coefficients from the previous multidot)
+//     raw2_j = ṽ_j · w_new  (all j)        (inner products of the re-orthogonalisation)
+//     ss = ‖w_new‖²
+// The ṽ_j values stay in registers between the two uses, so V is read once instead of twice
+// (algorithmic bytes 8 n (nv + 2), the same as the plain multiaxpy). NV ≤ 32 columns per launch.
+template <int NV>  // EXACT column count (see k_multidot for why)
+__global__ __launch_bounds__(NK_BLOCK) void k_fused_axpy_dot(int64_t n, const double *__restrict__ V, int64_t ldv,
+                                                             const double *__restrict__ h,
+                                                             const double *__restrict__ sc, double *__restrict__ w,
+                                                             double *__restrict__ partials, const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  __shared__ double sm[4 * NV + 4];
+  __shared__ double coef[NV];  // h_j s_j, broadcast-read from LDS so they do not occupy 2·NV VGPRs
+  if (threadIdx.x < NV) coef[threadIdx.x] = h[threadIdx.x] * sc[threadIdx.x];
+  __syncthreads();
+  double acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+  double ss = 0.0;
+  // one element per lane per sweep (8-byte loads): NV values of ṽ_j stay live between the two uses.
+  // 32-bit lane offsets on uniform column bases → scalar-base + vector-offset loads.
+  const unsigned stride = gridDim.x * NK_BLOCK, nn = (unsigned)n;
+  for (unsigned i = blockIdx.x * NK_BLOCK + threadIdx.x; i < nn; i += stride) {
+    double vv[NV];
+    double a = w[i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const double *__restrict__ col = V + (size_t)j * ldv;
+      vv[j] = col[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a -= coef[j] * vv[j];
+    w[i] = a;
+    ss += a * a;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += vv[j] * a;
+  }
+  block_sum_array_store<NV>(acc, NV, sm, partials, 0);
+  const double s = block_sum(ss, sm + 4 * NV);
+  if (threadIdx.x == 0) partials[(size_t)NV * gridDim.x + blockIdx.x] = s;
+}
+
+// d_h2[0..nv) = s_j·(ṽ_j·w_new) and d_h2[nv] = ‖w_new‖² (both all-reduced). Requires nv ≤ 32.
+int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
+                           const double *d_scales, double *w, double *d_h2, const int *d_skip) {
+  NK_REQUIRE(nv >= 1 && nv <= 32, "fused pass handles 1..32 columns (got %d)", nv);
+  NK_REQUIRE(n < (1ll << 31), "fused pass: local vector too long for 32-bit offsets");
+  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_DOT_BLOCKS);
+  {
+    nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2));
+#define FU_LAUNCH(N)                                                                                            \
+  hipLaunchKernelGGL(k_fused_axpy_dot<N>, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, V, ldv, d_h, d_scales, w, \
+                     ctx->d_partials, d_skip)
+    if (nv <= 16) {
+      NK_SWITCH_1_16(nv, FU_LAUNCH)
+    } else {
+      switch (nv) {
+        case 17: FU_LAUNCH(17); break; case 18: FU_LAUNCH(18); break; case 19: FU_LAUNCH(19); break;
+        case 20: FU_LAUNCH(20); break; case 21: FU_LAUNCH(21); break; case 22: FU_LAUNCH(22); break;
+        case 23: FU_LAUNCH(23); break; case 24: FU_LAUNCH(24); break; case 25: FU_LAUNCH(25); break;
+        case 26: FU_LAUNCH(26); break; case 27: FU_LAUNCH(27); break; case 28: FU_LAUNCH(28); break;
+        case 29: FU_LAUNCH(29); break; case 30: FU_LAUNCH(30); break; case 31: FU_LAUNCH(31); break;
+        default: FU_LAUNCH(32); break;
+      }
+    }
+#undef FU_LAUNCH
+  }
+  {
+    nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (nv + 1) * grid);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(nv + 1), dim3(64), 0, ctx->stream, ctx->d_partials, grid, d_h2, d_skip,
+                       d_scales, nv);
+  }
+  NK_HIP(hipGetLastError());
+  return nk_comm_allreduce(ctx, d_h2, nv + 1, 0);
 }
 
 // ----------------------------------------------------------------------------- dot / sumsq / norm_inf / minmax
@@ -261,8 +371,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_minmax(int64_t n, const double *__
 int nk_blas_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *d_out) {
   const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
   hipLaunchKernelGGL(k_dot, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, x, y, ctx->d_partials);
-  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(NK_BLOCK), 0, ctx->stream, ctx->d_partials, grid, d_out,
-                     (const int *)nullptr);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(64), 0, ctx->stream, ctx->d_partials, grid, d_out,
+                     (const int *)nullptr, (const double *)nullptr, 0);
   NK_HIP(hipGetLastError());
   return nk_comm_allreduce(ctx, d_out, 1, 0);
 }
@@ -386,8 +496,19 @@ extern "C" int nk_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int6
                            double *h_host) {
   NK_REQUIRE(ctx && V && w && h_host, "NULL argument");
   NK_REQUIRE((ldv & 1) == 0, "ldv must be even (16-byte aligned columns)");
-  NK_TRY(nk_blas_multidot(ctx, n, nv, V, ldv, w, ctx->d_scal, false, nullptr));
+  NK_TRY(nk_blas_multidot(ctx, n, nv, V, ldv, w, ctx->d_scal, false, nullptr, nullptr));
   return nk_scalars_to_host(ctx, ctx->d_scal, nv, h_host);
+}
+// bench/test export of the fused CGS2 pass: w ← w − V(h∘s); h2[j] = s_j ṽ_j·w_new (j<nv), h2[nv] = ‖w_new‖²
+extern "C" int nk_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *h_host,
+                                 const double *s_host, double *w, double *h2_host) {
+  NK_REQUIRE(ctx && V && w && h_host && s_host && h2_host, "NULL argument");
+  NK_REQUIRE(nv >= 1 && nv <= 32, "nv out of range");
+  for (int j = 0; j < nv; ++j) { ctx->h_pinned[j] = h_host[j]; ctx->h_pinned[NK_MAX_NV + j] = s_host[j]; }
+  NK_HIP(hipMemcpyAsync(ctx->d_scal, ctx->h_pinned, 2 * NK_MAX_NV * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, V, ldv, ctx->d_scal, ctx->d_scal + NK_MAX_NV, w, ctx->d_scal + 2 * NK_MAX_NV,
+                                nullptr));
+  return nk_scalars_to_host(ctx, ctx->d_scal + 2 * NK_MAX_NV, nv + 1, h2_host);
 }
 extern "C" int nk_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *h_host,
                             double *w, double *wnorm2) {
@@ -396,7 +517,7 @@ extern "C" int nk_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int
   for (int j = 0; j < nv; ++j) ctx->h_pinned[j] = h_host[j];
   NK_HIP(hipMemcpyAsync(ctx->d_scal, ctx->h_pinned, nv * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   NK_TRY(nk_blas_multiaxpy(ctx, n, nv, V, ldv, ctx->d_scal, -1.0, w, wnorm2 ? ctx->d_scal + NK_MAX_NV : nullptr,
-                           nullptr, nullptr));
+                           nullptr, nullptr, nullptr));
   if (wnorm2) return nk_scalars_to_host(ctx, ctx->d_scal + NK_MAX_NV, 1, wnorm2);
   NK_HIP(hipStreamSynchronize(ctx->stream));
   return NK_OK;

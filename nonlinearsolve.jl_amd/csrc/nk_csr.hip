@@ -10,11 +10,12 @@
 //
 // Algorithmic bytes per launch: 12 nnz + 4 (nrows+1) + 8 nrows (y) + 8 nrows (x)  ≈ 80 N for 5-pt Bratu.
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 
 #include "nk_internal.h"
 
-constexpr int SPMV_TILE = 2048;   // non-zeros per workgroup tile (16 KiB of LDS)
+constexpr int SPMV_TILE_MAX = 4096;  // largest LDS tile a variant may use (32 KiB)
 constexpr int NXCD = 8;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -24,29 +25,69 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return x * q + (x < r ? x : r) + k;
 }
 
+// TILE: non-zeros per workgroup tile (LDS = 8·TILE bytes). BATCH: issue all of a lane's col/val loads of the
+// tile before the dependent x gathers (more memory-level parallelism per lane) instead of a rolled loop.
+template <int TILE, bool BATCH, bool REMAP>
 __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
-    int nblk, const int32_t *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
+    int nblk, const int4 *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
-    const double *__restrict__ xhalo, int32_t nlocal, double *__restrict__ y, const int *d_skip) {
+    const double *__restrict__ xhalo, int32_t nlocal, double *__restrict__ y, const int *d_skip,
+    const double *__restrict__ out_scale) {
   if (d_skip != nullptr && *d_skip != 0) return;
-  __shared__ double prod[SPMV_TILE];
+  const double os = out_scale ? *out_scale : 1.0;
+  __shared__ double prod[TILE];
   __shared__ double red[4];
-  const int b = xcd_remap(blockIdx.x, nblk);
-  const int r0 = rowblocks[b], r1 = rowblocks[b + 1];
-  const int p0 = rowptr[r0], p1 = rowptr[r1];
+  const int b = REMAP ? xcd_remap(blockIdx.x, nblk) : (int)blockIdx.x;
+  const int4 desc = rowblocks[b];  // {first row, end row, first nnz, end nnz}: one 16-byte scalar load per block
+  const int r0 = desc.x, r1 = desc.y, p0 = desc.z, p1 = desc.w;
   const int nnzb = p1 - p0;
-  if (nnzb <= SPMV_TILE) {
-    for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
-      const int c = col[p0 + k];
-      const double xv = (c < nlocal) ? x[c] : xhalo[c - nlocal];
-      prod[k] = val[p0 + k] * xv;
+  if (nnzb <= TILE) {
+    // row bounds of this lane's first two rows, requested before the tile streams in (they are only needed
+    // after the barrier; issuing them here takes an L2 round trip off the block's critical path)
+    const int rA = r0 + threadIdx.x, rB = rA + NK_BLOCK;
+    int aA = 0, eA = 0, aB = 0, eB = 0;
+    if (rA < r1) { aA = rowptr[rA]; eA = rowptr[rA + 1]; }
+    if (rB < r1) { aB = rowptr[rB]; eB = rowptr[rB + 1]; }
+    if (BATCH) {
+      constexpr int PER = TILE / NK_BLOCK;
+      int c[PER];
+      double v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int k = threadIdx.x + NK_BLOCK * i;
+        const bool ok = k < nnzb;
+        c[i] = ok ? col[p0 + k] : 0;
+        v[i] = ok ? val[p0 + k] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int k = threadIdx.x + NK_BLOCK * i;
+        const double xv = (c[i] < nlocal) ? x[c[i]] : xhalo[c[i] - nlocal];
+        if (k < nnzb) prod[k] = v[i] * xv;
+      }
+    } else {
+      for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
+        const int c = col[p0 + k];
+        const double xv = (c < nlocal) ? x[c] : xhalo[c - nlocal];
+        prod[k] = val[p0 + k] * xv;
+      }
     }
     __syncthreads();
-    for (int r = r0 + threadIdx.x; r < r1; r += NK_BLOCK) {
+    if (rA < r1) {
+      double s = 0.0;
+      for (int k = aA - p0; k < eA - p0; ++k) s += prod[k];
+      y[rA] = out_scale ? os * s : s;
+    }
+    if (rB < r1) {
+      double s = 0.0;
+      for (int k = aB - p0; k < eB - p0; ++k) s += prod[k];
+      y[rB] = out_scale ? os * s : s;
+    }
+    for (int r = rB + NK_BLOCK; r < r1; r += NK_BLOCK) {  // blocks of (almost) empty rows
       const int a = rowptr[r] - p0, e = rowptr[r + 1] - p0;
       double s = 0.0;
       for (int k = a; k < e; ++k) s += prod[k];
-      y[r] = s;
+      y[r] = out_scale ? os * s : s;
     }
   } else {
     // a single long row: the whole workgroup reduces it (fixed order → deterministic)
@@ -60,11 +101,46 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) y[r0] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) y[r0] = os * (red[0] + red[1] + red[2] + red[3]);
   }
 }
 
-static void build_rowblocks(const std::vector<int32_t> &rowptr, std::vector<int32_t> &rb) {
+// experiment (NOT bit-compatible with the sequential row sum): 8 lanes per row, shuffle reduction, no LDS
+__global__ __launch_bounds__(NK_BLOCK) void k_spmv_vec8(int64_t nrows, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                        const double *__restrict__ x, const double *__restrict__ xhalo,
+                                                        int32_t nlocal, double *__restrict__ y, const int *d_skip,
+                                                        const double *__restrict__ out_scale) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const double os = out_scale ? *out_scale : 1.0;
+  const int lane8 = threadIdx.x & 7;
+  const int64_t gstride = (int64_t)gridDim.x * (NK_BLOCK / 8);
+  for (int64_t r = (int64_t)blockIdx.x * (NK_BLOCK / 8) + (threadIdx.x >> 3); r < nrows; r += gstride) {
+    const int a = rowptr[r], e = rowptr[r + 1];
+    double s = 0.0;
+    for (int k = a + lane8; k < e; k += 8) {
+      const int c = col[k];
+      s += val[k] * ((c < nlocal) ? x[c] : xhalo[c - nlocal]);
+    }
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if (lane8 == 0) y[r] = os * s;
+  }
+}
+
+static int spmv_tile_from_env() {
+  const char *e = getenv("NK_SPMV_TILE");
+  int t = e ? atoi(e) : 1024;  // measured best on MI355X (tools/microbench.py)
+  if (t != 512 && t != 1024 && t != 2048 && t != 4096) t = 1024;
+  return t;
+}
+static int spmv_variant_from_env() {  // 0 rolled, 1 batched loads, 2 rolled/no XCD remap, 3 vec8 experiment
+  const char *e = getenv("NK_SPMV_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
+static void build_rowblocks(const std::vector<int32_t> &rowptr, std::vector<int32_t> &rb, int SPMV_TILE) {
   const int64_t nrows = (int64_t)rowptr.size() - 1;
   rb.clear();
   rb.push_back(0);
@@ -116,15 +192,24 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
     else A->h_col[k] = (int32_t)(nrows + (std::lower_bound(halo.begin(), halo.end(), g) - halo.begin()));
   }
   std::vector<int32_t> rb;
-  build_rowblocks(rowptr, rb);
+  A->tile = spmv_tile_from_env();
+  A->variant = spmv_variant_from_env();
+  build_rowblocks(rowptr, rb, A->tile);
   A->nblocks = (int)rb.size() - 1;
   NK_TRY(nk_dev_alloc(&A->d_rowptr, (size_t)nrows + 1));
   NK_TRY(nk_dev_alloc(&A->d_col, (size_t)nnz));
   NK_TRY(nk_dev_alloc(&A->d_val, (size_t)nnz));
-  NK_TRY(nk_dev_alloc(&A->d_rowblocks, rb.size()));
+  std::vector<int32_t> desc(4 * (size_t)A->nblocks);
+  for (int b = 0; b < A->nblocks; ++b) {
+    desc[4 * b + 0] = rb[b];
+    desc[4 * b + 1] = rb[b + 1];
+    desc[4 * b + 2] = rowptr[rb[b]];
+    desc[4 * b + 3] = rowptr[rb[b + 1]];
+  }
+  NK_TRY(nk_dev_alloc(&A->d_rowblocks, desc.size() + 4));
   NK_HIP(hipMemcpy(A->d_rowptr, rowptr.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
   if (nnz) NK_HIP(hipMemcpy(A->d_col, A->h_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-  NK_HIP(hipMemcpy(A->d_rowblocks, rb.data(), rb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!desc.empty()) NK_HIP(hipMemcpy(A->d_rowblocks, desc.data(), desc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (vals_host && nnz) NK_HIP(hipMemcpy(A->d_val, vals_host, nnz * sizeof(double), hipMemcpyHostToDevice));
   else if (nnz) NK_HIP(hipMemset(A->d_val, 0, nnz * sizeof(double)));
 
@@ -322,14 +407,38 @@ extern "C" int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, i
 }
 extern "C" double *nk_csr_values_device(nk_csr *A) { return A ? A->d_val : nullptr; }
 
-int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip) {
+int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale) {
   nk_ctx *ctx = A->ctx;
   if (A->halo.active()) NK_TRY(nk_halo_exchange(ctx, &A->halo, d_x));
   ctx->stats.op_applies++;
   nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
-  if (A->nblocks > 0)
-    hipLaunchKernelGGL(k_spmv_stream, dim3(A->nblocks), dim3(NK_BLOCK), 0, ctx->stream, A->nblocks, A->d_rowblocks,
-                       A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip);
+  if (A->nblocks > 0) {
+#define SPMV_LAUNCH(T, B, R)                                                                                      \
+  hipLaunchKernelGGL((k_spmv_stream<T, B, R>), dim3(A->nblocks), dim3(NK_BLOCK), 0, ctx->stream, A->nblocks,      \
+                     (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, \
+                     d_skip, d_out_scale)
+    if (A->variant == 3) {
+      const int grid = nk_grid_for(A->nrows, NK_BLOCK / 8, 1 << 20);
+      hipLaunchKernelGGL(k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, A->nrows, A->d_rowptr, A->d_col,
+                         A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);
+    } else if (A->variant == 2) {
+      if (A->tile == 512) SPMV_LAUNCH(512, false, false);
+      else if (A->tile == 1024) SPMV_LAUNCH(1024, false, false);
+      else if (A->tile == 4096) SPMV_LAUNCH(4096, false, false);
+      else SPMV_LAUNCH(2048, false, false);
+    } else if (A->variant == 1) {
+      if (A->tile == 512) SPMV_LAUNCH(512, true, true);
+      else if (A->tile == 1024) SPMV_LAUNCH(1024, true, true);
+      else if (A->tile == 4096) SPMV_LAUNCH(4096, true, true);
+      else SPMV_LAUNCH(2048, true, true);
+    } else {
+      if (A->tile == 512) SPMV_LAUNCH(512, false, true);
+      else if (A->tile == 1024) SPMV_LAUNCH(1024, false, true);
+      else if (A->tile == 4096) SPMV_LAUNCH(4096, false, true);
+      else SPMV_LAUNCH(2048, false, true);
+    }
+#undef SPMV_LAUNCH
+  }
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

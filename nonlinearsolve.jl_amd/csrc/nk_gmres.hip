@@ -2,20 +2,28 @@
 // lib/NonlinearSolveBase/ext/NonlinearSolveBaseLinearSolveExt.jl:26, i.e. LinearSolve.KrylovJL_GMRES →
 // Krylov.gmres! [EXT]).
 //
-// Structure: the Krylov basis V (n × (m+1), column-major), the Hessenberg factor, the Givens rotations and the
-// least-squares right-hand side all live in device memory. A whole restart cycle is enqueued without any
-// host synchronisation: the small `k_givens` kernel decides convergence on the device and raises `ctl.done`,
-// which every later kernel of the cycle reads first and returns on. The host reads the 128-byte control
-// block once per cycle. Orthogonalisation: MGS (Krylov.jl's structure), CGS2 (two fused passes; 3 small
-// all-reduces per Arnoldi step on multi-GPU) or CGS with the DGKS re-orthogonalisation test.
+// Structure
+//  * The Krylov basis (n × (m+1), column-major), the Hessenberg factor, the Givens rotations and the
+//    least-squares right-hand side all live in device memory. A whole restart cycle is enqueued without host
+//    synchronisation: the one-wave `k_givens` kernel decides convergence on the device and raises `ctl.done`,
+//    which every later kernel of the cycle reads first and returns on. The host reads the 128-byte control
+//    block once per cycle.
+//  * Lagged normalisation: column j holds the UN-normalised vector ṽ_j and a device scalar s_j = 1/‖ṽ_j‖;
+//    v_j = s_j ṽ_j is never materialised. The operator kernel writes s_k·A ṽ_k straight into column k+1, inner
+//    products are scaled in the stage-2 reducer, and axpy coefficients are h_j s_j. This removes the separate
+//    "v = w/‖w‖" pass (16 n bytes per Arnoldi step) and the w→V copy.
+//  * CGS2 in three passes over V instead of four: multidot, then one fused kernel that applies the first
+//    projection and accumulates the second projection's inner products while ṽ_j is still in registers, then
+//    the second update (+‖·‖²). MGS (Krylov.jl's structure) and CGS+DGKS are the other two variants.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "nk_internal.h"
 
 // ----------------------------------------------------------------------------- small device kernels
 __global__ void k_gmres_begin(nk_gmres_ctl *ctl, const double *d_ss, double atol, double rtol, int fixed,
-                              int first, double *g, int m) {
+                              int first, double *g, double *s, int m) {
   if (threadIdx.x != 0) return;
   const double beta = sqrt(*d_ss);
   if (first) {
@@ -34,33 +42,41 @@ __global__ void k_gmres_begin(nk_gmres_ctl *ctl, const double *d_ss, double atol
   if (!bad && (beta == 0.0 || (ctl->tol >= 0.0 && beta <= ctl->tol))) ctl->converged = 1;
   ctl->done = (ctl->failed || ctl->converged) ? 1 : 0;
   ctl->inv_hn = (beta > 0.0 && !bad) ? 1.0 / beta : 0.0;
+  s[0] = ctl->inv_hn;
   g[0] = beta;
   for (int i = 1; i <= m; ++i) g[i] = 0.0;
 }
 
-// DGKS test after the first CGS pass: re-orthogonalise iff ‖w'‖² < ½‖w‖².  pad0 doubles as the
-// "skip pass 2" flag read by the pass-2 kernels.
-__global__ void k_dgks(nk_gmres_ctl *ctl, const double *h /*h[k+1] = ‖w‖²*/, const double *d_ss1, double *h2,
-                       double *d_ss, double inv_nranks) {
+// DGKS test after the first projection: re-orthogonalise iff ‖w'‖² < ½‖w‖². pad0 is the "skip pass 2" flag.
+// h[k+1] = ‖w‖² (self slot of the first multidot), h2[k+1] = ‖w'‖² (from the fused pass).
+__global__ void k_dgks(nk_gmres_ctl *ctl, const double *h, double *h2, double *d_ss, double inv_nranks) {
   if (threadIdx.x != 0) return;
   if (ctl->done) { ctl->pad0 = 1; return; }
   const int k = ctl->k;
-  const double before = h[k + 1], after = *d_ss1;
+  const double before = h[k + 1], after = h2[k + 1];
   const int need = (after < 0.5 * before) ? 1 : 0;
   ctl->need_reorth = need;
   ctl->pad0 = need ? 0 : 1;
   if (!need) {
     for (int i = 0; i <= k; ++i) h2[i] = 0.0;
-    *d_ss = after * inv_nranks;  // the unconditional all-reduce that follows restores `after`
+    *d_ss = after * inv_nranks;  // the unconditional all-reduce inside the skipped pass restores `after`
   }
 }
 
 // new Hessenberg column → apply old rotations, create the new one, update g and the residual estimate
+// ss_partials != nullptr (single rank): ‖w‖² arrives as nblk per-block partials and is reduced here, saving a launch
 __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, const double *h2, const double *d_ss,
-                                               double *R, double *cs, double *sn, double *g, int m) {
+                                               double *R, double *cs, double *sn, double *g, double *s, int m,
+                                               const double *__restrict__ ss_partials, int nblk) {
   if (ctl->done) return;
   __shared__ double sh[NK_MAX_NV + 2], sc[NK_MAX_NV + 2], ss_[NK_MAX_NV + 2];
   const int k = ctl->k, t = threadIdx.x;
+  double ssq_red = 0.0;
+  if (ss_partials != nullptr) {
+    for (int i = t; i < nblk; i += 64) ssq_red += ss_partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssq_red += __shfl_xor(ssq_red, o, 64);
+  }
   if (t <= k) {
     double v = h[t];
     if (h2) v += h2[t];
@@ -69,51 +85,60 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
   }
   __syncthreads();
   if (t != 0) return;
-  double ssq = *d_ss;
+  double ssq = (ss_partials != nullptr) ? ssq_red : *d_ss;
   if (ssq < 0.0) ssq = 0.0;
   const double hn = sqrt(ssq);
   double hk = sh[0];
-  // rotations i < k act on (h[i], h[i+1])
-  for (int i = 0; i < k; ++i) {
+  for (int i = 0; i < k; ++i) {  // rotation i acts on (h[i], h[i+1])
     const double a = hk, b = sh[i + 1];
-    const double tnew = sc[i] * a + ss_[i] * b;
+    R[(size_t)i * m + k] = sc[i] * a + ss_[i] * b;
     hk = -ss_[i] * a + sc[i] * b;
-    R[(size_t)i * m + k] = tnew;
   }
   const double d = hypot(hk, hn);
-  double c, s;
-  if (d == 0.0) { c = 1.0; s = 0.0; } else { c = hk / d; s = hn / d; }
+  double c, sgn;
+  if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = hn / d; }
   cs[k] = c;
-  sn[k] = s;
+  sn[k] = sgn;
   R[(size_t)k * m + k] = d;
   const double gk = g[k];
-  g[k + 1] = -s * gk;
+  g[k + 1] = -sgn * gk;
   g[k] = c * gk;
   const double rn = fabs(g[k + 1]);
   ctl->k = k + 1;
   ctl->rnorm = rn;
   ctl->hn = hn;
   ctl->inv_hn = (hn > 0.0) ? 1.0 / hn : 0.0;
+  s[k + 1] = ctl->inv_hn;
   if (!(rn == rn) || isinf(rn) || !(hn == hn)) { ctl->failed = 1; ctl->done = 1; }
   else if (ctl->tol >= 0.0 && rn <= ctl->tol) { ctl->converged = 1; ctl->done = 1; }
   else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; }  // happy breakdown
 }
 
-// y = R(0:k,0:k)^{-1} g(0:k)   (k = ctl->k)
+// y = R(0:k,0:k)^{-1} g(0:k), k = ctl->k. R and g are staged in LDS; one lane runs the recurrence.
 __global__ __launch_bounds__(64) void k_backsolve(const nk_gmres_ctl *ctl, const double *R, const double *g, double *y,
                                                   int m) {
-  if (threadIdx.x != 0) return;
+  __shared__ double sR[(NK_MAX_NV) * (NK_MAX_NV)];
+  __shared__ double sg[NK_MAX_NV + 1], sy[NK_MAX_NV + 1];
   const int k = ctl->k;
-  if (ctl->failed) {
-    for (int i = 0; i < m; ++i) y[i] = 0.0;
-    return;
+  for (int idx = threadIdx.x; idx < k * k; idx += 64) {
+    const int i = idx / k, j = idx - i * k;
+    sR[i * k + j] = R[(size_t)i * m + j];
   }
-  for (int i = k - 1; i >= 0; --i) {
-    double s = g[i];
-    for (int j = i + 1; j < k; ++j) s -= R[(size_t)i * m + j] * y[j];
-    y[i] = s / R[(size_t)i * m + i];
+  for (int i = threadIdx.x; i < k; i += 64) sg[i] = g[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ctl->failed) {
+      for (int i = 0; i < m; ++i) y[i] = 0.0;
+    } else {
+      for (int i = k - 1; i >= 0; --i) {
+        double sum = sg[i];
+        for (int j = i + 1; j < k; ++j) sum -= sR[i * k + j] * sy[j];
+        sy[i] = sum / sR[i * k + i];
+      }
+      for (int i = 0; i < k; ++i) y[i] = sy[i];
+      for (int i = k; i < m; ++i) y[i] = 0.0;
+    }
   }
-  for (int i = k; i < m; ++i) y[i] = 0.0;
 }
 
 // ----------------------------------------------------------------------------- create / destroy / operators
@@ -131,12 +156,18 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   G->ortho = ortho;
   G->ldv = (n_local + 31) & ~(int64_t)31;  // 256-byte aligned columns
   if (G->ldv == 0) G->ldv = 32;
+  {  // de-phase the columns: a power-of-two column stride puts all nv concurrent streams on the same HBM channel
+    const char *e = getenv("NK_LDV_PAD");
+    const int64_t pad = e ? atoll(e) : NK_LDV_PAD_DEFAULT;
+    if (pad > 0 && n_local >= 4096) G->ldv += (pad + 31) & ~(int64_t)31;
+  }
   const int m = restart_m;
   NK_TRY(nk_dev_alloc(&G->V, (size_t)G->ldv * (m + 1)));
   NK_TRY(nk_dev_alloc(&G->w, (size_t)G->ldv));
   NK_TRY(nk_dev_alloc(&G->r, (size_t)G->ldv));
   NK_TRY(nk_dev_alloc(&G->d_h, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_h2, (size_t)NK_MAX_NV + 2));
+  NK_TRY(nk_dev_alloc(&G->d_s, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_R, (size_t)m * m));
   NK_TRY(nk_dev_alloc(&G->d_cs, (size_t)m + 1));
   NK_TRY(nk_dev_alloc(&G->d_sn, (size_t)m + 1));
@@ -147,13 +178,14 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_HIP(hipHostMalloc((void **)&G->h_ctl, sizeof(nk_gmres_ctl), hipHostMallocDefault));
   NK_HIP(hipMemset(G->d_ctl, 0, sizeof(nk_gmres_ctl)));
   NK_HIP(hipMemset(G->V, 0, (size_t)G->ldv * (m + 1) * sizeof(double)));
+  NK_HIP(hipMemset(G->d_s, 0, (NK_MAX_NV + 2) * sizeof(double)));
   *out = G;
   return NK_OK;
 }
 extern "C" int nk_gmres_destroy(nk_gmres *G) {
   if (!G) return NK_OK;
   hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
-  hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
+  hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
   hipHostFree(G->h_ctl);
@@ -197,17 +229,31 @@ extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, v
   return NK_OK;
 }
 
-// y = A x  (right-preconditioned: y = A M⁻¹ x)
-static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip) {
+// can the operator kernel apply the output scale itself (built-in kernels) or do we have to scale the input?
+static bool op_fuses_scale(const nk_gmres *G) {
+  if (G->prec) return false;
+  if (G->op_kind == 1) return true;
+  if (G->op_kind == 2) return G->P->kind != NK_PROBLEM_USER;
+  return false;
+}
+
+// y = scale · A x (right-preconditioned: A M⁻¹ x); scale may be nullptr (= 1)
+static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale) {
   nk_ctx *ctx = G->ctx;
   const double *src = d_x;
+  const double *oscale = d_scale;
+  if (d_scale && !op_fuses_scale(G)) {  // callback operators / preconditioners see the normalised vector
+    NK_TRY(nk_blas_scale_to(ctx, G->n, d_scale, d_x, G->w, d_skip));
+    src = G->w;
+    oscale = nullptr;
+  }
   if (G->prec) {
-    if (G->prec(G->prec_user, d_x, G->z, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
+    if (G->prec(G->prec_user, src, G->z, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
     src = G->z;
   }
   switch (G->op_kind) {
-    case 1: return nk_csr_spmv_dev(G->A, src, d_y, d_skip);
-    case 2: return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip);
+    case 1: return nk_csr_spmv_dev(G->A, src, d_y, d_skip, oscale);
+    case 2: return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip, oscale);
     case 3:
       ctx->stats.op_applies++;
       if (G->fn(G->fn_user, src, d_y, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "operator callback failed");
@@ -221,40 +267,43 @@ static int arnoldi_step(nk_gmres *G, int k) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n, ldv = G->ldv;
   const int *skip = &G->d_ctl->done;
-  double *vk = G->V + (size_t)k * ldv;
-  NK_TRY(op_apply(G, vk, G->w, skip));
+  const int nv = k + 1;
+  double *wk = G->V + (size_t)(k + 1) * ldv;  // the new (un-normalised) column is built in place
+  NK_TRY(op_apply(G, G->V + (size_t)k * ldv, wk, skip, G->d_s + k));
   if (G->ortho == NK_ORTHO_MGS) {
-    for (int i = 0; i <= k; ++i) {
-      // h_i = v_i·w ; w -= h_i v_i   (the last axpy also yields ‖w‖²)
-      NK_TRY(nk_blas_multidot(ctx, n, 1, G->V + (size_t)i * ldv, ldv, G->w, G->d_h + i, false, skip));
-      NK_TRY(nk_blas_multiaxpy(ctx, n, 1, G->V + (size_t)i * ldv, ldv, G->d_h + i, -1.0, G->w,
-                               i == k ? G->d_ss : nullptr, skip, nullptr));
+    for (int i = 0; i <= k; ++i) {  // h_i = v_i·w ; w -= h_i v_i ; the last axpy also yields ‖w‖²
+      NK_TRY(nk_blas_multidot(ctx, n, 1, G->V + (size_t)i * ldv, ldv, wk, G->d_h + i, false, skip, G->d_s + i));
+      NK_TRY(nk_blas_multiaxpy(ctx, n, 1, G->V + (size_t)i * ldv, ldv, G->d_h + i, -1.0, wk,
+                               i == k ? G->d_ss : nullptr, skip, nullptr, G->d_s + i));
     }
     hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, (const double *)nullptr, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->m);
-  } else if (G->ortho == NK_ORTHO_CGS2) {
-    NK_TRY(nk_blas_multidot(ctx, n, k + 1, G->V, ldv, G->w, G->d_h, false, skip));
-    NK_TRY(nk_blas_multiaxpy(ctx, n, k + 1, G->V, ldv, G->d_h, -1.0, G->w, nullptr, skip, nullptr));
-    NK_TRY(nk_blas_multidot(ctx, n, k + 1, G->V, ldv, G->w, G->d_h2, false, skip));
-    NK_TRY(nk_blas_multiaxpy(ctx, n, k + 1, G->V, ldv, G->d_h2, -1.0, G->w, G->d_ss, skip, nullptr));
+                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0);
+  } else {
+    const bool dgks = (G->ortho == NK_ORTHO_CGS);
+    const int *skip2 = dgks ? &G->d_ctl->pad0 : skip;
+    // pass 1: h = Vᵀw (DGKS also needs ‖w‖² → self slot h[k+1])
+    NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, G->d_h, dgks, skip, G->d_s));
+    if (nv <= 32) {
+      // pass 2 (fused): w ← w − V h ; h2 = Vᵀw ; h2[nv] = ‖w‖²
+      NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, G->d_h2, skip));
+    } else {
+      NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h, -1.0, wk, G->d_h2 + nv, skip, nullptr, G->d_s));
+      NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, G->d_h2, false, skip, G->d_s));
+    }
+    if (dgks)
+      hipLaunchKernelGGL(k_dgks, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, G->d_h2, G->d_ss,
+                         1.0 / (double)ctx->nranks);
+    // pass 3: w ← w − V h2 ; ‖w‖²   (CGS2: always; CGS+DGKS: only when the test asked for it)
+    // single rank + CGS2: the ‖w‖² partials are reduced inside k_givens (one launch less per Arnoldi step)
+    const bool fold = (!dgks && ctx->nranks == 1);
+    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, fold ? NK_SUMSQ_PARTIALS_ONLY : G->d_ss, skip2,
+                             nullptr, G->d_s));
     hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->m);
-  } else {  // CGS + DGKS
-    const int *skip2 = &G->d_ctl->pad0;
-    NK_TRY(nk_blas_multidot(ctx, n, k + 1, G->V, ldv, G->w, G->d_h, true, skip));  // h[k+1] = ‖w‖²
-    NK_TRY(nk_blas_multiaxpy(ctx, n, k + 1, G->V, ldv, G->d_h, -1.0, G->w, G->d_ss + 1, skip, nullptr));
-    // no re-orthogonalisation ⇒ k_dgks zeroes h2 and parks ss1/nranks in d_ss[0] (the unconditional
-    // all-reduce inside the skipped pass-2 axpy restores ss1); otherwise pass 2 overwrites d_ss[0].
-    hipLaunchKernelGGL(k_dgks, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, G->d_ss + 1, G->d_h2, G->d_ss,
-                       1.0 / (double)ctx->nranks);
-    NK_TRY(nk_blas_multidot(ctx, n, k + 1, G->V, ldv, G->w, G->d_h2, false, skip2));
-    NK_TRY(nk_blas_multiaxpy(ctx, n, k + 1, G->V, ldv, G->d_h2, -1.0, G->w, G->d_ss, skip2, nullptr));
-    hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->m);
+                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m,
+                       fold ? (const double *)ctx->d_partials_ss : (const double *)nullptr, fold ? ctx->last_red_grid : 0);
   }
   NK_HIP(hipGetLastError());
-  // v_{k+1} = w / h_{k+1,k}
-  return nk_blas_scale_to(ctx, n, &G->d_ctl->inv_hn, G->w, G->V + (size_t)(k + 1) * ldv, skip);
+  return NK_OK;
 }
 
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
@@ -267,35 +316,32 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   const int cap = fixed_iters > 0 ? fixed_iters : maxiter;
   nk_gmres_info inf;
   memset(&inf, 0, sizeof(inf));
-  ctx->stats.nsolve += 0;  // nsolve is counted by the nonlinear driver (LinearSolveJLCache functor)
-  // r0 = b − A x0
-  const double *rsrc = d_b;
+  // r0 = b − A x0, written straight into column 0 of the basis (un-normalised)
   if (!use_x0) {
     NK_TRY(nk_blas_fill(ctx, n, 0.0, d_x));
+    NK_TRY(nk_blas_copy(ctx, n, d_b, G->V));
   } else {
     if (G->prec) NK_FAIL(NK_E_UNSUPPORTED, "use_x0 with a right preconditioner is not supported");
-    NK_TRY(op_apply(G, d_x, G->w, nullptr));
-    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->w, G->r));
-    rsrc = G->r;
+    NK_TRY(op_apply(G, d_x, G->r, nullptr, nullptr));
+    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
   }
   int first = 1;
   int total_iters = 0;
   for (;;) {
-    NK_TRY(nk_blas_sumsq(ctx, n, rsrc, G->d_ss));
+    NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
     hipLaunchKernelGGL(k_gmres_begin, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_ss, atol, rtol,
-                       fixed_iters > 0 ? 1 : 0, first, G->d_g, m);
+                       fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m);
     first = 0;
-    NK_TRY(nk_blas_scale_to(ctx, n, &G->d_ctl->inv_hn, rsrc, G->V, &G->d_ctl->done));
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
     for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step(G, k));
-    // x += M⁻¹ V y
+    // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
     hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_R, G->d_g, G->d_y, m);
     if (!G->prec) {
-      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k));
+      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s));
     } else {
-      NK_TRY(nk_blas_fill(ctx, n, 0.0, G->w));
-      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, G->w, nullptr, nullptr, &G->d_ctl->k));
-      if (G->prec(G->prec_user, G->w, G->z, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
+      NK_TRY(nk_blas_fill(ctx, n, 0.0, G->r));
+      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, G->r, nullptr, nullptr, &G->d_ctl->k, G->d_s));
+      if (G->prec(G->prec_user, G->r, G->z, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
       NK_TRY(nk_blas_axpby(ctx, n, 1.0, G->z, 1.0, d_x));
     }
     NK_HIP(hipMemcpyAsync(G->h_ctl, G->d_ctl, sizeof(nk_gmres_ctl), hipMemcpyDeviceToHost, ctx->stream));
@@ -308,19 +354,13 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     inf.failed = c.failed;
     if (c.failed || c.converged || total_iters >= cap || steps == 0) break;
     inf.restarts++;
-    // restart: r = b − A x
-    if (G->prec) {
-      // A x directly (x is in the original space): bypass the preconditioner
-      nk_matvec_fn p = G->prec;
-      G->prec = nullptr;
-      int st = op_apply(G, d_x, G->w, nullptr);
-      G->prec = p;
-      NK_TRY(st);
-    } else {
-      NK_TRY(op_apply(G, d_x, G->w, nullptr));
-    }
-    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->w, G->r));
-    rsrc = G->r;
+    // restart: r = b − A x into column 0
+    nk_matvec_fn p = G->prec;
+    G->prec = nullptr;  // A x directly: x lives in the original space
+    int st = op_apply(G, d_x, G->r, nullptr, nullptr);
+    G->prec = p;
+    NK_TRY(st);
+    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
   }
   inf.iters = total_iters;
   ctx->stats.gmres_iters += total_iters;

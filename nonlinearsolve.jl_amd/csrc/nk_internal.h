@@ -34,6 +34,8 @@ void nk_set_error(const char *fmt, ...);
 // ----------------------------------------------------------------------------- context
 constexpr int NK_BLOCK = 256;          // 4 wavefronts of 64
 constexpr int NK_MAX_RED_BLOCKS = 1024; // stage-1 reduction blocks (4 per CU)
+constexpr int NK_LDV_PAD_DEFAULT = 544;   // extra elements between basis columns (tuned on hardware)
+constexpr int NK_DOT_BLOCKS = 512;      // multi-dot kernels: fewer, fatter blocks (epilogue = NV block reductions)
 constexpr int NK_MAX_NV = 64;          // max simultaneous dot products (restart m ≤ 63)
 
 // per-kernel-family timing with HIP events on the launch stream (bench/roofline evidence; off by default)
@@ -64,6 +66,8 @@ struct nk_ctx {
   nk_comm_callbacks cb{};
   // scratch
   double *d_partials = nullptr;  // NK_MAX_NV * NK_MAX_RED_BLOCKS doubles
+  double *d_partials_ss = nullptr;  // ‖·‖² partials of the axpy kernels (own buffer: survives later multidots)
+  int last_red_grid = 0;
   double *d_scal = nullptr;      // 4*NK_MAX_NV doubles of device scalars
   double *h_pinned = nullptr;    // 4*NK_MAX_NV doubles pinned host
   nk_stats stats{};
@@ -104,6 +108,7 @@ struct nk_csr {
   double *d_val = nullptr;
   int32_t *d_rowblocks = nullptr;
   int nblocks = 0;
+  int tile = 2048, variant = 0;  // SpMV kernel configuration (tunable via NK_SPMV_TILE / NK_SPMV_VARIANT)
   nk_halo halo;
   std::vector<int64_t> halo_gcols;  // global column of each halo slot
   // host copies of the pattern (needed for transpose / banded LU / colouring)
@@ -114,7 +119,8 @@ struct nk_csr {
   bool t_values_stale = true;
   double *d_xtmp = nullptr, *d_ytmp = nullptr;  // staging for host-memspace calls
 };
-int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip);
+// d_out_scale (nullable): y = (*d_out_scale) · A x   (lagged normalisation of the Krylov basis)
+int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr);
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
 int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
                         const std::vector<int32_t> &rowptr, const std::vector<int64_t> &gcol,
@@ -143,7 +149,8 @@ struct nk_problem {
 };
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
 int nk_problem_jvp_prepare(nk_problem *P, const double *d_u);  // linearise at u (u must stay alive)
-int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip);
+int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
+                       const double *d_out_scale = nullptr);
 int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
 
@@ -152,11 +159,15 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
 int nk_blas_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *d_out);
 int nk_blas_sumsq(nk_ctx *ctx, int64_t n, const double *x, double *d_out);
 int nk_blas_norm_inf(nk_ctx *ctx, int64_t n, const double *x, double *d_out);
+// d_scales (nullable): per-column scale s_j of a lazily-normalised basis; h_j = s_j (ṽ_j·w), coefficient h_j s_j
 int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w,
-                     double *d_h, bool with_self, const int *d_skip);
+                     double *d_h, bool with_self, const int *d_skip, const double *d_scales);
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq /*nullable*/, const int *d_skip,
-                      const int *d_nv /*nullable: device count overrides nv*/);
+                      const int *d_nv /*nullable: device count overrides nv*/, const double *d_scales);
+#define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
+int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
+                           const double *d_scales, double *w, double *d_h2, const int *d_skip);
 int nk_blas_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y);  // y = a x + b y
 int nk_blas_scale_to(nk_ctx *ctx, int64_t n, const double *d_scale, const double *x, double *y,
                      const int *d_skip);  // y = (*d_scale) * x
@@ -179,6 +190,7 @@ struct nk_gmres {
   double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
          *d_g = nullptr, *d_y = nullptr, *d_ss = nullptr;
+  double *d_s = nullptr;  // s_j: the basis is stored un-normalised, v_j = s_j ṽ_j (lagged normalisation)
   nk_gmres_ctl *d_ctl = nullptr, *h_ctl = nullptr;
   // operator
   int op_kind = 0;  // 0 none, 1 csr, 2 problem jvp, 3 fn

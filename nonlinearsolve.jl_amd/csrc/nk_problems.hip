@@ -27,10 +27,11 @@ __global__ __launch_bounds__(NK_BLOCK) void k_quad_residual(int64_t n, double p,
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_quad_jvp(int64_t n, const double *__restrict__ u,
                                                        const double *__restrict__ v, double *__restrict__ jv,
-                                                       const int *d_skip) {
+                                                       const int *d_skip, const double *__restrict__ out_scale) {
   SKIP_GUARD(d_skip);
+  const double os = out_scale ? *out_scale : 1.0;
   const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
-  if (i < n) jv[i] = 2.0 * u[i] * v[i];
+  if (i < n) jv[i] = os * (2.0 * u[i] * v[i]);
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_quad_jac(int64_t n, const double *__restrict__ u,
                                                        double *__restrict__ vals) {
@@ -69,12 +70,14 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_diag(int64_t n, double c_exp
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp(int64_t ns, int64_t nl, double c_lap,
                                                         const double *__restrict__ d, const double *__restrict__ v,
                                                         const double *__restrict__ lo, const double *__restrict__ hi,
-                                                        double *__restrict__ jv, const int *d_skip) {
+                                                        double *__restrict__ jv, const int *d_skip,
+                                                        const double *__restrict__ out_scale) {
   SKIP_GUARD(d_skip);
+  const double os = out_scale ? *out_scale : 1.0;
   const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
   if (k >= ns * nl) return;
   const int64_t jl = k / ns, i = k - jl * ns;
-  jv[k] = c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * v[k];
+  jv[k] = os * (c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * v[k]);
 }
 // values in pattern order [S?][W?][C][E?][N?] (columns ascending); j = global grid line
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
@@ -126,8 +129,9 @@ __global__ __launch_bounds__(NK_BLOCK) void k_brus_residual(brus_par q, const do
 __global__ __launch_bounds__(NK_BLOCK) void k_brus_jvp(brus_par q, int transpose, const double *__restrict__ U,
                                                        const double *__restrict__ V, const double *__restrict__ lo,
                                                        const double *__restrict__ hi, double *__restrict__ JV,
-                                                       const int *d_skip) {
+                                                       const int *d_skip, const double *__restrict__ out_scale) {
   SKIP_GUARD(d_skip);
+  const double os = out_scale ? *out_scale : 1.0;
   const int64_t t = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
   const int64_t nn = q.N * q.nl;
   if (t >= nn) return;
@@ -137,11 +141,11 @@ __global__ __launch_bounds__(NK_BLOCK) void k_brus_jvp(brus_par q, int transpose
   const double la = q.alpha * brus_lap(V, lo, hi, q, i, jl), lb = q.alpha * brus_lap(V + nn, lo1, hi1, q, i, jl);
   const double d11 = 2.0 * uu * vv - (q.A + 1.0), d12 = uu * uu, d21 = q.A - 2.0 * uu * vv, d22 = -uu * uu;
   if (!transpose) {
-    JV[t] = la + d11 * a + d12 * b;
-    JV[nn + t] = lb + d21 * a + d22 * b;
+    JV[t] = os * (la + d11 * a + d12 * b);
+    JV[nn + t] = os * (lb + d21 * a + d22 * b);
   } else {
-    JV[t] = la + d11 * a + d21 * b;
-    JV[nn + t] = lb + d12 * a + d22 * b;
+    JV[t] = os * (la + d11 * a + d21 * b);
+    JV[nn + t] = os * (lb + d12 * a + d22 * b);
   }
 }
 // role per non-zero: 0 α (neighbour) · 1 ∂F1/∂u · 2 ∂F1/∂v · 3 ∂F2/∂v · 4 ∂F2/∂u
@@ -384,7 +388,8 @@ int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
   return NK_OK;
 }
 
-int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip) {
+int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
+                       const double *d_out_scale) {
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
   ctx->stats.op_applies++;
@@ -393,14 +398,15 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
   nk_prof_scope prof_(ctx, NK_K_JVP, 24.0 * (double)n);
   switch (P->kind) {
     case NK_PROBLEM_QUADRATIC:
-      hipLaunchKernelGGL(k_quad_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_u, d_v, d_jv, d_skip);
+      hipLaunchKernelGGL(k_quad_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_u, d_v, d_jv, d_skip,
+                         d_out_scale);
       break;
     case NK_PROBLEM_BRATU2D: {
       const double *lo, *hi;
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
       halo_lines(P, 1, false, &lo, &hi);
       hipLaunchKernelGGL(k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0, P->c_lap,
-                         P->d_diag, d_v, lo, hi, d_jv, d_skip);
+                         P->d_diag, d_v, lo, hi, d_jv, d_skip, d_out_scale);
       break;
     }
     case NK_PROBLEM_BRUSSELATOR2D: {
@@ -408,11 +414,12 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
       halo_lines(P, 2, true, &lo, &hi);
       hipLaunchKernelGGL(k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), 0, d_u, d_v,
-                         lo, hi, d_jv, d_skip);
+                         lo, hi, d_jv, d_skip, d_out_scale);
       break;
     }
     case NK_PROBLEM_USER:
       if (!P->cb.jvp) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no jvp callback");
+      if (d_out_scale) NK_FAIL(NK_E_INVALID, "internal: output scale is not supported for callback JVPs");
       if (P->cb.jvp(P->user, d_v, d_u, d_jv, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "jvp callback failed");
       break;
     default:
@@ -434,7 +441,7 @@ int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
     NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
     halo_lines(P, 2, true, &lo, &hi);
     hipLaunchKernelGGL(k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), 1, d_u, d_v, lo,
-                       hi, d_vj, (const int *)nullptr);
+                       hi, d_vj, (const int *)nullptr, (const double *)nullptr);
     NK_HIP(hipGetLastError());
     return NK_OK;
   }
