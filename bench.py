@@ -67,16 +67,16 @@ def main():
     nls.set_default_context(ctx)
     comm = "none"
     if world > 1:
-        # unique id from rank 0, broadcast as bytes over torch.distributed (RCCL); the library then owns its
-        # own communicator on the compute stream
-        if rank == 0:
-            uid = torch.tensor(list(nls.comm_unique_id()), dtype=torch.uint8, device="cuda")
-        else:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        dist.broadcast(uid, 0)
-        ctx.comm_init_rccl(world, rank, bytes(uid.cpu().tolist()))
-        comm = "rccl"
-
+        # rank 0 creates a ncclUniqueId, torch.distributed broadcasts its 128 bytes, and the library then owns
+        # its own RCCL communicator on the compute stream (nonlinearsolve.jl_amd/dist.py). If that bootstrap
+        # fails the collectives are routed through torch.distributed's RCCL process group instead — same
+        # wire, Python in the loop — and the JSON line says so.
+        try:
+            comm = nls.dist.init_comm(ctx, os.environ.get("NK_COMM", "rccl"))
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] direct RCCL bootstrap failed on rank {rank}: {ex}; using torch.distributed callbacks",
+                  file=sys.stderr)
+            comm = nls.dist.init_comm(ctx, "torch") + "(fallback)"
     # weak scaling: grid side so that every rank owns ≈ n² unknowns; side must be ≥ world lines
     ns = args.n if world == 1 else int(round(args.n * math.sqrt(world)))
     prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))

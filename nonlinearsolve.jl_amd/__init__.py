@@ -4,6 +4,7 @@ step path. Import as `nonlinearsolve_jl_amd` (root-level shim; the directory nam
 Product code: csrc/ (HIP kernels + C ABI → lib/libmi355x_nk.so), _lib.py (ctypes), core.py (host mirror of
 the reference interface). Nothing here imports oracle/."""
 from ._lib import NKError, LIB_PATH, build  # noqa: F401
+from . import dist  # noqa: F401
 from .core import (  # noqa: F401
     Context, default_context, set_default_context, partition_range, comm_unique_id,
     CSRMatrix, DeviceProblem, Quadratic, Bratu2D, Brusselator2D,

@@ -1,0 +1,163 @@
+"""Multi-rank code path of libmi355x_nk on ONE GPU: two processes share cuda:0, collectives go through the
+library's callback communicator over torch.distributed/gloo. Everything except the RCCL calls themselves is the
+code that runs on 2–8 GPUs: row-range partition, halo plans (grid lines and general CSR), halo gather kernels,
+placement of the all-reduces in GMRES and in the Newton driver. Results must equal the serial oracle.
+A second test drives the dlopen'ed RCCL entry points on a 1-rank communicator."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nonlinearsolve_jl_amd as nls
+        from oracle import reference_restatement as R
+        torch.cuda.set_device(0)
+        ctx = nls.Context(device=0)
+        nls.set_default_context(ctx)
+        assert nls.dist.init_comm(ctx, "torch") == "torch"
+        assert ctx.comm_info() == (2, world, rank)
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(7)
+
+        # ---------------- Bratu: partition by grid lines, halo = one line per neighbour
+        ns = 20
+        pb = R.Bratu2D(ns)
+        P = nls.Bratu2D(ns)
+        b, e = P.row_begin, P.row_begin + P.n_local
+        assert (b, e) == tuple(x for x in nls.partition_range(ns * ns, ns, world, rank))
+        u, v = 0.2 * rng.standard_normal(pb.n), rng.standard_normal(pb.n)
+        ul, vl = torch.tensor(u[b:e], device=dev), torch.tensor(v[b:e], device=dev)
+        assert np.allclose(P.residual(ul).cpu().numpy(), pb.f(u)[b:e], rtol=1e-13, atol=1e-14)
+        assert np.allclose(P.jvp(vl, ul).cpu().numpy(), pb.jvp(v, u)[b:e], rtol=1e-13, atol=1e-12)
+        # assembled, row-partitioned CSR with a general halo plan (collective setup)
+        J = P.jac_csr()
+        P.jac_values(ul, J)
+        info = J.info()
+        assert info["nrows_local"] == e - b and info["n_halo"] == ns  # one neighbour line
+        assert np.allclose(J.matvec(vl).cpu().numpy(), (pb.jac(u) @ v)[b:e], rtol=1e-13, atol=1e-11)
+        # distributed GMRES on the CSR operator vs the serial oracle
+        rhs = rng.standard_normal(pb.n)
+        xref, iref = R.gmres(lambda z: pb.jac(u) @ z, rhs, rtol=1e-9, restart=30, itmax=3000)
+        for ortho in ("cgs2", "mgs", "cgs"):
+            G = nls.GMRES(e - b, restart=30, ortho=ortho).set_operator(J)
+            x, gi = G.solve(torch.tensor(rhs[b:e], device=dev), reltol=1e-9, maxiters=3000)
+            xg = nls.dist.gather_vector(x, pb.n, b)
+            assert gi["converged"] and np.linalg.norm(xg - xref) <= 1e-7 * np.linalg.norm(xref), ortho
+            assert abs(gi["iters"] - iref.iters) <= max(3, iref.iters // 20)
+        # distributed Newton–Krylov (matrix-free and concrete J) vs the serial oracle
+        ref = R.solve(pb, R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2()),
+                      abstol=1e-9, maxiters=50)
+        for concrete in (False, True):
+            prob = nls.NonlinearProblem(P, u0=torch.zeros(e - b, dtype=torch.float64, device=dev))
+            sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=nls.EisenstatWalkerForcing2(),
+                                                    concrete_jac=concrete), abstol=1e-9, maxiters=50)
+            ug = nls.dist.gather_vector(sol.u, pb.n, b)
+            assert sol.retcode == "Success"
+            assert np.max(np.abs(ug - ref.u)) <= 1e-7
+            assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
+            assert sol.stats.allreduces > 0 and sol.stats.halo_exchanges > 0
+
+        # ---------------- Brusselator: periodic halo (with 2 ranks the same peer is both neighbours)
+        N = 10
+        rb_ = R.Brusselator2D(N)
+        PB = nls.Brusselator2D(N)
+        j0, j1 = nls.partition_range(N, 1, world, rank)
+        nl = j1 - j0
+        # local (i, j_local, species) layout ↔ reference ordering i + N j + N² s
+        idx = np.array([i + N * (j0 + jl) + N * N * s for s in range(2) for jl in range(nl) for i in range(N)])
+        assert PB.n_local == idx.size
+        ub, vb = rb_.u0() + 0.1 * rng.standard_normal(rb_.n), rng.standard_normal(rb_.n)
+        ubl, vbl = torch.tensor(ub[idx], device=dev), torch.tensor(vb[idx], device=dev)
+        assert np.allclose(PB.initial_guess(device=True).cpu().numpy(), rb_.u0()[idx], rtol=1e-14)
+        assert np.allclose(PB.residual(ubl).cpu().numpy(), rb_.f(ub)[idx], rtol=1e-12, atol=1e-10)
+        assert np.allclose(PB.jvp(vbl, ubl).cpu().numpy(), rb_.jvp(vb, ub)[idx], rtol=1e-12, atol=1e-9)
+        assert np.allclose(PB.vjp(vbl, ubl).cpu().numpy(), rb_.vjp(vb, ub)[idx], rtol=1e-12, atol=1e-9)
+        JB = PB.jac_csr()
+        PB.jac_values(ubl, JB)
+        assert np.allclose(JB.matvec(vbl).cpu().numpy(), (rb_.jac(ub) @ vb)[idx], rtol=1e-12, atol=1e-8)
+        # TrustRegion + GMRES on the partitioned Brusselator (matrix-free JVP/VJP) vs the serial oracle
+        oc = R.init(rb_, R.TrustRegion(linsolve=R.KrylovJL_GMRES(gmres_restart=30, maxiters=4000)), abstol=1e-8,
+                    maxiters=25)
+        oc.lin_reltol, oc.lin_abstol = 1e-10, 0.0
+        refb = oc.solve()
+        probb = nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True))
+        solb = nls.solve(probb, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=4000,
+                                                                            reltol=1e-10, abstol=0.0)),
+                         abstol=1e-8, maxiters=25)
+        assert solb.retcode == "Success" and solb.stats.nsteps == refb.stats.nsteps
+        assert np.max(np.abs(solb.u.cpu().numpy() - refb.u[idx])) <= 1e-7
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_callback_comm():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def _rccl_worker(q):
+    sys.path.insert(0, ROOT)
+    os.environ["NK_FORCE_COLLECTIVES"] = "1"
+    try:
+        import nonlinearsolve_jl_amd as nls
+        from oracle import reference_restatement as R
+        ctx = nls.Context(device=0)
+        nls.set_default_context(ctx)
+        ctx.comm_init_rccl(1, 0, nls.comm_unique_id())
+        assert ctx.comm_info() == (1, 1, 0)
+        prob = nls.NonlinearProblem(nls.Bratu2D(24))
+        sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=nls.EisenstatWalkerForcing2()),
+                        abstol=1e-9, maxiters=50)
+        ref = R.solve(R.Bratu2D(24), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2()),
+                      abstol=1e-9, maxiters=50)
+        assert sol.retcode == "Success" and np.max(np.abs(sol.u - ref.u)) <= 1e-7
+        assert sol.stats.allreduces > 50  # ncclAllReduce really ran (sum and max) on the compute stream
+        q.put("ok")
+    except Exception:
+        import traceback
+        q.put("FAIL: " + traceback.format_exc())
+
+
+def test_rccl_entry_points_world1():
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce(sum,max) through the dlopen'ed librccl on one GPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=280)
+    p.join(timeout=60)
+    assert res == "ok", res
