@@ -56,14 +56,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev  # BENCH_BACKEND=gloo lets two ranks share one GPU (code-path dry run only)
+    torch.cuda.set_device(dev_index)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import nonlinearsolve_jl_amd as nls
 
-    ctx = nls.Context(device=local_rank)
+    ctx = nls.Context(device=dev_index)
     nls.set_default_context(ctx)
     comm = "none"
     if world > 1:
@@ -72,7 +78,7 @@ def main():
         # fails the collectives are routed through torch.distributed's RCCL process group instead — same
         # wire, Python in the loop — and the JSON line says so.
         try:
-            comm = nls.dist.init_comm(ctx, os.environ.get("NK_COMM", "rccl"))
+            comm = nls.dist.init_comm(ctx, os.environ.get("NK_COMM", "rccl" if backend == "nccl" else "torch"))
         except Exception as ex:  # noqa: BLE001
             print(f"[bench] direct RCCL bootstrap failed on rank {rank}: {ex}; using torch.distributed callbacks",
                   file=sys.stderr)
@@ -107,7 +113,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     steps_per_s = args.steps / dt
@@ -127,10 +133,28 @@ def main():
     roof = None
     if dom in kernels:
         k = kernels[dom]
-        roof = {"kernel": "k_spmv_stream" if dom == "spmv" else "k_bratu_jvp", "bound": "hbm",
+        kname = "k_spmv_stream" if dom == "spmv" else "k_bratu_jvp"
+        # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE/WRITE_SIZE,
+        # separate --pmc runs, gfx950 ×2 correction on FETCH_SIZE — tools/pmc_summary.py). bench.py cannot collect
+        # PMC counters itself; the same kernel at the same size is a per-launch constant. null if no profile.
+        traffic, tsrc = None, None
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+            if cand and world == 1 and ns == 1024:
+                pm = json.load(open(cand[-1]))
+                for key, v in pm.items():
+                    if key.startswith(kname):
+                        traffic, tsrc = int(v["hbm_bytes_per_launch"]), os.path.basename(cand[-1])
+        except Exception:  # noqa: BLE001
+            pass
+        roof = {"kernel": kname, "bound": "hbm",
                 "achieved": round(k["gbps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(k["gbps"] / HBM_PEAK_GBS, 4), "frac_of_achievable_6.29TBs": round(k["gbps"] / HBM_ACHIEVABLE_GBS, 4),
-                "traffic": None, "launches": k["launches"], "avg_us": round(k["avg_us"], 2),
+                "frac": round(k["gbps"] / HBM_PEAK_GBS, 4),
+                "frac_of_achievable_6.29TBs": round(k["gbps"] / HBM_ACHIEVABLE_GBS, 4),
+                "traffic": traffic, "traffic_source": tsrc, "launches": k["launches"],
+                "avg_us": round(k["avg_us"], 2),
+                "timing": "hipExtLaunchKernelGGL start/stop events (kernel begin→end on the launch stream)",
                 "algorithmic_bytes_per_launch": int(k["bytes"] / k["launches"])}
     ksum = {name: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbps"], 1),
                    "frac_of_8TBs": round(v["gbps"] / HBM_PEAK_GBS, 4), "share_of_step_time": None}

@@ -219,8 +219,10 @@ int nk_ctx_synchronize(nk_ctx *ctx);
 /* deterministic=1 (default): fixed-order two-stage reductions, bitwise reproducible run to run. */
 int nk_ctx_set_deterministic(nk_ctx *ctx, int deterministic);
 
-/* Per-kernel-family timing with HIP events recorded on the context's stream (bench.py's roofline numbers).
- * Off by default; when on, every launch of a profiled family is bracketed by two events. */
+/* Per-kernel-family timing (bench.py's roofline numbers). Off by default; when on, every launch of a profiled
+ * family is issued with hipExtLaunchKernelGGL start/stop events, i.e. the kernel's own begin/end device
+ * timestamps on the context's stream — the quantity rocprofv3's kernel trace reports. `launches` counts logical
+ * operations (a multidot over 31 columns is one operation although it is two kernel launches). */
 int nk_ctx_profile_enable(nk_ctx *ctx, int on);          /* on=1 also resets the accumulators */
 int nk_ctx_profile_kernel_count(void);
 int nk_ctx_profile_query(nk_ctx *ctx, int kernel_id, const char **name, int64_t *launches,

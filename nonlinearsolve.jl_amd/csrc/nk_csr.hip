@@ -414,12 +414,12 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
   if (A->nblocks > 0) {
 #define SPMV_LAUNCH(T, B, R)                                                                                      \
-  hipLaunchKernelGGL((k_spmv_stream<T, B, R>), dim3(A->nblocks), dim3(NK_BLOCK), 0, ctx->stream, A->nblocks,      \
+  NK_LAUNCH(ctx, (k_spmv_stream<T, B, R>), dim3(A->nblocks), dim3(NK_BLOCK), A->nblocks,      \
                      (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, \
                      d_skip, d_out_scale)
     if (A->variant == 3) {
       const int grid = nk_grid_for(A->nrows, NK_BLOCK / 8, 1 << 20);
-      hipLaunchKernelGGL(k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, A->nrows, A->d_rowptr, A->d_col,
+      NK_LAUNCH(ctx, k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col,
                          A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);
     } else if (A->variant == 2) {
       if (A->tile == 512) SPMV_LAUNCH(512, false, false);
@@ -475,7 +475,7 @@ int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y) {
   if (!A->T) NK_TRY(build_transpose(A));
   if (A->t_values_stale && A->nnz) {
     const int grid = (int)((A->nnz + NK_BLOCK - 1) / NK_BLOCK);
-    hipLaunchKernelGGL(k_permute_vals, dim3(grid), dim3(NK_BLOCK), 0, A->ctx->stream, A->nnz, A->d_tperm, A->d_val,
+    NK_LAUNCH(A->ctx, k_permute_vals, dim3(grid), dim3(NK_BLOCK), A->nnz, A->d_tperm, A->d_val,
                        A->T->d_val);
     A->t_values_stale = false;
   }

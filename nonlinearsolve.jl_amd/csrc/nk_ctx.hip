@@ -46,6 +46,7 @@ extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   ctx->stream = (hipStream_t)stream;  // NULL = the device's default (null) stream, as in every HIP API
   NK_TRY(nk_dev_alloc(&ctx->d_partials, (size_t)(NK_MAX_NV + 2) * NK_MAX_RED_BLOCKS));
+  NK_TRY(nk_dev_alloc(&ctx->d_partials2, (size_t)(NK_MAX_NV + 2) * NK_MAX_RED_BLOCKS));
   NK_TRY(nk_dev_alloc(&ctx->d_partials_ss, (size_t)NK_MAX_RED_BLOCKS));
   NK_TRY(nk_dev_alloc(&ctx->d_scal, (size_t)4 * NK_MAX_NV));
   NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV, hipHostMallocDefault));
@@ -59,6 +60,7 @@ extern "C" int nk_ctx_destroy(nk_ctx *ctx) {
   hipStreamSynchronize(ctx->stream);
   nk_comm_destroy(ctx);
   hipFree(ctx->d_partials);
+  hipFree(ctx->d_partials2);
   hipFree(ctx->d_partials_ss);
   hipFree(ctx->d_scal);
   hipHostFree(ctx->h_pinned);
@@ -86,8 +88,15 @@ extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {
 // ----------------------------------------------------------------------------- kernel-family profiling
 static const char *k_names[NK_K_COUNT] = {"spmv", "multidot", "multiaxpy", "jvp", "residual", "scale",
                                           "reduce_small", "jacfill", "newton_update", "other"};
-void nk_prof_begin(nk_ctx *ctx, int id, double bytes) {
+void nk_prof_scope_begin(nk_ctx *ctx, int id, double bytes) {
+  ctx->prof.cur_id = id;
+  ctx->prof.cur_bytes = bytes;
+}
+void nk_prof_scope_end(nk_ctx *ctx) { ctx->prof.cur_id = -1; }
+// hands out the event pair for the next launch of the active scope (false: no scope active → plain launch)
+bool nk_prof_next(nk_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
   nk_prof &p = ctx->prof;
+  if (p.cur_id < 0) return false;
   if (p.used + 2 > p.ev.size()) {
     if (p.ev.size() >= 16384) nk_prof_flush(ctx);
     else {
@@ -96,14 +105,13 @@ void nk_prof_begin(nk_ctx *ctx, int id, double bytes) {
       for (size_t i = old; i < p.ev.size(); ++i) hipEventCreate(&p.ev[i]);
     }
   }
-  p.ids.push_back(id);
-  p.nbytes.push_back(bytes);
-  hipEventRecord(p.ev[p.used], ctx->stream);
-}
-void nk_prof_end(nk_ctx *ctx) {
-  nk_prof &p = ctx->prof;
-  hipEventRecord(p.ev[p.used + 1], ctx->stream);
+  p.ids.push_back(p.cur_id);
+  p.nbytes.push_back(p.cur_bytes);  // a scope's bytes are attributed to its first launch
+  p.cur_bytes = 0.0;
+  *start = p.ev[p.used];
+  *stop = p.ev[p.used + 1];
   p.used += 2;
+  return true;
 }
 void nk_prof_flush(nk_ctx *ctx) {
   nk_prof &p = ctx->prof;
@@ -114,7 +122,7 @@ void nk_prof_flush(nk_ctx *ctx) {
     if (hipEventElapsedTime(&ms, p.ev[2 * r], p.ev[2 * r + 1]) == hipSuccess) {
       p.ms[p.ids[r]] += ms;
       p.bytes[p.ids[r]] += p.nbytes[r];
-      p.count[p.ids[r]]++;
+      if (p.nbytes[r] > 0.0 || p.ids[r] == NK_K_REDUCE_SMALL || p.ids[r] == NK_K_OTHER) p.count[p.ids[r]]++;
     }
   }
   p.ids.clear();
@@ -257,6 +265,10 @@ void nk_comm_destroy(nk_ctx *ctx) {
   ctx->rank = 0;
 }
 
+bool nk_ctx_is_single(const nk_ctx *ctx) {
+  static const bool force = getenv("NK_FORCE_COLLECTIVES") != nullptr;
+  return ctx->nranks <= 1 && !(force && ctx->comm_kind != NK_COMM_NONE);
+}
 int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op) {
   // NK_FORCE_COLLECTIVES=1: issue the collective even on a 1-rank communicator (exercises the RCCL entry points
   // on a single GPU; used by tests only)
@@ -339,7 +351,7 @@ int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
   const int P = ctx->nranks;
   if (H->n_send) {
     int grid = (int)((H->n_send + NK_BLOCK - 1) / NK_BLOCK);
-    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, H->n_send, H->d_send_idx,
+    NK_LAUNCH(ctx, k_gather, dim3(grid), dim3(NK_BLOCK), H->n_send, H->d_send_idx,
                        d_x_local, H->d_send);
   }
   // entries a rank "sends to itself" (periodic wrap on one rank) are a device copy

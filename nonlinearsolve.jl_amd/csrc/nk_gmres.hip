@@ -276,11 +276,24 @@ static int arnoldi_step(nk_gmres *G, int k) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, 1, G->V + (size_t)i * ldv, ldv, G->d_h + i, -1.0, wk,
                                i == k ? G->d_ss : nullptr, skip, nullptr, G->d_s + i));
     }
-    hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, (const double *)nullptr, G->d_ss,
+    NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)nullptr, G->d_ss,
                        G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0);
   } else {
     const bool dgks = (G->ortho == NK_ORTHO_CGS);
     const int *skip2 = dgks ? &G->d_ctl->pad0 : skip;
+    // EXPERIMENT (off by default, NK_PROLOGUE_REDUCE=1): fold the stage-2 reductions into the consumers' prologues
+    // (5 launches per Arnoldi step). Measured SLOWER on MI355X (253 vs 282 steps/s): every one of the 512–1024
+    // consumer blocks re-reads all nv×512 partials, ≈130 MB of extra L2/MALL traffic per kernel.
+    static const bool use_pr = getenv("NK_PROLOGUE_REDUCE") != nullptr;
+    if (!dgks && nk_ctx_is_single(ctx) && nv <= 32 && use_pr) {
+      NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, nullptr, false, skip, G->d_s));
+      NK_TRY(nk_blas_cgs2_passes_pr(ctx, n, nv, G->V, ldv, G->d_s, wk, G->d_h, G->d_h2, skip));
+      NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2,
+                         G->d_ss, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)ctx->d_partials_ss,
+                         ctx->last_red_grid);
+      NK_HIP(hipGetLastError());
+      return NK_OK;
+    }
     // pass 1: h = Vᵀw (DGKS also needs ‖w‖² → self slot h[k+1])
     NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, G->d_h, dgks, skip, G->d_s));
     if (nv <= 32) {
@@ -291,16 +304,12 @@ static int arnoldi_step(nk_gmres *G, int k) {
       NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, G->d_h2, false, skip, G->d_s));
     }
     if (dgks)
-      hipLaunchKernelGGL(k_dgks, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, G->d_h2, G->d_ss,
+      NK_LAUNCH(ctx, k_dgks, dim3(1), dim3(64), G->d_ctl, G->d_h, G->d_h2, G->d_ss,
                          1.0 / (double)ctx->nranks);
     // pass 3: w ← w − V h2 ; ‖w‖²   (CGS2: always; CGS+DGKS: only when the test asked for it)
-    // single rank + CGS2: the ‖w‖² partials are reduced inside k_givens (one launch less per Arnoldi step)
-    const bool fold = (!dgks && ctx->nranks == 1);
-    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, fold ? NK_SUMSQ_PARTIALS_ONLY : G->d_ss, skip2,
-                             nullptr, G->d_s));
-    hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m,
-                       fold ? (const double *)ctx->d_partials_ss : (const double *)nullptr, fold ? ctx->last_red_grid : 0);
+    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, G->d_ss, skip2, nullptr, G->d_s));
+    NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss,
+                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0);
   }
   NK_HIP(hipGetLastError());
   return NK_OK;
@@ -329,13 +338,13 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   int total_iters = 0;
   for (;;) {
     NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
-    hipLaunchKernelGGL(k_gmres_begin, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_ss, atol, rtol,
+    NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol,
                        fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m);
     first = 0;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
     for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step(G, k));
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
-    hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(64), 0, ctx->stream, G->d_ctl, G->d_R, G->d_g, G->d_y, m);
+    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(64), G->d_ctl, G->d_R, G->d_g, G->d_y, m);
     if (!G->prec) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s));
     } else {

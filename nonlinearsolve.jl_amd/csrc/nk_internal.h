@@ -1,6 +1,7 @@
 // Internal declarations of libmi355x_nk.so (gfx950 only). Not part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -50,6 +51,8 @@ struct nk_prof {
   std::vector<double> nbytes;
   size_t used = 0;
   double ms[NK_K_COUNT] = {0}, bytes[NK_K_COUNT] = {0};
+  int cur_id = -1;          // kernel family of the active scope (-1: none)
+  double cur_bytes = 0.0;   // algorithmic bytes not yet attributed to a launch of the active scope
   int64_t count[NK_K_COUNT] = {0};
 };
 
@@ -66,6 +69,7 @@ struct nk_ctx {
   nk_comm_callbacks cb{};
   // scratch
   double *d_partials = nullptr;  // NK_MAX_NV * NK_MAX_RED_BLOCKS doubles
+  double *d_partials2 = nullptr;    // second partials buffer (fused pass) for the prologue-reduced variants
   double *d_partials_ss = nullptr;  // ‖·‖² partials of the axpy kernels (own buffer: survives later multidots)
   int last_red_grid = 0;
   double *d_scal = nullptr;      // 4*NK_MAX_NV doubles of device scalars
@@ -73,14 +77,28 @@ struct nk_ctx {
   nk_stats stats{};
 };
 
-void nk_prof_begin(nk_ctx *ctx, int id, double bytes);
-void nk_prof_end(nk_ctx *ctx);
+// true when no collective has to be issued (1 rank and not in the NK_FORCE_COLLECTIVES test mode)
+bool nk_ctx_is_single(const nk_ctx *ctx);
+// Profiling: inside an nk_prof_scope every launch goes through hipExtLaunchKernelGGL with its own start/stop
+// events, which carry the kernel's begin/end device timestamps (the same quantity rocprofv3's kernel trace
+// reports) — not host-side event brackets, which also measure the record overhead and the launch gap.
+void nk_prof_scope_begin(nk_ctx *ctx, int id, double bytes);
+void nk_prof_scope_end(nk_ctx *ctx);
+bool nk_prof_next(nk_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 void nk_prof_flush(nk_ctx *ctx);
-struct nk_prof_scope {  // RAII: brackets the launches issued in its lifetime with two events
+struct nk_prof_scope {
   nk_ctx *c;
-  nk_prof_scope(nk_ctx *ctx, int id, double bytes) : c(ctx->prof.on ? ctx : nullptr) { if (c) nk_prof_begin(c, id, bytes); }
-  ~nk_prof_scope() { if (c) nk_prof_end(c); }
+  nk_prof_scope(nk_ctx *ctx, int id, double bytes) : c(ctx->prof.on ? ctx : nullptr) { if (c) nk_prof_scope_begin(c, id, bytes); }
+  ~nk_prof_scope() { if (c) nk_prof_scope_end(c); }
 };
+#define NK_LAUNCH(ctxp, kern, grid, block, ...)                                                              \
+  do {                                                                                                      \
+    hipEvent_t e0_, e1_;                                                                                    \
+    if ((ctxp)->prof.on && nk_prof_next((ctxp), &e0_, &e1_))                                                \
+      hipExtLaunchKernelGGL(kern, grid, block, 0, (ctxp)->stream, e0_, e1_, 0, __VA_ARGS__);                \
+    else                                                                                                    \
+      hipLaunchKernelGGL(kern, grid, block, 0, (ctxp)->stream, __VA_ARGS__);                                \
+  } while (0)
 int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op /*0 sum,1 max*/);
 int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
                       void *recv, const int64_t *roff, const int64_t *rbytes);
@@ -165,6 +183,8 @@ int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ld
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq /*nullable*/, const int *d_skip,
                       const int *d_nv /*nullable: device count overrides nv*/, const double *d_scales);
+int nk_blas_cgs2_passes_pr(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_scales,
+                           double *w, double *d_h1_out, double *d_h2_out, const int *d_skip);
 #define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
 int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                            const double *d_scales, double *w, double *d_h2, const int *d_skip);

@@ -348,13 +348,13 @@ int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f) {
   nk_prof_scope prof_(ctx, NK_K_RESIDUAL, 16.0 * (double)n);
   switch (P->kind) {
     case NK_PROBLEM_QUADRATIC:
-      hipLaunchKernelGGL(k_quad_residual, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, P->params[1], d_u, d_f);
+      NK_LAUNCH(ctx, k_quad_residual, dim3(grid1(n)), dim3(NK_BLOCK), n, P->params[1], d_u, d_f);
       break;
     case NK_PROBLEM_BRATU2D: {
       const double *lo, *hi;
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
       halo_lines(P, 1, false, &lo, &hi);
-      hipLaunchKernelGGL(k_bratu_residual, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0,
+      NK_LAUNCH(ctx, k_bratu_residual, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0,
                          P->c_lap, P->c_exp, d_u, lo, hi, d_f);
       break;
     }
@@ -362,7 +362,7 @@ int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f) {
       const double *lo, *hi;
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
       halo_lines(P, 2, true, &lo, &hi);
-      hipLaunchKernelGGL(k_brus_residual, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), d_u, lo,
+      NK_LAUNCH(ctx, k_brus_residual, dim3(grid1(n / 2)), dim3(NK_BLOCK), brus_params(P), d_u, lo,
                          hi, d_f);
       break;
     }
@@ -381,7 +381,7 @@ int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
   if (P->kind == NK_PROBLEM_BRATU2D) {
     if (!P->d_diag) NK_TRY(nk_dev_alloc(&P->d_diag, (size_t)P->n_local + 1));
     if (P->n_local)
-      hipLaunchKernelGGL(k_bratu_diag, dim3(grid1(P->n_local)), dim3(NK_BLOCK), 0, P->ctx->stream, P->n_local,
+      NK_LAUNCH(P->ctx, k_bratu_diag, dim3(grid1(P->n_local)), dim3(NK_BLOCK), P->n_local,
                          P->c_exp, d_u, P->d_diag);
     NK_HIP(hipGetLastError());
   }
@@ -398,14 +398,14 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
   nk_prof_scope prof_(ctx, NK_K_JVP, 24.0 * (double)n);
   switch (P->kind) {
     case NK_PROBLEM_QUADRATIC:
-      hipLaunchKernelGGL(k_quad_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_u, d_v, d_jv, d_skip,
+      NK_LAUNCH(ctx, k_quad_jvp, dim3(grid1(n)), dim3(NK_BLOCK), n, d_u, d_v, d_jv, d_skip,
                          d_out_scale);
       break;
     case NK_PROBLEM_BRATU2D: {
       const double *lo, *hi;
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
       halo_lines(P, 1, false, &lo, &hi);
-      hipLaunchKernelGGL(k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0, P->c_lap,
+      NK_LAUNCH(ctx, k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->c_lap,
                          P->d_diag, d_v, lo, hi, d_jv, d_skip, d_out_scale);
       break;
     }
@@ -413,7 +413,7 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
       const double *lo, *hi;
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
       halo_lines(P, 2, true, &lo, &hi);
-      hipLaunchKernelGGL(k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), 0, d_u, d_v,
+      NK_LAUNCH(ctx, k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), brus_params(P), 0, d_u, d_v,
                          lo, hi, d_jv, d_skip, d_out_scale);
       break;
     }
@@ -440,7 +440,7 @@ int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
     const double *lo, *hi;
     NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
     halo_lines(P, 2, true, &lo, &hi);
-    hipLaunchKernelGGL(k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), 0, ctx->stream, brus_params(P), 1, d_u, d_v, lo,
+    NK_LAUNCH(ctx, k_brus_jvp, dim3(grid1(n / 2)), dim3(NK_BLOCK), brus_params(P), 1, d_u, d_v, lo,
                        hi, d_vj, (const int *)nullptr, (const double *)nullptr);
     NK_HIP(hipGetLastError());
     return NK_OK;
@@ -553,10 +553,10 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
   nk_prof_scope prof_(ctx, NK_K_JACFILL, 8.0 * (double)J->nnz + 8.0 * (double)n);
   switch (P->kind) {
     case NK_PROBLEM_QUADRATIC:
-      hipLaunchKernelGGL(k_quad_jac, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_u, J->d_val);
+      NK_LAUNCH(ctx, k_quad_jac, dim3(grid1(n)), dim3(NK_BLOCK), n, d_u, J->d_val);
       break;
     case NK_PROBLEM_BRATU2D:
-      hipLaunchKernelGGL(k_bratu_jac, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, P->ns, P->j1 - P->j0, P->j0,
+      NK_LAUNCH(ctx, k_bratu_jac, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->j0,
                          P->c_lap, P->c_exp, d_u, J->d_rowptr, J->d_val);
       break;
     case NK_PROBLEM_BRUSSELATOR2D: {
@@ -565,7 +565,7 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
         if (pr.first == J) ex = &pr.second;
       NK_REQUIRE(ex, "CSR was not created by nk_problem_jac_csr for a Brusselator problem");
       const brus_par q = brus_params(P);
-      hipLaunchKernelGGL(k_brus_jac, dim3(grid1(J->nnz)), dim3(NK_BLOCK), 0, ctx->stream, J->nnz, q.N * q.nl, q.A,
+      NK_LAUNCH(ctx, k_brus_jac, dim3(grid1(J->nnz)), dim3(NK_BLOCK), J->nnz, q.N * q.nl, q.A,
                          q.alpha, ex->d_role, ex->d_node, d_u, J->d_val);
       break;
     }
@@ -612,7 +612,7 @@ extern "C" int nk_problem_initial_guess(nk_problem *P, double *u0, int memspace)
     case NK_PROBLEM_BRATU2D: NK_TRY(nk_blas_fill(P->ctx, P->n_local, 0.0, d)); break;
     case NK_PROBLEM_BRUSSELATOR2D:
       if (P->n_local)
-        hipLaunchKernelGGL(k_brus_u0, dim3(grid1(P->n_local / 2)), dim3(NK_BLOCK), 0, P->ctx->stream, brus_params(P), d);
+        NK_LAUNCH(P->ctx, k_brus_u0, dim3(grid1(P->n_local / 2)), dim3(NK_BLOCK), brus_params(P), d);
       NK_HIP(hipGetLastError());
       break;
     default: NK_FAIL(NK_E_UNSUPPORTED, "no built-in initial guess for this problem kind");
@@ -713,10 +713,10 @@ extern "C" int nk_jac_values_colored(nk_problem *P, const double *u, int memspac
   P->d_u_lin = nullptr;
   int st = NK_OK;
   for (int c = 0; c < ncolors && st == NK_OK; ++c) {
-    hipLaunchKernelGGL(k_seed, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, d_color, c, d_seed);
+    NK_LAUNCH(ctx, k_seed, dim3(grid1(n)), dim3(NK_BLOCK), n, d_color, c, d_seed);
     st = nk_problem_jvp_dev(P, du, d_seed, d_B, nullptr);
     if (st != NK_OK) break;
-    hipLaunchKernelGGL(k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), 0, ctx->stream, n, J->d_rowptr, d_nnzcolor, c, d_B,
+    NK_LAUNCH(ctx, k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), n, J->d_rowptr, d_nnzcolor, c, d_B,
                        J->d_val);
   }
   hipStreamSynchronize(ctx->stream);

@@ -590,8 +590,8 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
     {
     nk_prof_scope prof_(ctx, NK_K_NEWTON_UPDATE, 24.0 * (double)n);
-    hipLaunchKernelGGL(k_newton_update, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, S->du, S->u, ctx->d_partials);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(NK_BLOCK), 0, ctx->stream, ctx->d_partials, grid, slot(S, 1));
+    NK_LAUNCH(ctx, k_newton_update, dim3(grid), dim3(NK_BLOCK), n, S->du, S->u, ctx->d_partials);
+    NK_LAUNCH(ctx, k_sum_partials, dim3(1), dim3(NK_BLOCK), ctx->d_partials, grid, slot(S, 1));
     }
     NK_HIP(hipGetLastError());
     NK_TRY(nk_comm_allreduce(ctx, slot(S, 1), 1, 0));
