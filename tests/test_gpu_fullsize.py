@@ -1,0 +1,108 @@
+"""Parity at BASELINE.json's full sizes (C3: 1024², C4: 4096² Bratu; C5: Brusselator 512²) — against the C oracle
+where it finishes in seconds, and through size-independent properties (linearity, symmetry, CSR ≡ matrix-free
+JVP, true-residual checks, monotone Newton residuals) where it does not."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("ns", [1024, 4096])
+def test_bratu_fullsize_kernels_vs_c_oracle(nls, dev, ns):
+    import torch
+    n = ns * ns
+    rng = np.random.default_rng(ns)
+    u = 0.3 * rng.standard_normal(n)
+    v = rng.standard_normal(n)
+    P = nls.Bratu2D(ns, 6.0)
+    du, dv = torch.tensor(u, device=dev), torch.tensor(v, device=dev)
+    f = P.residual(du).cpu().numpy()
+    assert relerr(f, CO.bratu_residual(ns, 6.0, 0.0, u)) <= 1e-13
+    jv = P.jvp(dv, du)
+    assert relerr(jv.cpu().numpy(), CO.bratu_jvp(ns, 6.0, 0.0, u, v)) <= 1e-13
+    # assembled CSR: values, SpMV (bit-exact row sums), and CSR·v ≡ matrix-free JVP
+    J = P.jac_csr()
+    P.jac_values(du, J)
+    assert J.info()["nnz"] == 5 * n - 4 * ns
+    rp, ci = CO.bratu_pattern(ns)
+    val = CO.bratu_jac_values(ns, 6.0, 0.0, u, rp)
+    y = J.matvec(dv)
+    assert np.array_equal(y.cpu().numpy(), CO.spmv(rp, ci, val, v))
+    assert float((y - jv).abs().max() / jv.abs().max()) <= 1e-13
+    # symmetry of the Bratu Jacobian: xᵀ(Jy) = yᵀ(Jx), and Jᵀ via the transposed SpMV
+    x2 = torch.tensor(rng.standard_normal(n), device=dev)
+    ctx = nls.default_context()
+    a, b = ctx.dot(x2, J.matvec(dv)), ctx.dot(dv, J.matvec(x2))
+    assert abs(a - b) <= 1e-11 * abs(a)
+    # linearity: J(αx + βy) = αJx + βJy
+    lin = J.matvec(2.5 * x2 - 0.5 * dv) - (2.5 * J.matvec(x2) - 0.5 * J.matvec(dv))
+    assert float(lin.abs().max()) <= 1e-10 * float(J.matvec(x2).abs().max())
+
+
+def test_c3_gmres_true_residual_and_newton_descent(nls, dev):
+    """C3 (1024², matrix-free JVP + GMRES(30)): the recurrence residual equals the true residual ‖b − J x‖, GMRES(30)
+    is monotone, and fixed-work Newton steps reproduce the C oracle's ‖F‖∞ trace and iterate at full size."""
+    import torch
+    ns = 1024
+    n = ns * ns
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+    u = torch.zeros(n, dtype=torch.float64, device=dev)
+    op = nls.StatefulJacobianOperator(nls.JacobianOperator(prob), u)
+    G = nls.GMRES(n, restart=30).set_operator(op)
+    b = prob.device_problem.residual(u)
+    ctx = nls.default_context()
+    last = None
+    for iters in (30, 90):
+        x, info = G.solve(b, fixed_iters=iters)
+        r = b - (op @ x)
+        true = ctx.nrm2(r)
+        assert abs(true - info["rnorm"]) <= 1e-8 * info["rnorm0"]
+        assert info["rnorm"] < info["rnorm0"] and (last is None or info["rnorm"] <= last)
+        last = info["rnorm"]
+    cache = nls.init(nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=u),
+                     nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30)), abstol=1e-300,
+                     maxiters=100, store_trace=True)
+    nsteps = 4
+    for _ in range(nsteps):
+        cache.step()
+    fn = np.array([t["fnorm_inf"] for t in cache.trace])
+    # the same fixed-work protocol on the C oracle (MGS there, CGS2 here): ‖F‖∞ after every step and the iterate
+    uC, fnC, giC, _ = CO.bratu_newton(ns, 6.0, 0.0, np.zeros(n), nsteps, use_csr=False, m=30, itmax=30, fixed_iters=30,
+                                      forcing=False)
+    assert np.all(giC == 30)
+    assert np.allclose(fn, fnC, rtol=1e-6), (fn, fnC)
+    assert np.max(np.abs(cache.u.cpu().numpy() - uC)) <= 1e-9
+    assert cache.stats.gmres_iters == 30 * nsteps and cache.stats.nf == nsteps
+    cache.close()
+
+
+def test_c5_brusselator_512_kernels(nls, dev):
+    """C5 size (N_g = 512, 524 288 unknowns): residual vs the C oracle, JVP/VJP adjointness vᵀ(J w) = wᵀ(Jᵀ v),
+    CSR ≡ matrix-free JVP, and nnz = 6·unknowns."""
+    import torch
+    N = 512
+    P = nls.Brusselator2D(N)
+    u0 = P.initial_guess(device=True)
+    rng = np.random.default_rng(5)
+    u = u0 + torch.tensor(0.1 * rng.standard_normal(2 * N * N), device=dev)
+    f = P.residual(u).cpu().numpy()
+    ref = CO.brusselator_residual(N, 3.4, 1.0, 10.0, 1.0 / (N - 1), u.cpu().numpy())
+    assert relerr(f, ref) <= 1e-12
+    v = torch.tensor(rng.standard_normal(2 * N * N), device=dev)
+    w = torch.tensor(rng.standard_normal(2 * N * N), device=dev)
+    ctx = nls.default_context()
+    a, b = ctx.dot(v, P.jvp(w, u)), ctx.dot(w, P.vjp(v, u))
+    assert abs(a - b) <= 1e-10 * abs(a)
+    J = P.jac_csr()
+    P.jac_values(u, J)
+    assert J.info()["nnz"] == 6 * 2 * N * N
+    jw = P.jvp(w, u)
+    assert float((J.matvec(w) - jw).abs().max() / jw.abs().max()) <= 1e-12
+    jtv = P.vjp(v, u)
+    assert float((J.rmatvec(v) - jtv).abs().max() / jtv.abs().max()) <= 1e-12
