@@ -25,9 +25,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return x * q + (x < r ? x : r) + k;
 }
 
-// TILE: non-zeros per workgroup tile (LDS = 8·TILE bytes). BATCH: issue all of a lane's col/val loads of the
-// tile before the dependent x gathers (more memory-level parallelism per lane) instead of a rolled loop.
-template <int TILE, bool BATCH, bool REMAP>
+// TILE: non-zeros per workgroup tile (LDS = 8·TILE bytes). HALO: columns ≥ nlocal live in the halo buffer.
+// The tile phase is written branch-free on purpose: hipcc turns `if (k < nnzb)` around a load into an exec-mask
+// branch plus a full `s_waitcnt vmcnt(0)` per element (seen in the ISA: one load in flight per wave). Instead
+// every lane issues ALL its col/val loads unconditionally (the arrays are padded by one tile), then all x
+// gathers (out-of-tile lanes gather x[0]), then the LDS writes — TILE/256 independent loads in flight per lane.
+template <int TILE, bool HALO, bool REMAP>
 __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     int nblk, const int4 *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
@@ -45,33 +48,30 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     // row bounds of this lane's first two rows, requested before the tile streams in (they are only needed
     // after the barrier; issuing them here takes an L2 round trip off the block's critical path)
     const int rA = r0 + threadIdx.x, rB = rA + NK_BLOCK;
-    int aA = 0, eA = 0, aB = 0, eB = 0;
-    if (rA < r1) { aA = rowptr[rA]; eA = rowptr[rA + 1]; }
-    if (rB < r1) { aB = rowptr[rB]; eB = rowptr[rB + 1]; }
-    if (BATCH) {
-      constexpr int PER = TILE / NK_BLOCK;
-      int c[PER];
-      double v[PER];
+    const int rAc = rA < r1 ? rA : r0, rBc = rB < r1 ? rB : r0;  // clamped: loads stay unconditional
+    const int aA = rowptr[rAc], eA = rowptr[rAc + 1], aB = rowptr[rBc], eB = rowptr[rBc + 1];
+    constexpr int PER = TILE / NK_BLOCK;
+    int c[PER];
+    double v[PER], xv[PER];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int k = threadIdx.x + NK_BLOCK * i;
-        const bool ok = k < nnzb;
-        c[i] = ok ? col[p0 + k] : 0;
-        v[i] = ok ? val[p0 + k] : 0.0;
-      }
+    for (int i = 0; i < PER; ++i) {
+      const int k = threadIdx.x + NK_BLOCK * i;
+      c[i] = col[p0 + k];  // in bounds: col/val are padded by SPMV_TILE_MAX entries
+      v[i] = val[p0 + k];
+    }
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int k = threadIdx.x + NK_BLOCK * i;
-        const double xv = (c[i] < nlocal) ? x[c[i]] : xhalo[c[i] - nlocal];
-        if (k < nnzb) prod[k] = v[i] * xv;
-      }
-    } else {
-      for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
-        const int c = col[p0 + k];
-        const double xv = (c < nlocal) ? x[c] : xhalo[c - nlocal];
-        prod[k] = val[p0 + k] * xv;
+    for (int i = 0; i < PER; ++i) {
+      const int k = threadIdx.x + NK_BLOCK * i;
+      const int cc = (k < nnzb) ? c[i] : 0;
+      if (HALO) {
+        const double *__restrict__ base = (cc < nlocal) ? x : (xhalo - nlocal);
+        xv[i] = base[cc];
+      } else {
+        xv[i] = x[cc];
       }
     }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) prod[threadIdx.x + NK_BLOCK * i] = v[i] * xv[i];
     __syncthreads();
     if (rA < r1) {
       double s = 0.0;
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     // a single long row: the whole workgroup reduces it (fixed order → deterministic)
     double s = 0.0;
     for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
-      const int c = col[p0 + k];
-      const double xv = (c < nlocal) ? x[c] : xhalo[c - nlocal];
-      s += val[p0 + k] * xv;
+      const int cc = col[p0 + k];
+      const double xx = (cc < nlocal) ? x[cc] : xhalo[cc - nlocal];
+      s += val[p0 + k] * xx;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -197,8 +197,10 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   build_rowblocks(rowptr, rb, A->tile);
   A->nblocks = (int)rb.size() - 1;
   NK_TRY(nk_dev_alloc(&A->d_rowptr, (size_t)nrows + 1));
-  NK_TRY(nk_dev_alloc(&A->d_col, (size_t)nnz));
-  NK_TRY(nk_dev_alloc(&A->d_val, (size_t)nnz));
+  NK_TRY(nk_dev_alloc(&A->d_col, (size_t)nnz + SPMV_TILE_MAX));  // padded: the tile phase reads whole tiles
+  NK_TRY(nk_dev_alloc(&A->d_val, (size_t)nnz + SPMV_TILE_MAX));
+  NK_HIP(hipMemset(A->d_col + nnz, 0, SPMV_TILE_MAX * sizeof(int32_t)));
+  NK_HIP(hipMemset(A->d_val + nnz, 0, SPMV_TILE_MAX * sizeof(double)));
   std::vector<int32_t> desc(4 * (size_t)A->nblocks);
   for (int b = 0; b < A->nblocks; ++b) {
     desc[4 * b + 0] = rb[b];
@@ -413,30 +415,26 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   ctx->stats.op_applies++;
   nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
   if (A->nblocks > 0) {
-#define SPMV_LAUNCH(T, B, R)                                                                                      \
-  NK_LAUNCH(ctx, (k_spmv_stream<T, B, R>), dim3(A->nblocks), dim3(NK_BLOCK), A->nblocks,      \
-                     (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, \
-                     d_skip, d_out_scale)
+#define SPMV_LAUNCH(T, H, R)                                                                                      \
+  NK_LAUNCH(ctx, (k_spmv_stream<T, H, R>), dim3(A->nblocks), dim3(NK_BLOCK), A->nblocks,                          \
+            (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, \
+            d_y, d_skip, d_out_scale)
+#define SPMV_TILES(H, R)                                  \
+  if (A->tile == 512) SPMV_LAUNCH(512, H, R);             \
+  else if (A->tile == 2048) SPMV_LAUNCH(2048, H, R);      \
+  else if (A->tile == 4096) SPMV_LAUNCH(4096, H, R);      \
+  else SPMV_LAUNCH(1024, H, R)
+    const bool halo = A->halo.n_recv > 0;
     if (A->variant == 3) {
       const int grid = nk_grid_for(A->nrows, NK_BLOCK / 8, 1 << 20);
-      NK_LAUNCH(ctx, k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col,
-                         A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);
+      NK_LAUNCH(ctx, k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col, A->d_val, d_x,
+                A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);
     } else if (A->variant == 2) {
-      if (A->tile == 512) SPMV_LAUNCH(512, false, false);
-      else if (A->tile == 1024) SPMV_LAUNCH(1024, false, false);
-      else if (A->tile == 4096) SPMV_LAUNCH(4096, false, false);
-      else SPMV_LAUNCH(2048, false, false);
-    } else if (A->variant == 1) {
-      if (A->tile == 512) SPMV_LAUNCH(512, true, true);
-      else if (A->tile == 1024) SPMV_LAUNCH(1024, true, true);
-      else if (A->tile == 4096) SPMV_LAUNCH(4096, true, true);
-      else SPMV_LAUNCH(2048, true, true);
+      if (halo) { SPMV_TILES(true, false); } else { SPMV_TILES(false, false); }
     } else {
-      if (A->tile == 512) SPMV_LAUNCH(512, false, true);
-      else if (A->tile == 1024) SPMV_LAUNCH(1024, false, true);
-      else if (A->tile == 4096) SPMV_LAUNCH(4096, false, true);
-      else SPMV_LAUNCH(2048, false, true);
+      if (halo) { SPMV_TILES(true, true); } else { SPMV_TILES(false, true); }
     }
+#undef SPMV_TILES
 #undef SPMV_LAUNCH
   }
   NK_HIP(hipGetLastError());

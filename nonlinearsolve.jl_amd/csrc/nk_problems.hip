@@ -41,17 +41,19 @@ __global__ __launch_bounds__(NK_BLOCK) void k_quad_jac(int64_t n, const double *
 
 // ============================================================================ Bratu 2-D
 // local point k = jl*ns + i, jl = j - j0. lo/hi: halo lines (nullptr at the physical boundary).
+// Branch-free on purpose (see k_spmv_stream): every neighbour load is unconditional on a clamped address and the
+// boundary is applied as a 0/1 weight, so the five loads of a point are in flight together.
 __device__ __forceinline__ double bratu_lap(const double *__restrict__ u, const double *__restrict__ lo,
                                             const double *__restrict__ hi, int64_t ns, int64_t nl, int64_t i,
                                             int64_t jl, int64_t k) {
-  double s = 4.0 * u[k];
-  if (i > 0) s -= u[k - 1];
-  if (i < ns - 1) s -= u[k + 1];
-  if (jl > 0) s -= u[k - ns];
-  else if (lo) s -= lo[i];
-  if (jl < nl - 1) s -= u[k + ns];
-  else if (hi) s -= hi[i];
-  return s;
+  const double *pw = u + (i > 0 ? k - 1 : k);
+  const double *pe = u + (i < ns - 1 ? k + 1 : k);
+  const double *ps = (jl > 0) ? (u + k - ns) : (lo ? lo + i : u + k);
+  const double *pn = (jl < nl - 1) ? (u + k + ns) : (hi ? hi + i : u + k);
+  const double c = u[k], w = *pw, e = *pe, s = *ps, n = *pn;
+  const double mw = (i > 0) ? 1.0 : 0.0, me = (i < ns - 1) ? 1.0 : 0.0;
+  const double ms = (jl > 0 || lo) ? 1.0 : 0.0, mn = (jl < nl - 1 || hi) ? 1.0 : 0.0;
+  return 4.0 * c - mw * w - me * e - ms * s - mn * n;
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual(int64_t ns, int64_t nl, double c_lap, double c_exp,
                                                              const double *__restrict__ u,
