@@ -103,6 +103,7 @@ typedef struct nk_csr nk_csr;         /* row-partitioned CSR (f64 values, i32 in
 typedef struct nk_problem nk_problem; /* residual / JVP / VJP / Jacobian provider                  */
 typedef struct nk_gmres nk_gmres;     /* GMRES(m) workspace (LinearSolve "LinearCache" analogue)    */
 typedef struct nk_solver nk_solver;   /* GeneralizedFirstOrderAlgorithmCache analogue               */
+typedef struct nk_bandlu nk_lu;       /* banded LU factorisation (LinearSolve factorisation-cache analogue) */
 
 /* ---------------------------------------------------------------- plain structs */
 
@@ -294,6 +295,16 @@ int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
  * Stop when ‖r‖₂ ≤ atol + rtol‖r0‖₂ or after maxiter Arnoldi steps; fixed_iters>0 overrides both. */
 int nk_gmres_solve(nk_gmres *G, const double *b, double *x, int memspace, int use_x0,
                    double atol, double rtol, int maxiter, int fixed_iters, nk_gmres_info *info);
+
+/* ---------------------------------------------------------------- direct factorisation (seam 1, `linsolve = nothing`)
+ * Banded LU without pivoting of a concrete sparse J on the device; factor once, solve many
+ * (reuse_A_if_factorization, lib/NonlinearSolveBase/ext/NonlinearSolveBaseLinearSolveExt.jl:81-86). Single rank.
+ * *ok = 0 when a pivot vanished. Lower bandwidth ≤ ~550 (the panel is factored in LDS). */
+int nk_lu_create(nk_csr *A, nk_lu **out);
+int nk_lu_destroy(nk_lu *F);
+int nk_lu_factor(nk_lu *F, nk_csr *A, int *ok);
+int nk_lu_solve(nk_lu *F, const double *b, double *x, int memspace);
+int nk_lu_info(nk_lu *F, int *kl, int *ku, int64_t *band_bytes);
 
 /* ---------------------------------------------------------------- Newton / TrustRegion (seam 3) */
 int nk_options_default(nk_options *opts);

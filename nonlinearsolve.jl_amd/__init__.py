@@ -11,6 +11,6 @@ from .core import (  # noqa: F401
     NonlinearFunction, NonlinearProblem,
     KrylovJL_GMRES, EisenstatWalkerForcing2, RadiusUpdateSchemes, NewtonRaphson, TrustRegion,
     NLStats, NonlinearSolution, FirstOrderCache, init, solve, step_, solve_, reinit_,
-    GMRES, JacobianOperator, JacVecOperator, VecJacOperator, StatefulJacobianOperator,
+    GMRES, BandedLU, JacobianOperator, JacVecOperator, VecJacOperator, StatefulJacobianOperator,
     StatefulJacobianNormalFormOperator,
 )

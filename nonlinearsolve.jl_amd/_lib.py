@@ -132,6 +132,11 @@ SIGNATURES = {
     "nk_gmres_set_operator_fn": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_right_preconditioner": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_solve": (_I, [_P, _P, _P, _I, _I, _D, _D, _I, _I, C.POINTER(GmresInfo)]),
+    "nk_lu_create": (_I, [_P, _PP]),
+    "nk_lu_destroy": (_I, [_P]),
+    "nk_lu_factor": (_I, [_P, _P, C.POINTER(_I)]),
+    "nk_lu_solve": (_I, [_P, _P, _P, _I]),
+    "nk_lu_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L)]),
     "nk_options_default": (_I, [C.POINTER(Options)]),
     "nk_solver_init": (_I, [_P, _P, _I, C.POINTER(Options), _PP]),
     "nk_solver_destroy": (_I, [_P]),

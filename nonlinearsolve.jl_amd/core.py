@@ -539,11 +539,13 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o = L.Options()
     check(L.lib().nk_options_default(C.byref(o)))
     ls = alg.linsolve
-    if ls is None:
-        raise NotImplementedError("linsolve = nothing (LinearSolve's default factorisation) is not built yet; "
-                                  "pass linsolve = KrylovJL_GMRES(...)")
     o.algorithm = L.ALG_TRUST_REGION if isinstance(alg, TrustRegion) else L.ALG_NEWTON_RAPHSON
-    o.linsolve = L.LINSOLVE_GMRES_CSR if alg.concrete_jac else L.LINSOLVE_GMRES_MATFREE
+    if ls is None:
+        # linsolve = nothing: LinearSolve's default factorisation of the concrete sparse J → banded LU on device
+        o.linsolve = L.LINSOLVE_BANDED_LU
+        ls = KrylovJL_GMRES()  # unused Krylov fields keep their defaults
+    else:
+        o.linsolve = L.LINSOLVE_GMRES_CSR if alg.concrete_jac else L.LINSOLVE_GMRES_MATFREE
     o.maxiters = int(maxiters)
     o.abstol = 0.0 if abstol is None else float(abstol)
     o.reltol = 0.0 if reltol is None else float(reltol)
@@ -812,6 +814,40 @@ class GMRES:
     def close(self):
         if self._h:
             L.lib().nk_gmres_destroy(self._h)
+            self._h = None
+
+
+class BandedLU:
+    """nk_lu: direct factorisation of a concrete sparse J (the LinearSolve factorisation cache analogue)."""
+
+    def __init__(self, A: CSRMatrix):
+        h = C.c_void_p()
+        check(L.lib().nk_lu_create(A._h, C.byref(h)))
+        self._h, self.A, self.n = h, A, A.info()["nrows_local"]
+        self.factor()
+
+    def factor(self, A: Optional[CSRMatrix] = None):
+        ok = C.c_int()
+        check(L.lib().nk_lu_factor(self._h, (A or self.A)._h, C.byref(ok)))
+        if not ok.value:
+            raise NKError("banded LU: zero or non-finite pivot")
+        return self
+
+    def solve(self, b):
+        x = _like(b, self.n)
+        pb, ms, _a = _ptr(b, self.n)
+        px, _m, _b = _ptr(x)
+        check(L.lib().nk_lu_solve(self._h, pb, px, ms))
+        return x
+
+    def info(self):
+        kl, ku, by = C.c_int(), C.c_int(), C.c_int64()
+        check(L.lib().nk_lu_info(self._h, C.byref(kl), C.byref(ku), C.byref(by)))
+        return dict(kl=kl.value, ku=ku.value, band_bytes=by.value)
+
+    def close(self):
+        if self._h:
+            L.lib().nk_lu_destroy(self._h)
             self._h = None
 
 

@@ -56,15 +56,19 @@ __device__ __forceinline__ void block_sum_array_store(const double (&acc)[NV], i
 // ----------------------------------------------------------------------------- stage-2 reducers
 // block s reduces partials[s*nblk .. s*nblk+nblk) in a fixed order
 // optional per-slot scale (lagged normalisation of the Krylov basis: h_j = s_j · (ṽ_j·w)) for slots < nscaled
-__global__ __launch_bounds__(64) void k_reduce_sum(const double *__restrict__ partials, int nblk,
-                                                   double *__restrict__ out, const int *d_skip,
-                                                   const double *__restrict__ scales, int nscaled) {
+__global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum(const double *__restrict__ partials, int nblk,
+                                                         double *__restrict__ out, const int *d_skip,
+                                                         const double *__restrict__ scales, int nscaled) {
   SKIP_GUARD(d_skip);
+  __shared__ double sm[4];
   const double *p = partials + (size_t)blockIdx.x * nblk;
   double v = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 64) v += p[i];
+  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) v += p[i];
   v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
     if (scales != nullptr && (int)blockIdx.x < nscaled) v *= scales[blockIdx.x];
     out[blockIdx.x] = v;
   }
@@ -168,7 +172,7 @@ int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ld
   }
   {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
-    NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(64), ctx->d_partials, grid, d_h,
+    NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), ctx->d_partials, grid, d_h,
                        d_skip, d_scales, nv);
   }
   NK_HIP(hipGetLastError());
@@ -240,7 +244,7 @@ int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t l
   }
   if (d_sumsq) {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * grid);
-    NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(64), ctx->d_partials_ss, grid, d_sumsq,
+    NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), ctx->d_partials_ss, grid, d_sumsq,
                        d_skip, (const double *)nullptr, 0);
     NK_HIP(hipGetLastError());
     return nk_comm_allreduce(ctx, d_sumsq, 1, 0);
@@ -320,7 +324,7 @@ int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int6
   }
   {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (nv + 1) * grid);
-    NK_LAUNCH(ctx, k_reduce_sum, dim3(nv + 1), dim3(64), ctx->d_partials, grid, d_h2, d_skip,
+    NK_LAUNCH(ctx, k_reduce_sum, dim3(nv + 1), dim3(NK_BLOCK), ctx->d_partials, grid, d_h2, d_skip,
                        d_scales, nv);
   }
   NK_HIP(hipGetLastError());
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_minmax(int64_t n, const double *__
 int nk_blas_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *d_out) {
   const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
   NK_LAUNCH(ctx, k_dot, dim3(grid), dim3(NK_BLOCK), n, x, y, ctx->d_partials);
-  NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(64), ctx->d_partials, grid, d_out,
+  NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), ctx->d_partials, grid, d_out,
                      (const int *)nullptr, (const double *)nullptr, 0);
   NK_HIP(hipGetLastError());
   return nk_comm_allreduce(ctx, d_out, 1, 0);

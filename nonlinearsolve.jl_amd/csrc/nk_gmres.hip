@@ -306,10 +306,14 @@ static int arnoldi_step(nk_gmres *G, int k) {
     if (dgks)
       NK_LAUNCH(ctx, k_dgks, dim3(1), dim3(64), G->d_ctl, G->d_h, G->d_h2, G->d_ss,
                          1.0 / (double)ctx->nranks);
-    // pass 3: w ← w − V h2 ; ‖w‖²   (CGS2: always; CGS+DGKS: only when the test asked for it)
-    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, G->d_ss, skip2, nullptr, G->d_s));
-    NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0);
+    // pass 3: w ← w − V h2 ; ‖w‖²   (CGS2: always; CGS+DGKS: only when the test asked for it).
+    // Single rank + CGS2: the ‖w‖² partials are reduced inside k_givens (one launch less per Arnoldi step).
+    const bool fold = (!dgks && nk_ctx_is_single(ctx));
+    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, fold ? NK_SUMSQ_PARTIALS_ONLY : G->d_ss, skip2,
+                             nullptr, G->d_s));
+    NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
+              G->d_sn, G->d_g, G->d_s, G->m, fold ? (const double *)ctx->d_partials_ss : (const double *)nullptr,
+              fold ? ctx->last_red_grid : 0);
   }
   NK_HIP(hipGetLastError());
   return NK_OK;

@@ -227,6 +227,22 @@ struct nk_gmres {
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info);
 
+// ----------------------------------------------------------------------------- banded LU (direct linsolve, C2)
+struct nk_bandlu {
+  nk_ctx *ctx = nullptr;
+  int64_t n = 0;
+  int kl = 0, ku = 0, ldab = 0, nblk = 0;
+  double *AB = nullptr;    // ldab × n band storage
+  double *invL = nullptr;  // nblk × 32 × 32: L11⁻¹ of every diagonal block
+  double *invU = nullptr;  // nblk × 32 × 32: U11⁻¹
+  double *tmp = nullptr;
+  int *d_fail = nullptr;
+};
+int nk_bandlu_create(nk_csr *A, nk_bandlu **out);
+void nk_bandlu_destroy(nk_bandlu *B);
+int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok);
+int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x);
+
 // ----------------------------------------------------------------------------- misc helpers
 template <typename T>
 static inline int nk_dev_alloc(T **p, size_t count) {

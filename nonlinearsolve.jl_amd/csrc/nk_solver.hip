@@ -25,6 +25,8 @@ struct nk_solver {
   nk_gmres *G = nullptr;
   nk_csr *J = nullptr;
   bool own_J = false;
+  nk_bandlu *B = nullptr;   // direct linsolve (NK_LINSOLVE_BANDED_LU)
+  bool lu_valid = false;
   // driver state
   int nsteps = 0, retcode = NK_RET_DEFAULT;
   bool force_stop = false, make_new_jacobian = true;
@@ -117,6 +119,7 @@ static const double DEFAULT_TOL = 3.0e-13;  // common_defaults.jl:44-48
 
 static bool is_tr(const nk_solver *S) { return S->o.algorithm == NK_ALG_TRUST_REGION; }
 static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE; }
+static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BANDED_LU; }
 
 // ---- scalar helpers (device reductions → pinned host, one synchronisation)
 static int fetch(nk_solver *S, int count, double *out) { return nk_scalars_to_host(S->ctx, S->ctx->d_scal, count, out); }
@@ -265,6 +268,7 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   if (concrete(S)) {  // jacobian.jl:104-118 evaluates J once at init
     NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
     S->stats.njacs++;
+    S->lu_valid = false;
   }
   NK_TRY(nk_blas_fill(ctx, S->n, 0.0, S->du));  // descent/newton.jl:34-36
   S->eta = S->o.ew_eta0;
@@ -287,8 +291,11 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   nk_ctx *ctx = P->ctx;
   NK_HIP(hipSetDevice(ctx->device));
   NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION, "bad algorithm");
-  NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_MATFREE || opts->linsolve == NK_LINSOLVE_GMRES_CSR,
-             "linsolve %d not supported by this build", opts->linsolve);
+  NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_MATFREE || opts->linsolve == NK_LINSOLVE_GMRES_CSR ||
+                 opts->linsolve == NK_LINSOLVE_BANDED_LU,
+             "unknown linsolve %d", opts->linsolve);
+  NK_REQUIRE(!(opts->linsolve == NK_LINSOLVE_BANDED_LU && opts->forcing != NK_FORCING_NONE),
+             "a forcing term needs an iterative linear solver");
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->forcing != NK_FORCING_NONE),
              "TrustRegion does not accept a forcing term (trust_region.jl:25-43)");
   nk_solver *S = new nk_solver();
@@ -323,8 +330,13 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     NK_TRY(nk_problem_jac_csr(P, &S->J));
     S->own_J = (P->kind != NK_PROBLEM_USER);
   }
-  NK_TRY(nk_gmres_create(ctx, n, S->o.gmres_restart, S->o.gmres_ortho, &S->G));
-  if (concrete(S)) NK_TRY(nk_gmres_set_operator_csr(S->G, S->J));
+  if (direct(S)) {
+    NK_TRY(nk_bandlu_create(S->J, &S->B));
+    NK_TRY(nk_dev_alloc(&S->stage, na));
+  } else {
+    NK_TRY(nk_gmres_create(ctx, n, S->o.gmres_restart, S->o.gmres_ortho, &S->G));
+    if (concrete(S)) NK_TRY(nk_gmres_set_operator_csr(S->G, S->J));
+  }
   NK_HIP(hipMemcpyAsync(S->u, u0, n * sizeof(double),
                         memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   int st = solver_start(S);
@@ -340,6 +352,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage};
   for (double *b : bufs) hipFree(b);
   nk_gmres_destroy(S->G);
+  nk_bandlu_destroy(S->B);
   if (S->own_J) nk_csr_destroy(S->J);
   delete S;
   return NK_OK;
@@ -368,8 +381,31 @@ static int pre_step_forcing(nk_solver *S, int iter) {
 }
 
 // ---- NewtonDescent.solve! : J δ = fu through GMRES, then δu = −δ  (newton.jl:121-138)
-static int newton_descent(nk_solver *S, double *du_out, bool *ok) {
+static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacobian) {
   S->stats.nsolve++;
+  if (direct(S)) {
+    // update_A!(cache, ::AbstractFactorization, A, reuse): refactorise unless the caller asked for reuse
+    // (ext/NonlinearSolveBaseLinearSolveExt.jl:81-86; reuse_A_if_factorization = !new_jacobian, newton.jl:125)
+    if (new_jacobian || !S->lu_valid) {
+      int fok = 0;
+      NK_TRY(nk_bandlu_factor(S->B, S->J, &fok));
+      S->stats.nfactors++;
+      S->lu_valid = fok != 0;
+      if (!fok) { *ok = false; return NK_OK; }
+    }
+    NK_TRY(nk_bandlu_solve(S->B, S->fu, du_out));
+    // no pivoting ⇒ verify the solve: ‖J x − b‖₂ ≤ 1e-6 ‖b‖₂, otherwise report the linear solve as failed
+    NK_TRY(nk_csr_spmv_dev(S->J, du_out, S->stage, nullptr));
+    NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->stage, -1.0, S->fu, S->stage));
+    NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->stage, slot(S, 0)));
+    NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu, slot(S, 1)));
+    double v[2];
+    NK_TRY(fetch(S, 2, v));
+    S->last_gmres_iters = 0;
+    *ok = (v[0] == v[0]) && (sqrt(v[0]) <= 1e-6 * sqrt(v[1]) + 1e-300);
+    if (!*ok) return NK_OK;
+    return nk_blas_lincomb(S->ctx, S->n, -1.0, du_out, 0.0, du_out, du_out);
+  }
   nk_gmres_info info;
   NK_TRY(nk_gmres_solve_dev(S->G, S->fu, du_out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
                             S->o.gmres_fixed_iters, &info));
@@ -381,11 +417,11 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok) {
 }
 
 // ---- Dogleg.solve! (dogleg.jl:86-151). duJJdu = NaN ⇒ "not computed"
-static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out) {
+static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out, bool new_jacobian) {
   nk_ctx *ctx = S->ctx;
   const int64_t n = S->n;
   *duJJdu_out = NAN;
-  NK_TRY(newton_descent(S, S->du_newton, ok));
+  NK_TRY(newton_descent(S, S->du_newton, ok, new_jacobian));
   if (!*ok) return NK_OK;
   double v[4];
   NK_TRY(nk_blas_sumsq(ctx, n, S->du_newton, slot(S, 0)));
@@ -533,6 +569,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     if (concrete(S)) {
       NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
       S->stats.njacs++;
+      S->lu_valid = false;
     } else {
       NK_TRY(nk_gmres_set_operator_jvp(S->G, S->P, S->u, NK_DEVICE));  // StatefulJacobianOperator(J, u, p)
     }
@@ -545,8 +582,8 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
 
   bool ok = true;
   double duJJdu = NAN;
-  if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu));
-  else NK_TRY(newton_descent(S, S->du, &ok));
+  if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu, new_jacobian));
+  else NK_TRY(newton_descent(S, S->du, &ok, new_jacobian));
   if (!ok) {
     if (new_jacobian) {
       S->retcode = NK_RET_INTERNAL_LINEAR_SOLVE_FAILED;

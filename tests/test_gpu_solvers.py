@@ -252,3 +252,80 @@ def test_jacobian_operators(nls):
         assert np.allclose(sop @ v, J @ v, atol=1e-5)
         assert np.allclose(sop.T @ v, J.T @ v, atol=1e-5)
         assert np.allclose((sop.T @ sop) @ v, J.T @ (J @ v), atol=1e-5, rtol=1e-10)
+
+
+# ------------------------------------------------------------------ direct linsolve (linsolve = nothing → banded LU)
+def test_quadratic_default_linsolve(nls):
+    """Config C1 / rootfind_tests: NewtonRaphson() with the default (direct) linear solver on quadratic_f."""
+    prob = nls.NonlinearProblem(nls.Quadratic(1000, 2.0))
+    sol = nls.solve(prob, nls.NewtonRaphson())
+    ref = R.solve(R.Quadratic(1000), R.NewtonRaphson())
+    assert sol.retcode == "Success" and np.max(np.abs(sol.resid)) <= 3e-13
+    assert np.max(np.abs(sol.u - np.sqrt(2.0))) < 1e-12
+    assert (sol.stats.nsteps, sol.stats.nf, sol.stats.njacs, sol.stats.nfactors, sol.stats.nsolve) == \
+        (ref.stats.nsteps, ref.stats.nf, ref.stats.njacs, ref.stats.nfactors, ref.stats.nsolve)
+
+
+@pytest.mark.parametrize("ns", [5, 33, 64])
+def test_bratu_direct_newton_vs_oracle(nls, ns):
+    """Config C2 protocol at small sizes: NewtonRaphson + concrete sparse J + direct solve (SuperLU on the oracle)."""
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+    sol = nls.solve(prob, nls.NewtonRaphson(), abstol=1e-10, maxiters=50, store_trace=True)
+    ref = R.solve(R.Bratu2D(ns), R.NewtonRaphson(), abstol=1e-10, maxiters=50)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert uerr(sol.u, ref.u) <= 1e-10
+    assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nfactors == ref.stats.nfactors
+    for a, b in zip(sol.trace, ref.trace):
+        assert abs(a["fnorm_inf"] - b["fnorm_inf"]) <= 1e-9 * max(b["fnorm_inf"], 1e-9) + 1e-14
+
+
+def test_c2_bratu_256_direct(nls):
+    """Config C2 at full size (n = 256², N = 65 536, band 513 × 65 536): Newton + direct solve; solution checked
+    against the oracle's sparse-direct Newton and through the residual."""
+    ns = 256
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+    sol = nls.solve(prob, nls.NewtonRaphson(), abstol=1e-8, maxiters=50)
+    ref = R.solve(R.Bratu2D(ns), R.NewtonRaphson(), abstol=1e-8, maxiters=50)
+    assert sol.retcode == "Success" and sol.stats.nsteps == ref.stats.nsteps <= 6
+    assert np.max(np.abs(sol.resid)) <= 1e-8
+    assert uerr(sol.u, ref.u) <= 1e-9
+    assert 0.79 < float(np.max(sol.u)) < 0.80
+
+
+def test_trust_region_direct_reuses_factorisation(nls):
+    """reuse_A_if_factorization = !new_jacobian: a rejected trust-region step must not refactorise."""
+    ns = 24
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=np.full(ns * ns, 3.0))  # far start ⇒ some rejections
+    sol = nls.solve(prob, nls.TrustRegion(), abstol=1e-9, maxiters=12, store_trace=True)
+    ref = R.solve(R.Bratu2D(ns), R.TrustRegion(), abstol=1e-9, maxiters=12, u0=np.full(ns * ns, 3.0))
+    assert not all(t["accepted"] for t in ref.trace)  # the scenario really contains rejected steps
+    assert sol.retcode == R.RETCODE_NAMES[ref.retcode]
+    assert sol.stats.nsteps == ref.stats.nsteps
+    assert sol.stats.nfactors == ref.stats.nfactors and sol.stats.njacs == ref.stats.njacs
+    assert [t["accepted"] for t in sol.trace] == [t["accepted"] for t in ref.trace]
+    if sol.retcode == "Success":
+        assert uerr(sol.u, ref.u) <= 1e-8
+
+
+def test_banded_lu_seam_vs_scipy(nls, dev):
+    """linear_solver_routing.jl:44-61 — res.u ≈ A \\ b for the factorisation seam; refactor after A changes."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+    rng = np.random.default_rng(0)
+    n, bw = 700, 9
+    diags = [rng.standard_normal(n - abs(k)) for k in range(-bw, bw + 1)]
+    A = sp.diags(diags, list(range(-bw, bw + 1)), format="csr") + sp.identity(n) * (4.0 * bw)  # diagonally dominant
+    A = sp.csr_matrix(A)
+    M = nls.CSRMatrix.from_scipy(A)
+    F = nls.BandedLU(M)
+    assert F.info()["kl"] == bw and F.info()["ku"] == bw
+    b = rng.standard_normal(n)
+    x = F.solve(b)
+    assert np.allclose(x, spla.spsolve(A.tocsc(), b), rtol=1e-11, atol=1e-12)
+    xd = F.solve(torch.tensor(b, device=dev))
+    assert np.allclose(xd.cpu().numpy(), x, rtol=1e-14)
+    A2 = sp.csr_matrix(A + sp.identity(n))
+    M.set_values(A2.data)
+    F.factor()
+    assert np.allclose(F.solve(b), spla.spsolve(A2.tocsc(), b), rtol=1e-11, atol=1e-12)

@@ -1,8 +1,11 @@
-NK_SPMV_TILE=1024 timeout 100 python tools/microbench.py --mode spmv 2>&1 | grep -v amdgpu.ids
-timeout 200 python bench.py --cpu-steps 0 2>&1 | grep -v amdgpu.ids > gpurun_out/bench6.log; python -c "
-import json
-d=json.loads(open('gpurun_out/bench6.log').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_us']); print({k:(v['avg_us'],v['launches'],v['GB/s']) for k,v in d['kernels'].items()})"
-timeout 200 python bench.py --cpu-steps 0 --matfree 2>&1 | grep -v amdgpu.ids > gpurun_out/bench6m.log; python -c "
-import json
-d=json.loads(open('gpurun_out/bench6m.log').read().strip().splitlines()[-1]); print('matfree', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_us'])"
-timeout 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py -m gpu -q -x --timeout 200 2>&1 | tail -2
+mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 10 --warmup 2 --cpu-steps 0 --no-profile-pass"
+rm -rf $R/gpurun_out/prof3
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof3 -o kt -- $B > $R/gpurun_out/prof3_kt.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof3 -o fetch -- $B > $R/gpurun_out/prof3_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof3 -o write -- $B > $R/gpurun_out/prof3_write.log 2>&1
+cd $R
+timeout 250 python bench.py > gpurun_out/bench_full2.log 2>&1; tail -1 gpurun_out/bench_full2.log | cut -c1-200
+timeout 250 python bench.py --matfree > gpurun_out/bench_full2_matfree.log 2>&1; tail -1 gpurun_out/bench_full2_matfree.log | cut -c1-200
