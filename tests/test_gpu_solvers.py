@@ -329,3 +329,110 @@ def test_banded_lu_seam_vs_scipy(nls, dev):
     M.set_values(A2.data)
     F.factor()
     assert np.allclose(F.solve(b), spla.spsolve(A2.tocsc(), b), rtol=1e-11, atol=1e-12)
+
+
+# ------------------------------------------------------------------ more reference fixtures / edge cases
+@pytest.mark.parametrize("lin", ["gmres", "gmres_concrete", "direct"])
+def test_operator_jacobian_tridiagonal(nls, dev, lin):
+    """operator_jacobian.jl:11-29 — linear residual W z − b with `jac_prototype`, N = 40: sol.u ≈ W \\ b for
+    GMRES (matrix-free), GMRES on the concrete J, and the factorisation."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+    N = 40
+    W = sp.csr_matrix(sp.diags([-np.ones(N - 1), 4.0 * np.ones(N), -np.ones(N - 1)], [-1, 0, 1]))
+    bvec = np.arange(1.0, N + 1)
+    xref = spla.spsolve(W.tocsc(), bvec)
+    Wd = nls.CSRMatrix.from_scipy(W)             # used inside the residual (device SpMV)
+    proto = nls.CSRMatrix.from_scipy(W)          # jac_prototype
+    bd = torch.tensor(bvec, device=dev)
+    wvals = torch.tensor(W.data, device=dev)
+
+    def resid(F, z, p):
+        Wd.matvec(z, out=F)
+        F.sub_(bd)
+
+    def jvp(Jv, v, z, p):
+        Wd.matvec(v, out=Jv)
+
+    def jac(nzval, z, p):
+        nzval.copy_(wvals)
+
+    f = nls.NonlinearFunction(resid, jvp=jvp, jac=jac, jac_prototype=proto)
+    prob = nls.NonlinearProblem(f, torch.zeros(N, dtype=torch.float64, device=dev))
+    alg = {"gmres": nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()),
+           "gmres_concrete": nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), concrete_jac=True),
+           "direct": nls.NewtonRaphson()}[lin]
+    sol = nls.solve(prob, alg)
+    assert sol.successful_retcode
+    assert np.allclose(sol.u.cpu().numpy(), xref, rtol=1e-8)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_tiny_systems(nls, n):
+    for alg in (nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), nls.NewtonRaphson(),
+                nls.TrustRegion(linsolve=nls.KrylovJL_GMRES()), nls.TrustRegion()):
+        sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(n, 2.0)), alg, abstol=1e-9)
+        assert sol.retcode == "Success" and np.allclose(sol.u, np.sqrt(2.0), atol=1e-9)
+
+
+def test_unstable_retcode_on_nan_residual(nls, dev):
+    """termination_conditions.jl:260-264 — a non-finite objective ends the solve with ReturnCode.Unstable."""
+    import torch
+
+    def f(du, u, p):
+        du.copy_(torch.where(u > 5.0, torch.full_like(u, float("nan")), u * u - 100.0))
+
+    def jvp(Jv, v, u, p):
+        Jv.copy_(2.0 * u * v)
+
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(f, jvp=jvp), torch.ones(4, dtype=torch.float64, device=dev))
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()))
+    assert sol.retcode == "Unstable"
+
+
+def test_maxtime_retcode(nls):
+    prob = nls.NonlinearProblem(nls.Bratu2D(128))
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30)), abstol=1e-300,
+                    maxiters=10 ** 6, maxtime=0.05)
+    assert sol.retcode == "MaxTime" and 1 <= sol.stats.nsteps < 10 ** 6
+
+
+def test_best_iterate_rollback(nls):
+    """Safe-best mode: the returned u is the iterate with the smallest ‖f‖∞ seen (termination_conditions.jl:440-453)."""
+    prob = nls.NonlinearProblem(nls.Bratu2D(16))
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=3, maxiters=3, ortho="mgs")),
+                    abstol=1e-14, maxiters=8, store_trace=True)
+    ref = R.solve(R.Bratu2D(16), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(fixed_iters=3)), abstol=1e-14, maxiters=8)
+    best = min(t["fnorm_inf"] for t in sol.trace)
+    assert np.isclose(np.max(np.abs(sol.resid)), best, rtol=1e-12)
+    assert sol.retcode == "MaxIters" == R.RETCODE_NAMES[ref.retcode]
+    assert uerr(sol.u, ref.u) <= 1e-9
+
+
+def test_right_preconditioner_hook(nls, dev):
+    """precs hook (test/Core/core_tests__item21.jl): a Jacobi right preconditioner is applied through the device
+    callback, is called, and GMRES converges to the same solution."""
+    import scipy.sparse as sp
+    import torch
+    rng = np.random.default_rng(0)
+    n = 400
+    d = np.linspace(1.0, 1e4, n)                      # badly scaled diagonal + weak coupling
+    A = sp.csr_matrix(sp.diags(d) + 0.1 * sp.diags([np.ones(n - 1), np.ones(n - 1)], [-1, 1]))
+    b = rng.standard_normal(n)
+    xref = np.linalg.solve(A.toarray(), b)
+    M = nls.CSRMatrix.from_scipy(A)
+    G0 = nls.GMRES(n, restart=30).set_operator(M)
+    x0, i0 = G0.solve(b, reltol=1e-10, maxiters=3000)
+    calls = [0]
+    dinv = torch.tensor(1.0 / d, device=dev)
+
+    def jacobi(x):
+        calls[0] += 1
+        return dinv * x
+
+    G1 = nls.GMRES(n, restart=30).set_operator(M).set_right_preconditioner(jacobi)
+    x1, i1 = G1.solve(b, reltol=1e-10, maxiters=3000)
+    assert i1["converged"] and calls[0] >= i1["iters"]
+    assert np.linalg.norm(x1 - xref) <= 1e-7 * np.linalg.norm(xref)
+    assert i1["iters"] < i0["iters"]
