@@ -67,7 +67,7 @@ __global__ void k_dgks(nk_gmres_ctl *ctl, const double *h, double *h2, double *d
 // ss_partials != nullptr (single rank): ‖w‖² arrives as nblk per-block partials and is reduced here, saving a launch
 __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, const double *h2, const double *d_ss,
                                                double *R, double *cs, double *sn, double *g, double *s, int m,
-                                               const double *__restrict__ ss_partials, int nblk) {
+                                               const double *__restrict__ ss_partials, int nblk, int pythag) {
   if (ctl->done) return;
   __shared__ double sh[NK_MAX_NV + 2], sc[NK_MAX_NV + 2], ss_[NK_MAX_NV + 2];
   const int k = ctl->k, t = threadIdx.x;
@@ -86,6 +86,13 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
   __syncthreads();
   if (t != 0) return;
   double ssq = (ss_partials != nullptr) ? ssq_red : *d_ss;
+  if (pythag) {
+    // multi-GPU CGS2: ‖w₂‖² = ‖w₁‖² − ‖h₂‖² (w₂ = w₁ − V h₂ with VᵀV = I and h₂ = Vᵀw₁). h₂ is the tiny
+    // re-orthogonalisation correction, so there is no cancellation; this saves the third all-reduce of the step.
+    double s2 = 0.0;
+    for (int i = 0; i <= k; ++i) s2 += h2[i] * h2[i];
+    ssq = h2[k + 1] - s2;
+  }
   if (ssq < 0.0) ssq = 0.0;
   const double hn = sqrt(ssq);
   double hk = sh[0];
@@ -277,7 +284,7 @@ static int arnoldi_step(nk_gmres *G, int k) {
                                i == k ? G->d_ss : nullptr, skip, nullptr, G->d_s + i));
     }
     NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)nullptr, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0);
+                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 0);
   } else {
     const bool dgks = (G->ortho == NK_ORTHO_CGS);
     const int *skip2 = dgks ? &G->d_ctl->pad0 : skip;
@@ -290,7 +297,7 @@ static int arnoldi_step(nk_gmres *G, int k) {
       NK_TRY(nk_blas_cgs2_passes_pr(ctx, n, nv, G->V, ldv, G->d_s, wk, G->d_h, G->d_h2, skip));
       NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2,
                          G->d_ss, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)ctx->d_partials_ss,
-                         ctx->last_red_grid);
+                         ctx->last_red_grid, 0);
       NK_HIP(hipGetLastError());
       return NK_OK;
     }
@@ -309,11 +316,13 @@ static int arnoldi_step(nk_gmres *G, int k) {
     // pass 3: w ← w − V h2 ; ‖w‖²   (CGS2: always; CGS+DGKS: only when the test asked for it).
     // Single rank + CGS2: the ‖w‖² partials are reduced inside k_givens (one launch less per Arnoldi step).
     const bool fold = (!dgks && nk_ctx_is_single(ctx));
-    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, fold ? NK_SUMSQ_PARTIALS_ONLY : G->d_ss, skip2,
-                             nullptr, G->d_s));
+    // several ranks + CGS2 + fused pass: ‖w‖² by Pythagoras inside k_givens → 2 all-reduces per step instead of 3
+    const bool pythag = (!dgks && !fold && nv <= 32);
+    double *ss_dst = fold ? NK_SUMSQ_PARTIALS_ONLY : (pythag ? nullptr : G->d_ss);
+    NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, ss_dst, skip2, nullptr, G->d_s));
     NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
               G->d_sn, G->d_g, G->d_s, G->m, fold ? (const double *)ctx->d_partials_ss : (const double *)nullptr,
-              fold ? ctx->last_red_grid : 0);
+              fold ? ctx->last_red_grid : 0, pythag ? 1 : 0);
   }
   NK_HIP(hipGetLastError());
   return NK_OK;
