@@ -69,39 +69,45 @@ __global__ __launch_bounds__(1024) void k_band_panel(int64_t n, int kl, int ku, 
     const int64_t i = j0 + r, j = j0 + c;
     if (in_band(i, j, kl, ku)) AB[bidx(i, j, ku, ldab)] = sp[c * ld + r];
   }
-  // triangular inverses of the diagonal block (column-major NB×NB, zero padded)
-  double *iL = invL + (size_t)J * NB * NB, *iU = invU + (size_t)J * NB * NB;
-  if (t < NB) {  // column t of L11⁻¹ (unit lower): forward substitution on e_t
-    double x[NB];
-    for (int r = 0; r < NB; ++r) x[r] = 0.0;
-    if (t < nc) {
-      x[t] = 1.0;
-      for (int r = t + 1; r < nc; ++r) {
-        double s = 0.0;
-        for (int q = t; q < r; ++q) s += sp[q * ld + r] * x[q];
-        x[r] = -s;
-      }
-    }
-    for (int r = 0; r < NB; ++r) iL[t * NB + r] = x[r];
-  } else if (t < 2 * NB) {  // column c of U11⁻¹: back substitution on e_c
-    const int c = t - NB;
-    double x[NB];
-    for (int r = 0; r < NB; ++r) x[r] = 0.0;
-    if (c < nc) {
-      x[c] = 1.0 / sp[c * ld + c];
-      for (int r = c - 1; r >= 0; --r) {
-        double s = 0.0;
-        for (int q = r + 1; q <= c; ++q) s += sp[q * ld + r] * x[q];
-        x[r] = -s / sp[r * ld + r];
-      }
-    }
-    for (int r = 0; r < NB; ++r) iU[c * NB + r] = x[r];
+  // Triangular inverses of the diagonal block, formed cooperatively in LDS (row-major NB×NB, zero padded):
+  //   XL = L11⁻¹ by forward elimination  (for c: rows r>c: XL[r,:] −= L[r,c]·XL[c,:])
+  //   XU = U11⁻¹ by backward elimination (for c = nc−1…0: XU[c,:] /= U[c,c]; rows r<c: XU[r,:] −= U[r,c]·XU[c,:])
+  // threads 0..1023: one (row, col) element of each matrix per thread; NB sequential steps, one barrier each.
+  __shared__ double XL[NB * NB], XU[NB * NB];
+  const int er = t / NB, ec = t % NB;  // this thread's element (T == NB*NB)
+  XL[t] = (er == ec) ? 1.0 : 0.0;
+  XU[t] = (er == ec) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cu = nc - 1 - c;
+    // L: eliminate column c below the diagonal
+    const double lrc = (er > c && er < nc) ? sp[c * ld + er] : 0.0;
+    const double xlc = XL[c * NB + ec];
+    // U: scale row cu, eliminate above
+    const double ucc = sp[cu * ld + cu];
+    const double xuc = XU[cu * NB + ec] / ucc;
+    const double urc = (er < cu) ? sp[cu * ld + er] : 0.0;
+    __syncthreads();
+    if (er > c && er < nc) XL[t] -= lrc * xlc;
+    if (er == cu) XU[t] = xuc;
+    else if (er < cu) XU[t] -= urc * xuc;
+    __syncthreads();
   }
+  // rows/cols ≥ nc of the last (partial) block: identity rows were never touched; zero them so that padded
+  // entries cannot leak into the sweeps
+  double vl = XL[t], vu = XU[t];
+  if (er >= nc || ec >= nc) { vl = 0.0; vu = 0.0; }
+  double *iL = invL + (size_t)J * NB * NB, *iU = invU + (size_t)J * NB * NB;
+  iL[ec * NB + er] = vl;  // stored column-major: element (row er, col ec)
+  iU[ec * NB + er] = vu;
 }
 
-// trailing update for block column J: this workgroup owns UPD_COLS columns right of the panel
+// trailing update for block column J: this workgroup owns UPD_COLS columns right of the panel.
+// L21 (kl × NB) is staged once in dynamic LDS (zero outside the band) so the rank-NB update reads no global
+// memory in its inner loop.
 __global__ __launch_bounds__(NK_BLOCK) void k_band_update(int64_t n, int kl, int ku, int ldab, double *__restrict__ AB,
                                                           int J, const double *__restrict__ invL) {
+  extern __shared__ __attribute__((aligned(16))) double sL21[];  // kl × NB, column-major (ld = kl)
   __shared__ double sU[NB * UPD_COLS];   // U12 chunk (NB × UPD_COLS)
   __shared__ double sA[NB * UPD_COLS];   // A12 chunk
   __shared__ double sL[NB * NB];
@@ -115,6 +121,11 @@ __global__ __launch_bounds__(NK_BLOCK) void k_band_update(int64_t n, int kl, int
     const int c = e / NB, r = e - c * NB;
     const int64_t i = j0 + r, j = c0 + c;
     sA[e] = (j < n && i < n && in_band(i, j, kl, ku)) ? AB[bidx(i, j, ku, ldab)] : 0.0;
+  }
+  for (int e = t; e < kl * NB; e += NK_BLOCK) {
+    const int q = e / kl, r = e - q * kl;
+    const int64_t i = j0 + NB + r, jq = j0 + q;
+    sL21[e] = (i < n && jq < n && in_band(i, jq, kl, ku)) ? AB[bidx(i, jq, ku, ldab)] : 0.0;
   }
   __syncthreads();
   // U12 = L11⁻¹ A12
@@ -136,11 +147,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_band_update(int64_t n, int kl, int
     const int64_t i = j0 + NB + r, j = c0 + c;
     if (i >= n || j >= n || !in_band(i, j, kl, ku)) continue;
     double s = 0.0;
-#pragma unroll 8
-    for (int q = 0; q < NB; ++q) {
-      const int64_t jq = j0 + q;
-      if (in_band(i, jq, kl, ku)) s += AB[bidx(i, jq, ku, ldab)] * sU[c * NB + q];
-    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) s += sL21[q * kl + r] * sU[c * NB + q];
     AB[bidx(i, j, ku, ldab)] -= s;
   }
 }
@@ -165,13 +173,24 @@ __global__ __launch_bounds__(1024) void k_band_solve(int64_t n, int kl, int ku, 
       if (t < nc) x[j0 + t] = s;
     }
     __syncthreads();
-    for (int r = t; r < kl; r += T) {
-      const int64_t i = j0 + NB + r;
-      if (i >= n) break;
-      double s = 0.0;
-      for (int q = 0; q < nc; ++q)
-        if (in_band(i, j0 + q, kl, ku)) s += AB[bidx(i, j0 + q, ku, ldab)] * sy[q];
-      x[i] -= s;
+    {  // b[below] −= L21 y_J : 4 lanes per row (kl ≤ 256 rows per pass), 8 columns each, shuffle-reduced
+      for (int rb = 0; rb < kl; rb += T / 4) {
+        const int r = rb + (t >> 2), sub = t & 3;
+        const int64_t i = j0 + NB + r;
+        double s = 0.0;
+        if (r < kl && i < n) {
+#pragma unroll
+          for (int qq = 0; qq < NB / 4; ++qq) {
+            const int q = sub * (NB / 4) + qq;
+            const bool ok = (q < nc) && in_band(i, j0 + q, kl, ku);
+            const double a = AB[ok ? bidx(i, j0 + q, ku, ldab) : 0];
+            s += ok ? a * sy[q] : 0.0;
+          }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (sub == 0 && r < kl && i < n) x[i] -= s;
+      }
     }
     __syncthreads();
   }
@@ -219,7 +238,8 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
   const int64_t n = A->nrows;
   const size_t band_bytes = (size_t)(kl + ku + 1) * n * sizeof(double);
   NK_REQUIRE(band_bytes < ((size_t)64 << 30), "band storage of %zu bytes is too large (bandwidth %d+%d)", band_bytes, kl, ku);
-  NK_REQUIRE((size_t)(NB + kl) * NB * sizeof(double) <= 150 * 1024, "lower bandwidth %d too large for the LDS panel", kl);
+  NK_REQUIRE((size_t)(NB + kl) * NB * sizeof(double) <= 136 * 1024,
+             "lower bandwidth %d too large for the LDS panel", kl);
   nk_bandlu *B = new nk_bandlu();
   B->ctx = ctx;
   B->n = n;
@@ -234,7 +254,8 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
   NK_TRY(nk_dev_alloc(&B->d_fail, (size_t)1));
   static bool attr_set = false;
   if (!attr_set) {
-    NK_HIP(hipFuncSetAttribute((const void *)k_band_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    NK_HIP(hipFuncSetAttribute((const void *)k_band_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    NK_HIP(hipFuncSetAttribute((const void *)k_band_update, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
     attr_set = true;
   }
   *out = B;
@@ -262,8 +283,8 @@ int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok) {
     const int64_t right = imin64(B->ku, n - ((int64_t)J * NB + NB));
     if (right > 0) {
       const int grid = (int)((right + UPD_COLS - 1) / UPD_COLS);
-      hipLaunchKernelGGL(k_band_update, dim3(grid), dim3(NK_BLOCK), 0, ctx->stream, n, B->kl, B->ku, B->ldab, B->AB, J,
-                         (const double *)B->invL);
+      hipLaunchKernelGGL(k_band_update, dim3(grid), dim3(NK_BLOCK), (size_t)B->kl * NB * sizeof(double), ctx->stream, n,
+                         B->kl, B->ku, B->ldab, B->AB, J, (const double *)B->invL);
     }
   }
   NK_HIP(hipGetLastError());
