@@ -436,3 +436,15 @@ def test_right_preconditioner_hook(nls, dev):
     assert i1["converged"] and calls[0] >= i1["iters"]
     assert np.linalg.norm(x1 - xref) <= 1e-7 * np.linalg.norm(xref)
     assert i1["iters"] < i0["iters"]
+
+
+def test_bitwise_reproducible(nls):
+    """Fixed-order two-stage reductions, no float atomics: the same solve twice gives bit-identical iterates."""
+    outs = []
+    for _ in range(2):
+        prob = nls.NonlinearProblem(nls.Bratu2D(96, 6.0))
+        sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=nls.EisenstatWalkerForcing2()),
+                        abstol=1e-8, maxiters=50)
+        outs.append((np.asarray(sol.u).copy(), sol.stats.gmres_iters))
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][0], outs[1][0])
