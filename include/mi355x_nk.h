@@ -97,6 +97,13 @@ typedef enum {
 
 typedef enum { NK_COMM_NONE = 0, NK_COMM_RCCL = 1, NK_COMM_CALLBACKS = 2 } nk_comm_kind;
 
+/* the nine SciMLBase termination modes (common/common_rootfind_testing.jl:3-13;
+ * lib/NonlinearSolveBase/src/termination_conditions.jl:243-376). 0 is the reference's default (:385-389). */
+typedef enum {
+  NK_TM_ABSNORM_SAFEBEST = 0, NK_TM_NORM = 1, NK_TM_REL = 2, NK_TM_RELNORM = 3, NK_TM_RELNORM_SAFE = 4,
+  NK_TM_RELNORM_SAFEBEST = 5, NK_TM_ABS = 6, NK_TM_ABSNORM = 7, NK_TM_ABSNORM_SAFE = 8
+} nk_termination_mode;
+
 /* ---------------------------------------------------------------- opaque handles */
 typedef struct nk_ctx nk_ctx;         /* device, stream, communicator, scratch                     */
 typedef struct nk_csr nk_csr;         /* row-partitioned CSR (f64 values, i32 indices) + halo plan */
@@ -146,7 +153,7 @@ typedef struct {
   int32_t algorithm;            /* nk_algorithm                                                     */
   int32_t linsolve;             /* nk_linsolve                                                      */
   int32_t maxiters;             /* 1000  (FirstOrder/src/solve.jl:142)                              */
-  int32_t reserved0;
+  int32_t termination_norm;     /* internalnorm of the termination mode: 0 = maximum∘abs (default), 1 = 2-norm */
   double  abstol;               /* ≤0 → 3.0e-13 (common_defaults.jl:44-48)                          */
   double  reltol;               /* ≤0 → 3.0e-13; only forwarded to the linear solver                */
   double  maxtime;              /* seconds, ≤0 → none (Base/src/solve.jl:846-856)                   */
@@ -175,7 +182,7 @@ typedef struct {
   double  protective_threshold; /* ≤0 → off                                                         */
   /* --- tracing */
   int32_t store_trace;          /* keep nk_trace_entry rows (costs one extra 2-norm per step)       */
-  int32_t reserved1;
+  int32_t termination_mode;     /* nk_termination_mode; 0 = AbsNormSafeBest, the reference default  */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)

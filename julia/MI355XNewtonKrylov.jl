@@ -177,7 +177,7 @@ end
 
 # nk_options mirrors include/mi355x_nk.h field for field (isbits ⇒ passable by Ref)
 Base.@kwdef mutable struct NKOptions
-    algorithm::Int32 = 0; linsolve::Int32 = 0; maxiters::Int32 = 1000; reserved0::Int32 = 0
+    algorithm::Int32 = 0; linsolve::Int32 = 0; maxiters::Int32 = 1000; termination_norm::Int32 = 0
     abstol::Float64 = 0.0; reltol::Float64 = 0.0; maxtime::Float64 = 0.0
     gmres_restart::Int32 = 30; gmres_maxiters::Int32 = 300; gmres_ortho::Int32 = 1; gmres_fixed_iters::Int32 = 0
     lin_abstol::Float64 = -1.0; lin_reltol::Float64 = -1.0
@@ -190,7 +190,7 @@ Base.@kwdef mutable struct NKOptions
     expand_factor::Float64 = 2.0
     patience_steps::Int32 = 100; max_stalled_steps::Int32 = 32
     patience_objective_multiplier::Float64 = 3.0; min_max_factor::Float64 = 1.3; protective_threshold::Float64 = 0.0
-    store_trace::Int32 = 0; reserved1::Int32 = 0
+    store_trace::Int32 = 0; termination_mode::Int32 = 0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,

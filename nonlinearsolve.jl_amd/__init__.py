@@ -10,6 +10,9 @@ from .core import (  # noqa: F401
     CSRMatrix, DeviceProblem, Quadratic, Bratu2D, Brusselator2D,
     NonlinearFunction, NonlinearProblem,
     KrylovJL_GMRES, EisenstatWalkerForcing2, RadiusUpdateSchemes, NewtonRaphson, TrustRegion,
+    AbsNormSafeBestTerminationMode, NormTerminationMode, RelTerminationMode, RelNormTerminationMode,
+    RelNormSafeTerminationMode, RelNormSafeBestTerminationMode, AbsTerminationMode, AbsNormTerminationMode,
+    AbsNormSafeTerminationMode, TERMINATION_CONDITIONS,
     NLStats, NonlinearSolution, FirstOrderCache, init, solve, step_, solve_, reinit_,
     GMRES, BandedLU, JacobianOperator, JacVecOperator, VecJacOperator, StatefulJacobianOperator,
     StatefulJacobianNormalFormOperator,

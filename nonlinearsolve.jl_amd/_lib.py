@@ -49,7 +49,7 @@ class TraceEntry(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [
-        ("algorithm", C.c_int32), ("linsolve", C.c_int32), ("maxiters", C.c_int32), ("reserved0", C.c_int32),
+        ("algorithm", C.c_int32), ("linsolve", C.c_int32), ("maxiters", C.c_int32), ("termination_norm", C.c_int32),
         ("abstol", C.c_double), ("reltol", C.c_double), ("maxtime", C.c_double),
         ("gmres_restart", C.c_int32), ("gmres_maxiters", C.c_int32), ("gmres_ortho", C.c_int32),
         ("gmres_fixed_iters", C.c_int32), ("lin_abstol", C.c_double), ("lin_reltol", C.c_double),
@@ -63,7 +63,7 @@ class Options(C.Structure):
         ("patience_steps", C.c_int32), ("max_stalled_steps", C.c_int32),
         ("patience_objective_multiplier", C.c_double), ("min_max_factor", C.c_double),
         ("protective_threshold", C.c_double),
-        ("store_trace", C.c_int32), ("reserved1", C.c_int32),
+        ("store_trace", C.c_int32), ("termination_mode", C.c_int32),
     ]
 
 

@@ -532,10 +532,66 @@ class TrustRegion:  # trust_region.jl:25-43
     name: str = "TrustRegion"
 
 
+@dataclass
+class _TerminationMode:
+    """SciMLBase termination modes (lib/NonlinearSolveBase/src/termination_conditions.jl); `internalnorm` is
+    "inf" (Base.Fix1(maximum, abs), the reference default) or "l2"."""
+    internalnorm: str = "inf"
+    patience_steps: int = 100
+    patience_objective_multiplier: float = 3.0
+    min_max_factor: float = 1.3
+    max_stalled_steps: Optional[int] = None
+    protective_threshold: Optional[float] = None
+    code = 0
+
+
+class AbsNormSafeBestTerminationMode(_TerminationMode):
+    code = 0
+
+
+class NormTerminationMode(_TerminationMode):
+    code = 1
+
+
+class RelTerminationMode(_TerminationMode):
+    code = 2
+
+
+class RelNormTerminationMode(_TerminationMode):
+    code = 3
+
+
+class RelNormSafeTerminationMode(_TerminationMode):
+    code = 4
+
+
+class RelNormSafeBestTerminationMode(_TerminationMode):
+    code = 5
+
+
+class AbsTerminationMode(_TerminationMode):
+    code = 6
+
+
+class AbsNormTerminationMode(_TerminationMode):
+    code = 7
+
+
+class AbsNormSafeTerminationMode(_TerminationMode):
+    code = 8
+
+
+TERMINATION_CONDITIONS = [  # common/common_rootfind_testing.jl:3-13
+    NormTerminationMode, RelTerminationMode, RelNormTerminationMode, RelNormSafeTerminationMode,
+    RelNormSafeBestTerminationMode, AbsTerminationMode, AbsNormTerminationMode, AbsNormSafeTerminationMode,
+    AbsNormSafeBestTerminationMode,
+]
+
 _ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS}
 
 
-def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs) -> L.Options:
+def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,
+             termination_condition=None) -> L.Options:
     o = L.Options()
     check(L.lib().nk_options_default(C.byref(o)))
     ls = alg.linsolve
@@ -565,6 +621,17 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
         for k in ("max_trust_radius", "initial_trust_radius", "step_threshold", "shrink_threshold",
                   "expand_threshold", "shrink_factor", "expand_factor"):
             setattr(o, k, float(getattr(alg, k)))
+    if termination_condition is not None:
+        tc = termination_condition() if isinstance(termination_condition, type) else termination_condition
+        o.termination_mode = tc.code
+        o.termination_norm = {"inf": 0, "l2": 1}[tc.internalnorm]
+        o.patience_steps = int(tc.patience_steps)
+        o.patience_objective_multiplier = float(tc.patience_objective_multiplier)
+        o.min_max_factor = float(tc.min_max_factor)
+        # an explicitly constructed mode has max_stalled_steps = nothing unless given (the default *mode* of the
+        # solver is built with max_stalled_steps = 32, termination_conditions.jl:385-389)
+        o.max_stalled_steps = -1 if tc.max_stalled_steps is None else int(tc.max_stalled_steps)
+        o.protective_threshold = 0.0 if tc.protective_threshold is None else float(tc.protective_threshold)
     for k, v in (termination_kwargs or {}).items():
         setattr(o, k, v)
     o.store_trace = int(bool(store_trace))
@@ -602,9 +669,10 @@ class FirstOrderCache:
     """GeneralizedFirstOrderAlgorithmCache behind nk_solver: init / step! / solve! / reinit!."""
 
     def __init__(self, prob: NonlinearProblem, alg, abstol=None, reltol=None, maxiters=1000, maxtime=None,
-                 store_trace=False, termination_kwargs=None):
+                 store_trace=False, termination_kwargs=None, termination_condition=None):
         self.prob, self.alg = prob, alg
-        self._opts = _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs)
+        self._opts = _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,
+                              termination_condition)
         self._u0_is_torch = _is_torch(prob.u0)
         p, ms, _k = _ptr(prob.u0, prob.device_problem.n_local)
         h = C.c_void_p()

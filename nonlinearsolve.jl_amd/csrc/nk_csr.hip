@@ -377,6 +377,8 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_val);
   hipFree(A->d_rowblocks);
   hipFree(A->d_tperm);
+  hipFree(A->d_role);
+  hipFree(A->d_node);
   hipFree(A->d_xtmp);
   hipFree(A->d_ytmp);
   nk_halo_free(&A->halo);

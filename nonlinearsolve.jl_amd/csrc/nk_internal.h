@@ -136,6 +136,9 @@ struct nk_csr {
   int32_t *d_tperm = nullptr;
   bool t_values_stale = true;
   double *d_xtmp = nullptr, *d_ytmp = nullptr;  // staging for host-memspace calls
+  // problem-specific device tables attached by nk_problem_jac_csr (freed with the matrix)
+  uint8_t *d_role = nullptr;   // Brusselator: role of every non-zero
+  int32_t *d_node = nullptr;   // Brusselator: grid node of every non-zero's row
 };
 // d_out_scale (nullable): y = (*d_out_scale) · A x   (lagged normalisation of the Krylov basis)
 int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr);

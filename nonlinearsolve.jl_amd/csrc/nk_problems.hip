@@ -181,12 +181,6 @@ __global__ __launch_bounds__(NK_BLOCK) void k_brus_u0(brus_par q, double *__rest
 }
 
 // ============================================================================ host side
-struct brus_extra {  // kept alongside the Jacobian CSR created by nk_problem_jac_csr
-  uint8_t *d_role = nullptr;
-  int32_t *d_node = nullptr;
-};
-static std::vector<std::pair<nk_csr *, brus_extra>> g_brus_extras;  // tiny registry (ctx is single-threaded)
-
 static inline int grid1(int64_t n) { return (int)((n + NK_BLOCK - 1) / NK_BLOCK); }
 
 static brus_par brus_params(const nk_problem *P) {
@@ -530,12 +524,11 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
         }
     rp.push_back((int32_t)gc.size());
     NK_TRY(nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out));
-    brus_extra ex;
-    NK_TRY(nk_dev_alloc(&ex.d_role, role.size()));
-    NK_TRY(nk_dev_alloc(&ex.d_node, node.size()));
-    NK_HIP(hipMemcpy(ex.d_role, role.data(), role.size(), hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(ex.d_node, node.data(), node.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    g_brus_extras.push_back({*out, ex});
+    nk_csr *Jc = *out;
+    NK_TRY(nk_dev_alloc(&Jc->d_role, role.size()));
+    NK_TRY(nk_dev_alloc(&Jc->d_node, node.size()));
+    NK_HIP(hipMemcpy(Jc->d_role, role.data(), role.size(), hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(Jc->d_node, node.data(), node.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     (void)nn;
     return NK_OK;
   }
@@ -562,10 +555,8 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
                          P->c_lap, P->c_exp, d_u, J->d_rowptr, J->d_val);
       break;
     case NK_PROBLEM_BRUSSELATOR2D: {
-      brus_extra *ex = nullptr;
-      for (auto &pr : g_brus_extras)
-        if (pr.first == J) ex = &pr.second;
-      NK_REQUIRE(ex, "CSR was not created by nk_problem_jac_csr for a Brusselator problem");
+      NK_REQUIRE(J->d_role && J->d_node, "CSR was not created by nk_problem_jac_csr for a Brusselator problem");
+      const nk_csr *ex = J;
       const brus_par q = brus_params(P);
       NK_LAUNCH(ctx, k_brus_jac, dim3(grid1(J->nnz)), dim3(NK_BLOCK), J->nnz, q.N * q.nl, q.A,
                          q.alpha, ex->d_role, ex->d_node, d_u, J->d_val);

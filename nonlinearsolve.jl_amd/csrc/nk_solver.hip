@@ -35,6 +35,7 @@ struct nk_solver {
   uint64_t u_version = 0, best_version = 0;
   // termination cache
   double abstol = 0, reltol = 0, best_obj = 0, initial_obj = 0, fnorm_inf = 0;
+  double tc_u0_norm = 0;  // ‖u0‖₂ for the relative stall test
   int tc_nsteps = 0, tc_retcode = NK_RET_DEFAULT;
   std::vector<double> objectives_trace, step_norm_trace;
   // forcing
@@ -75,6 +76,72 @@ __global__ __launch_bounds__(NK_BLOCK) void k_sum_partials(const double *__restr
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) *out = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// one pass over (fu, u): Σ(fu+u)², max|fu+u|, max(|fu| − reltol·|u+fu|)  — the quantities the Norm/Rel* termination
+// modes need (check_convergence, termination_conditions.jl:338-376; apply_norm(f, du, u) = f(du .+ u), utils.jl:102)
+__global__ __launch_bounds__(NK_BLOCK) void k_tc_pair(int64_t n, const double *__restrict__ fu,
+                                                      const double *__restrict__ u, double reltol,
+                                                      double *__restrict__ partials) {
+  __shared__ double sm[12];
+  double ss = 0.0, mx = 0.0, viol = -__builtin_inf();
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double f = fu[i], s = f + u[i], as = fabs(s);
+    ss += s * s;
+    mx = (as > mx || as != as) ? as : mx;
+    const double vv = fabs(f) - reltol * as;
+    viol = (vv > viol || vv != vv) ? vv : viol;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    const double m2 = __shfl_xor(mx, o, 64), v2 = __shfl_xor(viol, o, 64);
+    mx = (m2 > mx || m2 != m2) ? m2 : mx;
+    viol = (v2 > viol || v2 != v2) ? v2 : viol;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w] = ss; sm[4 + w] = mx; sm[8 + w] = viol; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = sm[0] + sm[1] + sm[2] + sm[3], b = sm[4], c = sm[8];
+    for (int k = 1; k < 4; ++k) {
+      b = (sm[4 + k] > b || sm[4 + k] != sm[4 + k]) ? sm[4 + k] : b;
+      c = (sm[8 + k] > c || sm[8 + k] != sm[8 + k]) ? sm[8 + k] : c;
+    }
+    partials[blockIdx.x] = a;
+    partials[gridDim.x + blockIdx.x] = b;
+    partials[2 * gridDim.x + blockIdx.x] = c;
+  }
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_tc_pair_reduce(const double *__restrict__ partials, int nblk,
+                                                             double *__restrict__ out) {
+  __shared__ double sm[12];
+  double ss = 0.0, mx = 0.0, viol = -__builtin_inf();
+  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) {
+    ss += partials[i];
+    const double b = partials[nblk + i], c = partials[2 * nblk + i];
+    mx = (b > mx || b != b) ? b : mx;
+    viol = (c > viol || c != c) ? c : viol;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    const double m2 = __shfl_xor(mx, o, 64), v2 = __shfl_xor(viol, o, 64);
+    mx = (m2 > mx || m2 != m2) ? m2 : mx;
+    viol = (v2 > viol || v2 != v2) ? v2 : viol;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w] = ss; sm[4 + w] = mx; sm[8 + w] = viol; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = sm[0] + sm[1] + sm[2] + sm[3], b = sm[4], c = sm[8];
+    for (int k = 1; k < 4; ++k) {
+      b = (sm[4 + k] > b || sm[4 + k] != sm[4 + k]) ? sm[4 + k] : b;
+      c = (sm[8 + k] > c || sm[8 + k] != sm[8 + k]) ? sm[8 + k] : c;
+    }
+    out[0] = a; out[1] = b; out[2] = c;
+  }
 }
 
 extern "C" int nk_options_default(nk_options *o) {
@@ -184,26 +251,97 @@ static int tr_radii(nk_solver *S) {
   return NK_OK;
 }
 
-// ---- termination cache (AbsNormSafeBest, termination_conditions.jl)
-static void tc_reinit(nk_solver *S, double fnorm_inf0) {
+// ---- termination cache: the nine SciMLBase termination modes (termination_conditions.jl:243-376)
+enum {
+  TM_ABSNORM_SAFEBEST = 0,  // default_termination_mode(::NonlinearProblem, Val(:regular))  (:385-389)
+  TM_NORM = 1, TM_REL = 2, TM_RELNORM = 3, TM_RELNORM_SAFE = 4, TM_RELNORM_SAFEBEST = 5,
+  TM_ABS = 6, TM_ABSNORM = 7, TM_ABSNORM_SAFE = 8
+};
+static bool tm_safe(int m) { return m == TM_ABSNORM_SAFEBEST || m == TM_ABSNORM_SAFE || m == TM_RELNORM_SAFE || m == TM_RELNORM_SAFEBEST; }
+static bool tm_best(int m) { return m == TM_ABSNORM_SAFEBEST || m == TM_RELNORM_SAFEBEST; }
+static bool tm_rel(int m) { return m == TM_RELNORM_SAFE || m == TM_RELNORM_SAFEBEST; }
+static bool tm_needs_pair(int m) { return m == TM_NORM || m == TM_REL || m == TM_RELNORM || tm_rel(m); }
+
+struct tc_quant {
+  double nf = 0;      // internalnorm(fu)
+  double nfu = 0;     // internalnorm(fu .+ u)
+  double relviol = 0; // max_i(|fu_i| − reltol |u_i + fu_i|)  (RelTerminationMode: converged iff ≤ 0)
+};
+// device reductions for the current (fu, u); ‖fu‖∞ is already in S->fnorm_inf
+static int tc_quantities(nk_solver *S, tc_quant *q) {
+  nk_ctx *ctx = S->ctx;
+  const int mode = S->o.termination_mode;
+  const bool l2 = S->o.termination_norm == 1;
+  q->nf = S->fnorm_inf;
+  int cnt = 0;
+  if (l2) { NK_TRY(nk_blas_sumsq(ctx, S->n, S->fu, slot(S, 8))); cnt = 1; }
+  if (tm_needs_pair(mode)) {
+    const int grid = nk_grid_for(S->n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+    NK_LAUNCH(ctx, k_tc_pair, dim3(grid), dim3(NK_BLOCK), S->n, S->fu, S->u, S->reltol, ctx->d_partials);
+    NK_LAUNCH(ctx, k_tc_pair_reduce, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, slot(S, 9));
+    NK_HIP(hipGetLastError());
+    NK_TRY(nk_comm_allreduce(ctx, slot(S, 9), 1, 0));
+    NK_TRY(nk_comm_allreduce(ctx, slot(S, 10), 2, 1));
+    cnt = 4;
+  }
+  if (cnt) {
+    double v[4] = {0, 0, 0, 0};
+    NK_TRY(nk_scalars_to_host(ctx, slot(S, 8), cnt, v));
+    if (l2) q->nf = sqrt(v[0]);
+    if (cnt == 4) { q->nfu = l2 ? sqrt(v[1]) : v[2]; q->relviol = v[3]; }
+  }
+  return NK_OK;
+}
+static double tc_objective(const nk_solver *S, const tc_quant &q) {
+  if (tm_rel(S->o.termination_mode)) return q.nf / (q.nfu + 2.220446049250313e-16 * S->reltol);  // eps(reltol)
+  return q.nf;
+}
+
+static int tc_reinit(nk_solver *S) {
   S->tc_retcode = NK_RET_DEFAULT;
   S->tc_nsteps = 0;
-  S->initial_obj = fnorm_inf0;
-  S->best_obj = fnorm_inf0;
+  tc_quant q;
+  NK_TRY(tc_quantities(S, &q));
+  S->initial_obj = tm_safe(S->o.termination_mode) ? tc_objective(S, q) : INFINITY;
+  S->best_obj = S->initial_obj;
   S->objectives_trace.assign(S->o.patience_steps > 0 ? S->o.patience_steps : 1, 0.0);
   if (S->o.max_stalled_steps >= 0) S->step_norm_trace.assign(S->o.max_stalled_steps > 0 ? S->o.max_stalled_steps : 1, 0.0);
   else S->step_norm_trace.clear();
+  if (tm_rel(S->o.termination_mode) && !S->step_norm_trace.empty()) {
+    NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->u, slot(S, 0)));
+    double v;
+    NK_TRY(fetch(S, 1, &v));
+    S->tc_u0_norm = sqrt(v);
+  }
+  return NK_OK;
 }
-// returns true when the solve must stop; step_norm = ‖u − uprev‖₂
-static int tc_check(nk_solver *S, double objective, double step_norm, bool *stop) {
+// sets *stop when the solve must end; step_norm = ‖u − uprev‖₂
+static int tc_check(nk_solver *S, double step_norm, bool *stop) {
   *stop = false;
-  const double criteria = S->abstol;
+  const int mode = S->o.termination_mode;
+  tc_quant q;
+  NK_TRY(tc_quantities(S, &q));
+  if (!tm_safe(mode)) {  // plain modes: check_convergence only (termination_conditions.jl:232-241)
+    bool conv = false;
+    switch (mode) {
+      case TM_NORM: conv = (q.nf <= S->abstol) || (q.nf <= S->reltol * q.nfu); break;
+      case TM_REL: conv = (q.relviol <= 0.0); break;
+      case TM_RELNORM: conv = (q.nf <= S->reltol * q.nfu); break;
+      case TM_ABS: conv = (S->fnorm_inf <= S->abstol); break;
+      case TM_ABSNORM: conv = (q.nf <= S->abstol); break;
+      default: break;
+    }
+    if (conv) { S->tc_retcode = NK_RET_SUCCESS; *stop = true; }
+    return NK_OK;
+  }
+  const double objective = tc_objective(S, q);
+  const double criteria = tm_rel(mode) ? S->reltol : S->abstol;
   if (!isfinite(objective)) { S->tc_retcode = NK_RET_UNSTABLE; *stop = true; return NK_OK; }
   if (S->o.protective_threshold > 0.0 &&
       objective > S->initial_obj * S->o.protective_threshold * (double)S->P->n_global) {
     S->tc_retcode = NK_RET_UNSTABLE; *stop = true; return NK_OK;
   }
-  if (objective < S->best_obj) {
+  if (tm_best(mode) && objective < S->best_obj) {
     S->best_obj = objective;
     NK_TRY(nk_blas_copy(S->ctx, S->n, S->u, S->best_u));
     S->best_version = S->u_version;
@@ -224,7 +362,8 @@ static int tc_check(nk_solver *S, double objective, double step_norm, bool *stop
     if (S->tc_nsteps > S->o.max_stalled_steps) {
       double mx = -INFINITY;
       for (double v : S->step_norm_trace) mx = fmax(mx, v);
-      if (mx <= S->abstol) { S->tc_retcode = NK_RET_STALLED; *stop = true; return NK_OK; }
+      const bool stalled = tm_rel(mode) ? (mx <= S->reltol * (mx + S->tc_u0_norm)) : (mx <= S->abstol);
+      if (stalled) { S->tc_retcode = NK_RET_STALLED; *stop = true; return NK_OK; }
     }
   }
   S->tc_retcode = NK_RET_FAILURE;
@@ -232,6 +371,7 @@ static int tc_check(nk_solver *S, double objective, double step_norm, bool *stop
 }
 // update_from_termination_cache! (termination_conditions.jl:440-453)
 static int rollback_to_best(nk_solver *S) {
+  if (!tm_best(S->o.termination_mode)) return NK_OK;  // only the *Best modes retain an iterate
   if (S->best_version == S->u_version) return NK_OK;
   NK_TRY(nk_blas_copy(S->ctx, S->n, S->best_u, S->u));
   S->u_version++;
@@ -264,7 +404,7 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   double v[2];
   NK_TRY(fetch(S, 2, v));
   S->fnorm_inf = v[0];
-  tc_reinit(S, v[0]);
+  NK_TRY(tc_reinit(S));
   if (concrete(S)) {  // jacobian.jl:104-118 evaluates J once at init
     NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
     S->stats.njacs++;
@@ -296,6 +436,8 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
              "unknown linsolve %d", opts->linsolve);
   NK_REQUIRE(!(opts->linsolve == NK_LINSOLVE_BANDED_LU && opts->forcing != NK_FORCING_NONE),
              "a forcing term needs an iterative linear solver");
+  NK_REQUIRE(opts->termination_mode >= 0 && opts->termination_mode <= 8, "bad termination_mode %d", opts->termination_mode);
+  NK_REQUIRE(opts->termination_norm == 0 || opts->termination_norm == 1, "bad termination_norm %d", opts->termination_norm);
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->forcing != NK_FORCING_NONE),
              "TrustRegion does not accept a forcing term (trust_region.jl:25-43)");
   nk_solver *S = new nk_solver();
@@ -645,7 +787,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     if (S->o.store_trace) du_norm = sqrt(v[2]);
   }
   bool stop = false;
-  NK_TRY(tc_check(S, S->fnorm_inf, step_norm, &stop));
+  NK_TRY(tc_check(S, step_norm, &stop));
   if (stop) {
     S->retcode = S->tc_retcode;
     NK_TRY(rollback_to_best(S));

@@ -428,13 +428,23 @@ class Solution:
 
 
 # ----------------------------------------------------------------------------- termination cache
-class TerminationCache:
-    """AbsNormSafeBestTerminationMode(maximum∘abs; max_stalled_steps = 32) functor —
-    termination_conditions.jl:243-336 (default mode :385-389)."""
+(TM_ABSNORM_SAFEBEST, TM_NORM, TM_REL, TM_RELNORM, TM_RELNORM_SAFE, TM_RELNORM_SAFEBEST, TM_ABS, TM_ABSNORM,
+ TM_ABSNORM_SAFE) = range(9)
+_SAFE = (TM_ABSNORM_SAFEBEST, TM_ABSNORM_SAFE, TM_RELNORM_SAFE, TM_RELNORM_SAFEBEST)
+_BEST = (TM_ABSNORM_SAFEBEST, TM_RELNORM_SAFEBEST)
+_RELSAFE = (TM_RELNORM_SAFE, TM_RELNORM_SAFEBEST)
 
-    def __init__(self, fu, u, abstol, patience_steps=100, patience_objective_multiplier=3.0,
-                 min_max_factor=1.3, max_stalled_steps=32, protective_threshold=None, leastsq=False):
-        self.abstol = abstol
+
+class TerminationCache:
+    """NonlinearTerminationModeCache functor for the nine SciMLBase modes — termination_conditions.jl:243-376.
+    Mode 0 with max_stalled_steps = 32 is the solver default (:385-389). `norm` is the mode's internalnorm:
+    "inf" = Base.Fix1(maximum, abs), "l2" = Base.Fix2(norm, 2); apply_norm(f, du, u) = f(du .+ u) (utils.jl:102)."""
+
+    def __init__(self, fu, u, abstol, reltol=DEFAULT_TOL, mode=TM_ABSNORM_SAFEBEST, norm="inf", patience_steps=100,
+                 patience_objective_multiplier=3.0, min_max_factor=1.3, max_stalled_steps=32,
+                 protective_threshold=None, leastsq=False):
+        self.abstol, self.reltol, self.mode = abstol, reltol, mode
+        self.nrm = Linf_NORM if norm == "inf" else L2_NORM
         self.patience_steps = patience_steps
         self.pom = patience_objective_multiplier
         self.min_max_factor = min_max_factor
@@ -443,18 +453,45 @@ class TerminationCache:
         self.leastsq = leastsq
         self.reinit(fu, u)
 
+    def _objective(self, du, u):
+        if self.mode in _RELSAFE:
+            return self.nrm(du) / (self.nrm(du + u) + np.finfo(float).eps * self.reltol)  # eps(reltol)
+        return self.nrm(du)
+
     def reinit(self, fu, u):
-        self.u = np.array(u, copy=True)
+        self.u = np.array(u, copy=True) if self.mode in _BEST else None
         self.retcode = DEFAULT
         self.nsteps = 0
-        self.initial_objective = Linf_NORM(fu)
+        if self.mode in _SAFE:
+            self.initial_objective = self._objective(fu, u)
+            self.u0_norm = L2_NORM(u) if (self.mode in _RELSAFE and self.max_stalled_steps is not None) else None
+        else:
+            self.initial_objective = float("inf")
         self.best_objective_value = self.initial_objective
         self.objectives_trace = np.zeros(self.patience_steps)
         self.step_norm_trace = None if self.max_stalled_steps is None else np.zeros(self.max_stalled_steps)
 
+    def _check_convergence(self, du, u):  # termination_conditions.jl:338-376
+        m = self.mode
+        if m == TM_REL:
+            return bool(np.all(np.abs(du) <= self.reltol * np.abs(u + du)))
+        if m == TM_ABS:
+            return bool(np.all(np.abs(du) <= self.abstol))
+        dn = self.nrm(du)
+        if m == TM_NORM:
+            return dn <= self.abstol or dn <= self.reltol * self.nrm(du + u)
+        if m == TM_RELNORM:
+            return dn <= self.reltol * self.nrm(du + u)
+        return dn <= self.abstol  # TM_ABSNORM
+
     def __call__(self, du, u, uprev):
-        objective = Linf_NORM(du)
-        criteria = self.abstol
+        if self.mode not in _SAFE:
+            if self._check_convergence(du, u):
+                self.retcode = SUCCESS
+                return True
+            return False
+        objective = self._objective(du, u)
+        criteria = self.reltol if self.mode in _RELSAFE else self.abstol
         if not math.isfinite(objective):
             self.retcode = UNSTABLE
             return True
@@ -462,7 +499,7 @@ class TerminationCache:
                 objective > self.initial_objective * self.protective_threshold * du.size:
             self.retcode = UNSTABLE
             return True
-        if objective < self.best_objective_value:
+        if self.mode in _BEST and objective < self.best_objective_value:
             self.best_objective_value = objective
             self.u[...] = u
         if objective <= criteria:
@@ -480,7 +517,9 @@ class TerminationCache:
             du_norm = L2_NORM(u - uprev)
             self.step_norm_trace[(self.nsteps - 1) % len(self.step_norm_trace)] = du_norm
             if self.nsteps > self.max_stalled_steps:
-                if self.step_norm_trace.max() <= self.abstol:
+                mx = self.step_norm_trace.max()
+                stalled = (mx <= self.reltol * (mx + self.u0_norm)) if self.mode in _RELSAFE else (mx <= self.abstol)
+                if stalled:
                     self.retcode = STALLED
                     return True
         self.retcode = FAILURE
@@ -517,7 +556,7 @@ class FirstOrderCache:
         self.retcode = DEFAULT
         self.force_stop = False
         self.make_new_jacobian = True
-        self.tc = TerminationCache(self.fu, self.u, self.abstol, **self.termination_kwargs)
+        self.tc = TerminationCache(self.fu, self.u, self.abstol, self.reltol, **self.termination_kwargs)
         self.J = None
         if self.concrete:
             self.J = prob.jac(self.u)  # jacobian.jl:104-118 (evaluated once "to get the type")
@@ -810,7 +849,7 @@ class FirstOrderCache:
         self.u_cache = self.u.copy()
 
     def _rollback_to_best(self):  # update_from_termination_cache! (termination_conditions.jl:440-453)
-        if np.array_equal(self.u, self.tc.u):
+        if self.tc.u is None or np.array_equal(self.u, self.tc.u):
             return
         self.u = self.tc.u.copy()
         self.fu = self.prob.f(self.u)

@@ -448,3 +448,37 @@ def test_bitwise_reproducible(nls):
         outs.append((np.asarray(sol.u).copy(), sol.stats.gmres_iters))
     assert outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][0], outs[1][0])
+
+
+# ------------------------------------------------------------------ termination conditions
+@pytest.mark.parametrize("idx", list(range(9)))
+@pytest.mark.parametrize("algname", ["nr", "tr"])
+def test_all_termination_conditions(nls, idx, algname):
+    """rootfind_tests__item4.jl / __item7.jl: `solve(prob, alg; termination_condition)` over the nine
+    TERMINATION_CONDITIONS on quadratic_f, err < 1e-9 — and the same step count / retcode as the oracle."""
+    tc = nls.TERMINATION_CONDITIONS[idx]()
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()) if algname == "nr" else nls.TrustRegion(linsolve=nls.KrylovJL_GMRES())
+    sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(2, 2.0)), alg, termination_condition=tc)
+    assert np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9 and sol.retcode == "Success"
+    oalg = R.NewtonRaphson(linsolve=R.KrylovJL_GMRES()) if algname == "nr" else R.TrustRegion(linsolve=R.KrylovJL_GMRES())
+    ref = R.solve(R.Quadratic(2, 2.0), oalg, termination_kwargs=dict(mode=tc.code, max_stalled_steps=None))
+    assert sol.stats.nsteps == ref.stats.nsteps and sol.retcode == R.RETCODE_NAMES[ref.retcode]
+
+
+@pytest.mark.parametrize("norm", ["inf", "l2"])
+def test_termination_internalnorm_and_relative_modes_on_bratu(nls, norm):
+    """Relative / 2-norm modes on a real problem: same stopping step as the oracle."""
+    for cls in (nls.RelNormSafeBestTerminationMode, nls.NormTerminationMode, nls.AbsNormTerminationMode):
+        tc = cls(internalnorm=norm)
+        prob = nls.NonlinearProblem(nls.Bratu2D(24, 6.0), u0=np.full(24 * 24, 0.5))
+        lin = dict(maxiters=4000, reltol=1e-11, abstol=0.0)
+        sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(**lin)), abstol=1e-9, reltol=1e-9,
+                        termination_condition=tc, maxiters=30)
+        oc = R.init(R.Bratu2D(24), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(maxiters=4000)), abstol=1e-9, reltol=1e-9,
+                    maxiters=30, u0=np.full(24 * 24, 0.5),
+                    termination_kwargs=dict(mode=tc.code, norm=norm, max_stalled_steps=None))
+        oc.lin_reltol, oc.lin_abstol = 1e-11, 0.0
+        ref = oc.solve()
+        assert sol.retcode == R.RETCODE_NAMES[ref.retcode] == "Success"
+        assert sol.stats.nsteps == ref.stats.nsteps
+        assert uerr(sol.u, ref.u) <= 1e-8

@@ -261,3 +261,14 @@ def test_golden_fixtures_reproduce():
     assert np.allclose(s.u, g["brus8_u"], rtol=1e-10, atol=1e-10)
     p = R.Bratu2D(16)
     assert np.allclose(p.jac(g["bratu16_u"]) @ g["v256"], g["bratu16_Jv"], rtol=1e-13)
+
+
+# ---- rootfind_tests__item4.jl / __item7.jl: every termination condition of TERMINATION_CONDITIONS, NR and TR
+@pytest.mark.parametrize("mode", list(range(9)))
+@pytest.mark.parametrize("alg", [R.NewtonRaphson(), R.TrustRegion()])
+def test_all_termination_conditions(mode, alg):
+    # explicit modes carry max_stalled_steps = nothing; mode 0 as the solver default carries 32
+    tk = dict(mode=mode, max_stalled_steps=None if mode else 32)
+    sol = R.solve(R.Quadratic(2, 2.0), alg, termination_kwargs=tk)
+    assert np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+    assert sol.retcode == R.SUCCESS
