@@ -183,6 +183,11 @@ typedef struct {
   /* --- tracing */
   int32_t store_trace;          /* keep nk_trace_entry rows (costs one extra 2-norm per step)       */
   int32_t termination_mode;     /* nk_termination_mode; 0 = AbsNormSafeBest, the reference default  */
+  /* --- preconditioner of the Krylov solver (`precs`): 0 none, >0 Chebyshev polynomial of that degree, its
+   *     interval re-estimated for every new Jacobian (lambda_max by power iteration, lambda_min = max/ratio) */
+  int32_t cheb_degree;
+  int32_t reserved2;
+  double  cheb_ratio;           /* ≤1 → 30 */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -298,6 +303,13 @@ int nk_gmres_set_operator_jvp(nk_gmres *G, nk_problem *P, const double *u, int m
 int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);   /* AbstractSciMLOperator    */
 /* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
 int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
+/* Built-in right preconditioner M⁻¹ = p_d(A): `degree` steps of the Chebyshev iteration on [lambda_min, lambda_max]
+ * (operator applications only: no inner products, no all-reduce). lambda_max = 0 ⇒ the dominant eigenvalue is
+ * bounded by Gershgorin (concrete CSR) or estimated by 30 power iterations ×1.15 (matrix-free / callback
+ * operators) and lambda_min = lambda_max / ratio. The interval must not contain 0
+ * (negative-definite operators are fine). degree ≤ 0 removes it. Call after the operator is set. */
+int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, double lambda_min, double lambda_max, double ratio);
+int nk_gmres_get_chebyshev_interval(nk_gmres *G, double *lambda_min, double *lambda_max);
 /* Solve A x = b. use_x0 = 0 ⇒ zero initial guess (our protocol); 1 ⇒ x holds x0.
  * Stop when ‖r‖₂ ≤ atol + rtol‖r0‖₂ or after maxiter Arnoldi steps; fixed_iters>0 overrides both. */
 int nk_gmres_solve(nk_gmres *G, const double *b, double *x, int memspace, int use_x0,

@@ -191,6 +191,7 @@ Base.@kwdef mutable struct NKOptions
     patience_steps::Int32 = 100; max_stalled_steps::Int32 = 32
     patience_objective_multiplier::Float64 = 3.0; min_max_factor::Float64 = 1.3; protective_threshold::Float64 = 0.0
     store_trace::Int32 = 0; termination_mode::Int32 = 0
+    cheb_degree::Int32 = 0; reserved2::Int32 = 0; cheb_ratio::Float64 = 0.0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,

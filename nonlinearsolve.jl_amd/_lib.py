@@ -64,6 +64,7 @@ class Options(C.Structure):
         ("patience_objective_multiplier", C.c_double), ("min_max_factor", C.c_double),
         ("protective_threshold", C.c_double),
         ("store_trace", C.c_int32), ("termination_mode", C.c_int32),
+        ("cheb_degree", C.c_int32), ("reserved2", C.c_int32), ("cheb_ratio", C.c_double),
     ]
 
 
@@ -131,6 +132,8 @@ SIGNATURES = {
     "nk_gmres_set_operator_jvp": (_I, [_P, _P, _P, _I]),
     "nk_gmres_set_operator_fn": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_right_preconditioner": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_chebyshev_preconditioner": (_I, [_P, _I, _D, _D, _D]),
+    "nk_gmres_get_chebyshev_interval": (_I, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "nk_gmres_solve": (_I, [_P, _P, _P, _I, _I, _D, _D, _I, _I, C.POINTER(GmresInfo)]),
     "nk_lu_create": (_I, [_P, _PP]),
     "nk_lu_destroy": (_I, [_P]),

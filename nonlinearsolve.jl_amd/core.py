@@ -484,6 +484,14 @@ class _nullctx:
 
 # ------------------------------------------------------------------------------------------- algorithms
 @dataclass
+class ChebyshevPrecs:
+    """`precs` for KrylovJL_GMRES: right preconditioner M⁻¹ = p_d(A), d Chebyshev steps on [λmax/ratio, λmax]
+    (λmax bounded/estimated by the library for every new Jacobian). Operator applications only."""
+    degree: int = 16
+    ratio: float = 100.0
+
+
+@dataclass
 class KrylovJL_GMRES:
     """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
     gmres_restart: int = 30
@@ -492,6 +500,7 @@ class KrylovJL_GMRES:
     fixed_iters: int = 0
     abstol: Optional[float] = None   # None → the nonlinear tolerances are forwarded (FirstOrder/src/solve.jl:203)
     reltol: Optional[float] = None
+    precs: Optional[ChebyshevPrecs] = None
 
 
 @dataclass
@@ -610,6 +619,8 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o.gmres_ortho, o.gmres_fixed_iters = _ORTHO[ls.ortho], int(ls.fixed_iters)
     o.lin_abstol = -1.0 if ls.abstol is None else float(ls.abstol)
     o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
+    if getattr(ls, "precs", None) is not None:
+        o.cheb_degree, o.cheb_ratio = int(ls.precs.degree), float(ls.precs.ratio)
     fo = getattr(alg, "forcing", None)
     if fo is not None:
         o.forcing = L.FORCING_EW2
@@ -853,6 +864,17 @@ class GMRES:
         self._keep.append(fn)
         check(L.lib().nk_gmres_set_right_preconditioner(self._h, fn, None))
         return self
+
+    def set_chebyshev_preconditioner(self, degree: int, lambda_min: float = 0.0, lambda_max: float = 0.0,
+                                     ratio: float = 30.0):
+        check(L.lib().nk_gmres_set_chebyshev_preconditioner(self._h, int(degree), float(lambda_min), float(lambda_max),
+                                                            float(ratio)))
+        return self
+
+    def chebyshev_interval(self):
+        a, b = C.c_double(), C.c_double()
+        check(L.lib().nk_gmres_get_chebyshev_interval(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def update_tolerances(self, abstol=None, reltol=None):  # LinearSolve.update_tolerances!
         if abstol is not None:

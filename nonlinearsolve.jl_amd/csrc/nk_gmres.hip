@@ -19,6 +19,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "nk_internal.h"
 
 // ----------------------------------------------------------------------------- small device kernels
@@ -195,6 +197,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
+  hipFree(G->cr); hipFree(G->cd); hipFree(G->ct);
   hipHostFree(G->h_ctl);
   delete G;
   return NK_OK;
@@ -232,13 +235,222 @@ extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, v
   NK_REQUIRE(G, "NULL argument");
   G->prec = fn;
   G->prec_user = user;
+  G->prec_kind = fn ? 1 : 0;
   if (fn && !G->z) NK_TRY(nk_dev_alloc(&G->z, (size_t)G->ldv));
+  return NK_OK;
+}
+
+// raw operator: y = scale · A x (no preconditioner)
+static int op_apply_raw(nk_gmres *G, const double *src, double *d_y, const int *d_skip, const double *oscale) {
+  nk_ctx *ctx = G->ctx;
+  switch (G->op_kind) {
+    case 1: return nk_csr_spmv_dev(G->A, src, d_y, d_skip, oscale);
+    case 2: return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip, oscale);
+    case 3:
+      ctx->stats.op_applies++;
+      if (oscale) NK_FAIL(NK_E_INVALID, "internal: output scale with a callback operator");
+      if (G->fn(G->fn_user, src, d_y, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "operator callback failed");
+      return NK_OK;
+    default: NK_FAIL(NK_E_INVALID, "GMRES has no operator");
+  }
+}
+
+// ----------------------------------------------------------------------------- Chebyshev polynomial preconditioner
+// M⁻¹ v = p_d(A) v: d steps of the Chebyshev iteration for A y = v from y = 0 on the interval [lmin, lmax]
+// (Saad, Iterative Methods, Alg. 12.1). Operator applications only — no inner products, hence no all-reduce on
+// multi-GPU — and it reuses the fastest kernel of the library (SpMV / fused JVP). The `precs` hook of the
+// reference (test/Core/core_tests__item21.jl) is where a user would plug such a preconditioner in.
+__global__ __launch_bounds__(NK_BLOCK) void k_cheb_init(int64_t n, const double *__restrict__ v, double inv_theta,
+                                                        double *__restrict__ r, double *__restrict__ d,
+                                                        double *__restrict__ y, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double x = v[i], dd = x * inv_theta;
+    r[i] = x;
+    d[i] = dd;
+    y[i] = dd;
+  }
+}
+// r −= A d ; d = c1 d + c2 r ; y += d      (56 n bytes)
+__global__ __launch_bounds__(NK_BLOCK) void k_cheb_update(int64_t n, const double *__restrict__ Ad, double c1, double c2,
+                                                          double *__restrict__ r, double *__restrict__ d,
+                                                          double *__restrict__ y, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const int64_t npair = n >> 1, stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < npair; i += stride) {
+    const double2 t = reinterpret_cast<const double2 *>(Ad)[i];
+    double2 rr = reinterpret_cast<double2 *>(r)[i], dd = reinterpret_cast<double2 *>(d)[i],
+            yy = reinterpret_cast<double2 *>(y)[i];
+    rr.x -= t.x; rr.y -= t.y;
+    dd.x = c1 * dd.x + c2 * rr.x; dd.y = c1 * dd.y + c2 * rr.y;
+    yy.x += dd.x; yy.y += dd.y;
+    reinterpret_cast<double2 *>(r)[i] = rr;
+    reinterpret_cast<double2 *>(d)[i] = dd;
+    reinterpret_cast<double2 *>(y)[i] = yy;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    r[i] -= Ad[i];
+    d[i] = c1 * d[i] + c2 * r[i];
+    y[i] += d[i];
+  }
+}
+
+static int cheb_apply(nk_gmres *G, const double *src, double *dst, const int *d_skip) {
+  nk_ctx *ctx = G->ctx;
+  const int64_t n = G->n;
+  const double theta = 0.5 * (G->cheb_lmax + G->cheb_lmin), delta = 0.5 * (G->cheb_lmax - G->cheb_lmin);
+  const double sigma1 = theta / delta;
+  double rho = 1.0 / sigma1;
+  const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, 4096);
+  {
+    nk_prof_scope prof_(ctx, NK_K_OTHER, 32.0 * (double)n);
+    NK_LAUNCH(ctx, k_cheb_init, dim3(grid), dim3(NK_BLOCK), n, src, 1.0 / theta, G->cr, G->cd, dst, d_skip);
+  }
+  for (int k = 1; k < G->cheb_degree; ++k) {
+    NK_TRY(op_apply_raw(G, G->cd, G->ct, d_skip, nullptr));
+    const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+    nk_prof_scope prof_(ctx, NK_K_OTHER, 56.0 * (double)n);
+    NK_LAUNCH(ctx, k_cheb_update, dim3(grid), dim3(NK_BLOCK), n, (const double *)G->ct, rho_new * rho, 2.0 * rho_new / delta,
+              G->cr, G->cd, dst, d_skip);
+    rho = rho_new;
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+// start vector with energy in every mode (a constant vector has none in the oscillatory ones)
+__global__ __launch_bounds__(NK_BLOCK) void k_hash_fill(int64_t n, double *__restrict__ x) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const uint32_t hsh = (uint32_t)i * 2654435761u;
+    x[i] = 0.5 + (double)((hsh >> 8) & 0xffff) / 65536.0 * ((hsh & 1) ? 1.0 : -1.0);
+  }
+}
+// Gershgorin: per-block max of Σ_j |a_ij| and of the signed diagonal-dominant centre (for the sign of the spectrum)
+__global__ __launch_bounds__(NK_BLOCK) void k_gershgorin(int64_t nrows, const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                         double *__restrict__ partials) {
+  __shared__ double sm[8];
+  double mx = 0.0, dsum = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; r < nrows; r += stride) {
+    double s = 0.0;
+    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      s += fabs(val[p]);
+      if (col[p] == r) dsum += val[p];
+    }
+    mx = s > mx ? s : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double m2 = __shfl_xor(mx, o, 64);
+    mx = m2 > mx ? m2 : mx;
+    dsum += __shfl_xor(dsum, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mx; sm[4 + (threadIdx.x >> 6)] = dsum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = sm[0];
+    for (int k = 1; k < 4; ++k) a = sm[k] > a ? sm[k] : a;
+    partials[blockIdx.x] = a;
+    partials[gridDim.x + blockIdx.x] = sm[4] + sm[5] + sm[6] + sm[7];
+  }
+}
+
+// bound / estimate of the dominant eigenvalue (with its sign):
+//   concrete CSR: Gershgorin max_i Σ_j|a_ij| — a guaranteed bound; sign from the trace
+//   otherwise   : 30 power iterations, Rayleigh quotient, widened by 15 %
+static int estimate_lambda(nk_gmres *G, double *lambda) {
+  nk_ctx *ctx = G->ctx;
+  const int64_t n = G->n;
+  if (G->op_kind == 1) {
+    nk_csr *A = G->A;
+    const int grid = nk_grid_for(A->nrows, NK_BLOCK, NK_MAX_RED_BLOCKS);
+    NK_LAUNCH(ctx, k_gershgorin, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col, A->d_val, ctx->d_partials);
+    // reduce on the host side of a tiny copy (≤ 2048 doubles)
+    std::vector<double> hp(2 * (size_t)grid);
+    NK_HIP(hipMemcpyAsync(hp.data(), ctx->d_partials, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    double mx = 0.0, tr = 0.0;
+    for (int b = 0; b < grid; ++b) { mx = hp[b] > mx ? hp[b] : mx; tr += hp[grid + b]; }
+    if (ctx->nranks > 1) {
+      ctx->h_pinned[0] = mx;
+      NK_HIP(hipMemcpyAsync(ctx->d_scal, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      NK_TRY(nk_comm_allreduce(ctx, ctx->d_scal, 1, 1));
+      ctx->h_pinned[0] = tr;
+      NK_HIP(hipMemcpyAsync(ctx->d_scal + 1, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      NK_TRY(nk_comm_allreduce(ctx, ctx->d_scal + 1, 1, 0));
+      double v[2];
+      NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 2, v));
+      mx = v[0];
+      tr = v[1];
+    }
+    *lambda = (tr < 0.0) ? -mx : mx;
+    return NK_OK;
+  }
+  NK_LAUNCH(ctx, k_hash_fill, dim3(nk_grid_for(n, NK_BLOCK * 4, 4096)), dim3(NK_BLOCK), n, G->cd);
+  double lam = 0.0;
+  for (int it = 0; it < 30; ++it) {
+    NK_TRY(op_apply_raw(G, G->cd, G->ct, nullptr, nullptr));
+    NK_TRY(nk_blas_dot(ctx, n, G->cd, G->ct, ctx->d_scal));
+    NK_TRY(nk_blas_dot(ctx, n, G->cd, G->cd, ctx->d_scal + 1));
+    NK_TRY(nk_blas_dot(ctx, n, G->ct, G->ct, ctx->d_scal + 2));
+    double v[3];
+    NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 3, v));
+    if (!(v[1] > 0.0) || !(v[2] > 0.0)) break;
+    lam = v[0] / v[1];  // Rayleigh quotient of the current vector
+    NK_TRY(nk_blas_lincomb(ctx, n, 1.0 / sqrt(v[2]), G->ct, 0.0, G->ct, G->cd));
+  }
+  *lambda = 1.15 * lam;
+  return NK_OK;
+}
+
+extern "C" int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, double lambda_min, double lambda_max,
+                                                     double ratio) {
+  NK_REQUIRE(G, "NULL argument");
+  NK_REQUIRE(G->op_kind != 0, "set the operator before the preconditioner");
+  if (degree <= 0) {
+    G->prec_kind = G->prec ? 1 : 0;
+    return NK_OK;
+  }
+  NK_HIP(hipSetDevice(G->ctx->device));
+  if (!G->z) NK_TRY(nk_dev_alloc(&G->z, (size_t)G->ldv));
+  if (!G->cr) NK_TRY(nk_dev_alloc(&G->cr, (size_t)G->ldv));
+  if (!G->cd) NK_TRY(nk_dev_alloc(&G->cd, (size_t)G->ldv));
+  if (!G->ct) NK_TRY(nk_dev_alloc(&G->ct, (size_t)G->ldv));
+  if (lambda_max == 0.0) {  // estimate the dominant eigenvalue, widen by 10 %, and take lmin = lmax / ratio
+    double lam = 0.0;
+    NK_TRY(estimate_lambda(G, &lam));
+    NK_REQUIRE(lam != 0.0 && lam == lam, "could not estimate the spectrum of the operator");
+    if (ratio <= 1.0) ratio = 30.0;
+    lambda_max = lam;
+    lambda_min = lambda_max / ratio;
+  }
+  NK_REQUIRE(lambda_min * lambda_max > 0.0 && lambda_min != lambda_max, "Chebyshev interval must not contain 0");
+  G->cheb_degree = degree;
+  G->cheb_lmin = lambda_min;
+  G->cheb_lmax = lambda_max;
+  G->prec_kind = 2;
+  return NK_OK;
+}
+extern "C" int nk_gmres_get_chebyshev_interval(nk_gmres *G, double *lambda_min, double *lambda_max) {
+  NK_REQUIRE(G, "NULL argument");
+  if (lambda_min) *lambda_min = G->cheb_lmin;
+  if (lambda_max) *lambda_max = G->cheb_lmax;
+  return NK_OK;
+}
+
+static int prec_apply(nk_gmres *G, const double *src, double *dst, const int *d_skip) {
+  if (G->prec_kind == 2) return cheb_apply(G, src, dst, d_skip);
+  if (G->prec(G->prec_user, src, dst, (void *)G->ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
   return NK_OK;
 }
 
 // can the operator kernel apply the output scale itself (built-in kernels) or do we have to scale the input?
 static bool op_fuses_scale(const nk_gmres *G) {
-  if (G->prec) return false;
+  if (G->prec_kind) return false;
   if (G->op_kind == 1) return true;
   if (G->op_kind == 2) return G->P->kind != NK_PROBLEM_USER;
   return false;
@@ -254,19 +466,11 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
     src = G->w;
     oscale = nullptr;
   }
-  if (G->prec) {
-    if (G->prec(G->prec_user, src, G->z, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
+  if (G->prec_kind) {
+    NK_TRY(prec_apply(G, src, G->z, d_skip));
     src = G->z;
   }
-  switch (G->op_kind) {
-    case 1: return nk_csr_spmv_dev(G->A, src, d_y, d_skip, oscale);
-    case 2: return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip, oscale);
-    case 3:
-      ctx->stats.op_applies++;
-      if (G->fn(G->fn_user, src, d_y, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "operator callback failed");
-      return NK_OK;
-    default: NK_FAIL(NK_E_INVALID, "GMRES has no operator");
-  }
+  return op_apply_raw(G, src, d_y, d_skip, oscale);
 }
 
 // ----------------------------------------------------------------------------- one Arnoldi step (enqueue only)
@@ -343,8 +547,8 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     NK_TRY(nk_blas_fill(ctx, n, 0.0, d_x));
     NK_TRY(nk_blas_copy(ctx, n, d_b, G->V));
   } else {
-    if (G->prec) NK_FAIL(NK_E_UNSUPPORTED, "use_x0 with a right preconditioner is not supported");
-    NK_TRY(op_apply(G, d_x, G->r, nullptr, nullptr));
+    if (G->prec_kind) NK_FAIL(NK_E_UNSUPPORTED, "use_x0 with a right preconditioner is not supported");
+    NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
     NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
   }
   int first = 1;
@@ -358,12 +562,12 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step(G, k));
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
     NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(64), G->d_ctl, G->d_R, G->d_g, G->d_y, m);
-    if (!G->prec) {
+    if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s));
     } else {
       NK_TRY(nk_blas_fill(ctx, n, 0.0, G->r));
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, G->r, nullptr, nullptr, &G->d_ctl->k, G->d_s));
-      if (G->prec(G->prec_user, G->r, G->z, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
+      NK_TRY(prec_apply(G, G->r, G->z, nullptr));
       NK_TRY(nk_blas_axpby(ctx, n, 1.0, G->z, 1.0, d_x));
     }
     NK_HIP(hipMemcpyAsync(G->h_ctl, G->d_ctl, sizeof(nk_gmres_ctl), hipMemcpyDeviceToHost, ctx->stream));
@@ -377,11 +581,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     if (c.failed || c.converged || total_iters >= cap || steps == 0) break;
     inf.restarts++;
     // restart: r = b − A x into column 0
-    nk_matvec_fn p = G->prec;
-    G->prec = nullptr;  // A x directly: x lives in the original space
-    int st = op_apply(G, d_x, G->r, nullptr, nullptr);
-    G->prec = p;
-    NK_TRY(st);
+    NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));  // A x directly: x lives in the original space
     NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
   }
   inf.iters = total_iters;

@@ -225,6 +225,10 @@ struct nk_gmres {
   void *fn_user = nullptr;
   nk_matvec_fn prec = nullptr;
   void *prec_user = nullptr;
+  int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial
+  int cheb_degree = 0;
+  double cheb_lmin = 0, cheb_lmax = 0;
+  double *cr = nullptr, *cd = nullptr, *ct = nullptr;  // Chebyshev work vectors
   double *d_b = nullptr, *d_x = nullptr;  // staging for host-memspace calls
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,

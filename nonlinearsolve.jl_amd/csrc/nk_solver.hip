@@ -716,6 +716,8 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       NK_TRY(nk_gmres_set_operator_jvp(S->G, S->P, S->u, NK_DEVICE));  // StatefulJacobianOperator(J, u, p)
     }
     new_jacobian = true;
+    if (!direct(S) && S->o.cheb_degree > 0)  // precs(A, p) is re-evaluated for every new A
+      NK_TRY(nk_gmres_set_chebyshev_preconditioner(S->G, S->o.cheb_degree, 0.0, 0.0, S->o.cheb_ratio));
   } else {
     new_jacobian = false;
   }

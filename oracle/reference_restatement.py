@@ -267,12 +267,45 @@ class GmresInfo:
     residuals: list = field(default_factory=list)
 
 
+def chebyshev_preconditioner(matvec: Callable, lmin: float, lmax: float, degree: int) -> Callable:
+    """M⁻¹ v = p_d(A) v: `degree` steps of the Chebyshev iteration for A y = v from y = 0 on [lmin, lmax]
+    (Saad, Iterative Methods for Sparse Linear Systems, Alg. 12.1) — the polynomial preconditioner a user would
+    return from the reference's `precs(A, p)` hook (test/Core/core_tests__item21.jl:10-18)."""
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    sigma1 = theta / delta
+
+    def M(v):
+        rho = 1.0 / sigma1
+        r = np.array(v, dtype=np.float64, copy=True)
+        d = r / theta
+        y = d.copy()
+        for _ in range(1, degree):
+            r = r - matvec(d)
+            rho_new = 1.0 / (2.0 * sigma1 - rho)
+            d = rho_new * rho * d + (2.0 * rho_new / delta) * r
+            y = y + d
+            rho = rho_new
+        return y
+    return M
+
+
+def gershgorin_lambda(J) -> float:
+    """max_i Σ_j |a_ij| with the sign of the trace: the bound the device library uses for a concrete J."""
+    J = sp.csr_matrix(J)
+    mx = float(abs(J).sum(axis=1).max())
+    return -mx if J.diagonal().sum() < 0 else mx
+
+
 def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0,
-          ortho="mgs", allreduce: Optional[Callable] = None):
+          ortho="mgs", allreduce: Optional[Callable] = None, M: Optional[Callable] = None):
     """Restarted GMRES(m) with MGS Arnoldi and Givens rotations, right-hand side b, zero (or given)
     initial guess.  Stop when the recurrence residual ≤ atol + rtol*‖r0‖ or after itmax Arnoldi steps.
     fixed_iters>0: run exactly that many Arnoldi steps (tolerances ignored).
     `allreduce(x)` (optional) sums partial inner products across ranks (distributed oracle, tests only)."""
+    if M is not None:  # right preconditioning: solve (A M⁻¹) z = b, x = M⁻¹ z  (zero initial guess only)
+        assert x0 is None
+        z, info = gmres(lambda v: matvec(M(v)), b, None, atol, rtol, restart, itmax, fixed_iters, ortho, allreduce)
+        return M(z), info
     ar = allreduce if allreduce is not None else (lambda z: z)
     b = np.asarray(b, dtype=np.float64)
     n = b.size
@@ -358,12 +391,19 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
 
 # ----------------------------------------------------------------------------- algorithm descriptors
 @dataclass
+class ChebyshevPrecs:
+    degree: int = 16
+    ratio: float = 100.0
+
+
+@dataclass
 class KrylovJL_GMRES:
-    """Krylov protocol of SURVEY.md §8d (GMRES(m), restart on, x0 = 0, no preconditioner)."""
+    """Krylov protocol of SURVEY.md §8d (GMRES(m), restart on, x0 = 0); `precs` = optional right preconditioner."""
     gmres_restart: int = 30
     maxiters: int = 300
     ortho: str = "mgs"
     fixed_iters: int = 0
+    precs: Optional[ChebyshevPrecs] = None
 
 
 @dataclass
@@ -634,9 +674,15 @@ class FirstOrderCache:
         if self.krylov is not None:
             kr = self.krylov
             u_now = self.u
+            M = None
+            if kr.precs is not None:  # precs(A, p) re-evaluated for the current J (concrete J: Gershgorin bound)
+                assert self.concrete, "the oracle's Chebyshev precs needs a concrete J (Gershgorin bound)"
+                lmax = gershgorin_lambda(self.J)
+                M = chebyshev_preconditioner(lambda v: self._apply_J(v, u_now), lmax / kr.precs.ratio, lmax,
+                                             kr.precs.degree)
             x, info = gmres(lambda v: self._apply_J(v, u_now), self.fu, None, atol=self.lin_abstol,
                             rtol=self.lin_reltol, restart=kr.gmres_restart, itmax=kr.maxiters,
-                            fixed_iters=kr.fixed_iters, ortho=kr.ortho)
+                            fixed_iters=kr.fixed_iters, ortho=kr.ortho, M=M)
             self.stats.gmres_iters += info.iters
             self.last_gmres = info
             if info.failed:

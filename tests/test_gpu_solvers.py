@@ -482,3 +482,48 @@ def test_termination_internalnorm_and_relative_modes_on_bratu(nls, norm):
         assert sol.retcode == R.RETCODE_NAMES[ref.retcode] == "Success"
         assert sol.stats.nsteps == ref.stats.nsteps
         assert uerr(sol.u, ref.u) <= 1e-8
+
+
+# ------------------------------------------------------------------ built-in Chebyshev preconditioner (`precs`)
+@pytest.mark.parametrize("op", ["csr", "matfree"])
+def test_chebyshev_preconditioned_gmres(nls, dev, op):
+    ns = 96
+    p = R.Bratu2D(ns)
+    u = 0.2 * np.random.default_rng(0).standard_normal(p.n)
+    J = p.jac(u)
+    b = np.random.default_rng(1).standard_normal(p.n)
+    G = nls.GMRES(p.n, restart=30)
+    if op == "csr":
+        G.set_operator(nls.CSRMatrix.from_scipy(J))
+    else:
+        G.set_operator(nls.StatefulJacobianOperator(nls.JacobianOperator(nls.NonlinearProblem(nls.Bratu2D(ns))), u))
+    x0, i0 = G.solve(b, reltol=1e-8, maxiters=20000)
+    G.set_chebyshev_preconditioner(16, ratio=100.0)
+    lmin, lmax = G.chebyshev_interval()
+    gl = R.gershgorin_lambda(J)
+    if op == "csr":
+        assert np.isclose(lmax, gl, rtol=1e-12) and np.isclose(lmin, gl / 100, rtol=1e-12)
+    else:  # power iteration ×1.15 must still bound the spectrum (8·c_lap is its supremum) without gross excess
+        assert 0.97 * gl <= lmax <= 1.25 * gl
+    x1, i1 = G.solve(b, reltol=1e-8, maxiters=2000)
+    assert i1["converged"] and i1["iters"] * 10 < i0["iters"]
+    xd = np.linalg.solve(J.toarray(), b) if p.n <= 4096 else __import__("scipy.sparse.linalg").sparse.linalg.spsolve(J.tocsc(), b)
+    assert np.linalg.norm(x1 - xd) <= 1e-6 * np.linalg.norm(xd)
+    if op == "csr":  # same algorithm, same interval ⇒ the oracle takes (almost) the same number of steps
+        M = R.chebyshev_preconditioner(lambda z: J @ z, gl / 100, gl, 16)
+        xr, ir = R.gmres(lambda z: J @ z, b, rtol=1e-8, itmax=2000, M=M)
+        assert abs(ir.iters - i1["iters"]) <= 2 and np.linalg.norm(x1 - xr) <= 1e-6 * np.linalg.norm(xr)
+
+
+def test_newton_with_chebyshev_precs_vs_oracle(nls):
+    ns = 128
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.ChebyshevPrecs(16, 100.0)),
+                            forcing=nls.EisenstatWalkerForcing2(), concrete_jac=True)
+    sol = nls.solve(nls.NonlinearProblem(nls.Bratu2D(ns)), alg, abstol=1e-9, maxiters=50)
+    ref = R.solve(R.Bratu2D(ns), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=R.ChebyshevPrecs(16, 100.0)),
+                                                 forcing=R.EisenstatWalkerForcing2(), concrete_jac=True),
+                  abstol=1e-9, maxiters=50)
+    direct = R.solve(R.Bratu2D(ns), R.NewtonRaphson(), abstol=1e-9, maxiters=50)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
+    assert uerr(sol.u, direct.u) <= 5e-7 and uerr(sol.u, ref.u) <= 5e-7

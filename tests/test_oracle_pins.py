@@ -272,3 +272,22 @@ def test_all_termination_conditions(mode, alg):
     sol = R.solve(R.Quadratic(2, 2.0), alg, termination_kwargs=tk)
     assert np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
     assert sol.retcode == R.SUCCESS
+
+
+# ---- Chebyshev polynomial right preconditioner (what a `precs` hook would return): same solution, far fewer steps
+def test_chebyshev_precs_oracle():
+    p = R.Bratu2D(64)
+    J = p.jac(np.zeros(p.n))
+    b = np.random.default_rng(3).standard_normal(p.n)
+    x0, i0 = R.gmres(lambda z: J @ z, b, rtol=1e-8, itmax=20000)
+    lmax = R.gershgorin_lambda(J)
+    assert np.isclose(lmax, 8.0 * p.c_lap - p.c_exp, rtol=1e-12) or lmax > 0
+    M = R.chebyshev_preconditioner(lambda z: J @ z, lmax / 100, lmax, 16)
+    x1, i1 = R.gmres(lambda z: J @ z, b, rtol=1e-8, itmax=2000, M=M)
+    xd = spla.spsolve(J.tocsc(), b)
+    assert i0.converged and i1.converged and i1.iters * 10 < i0.iters
+    assert np.linalg.norm(x1 - xd) <= 1e-6 * np.linalg.norm(xd)
+    s = R.solve(p, R.NewtonRaphson(linsolve=GM(precs=R.ChebyshevPrecs(16, 100)), forcing=R.EisenstatWalkerForcing2(),
+                                   concrete_jac=True), abstol=1e-9, maxiters=50)
+    d = R.solve(p, R.NewtonRaphson(), abstol=1e-9, maxiters=50)
+    assert s.retcode == R.SUCCESS and np.max(np.abs(s.u - d.u)) < 1e-7 and s.stats.nsteps <= d.stats.nsteps + 6
