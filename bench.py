@@ -178,6 +178,33 @@ def main():
                "sample": f"{args.cpu_steps} fixed-work Newton steps (30 MGS-GMRES Arnoldi steps each) of the same "
                          f"Bratu {ns}x{ns} workload, oracle/nk_oracle.c with OpenMP on {cores} threads, {tcpu:.1f} s"}
 
+    # ---- time to tolerance (extra, not `value`): the §3 protocol (NewtonRaphson + GMRES(30) + Eisenstat–Walker,
+    # inner cap 300, ‖h²F‖∞ ≤ 1e-8) with the Chebyshev(32, ratio 300) right preconditioner, device vs the oracle's
+    # C/OpenMP restatement of the same algorithm on the host cores
+    ttt = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        import numpy as np
+        from oracle import c_oracle as CO
+        prob2 = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(n_local, dtype=torch.float64, device="cuda"))
+        alg2 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300,
+                                                             precs=nls.ChebyshevPrecs(32, 300.0)),
+                                 forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
+        nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)  # warm-up (allocations, first-touch)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        sol2 = nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg
+        tc2 = time.perf_counter()
+        uC, fnC, giC = CO.bratu_newton_cheb(ns, 6.0, 0.0, np.zeros(ns * ns), 50, not args.matfree, 30, 300, 32, 300.0, 1e-8)
+        tc2 = time.perf_counter() - tc2
+        ttt = {"protocol": "NewtonRaphson+GMRES(30)+EisenstatWalkerForcing2+Chebyshev(32,300) to |h^2 F|inf<=1e-8",
+               "gpu_seconds": round(tg, 4), "gpu_newton_steps": sol2.stats.nsteps, "gpu_gmres_iters": sol2.stats.gmres_iters,
+               "gpu_retcode": sol2.retcode, "cpu_seconds": round(tc2, 3), "cpu_newton_steps": int(len(fnC)),
+               "cpu_gmres_iters": int(giC.sum()), "cpu_cores": CO.num_threads(),
+               "u_maxdiff_gpu_vs_cpu": float(np.max(np.abs(sol2.u.cpu().numpy() - uC))),
+               "speedup": round(tc2 / tg, 1)}
+
     if rank == 0:
         line = {
             "metric": "newton_steps_per_sec", "value": round(steps_per_s, 3), "unit": "newton_steps/s",
@@ -189,7 +216,7 @@ def main():
                        "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
                        "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho,
                        "parallelism": f"row-range x{world}", "comm": comm},
-            "roofline": roof, "kernels": ksum, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt,
             "gpu_vs_cpu": round(steps_per_s / cpu["value"], 1) if cpu else None,
             "check": {"fnorm_inf_after_timed_steps": fnorm, "gmres_iters": stats.gmres_iters,
                       "nsteps": stats.nsteps, "allreduces": stats.allreduces},

@@ -48,6 +48,9 @@ def lib():
         L.orc_bratu_newton.restype = C.c_int
         L.orc_bratu_newton.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_double, _d, _i, _d]
+        L.orc_bratu_newton_cheb.restype = C.c_int
+        L.orc_bratu_newton_cheb.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_double, C.c_double, _d, _i]
         _lib = L
     return _lib
 
@@ -121,3 +124,15 @@ def bratu_newton(ns, lam, scale, u0, nsteps, use_csr=True, m=30, itmax=300, fixe
     lib().orc_bratu_newton(ns, lam, scale, u, nsteps, int(use_csr), m, itmax, fixed_iters, int(forcing), rtol,
                            fn, gi, eta)
     return u, fn, gi, eta
+
+
+def bratu_newton_cheb(ns, lam, scale, u0, maxsteps=50, use_csr=True, m=30, itmax=300, cheb_degree=32, cheb_ratio=300.0,
+                      abstol=1e-8):
+    """NewtonRaphson + GMRES(m) + Eisenstat–Walker + Chebyshev(degree, ratio) right preconditioner, stop at
+    ‖f‖∞ ≤ abstol — the CPU counterpart of the device `precs` path. Returns (u, fnorm trace, gmres iters)."""
+    u = np.array(u0, dtype=np.float64, copy=True)
+    fn = np.zeros(maxsteps)
+    gi = np.zeros(maxsteps, dtype=np.int32)
+    k = lib().orc_bratu_newton_cheb(ns, lam, scale, u, maxsteps, int(use_csr), m, itmax, cheb_degree, cheb_ratio, abstol,
+                                    fn, gi)
+    return u, fn[:k], gi[:k]

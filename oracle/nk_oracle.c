@@ -180,6 +180,35 @@ static void op_apply(const orc_op *A, const double *x, double *y) {
   else orc_bratu_jvp(A->ns, A->lambda, A->scale, A->u, x, y);
 }
 
+/* Chebyshev polynomial right preconditioner (Saad Alg. 12.1): y = p_d(A) v on [lmin, lmax]; work = 3 n doubles */
+typedef struct { int degree; double lmin, lmax; double *work; } orc_cheb;
+static void cheb_apply(const orc_op *A, const orc_cheb *C, const double *v, double *y) {
+  const int64_t n = A->n;
+  double *r = C->work, *d = C->work + n, *t = C->work + 2 * n;
+  const double theta = 0.5 * (C->lmax + C->lmin), delta = 0.5 * (C->lmax - C->lmin), sigma1 = theta / delta;
+  double rho = 1.0 / sigma1;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) { r[i] = v[i]; d[i] = v[i] / theta; y[i] = d[i]; }
+  for (int k = 1; k < C->degree; ++k) {
+    op_apply(A, d, t);
+    const double rho_new = 1.0 / (2.0 * sigma1 - rho), c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      r[i] -= t[i];
+      d[i] = c1 * d[i] + c2 * r[i];
+      y[i] += d[i];
+    }
+    rho = rho_new;
+  }
+}
+static const orc_cheb *g_cheb = NULL; /* set by the callers below; NULL = no preconditioner */
+static double *g_cheb_tmp = NULL;
+static void op_apply_prec(const orc_op *A, const double *x, double *y) {
+  if (!g_cheb) { op_apply(A, x, y); return; }
+  cheb_apply(A, g_cheb, x, g_cheb_tmp);
+  op_apply(A, g_cheb_tmp, y);
+}
+
 /* GMRES(m), zero initial guess. Returns Arnoldi steps done; *converged, *rnorm0, *rnorm filled.
  * fixed_iters>0: exactly that many steps. work: (m+2)*n doubles. */
 static int gmres_run(const orc_op *A, const double *b, double *x, double atol, double rtol, int m,
@@ -211,7 +240,7 @@ static int gmres_run(const orc_op *A, const double *b, double *x, double atol, d
       g[0] = beta;
       int k = 0, done = 0;
       while (k < m && iters < cap) {
-        op_apply(A, V + (size_t)k * n, w);
+        op_apply_prec(A, V + (size_t)k * n, w);
         for (int i = 0; i <= k; ++i) { /* modified Gram–Schmidt */
           h[i] = dot(n, V + (size_t)i * n, w);
           axpy(n, -h[i], V + (size_t)i * n, w);
@@ -249,7 +278,7 @@ static int gmres_run(const orc_op *A, const double *b, double *x, double atol, d
       }
       if (done || iters >= cap) { free(rbuf); break; }
       if (!rbuf) rbuf = (double *)malloc((size_t)n * sizeof(double));
-      op_apply(A, x, w);
+      op_apply_prec(A, x, w); /* x is still in the preconditioned space here */
 #pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) rbuf[i] = b[i] - w[i];
       r = rbuf;
@@ -258,6 +287,10 @@ static int gmres_run(const orc_op *A, const double *b, double *x, double atol, d
   }
 out:
   free(R); free(cs); free(sn); free(g); free(h); free(yv);
+  if (g_cheb) { /* x = M⁻¹ z */
+    cheb_apply(A, g_cheb, x, g_cheb_tmp);
+    memcpy(x, g_cheb_tmp, (size_t)n * sizeof(double));
+  }
   return iters;
 }
 
@@ -328,4 +361,72 @@ int orc_bratu_newton(int64_t ns, double lambda, double scale, double *u, int nst
   }
   free(f); free(dx); free(work); free(rowptr); free(col); free(val);
   return 0;
+}
+
+/* Same Newton–Krylov loop with the Chebyshev(degree, ratio) right preconditioner (λmax = Gershgorin bound of the
+ * Bratu Jacobian, λmin = λmax/ratio) and an early stop at ‖f‖∞ ≤ abstol: the CPU counterpart of the device
+ * library's `precs` path, used for time-to-tolerance baselines. Returns the number of Newton steps taken. */
+int orc_bratu_newton_cheb(int64_t ns, double lambda, double scale, double *u, int maxsteps, int use_csr, int m,
+                          int itmax, int cheb_degree, double cheb_ratio, double abstol, double *fnorm_inf,
+                          int32_t *gmres_iters) {
+  const int64_t n = ns * ns;
+  bratu_t b = bratu_make(ns, lambda, scale);
+  double *f = (double *)malloc((size_t)n * sizeof(double));
+  double *dx = (double *)malloc((size_t)n * sizeof(double));
+  double *work = (double *)malloc((size_t)(m + 2) * n * sizeof(double));
+  double *cw = (double *)malloc((size_t)4 * n * sizeof(double));
+  int32_t *rowptr = NULL, *col = NULL;
+  double *val = NULL;
+  if (use_csr) {
+    int64_t nnz = orc_bratu_nnz(ns);
+    rowptr = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
+    col = (int32_t *)malloc((size_t)nnz * sizeof(int32_t));
+    val = (double *)malloc((size_t)nnz * sizeof(double));
+    orc_bratu_pattern(ns, rowptr, col);
+  }
+  orc_bratu_residual(ns, lambda, scale, u, f);
+  double eta = 0.5, rn = sqrt(dot(n, f, f)), rn_prev = rn;
+  const double gamma = 0.9, alpha = 2.0, eta_max = 0.9, sg_thr = 0.1;
+  orc_cheb C = {cheb_degree, 0.0, 0.0, cw};
+  int k = 0;
+  for (; k < maxsteps; ++k) {
+    orc_op A;
+    if (use_csr) {
+      orc_bratu_jac_values(ns, lambda, scale, u, rowptr, val);
+      orc_op t = {0, n, rowptr, col, val, 0, 0, 0, NULL};
+      A = t;
+    } else {
+      orc_op t = {1, n, NULL, NULL, NULL, ns, lambda, scale, u};
+      A = t;
+    }
+    /* Gershgorin bound of J = c_lap·pentadiag − c_exp·diag(e^u): max_i (|4c − c_exp e^{u_i}| + 4c) */
+    double gmax = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      double d = fabs(4.0 * b.c_lap - b.c_exp * exp(u[i])) + 4.0 * b.c_lap;
+      if (d > gmax) gmax = d;
+    }
+    C.lmax = gmax;
+    C.lmin = gmax / cheb_ratio;
+    g_cheb = cheb_degree > 0 ? &C : NULL;
+    g_cheb_tmp = cw + 3 * n;
+    if (k == 0) { eta = 0.5; rn = rn_prev = sqrt(dot(n, f, f)); }
+    else {
+      double eprev = eta;
+      eta = gamma * pow(rn / rn_prev, alpha);
+      double esg = gamma * pow(eprev, alpha);
+      if (esg > sg_thr && esg > eta) eta = esg;
+      if (eta < 0.0) eta = 0.0;
+      if (eta > eta_max) eta = eta_max;
+    }
+    int conv; double r0, r1;
+    gmres_iters[k] = gmres_run(&A, f, dx, 0.0, eta, m, itmax, 0, work, &conv, &r0, &r1);
+    g_cheb = NULL;
+    rn_prev = rn; rn = sqrt(dot(n, f, f));
+    axpy(n, -1.0, dx, u);
+    orc_bratu_residual(ns, lambda, scale, u, f);
+    fnorm_inf[k] = norm_inf(n, f);
+    if (fnorm_inf[k] <= abstol) { ++k; break; }
+  }
+  free(f); free(dx); free(work); free(cw); free(rowptr); free(col); free(val);
+  return k;
 }

@@ -106,3 +106,20 @@ def test_c5_brusselator_512_kernels(nls, dev):
     assert float((J.matvec(w) - jw).abs().max() / jw.abs().max()) <= 1e-12
     jtv = P.vjp(v, u)
     assert float((J.rmatvec(v) - jtv).abs().max() / jtv.abs().max()) <= 1e-12
+
+
+def test_c3_full_solve_with_chebyshev_precs_vs_c_oracle(nls, dev):
+    """C3 at full size, solved to ‖h²F‖∞ ≤ 1e-8: NewtonRaphson + GMRES(30) + Eisenstat–Walker + Chebyshev(32, 300)
+    right preconditioner on the assembled CSR Jacobian — against the C oracle running the same algorithm."""
+    import torch
+    ns = 1024
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(ns * ns, dtype=torch.float64, device=dev))
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.ChebyshevPrecs(32, 300.0)),
+                            forcing=nls.EisenstatWalkerForcing2(), concrete_jac=True)
+    sol = nls.solve(prob, alg, abstol=1e-8, maxiters=50)
+    uC, fnC, giC = CO.bratu_newton_cheb(ns, 6.0, 0.0, np.zeros(ns * ns), 50, True, 30, 300, 32, 300.0, 1e-8)
+    assert sol.retcode == "Success" and float(sol.resid.abs().max()) <= 1e-8 and fnC[-1] <= 1e-8
+    assert abs(sol.stats.nsteps - len(fnC)) <= 1
+    assert abs(sol.stats.gmres_iters - int(giC.sum())) <= 0.1 * giC.sum() + 5
+    assert np.max(np.abs(sol.u.cpu().numpy() - uC)) <= 5e-7
+    assert 0.79 < float(sol.u.max()) < 0.80
