@@ -30,12 +30,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // branch plus a full `s_waitcnt vmcnt(0)` per element (seen in the ISA: one load in flight per wave). Instead
 // every lane issues ALL its col/val loads unconditionally (the arrays are padded by one tile), then all x
 // gathers (out-of-tile lanes gather x[0]), then the LDS writes — TILE/256 independent loads in flight per lane.
+// Row epilogue. mode 0: y[row] = scale·s. mode 1 (fused Chebyshev step, x = d_old): r −= s; d_new = c1·d_old + c2·r;
+// yacc += d_new — saves the separate 56 n-byte vector update and a kernel boundary per polynomial degree.
+__device__ __forceinline__ void spmv_store_row(int row, double s, double *__restrict__ y, const double *out_scale,
+                                               double os, const double *__restrict__ x, const nk_spmv_epi &epi) {
+  if (epi.mode == 0) {
+    y[row] = out_scale ? os * s : s;
+  } else {
+    const double rr = epi.r[row] - s;
+    epi.r[row] = rr;
+    const double dn = epi.c1 * x[row] + epi.c2 * rr;
+    epi.dnew[row] = dn;
+    epi.yacc[row] += dn;
+  }
+}
+
 template <int TILE, bool HALO, bool REMAP>
 __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     int nblk, const int4 *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
     const double *__restrict__ xhalo, int32_t nlocal, double *__restrict__ y, const int *d_skip,
-    const double *__restrict__ out_scale) {
+    const double *__restrict__ out_scale, const nk_spmv_epi epi) {
   if (d_skip != nullptr && *d_skip != 0) return;
   const double os = out_scale ? *out_scale : 1.0;
   __shared__ double prod[TILE];
@@ -76,18 +91,18 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     if (rA < r1) {
       double s = 0.0;
       for (int k = aA - p0; k < eA - p0; ++k) s += prod[k];
-      y[rA] = out_scale ? os * s : s;
+      spmv_store_row(rA, s, y, out_scale, os, x, epi);
     }
     if (rB < r1) {
       double s = 0.0;
       for (int k = aB - p0; k < eB - p0; ++k) s += prod[k];
-      y[rB] = out_scale ? os * s : s;
+      spmv_store_row(rB, s, y, out_scale, os, x, epi);
     }
     for (int r = rB + NK_BLOCK; r < r1; r += NK_BLOCK) {  // blocks of (almost) empty rows
       const int a = rowptr[r] - p0, e = rowptr[r + 1] - p0;
       double s = 0.0;
       for (int k = a; k < e; ++k) s += prod[k];
-      y[r] = out_scale ? os * s : s;
+      spmv_store_row(r, s, y, out_scale, os, x, epi);
     }
   } else {
     // a single long row: the whole workgroup reduces it (fixed order → deterministic)
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) y[r0] = os * (red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) spmv_store_row(r0, red[0] + red[1] + red[2] + red[3], y, out_scale, os, x, epi);
   }
 }
 
@@ -411,8 +426,11 @@ extern "C" int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, i
 }
 extern "C" double *nk_csr_values_device(nk_csr *A) { return A ? A->d_val : nullptr; }
 
-int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale) {
+int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale,
+                    const nk_spmv_epi *epi) {
   nk_ctx *ctx = A->ctx;
+  nk_spmv_epi ep{};
+  if (epi) ep = *epi;
   if (A->halo.active()) NK_TRY(nk_halo_exchange(ctx, &A->halo, d_x));
   ctx->stats.op_applies++;
   nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
@@ -420,14 +438,14 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
 #define SPMV_LAUNCH(T, H, R)                                                                                      \
   NK_LAUNCH(ctx, (k_spmv_stream<T, H, R>), dim3(A->nblocks), dim3(NK_BLOCK), A->nblocks,                          \
             (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, \
-            d_y, d_skip, d_out_scale)
+            d_y, d_skip, d_out_scale, ep)
 #define SPMV_TILES(H, R)                                  \
   if (A->tile == 512) SPMV_LAUNCH(512, H, R);             \
   else if (A->tile == 2048) SPMV_LAUNCH(2048, H, R);      \
   else if (A->tile == 4096) SPMV_LAUNCH(4096, H, R);      \
   else SPMV_LAUNCH(1024, H, R)
     const bool halo = A->halo.n_recv > 0;
-    if (A->variant == 3) {
+    if (A->variant == 3 && ep.mode == 0) {
       const int grid = nk_grid_for(A->nrows, NK_BLOCK / 8, 1 << 20);
       NK_LAUNCH(ctx, k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col, A->d_val, d_x,
                 A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);

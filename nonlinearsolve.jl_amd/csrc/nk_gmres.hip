@@ -197,7 +197,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
-  hipFree(G->cr); hipFree(G->cd); hipFree(G->ct);
+  hipFree(G->cr); hipFree(G->cd); hipFree(G->ct); hipFree(G->cd2);
   hipHostFree(G->h_ctl);
   delete G;
   return NK_OK;
@@ -308,12 +308,28 @@ static int cheb_apply(nk_gmres *G, const double *src, double *dst, const int *d_
     nk_prof_scope prof_(ctx, NK_K_OTHER, 32.0 * (double)n);
     NK_LAUNCH(ctx, k_cheb_init, dim3(grid), dim3(NK_BLOCK), n, src, 1.0 / theta, G->cr, G->cd, dst, d_skip);
   }
+  // concrete CSR operator: the vector update rides in the SpMV's row epilogue (d ping-pongs between two buffers)
+  const bool fuse = (G->op_kind == 1) || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D);
+  double *dcur = G->cd, *dnext = G->cd2;
   for (int k = 1; k < G->cheb_degree; ++k) {
-    NK_TRY(op_apply_raw(G, G->cd, G->ct, d_skip, nullptr));
     const double rho_new = 1.0 / (2.0 * sigma1 - rho);
-    nk_prof_scope prof_(ctx, NK_K_OTHER, 56.0 * (double)n);
-    NK_LAUNCH(ctx, k_cheb_update, dim3(grid), dim3(NK_BLOCK), n, (const double *)G->ct, rho_new * rho, 2.0 * rho_new / delta,
-              G->cr, G->cd, dst, d_skip);
+    if (fuse) {
+      nk_spmv_epi ep;
+      ep.mode = 1;
+      ep.c1 = rho_new * rho;
+      ep.c2 = 2.0 * rho_new / delta;
+      ep.r = G->cr;
+      ep.dnew = dnext;
+      ep.yacc = dst;
+      if (G->op_kind == 1) NK_TRY(nk_csr_spmv_dev(G->A, dcur, nullptr, d_skip, nullptr, &ep));
+      else NK_TRY(nk_problem_jvp_dev(G->P, G->d_u, dcur, nullptr, d_skip, nullptr, &ep));
+      double *tmp = dcur; dcur = dnext; dnext = tmp;
+    } else {
+      NK_TRY(op_apply_raw(G, G->cd, G->ct, d_skip, nullptr));
+      nk_prof_scope prof_(ctx, NK_K_OTHER, 56.0 * (double)n);
+      NK_LAUNCH(ctx, k_cheb_update, dim3(grid), dim3(NK_BLOCK), n, (const double *)G->ct, rho_new * rho,
+                2.0 * rho_new / delta, G->cr, G->cd, dst, d_skip);
+    }
     rho = rho_new;
   }
   NK_HIP(hipGetLastError());
@@ -420,6 +436,7 @@ extern "C" int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, do
   if (!G->cr) NK_TRY(nk_dev_alloc(&G->cr, (size_t)G->ldv));
   if (!G->cd) NK_TRY(nk_dev_alloc(&G->cd, (size_t)G->ldv));
   if (!G->ct) NK_TRY(nk_dev_alloc(&G->ct, (size_t)G->ldv));
+  if (!G->cd2) NK_TRY(nk_dev_alloc(&G->cd2, (size_t)G->ldv));
   if (lambda_max == 0.0) {  // estimate the dominant eigenvalue, widen by 10 %, and take lmin = lmax / ratio
     double lam = 0.0;
     NK_TRY(estimate_lambda(G, &lam));

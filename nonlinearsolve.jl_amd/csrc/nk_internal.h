@@ -104,6 +104,13 @@ int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const 
                       void *recv, const int64_t *roff, const int64_t *rbytes);
 void nk_comm_destroy(nk_ctx *ctx);
 
+// optional row epilogue of the SpMV / JVP kernels: mode 1 fuses one Chebyshev-iteration vector update
+struct nk_spmv_epi {
+  int mode = 0;
+  double c1 = 0, c2 = 0;
+  double *r = nullptr, *dnew = nullptr, *yacc = nullptr;
+};
+
 // ----------------------------------------------------------------------------- halo plan
 // recv_buf holds the off-rank entries a kernel needs ("halo"), in the order defined by the plan's owner.
 struct nk_halo {
@@ -141,7 +148,8 @@ struct nk_csr {
   int32_t *d_node = nullptr;   // Brusselator: grid node of every non-zero's row
 };
 // d_out_scale (nullable): y = (*d_out_scale) · A x   (lagged normalisation of the Krylov basis)
-int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr);
+int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr,
+                    const nk_spmv_epi *epi = nullptr);
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
 int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
                         const std::vector<int32_t> &rowptr, const std::vector<int64_t> &gcol,
@@ -171,7 +179,7 @@ struct nk_problem {
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
 int nk_problem_jvp_prepare(nk_problem *P, const double *d_u);  // linearise at u (u must stay alive)
 int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
-                       const double *d_out_scale = nullptr);
+                       const double *d_out_scale = nullptr, const struct nk_spmv_epi *epi = nullptr);
 int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
 
@@ -228,7 +236,7 @@ struct nk_gmres {
   int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial
   int cheb_degree = 0;
   double cheb_lmin = 0, cheb_lmax = 0;
-  double *cr = nullptr, *cd = nullptr, *ct = nullptr;  // Chebyshev work vectors
+  double *cr = nullptr, *cd = nullptr, *ct = nullptr, *cd2 = nullptr;  // Chebyshev work vectors (cd/cd2 ping-pong)
   double *d_b = nullptr, *d_x = nullptr;  // staging for host-memspace calls
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,

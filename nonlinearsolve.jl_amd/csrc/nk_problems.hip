@@ -73,13 +73,23 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp(int64_t ns, int64_t nl, 
                                                         const double *__restrict__ d, const double *__restrict__ v,
                                                         const double *__restrict__ lo, const double *__restrict__ hi,
                                                         double *__restrict__ jv, const int *d_skip,
-                                                        const double *__restrict__ out_scale) {
+                                                        const double *__restrict__ out_scale, const nk_spmv_epi epi) {
   SKIP_GUARD(d_skip);
   const double os = out_scale ? *out_scale : 1.0;
   const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
   if (k >= ns * nl) return;
   const int64_t jl = k / ns, i = k - jl * ns;
-  jv[k] = os * (c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * v[k]);
+  const double vk = v[k];
+  const double res = c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * vk;
+  if (epi.mode == 0) {
+    jv[k] = os * res;
+  } else {  // fused Chebyshev step (v = d_old): r −= J d; d_new = c1 d_old + c2 r; y += d_new
+    const double rr = epi.r[k] - res;
+    epi.r[k] = rr;
+    const double dn = epi.c1 * vk + epi.c2 * rr;
+    epi.dnew[k] = dn;
+    epi.yacc[k] += dn;
+  }
 }
 // values in pattern order [S?][W?][C][E?][N?] (columns ascending); j = global grid line
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
@@ -385,7 +395,11 @@ int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
 }
 
 int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
-                       const double *d_out_scale) {
+                       const double *d_out_scale, const nk_spmv_epi *epi) {
+  if (epi && epi->mode != 0 && P->kind != NK_PROBLEM_BRATU2D)
+    NK_FAIL(NK_E_UNSUPPORTED, "internal: fused epilogue only exists for the Bratu JVP");
+  nk_spmv_epi ep{};
+  if (epi) ep = *epi;
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
   ctx->stats.op_applies++;
@@ -402,7 +416,7 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
       halo_lines(P, 1, false, &lo, &hi);
       NK_LAUNCH(ctx, k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->c_lap,
-                         P->d_diag, d_v, lo, hi, d_jv, d_skip, d_out_scale);
+                         P->d_diag, d_v, lo, hi, d_jv, d_skip, d_out_scale, ep);
       break;
     }
     case NK_PROBLEM_BRUSSELATOR2D: {
