@@ -176,3 +176,23 @@ def test_quadratic_kernels(nls):
     assert relerr(P.residual(u), u * u - 2.0) <= RTOL
     assert relerr(P.jvp(v, u), 2 * u * v) <= RTOL
     assert np.all(P.initial_guess() == 1.0)
+
+
+def test_against_committed_golden_fixtures(nls):
+    """tests/golden/oracle_golden.npz (made by tests/golden/make_golden.py from the oracle, cross-checked with SciPy)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+    P = nls.Bratu2D(16, 6.0)
+    assert relerr(P.jvp(g["v256"], g["bratu16_u"]), g["bratu16_Jv"]) <= 1e-13
+    J = P.jac_csr()
+    P.jac_values(g["bratu16_u"], J)
+    assert relerr(J.matvec(g["v256"]), g["bratu16_Jv"]) <= 1e-13
+    assert np.max(np.abs(P.residual(g["bratu16_u"]))) <= 1e-10          # the golden u is a root
+    sol = nls.solve(nls.NonlinearProblem(P), nls.NewtonRaphson(), abstol=1e-10, maxiters=50)
+    assert np.max(np.abs(sol.u - g["bratu16_u"])) <= 1e-11
+    B = nls.Brusselator2D(8)
+    assert relerr(B.initial_guess(), g["brus8_u0"]) <= 1e-14
+    assert relerr(B.residual(g["brus8_u0"]), g["brus8_f0"]) <= 1e-13
+    solb = nls.solve(nls.NonlinearProblem(B), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(maxiters=4000, reltol=1e-12, abstol=0.0)),
+                     abstol=1e-10, maxiters=30)
+    assert solb.retcode == "Success" and np.max(np.abs(solb.u - g["brus8_u"])) <= 1e-8
