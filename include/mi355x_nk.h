@@ -62,7 +62,8 @@ typedef enum {
   NK_RET_INTERNAL_LINEAR_SOLVE_FAILED = 5,
   NK_RET_SHRINK_THRESHOLD_EXCEEDED = 6,
   NK_RET_MAXTIME = 7,
-  NK_RET_FAILURE = 8
+  NK_RET_FAILURE = 8,
+  NK_RET_INTERNAL_LINESEARCH_FAILED = 9
 } nk_retcode;
 
 typedef enum {
@@ -186,8 +187,14 @@ typedef struct {
   /* --- preconditioner of the Krylov solver (`precs`): 0 none, >0 Chebyshev polynomial of that degree, its
    *     interval re-estimated for every new Jacobian (lambda_max by power iteration, lambda_min = max/ratio) */
   int32_t cheb_degree;
-  int32_t reserved2;
+  int32_t linesearch;           /* 0 none (missing), 1 BackTracking — globalisation Val(:LineSearch),
+                                   lib/NonlinearSolveFirstOrder/src/solve.jl:392-408 (NewtonRaphson only)      */
   double  cheb_ratio;           /* ≤1 → 30 */
+  /* --- BackTracking line search (LineSearch.jl / LineSearches.jl [EXT]: c_1 = 1e-4, ρ_hi = 0.5, ρ_lo = 0.1,
+   *     order = 3, iterations = 1000) on ϕ(α) = ½‖f(u + α δu)‖², ϕ'(0) = fuᵀ J δu */
+  double  ls_c1, ls_rho_hi, ls_rho_lo;
+  int32_t ls_order;             /* 2 | 3 */
+  int32_t ls_maxiters;
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)

@@ -191,12 +191,13 @@ Base.@kwdef mutable struct NKOptions
     patience_steps::Int32 = 100; max_stalled_steps::Int32 = 32
     patience_objective_multiplier::Float64 = 3.0; min_max_factor::Float64 = 1.3; protective_threshold::Float64 = 0.0
     store_trace::Int32 = 0; termination_mode::Int32 = 0
-    cheb_degree::Int32 = 0; reserved2::Int32 = 0; cheb_ratio::Float64 = 0.0
+    cheb_degree::Int32 = 0; linesearch::Int32 = 0; cheb_ratio::Float64 = 0.0
+    ls_c1::Float64 = 1e-4; ls_rho_hi::Float64 = 0.5; ls_rho_lo::Float64 = 0.1; ls_order::Int32 = 3; ls_maxiters::Int32 = 1000
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,
     ReturnCode.Stalled, ReturnCode.InternalLinearSolveFailed, ReturnCode.ShrinkThresholdExceeded,
-    ReturnCode.MaxTime, ReturnCode.Failure)
+    ReturnCode.MaxTime, ReturnCode.Failure, ReturnCode.InternalLineSearchFailed)
 
 function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, args...;
         abstol = nothing, reltol = nothing, maxiters = 1000, kwargs...)

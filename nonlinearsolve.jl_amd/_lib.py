@@ -18,7 +18,7 @@ class NKError(RuntimeError):
 # ---------------------------------------------------------------------------- enums (mirror the header)
 HOST, DEVICE = 0, 1
 RET_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalLinearSolveFailed",
-             "ShrinkThresholdExceeded", "MaxTime", "Failure"]
+             "ShrinkThresholdExceeded", "MaxTime", "Failure", "InternalLineSearchFailed"]
 PROBLEM_QUADRATIC, PROBLEM_BRATU2D, PROBLEM_BRUSSELATOR2D, PROBLEM_USER = 1, 2, 3, 100
 ALG_NEWTON_RAPHSON, ALG_TRUST_REGION = 0, 1
 LINSOLVE_GMRES_MATFREE, LINSOLVE_GMRES_CSR, LINSOLVE_BANDED_LU = 0, 1, 2
@@ -64,7 +64,9 @@ class Options(C.Structure):
         ("patience_objective_multiplier", C.c_double), ("min_max_factor", C.c_double),
         ("protective_threshold", C.c_double),
         ("store_trace", C.c_int32), ("termination_mode", C.c_int32),
-        ("cheb_degree", C.c_int32), ("reserved2", C.c_int32), ("cheb_ratio", C.c_double),
+        ("cheb_degree", C.c_int32), ("linesearch", C.c_int32), ("cheb_ratio", C.c_double),
+        ("ls_c1", C.c_double), ("ls_rho_hi", C.c_double), ("ls_rho_lo", C.c_double),
+        ("ls_order", C.c_int32), ("ls_maxiters", C.c_int32),
     ]
 
 

@@ -513,6 +513,16 @@ class EisenstatWalkerForcing2:  # eisenstat_walker.jl:18-29
     safeguard_threshold: float = 0.1
 
 
+@dataclass
+class BackTracking:
+    """LineSearch.jl / LineSearches.jl BackTracking [EXT]: `NewtonRaphson(linesearch = BackTracking())`."""
+    c_1: float = 1e-4
+    rho_hi: float = 0.5
+    rho_lo: float = 0.1
+    order: int = 3
+    maxiters: int = 1000
+
+
 class RadiusUpdateSchemes:  # trust_region.jl:59-147
     Simple, NLsolve, NocedalWright, Hei, Yuan, Bastin, Fan = range(7)
 
@@ -522,6 +532,7 @@ class NewtonRaphson:  # raphson.jl:30-43
     linsolve: Optional[KrylovJL_GMRES] = None
     forcing: Optional[EisenstatWalkerForcing2] = None
     concrete_jac: Optional[bool] = None
+    linesearch: Optional[BackTracking] = None   # `missing` in the reference = no line search
     name: str = "NewtonRaphson"
 
 
@@ -619,6 +630,11 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o.gmres_ortho, o.gmres_fixed_iters = _ORTHO[ls.ortho], int(ls.fixed_iters)
     o.lin_abstol = -1.0 if ls.abstol is None else float(ls.abstol)
     o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
+    lsr = getattr(alg, "linesearch", None)
+    if lsr is not None:
+        o.linesearch = 1
+        o.ls_c1, o.ls_rho_hi, o.ls_rho_lo = float(lsr.c_1), float(lsr.rho_hi), float(lsr.rho_lo)
+        o.ls_order, o.ls_maxiters = int(lsr.order), int(lsr.maxiters)
     if getattr(ls, "precs", None) is not None:
         o.cheb_degree, o.cheb_ratio = int(ls.precs.degree), float(ls.precs.ratio)
     fo = getattr(alg, "forcing", None)

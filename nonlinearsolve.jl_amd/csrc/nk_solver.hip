@@ -179,6 +179,12 @@ extern "C" int nk_options_default(nk_options *o) {
   o->min_max_factor = 1.3;
   o->protective_threshold = 0.0;
   o->store_trace = 0;
+  o->linesearch = 0;
+  o->ls_c1 = 1e-4;
+  o->ls_rho_hi = 0.5;
+  o->ls_rho_lo = 0.1;
+  o->ls_order = 3;
+  o->ls_maxiters = 1000;
   return NK_OK;
 }
 
@@ -438,6 +444,9 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
              "a forcing term needs an iterative linear solver");
   NK_REQUIRE(opts->termination_mode >= 0 && opts->termination_mode <= 8, "bad termination_mode %d", opts->termination_mode);
   NK_REQUIRE(opts->termination_norm == 0 || opts->termination_norm == 1, "bad termination_norm %d", opts->termination_norm);
+  NK_REQUIRE(opts->linesearch == 0 || opts->linesearch == 1, "bad linesearch %d", opts->linesearch);
+  NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->linesearch != 0),
+             "TrustRegion and LineSearch methods are algorithmically incompatible (FirstOrder/src/solve.jl:221-223)");
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->forcing != NK_FORCING_NONE),
              "TrustRegion does not accept a forcing term (trust_region.jl:25-43)");
   nk_solver *S = new nk_solver();
@@ -457,6 +466,11 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   NK_TRY(nk_dev_alloc(&S->fu, na));
   NK_TRY(nk_dev_alloc(&S->du, na));
   NK_TRY(nk_dev_alloc(&S->best_u, na));
+  if (!is_tr(S) && S->o.linesearch) {
+    NK_TRY(nk_dev_alloc(&S->u_trial, na));
+    NK_TRY(nk_dev_alloc(&S->fu_trial, na));
+    NK_TRY(nk_dev_alloc(&S->Jdu, na));
+  }
   if (is_tr(S)) {
     NK_TRY(nk_dev_alloc(&S->u_trial, na));
     NK_TRY(nk_dev_alloc(&S->fu_trial, na));
@@ -702,6 +716,66 @@ static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
   return NK_OK;
 }
 
+// ---- BackTracking line search on ϕ(α) = ½‖f(u + α δu)‖² (LineSearches.jl BackTracking restated, [EXT]):
+// sufficient decrease ϕ(α) ≤ ϕ(0) + c₁ α ϕ'(0); quadratic, then cubic interpolation, safeguarded to
+// [ρ_lo α, ρ_hi α]. Every ϕ evaluation is one residual (stats.nf += 1, as the reference's line-search cache does).
+static int ls_phi(nk_solver *S, double alpha, double *phi) {
+  NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->u, alpha, S->du, S->u_trial));
+  NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
+  S->stats.nf++;
+  NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu_trial, slot(S, 0)));
+  double v;
+  NK_TRY(fetch(S, 1, &v));
+  *phi = 0.5 * v;
+  return NK_OK;
+}
+static int backtracking(nk_solver *S, double *alpha_out, bool *failed) {
+  const nk_options &o = S->o;
+  *failed = false;
+  // ϕ(0) and ϕ'(0) = fuᵀ (J δu)
+  NK_TRY(apply_J(S, S->du, S->Jdu));
+  NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu, slot(S, 0)));
+  NK_TRY(nk_blas_dot(S->ctx, S->n, S->fu, S->Jdu, slot(S, 1)));
+  double v[2];
+  NK_TRY(fetch(S, 2, v));
+  const double phi0 = 0.5 * v[0], dphi0 = v[1];
+  double a1 = 1.0, a2 = 1.0, phx0 = phi0, phx1 = phi0;
+  NK_TRY(ls_phi(S, a1, &phx1));
+  int iterfinite = 0;
+  const int iterfinitemax = 1074;  // -log2(eps(Float64)) style bound used by LineSearches.jl
+  while (!isfinite(phx1) && iterfinite < iterfinitemax) {
+    ++iterfinite;
+    a1 = a2;
+    a2 = a1 / 2.0;
+    NK_TRY(ls_phi(S, a2, &phx1));
+  }
+  int iteration = 0;
+  while (phx1 > phi0 + o.ls_c1 * a2 * dphi0) {
+    ++iteration;
+    if (iteration > o.ls_maxiters) { *failed = true; break; }
+    double atmp;
+    if (o.ls_order == 2 || iteration == 1) {
+      atmp = -(dphi0 * a2 * a2) / (2.0 * (phx1 - phi0 - dphi0 * a2));
+    } else {
+      const double div = 1.0 / (a1 * a1 * a2 * a2 * (a2 - a1));
+      const double ca = (a1 * a1 * (phx1 - phi0 - dphi0 * a2) - a2 * a2 * (phx0 - phi0 - dphi0 * a1)) * div;
+      const double cb = (-a1 * a1 * a1 * (phx1 - phi0 - dphi0 * a2) + a2 * a2 * a2 * (phx0 - phi0 - dphi0 * a1)) * div;
+      if (fabs(ca) <= 2.220446049250313e-16) atmp = dphi0 / (2.0 * cb);  // isapprox(a, 0; atol = eps)
+      else {
+        const double disc = fmax(cb * cb - 3.0 * ca * dphi0, 0.0);
+        atmp = (-cb + sqrt(disc)) / (3.0 * ca);
+      }
+    }
+    a1 = a2;
+    atmp = (atmp == atmp) ? fmin(atmp, a2 * o.ls_rho_hi) : a2 * o.ls_rho_hi;  // NaNMath.min
+    a2 = (atmp == atmp) ? fmax(atmp, a2 * o.ls_rho_lo) : a2 * o.ls_rho_lo;    // NaNMath.max
+    phx0 = phx1;
+    NK_TRY(ls_phi(S, a2, &phx1));
+  }
+  *alpha_out = a2;
+  return NK_OK;
+}
+
 // ---- InternalAPI.step! (FirstOrder/src/solve.jl:325-465)
 static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/) {
   nk_ctx *ctx = S->ctx;
@@ -768,6 +842,16 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       S->force_stop = true;
     }
   } else {
+    if (S->o.linesearch) {  // Val(:LineSearch): α from the line search, then axpy!(α, δu, u)  (solve.jl:392-408)
+      double alpha = 1.0;
+      bool lsfail = false;
+      NK_TRY(backtracking(S, &alpha, &lsfail));
+      if (lsfail) {
+        S->retcode = NK_RET_INTERNAL_LINESEARCH_FAILED;
+        S->force_stop = true;
+      }
+      if (alpha != 1.0) NK_TRY(nk_blas_lincomb(ctx, n, alpha, S->du, 0.0, S->du, S->du));  // δu ← α δu, then u += δu
+    }
     const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
     {
     nk_prof_scope prof_(ctx, NK_K_NEWTON_UPDATE, 24.0 * (double)n);

@@ -37,9 +37,10 @@ import numpy as np
 import scipy.sparse as sp
 
 # ----------------------------------------------------------------------------- return codes
-DEFAULT, SUCCESS, MAXITERS, UNSTABLE, STALLED, LINSOLVE_FAILED, SHRINK_EXCEEDED, MAXTIME, FAILURE = range(9)
+(DEFAULT, SUCCESS, MAXITERS, UNSTABLE, STALLED, LINSOLVE_FAILED, SHRINK_EXCEEDED, MAXTIME, FAILURE,
+ LINESEARCH_FAILED) = range(10)
 RETCODE_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalLinearSolveFailed",
-                 "ShrinkThresholdExceeded", "MaxTime", "Failure"]
+                 "ShrinkThresholdExceeded", "MaxTime", "Failure", "InternalLineSearchFailed"]
 
 
 def L2_NORM(x):  # common_defaults.jl:19-30
@@ -422,10 +423,21 @@ class EisenstatWalkerForcing2:  # eisenstat_walker.jl:18-29
 
 
 @dataclass
+class BackTracking:
+    """LineSearches.jl BackTracking [EXT] (c_1 = 1e-4, ρ_hi = 0.5, ρ_lo = 0.1, order = 3, iterations = 1000)."""
+    c_1: float = 1e-4
+    rho_hi: float = 0.5
+    rho_lo: float = 0.1
+    order: int = 3
+    maxiters: int = 1000
+
+
+@dataclass
 class NewtonRaphson:  # raphson.jl:30-43
     linsolve: object = None
     forcing: Optional[EisenstatWalkerForcing2] = None
     concrete_jac: Optional[bool] = None
+    linesearch: Optional[BackTracking] = None
     name: str = "NewtonRaphson"
 
 
@@ -811,6 +823,44 @@ class FirstOrderCache:
         self.trust_region = min(self.trust_region, self.max_trust_radius)
         return self.last_step_accepted, u_new, fu_new
 
+    # -- BackTracking on ϕ(α) = ½‖f(u + α δu)‖², ϕ'(0) = fuᵀ J δu  (LineSearches.jl backtracking.jl restated, [EXT])
+    def _backtracking(self, ls, du):
+        def phi(a):
+            self.stats.nf += 1
+            f = self.prob.f(self.u + a * du)
+            return 0.5 * float(np.dot(f, f))
+        phi0 = 0.5 * float(np.dot(self.fu, self.fu))
+        dphi0 = float(np.dot(self.fu, self._apply_J(du, self.u)))
+        a1 = a2 = 1.0
+        phx0 = phi0
+        phx1 = phi(a1)
+        itf = 0
+        while not math.isfinite(phx1) and itf < 1074:
+            itf += 1
+            a1 = a2
+            a2 = a1 / 2.0
+            phx1 = phi(a2)
+        it = 0
+        while phx1 > phi0 + ls.c_1 * a2 * dphi0:
+            it += 1
+            if it > ls.maxiters:
+                return a2, True
+            if ls.order == 2 or it == 1:
+                atmp = -(dphi0 * a2 * a2) / (2.0 * (phx1 - phi0 - dphi0 * a2))
+            else:
+                div = 1.0 / (a1 * a1 * a2 * a2 * (a2 - a1))
+                ca = (a1 * a1 * (phx1 - phi0 - dphi0 * a2) - a2 * a2 * (phx0 - phi0 - dphi0 * a1)) * div
+                cb = (-a1 ** 3 * (phx1 - phi0 - dphi0 * a2) + a2 ** 3 * (phx0 - phi0 - dphi0 * a1)) * div
+                if abs(ca) <= np.finfo(float).eps:
+                    atmp = dphi0 / (2.0 * cb)
+                else:
+                    atmp = (-cb + math.sqrt(max(cb * cb - 3.0 * ca * dphi0, 0.0))) / (3.0 * ca)
+            a1 = a2
+            atmp = min(atmp, a2 * ls.rho_hi) if atmp == atmp else a2 * ls.rho_hi
+            a2 = max(atmp, a2 * ls.rho_lo) if atmp == atmp else a2 * ls.rho_lo
+            phx0, phx1 = phx1, phi(a2)
+        return a2, False
+
     # -- pre/post_step_forcing! (eisenstat_walker.jl:42-89)
     def _pre_step_forcing(self, it):
         p = self.forcing
@@ -877,7 +927,15 @@ class FirstOrderCache:
                 self.retcode = SHRINK_EXCEEDED
                 self.force_stop = True
         else:
-            self.u = self.u + du         # @bb axpy!(1, δu, cache.u)
+            ls = getattr(self.alg, "linesearch", None)
+            if ls is not None:  # Val(:LineSearch), solve.jl:392-408
+                alpha, ls_failed = self._backtracking(ls, du)
+                if ls_failed:
+                    self.retcode = LINESEARCH_FAILED
+                    self.force_stop = True
+                du = alpha * du
+                self.du = du
+            self.u = self.u + du         # @bb axpy!(α, δu, cache.u)
             self.fu = self.prob.f(self.u)  # Utils.evaluate_f!
             self.stats.nf += 1
         # check_and_update! (termination_conditions.jl:414-426)

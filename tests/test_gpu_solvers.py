@@ -527,3 +527,48 @@ def test_newton_with_chebyshev_precs_vs_oracle(nls):
     assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
     assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
     assert uerr(sol.u, direct.u) <= 5e-7 and uerr(sol.u, ref.u) <= 5e-7
+
+
+# ------------------------------------------------------------------ line search globalisation
+def test_backtracking_linesearch_vs_oracle(nls, dev):
+    """rootfind_tests__item2.jl (NewtonRaphson × line searches) — BackTracking on quadratic_f, and on atan(u) where
+    plain Newton diverges; α sequence, residual-evaluation counts and iterates equal the oracle's."""
+    import scipy.sparse as sp
+    import torch
+    sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(3, 2.0)),
+                    nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), linesearch=nls.BackTracking()), abstol=1e-9)
+    ref = R.solve(R.Quadratic(3, 2.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), linesearch=R.BackTracking()), abstol=1e-9)
+    assert sol.retcode == "Success" and sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf
+
+    def f(du, u, p):
+        du.copy_(torch.atan(u))
+
+    def jvp(Jv, v, u, p):
+        Jv.copy_(v / (1.0 + u * u))
+
+    u0 = np.array([2.0, -3.0, 1.5])
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(f, jvp=jvp), torch.tensor(u0, device=dev))
+    lin = nls.KrylovJL_GMRES(reltol=1e-14, abstol=0.0)
+    plain = nls.solve(prob, nls.NewtonRaphson(linsolve=lin), abstol=1e-10, maxiters=30)
+    ls = nls.solve(prob, nls.NewtonRaphson(linsolve=lin, linesearch=nls.BackTracking()), abstol=1e-10, maxiters=60,
+                   store_trace=True)
+    atan = R.FunctionProblem(np.arctan, u0, jac=lambda u: sp.diags(1.0 / (1.0 + u * u)))
+    oref = R.solve(atan, R.NewtonRaphson(linesearch=R.BackTracking()), abstol=1e-10, maxiters=60)
+    assert plain.retcode != "Success"
+    assert ls.retcode == "Success" and float(ls.u.abs().max()) < 1e-9
+    assert ls.stats.nsteps == oref.stats.nsteps and ls.stats.nf == oref.stats.nf
+    for a, b in zip(ls.trace, oref.trace):
+        assert abs(a["step_norm2"] - b["step_norm2"]) <= 1e-9 * max(b["step_norm2"], 1e-12) + 1e-13
+
+
+def test_linesearch_with_trust_region_is_rejected(nls):
+    import ctypes as C
+    from nonlinearsolve_jl_amd import _lib as L
+    o = L.Options()
+    L.lib().nk_options_default(C.byref(o))
+    o.algorithm, o.linesearch = L.ALG_TRUST_REGION, 1
+    P = nls.Quadratic(2, 2.0)
+    h = C.c_void_p()
+    u0 = np.ones(2)
+    st = L.lib().nk_solver_init(P._h, C.c_void_p(u0.ctypes.data), L.HOST, C.byref(o), C.byref(h))
+    assert st != 0 and b"incompatible" in L.lib().nk_last_error()

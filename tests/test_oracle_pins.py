@@ -291,3 +291,16 @@ def test_chebyshev_precs_oracle():
                                    concrete_jac=True), abstol=1e-9, maxiters=50)
     d = R.solve(p, R.NewtonRaphson(), abstol=1e-9, maxiters=50)
     assert s.retcode == R.SUCCESS and np.max(np.abs(s.u - d.u)) < 1e-7 and s.stats.nsteps <= d.stats.nsteps + 6
+
+
+# ---- rootfind_tests__item2.jl: NewtonRaphson(linesearch = BackTracking()) on quadratic_f; and a case where the
+#      full Newton step diverges (atan) but the backtracked one converges
+def test_backtracking_linesearch():
+    s = R.solve(R.Quadratic(3, 2.0), R.NewtonRaphson(linesearch=R.BackTracking()), abstol=1e-9)
+    assert s.retcode == R.SUCCESS and np.max(np.abs(s.u - np.sqrt(2.0))) < 1e-9
+    atan = R.FunctionProblem(np.arctan, np.array([2.0, -3.0, 1.5]), jac=lambda u: sp.diags(1.0 / (1.0 + u * u)))
+    plain = R.solve(atan, R.NewtonRaphson(), abstol=1e-10, maxiters=6)
+    ls = R.solve(atan, R.NewtonRaphson(linesearch=R.BackTracking()), abstol=1e-10, maxiters=60)
+    assert plain.retcode != R.SUCCESS            # Newton on atan from |u0| > 1.39 diverges
+    assert ls.retcode == R.SUCCESS and np.max(np.abs(ls.u)) < 1e-9
+    assert ls.stats.nf > ls.stats.nsteps          # backtracking spent extra residual evaluations
