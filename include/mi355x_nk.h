@@ -207,9 +207,11 @@ typedef int (*nk_vjp_fn)(void *user, const double *v, const double *u, double *v
 typedef int (*nk_jacvals_fn)(void *user, const double *u, double *csr_vals, void *stream);
 typedef struct {
   nk_residual_fn residual; /* required */
-  nk_jvp_fn jvp;           /* required for NK_LINSOLVE_GMRES_MATFREE */
+  nk_jvp_fn jvp;           /* NULL ⇒ forward differences through `residual`, (f(u+εv) − f(u))/ε, ε = √eps — the
+                            * AutoFiniteDiff pushforward of SciMLJacobianOperators.jl:396-414 */
   nk_vjp_fn vjp;           /* required for TrustRegion on the matrix-free path */
-  nk_jacvals_fn jac_values;/* required for concrete-J linsolves (pattern given at create) */
+  nk_jacvals_fn jac_values;/* NULL ⇒ concrete-J linsolves assemble J on the pattern given at create from ncolors seeded
+                            * JVPs + decompression (greedy column colouring, cached per pattern; jacobian.jl:244-247) */
 } nk_user_callbacks;
 
 /* generic operator for nk_gmres: y = A x on device (an AbstractSciMLOperator / FunctionOperator) */

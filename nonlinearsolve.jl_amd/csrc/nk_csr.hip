@@ -396,6 +396,10 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_node);
   hipFree(A->d_xtmp);
   hipFree(A->d_ytmp);
+  hipFree(A->d_color);
+  hipFree(A->d_nnzcolor);
+  hipFree(A->d_seed);
+  hipFree(A->d_B);
   nk_halo_free(&A->halo);
   if (A->T) nk_csr_destroy(A->T);
   delete A;

@@ -142,6 +142,10 @@ struct nk_csr {
   nk_csr *T = nullptr;
   int32_t *d_tperm = nullptr;
   bool t_values_stale = true;
+  // column colouring of the pattern (structurally orthogonal columns), built on first use by coloured assembly
+  int ncolors = 0;
+  int32_t *d_color = nullptr, *d_nnzcolor = nullptr;
+  double *d_seed = nullptr, *d_B = nullptr;
   double *d_xtmp = nullptr, *d_ytmp = nullptr;  // staging for host-memspace calls
   // problem-specific device tables attached by nk_problem_jac_csr (freed with the matrix)
   uint8_t *d_role = nullptr;   // Brusselator: role of every non-zero
@@ -173,6 +177,8 @@ struct nk_problem {
   nk_user_callbacks cb{};
   void *user = nullptr;
   nk_csr *user_pattern = nullptr;
+  // forward-difference JVP for user problems without a jvp callback: f(u) at the linearisation point, u + εv, f(u + εv)
+  double *d_fd_f0 = nullptr, *d_fd_up = nullptr, *d_fd_f1 = nullptr;
   // staging buffers for host-memspace calls
   double *d_tmp[3] = {nullptr, nullptr, nullptr};
 };
@@ -182,6 +188,7 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
                        const double *d_out_scale = nullptr, const struct nk_spmv_epi *epi = nullptr);
 int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
+int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J);  // ncolors JVPs + decompression
 
 // ----------------------------------------------------------------------------- BLAS-1 launchers (device)
 // reductions leave their (all-reduced) result in device memory at d_out

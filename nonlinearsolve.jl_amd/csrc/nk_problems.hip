@@ -316,6 +316,9 @@ extern "C" int nk_problem_create_user(nk_ctx *ctx, int64_t n_local, int64_t n_gl
 extern "C" int nk_problem_destroy(nk_problem *P) {
   if (!P) return NK_OK;
   hipFree(P->d_diag);
+  hipFree(P->d_fd_f0);
+  hipFree(P->d_fd_up);
+  hipFree(P->d_fd_f1);
   for (double *&t : P->d_tmp) hipFree(t);
   nk_halo_free(&P->halo);
   delete P;
@@ -391,7 +394,33 @@ int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
                          P->c_exp, d_u, P->d_diag);
     NK_HIP(hipGetLastError());
   }
+  if (P->kind == NK_PROBLEM_USER && !P->cb.jvp && P->n_local) {  // forward differences need f at the linearisation point
+    if (!P->d_fd_f0) {
+      NK_TRY(nk_dev_alloc(&P->d_fd_f0, (size_t)P->n_local + 1));
+      NK_TRY(nk_dev_alloc(&P->d_fd_up, (size_t)P->n_local + 1));
+      NK_TRY(nk_dev_alloc(&P->d_fd_f1, (size_t)P->n_local + 1));
+    }
+    if (P->cb.residual(P->user, d_u, P->d_fd_f0, (void *)P->ctx->stream) != 0)
+      NK_FAIL(NK_E_CALLBACK, "residual callback failed");
+  }
   return NK_OK;
+}
+
+// Forward-difference directional derivative Jv ≈ (f(u + εv) − f(u))/ε with ε = √eps — what the reference's
+// JacobianOperator does for a NonlinearFunction without jvp under AutoFiniteDiff (DI.pushforward!,
+// SciMLJacobianOperators.jl:396-414; step rule FiniteDiff.jl [EXT]: absstep = relstep = √eps at t = 0).
+#define NK_FD_EPS 1.4901161193847656e-08
+__global__ __launch_bounds__(NK_BLOCK) void k_fd_perturb(int64_t n, const double *__restrict__ u,
+                                                         const double *__restrict__ v, double eps,
+                                                         double *__restrict__ up) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) up[i] = u[i] + eps * v[i];
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_fd_diff(int64_t n, const double *__restrict__ f1,
+                                                      const double *__restrict__ f0, double inv_eps,
+                                                      double *__restrict__ jv) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) jv[i] = (f1[i] - f0[i]) * inv_eps;
 }
 
 int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
@@ -405,6 +434,7 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
   ctx->stats.op_applies++;
   if (n == 0) return NK_OK;
   if (P->kind == NK_PROBLEM_BRATU2D && (P->d_u_lin != d_u || !P->d_diag)) NK_TRY(nk_problem_jvp_prepare(P, d_u));
+  if (P->kind == NK_PROBLEM_USER && !P->cb.jvp && (P->d_u_lin != d_u || !P->d_fd_f0)) NK_TRY(nk_problem_jvp_prepare(P, d_u));
   nk_prof_scope prof_(ctx, NK_K_JVP, 24.0 * (double)n);
   switch (P->kind) {
     case NK_PROBLEM_QUADRATIC:
@@ -428,8 +458,14 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
       break;
     }
     case NK_PROBLEM_USER:
-      if (!P->cb.jvp) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no jvp callback");
       if (d_out_scale) NK_FAIL(NK_E_INVALID, "internal: output scale is not supported for callback JVPs");
+      if (!P->cb.jvp) {  // forward differences through the residual callback
+        NK_LAUNCH(ctx, k_fd_perturb, dim3(grid1(n)), dim3(NK_BLOCK), n, d_u, d_v, NK_FD_EPS, P->d_fd_up);
+        if (P->cb.residual(P->user, P->d_fd_up, P->d_fd_f1, (void *)ctx->stream) != 0)
+          NK_FAIL(NK_E_CALLBACK, "residual callback failed");
+        NK_LAUNCH(ctx, k_fd_diff, dim3(grid1(n)), dim3(NK_BLOCK), n, P->d_fd_f1, P->d_fd_f0, 1.0 / NK_FD_EPS, d_jv);
+        break;
+      }
       if (P->cb.jvp(P->user, d_v, d_u, d_jv, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "jvp callback failed");
       break;
     default:
@@ -577,7 +613,7 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
       break;
     }
     case NK_PROBLEM_USER:
-      if (!P->cb.jac_values) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no jac_values callback");
+      if (!P->cb.jac_values) return nk_problem_jac_colored_dev(P, d_u, J);  // AutoSparse(AutoFiniteDiff) analogue
       if (P->cb.jac_values(P->user, d_u, J->d_val, (void *)ctx->stream) != 0)
         NK_FAIL(NK_E_CALLBACK, "jac_values callback failed");
       break;
@@ -682,24 +718,28 @@ __global__ __launch_bounds__(NK_BLOCK) void k_decompress(int64_t nrows, const in
     if (colcolor_of_nnz[p] == c) vals[p] = Bc[r];
 }
 
-extern "C" int nk_jac_values_colored(nk_problem *P, const double *u, int memspace, nk_csr *J, int *ncolors_out) {
-  NK_REQUIRE(P && u && J, "NULL argument");
-  nk_ctx *ctx = P->ctx;
-  NK_REQUIRE(ctx->nranks == 1, "coloured assembly is single-rank in this round");
-  NK_HIP(hipSetDevice(ctx->device));
-  const int64_t n = J->nrows;
-  // greedy distance-2 column colouring on the host pattern (columns sharing a row get different colours)
-  std::vector<std::vector<int32_t>> rows_of_col(n);
+// greedy distance-2 column colouring on the host pattern, natural order (columns sharing a row get different
+// colours) — SparseMatrixColorings' GreedyColoringAlgorithm() default, [EXT]; computed once per pattern.
+static int csr_ensure_coloring(nk_csr *J) {
+  if (J->ncolors > 0) return NK_OK;
+  const int64_t n = J->nrows, ncols = J->n_global;
+  NK_REQUIRE(J->ctx->nranks == 1 && J->halo_gcols.empty(), "coloured assembly is single-rank in this round");
+  std::vector<int32_t> cnt(ncols + 1, 0);
+  for (int64_t p = 0; p < J->nnz; ++p) cnt[J->h_col[p] + 1]++;
+  for (int64_t c = 0; c < ncols; ++c) cnt[c + 1] += cnt[c];
+  std::vector<int32_t> rows_of_col(J->nnz), fillp(cnt.begin(), cnt.end() - 1);
   for (int64_t r = 0; r < n; ++r)
-    for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) rows_of_col[J->h_col[p]].push_back((int32_t)r);
-  std::vector<int32_t> color(n, -1), mark(n + 1, -1);
+    for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) rows_of_col[fillp[J->h_col[p]]++] = (int32_t)r;
+  std::vector<int32_t> color(ncols, -1), mark(ncols + 1, -1);
   int ncolors = 0;
-  for (int64_t c = 0; c < n; ++c) {
-    for (int32_t r : rows_of_col[c])
+  for (int64_t c = 0; c < ncols; ++c) {
+    for (int32_t q = cnt[c]; q < cnt[c + 1]; ++q) {
+      const int32_t r = rows_of_col[q];
       for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) {
         const int32_t oc = color[J->h_col[p]];
         if (oc >= 0) mark[oc] = (int32_t)c;
       }
+    }
     int32_t k = 0;
     while (mark[k] == (int32_t)c) ++k;
     color[c] = k;
@@ -707,31 +747,39 @@ extern "C" int nk_jac_values_colored(nk_problem *P, const double *u, int memspac
   }
   std::vector<int32_t> nnzcolor(J->nnz);
   for (int64_t p = 0; p < J->nnz; ++p) nnzcolor[p] = color[J->h_col[p]];
-  int32_t *d_color = nullptr, *d_nnzcolor = nullptr;
-  double *d_seed = nullptr, *d_B = nullptr;
-  NK_TRY(nk_dev_alloc(&d_color, (size_t)n));
-  NK_TRY(nk_dev_alloc(&d_nnzcolor, (size_t)J->nnz));
-  NK_TRY(nk_dev_alloc(&d_seed, (size_t)n + 1));
-  NK_TRY(nk_dev_alloc(&d_B, (size_t)n + 1));
-  NK_HIP(hipMemcpy(d_color, color.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-  NK_HIP(hipMemcpy(d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_TRY(nk_dev_alloc(&J->d_color, (size_t)ncols + 1));
+  NK_TRY(nk_dev_alloc(&J->d_nnzcolor, (size_t)J->nnz + 1));
+  NK_TRY(nk_dev_alloc(&J->d_seed, (size_t)ncols + 1));
+  NK_TRY(nk_dev_alloc(&J->d_B, (size_t)n + 1));
+  NK_HIP(hipMemcpy(J->d_color, color.data(), ncols * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(hipMemcpy(J->d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  J->ncolors = ncolors;
+  return NK_OK;
+}
+
+int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J) {
+  nk_ctx *ctx = P->ctx;
+  NK_REQUIRE(J->nrows == P->n_local && J->n_global == P->n_global, "pattern/problem size mismatch");
+  NK_TRY(csr_ensure_coloring(J));
+  const int64_t n = J->nrows;
+  NK_TRY(nk_problem_jvp_prepare(P, d_u));  // the caller's u may have changed in place
+  for (int c = 0; c < J->ncolors; ++c) {
+    NK_LAUNCH(ctx, k_seed, dim3(grid1(n)), dim3(NK_BLOCK), n, J->d_color, c, J->d_seed);
+    NK_TRY(nk_problem_jvp_dev(P, d_u, J->d_seed, J->d_B, nullptr));
+    NK_LAUNCH(ctx, k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), n, J->d_rowptr, J->d_nnzcolor, c, J->d_B, J->d_val);
+  }
+  NK_HIP(hipGetLastError());
+  J->t_values_stale = true;
+  return NK_OK;
+}
+
+extern "C" int nk_jac_values_colored(nk_problem *P, const double *u, int memspace, nk_csr *J, int *ncolors_out) {
+  NK_REQUIRE(P && u && J, "NULL argument");
+  NK_HIP(hipSetDevice(P->ctx->device));
   const double *du;
   NK_TRY(stage(P, 0, u, memspace, &du));
-  P->d_u_lin = nullptr;
-  int st = NK_OK;
-  for (int c = 0; c < ncolors && st == NK_OK; ++c) {
-    NK_LAUNCH(ctx, k_seed, dim3(grid1(n)), dim3(NK_BLOCK), n, d_color, c, d_seed);
-    st = nk_problem_jvp_dev(P, du, d_seed, d_B, nullptr);
-    if (st != NK_OK) break;
-    NK_LAUNCH(ctx, k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), n, J->d_rowptr, d_nnzcolor, c, d_B,
-                       J->d_val);
-  }
-  hipStreamSynchronize(ctx->stream);
-  hipFree(d_color);
-  hipFree(d_nnzcolor);
-  hipFree(d_seed);
-  hipFree(d_B);
-  J->t_values_stale = true;
-  if (ncolors_out) *ncolors_out = ncolors;
-  return st;
+  NK_TRY(nk_problem_jac_colored_dev(P, du, J));
+  NK_HIP(hipStreamSynchronize(P->ctx->stream));
+  if (ncolors_out) *ncolors_out = J->ncolors;
+  return NK_OK;
 }

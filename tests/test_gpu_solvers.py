@@ -572,3 +572,65 @@ def test_linesearch_with_trust_region_is_rejected(nls):
     u0 = np.ones(2)
     st = L.lib().nk_solver_init(P._h, C.c_void_p(u0.ctypes.data), L.HOST, C.byref(o), C.byref(h))
     assert st != 0 and b"incompatible" in L.lib().nk_last_error()
+
+
+# ------------------------------------------------------------------ NonlinearFunction with f only (no jvp / jac)
+def _bratu1d(dev, n=200, lam=1.0):
+    import torch
+    h2 = (1.0 / (n + 1)) ** 2
+
+    def F(du, u, p):
+        du.copy_(2.0 * u - h2 * p * torch.exp(u))
+        du[1:] -= u[:-1]
+        du[:-1] -= u[1:]
+
+    def J_dense(u):
+        J = np.diag(2.0 - h2 * lam * np.exp(u)) - np.diag(np.ones(n - 1), 1) - np.diag(np.ones(n - 1), -1)
+        return J
+    return F, J_dense
+
+
+def test_user_function_without_jvp_uses_forward_differences(nls, dev):
+    """NonlinearFunction(f) only: the JacobianOperator falls back to a finite-difference pushforward
+    (SciMLJacobianOperators.jl:396-414 with AutoFiniteDiff); Newton–GMRES converges to the analytic-J solution."""
+    import torch
+    n = 200
+    F, J_dense = _bratu1d(dev, n)
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(F), torch.zeros(n, device=dev, dtype=torch.float64), 1.0)
+    u = np.linspace(0.0, 1.0, n)
+    v = np.cos(np.arange(n))
+    Jop = nls.StatefulJacobianOperator(nls.JacobianOperator(prob), torch.tensor(u, device=dev))
+    Jv = (Jop @ torch.tensor(v, device=dev)).cpu().numpy()
+    assert np.max(np.abs(Jv - J_dense(u) @ v)) < 1e-6          # forward differences, ε = √eps
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=60, reltol=1e-10)), abstol=1e-10)
+    assert sol.retcode == "Success"
+    uref = np.zeros(n)
+    for _ in range(20):                                         # dense Newton on the host as the check
+        f = 2 * uref - (1.0 / (n + 1)) ** 2 * np.exp(uref)
+        f[1:] -= uref[:-1]
+        f[:-1] -= uref[1:]
+        uref -= np.linalg.solve(J_dense(uref), f)
+    assert np.max(np.abs(sol.u.cpu().numpy() - uref)) < 1e-7
+
+
+def test_user_function_sparse_prototype_coloured_fd_jacobian(nls, dev):
+    """sparsity_tests__item1.jl shape: NonlinearFunction(f; jac_prototype = pattern) — the concrete sparse J is
+    assembled from ncolors seeded (finite-difference) JVPs + decompression; `linsolve = nothing` then factorises it."""
+    import torch
+    import scipy.sparse as sp
+    n = 200
+    F, J_dense = _bratu1d(dev, n)
+    pat = sp.csr_matrix(sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1]))
+    proto = nls.CSRMatrix.from_scipy(pat)
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(F, jac_prototype=proto),
+                                torch.zeros(n, device=dev, dtype=torch.float64), 1.0)
+    u = np.linspace(0.0, 1.0, n)
+    ncol = prob.device_problem.jac_values(u, proto, colored=True)
+    assert ncol == 3                                            # tridiagonal ⇒ 3 structurally orthogonal groups
+    J = sp.csr_matrix((proto.values(), pat.indices, pat.indptr), shape=(n, n)).toarray()
+    assert np.max(np.abs(J - J_dense(u))) < 1e-6
+    for alg in (nls.NewtonRaphson(), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=60, reltol=1e-10),
+                                                       concrete_jac=True)):
+        sol = nls.solve(prob, alg, abstol=1e-10)
+        assert sol.retcode == "Success" and float(sol.resid.abs().max()) < 1e-10
+        assert sol.stats.njacs >= sol.stats.nsteps - 1
