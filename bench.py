@@ -12,7 +12,9 @@ orthogonalisation — on the assembled CSR Jacobian (values refilled every step,
 A "step" is one such Newton step: Jacobian value fill + 30×(SpMV + CGS2 pass) + solution update + u += δu +
 residual + ‖·‖∞ + termination bookkeeping, everything resident in HBM.
 N > 1: weak scaling — every rank owns ≈1024² unknowns of a (1024·√N)² grid (row-range partition by grid
-lines, halo lines by RCCL send/recv, Krylov inner products by RCCL all-reduce).
+lines, halo lines by RCCL send/recv, Krylov inner products by RCCL all-reduce). `value` is the whole-job
+aggregate: Newton steps/s × (global unknowns / 1024²), i.e. 1024²-unknown step equivalents per second, which
+is plain Newton steps/s at N = 1; the raw rate of the global problem is config.global_newton_steps_per_sec.
 
 Extra objects on the JSON line: `roofline` (CSR SpMV kernel, HIP-event timed on the launch stream in a second,
 instrumented pass of the same K steps), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
@@ -117,6 +119,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     steps_per_s = args.steps / dt
+    # whole-job aggregate: one unit = one Newton step on 1024² unknowns (exactly the N = 1 workload). Under weak
+    # scaling the global problem has world×1024² unknowns, so a global Newton step is `world` units.
+    units_per_step = n_global / float(1024 * 1024)
+    value = steps_per_s * units_per_step
     stats = cache.stats
     fnorm = cache.fnorm_inf
 
@@ -207,12 +213,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "newton_steps_per_sec", "value": round(steps_per_s, 3), "unit": "newton_steps/s",
+            "metric": "newton_steps_per_sec", "value": round(value, 3),
+            "unit": "newton_steps/s" if world == 1 else "newton_steps/s x (unknowns / 1024^2)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"bratu2d_{ns}x{ns}_newtonraphson_gmres{args.arnoldi}_fixedwork_"
                                    f"{'matfree_jvp' if args.matfree else 'csr_spmv'}",
+                       "global_newton_steps_per_sec": round(steps_per_s, 3), "units_per_global_step": round(units_per_step, 4),
                        "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
                        "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho,
                        "parallelism": f"row-range x{world}", "comm": comm},
