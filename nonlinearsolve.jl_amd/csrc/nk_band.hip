@@ -3,16 +3,23 @@
 // — lib/NonlinearSolveBase/ext/NonlinearSolveBaseLinearSolveExt.jl:81-86, descent/newton.jl:121-127).
 //
 // Blocked right-looking LU without pivoting on LAPACK-style band storage AB[(ku + i − j) + j·ldab]
-// (ldab = kl + ku + 1, fill-in stays inside the band). Block size NB = 32:
-//   k_band_panel   one workgroup: the (NB + kl) × NB panel is factored in LDS, and the two NB×NB triangular
-//                  inverses (L11⁻¹, U11⁻¹) are formed so that the later sweeps are matrix–vector products
-//   k_band_update  one workgroup per 8 columns: U12 = L11⁻¹ A12, A22 −= L21 U12 (columns are independent)
-//   k_band_solve   one persistent workgroup: forward and backward block sweeps
+// (ldab = kl + ku + 1, fill-in stays inside the band), block size NB = 32. The factorisation is a chain of
+// n/NB dependent block columns, so the design minimises the latency of one link:
+//   k_band_step(J)  ONE launch per block column. Workgroup 0 applies the rank-NB update of panel J−1 to the NB
+//                   columns of panel J (L21 rows streamed from L2 into registers, U12 broadcast from LDS), factors
+//                   the NB×NB diagonal block inside a single wavefront (one matrix row per lane, pivot rows passed
+//                   by v_readlane — no barriers), forms L11⁻¹ and U11⁻¹ on two wavefronts (one column per lane) and
+//                   L21 = A21 U11⁻¹ on all 16. Workgroups 1… apply the same update of panel J−1 to the remaining
+//                   ku − NB trailing columns (16 columns each) — off the critical path.
+//   k_band_sweep    forward (L) or backward (U) block substitution by one persistent workgroup: the right-hand-side
+//                   window lives in LDS, every thread owns one row of the NB-column coupling block, whose entries
+//                   (and the diagonal-block inverse) are prefetched into registers one block ahead; the diagonal
+//                   solve is a 32×32 matrix–vector product with the stored inverse; 2 barriers per block.
 // No pivoting: valid for the diagonally dominant / SPD-like Jacobians of the grid problems; the driver
 // verifies ‖J x − b‖ after the solve and reports the linear solve as failed otherwise (then the nonlinear
 // driver follows the reference's failure path, lib/NonlinearSolveFirstOrder/src/solve.jl:367-382).
-// FP64 work: 2 n kl ku flops (8.6 GFLOP at n = 65 536, kl = ku = 256) — the run time is launch-latency bound
-// (2 launches per block column), not MFMA bound.
+// FP64 work: 2 n kl ku flops (8.6 GFLOP at n = 65 536, kl = ku = 256); the run time is the latency of the
+// n/NB-long dependency chain (≈10 µs per link), not FP64 throughput — MFMA would not shorten it.
 #include <math.h>
 
 #include <algorithm>
@@ -21,10 +28,24 @@
 
 __host__ __device__ static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 constexpr int NB = 32;
-constexpr int UPD_COLS = 8;
+constexpr int UPD_COLS = 16;   // trailing columns per update workgroup
+constexpr int STEP_T = 512;    // threads per workgroup of k_band_step (8 wavefronts ⇒ 256 VGPRs each)
+constexpr int LUP = NB + 1;    // padded leading dimension of the small LDS matrices
 
 __device__ __forceinline__ bool in_band(int64_t i, int64_t j, int kl, int ku) { return (j - i) <= ku && (i - j) <= kl; }
 __device__ __forceinline__ size_t bidx(int64_t i, int64_t j, int ku, int ldab) { return (size_t)(ku + i - j) + (size_t)j * ldab; }
+// branch-free band load: out-of-band / out-of-range entries read element 0 and are replaced by 0
+__device__ __forceinline__ double ld_band(const double *__restrict__ AB, int64_t i, int64_t j, int64_t n, int kl, int ku,
+                                          int ldab) {
+  const bool ok = (i >= 0) & (j >= 0) & (i < n) & (j < n) & ((j - i) <= ku) & ((i - j) <= kl);
+  const double v = AB[ok ? bidx(i, j, ku, ldab) : 0];
+  return ok ? v : 0.0;
+}
+__device__ __forceinline__ double rdlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 
 __global__ __launch_bounds__(NK_BLOCK) void k_band_fill(int64_t nrows, const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ col, const double *__restrict__ val,
@@ -34,193 +55,322 @@ __global__ __launch_bounds__(NK_BLOCK) void k_band_fill(int64_t nrows, const int
   for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) AB[bidx(r, col[p], ku, ldab)] = val[p];
 }
 
-// panel of block column J: rows [j0, j0+NB+kl) × cols [j0, j0+NB), factored in LDS
-__global__ __launch_bounds__(1024) void k_band_panel(int64_t n, int kl, int ku, int ldab, double *__restrict__ AB,
-                                                     int J, double *__restrict__ invL, double *__restrict__ invU,
-                                                     int *__restrict__ fail) {
-  extern __shared__ __attribute__((aligned(16))) double sp[];  // (NB+kl) × NB column-major, ld = NB+kl
-  const int64_t j0 = (int64_t)J * NB;
-  const int nc = (int)imin64(NB, n - j0);
-  const int nr = (int)imin64(NB + kl, n - j0);
-  const int ld = NB + kl;
-  const int t = threadIdx.x, T = blockDim.x;
-  for (int e = t; e < nr * nc; e += T) {
-    const int c = e / nr, r = e - c * nr;
-    const int64_t i = j0 + r, j = j0 + c;
-    sp[c * ld + r] = in_band(i, j, kl, ku) ? AB[bidx(i, j, ku, ldab)] : 0.0;
-  }
-  __syncthreads();
-  for (int c = 0; c < nc; ++c) {
-    const double piv = sp[c * ld + c];
-    if (t == 0 && (piv == 0.0 || !(piv == piv) || isinf(piv))) *fail = 1;
-    const double ip = 1.0 / piv;
-    for (int r = c + 1 + t; r < nr; r += T) sp[c * ld + r] *= ip;
-    __syncthreads();
-    const int rem = nc - c - 1, rows = nr - c - 1;
-    for (int e = t; e < rem * rows; e += T) {
-      const int cc = c + 1 + e / rows, r = c + 1 + (e - (e / rows) * rows);
-      sp[cc * ld + r] -= sp[c * ld + r] * sp[cc * ld + c];
-    }
-    __syncthreads();
-  }
-  // write the factored panel back
-  for (int e = t; e < nr * nc; e += T) {
-    const int c = e / nr, r = e - c * nr;
-    const int64_t i = j0 + r, j = j0 + c;
-    if (in_band(i, j, kl, ku)) AB[bidx(i, j, ku, ldab)] = sp[c * ld + r];
-  }
-  // Triangular inverses of the diagonal block, formed cooperatively in LDS (row-major NB×NB, zero padded):
-  //   XL = L11⁻¹ by forward elimination  (for c: rows r>c: XL[r,:] −= L[r,c]·XL[c,:])
-  //   XU = U11⁻¹ by backward elimination (for c = nc−1…0: XU[c,:] /= U[c,c]; rows r<c: XU[r,:] −= U[r,c]·XU[c,:])
-  // threads 0..1023: one (row, col) element of each matrix per thread; NB sequential steps, one barrier each.
-  __shared__ double XL[NB * NB], XU[NB * NB];
-  const int er = t / NB, ec = t % NB;  // this thread's element (T == NB*NB)
-  XL[t] = (er == ec) ? 1.0 : 0.0;
-  XU[t] = (er == ec) ? 1.0 : 0.0;
-  __syncthreads();
-  for (int c = 0; c < nc; ++c) {
-    const int cu = nc - 1 - c;
-    // L: eliminate column c below the diagonal
-    const double lrc = (er > c && er < nc) ? sp[c * ld + er] : 0.0;
-    const double xlc = XL[c * NB + ec];
-    // U: scale row cu, eliminate above
-    const double ucc = sp[cu * ld + cu];
-    const double xuc = XU[cu * NB + ec] / ucc;
-    const double urc = (er < cu) ? sp[cu * ld + er] : 0.0;
-    __syncthreads();
-    if (er > c && er < nc) XL[t] -= lrc * xlc;
-    if (er == cu) XU[t] = xuc;
-    else if (er < cu) XU[t] -= urc * xuc;
-    __syncthreads();
-  }
-  // rows/cols ≥ nc of the last (partial) block: identity rows were never touched; zero them so that padded
-  // entries cannot leak into the sweeps
-  double vl = XL[t], vu = XU[t];
-  if (er >= nc || ec >= nc) { vl = 0.0; vu = 0.0; }
-  double *iL = invL + (size_t)J * NB * NB, *iU = invU + (size_t)J * NB * NB;
-  iL[ec * NB + er] = vl;  // stored column-major: element (row er, col ec)
-  iU[ec * NB + er] = vu;
-}
-
-// trailing update for block column J: this workgroup owns UPD_COLS columns right of the panel.
-// L21 (kl × NB) is staged once in dynamic LDS (zero outside the band) so the rank-NB update reads no global
-// memory in its inner loop.
-__global__ __launch_bounds__(NK_BLOCK) void k_band_update(int64_t n, int kl, int ku, int ldab, double *__restrict__ AB,
-                                                          int J, const double *__restrict__ invL) {
-  extern __shared__ __attribute__((aligned(16))) double sL21[];  // kl × NB, column-major (ld = kl)
-  __shared__ double sU[NB * UPD_COLS];   // U12 chunk (NB × UPD_COLS)
-  __shared__ double sA[NB * UPD_COLS];   // A12 chunk
-  __shared__ double sL[NB * NB];
-  const int64_t j0 = (int64_t)J * NB;
-  const int64_t c0 = j0 + NB + (int64_t)blockIdx.x * UPD_COLS;  // first column of this chunk
-  if (c0 >= n) return;
+// One block column of the factorisation (see the file header). Dynamic LDS: the (NB + kl) × NB panel.
+__global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku, int ldab, double *__restrict__ AB, int J,
+                                                      double *__restrict__ invL, double *__restrict__ invU,
+                                                      int *__restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];  // panel, column-major, ld = NB + kl + 1
+  __shared__ double sInv[NB * LUP];   // L11⁻¹ of panel J−1 (row-major, padded)
+  __shared__ double sA12[NB * LUP];   // A12 chunk, then reused as U⁻¹ of panel J
+  __shared__ double sU12[NB * LUP];   // U12 chunk [q][c]
+  __shared__ double sLU[NB * LUP];    // factored diagonal block [r][c]
   const int t = threadIdx.x;
-  const double *iL = invL + (size_t)J * NB * NB;
-  for (int e = t; e < NB * NB; e += NK_BLOCK) sL[e] = iL[e];
-  for (int e = t; e < NB * UPD_COLS; e += NK_BLOCK) {
-    const int c = e / NB, r = e - c * NB;
-    const int64_t i = j0 + r, j = c0 + c;
-    sA[e] = (j < n && i < n && in_band(i, j, kl, ku)) ? AB[bidx(i, j, ku, ldab)] : 0.0;
-  }
-  for (int e = t; e < kl * NB; e += NK_BLOCK) {
-    const int q = e / kl, r = e - q * kl;
-    const int64_t i = j0 + NB + r, jq = j0 + q;
-    sL21[e] = (i < n && jq < n && in_band(i, jq, kl, ku)) ? AB[bidx(i, jq, ku, ldab)] : 0.0;
-  }
-  __syncthreads();
-  // U12 = L11⁻¹ A12
-  for (int e = t; e < NB * UPD_COLS; e += NK_BLOCK) {
-    const int c = e / NB, r = e - c * NB;
-    double s = 0.0;
-    for (int q = 0; q <= r; ++q) s += sL[q * NB + r] * sA[c * NB + q];
-    sU[e] = s;
-  }
-  __syncthreads();
-  for (int e = t; e < NB * UPD_COLS; e += NK_BLOCK) {
-    const int c = e / NB, r = e - c * NB;
-    const int64_t i = j0 + r, j = c0 + c;
-    if (j < n && i < n && in_band(i, j, kl, ku)) AB[bidx(i, j, ku, ldab)] = sU[e];
-  }
-  // A22[:, chunk] −= L21 U12, rows j0+NB … j0+NB+kl−1 (consecutive lanes walk down a column: coalesced)
-  for (int e = t; e < kl * UPD_COLS; e += NK_BLOCK) {
-    const int c = e / kl, r = e - c * kl;
-    const int64_t i = j0 + NB + r, j = c0 + c;
-    if (i >= n || j >= n || !in_band(i, j, kl, ku)) continue;
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) s += sL21[q * kl + r] * sU[c * NB + q];
-    AB[bidx(i, j, ku, ldab)] -= s;
-  }
-}
+  const int64_t j0 = (int64_t)J * NB;  // first column of panel J
+  const int64_t jp = j0 - NB;          // first column of panel J−1
+  const int ld = NB + kl + 1;
+  const bool panel_wg = (blockIdx.x == 0);
+  // columns handled by this workgroup: the panel's NB columns, or UPD_COLS trailing columns right of it
+  const int ncols = panel_wg ? NB : UPD_COLS;
+  const int64_t cbase = panel_wg ? j0 : j0 + NB + (int64_t)(blockIdx.x - 1) * UPD_COLS;
 
-// x ← U⁻¹ L⁻¹ x, one persistent workgroup (block sweeps are inherently sequential)
-__global__ __launch_bounds__(1024) void k_band_solve(int64_t n, int kl, int ku, int ldab, const double *__restrict__ AB,
-                                                     int nblk, const double *__restrict__ invL,
-                                                     const double *__restrict__ invU, double *__restrict__ x) {
-  __shared__ double sy[NB], sb[NB];
-  const int t = threadIdx.x, T = blockDim.x;
-  // forward: y_J = L11⁻¹ b_J ; b[below] −= L21 y_J
-  for (int J = 0; J < nblk; ++J) {
-    const int64_t j0 = (int64_t)J * NB;
-    const int nc = (int)imin64(NB, n - j0);
-    if (t < NB) sb[t] = (t < nc) ? x[j0 + t] : 0.0;
-    __syncthreads();
-    if (t < NB) {
-      const double *iL = invL + (size_t)J * NB * NB;
-      double s = 0.0;
-      for (int q = 0; q <= t; ++q) s += iL[q * NB + t] * sb[q];
-      sy[t] = s;
-      if (t < nc) x[j0 + t] = s;
+  if (J > 0) {
+    // P1: L11⁻¹(J−1) and the A12 chunk (rows of block J−1 × our columns)
+    {
+      const double *iL = invL + (size_t)(J - 1) * NB * NB;  // column-major: element (r, q) at q·NB + r
+      for (int e = t; e < NB * NB; e += STEP_T) {
+        const int r = e & (NB - 1), q = e >> 5;
+        sInv[r * LUP + q] = iL[q * NB + r];
+        if (q < ncols) sA12[r * LUP + q] = ld_band(AB, jp + r, cbase + q, n, kl, ku, ldab);
+      }
     }
     __syncthreads();
-    {  // b[below] −= L21 y_J : 4 lanes per row (kl ≤ 256 rows per pass), 8 columns each, shuffle-reduced
-      for (int rb = 0; rb < kl; rb += T / 4) {
-        const int r = rb + (t >> 2), sub = t & 3;
-        const int64_t i = j0 + NB + r;
+    // P2: U12 = L11⁻¹ A12 (one element per thread), kept in LDS and written back
+    {
+      for (int e = t; e < NB * ncols; e += STEP_T) {
+        const int r = e & (NB - 1), c = e >> 5;
         double s = 0.0;
-        if (r < kl && i < n) {
 #pragma unroll
-          for (int qq = 0; qq < NB / 4; ++qq) {
-            const int q = sub * (NB / 4) + qq;
-            const bool ok = (q < nc) && in_band(i, j0 + q, kl, ku);
-            const double a = AB[ok ? bidx(i, j0 + q, ku, ldab) : 0];
-            s += ok ? a * sy[q] : 0.0;
-          }
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (sub == 0 && r < kl && i < n) x[i] -= s;
+        for (int q = 0; q < NB; ++q) s = fma(sInv[r * LUP + q], sA12[q * LUP + c], s);  // sInv is lower triangular
+        sU12[r * LUP + c] = s;
+        const int64_t i = jp + r, j = cbase + c;
+        if (j < n && in_band(i, j, kl, ku)) AB[bidx(i, j, ku, ldab)] = s;
       }
     }
     __syncthreads();
   }
-  // backward: x_J = U11⁻¹ (y_J − U12 x_after)
-  for (int J = nblk - 1; J >= 0; --J) {
-    const int64_t j0 = (int64_t)J * NB;
-    const int nc = (int)imin64(NB, n - j0);
-    // partial sums of U12 x_after: NB rows × (ku) columns, spread over the workgroup then reduced per row
-    __shared__ double part[NB][33];
-    const int row = t & (NB - 1), lane = t / NB;  // T/NB = 32 lanes per row
-    double s = 0.0;
-    if (row < nc) {
-      const int64_t i = j0 + row;
-      for (int64_t j = j0 + NB + lane; j <= i + ku && j < n; j += T / NB) s += AB[bidx(i, j, ku, ldab)] * x[j];
+
+  if (!panel_wg) {
+    // P3 (update workgroups): A22[:, chunk] −= L21 U12 — thread = one row × 4 columns; the L21 row streams from L2
+    const int cg = t >> 8;  // 2 column groups of UPD_COLS / 2
+    constexpr int CW = UPD_COLS / (STEP_T / 256);
+    for (int rr = t & 255; rr < kl; rr += 256) {
+      const int64_t i = j0 + rr;
+      double acc[CW];
+#pragma unroll
+      for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.0;
+      // row i of L21(J−1): element q sits at Lp[q·(ldab−1)]; inside the band for q ≥ NB + rr − kl (the allocation is
+      // padded, so the unconditional loads of masked entries stay in bounds)
+      const double *Lp = AB + bidx(i, jp, ku, ldab);
+      const int qmin = (i < n) ? NB + rr - kl : NB;
+#pragma unroll 8
+      for (int q = 0; q < NB; ++q) {
+        const double lv = Lp[(size_t)q * (ldab - 1)];
+        const double l = (q >= qmin) ? lv : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) acc[cc] = fma(l, sU12[q * LUP + cg * CW + cc], acc[cc]);
+      }
+      // element (i, cbase + c) at Ap[c·(ldab−1)]; in the band while c_abs − i ≤ ku
+      double *Ap = AB + bidx(i, cbase + cg * CW, ku, ldab);
+      const int cmax = (int)imin64(imin64(n - 1, i + ku) - (cbase + cg * CW), CW - 1);  // last valid local column
+      if (i < n) {
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc)
+          if (cc <= cmax) Ap[(size_t)cc * (ldab - 1)] -= acc[cc];
+      }
     }
-    part[row][lane] = s;
-    __syncthreads();
+    return;
+  }
+
+  // ---- panel workgroup
+  const int nc = (int)imin64(NB, n - j0);
+  // P3: panel rows 0..kl−1 with the update of panel J−1 applied, rows kl..kl+NB−1 as they are
+  {
+    const int cg = t >> 8;  // 2 column groups of 16
+    constexpr int CW = NB / (STEP_T / 256);
+    for (int rr = t & 255; rr < kl; rr += 256) {
+      const int64_t i = j0 + rr;
+      double acc[CW];
+#pragma unroll
+      for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.0;
+      if (J > 0) {
+        const double *Lp = AB + bidx(i, jp, ku, ldab);
+        const int qmin = (i < n) ? NB + rr - kl : NB;
+#pragma unroll 8
+        for (int q = 0; q < NB; ++q) {
+          const double lv = Lp[(size_t)q * (ldab - 1)];
+          const double l = (q >= qmin) ? lv : 0.0;
+#pragma unroll
+          for (int cc = 0; cc < CW; ++cc) acc[cc] = fma(l, sU12[q * LUP + cg * CW + cc], acc[cc]);
+        }
+      }
+      const double *Ap = AB + bidx(i, j0 + cg * CW, ku, ldab);
+      const int cmax = (i < n) ? (int)imin64(imin64(n - 1, i + ku) - (j0 + cg * CW), CW - 1) : -1;
+#pragma unroll
+      for (int cc = 0; cc < CW; ++cc) {
+        const double av = Ap[(size_t)cc * (ldab - 1)];
+        sp[(cg * CW + cc) * ld + rr] = ((cc <= cmax) ? av : 0.0) - acc[cc];
+      }
+    }
+    for (int e = t; e < NB * NB; e += STEP_T) {
+      const int r2 = kl + (e & (NB - 1)), c = e >> 5;
+      sp[c * ld + r2] = ld_band(AB, j0 + r2, j0 + c, n, kl, ku, ldab);
+    }
+  }
+  __syncthreads();
+  // P4: LU of the diagonal block in wavefront 0 — lane r holds row r, the pivot row travels by v_readlane
+  if (t < 64) {
+    const int lane = t;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      double v = (lane < NB) ? sp[c * ld + (lane & (NB - 1))] : 0.0;
+      if (lane >= nc || c >= nc) v = (lane == c) ? 1.0 : 0.0;  // identity padding of the last, partial block
+      a[c] = v;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const double piv = rdlane(a[c], c);
+      bad |= !(fabs(piv) > 0.0) || isinf(piv);
+      const double ip = 1.0 / piv;
+      const bool below = lane > c;
+      const double l = a[c] * ip;
+      if (below) a[c] = l;
+#pragma unroll
+      for (int k = c + 1; k < NB; ++k) {
+        const double u = rdlane(a[k], c);
+        if (below) a[k] = fma(-l, u, a[k]);
+      }
+    }
+    if (lane == 0 && bad) *fail = 1;
+    if (lane < NB) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        sLU[lane * LUP + c] = a[c];
+        if (lane < nc && c < nc && in_band(j0 + lane, j0 + c, kl, ku)) AB[bidx(j0 + lane, j0 + c, ku, ldab)] = a[c];
+      }
+    }
+  }
+  __syncthreads();
+  // P5: triangular inverses, one column per lane: wavefront 0 → L11⁻¹ (forward), wavefront 1 → U11⁻¹ (backward)
+  if (t < 128) {
+    const int w = t >> 6, j = t & 63;
+    if (j < NB) {
+      double x[NB];
+      if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = 0; k < i; ++k) s = fma(-sLU[i * LUP + k], x[k], s);
+          x[i] = s;
+        }
+      } else {
+#pragma unroll
+        for (int i = NB - 1; i >= 0; --i) {
+          double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = i + 1; k < NB; ++k) s = fma(-sLU[i * LUP + k], x[k], s);
+          x[i] = s / sLU[i * LUP + i];
+        }
+      }
+      double *dst = (w == 0 ? invL : invU) + (size_t)J * NB * NB + (size_t)j * NB;  // column-major
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const double v = (i >= nc || j >= nc) ? 0.0 : x[i];  // padded rows/cols must not leak into the sweeps
+        dst[i] = v;
+        if (w == 1) sA12[i * LUP + j] = v;  // U⁻¹ [q][c] for P6
+      }
+    }
+  }
+  __syncthreads();
+  // P6: L21 = A21 U11⁻¹ for the kl rows below the diagonal block
+  {
+    const int cg = t >> 8;
+    constexpr int CW = NB / (STEP_T / 256);
+    for (int rr = t & 255; rr < kl; rr += 256) {
+      const int pr = NB + rr;
+      const int64_t i = j0 + pr;
+      double acc[CW];
+#pragma unroll
+      for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < NB; ++q) {
+        const double a = sp[q * ld + pr];
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) acc[cc] = fma(a, sA12[q * LUP + cg * CW + cc], acc[cc]);  // U⁻¹ upper triangular
+      }
+      // element (i, j0 + c) at Ap[c·(ldab−1)]; in the band while i − (j0 + c) ≤ kl, i.e. c ≥ pr − kl
+      double *Ap = AB + bidx(i, j0 + cg * CW, ku, ldab);
+      if (i < n) {
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) {
+          const int c = cg * CW + cc;
+          if (c < nc && c >= pr - kl) Ap[(size_t)cc * (ldab - 1)] = acc[cc];
+        }
+      }
+    }
+  }
+}
+
+// Block substitution sweeps on the factored band. One persistent workgroup of `T ≥ max(kl, ku)` threads.
+//   FWD: for J = 0…nblk−1:  y_J = L11⁻¹ b_J ;  b[rows below] −= L21 y_J      (rows j0+NB … j0+NB+kl−1)
+//   BWD: for J = nblk−1…0:  x_J = U11⁻¹ y_J ;  y[rows above] −= U01 x_J      (rows j0−ku … j0−1)
+// The coupling block (kl or ku rows × NB columns) is contiguous down a column in band storage, so thread r owns
+// row r and its NB entries are prefetched into registers one block ahead; the right-hand-side window lives in LDS.
+template <bool FWD>
+__global__ __launch_bounds__(512) void k_band_sweep(int64_t n, int kl, int ku, int ldab, const double *__restrict__ AB,
+                                                    int nblk, const double *__restrict__ inv, double *__restrict__ x) {
+  extern __shared__ __attribute__((aligned(16))) double win[];  // window of W right-hand-side entries, slot = row mod W
+  __shared__ double sy[2][NB];
+  __shared__ double sinv[2][NB * LUP];  // diagonal-block inverse of the current / next block, [row][col] padded
+  const int t = threadIdx.x, T = blockDim.x;
+  // rows coupled to a block; at least NB so that every row enters the window before it becomes a block's own row
+  const int band = FWD ? kl : ku;
+  const int reach = max(band, NB);
+  const int W = ((reach + NB - 1) / NB) * NB + NB;  // window size (multiple of NB)
+  const int Jfirst = FWD ? 0 : nblk - 1, dJ = FWD ? 1 : -1;
+  const bool mine = t < reach;                    // this thread owns a coupled row
+  const bool enters = mine && (t >= reach - NB);  // … which enters the window with the current block
+  auto row_of = [&](int J) -> int64_t { return FWD ? (int64_t)J * NB + NB + t : (int64_t)J * NB - 1 - t; };
+  auto wrap = [&](int64_t i) -> int { return (int)(((i % W) + W) % W); };
+  // in-band columns q of this thread's coupling row: FWD i − j = NB + t − q ≤ kl ⇔ q ≥ NB + t − kl;
+  //                                                  BWD j − i = q + 1 + t ≤ ku ⇔ q ≤ ku − 1 − t
+  const int qlo = FWD ? NB + t - kl : 0, qhi = FWD ? NB - 1 : ku - 1 - t;
+  // coupling row of this thread for block J (zero outside the band / matrix) and the right-hand-side entry that
+  // enters the window with this block (never updated before)
+  auto load_block = [&](int J, double *c, double &fresh) {
+    const bool valid = (J >= 0) & (J < nblk);
+    const int Jc = valid ? J : Jfirst;
+    const int64_t j0 = (int64_t)Jc * NB;
+    const int64_t i = row_of(Jc);
+    const bool rowok = valid & mine & (i >= 0) & (i < n);
+    const double *p = AB + (rowok ? bidx(i, j0, ku, ldab) : 0);  // element (i, j0 + q) at p[q·(ldab−1)] (padded alloc.)
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const double v = p[(size_t)q * (ldab - 1)];
+      c[q] = (rowok & (q >= qlo) & (q <= qhi)) ? v : 0.0;
+    }
+    const bool ok = rowok & enters;
+    const double f = x[ok ? i : 0];
+    fresh = ok ? f : 0.0;
+  };
+  // the inverse of block J travels global → registers (two blocks ahead) → sinv (one block ahead); T ≥ 256 threads,
+  // NB·NB entries stored column-major in global memory
+  constexpr int TI = NB * NB / 256;
+  auto load_inv = [&](int J, double *r) {
+    const int Jc = (J >= 0 && J < nblk) ? J : Jfirst;
+    const double *iv = inv + (size_t)Jc * NB * NB;
+#pragma unroll
+    for (int k = 0; k < TI; ++k) { const int e = t + k * T; r[k] = iv[e < NB * NB ? e : 0]; }
+  };
+  auto store_inv = [&](const double *r, int buf) {
+#pragma unroll
+    for (int k = 0; k < TI; ++k) {
+      const int e = t + k * T;
+      if (e < NB * NB) sinv[buf][(e & (NB - 1)) * LUP + (e >> 5)] = r[k];
+    }
+  };
+  int own_slot, row_slot;  // window slots of the block's first own row and of this thread's coupled row
+  {
+    const int64_t j0 = (int64_t)Jfirst * NB;
+    own_slot = wrap(j0);
+    row_slot = wrap(row_of(Jfirst));
+    if (t < NB) { const int64_t i = j0 + t; win[own_slot + t] = (i < n) ? x[i] : 0.0; }
+    if (t < reach - NB) { const int64_t i = row_of(Jfirst); win[row_slot] = (i >= 0 && i < n) ? x[i] : 0.0; }
+  }
+  auto advance = [&](int &s) { s += dJ * NB; if (s >= W) s -= W; if (s < 0) s += W; };
+  // one block: diagonal solve by wavefront 0 (lanes 0..31), then the coupling update by every row owner
+  auto process = [&](int J, int par, const double *c, double fresh, const double *inv_next) {
+    const int64_t j0 = (int64_t)J * NB;
     if (t < NB) {
       double acc = 0.0;
-      for (int l = 0; l < T / NB; ++l) acc += part[t][l];
-      sb[t] = (t < nc) ? x[j0 + t] - acc : 0.0;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) acc = fma(sinv[par][t * LUP + q], win[own_slot + q], acc);
+      sy[par][t] = acc;
+      if (j0 + t < n) x[j0 + t] = acc;
     }
     __syncthreads();
-    if (t < NB) {
-      const double *iU = invU + (size_t)J * NB * NB;
-      double v = 0.0;
-      for (int q = t; q < NB; ++q) v += iU[q * NB + t] * sb[q];
-      if (t < nc) x[j0 + t] = v;
+    store_inv(inv_next, par ^ 1);  // inverse of the next block (sinv[par^1] was last read before this barrier's twin)
+    if (mine) {
+      const int64_t i = row_of(J);
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) acc = fma(c[q], sy[par][q], acc);
+      const double base = enters ? fresh : win[row_slot];
+      if (i >= 0 && i < n) win[row_slot] = base - acc;
     }
     __syncthreads();
+    advance(own_slot);
+    advance(row_slot);
+  };
+  double bufA[NB], bufB[NB], invE[TI], invO[TI];  // invE/invO: inverses loaded during even/odd steps
+  double freshA = 0.0, freshB = 0.0;
+  load_inv(Jfirst, invE);
+  store_inv(invE, 0);
+  load_inv(Jfirst + dJ, invO);
+  load_block(Jfirst, bufA, freshA);
+  __syncthreads();
+  for (int s = 0; s < nblk; s += 2) {  // two blocks per trip so that the register double buffers need no copies
+    const int J = Jfirst + s * dJ;
+    load_inv(J + 2 * dJ, invE);
+    load_block(J + dJ, bufB, freshB);
+    process(J, 0, bufA, freshA, invO);
+    if (s + 1 < nblk) {
+      load_inv(J + 3 * dJ, invO);
+      load_block(J + 2 * dJ, bufA, freshA);
+      process(J + dJ, 1, bufB, freshB, invE);
+    }
   }
 }
 
@@ -238,8 +388,9 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
   const int64_t n = A->nrows;
   const size_t band_bytes = (size_t)(kl + ku + 1) * n * sizeof(double);
   NK_REQUIRE(band_bytes < ((size_t)64 << 30), "band storage of %zu bytes is too large (bandwidth %d+%d)", band_bytes, kl, ku);
-  NK_REQUIRE((size_t)(NB + kl) * NB * sizeof(double) <= 136 * 1024,
+  NK_REQUIRE((size_t)(NB + kl + 1) * NB * sizeof(double) <= 120 * 1024,
              "lower bandwidth %d too large for the LDS panel", kl);
+  NK_REQUIRE(kl <= 512 && ku <= 512, "bandwidth %d+%d too large for the substitution sweeps", kl, ku);
   nk_bandlu *B = new nk_bandlu();
   B->ctx = ctx;
   B->n = n;
@@ -247,15 +398,14 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
   B->ku = ku;
   B->ldab = kl + ku + 1;
   B->nblk = (int)((n + NB - 1) / NB);
-  NK_TRY(nk_dev_alloc(&B->AB, (size_t)B->ldab * n));
+  NK_TRY(nk_dev_alloc(&B->AB, (size_t)B->ldab * (n + NB + 2)));  // padded: masked loads past the band stay in bounds
   NK_TRY(nk_dev_alloc(&B->invL, (size_t)B->nblk * NB * NB));
   NK_TRY(nk_dev_alloc(&B->invU, (size_t)B->nblk * NB * NB));
   NK_TRY(nk_dev_alloc(&B->tmp, (size_t)n + 1));
   NK_TRY(nk_dev_alloc(&B->d_fail, (size_t)1));
   static bool attr_set = false;
   if (!attr_set) {
-    NK_HIP(hipFuncSetAttribute((const void *)k_band_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    NK_HIP(hipFuncSetAttribute((const void *)k_band_update, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    NK_HIP(hipFuncSetAttribute((const void *)k_band_step, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     attr_set = true;
   }
   *out = B;
@@ -272,20 +422,18 @@ void nk_bandlu_destroy(nk_bandlu *B) {
 int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok) {
   nk_ctx *ctx = B->ctx;
   const int64_t n = B->n;
-  NK_HIP(hipMemsetAsync(B->AB, 0, (size_t)B->ldab * n * sizeof(double), ctx->stream));
+  NK_HIP(hipMemsetAsync(B->AB, 0, (size_t)B->ldab * (n + NB + 2) * sizeof(double), ctx->stream));
   NK_HIP(hipMemsetAsync(B->d_fail, 0, sizeof(int), ctx->stream));
   NK_LAUNCH(ctx, k_band_fill, dim3((unsigned)((n + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), n, A->d_rowptr, A->d_col,
             A->d_val, B->AB, B->ku, B->ldab);
-  const size_t lds = (size_t)(NB + B->kl) * NB * sizeof(double);
+  const size_t lds = (size_t)(NB + B->kl + 1) * NB * sizeof(double);
   for (int J = 0; J < B->nblk; ++J) {
-    hipLaunchKernelGGL(k_band_panel, dim3(1), dim3(1024), lds, ctx->stream, n, B->kl, B->ku, B->ldab, B->AB, J, B->invL,
-                       B->invU, B->d_fail);
-    const int64_t right = imin64(B->ku, n - ((int64_t)J * NB + NB));
-    if (right > 0) {
-      const int grid = (int)((right + UPD_COLS - 1) / UPD_COLS);
-      hipLaunchKernelGGL(k_band_update, dim3(grid), dim3(NK_BLOCK), (size_t)B->kl * NB * sizeof(double), ctx->stream, n,
-                         B->kl, B->ku, B->ldab, B->AB, J, (const double *)B->invL);
-    }
+    // trailing columns of panel J−1 beyond panel J's own: ku − NB of them, clipped at the matrix edge
+    const int64_t j0 = (int64_t)J * NB;
+    const int64_t extra = (J > 0) ? std::max<int64_t>(0, imin64((int64_t)B->ku - NB, n - (j0 + NB))) : 0;
+    const int grid = 1 + (int)((extra + UPD_COLS - 1) / UPD_COLS);
+    hipLaunchKernelGGL(k_band_step, dim3(grid), dim3(STEP_T), lds, ctx->stream, n, B->kl, B->ku, B->ldab, B->AB, J,
+                       B->invL, B->invU, B->d_fail);
   }
   NK_HIP(hipGetLastError());
   int h = 0;
@@ -299,8 +447,12 @@ int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok) {
 int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x) {
   nk_ctx *ctx = B->ctx;
   NK_TRY(nk_blas_copy(ctx, B->n, d_b, d_x));
-  hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(1024), 0, ctx->stream, B->n, B->kl, B->ku, B->ldab,
-                     (const double *)B->AB, B->nblk, (const double *)B->invL, (const double *)B->invU, d_x);
+  auto threads = [](int reach) { return std::min(512, std::max(256, ((std::max(reach, NB) + 63) / 64) * 64)); };
+  auto window = [](int reach) { return (size_t)(((std::max(reach, NB) + NB - 1) / NB) * NB + NB) * sizeof(double); };
+  hipLaunchKernelGGL(k_band_sweep<true>, dim3(1), dim3(threads(B->kl)), window(B->kl), ctx->stream, B->n, B->kl, B->ku,
+                     B->ldab, (const double *)B->AB, B->nblk, (const double *)B->invL, d_x);
+  hipLaunchKernelGGL(k_band_sweep<false>, dim3(1), dim3(threads(B->ku)), window(B->ku), ctx->stream, B->n, B->kl, B->ku,
+                     B->ldab, (const double *)B->AB, B->nblk, (const double *)B->invU, d_x);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

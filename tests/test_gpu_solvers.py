@@ -634,3 +634,23 @@ def test_user_function_sparse_prototype_coloured_fd_jacobian(nls, dev):
         sol = nls.solve(prob, alg, abstol=1e-10)
         assert sol.retcode == "Success" and float(sol.resid.abs().max()) < 1e-10
         assert sol.stats.njacs >= sol.stats.nsteps - 1
+
+
+@pytest.mark.parametrize("n,kl,ku", [(33, 1, 1), (257, 3, 40), (1000, 70, 5), (2048, 256, 256), (1500, 300, 129),
+                                     (64, 31, 32), (31, 2, 2)])
+def test_banded_lu_shapes_vs_scipy(nls, n, kl, ku):
+    """Band shapes around the block size (NB = 32): kl ≠ ku, bandwidth < NB, > 256 rows per panel pass, n not a
+    multiple of NB, and the C2 shape kl = ku = 256 — factor + both substitution sweeps against SuperLU."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(n + kl)
+    offs = list(range(-kl, ku + 1))
+    A = sp.diags([rng.standard_normal(n - abs(k)) for k in offs], offs, format="csr")
+    A = sp.csr_matrix(A + sp.identity(n) * (2.0 * (kl + ku)))   # diagonally dominant: no pivoting needed
+    F = nls.BandedLU(nls.CSRMatrix.from_scipy(A))
+    assert F.info()["kl"] == kl and F.info()["ku"] == ku
+    for _ in range(2):
+        b = rng.standard_normal(n)
+        x = F.solve(b)
+        assert np.max(np.abs(A @ x - b)) <= 1e-12 * np.max(np.abs(b)) * (kl + ku)
+        assert np.allclose(x, spla.spsolve(A.tocsc(), b), rtol=1e-10, atol=1e-13)
