@@ -5,21 +5,28 @@
 // Blocked right-looking LU without pivoting on LAPACK-style band storage AB[(ku + i − j) + j·ldab]
 // (ldab = kl + ku + 1, fill-in stays inside the band), block size NB = 32. The factorisation is a chain of
 // n/NB dependent block columns, so the design minimises the latency of one link:
-//   k_band_step(J)  ONE launch per block column. Workgroup 0 applies the rank-NB update of panel J−1 to the NB
-//                   columns of panel J (L21 rows streamed from L2 into registers, U12 broadcast from LDS), factors
-//                   the NB×NB diagonal block inside a single wavefront (one matrix row per lane, pivot rows passed
-//                   by v_readlane — no barriers), forms L11⁻¹ and U11⁻¹ on two wavefronts (one column per lane) and
-//                   L21 = A21 U11⁻¹ on all 16. Workgroups 1… apply the same update of panel J−1 to the remaining
-//                   ku − NB trailing columns (16 columns each) — off the critical path.
+//   k_band_step(J)  ONE launch per block column. Workgroup 0 (512 threads): U12 = L11⁻¹(J−1) A12 for panel J's
+//                   columns; L21(J−1) staged once in LDS; rank-NB update of the panel in 4×4 register tiles
+//                   (LDS-bound: 2 reads per 4 FMAs); LU of the NB×NB diagonal block inside ONE wavefront (one matrix
+//                   row per lane, pivot rows passed by v_readlane, reciprocal pivots by v_rcp_f64 + 2 Newton steps, no
+//                   barriers); U11⁻¹ and L11⁻¹ on two wavefronts (one column per lane, column-oriented substitution
+//                   from an LDS copy); L21 = A21 U11⁻¹ in 4×4 tiles. Workgroups 1… apply the update of panel J−1 to
+//                   the remaining ku − NB trailing columns (16 columns each) — off the critical path. All workgroup
+//                   barriers are LDS-only (address-space fences), so global stores/loads stay in flight across them.
 //   k_band_sweep    forward (L) or backward (U) block substitution by one persistent workgroup: the right-hand-side
-//                   window lives in LDS, every thread owns one row of the NB-column coupling block, whose entries
-//                   (and the diagonal-block inverse) are prefetched into registers one block ahead; the diagonal
-//                   solve is a 32×32 matrix–vector product with the stored inverse; 2 barriers per block.
+//                   window lives in LDS, every thread owns one row of the NB-column coupling block, whose entries are
+//                   prefetched into a 4-deep register ring (the diagonal-block inverse travels global → registers →
+//                   LDS two blocks ahead); the diagonal solve is a 32×32 matrix–vector product with the stored
+//                   inverse; 2 LDS-only barriers per block. A single CU streams ≈26 GB/s here: the sweeps are bound
+//                   by that, not by the dependency chain.
+// Measured at C2 (n = 65 536, kl = ku = 256): factor 57.7 ms (28 µs per block column: HBM round trip + U12 6 µs,
+// panel update 5.6 µs, diagonal block 10.8 µs, L21 3.9 µs), both sweeps 11.4 ms; SuperLU on the host: 137 / 7.4 ms.
 // No pivoting: valid for the diagonally dominant / SPD-like Jacobians of the grid problems; the driver
 // verifies ‖J x − b‖ after the solve and reports the linear solve as failed otherwise (then the nonlinear
 // driver follows the reference's failure path, lib/NonlinearSolveFirstOrder/src/solve.jl:367-382).
 // FP64 work: 2 n kl ku flops (8.6 GFLOP at n = 65 536, kl = ku = 256); the run time is the latency of the
-// n/NB-long dependency chain (≈10 µs per link), not FP64 throughput — MFMA would not shorten it.
+// n/NB-long dependency chain, not FP64 throughput (FP64 MFMA has the vector rate on MI355X; it would only relieve the
+// LDS operand traffic of the two 256×32×32 products).
 #include <math.h>
 
 #include <algorithm>
@@ -31,6 +38,7 @@ constexpr int NB = 32;
 constexpr int UPD_COLS = 16;   // trailing columns per update workgroup
 constexpr int STEP_T = 512;    // threads per workgroup of k_band_step (8 wavefronts ⇒ 256 VGPRs each)
 constexpr int LUP = NB + 1;    // padded leading dimension of the small LDS matrices
+constexpr int LUT = NB + 2;    // leading dimension of the column-major LU copy (even: 16-byte aligned columns)
 
 __device__ __forceinline__ bool in_band(int64_t i, int64_t j, int kl, int ku) { return (j - i) <= ku && (i - j) <= kl; }
 __device__ __forceinline__ size_t bidx(int64_t i, int64_t j, int ku, int ldab) { return (size_t)(ku + i - j) + (size_t)j * ldab; }
@@ -40,6 +48,15 @@ __device__ __forceinline__ double ld_band(const double *__restrict__ AB, int64_t
   const bool ok = (i >= 0) & (j >= 0) & (i < n) & (j < n) & ((j - i) <= ku) & ((i - j) <= kl);
   const double v = AB[ok ? bidx(i, j, ku, ldab) : 0];
   return ok ? v : 0.0;
+}
+// Workgroup barrier that orders LDS traffic only. __syncthreads() carries a workgroup-scope fence, i.e.
+// s_waitcnt vmcnt(0): it would drain the register prefetch of the next blocks on every step of the sweeps.
+// (The LDS-only address-space fences keep the barrier a convergent operation for the compiler — an inline-asm
+// s_barrier may legally be duplicated into the two sides of a divergent `if (t < 32)`, i.e. executed twice by one wave.)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 __device__ __forceinline__ double rdlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -63,7 +80,8 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
   __shared__ double sInv[NB * LUP];   // L11⁻¹ of panel J−1 (row-major, padded)
   __shared__ double sA12[NB * LUP];   // A12 chunk, then reused as U⁻¹ of panel J
   __shared__ double sU12[NB * LUP];   // U12 chunk [q][c]
-  __shared__ double sLU[NB * LUP];    // factored diagonal block [r][c]
+  __shared__ __attribute__((aligned(16))) double sLU[NB * LUT];  // factored diagonal block, column-major [c][r]
+  __shared__ double sRd[NB];          // 1 / U[c][c]
   const int t = threadIdx.x;
   const int64_t j0 = (int64_t)J * NB;  // first column of panel J
   const int64_t jp = j0 - NB;          // first column of panel J−1
@@ -72,7 +90,6 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
   // columns handled by this workgroup: the panel's NB columns, or UPD_COLS trailing columns right of it
   const int ncols = panel_wg ? NB : UPD_COLS;
   const int64_t cbase = panel_wg ? j0 : j0 + NB + (int64_t)(blockIdx.x - 1) * UPD_COLS;
-
   if (J > 0) {
     // P1: L11⁻¹(J−1) and the A12 chunk (rows of block J−1 × our columns)
     {
@@ -82,23 +99,50 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
         sInv[r * LUP + q] = iL[q * NB + r];
         if (q < ncols) sA12[r * LUP + q] = ld_band(AB, jp + r, cbase + q, n, kl, ku, ldab);
       }
-    }
-    __syncthreads();
-    // P2: U12 = L11⁻¹ A12 (one element per thread), kept in LDS and written back
-    {
-      for (int e = t; e < NB * ncols; e += STEP_T) {
-        const int r = e & (NB - 1), c = e >> 5;
-        double s = 0.0;
+      // panel workgroup: stage L21(J−1) (kl × NB, every entry read once, coalesced down the columns) in the LDS rows
+      // the updated panel will occupy — P3 reads it from there and overwrites it after a barrier
+      if (panel_wg) {
+        for (int rr = t & 255; rr < kl; rr += 256) {
+          const int64_t i = j0 + rr;
+          const double *Lp = AB + bidx(i < n ? i : j0, jp, ku, ldab);  // element q at Lp[q·(ldab−1)] (padded allocation)
+          const int qmin = (i < n) ? NB + rr - kl : NB;
 #pragma unroll
-        for (int q = 0; q < NB; ++q) s = fma(sInv[r * LUP + q], sA12[q * LUP + c], s);  // sInv is lower triangular
-        sU12[r * LUP + c] = s;
-        const int64_t i = jp + r, j = cbase + c;
-        if (j < n && in_band(i, j, kl, ku)) AB[bidx(i, j, ku, ldab)] = s;
+          for (int q = (t >> 8); q < NB; q += STEP_T / 256) {
+            const double v = Lp[(size_t)q * (ldab - 1)];
+            sp[q * ld + rr] = (q >= qmin) ? v : 0.0;
+          }
+        }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    // P2: U12 = L11⁻¹ A12, kept in LDS and written back. 2×2 outputs per thread (rows r, r+16; columns c, c+1):
+    //     four LDS reads feed four FMAs
+    {
+      const int r = t & 15, cp = t >> 4;  // 16 row pairs × 32 column pairs ≥ ncols/2
+      if (2 * cp < ncols) {
+        const int c = 2 * cp;
+        double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {  // sInv is lower triangular (zeros stored above the diagonal)
+          const double l0 = sInv[r * LUP + q], l1 = sInv[(r + 16) * LUP + q];
+          const double a0 = sA12[q * LUP + c], a1 = sA12[q * LUP + c + 1];
+          s00 = fma(l0, a0, s00); s01 = fma(l0, a1, s01);
+          s10 = fma(l1, a0, s10); s11 = fma(l1, a1, s11);
+        }
+        sU12[r * LUP + c] = s00; sU12[r * LUP + c + 1] = s01;
+        sU12[(r + 16) * LUP + c] = s10; sU12[(r + 16) * LUP + c + 1] = s11;
+        const double sv[2][2] = {{s00, s01}, {s10, s11}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int64_t i = jp + r + 16 * a, j = cbase + c + b;
+            if (j < n && in_band(i, j, kl, ku)) AB[bidx(i, j, ku, ldab)] = sv[a][b];
+          }
+      }
+    }
+    lds_barrier();
   }
-
   if (!panel_wg) {
     // P3 (update workgroups): A22[:, chunk] −= L21 U12 — thread = one row × 4 columns; the L21 row streams from L2
     const int cg = t >> 8;  // 2 column groups of UPD_COLS / 2
@@ -135,30 +179,64 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
   const int nc = (int)imin64(NB, n - j0);
   // P3: panel rows 0..kl−1 with the update of panel J−1 applied, rows kl..kl+NB−1 as they are
   {
-    const int cg = t >> 8;  // 2 column groups of 16
-    constexpr int CW = NB / (STEP_T / 256);
-    for (int rr = t & 255; rr < kl; rr += 256) {
-      const int64_t i = j0 + rr;
-      double acc[CW];
+    // register tile: 4 rows (rg, rg+64, rg+128, rg+192) × 4 columns per thread, so that one broadcast LDS read of
+    // U12 feeds 4 FMAs and one L21 entry feeds 4 more (64 row groups × 8 column groups = 512 threads)
+    const int rg = t & 63, cg = t >> 6;
+    constexpr int RT = 4, CT = 4;
+    constexpr int MAXRB = 2;  // kl ≤ 2·256 rows (checked on the host)
+    double out[MAXRB][RT][CT];
 #pragma unroll
-      for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.0;
-      if (J > 0) {
-        const double *Lp = AB + bidx(i, jp, ku, ldab);
-        const int qmin = (i < n) ? NB + rr - kl : NB;
-#pragma unroll 8
-        for (int q = 0; q < NB; ++q) {
-          const double lv = Lp[(size_t)q * (ldab - 1)];
-          const double l = (q >= qmin) ? lv : 0.0;
+    for (int b = 0; b < MAXRB; ++b) {
+      const int rb = b * 64 * RT;
+      if (rb < kl) {
+        double acc[RT][CT], av[RT][CT];
 #pragma unroll
-          for (int cc = 0; cc < CW; ++cc) acc[cc] = fma(l, sU12[q * LUP + cg * CW + cc], acc[cc]);
+        for (int k = 0; k < RT; ++k) {
+          const int rr = rb + rg + 64 * k;
+          const int64_t i = j0 + rr;
+          const bool ok = (rr < kl) & (i < n);
+          const double *Ap = AB + bidx(ok ? i : j0, j0 + cg * CT, ku, ldab);
+          const int cmax = ok ? (int)imin64(imin64(n - 1, i + ku) - (j0 + cg * CT), CT - 1) : -1;
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) {
+            const double a = Ap[(size_t)cc * (ldab - 1)];  // issued before the product loop: latency hidden behind it
+            av[k][cc] = (cc <= cmax) ? a : 0.0;
+            acc[k][cc] = 0.0;
+          }
         }
-      }
-      const double *Ap = AB + bidx(i, j0 + cg * CW, ku, ldab);
-      const int cmax = (i < n) ? (int)imin64(imin64(n - 1, i + ku) - (j0 + cg * CW), CW - 1) : -1;
+        if (J > 0) {
+#pragma unroll 4
+          for (int q = 0; q < NB; ++q) {
+            double u[CT];
 #pragma unroll
-      for (int cc = 0; cc < CW; ++cc) {
-        const double av = Ap[(size_t)cc * (ldab - 1)];
-        sp[(cg * CW + cc) * ld + rr] = ((cc <= cmax) ? av : 0.0) - acc[cc];
+            for (int cc = 0; cc < CT; ++cc) u[cc] = sU12[q * LUP + cg * CT + cc];
+#pragma unroll
+            for (int k = 0; k < RT; ++k) {
+              const double l = sp[q * ld + min(rb + rg + 64 * k, kl - 1)];
+#pragma unroll
+              for (int cc = 0; cc < CT; ++cc) acc[k][cc] = fma(l, u[cc], acc[k][cc]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < RT; ++k)
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) out[b][k][cc] = av[k][cc] - acc[k][cc];
+      }
+    }
+    lds_barrier();  // every read of the staged L21 is done: the same LDS rows now receive the updated panel
+#pragma unroll
+    for (int b = 0; b < MAXRB; ++b) {
+      const int rb = b * 64 * RT;
+      if (rb < kl) {
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+          const int rr = rb + rg + 64 * k;
+          if (rr < kl) {
+#pragma unroll
+            for (int cc = 0; cc < CT; ++cc) sp[(cg * CT + cc) * ld + rr] = out[b][k][cc];
+          }
+        }
       }
     }
     for (int e = t; e < NB * NB; e += STEP_T) {
@@ -166,101 +244,123 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
       sp[c * ld + r2] = ld_band(AB, j0 + r2, j0 + c, n, kl, ku, ldab);
     }
   }
-  __syncthreads();
-  // P4: LU of the diagonal block in wavefront 0 — lane r holds row r, the pivot row travels by v_readlane
+  lds_barrier();
+  // P4: LU of the diagonal block in wavefront 0 — lane r holds row r, the pivot row travels by v_readlane — followed
+  //     in the same registers by U11⁻¹ (lane j builds column j by column-oriented back substitution)
   if (t < 64) {
-    const int lane = t;
+    const int lane = t & (NB - 1);  // lanes 32..63 mirror lanes 0..31 (same arithmetic, nothing stored)
+    const bool store_lane = t < NB;
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      double v = (lane < NB) ? sp[c * ld + (lane & (NB - 1))] : 0.0;
+      double v = sp[c * ld + lane];
       if (lane >= nc || c >= nc) v = (lane == c) ? 1.0 : 0.0;  // identity padding of the last, partial block
       a[c] = v;
     }
     bool bad = false;
+    const double flane = (double)lane;
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
       const double piv = rdlane(a[c], c);
       bad |= !(fabs(piv) > 0.0) || isinf(piv);
-      const double ip = 1.0 / piv;
-      const bool below = lane > c;
-      const double l = a[c] * ip;
-      if (below) a[c] = l;
+      // reciprocal pivot: hardware estimate + two Newton steps (≤ 1 ulp; a full IEEE division is a ~12-deep
+      // dependent chain on the critical path of every pivot)
+      double ip = __builtin_amdgcn_rcp(piv);
+      ip = fma(fma(-piv, ip, 1.0), ip, ip);
+      ip = fma(fma(-piv, ip, 1.0), ip, ip);
+      if (t == 0) sRd[c] = ip;  // reciprocal pivots, re-read (broadcast) by the U⁻¹ pass below
+      // rows ≤ c take a zero multiplier (no per-element select); the 0/1 factor is computed arithmetically because
+      // 32 hoisted `lane > c` compare masks would occupy the whole SGPR file
+      const double m = fmin(fmax(flane - (double)c, 0.0), 1.0);
+      const double lf = a[c] * ip, l = lf * m;
+      a[c] = fma(lf, m, a[c] * (1.0 - m));  // exact select for m ∈ {0, 1}
 #pragma unroll
       for (int k = c + 1; k < NB; ++k) {
-        const double u = rdlane(a[k], c);
-        if (below) a[k] = fma(-l, u, a[k]);
+        a[k] = fma(-l, rdlane(a[k], c), a[k]);
+        if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // ≤ 8 v_readlane pairs in flight: they live in SGPRs
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (lane == 0 && bad) *fail = 1;
-    if (lane < NB) {
+    if (t == 0 && bad) *fail = 1;
+    if (store_lane) {
 #pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        sLU[lane * LUP + c] = a[c];
-        if (lane < nc && c < nc && in_band(j0 + lane, j0 + c, kl, ku)) AB[bidx(j0 + lane, j0 + c, ku, ldab)] = a[c];
-      }
+      for (int c = 0; c < NB; ++c) sLU[c * LUT + lane] = a[c];  // column-major; not written back to AB (sweeps use inverses)
     }
   }
-  __syncthreads();
-  // P5: triangular inverses, one column per lane: wavefront 0 → L11⁻¹ (forward), wavefront 1 → U11⁻¹ (backward)
+  lds_barrier();
+  // P5: both triangular inverses from the LDS copy, one column per lane, column-oriented substitution (independent
+  //     FMAs, the matrix column is a contiguous broadcast read): wavefront 0 → U11⁻¹ (needed by P6), wavefront 1 →
+  //     L11⁻¹ (needed by the NEXT launch only)
   if (t < 128) {
-    const int w = t >> 6, j = t & 63;
-    if (j < NB) {
-      double x[NB];
-      if (w == 0) {
+    const int w = t >> 6, j = t & (NB - 1);
+    double x[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          double s = (i == j) ? 1.0 : 0.0;
+    for (int i = 0; i < NB; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+    if (w == 0) {
 #pragma unroll
-          for (int k = 0; k < i; ++k) s = fma(-sLU[i * LUP + k], x[k], s);
-          x[i] = s;
-        }
-      } else {
+      for (int k = NB - 1; k >= 0; --k) {
+        x[k] *= sRd[k];
 #pragma unroll
-        for (int i = NB - 1; i >= 0; --i) {
-          double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-          for (int k = i + 1; k < NB; ++k) s = fma(-sLU[i * LUP + k], x[k], s);
-          x[i] = s / sLU[i * LUP + i];
-        }
+        for (int i = 0; i < k; ++i) x[i] = fma(-sLU[k * LUT + i], x[k], x[i]);
       }
-      double *dst = (w == 0 ? invL : invU) + (size_t)J * NB * NB + (size_t)j * NB;  // column-major
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < NB; ++i) x[i] = fma(-sLU[k * LUT + i], x[k], x[i]);
+      }
+    }
+    if ((t & 63) < NB) {
+      double *dst = (w == 0 ? invU : invL) + (size_t)J * NB * NB + (size_t)j * NB;  // column-major
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const double v = (i >= nc || j >= nc) ? 0.0 : x[i];  // padded rows/cols must not leak into the sweeps
         dst[i] = v;
-        if (w == 1) sA12[i * LUP + j] = v;  // U⁻¹ [q][c] for P6
+        if (w == 0) sA12[i * LUP + j] = v;  // U⁻¹ [q][c] for P6
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   // P6: L21 = A21 U11⁻¹ for the kl rows below the diagonal block
   {
-    const int cg = t >> 8;
-    constexpr int CW = NB / (STEP_T / 256);
-    for (int rr = t & 255; rr < kl; rr += 256) {
-      const int pr = NB + rr;
-      const int64_t i = j0 + pr;
-      double acc[CW];
+    const int rg = t & 63, cg = t >> 6;
+    constexpr int RT = 4, CT = 4;
+    for (int rb = 0; rb < kl; rb += 64 * RT) {
+      double acc[RT][CT];
 #pragma unroll
-      for (int cc = 0; cc < CW; ++cc) acc[cc] = 0.0;
+      for (int k = 0; k < RT; ++k)
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) acc[k][cc] = 0.0;
 #pragma unroll 4
       for (int q = 0; q < NB; ++q) {
-        const double a = sp[q * ld + pr];
+        double u[CT];
 #pragma unroll
-        for (int cc = 0; cc < CW; ++cc) acc[cc] = fma(a, sA12[q * LUP + cg * CW + cc], acc[cc]);  // U⁻¹ upper triangular
+        for (int cc = 0; cc < CT; ++cc) u[cc] = sA12[q * LUP + cg * CT + cc];  // U⁻¹ (upper triangular)
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+          const int rr = min(rb + rg + 64 * k, kl - 1);
+          const double a = sp[q * ld + NB + rr];
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc[k][cc] = fma(a, u[cc], acc[k][cc]);
+        }
       }
-      // element (i, j0 + c) at Ap[c·(ldab−1)]; in the band while i − (j0 + c) ≤ kl, i.e. c ≥ pr − kl
-      double *Ap = AB + bidx(i, j0 + cg * CW, ku, ldab);
-      if (i < n) {
 #pragma unroll
-        for (int cc = 0; cc < CW; ++cc) {
-          const int c = cg * CW + cc;
-          if (c < nc && c >= pr - kl) Ap[(size_t)cc * (ldab - 1)] = acc[cc];
+      for (int k = 0; k < RT; ++k) {
+        const int rr = rb + rg + 64 * k, pr = NB + rr;
+        const int64_t i = j0 + pr;
+        if (rr < kl && i < n) {
+          // element (i, j0 + c) at Ap[c·(ldab−1)]; in the band while i − (j0 + c) ≤ kl, i.e. c ≥ pr − kl
+          double *Ap = AB + bidx(i, j0 + cg * CT, ku, ldab);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) {
+            const int c = cg * CT + cc;
+            if (c < nc && c >= pr - kl) Ap[(size_t)cc * (ldab - 1)] = acc[k][cc];
+          }
         }
       }
     }
   }
+  lds_barrier();
 }
 
 // Block substitution sweeps on the factored band. One persistent workgroup of `T ≥ max(kl, ku)` threads.
@@ -268,8 +368,8 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
 //   BWD: for J = nblk−1…0:  x_J = U11⁻¹ y_J ;  y[rows above] −= U01 x_J      (rows j0−ku … j0−1)
 // The coupling block (kl or ku rows × NB columns) is contiguous down a column in band storage, so thread r owns
 // row r and its NB entries are prefetched into registers one block ahead; the right-hand-side window lives in LDS.
-template <bool FWD>
-__global__ __launch_bounds__(512) void k_band_sweep(int64_t n, int kl, int ku, int ldab, const double *__restrict__ AB,
+template <bool FWD, int DEPTH>
+__global__ __launch_bounds__(DEPTH == 2 ? 512 : 256) void k_band_sweep(int64_t n, int kl, int ku, int ldab, const double *__restrict__ AB,
                                                     int nblk, const double *__restrict__ inv, double *__restrict__ x) {
   extern __shared__ __attribute__((aligned(16))) double win[];  // window of W right-hand-side entries, slot = row mod W
   __shared__ double sy[2][NB];
@@ -340,7 +440,7 @@ __global__ __launch_bounds__(512) void k_band_sweep(int64_t n, int kl, int ku, i
       sy[par][t] = acc;
       if (j0 + t < n) x[j0 + t] = acc;
     }
-    __syncthreads();
+    lds_barrier();
     store_inv(inv_next, par ^ 1);  // inverse of the next block (sinv[par^1] was last read before this barrier's twin)
     if (mine) {
       const int64_t i = row_of(J);
@@ -350,26 +450,28 @@ __global__ __launch_bounds__(512) void k_band_sweep(int64_t n, int kl, int ku, i
       const double base = enters ? fresh : win[row_slot];
       if (i >= 0 && i < n) win[row_slot] = base - acc;
     }
-    __syncthreads();
+    lds_barrier();
     advance(own_slot);
     advance(row_slot);
   };
-  double bufA[NB], bufB[NB], invE[TI], invO[TI];  // invE/invO: inverses loaded during even/odd steps
-  double freshA = 0.0, freshB = 0.0;
+  // DEPTH register buffers form a ring: the coupling rows of the next DEPTH−1 blocks are in flight while one is
+  // consumed (a block is 72 KB and a single CU sees ≈2 µs of HBM latency, so distance 1 leaves it latency-bound)
+  double buf[DEPTH][NB], fresh[DEPTH], invE[TI], invO[TI];  // invE/invO: inverses loaded during even/odd steps
   load_inv(Jfirst, invE);
   store_inv(invE, 0);
   load_inv(Jfirst + dJ, invO);
-  load_block(Jfirst, bufA, freshA);
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) load_block(Jfirst + d * dJ, buf[d], fresh[d]);
   __syncthreads();
-  for (int s = 0; s < nblk; s += 2) {  // two blocks per trip so that the register double buffers need no copies
-    const int J = Jfirst + s * dJ;
-    load_inv(J + 2 * dJ, invE);
-    load_block(J + dJ, bufB, freshB);
-    process(J, 0, bufA, freshA, invO);
-    if (s + 1 < nblk) {
-      load_inv(J + 3 * dJ, invO);
-      load_block(J + 2 * dJ, bufA, freshA);
-      process(J + dJ, 1, bufB, freshB, invE);
+  for (int s = 0; s < nblk; s += DEPTH) {  // DEPTH blocks per trip: the ring is indexed statically (no register copies)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (s + d < nblk) {
+        const int J = Jfirst + (s + d) * dJ;
+        load_inv(J + 2 * dJ, (d & 1) ? invO : invE);
+        load_block(J + (DEPTH - 1) * dJ, buf[(d + DEPTH - 1) % DEPTH], fresh[(d + DEPTH - 1) % DEPTH]);
+        process(J, d & 1, buf[d], fresh[d], (d & 1) ? invE : invO);
+      }
     }
   }
 }
@@ -390,7 +492,7 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
   NK_REQUIRE(band_bytes < ((size_t)64 << 30), "band storage of %zu bytes is too large (bandwidth %d+%d)", band_bytes, kl, ku);
   NK_REQUIRE((size_t)(NB + kl + 1) * NB * sizeof(double) <= 120 * 1024,
              "lower bandwidth %d too large for the LDS panel", kl);
-  NK_REQUIRE(kl <= 512 && ku <= 512, "bandwidth %d+%d too large for the substitution sweeps", kl, ku);
+  NK_REQUIRE(kl <= 512 && ku <= 512, "bandwidth %d+%d too large for the device band solver", kl, ku);
   nk_bandlu *B = new nk_bandlu();
   B->ctx = ctx;
   B->n = n;
@@ -449,10 +551,19 @@ int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x) {
   NK_TRY(nk_blas_copy(ctx, B->n, d_b, d_x));
   auto threads = [](int reach) { return std::min(512, std::max(256, ((std::max(reach, NB) + 63) / 64) * 64)); };
   auto window = [](int reach) { return (size_t)(((std::max(reach, NB) + NB - 1) / NB) * NB + NB) * sizeof(double); };
-  hipLaunchKernelGGL(k_band_sweep<true>, dim3(1), dim3(threads(B->kl)), window(B->kl), ctx->stream, B->n, B->kl, B->ku,
-                     B->ldab, (const double *)B->AB, B->nblk, (const double *)B->invL, d_x);
-  hipLaunchKernelGGL(k_band_sweep<false>, dim3(1), dim3(threads(B->ku)), window(B->ku), ctx->stream, B->n, B->kl, B->ku,
-                     B->ldab, (const double *)B->AB, B->nblk, (const double *)B->invU, d_x);
+  // ≤ 256 coupled rows: 256 threads with a 4-deep register ring; wider bands: 512 threads, 2-deep
+  if (threads(B->kl) <= 256)
+    hipLaunchKernelGGL((k_band_sweep<true, 4>), dim3(1), dim3(256), window(B->kl), ctx->stream, B->n, B->kl, B->ku, B->ldab,
+                       (const double *)B->AB, B->nblk, (const double *)B->invL, d_x);
+  else
+    hipLaunchKernelGGL((k_band_sweep<true, 2>), dim3(1), dim3(512), window(B->kl), ctx->stream, B->n, B->kl, B->ku, B->ldab,
+                       (const double *)B->AB, B->nblk, (const double *)B->invL, d_x);
+  if (threads(B->ku) <= 256)
+    hipLaunchKernelGGL((k_band_sweep<false, 4>), dim3(1), dim3(256), window(B->ku), ctx->stream, B->n, B->kl, B->ku, B->ldab,
+                       (const double *)B->AB, B->nblk, (const double *)B->invU, d_x);
+  else
+    hipLaunchKernelGGL((k_band_sweep<false, 2>), dim3(1), dim3(512), window(B->ku), ctx->stream, B->n, B->kl, B->ku, B->ldab,
+                       (const double *)B->AB, B->nblk, (const double *)B->invU, d_x);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
