@@ -112,6 +112,7 @@ typedef struct nk_problem nk_problem; /* residual / JVP / VJP / Jacobian provide
 typedef struct nk_gmres nk_gmres;     /* GMRES(m) workspace (LinearSolve "LinearCache" analogue)    */
 typedef struct nk_solver nk_solver;   /* GeneralizedFirstOrderAlgorithmCache analogue               */
 typedef struct nk_bandlu nk_lu;       /* banded LU factorisation (LinearSolve factorisation-cache analogue) */
+typedef struct nk_batch nk_batch;     /* ensemble of small dense systems, one per GPU thread */
 
 /* ---------------------------------------------------------------- plain structs */
 
@@ -352,6 +353,25 @@ int nk_solver_get_trace(nk_solver *S, nk_trace_entry *rows, int capacity, int *n
 /* one call: init + solve + results (what SciMLBase.__solve of the extension algorithm does) */
 int nk_newton_solve(nk_problem *P, const double *u0, int memspace, const nk_options *opts,
                     double *u_out, double *resid_out, nk_stats *stats, int *retcode);
+
+/* ---------------------------------------------------------------- ensembles of small systems (kernel generation)
+ * The reference's "GPU acceleration over large parameter searches" (docs/src/tutorials/nonlinear_solve_gpus.md:70-176):
+ * SimpleNewtonRaphson (lib/SimpleNonlinearSolve/src/raphson.jl:39-83) for thousands of small (n ≤ 64) systems
+ * f(u, p_b) = 0, one system per GPU thread. `source` is HIP C++ defining
+ *     template <typename T> __device__ void nk_f(const T *u, const double *p, T *f);
+ * (and, with flags & 1, `__device__ void nk_jac(const double *u, const double *p, double *J)`, row-major n×n). It is
+ * compiled at run time (hiprtc, gfx950) with the solver kernel; without nk_jac the Jacobian comes from forward-mode dual
+ * numbers (AutoForwardDiff, the reference default). Semantics per system: iszero(f(u0)) ⇒ Success; δ = J \ f (partial
+ * pivoting), u −= δ, then AbsNormTerminationMode(maximum∘abs) on the residual of the previous iterate; default abstol
+ * eps^(4/5), maxiters 1000; per-system retcode (NK_RET_SUCCESS | NK_RET_MAXITERS) and iteration count.
+ * nk_batch_compile_check compiles only (no device needed). */
+int nk_batch_compile_check(const char *source, int n, int nparams, int flags, int64_t *code_bytes);
+int nk_batch_create(nk_ctx *ctx, const char *source, int n, int nparams, int flags, nk_batch **out);
+int nk_batch_destroy(nk_batch *B);
+/* u0: n doubles shared by all systems (u0_per_system = 0) or nbatch×n; p: nbatch×nparams; outputs nbatch×n, nbatch×n,
+ * nbatch, nbatch (retcode/iters nullable); abstol ≤ 0 and maxiters ≤ 0 select the defaults. */
+int nk_batch_solve(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int memspace,
+                   double abstol, int maxiters, double *u_out, double *resid_out, int32_t *retcode_out, int32_t *iters_out);
 
 /* ---------------------------------------------------------------- BLAS-1 building blocks (exported for
  * the bench / tests; all on the ctx stream, results of reductions are all-reduced over the ranks) */

@@ -142,6 +142,10 @@ SIGNATURES = {
     "nk_lu_factor": (_I, [_P, _P, C.POINTER(_I)]),
     "nk_lu_solve": (_I, [_P, _P, _P, _I]),
     "nk_lu_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L)]),
+    "nk_batch_compile_check": (_I, [C.c_char_p, _I, _I, _I, C.POINTER(_L)]),
+    "nk_batch_create": (_I, [_P, C.c_char_p, _I, _I, _I, _PP]),
+    "nk_batch_destroy": (_I, [_P]),
+    "nk_batch_solve": (_I, [_P, _L, _P, _I, _P, _I, _D, _I, _P, _P, _P, _P]),
     "nk_options_default": (_I, [C.POINTER(Options)]),
     "nk_solver_init": (_I, [_P, _P, _I, C.POINTER(Options), _PP]),
     "nk_solver_destroy": (_I, [_P]),

@@ -957,6 +957,88 @@ class BandedLU:
             self._h = None
 
 
+# ------------------------------------------------------------------------------------------- ensembles of small systems
+@dataclass
+class SimpleNewtonRaphson:
+    """lib/SimpleNonlinearSolve/src/raphson.jl:23-25 — the algorithm the reference allows inside GPU kernels.
+    `autodiff=None` = AutoForwardDiff (dual numbers in the kernel); `jac=True` uses the `nk_jac` of the source."""
+    jac: bool = False
+    name: str = "SimpleNewtonRaphson"
+
+
+class ImmutableNonlinearProblem:
+    """SciMLBase.ImmutableNonlinearProblem{false}(f, u0, p) for the kernel-generation path
+    (docs/src/tutorials/nonlinear_solve_gpus.md:120-140). `f_source` is HIP C++ defining
+    `template <typename T> __device__ void nk_f(const T *u, const double *p, T *f)`; `u0` has n entries (shared by
+    every system) or shape (nbatch, n); `p` has shape (nbatch, nparams) — one parameter set per system."""
+
+    def __init__(self, f_source: str, u0, p, ctx: Optional[Context] = None):
+        self.f_source, self.ctx = f_source, ctx or default_context()
+        self.u0, self.p = u0, p
+        pshape = tuple(p.shape)
+        if len(pshape) != 2:
+            raise ValueError("p must have shape (nbatch, nparams)")
+        self.nbatch, self.nparams = int(pshape[0]), int(pshape[1])
+        ushape = tuple(u0.shape)
+        self.n = int(ushape[-1])
+        self.u0_per_system = len(ushape) == 2
+        if self.u0_per_system and ushape[0] != self.nbatch:
+            raise ValueError("u0 and p disagree on the number of systems")
+
+
+@dataclass
+class EnsembleSolution:
+    u: object          # (nbatch, n)
+    resid: object      # (nbatch, n): residual at the last evaluated iterate (reference: `fx` returned by check_termination)
+    retcode: np.ndarray  # (nbatch,) strings
+    iters: np.ndarray    # (nbatch,)
+    retcode_raw: np.ndarray = None
+
+
+class _BatchKernel:
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, ctx, source, n, nparams, flags):
+        key = (id(ctx), source, n, nparams, flags)
+        if key not in cls._cache:
+            h = C.c_void_p()
+            check(L.lib().nk_batch_create(ctx._h, source.encode(), n, nparams, flags, C.byref(h)))
+            cls._cache[key] = h
+        return cls._cache[key]
+
+
+def vectorized_solve(prob: ImmutableNonlinearProblem, alg: SimpleNewtonRaphson = None, abstol=None, maxiters=1000):
+    """`vectorized_solve(prob, alg; backend = ROCBackend())` of the tutorial (nonlinear_solve_gpus.md:106-114): solve
+    every parameter set with SimpleNewtonRaphson, one system per GPU thread, in one kernel launch."""
+    alg = alg or SimpleNewtonRaphson()
+    h = _BatchKernel.get(prob.ctx, prob.f_source, prob.n, prob.nparams, 1 if alg.jac else 0)
+    on_dev = _is_torch(prob.p) and prob.p.is_cuda
+    nb, n = prob.nbatch, prob.n
+    if on_dev:
+        u0 = prob.u0 if (_is_torch(prob.u0) and prob.u0.is_cuda) else torch.as_tensor(np.asarray(prob.u0), device=prob.p.device)
+        u0 = u0.to(torch.float64).contiguous()
+        pp = prob.p.to(torch.float64).contiguous()
+        u = torch.empty((nb, n), dtype=torch.float64, device=pp.device)
+        r = torch.empty_like(u)
+        rc = torch.empty(nb, dtype=torch.int32, device=pp.device)
+        it = torch.empty(nb, dtype=torch.int32, device=pp.device)
+        ptr = lambda x: C.c_void_p(x.data_ptr())
+        ms = L.DEVICE
+    else:
+        u0 = np.ascontiguousarray(np.asarray(prob.u0.cpu() if _is_torch(prob.u0) else prob.u0), dtype=np.float64)
+        pp = np.ascontiguousarray(np.asarray(prob.p.cpu() if _is_torch(prob.p) else prob.p), dtype=np.float64)
+        u, r = np.empty((nb, n)), np.empty((nb, n))
+        rc, it = np.empty(nb, dtype=np.int32), np.empty(nb, dtype=np.int32)
+        ptr = lambda x: C.c_void_p(x.ctypes.data)
+        ms = L.HOST
+    check(L.lib().nk_batch_solve(h, nb, ptr(u0), 1 if prob.u0_per_system else 0, ptr(pp), ms,
+                                 0.0 if abstol is None else float(abstol), int(maxiters), ptr(u), ptr(r), ptr(rc), ptr(it)))
+    rch = rc.cpu().numpy() if on_dev else rc
+    ith = it.cpu().numpy() if on_dev else it
+    return EnsembleSolution(u, r, np.asarray(L.RET_NAMES)[rch], ith.copy(), rch.copy())
+
+
 # ------------------------------------------------------------------------------------------- Jacobian operators
 class JacobianOperator:
     """JacobianOperator(prob, fu, u): JVP by default, `.T` flips to VJP

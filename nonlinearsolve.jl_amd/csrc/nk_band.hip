@@ -107,7 +107,8 @@ __global__ __launch_bounds__(STEP_T) void k_band_step(int64_t n, int kl, int ku,
           const double *Lp = AB + bidx(i < n ? i : j0, jp, ku, ldab);  // element q at Lp[q·(ldab−1)] (padded allocation)
           const int qmin = (i < n) ? NB + rr - kl : NB;
 #pragma unroll
-          for (int q = (t >> 8); q < NB; q += STEP_T / 256) {
+          for (int qq = 0; qq < NB / (STEP_T / 256); ++qq) {
+            const int q = qq * (STEP_T / 256) + (t >> 8);
             const double v = Lp[(size_t)q * (ldab - 1)];
             sp[q * ld + rr] = (q >= qmin) ? v : 0.0;
           }

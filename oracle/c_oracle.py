@@ -45,6 +45,8 @@ def lib():
         L.orc_gmres_csr.restype = C.c_int
         L.orc_gmres_csr.argtypes = [C.c_int64, _i, _i, _d, _d, _d, C.c_double, C.c_double, C.c_int, C.c_int,
                                     C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_ensemble_newton.argtypes = [C.c_int, C.c_int, C.c_int64, _d, C.c_int, _d, C.c_int, C.c_double, C.c_int, _d, _d,
+                                          _i, _i]
         L.orc_bratu_newton.restype = C.c_int
         L.orc_bratu_newton.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_double, _d, _i, _d]
@@ -136,3 +138,18 @@ def bratu_newton_cheb(ns, lam, scale, u0, maxsteps=50, use_csr=True, m=30, itmax
     k = lib().orc_bratu_newton_cheb(ns, lam, scale, u, maxsteps, int(use_csr), m, itmax, cheb_degree, cheb_ratio, abstol,
                                     fn, gi)
     return u, fn[:k], gi[:k]
+
+
+def ensemble_newton(kind, u0, P, abstol=None, maxiters=1000):
+    """SimpleNewtonRaphson over the rows of P (kind 0: u.*u .- p, kind 1: tutorial p2_f); OpenMP over systems.
+    Returns (u, resid, retcode, iters)."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    u0 = np.ascontiguousarray(u0, dtype=np.float64)
+    nb, npar = P.shape
+    n = u0.shape[-1]
+    u, r = np.empty((nb, n)), np.empty((nb, n))
+    rc, it = np.empty(nb, dtype=np.int32), np.empty(nb, dtype=np.int32)
+    if abstol is None:
+        abstol = float(np.finfo(float).eps) ** 0.8
+    lib().orc_ensemble_newton(kind, n, nb, u0, int(u0.ndim == 2), P, npar, abstol, maxiters, u, r, rc, it)
+    return u, r, rc, it

@@ -430,3 +430,86 @@ int orc_bratu_newton_cheb(int64_t ns, double lambda, double scale, double *u, in
   free(f); free(dx); free(work); free(cw); free(rowptr); free(col); free(val);
   return k;
 }
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * SimpleNewtonRaphson over an ensemble of small systems (lib/SimpleNonlinearSolve/src/raphson.jl:39-83 restated; see
+ * oracle/reference_restatement.py::simple_newton_raphson), OpenMP over the systems. kind 0: f = u.*u .- p (n ≤ 16),
+ * kind 1: the tutorial's p2_f (n = 4, docs/src/tutorials/nonlinear_solve_gpus.md:120-127). Analytic Jacobians,
+ * Gaussian elimination with partial pivoting. TEST INFRASTRUCTURE / CPU baseline only. */
+#define ORC_BMAX 16
+static void ens_f(int kind, int n, const double *x, const double *p, double *f) {
+  if (kind == 0) {
+    for (int i = 0; i < n; ++i) f[i] = x[i] * x[i] - p[i];
+  } else {
+    f[0] = x[0] + p[0] * x[1];
+    f[1] = sqrt(p[1]) * (x[2] - x[3]);
+    f[2] = (x[1] - p[2] * x[2]) * (x[1] - p[2] * x[2]);
+    f[3] = sqrt(p[3]) * (x[0] - x[3]) * (x[0] - x[3]);
+  }
+}
+static void ens_jac(int kind, int n, const double *x, const double *p, double J[ORC_BMAX][ORC_BMAX]) {
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < n; ++k) J[i][k] = 0.0;
+  if (kind == 0) {
+    for (int i = 0; i < n; ++i) J[i][i] = 2.0 * x[i];
+  } else {
+    const double s1 = sqrt(p[1]), s3 = sqrt(p[3]), d = x[1] - p[2] * x[2], e = x[0] - x[3];
+    J[0][0] = 1.0; J[0][1] = p[0];
+    J[1][2] = s1; J[1][3] = -s1;
+    J[2][1] = 2.0 * d; J[2][2] = -2.0 * p[2] * d;
+    J[3][0] = 2.0 * s3 * e; J[3][3] = -2.0 * s3 * e;
+  }
+}
+static void ens_solve(int n, double A[ORC_BMAX][ORC_BMAX], double *b, double *dx) {
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    double best = fabs(A[c][c]);
+    for (int r = c + 1; r < n; ++r)
+      if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+    if (piv != c) {
+      for (int k = c; k < n; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+      const double t = b[c]; b[c] = b[piv]; b[piv] = t;
+    }
+    const double inv = 1.0 / A[c][c];
+    for (int r = c + 1; r < n; ++r) {
+      const double l = A[r][c] * inv;
+      for (int k = c + 1; k < n; ++k) A[r][k] -= l * A[c][k];
+      b[r] -= l * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double s = b[r];
+    for (int k = r + 1; k < n; ++k) s -= A[r][k] * dx[k];
+    dx[r] = s / A[r][r];
+  }
+}
+void orc_ensemble_newton(int kind, int n, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int np,
+                         double abstol, int maxiters, double *u_out, double *r_out, int32_t *retcode, int32_t *iters) {
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < nbatch; ++b) {
+    double x[ORC_BMAX], fx[ORC_BMAX], dx[ORC_BMAX], rhs[ORC_BMAX], J[ORC_BMAX][ORC_BMAX], A[ORC_BMAX][ORC_BMAX];
+    const double *pp = p + b * np;
+    for (int i = 0; i < n; ++i) x[i] = u0[(u0_per_system ? b * n : 0) + i];
+    ens_f(kind, n, x, pp, fx);
+    int allzero = 1, rc = 2, it = 0;
+    for (int i = 0; i < n; ++i) allzero = allzero && (fx[i] == 0.0);
+    if (allzero) rc = 1;
+    else {
+      ens_jac(kind, n, x, pp, J);
+      for (it = 1; it <= maxiters; ++it) {
+        for (int i = 0; i < n; ++i) { rhs[i] = fx[i]; for (int k = 0; k < n; ++k) A[i][k] = J[i][k]; }
+        ens_solve(n, A, rhs, dx);
+        for (int i = 0; i < n; ++i) x[i] -= dx[i];
+        double nrm = 0.0; int nan = 0;
+        for (int i = 0; i < n; ++i) { const double a = fabs(fx[i]); nan = nan || (a != a); nrm = a > nrm ? a : nrm; }
+        if (!nan && nrm <= abstol) { rc = 1; break; }
+        ens_f(kind, n, x, pp, fx);
+        ens_jac(kind, n, x, pp, J);
+      }
+      if (it > maxiters) it = maxiters;
+    }
+    for (int i = 0; i < n; ++i) { u_out[b * n + i] = x[i]; r_out[b * n + i] = fx[i]; }
+    retcode[b] = rc;
+    iters[b] = it;
+  }
+}

@@ -999,6 +999,33 @@ def init(prob, alg, **kw):
     return FirstOrderCache(prob, alg, **kw)
 
 
+def simple_newton_raphson(f, jac, u0, p, abstol=None, maxiters=1000):
+    """SimpleNewtonRaphson for one small system — lib/SimpleNonlinearSolve/src/raphson.jl:39-83 restated:
+    iszero(fx) short cut; per iteration δx = J \\ fx, x −= δx, THEN the AbsNorm(maximum∘abs) test on the residual of the
+    previous iterate (check_termination precedes evaluate_f!!, utils.jl:64-66), then f and J at the new x.
+    Returns (x, fx, retcode, iterations)."""
+    if abstol is None:
+        abstol = float(np.finfo(float).eps) ** 0.8
+    x = np.array(u0, dtype=float)
+    fx = np.asarray(f(x, p), dtype=float)
+    if not np.any(fx):
+        return x, fx, SUCCESS, 0
+    J = np.asarray(jac(x, p), dtype=float)
+    for it in range(1, maxiters + 1):
+        with np.errstate(all="ignore"):
+            try:
+                dx = np.linalg.solve(J, fx)
+            except np.linalg.LinAlgError:        # singular J: StaticArrays' LU yields Inf/NaN, the loop runs on
+                dx = np.full_like(x, np.nan)
+            x = x - dx
+            nrm = np.max(np.abs(fx)) if not np.any(np.isnan(fx)) else np.nan
+            if nrm <= abstol:
+                return x, fx, SUCCESS, it
+            fx = np.asarray(f(x, p), dtype=float)
+            J = np.asarray(jac(x, p), dtype=float)
+    return x, fx, MAXITERS, maxiters
+
+
 def solve(prob, alg, **kw):
     return FirstOrderCache(prob, alg, **kw).solve()
 

@@ -109,3 +109,19 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "nk_oracle" not in txt, f
+
+
+def test_ensemble_residuals_compile_for_gfx950_without_a_gpu():
+    """hiprtc cross-compiles the user residual + dual-number Jacobian + LU kernel for gfx950 (no device needed);
+    a broken source is reported through nk_last_error, not a crash."""
+    import ctypes as C
+    import ensemble_sources as E
+    from nonlinearsolve_jl_amd import _lib as L
+    nb = C.c_int64()
+    for src, n, npar, flags in [(E.QUADRATIC, 3, 3, 0), (E.P2, 4, 4, 0), (E.TRIG_WITH_JAC, 3, 3, 1), (E.QUADRATIC, 24, 24, 0)]:
+        assert L.lib().nk_batch_compile_check(src.encode(), n, npar, flags, C.byref(nb)) == 0, L.lib().nk_last_error()
+        assert nb.value > 1000
+    bad = b"template <typename T> __device__ void nk_f(const T *u, const double *p, T *f) { f[0] = nope; }"
+    assert L.lib().nk_batch_compile_check(bad, 1, 0, 0, C.byref(nb)) != 0
+    assert b"nope" in L.lib().nk_last_error()
+    assert L.lib().nk_batch_compile_check(E.QUADRATIC.encode(), 65, 1, 0, C.byref(nb)) != 0   # n outside 1..64

@@ -304,3 +304,38 @@ def test_backtracking_linesearch():
     assert plain.retcode != R.SUCCESS            # Newton on atan from |u0| > 1.39 diverges
     assert ls.retcode == R.SUCCESS and np.max(np.abs(ls.u)) < 1e-9
     assert ls.stats.nf > ls.stats.nsteps          # backtracking spent extra residual evaluations
+
+
+# ---- SimpleNewtonRaphson (lib/SimpleNonlinearSolve/src/raphson.jl) — the ensemble path's oracle
+def test_simple_newton_raphson_restatement():
+    import ensemble_sources as E
+    # quadratic_f, u0 = ones, p = 2: root √2 (common_rootfind_testing.jl:15-17,37-45: err < 1e-9)
+    x, fx, rc, it = R.simple_newton_raphson(E.quadratic_f, E.quadratic_jac, np.ones(3), np.full(3, 2.0))
+    assert rc == R.SUCCESS and np.max(np.abs(x - np.sqrt(2.0))) < 1e-9
+    # the termination test looks at the residual of the PREVIOUS iterate: the returned fx is that residual, and one more
+    # Newton step has been taken after it fell below abstol
+    assert np.max(np.abs(fx)) <= np.finfo(float).eps ** 0.8 and np.max(np.abs(E.quadratic_f(x, 2.0))) <= np.max(np.abs(fx))
+    # iszero(f(u0)) short cut: zero iterations
+    x, fx, rc, it = R.simple_newton_raphson(E.quadratic_f, E.quadratic_jac, np.full(2, 3.0), np.full(2, 9.0))
+    assert rc == R.SUCCESS and it == 0
+    # maxiters and NaN (singular J at u0 = 0): never terminates
+    x, fx, rc, it = R.simple_newton_raphson(E.quadratic_f, E.quadratic_jac, np.zeros(2), np.full(2, 2.0), maxiters=7)
+    assert rc == R.MAXITERS and it == 7
+    # parameter sweep ≈ sqrt.(p) (rootfind_tests__item3.jl:4-6)
+    for pv in np.linspace(1.0, 10.0, 7):
+        x, *_ = R.simple_newton_raphson(E.quadratic_f, E.quadratic_jac, np.ones(2), np.full(2, pv))
+        assert np.allclose(x, np.sqrt(pv), rtol=0, atol=1e-9)
+
+
+def test_c_ensemble_oracle_equals_python_restatement():
+    import ensemble_sources as E
+    rng = np.random.default_rng(1)
+    P = rng.random((64, 4)) + 0.05
+    u0 = np.array([1.0, 2.0, 3.0, 4.0])
+    u, r, rc, it = CO.ensemble_newton(1, u0, P, maxiters=200)
+    ref = [R.simple_newton_raphson(E.p2_f, E.p2_jac, u0, P[b], maxiters=200) for b in range(64)]
+    assert (it == np.array([x[3] for x in ref])).all() and (rc == np.array([x[2] for x in ref])).all()
+    assert np.max(np.abs(u - np.array([x[0] for x in ref]))) < 1e-12
+    Pq = np.repeat(np.arange(1.0, 33.0)[:, None], 3, axis=1)
+    u, r, rc, it = CO.ensemble_newton(0, np.ones(3), Pq)
+    assert (rc == R.SUCCESS).all() and np.max(np.abs(u - np.sqrt(Pq))) < 1e-12
