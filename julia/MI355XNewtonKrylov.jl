@@ -215,6 +215,36 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
         original = (; gmres_iters = stats[6], op_applies = stats[7], allreduces = stats[8]))
 end
 
-export Ctx, DeviceCSR, DeviceProblem, bratu2d, brusselator2d, mi355x_function, MI355XGMRES, MI355XNewtonKrylovAlg
+# ------------------------------------------------------------------------------------------ seam 4: ensembles of small systems
+# The tutorial's `vectorized_solve(prob, SimpleNewtonRaphson(); backend = ROCBackend())`
+# (docs/src/tutorials/nonlinear_solve_gpus.md:106-114) behind one ccall: `f_source` is HIP C++ defining
+# `template <typename T> __device__ void nk_f(const T *u, const double *p, T *f)`; hiprtc specialises it into the solver kernel
+# the way GPUCompiler specialises a Julia `f` into the KernelAbstractions kernel. p: nparams × nbatch (one column per system).
+mutable struct EnsembleKernel
+    ptr::Ptr{Cvoid}
+    n::Int
+    nparams::Int
+    function EnsembleKernel(ctx::Ctx, f_source::String, n::Integer, nparams::Integer; has_jac::Bool = false)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        nkcheck(@ccall libnk.nk_batch_create(ctx.ptr::Ptr{Cvoid}, f_source::Cstring, n::Cint, nparams::Cint,
+            (has_jac ? 1 : 0)::Cint, h::Ptr{Ptr{Cvoid}})::Cint)
+        k = new(h[], n, nparams)
+        finalizer(x -> @ccall(libnk.nk_batch_destroy(x.ptr::Ptr{Cvoid})::Cint), k)
+        return k
+    end
+end
+
+function vectorized_solve(k::EnsembleKernel, u0::Vector{Float64}, p::Matrix{Float64}; abstol = 0.0, maxiters = 1000)
+    nb = size(p, 2)
+    u = Matrix{Float64}(undef, k.n, nb); resid = similar(u)
+    rc = Vector{Int32}(undef, nb); iters = Vector{Int32}(undef, nb)
+    GC.@preserve u0 p u resid rc iters nkcheck(@ccall libnk.nk_batch_solve(k.ptr::Ptr{Cvoid}, nb::Int64,
+        u0::Ptr{Float64}, 0::Cint, p::Ptr{Float64}, 0::Cint, abstol::Float64, maxiters::Cint, u::Ptr{Float64},
+        resid::Ptr{Float64}, rc::Ptr{Int32}, iters::Ptr{Int32})::Cint)
+    return (; u, resid, retcode = [RETCODES[c + 1] for c in rc], iters)
+end
+
+export Ctx, DeviceCSR, DeviceProblem, bratu2d, brusselator2d, mi355x_function, MI355XGMRES, MI355XNewtonKrylovAlg,
+    EnsembleKernel, vectorized_solve
 
 end # module
