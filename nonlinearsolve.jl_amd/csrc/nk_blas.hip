@@ -6,6 +6,23 @@
 //   dot        : 16 n    sumsq/norm_inf : 8 n    axpby : 24 n    copy : 16 n
 #include "nk_internal.h"
 
+// Krylov-basis loads. The basis (m+1 columns × 8N bytes ≈ 260 MB at N = 2²⁰) is streamed and never re-used before it
+// has left every cache; NK_NT_BASIS=1 marks those loads non-temporal so that they do not evict the Jacobian
+// (60 MB, re-read by every SpMV) from L2 / Infinity Cache. Measured on MI355X (Bratu 1024², fixed-work step): the SpMV
+// gains 2 % (16.46 → 16.17 µs) but the basis kernels lose 12–14 % (multidot 26.9 → 30.7 µs), 303 → 274 steps/s — off.
+#ifndef NK_NT_BASIS
+#define NK_NT_BASIS 0
+#endif
+typedef double nk_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldv2(const double *col, int64_t i) {
+#if NK_NT_BASIS
+  const nk_d2v v = __builtin_nontemporal_load(reinterpret_cast<const nk_d2v *>(col) + i);
+  return make_double2(v.x, v.y);
+#else
+  return reinterpret_cast<const double2 *>(col)[i];
+#endif
+}
+
 #define SKIP_GUARD(d_skip) \
   if ((d_skip) != nullptr && *(d_skip) != 0) return;
 
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multidot(int64_t n, const double *
     const double2 wv = w2[i];
     double2 vv[NA];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) vv[j] = reinterpret_cast<const double2 *>(V + (size_t)(jbase + j) * ldv)[i];
+    for (int j = 0; j < NV; ++j) vv[j] = ldv2(V + (size_t)(jbase + j) * ldv, i);
     self += wv.x * wv.x + wv.y * wv.y;
 #pragma unroll
     for (int j = 0; j < NV; ++j) acc[j] += wv.x * vv[j].x + wv.y * vv[j].y;
@@ -197,10 +214,10 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
     double2 a = w2[i];
     int j = 0;
     for (; j + 4 <= nv; j += 4) {
-      const double2 v0 = reinterpret_cast<const double2 *>(V + (size_t)(j + 0) * ldv)[i];
-      const double2 v1 = reinterpret_cast<const double2 *>(V + (size_t)(j + 1) * ldv)[i];
-      const double2 v2 = reinterpret_cast<const double2 *>(V + (size_t)(j + 2) * ldv)[i];
-      const double2 v3 = reinterpret_cast<const double2 *>(V + (size_t)(j + 3) * ldv)[i];
+      const double2 v0 = ldv2(V + (size_t)(j + 0) * ldv, i);
+      const double2 v1 = ldv2(V + (size_t)(j + 1) * ldv, i);
+      const double2 v2 = ldv2(V + (size_t)(j + 2) * ldv, i);
+      const double2 v3 = ldv2(V + (size_t)(j + 3) * ldv, i);
       double c0 = sign * h[j], c1 = sign * h[j + 1], c2 = sign * h[j + 2], c3 = sign * h[j + 3];
       if (sc) { c0 *= sc[j]; c1 *= sc[j + 1]; c2 *= sc[j + 2]; c3 *= sc[j + 3]; }
       a.x += c0 * v0.x; a.y += c0 * v0.y;
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
       a.x += c3 * v3.x; a.y += c3 * v3.y;
     }
     for (; j < nv; ++j) {
-      const double2 v0 = reinterpret_cast<const double2 *>(V + (size_t)j * ldv)[i];
+      const double2 v0 = ldv2(V + (size_t)j * ldv, i);
       const double c0 = sign * h[j] * (sc ? sc[j] : 1.0);
       a.x += c0 * v0.x; a.y += c0 * v0.y;
     }
@@ -408,10 +425,10 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy_pr(int64_t n, const doub
     double2 a = w2[i];
     int j = 0;
     for (; j + 4 <= nv; j += 4) {
-      const double2 v0 = reinterpret_cast<const double2 *>(V + (size_t)(j + 0) * ldv)[i];
-      const double2 v1 = reinterpret_cast<const double2 *>(V + (size_t)(j + 1) * ldv)[i];
-      const double2 v2 = reinterpret_cast<const double2 *>(V + (size_t)(j + 2) * ldv)[i];
-      const double2 v3 = reinterpret_cast<const double2 *>(V + (size_t)(j + 3) * ldv)[i];
+      const double2 v0 = ldv2(V + (size_t)(j + 0) * ldv, i);
+      const double2 v1 = ldv2(V + (size_t)(j + 1) * ldv, i);
+      const double2 v2 = ldv2(V + (size_t)(j + 2) * ldv, i);
+      const double2 v3 = ldv2(V + (size_t)(j + 3) * ldv, i);
       const double c0 = coef[j], c1 = coef[j + 1], c2 = coef[j + 2], c3 = coef[j + 3];
       a.x -= c0 * v0.x; a.y -= c0 * v0.y;
       a.x -= c1 * v1.x; a.y -= c1 * v1.y;
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy_pr(int64_t n, const doub
       a.x -= c3 * v3.x; a.y -= c3 * v3.y;
     }
     for (; j < nv; ++j) {
-      const double2 v0 = reinterpret_cast<const double2 *>(V + (size_t)j * ldv)[i];
+      const double2 v0 = ldv2(V + (size_t)j * ldv, i);
       const double c0 = coef[j];
       a.x -= c0 * v0.x; a.y -= c0 * v0.y;
     }
