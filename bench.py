@@ -211,6 +211,7 @@ def main():
                "u_maxdiff_gpu_vs_cpu": float(np.max(np.abs(sol2.u.cpu().numpy() - uC))),
                "speedup": round(tc2 / tg, 1)}
 
+    line = None
     if rank == 0:
         line = {
             "metric": "newton_steps_per_sec", "value": round(value, 3),
@@ -229,6 +230,51 @@ def main():
             "check": {"fnorm_inf_after_timed_steps": fnorm, "gmres_iters": stats.gmres_iters,
                       "nsteps": stats.nsteps, "allreduces": stats.allreduces},
         }
+    # ---- N > 1 on the CSR operator: try the SpMV with its halo exchange overlapped with the interior row blocks
+    # (second stream + events, off by default in the library). The measurement above is complete and stays the
+    # result unless the overlapped variant, measured by the same protocol, is faster; a watchdog prints the result
+    # above and leaves if the attempt does not come back.
+    overlap = {"tried": False}
+    if world > 1 and not args.matfree and os.environ.get("NK_BENCH_OVERLAP", "auto") != "off":
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(timeout=float(os.environ.get("NK_BENCH_OVERLAP_TIMEOUT", "90"))):
+                if rank == 0:
+                    line["config"]["halo_overlap"] = "attempt timed out; serial exchange reported"
+                    print(json.dumps(line))
+                    sys.stdout.flush()
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            ctx.set_halo_overlap(True)
+            run_steps(args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            barrier()
+            dt2 = time.perf_counter() - t0
+            t2 = torch.tensor([dt2], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            dt2 = float(t2.item())
+            ok = math.isfinite(cache.fnorm_inf)
+            overlap = {"tried": True, "ms_per_step": round(1e3 * dt2 / args.steps, 4), "ok": bool(ok)}
+            if rank == 0:
+                line["config"]["halo_overlap"] = {"serial_ms_per_step": line["ms_per_step"],
+                                                  "overlapped_ms_per_step": overlap["ms_per_step"],
+                                                  "reported": "overlapped" if (ok and dt2 < dt) else "serial"}
+                if ok and dt2 < dt:
+                    sps = args.steps / dt2
+                    line["value"] = round(sps * units_per_step, 3)
+                    line["ms_per_step"] = overlap["ms_per_step"]
+                    line["config"]["global_newton_steps_per_sec"] = round(sps, 3)
+        except Exception as ex:  # noqa: BLE001
+            if rank == 0:
+                line["config"]["halo_overlap"] = f"attempt failed ({ex}); serial exchange reported"
+        finished.set()
+    if rank == 0:
         print(json.dumps(line))
     cache.close()
     if world > 1:

@@ -241,6 +241,9 @@ int nk_ctx_set_stream(nk_ctx *ctx, void *stream);
 int nk_ctx_synchronize(nk_ctx *ctx);
 /* deterministic=1 (default): fixed-order two-stage reductions, bitwise reproducible run to run. */
 int nk_ctx_set_deterministic(nk_ctx *ctx, int deterministic);
+/* Multi-rank CSR SpMV: run the halo exchange on a second stream while the row blocks that read no halo column are
+ * computed (off by default; also enabled by NK_HALO_OVERLAP=1 in the environment at context creation). */
+int nk_ctx_set_halo_overlap(nk_ctx *ctx, int on);
 
 /* Per-kernel-family timing (bench.py's roofline numbers). Off by default; when on, every launch of a profiled
  * family is issued with hipExtLaunchKernelGGL start/stop events, i.e. the kernel's own begin/end device

@@ -98,6 +98,7 @@ SIGNATURES = {
     "nk_ctx_destroy": (_I, [_P]),
     "nk_ctx_set_stream": (_I, [_P, _P]),
     "nk_ctx_synchronize": (_I, [_P]),
+    "nk_ctx_set_halo_overlap": (_I, [_P, _I]),
     "nk_ctx_set_deterministic": (_I, [_P, _I]),
     "nk_ctx_profile_enable": (_I, [_P, _I]),
     "nk_ctx_profile_kernel_count": (_I, []),

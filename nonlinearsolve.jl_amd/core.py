@@ -89,6 +89,10 @@ class Context:
     def set_deterministic(self, flag: bool = True):
         check(L.lib().nk_ctx_set_deterministic(self._h, int(bool(flag))))
 
+    def set_halo_overlap(self, flag: bool = True):
+        """Multi-rank CSR SpMV: halo exchange on a second stream, overlapped with the interior row blocks."""
+        check(L.lib().nk_ctx_set_halo_overlap(self._h, int(bool(flag))))
+
     # -- per-kernel-family HIP-event timing (bench.py roofline evidence)
     def profile_enable(self, on: bool = True):
         check(L.lib().nk_ctx_profile_enable(self._h, int(bool(on))))

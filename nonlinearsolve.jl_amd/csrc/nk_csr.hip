@@ -216,12 +216,26 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   NK_TRY(nk_dev_alloc(&A->d_val, (size_t)nnz + SPMV_TILE_MAX));
   NK_HIP(hipMemset(A->d_col + nnz, 0, SPMV_TILE_MAX * sizeof(int32_t)));
   NK_HIP(hipMemset(A->d_val + nnz, 0, SPMV_TILE_MAX * sizeof(double)));
+  // block descriptors, those that read no halo column first: with halo overlap the SpMV launches the two groups
+  // separately (interior while the exchange is in flight, boundary after it); on one rank every block is interior
   std::vector<int32_t> desc(4 * (size_t)A->nblocks);
-  for (int b = 0; b < A->nblocks; ++b) {
-    desc[4 * b + 0] = rb[b];
-    desc[4 * b + 1] = rb[b + 1];
-    desc[4 * b + 2] = rowptr[rb[b]];
-    desc[4 * b + 3] = rowptr[rb[b + 1]];
+  {
+    std::vector<int> order;
+    order.reserve(A->nblocks);
+    std::vector<char> touches(A->nblocks, 0);
+    for (int b = 0; b < A->nblocks; ++b)
+      for (int32_t k = rowptr[rb[b]]; k < rowptr[rb[b + 1]]; ++k)
+        if (A->h_col[k] >= nrows) { touches[b] = 1; break; }
+    for (int b = 0; b < A->nblocks; ++b) if (!touches[b]) order.push_back(b);
+    A->nblocks_interior = (int)order.size();
+    for (int b = 0; b < A->nblocks; ++b) if (touches[b]) order.push_back(b);
+    for (int i = 0; i < A->nblocks; ++i) {
+      const int b = order[i];
+      desc[4 * i + 0] = rb[b];
+      desc[4 * i + 1] = rb[b + 1];
+      desc[4 * i + 2] = rowptr[rb[b]];
+      desc[4 * i + 3] = rowptr[rb[b + 1]];
+    }
   }
   NK_TRY(nk_dev_alloc(&A->d_rowblocks, desc.size() + 4));
   NK_HIP(hipMemcpy(A->d_rowptr, rowptr.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -435,13 +449,16 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   nk_ctx *ctx = A->ctx;
   nk_spmv_epi ep{};
   if (epi) ep = *epi;
-  if (A->halo.active()) NK_TRY(nk_halo_exchange(ctx, &A->halo, d_x));
+  // halo overlap: interior row blocks run while the exchange is in flight on the communication stream
+  const bool overlap = A->halo.active() && ctx->halo_overlap && ctx->nranks > 1 && A->variant != 3 &&
+                       A->nblocks_interior > 0 && A->nblocks_interior < A->nblocks;
+  if (A->halo.active()) NK_TRY(overlap ? nk_halo_exchange_begin(ctx, &A->halo, d_x) : nk_halo_exchange(ctx, &A->halo, d_x));
   ctx->stats.op_applies++;
   nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
   if (A->nblocks > 0) {
 #define SPMV_LAUNCH(T, H, R)                                                                                      \
-  NK_LAUNCH(ctx, (k_spmv_stream<T, H, R>), dim3(A->nblocks), dim3(NK_BLOCK), A->nblocks,                          \
-            (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, \
+  NK_LAUNCH(ctx, (k_spmv_stream<T, H, R>), dim3(nb_), dim3(NK_BLOCK), nb_,                                         \
+            (const int4 *)A->d_rowblocks + b0_, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, \
             d_y, d_skip, d_out_scale, ep)
 #define SPMV_TILES(H, R)                                  \
   if (A->tile == 512) SPMV_LAUNCH(512, H, R);             \
@@ -453,10 +470,18 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
       const int grid = nk_grid_for(A->nrows, NK_BLOCK / 8, 1 << 20);
       NK_LAUNCH(ctx, k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col, A->d_val, d_x,
                 A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);
-    } else if (A->variant == 2) {
-      if (halo) { SPMV_TILES(true, false); } else { SPMV_TILES(false, false); }
     } else {
-      if (halo) { SPMV_TILES(true, true); } else { SPMV_TILES(false, true); }
+      const int nparts = overlap ? 2 : 1;
+      for (int part = 0; part < nparts; ++part) {
+        const int b0_ = (overlap && part == 1) ? A->nblocks_interior : 0;
+        const int nb_ = overlap ? (part == 0 ? A->nblocks_interior : A->nblocks - A->nblocks_interior) : A->nblocks;
+        if (overlap && part == 1) NK_TRY(nk_halo_exchange_end(ctx, &A->halo));
+        if (A->variant == 2) {
+          if (halo) { SPMV_TILES(true, false); } else { SPMV_TILES(false, false); }
+        } else {
+          if (halo) { SPMV_TILES(true, true); } else { SPMV_TILES(false, true); }
+        }
+      }
     }
 #undef SPMV_TILES
 #undef SPMV_LAUNCH

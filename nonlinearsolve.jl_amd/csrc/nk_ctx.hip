@@ -50,7 +50,23 @@ extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
   NK_TRY(nk_dev_alloc(&ctx->d_partials_ss, (size_t)NK_MAX_RED_BLOCKS));
   NK_TRY(nk_dev_alloc(&ctx->d_scal, (size_t)4 * NK_MAX_NV));
   NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV, hipHostMallocDefault));
+  const char *ov = getenv("NK_HALO_OVERLAP");
+  if (ov && atoi(ov) != 0) NK_TRY(nk_ctx_set_halo_overlap(ctx, 1));
   *out = ctx;
+  return NK_OK;
+}
+
+// Overlap of the SpMV's halo exchange with its interior rows: the exchange is enqueued on a second
+// stream between two events, so the compute stream only waits for it before the row blocks that read halo columns.
+extern "C" int nk_ctx_set_halo_overlap(nk_ctx *ctx, int on) {
+  NK_REQUIRE(ctx, "ctx is NULL");
+  NK_HIP(hipSetDevice(ctx->device));
+  if (on && !ctx->comm_stream) {
+    NK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    NK_HIP(hipEventCreateWithFlags(&ctx->ev_halo_ready, hipEventDisableTiming));
+    NK_HIP(hipEventCreateWithFlags(&ctx->ev_halo_done, hipEventDisableTiming));
+  }
+  ctx->halo_overlap = on ? 1 : 0;
   return NK_OK;
 }
 
@@ -64,6 +80,12 @@ extern "C" int nk_ctx_destroy(nk_ctx *ctx) {
   hipFree(ctx->d_partials_ss);
   hipFree(ctx->d_scal);
   hipHostFree(ctx->h_pinned);
+  if (ctx->comm_stream) {
+    hipStreamSynchronize(ctx->comm_stream);
+    hipStreamDestroy(ctx->comm_stream);
+    hipEventDestroy(ctx->ev_halo_ready);
+    hipEventDestroy(ctx->ev_halo_done);
+  }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return NK_OK;
@@ -290,22 +312,23 @@ int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op) {
 }
 
 int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
-                      void *recv, const int64_t *roff, const int64_t *rbytes) {
+                      void *recv, const int64_t *roff, const int64_t *rbytes, hipStream_t stream) {
   if (ctx->nranks <= 1) return NK_OK;
+  if (!stream) stream = ctx->stream;
   if (ctx->comm_kind == NK_COMM_RCCL) {
     NK_RCCL(R.GroupStart());
     for (int p = 0; p < ctx->nranks; ++p) {
       if (p == ctx->rank) continue;
       if (sbytes[p] > 0)
-        NK_RCCL(R.Send((const char *)send + soff[p], (size_t)sbytes[p], RCCL_INT8, p, ctx->rccl_comm, ctx->stream));
+        NK_RCCL(R.Send((const char *)send + soff[p], (size_t)sbytes[p], RCCL_INT8, p, ctx->rccl_comm, stream));
       if (rbytes[p] > 0)
-        NK_RCCL(R.Recv((char *)recv + roff[p], (size_t)rbytes[p], RCCL_INT8, p, ctx->rccl_comm, ctx->stream));
+        NK_RCCL(R.Recv((char *)recv + roff[p], (size_t)rbytes[p], RCCL_INT8, p, ctx->rccl_comm, stream));
     }
     NK_RCCL(R.GroupEnd());
     return NK_OK;
   }
   if (ctx->comm_kind == NK_COMM_CALLBACKS) {
-    if (ctx->cb.alltoallv(ctx->cb.user, send, soff, sbytes, recv, roff, rbytes, (void *)ctx->stream) != 0)
+    if (ctx->cb.alltoallv(ctx->cb.user, send, soff, sbytes, recv, roff, rbytes, (void *)stream) != 0)
       NK_FAIL(NK_E_CALLBACK, "alltoallv callback failed");
     return NK_OK;
   }
@@ -346,8 +369,8 @@ int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t
   return NK_OK;
 }
 
-int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
-  if (!H->active()) return NK_OK;
+// gather + (optionally on `xstream`) the exchange itself
+static int halo_exchange_on(nk_ctx *ctx, nk_halo *H, const double *d_x_local, hipStream_t xstream) {
   const int P = ctx->nranks;
   if (H->n_send) {
     int grid = (int)((H->n_send + NK_BLOCK - 1) / NK_BLOCK);
@@ -368,8 +391,27 @@ int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
       rb[p] = (p == ctx->rank) ? 0 : H->recv_cnt[p] * 8;
     }
     ctx->stats.halo_exchanges++;
-    NK_TRY(nk_comm_alltoallv(ctx, H->d_send, so.data(), sb.data(), H->d_recv, ro.data(), rb.data()));
+    if (xstream) {  // the exchange may start once the gather (and everything before it) is done
+      NK_HIP(hipEventRecord(ctx->ev_halo_ready, ctx->stream));
+      NK_HIP(hipStreamWaitEvent(xstream, ctx->ev_halo_ready, 0));
+    }
+    NK_TRY(nk_comm_alltoallv(ctx, H->d_send, so.data(), sb.data(), H->d_recv, ro.data(), rb.data(), xstream));
+    if (xstream) NK_HIP(hipEventRecord(ctx->ev_halo_done, xstream));
   }
+  return NK_OK;
+}
+
+int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
+  if (!H->active()) return NK_OK;
+  return halo_exchange_on(ctx, H, d_x_local, nullptr);
+}
+int nk_halo_exchange_begin(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
+  if (!H->active()) return NK_OK;
+  return halo_exchange_on(ctx, H, d_x_local, ctx->comm_stream);
+}
+int nk_halo_exchange_end(nk_ctx *ctx, nk_halo *H) {
+  if (!H->active() || ctx->nranks <= 1) return NK_OK;
+  NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done, 0));
   return NK_OK;
 }
 

@@ -61,6 +61,10 @@ struct nk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // halo exchange overlapped with the interior rows of the SpMV: the exchange runs on comm_stream, ordered by events
+  int halo_overlap = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;
   int deterministic = 1;
   int num_cus = 256;
   // communicator
@@ -101,7 +105,7 @@ struct nk_prof_scope {
   } while (0)
 int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op /*0 sum,1 max*/);
 int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
-                      void *recv, const int64_t *roff, const int64_t *rbytes);
+                      void *recv, const int64_t *roff, const int64_t *rbytes, hipStream_t stream = nullptr /* ctx->stream */);
 void nk_comm_destroy(nk_ctx *ctx);
 
 // optional row epilogue of the SpMV / JVP kernels: mode 1 fuses one Chebyshev-iteration vector update
@@ -123,6 +127,9 @@ struct nk_halo {
 int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
                   const std::vector<int64_t> &recv_cnt_per_peer);
 int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local);  // result in H->d_recv
+// split form: begin = gather on the compute stream + exchange on ctx->comm_stream; end = compute stream waits for it
+int nk_halo_exchange_begin(nk_ctx *ctx, nk_halo *H, const double *d_x_local);
+int nk_halo_exchange_end(nk_ctx *ctx, nk_halo *H);
 void nk_halo_free(nk_halo *H);
 
 // ----------------------------------------------------------------------------- CSR
@@ -133,6 +140,7 @@ struct nk_csr {
   double *d_val = nullptr;
   int32_t *d_rowblocks = nullptr;
   int nblocks = 0;
+  int nblocks_interior = 0;  // descriptors [0, nblocks_interior) touch no halo column (ordered first at creation)
   int tile = 2048, variant = 0;  // SpMV kernel configuration (tunable via NK_SPMV_TILE / NK_SPMV_VARIANT)
   nk_halo halo;
   std::vector<int64_t> halo_gcols;  // global column of each halo slot

@@ -78,6 +78,31 @@ def _worker(rank, world, port, q):
             assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
             assert sol.stats.allreduces > 0 and sol.stats.halo_exchanges > 0
 
+        # ---------------- halo exchange overlapped with the interior row blocks (second stream + events): a grid large
+        # enough to have both interior and boundary row blocks; every result is bitwise equal to the serial-exchange path
+        ns2 = 64
+        pb2, P2 = R.Bratu2D(ns2), nls.Bratu2D(ns2)
+        b2, e2 = P2.row_begin, P2.row_begin + P2.n_local
+        u2, v2 = 0.2 * rng.standard_normal(pb2.n), rng.standard_normal(pb2.n)
+        u2l, v2l = torch.tensor(u2[b2:e2], device=dev), torch.tensor(v2[b2:e2], device=dev)
+        J2 = P2.jac_csr()
+        P2.jac_values(u2l, J2)
+        rhs2 = torch.tensor(rng.standard_normal(pb2.n)[b2:e2], device=dev)
+        outs = []
+        for ov in (False, True):
+            ctx.set_halo_overlap(ov)
+            y = J2.matvec(v2l).clone()
+            G2 = nls.GMRES(e2 - b2, restart=30).set_operator(J2)
+            x2, gi2 = G2.solve(rhs2, reltol=1e-10, maxiters=2000)
+            prob2 = nls.NonlinearProblem(P2, u0=torch.zeros(e2 - b2, dtype=torch.float64, device=dev))
+            s2 = nls.solve(prob2, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=nls.EisenstatWalkerForcing2(),
+                                                    concrete_jac=True), abstol=1e-9, maxiters=50)
+            outs.append((y, x2.clone(), gi2["iters"], s2.u.clone(), s2.stats.nsteps, s2.stats.gmres_iters))
+        ctx.set_halo_overlap(False)
+        assert np.allclose(outs[0][0].cpu().numpy(), (pb2.jac(u2) @ v2)[b2:e2], rtol=1e-13, atol=1e-10)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+        assert torch.equal(outs[0][3], outs[1][3]) and outs[0][4:] == outs[1][4:]
+
         # ---------------- Brusselator: periodic halo (with 2 ranks the same peer is both neighbours)
         N = 10
         rb_ = R.Brusselator2D(N)
