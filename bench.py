@@ -8,8 +8,8 @@
 Workload (config C3 of BASELINE.md, the configuration the metric is quoted on): 2-D Bratu n = 1024²
 (N = 1 048 576 unknowns, nnz = 5 238 784, λ = 6, u0 = 0), NewtonRaphson with the *fixed-work* Krylov protocol
 of SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step, zero initial guess, CGS2
-orthogonalisation — on the assembled CSR Jacobian (values refilled every step, SpMV as the operator).
-A "step" is one such Newton step: Jacobian value fill + 30×(SpMV + CGS2 pass) + solution update + u += δu +
+orthogonalisation (in its delayed form `dcgs2`: same arithmetic to rounding, 2 sweeps over the basis per step) — on the assembled CSR Jacobian (values refilled every step, SpMV as the operator).
+A "step" is one such Newton step: Jacobian value fill + 30×(SpMV + CGS2 passes) + solution update + u += δu +
 residual + ‖·‖∞ + termination bookkeeping, everything resident in HBM.
 N > 1: weak scaling — every rank owns ≈1024² unknowns of a (1024·√N)² grid (row-range partition by grid
 lines, halo lines by RCCL send/recv, Krylov inner products by RCCL all-reduce). `value` is the whole-job
@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", dest="n", type=int, default=1024, help="grid side per GPU-equivalent (1024 ⇒ N = 1e6)")
-    ap.add_argument("--ortho", default="cgs2", choices=["cgs2", "cgs", "mgs"])
+    ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "cgs", "mgs"])
     ap.add_argument("--arnoldi", type=int, default=30)
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
     ap.add_argument("--cpu-steps", type=int, default=12, help="Newton steps of the CPU baseline sample (0 = skip)")

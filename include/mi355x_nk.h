@@ -85,7 +85,10 @@ typedef enum {
 typedef enum {
   NK_ORTHO_MGS = 0,  /* modified Gram–Schmidt: the structure Krylov.jl's gmres uses [EXT]            */
   NK_ORTHO_CGS2 = 1, /* classical GS, always re-orthogonalised (2 fused passes)                       */
-  NK_ORTHO_CGS = 2   /* classical GS, re-orthogonalise only when ‖w'‖ < ‖w‖/√2 (DGKS)                 */
+  NK_ORTHO_CGS = 2,  /* classical GS, re-orthogonalise only when ‖w'‖ < ‖w‖/√2 (DGKS)                 */
+  NK_ORTHO_DCGS2 = 3 /* CGS2 with the second correction applied one step late, fused into the next step's
+                      * first pass (2 passes over the basis per step instead of 3); the default. restart > 31
+                      * silently uses NK_ORTHO_CGS2                                                      */
 } nk_ortho;
 
 typedef enum { NK_FORCING_NONE = 0, NK_FORCING_EISENSTAT_WALKER2 = 1 } nk_forcing;

@@ -90,7 +90,7 @@ end
 
 # ------------------------------------------------------------------ seam 1: linsolve backend
 """
-    MI355XGMRES(; gmres_restart = 30, ortho = :cgs2)
+    MI355XGMRES(; gmres_restart = 30, ortho = :dcgs2)
 
 `NewtonRaphson(linsolve = MI355XGMRES())`. NonlinearSolveBase only needs what
 ext/NonlinearSolveBaseLinearSolveExt.jl:16-32,60-115 uses: `needs_concrete_A == false`, a cache with settable
@@ -98,7 +98,7 @@ ext/NonlinearSolveBaseLinearSolveExt.jl:16-32,60-115 uses: `needs_concrete_A == 
 """
 Base.@kwdef struct MI355XGMRES <: LinearSolve.AbstractKrylovSubspaceMethod   # [EXT]
     gmres_restart::Int = 30
-    ortho::Symbol = :cgs2
+    ortho::Symbol = :dcgs2
 end
 LinearSolve.needs_concrete_A(::MI355XGMRES) = false                           # [EXT]
 
@@ -107,7 +107,7 @@ mutable struct GMRESWorkspace
     n::Int
     csr::Union{Nothing, DeviceCSR}
 end
-const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2)
+const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2, :dcgs2 => 3)
 
 function LinearSolve.init_cacheval(alg::MI355XGMRES, A, b, u, Pl, Pr, maxiters::Int, abstol, reltol,
         verbose, assumptions)                                                  # [EXT signature]
@@ -179,7 +179,7 @@ end
 Base.@kwdef mutable struct NKOptions
     algorithm::Int32 = 0; linsolve::Int32 = 0; maxiters::Int32 = 1000; termination_norm::Int32 = 0
     abstol::Float64 = 0.0; reltol::Float64 = 0.0; maxtime::Float64 = 0.0
-    gmres_restart::Int32 = 30; gmres_maxiters::Int32 = 300; gmres_ortho::Int32 = 1; gmres_fixed_iters::Int32 = 0
+    gmres_restart::Int32 = 30; gmres_maxiters::Int32 = 300; gmres_ortho::Int32 = 3; gmres_fixed_iters::Int32 = 0
     lin_abstol::Float64 = -1.0; lin_reltol::Float64 = -1.0
     forcing::Int32 = 0; ew_safeguard::Int32 = 1
     ew_eta0::Float64 = 0.5; ew_eta_max::Float64 = 0.9; ew_gamma::Float64 = 0.9; ew_alpha::Float64 = 2.0

@@ -500,7 +500,7 @@ class KrylovJL_GMRES:
     """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
     gmres_restart: int = 30
     maxiters: int = 300
-    ortho: str = "cgs2"        # "mgs" (Krylov.jl's structure) | "cgs2" | "cgs"
+    ortho: str = "dcgs2"       # "mgs" (Krylov.jl's structure) | "cgs2" | "dcgs2" (= cgs2, delayed 2nd pass) | "cgs"
     fixed_iters: int = 0
     abstol: Optional[float] = None   # None → the nonlinear tolerances are forwarded (FirstOrder/src/solve.jl:203)
     reltol: Optional[float] = None
@@ -611,7 +611,7 @@ TERMINATION_CONDITIONS = [  # common/common_rootfind_testing.jl:3-13
     AbsNormSafeBestTerminationMode,
 ]
 
-_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS}
+_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2": L.ORTHO_DCGS2}
 
 
 def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,
@@ -828,7 +828,7 @@ def reinit_(cache: FirstOrderCache, u0=None, p=None):  # reinit!(cache, u0; p)
 class GMRES:
     """nk_gmres: the LinearCache analogue NonlinearSolveBase drives (A, b, u, reltol; solve!)."""
 
-    def __init__(self, n: int, restart: int = 30, ortho: str = "cgs2", ctx: Optional[Context] = None):
+    def __init__(self, n: int, restart: int = 30, ortho: str = "dcgs2", ctx: Optional[Context] = None):
         self.ctx = ctx or default_context()
         h = C.c_void_p()
         check(L.lib().nk_gmres_create(self.ctx._h, n, restart, _ORTHO[ortho], C.byref(h)))

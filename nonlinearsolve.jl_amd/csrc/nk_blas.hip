@@ -314,6 +314,79 @@ __global__ __launch_bounds__(NK_BLOCK) void k_fused_axpy_dot(int64_t n, const do
   if (threadIdx.x == 0) partials[(size_t)NV * gridDim.x + blockIdx.x] = s;
 }
 
+// DCGS2 pass A (see nk_gmres.hip): NV final columns ṽ_0..ṽ_{NV−1}, the pending column p = V[:,NV] (first projection
+// of the previous step, not yet re-orthogonalised) and z = V[:,NV+1] = s·A p. Per element, in one sweep over the basis:
+//   p ← p − Σ a_j ṽ_j                (the delayed second Gram–Schmidt correction of the previous step)
+//   z ← z − Σ b_j ṽ_j − b_NV p       (= A v_NV by linearity and the Arnoldi relation A V = V H̄)
+//   g_j = ṽ_j·z (j < NV), g_NV = p·z  (first projection of the new vector, over the corrected basis)
+template <int NV>
+__global__ __launch_bounds__(NK_BLOCK) void k_dcgs2_pass_a(int64_t n, double *__restrict__ V, int64_t ldv,
+                                                           const double *__restrict__ ca_g, const double *__restrict__ cb_g,
+                                                           double *__restrict__ partials, const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  __shared__ double sm[4 * (NV + 1) + 4];
+  __shared__ double ca[NV + 1], cb[NV + 1];
+  if (threadIdx.x < NV) ca[threadIdx.x] = ca_g[threadIdx.x];
+  if (threadIdx.x <= NV) cb[threadIdx.x] = cb_g[threadIdx.x];
+  __syncthreads();
+  double acc[NV + 1];
+#pragma unroll
+  for (int j = 0; j <= NV; ++j) acc[j] = 0.0;
+  double *__restrict__ pk = V + (size_t)NV * ldv;
+  double *__restrict__ zk = V + (size_t)(NV + 1) * ldv;
+  const unsigned stride = gridDim.x * NK_BLOCK, nn = (unsigned)n;
+  for (unsigned i = blockIdx.x * NK_BLOCK + threadIdx.x; i < nn; i += stride) {
+    double vv[NV];
+    double pv = pk[i], zv = zk[i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const double *__restrict__ col = V + (size_t)j * ldv;
+      vv[j] = col[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      pv -= ca[j] * vv[j];
+      zv -= cb[j] * vv[j];
+    }
+    zv -= cb[NV] * pv;
+    pk[i] = pv;
+    zk[i] = zv;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += vv[j] * zv;
+    acc[NV] += pv * zv;
+  }
+  block_sum_array_store<NV + 1>(acc, NV + 1, sm, partials, 0);
+}
+
+int nk_blas_dcgs2_pass_a(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
+                         const double *d_scales, double *d_h, const int *d_skip) {
+  NK_REQUIRE(k >= 1 && k <= 31, "DCGS2 pass A handles 1..31 final columns (got %d)", k);
+  NK_REQUIRE(n < (1ll << 31), "fused pass: local vector too long for 32-bit offsets");
+  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_DOT_BLOCKS);
+  {
+    nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + 4));
+#define PA_LAUNCH(N) NK_LAUNCH(ctx, k_dcgs2_pass_a<N>, dim3(grid), dim3(NK_BLOCK), n, V, ldv, d_a, d_b, ctx->d_partials, d_skip)
+    if (k <= 16) {
+      NK_SWITCH_1_16(k, PA_LAUNCH)
+    } else {
+      switch (k) {
+        case 17: PA_LAUNCH(17); break; case 18: PA_LAUNCH(18); break; case 19: PA_LAUNCH(19); break;
+        case 20: PA_LAUNCH(20); break; case 21: PA_LAUNCH(21); break; case 22: PA_LAUNCH(22); break;
+        case 23: PA_LAUNCH(23); break; case 24: PA_LAUNCH(24); break; case 25: PA_LAUNCH(25); break;
+        case 26: PA_LAUNCH(26); break; case 27: PA_LAUNCH(27); break; case 28: PA_LAUNCH(28); break;
+        case 29: PA_LAUNCH(29); break; case 30: PA_LAUNCH(30); break; default: PA_LAUNCH(31); break;
+      }
+    }
+#undef PA_LAUNCH
+  }
+  {
+    nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (k + 1) * grid);
+    NK_LAUNCH(ctx, k_reduce_sum, dim3(k + 1), dim3(NK_BLOCK), ctx->d_partials, grid, d_h, d_skip, d_scales, k + 1);
+  }
+  NK_HIP(hipGetLastError());
+  return nk_comm_allreduce(ctx, d_h, k + 1, 0);
+}
+
 // d_h2[0..nv) = s_j·(ṽ_j·w_new) and d_h2[nv] = ‖w_new‖² (both all-reduced). Requires nv ≤ 32.
 int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                            const double *d_scales, double *w, double *d_h2, const int *d_skip) {

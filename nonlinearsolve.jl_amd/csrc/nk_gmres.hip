@@ -65,11 +65,32 @@ __global__ void k_dgks(nk_gmres_ctl *ctl, const double *h, double *h2, double *d
   }
 }
 
+// DCGS2, start of step k ≥ 1: r = h2 of step k−1 (the pending re-orthogonalisation of column k), c = H̄_{k−1} r.
+//   a_j = r_j s_j (j < k)                      : ṽ_k ← p − Σ a_j ṽ_j
+//   b_j = s_k c_j s_j (j < k), b_k = s_k² c_k  : A v_k = s_k A p − s_k Σ_{j≤k} c_j v_j   (v_j = s_j ṽ_j)
+__global__ __launch_bounds__(64) void k_dcgs2_coef(const nk_gmres_ctl *ctl, int k, const double *__restrict__ Hraw, int m,
+                                                   const double *__restrict__ r, const double *__restrict__ s,
+                                                   double *__restrict__ a, double *__restrict__ b) {
+  if (ctl->done) return;
+  __shared__ double sr[NK_MAX_NV];
+  const int t = threadIdx.x;
+  if (t < k) sr[t] = r[t];
+  __syncthreads();
+  const double sk = s[k];
+  if (t <= k) {
+    double c = 0.0;
+    for (int j = (t > 0 ? t - 1 : 0); j < k; ++j) c += Hraw[(size_t)t * m + j] * sr[j];  // H is upper Hessenberg
+    b[t] = sk * c * s[t];
+    if (t < k) a[t] = sr[t] * s[t];
+  }
+}
+
 // new Hessenberg column → apply old rotations, create the new one, update g and the residual estimate
 // ss_partials != nullptr (single rank): ‖w‖² arrives as nblk per-block partials and is reduced here, saving a launch
 __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, const double *h2, const double *d_ss,
                                                double *R, double *cs, double *sn, double *g, double *s, int m,
-                                               const double *__restrict__ ss_partials, int nblk, int pythag) {
+                                               const double *__restrict__ ss_partials, int nblk, int pythag,
+                                               double *__restrict__ Hraw) {
   if (ctl->done) return;
   __shared__ double sh[NK_MAX_NV + 2], sc[NK_MAX_NV + 2], ss_[NK_MAX_NV + 2];
   const int k = ctl->k, t = threadIdx.x;
@@ -97,6 +118,10 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
   }
   if (ssq < 0.0) ssq = 0.0;
   const double hn = sqrt(ssq);
+  if (Hraw) {  // DCGS2 keeps the un-rotated Hessenberg column ((m+1) × m, row-major) for the Arnoldi-relation update
+    for (int i = 0; i <= k; ++i) Hraw[(size_t)i * m + k] = sh[i];
+    Hraw[(size_t)(k + 1) * m + k] = hn;
+  }
   double hk = sh[0];
   for (int i = 0; i < k; ++i) {  // rotation i acts on (h[i], h[i+1])
     const double a = hk, b = sh[i + 1];
@@ -156,7 +181,9 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_REQUIRE(n_local >= 0, "negative size");
   if (restart_m <= 0) restart_m = 30;
   NK_REQUIRE(restart_m < NK_MAX_NV, "restart m=%d too large (max %d)", restart_m, NK_MAX_NV - 1);
-  NK_REQUIRE(ortho == NK_ORTHO_MGS || ortho == NK_ORTHO_CGS2 || ortho == NK_ORTHO_CGS, "bad ortho %d", ortho);
+  NK_REQUIRE(ortho == NK_ORTHO_MGS || ortho == NK_ORTHO_CGS2 || ortho == NK_ORTHO_CGS || ortho == NK_ORTHO_DCGS2,
+             "bad ortho %d", ortho);
+  if (ortho == NK_ORTHO_DCGS2 && restart_m > 31) ortho = NK_ORTHO_CGS2;  // the fused sweeps hold ≤ 32 columns in registers
   NK_HIP(hipSetDevice(ctx->device));
   nk_gmres *G = new nk_gmres();
   G->ctx = ctx;
@@ -176,6 +203,9 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_TRY(nk_dev_alloc(&G->r, (size_t)G->ldv));
   NK_TRY(nk_dev_alloc(&G->d_h, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_h2, (size_t)NK_MAX_NV + 2));
+  NK_TRY(nk_dev_alloc(&G->d_Hraw, (size_t)(NK_MAX_NV + 1) * NK_MAX_NV));
+  NK_TRY(nk_dev_alloc(&G->d_ca, (size_t)NK_MAX_NV + 2));
+  NK_TRY(nk_dev_alloc(&G->d_cb, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_s, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_R, (size_t)m * m));
   NK_TRY(nk_dev_alloc(&G->d_cs, (size_t)m + 1));
@@ -194,6 +224,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
 extern "C" int nk_gmres_destroy(nk_gmres *G) {
   if (!G) return NK_OK;
   hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
+  hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb);
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
@@ -498,14 +529,30 @@ static int arnoldi_step(nk_gmres *G, int k) {
   const int nv = k + 1;
   double *wk = G->V + (size_t)(k + 1) * ldv;  // the new (un-normalised) column is built in place
   NK_TRY(op_apply(G, G->V + (size_t)k * ldv, wk, skip, G->d_s + k));
-  if (G->ortho == NK_ORTHO_MGS) {
+  if (G->ortho == NK_ORTHO_DCGS2) {
+    // CGS2 with delayed re-orthogonalisation: column k holds p (first projection only) when k ≥ 1; the operator above
+    // was applied to it. Pass A applies the pending correction to column k, rebuilds A v_k from A p through the Arnoldi
+    // relation and takes the first projection of the new vector — one sweep over the basis; pass B is the usual fused
+    // axpy + second projection, whose correction stays pending. ‖w″‖ comes from Pythagoras in k_givens. Two sweeps and
+    // two reductions per step instead of three (oracle/reference_restatement.py::gmres(ortho="dcgs2")).
+    if (k == 0) {
+      NK_TRY(nk_blas_multidot(ctx, n, 1, G->V, ldv, wk, G->d_h, false, skip, G->d_s));
+    } else {
+      NK_LAUNCH(ctx, k_dcgs2_coef, dim3(1), dim3(64), (const nk_gmres_ctl *)G->d_ctl, k, (const double *)G->d_Hraw, G->m,
+                (const double *)G->d_h2, (const double *)G->d_s, G->d_ca, G->d_cb);
+      NK_TRY(nk_blas_dcgs2_pass_a(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, G->d_s, G->d_h, skip));
+    }
+    NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, G->d_h2, skip));
+    NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
+              G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 1, G->d_Hraw);
+  } else if (G->ortho == NK_ORTHO_MGS) {
     for (int i = 0; i <= k; ++i) {  // h_i = v_i·w ; w -= h_i v_i ; the last axpy also yields ‖w‖²
       NK_TRY(nk_blas_multidot(ctx, n, 1, G->V + (size_t)i * ldv, ldv, wk, G->d_h + i, false, skip, G->d_s + i));
       NK_TRY(nk_blas_multiaxpy(ctx, n, 1, G->V + (size_t)i * ldv, ldv, G->d_h + i, -1.0, wk,
                                i == k ? G->d_ss : nullptr, skip, nullptr, G->d_s + i));
     }
     NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)nullptr, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 0);
+                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 0, (double *)nullptr);
   } else {
     const bool dgks = (G->ortho == NK_ORTHO_CGS);
     const int *skip2 = dgks ? &G->d_ctl->pad0 : skip;
@@ -518,7 +565,7 @@ static int arnoldi_step(nk_gmres *G, int k) {
       NK_TRY(nk_blas_cgs2_passes_pr(ctx, n, nv, G->V, ldv, G->d_s, wk, G->d_h, G->d_h2, skip));
       NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2,
                          G->d_ss, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)ctx->d_partials_ss,
-                         ctx->last_red_grid, 0);
+                         ctx->last_red_grid, 0, (double *)nullptr);
       NK_HIP(hipGetLastError());
       return NK_OK;
     }
@@ -543,7 +590,7 @@ static int arnoldi_step(nk_gmres *G, int k) {
     NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, ss_dst, skip2, nullptr, G->d_s));
     NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
               G->d_sn, G->d_g, G->d_s, G->m, fold ? (const double *)ctx->d_partials_ss : (const double *)nullptr,
-              fold ? ctx->last_red_grid : 0, pythag ? 1 : 0);
+              fold ? ctx->last_red_grid : 0, pythag ? 1 : 0, (double *)nullptr);
   }
   NK_HIP(hipGetLastError());
   return NK_OK;

@@ -212,6 +212,10 @@ int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t l
 int nk_blas_cgs2_passes_pr(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_scales,
                            double *w, double *d_h1_out, double *d_h2_out, const int *d_skip);
 #define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
+// DCGS2 pass A: correct the pending column V[:,k] by −Σ a_j ṽ_j, turn V[:,k+1] (= s_k·A·pending) into the true next
+// vector by −Σ b_j ṽ_j − b_k·corrected, and return d_h[0..k] = s_j·(ṽ_j·w) over the corrected basis
+int nk_blas_dcgs2_pass_a(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
+                         const double *d_scales, double *d_h, const int *d_skip);
 int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                            const double *d_scales, double *w, double *d_h2, const int *d_skip);
 int nk_blas_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y);  // y = a x + b y
@@ -234,6 +238,7 @@ struct nk_gmres {
   int64_t n = 0, ldv = 0;
   int m = 30, ortho = NK_ORTHO_CGS2;
   double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
+  double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
          *d_g = nullptr, *d_y = nullptr, *d_ss = nullptr;
   double *d_s = nullptr;  // s_j: the basis is stored un-normalised, v_j = s_j ṽ_j (lagged normalisation)

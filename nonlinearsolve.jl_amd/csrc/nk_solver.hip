@@ -155,7 +155,7 @@ extern "C" int nk_options_default(nk_options *o) {
   o->maxtime = 0.0;
   o->gmres_restart = 30;
   o->gmres_maxiters = 300;
-  o->gmres_ortho = NK_ORTHO_CGS2;
+  o->gmres_ortho = NK_ORTHO_DCGS2;  // CGS2 arithmetic, one sweep over the basis less per step (CGS2 itself if restart > 31)
   o->gmres_fixed_iters = 0;
   o->lin_abstol = -1.0;
   o->lin_reltol = -1.0;

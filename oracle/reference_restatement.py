@@ -335,10 +335,29 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
         g[0] = beta
         k = 0
         done = False
+        Hraw = np.zeros((m + 1, m))   # un-rotated Hessenberg (dcgs2 only)
+        pend_r, pend_beta = None, 1.0
         while k < m and info.iters < cap:
             w = matvec(V[k])
             h = np.zeros(k + 2)
-            if ortho == "mgs":
+            if ortho == "dcgs2":
+                # CGS2 whose second correction is applied one step late (the device's NK_ORTHO_DCGS2): V[k] holds the
+                # once-projected p when k ≥ 1 and `w` above is A p. Finish v_k = (p − V r)/β, rebuild A v_k from A p
+                # through the Arnoldi relation A V = V H̄, then do the first projection, the second projection's
+                # coefficients (its application stays pending) and ‖w″‖ by Pythagoras.
+                if k > 0:
+                    c = Hraw[: k + 1, :k] @ pend_r
+                    V[k] = (V[k] - V[:k].T @ pend_r) / pend_beta
+                    w = (w - V[: k + 1].T @ c) / pend_beta
+                hh = ar(V[: k + 1] @ w)
+                w = w - V[: k + 1].T @ hh
+                h2 = ar(V[: k + 1] @ w)
+                ss = float(ar(np.dot(w, w)))
+                h[: k + 1] = hh + h2
+                Hraw[: k + 1, k] = h[: k + 1]
+                pend_r, pend_beta = h2, math.sqrt(max(ss - float(h2 @ h2), 0.0))
+                Hraw[k + 1, k] = pend_beta
+            elif ortho == "mgs":
                 for i in range(k + 1):
                     h[i] = float(ar(np.dot(V[i], w)))
                     w = w - h[i] * V[i]
@@ -348,7 +367,7 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
                 h2 = ar(V[: k + 1] @ w)
                 w = w - V[: k + 1].T @ h2
                 h[: k + 1] = hh + h2
-            hn = math.sqrt(float(ar(np.dot(w, w))))
+            hn = pend_beta if ortho == "dcgs2" else math.sqrt(float(ar(np.dot(w, w))))
             h[k + 1] = hn
             for i in range(k):  # apply previous rotations
                 t = cs[i] * h[i] + sn[i] * h[i + 1]
@@ -379,7 +398,7 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
                 info.converged = True
                 done = True
                 break
-            V[k] = w / hn
+            V[k] = w if ortho == "dcgs2" else w / hn   # dcgs2: un-normalised, un-corrected until the next step
         if k > 0 and not info.failed:
             y = np.linalg.solve(np.triu(R[:k, :k]), g[:k]) if k > 1 else np.array([g[0] / R[0, 0]])
             x = x + V[:k].T @ y

@@ -59,7 +59,7 @@ def _worker(rank, world, port, q):
         # distributed GMRES on the CSR operator vs the serial oracle
         rhs = rng.standard_normal(pb.n)
         xref, iref = R.gmres(lambda z: pb.jac(u) @ z, rhs, rtol=1e-9, restart=30, itmax=3000)
-        for ortho in ("cgs2", "mgs", "cgs"):
+        for ortho in ("cgs2", "mgs", "cgs", "dcgs2"):
             G = nls.GMRES(e - b, restart=30, ortho=ortho).set_operator(J)
             x, gi = G.solve(torch.tensor(rhs[b:e], device=dev), reltol=1e-9, maxiters=3000)
             xg = nls.dist.gather_vector(x, pb.n, b)

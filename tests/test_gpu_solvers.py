@@ -16,7 +16,7 @@ def uerr(u, uref):
     return float(np.max(np.abs(np.asarray(u) - uref)) / max(1.0, np.max(np.abs(uref))))
 
 
-@pytest.mark.parametrize("ortho", ["mgs", "cgs2", "cgs"])
+@pytest.mark.parametrize("ortho", ["mgs", "cgs2", "cgs", "dcgs2"])
 @pytest.mark.parametrize("ns,rtol", [(16, 1e-10), (48, 1e-6)])
 def test_gmres_csr_vs_oracle(nls, ns, rtol, ortho):
     p = R.Bratu2D(ns)
@@ -46,6 +46,31 @@ def test_gmres_first_cycle_matches_oracle_mgs(nls):
         assert info["iters"] == k == iref.iters
         assert abs(info["rnorm"] - iref.rnorm) <= 1e-10 * iref.rnorm0
         assert np.linalg.norm(x - xref) <= 1e-9 * np.linalg.norm(xref)
+
+
+def test_gmres_dcgs2_follows_the_oracle_restatement(nls):
+    """CGS2 with delayed re-orthogonalisation (2 sweeps over the basis per step): recurrence residuals and iterates agree
+    with the oracle's restatement of the same scheme — and hence with CGS2 — to rounding, across restarts, with the
+    Chebyshev right preconditioner, and at early termination inside a cycle."""
+    p = R.Bratu2D(24)
+    J = p.jac(0.1 * np.random.default_rng(5).standard_normal(p.n))
+    b = np.random.default_rng(2).standard_normal(p.n)
+    A = nls.CSRMatrix.from_scipy(J)
+    for k in (1, 2, 5, 30, 31, 45, 90):
+        xref, iref = R.gmres(lambda z: J @ z, b, restart=30, fixed_iters=k, ortho="dcgs2")
+        xc, ic = R.gmres(lambda z: J @ z, b, restart=30, fixed_iters=k, ortho="cgs2")
+        x, info = nls.GMRES(p.n, restart=30, ortho="dcgs2").set_operator(A).solve(b, fixed_iters=k)
+        assert info["iters"] == k == iref.iters
+        assert abs(info["rnorm"] - iref.rnorm) <= 1e-10 * iref.rnorm0 and abs(iref.rnorm - ic.rnorm) <= 1e-10 * ic.rnorm0
+        assert np.linalg.norm(x - xref) <= 1e-9 * np.linalg.norm(xref)
+    G = nls.GMRES(p.n, restart=30, ortho="dcgs2").set_operator(A)
+    G.set_chebyshev_preconditioner(8, ratio=30.0)
+    x, info = G.solve(b, abstol=0.0, reltol=1e-10, maxiters=2000)
+    G2 = nls.GMRES(p.n, restart=30, ortho="cgs2").set_operator(A)
+    G2.set_chebyshev_preconditioner(8, ratio=30.0)
+    x2, info2 = G2.solve(b, abstol=0.0, reltol=1e-10, maxiters=2000)
+    assert info["converged"] and info["iters"] == info2["iters"]
+    assert np.linalg.norm(J @ x - b) <= 1.01e-10 * np.linalg.norm(b) and np.linalg.norm(x - x2) <= 1e-9 * np.linalg.norm(x2)
 
 
 def test_gmres_matrix_free_and_callable_operator(nls, dev):
@@ -106,7 +131,7 @@ def test_quadratic_newton_gmres(nls):
 
 
 @pytest.mark.parametrize("concrete", [False, True])
-@pytest.mark.parametrize("ortho", ["mgs", "cgs2"])
+@pytest.mark.parametrize("ortho", ["mgs", "cgs2", "dcgs2"])
 def test_bratu_newton_ew_vs_oracle(nls, concrete, ortho):
     ns = 48
     prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
