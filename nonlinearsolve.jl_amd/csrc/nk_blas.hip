@@ -412,6 +412,11 @@ int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int6
     }
 #undef FU_LAUNCH
   }
+  ctx->last_red_grid = grid;
+  if (d_h2 == NK_SUMSQ_PARTIALS_ONLY) {  // single rank: the consumer (k_givens_dcgs2) reduces ctx->d_partials itself
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
   {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (nv + 1) * grid);
     NK_LAUNCH(ctx, k_reduce_sum, dim3(nv + 1), dim3(NK_BLOCK), ctx->d_partials, grid, d_h2, d_skip,

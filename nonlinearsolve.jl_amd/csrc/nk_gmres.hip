@@ -85,6 +85,105 @@ __global__ __launch_bounds__(64) void k_dcgs2_coef(const nk_gmres_ctl *ctl, int 
   }
 }
 
+// Single-rank DCGS2 tail of an Arnoldi step in ONE launch (1024 threads): (1) reduce pass B's per-block partials —
+// 32 lanes per slot, fixed order — into h2[0..k] (scaled by s_j) and ‖w′‖²; (2) Hessenberg column h1 + h2, ‖w″‖ by
+// Pythagoras, Givens update, convergence flags (as k_givens); (3) the pass-A coefficients of the NEXT step
+// (a_j = h2_j s_j, b = s_{k+1}·(H̄ h2)·s). Replaces k_reduce_sum + k_givens + k_dcgs2_coef.
+__global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const double *__restrict__ h1,
+                                                       const double *__restrict__ partials, int nblk, double *R,
+                                                       double *cs, double *sn, double *g, double *s, int m,
+                                                       double *__restrict__ Hraw, double *__restrict__ a_out,
+                                                       double *__restrict__ b_out, double *__restrict__ h2_out) {
+  if (ctl->done) return;
+  constexpr int LH = NK_MAX_NV + 1;
+  __shared__ double sh[NK_MAX_NV + 2], sh2[NK_MAX_NV + 2], sc[NK_MAX_NV + 2], ss_[NK_MAX_NV + 2], ssc[NK_MAX_NV + 2];
+  __shared__ double sH[(NK_MAX_NV / 2 + 2) * LH];  // H̄ rows 0..k+1, columns 0..k (restart ≤ 31 ⇒ 33 × 32 entries)
+  __shared__ double s_next, s_gk, s_tol;
+  const int k = ctl->k, t = threadIdx.x;
+  const int nslots = k + 2;  // k+1 inner products and ‖w′‖²
+  // every global read of the kernel is issued here, in one round trip: partials, h1, rotations, scales, g_k, H̄
+  const int slot = t >> 5, lane = t & 31;
+  double v = 0.0;
+  if (slot < nslots) {
+    const double *p = partials + (size_t)slot * nblk;
+    if ((nblk & 1) == 0) {  // 16-byte loads (the slot base stays 16-byte aligned when nblk is even)
+      const double2 *p2 = reinterpret_cast<const double2 *>(p);
+      double v1 = 0.0;
+      for (int i = lane; i < (nblk >> 1); i += 32) { const double2 q = p2[i]; v += q.x; v1 += q.y; }
+      v += v1;
+    } else {
+      for (int i = lane; i < nblk; i += 32) v += p[i];
+    }
+  }
+  if (t <= k) {
+    sh[t] = h1[t];
+    ssc[t] = s[t];
+    if (t < k) { sc[t] = cs[t]; ss_[t] = sn[t]; }
+  }
+  if (t == 0) { s_gk = g[k]; s_tol = ctl->tol; }
+  for (int e = t; e < (k + 2) * k; e += 1024) {  // previous columns j < k of H̄ (upper Hessenberg: zero below the subdiagonal)
+    const int i = e / k, j = e - i * k;
+    sH[i * LH + j] = (i <= j + 1) ? Hraw[(size_t)i * m + j] : 0.0;
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0 && slot < nslots) sh2[slot] = (slot <= k) ? v * ssc[slot] : v;
+  __syncthreads();
+  if (t <= k) {
+    const double hv = sh[t] + sh2[t];
+    sh[t] = hv;
+    sH[t * LH + k] = hv;
+    Hraw[(size_t)t * m + k] = hv;
+    h2_out[t] = sh2[t];
+  }
+  __syncthreads();
+  if (t == 0) {
+    double s2 = 0.0;
+    for (int i = 0; i <= k; ++i) s2 += sh2[i] * sh2[i];
+    double ssq = sh2[k + 1] - s2;  // ‖w″‖² = ‖w′‖² − ‖h₂‖²
+    if (ssq < 0.0) ssq = 0.0;
+    const double hn = sqrt(ssq);
+    sH[(k + 1) * LH + k] = hn;
+    Hraw[(size_t)(k + 1) * m + k] = hn;
+    double hk = sh[0];
+    for (int i = 0; i < k; ++i) {
+      const double a = hk, b = sh[i + 1];
+      R[(size_t)i * m + k] = sc[i] * a + ss_[i] * b;
+      hk = -ss_[i] * a + sc[i] * b;
+    }
+    const double d = hypot(hk, hn);
+    double c, sgn;
+    if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = hn / d; }
+    cs[k] = c;
+    sn[k] = sgn;
+    R[(size_t)k * m + k] = d;
+    const double gk = s_gk;
+    g[k + 1] = -sgn * gk;
+    g[k] = c * gk;
+    const double rn = fabs(sgn * gk);
+    const double inv = (hn > 0.0) ? 1.0 / hn : 0.0;
+    ctl->k = k + 1;
+    ctl->rnorm = rn;
+    ctl->hn = hn;
+    ctl->inv_hn = inv;
+    s[k + 1] = inv;
+    s_next = inv;
+    if (!(rn == rn) || isinf(rn) || !(hn == hn)) { ctl->failed = 1; ctl->done = 1; }
+    else if (s_tol >= 0.0 && rn <= s_tol) { ctl->converged = 1; ctl->done = 1; }
+    else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; }
+  }
+  __syncthreads();
+  // coefficients for the next step's pass A (pending column k+1, r = h2): c_i = Σ_{j ≤ k} H̄[i][j] r_j, i ≤ k+1
+  if (t <= k + 1) {
+    double c = 0.0;
+    for (int j = (t > 0 ? t - 1 : 0); j <= k; ++j) c += sH[t * LH + j] * sh2[j];
+    const double st = (t <= k) ? ssc[t] : s_next;
+    b_out[t] = s_next * c * st;
+    if (t <= k) a_out[t] = sh2[t] * st;
+  }
+}
+
 // new Hessenberg column → apply old rotations, create the new one, update g and the residual estimate
 // ss_partials != nullptr (single rank): ‖w‖² arrives as nblk per-block partials and is reduced here, saving a launch
 __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, const double *h2, const double *d_ss,
@@ -535,16 +634,25 @@ static int arnoldi_step(nk_gmres *G, int k) {
     // relation and takes the first projection of the new vector — one sweep over the basis; pass B is the usual fused
     // axpy + second projection, whose correction stays pending. ‖w″‖ comes from Pythagoras in k_givens. Two sweeps and
     // two reductions per step instead of three (oracle/reference_restatement.py::gmres(ortho="dcgs2")).
+    const bool single = nk_ctx_is_single(ctx);
     if (k == 0) {
       NK_TRY(nk_blas_multidot(ctx, n, 1, G->V, ldv, wk, G->d_h, false, skip, G->d_s));
     } else {
-      NK_LAUNCH(ctx, k_dcgs2_coef, dim3(1), dim3(64), (const nk_gmres_ctl *)G->d_ctl, k, (const double *)G->d_Hraw, G->m,
-                (const double *)G->d_h2, (const double *)G->d_s, G->d_ca, G->d_cb);
+      if (!single)  // (single rank: the coefficients were produced by the previous step's k_givens_dcgs2)
+        NK_LAUNCH(ctx, k_dcgs2_coef, dim3(1), dim3(64), (const nk_gmres_ctl *)G->d_ctl, k, (const double *)G->d_Hraw, G->m,
+                  (const double *)G->d_h2, (const double *)G->d_s, G->d_ca, G->d_cb);
       NK_TRY(nk_blas_dcgs2_pass_a(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, G->d_s, G->d_h, skip));
     }
-    NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, G->d_h2, skip));
-    NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
-              G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 1, G->d_Hraw);
+    if (single) {
+      NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, NK_SUMSQ_PARTIALS_ONLY, skip));
+      nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (nv + 1) * ctx->last_red_grid);
+      NK_LAUNCH(ctx, k_givens_dcgs2, dim3(1), dim3(1024), G->d_ctl, (const double *)G->d_h, (const double *)ctx->d_partials,
+                ctx->last_red_grid, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, G->d_Hraw, G->d_ca, G->d_cb, G->d_h2);
+    } else {
+      NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, G->d_h2, skip));
+      NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
+                G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 1, G->d_Hraw);
+    }
   } else if (G->ortho == NK_ORTHO_MGS) {
     for (int i = 0; i <= k; ++i) {  // h_i = v_i·w ; w -= h_i v_i ; the last axpy also yields ‖w‖²
       NK_TRY(nk_blas_multidot(ctx, n, 1, G->V + (size_t)i * ldv, ldv, wk, G->d_h + i, false, skip, G->d_s + i));
