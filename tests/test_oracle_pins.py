@@ -339,3 +339,21 @@ def test_c_ensemble_oracle_equals_python_restatement():
     Pq = np.repeat(np.arange(1.0, 33.0)[:, None], 3, axis=1)
     u, r, rc, it = CO.ensemble_newton(0, np.ones(3), Pq)
     assert (rc == R.SUCCESS).all() and np.max(np.abs(u - np.sqrt(Pq))) < 1e-12
+
+
+def test_dcgs2_restatement_equals_cgs2():
+    """CGS2 with the second correction applied one step late (the device default) is CGS2 up to rounding: same
+    iteration counts, recurrence residuals and solutions, across restarts; orthogonality of the basis stays O(ε)."""
+    pb = R.Bratu2D(20)
+    J = pb.jac(0.1 * np.random.default_rng(0).standard_normal(pb.n))
+    b = np.random.default_rng(1).standard_normal(pb.n)
+    for kw in (dict(rtol=1e-10, itmax=3000), dict(fixed_iters=30), dict(fixed_iters=47), dict(fixed_iters=1)):
+        x1, i1 = R.gmres(lambda z: J @ z, b, restart=30, ortho="cgs2", **kw)
+        x2, i2 = R.gmres(lambda z: J @ z, b, restart=30, ortho="dcgs2", **kw)
+        assert i1.iters == i2.iters and i1.converged == i2.converged
+        assert abs(i1.rnorm - i2.rnorm) <= 1e-12 * i1.rnorm0
+        assert np.linalg.norm(x1 - x2) <= 1e-12 * np.linalg.norm(x1)
+    # distributed oracle: the partial inner products of two row blocks are summed by the all-reduce stand-in
+    xr, ir = R.gmres(lambda z: J @ z, b, restart=30, rtol=1e-10, itmax=3000, ortho="cgs2")
+    x3, i3 = R.gmres(lambda z: J @ z, b, restart=30, rtol=1e-10, itmax=3000, ortho="dcgs2", allreduce=lambda v: v)
+    assert i3.iters == ir.iters and np.linalg.norm(x3 - xr) <= 1e-12 * np.linalg.norm(xr)
