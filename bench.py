@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", dest="n", type=int, default=1024, help="grid side per GPU-equivalent (1024 ⇒ N = 1e6)")
-    ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "cgs", "mgs"])
+    ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs"])
     ap.add_argument("--arnoldi", type=int, default=30)
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
     ap.add_argument("--cpu-steps", type=int, default=12, help="Newton steps of the CPU baseline sample (0 = skip)")

@@ -86,9 +86,12 @@ typedef enum {
   NK_ORTHO_MGS = 0,  /* modified Gram–Schmidt: the structure Krylov.jl's gmres uses [EXT]            */
   NK_ORTHO_CGS2 = 1, /* classical GS, always re-orthogonalised (2 fused passes)                       */
   NK_ORTHO_CGS = 2,  /* classical GS, re-orthogonalise only when ‖w'‖ < ‖w‖/√2 (DGKS)                 */
-  NK_ORTHO_DCGS2 = 3 /* CGS2 with the second correction applied one step late, fused into the next step's
-                      * first pass (2 passes over the basis per step instead of 3); the default. restart > 31
-                      * silently uses NK_ORTHO_CGS2                                                      */
+  NK_ORTHO_DCGS2 = 3, /* the default: CGS2 arithmetic with delayed re-orthogonalisation — two sweeps over the basis and
+                       * (with the built-in linear operators) ONE reduction / all-reduce per Arnoldi step; operators
+                       * reached through callbacks keep two reductions; restart > 31 silently uses NK_ORTHO_CGS2      */
+  NK_ORTHO_DCGS2_1R = 4 /* insist on the one-reduction form (the pending vector's second projection and the new vector's
+                       * first projection share a fused dot sweep; the Hessenberg column and the stopping test lag
+                       * one step); falls back like NK_ORTHO_DCGS2 where the operator does not allow it            */
 } nk_ortho;
 
 typedef enum { NK_FORCING_NONE = 0, NK_FORCING_EISENSTAT_WALKER2 = 1 } nk_forcing;

@@ -22,7 +22,7 @@ RET_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalL
 PROBLEM_QUADRATIC, PROBLEM_BRATU2D, PROBLEM_BRUSSELATOR2D, PROBLEM_USER = 1, 2, 3, 100
 ALG_NEWTON_RAPHSON, ALG_TRUST_REGION = 0, 1
 LINSOLVE_GMRES_MATFREE, LINSOLVE_GMRES_CSR, LINSOLVE_BANDED_LU = 0, 1, 2
-ORTHO_MGS, ORTHO_CGS2, ORTHO_CGS, ORTHO_DCGS2 = 0, 1, 2, 3
+ORTHO_MGS, ORTHO_CGS2, ORTHO_CGS, ORTHO_DCGS2, ORTHO_DCGS2_1R = 0, 1, 2, 3, 4
 FORCING_NONE, FORCING_EW2 = 0, 1
 COMM_NONE, COMM_RCCL, COMM_CALLBACKS = 0, 1, 2
 

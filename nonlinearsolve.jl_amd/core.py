@@ -611,7 +611,7 @@ TERMINATION_CONDITIONS = [  # common/common_rootfind_testing.jl:3-13
     AbsNormSafeBestTerminationMode,
 ]
 
-_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2": L.ORTHO_DCGS2}
+_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2": L.ORTHO_DCGS2, "dcgs2_1r": L.ORTHO_DCGS2_1R}
 
 
 def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,

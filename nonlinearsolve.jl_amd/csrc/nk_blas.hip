@@ -4,6 +4,8 @@
 // Every kernel is HBM-bound streaming work; algorithmic bytes per launch:
 //   multidot   : 8 n (nv + 1)            multiaxpy : 8 n (nv + 2)      scale_to : 16 n
 //   dot        : 16 n    sumsq/norm_inf : 8 n    axpby : 24 n    copy : 16 n
+#include <algorithm>
+
 #include "nk_internal.h"
 
 // Krylov-basis loads. The basis (m+1 columns × 8N bytes ≈ 260 MB at N = 2²⁰) is streamed and never re-used before it
@@ -385,6 +387,189 @@ int nk_blas_dcgs2_pass_a(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, 
   }
   NK_HIP(hipGetLastError());
   return nk_comm_allreduce(ctx, d_h, k + 1, 0);
+}
+
+// ----------------------------------------------------------------------------- DCGS2 with one reduction per step
+// dot sweep: NV final columns, pending p = V[:,NV], z = V[:,NV+1] (absent when !WITHZ: the flush of a cycle).
+// slots: [0,NV) ṽ_j·p | NV: p·p | [NV+1, 2NV+1) ṽ_j·z | 2NV+1: p·z
+// Every workgroup owns a contiguous tile of DR·256 rows: its slice of p (and z) stays in registers while the final
+// columns stream past eight at a time — 16 accumulators instead of 2·NV+2, so the kernel keeps its occupancy at any NV
+// (a first version with all accumulators live ran at 3.0 TB/s). nv is a run-time argument.
+constexpr int DR = 8;  // rows per thread
+template <bool WITHZ>
+__global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_dots(int64_t n, int nv, const double *__restrict__ V, int64_t ldv,
+                                                          double *__restrict__ partials, const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  constexpr int CH = 2;  // columns per chunk (measured on MI355X: 16 → 3.0, 8 → 4.8, 4 → 5.5, 2 → 6.25, 1 → 5.8 TB/s)
+  __shared__ double sm[4 * 2 * CH + 8];
+  const double *__restrict__ pk = V + (size_t)nv * ldv;
+  const double *__restrict__ zk = V + (size_t)(nv + 1) * ldv;
+  const unsigned nn = (unsigned)n, base = blockIdx.x * (NK_BLOCK * DR) + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  unsigned idx[DR];
+  double pv[DR], zv[DR], msk[DR];
+  double aa = 0.0, dd = 0.0;
+#pragma unroll
+  for (int i = 0; i < DR; ++i) {
+    const unsigned r = base + NK_BLOCK * i;
+    idx[i] = r < nn ? r : 0;          // clamped: loads stay unconditional
+    msk[i] = r < nn ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < DR; ++i) {
+    pv[i] = pk[idx[i]] * msk[i];
+    zv[i] = WITHZ ? zk[idx[i]] * msk[i] : 0.0;
+    aa += pv[i] * pv[i];
+    dd += pv[i] * zv[i];
+  }
+  const int zoff = nv + 1;  // slot of ṽ_0·z
+  for (int c0 = 0; c0 < nv; c0 += CH) {
+    double acc[2 * CH];
+#pragma unroll
+    for (int q = 0; q < 2 * CH; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+      const int j = min(c0 + jj, nv - 1);  // columns past nv repeat the last one; their sums are not stored
+      const double *__restrict__ col = V + (size_t)j * ldv;
+      double vj[DR];
+#pragma unroll
+      for (int i = 0; i < DR; ++i) vj[i] = col[idx[i]];
+#pragma unroll
+      for (int i = 0; i < DR; ++i) {
+        acc[2 * jj] += vj[i] * pv[i];
+        if (WITHZ) acc[2 * jj + 1] += vj[i] * zv[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * CH; ++q) {
+      if (WITHZ || (q & 1) == 0) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) sm[wid * 2 * CH + q] = v;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CH) {
+      const int q = threadIdx.x, j = c0 + (q >> 1);
+      if (j < nv && (WITHZ || (q & 1) == 0)) {
+        const double v = (sm[q] + sm[2 * CH + q]) + (sm[4 * CH + q] + sm[6 * CH + q]);
+        const int slot = (q & 1) ? zoff + j : j;
+        partials[(size_t)slot * gridDim.x + blockIdx.x] = v;
+      }
+    }
+    __syncthreads();
+  }
+  {
+    const double va = wave_sum(aa), vd = wave_sum(dd);
+    if (lane == 0) { sm[wid] = va; sm[4 + wid] = vd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      partials[(size_t)nv * gridDim.x + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      if (WITHZ) partials[(size_t)(2 * nv + 1) * gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+    }
+  }
+}
+
+// axpy sweep: p ← p − Σ a_j ṽ_j ; z ← b_{nv+1}·z − Σ b_j ṽ_j − b_nv·p (no reduction). Same shape as the dot sweep: the
+// workgroup's row tile of p and z lives in registers, the final columns stream past two at a time.
+__global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy(int64_t n, int nv, double *__restrict__ V, int64_t ldv,
+                                                          const double *__restrict__ ca_g, const double *__restrict__ cb_g,
+                                                          const int *d_skip) {
+  SKIP_GUARD(d_skip);
+  __shared__ double ca[NK_MAX_NV / 2 + 2], cb[NK_MAX_NV / 2 + 2];
+  __shared__ double s_bk, s_sz;
+  if ((int)threadIdx.x <= nv) {  // one zero entry past the end pads an odd column count
+    ca[threadIdx.x] = ((int)threadIdx.x < nv) ? ca_g[threadIdx.x] : 0.0;
+    cb[threadIdx.x] = ((int)threadIdx.x < nv) ? cb_g[threadIdx.x] : 0.0;
+  }
+  if (threadIdx.x == 0) { s_bk = cb_g[nv]; s_sz = cb_g[nv + 1]; }
+  __syncthreads();
+  double *__restrict__ pk = V + (size_t)nv * ldv;
+  double *__restrict__ zk = V + (size_t)(nv + 1) * ldv;
+  const unsigned nn = (unsigned)n, base = blockIdx.x * (NK_BLOCK * DR) + threadIdx.x;
+  unsigned idx[DR];
+  double pv[DR], zv[DR];
+  const double sz = s_sz, bk = s_bk;
+#pragma unroll
+  for (int i = 0; i < DR; ++i) {
+    const unsigned r = base + NK_BLOCK * i;
+    idx[i] = r < nn ? r : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < DR; ++i) {
+    pv[i] = pk[idx[i]];
+    zv[i] = sz * zk[idx[i]];
+  }
+  for (int j = 0; j < nv; j += 2) {
+    const int j1 = min(j + 1, nv - 1);
+    const double *__restrict__ c0 = V + (size_t)j * ldv;
+    const double *__restrict__ c1 = V + (size_t)j1 * ldv;
+    const double a0 = ca[j], a1 = ca[j + 1], b0 = cb[j], b1 = cb[j + 1];
+    double v0[DR], v1[DR];
+#pragma unroll
+    for (int i = 0; i < DR; ++i) { v0[i] = c0[idx[i]]; v1[i] = c1[idx[i]]; }
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+      pv[i] -= a0 * v0[i];
+      pv[i] -= a1 * v1[i];
+      zv[i] -= b0 * v0[i];
+      zv[i] -= b1 * v1[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DR; ++i) {
+    const unsigned r = base + NK_BLOCK * i;
+    if (r < nn) {
+      if (nv > 0) pk[r] = pv[i];
+      zk[r] = zv[i] - bk * pv[i];
+    }
+  }
+}
+
+#define NK_SWITCH_0_31(nvc, F)                                                                                 \
+  switch (nvc) {                                                                                               \
+    case 0: F(0); break;   case 1: F(1); break;   case 2: F(2); break;   case 3: F(3); break;                  \
+    case 4: F(4); break;   case 5: F(5); break;   case 6: F(6); break;   case 7: F(7); break;                  \
+    case 8: F(8); break;   case 9: F(9); break;   case 10: F(10); break; case 11: F(11); break;                \
+    case 12: F(12); break; case 13: F(13); break; case 14: F(14); break; case 15: F(15); break;                \
+    case 16: F(16); break; case 17: F(17); break; case 18: F(18); break; case 19: F(19); break;                \
+    case 20: F(20); break; case 21: F(21); break; case 22: F(22); break; case 23: F(23); break;                \
+    case 24: F(24); break; case 25: F(25); break; case 26: F(26); break; case 27: F(27); break;                \
+    case 28: F(28); break; case 29: F(29); break; case 30: F(30); break; default: F(31); break;                \
+  }
+
+int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double *V, int64_t ldv, double *d_red,
+                        const int *d_skip) {
+  NK_REQUIRE(k >= 0 && k <= 31, "DCGS2-1R handles 0..31 final columns (got %d)", k);
+  NK_REQUIRE(n < (1ll << 31), "fused pass: local vector too long for 32-bit offsets");
+  const int64_t tile = (int64_t)NK_BLOCK * DR;
+  const int64_t g64 = (n + tile - 1) / tile;
+  NK_REQUIRE(g64 <= NK_MAX_ROW_TILES, "DCGS2-1R: %lld local rows exceed %d row tiles of %lld (use NK_ORTHO_DCGS2)",
+             (long long)n, NK_MAX_ROW_TILES, (long long)tile);
+  const int grid = g64 > 0 ? (int)g64 : 1;
+  const int nslots = flush ? k + 1 : 2 * k + 2;
+  {
+    nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + (flush ? 1 : 2)));
+    if (flush) NK_LAUNCH(ctx, k_dcgs2r_dots<false>, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, ctx->d_partials, d_skip);
+    else NK_LAUNCH(ctx, k_dcgs2r_dots<true>, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, ctx->d_partials, d_skip);
+  }
+  {
+    nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
+    NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), ctx->d_partials, grid, d_red, d_skip,
+              (const double *)nullptr, 0);
+  }
+  NK_HIP(hipGetLastError());
+  return nk_comm_allreduce(ctx, d_red, nslots, 0);
+}
+
+int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
+                        const int *d_skip) {
+  NK_REQUIRE(k >= 0 && k <= 31, "DCGS2-1R handles 0..31 final columns (got %d)", k);
+  const int64_t tile = (int64_t)NK_BLOCK * DR;
+  const int grid = (int)std::max<int64_t>(1, (n + tile - 1) / tile);
+  nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 4));
+  NK_LAUNCH(ctx, k_dcgs2r_axpy, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, d_a, d_b, d_skip);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
 }
 
 // d_h2[0..nv) = s_j·(ṽ_j·w_new) and d_h2[nv] = ‖w_new‖² (both all-reduced). Requires nv ≤ 32.

@@ -184,6 +184,112 @@ __global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const 
   }
 }
 
+// DCGS2 with one reduction per step — the scalar work between the dot sweep and the axpy sweep of step k (one wave does
+// the serial part; k ≤ 31). red = [R_j = ṽ_j·u (k), a = u·u, G_j = ṽ_j·z (k), d = u·z], all-reduced, unscaled.
+//   r = s∘R, g = s∘G, β² = a − rᵀr, s_k = 1/β;  H[0:k, k−1] = t_prev + r, H[k, k−1] = β  → Givens on column k−1 (one step
+//   late), stopping test;  c = H̄_{k−1} r;  t = [(g − c_{0:k})/β ; (d − rᵀg − β c_k)/β²]  (first projection of A v_k)
+//   axpy coefficients: a_j = r_j s_j;  b_j = (s_k c_j + t_j) s_j (j<k), b_k = (s_k c_k + t_k) s_k, b_{k+1} = s_k (scale of z)
+// k = 0: column 0 is final, only t_0 = s_0² d. `last`: the flush after the cycle's last step — no z, no coefficients.
+__global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, int last, const double *__restrict__ red,
+                                                     double *s, double *__restrict__ Hraw, int m, double *__restrict__ tprev,
+                                                     double *R, double *cs, double *sn, double *g,
+                                                     double *__restrict__ a_out, double *__restrict__ b_out) {
+  if (ctl->done) return;
+  constexpr int NH = NK_MAX_NV / 2 + 2, LH = NK_MAX_NV / 2 + 1;
+  __shared__ double sr[NH], sg[NH], sc_[NH], sh[NH], scs[NH], ssn[NH], ssc[NH];
+  __shared__ double sH[NH * LH];  // H̄ rows 0..k, columns 0..k−1, staged in one round trip
+  __shared__ double s_beta, s_sk, s_gj, s_a, s_d, s_tol;
+  const int t = threadIdx.x;
+  if (k == 0) {
+    if (t == 0) {
+      const double s0 = s[0], tl = s0 * s0 * red[1];
+      tprev[0] = tl;
+      b_out[0] = tl * s0;
+      b_out[1] = s0;
+    }
+    return;
+  }
+  // every global read is issued here
+  if (t < k) {
+    const double st = s[t];
+    ssc[t] = st;
+    sr[t] = st * red[t];
+    sg[t] = last ? 0.0 : st * red[k + 1 + t];
+    sh[t] = tprev[t];
+    if (t < k - 1) { scs[t] = cs[t]; ssn[t] = sn[t]; }
+  }
+  if (t == 0) { s_gj = g[k - 1]; s_a = red[k]; s_d = last ? 0.0 : red[2 * k + 1]; s_tol = ctl->tol; }
+  if (!last) {
+    for (int e = t; e < (k + 1) * (k - 1); e += 256) {  // columns 0..k−2 (column k−1 is completed below)
+      const int i = e / (k - 1), j = e - i * (k - 1);
+      sH[i * LH + j] = (i <= j + 1) ? Hraw[(size_t)i * m + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (t < k) sh[t] += sr[t];
+  __syncthreads();
+  if (t == 0) {
+    double rr = 0.0;
+    for (int j = 0; j < k; ++j) rr += sr[j] * sr[j];
+    double b2 = s_a - rr;  // ‖u − V r‖² by Pythagoras
+    if (b2 < 0.0) b2 = 0.0;
+    const double beta = sqrt(b2), sk = (beta > 0.0) ? 1.0 / beta : 0.0;
+    s_beta = beta;
+    s_sk = sk;
+    s[k] = sk;
+    const int j = k - 1;  // the Hessenberg column that is complete now
+    for (int i = 0; i < k; ++i) { Hraw[(size_t)i * m + j] = sh[i]; sH[i * LH + j] = sh[i]; }
+    Hraw[(size_t)k * m + j] = beta;
+    sH[k * LH + j] = beta;
+    double hk = sh[0];
+    for (int i = 0; i < j; ++i) {
+      const double a = hk, b = sh[i + 1];
+      R[(size_t)i * m + j] = scs[i] * a + ssn[i] * b;
+      hk = -ssn[i] * a + scs[i] * b;
+    }
+    const double d = hypot(hk, beta);
+    double c, sgn;
+    if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
+    cs[j] = c;
+    sn[j] = sgn;
+    R[(size_t)j * m + j] = d;
+    const double gj = s_gj;
+    g[j + 1] = -sgn * gj;
+    g[j] = c * gj;
+    const double rn = fabs(sgn * gj);
+    ctl->k = k;
+    ctl->rnorm = rn;
+    ctl->hn = beta;
+    ctl->inv_hn = sk;
+    if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; ctl->done = 1; }
+    else if (s_tol >= 0.0 && rn <= s_tol) { ctl->converged = 1; ctl->done = 1; }
+    else if (beta == 0.0) { ctl->converged = 1; ctl->done = 1; }
+  }
+  __syncthreads();
+  if (last) return;
+  if (t <= k) {  // c = H̄_{k−1} r: rows 0..k, columns 0..k−1 (upper Hessenberg)
+    double c = 0.0;
+    for (int j = (t > 0 ? t - 1 : 0); j < k; ++j) c += sH[t * LH + j] * sr[j];
+    sc_[t] = c;
+  }
+  __syncthreads();
+  const double beta = s_beta, sk = s_sk;
+  if (t < k) {
+    const double tt = (sg[t] - sc_[t]) * sk;
+    tprev[t] = tt;
+    a_out[t] = sr[t] * ssc[t];
+    b_out[t] = (sk * sc_[t] + tt) * ssc[t];
+  }
+  if (t == 0) {
+    double rg = 0.0;
+    for (int j = 0; j < k; ++j) rg += sr[j] * sg[j];
+    const double tl = (s_d - rg - beta * sc_[k]) * sk * sk;
+    tprev[k] = tl;
+    b_out[k] = (sk * sc_[k] + tl) * sk;
+    b_out[k + 1] = sk;
+  }
+}
+
 // new Hessenberg column → apply old rotations, create the new one, update g and the residual estimate
 // ss_partials != nullptr (single rank): ‖w‖² arrives as nblk per-block partials and is reduced here, saving a launch
 __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, const double *h2, const double *d_ss,
@@ -280,9 +386,10 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_REQUIRE(n_local >= 0, "negative size");
   if (restart_m <= 0) restart_m = 30;
   NK_REQUIRE(restart_m < NK_MAX_NV, "restart m=%d too large (max %d)", restart_m, NK_MAX_NV - 1);
-  NK_REQUIRE(ortho == NK_ORTHO_MGS || ortho == NK_ORTHO_CGS2 || ortho == NK_ORTHO_CGS || ortho == NK_ORTHO_DCGS2,
+  NK_REQUIRE(ortho == NK_ORTHO_MGS || ortho == NK_ORTHO_CGS2 || ortho == NK_ORTHO_CGS || ortho == NK_ORTHO_DCGS2 ||
+                 ortho == NK_ORTHO_DCGS2_1R,
              "bad ortho %d", ortho);
-  if (ortho == NK_ORTHO_DCGS2 && restart_m > 31) ortho = NK_ORTHO_CGS2;  // the fused sweeps hold ≤ 32 columns in registers
+  if ((ortho == NK_ORTHO_DCGS2 || ortho == NK_ORTHO_DCGS2_1R) && restart_m > 31) ortho = NK_ORTHO_CGS2;  // the fused sweeps hold ≤ 32 columns in registers
   NK_HIP(hipSetDevice(ctx->device));
   nk_gmres *G = new nk_gmres();
   G->ctx = ctx;
@@ -304,6 +411,8 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_TRY(nk_dev_alloc(&G->d_h2, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_Hraw, (size_t)(NK_MAX_NV + 1) * NK_MAX_NV));
   NK_TRY(nk_dev_alloc(&G->d_ca, (size_t)NK_MAX_NV + 2));
+  NK_TRY(nk_dev_alloc(&G->d_tprev, (size_t)NK_MAX_NV + 2));
+  NK_TRY(nk_dev_alloc(&G->d_red, (size_t)2 * NK_MAX_NV + 4));
   NK_TRY(nk_dev_alloc(&G->d_cb, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_s, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_R, (size_t)m * m));
@@ -323,7 +432,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
 extern "C" int nk_gmres_destroy(nk_gmres *G) {
   if (!G) return NK_OK;
   hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
-  hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb);
+  hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb); hipFree(G->d_tprev); hipFree(G->d_red);
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
@@ -620,6 +729,42 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
   return op_apply_raw(G, src, d_y, d_skip, oscale);
 }
 
+// ----------------------------------------------------------------------------- DCGS2, one reduction per step
+// eligible: built-in linear operators (they take the un-normalised pending column as it is) and no callback preconditioner
+static bool dcgs2r_eligible(const nk_gmres *G) {
+  const bool op_ok = (G->op_kind == 1) || (G->op_kind == 2 && G->P->kind != NK_PROBLEM_USER);
+  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2) && G->m <= 31 &&
+         G->n <= (int64_t)NK_MAX_ROW_TILES * NK_BLOCK * 8;
+}
+static bool use_dcgs2r(const nk_gmres *G) {
+  if (!dcgs2r_eligible(G)) return false;
+  static const bool two = getenv("NK_DCGS2_TWO_REDUCTIONS") != nullptr;  // A/B switch: keep the two-reduction form
+  return G->ortho == NK_ORTHO_DCGS2_1R || (G->ortho == NK_ORTHO_DCGS2 && !two);
+}
+static int arnoldi_step_1r(nk_gmres *G, int k) {
+  nk_ctx *ctx = G->ctx;
+  const int64_t n = G->n, ldv = G->ldv;
+  const int *skip = &G->d_ctl->done;
+  double *zk = G->V + (size_t)(k + 1) * ldv;
+  NK_TRY(op_apply(G, G->V + (size_t)k * ldv, zk, skip, nullptr));  // z = A u on the pending (un-normalised) column
+  NK_TRY(nk_blas_dcgs2r_dots(ctx, n, k, false, G->V, ldv, G->d_red, skip));
+  NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, k, 0, (const double *)G->d_red, G->d_s, G->d_Hraw, G->m,
+            G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
+  NK_TRY(nk_blas_dcgs2r_axpy(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, skip));
+  return NK_OK;
+}
+// after the last step of a cycle: the pending column's reduction completes the last Hessenberg column
+static int arnoldi_flush_1r(nk_gmres *G, int steps) {
+  nk_ctx *ctx = G->ctx;
+  const int *skip = &G->d_ctl->done;
+  if (steps <= 0) return NK_OK;
+  NK_TRY(nk_blas_dcgs2r_dots(ctx, G->n, steps, true, G->V, G->ldv, G->d_red, skip));
+  NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, steps, 1, (const double *)G->d_red, G->d_s, G->d_Hraw, G->m,
+            G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
 // ----------------------------------------------------------------------------- one Arnoldi step (enqueue only)
 static int arnoldi_step(nk_gmres *G, int k) {
   nk_ctx *ctx = G->ctx;
@@ -628,7 +773,7 @@ static int arnoldi_step(nk_gmres *G, int k) {
   const int nv = k + 1;
   double *wk = G->V + (size_t)(k + 1) * ldv;  // the new (un-normalised) column is built in place
   NK_TRY(op_apply(G, G->V + (size_t)k * ldv, wk, skip, G->d_s + k));
-  if (G->ortho == NK_ORTHO_DCGS2) {
+  if (G->ortho == NK_ORTHO_DCGS2 || G->ortho == NK_ORTHO_DCGS2_1R) {
     // CGS2 with delayed re-orthogonalisation: column k holds p (first projection only) when k ≥ 1; the operator above
     // was applied to it. Pass A applies the pending correction to column k, rebuilds A v_k from A p through the Arnoldi
     // relation and takes the first projection of the new vector — one sweep over the basis; pass B is the usual fused
@@ -731,7 +876,12 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
                        fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m);
     first = 0;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
-    for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step(G, k));
+    if (use_dcgs2r(G)) {
+      for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step_1r(G, k));
+      NK_TRY(arnoldi_flush_1r(G, steps));
+    } else {
+      for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step(G, k));
+    }
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
     NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(64), G->d_ctl, G->d_R, G->d_g, G->d_y, m);
     if (!G->prec_kind) {

@@ -35,6 +35,7 @@ void nk_set_error(const char *fmt, ...);
 // ----------------------------------------------------------------------------- context
 constexpr int NK_BLOCK = 256;          // 4 wavefronts of 64
 constexpr int NK_MAX_RED_BLOCKS = 1024; // stage-1 reduction blocks (4 per CU)
+constexpr int NK_MAX_ROW_TILES = 16384; // DCGS2-1R dot sweep: one block per 2048-row tile (≤ 33.5 M local rows)
 constexpr int NK_LDV_PAD_DEFAULT = 544;   // extra elements between basis columns (tuned on hardware)
 constexpr int NK_DOT_BLOCKS = 512;      // multi-dot kernels: fewer, fatter blocks (epilogue = NV block reductions)
 constexpr int NK_MAX_NV = 64;          // max simultaneous dot products (restart m ≤ 63)
@@ -214,6 +215,12 @@ int nk_blas_cgs2_passes_pr(nk_ctx *ctx, int64_t n, int nv, const double *V, int6
 #define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
 // DCGS2 pass A: correct the pending column V[:,k] by −Σ a_j ṽ_j, turn V[:,k+1] (= s_k·A·pending) into the true next
 // vector by −Σ b_j ṽ_j − b_k·corrected, and return d_h[0..k] = s_j·(ṽ_j·w) over the corrected basis
+// DCGS2-1R sweeps: dots of the pending column p = V[:,k] (and, unless `flush`, of z = V[:,k+1] = A p) against the k final
+// columns: d_red = [ṽ_j·p (k), p·p, ṽ_j·z (k), p·z], all-reduced, unscaled; axpy: p −= Σ a_j ṽ_j, z = b_{k+1} z − Σ b_j ṽ_j − b_k p
+int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double *V, int64_t ldv, double *d_red,
+                        const int *d_skip);
+int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
+                        const int *d_skip);
 int nk_blas_dcgs2_pass_a(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
                          const double *d_scales, double *d_h, const int *d_skip);
 int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
@@ -239,6 +246,7 @@ struct nk_gmres {
   int m = 30, ortho = NK_ORTHO_CGS2;
   double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
+  double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
          *d_g = nullptr, *d_y = nullptr, *d_ss = nullptr;
   double *d_s = nullptr;  // s_j: the basis is stored un-normalised, v_j = s_j ṽ_j (lagged normalisation)

@@ -16,6 +16,7 @@
 struct nk_solver {
   nk_problem *P = nullptr;
   nk_ctx *ctx = nullptr;
+  nk_stats ctx_base{};  // context-wide counters (operator applications, all-reduces, halo exchanges) at (re)initialisation
   nk_options o{};
   int64_t n = 0;
   // vectors
@@ -396,6 +397,9 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   nk_ctx *ctx = S->ctx;
   NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
   S->stats = nk_stats{};
+  S->ctx_base.op_applies = S->ctx->stats.op_applies;
+  S->ctx_base.allreduces = S->ctx->stats.allreduces;
+  S->ctx_base.halo_exchanges = S->ctx->stats.halo_exchanges;
   S->nsteps = 0;
   S->retcode = NK_RET_DEFAULT;
   S->force_stop = false;
@@ -956,9 +960,9 @@ extern "C" int nk_solver_get_resid(nk_solver *S, double *f, int memspace) {
 extern "C" int nk_solver_get_stats(nk_solver *S, nk_stats *st) {
   NK_REQUIRE(S && st, "NULL argument");
   *st = S->stats;
-  st->op_applies = S->ctx->stats.op_applies;
-  st->allreduces = S->ctx->stats.allreduces;
-  st->halo_exchanges = S->ctx->stats.halo_exchanges;
+  st->op_applies = S->ctx->stats.op_applies - S->ctx_base.op_applies;  // since this cache was (re)initialised
+  st->allreduces = S->ctx->stats.allreduces - S->ctx_base.allreduces;
+  st->halo_exchanges = S->ctx->stats.halo_exchanges - S->ctx_base.halo_exchanges;
   return NK_OK;
 }
 extern "C" int nk_solver_get_retcode(nk_solver *S, int *retcode, int *nsteps, int *force_stop) {

@@ -409,6 +409,106 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
         beta = math.sqrt(float(ar(np.dot(r, r))))
 
 
+def gmres_dcgs2_1r(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0,
+                   allreduce: Optional[Callable] = None):
+    """Restarted GMRES(m), zero initial guess, whose Arnoldi process is CGS2 with delayed re-orthogonalisation and ONE
+    reduction per step (the device's NK_ORTHO_DCGS2_1R; Bielich, Langou, Thomas, Świrydowicz et al., "Low-synch
+    Gram–Schmidt with delayed reorthogonalization for Krylov solvers"). Column k holds the once-projected, un-normalised
+    u_k; the operator is applied to it; one fused reduction yields r = Vᵀu (its pending second projection), ‖u‖², and
+    the raw projections Vᵀz, uᵀz of z = A u; the Hessenberg column k−1 (one step late), v_k = (u − V r)/β,
+    A v_k = (z − V H̄ r)/β and its first projection follow algebraically; one axpy sweep stores v_k and u_{k+1}.
+    Same arithmetic as CGS2 up to rounding; the stopping test sees a column one step after CGS2 would."""
+    ar = allreduce if allreduce is not None else (lambda z: z)
+    b = np.asarray(b, dtype=np.float64)
+    n = b.size
+    x = np.zeros(n)
+    info = GmresInfo()
+    r0 = b.copy()
+    beta0 = math.sqrt(float(ar(np.dot(r0, r0))))
+    info.rnorm0 = info.rnorm = beta0
+    info.residuals.append(beta0)
+    if not math.isfinite(beta0):
+        info.failed = True
+        return x, info
+    eps_stop, cap = (-1.0, int(fixed_iters)) if fixed_iters > 0 else (atol + rtol * beta0, int(itmax))
+    if beta0 == 0.0 or (fixed_iters <= 0 and beta0 <= eps_stop):
+        info.converged = True
+        return x, info
+    m = int(restart)
+    while True:
+        V = np.zeros((m + 2, n))
+        Hraw = np.zeros((m + 2, m + 1))
+        R = np.zeros((m, m))
+        cs, sn, g = np.zeros(m), np.zeros(m), np.zeros(m + 1)
+        V[0] = r0 / beta0
+        g[0] = beta0
+        steps = min(m, cap - info.iters)
+        kdone, done = 0, False
+
+        def finish_column(j, h):  # Givens on Hessenberg column j (entries 0..j+1), as in `gmres`
+            nonlocal kdone, done
+            for i in range(j):
+                tt = cs[i] * h[i] + sn[i] * h[i + 1]
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]
+                h[i] = tt
+            dd = math.hypot(h[j], h[j + 1])
+            cs[j], sn[j] = (1.0, 0.0) if dd == 0.0 else (h[j] / dd, h[j + 1] / dd)
+            R[:j, j] = h[:j]
+            R[j, j] = dd
+            g[j + 1] = -sn[j] * g[j]
+            g[j] = cs[j] * g[j]
+            info.iters += 1
+            kdone = j + 1
+            info.rnorm = abs(g[j + 1])
+            info.residuals.append(info.rnorm)
+            if not math.isfinite(info.rnorm):
+                info.failed = True
+                done = True
+            elif (fixed_iters <= 0 and info.rnorm <= eps_stop) or h[j + 1] == 0.0:
+                info.converged = True
+                done = True
+
+        tprev = None
+        for k in range(steps + 1):
+            last = (k == steps)                      # the flush: no operator, only the pending column's reduction
+            u = V[k]
+            z = None if last else matvec(u)
+            if k == 0:
+                tl = float(ar(np.dot(V[0], z)))      # v_0 is final: only the first projection of A v_0
+                V[1] = z - tl * V[0]
+                tprev = np.array([tl])
+                continue
+            red = ar(np.concatenate([V[:k] @ u, [np.dot(u, u)]] + ([] if last else [V[:k] @ z, [np.dot(u, z)]])))
+            rr, a = red[:k], float(red[k])
+            beta = math.sqrt(max(a - float(rr @ rr), 0.0))
+            h = np.zeros(k + 1)
+            h[:k] = tprev + rr
+            h[k] = beta
+            Hraw[: k + 1, k - 1] = h
+            finish_column(k - 1, h.copy())
+            if done or last:
+                if not done and beta > 0:
+                    V[k] = (u - V[:k].T @ rr) / beta
+                break
+            gg, d = red[k + 1: 2 * k + 1], float(red[2 * k + 1])
+            c = Hraw[: k + 1, :k] @ rr
+            ttop = (gg - c[:k]) / beta
+            tlast = (d - float(rr @ gg) - beta * c[k]) / beta ** 2
+            vk = (u - V[:k].T @ rr) / beta
+            w = (z - V[:k].T @ c[:k] - vk * c[k]) / beta
+            V[k] = vk
+            V[k + 1] = w - V[:k].T @ ttop - vk * tlast
+            tprev = np.concatenate([ttop, [tlast]])
+        if kdone > 0 and not info.failed:
+            y = np.linalg.solve(np.triu(R[:kdone, :kdone]), g[:kdone]) if kdone > 1 else np.array([g[0] / R[0, 0]])
+            x = x + V[:kdone].T @ y
+        if done or info.iters >= cap:
+            return x, info
+        info.restarts += 1
+        r0 = b - matvec(x)
+        beta0 = math.sqrt(float(ar(np.dot(r0, r0))))
+
+
 # ----------------------------------------------------------------------------- algorithm descriptors
 @dataclass
 class ChebyshevPrecs:

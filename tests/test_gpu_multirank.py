@@ -59,7 +59,7 @@ def _worker(rank, world, port, q):
         # distributed GMRES on the CSR operator vs the serial oracle
         rhs = rng.standard_normal(pb.n)
         xref, iref = R.gmres(lambda z: pb.jac(u) @ z, rhs, rtol=1e-9, restart=30, itmax=3000)
-        for ortho in ("cgs2", "mgs", "cgs", "dcgs2"):
+        for ortho in ("cgs2", "mgs", "cgs", "dcgs2", "dcgs2_1r"):   # "dcgs2" itself runs as dcgs2_1r on several ranks
             G = nls.GMRES(e - b, restart=30, ortho=ortho).set_operator(J)
             x, gi = G.solve(torch.tensor(rhs[b:e], device=dev), reltol=1e-9, maxiters=3000)
             xg = nls.dist.gather_vector(x, pb.n, b)
@@ -77,6 +77,10 @@ def _worker(rank, world, port, q):
             assert np.max(np.abs(ug - ref.u)) <= 1e-7
             assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
             assert sol.stats.allreduces > 0 and sol.stats.halo_exchanges > 0
+            # the default orthogonalisation on several ranks is DCGS2 with ONE all-reduce per Arnoldi step (+ one per
+            # cycle for ‖r0‖, one for the flush, a handful per Newton step); counters are per solver cache
+            bound = sol.stats.gmres_iters + 24 * (sol.stats.nsteps + 1)   # (two reductions per step would exceed it)
+            assert sol.stats.allreduces <= bound, (sol.stats.allreduces, sol.stats.gmres_iters, sol.stats.nsteps, bound)
 
         # ---------------- halo exchange overlapped with the interior row blocks (second stream + events): a grid large
         # enough to have both interior and boundary row blocks; every result is bitwise equal to the serial-exchange path

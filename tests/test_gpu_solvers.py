@@ -73,6 +73,39 @@ def test_gmres_dcgs2_follows_the_oracle_restatement(nls):
     assert np.linalg.norm(J @ x - b) <= 1.01e-10 * np.linalg.norm(b) and np.linalg.norm(x - x2) <= 1e-9 * np.linalg.norm(x2)
 
 
+def test_gmres_dcgs2_one_reduction_follows_the_oracle(nls):
+    """DCGS2 with a single reduction per Arnoldi step (`ortho="dcgs2_1r"`, what several ranks use): iterates, recurrence
+    residuals and iteration counts equal the oracle's restatement of the scheme and plain CGS2 to rounding — fixed
+    numbers of steps across restarts, tolerance stops inside a cycle, matrix-free operator, Chebyshev preconditioner."""
+    p = R.Bratu2D(24)
+    u = 0.1 * np.random.default_rng(5).standard_normal(p.n)
+    J = p.jac(u)
+    b = np.random.default_rng(2).standard_normal(p.n)
+    A = nls.CSRMatrix.from_scipy(J)
+    for k in (1, 2, 5, 30, 31, 45, 90):
+        xref, iref = R.gmres_dcgs2_1r(lambda z: J @ z, b, restart=30, fixed_iters=k)
+        x, info = nls.GMRES(p.n, restart=30, ortho="dcgs2_1r").set_operator(A).solve(b, fixed_iters=k)
+        assert info["iters"] == k == iref.iters
+        assert abs(info["rnorm"] - iref.rnorm) <= 1e-10 * iref.rnorm0
+        assert np.linalg.norm(x - xref) <= 1e-9 * np.linalg.norm(xref)
+    for rtol in (1e-4, 1e-10):
+        xref, iref = R.gmres_dcgs2_1r(lambda z: J @ z, b, rtol=rtol, restart=30, itmax=3000)
+        xc, ic = R.gmres(lambda z: J @ z, b, rtol=rtol, restart=30, itmax=3000, ortho="cgs2")
+        x, info = nls.GMRES(p.n, restart=30, ortho="dcgs2_1r").set_operator(A).solve(b, abstol=0.0, reltol=rtol, maxiters=3000)
+        assert info["converged"] and info["iters"] == iref.iters == ic.iters
+        assert np.linalg.norm(x - xc) <= 1e-9 * np.linalg.norm(xc)
+    prob = nls.NonlinearProblem(nls.Bratu2D(24))
+    op = nls.StatefulJacobianOperator(nls.JacobianOperator(prob), u)
+    G = nls.GMRES(p.n, restart=30, ortho="dcgs2_1r").set_operator(op)
+    G.set_chebyshev_preconditioner(8, ratio=30.0)
+    x, info = G.solve(b, abstol=0.0, reltol=1e-10, maxiters=2000)
+    G2 = nls.GMRES(p.n, restart=30, ortho="cgs2").set_operator(op)
+    G2.set_chebyshev_preconditioner(8, ratio=30.0)
+    x2, info2 = G2.solve(b, abstol=0.0, reltol=1e-10, maxiters=2000)
+    assert info["converged"] and info["iters"] == info2["iters"]
+    assert np.linalg.norm(J @ x - b) <= 1.01e-10 * np.linalg.norm(b) and np.linalg.norm(x - x2) <= 1e-9 * np.linalg.norm(x2)
+
+
 def test_gmres_matrix_free_and_callable_operator(nls, dev):
     import torch
     ns = 32
