@@ -611,149 +611,6 @@ int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int6
   return nk_comm_allreduce(ctx, d_h2, nv + 1, 0);
 }
 
-// ----------------------------------------------------------------------------- single-rank variants that fold the
-// stage-2 reduction of the PREVIOUS kernel's partials into their own prologue (saves two one-wavefront launches
-// and their kernel boundaries per Arnoldi step). 8 lanes per column add the g per-block partials in a fixed order.
-// coef[j] = s_j² Σ_b P[j][b] (the axpy coefficient h_j s_j); block 0 publishes h_out[j] = s_j Σ_b for k_givens.
-__device__ __forceinline__ void prologue_reduce(const double *__restrict__ P, int g, int nv,
-                                                const double *__restrict__ sc, double *coef,
-                                                double *__restrict__ h_out) {
-  const int j = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  double v = 0.0;
-  if (j < nv) {
-    const double *p = P + (size_t)j * g;
-    for (int b = sub; b < g; b += 8) v += p[b];
-  }
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  if (sub == 0 && j < nv) {
-    const double s = sc[j], hj = s * v;
-    coef[j] = s * hj;
-    if (blockIdx.x == 0) h_out[j] = hj;
-  }
-  __syncthreads();
-}
-
-template <int NV>
-__global__ __launch_bounds__(NK_BLOCK) void k_fused_axpy_dot_pr(int64_t n, const double *__restrict__ V, int64_t ldv,
-                                                                const double *__restrict__ P1, int g1,
-                                                                const double *__restrict__ sc,
-                                                                double *__restrict__ h1_out, double *__restrict__ w,
-                                                                double *__restrict__ partials, const int *d_skip) {
-  SKIP_GUARD(d_skip);
-  __shared__ double sm[4 * NV + 4];
-  __shared__ double coef[32];
-  prologue_reduce(P1, g1, NV, sc, coef, h1_out);
-  double acc[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) acc[j] = 0.0;
-  double ss = 0.0;
-  const unsigned stride = gridDim.x * NK_BLOCK, nn = (unsigned)n;
-  for (unsigned i = blockIdx.x * NK_BLOCK + threadIdx.x; i < nn; i += stride) {
-    double vv[NV];
-    double a = w[i];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const double *__restrict__ col = V + (size_t)j * ldv;
-      vv[j] = col[i];
-    }
-#pragma unroll
-    for (int j = 0; j < NV; ++j) a -= coef[j] * vv[j];
-    w[i] = a;
-    ss += a * a;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) acc[j] += vv[j] * a;
-  }
-  block_sum_array_store<NV>(acc, NV, sm, partials, 0);
-  const double s = block_sum(ss, sm + 4 * NV);
-  if (threadIdx.x == 0) partials[(size_t)NV * gridDim.x + blockIdx.x] = s;
-}
-
-// w −= Σ_j coef_j ṽ_j with coef from P2 (prologue); ‖w‖² partials → pss. nv ≤ 32.
-__global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy_pr(int64_t n, const double *__restrict__ V, int64_t ldv, int nv,
-                                                           const double *__restrict__ P2, int g2,
-                                                           const double *__restrict__ sc, double *__restrict__ h2_out,
-                                                           double *__restrict__ w, double *__restrict__ pss,
-                                                           const int *d_skip) {
-  SKIP_GUARD(d_skip);
-  __shared__ double sm[4];
-  __shared__ double coef[32];
-  prologue_reduce(P2, g2, nv, sc, coef, h2_out);
-  const int64_t npair = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
-  double2 *w2 = reinterpret_cast<double2 *>(w);
-  double ss = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < npair; i += stride) {
-    double2 a = w2[i];
-    int j = 0;
-    for (; j + 4 <= nv; j += 4) {
-      const double2 v0 = ldv2(V + (size_t)(j + 0) * ldv, i);
-      const double2 v1 = ldv2(V + (size_t)(j + 1) * ldv, i);
-      const double2 v2 = ldv2(V + (size_t)(j + 2) * ldv, i);
-      const double2 v3 = ldv2(V + (size_t)(j + 3) * ldv, i);
-      const double c0 = coef[j], c1 = coef[j + 1], c2 = coef[j + 2], c3 = coef[j + 3];
-      a.x -= c0 * v0.x; a.y -= c0 * v0.y;
-      a.x -= c1 * v1.x; a.y -= c1 * v1.y;
-      a.x -= c2 * v2.x; a.y -= c2 * v2.y;
-      a.x -= c3 * v3.x; a.y -= c3 * v3.y;
-    }
-    for (; j < nv; ++j) {
-      const double2 v0 = ldv2(V + (size_t)j * ldv, i);
-      const double c0 = coef[j];
-      a.x -= c0 * v0.x; a.y -= c0 * v0.y;
-    }
-    w2[i] = a;
-    ss += a.x * a.x + a.y * a.y;
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    double a = w[n - 1];
-    for (int j = 0; j < nv; ++j) a -= coef[j] * V[(size_t)j * ldv + n - 1];
-    w[n - 1] = a;
-    ss += a * a;
-  }
-  const double s = block_sum(ss, sm);
-  if (threadIdx.x == 0) pss[blockIdx.x] = s;
-}
-
-// single-rank CGS2 passes 2 and 3 with prologue reductions. Partials of the preceding multidot are in
-// ctx->d_partials (grid ctx->last_red_grid); pass 2 leaves its own in ctx->d_partials2; pass 3's ‖w‖² partials go
-// to ctx->d_partials_ss (reduced by k_givens). h1_out/h2_out receive the Hessenberg contributions.
-int nk_blas_cgs2_passes_pr(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_scales,
-                           double *w, double *d_h1_out, double *d_h2_out, const int *d_skip) {
-  NK_REQUIRE(nv >= 1 && nv <= 32, "prologue-reduced passes handle 1..32 columns (got %d)", nv);
-  NK_REQUIRE(n < (1ll << 31), "local vector too long for 32-bit offsets");
-  const int g1 = ctx->last_red_grid;
-  const int g2 = nk_grid_for(n, NK_BLOCK * 4, NK_DOT_BLOCKS);
-  {
-    nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2));
-#define FU_LAUNCH(N)                                                                                             \
-  NK_LAUNCH(ctx, k_fused_axpy_dot_pr<N>, dim3(g2), dim3(NK_BLOCK), n, V, ldv,                    \
-                     (const double *)ctx->d_partials, g1, d_scales, d_h1_out, w, ctx->d_partials2, d_skip)
-    if (nv <= 16) {
-      NK_SWITCH_1_16(nv, FU_LAUNCH)
-    } else {
-      switch (nv) {
-        case 17: FU_LAUNCH(17); break; case 18: FU_LAUNCH(18); break; case 19: FU_LAUNCH(19); break;
-        case 20: FU_LAUNCH(20); break; case 21: FU_LAUNCH(21); break; case 22: FU_LAUNCH(22); break;
-        case 23: FU_LAUNCH(23); break; case 24: FU_LAUNCH(24); break; case 25: FU_LAUNCH(25); break;
-        case 26: FU_LAUNCH(26); break; case 27: FU_LAUNCH(27); break; case 28: FU_LAUNCH(28); break;
-        case 29: FU_LAUNCH(29); break; case 30: FU_LAUNCH(30); break; case 31: FU_LAUNCH(31); break;
-        default: FU_LAUNCH(32); break;
-      }
-    }
-#undef FU_LAUNCH
-  }
-  const int g3 = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
-  {
-    nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2));
-    NK_LAUNCH(ctx, k_multiaxpy_pr, dim3(g3), dim3(NK_BLOCK), n, V, ldv, nv,
-                       (const double *)ctx->d_partials2, g2, d_scales, d_h2_out, w, ctx->d_partials_ss, d_skip);
-  }
-  ctx->last_red_grid = g3;
-  NK_HIP(hipGetLastError());
-  return NK_OK;
-}
 
 // ----------------------------------------------------------------------------- dot / sumsq / norm_inf / minmax
 __global__ __launch_bounds__(NK_BLOCK) void k_dot(int64_t n, const double *__restrict__ x,

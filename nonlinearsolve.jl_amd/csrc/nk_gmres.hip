@@ -809,19 +809,8 @@ static int arnoldi_step(nk_gmres *G, int k) {
   } else {
     const bool dgks = (G->ortho == NK_ORTHO_CGS);
     const int *skip2 = dgks ? &G->d_ctl->pad0 : skip;
-    // EXPERIMENT (off by default, NK_PROLOGUE_REDUCE=1): fold the stage-2 reductions into the consumers' prologues
-    // (5 launches per Arnoldi step). Measured SLOWER on MI355X (253 vs 282 steps/s): every one of the 512–1024
-    // consumer blocks re-reads all nv×512 partials, ≈130 MB of extra L2/MALL traffic per kernel.
-    static const bool use_pr = getenv("NK_PROLOGUE_REDUCE") != nullptr;
-    if (!dgks && nk_ctx_is_single(ctx) && nv <= 32 && use_pr) {
-      NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, nullptr, false, skip, G->d_s));
-      NK_TRY(nk_blas_cgs2_passes_pr(ctx, n, nv, G->V, ldv, G->d_s, wk, G->d_h, G->d_h2, skip));
-      NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2,
-                         G->d_ss, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)ctx->d_partials_ss,
-                         ctx->last_red_grid, 0, (double *)nullptr);
-      NK_HIP(hipGetLastError());
-      return NK_OK;
-    }
+    // (Folding the stage-2 reductions into the consumers' prologues was tried and measured slower — 253 vs 282 steps/s:
+    //  every one of the 512 consumer blocks re-reads all nv × 512 partials, ≈130 MB of extra L2 traffic per kernel.)
     // pass 1: h = Vᵀw (DGKS also needs ‖w‖² → self slot h[k+1])
     NK_TRY(nk_blas_multidot(ctx, n, nv, G->V, ldv, wk, G->d_h, dgks, skip, G->d_s));
     if (nv <= 32) {

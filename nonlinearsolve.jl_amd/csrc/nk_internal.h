@@ -210,8 +210,6 @@ int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ld
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq /*nullable*/, const int *d_skip,
                       const int *d_nv /*nullable: device count overrides nv*/, const double *d_scales);
-int nk_blas_cgs2_passes_pr(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_scales,
-                           double *w, double *d_h1_out, double *d_h2_out, const int *d_skip);
 #define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
 // DCGS2 pass A: correct the pending column V[:,k] by −Σ a_j ṽ_j, turn V[:,k+1] (= s_k·A·pending) into the true next
 // vector by −Σ b_j ṽ_j − b_k·corrected, and return d_h[0..k] = s_j·(ṽ_j·w) over the corrected basis
