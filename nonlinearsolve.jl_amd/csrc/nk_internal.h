@@ -74,7 +74,6 @@ struct nk_ctx {
   nk_comm_callbacks cb{};
   // scratch
   double *d_partials = nullptr;  // NK_MAX_NV * NK_MAX_RED_BLOCKS doubles
-  double *d_partials2 = nullptr;    // second partials buffer (fused pass) for the prologue-reduced variants
   double *d_partials_ss = nullptr;  // ‖·‖² partials of the axpy kernels (own buffer: survives later multidots)
   int last_red_grid = 0;
   double *d_scal = nullptr;      // 4*NK_MAX_NV doubles of device scalars
