@@ -712,3 +712,29 @@ def test_banded_lu_shapes_vs_scipy(nls, n, kl, ku):
         x = F.solve(b)
         assert np.max(np.abs(A @ x - b)) <= 1e-12 * np.max(np.abs(b)) * (kl + ku)
         assert np.allclose(x, spla.spsolve(A.tocsc(), b), rtol=1e-10, atol=1e-13)
+
+
+def test_newton_fails_converges_with_trust_region_on_device(nls, dev):
+    """rootfind_tests__item10.jl: `newton_fails` (7 unknowns) must converge with TrustRegion(); the residual is given as
+    a device function only — the Jacobian comes from the coloured finite-difference assembly on a diagonal prototype
+    (the system is separable), J and Jᵀ products from the assembled CSR — and the result matches the oracle's."""
+    import scipy.sparse as sp
+    import torch
+
+    def nf(u):
+        return (0.010000000000000002 + 10.000000000000002 / (1 + (0.21640425613334457 + 216.40425613334457 / (
+            1 + (0.21640425613334457 + 216.40425613334457 / (1 + 0.0006250000000000001 * (u ** 2.0))) ** 2.0)) ** 2.0)
+            - 0.0011552453009332421 * u)
+
+    def F(du, u, p):
+        du.copy_(nf(u))
+
+    u0 = np.array([-10.0, -1.0, 1.0, 2.0, 3.0, 4.0, 10.0])
+    proto = nls.CSRMatrix.from_scipy(sp.csr_matrix(sp.identity(7)))
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(F, jac_prototype=proto), torch.tensor(u0, device=dev))
+    sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(reltol=1e-12, abstol=0.0), concrete_jac=True),
+                    abstol=1e-9, maxiters=200)
+    assert sol.retcode == "Success" and float(sol.resid.abs().max()) < 1e-9
+    ref = R.solve(R.FunctionProblem(lambda u: nf(u), u0, jac=lambda u: sp.diags((nf(u + 1e-7) - nf(u - 1e-7)) / 2e-7)),
+                  R.TrustRegion(), abstol=1e-9)
+    assert np.max(np.abs(sol.u.cpu().numpy() - ref.u)) < 1e-5   # same root as the oracle (FD Jacobians on both sides)
