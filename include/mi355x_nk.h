@@ -202,6 +202,10 @@ typedef struct {
   double  ls_c1, ls_rho_hi, ls_rho_lo;
   int32_t ls_order;             /* 2 | 3 */
   int32_t ls_maxiters;
+  /* --- built-in multigrid V-cycle as the Krylov right preconditioner (BRATU2D, single rank), re-linearised for every
+   *     new Jacobian like `precs(A, p)`: mg_nu smoothing steps (0 = off), coarsest grid side ≤ mg_coarse (0 → 63) */
+  int32_t mg_nu;
+  int32_t mg_coarse;
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -329,6 +333,12 @@ int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
  * (negative-definite operators are fine). degree ≤ 0 removes it. Call after the operator is set. */
 int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, double lambda_min, double lambda_max, double ratio);
 int nk_gmres_get_chebyshev_interval(nk_gmres *G, double *lambda_min, double *lambda_max);
+/* Built-in right preconditioner M⁻¹ = one geometric multigrid V-cycle on the Jacobian of a BRATU2D problem linearised at u
+ * (level operators by rediscretisation, bilinear transfers between non-nested grids, `nu` Chebyshev smoothing steps before
+ * and after, banded LU on the coarsest grid of side ≤ coarse_max; 0 → 2 and 63) — the device counterpart of an algebraic-
+ * multigrid `precs` (docs/src/tutorials/large_systems.md:244-316). Mesh-independent Krylov iteration counts. Call it again
+ * for every new linearisation point; nu ≤ 0 or P == NULL removes it. Single rank. */
+int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P, const double *u, int memspace, int nu, int coarse_max);
 /* Solve A x = b. use_x0 = 0 ⇒ zero initial guess (our protocol); 1 ⇒ x holds x0.
  * Stop when ‖r‖₂ ≤ atol + rtol‖r0‖₂ or after maxiter Arnoldi steps; fixed_iters>0 overrides both. */
 int nk_gmres_solve(nk_gmres *G, const double *b, double *x, int memspace, int use_x0,

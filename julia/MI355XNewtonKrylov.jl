@@ -193,6 +193,7 @@ Base.@kwdef mutable struct NKOptions
     store_trace::Int32 = 0; termination_mode::Int32 = 0
     cheb_degree::Int32 = 0; linesearch::Int32 = 0; cheb_ratio::Float64 = 0.0
     ls_c1::Float64 = 1e-4; ls_rho_hi::Float64 = 0.5; ls_rho_lo::Float64 = 0.1; ls_order::Int32 = 3; ls_maxiters::Int32 = 1000
+    mg_nu::Int32 = 0; mg_coarse::Int32 = 0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,

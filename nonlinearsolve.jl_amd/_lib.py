@@ -66,7 +66,7 @@ class Options(C.Structure):
         ("store_trace", C.c_int32), ("termination_mode", C.c_int32),
         ("cheb_degree", C.c_int32), ("linesearch", C.c_int32), ("cheb_ratio", C.c_double),
         ("ls_c1", C.c_double), ("ls_rho_hi", C.c_double), ("ls_rho_lo", C.c_double),
-        ("ls_order", C.c_int32), ("ls_maxiters", C.c_int32),
+        ("ls_order", C.c_int32), ("ls_maxiters", C.c_int32), ("mg_nu", C.c_int32), ("mg_coarse", C.c_int32),
     ]
 
 
@@ -136,6 +136,7 @@ SIGNATURES = {
     "nk_gmres_set_operator_fn": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_right_preconditioner": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_chebyshev_preconditioner": (_I, [_P, _I, _D, _D, _D]),
+    "nk_gmres_set_multigrid_preconditioner": (_I, [_P, _P, _P, _I, _I, _I]),
     "nk_gmres_get_chebyshev_interval": (_I, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "nk_gmres_solve": (_I, [_P, _P, _P, _I, _I, _D, _D, _I, _I, C.POINTER(GmresInfo)]),
     "nk_lu_create": (_I, [_P, _PP]),

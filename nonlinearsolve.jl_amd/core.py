@@ -496,6 +496,15 @@ class ChebyshevPrecs:
 
 
 @dataclass
+class MultigridPrecs:
+    """`precs` for KrylovJL_GMRES on Bratu2D problems: one geometric multigrid V-cycle as the right preconditioner
+    (nu Chebyshev smoothing steps, coarsest grid side ≤ coarse_max, banded LU there) — the device counterpart of an
+    algebraic-multigrid `precs` (docs/src/tutorials/large_systems.md:244-316). Mesh-independent iteration counts."""
+    nu: int = 2
+    coarse_max: int = 63
+
+
+@dataclass
 class KrylovJL_GMRES:
     """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
     gmres_restart: int = 30
@@ -639,7 +648,9 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
         o.linesearch = 1
         o.ls_c1, o.ls_rho_hi, o.ls_rho_lo = float(lsr.c_1), float(lsr.rho_hi), float(lsr.rho_lo)
         o.ls_order, o.ls_maxiters = int(lsr.order), int(lsr.maxiters)
-    if getattr(ls, "precs", None) is not None:
+    if isinstance(getattr(ls, "precs", None), MultigridPrecs):
+        o.mg_nu, o.mg_coarse = int(ls.precs.nu), int(ls.precs.coarse_max)
+    elif getattr(ls, "precs", None) is not None:
         o.cheb_degree, o.cheb_ratio = int(ls.precs.degree), float(ls.precs.ratio)
     fo = getattr(alg, "forcing", None)
     if fo is not None:
@@ -889,6 +900,14 @@ class GMRES:
                                      ratio: float = 30.0):
         check(L.lib().nk_gmres_set_chebyshev_preconditioner(self._h, int(degree), float(lambda_min), float(lambda_max),
                                                             float(ratio)))
+        return self
+
+    def set_multigrid_preconditioner(self, problem, u, nu: int = 2, coarse_max: int = 63):
+        """One V-cycle of the built-in geometric multigrid (Bratu2D problems) as the right preconditioner, linearised at u."""
+        dp = problem.device_problem if hasattr(problem, "device_problem") else problem
+        pu, ms, keep = _ptr(u, self.n)
+        self._mg_u = (u, keep)  # the hierarchy keeps reading the fine-level u: keep it alive
+        check(L.lib().nk_gmres_set_multigrid_preconditioner(self._h, dp._h, pu, ms, int(nu), int(coarse_max)))
         return self
 
     def chebyshev_interval(self):

@@ -433,6 +433,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   if (!G) return NK_OK;
   hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
   hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb); hipFree(G->d_tprev); hipFree(G->d_red);
+  nk_mg_destroy(G->mg);
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
@@ -698,8 +699,36 @@ extern "C" int nk_gmres_get_chebyshev_interval(nk_gmres *G, double *lambda_min, 
   return NK_OK;
 }
 
+// Built-in multigrid V-cycle as the right preconditioner (Bratu problems, single rank): builds the hierarchy on first use,
+// afterwards only re-linearises it at `u` — call it again for every new Jacobian, like `precs(A, p)`.
+extern "C" int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P, const double *u, int memspace, int nu,
+                                                     int coarse_max) {
+  NK_REQUIRE(G, "NULL argument");
+  if (nu <= 0 || !P) {  // remove
+    G->prec_kind = G->prec ? 1 : 0;
+    return NK_OK;
+  }
+  NK_REQUIRE(u, "NULL argument");
+  NK_REQUIRE(G->op_kind != 0, "set the operator before the preconditioner");
+  NK_REQUIRE(P->n_local == G->n, "problem size %lld != GMRES size %lld", (long long)P->n_local, (long long)G->n);
+  NK_HIP(hipSetDevice(G->ctx->device));
+  const double *du = u;
+  if (memspace != NK_DEVICE) {
+    if (!G->d_u_own) NK_TRY(nk_dev_alloc(&G->d_u_own, (size_t)G->n + 1));
+    NK_HIP(hipMemcpyAsync(G->d_u_own, u, G->n * sizeof(double), hipMemcpyHostToDevice, G->ctx->stream));
+    du = G->d_u_own;
+  }
+  if (!G->mg) NK_TRY(nk_mg_create(P, nu, coarse_max, &G->mg));
+  NK_TRY(nk_problem_jvp_prepare(P, du));
+  NK_TRY(nk_mg_update(G->mg, du));
+  if (!G->z) NK_TRY(nk_dev_alloc(&G->z, (size_t)G->ldv));
+  G->prec_kind = 3;
+  return NK_OK;
+}
+
 static int prec_apply(nk_gmres *G, const double *src, double *dst, const int *d_skip) {
   if (G->prec_kind == 2) return cheb_apply(G, src, dst, d_skip);
+  if (G->prec_kind == 3) return nk_mg_apply(G->mg, src, dst, d_skip);
   if (G->prec(G->prec_user, src, dst, (void *)G->ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
   return NK_OK;
 }
@@ -733,7 +762,7 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
 // eligible: built-in linear operators (they take the un-normalised pending column as it is) and no callback preconditioner
 static bool dcgs2r_eligible(const nk_gmres *G) {
   const bool op_ok = (G->op_kind == 1) || (G->op_kind == 2 && G->P->kind != NK_PROBLEM_USER);
-  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2) && G->m <= 31 &&
+  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2 || G->prec_kind == 3) && G->m <= 31 &&
          G->n <= (int64_t)NK_MAX_ROW_TILES * NK_BLOCK * 8;
 }
 static bool use_dcgs2r(const nk_gmres *G) {

@@ -232,6 +232,14 @@ int nk_blas_lincomb(nk_ctx *ctx, int64_t n, double a, const double *x, double b,
 int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst);  // synchronises
 int nk_blas_minmax(nk_ctx *ctx, int64_t n, const double *x, double *d_out2 /*min,max*/);
 
+// ----------------------------------------------------------------------------- multigrid preconditioner (nk_mg.hip)
+struct nk_mg;
+int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out);
+int nk_mg_update(nk_mg *M, const double *d_u);
+int nk_mg_apply(nk_mg *M, const double *src, double *dst, const int *d_skip);
+int nk_mg_levels(const nk_mg *M);
+void nk_mg_destroy(nk_mg *M);
+
 // ----------------------------------------------------------------------------- GMRES
 struct nk_gmres_ctl {  // lives in device memory, mirrored to pinned host memory
   int done, k, converged, failed, need_reorth, pad0, pad1, pad2;
@@ -258,7 +266,8 @@ struct nk_gmres {
   void *fn_user = nullptr;
   nk_matvec_fn prec = nullptr;
   void *prec_user = nullptr;
-  int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial
+  int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle
+  struct nk_mg *mg = nullptr;
   int cheb_degree = 0;
   double cheb_lmin = 0, cheb_lmax = 0;
   double *cr = nullptr, *cd = nullptr, *ct = nullptr, *cd2 = nullptr;  // Chebyshev work vectors (cd/cd2 ping-pong)

@@ -1,0 +1,298 @@
+// Geometric multigrid V-cycle as a right preconditioner for the Bratu Jacobian — what the reference reaches through
+// `precs(A, p) -> (Pl, Pr)` with an AlgebraicMultigrid.jl preconditioner (docs/src/tutorials/large_systems.md:244-316;
+// hook: test/Core/core_tests__item21.jl:10-18). The Chebyshev polynomial (nk_gmres.hip) removes the restart stagnation
+// but its degree grows with the grid; a V-cycle keeps the Krylov iteration count mesh independent (7 at every size).
+//
+//   levels     n_l = n_{l−1}/2 interior points per side down to ≤ coarse_max; level operator by REDISCRETISATION:
+//              J_l = scale·(Δ_{h_l} − λ diag(exp(u_l))) with the fine level's `scale` and u_l = R u_{l−1} — each level is a
+//              Bratu problem object, so the matrix-free stencil JVP kernel serves every level
+//   transfers  bilinear interpolation at the points' physical positions (the grids need not be nested: n = 1024 → 512 →
+//              …); restriction = row-normalised transpose, evaluated as a gather (≤ 5×5 fine points per coarse point)
+//   smoother   ν steps of the Chebyshev iteration on [λmax/4, λmax], λmax = 8·scale/h_l² (Gershgorin for the stencil)
+//   coarsest   banded LU (nk_band.hip) of the assembled coarse Jacobian, refactored whenever u changes
+// Single rank, BRATU2D only in this round. Restated on the CPU by oracle/reference_restatement.py::BratuMultigrid.
+#include <math.h>
+
+#include <vector>
+
+#include "nk_internal.h"
+
+struct nk_mg_level {
+  int64_t ns = 0, n = 0;
+  nk_problem *P = nullptr;   // Bratu problem of this level (level 0: the caller's, not owned)
+  double *u = nullptr;       // linearisation point (level 0: the caller's vector, not owned)
+  double *b = nullptr, *x = nullptr, *r = nullptr, *d = nullptr, *t = nullptr;
+  double lmax = 0;
+  // transfers to / from the next coarser level
+  int32_t *pI0 = nullptr;    // per fine index: left coarse neighbour (−1 … nc−1)
+  double *pw1 = nullptr;     // weight of the right neighbour
+  int32_t *rlo = nullptr;    // per coarse index: first fine index of its support
+  double *rw = nullptr;      // 5 normalised 1-D weights per coarse index
+};
+struct nk_mg {
+  nk_ctx *ctx = nullptr;
+  int nu = 2;
+  std::vector<nk_mg_level> lv;
+  nk_csr *Jc = nullptr;
+  nk_bandlu *LU = nullptr;
+};
+
+// ----------------------------------------------------------------------------- kernels
+#define MG_SKIP(p) if ((p) != nullptr && *(p) != 0) return
+// x_f += P e_c   (bilinear, homogeneous Dirichlet: neighbours outside the coarse grid are zero)
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_prolong_add(int nf, int nc, const int32_t *__restrict__ I0,
+                                                             const double *__restrict__ w1, const double *__restrict__ ec,
+                                                             double *__restrict__ xf, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= nf * nf) return;
+  const int j = k / nf, i = k - j * nf;
+  const int Il = I0[i], Jl = I0[j];
+  const double wi1 = w1[i], wi0 = 1.0 - wi1, wj1 = w1[j], wj0 = 1.0 - wj1;
+  // clamped loads + 0/1 masks keep the four loads unconditional
+  const int ia = Il < 0 ? 0 : Il, ib = Il + 1 >= nc ? nc - 1 : Il + 1;
+  const int ja = Jl < 0 ? 0 : Jl, jb = Jl + 1 >= nc ? nc - 1 : Jl + 1;
+  const double ma = Il >= 0 ? 1.0 : 0.0, mb = Il + 1 < nc ? 1.0 : 0.0, na = Jl >= 0 ? 1.0 : 0.0, nb = Jl + 1 < nc ? 1.0 : 0.0;
+  const double v = wj0 * na * (wi0 * ma * ec[ja * nc + ia] + wi1 * mb * ec[ja * nc + ib]) +
+                   wj1 * nb * (wi0 * ma * ec[jb * nc + ia] + wi1 * mb * ec[jb * nc + ib]);
+  xf[k] += v;
+}
+// r_c = R r_f, R = row-normalised Pᵀ = (tensor product of the 1-D normalised weights)
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_restrict(int nf, int nc, const int32_t *__restrict__ lo,
+                                                          const double *__restrict__ w, const double *__restrict__ rf,
+                                                          double *__restrict__ rc, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= nc * nc) return;
+  const int J = k / nc, I = k - J * nc;
+  const int i0 = lo[I], j0 = lo[J];
+  double s = 0.0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    const int j = min(j0 + b, nf - 1);
+    const double wj = w[J * 5 + b];
+    double row = 0.0;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) row += w[I * 5 + a] * rf[j * nf + min(i0 + a, nf - 1)];
+    s += wj * row;
+  }
+  rc[k] = s;
+}
+// Chebyshev smoother pieces
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_resid(int64_t n, const double *__restrict__ b, const double *__restrict__ Jx,
+                                                       double *__restrict__ r, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) r[i] = b[i] - Jx[i];
+}
+// d = r/θ ; x = (zero ? 0 : x) + d
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_first(int64_t n, const double *__restrict__ r, double inv_theta, int zero,
+                                                            double *__restrict__ d, double *__restrict__ x, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double dd = r[i] * inv_theta;
+  d[i] = dd;
+  x[i] = zero ? dd : x[i] + dd;
+}
+// r −= J d ; d = c1 d + c2 r ; x += d
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_next(int64_t n, const double *__restrict__ Jd, double c1, double c2,
+                                                           double *__restrict__ r, double *__restrict__ d, double *__restrict__ x,
+                                                           const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double rr = r[i] - Jd[i];
+  const double dd = c1 * d[i] + c2 * rr;
+  r[i] = rr;
+  d[i] = dd;
+  x[i] += dd;
+}
+
+static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + NK_BLOCK - 1) / NK_BLOCK)); }
+
+// ----------------------------------------------------------------------------- setup
+static void interp_tables(int nf, int nc, std::vector<int32_t> &I0, std::vector<double> &w1, std::vector<int32_t> &lo,
+                          std::vector<double> &w) {
+  const double h = 1.0 / (nf + 1), H = 1.0 / (nc + 1);
+  I0.resize(nf);
+  w1.resize(nf);
+  for (int i = 0; i < nf; ++i) {
+    const double t = (i + 1) * h / H;  // coarse coordinate (coarse interior point I, 1-based, sits at t = I)
+    const int fl = (int)floor(t);
+    I0[i] = fl - 1;                    // 0-based left neighbour; −1 / nc are the zero boundary values
+    w1[i] = t - fl;
+  }
+  lo.assign(nc, 0);
+  w.assign((size_t)nc * 5, 0.0);
+  std::vector<double> sum(nc, 0.0);
+  std::vector<int> first(nc, -1);
+  for (int i = 0; i < nf; ++i)
+    for (int side = 0; side < 2; ++side) {
+      const int I = I0[i] + side;
+      const double wt = side ? w1[i] : 1.0 - w1[i];
+      if (I < 0 || I >= nc || wt == 0.0) continue;
+      if (first[I] < 0) first[I] = i;
+      const int a = i - first[I];
+      if (a < 5) w[(size_t)I * 5 + a] += wt;
+      sum[I] += wt;
+    }
+  for (int I = 0; I < nc; ++I) {
+    lo[I] = first[I] < 0 ? 0 : first[I];
+    for (int a = 0; a < 5; ++a) w[(size_t)I * 5 + a] /= (sum[I] > 0.0 ? sum[I] : 1.0);
+  }
+}
+
+void nk_mg_destroy(nk_mg *M) {
+  if (!M) return;
+  for (size_t l = 0; l < M->lv.size(); ++l) {
+    nk_mg_level &L = M->lv[l];
+    if (l > 0) { nk_problem_destroy(L.P); hipFree(L.u); }
+    hipFree(L.b); hipFree(L.x); hipFree(L.r); hipFree(L.d); hipFree(L.t);
+    hipFree(L.pI0); hipFree(L.pw1); hipFree(L.rlo); hipFree(L.rw);
+  }
+  if (M->LU) nk_bandlu_destroy(M->LU);
+  if (M->Jc) nk_csr_destroy(M->Jc);
+  delete M;
+}
+
+// build the hierarchy for problem P (level vectors, transfer tables, level problems); values follow in nk_mg_update
+int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
+  nk_ctx *ctx = P->ctx;
+  NK_REQUIRE(P->kind == NK_PROBLEM_BRATU2D, "the multigrid preconditioner is built for BRATU2D problems");
+  NK_REQUIRE(ctx->nranks == 1, "the multigrid preconditioner is single-rank in this round");
+  NK_REQUIRE(P->ns < 46000, "grid too large for 32-bit point indices");
+  if (nu <= 0) nu = 2;
+  if (coarse_max < 3) coarse_max = 63;
+  nk_mg *M = new nk_mg();
+  M->ctx = ctx;
+  M->nu = nu;
+  const double hf = 1.0 / (double)(P->ns + 1);
+  const double scale = P->c_lap * hf * hf, lambda = P->params[1];
+  int64_t ns = P->ns;
+  for (int l = 0;; ++l) {
+    nk_mg_level L;
+    L.ns = ns;
+    L.n = ns * ns;
+    const double h = 1.0 / (double)(ns + 1);
+    L.lmax = 8.0 * scale / (h * h);
+    if (l == 0) L.P = P;
+    else {
+      const double par[3] = {(double)ns, lambda, scale};
+      if (nk_problem_create(ctx, NK_PROBLEM_BRATU2D, par, 3, &L.P) != NK_OK) { nk_mg_destroy(M); return NK_E_HIP; }
+      NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
+    }
+    NK_TRY(nk_dev_alloc(&L.b, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.x, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.r, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.d, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.t, (size_t)L.n + 1));
+    const bool coarsest = ns <= coarse_max || ns / 2 < 3;
+    if (!coarsest) {
+      const int nf = (int)ns, nc = (int)(ns / 2);
+      std::vector<int32_t> I0, lo;
+      std::vector<double> w1, w;
+      interp_tables(nf, nc, I0, w1, lo, w);
+      NK_TRY(nk_dev_alloc(&L.pI0, (size_t)nf));
+      NK_TRY(nk_dev_alloc(&L.pw1, (size_t)nf));
+      NK_TRY(nk_dev_alloc(&L.rlo, (size_t)nc));
+      NK_TRY(nk_dev_alloc(&L.rw, (size_t)nc * 5));
+      NK_HIP(hipMemcpy(L.pI0, I0.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
+      NK_HIP(hipMemcpy(L.pw1, w1.data(), nf * sizeof(double), hipMemcpyHostToDevice));
+      NK_HIP(hipMemcpy(L.rlo, lo.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
+      NK_HIP(hipMemcpy(L.rw, w.data(), (size_t)nc * 5 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    M->lv.push_back(L);
+    if (coarsest) break;
+    ns /= 2;
+  }
+  nk_mg_level &C = M->lv.back();
+  if (M->lv.size() > 1) {
+    NK_TRY(nk_problem_jac_csr(C.P, &M->Jc));
+    NK_TRY(nk_bandlu_create(M->Jc, &M->LU));
+  }
+  *out = M;
+  return NK_OK;
+}
+
+// new linearisation point: restrict u down the hierarchy, refresh exp(u_l) of every level, refactor the coarsest J
+int nk_mg_update(nk_mg *M, const double *d_u) {
+  nk_ctx *ctx = M->ctx;
+  M->lv[0].u = const_cast<double *>(d_u);
+  for (size_t l = 0; l + 1 < M->lv.size(); ++l) {
+    nk_mg_level &F = M->lv[l], &Cc = M->lv[l + 1];
+    NK_LAUNCH(ctx, k_mg_restrict, g1(Cc.n), dim3(NK_BLOCK), (int)F.ns, (int)Cc.ns, (const int32_t *)F.rlo, (const double *)F.rw,
+              (const double *)F.u, Cc.u, (const int *)nullptr);
+  }
+  for (size_t l = 1; l < M->lv.size(); ++l) NK_TRY(nk_problem_jvp_prepare(M->lv[l].P, M->lv[l].u));
+  if (M->LU) {
+    nk_mg_level &C = M->lv.back();
+    NK_TRY(nk_problem_jac_values_dev(C.P, C.u, M->Jc));
+    int ok = 0;
+    NK_TRY(nk_bandlu_factor(M->LU, M->Jc, &ok));
+    NK_REQUIRE(ok, "multigrid: the coarsest Jacobian has a zero pivot");
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+// ν Chebyshev steps for J_l x = b on [λmax/4, λmax]; zero_guess: x starts at 0 (then r = b)
+static int mg_smooth(nk_mg *M, nk_mg_level &L, bool zero_guess, const int *d_skip) {
+  nk_ctx *ctx = M->ctx;
+  const double lmax = L.lmax, lmin = lmax / 4.0;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  const double *r0 = L.b;
+  if (!zero_guess) {
+    NK_TRY(nk_problem_jvp_dev(L.P, L.u, L.x, L.t, d_skip));
+    NK_LAUNCH(ctx, k_mg_resid, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.b, (const double *)L.t, L.r, d_skip);
+    r0 = L.r;
+  } else if (M->nu > 1) {
+    NK_TRY(nk_blas_copy(ctx, L.n, L.b, L.r));  // the recurrence below updates r in place
+    r0 = L.r;
+  }
+  NK_LAUNCH(ctx, k_mg_cheb_first, g1(L.n), dim3(NK_BLOCK), L.n, r0, 1.0 / theta, zero_guess ? 1 : 0, L.d, L.x, d_skip);
+  for (int k = 1; k < M->nu; ++k) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    NK_TRY(nk_problem_jvp_dev(L.P, L.u, L.d, L.t, d_skip));
+    NK_LAUNCH(ctx, k_mg_cheb_next, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.t, rho_new * rho, 2.0 * rho_new / delta, L.r,
+              L.d, L.x, d_skip);
+    rho = rho_new;
+  }
+  return NK_OK;
+}
+
+// dst = V-cycle(src)
+int nk_mg_apply(nk_mg *M, const double *src, double *dst, const int *d_skip) {
+  nk_ctx *ctx = M->ctx;
+  const int nl = (int)M->lv.size();
+  if (nl == 1) {  // a single (small) level: smoothing only
+    nk_mg_level &L = M->lv[0];
+    NK_TRY(nk_blas_copy(ctx, L.n, src, L.b));
+    NK_TRY(mg_smooth(M, L, true, d_skip));
+    return nk_blas_copy(ctx, L.n, L.x, dst);
+  }
+  NK_TRY(nk_blas_copy(ctx, M->lv[0].n, src, M->lv[0].b));
+  for (int l = 0; l + 1 < nl; ++l) {
+    nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
+    NK_TRY(mg_smooth(M, F, true, d_skip));
+    NK_TRY(nk_problem_jvp_dev(F.P, F.u, F.x, F.t, d_skip));
+    NK_LAUNCH(ctx, k_mg_resid, g1(F.n), dim3(NK_BLOCK), F.n, (const double *)F.b, (const double *)F.t, F.r, d_skip);
+    NK_LAUNCH(ctx, k_mg_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.rlo, (const double *)F.rw,
+              (const double *)F.r, C.b, d_skip);
+  }
+  {
+    nk_mg_level &C = M->lv[nl - 1];
+    NK_TRY(nk_bandlu_solve(M->LU, C.b, C.x));
+  }
+  for (int l = nl - 2; l >= 0; --l) {
+    nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
+    NK_LAUNCH(ctx, k_mg_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.pI0, (const double *)F.pw1,
+              (const double *)C.x, F.x, d_skip);
+    NK_TRY(mg_smooth(M, F, false, d_skip));
+  }
+  NK_HIP(hipGetLastError());
+  return nk_blas_copy(ctx, M->lv[0].n, M->lv[0].x, dst);
+}
+
+int nk_mg_levels(const nk_mg *M) { return (int)M->lv.size(); }

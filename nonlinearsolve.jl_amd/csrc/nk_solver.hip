@@ -186,6 +186,8 @@ extern "C" int nk_options_default(nk_options *o) {
   o->ls_rho_lo = 0.1;
   o->ls_order = 3;
   o->ls_maxiters = 1000;
+  o->mg_nu = 0;
+  o->mg_coarse = 0;
   return NK_OK;
 }
 
@@ -796,6 +798,8 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     new_jacobian = true;
     if (!direct(S) && S->o.cheb_degree > 0)  // precs(A, p) is re-evaluated for every new A
       NK_TRY(nk_gmres_set_chebyshev_preconditioner(S->G, S->o.cheb_degree, 0.0, 0.0, S->o.cheb_ratio));
+    if (!direct(S) && S->o.mg_nu > 0)
+      NK_TRY(nk_gmres_set_multigrid_preconditioner(S->G, S->P, S->u, NK_DEVICE, S->o.mg_nu, S->o.mg_coarse));
   } else {
     new_jacobian = false;
   }

@@ -510,6 +510,87 @@ def gmres_dcgs2_1r(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=3
 
 
 # ----------------------------------------------------------------------------- algorithm descriptors
+class BratuMultigrid:
+    """Geometric multigrid V-cycle for the Bratu Jacobian, the CPU restatement of csrc/nk_mg.hip (what a user would plug in
+    through `precs(A, p)`, docs/src/tutorials/large_systems.md:244-316, with an AMG preconditioner). Levels n_l = n_{l−1}//2
+    down to ≤ coarse_max; J_l by rediscretisation with the fine level's scale and u_l = R u_{l−1}; bilinear interpolation at
+    the points' physical positions (grids need not be nested), restriction = row-normalised transpose; ν Chebyshev steps
+    on [λmax/4, λmax], λmax = 8·scale/h_l²; sparse LU on the coarsest grid."""
+
+    def __init__(self, prob: "Bratu2D", u, nu=2, coarse_max=63):
+        import scipy.sparse.linalg as spla
+        self.nu = int(nu) if nu > 0 else 2
+        coarse_max = coarse_max if coarse_max >= 3 else 63
+        scale = prob.c_lap * prob.h * prob.h
+        self.levels = []
+        ns, ul = prob.ns, np.asarray(u, dtype=np.float64)
+        while True:
+            pl = Bratu2D(ns, prob.lam, scale)
+            lev = dict(ns=ns, J=sp.csr_matrix(pl.jac(ul)), lmax=8.0 * scale / (pl.h * pl.h))
+            self.levels.append(lev)
+            if ns <= coarse_max or ns // 2 < 3:
+                break
+            nc = ns // 2
+            P1 = self._interp1d(ns, nc)
+            P = sp.kron(P1, P1).tocsr()                      # lexicographic k = j·n + i
+            Rm = P.T.tocsr()
+            Rm = sp.diags(1.0 / np.asarray(Rm.sum(axis=1)).ravel()) @ Rm
+            lev["P"], lev["R"] = P, sp.csr_matrix(Rm)
+            ul = lev["R"] @ ul
+            ns = nc
+        self.lu = spla.splu(sp.csc_matrix(self.levels[-1]["J"])) if len(self.levels) > 1 else None
+
+    @staticmethod
+    def _interp1d(nf, nc):
+        h, H = 1.0 / (nf + 1), 1.0 / (nc + 1)
+        rows, cols, vals = [], [], []
+        for i in range(nf):
+            t = (i + 1) * h / H
+            fl = int(math.floor(t))
+            w1 = t - fl
+            for I, w in ((fl - 1, 1.0 - w1), (fl, w1)):      # 0-based coarse neighbours; outside = zero boundary
+                if 0 <= I < nc and w != 0.0:
+                    rows.append(i), cols.append(I), vals.append(w)
+        return sp.csr_matrix((vals, (rows, cols)), shape=(nf, nc))
+
+    def _smooth(self, lev, x, b, zero_guess):
+        lmax, lmin = lev["lmax"], lev["lmax"] / 4.0
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        rho = 1.0 / sigma
+        J = lev["J"]
+        r = b.copy() if zero_guess else b - J @ x
+        d = r / theta
+        x = d.copy() if zero_guess else x + d
+        for _ in range(1, self.nu):
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            r = r - J @ d
+            d = rho_new * rho * d + 2.0 * rho_new / delta * r
+            x = x + d
+            rho = rho_new
+        return x
+
+    def __call__(self, v):
+        L = self.levels
+        if len(L) == 1:
+            return self._smooth(L[0], None, v, True)
+        bs, xs = [np.asarray(v, dtype=np.float64)], []
+        for l in range(len(L) - 1):
+            x = self._smooth(L[l], None, bs[l], True)
+            xs.append(x)
+            bs.append(L[l]["R"] @ (bs[l] - L[l]["J"] @ x))
+        e = self.lu.solve(bs[-1])
+        for l in range(len(L) - 2, -1, -1):
+            e = self._smooth(L[l], xs[l] + L[l]["P"] @ e, bs[l], False)
+        return e
+
+
+@dataclass
+class MultigridPrecs:
+    nu: int = 2
+    coarse_max: int = 63
+
+
 @dataclass
 class ChebyshevPrecs:
     degree: int = 16
@@ -806,7 +887,9 @@ class FirstOrderCache:
             kr = self.krylov
             u_now = self.u
             M = None
-            if kr.precs is not None:  # precs(A, p) re-evaluated for the current J (concrete J: Gershgorin bound)
+            if isinstance(kr.precs, MultigridPrecs):  # precs(A, p) re-evaluated at the current u
+                M = BratuMultigrid(self.prob, u_now, kr.precs.nu, kr.precs.coarse_max)
+            elif kr.precs is not None:  # precs(A, p) re-evaluated for the current J (concrete J: Gershgorin bound)
                 assert self.concrete, "the oracle's Chebyshev precs needs a concrete J (Gershgorin bound)"
                 lmax = gershgorin_lambda(self.J)
                 M = chebyshev_preconditioner(lambda v: self._apply_J(v, u_now), lmax / kr.precs.ratio, lmax,

@@ -738,3 +738,46 @@ def test_newton_fails_converges_with_trust_region_on_device(nls, dev):
     ref = R.solve(R.FunctionProblem(lambda u: nf(u), u0, jac=lambda u: sp.diags((nf(u + 1e-7) - nf(u - 1e-7)) / 2e-7)),
                   R.TrustRegion(), abstol=1e-9)
     assert np.max(np.abs(sol.u.cpu().numpy() - ref.u)) < 1e-5   # same root as the oracle (FD Jacobians on both sides)
+
+
+# ------------------------------------------------------------------ geometric multigrid `precs`
+@pytest.mark.parametrize("ns,coarse", [(64, 15), (100, 15), (127, 31), (33, 8)])
+def test_multigrid_preconditioner_vs_oracle(nls, ns, coarse):
+    """The built-in V-cycle (rediscretised level operators, bilinear transfers between non-nested grids, Chebyshev
+    smoothing, banded LU on the coarsest grid) applied to a vector, and right-preconditioned GMRES with it, agree with the
+    oracle's restatement; the iteration count does not grow with the grid (7 ± 1)."""
+    pb = R.Bratu2D(ns, 6.0)
+    xs = np.arange(1, ns + 1) / (ns + 1)
+    X, Y = np.meshgrid(xs, xs)
+    u = (0.8 * np.sin(np.pi * X) * np.sin(np.pi * Y)).ravel()
+    J = pb.jac(u)
+    b = np.random.default_rng(0).standard_normal(pb.n)
+    Mo = R.BratuMultigrid(pb, u, 2, coarse)
+    P = nls.Bratu2D(ns, 6.0)
+    prob = nls.NonlinearProblem(P)
+    op = nls.StatefulJacobianOperator(nls.JacobianOperator(prob), u)
+    G = nls.GMRES(pb.n, restart=30).set_operator(op)
+    G.set_multigrid_preconditioner(P, u, nu=2, coarse_max=coarse)
+    # one preconditioner application = GMRES's first direction; compare through a 1-step solve and a full solve
+    xo, io = R.gmres(lambda z: J @ z, b, rtol=1e-9, restart=30, itmax=300, M=Mo, ortho="cgs2")
+    x, info = G.solve(b, abstol=0.0, reltol=1e-9, maxiters=300)
+    assert info["converged"] and abs(info["iters"] - io.iters) <= 1 and info["iters"] <= 9
+    assert np.linalg.norm(x - xo) <= 1e-7 * np.linalg.norm(xo)
+    assert np.linalg.norm(J @ x - b) <= 1.01e-9 * np.linalg.norm(b)
+    x1, i1 = G.solve(b, fixed_iters=1)
+    xo1, _ = R.gmres(lambda z: J @ z, b, restart=30, fixed_iters=1, M=Mo, ortho="cgs2")
+    assert np.linalg.norm(x1 - xo1) <= 1e-10 * np.linalg.norm(xo1)     # V-cycle itself: agreement to rounding
+
+
+@pytest.mark.parametrize("concrete", [False, True])
+def test_bratu_newton_with_multigrid_precs_vs_oracle(nls, concrete):
+    ns = 128
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 15)), forcing=nls.EisenstatWalkerForcing2(),
+                            concrete_jac=concrete)
+    sol = nls.solve(nls.NonlinearProblem(nls.Bratu2D(ns, 6.0)), alg, abstol=1e-8, maxiters=50)
+    ref = R.solve(R.Bratu2D(ns), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=R.MultigridPrecs(2, 15)),
+                                                forcing=R.EisenstatWalkerForcing2(), concrete_jac=concrete), abstol=1e-8, maxiters=50)
+    assert sol.retcode == "Success" and np.max(np.abs(sol.resid)) <= 1e-8
+    assert sol.stats.nsteps == ref.stats.nsteps and abs(sol.stats.gmres_iters - ref.stats.gmres_iters) <= 2
+    assert sol.stats.gmres_iters <= 3 * sol.stats.nsteps          # ≈ one or two Krylov iterations per Newton step
+    assert uerr(sol.u, ref.u) <= 1e-6
