@@ -210,6 +210,19 @@ def main():
                "cpu_gmres_iters": int(giC.sum()), "cpu_cores": CO.num_threads(),
                "u_maxdiff_gpu_vs_cpu": float(np.max(np.abs(sol2.u.cpu().numpy() - uC))),
                "speedup": round(tc2 / tg, 1)}
+        # the same solve with the built-in geometric multigrid V-cycle behind the `precs` hook (GPU only: the C oracle has
+        # no multigrid; its NumPy restatement pins iteration counts at small sizes in the tests)
+        alg3 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(2, 63)),
+                                 forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
+        nls.solve(prob2, alg3, abstol=1e-8, maxiters=50)
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        sol3 = nls.solve(prob2, alg3, abstol=1e-8, maxiters=50)
+        torch.cuda.synchronize()
+        tm = time.perf_counter() - tm
+        ttt["multigrid_precs"] = {"gpu_seconds": round(tm, 4), "gpu_newton_steps": sol3.stats.nsteps,
+                                  "gpu_gmres_iters": sol3.stats.gmres_iters, "gpu_retcode": sol3.retcode,
+                                  "u_maxdiff_vs_chebyshev_run": float((sol3.u - sol2.u).abs().max())}
 
     line = None
     if rank == 0:
