@@ -391,6 +391,13 @@ int nk_batch_destroy(nk_batch *B);
  * nbatch, nbatch (retcode/iters nullable); abstol ≤ 0 and maxiters ≤ 0 select the defaults. */
 int nk_batch_solve(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int memspace,
                    double abstol, int maxiters, double *u_out, double *resid_out, int32_t *retcode_out, int32_t *iters_out);
+/* SimpleTrustRegion (lib/SimpleNonlinearSolve/src/trust_region.jl:57-229, default radius update) per system; thresholds and
+ * factors ≤ 0, max_shrink_times < 0 select the reference defaults (1e-4, 0.25, 0.75, 0.25, 2, 32). Retcodes: NK_RET_SUCCESS,
+ * NK_RET_MAXITERS, NK_RET_SHRINK_THRESHOLD_EXCEEDED. */
+int nk_batch_solve_trust_region(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int memspace,
+                                double abstol, int maxiters, double step_threshold, double shrink_threshold,
+                                double expand_threshold, double shrink_factor, double expand_factor, int max_shrink_times,
+                                double *u_out, double *resid_out, int32_t *retcode_out, int32_t *iters_out);
 
 /* ---------------------------------------------------------------- BLAS-1 building blocks (exported for
  * the bench / tests; all on the ctx stream, results of reductions are all-reduced over the ranks) */

@@ -148,6 +148,7 @@ SIGNATURES = {
     "nk_batch_create": (_I, [_P, C.c_char_p, _I, _I, _I, _PP]),
     "nk_batch_destroy": (_I, [_P]),
     "nk_batch_solve": (_I, [_P, _L, _P, _I, _P, _I, _D, _I, _P, _P, _P, _P]),
+    "nk_batch_solve_trust_region": (_I, [_P, _L, _P, _I, _P, _I, _D, _I, _D, _D, _D, _D, _D, _I, _P, _P, _P, _P]),
     "nk_options_default": (_I, [C.POINTER(Options)]),
     "nk_solver_init": (_I, [_P, _P, _I, C.POINTER(Options), _PP]),
     "nk_solver_destroy": (_I, [_P]),

@@ -989,6 +989,19 @@ class SimpleNewtonRaphson:
     name: str = "SimpleNewtonRaphson"
 
 
+@dataclass
+class SimpleTrustRegion:
+    """lib/SimpleNonlinearSolve/src/trust_region.jl:44-55 (default radius update rule); None = reference default."""
+    jac: bool = False
+    step_threshold: float = 1e-4
+    shrink_threshold: Optional[float] = None   # 0.25
+    expand_threshold: Optional[float] = None   # 0.75
+    shrink_factor: Optional[float] = None      # 0.25
+    expand_factor: float = 2.0
+    max_shrink_times: int = 32
+    name: str = "SimpleTrustRegion"
+
+
 class ImmutableNonlinearProblem:
     """SciMLBase.ImmutableNonlinearProblem{false}(f, u0, p) for the kernel-generation path
     (docs/src/tutorials/nonlinear_solve_gpus.md:120-140). `f_source` is HIP C++ defining
@@ -1031,7 +1044,7 @@ class _BatchKernel:
         return cls._cache[key]
 
 
-def vectorized_solve(prob: ImmutableNonlinearProblem, alg: SimpleNewtonRaphson = None, abstol=None, maxiters=1000):
+def vectorized_solve(prob: ImmutableNonlinearProblem, alg=None, abstol=None, maxiters=1000):
     """`vectorized_solve(prob, alg; backend = ROCBackend())` of the tutorial (nonlinear_solve_gpus.md:106-114): solve
     every parameter set with SimpleNewtonRaphson, one system per GPU thread, in one kernel launch."""
     alg = alg or SimpleNewtonRaphson()
@@ -1055,8 +1068,16 @@ def vectorized_solve(prob: ImmutableNonlinearProblem, alg: SimpleNewtonRaphson =
         rc, it = np.empty(nb, dtype=np.int32), np.empty(nb, dtype=np.int32)
         ptr = lambda x: C.c_void_p(x.ctypes.data)
         ms = L.HOST
-    check(L.lib().nk_batch_solve(h, nb, ptr(u0), 1 if prob.u0_per_system else 0, ptr(pp), ms,
-                                 0.0 if abstol is None else float(abstol), int(maxiters), ptr(u), ptr(r), ptr(rc), ptr(it)))
+    if isinstance(alg, SimpleTrustRegion):
+        d = lambda v: -1.0 if v is None else float(v)
+        check(L.lib().nk_batch_solve_trust_region(h, nb, ptr(u0), 1 if prob.u0_per_system else 0, ptr(pp), ms,
+                                                  0.0 if abstol is None else float(abstol), int(maxiters),
+                                                  d(alg.step_threshold), d(alg.shrink_threshold), d(alg.expand_threshold),
+                                                  d(alg.shrink_factor), d(alg.expand_factor), int(alg.max_shrink_times),
+                                                  ptr(u), ptr(r), ptr(rc), ptr(it)))
+    else:
+        check(L.lib().nk_batch_solve(h, nb, ptr(u0), 1 if prob.u0_per_system else 0, ptr(pp), ms,
+                                     0.0 if abstol is None else float(abstol), int(maxiters), ptr(u), ptr(r), ptr(rc), ptr(it)))
     rch = rc.cpu().numpy() if on_dev else rc
     ith = it.cpu().numpy() if on_dev else it
     return EnsembleSolution(u, r, np.asarray(L.RET_NAMES)[rch], ith.copy(), rch.copy())

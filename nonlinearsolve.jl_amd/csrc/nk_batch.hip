@@ -180,6 +180,97 @@ nk_batch_newton(long nbatch, const double *__restrict__ u0, int u0_per_system, c
   retcode[b] = rc;
   iters[b] = it;
 }
+// ---- SimpleTrustRegion (lib/SimpleNonlinearSolve/src/trust_region.jl:57-229, default update rule): dogleg step
+// (Newton step if inside the region, else −g clipped to Δ, else the boundary point of the segment), ratio
+// r = (f_{k+1} − f_k)/(δ·g + δ·Hδ/2) with H = JᵀJ, g = Jᵀf; shrink by t₁ when r < η₂ (ShrinkThresholdExceeded after
+// max_shrink consecutive shrinks), accept when r ≥ η₁ (termination test on the NEW residual, then J, g at the new point,
+// expand by t₂ up to Δmax when r > η₃). Δmax = max(‖f(u0)‖₂, max(u0) − min(u0)), Δ0 = Δmax/11.
+__device__ inline double nk_norm2(const double *v) {
+  double s = 0.0;
+  NK_UNROLL for (int i = 0; i < NK_N; ++i) s += v[i] * v[i];
+  return sqrt(s);
+}
+extern "C" __global__ void __launch_bounds__(NK_BLOCK_T)
+nk_batch_trust_region(long nbatch, const double *__restrict__ u0, int u0_per_system, const double *__restrict__ p, double abstol,
+                      int maxiters, double eta1, double eta2, double eta3, double t1, double t2, int max_shrink,
+                      double *__restrict__ u_out, double *__restrict__ r_out, int *__restrict__ retcode, int *__restrict__ iters) {
+  const long b = (long)blockIdx.x * NK_BLOCK_T + threadIdx.x;
+  if (b >= nbatch) return;
+  double x[NK_N], xo[NK_N], fx[NK_N], g[NK_N], dl[NK_N], dN[NK_N], dsd[NK_N], tmp[NK_N], pp[NK_NP > 0 ? NK_NP : 1];
+  double J[NK_N][NK_N], A[NK_N][NK_N];
+  NK_UNROLL for (int i = 0; i < NK_N; ++i) { x[i] = u0[(u0_per_system ? b * NK_N : 0) + i]; xo[i] = x[i]; }
+  NK_UNROLL for (int i = 0; i < NK_NP; ++i) pp[i] = p[b * NK_NP + i];
+  nk_f<double>(x, pp, fx);
+  const double norm_fx = nk_norm2(fx);
+  nk_jacobian(x, pp, J);
+  double xmax = x[0], xmin = x[0];
+  NK_UNROLL for (int i = 1; i < NK_N; ++i) { xmax = x[i] > xmax ? x[i] : xmax; xmin = x[i] < xmin ? x[i] : xmin; }
+  const double dmax = norm_fx > xmax - xmin ? norm_fx : xmax - xmin;
+  double delta = dmax / 11.0;
+  double fk = 0.5 * norm_fx * norm_fx;
+  NK_UNROLL for (int i = 0; i < NK_N; ++i) { double s = 0.0; NK_UNROLL for (int k = 0; k < NK_N; ++k) s += J[k][i] * fx[k]; g[i] = s; }
+  int shrink = 0, rc = 2, it = 0;
+  auto absmax_ok = [&](const double *f) {
+    double nrm = 0.0; bool nan = false;
+    NK_UNROLL for (int i = 0; i < NK_N; ++i) { const double a = fabs(f[i]); nan = nan || (a != a); nrm = a > nrm ? a : nrm; }
+    return !nan && nrm <= abstol;
+  };
+  if (absmax_ok(fx)) rc = 1;
+  else {
+    for (it = 1; it <= maxiters; ++it) {
+      // dogleg
+      NK_UNROLL for (int i = 0; i < NK_N; ++i) { tmp[i] = fx[i]; NK_UNROLL for (int k = 0; k < NK_N; ++k) A[i][k] = J[i][k]; }
+      nk_lu_solve(A, tmp, dN);
+      NK_UNROLL for (int i = 0; i < NK_N; ++i) dN[i] = -dN[i];
+      if (nk_norm2(dN) <= delta) {
+        NK_UNROLL for (int i = 0; i < NK_N; ++i) dl[i] = dN[i];
+      } else {
+        NK_UNROLL for (int i = 0; i < NK_N; ++i) dsd[i] = -g[i];
+        const double nsd = nk_norm2(dsd);
+        if (nsd >= delta) {
+          NK_UNROLL for (int i = 0; i < NK_N; ++i) dl[i] = dsd[i] * (delta / nsd);
+        } else {
+          double dNN = 0.0, dSN = 0.0, dSS = 0.0;
+          NK_UNROLL for (int i = 0; i < NK_N; ++i) { const double q = dN[i] - dsd[i]; dNN += q * q; dSN += dsd[i] * q; dSS += dsd[i] * dsd[i]; }
+          const double fact = dSN * dSN - dNN * (dSS - delta * delta);
+          const double tau = (-dSN + sqrt(fact)) / dNN;
+          NK_UNROLL for (int i = 0; i < NK_N; ++i) dl[i] = dsd[i] + tau * (dN[i] - dsd[i]);
+        }
+      }
+      NK_UNROLL for (int i = 0; i < NK_N; ++i) x[i] = xo[i] + dl[i];
+      nk_f<double>(x, pp, fx);
+      const double nf = nk_norm2(fx);
+      const double fk1 = nf * nf / 2.0;
+      // Hδ = Jᵀ(Jδ)
+      NK_UNROLL for (int i = 0; i < NK_N; ++i) { double s = 0.0; NK_UNROLL for (int k = 0; k < NK_N; ++k) s += J[i][k] * dl[k]; tmp[i] = s; }
+      double dg = 0.0, dHd = 0.0;
+      NK_UNROLL for (int i = 0; i < NK_N; ++i) {
+        double s = 0.0;
+        NK_UNROLL for (int k = 0; k < NK_N; ++k) s += J[k][i] * tmp[k];
+        dHd += dl[i] * s;
+        dg += dl[i] * g[i];
+      }
+      const double r = (fk1 - fk) / (dg + dHd / 2.0);
+      if (r >= eta2) shrink = 0;
+      else {
+        delta = t1 * delta;
+        if (++shrink > max_shrink) { rc = 6; break; }   // ShrinkThresholdExceeded
+      }
+      if (r >= eta1) {
+        if (absmax_ok(fx)) { rc = 1; break; }
+        NK_UNROLL for (int i = 0; i < NK_N; ++i) xo[i] = x[i];
+        nk_jacobian(x, pp, J);
+        if (r > eta3) delta = t2 * delta < dmax ? t2 * delta : dmax;
+        fk = fk1;
+        NK_UNROLL for (int i = 0; i < NK_N; ++i) { double s = 0.0; NK_UNROLL for (int k = 0; k < NK_N; ++k) s += J[k][i] * fx[k]; g[i] = s; }
+      }
+    }
+    if (it > maxiters) it = maxiters;
+  }
+  NK_UNROLL for (int i = 0; i < NK_N; ++i) { u_out[b * NK_N + i] = x[i]; r_out[b * NK_N + i] = fx[i]; }
+  retcode[b] = rc;
+  iters[b] = it;
+}
 )NKSRC";
 
 // ----------------------------------------------------------------------------- hiprtc through dlopen
@@ -221,7 +312,7 @@ struct nk_batch {
   nk_ctx *ctx = nullptr;
   int n = 0, np = 0, block = 64;
   hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
+  hipFunction_t fn = nullptr, fn_tr = nullptr;
   // staging for host-memspace calls
   double *d_u0 = nullptr, *d_p = nullptr, *d_u = nullptr, *d_r = nullptr;
   int *d_rc = nullptr, *d_it = nullptr;
@@ -284,6 +375,7 @@ extern "C" int nk_batch_create(nk_ctx *ctx, const char *source, int n, int npara
     delete B;
     NK_FAIL(NK_E_HIP, "kernel nk_batch_newton not found in the compiled module");
   }
+  if (hipModuleGetFunction(&B->fn_tr, B->mod, "nk_batch_trust_region") != hipSuccess) B->fn_tr = nullptr;
   *out = B;
   return NK_OK;
 }
@@ -298,17 +390,19 @@ extern "C" int nk_batch_destroy(nk_batch *B) {
 
 // Solve all systems. u0: n doubles shared by every system (u0_per_system = 0, the tutorial's case) or nbatch×n;
 // p: nbatch×nparams. Outputs (nbatch×n, nbatch×n, nbatch, nbatch); retcode/iters may be NULL.
-extern "C" int nk_batch_solve(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int memspace,
-                              double abstol, int maxiters, double *u_out, double *resid_out, int32_t *retcode_out,
-                              int32_t *iters_out) {
+// tr == nullptr: SimpleNewtonRaphson; else SimpleTrustRegion with tr = {η₁, η₂, η₃, t₁, t₂, max_shrink_times}.
+static int batch_run(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int memspace,
+                     double abstol, int maxiters, const double *tr, double *u_out, double *resid_out, int32_t *retcode_out,
+                     int32_t *iters_out) {
   NK_REQUIRE(B && u0 && u_out && resid_out, "NULL argument");
   NK_REQUIRE(nbatch >= 0, "negative batch size");
   NK_REQUIRE(B->np == 0 || p, "parameters are required (nparams = %d)", B->np);
+  NK_REQUIRE(!tr || B->fn_tr, "the compiled module lacks the trust-region kernel");
   nk_ctx *ctx = B->ctx;
   NK_HIP(hipSetDevice(ctx->device));
   if (nbatch == 0) return NK_OK;
   if (!(abstol > 0.0)) abstol = pow(2.220446049250313e-16, 0.8);  // common_defaults.jl:39-48
-  if (maxiters <= 0) maxiters = 1000;                             // raphson.jl:42
+  if (maxiters <= 0) maxiters = 1000;                             // raphson.jl:42 / trust_region.jl:60
   const int n = B->n, np = B->np;
   if (B->cap < nbatch) {
     hipFree(B->d_u0); hipFree(B->d_p); hipFree(B->d_u); hipFree(B->d_r); hipFree(B->d_rc); hipFree(B->d_it);
@@ -336,10 +430,18 @@ extern "C" int nk_batch_solve(nk_batch *B, int64_t nbatch, const double *u0, int
   long nb = (long)nbatch;
   int ups = u0_per_system ? 1 : 0;
   int *drc = B->d_rc, *dit = B->d_it;
-  void *args[] = {&nb, &du0, &ups, &dp, &abstol, &maxiters, &du, &dr, &drc, &dit};
   const unsigned grid = (unsigned)((nbatch + B->block - 1) / B->block);
-  if (hipModuleLaunchKernel(B->fn, grid, 1, 1, B->block, 1, 1, 0, ctx->stream, args, nullptr) != hipSuccess)
-    NK_FAIL(NK_E_HIP, "launch of nk_batch_newton failed");
+  if (!tr) {
+    void *args[] = {&nb, &du0, &ups, &dp, &abstol, &maxiters, &du, &dr, &drc, &dit};
+    if (hipModuleLaunchKernel(B->fn, grid, 1, 1, B->block, 1, 1, 0, ctx->stream, args, nullptr) != hipSuccess)
+      NK_FAIL(NK_E_HIP, "launch of nk_batch_newton failed");
+  } else {
+    double e1 = tr[0], e2 = tr[1], e3 = tr[2], t1 = tr[3], t2 = tr[4];
+    int ms = (int)tr[5];
+    void *args[] = {&nb, &du0, &ups, &dp, &abstol, &maxiters, &e1, &e2, &e3, &t1, &t2, &ms, &du, &dr, &drc, &dit};
+    if (hipModuleLaunchKernel(B->fn_tr, grid, 1, 1, B->block, 1, 1, 0, ctx->stream, args, nullptr) != hipSuccess)
+      NK_FAIL(NK_E_HIP, "launch of nk_batch_trust_region failed");
+  }
   if (memspace != NK_DEVICE) {
     NK_HIP(hipMemcpyAsync(u_out, du, (size_t)nbatch * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     NK_HIP(hipMemcpyAsync(resid_out, dr, (size_t)nbatch * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -353,4 +455,24 @@ extern "C" int nk_batch_solve(nk_batch *B, int64_t nbatch, const double *u0, int
                           memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
   if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(ctx->stream));
   return NK_OK;
+}
+
+extern "C" int nk_batch_solve(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p, int memspace,
+                              double abstol, int maxiters, double *u_out, double *resid_out, int32_t *retcode_out,
+                              int32_t *iters_out) {
+  return batch_run(B, nbatch, u0, u0_per_system, p, memspace, abstol, maxiters, nullptr, u_out, resid_out, retcode_out, iters_out);
+}
+
+// SimpleTrustRegion (lib/SimpleNonlinearSolve/src/trust_region.jl); thresholds/factors ≤ 0 and max_shrink_times < 0 select
+// the reference defaults η₁ = 1e-4, η₂ = 0.25, η₃ = 0.75, t₁ = 0.25, t₂ = 2, 32. Retcodes: Success, MaxIters,
+// ShrinkThresholdExceeded.
+extern "C" int nk_batch_solve_trust_region(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_system, const double *p,
+                                           int memspace, double abstol, int maxiters, double step_threshold,
+                                           double shrink_threshold, double expand_threshold, double shrink_factor,
+                                           double expand_factor, int max_shrink_times, double *u_out, double *resid_out,
+                                           int32_t *retcode_out, int32_t *iters_out) {
+  const double tr[6] = {step_threshold > 0 ? step_threshold : 1e-4, shrink_threshold > 0 ? shrink_threshold : 0.25,
+                        expand_threshold > 0 ? expand_threshold : 0.75, shrink_factor > 0 ? shrink_factor : 0.25,
+                        expand_factor > 0 ? expand_factor : 2.0, (double)(max_shrink_times >= 0 ? max_shrink_times : 32)};
+  return batch_run(B, nbatch, u0, u0_per_system, p, memspace, abstol, maxiters, tr, u_out, resid_out, retcode_out, iters_out);
 }

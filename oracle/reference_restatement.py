@@ -1228,6 +1228,70 @@ def simple_newton_raphson(f, jac, u0, p, abstol=None, maxiters=1000):
     return x, fx, MAXITERS, maxiters
 
 
+def simple_trust_region(f, jac, u0, p, abstol=None, maxiters=1000, step_threshold=1e-4, shrink_threshold=0.25,
+                        expand_threshold=0.75, shrink_factor=0.25, expand_factor=2.0, max_shrink_times=32):
+    """SimpleTrustRegion for one small system — lib/SimpleNonlinearSolve/src/trust_region.jl:57-229 restated (default
+    radius-update rule), including its quirks: δsd = −g (no Cauchy step length), and after a rejected trial `fx` keeps the
+    trial point's residual while J, g, f_k stay at the accepted point. Returns (x, fx, retcode, iterations)."""
+    if abstol is None:
+        abstol = float(np.finfo(float).eps) ** 0.8
+    x = np.array(u0, dtype=float)
+    xo = x.copy()
+    fx = np.asarray(f(x, p), dtype=float)
+    norm_fx = float(np.linalg.norm(fx))
+    J = np.asarray(jac(x, p), dtype=float)
+    dmax = max(norm_fx, float(np.max(x) - np.min(x)))
+    delta = dmax / 11.0
+    fk = 0.5 * norm_fx ** 2
+    g = J.T @ fx
+    shrink = 0
+
+    def done(fv):
+        return (not np.any(np.isnan(fv))) and np.max(np.abs(fv)) <= abstol
+
+    if done(fx):
+        return x, fx, SUCCESS, 0
+    with np.errstate(all="ignore"):
+        for it in range(1, maxiters + 1):
+            try:
+                dN = -np.linalg.solve(J, fx)
+            except np.linalg.LinAlgError:
+                dN = np.full_like(x, np.nan)
+            if np.linalg.norm(dN) <= delta:
+                dl = dN
+            else:
+                dsd = -g
+                nsd = np.linalg.norm(dsd)
+                if nsd >= delta:
+                    dl = dsd * (delta / nsd)
+                else:
+                    q = dN - dsd
+                    dNN, dSN, dSS = float(q @ q), float(dsd @ q), float(dsd @ dsd)
+                    tau = (-dSN + math.sqrt(dSN * dSN - dNN * (dSS - delta * delta))) / dNN
+                    dl = dsd + tau * q
+            x = xo + dl
+            fx = np.asarray(f(x, p), dtype=float)
+            fk1 = float(np.linalg.norm(fx)) ** 2 / 2.0
+            r = (fk1 - fk) / (float(dl @ g) + float(dl @ (J.T @ (J @ dl))) / 2.0)
+            if r >= shrink_threshold:
+                shrink = 0
+            else:
+                delta = shrink_factor * delta
+                shrink += 1
+                if shrink > max_shrink_times:
+                    return x, fx, SHRINK_EXCEEDED, it
+            if r >= step_threshold:
+                if done(fx):
+                    return x, fx, SUCCESS, it
+                xo = x.copy()
+                J = np.asarray(jac(x, p), dtype=float)
+                if r > expand_threshold:
+                    delta = min(expand_factor * delta, dmax)
+                fk = fk1
+                g = J.T @ fx
+    return x, fx, MAXITERS, maxiters
+
+
 def solve(prob, alg, **kw):
     return FirstOrderCache(prob, alg, **kw).solve()
 

@@ -83,3 +83,55 @@ def test_larger_systems_scratch_path(nls):
     P = rng.uniform(1.0, 5.0, (nb, n))
     sol = nls.vectorized_solve(nls.ImmutableNonlinearProblem(E.QUADRATIC, np.ones(n), P))
     assert (sol.retcode == "Success").all() and np.max(np.abs(sol.u - np.sqrt(P))) < 1e-12
+
+
+NEWTON_FAILS = """
+template <typename T> __device__ void nk_f(const T *u, const double *p, T *f) {
+  const T a = 0.21640425613334457 + 216.40425613334457 / (1.0 + 0.0006250000000000001 * (u[0] * u[0]));
+  const T b = 0.21640425613334457 + 216.40425613334457 / (1.0 + a * a);
+  f[0] = 0.010000000000000002 + 10.000000000000002 / (1.0 + b * b) - 0.0011552453009332421 * u[0] - p[0];
+}
+"""
+
+
+def _newton_fails(u, p):
+    a = 0.21640425613334457 + 216.40425613334457 / (1 + 0.0006250000000000001 * u ** 2.0)
+    b = 0.21640425613334457 + 216.40425613334457 / (1 + a ** 2.0)
+    return 0.010000000000000002 + 10.000000000000002 / (1 + b ** 2.0) - 0.0011552453009332421 * u - p
+
+
+def test_simple_trust_region_newton_fails_fixture(nls):
+    """rootfind_tests__item10.jl: `newton_fails` must converge with a trust-region method — here every component is its own
+    scalar system of an ensemble (the function is separable), solved by SimpleTrustRegion on the device; plain
+    SimpleNewtonRaphson does not converge from all seven starts. Iteration counts and iterates equal the oracle's."""
+    u0 = np.array([-10.0, -1.0, 1.0, 2.0, 3.0, 4.0, 10.0])[:, None]
+    P = np.zeros((7, 1))
+    prob = nls.ImmutableNonlinearProblem(NEWTON_FAILS, u0, P)
+    tr = nls.vectorized_solve(prob, nls.SimpleTrustRegion(), abstol=1e-9, maxiters=1000)
+    assert (tr.retcode == "Success").all() and np.max(np.abs(_newton_fails(tr.u, 0.0))) < 1e-9
+    jac = lambda u, p: np.array([[(_newton_fails(u[0] + 1e-7, p[0]) - _newton_fails(u[0] - 1e-7, p[0])) / 2e-7]])
+    ref = [R.simple_trust_region(lambda u, p: _newton_fails(u, p), jac, u0[b], P[b], abstol=1e-9) for b in range(7)]
+    assert all(r[2] == R.SUCCESS for r in ref)
+    assert np.max(np.abs(tr.u[:, 0] - np.array([r[0][0] for r in ref]))) < 1e-6     # same roots (FD Jacobian on the oracle)
+    nr = nls.vectorized_solve(prob, nls.SimpleNewtonRaphson(), abstol=1e-9, maxiters=200)
+    assert not (nr.retcode == "Success").all()
+
+
+def test_simple_trust_region_vs_oracle_on_coupled_systems(nls):
+    """SimpleTrustRegion with the dual-number Jacobian on the 3-unknown transcendental system from rough starts: retcodes,
+    iteration counts and iterates follow the oracle's restatement of trust_region.jl (including its handling of rejected
+    trials)."""
+    rng = np.random.default_rng(5)
+    nb = 200
+    utrue = rng.uniform(0.2, 1.2, (nb, 3))
+    P = np.array([E.trig_f(u, np.zeros(3)) for u in utrue])
+    u0 = utrue + 0.8 * rng.standard_normal((nb, 3))
+    sol = nls.vectorized_solve(nls.ImmutableNonlinearProblem(E.TRIG_WITH_JAC, u0, P), nls.SimpleTrustRegion(), maxiters=300)
+    ref = [R.simple_trust_region(E.trig_f, E.trig_jac, u0[b], P[b], maxiters=300) for b in range(nb)]
+    rco, ito = np.array([r[2] for r in ref]), np.array([r[3] for r in ref])
+    xo = np.array([r[0] for r in ref])
+    same = (sol.retcode_raw == rco) & (sol.iters == ito)
+    assert same.mean() > 0.97                       # chaotic far-from-root paths may split at a rounding-level tie
+    assert np.nanmax(np.abs(sol.u[same] - xo[same])) < 1e-8
+    ok = sol.retcode_raw == 1
+    assert ok.mean() > 0.8 and np.max(np.abs(sol.resid[ok])) <= np.finfo(float).eps ** 0.8

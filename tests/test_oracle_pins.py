@@ -357,3 +357,24 @@ def test_dcgs2_restatement_equals_cgs2():
     xr, ir = R.gmres(lambda z: J @ z, b, restart=30, rtol=1e-10, itmax=3000, ortho="cgs2")
     x3, i3 = R.gmres(lambda z: J @ z, b, restart=30, rtol=1e-10, itmax=3000, ortho="dcgs2", allreduce=lambda v: v)
     assert i3.iters == ir.iters and np.linalg.norm(x3 - xr) <= 1e-12 * np.linalg.norm(xr)
+
+
+def test_simple_trust_region_restatement():
+    """lib/SimpleNonlinearSolve/src/trust_region.jl restated: quadratic_f → √p (err < 1e-9, the bound of the reference's
+    rootfind tests) and newton_fails (rootfind_tests__item10.jl) from its seven starting values, one scalar system each."""
+    import ensemble_sources as E
+    x, fx, rc, it = R.simple_trust_region(E.quadratic_f, E.quadratic_jac, np.ones(3), np.full(3, 2.0), abstol=1e-10)
+    assert rc == R.SUCCESS and np.max(np.abs(x - np.sqrt(2.0))) < 1e-9
+
+    def nf(u, p):
+        a = 0.21640425613334457 + 216.40425613334457 / (1 + 0.0006250000000000001 * u ** 2.0)
+        b = 0.21640425613334457 + 216.40425613334457 / (1 + a ** 2.0)
+        return 0.010000000000000002 + 10.000000000000002 / (1 + b ** 2.0) - 0.0011552453009332421 * u - p
+
+    jac = lambda u, p: np.array([[(nf(u[0] + 1e-7, p[0]) - nf(u[0] - 1e-7, p[0])) / 2e-7]])
+    for u0 in (-10.0, -1.0, 1.0, 2.0, 3.0, 4.0, 10.0):
+        x, fx, rc, it = R.simple_trust_region(nf, jac, np.array([u0]), np.zeros(1), abstol=1e-9)
+        assert rc == R.SUCCESS and abs(nf(x, 0.0)[0]) < 1e-9
+    # max_shrink_times: a residual with no root shrinks the region until the solver gives up
+    x, fx, rc, it = R.simple_trust_region(lambda u, p: u * u + 1.0, lambda u, p: np.diag(2.0 * u), np.array([0.3]), None)
+    assert rc in (R.SHRINK_EXCEEDED, R.MAXITERS)
