@@ -235,10 +235,18 @@ mutable struct EnsembleKernel
     end
 end
 
-function vectorized_solve(k::EnsembleKernel, u0::Vector{Float64}, p::Matrix{Float64}; abstol = 0.0, maxiters = 1000)
+function vectorized_solve(k::EnsembleKernel, u0::Vector{Float64}, p::Matrix{Float64}; alg = :SimpleNewtonRaphson,
+        abstol = 0.0, maxiters = 1000)
     nb = size(p, 2)
     u = Matrix{Float64}(undef, k.n, nb); resid = similar(u)
     rc = Vector{Int32}(undef, nb); iters = Vector{Int32}(undef, nb)
+    if alg === :SimpleTrustRegion   # reference defaults for thresholds / factors (negative = default)
+        GC.@preserve u0 p u resid rc iters nkcheck(@ccall libnk.nk_batch_solve_trust_region(k.ptr::Ptr{Cvoid}, nb::Int64,
+            u0::Ptr{Float64}, 0::Cint, p::Ptr{Float64}, 0::Cint, abstol::Float64, maxiters::Cint, (-1.0)::Float64,
+            (-1.0)::Float64, (-1.0)::Float64, (-1.0)::Float64, (-1.0)::Float64, (-1)::Cint, u::Ptr{Float64},
+            resid::Ptr{Float64}, rc::Ptr{Int32}, iters::Ptr{Int32})::Cint)
+        return (; u, resid, retcode = [RETCODES[c + 1] for c in rc], iters)
+    end
     GC.@preserve u0 p u resid rc iters nkcheck(@ccall libnk.nk_batch_solve(k.ptr::Ptr{Cvoid}, nb::Int64,
         u0::Ptr{Float64}, 0::Cint, p::Ptr{Float64}, 0::Cint, abstol::Float64, maxiters::Cint, u::Ptr{Float64},
         resid::Ptr{Float64}, rc::Ptr{Int32}, iters::Ptr{Int32})::Cint)
