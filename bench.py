@@ -212,7 +212,7 @@ def main():
                "speedup": round(tc2 / tg, 1)}
         # the same solve with the built-in geometric multigrid V-cycle behind the `precs` hook (GPU only: the C oracle has
         # no multigrid; its NumPy restatement pins iteration counts at small sizes in the tests)
-        alg3 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(2, 63)),
+        alg3 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(2, 31)),
                                  forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
         nls.solve(prob2, alg3, abstol=1e-8, maxiters=50)
         torch.cuda.synchronize()

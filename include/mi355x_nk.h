@@ -203,7 +203,7 @@ typedef struct {
   int32_t ls_order;             /* 2 | 3 */
   int32_t ls_maxiters;
   /* --- built-in multigrid V-cycle as the Krylov right preconditioner (BRATU2D, single rank), re-linearised for every
-   *     new Jacobian like `precs(A, p)`: mg_nu smoothing steps (0 = off), coarsest grid side ≤ mg_coarse (0 → 63) */
+   *     new Jacobian like `precs(A, p)`: mg_nu smoothing steps (0 = off), coarsest grid side ≤ mg_coarse (0 → 31) */
   int32_t mg_nu;
   int32_t mg_coarse;
 } nk_options;
@@ -335,7 +335,7 @@ int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, double lambda
 int nk_gmres_get_chebyshev_interval(nk_gmres *G, double *lambda_min, double *lambda_max);
 /* Built-in right preconditioner M⁻¹ = one geometric multigrid V-cycle on the Jacobian of a BRATU2D problem linearised at u
  * (level operators by rediscretisation, bilinear transfers between non-nested grids, `nu` Chebyshev smoothing steps before
- * and after, banded LU on the coarsest grid of side ≤ coarse_max; 0 → 2 and 63) — the device counterpart of an algebraic-
+ * and after, banded LU on the coarsest grid of side ≤ coarse_max; 0 → 2 and 31) — the device counterpart of an algebraic-
  * multigrid `precs` (docs/src/tutorials/large_systems.md:244-316). Mesh-independent Krylov iteration counts. Call it again
  * for every new linearisation point; nu ≤ 0 or P == NULL removes it. Single rank. */
 int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P, const double *u, int memspace, int nu, int coarse_max);

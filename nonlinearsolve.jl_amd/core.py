@@ -501,7 +501,7 @@ class MultigridPrecs:
     (nu Chebyshev smoothing steps, coarsest grid side ≤ coarse_max, banded LU there) — the device counterpart of an
     algebraic-multigrid `precs` (docs/src/tutorials/large_systems.md:244-316). Mesh-independent iteration counts."""
     nu: int = 2
-    coarse_max: int = 63
+    coarse_max: int = 31
 
 
 @dataclass
@@ -902,7 +902,7 @@ class GMRES:
                                                             float(ratio)))
         return self
 
-    def set_multigrid_preconditioner(self, problem, u, nu: int = 2, coarse_max: int = 63):
+    def set_multigrid_preconditioner(self, problem, u, nu: int = 2, coarse_max: int = 31):
         """One V-cycle of the built-in geometric multigrid (Bratu2D problems) as the right preconditioner, linearised at u."""
         dp = problem.device_problem if hasattr(problem, "device_problem") else problem
         pu, ms, keep = _ptr(u, self.n)

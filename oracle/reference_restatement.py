@@ -517,10 +517,10 @@ class BratuMultigrid:
     the points' physical positions (grids need not be nested), restriction = row-normalised transpose; ν Chebyshev steps
     on [λmax/4, λmax], λmax = 8·scale/h_l²; sparse LU on the coarsest grid."""
 
-    def __init__(self, prob: "Bratu2D", u, nu=2, coarse_max=63):
+    def __init__(self, prob: "Bratu2D", u, nu=2, coarse_max=31):
         import scipy.sparse.linalg as spla
         self.nu = int(nu) if nu > 0 else 2
-        coarse_max = coarse_max if coarse_max >= 3 else 63
+        coarse_max = coarse_max if coarse_max >= 3 else 31
         scale = prob.c_lap * prob.h * prob.h
         self.levels = []
         ns, ul = prob.ns, np.asarray(u, dtype=np.float64)
@@ -588,7 +588,7 @@ class BratuMultigrid:
 @dataclass
 class MultigridPrecs:
     nu: int = 2
-    coarse_max: int = 63
+    coarse_max: int = 31
 
 
 @dataclass

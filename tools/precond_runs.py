@@ -33,7 +33,7 @@ for ns in (1024, 4096):
             for rep in range(2):  # second run: hierarchy and buffers warm
                 u0 = torch.zeros(ns * ns, dtype=torch.float64, device=dev)
                 prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=u0)
-                alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(nu, 63)),
+                alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(nu, 31)),
                                         forcing=nls.EisenstatWalkerForcing2(), concrete_jac=concrete)
                 sol = run(f"bratu {ns}^2 NR+GMRES(30)+EW+Multigrid(nu={nu}) {'CSR' if concrete else 'matfree'} run{rep}", prob, alg,
                           abstol=1e-8, maxiters=50)
