@@ -126,3 +126,20 @@ def test_c3_full_solve_with_chebyshev_precs_vs_c_oracle(nls, dev):
     # tightly (tests/test_gpu_solvers.py::test_bratu_newton_tight_inner_matches_direct).
     assert np.max(np.abs(sol.u.cpu().numpy() - uC)) <= 2e-5
     assert 0.79 < float(sol.u.max()) < 0.80
+
+
+def test_bratu_1024_multigrid_precs_reaches_tolerance_in_a_handful_of_krylov_iterations(nls):
+    """Config C3 at full size with the built-in geometric multigrid `precs`: ‖h²F‖∞ ≤ 1e-8 in ≤ 6 Newton steps and ≤ 8
+    GMRES iterations in total (mesh-independent: the same counts as at 128² in test_gpu_solvers.py), and the solution agrees
+    with the Chebyshev-preconditioned one to the conditioning-limited 1e-4."""
+    import torch
+    ns = 1024
+    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(ns * ns, dtype=torch.float64, device="cuda"))
+    mg = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 31)),
+                                           forcing=nls.EisenstatWalkerForcing2()), abstol=1e-8, maxiters=50)
+    assert mg.retcode == "Success" and float(mg.resid.abs().max()) <= 1e-8
+    assert mg.stats.nsteps <= 6 and mg.stats.gmres_iters <= 8
+    ch = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.ChebyshevPrecs(32, 300.0)),
+                                           forcing=nls.EisenstatWalkerForcing2()), abstol=1e-8, maxiters=50)
+    assert ch.retcode == "Success" and float((mg.u - ch.u).abs().max()) < 1e-4
+    assert abs(float(mg.u.max()) - 0.797) < 2e-3     # the λ = 6 lower-branch solution peaks at ≈ 0.797
