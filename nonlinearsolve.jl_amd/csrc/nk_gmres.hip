@@ -894,11 +894,23 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
                        fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m);
     first = 0;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
-    if (use_dcgs2r(G)) {
-      for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step_1r(G, k));
-      NK_TRY(arnoldi_flush_1r(G, steps));
-    } else {
-      for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step(G, k));
+    // The whole cycle is enqueued without host synchronisation; kernels after convergence return at once on the device
+    // flag. With a launch-heavy preconditioner (a multigrid V-cycle is ≈ 70 launches) those no-op launches would dominate
+    // a cycle that converges after one or two steps, so there the flag is read back every `sync_every` steps instead.
+    {
+      const bool one_red = use_dcgs2r(G);
+      const int sync_every = (G->prec_kind == 3) ? 2 : steps;
+      bool stopped = false;
+      for (int k = 0; k < steps && !stopped;) {
+        const int kend = (k + sync_every < steps) ? k + sync_every : steps;
+        for (; k < kend; ++k) NK_TRY(one_red ? arnoldi_step_1r(G, k) : arnoldi_step(G, k));
+        if (kend < steps) {
+          NK_HIP(hipMemcpyAsync(G->h_ctl, G->d_ctl, sizeof(nk_gmres_ctl), hipMemcpyDeviceToHost, ctx->stream));
+          NK_HIP(hipStreamSynchronize(ctx->stream));
+          stopped = G->h_ctl->done != 0;
+        }
+      }
+      if (one_red && !stopped) NK_TRY(arnoldi_flush_1r(G, steps));
     }
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
     NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(64), G->d_ctl, G->d_R, G->d_g, G->d_y, m);

@@ -163,7 +163,7 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   NK_REQUIRE(ctx->nranks == 1, "the multigrid preconditioner is single-rank in this round");
   NK_REQUIRE(P->ns < 46000, "grid too large for 32-bit point indices");
   if (nu <= 0) nu = 2;
-  if (coarse_max < 3) coarse_max = 31;  // measured best on MI355X: 63 → 48 ms, 31 → 38 ms, 15 → 42 ms at 1024²
+  if (coarse_max < 3) coarse_max = 31;  // MI355X, 1024² with set-up: 63 → 13.5 ms, 31 → 10.1, 15 → 9.5, 7 → 9.7
   nk_mg *M = new nk_mg();
   M->ctx = ctx;
   M->nu = nu;
