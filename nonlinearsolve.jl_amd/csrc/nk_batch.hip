@@ -12,6 +12,7 @@
 // eps^(4/5) (common_defaults.jl:39-48), maxiters 1000; retcodes Success / MaxIters; a NaN residual never terminates.
 #include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -273,6 +274,116 @@ nk_batch_trust_region(long nbatch, const double *__restrict__ u0, int u0_per_sys
 }
 )NKSRC";
 
+
+// ----------------------------------------------------------------------------- one system per WAVEFRONT (8 < n ≤ 64)
+// The per-thread kernel keeps the n×n Jacobian in registers only while n ≤ 8; beyond that it runs from scratch memory
+// (measured ≈ 1 TFLOP/s against 16–27 TFLOP/s for n ≤ 8). Here a wavefront owns one system and lane j owns COLUMN j of the
+// Jacobian: lane j evaluates the residual on dual numbers seeded with e_j (one partial), which gives it its column; the LU
+// uses COLUMN pivoting — the pivot of row c is the largest entry of that row among the columns not used yet, found with a
+// wave reduction, so no register ever moves; the multipliers l_r = a[r][p]/a[c][p] live in lane p and reach the others through
+// v_readlane with a scalar lane index; every lane then updates its own column with register indices that are compile-time
+// constants. The right-hand side, x and f(x) are replicated in all lanes. (nk_jac, if supplied, is not used by this kernel.)
+static const char *k_kernel_wave = R"NKSRC(
+__device__ inline double nk_rl(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double nk_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+extern "C" __global__ void __launch_bounds__(NK_BLOCK_T)
+nk_batch_newton_wave(long nbatch, const double *__restrict__ u0, int u0_per_system, const double *__restrict__ p, double abstol,
+                     int maxiters, double *__restrict__ u_out, double *__restrict__ r_out, int *__restrict__ retcode,
+                     int *__restrict__ iters) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * (NK_BLOCK_T / 64) + (threadIdx.x >> 6);
+  if (b >= nbatch) return;   // whole wavefronts leave together
+  double x[NK_N], fx[NK_N], col[NK_N], pp[NK_NP > 0 ? NK_NP : 1];  // fx doubles as the right-hand side of the solve
+#pragma unroll
+  for (int i = 0; i < NK_N; ++i) x[i] = u0[(u0_per_system ? b * NK_N : 0) + i];
+#pragma unroll
+  for (int i = 0; i < NK_NP; ++i) pp[i] = p[b * NK_NP + i];
+  nk_f<double>(x, pp, fx);
+  bool allzero = true;
+#pragma unroll
+  for (int i = 0; i < NK_N; ++i) allzero = allzero && (fx[i] == 0.0);
+  int rc = 2, it = 0;
+  if (allzero) rc = 1;
+  else {
+    for (it = 1; it <= maxiters; ++it) {
+      {  // column `lane` of J by one dual-number sweep (AutoForwardDiff with a single partial per lane)
+        Dual xd[NK_N], fd[NK_N];
+#pragma unroll
+        for (int i = 0; i < NK_N; ++i) { xd[i].v = x[i]; xd[i].d[0] = (i == lane) ? 1.0 : 0.0; }
+        nk_f<Dual>(xd, pp, fd);
+#pragma unroll
+        for (int i = 0; i < NK_N; ++i) col[i] = (lane < NK_N) ? fd[i].d[0] : 0.0;
+      }
+      // AbsNormTerminationMode(maximum∘abs) on the residual of the iterate the step starts from — the quantity the reference
+      // tests AFTER the update (raphson.jl:72-75); taken here because the solve below overwrites fx
+      double nrm = 0.0;
+      bool nan = false;
+#pragma unroll
+      for (int i = 0; i < NK_N; ++i) { const double a = fabs(fx[i]); nan = nan || (a != a); nrm = a > nrm ? a : nrm; }
+      const bool converged = !nan && nrm <= abstol;
+      double *rhs = fx;
+      // ---- LU with column pivoting, applied to the right-hand side on the fly
+      bool used = lane >= NK_N;   // lanes without a column never pivot
+      int perm[NK_N];
+#pragma unroll
+      for (int c = 0; c < NK_N; ++c) {
+        const double mine = used ? -1.0 : fabs(col[c]);
+        const double best = nk_wave_max(mine);
+        const unsigned long long m = __ballot(!used && mine == best);
+        const int pl = m ? (int)__ffsll((long long)m) - 1 : 0;   // (a NaN row: every compare fails — take lane 0, NaNs propagate)
+        const int pv = __builtin_amdgcn_readfirstlane(pl);
+        perm[c] = pv;
+        const double inv = 1.0 / nk_rl(col[c], pv);
+        if (lane == pv) used = true;
+        const double cc = col[c];
+#pragma unroll
+        for (int r = c + 1; r < NK_N; ++r) {
+          const double l = nk_rl(col[r], pv) * inv;
+          if (!used) col[r] -= l * cc;
+          rhs[r] -= l * rhs[c];
+        }
+      }
+      // ---- back substitution: the unknown of step c belongs to lane perm[c]
+      double mydx = 0.0;
+#pragma unroll
+      for (int c = NK_N - 1; c >= 0; --c) {
+        const int pv = perm[c];
+        const double xc = rhs[c] / nk_rl(col[c], pv);
+        if (lane == pv) mydx = xc;
+#pragma unroll
+        for (int r = 0; r < c; ++r) rhs[r] -= nk_rl(col[r], pv) * xc;
+      }
+#pragma unroll
+      for (int i = 0; i < NK_N; ++i) x[i] -= nk_rl(mydx, i);
+      if (converged) {  // the reference returns the residual of the iterate the last step started from: rebuild it (x + δ)
+        rc = 1;
+        double xp[NK_N];
+#pragma unroll
+        for (int i = 0; i < NK_N; ++i) xp[i] = x[i] + nk_rl(mydx, i);
+        nk_f<double>(xp, pp, fx);
+        break;
+      }
+      nk_f<double>(x, pp, fx);
+    }
+    if (it > maxiters) it = maxiters;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NK_N; ++i) { u_out[b * NK_N + i] = x[i]; r_out[b * NK_N + i] = fx[i]; }
+    retcode[b] = rc;
+    iters[b] = it;
+  }
+}
+)NKSRC";
+
 // ----------------------------------------------------------------------------- hiprtc through dlopen
 typedef void *rtc_program;
 static struct {
@@ -311,8 +422,8 @@ static int rtc_load() {
 struct nk_batch {
   nk_ctx *ctx = nullptr;
   int n = 0, np = 0, block = 64;
-  hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr, fn_tr = nullptr;
+  hipModule_t mod = nullptr, mod_wave = nullptr;
+  hipFunction_t fn = nullptr, fn_tr = nullptr, fn_wave = nullptr;  // fn_wave: one system per wavefront (8 < n ≤ 64)
   // staging for host-memspace calls
   double *d_u0 = nullptr, *d_p = nullptr, *d_u = nullptr, *d_r = nullptr;
   int *d_rc = nullptr, *d_it = nullptr;
@@ -320,20 +431,21 @@ struct nk_batch {
 };
 
 // compile `source` (+ prelude + solver kernel) for n unknowns / np parameters; code object into `code`, log into `log`
-static int batch_compile(const char *source, int n, int np, int flags, std::vector<char> *code, std::string *log) {
+static int batch_compile(const char *source, int n, int np, int flags, std::vector<char> *code, std::string *log,
+                         bool wave = false) {
   NK_REQUIRE(source, "NULL source");
   NK_REQUIRE(n >= 1 && n <= 64, "n = %d outside 1..64 (one system per thread)", n);
   NK_REQUIRE(np >= 0 && np <= 256, "nparams = %d outside 0..256", np);
   NK_TRY(rtc_load());
-  std::string full = std::string(k_prelude) + "\n// ---- user source\n" + source + "\n" + k_kernel;
+  std::string full = std::string(k_prelude) + "\n// ---- user source\n" + source + "\n" + (wave ? k_kernel_wave : k_kernel);
   rtc_program prog = nullptr;
   if (RTC.Create(&prog, full.c_str(), "nk_batch_user.hip", 0, nullptr, nullptr) != 0) NK_FAIL(NK_E_HIP, "hiprtcCreateProgram failed");
-  const int ch = n < 8 ? n : 8;  // dual-number partials per residual sweep
+  const int ch = wave ? 1 : (n < 8 ? n : 8);  // dual-number partials per residual sweep (wave kernel: one per lane)
   const std::string dn = "-DNK_N=" + std::to_string(n), dp = "-DNK_NP=" + std::to_string(np), dc = "-DNK_CH=" + std::to_string(ch),
-                    db = "-DNK_BLOCK_T=64";
+                    db = wave ? "-DNK_BLOCK_T=256" : "-DNK_BLOCK_T=64";
   std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", dn.c_str(), dp.c_str(), dc.c_str(),
                                     db.c_str()};
-  if (flags & 1) opts.push_back("-DNK_HAS_JAC=1");
+  if ((flags & 1) && !wave) opts.push_back("-DNK_HAS_JAC=1");
   const int rc = RTC.Compile(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   RTC.LogSize(prog, &ls);
@@ -356,6 +468,12 @@ extern "C" int nk_batch_compile_check(const char *source, int n, int nparams, in
   std::string log;
   NK_TRY(batch_compile(source, n, nparams, flags, &code, &log));
   if (code_bytes) *code_bytes = (int64_t)code.size();
+  if (n > 8) {  // medium systems also get the per-wavefront Newton kernel
+    std::vector<char> wcode;
+    std::string wlog;
+    NK_TRY(batch_compile(source, n, nparams, flags, &wcode, &wlog, true));
+    if (code_bytes) *code_bytes += (int64_t)wcode.size();
+  }
   return NK_OK;
 }
 
@@ -376,6 +494,16 @@ extern "C" int nk_batch_create(nk_ctx *ctx, const char *source, int n, int npara
     NK_FAIL(NK_E_HIP, "kernel nk_batch_newton not found in the compiled module");
   }
   if (hipModuleGetFunction(&B->fn_tr, B->mod, "nk_batch_trust_region") != hipSuccess) B->fn_tr = nullptr;
+  if (n > 8) {  // Newton for medium systems: the per-wavefront kernel
+    std::vector<char> wcode;
+    std::string wlog;
+    if (batch_compile(source, n, nparams, flags, &wcode, &wlog, true) == NK_OK &&
+        hipModuleLoadData(&B->mod_wave, wcode.data()) == hipSuccess) {
+      if (hipModuleGetFunction(&B->fn_wave, B->mod_wave, "nk_batch_newton_wave") != hipSuccess) B->fn_wave = nullptr;
+    }
+    static const bool no_wave = getenv("NK_BATCH_NO_WAVE") != nullptr;  // A/B switch
+    if (no_wave) B->fn_wave = nullptr;
+  }
   *out = B;
   return NK_OK;
 }
@@ -384,6 +512,7 @@ extern "C" int nk_batch_destroy(nk_batch *B) {
   if (!B) return NK_OK;
   hipFree(B->d_u0); hipFree(B->d_p); hipFree(B->d_u); hipFree(B->d_r); hipFree(B->d_rc); hipFree(B->d_it);
   if (B->mod) hipModuleUnload(B->mod);
+  if (B->mod_wave) hipModuleUnload(B->mod_wave);
   delete B;
   return NK_OK;
 }
@@ -431,7 +560,12 @@ static int batch_run(nk_batch *B, int64_t nbatch, const double *u0, int u0_per_s
   int ups = u0_per_system ? 1 : 0;
   int *drc = B->d_rc, *dit = B->d_it;
   const unsigned grid = (unsigned)((nbatch + B->block - 1) / B->block);
-  if (!tr) {
+  if (!tr && B->fn_wave) {
+    void *args[] = {&nb, &du0, &ups, &dp, &abstol, &maxiters, &du, &dr, &drc, &dit};
+    const unsigned wgrid = (unsigned)((nbatch + 3) / 4);  // 4 wavefronts = 4 systems per 256-thread workgroup
+    if (hipModuleLaunchKernel(B->fn_wave, wgrid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr) != hipSuccess)
+      NK_FAIL(NK_E_HIP, "launch of nk_batch_newton_wave failed");
+  } else if (!tr) {
     void *args[] = {&nb, &du0, &ups, &dp, &abstol, &maxiters, &du, &dr, &drc, &dit};
     if (hipModuleLaunchKernel(B->fn, grid, 1, 1, B->block, 1, 1, 0, ctx->stream, args, nullptr) != hipSuccess)
       NK_FAIL(NK_E_HIP, "launch of nk_batch_newton failed");
