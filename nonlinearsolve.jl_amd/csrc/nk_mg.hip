@@ -84,37 +84,19 @@ __global__ __launch_bounds__(NK_BLOCK) void k_mg_restrict(int nf, int nc, const 
   }
   rc[k] = s;
 }
-// Chebyshev smoother pieces
-__global__ __launch_bounds__(NK_BLOCK) void k_mg_resid(int64_t n, const double *__restrict__ b, const double *__restrict__ Jx,
-                                                       double *__restrict__ r, const int *d_skip) {
-  MG_SKIP(d_skip);
-  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
-  if (i < n) r[i] = b[i] - Jx[i];
-}
-// d = r/θ ; x = (zero ? 0 : x) + d
+// Chebyshev smoother: the first step; the later steps and the residual are fused into the stencil JVP's row epilogue
+// d = r/θ ; x = (zero ? 0 : x) + d ; r_copy = r (optional: the recurrence continues on a private copy of b)
 __global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_first(int64_t n, const double *__restrict__ r, double inv_theta, int zero,
-                                                            double *__restrict__ d, double *__restrict__ x, const int *d_skip) {
+                                                            double *__restrict__ d, double *__restrict__ x,
+                                                            double *__restrict__ r_copy, const int *d_skip) {
   MG_SKIP(d_skip);
   const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
   if (i >= n) return;
-  const double dd = r[i] * inv_theta;
+  const double rv = r[i], dd = rv * inv_theta;
   d[i] = dd;
   x[i] = zero ? dd : x[i] + dd;
+  if (r_copy) r_copy[i] = rv;
 }
-// r −= J d ; d = c1 d + c2 r ; x += d
-__global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_next(int64_t n, const double *__restrict__ Jd, double c1, double c2,
-                                                           double *__restrict__ r, double *__restrict__ d, double *__restrict__ x,
-                                                           const int *d_skip) {
-  MG_SKIP(d_skip);
-  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const double rr = r[i] - Jd[i];
-  const double dd = c1 * d[i] + c2 * rr;
-  r[i] = rr;
-  d[i] = dd;
-  x[i] += dd;
-}
-
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + NK_BLOCK - 1) / NK_BLOCK)); }
 
 // ----------------------------------------------------------------------------- setup
@@ -245,26 +227,41 @@ int nk_mg_update(nk_mg *M, const double *d_u) {
 }
 
 // ν Chebyshev steps for J_l x = b on [λmax/4, λmax]; zero_guess: x starts at 0 (then r = b)
+// b − J x in ONE kernel: the stencil JVP's row epilogue subtracts from b (nk_spmv_epi mode 2)
+static int mg_residual(nk_mg_level &L, const double *x, double *out, const int *d_skip) {
+  nk_spmv_epi ep;
+  ep.mode = 2;
+  ep.r = L.b;
+  return nk_problem_jvp_dev(L.P, L.u, x, out, d_skip, nullptr, &ep);
+}
+
 static int mg_smooth(nk_mg *M, nk_mg_level &L, bool zero_guess, const int *d_skip) {
   nk_ctx *ctx = M->ctx;
   const double lmax = L.lmax, lmin = lmax / 4.0;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
   double rho = 1.0 / sigma;
-  const double *r0 = L.b;
   if (!zero_guess) {
-    NK_TRY(nk_problem_jvp_dev(L.P, L.u, L.x, L.t, d_skip));
-    NK_LAUNCH(ctx, k_mg_resid, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.b, (const double *)L.t, L.r, d_skip);
-    r0 = L.r;
-  } else if (M->nu > 1) {
-    NK_TRY(nk_blas_copy(ctx, L.n, L.b, L.r));  // the recurrence below updates r in place
-    r0 = L.r;
+    NK_TRY(mg_residual(L, L.x, L.r, d_skip));
+    NK_LAUNCH(ctx, k_mg_cheb_first, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.r, 1.0 / theta, 0, L.d, L.x,
+              (double *)nullptr, d_skip);
+  } else {  // x0 = 0: r = b; the recurrence below updates r in place, so it gets its own copy in the same sweep
+    NK_LAUNCH(ctx, k_mg_cheb_first, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.b, 1.0 / theta, 1, L.d, L.x,
+              M->nu > 1 ? L.r : (double *)nullptr, d_skip);
   }
-  NK_LAUNCH(ctx, k_mg_cheb_first, g1(L.n), dim3(NK_BLOCK), L.n, r0, 1.0 / theta, zero_guess ? 1 : 0, L.d, L.x, d_skip);
+  double *dcur = L.d, *dalt = L.t;
   for (int k = 1; k < M->nu; ++k) {
+    // r −= J d ; d_new = c1 d + c2 r ; x += d_new — fused into the JVP's row epilogue (mode 1); d ping-pongs because the
+    // stencil reads the neighbours' old d
     const double rho_new = 1.0 / (2.0 * sigma - rho);
-    NK_TRY(nk_problem_jvp_dev(L.P, L.u, L.d, L.t, d_skip));
-    NK_LAUNCH(ctx, k_mg_cheb_next, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.t, rho_new * rho, 2.0 * rho_new / delta, L.r,
-              L.d, L.x, d_skip);
+    nk_spmv_epi ep;
+    ep.mode = 1;
+    ep.c1 = rho_new * rho;
+    ep.c2 = 2.0 * rho_new / delta;
+    ep.r = L.r;
+    ep.dnew = dalt;
+    ep.yacc = L.x;
+    NK_TRY(nk_problem_jvp_dev(L.P, L.u, dcur, dalt, d_skip, nullptr, &ep));
+    double *tmp = dcur; dcur = dalt; dalt = tmp;
     rho = rho_new;
   }
   return NK_OK;
@@ -331,8 +328,7 @@ static int mg_vcycle_body(nk_mg *M, const int *d_skip) {
   for (int l = 0; l + 1 < nl; ++l) {
     nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
     NK_TRY(mg_smooth(M, F, true, d_skip));
-    NK_TRY(nk_problem_jvp_dev(F.P, F.u, F.x, F.t, d_skip));
-    NK_LAUNCH(ctx, k_mg_resid, g1(F.n), dim3(NK_BLOCK), F.n, (const double *)F.b, (const double *)F.t, F.r, d_skip);
+    NK_TRY(mg_residual(F, F.x, F.r, d_skip));
     NK_LAUNCH(ctx, k_mg_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.rlo, (const double *)F.rw,
               (const double *)F.r, C.b, d_skip);
   }

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp(int64_t ns, int64_t nl, 
   const double res = c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * vk;
   if (epi.mode == 0) {
     jv[k] = os * res;
+  } else if (epi.mode == 2) {  // fused residual: out = b − J v (b = epi.r)
+    jv[k] = epi.r[k] - res;
   } else {  // fused Chebyshev step (v = d_old): r −= J d; d_new = c1 d_old + c2 r; y += d_new
     const double rr = epi.r[k] - res;
     epi.r[k] = rr;
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_fd_diff(int64_t n, const double *_
 
 int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
                        const double *d_out_scale, const nk_spmv_epi *epi) {
-  if (epi && epi->mode != 0 && P->kind != NK_PROBLEM_BRATU2D)
+  if (epi && epi->mode != 0 && P->kind != NK_PROBLEM_BRATU2D)  // (modes: 1 fused Chebyshev step, 2 fused residual b − Jv)
     NK_FAIL(NK_E_UNSUPPORTED, "internal: fused epilogue only exists for the Bratu JVP");
   nk_spmv_epi ep{};
   if (epi) ep = *epi;
