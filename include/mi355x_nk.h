@@ -88,7 +88,7 @@ typedef enum {
   NK_ORTHO_CGS = 2,  /* classical GS, re-orthogonalise only when ‖w'‖ < ‖w‖/√2 (DGKS)                 */
   NK_ORTHO_DCGS2 = 3, /* the default: CGS2 arithmetic with delayed re-orthogonalisation — two sweeps over the basis and
                        * (with the built-in linear operators) ONE reduction / all-reduce per Arnoldi step; operators
-                       * reached through callbacks keep two reductions; restart > 31 silently uses NK_ORTHO_CGS2      */
+                       * reached through callbacks keep two reductions (and plain CGS2 when restart > 31)            */
   NK_ORTHO_DCGS2_1R = 4 /* insist on the one-reduction form (the pending vector's second projection and the new vector's
                        * first projection share a fused dot sweep; the Hessenberg column and the stopping test lag
                        * one step); falls back like NK_ORTHO_DCGS2 where the operator does not allow it            */

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy(int64_t n, int nv, dou
                                                           const double *__restrict__ ca_g, const double *__restrict__ cb_g,
                                                           const int *d_skip) {
   SKIP_GUARD(d_skip);
-  __shared__ double ca[NK_MAX_NV / 2 + 2], cb[NK_MAX_NV / 2 + 2];
+  __shared__ double ca[NK_MAX_NV + 2], cb[NK_MAX_NV + 2];
   __shared__ double s_bk, s_sz;
   if ((int)threadIdx.x <= nv) {  // one zero entry past the end pads an odd column count
     ca[threadIdx.x] = ((int)threadIdx.x < nv) ? ca_g[threadIdx.x] : 0.0;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy(int64_t n, int nv, dou
 
 int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double *V, int64_t ldv, double *d_red,
                         const int *d_skip) {
-  NK_REQUIRE(k >= 0 && k <= 31, "DCGS2-1R handles 0..31 final columns (got %d)", k);
+  NK_REQUIRE(k >= 0 && k <= NK_MAX_NV - 2, "DCGS2-1R handles 0..%d final columns (got %d)", NK_MAX_NV - 2, k);
   NK_REQUIRE(n < (1ll << 31), "fused pass: local vector too long for 32-bit offsets");
   const int64_t tile = (int64_t)NK_BLOCK * DR;
   const int64_t g64 = (n + tile - 1) / tile;
@@ -563,7 +563,7 @@ int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double 
 
 int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
                         const int *d_skip) {
-  NK_REQUIRE(k >= 0 && k <= 31, "DCGS2-1R handles 0..31 final columns (got %d)", k);
+  NK_REQUIRE(k >= 0 && k <= NK_MAX_NV - 2, "DCGS2-1R handles 0..%d final columns (got %d)", NK_MAX_NV - 2, k);
   const int64_t tile = (int64_t)NK_BLOCK * DR;
   const int grid = (int)std::max<int64_t>(1, (n + tile - 1) / tile);
   nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 4));

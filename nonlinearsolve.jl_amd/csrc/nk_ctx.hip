@@ -45,7 +45,7 @@ extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   ctx->stream = (hipStream_t)stream;  // NULL = the device's default (null) stream, as in every HIP API
-  NK_TRY(nk_dev_alloc(&ctx->d_partials, (size_t)(NK_MAX_NV + 2) * NK_MAX_ROW_TILES));
+  NK_TRY(nk_dev_alloc(&ctx->d_partials, (size_t)(2 * NK_MAX_NV + 2) * NK_MAX_ROW_TILES));  // DCGS2 dot sweep: 2k+2 slots
   NK_TRY(nk_dev_alloc(&ctx->d_partials_ss, (size_t)NK_MAX_RED_BLOCKS));
   NK_TRY(nk_dev_alloc(&ctx->d_scal, (size_t)4 * NK_MAX_NV));
   NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV, hipHostMallocDefault));

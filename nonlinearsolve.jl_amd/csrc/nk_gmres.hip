@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const 
 }
 
 // DCGS2 with one reduction per step — the scalar work between the dot sweep and the axpy sweep of step k (one wave does
-// the serial part; k ≤ 31). red = [R_j = ṽ_j·u (k), a = u·u, G_j = ṽ_j·z (k), d = u·z], all-reduced, unscaled.
+// the serial part; k < NK_MAX_NV). red = [R_j = ṽ_j·u (k), a = u·u, G_j = ṽ_j·z (k), d = u·z], all-reduced, unscaled.
 //   r = s∘R, g = s∘G, β² = a − rᵀr, s_k = 1/β;  H[0:k, k−1] = t_prev + r, H[k, k−1] = β  → Givens on column k−1 (one step
 //   late), stopping test;  c = H̄_{k−1} r;  t = [(g − c_{0:k})/β ; (d − rᵀg − β c_k)/β²]  (first projection of A v_k)
 //   axpy coefficients: a_j = r_j s_j;  b_j = (s_k c_j + t_j) s_j (j<k), b_k = (s_k c_k + t_k) s_k, b_{k+1} = s_k (scale of z)
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
                                                      double *R, double *cs, double *sn, double *g,
                                                      double *__restrict__ a_out, double *__restrict__ b_out) {
   if (ctl->done) return;
-  constexpr int NH = NK_MAX_NV / 2 + 2, LH = NK_MAX_NV / 2 + 1;
+  constexpr int NH = NK_MAX_NV + 2, LH = NK_MAX_NV + 1;  // any restart the GMRES object accepts (m < NK_MAX_NV)
   __shared__ double sr[NH], sg[NH], sc_[NH], sh[NH], scs[NH], ssn[NH], ssc[NH];
   __shared__ double sH[NH * LH];  // H̄ rows 0..k, columns 0..k−1, staged in one round trip
   __shared__ double s_beta, s_sk, s_gj, s_a, s_d, s_tol;
@@ -389,7 +389,6 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_REQUIRE(ortho == NK_ORTHO_MGS || ortho == NK_ORTHO_CGS2 || ortho == NK_ORTHO_CGS || ortho == NK_ORTHO_DCGS2 ||
                  ortho == NK_ORTHO_DCGS2_1R,
              "bad ortho %d", ortho);
-  if ((ortho == NK_ORTHO_DCGS2 || ortho == NK_ORTHO_DCGS2_1R) && restart_m > 31) ortho = NK_ORTHO_CGS2;  // the fused sweeps hold ≤ 32 columns in registers
   NK_HIP(hipSetDevice(ctx->device));
   nk_gmres *G = new nk_gmres();
   G->ctx = ctx;
@@ -762,7 +761,7 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
 // eligible: built-in linear operators (they take the un-normalised pending column as it is) and no callback preconditioner
 static bool dcgs2r_eligible(const nk_gmres *G) {
   const bool op_ok = (G->op_kind == 1) || (G->op_kind == 2 && G->P->kind != NK_PROBLEM_USER);
-  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2 || G->prec_kind == 3) && G->m <= 31 &&
+  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2 || G->prec_kind == 3) && G->m <= NK_MAX_NV - 2 &&
          G->n <= (int64_t)NK_MAX_ROW_TILES * NK_BLOCK * 8;
 }
 static bool use_dcgs2r(const nk_gmres *G) {
@@ -802,7 +801,10 @@ static int arnoldi_step(nk_gmres *G, int k) {
   const int nv = k + 1;
   double *wk = G->V + (size_t)(k + 1) * ldv;  // the new (un-normalised) column is built in place
   NK_TRY(op_apply(G, G->V + (size_t)k * ldv, wk, skip, G->d_s + k));
-  if (G->ortho == NK_ORTHO_DCGS2 || G->ortho == NK_ORTHO_DCGS2_1R) {
+  // (operators reached through callbacks cannot take the one-reduction form; their two-reduction form keeps ≤ 32 columns in
+  //  registers, so longer restarts fall through to plain CGS2 below)
+  const bool dcgs2_family = (G->ortho == NK_ORTHO_DCGS2 || G->ortho == NK_ORTHO_DCGS2_1R);
+  if (dcgs2_family && G->m <= 31) {
     // CGS2 with delayed re-orthogonalisation: column k holds p (first projection only) when k ≥ 1; the operator above
     // was applied to it. Pass A applies the pending correction to column k, rebuilds A v_k from A p through the Arnoldi
     // relation and takes the first projection of the new vector — one sweep over the basis; pass B is the usual fused
