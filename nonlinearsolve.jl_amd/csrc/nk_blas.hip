@@ -78,11 +78,12 @@ __device__ __forceinline__ void block_sum_array_store(const double (&acc)[NV], i
 __global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum(const double *__restrict__ partials, int nblk,
                                                          double *__restrict__ out, const int *d_skip,
                                                          const double *__restrict__ scales, int nscaled) {
-  SKIP_GUARD(d_skip);
+  const int skip = (d_skip != nullptr) ? *d_skip : 0;  // requested together with the partials (one round trip)
   __shared__ double sm[4];
   const double *p = partials + (size_t)blockIdx.x * nblk;
   double v = 0.0;
   for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) v += p[i];
+  if (skip) return;
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();

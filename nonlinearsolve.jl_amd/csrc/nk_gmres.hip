@@ -190,18 +190,21 @@ __global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const 
 //   late), stopping test;  c = H̄_{k−1} r;  t = [(g − c_{0:k})/β ; (d − rᵀg − β c_k)/β²]  (first projection of A v_k)
 //   axpy coefficients: a_j = r_j s_j;  b_j = (s_k c_j + t_j) s_j (j<k), b_k = (s_k c_k + t_k) s_k, b_{k+1} = s_k (scale of z)
 // k = 0: column 0 is final, only t_0 = s_0² d. `last`: the flush after the cycle's last step — no z, no coefficients.
+// Latency matters here, not bandwidth (one workgroup between two sweeps): every global operand is requested up front with
+// clamped, unconditional addresses (a load behind a lane predicate costs a full round trip each — five of them in the first
+// version of this kernel), the two inner products run as wave reductions, and H̄ r is split four ways.
 __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, int last, const double *__restrict__ red,
                                                      double *s, double *__restrict__ Hraw, int m, double *__restrict__ tprev,
                                                      double *R, double *cs, double *sn, double *g,
                                                      double *__restrict__ a_out, double *__restrict__ b_out) {
-  if (ctl->done) return;
+  const int done = ctl->done;
   constexpr int NH = NK_MAX_NV + 2, LH = NK_MAX_NV + 1;  // any restart the GMRES object accepts (m < NK_MAX_NV)
   __shared__ double sr[NH], sg[NH], sc_[NH], sh[NH], scs[NH], ssn[NH], ssc[NH];
   __shared__ double sH[NH * LH];  // H̄ rows 0..k, columns 0..k−1, staged in one round trip
-  __shared__ double s_beta, s_sk, s_gj, s_a, s_d, s_tol;
+  __shared__ double spart[4 * 64];
   const int t = threadIdx.x;
   if (k == 0) {
-    if (t == 0) {
+    if (t == 0 && !done) {
       const double s0 = s[0], tl = s0 * s0 * red[1];
       tprev[0] = tl;
       b_out[0] = tl * s0;
@@ -209,71 +212,99 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
     }
     return;
   }
-  // every global read is issued here
-  if (t < k) {
-    const double st = s[t];
-    ssc[t] = st;
-    sr[t] = st * red[t];
-    sg[t] = last ? 0.0 : st * red[k + 1 + t];
-    sh[t] = tprev[t];
-    if (t < k - 1) { scs[t] = cs[t]; ssn[t] = sn[t]; }
-  }
-  if (t == 0) { s_gj = g[k - 1]; s_a = red[k]; s_d = last ? 0.0 : red[2 * k + 1]; s_tol = ctl->tol; }
-  if (!last) {
-    for (int e = t; e < (k + 1) * (k - 1); e += 256) {  // columns 0..k−2 (column k−1 is completed below)
-      const int i = e / (k - 1), j = e - i * (k - 1);
-      sH[i * LH + j] = (i <= j + 1) ? Hraw[(size_t)i * m + j] : 0.0;
+  // ---- every global read, back to back
+  const int tc = t < k ? t : k - 1;
+  const int tr = t < k - 1 ? t : (k > 1 ? k - 2 : 0);
+  const double st = s[tc];
+  const double r_raw = red[tc];
+  const double g_raw = red[last ? tc : k + 1 + tc];
+  const double tp = tprev[tc];
+  const double csv = cs[tr], snv = sn[tr];
+  const double gj = g[k - 1], ra = red[k], rd = red[last ? k : 2 * k + 1], tol = ctl->tol;
+  const int km1 = k > 1 ? k - 1 : 1;
+  const int tot = last ? 0 : (k + 1) * (k - 1);  // columns 0..k−2 (column k−1 is completed below)
+  for (int e0 = 0; e0 < tot; e0 += 1024) {
+    double hv[4];
+    int at[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + t + 256 * q, ec = e < tot ? e : 0;
+      const int i = ec / km1, j = ec - i * km1;
+      hv[q] = Hraw[(size_t)i * m + j];
+      at[q] = (e < tot) ? (i * LH + j) : -1;
+      if (i > j + 1) hv[q] = 0.0;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (at[q] >= 0) sH[at[q]] = hv[q];
   }
-  __syncthreads();
-  if (t < k) sh[t] += sr[t];
+  const double rt = (t < k) ? st * r_raw : 0.0;
+  const double gt = (t < k && !last) ? st * g_raw : 0.0;
+  const double ht = tp + rt;  // entry t of the Hessenberg column that completes now (t < k)
+  double rr = rt * rt, rg = rt * gt;  // wave 0 holds every t < k ≤ 62
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    rr += __shfl_xor(rr, o, 64);
+    rg += __shfl_xor(rg, o, 64);
+  }
+  if (done) return;  // uniform
+  const int jc = k - 1;
+  if (t < k) {
+    ssc[t] = st;
+    sr[t] = rt;
+    sg[t] = gt;
+    sh[t] = ht;
+    if (t < k - 1) { scs[t] = csv; ssn[t] = snv; }
+    Hraw[(size_t)t * m + jc] = ht;
+    sH[t * LH + jc] = ht;
+  }
+  double b2 = ra - rr;  // ‖u − V r‖² by Pythagoras
+  if (b2 < 0.0) b2 = 0.0;
+  const double beta = sqrt(b2), sk = (beta > 0.0) ? 1.0 / beta : 0.0;
+  if (t == 0) {
+    s[k] = sk;
+    Hraw[(size_t)k * m + jc] = beta;
+    sH[k * LH + jc] = beta;
+  }
   __syncthreads();
   if (t == 0) {
-    double rr = 0.0;
-    for (int j = 0; j < k; ++j) rr += sr[j] * sr[j];
-    double b2 = s_a - rr;  // ‖u − V r‖² by Pythagoras
-    if (b2 < 0.0) b2 = 0.0;
-    const double beta = sqrt(b2), sk = (beta > 0.0) ? 1.0 / beta : 0.0;
-    s_beta = beta;
-    s_sk = sk;
-    s[k] = sk;
-    const int j = k - 1;  // the Hessenberg column that is complete now
-    for (int i = 0; i < k; ++i) { Hraw[(size_t)i * m + j] = sh[i]; sH[i * LH + j] = sh[i]; }
-    Hraw[(size_t)k * m + j] = beta;
-    sH[k * LH + j] = beta;
     double hk = sh[0];
-    for (int i = 0; i < j; ++i) {
+#pragma unroll 4
+    for (int i = 0; i < jc; ++i) {
       const double a = hk, b = sh[i + 1];
-      R[(size_t)i * m + j] = scs[i] * a + ssn[i] * b;
+      R[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
       hk = -ssn[i] * a + scs[i] * b;
     }
     const double d = hypot(hk, beta);
     double c, sgn;
     if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
-    cs[j] = c;
-    sn[j] = sgn;
-    R[(size_t)j * m + j] = d;
-    const double gj = s_gj;
-    g[j + 1] = -sgn * gj;
-    g[j] = c * gj;
+    cs[jc] = c;
+    sn[jc] = sgn;
+    R[(size_t)jc * m + jc] = d;
+    g[jc + 1] = -sgn * gj;
+    g[jc] = c * gj;
     const double rn = fabs(sgn * gj);
     ctl->k = k;
     ctl->rnorm = rn;
     ctl->hn = beta;
     ctl->inv_hn = sk;
     if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; ctl->done = 1; }
-    else if (s_tol >= 0.0 && rn <= s_tol) { ctl->converged = 1; ctl->done = 1; }
+    else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; ctl->done = 1; }
     else if (beta == 0.0) { ctl->converged = 1; ctl->done = 1; }
   }
-  __syncthreads();
   if (last) return;
-  if (t <= k) {  // c = H̄_{k−1} r: rows 0..k, columns 0..k−1 (upper Hessenberg)
+  {  // c = H̄_{k−1} r: rows 0..k, columns 0..k−1; the entries below the sub-diagonal are stored zeros
+    const int row = t & 63, part = t >> 6;
     double c = 0.0;
-    for (int j = (t > 0 ? t - 1 : 0); j < k; ++j) c += sH[t * LH + j] * sr[j];
-    sc_[t] = c;
+    if (row <= k) {
+#pragma unroll 4
+      for (int j = part; j < k; j += 4) c += sH[row * LH + j] * sr[j];
+    }
+    spart[part * 64 + row] = c;
   }
   __syncthreads();
-  const double beta = s_beta, sk = s_sk;
+  if (t <= k) sc_[t] = (spart[t] + spart[64 + t]) + (spart[128 + t] + spart[192 + t]);
+  __syncthreads();
   if (t < k) {
     const double tt = (sg[t] - sc_[t]) * sk;
     tprev[t] = tt;
@@ -281,9 +312,7 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
     b_out[t] = (sk * sc_[t] + tt) * ssc[t];
   }
   if (t == 0) {
-    double rg = 0.0;
-    for (int j = 0; j < k; ++j) rg += sr[j] * sg[j];
-    const double tl = (s_d - rg - beta * sc_[k]) * sk * sk;
+    const double tl = (rd - rg - beta * sc_[k]) * sk * sk;
     tprev[k] = tl;
     b_out[k] = (sk * sc_[k] + tl) * sk;
     b_out[k + 1] = sk;
