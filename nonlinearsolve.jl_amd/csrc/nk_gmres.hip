@@ -382,31 +382,44 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
   else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; }  // happy breakdown
 }
 
-// y = R(0:k,0:k)^{-1} g(0:k), k = ctl->k. R and g are staged in LDS; one lane runs the recurrence.
-__global__ __launch_bounds__(64) void k_backsolve(const nk_gmres_ctl *ctl, const double *R, const double *g, double *y,
-                                                  int m) {
-  __shared__ double sR[(NK_MAX_NV) * (NK_MAX_NV)];
-  __shared__ double sg[NK_MAX_NV + 1], sy[NK_MAX_NV + 1];
-  const int k = ctl->k;
-  for (int idx = threadIdx.x; idx < k * k; idx += 64) {
-    const int i = idx / k, j = idx - i * k;
-    sR[i * k + j] = R[(size_t)i * m + j];
-  }
-  for (int i = threadIdx.x; i < k; i += 64) sg[i] = g[i];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (ctl->failed) {
-      for (int i = 0; i < m; ++i) y[i] = 0.0;
-    } else {
-      for (int i = k - 1; i >= 0; --i) {
-        double sum = sg[i];
-        for (int j = i + 1; j < k; ++j) sum -= sR[i * k + j] * sy[j];
-        sy[i] = sum / sR[i * k + i];
-      }
-      for (int i = 0; i < k; ++i) y[i] = sy[i];
-      for (int i = k; i < m; ++i) y[i] = 0.0;
+// y = R(0:k,0:k)^{-1} g(0:k), k = ctl->k. R is staged in LDS with batched loads; wave 0 runs the column-oriented
+// recurrence (lane t owns g_t: after y_i is known every lane t < i takes R_ti y_i off its entry) — k dependent steps instead
+// of k²/2 on one lane.
+__global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, const double *__restrict__ R,
+                                                   const double *__restrict__ g, double *__restrict__ y, int m) {
+  constexpr int LK = NK_MAX_NV + 1;  // odd stride: the column reads below are conflict-free
+  __shared__ double sR[NK_MAX_NV * LK];
+  const int k = ctl->k, failed = ctl->failed;
+  const int t = threadIdx.x;
+  const int tot = k * k, kd = k > 0 ? k : 1;
+  double gv = g[t < k ? t : 0];
+  for (int e0 = 0; e0 < tot; e0 += 1024) {
+    double rv[4];
+    int at[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + t + 256 * q, ec = e < tot ? e : 0;
+      const int i = ec / kd, j = ec - i * kd;
+      rv[q] = R[(size_t)i * m + j];
+      at[q] = (e < tot) ? i * LK + j : -1;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (at[q] >= 0) sR[at[q]] = rv[q];
   }
+  __syncthreads();
+  if (t >= 64) return;
+  if (t >= k) gv = 0.0;
+  if (!failed) {
+    for (int i = k - 1; i >= 0; --i) {
+      const double yi = __shfl(gv, i, 64) / sR[i * LK + i];
+      if (t < i) gv -= sR[t * LK + i] * yi;
+      if (t == i) gv = yi;
+    }
+  } else {
+    gv = 0.0;
+  }
+  if (t < m) y[t] = gv;
 }
 
 // ----------------------------------------------------------------------------- create / destroy / operators
@@ -944,7 +957,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
       if (one_red && !stopped) NK_TRY(arnoldi_flush_1r(G, steps));
     }
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
-    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(64), G->d_ctl, G->d_R, G->d_g, G->d_y, m);
+    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m);
     if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s));
     } else {
