@@ -93,6 +93,65 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp(int64_t ns, int64_t nl, 
     epi.yacc[k] += dn;
   }
 }
+// Tiled form of k_bratu_jvp: a thread owns column i of TY consecutive grid lines, so the TY+2 values of its column are
+// loaded once (6 instead of 12 vertical loads for TY = 4), the index arithmetic is 32-bit with no division (blockIdx.y is
+// the line tile), and every load of the tile is issued before the first use. Same arithmetic, term by term, as bratu_lap.
+template <int TY>
+__global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp_tile(int ns, int nl, double c_lap, const double *__restrict__ d,
+                                                             const double *__restrict__ v,
+                                                             const double *__restrict__ lo,
+                                                             const double *__restrict__ hi, double *__restrict__ jv,
+                                                             const int *d_skip, const double *__restrict__ out_scale,
+                                                             const nk_spmv_epi epi) {
+  const int skip = d_skip ? *d_skip : 0;
+  const double os = out_scale ? *out_scale : 1.0;
+  const int i = blockIdx.x * NK_BLOCK + threadIdx.x;
+  const int j0 = blockIdx.y * TY;
+  if (i >= ns) return;
+  const int iw = i > 0 ? i - 1 : i, ie = i < ns - 1 ? i + 1 : i;
+  const double mw = (i > 0) ? 1.0 : 0.0, me = (i < ns - 1) ? 1.0 : 0.0;
+  double col[TY + 2], w[TY], e[TY], dg[TY], rr[TY];
+#pragma unroll
+  for (int q = 0; q < TY + 2; ++q) {
+    int jl = j0 - 1 + q;
+    jl = jl < 0 ? 0 : (jl > nl - 1 ? nl - 1 : jl);
+    col[q] = v[(size_t)jl * ns + i];
+  }
+#pragma unroll
+  for (int r = 0; r < TY; ++r) {
+    const int jl = (j0 + r < nl) ? j0 + r : nl - 1;
+    const size_t row = (size_t)jl * ns;
+    w[r] = v[row + iw];
+    e[r] = v[row + ie];
+    dg[r] = d[row + i];
+    rr[r] = (epi.mode != 0) ? epi.r[row + i] : 0.0;
+  }
+  if (j0 == 0 && lo) col[0] = lo[i];                                  // uniform per workgroup
+  const double hiv = (j0 + TY >= nl && hi) ? hi[i] : 0.0;             // line nl: the upper neighbour rank's first line
+  if (skip) return;
+#pragma unroll
+  for (int r = 0; r < TY; ++r) {
+    const int jl = j0 + r;
+    if (jl < nl) {
+      const double ms = (jl > 0 || lo) ? 1.0 : 0.0, mn = (jl < nl - 1 || hi) ? 1.0 : 0.0;
+      const double c = col[r + 1];
+      const double nn = (jl == nl - 1) ? hiv : col[r + 2];  // (weight mn = 0 without an upper neighbour)
+      const double res = c_lap * (4.0 * c - mw * w[r] - me * e[r] - ms * col[r] - mn * nn) - dg[r] * c;
+      const size_t k = (size_t)jl * ns + i;
+      if (epi.mode == 0) {
+        jv[k] = os * res;
+      } else if (epi.mode == 2) {  // fused residual: out = b − J v (b = epi.r)
+        jv[k] = rr[r] - res;
+      } else {  // fused Chebyshev step (v = d_old): r −= J d; d_new = c1 d_old + c2 r; y += d_new
+        const double rn = rr[r] - res;
+        epi.r[k] = rn;
+        const double dn = epi.c1 * c + epi.c2 * rn;
+        epi.dnew[k] = dn;
+        epi.yacc[k] += dn;
+      }
+    }
+  }
+}
 // values in pattern order [S?][W?][C][E?][N?] (columns ascending); j = global grid line
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
                                                         double c_exp, const double *__restrict__ u,
@@ -447,8 +506,17 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
       const double *lo, *hi;
       NK_TRY(nk_halo_exchange(ctx, &P->halo, d_v));
       halo_lines(P, 1, false, &lo, &hi);
-      NK_LAUNCH(ctx, k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->c_lap,
-                         P->d_diag, d_v, lo, hi, d_jv, d_skip, d_out_scale, ep);
+      static const bool flat = getenv("NK_BRATU_JVP_FLAT") != nullptr;  // A/B switch: one point per thread
+      const int64_t nl = P->j1 - P->j0;
+      if (flat || P->ns >= (1ll << 30)) {
+        NK_LAUNCH(ctx, k_bratu_jvp, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, nl, P->c_lap, P->d_diag, d_v, lo, hi, d_jv,
+                  d_skip, d_out_scale, ep);
+      } else {
+        constexpr int TY = 4;
+        const dim3 grid((unsigned)((P->ns + NK_BLOCK - 1) / NK_BLOCK), (unsigned)((nl + TY - 1) / TY));
+        NK_LAUNCH(ctx, k_bratu_jvp_tile<TY>, grid, dim3(NK_BLOCK), (int)P->ns, (int)nl, P->c_lap, P->d_diag, d_v, lo, hi,
+                  d_jv, d_skip, d_out_scale, ep);
+      }
       break;
     }
     case NK_PROBLEM_BRUSSELATOR2D: {
