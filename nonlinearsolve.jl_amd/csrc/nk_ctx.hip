@@ -360,6 +360,15 @@ int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t
   }
   H->n_send = so;
   H->n_recv = ro;
+  H->contig_base.assign(P, 0);
+  H->contig = getenv("NK_HALO_GATHER") == nullptr;  // NK_HALO_GATHER=1: always stage through the gather kernel (A/B)
+  for (int p = 0; p < P && H->contig; ++p) {
+    const std::vector<int32_t> &ix = send_idx_per_peer[p];
+    if (ix.empty()) continue;
+    H->contig_base[p] = ix[0];
+    for (size_t q = 1; q < ix.size(); ++q)
+      if (ix[q] != ix[0] + (int32_t)q) { H->contig = false; break; }
+  }
   NK_TRY(nk_dev_alloc(&H->d_send_idx, (size_t)so));
   NK_TRY(nk_dev_alloc(&H->d_send, (size_t)so));
   NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)ro));
@@ -370,7 +379,8 @@ int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t
 // gather + (optionally on `xstream`) the exchange itself
 static int halo_exchange_on(nk_ctx *ctx, nk_halo *H, const double *d_x_local, hipStream_t xstream) {
   const int P = ctx->nranks;
-  if (H->n_send) {
+  const bool direct = H->contig && H->send_cnt[ctx->rank] == 0;  // send from the vector itself
+  if (H->n_send && !direct) {
     int grid = (int)((H->n_send + NK_BLOCK - 1) / NK_BLOCK);
     NK_LAUNCH(ctx, k_gather, dim3(grid), dim3(NK_BLOCK), H->n_send, H->d_send_idx,
                        d_x_local, H->d_send);
@@ -383,7 +393,7 @@ static int halo_exchange_on(nk_ctx *ctx, nk_halo *H, const double *d_x_local, hi
   if (P > 1) {
     std::vector<int64_t> so(P), sb(P), ro(P), rb(P);
     for (int p = 0; p < P; ++p) {
-      so[p] = H->send_off[p] * 8;
+      so[p] = (direct ? H->contig_base[p] : H->send_off[p]) * 8;
       sb[p] = (p == ctx->rank) ? 0 : H->send_cnt[p] * 8;
       ro[p] = H->recv_off[p] * 8;
       rb[p] = (p == ctx->rank) ? 0 : H->recv_cnt[p] * 8;
@@ -393,7 +403,8 @@ static int halo_exchange_on(nk_ctx *ctx, nk_halo *H, const double *d_x_local, hi
       NK_HIP(hipEventRecord(ctx->ev_halo_ready, ctx->stream));
       NK_HIP(hipStreamWaitEvent(xstream, ctx->ev_halo_ready, 0));
     }
-    NK_TRY(nk_comm_alltoallv(ctx, H->d_send, so.data(), sb.data(), H->d_recv, ro.data(), rb.data(), xstream));
+    NK_TRY(nk_comm_alltoallv(ctx, direct ? (const void *)d_x_local : (const void *)H->d_send, so.data(), sb.data(),
+                             H->d_recv, ro.data(), rb.data(), xstream));
     if (xstream) NK_HIP(hipEventRecord(ctx->ev_halo_done, xstream));
   }
   return NK_OK;

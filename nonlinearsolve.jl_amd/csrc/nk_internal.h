@@ -122,6 +122,10 @@ struct nk_halo {
   std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;  // per peer (size nranks), in elements
   int32_t *d_send_idx = nullptr;  // local indices to gather (n_send)
   double *d_send = nullptr, *d_recv = nullptr;
+  // every peer's send list is one contiguous local range (row-partitioned stencils: whole grid lines) → the exchange
+  // sends straight from the vector, no gather launch
+  std::vector<int64_t> contig_base;
+  bool contig = false;
   bool active() const { return n_send > 0 || n_recv > 0; }
 };
 int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
