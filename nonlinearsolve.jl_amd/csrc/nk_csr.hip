@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     int nblk, const int4 *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
     const double *__restrict__ xhalo, int32_t nlocal, double *__restrict__ y, const int *d_skip,
-    const double *__restrict__ out_scale, const nk_spmv_epi epi) {
+    const double *__restrict__ out_scale, const nk_spmv_epi epi, const int16_t *__restrict__ col16, int n16) {
   if (d_skip != nullptr && *d_skip != 0) return;
   const double os = out_scale ? *out_scale : 1.0;
   __shared__ double prod[TILE];
@@ -69,10 +69,13 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     int c[PER];
     double v[PER], xv[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int k = threadIdx.x + NK_BLOCK * i;
-      c[i] = col[p0 + k];  // in bounds: col/val are padded by SPMV_TILE_MAX entries
-      v[i] = val[p0 + k];
+    for (int i = 0; i < PER; ++i) v[i] = val[p0 + threadIdx.x + NK_BLOCK * i];  // in bounds: padded by SPMV_TILE_MAX
+    if (b < n16) {  // uniform: this block's columns are stored as 16-bit offsets from its first row
+#pragma unroll
+      for (int i = 0; i < PER; ++i) c[i] = r0 + (int)col16[p0 + threadIdx.x + NK_BLOCK * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) c[i] = col[p0 + threadIdx.x + NK_BLOCK * i];
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -235,6 +238,25 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
       desc[4 * i + 1] = rb[b + 1];
       desc[4 * i + 2] = rowptr[rb[b]];
       desc[4 * i + 3] = rowptr[rb[b + 1]];
+    }
+  }
+  // 16-bit block-relative columns for the interior blocks (all or none; NK_SPMV_COL32=1 keeps 32-bit ids everywhere)
+  if (nnz && A->nblocks_interior > 0 && getenv("NK_SPMV_COL32") == nullptr) {
+    std::vector<int16_t> c16((size_t)nnz, 0);
+    bool fits = true;
+    for (int i = 0; i < A->nblocks_interior && fits; ++i) {
+      const int32_t r0 = desc[4 * i], p0 = desc[4 * i + 2], p1 = desc[4 * i + 3];
+      for (int32_t k = p0; k < p1; ++k) {
+        const int32_t dlt = A->h_col[k] - r0;
+        if (dlt < -32768 || dlt > 32767) { fits = false; break; }
+        c16[k] = (int16_t)dlt;
+      }
+    }
+    if (fits) {
+      NK_HIP(hipMalloc((void **)&A->d_col16, ((size_t)nnz + SPMV_TILE_MAX) * sizeof(int16_t)));
+      NK_HIP(hipMemset(A->d_col16, 0, ((size_t)nnz + SPMV_TILE_MAX) * sizeof(int16_t)));
+      NK_HIP(hipMemcpy(A->d_col16, c16.data(), (size_t)nnz * sizeof(int16_t), hipMemcpyHostToDevice));
+      A->n16 = A->nblocks_interior;
     }
   }
   NK_TRY(nk_dev_alloc(&A->d_rowblocks, desc.size() + 4));
@@ -403,6 +425,7 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   if (!A) return NK_OK;
   hipFree(A->d_rowptr);
   hipFree(A->d_col);
+  hipFree(A->d_col16);
   hipFree(A->d_val);
   hipFree(A->d_rowblocks);
   hipFree(A->d_tperm);
@@ -459,7 +482,7 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
 #define SPMV_LAUNCH(T, H, R)                                                                                      \
   NK_LAUNCH(ctx, (k_spmv_stream<T, H, R>), dim3(nb_), dim3(NK_BLOCK), nb_,                                         \
             (const int4 *)A->d_rowblocks + b0_, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, \
-            d_y, d_skip, d_out_scale, ep)
+            d_y, d_skip, d_out_scale, ep, (const int16_t *)A->d_col16, A->n16 - b0_)
 #define SPMV_TILES(H, R)                                  \
   if (A->tile == 512) SPMV_LAUNCH(512, H, R);             \
   else if (A->tile == 2048) SPMV_LAUNCH(2048, H, R);      \

@@ -141,6 +141,10 @@ struct nk_csr {
   nk_ctx *ctx = nullptr;
   int64_t nrows = 0, n_global = 0, row_begin = 0, nnz = 0;
   int32_t *d_rowptr = nullptr, *d_col = nullptr;  // local columns: [0,nrows) owned, ≥ nrows → halo slot
+  // SpMV-only copy of the column ids as 16-bit offsets from the row block's first row (banded matrices: 2 instead of
+  // 4 bytes per non-zero on the stream); used for descriptors [0, n16) — the interior blocks, when all of them fit
+  int16_t *d_col16 = nullptr;
+  int n16 = 0;
   double *d_val = nullptr;
   int32_t *d_rowblocks = nullptr;
   int nblocks = 0;
