@@ -472,12 +472,13 @@ __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_dots(int64_t n, int nv, con
 
 // axpy sweep: p ← p − Σ a_j ṽ_j ; z ← b_{nv+1}·z − Σ b_j ṽ_j − b_nv·p (no reduction). Same shape as the dot sweep: the
 // workgroup's row tile of p and z lives in registers, the final columns stream past two at a time.
+// ss_partials (last step of a cycle only): per-tile ‖z_new‖² — the norm that closes the cycle's last Hessenberg column.
 __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy(int64_t n, int nv, double *__restrict__ V, int64_t ldv,
                                                           const double *__restrict__ ca_g, const double *__restrict__ cb_g,
-                                                          const int *d_skip) {
+                                                          const int *d_skip, double *__restrict__ ss_partials) {
   SKIP_GUARD(d_skip);
   __shared__ double ca[NK_MAX_NV + 2], cb[NK_MAX_NV + 2];
-  __shared__ double s_bk, s_sz;
+  __shared__ double s_bk, s_sz, s_w[4];
   if ((int)threadIdx.x <= nv) {  // one zero entry past the end pads an odd column count
     ca[threadIdx.x] = ((int)threadIdx.x < nv) ? ca_g[threadIdx.x] : 0.0;
     cb[threadIdx.x] = ((int)threadIdx.x < nv) ? cb_g[threadIdx.x] : 0.0;
@@ -516,13 +517,22 @@ __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy(int64_t n, int nv, dou
       zv[i] -= b1 * v1[i];
     }
   }
+  double ss = 0.0;
 #pragma unroll
   for (int i = 0; i < DR; ++i) {
     const unsigned r = base + NK_BLOCK * i;
     if (r < nn) {
       if (nv > 0) pk[r] = pv[i];
-      zk[r] = zv[i] - bk * pv[i];
+      const double zn = zv[i] - bk * pv[i];
+      zk[r] = zn;
+      ss += zn * zn;
     }
+  }
+  if (ss_partials != nullptr) {  // uniform
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) ss_partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
   }
 }
 
@@ -562,14 +572,22 @@ int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double 
   return nk_comm_allreduce(ctx, d_red, nslots, 0);
 }
 
+// d_ss_out != nullptr: also ‖z_new‖² (all-reduced) into *d_ss_out — the cycle's last step
 int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
-                        const int *d_skip) {
+                        const int *d_skip, double *d_ss_out) {
   NK_REQUIRE(k >= 0 && k <= NK_MAX_NV - 2, "DCGS2-1R handles 0..%d final columns (got %d)", NK_MAX_NV - 2, k);
   const int64_t tile = (int64_t)NK_BLOCK * DR;
   const int grid = (int)std::max<int64_t>(1, (n + tile - 1) / tile);
   nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 4));
-  NK_LAUNCH(ctx, k_dcgs2r_axpy, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, d_a, d_b, d_skip);
+  NK_LAUNCH(ctx, k_dcgs2r_axpy, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, d_a, d_b, d_skip,
+            d_ss_out ? ctx->d_partials : (double *)nullptr);
   NK_HIP(hipGetLastError());
+  if (d_ss_out) {
+    NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), ctx->d_partials, grid, d_ss_out, d_skip,
+              (const double *)nullptr, 0);
+    NK_HIP(hipGetLastError());
+    return nk_comm_allreduce(ctx, d_ss_out, 1, 0);
+  }
   return NK_OK;
 }
 

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
   const int tc = t < k ? t : k - 1;
   const int tr = t < k - 1 ? t : (k > 1 ? k - 2 : 0);
   const double st = s[tc];
-  const double r_raw = red[tc];
+  const double r_raw = (last == 2) ? 0.0 : red[tc];  // last = 2: the pending column closes the cycle un-re-orthogonalised
   const double g_raw = red[last ? tc : k + 1 + tc];
   const double tp = tprev[tc];
   const double csv = cs[tr], snv = sn[tr];
@@ -811,7 +811,16 @@ static bool use_dcgs2r(const nk_gmres *G) {
   static const bool two = getenv("NK_DCGS2_TWO_REDUCTIONS") != nullptr;  // A/B switch: keep the two-reduction form
   return G->ortho == NK_ORTHO_DCGS2_1R || (G->ortho == NK_ORTHO_DCGS2 && !two);
 }
-static int arnoldi_step_1r(nk_gmres *G, int k) {
+// The cycle's last Hessenberg column needs the norm of the pending column that the last step leaves behind. That column is
+// never used as a basis vector, so it is closed WITHOUT its second projection: β = ‖u‖ comes out of the last axpy sweep for
+// free and the column is the first projection alone (differs from the re-orthogonalised one by the re-orthogonalisation
+// correction, i.e. at rounding level: 1e-15 relative on the solutions, oracle/reference_restatement.py::gmres_dcgs2_1r).
+// NK_DCGS2_FULL_FLUSH=1 keeps the full form (one more dot sweep over all columns per cycle) for A/B runs.
+static bool dcgs2r_full_flush() {
+  static const bool full = getenv("NK_DCGS2_FULL_FLUSH") != nullptr;
+  return full;
+}
+static int arnoldi_step_1r(nk_gmres *G, int k, bool last_of_cycle) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n, ldv = G->ldv;
   const int *skip = &G->d_ctl->done;
@@ -820,7 +829,8 @@ static int arnoldi_step_1r(nk_gmres *G, int k) {
   NK_TRY(nk_blas_dcgs2r_dots(ctx, n, k, false, G->V, ldv, G->d_red, skip));
   NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, k, 0, (const double *)G->d_red, G->d_s, G->d_Hraw, G->m,
             G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
-  NK_TRY(nk_blas_dcgs2r_axpy(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, skip));
+  double *ss_out = (last_of_cycle && !dcgs2r_full_flush()) ? G->d_red + (k + 1) : nullptr;  // slot of u·u at the flush
+  NK_TRY(nk_blas_dcgs2r_axpy(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, skip, ss_out));
   return NK_OK;
 }
 // after the last step of a cycle: the pending column's reduction completes the last Hessenberg column
@@ -828,9 +838,10 @@ static int arnoldi_flush_1r(nk_gmres *G, int steps) {
   nk_ctx *ctx = G->ctx;
   const int *skip = &G->d_ctl->done;
   if (steps <= 0) return NK_OK;
-  NK_TRY(nk_blas_dcgs2r_dots(ctx, G->n, steps, true, G->V, G->ldv, G->d_red, skip));
-  NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, steps, 1, (const double *)G->d_red, G->d_s, G->d_Hraw, G->m,
-            G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
+  const bool full = dcgs2r_full_flush();
+  if (full) NK_TRY(nk_blas_dcgs2r_dots(ctx, G->n, steps, true, G->V, G->ldv, G->d_red, skip));
+  NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, steps, full ? 1 : 2, (const double *)G->d_red, G->d_s,
+            G->d_Hraw, G->m, G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
@@ -947,7 +958,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
       bool stopped = false;
       for (int k = 0; k < steps && !stopped;) {
         const int kend = (k + sync_every < steps) ? k + sync_every : steps;
-        for (; k < kend; ++k) NK_TRY(one_red ? arnoldi_step_1r(G, k) : arnoldi_step(G, k));
+        for (; k < kend; ++k) NK_TRY(one_red ? arnoldi_step_1r(G, k, k == steps - 1) : arnoldi_step(G, k));
         if (kend < steps) {
           NK_HIP(hipMemcpyAsync(G->h_ctl, G->d_ctl, sizeof(nk_gmres_ctl), hipMemcpyDeviceToHost, ctx->stream));
           NK_HIP(hipStreamSynchronize(ctx->stream));

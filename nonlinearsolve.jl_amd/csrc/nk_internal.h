@@ -225,7 +225,7 @@ int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t l
 int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double *V, int64_t ldv, double *d_red,
                         const int *d_skip);
 int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
-                        const int *d_skip);
+                        const int *d_skip, double *d_ss_out = nullptr);
 int nk_blas_dcgs2_pass_a(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, const double *d_a, const double *d_b,
                          const double *d_scales, double *d_h, const int *d_skip);
 int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,

@@ -417,7 +417,9 @@ def gmres_dcgs2_1r(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=3
     u_k; the operator is applied to it; one fused reduction yields r = Vᵀu (its pending second projection), ‖u‖², and
     the raw projections Vᵀz, uᵀz of z = A u; the Hessenberg column k−1 (one step late), v_k = (u − V r)/β,
     A v_k = (z − V H̄ r)/β and its first projection follow algebraically; one axpy sweep stores v_k and u_{k+1}.
-    Same arithmetic as CGS2 up to rounding; the stopping test sees a column one step after CGS2 would."""
+    Same arithmetic as CGS2 up to rounding; the stopping test sees a column one step after CGS2 would. The pending column
+    left by a cycle's last step only closes the last Hessenberg column, so it is not re-orthogonalised (its norm comes out
+    of the last axpy sweep): the solutions differ from the fully re-orthogonalised form by ~1e-15 relative."""
     ar = allreduce if allreduce is not None else (lambda z: z)
     b = np.asarray(b, dtype=np.float64)
     n = b.size
@@ -478,7 +480,10 @@ def gmres_dcgs2_1r(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=3
                 V[1] = z - tl * V[0]
                 tprev = np.array([tl])
                 continue
-            red = ar(np.concatenate([V[:k] @ u, [np.dot(u, u)]] + ([] if last else [V[:k] @ z, [np.dot(u, z)]])))
+            if last:  # the column that closes the cycle is never a basis vector: first projection only, β = ‖u‖
+                red = np.concatenate([np.zeros(k), ar(np.array([np.dot(u, u)]))])
+            else:
+                red = ar(np.concatenate([V[:k] @ u, [np.dot(u, u)], V[:k] @ z, [np.dot(u, z)]]))
             rr, a = red[:k], float(red[k])
             beta = math.sqrt(max(a - float(rr @ rr), 0.0))
             h = np.zeros(k + 1)
