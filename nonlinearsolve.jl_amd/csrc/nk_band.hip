@@ -495,6 +495,7 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
              "lower bandwidth %d too large for the LDS panel", kl);
   NK_REQUIRE(kl <= 512 && ku <= 512, "bandwidth %d+%d too large for the device band solver", kl, ku);
   nk_bandlu *B = new nk_bandlu();
+  auto guard = nk_make_guard(B, [](nk_bandlu *b) { nk_bandlu_destroy(b); });
   B->ctx = ctx;
   B->n = n;
   B->kl = kl;
@@ -511,7 +512,7 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
     NK_HIP(hipFuncSetAttribute((const void *)k_band_step, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     attr_set = true;
   }
-  *out = B;
+  *out = guard.release();
   return NK_OK;
 }
 

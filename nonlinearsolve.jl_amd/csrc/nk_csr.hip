@@ -179,6 +179,7 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   const int64_t nnz = (int64_t)gcol.size();
   NK_REQUIRE(nnz < (1ll << 31) && nrows < (1ll << 31), "local CSR too large for int32 indices");
   nk_csr *A = new nk_csr();
+  auto guard = nk_make_guard(A, [](nk_csr *a) { nk_csr_destroy(a); });
   A->ctx = ctx;
   A->nrows = nrows;
   A->n_global = n_global;
@@ -192,7 +193,6 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   for (int64_t k = 0; k < nnz; ++k) {
     const int64_t g = gcol[k];
     if (g < 0 || g >= n_global) {
-      delete A;
       NK_FAIL(NK_E_INVALID, "column index %lld out of range [0,%lld)", (long long)g, (long long)n_global);
     }
     if (g < lo || g >= hi) halo.push_back(g);
@@ -200,7 +200,6 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   std::sort(halo.begin(), halo.end());
   halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
   if (ctx->nranks == 1 && !halo.empty()) {
-    delete A;
     NK_FAIL(NK_E_INVALID, "single-rank CSR must be square: column outside the local row range");
   }
   A->halo_gcols = halo;
@@ -337,7 +336,7 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
     // halo slots are sorted by global id and owners are ordered by rank → recv layout == halo order
     NK_TRY(nk_halo_setup(ctx, &A->halo, send_idx, recv_cnt));
   }
-  *out = A;
+  *out = guard.release();
   return NK_OK;
 }
 

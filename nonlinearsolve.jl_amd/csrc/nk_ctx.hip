@@ -41,6 +41,7 @@ extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
   NK_REQUIRE(device_id >= 0 && device_id < c, "device_id %d out of range [0,%d)", device_id, c);
   NK_HIP(hipSetDevice(device_id));
   nk_ctx *ctx = new nk_ctx();
+  auto guard = nk_make_guard(ctx, [](nk_ctx *c) { nk_ctx_destroy(c); });
   ctx->device = device_id;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
@@ -51,7 +52,7 @@ extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
   NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV, hipHostMallocDefault));
   const char *ov = getenv("NK_HALO_OVERLAP");
   if (ov && atoi(ov) != 0) NK_TRY(nk_ctx_set_halo_overlap(ctx, 1));
-  *out = ctx;
+  *out = guard.release();
   return NK_OK;
 }
 

@@ -433,6 +433,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
              "bad ortho %d", ortho);
   NK_HIP(hipSetDevice(ctx->device));
   nk_gmres *G = new nk_gmres();
+  auto guard = nk_make_guard(G, [](nk_gmres *g) { nk_gmres_destroy(g); });
   G->ctx = ctx;
   G->n = n_local;
   G->m = restart_m;
@@ -467,7 +468,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_HIP(hipMemset(G->d_ctl, 0, sizeof(nk_gmres_ctl)));
   NK_HIP(hipMemset(G->V, 0, (size_t)G->ldv * (m + 1) * sizeof(double)));
   NK_HIP(hipMemset(G->d_s, 0, (NK_MAX_NV + 2) * sizeof(double)));
-  *out = G;
+  *out = guard.release();
   return NK_OK;
 }
 extern "C" int nk_gmres_destroy(nk_gmres *G) {

@@ -32,6 +32,17 @@ void nk_set_error(const char *fmt, ...);
     if (!(cond)) NK_FAIL(NK_E_INVALID, __VA_ARGS__); \
   } while (0)
 
+// frees a half-built object when a create function leaves early (NK_TRY / NK_HIP / NK_REQUIRE return on error)
+template <class T, class D>
+struct nk_scope_guard {
+  T *p;
+  D d;
+  ~nk_scope_guard() { if (p) d(p); }
+  T *release() { T *q = p; p = nullptr; return q; }
+};
+template <class T, class D>
+nk_scope_guard<T, D> nk_make_guard(T *p, D d) { return {p, d}; }
+
 // ----------------------------------------------------------------------------- context
 constexpr int NK_BLOCK = 256;          // 4 wavefronts of 64
 constexpr int NK_MAX_RED_BLOCKS = 1024; // stage-1 reduction blocks (4 per CU)

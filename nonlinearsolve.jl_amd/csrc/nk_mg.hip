@@ -155,6 +155,7 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   if (nu <= 0) nu = 2;
   if (coarse_max < 3) coarse_max = 31;  // MI355X, 1024² with set-up: 63 → 13.5 ms, 31 → 10.1, 15 → 9.5, 7 → 9.7
   nk_mg *M = new nk_mg();
+  auto guard = nk_make_guard(M, [](nk_mg *g) { nk_mg_destroy(g); });
   M->ctx = ctx;
   M->nu = nu;
   const double hf = 1.0 / (double)(P->ns + 1);
@@ -169,7 +170,7 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
     if (l == 0) L.P = P;
     else {
       const double par[3] = {(double)ns, lambda, scale};
-      if (nk_problem_create(ctx, NK_PROBLEM_BRATU2D, par, 3, &L.P) != NK_OK) { nk_mg_destroy(M); return NK_E_HIP; }
+      if (nk_problem_create(ctx, NK_PROBLEM_BRATU2D, par, 3, &L.P) != NK_OK) return NK_E_HIP;
       NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
     }
     NK_TRY(nk_dev_alloc(&L.b, (size_t)L.n + 1));
@@ -201,7 +202,7 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
     NK_TRY(nk_problem_jac_csr(C.P, &M->Jc));
     NK_TRY(nk_bandlu_create(M->Jc, &M->LU));
   }
-  *out = M;
+  *out = guard.release();
   return NK_OK;
 }
 

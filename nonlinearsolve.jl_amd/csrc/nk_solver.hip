@@ -458,6 +458,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   nk_solver *S = new nk_solver();
   S->P = P;
   S->ctx = ctx;
+  auto guard = nk_make_guard(S, [](nk_solver *s) { nk_solver_destroy(s); });
   S->o = *opts;
   if (S->o.maxiters <= 0) S->o.maxiters = 1000;
   if (S->o.gmres_restart <= 0) S->o.gmres_restart = 30;
@@ -501,9 +502,8 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   }
   NK_HIP(hipMemcpyAsync(S->u, u0, n * sizeof(double),
                         memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-  int st = solver_start(S);
-  if (st != NK_OK) { nk_solver_destroy(S); return st; }
-  *out = S;
+  NK_TRY(solver_start(S));
+  *out = guard.release();
   return NK_OK;
 }
 
