@@ -125,3 +125,14 @@ def test_ensemble_residuals_compile_for_gfx950_without_a_gpu():
     assert L.lib().nk_batch_compile_check(bad, 1, 0, 0, C.byref(nb)) != 0
     assert b"nope" in L.lib().nk_last_error()
     assert L.lib().nk_batch_compile_check(E.QUADRATIC.encode(), 65, 1, 0, C.byref(nb)) != 0   # n outside 1..64
+
+
+def test_plain_c_example_compiles_against_the_header(tmp_path):
+    """examples/bratu_c2.c — a C99 caller of the ABI, the shape of the `ccall` binding — builds with -Werror and links."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "bratu_c2"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "bratu_c2.c"),
+                           "-L", os.path.join(root, "nonlinearsolve.jl_amd", "lib"), "-lmi355x_nk", "-lm", "-o", str(exe)])
+    assert exe.exists()

@@ -4,6 +4,8 @@ Stated tolerances:
   GMRES vs oracle GMRES at equal (m, rtol): ‖x−x_ref‖₂ ≤ 10·rtol·‖x_ref‖₂
   Newton/TR final u vs oracle:              ‖u−u_ref‖∞ ≤ 1e-8·max(1, ‖u_ref‖∞), both at ‖F‖∞ ≤ abstol
   Newton step counts equal ±1 under the identical protocol."""
+import os
+
 import numpy as np
 import pytest
 
@@ -806,3 +808,19 @@ def test_gmres_dcgs2_long_restart(nls):
     xc, ic = R.gmres(lambda z: J @ z, b, rtol=1e-10, restart=60, itmax=3000, ortho="cgs2")
     x, info = nls.GMRES(p.n, restart=60).set_operator(A).solve(b, abstol=0.0, reltol=1e-10, maxiters=3000)
     assert info["converged"] and info["iters"] == ic.iters and np.linalg.norm(x - xc) <= 1e-9 * np.linalg.norm(xc)
+
+
+def test_plain_c_caller_runs_config_c2(tmp_path):
+    """The C ABI from plain C (examples/bratu_c2.c): config C2 (Bratu 256², direct) and the Newton–Krylov path converge."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "bratu_c2"
+    libdir = os.path.join(root, "nonlinearsolve.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "bratu_c2.c"), "-L", libdir, "-lmi355x_nk", "-lm", "-o", str(exe)])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe), "256"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if "retcode=" in l]
+    assert len(lines) == 2 and all("retcode=1 " in l for l in lines), out.stdout
+    assert "nsteps=3 " in lines[0] and "nfactors=3 " in lines[0]  # C2: 3 Newton steps, 3 factorisations (BASELINE.md §4)
