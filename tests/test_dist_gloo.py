@@ -104,6 +104,15 @@ def _worker(rank, world, port, ns, q):
         assert np.linalg.norm(x_loc - x_ser[rb:re_]) <= 1e-7 * np.linalg.norm(x_ser)
         assert n_ar[0] == 3 * info.iters + 1 + info.restarts  # β₀ + 3 per step + one per restart
 
+        # (d) the device's default scheme — CGS2 with delayed re-orthogonalisation, ONE all-reduce per Arnoldi step
+        n_ar[0] = 0
+        x_1r, info_1r = R.gmres_dcgs2_1r(matvec_local, bvec[rb:re_], rtol=1e-9, restart=30, itmax=4000, allreduce=ar)
+        assert info_1r.converged and abs(info_1r.iters - info_s.iters) <= 1  # (its stopping test lags one column)
+        assert np.linalg.norm(x_1r - x_ser[rb:re_]) <= 1e-7 * np.linalg.norm(x_ser)
+        # β₀ per cycle (first + one per restart) + one per Arnoldi step + one scalar closing each cycle that ran to its end
+        cycles = info_1r.restarts + 1
+        assert info_1r.iters + cycles <= n_ar[0] <= info_1r.iters + 2 * cycles + 1
+
         # distributed residual + ∞-norm (max all-reduce) as in the Newton driver
         lo, hi = _exchange_lines(rank, world, u[rb:rb + ns].copy(), u[re_ - ns:re_].copy(), ns)
         f_loc = p.f(u)[rb:re_]
