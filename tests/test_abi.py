@@ -136,3 +136,22 @@ def test_plain_c_example_compiles_against_the_header(tmp_path):
                            os.path.join(root, "examples", "bratu_c2.c"),
                            "-L", os.path.join(root, "nonlinearsolve.jl_amd", "lib"), "-lmi355x_nk", "-lm", "-o", str(exe)])
     assert exe.exists()
+
+
+def test_julia_binding_matches_the_abi():
+    """julia/MI355XNewtonKrylov.jl (the reference-side binding; Julia is not installed here): every symbol it ccalls is
+    declared in the header, and its NKOptions mirror lists the fields of nk_options in the same order with the same types."""
+    from nonlinearsolve_jl_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "MI355XNewtonKrylov.jl")).read()
+    header = open(os.path.join(root, "include", "mi355x_nk.h")).read()
+    called = set(re.findall(r"libnk\.(nk_[a-z0-9_]+)\(", jl))
+    assert len(called) >= 15
+    missing = [s for s in sorted(called) if not re.search(r"\b%s\s*\(" % s, header)]
+    assert not missing, missing
+    body = jl[jl.index("mutable struct NKOptions"):]
+    body = body[:body.index("\nend")]
+    fields = re.findall(r"([a-z0-9_]+)::(Int32|Float64)", body)
+    jl_types = {"Int32": C.c_int32, "Float64": C.c_double}
+    expect = [(n, ty) for n, ty in _lib.Options._fields_]
+    assert [(n, jl_types[ty]) for n, ty in fields] == expect
