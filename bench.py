@@ -1,29 +1,36 @@
 #!/usr/bin/env python
 """bench.py — Newton steps/s + SpMV GB/s vs the HBM roofline on 2-D Bratu (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1: spawns its own N ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W            # …or is launched as one of them
 
-Workload (config C3 of BASELINE.md, the configuration the metric is quoted on): 2-D Bratu n = 1024²
-(N = 1 048 576 unknowns, nnz = 5 238 784, λ = 6, u0 = 0), NewtonRaphson with the *fixed-work* Krylov protocol
-of SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step, zero initial guess, CGS2
-orthogonalisation (in its delayed form `dcgs2`: same arithmetic to rounding, 2 sweeps over the basis per step) — on the assembled CSR Jacobian (values refilled every step, SpMV as the operator).
-A "step" is one such Newton step: Jacobian value fill + 30×(SpMV + CGS2 passes) + solution update + u += δu +
-residual + ‖·‖∞ + termination bookkeeping, everything resident in HBM.
-N > 1: weak scaling — every rank owns ≈1024² unknowns of a (1024·√N)² grid (row-range partition by grid
-lines, halo lines by RCCL send/recv, Krylov inner products by RCCL all-reduce). `value` is the whole-job
-aggregate: Newton steps/s × (global unknowns / 1024²), i.e. 1024²-unknown step equivalents per second, which
-is plain Newton steps/s at N = 1; the raw rate of the global problem is config.global_newton_steps_per_sec.
+Workload `c3` (default; config C3 of BASELINE.md, the configuration the metric is quoted on): 2-D Bratu n = 1024²
+(N = 1 048 576 unknowns, nnz = 5 238 784, λ = 6, u0 = 0), NewtonRaphson with the *fixed-work* Krylov protocol of
+SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step, zero initial guess, CGS2 orthogonalisation
+(delayed form `dcgs2`: same arithmetic to rounding, 2 sweeps over the basis and one reduction per step) — on the
+assembled CSR Jacobian (values refilled every step, SpMV as the operator). A "step" is one such Newton step: Jacobian
+value fill + 30×(SpMV + CGS2 sweeps) + solution update + u += δu + residual + ‖·‖∞ + termination bookkeeping,
+everything resident in HBM.
+
+N > 1 is STRONG scaling on the metric's configuration: the same 1024² problem row-partitioned by grid lines over N
+ranks (halo lines + Krylov inner products over xGMI: peer-mapped buffers, RCCL as fallback); `value` is the plain
+global Newton steps/s. `--workload c4` is Bratu 4096² (config C4), `--workload c5` the Brusselator 512² TrustRegion
+step (config C5) — both row-partitioned over N ranks as well. A weak-scaling run (every rank owns ≈1024² unknowns of a
+(1024·√N)² grid) is reported under the extra key `weak_scaling` when N > 1.
 
 Extra objects on the JSON line: `roofline` (CSR SpMV kernel, HIP-event timed on the launch stream in a second,
 instrumented pass of the same K steps), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
-C/OpenMP restatement timed on this box's host cores on a bounded sample of the same workload).
+tuned C/OpenMP restatement of the same step — first-touch placement, one persistent parallel region, the same
+delayed-CGS2 — timed on this box's host cores on a bounded sample, next to the box's STREAM triad, its CSR SpMV rate
+and a single-thread figure).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,18 +41,95 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", dest="n", type=int, default=1024, help="grid side per GPU-equivalent (1024 ⇒ N = 1e6)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"])
+    ap.add_argument("--grid", dest="n", type=int, default=0, help="grid side (default: 1024 for c3, 4096 for c4, 512 for c5)")
     ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs"])
     ap.add_argument("--arnoldi", type=int, default=30)
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
-    ap.add_argument("--cpu-steps", type=int, default=12, help="Newton steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling run")
+    ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance extras")
+    return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU on this node)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(cache, steps, barrier, dist, world, backend, torch):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cache.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(ns, arnoldi, matfree, budget_s):
+    """The oracle's tuned CPU leg on this box's host cores (rank 0, N = 1 only): bounded sample of the same workload."""
+    import numpy as np
+    from oracle import c_oracle as CO
+    CO.build()
+    cores = CO.num_threads()
+    n = ns * ns
+    bytes_per_step = None
+    nnz = 5 * n - 4 * ns
+    b_op = (12.0 * nnz + 4.0 * (n + 1) + 16.0 * n) if not matfree else 24.0 * n
+    # DCGS2-1R: per Arnoldi step k the dot sweep reads k+2 columns, the axpy sweep reads k+2 and writes 2
+    bytes_per_step = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(arnoldi)) + 8.0 * n * (arnoldi + 3) \
+        + 8.0 * nnz + 16.0 * n + 40.0 * n
+    triad = CO.stream_triad(1 << 26, 4)
+    spmv = CO.spmv_rate(ns, 8)
+    z = np.zeros(n)
+    _, _, t1 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, 1, use_csr=not matfree, m=arnoldi)   # also places / warms
+    k = int(max(2, min(200, (0.6 * budget_s) / max(t1, 1e-4))))
+    _, fn, tk = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
+    rate = k / tk
+    CO.set_num_threads(1)
+    k1 = 1 if t1 * cores > 0.2 * budget_s else 2
+    _, _, ts = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k1, use_csr=not matfree, m=arnoldi)
+    CO.set_num_threads(cores)
+    eff = rate * bytes_per_step * 1e-9
+    return {"value": round(rate, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} fixed-work Newton steps of the same Bratu {ns}x{ns} workload ({arnoldi} Arnoldi steps of delayed-CGS2 "
+                      f"GMRES each), oracle/nk_oracle.c::orc_bratu_newton_fast, OpenMP on {cores} threads, first-touch placement, "
+                      f"{tk:.1f} s",
+            "effective_GBs": round(eff, 1), "stream_triad_GBs": round(triad, 1),
+            "frac_of_stream_triad": round(eff / triad, 3) if triad > 0 else None,
+            "spmv_GBs": round(spmv, 1), "spmv_frac_of_triad": round(spmv / triad, 3) if triad > 0 else None,
+            "single_thread_value": round(k1 / ts, 4), "fnorm_inf_last": float(fn[-1]),
+            "note": "restatement of the reference algorithm (Julia is not installed on this box); a reported baseline, not the target"}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -53,15 +137,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % ndev  # BENCH_BACKEND=gloo lets two ranks share one GPU (code-path dry run only)
-    torch.cuda.set_device(dev_index)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if world > ndev and backend == "nccl":
+        raise SystemExit(f"--gpus {world} needs {world} GPUs, this node has {ndev} "
+                         "(BENCH_BACKEND=gloo lets ranks share a GPU for a code-path dry run)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -75,54 +159,45 @@ def main():
     nls.set_default_context(ctx)
     comm = "none"
     if world > 1:
-        # rank 0 creates a ncclUniqueId, torch.distributed broadcasts its 128 bytes, and the library then owns
-        # its own RCCL communicator on the compute stream (nonlinearsolve.jl_amd/dist.py). If that bootstrap
-        # fails the collectives are routed through torch.distributed's RCCL process group instead — same
-        # wire, Python in the loop — and the JSON line says so.
-        try:
-            comm = nls.dist.init_comm(ctx, os.environ.get("NK_COMM", "rccl" if backend == "nccl" else "torch"))
-        except Exception as ex:  # noqa: BLE001
-            print(f"[bench] direct RCCL bootstrap failed on rank {rank}: {ex}; using torch.distributed callbacks",
-                  file=sys.stderr)
-            comm = nls.dist.init_comm(ctx, "torch") + "(fallback)"
-    # weak scaling: grid side so that every rank owns ≈ n² unknowns; side must be ≥ world lines
-    ns = args.n if world == 1 else int(round(args.n * math.sqrt(world)))
-    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
-    n_local = prob.device_problem.n_local
-    n_global = prob.device_problem.n_global
-    alg = nls.NewtonRaphson(
-        linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho,
-                                    fixed_iters=args.arnoldi),
-        concrete_jac=not args.matfree)
-    u0 = torch.zeros(n_local, dtype=torch.float64, device="cuda")
-    prob.u0 = u0
-    # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
-    cache = nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)
+        # Transport of the library's small collectives, in order of preference: peer-mapped buffers over xGMI
+        # (hipIpc; "peer"), the library's own RCCL communicator ("rccl"), torch.distributed callbacks ("torch").
+        want = os.environ.get("NK_COMM", "peer" if backend == "nccl" else "torch")
+        order = [want] + [t for t in ("rccl", "torch") if t != want] if backend == "nccl" else [want, "torch"]
+        for tr in order:
+            try:
+                comm = nls.dist.init_comm(ctx, tr)
+                break
+            except Exception as ex:  # noqa: BLE001
+                print(f"[bench] transport {tr!r} failed on rank {rank}: {ex}", file=sys.stderr)
+        if comm == "none":
+            raise SystemExit("no communicator could be initialised")
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(k):
-        for _ in range(k):
-            cache.step()
+    def make_cache(kind, ns):
+        if kind == "c5":
+            PB = nls.Brusselator2D(ns)
+            prob = nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True))
+            alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho,
+                                                              fixed_iters=args.arnoldi), concrete_jac=not args.matfree)
+        else:
+            prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
+            prob.u0 = torch.zeros(prob.device_problem.n_local, dtype=torch.float64, device="cuda")
+            alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho,
+                                                                fixed_iters=args.arnoldi), concrete_jac=not args.matfree)
+        # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
+        return prob, nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)
 
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ns = args.n or {"c3": 1024, "c4": 4096, "c5": 512}[args.workload]
+    prob, cache = make_cache(args.workload, ns)
+    n_local, n_global = prob.device_problem.n_local, prob.device_problem.n_global
+    for _ in range(args.warmup):
+        cache.step()
+    dt = timed_steps(cache, args.steps, barrier, dist, world, backend, torch)
     steps_per_s = args.steps / dt
-    # whole-job aggregate: one unit = one Newton step on 1024² unknowns (exactly the N = 1 workload). Under weak
-    # scaling the global problem has world×1024² unknowns, so a global Newton step is `world` units.
-    units_per_step = n_global / float(1024 * 1024)
-    value = steps_per_s * units_per_step
     stats = cache.stats
     fnorm = cache.fnorm_inf
 
@@ -131,7 +206,8 @@ def main():
     kernels = {}
     if not args.no_profile_pass:
         ctx.profile_enable(True)
-        run_steps(args.steps)
+        for _ in range(args.steps):
+            cache.step()
         barrier()
         kernels = ctx.profile_report()
         ctx.profile_enable(False)
@@ -146,8 +222,10 @@ def main():
         traffic, tsrc = None, None
         try:
             import glob
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-            if cand and world == 1 and ns == 1024:
+            tag = {"c3": "", "c4": "c4size_1gpu_"}.get(args.workload)
+            cand = sorted(c for c in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_pmc.json"))
+                          if tag is not None and (("c4size" in c) == (tag != "")))
+            if cand and world == 1 and not args.n:
                 pm = json.load(open(cand[-1]))
                 for key, v in pm.items():
                     if key.startswith(kname):
@@ -169,128 +247,106 @@ def main():
     for name, v in kernels.items():
         ksum[name]["share_of_step_time"] = round(v["total_ms"] / tot, 4)
 
-    # ---- CPU baseline: the oracle's C/OpenMP restatement on this box's host cores, bounded sample
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_steps > 0:
-        import numpy as np
-        from oracle import c_oracle as CO
-        CO.build()
-        cores = CO.num_threads()
-        tc = time.perf_counter()
-        CO.bratu_newton(ns, 6.0, 0.0, np.zeros(ns * ns), args.cpu_steps, use_csr=not args.matfree, m=args.arnoldi,
-                        itmax=args.arnoldi, fixed_iters=args.arnoldi, forcing=False)
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": round(args.cpu_steps / tcpu, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port",
-               "sample": f"{args.cpu_steps} fixed-work Newton steps (30 MGS-GMRES Arnoldi steps each) of the same "
-                         f"Bratu {ns}x{ns} workload, oracle/nk_oracle.c with OpenMP on {cores} threads, {tcpu:.1f} s"}
-
-    # ---- time to tolerance (extra, not `value`): the §3 protocol (NewtonRaphson + GMRES(30) + Eisenstat–Walker,
-    # inner cap 300, ‖h²F‖∞ ≤ 1e-8) with the Chebyshev(32, ratio 300) right preconditioner, device vs the oracle's
-    # C/OpenMP restatement of the same algorithm on the host cores
-    ttt = None
-    if rank == 0 and world == 1 and args.cpu_steps > 0:
-        import numpy as np
-        from oracle import c_oracle as CO
-        prob2 = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(n_local, dtype=torch.float64, device="cuda"))
-        alg2 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300,
-                                                             precs=nls.ChebyshevPrecs(32, 300.0)),
-                                 forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
-        nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)  # warm-up (allocations, first-touch)
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        sol2 = nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)
-        torch.cuda.synchronize()
-        tg = time.perf_counter() - tg
-        tc2 = time.perf_counter()
-        uC, fnC, giC = CO.bratu_newton_cheb(ns, 6.0, 0.0, np.zeros(ns * ns), 50, not args.matfree, 30, 300, 32, 300.0, 1e-8)
-        tc2 = time.perf_counter() - tc2
-        ttt = {"protocol": "NewtonRaphson+GMRES(30)+EisenstatWalkerForcing2+Chebyshev(32,300) to |h^2 F|inf<=1e-8",
-               "gpu_seconds": round(tg, 4), "gpu_newton_steps": sol2.stats.nsteps, "gpu_gmres_iters": sol2.stats.gmres_iters,
-               "gpu_retcode": sol2.retcode, "cpu_seconds": round(tc2, 3), "cpu_newton_steps": int(len(fnC)),
-               "cpu_gmres_iters": int(giC.sum()), "cpu_cores": CO.num_threads(),
-               "u_maxdiff_gpu_vs_cpu": float(np.max(np.abs(sol2.u.cpu().numpy() - uC))),
-               "speedup": round(tc2 / tg, 1)}
-        # the same solve with the built-in geometric multigrid V-cycle behind the `precs` hook (GPU only: the C oracle has
-        # no multigrid; its NumPy restatement pins iteration counts at small sizes in the tests)
-        alg3 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(2, 31)),
-                                 forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
-        nls.solve(prob2, alg3, abstol=1e-8, maxiters=50)
-        torch.cuda.synchronize()
-        tm = time.perf_counter()
-        sol3 = nls.solve(prob2, alg3, abstol=1e-8, maxiters=50)
-        torch.cuda.synchronize()
-        tm = time.perf_counter() - tm
-        ttt["multigrid_precs"] = {"gpu_seconds": round(tm, 4), "gpu_newton_steps": sol3.stats.nsteps,
-                                  "gpu_gmres_iters": sol3.stats.gmres_iters, "gpu_retcode": sol3.retcode,
-                                  "u_maxdiff_vs_chebyshev_run": float((sol3.u - sol2.u).abs().max())}
-
-    line = None
-    if rank == 0:
-        line = {
-            "metric": "newton_steps_per_sec", "value": round(value, 3),
-            "unit": "newton_steps/s" if world == 1 else "newton_steps/s x (unknowns / 1024^2)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"bratu2d_{ns}x{ns}_newtonraphson_gmres{args.arnoldi}_fixedwork_"
-                                   f"{'matfree_jvp' if args.matfree else 'csr_spmv'}",
-                       "global_newton_steps_per_sec": round(steps_per_s, 3), "units_per_global_step": round(units_per_step, 4),
-                       "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
-                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho,
-                       "parallelism": f"row-range x{world}", "comm": comm},
-            "roofline": roof, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt,
-            "gpu_vs_cpu": round(steps_per_s / cpu["value"], 1) if cpu else None,
-            "check": {"fnorm_inf_after_timed_steps": fnorm, "gmres_iters": stats.gmres_iters,
-                      "nsteps": stats.nsteps, "allreduces": stats.allreduces},
-        }
-    # ---- N > 1 on the CSR operator: try the SpMV with its halo exchange overlapped with the interior row blocks
-    # (second stream + events, off by default in the library). The measurement above is complete and stays the
-    # result unless the overlapped variant, measured by the same protocol, is faster; a watchdog prints the result
-    # above and leaves if the attempt does not come back.
-    overlap = {"tried": False}
-    if world > 1 and not args.matfree and os.environ.get("NK_BENCH_OVERLAP", "auto") != "off":
+    # ---- N > 1 on the CSR operator with the RCCL transport: try the SpMV with its halo exchange overlapped with the
+    # interior row blocks (second stream + events). Reported only if faster, under a watchdog.
+    overlap = None
+    if world > 1 and not args.matfree and comm.startswith("rccl") and os.environ.get("NK_BENCH_OVERLAP", "auto") != "off":
         import threading
         finished = threading.Event()
+        partial = {"dt": dt}
 
         def watchdog():
             if not finished.wait(timeout=float(os.environ.get("NK_BENCH_OVERLAP_TIMEOUT", "90"))):
-                if rank == 0:
-                    line["config"]["halo_overlap"] = "attempt timed out; serial exchange reported"
-                    print(json.dumps(line))
-                    sys.stdout.flush()
-                os._exit(0)
+                print(f"[bench] rank {rank}: halo-overlap attempt timed out; leaving", file=sys.stderr)
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             ctx.set_halo_overlap(True)
-            run_steps(args.warmup)
-            barrier()
-            t0 = time.perf_counter()
-            run_steps(args.steps)
-            barrier()
-            dt2 = time.perf_counter() - t0
-            t2 = torch.tensor([dt2], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-            dt2 = float(t2.item())
+            for _ in range(args.warmup):
+                cache.step()
+            dt2 = timed_steps(cache, args.steps, barrier, dist, world, backend, torch)
             ok = math.isfinite(cache.fnorm_inf)
-            overlap = {"tried": True, "ms_per_step": round(1e3 * dt2 / args.steps, 4), "ok": bool(ok)}
-            if rank == 0:
-                line["config"]["halo_overlap"] = {"serial_ms_per_step": line["ms_per_step"],
-                                                  "overlapped_ms_per_step": overlap["ms_per_step"],
-                                                  "reported": "overlapped" if (ok and dt2 < dt) else "serial"}
-                if ok and dt2 < dt:
-                    sps = args.steps / dt2
-                    line["value"] = round(sps * units_per_step, 3)
-                    line["ms_per_step"] = overlap["ms_per_step"]
-                    line["config"]["global_newton_steps_per_sec"] = round(sps, 3)
+            overlap = {"serial_ms_per_step": round(1e3 * dt / args.steps, 4), "overlapped_ms_per_step": round(1e3 * dt2 / args.steps, 4),
+                       "reported": "overlapped" if (ok and dt2 < dt) else "serial"}
+            if ok and dt2 < dt:
+                dt, steps_per_s = dt2, args.steps / dt2
+            else:
+                ctx.set_halo_overlap(False)
         except Exception as ex:  # noqa: BLE001
-            if rank == 0:
-                line["config"]["halo_overlap"] = f"attempt failed ({ex}); serial exchange reported"
+            overlap = f"attempt failed ({ex}); serial exchange reported"
         finished.set()
+        del partial
+
+    # ---- N > 1: the weak-scaling run as an extra key (every rank owns ≈ ns² unknowns of a (ns·√N)² grid)
+    weak = None
+    if world > 1 and not args.no_weak and args.workload == "c3":
+        nsw = int(round(ns * math.sqrt(world)))
+        cache.close()
+        probw, cachew = make_cache("c3", nsw)
+        for _ in range(args.warmup):
+            cachew.step()
+        dtw = timed_steps(cachew, args.steps, barrier, dist, world, backend, torch)
+        weak = {"grid": nsw, "unknowns_global": probw.device_problem.n_global, "unknowns_per_gpu": probw.device_problem.n_local,
+                "global_newton_steps_per_sec": round(args.steps / dtw, 3), "ms_per_step": round(1e3 * dtw / args.steps, 4),
+                "value_in_1024sq_step_equivalents": round(args.steps / dtw * probw.device_problem.n_global / float(1024 * 1024), 3)}
+        cachew.close()
+        cache = None
+
+    # ---- CPU baseline (rank 0, N = 1): the oracle's tuned C/OpenMP leg on this box's host cores, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.workload != "c5":
+        try:
+            cpu = cpu_baseline(ns, args.arnoldi, args.matfree, args.cpu_seconds if ns <= 1024 else 2.5 * args.cpu_seconds)
+        except Exception as ex:  # noqa: BLE001
+            cpu = {"error": str(ex)}
+
+    # ---- time to tolerance (extra, not `value`): the §3 protocol (NewtonRaphson + GMRES(30) + Eisenstat–Walker,
+    # inner cap 300, ‖h²F‖∞ ≤ 1e-8) with the built-in right preconditioners behind the `precs` hook
+    ttt = None
+    if rank == 0 and world == 1 and not args.no_ttt and args.workload == "c3":
+        prob2 = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(n_local, dtype=torch.float64, device="cuda"))
+        ttt = {"protocol": "NewtonRaphson+GMRES(30)+EisenstatWalkerForcing2 to |h^2 F|inf<=1e-8"}
+        for name, precs in (("chebyshev_32_300", nls.ChebyshevPrecs(32, 300.0)), ("multigrid_2_31", nls.MultigridPrecs(2, 31))):
+            alg2 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=precs),
+                                     forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
+            nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)  # warm-up (allocations, first-touch)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            sol2 = nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            ttt[name] = {"gpu_seconds": round(tg, 4), "gpu_newton_steps": sol2.stats.nsteps,
+                         "gpu_gmres_iters": sol2.stats.gmres_iters, "gpu_retcode": sol2.retcode}
+
     if rank == 0:
+        op = "matfree_jvp" if args.matfree else "csr_spmv"
+        if args.workload == "c5":
+            wl = f"brusselator2d_{ns}x{ns}_trustregion_gmres{args.arnoldi}_fixedwork_{op}"
+        else:
+            wl = f"bratu2d_{ns}x{ns}_newtonraphson_gmres{args.arnoldi}_fixedwork_{op}"
+        if world > 1:
+            wl += f"_x{world}"
+        line = {
+            "metric": "newton_steps_per_sec", "value": round(steps_per_s, 3), "unit": "newton_steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl, "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
+                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho,
+                       "parallelism": f"row-range x{world}", "comm": comm, "halo_overlap": overlap},
+            "roofline": roof, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
+            "gpu_vs_cpu": round(steps_per_s / cpu["value"], 1) if cpu and "value" in cpu else None,
+            "check": {"fnorm_inf_after_timed_steps": fnorm, "gmres_iters": stats.gmres_iters,
+                      "nsteps": stats.nsteps, "allreduces": stats.allreduces, "halo_exchanges": stats.halo_exchanges},
+        }
         print(json.dumps(line))
-    cache.close()
+        sys.stdout.flush()
+    if cache is not None:
+        cache.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -445,7 +445,9 @@ class NonlinearProblem:
         def jac_cb(user, u_ptr, vals_ptr, stream):
             try:
                 nnz = f.jac_prototype.info()["nnz"]
-                f.jac(_view(vals_ptr, nnz), _view(u_ptr, n), prob.p)
+                # the fill must be ordered against the library's SpMV / LU kernels: run it on the library's stream
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream else _nullctx():
+                    f.jac(_view(vals_ptr, nnz), _view(u_ptr, n), prob.p)
                 return 0
             except Exception:  # pragma: no cover
                 import traceback

@@ -674,11 +674,12 @@ static int estimate_lambda(nk_gmres *G, double *lambda) {
     double mx = 0.0, tr = 0.0;
     for (int b = 0; b < grid; ++b) { mx = hp[b] > mx ? hp[b] : mx; tr += hp[grid + b]; }
     if (ctx->nranks > 1) {
+      // both scalars go up in ONE copy from two distinct pinned slots (re-using a slot between two async copies raced
+      // with the first copy when the collective is asynchronous, i.e. under RCCL)
       ctx->h_pinned[0] = mx;
-      NK_HIP(hipMemcpyAsync(ctx->d_scal, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ctx->h_pinned[1] = tr;
+      NK_HIP(hipMemcpyAsync(ctx->d_scal, ctx->h_pinned, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       NK_TRY(nk_comm_allreduce(ctx, ctx->d_scal, 1, 1));
-      ctx->h_pinned[0] = tr;
-      NK_HIP(hipMemcpyAsync(ctx->d_scal + 1, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       NK_TRY(nk_comm_allreduce(ctx, ctx->d_scal + 1, 1, 0));
       double v[2];
       NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 2, v));

@@ -397,6 +397,9 @@ static int rollback_to_best(nk_solver *S) {
 // ---- init
 static int solver_start(nk_solver *S) {  // everything after u has been set
   nk_ctx *ctx = S->ctx;
+  // the problem's linearisation caches (exp(u) diagonal, f(u) for forward differences) are keyed on the pointer of u:
+  // u changes in place between solves, and a new solver may receive a just-freed address — start from "not linearised"
+  S->P->d_u_lin = nullptr;
   NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
   S->stats = nk_stats{};
   S->ctx_base.op_applies = S->ctx->stats.op_applies;
@@ -510,6 +513,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
 extern "C" int nk_solver_destroy(nk_solver *S) {
   if (!S) return NK_OK;
   hipStreamSynchronize(S->ctx->stream);
+  if (S->P) S->P->d_u_lin = nullptr;  // the vectors the problem was linearised at are about to be freed
   double *bufs[] = {S->u, S->fu, S->du, S->best_u, S->u_trial, S->fu_trial, S->du_newton, S->du_cauchy,
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage};
   for (double *b : bufs) hipFree(b);

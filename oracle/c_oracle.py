@@ -53,6 +53,12 @@ def lib():
         L.orc_bratu_newton_cheb.restype = C.c_int
         L.orc_bratu_newton_cheb.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_double, C.c_double, _d, _i]
+        L.orc_stream_triad.restype = C.c_double
+        L.orc_stream_triad.argtypes = [C.c_int64, C.c_int]
+        L.orc_spmv_rate.restype = C.c_double
+        L.orc_spmv_rate.argtypes = [C.c_int64, C.c_int]
+        L.orc_bratu_newton_fast.restype = C.c_double
+        L.orc_bratu_newton_fast.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, _d]
         _lib = L
     return _lib
 
@@ -153,3 +159,24 @@ def ensemble_newton(kind, u0, P, abstol=None, maxiters=1000):
         abstol = float(np.finfo(float).eps) ** 0.8
     lib().orc_ensemble_newton(kind, n, nb, u0, int(u0.ndim == 2), P, npar, abstol, maxiters, u, r, rc, it)
     return u, r, rc, it
+
+
+def stream_triad(n=1 << 26, reps=5):
+    """Best-of-reps STREAM triad GB/s of this box (24 n bytes per pass, first-touch placement)."""
+    return lib().orc_stream_triad(int(n), int(reps))
+
+
+def spmv_rate(ns, reps=10):
+    """Best-of-reps CSR SpMV GB/s on the Bratu ns×ns pattern (algorithmic bytes 12 nnz + 4 (n+1) + 16 n)."""
+    return lib().orc_spmv_rate(int(ns), int(reps))
+
+
+def bratu_newton_fast(ns, lam, scale, u0, nsteps, use_csr=True, m=30):
+    """Tuned CPU leg: nsteps fixed-work Newton steps (m Arnoldi steps of DCGS2-1R GMRES each), one persistent OpenMP
+    region with first-touch placement. Returns (u, fnorm trace, seconds of the step loop)."""
+    u = np.array(u0, dtype=np.float64, copy=True)
+    fn = np.zeros(nsteps)
+    sec = lib().orc_bratu_newton_fast(ns, lam, scale, u, nsteps, int(use_csr), m, fn)
+    if sec < 0:
+        raise ValueError("bad restart length")
+    return u, fn, sec

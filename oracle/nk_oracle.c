@@ -513,3 +513,357 @@ void orc_ensemble_newton(int kind, int n, int64_t nbatch, const double *u0, int 
     iters[b] = it;
   }
 }
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Tuned CPU leg for bench.py's `cpu_baseline` (TEST INFRASTRUCTURE / baseline only, like everything in this file).
+ * Same fixed-work Newton step as the device benchmark — Jacobian value fill, GMRES(m) with exactly m Arnoldi steps,
+ * x = V y, u −= x, residual, ‖f‖∞ — and the SAME orthogonalisation the device runs by default: CGS2 with delayed
+ * re-orthogonalisation and one reduction per step (oracle/reference_restatement.py::gmres_dcgs2_1r, normalised-basis
+ * form): two sweeps over the basis per Arnoldi step. Written for the host's memory system:
+ *   - ONE persistent `omp parallel` region for the whole run; every loop uses the same static row partition;
+ *   - parallel first touch: each thread initialises (and thereby places) its own rows of every array;
+ *   - the sweeps keep a 512-row tile of u and z in L1 while the final columns stream past it;
+ *   - reductions: per-thread partials, one barrier, every thread sums them in thread order (deterministic).
+ * orc_stream_triad / orc_spmv_rate measure the box itself with the same partition.
+ */
+#include <time.h>
+static double now_s(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#ifdef _OPENMP
+#define TID() omp_get_thread_num()
+#define NTHR() omp_get_num_threads()
+#else
+#define TID() 0
+#define NTHR() 1
+#endif
+static void my_rows(int64_t n, int64_t gran, int t, int T, int64_t *lo, int64_t *hi) {
+  int64_t units = n / gran;
+  *lo = (units * t / T) * gran;
+  *hi = (t == T - 1) ? n : (units * (t + 1) / T) * gran;
+}
+
+/* STREAM triad a = b + s c over 3 arrays of n doubles; returns the best GB/s of `reps` (24 n bytes per pass) */
+double orc_stream_triad(int64_t n, int reps) {
+  double *a = (double *)malloc((size_t)n * 8), *b = (double *)malloc((size_t)n * 8), *c = (double *)malloc((size_t)n * 8);
+  double best = 0.0;
+  if (!a || !b || !c) { free(a); free(b); free(c); return 0.0; }
+#pragma omp parallel
+  {
+    int64_t lo, hi;
+    my_rows(n, 8, TID(), NTHR(), &lo, &hi);
+    for (int64_t i = lo; i < hi; ++i) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+    for (int r = 0; r < reps; ++r) {
+#pragma omp barrier
+      double t0 = now_s();
+      for (int64_t i = lo; i < hi; ++i) a[i] = b[i] + 3.0 * c[i];
+#pragma omp barrier
+      double dt = now_s() - t0;
+#pragma omp master
+      {
+        double gb = 24.0 * (double)n / dt * 1e-9;
+        if (gb > best) best = gb;
+      }
+    }
+  }
+  volatile double sink = a[n / 2];
+  (void)sink;
+  free(a); free(b); free(c);
+  return best;
+}
+
+/* CSR SpMV rate on the Bratu ns×ns Jacobian pattern with first-touch placement: best GB/s of `reps`, in the same
+ * algorithmic bytes as the device figure (12 nnz + 4 (n+1) + 16 n) */
+double orc_spmv_rate(int64_t ns, int reps) {
+  const int64_t n = ns * ns, nnz = orc_bratu_nnz(ns);
+  int32_t *rowptr = (int32_t *)malloc((size_t)(n + 1) * 4), *col = (int32_t *)malloc((size_t)nnz * 4);
+  int32_t *rp0 = (int32_t *)malloc((size_t)(n + 1) * 4), *c0 = (int32_t *)malloc((size_t)nnz * 4);
+  double *val = (double *)malloc((size_t)nnz * 8), *x = (double *)malloc((size_t)n * 8), *y = (double *)malloc((size_t)n * 8);
+  double best = 0.0;
+  orc_bratu_pattern(ns, rp0, c0);
+#pragma omp parallel
+  {
+    int64_t lo, hi;
+    my_rows(n, ns, TID(), NTHR(), &lo, &hi);
+    for (int64_t i = lo; i < hi; ++i) {
+      rowptr[i] = rp0[i];
+      x[i] = 1.0 + 1e-3 * (double)(i % 97);
+      y[i] = 0.0;
+      for (int32_t k = rp0[i]; k < rp0[i + 1]; ++k) { col[k] = c0[k]; val[k] = (c0[k] == i) ? 4.0 : -1.0; }
+    }
+#pragma omp master
+    rowptr[n] = rp0[n];
+    for (int r = 0; r < reps; ++r) {
+#pragma omp barrier
+      double t0 = now_s();
+      for (int64_t i = lo; i < hi; ++i) {
+        double s = 0.0;
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * x[col[k]];
+        y[i] = s;
+      }
+#pragma omp barrier
+      double dt = now_s() - t0;
+#pragma omp master
+      {
+        double gb = (12.0 * (double)nnz + 4.0 * (double)(n + 1) + 16.0 * (double)n) / dt * 1e-9;
+        if (gb > best) best = gb;
+      }
+    }
+  }
+  volatile double sink = y[n / 2];
+  (void)sink;
+  free(rowptr); free(col); free(rp0); free(c0); free(val); free(x); free(y);
+  return best;
+}
+
+#define ORC_TILE 512
+#define ORC_MAXM 64
+#define ORC_PAD 8 /* doubles between per-thread reduction rows (false sharing) */
+
+/* all-thread sum of cnt partials; part is [T][stride]; result in out[cnt] on every thread (identical order) */
+static void team_sum(double *part, int stride, int cnt, const double *mine, double *out) {
+  const int t = TID(), T = NTHR();
+  for (int q = 0; q < cnt; ++q) part[(size_t)t * stride + q] = mine[q];
+#pragma omp barrier
+  for (int q = 0; q < cnt; ++q) {
+    double s = 0.0;
+    for (int r = 0; r < T; ++r) s += part[(size_t)r * stride + q];
+    out[q] = s;
+  }
+#pragma omp barrier
+}
+static double team_max(double *part, int stride, double mine) {
+  const int t = TID(), T = NTHR();
+  part[(size_t)t * stride] = mine;
+#pragma omp barrier
+  double m = 0.0;
+  for (int r = 0; r < T; ++r) {
+    double a = part[(size_t)r * stride];
+    if (a > m || a != a) m = a;
+  }
+#pragma omp barrier
+  return m;
+}
+
+/* nsteps fixed-work Newton steps (m Arnoldi steps each, DCGS2-1R) on the assembled CSR Jacobian (use_csr=1) or the
+ * matrix-free JVP. u (length ns²) is updated in place; fnorm_inf[k] = ‖f(u_{k+1})‖∞. Returns the wall seconds of the
+ * step loop (set-up, first touch and the initial residual excluded, as on the device side). */
+double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_io, int nsteps, int use_csr, int m,
+                             double *fnorm_inf) {
+  const int64_t n = ns * ns, nnz = orc_bratu_nnz(ns);
+  if (m < 1 || m > ORC_MAXM - 2) return -1.0;
+  const bratu_t bp = bratu_make(ns, lambda, scale);
+  int32_t *rowptr = NULL, *col = NULL, *rp0 = NULL, *c0 = NULL;
+  double *val = NULL;
+  if (use_csr) {
+    rp0 = (int32_t *)malloc((size_t)(n + 1) * 4);
+    c0 = (int32_t *)malloc((size_t)nnz * 4);
+    orc_bratu_pattern(ns, rp0, c0);
+    rowptr = (int32_t *)malloc((size_t)(n + 1) * 4);
+    col = (int32_t *)malloc((size_t)nnz * 4);
+    val = (double *)malloc((size_t)nnz * 8);
+  }
+  double *V = (double *)malloc((size_t)(m + 2) * n * 8);
+  double *u = (double *)malloc((size_t)n * 8), *f = (double *)malloc((size_t)n * 8), *x = (double *)malloc((size_t)n * 8);
+  int maxT = orc_num_threads();
+  const int stride = 2 * ORC_MAXM + 4 + ORC_PAD;
+  double *part = (double *)calloc((size_t)maxT * stride, 8);
+  double elapsed = 0.0;
+#pragma omp parallel
+  {
+    const int t = TID(), T = NTHR();
+    int64_t lo, hi;
+    my_rows(n, ns, t, T, &lo, &hi);
+    /* ---- first touch: every thread places its own rows */
+    for (int64_t i = lo; i < hi; ++i) { u[i] = u_io[i]; f[i] = 0.0; x[i] = 0.0; }
+    for (int c = 0; c < m + 2; ++c) {
+      double *vc = V + (size_t)c * n;
+      for (int64_t i = lo; i < hi; ++i) vc[i] = 0.0;
+    }
+    if (use_csr) {
+      for (int64_t i = lo; i < hi; ++i) {
+        rowptr[i] = rp0[i];
+        for (int32_t k = rp0[i]; k < rp0[i + 1]; ++k) { col[k] = c0[k]; val[k] = 0.0; }
+      }
+      if (t == 0) rowptr[n] = rp0[n];
+    }
+    /* thread-private Krylov scalars (identical on every thread) */
+    double Hraw[(ORC_MAXM + 2) * (ORC_MAXM + 1)], R[ORC_MAXM * ORC_MAXM];
+    double cs[ORC_MAXM], sn[ORC_MAXM], g[ORC_MAXM + 1], tprev[ORC_MAXM + 1], yv[ORC_MAXM];
+    double mine[2 * ORC_MAXM + 4], red[2 * ORC_MAXM + 4];
+    const int LH = ORC_MAXM + 1;
+#pragma omp barrier
+    /* initial residual */
+    for (int64_t i = lo; i < hi; ++i) f[i] = bp.c_lap * lap5(u, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]);
+#pragma omp barrier
+    double t0 = now_s();
+    for (int step = 0; step < nsteps; ++step) {
+      /* ---- Jacobian values (f.jac): rows of this thread */
+      if (use_csr) {
+        for (int64_t k = lo; k < hi; ++k) {
+          const int64_t i = k % ns, j = k / ns;
+          int64_t p = rowptr[k];
+          if (j > 0) val[p++] = -bp.c_lap;
+          if (i > 0) val[p++] = -bp.c_lap;
+          val[p++] = 4.0 * bp.c_lap - bp.c_exp * exp(u[k]);
+          if (i < ns - 1) val[p++] = -bp.c_lap;
+          if (j < ns - 1) val[p++] = -bp.c_lap;
+        }
+      }
+      /* ---- GMRES(m), zero initial guess, exactly m Arnoldi steps: v_0 = f/‖f‖ */
+      double s0 = 0.0;
+      for (int64_t i = lo; i < hi; ++i) s0 += f[i] * f[i];
+      team_sum(part, stride, 1, &s0, red);
+      const double beta0 = sqrt(red[0]);
+      const double ib = beta0 > 0.0 ? 1.0 / beta0 : 0.0;
+      for (int64_t i = lo; i < hi; ++i) V[i] = f[i] * ib;
+      for (int i = 0; i <= m; ++i) g[i] = 0.0;
+      g[0] = beta0;
+      int kdone = 0;
+#pragma omp barrier
+      for (int k = 0; k <= m; ++k) {
+        const int last = (k == m);
+        double *uk = V + (size_t)k * n, *zk = V + (size_t)(k + 1) * n;
+        /* z = A u_k on this thread's rows */
+        if (!last) {
+          if (use_csr) {
+            for (int64_t i = lo; i < hi; ++i) {
+              double s = 0.0;
+              for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) s += val[q] * uk[col[q]];
+              zk[i] = s;
+            }
+          } else {
+            for (int64_t i = lo; i < hi; ++i)
+              zk[i] = bp.c_lap * lap5(uk, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]) * uk[i];
+          }
+        }
+        /* dot sweep: red = [V_jᵀu (k), u·u, V_jᵀz (k), u·z] */
+        const int cnt = last ? k + 1 : 2 * k + 2;
+        for (int q = 0; q < cnt; ++q) mine[q] = 0.0;
+        for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
+          const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
+          double a = 0.0, d = 0.0;
+          for (int64_t i = r0; i < r1; ++i) { a += uk[i] * uk[i]; if (!last) d += uk[i] * zk[i]; }
+          mine[k] += a;
+          if (!last) mine[2 * k + 1] += d;
+          if (!last || 0) {
+            for (int j = 0; j < k; ++j) {
+              const double *vj = V + (size_t)j * n;
+              double ru = 0.0, rz = 0.0;
+              for (int64_t i = r0; i < r1; ++i) { ru += vj[i] * uk[i]; rz += vj[i] * zk[i]; }
+              mine[j] += ru;
+              mine[k + 1 + j] += rz;
+            }
+          }
+        }
+        team_sum(part, stride, cnt, mine, red);
+        if (k == 0) { /* v_0 is final: only the first projection of A v_0 */
+          const double tl = red[1];
+          for (int64_t i = lo; i < hi; ++i) zk[i] -= tl * uk[i];
+          tprev[0] = tl;
+#pragma omp barrier
+          continue;
+        }
+        /* ---- scalar tail (every thread, identical): close Hessenberg column k−1 */
+        double rr[ORC_MAXM], h[ORC_MAXM + 1], cc[ORC_MAXM + 1];
+        double r2 = 0.0;
+        for (int j = 0; j < k; ++j) { rr[j] = last ? 0.0 : red[j]; r2 += rr[j] * rr[j]; }
+        double b2 = red[k] - r2;
+        if (b2 < 0.0) b2 = 0.0;
+        const double beta = sqrt(b2);
+        for (int j = 0; j < k; ++j) h[j] = tprev[j] + rr[j];
+        h[k] = beta;
+        for (int j = 0; j <= k; ++j) Hraw[j * LH + (k - 1)] = h[j];
+        {
+          const int jc = k - 1;
+          for (int i = 0; i < jc; ++i) {
+            const double tt = cs[i] * h[i] + sn[i] * h[i + 1];
+            h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+            h[i] = tt;
+          }
+          const double dd = hypot(h[jc], h[jc + 1]);
+          if (dd == 0.0) { cs[jc] = 1.0; sn[jc] = 0.0; } else { cs[jc] = h[jc] / dd; sn[jc] = h[jc + 1] / dd; }
+          for (int i = 0; i < jc; ++i) R[i * ORC_MAXM + jc] = h[i];
+          R[jc * ORC_MAXM + jc] = dd;
+          g[jc + 1] = -sn[jc] * g[jc];
+          g[jc] = cs[jc] * g[jc];
+          kdone = jc + 1;
+        }
+        if (last) break;
+        const double *gg = red + k + 1;
+        const double dval = red[2 * k + 1];
+        double rg = 0.0;
+        for (int j = 0; j < k; ++j) rg += rr[j] * gg[j];
+        for (int i = 0; i <= k; ++i) { /* c = H̄[0:k+1, 0:k] r (entries below the sub-diagonal are zero) */
+          double s = 0.0;
+          for (int j = (i > 0 ? i - 1 : 0); j < k; ++j) s += Hraw[i * LH + j] * rr[j];
+          cc[i] = s;
+        }
+        const double isb = beta > 0.0 ? 1.0 / beta : 0.0;
+        double ca[ORC_MAXM + 1], cb[ORC_MAXM + 1];
+        for (int j = 0; j < k; ++j) {
+          const double tt = (gg[j] - cc[j]) * isb;
+          tprev[j] = tt;
+          ca[j] = rr[j];                 /* v_k   = (u − Σ ca_j v_j) / β */
+          cb[j] = cc[j] * isb + tt;      /* u_k+1 = z/β − Σ cb_j v_j − cbk v_k */
+        }
+        const double tlast = (dval - rg - beta * cc[k]) * isb * isb;
+        tprev[k] = tlast;
+        const double cbk = cc[k] * isb + tlast;
+        /* ---- axpy sweep (tile of u, z kept in L1 while the final columns stream past) */
+        for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
+          const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
+          double pu[ORC_TILE], pz[ORC_TILE];
+          const int len = (int)(r1 - r0);
+          for (int i = 0; i < len; ++i) { pu[i] = uk[r0 + i]; pz[i] = zk[r0 + i] * isb; }
+          for (int j = 0; j < k; ++j) {
+            const double *vj = V + (size_t)j * n + r0;
+            const double a = ca[j], b = cb[j];
+            for (int i = 0; i < len; ++i) { pu[i] -= a * vj[i]; pz[i] -= b * vj[i]; }
+          }
+          for (int i = 0; i < len; ++i) {
+            const double vk = pu[i] * isb;
+            uk[r0 + i] = vk;
+            zk[r0 + i] = pz[i] - cbk * vk;
+          }
+        }
+#pragma omp barrier
+      }
+      /* ---- y = R⁻¹ g ; x = V y ; u −= x ; f = F(u) ; ‖f‖∞ */
+      for (int i = kdone - 1; i >= 0; --i) {
+        double s = g[i];
+        for (int j = i + 1; j < kdone; ++j) s -= R[i * ORC_MAXM + j] * yv[j];
+        yv[i] = s / R[i * ORC_MAXM + i];
+      }
+      for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
+        const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
+        double acc[ORC_TILE];
+        const int len = (int)(r1 - r0);
+        for (int i = 0; i < len; ++i) acc[i] = 0.0;
+        for (int j = 0; j < kdone; ++j) {
+          const double *vj = V + (size_t)j * n + r0;
+          const double yj = yv[j];
+          for (int i = 0; i < len; ++i) acc[i] += yj * vj[i];
+        }
+        for (int i = 0; i < len; ++i) { x[r0 + i] = acc[i]; u[r0 + i] -= acc[i]; }
+      }
+#pragma omp barrier
+      double mx = 0.0;
+      for (int64_t i = lo; i < hi; ++i) {
+        const double fi = bp.c_lap * lap5(u, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]);
+        f[i] = fi;
+        const double a = fabs(fi);
+        if (a > mx || a != a) mx = a;
+      }
+      mx = team_max(part, stride, mx);
+      if (t == 0) fnorm_inf[step] = mx;
+    }
+#pragma omp barrier
+    if (t == 0) elapsed = now_s() - t0;
+    for (int64_t i = lo; i < hi; ++i) u_io[i] = u[i];
+  }
+  free(rowptr); free(col); free(rp0); free(c0); free(val); free(V); free(u); free(f); free(x); free(part);
+  return elapsed;
+}
