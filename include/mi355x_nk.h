@@ -360,6 +360,15 @@ int nk_solver_init(nk_problem *P, const double *u0, int memspace, const nk_optio
                    nk_solver **out);                       /* SciMLBase.__init */
 int nk_solver_destroy(nk_solver *S);
 int nk_solver_step(nk_solver *S);                          /* CommonSolve.step!  */
+/* step!(cache; recompute_jacobian, evaluate_residual) (lib/NonlinearSolveBase/src/solve.jl:835-859 →
+ * lib/NonlinearSolveFirstOrder/src/solve.jl:325-465). recompute_jacobian: -1 = nothing (the algorithm decides), 0, 1.
+ * evaluate_residual = 0 is a HINT: honoured only when nk_solver_supports_deferred_residual says 1 (unglobalised Newton
+ * step, AbsTerminationMode / AbsNormTerminationMode, no trace — FirstOrder/src/solve.jl:303-316); the step then ends
+ * right after u += δu and nk_solver_refresh_residual (= refresh_residual!, :318-324) evaluates f(u) and runs the
+ * termination check on demand. step and solve settle an outstanding deferral themselves. */
+int nk_solver_step_ex(nk_solver *S, int recompute_jacobian, int evaluate_residual);
+int nk_solver_supports_deferred_residual(nk_solver *S, int *yes);
+int nk_solver_refresh_residual(nk_solver *S);
 int nk_solver_solve(nk_solver *S, int *retcode);           /* CommonSolve.solve! */
 int nk_solver_reinit(nk_solver *S, const double *u0, int memspace,
                      const double *params, int nparams);   /* SciMLBase.reinit!(cache, u0; p) */

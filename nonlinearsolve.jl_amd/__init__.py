@@ -14,6 +14,7 @@ from .core import (  # noqa: F401
     RelNormSafeTerminationMode, RelNormSafeBestTerminationMode, AbsTerminationMode, AbsNormTerminationMode,
     AbsNormSafeTerminationMode, TERMINATION_CONDITIONS,
     NLStats, NonlinearSolution, FirstOrderCache, init, solve, step_, solve_, reinit_,
+    supports_deferred_residual, refresh_residual,
     SimpleNewtonRaphson, SimpleTrustRegion, ImmutableNonlinearProblem, EnsembleSolution, vectorized_solve,
     GMRES, BandedLU, JacobianOperator, JacVecOperator, VecJacOperator, StatefulJacobianOperator,
     StatefulJacobianNormalFormOperator,

@@ -153,6 +153,9 @@ SIGNATURES = {
     "nk_solver_init": (_I, [_P, _P, _I, C.POINTER(Options), _PP]),
     "nk_solver_destroy": (_I, [_P]),
     "nk_solver_step": (_I, [_P]),
+    "nk_solver_step_ex": (_I, [_P, _I, _I]),
+    "nk_solver_supports_deferred_residual": (_I, [_P, C.POINTER(_I)]),
+    "nk_solver_refresh_residual": (_I, [_P]),
     "nk_solver_solve": (_I, [_P, C.POINTER(_I)]),
     "nk_solver_reinit": (_I, [_P, _P, _I, C.POINTER(_D), _I]),
     "nk_solver_get_u": (_I, [_P, _P, _I]),

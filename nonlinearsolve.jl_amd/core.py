@@ -786,9 +786,21 @@ class FirstOrderCache:
                      step_norm2=r.step_norm2, eta=r.eta, trust_region=r.trust_region, rho=r.rho)
                 for r in rows[: n.value]]
 
-    def step(self):
-        check(L.lib().nk_solver_step(self._h))
+    def step(self, recompute_jacobian: Optional[bool] = None, evaluate_residual: bool = True):
+        """step!(cache; recompute_jacobian = nothing, evaluate_residual = true)"""
+        rj = -1 if recompute_jacobian is None else int(bool(recompute_jacobian))
+        check(L.lib().nk_solver_step_ex(self._h, rj, int(bool(evaluate_residual))))
         return self
+
+    def supports_deferred_residual(self) -> bool:
+        y = C.c_int()
+        check(L.lib().nk_solver_supports_deferred_residual(self._h, C.byref(y)))
+        return bool(y.value)
+
+    def refresh_residual(self):
+        """refresh_residual!(cache): settle a residual evaluation deferred by step(evaluate_residual=False)."""
+        check(L.lib().nk_solver_refresh_residual(self._h))
+        return None
 
     def solve(self) -> NonlinearSolution:
         r = C.c_int()
@@ -825,8 +837,16 @@ def solve(prob: NonlinearProblem, alg, **kw) -> NonlinearSolution:
         cache.close()
 
 
-def step_(cache: FirstOrderCache):   # step!(cache)
-    return cache.step()
+def step_(cache: FirstOrderCache, **kw):   # step!(cache; recompute_jacobian, evaluate_residual)
+    return cache.step(**kw)
+
+
+def supports_deferred_residual(cache: FirstOrderCache) -> bool:
+    return cache.supports_deferred_residual()
+
+
+def refresh_residual(cache: FirstOrderCache):   # refresh_residual!(cache)
+    return cache.refresh_residual()
 
 
 def solve_(cache: FirstOrderCache):  # solve!(cache)

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
                                                         int nv, const int *__restrict__ d_nv,
                                                         const double *__restrict__ h, double sign,
                                                         double *__restrict__ w, double *__restrict__ partials,
-                                                        const int *d_skip, const double *__restrict__ sc) {
+                                                        const int *d_skip, const double *__restrict__ sc, int overwrite) {
   SKIP_GUARD(d_skip);
   __shared__ double sm[4];
   if (d_nv) nv = *d_nv;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
   double2 *w2 = reinterpret_cast<double2 *>(w);
   double ss = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < npair; i += stride) {
-    double2 a = w2[i];
+    double2 a = overwrite ? make_double2(0.0, 0.0) : w2[i];
     int j = 0;
     for (; j + 4 <= nv; j += 4) {
       const double2 v0 = ldv2(V + (size_t)(j + 0) * ldv, i);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
     ss += a.x * a.x + a.y * a.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    double a = w[n - 1];
+    double a = overwrite ? 0.0 : w[n - 1];
     for (int j = 0; j < nv; ++j) a += sign * h[j] * (sc ? sc[j] : 1.0) * V[(size_t)j * ldv + n - 1];
     w[n - 1] = a;
     ss += a * a;
@@ -250,12 +250,12 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
 
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq, const int *d_skip, const int *d_nv,
-                      const double *d_scales) {
+                      const double *d_scales, bool overwrite) {
   const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
   {
     nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2));
     NK_LAUNCH(ctx, k_multiaxpy, dim3(grid), dim3(NK_BLOCK), n, V, ldv, nv, d_nv, d_h, sign,
-                       w, d_sumsq ? ctx->d_partials_ss : nullptr, d_skip, d_scales);
+                       w, d_sumsq ? ctx->d_partials_ss : nullptr, d_skip, d_scales, overwrite ? 1 : 0);
   }
   if (d_sumsq == NK_SUMSQ_PARTIALS_ONLY) {  // consumer (k_givens) reduces ctx->d_partials[0..grid) itself
     ctx->last_red_grid = grid;
@@ -591,6 +591,13 @@ int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, c
   return NK_OK;
 }
 
+// *d_out = Σ partials[0..nblk) in the fixed stage-2 order, all-reduced
+int nk_blas_reduce_one(nk_ctx *ctx, const double *partials, int nblk, double *d_out, const int *d_skip) {
+  NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), partials, nblk, d_out, d_skip, (const double *)nullptr, 0);
+  NK_HIP(hipGetLastError());
+  return nk_comm_allreduce(ctx, d_out, 1, 0);
+}
+
 // d_h2[0..nv) = s_j·(ṽ_j·w_new) and d_h2[nv] = ‖w_new‖² (both all-reduced). Requires nv ≤ 32.
 int nk_blas_fused_axpy_dot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                            const double *d_scales, double *w, double *d_h2, const int *d_skip) {
@@ -701,6 +708,163 @@ int nk_blas_minmax(nk_ctx *ctx, int64_t n, const double *x, double *d_out2) {
   return nk_comm_allreduce(ctx, d_out2, 2, 1);
 }
 
+// y = x with the per-block Σ x² on the way (the start of a GMRES cycle: b → column 0 and ‖b‖² in one pass)
+__global__ __launch_bounds__(NK_BLOCK) void k_copy_sumsq(int64_t n, const double *__restrict__ x, double *__restrict__ y,
+                                                         double *__restrict__ partials) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  const int64_t npair = n >> 1, stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < npair; i += stride) {
+    const double2 a = reinterpret_cast<const double2 *>(x)[i];
+    reinterpret_cast<double2 *>(y)[i] = a;
+    s += a.x * a.x + a.y * a.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { y[n - 1] = x[n - 1]; s += x[n - 1] * x[n - 1]; }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+int nk_blas_copy_sumsq(nk_ctx *ctx, int64_t n, const double *x, double *y, double *d_out) {
+  const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
+  NK_LAUNCH(ctx, k_copy_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, y, ctx->d_partials);
+  NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), ctx->d_partials, grid, d_out,
+            (const int *)nullptr, (const double *)nullptr, 0);
+  NK_HIP(hipGetLastError());
+  return nk_comm_allreduce(ctx, d_out, 1, 0);
+}
+
+// max|x| (NaN-propagating) and Σ x² in one pass; stage 2 also folds a third set of partial sums left by another kernel
+__global__ __launch_bounds__(NK_BLOCK) void k_absmax_sumsq(int64_t n, const double *__restrict__ x,
+                                                           double *__restrict__ partials) {
+  __shared__ double sm[8];
+  double m = 0.0, s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double v = x[i];
+    m = nanmax(m, fabs(v));
+    s += v * v;
+  }
+  m = wave_nanmax(m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; sm[4 + (threadIdx.x >> 6)] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = nanmax(nanmax(sm[0], sm[1]), nanmax(sm[2], sm[3]));
+    partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  }
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_reduce_inf2(const double *__restrict__ partials, int nblk,
+                                                          const double *__restrict__ extra, int extra_n,
+                                                          double *__restrict__ out) {
+  __shared__ double sm[12];
+  double m = -__builtin_inf(), s = 0.0, e = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) { m = nanmax(m, partials[i]); s += partials[nblk + i]; }
+  for (int i = threadIdx.x; i < extra_n; i += NK_BLOCK) e += extra[i];
+  m = wave_nanmax(m);
+  s = wave_sum(s);
+  e = wave_sum(e);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w] = m; sm[4 + w] = s; sm[8 + w] = e; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = nanmax(nanmax(sm[0], sm[1]), nanmax(sm[2], sm[3]));
+    out[1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+    if (extra != nullptr) out[2] = (sm[8] + sm[9]) + (sm[10] + sm[11]);
+  }
+}
+int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n) {
+  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+  NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
+  NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out);
+  NK_HIP(hipGetLastError());
+  NK_TRY(nk_comm_allreduce(ctx, d_out, 1, 1));
+  return nk_comm_allreduce(ctx, d_out + 1, extra_partials ? 2 : 1, 0);
+}
+
+// ----------------------------------------------------------------------------- several reductions in one pass
+// Up to NK_MR_MAX inner products Σ x_q·y_q and one NaN-propagating max|a| over the same row range in ONE sweep, one
+// stage-2 launch (which also folds `extra_slots` sets of per-block partial sums another kernel left behind) — the
+// trust-region step's ρ quantities arrive with one fetch instead of six reductions of two launches each.
+struct nk_mr_spec {
+  const double *x[NK_MR_MAX], *y[NK_MR_MAX];
+  const double *amax;
+  int ndots;
+};
+__global__ __launch_bounds__(NK_BLOCK) void k_multi_reduce(int64_t n, nk_mr_spec sp, double *__restrict__ partials) {
+  __shared__ double sm[4 * (NK_MR_MAX + 1)];
+  double acc[NK_MR_MAX], mx = 0.0;
+#pragma unroll
+  for (int q = 0; q < NK_MR_MAX; ++q) acc[q] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+    for (int q = 0; q < NK_MR_MAX; ++q)
+      if (q < sp.ndots) acc[q] += sp.x[q][i] * sp.y[q][i];
+    if (sp.amax != nullptr) mx = nanmax(mx, fabs(sp.amax[i]));
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NK_MR_MAX; ++q) {
+    if (q < sp.ndots) {
+      const double v = wave_sum(acc[q]);
+      if (lane == 0) sm[wid * (NK_MR_MAX + 1) + q] = v;
+    }
+  }
+  mx = wave_nanmax(mx);
+  if (lane == 0) sm[wid * (NK_MR_MAX + 1) + NK_MR_MAX] = mx;
+  __syncthreads();
+  const int t = threadIdx.x;
+  constexpr int L = NK_MR_MAX + 1;
+  if (t < sp.ndots) partials[(size_t)t * gridDim.x + blockIdx.x] = (sm[t] + sm[L + t]) + (sm[2 * L + t] + sm[3 * L + t]);
+  if (t == NK_MR_MAX && sp.amax != nullptr)
+    partials[(size_t)sp.ndots * gridDim.x + blockIdx.x] =
+        nanmax(nanmax(sm[NK_MR_MAX], sm[L + NK_MR_MAX]), nanmax(sm[2 * L + NK_MR_MAX], sm[3 * L + NK_MR_MAX]));
+}
+// block s < ndots: Σ partials[s][:] ; block ndots (if has_max): nanmax ; blocks after that: Σ extra[e][:]
+__global__ __launch_bounds__(NK_BLOCK) void k_multi_reduce2(const double *__restrict__ partials, int nblk, int ndots, int has_max,
+                                                            const double *__restrict__ extra, int extra_n,
+                                                            double *__restrict__ out) {
+  __shared__ double sm[4];
+  const int b = blockIdx.x;
+  const int nmain = ndots + (has_max ? 1 : 0);
+  if (has_max && b == ndots) {
+    const double *p = partials + (size_t)b * nblk;
+    double v = -__builtin_inf();
+    for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) v = nanmax(v, p[i]);
+    v = wave_nanmax(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = nanmax(nanmax(sm[0], sm[1]), nanmax(sm[2], sm[3]));
+    return;
+  }
+  const double *p = (b < nmain) ? partials + (size_t)b * nblk : extra + (size_t)(b - nmain) * extra_n;
+  const int cnt = (b < nmain) ? nblk : extra_n;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < cnt; i += NK_BLOCK) v += p[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// d_out = [dot_0 … dot_{ndots−1}, max|amax| (if amax), extra sums …]; dots and extras all-reduced with +, the max with max
+int nk_blas_multi_reduce(nk_ctx *ctx, int64_t n, int ndots, const double *const *xs, const double *const *ys,
+                         const double *amax, const double *extra_partials, int extra_slots, int extra_n, double *d_out) {
+  NK_REQUIRE(ndots >= 0 && ndots <= NK_MR_MAX, "multi-reduce: at most %d inner products", NK_MR_MAX);
+  nk_mr_spec sp;
+  for (int q = 0; q < NK_MR_MAX; ++q) { sp.x[q] = q < ndots ? xs[q] : nullptr; sp.y[q] = q < ndots ? ys[q] : nullptr; }
+  sp.amax = amax;
+  sp.ndots = ndots;
+  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+  const int has_max = amax ? 1 : 0;
+  if (ndots || has_max) NK_LAUNCH(ctx, k_multi_reduce, dim3(grid), dim3(NK_BLOCK), n, sp, ctx->d_partials);
+  NK_LAUNCH(ctx, k_multi_reduce2, dim3(ndots + has_max + extra_slots), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid,
+            ndots, has_max, extra_partials, extra_n, d_out);
+  NK_HIP(hipGetLastError());
+  if (ndots) NK_TRY(nk_comm_allreduce(ctx, d_out, ndots, 0));
+  if (has_max) NK_TRY(nk_comm_allreduce(ctx, d_out + ndots, 1, 1));
+  if (extra_slots) NK_TRY(nk_comm_allreduce(ctx, d_out + ndots + has_max, extra_slots, 0));
+  return NK_OK;
+}
+
 // ----------------------------------------------------------------------------- elementwise
 __global__ __launch_bounds__(NK_BLOCK) void k_axpby(int64_t n, double a, const double *__restrict__ x, double b,
                                                     double *__restrict__ y) {
@@ -770,10 +934,29 @@ int nk_blas_fill(nk_ctx *ctx, int64_t n, double a, double *y) {
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
+// Device scalars → host without a copy engine and without a stream synchronisation: a one-workgroup kernel stores them
+// into coherent pinned memory, then releases a sequence word the host polls (a D2H hipMemcpyAsync + hipStreamSynchronize
+// cost ≈ 14 µs of blit kernel plus the wake-up latency per call — 2–8 calls per nonlinear step).
+__global__ __launch_bounds__(NK_BLOCK) void k_publish(const double *__restrict__ src, int count, double *h_dst,
+                                                      uint64_t *h_seq, uint64_t seq) {
+  if ((int)threadIdx.x < count) h_dst[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst) {
-  NK_REQUIRE(count <= 4 * NK_MAX_NV, "too many scalars");
-  NK_HIP(hipMemcpyAsync(ctx->h_pinned, d_src, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
+  NK_REQUIRE(count <= NK_BLOCK && count <= 4 * NK_MAX_NV, "too many scalars");
+  static const bool legacy = getenv("NK_FETCH_MEMCPY") != nullptr;  // A/B switch: copy + synchronise
+  if (legacy) {
+    NK_HIP(hipMemcpyAsync(ctx->h_pinned, d_src, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    const uint64_t seq = ++ctx->seq;
+    NK_LAUNCH(ctx, k_publish, dim3(1), dim3(NK_BLOCK), d_src, count, ctx->h_pinned_dev, ctx->h_seq_dev, seq);
+    NK_HIP(hipGetLastError());
+    volatile uint64_t *hs = ctx->h_seq;
+    NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(hs, __ATOMIC_ACQUIRE) == seq; }, "published scalars"));
+  }
   for (int i = 0; i < count; ++i) h_dst[i] = ctx->h_pinned[i];
   return NK_OK;
 }

@@ -49,7 +49,12 @@ extern "C" int nk_ctx_create(int device_id, void *stream, nk_ctx **out) {
   NK_TRY(nk_dev_alloc(&ctx->d_partials, (size_t)(2 * NK_MAX_NV + 2) * NK_MAX_ROW_TILES));  // DCGS2 dot sweep: 2k+2 slots
   NK_TRY(nk_dev_alloc(&ctx->d_partials_ss, (size_t)NK_MAX_RED_BLOCKS));
   NK_TRY(nk_dev_alloc(&ctx->d_scal, (size_t)4 * NK_MAX_NV));
-  NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV, hipHostMallocDefault));
+  // coherent (fine-grained) pinned memory: kernels store scalars and a sequence word straight into it, the host polls
+  NK_HIP(hipHostMalloc((void **)&ctx->h_pinned, sizeof(double) * 4 * NK_MAX_NV + 64, hipHostMallocCoherent | hipHostMallocMapped));
+  NK_HIP(hipHostGetDevicePointer((void **)&ctx->h_pinned_dev, ctx->h_pinned, 0));
+  ctx->h_seq = reinterpret_cast<uint64_t *>(ctx->h_pinned + 4 * NK_MAX_NV);
+  ctx->h_seq_dev = reinterpret_cast<uint64_t *>(ctx->h_pinned_dev + 4 * NK_MAX_NV);
+  *ctx->h_seq = 0;
   const char *ov = getenv("NK_HALO_OVERLAP");
   if (ov && atoi(ov) != 0) NK_TRY(nk_ctx_set_halo_overlap(ctx, 1));
   *out = guard.release();

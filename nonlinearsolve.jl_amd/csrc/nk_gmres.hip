@@ -24,8 +24,15 @@
 #include "nk_internal.h"
 
 // ----------------------------------------------------------------------------- small device kernels
+// progress word in coherent pinned host memory (nk_gmres_pub): the host polls it to bound its run-ahead and to stop
+// enqueueing once the cycle has converged — no copy, no stream synchronisation
+__device__ __forceinline__ void pub_progress(nk_gmres_pub *pub, uint64_t seq, int k, int done) {
+  if (pub != nullptr)
+    __hip_atomic_store(&pub->progress, (seq << 16) | ((uint64_t)k << 1) | (uint64_t)(done ? 1 : 0), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_gmres_begin(nk_gmres_ctl *ctl, const double *d_ss, double atol, double rtol, int fixed,
-                              int first, double *g, double *s, int m) {
+                              int first, double *g, double *s, int m, nk_gmres_pub *pub, uint64_t seq) {
   if (threadIdx.x != 0) return;
   const double beta = sqrt(*d_ss);
   if (first) {
@@ -47,6 +54,7 @@ __global__ void k_gmres_begin(nk_gmres_ctl *ctl, const double *d_ss, double atol
   s[0] = ctl->inv_hn;
   g[0] = beta;
   for (int i = 1; i <= m; ++i) g[i] = 0.0;
+  pub_progress(pub, seq, 0, ctl->done);
 }
 
 // DGKS test after the first projection: re-orthogonalise iff ‖w'‖² < ½‖w‖². pad0 is the "skip pass 2" flag.
@@ -93,7 +101,8 @@ __global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const 
                                                        const double *__restrict__ partials, int nblk, double *R,
                                                        double *cs, double *sn, double *g, double *s, int m,
                                                        double *__restrict__ Hraw, double *__restrict__ a_out,
-                                                       double *__restrict__ b_out, double *__restrict__ h2_out) {
+                                                       double *__restrict__ b_out, double *__restrict__ h2_out,
+                                                       nk_gmres_pub *pub, uint64_t seq) {
   if (ctl->done) return;
   constexpr int LH = NK_MAX_NV + 1;
   __shared__ double sh[NK_MAX_NV + 2], sh2[NK_MAX_NV + 2], sc[NK_MAX_NV + 2], ss_[NK_MAX_NV + 2], ssc[NK_MAX_NV + 2];
@@ -169,9 +178,11 @@ __global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const 
     ctl->inv_hn = inv;
     s[k + 1] = inv;
     s_next = inv;
-    if (!(rn == rn) || isinf(rn) || !(hn == hn)) { ctl->failed = 1; ctl->done = 1; }
-    else if (s_tol >= 0.0 && rn <= s_tol) { ctl->converged = 1; ctl->done = 1; }
-    else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; }
+    int dn = 0;
+    if (!(rn == rn) || isinf(rn) || !(hn == hn)) { ctl->failed = 1; ctl->done = 1; dn = 1; }
+    else if (s_tol >= 0.0 && rn <= s_tol) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+    else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+    pub_progress(pub, seq, k + 1, dn);
   }
   __syncthreads();
   // coefficients for the next step's pass A (pending column k+1, r = h2): c_i = Σ_{j ≤ k} H̄[i][j] r_j, i ≤ k+1
@@ -193,10 +204,14 @@ __global__ __launch_bounds__(1024) void k_givens_dcgs2(nk_gmres_ctl *ctl, const 
 // Latency matters here, not bandwidth (one workgroup between two sweeps): every global operand is requested up front with
 // clamped, unconditional addresses (a load behind a lane predicate costs a full round trip each — five of them in the first
 // version of this kernel), the two inner products run as wave reductions, and H̄ r is split four ways.
+// tprev is double-buffered by the parity of k (tprev_in = buffer k & 1, tprev_out = the other one): in the merged form
+// below every workgroup reads the old values while workgroup 0 writes the new ones.
 __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, int last, const double *__restrict__ red,
-                                                     double *s, double *__restrict__ Hraw, int m, double *__restrict__ tprev,
+                                                     double *s, double *__restrict__ Hraw, int m,
+                                                     const double *__restrict__ tprev_in, double *__restrict__ tprev,
                                                      double *R, double *cs, double *sn, double *g,
-                                                     double *__restrict__ a_out, double *__restrict__ b_out) {
+                                                     double *__restrict__ a_out, double *__restrict__ b_out,
+                                                     nk_gmres_pub *pub, uint64_t seq) {
   const int done = ctl->done;
   constexpr int NH = NK_MAX_NV + 2, LH = NK_MAX_NV + 1;  // any restart the GMRES object accepts (m < NK_MAX_NV)
   __shared__ double sr[NH], sg[NH], sc_[NH], sh[NH], scs[NH], ssn[NH], ssc[NH];
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
   const double st = s[tc];
   const double r_raw = (last == 2) ? 0.0 : red[tc];  // last = 2: the pending column closes the cycle un-re-orthogonalised
   const double g_raw = red[last ? tc : k + 1 + tc];
-  const double tp = tprev[tc];
+  const double tp = tprev_in[tc];
   const double csv = cs[tr], snv = sn[tr];
   const double gj = g[k - 1], ra = red[k], rd = red[last ? k : 2 * k + 1], tol = ctl->tol;
   const int km1 = k > 1 ? k - 1 : 1;
@@ -288,9 +303,11 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
     ctl->rnorm = rn;
     ctl->hn = beta;
     ctl->inv_hn = sk;
-    if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; ctl->done = 1; }
-    else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; ctl->done = 1; }
-    else if (beta == 0.0) { ctl->converged = 1; ctl->done = 1; }
+    int dn = 0;
+    if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; ctl->done = 1; dn = 1; }
+    else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+    else if (beta == 0.0) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+    pub_progress(pub, seq, k, dn);
   }
   if (last) return;
   {  // c = H̄_{k−1} r: rows 0..k, columns 0..k−1; the entries below the sub-diagonal are stored zeros
@@ -319,12 +336,216 @@ __global__ __launch_bounds__(256) void k_dcgs2r_tail(nk_gmres_ctl *ctl, int k, i
   }
 }
 
+
+// The same scalar work as k_dcgs2r_tail (step k, not the flush) done in the PROLOGUE of the axpy sweep: every workgroup
+// derives the axpy coefficients from the reduced inner products itself (≈ 8 KB of L2-resident operands, one round trip,
+// issued behind the loads of its own row tile), so the one-workgroup launch between the reduction and the sweep —
+// ≈ 5 µs of a 69 µs Arnoldi step at the launch-latency floor — disappears. Workgroup 0 also carries the state forward
+// (s_k, the Hessenberg column, tprev, Givens rotation, residual estimate, stopping test, progress word); the other
+// workgroups only read values that workgroup 0 does not write in this launch (tprev is double-buffered; `done` may flip
+// while the launch is in flight, which only decides whether columns k, k+1 — unused once the cycle is done — get updated).
+constexpr int DRT = 8;  // rows per thread (the tile shape of nk_blas.hip's sweeps)
+template <int MAXM>
+__global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy_tail(int64_t n, int k, double *__restrict__ V, int64_t ldv,
+                                                               nk_gmres_ctl *ctl, const double *__restrict__ red, double *s,
+                                                               double *__restrict__ Hraw, int m,
+                                                               const double *__restrict__ tprev_in,
+                                                               double *__restrict__ tprev_out, double *R, double *cs,
+                                                               double *sn, double *g, double *__restrict__ ss_partials,
+                                                               nk_gmres_pub *pub, uint64_t seq) {
+  constexpr int NH = MAXM + 2, LH = MAXM + 1;
+  __shared__ double sr[NH], sg[NH], sc_[NH], sh[NH], scs[NH], ssn[NH], ssc[NH], ca[NH + 1], cb[NH + 1];
+  __shared__ double sH[NH * LH];
+  __shared__ double spart[4 * 64];
+  __shared__ double s_bk, s_sz, s_beta, s_gj, s_tol, s_w[4];
+  __shared__ int s_done;
+  const int t = threadIdx.x;
+  const bool writer = blockIdx.x == 0;
+  if (t == 0) s_done = ctl->done;
+  // ---- this workgroup's row tile of the pending column p and of z = A p: independent of the coefficients, requested first
+  double *__restrict__ pk = V + (size_t)k * ldv;
+  double *__restrict__ zk = V + (size_t)(k + 1) * ldv;
+  const unsigned nn = (unsigned)n, base = blockIdx.x * (NK_BLOCK * DRT) + threadIdx.x;
+  unsigned idx[DRT];
+  double pv[DRT], zv[DRT];
+#pragma unroll
+  for (int i = 0; i < DRT; ++i) {
+    const unsigned r = base + NK_BLOCK * i;
+    idx[i] = r < nn ? r : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < DRT; ++i) {
+    pv[i] = pk[idx[i]];
+    zv[i] = zk[idx[i]];
+  }
+  if (k == 0) {  // column 0 is final: only t_0 = s_0² (v_0·z)
+    const double s0 = s[0], tl = s0 * s0 * red[1];
+    if (t == 0) { s_bk = tl * s0; s_sz = s0; ca[0] = 0.0; cb[0] = 0.0; }
+    __syncthreads();
+    if (s_done) return;
+    if (writer && t == 0) tprev_out[0] = tl;
+  } else {
+    // ---- every global operand of the scalar work, back to back (clamped, unconditional addresses)
+    const int tc = t < k ? t : k - 1;
+    const int tr = t < k - 1 ? t : (k > 1 ? k - 2 : 0);
+    const double st = s[tc], r_raw = red[tc], g_raw = red[k + 1 + tc], tp = tprev_in[tc];
+    const double ra = red[k], rd = red[2 * k + 1];
+    const double csv = cs[tr], snv = sn[tr];
+    if (t == 0) { s_gj = g[k - 1]; s_tol = ctl->tol; }
+    const int km1 = k > 1 ? k - 1 : 1;
+    const int tot = (k + 1) * (k - 1);  // rows 0..k, columns 0..k−2 of H̄ (column k−1 is completed below)
+    for (int e0 = 0; e0 < tot; e0 += 4 * NK_BLOCK) {
+      double hv[4];
+      int at[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + t + NK_BLOCK * q, ec = e < tot ? e : 0;
+        const int i = ec / km1, j = ec - i * km1;
+        hv[q] = Hraw[(size_t)i * m + j];
+        at[q] = (e < tot) ? (i * LH + j) : -1;
+        if (i > j + 1) hv[q] = 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (at[q] >= 0) sH[at[q]] = hv[q];
+    }
+    const double rt = (t < k) ? st * r_raw : 0.0;
+    const double gt = (t < k) ? st * g_raw : 0.0;
+    const double ht = tp + rt;  // entry t of the Hessenberg column that completes now (t < k)
+    double rr = rt * rt, rg = rt * gt;  // wave 0 holds every t < k ≤ 62
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      rr += __shfl_xor(rr, o, 64);
+      rg += __shfl_xor(rg, o, 64);
+    }
+    const int jc = k - 1;
+    if (t < k) {
+      ssc[t] = st;
+      sr[t] = rt;
+      sg[t] = gt;
+      sh[t] = ht;
+      sH[t * LH + jc] = ht;
+      if (t < k - 1) { scs[t] = csv; ssn[t] = snv; }
+    }
+    double b2 = ra - rr;  // ‖u − V r‖² by Pythagoras (valid in wave 0)
+    if (b2 < 0.0) b2 = 0.0;
+    const double beta = sqrt(b2), sk = (beta > 0.0) ? 1.0 / beta : 0.0;
+    if (t == 0) {
+      sH[k * LH + jc] = beta;
+      s_beta = beta;
+      s_sz = sk;
+    }
+    __syncthreads();
+    if (s_done) return;  // uniform
+    if (writer) {  // the state other kernels (and the next step) read
+      if (t < k) Hraw[(size_t)t * m + jc] = ht;
+      if (t == 0) { s[k] = sk; Hraw[(size_t)k * m + jc] = beta; }
+    }
+    {  // c = H̄_{k−1} r: rows 0..k, columns 0..k−1; the entries below the sub-diagonal are stored zeros
+      const int row = t & 63, part = t >> 6;
+      double c = 0.0;
+      if (row <= k) {
+#pragma unroll 4
+        for (int j = part; j < k; j += 4) c += sH[row * LH + j] * sr[j];
+      }
+      spart[part * 64 + row] = c;
+    }
+    __syncthreads();
+    if (t <= k) sc_[t] = (spart[t] + spart[64 + t]) + (spart[128 + t] + spart[192 + t]);
+    __syncthreads();
+    const double skk = s_sz, bet = s_beta;
+    if (t < k) {
+      const double tt = (sg[t] - sc_[t]) * skk;
+      if (writer) tprev_out[t] = tt;
+      ca[t] = sr[t] * ssc[t];
+      cb[t] = (skk * sc_[t] + tt) * ssc[t];
+    }
+    if (t == 0) {
+      const double tl = (rd - rg - bet * sc_[k]) * skk * skk;
+      if (writer) tprev_out[k] = tl;
+      s_bk = (skk * sc_[k] + tl) * skk;
+      ca[k] = 0.0;  // one zero entry past the end pads an odd column count
+      cb[k] = 0.0;
+    }
+    __syncthreads();
+  }
+  // ---- the sweep: p ← p − Σ a_j ṽ_j ; z ← s_k z − Σ b_j ṽ_j − b_k p   (as k_dcgs2r_axpy)
+  const double sz = s_sz, bk = s_bk;
+#pragma unroll
+  for (int i = 0; i < DRT; ++i) zv[i] *= sz;
+  for (int j = 0; j < k; j += 2) {
+    const int j1 = min(j + 1, k - 1);
+    const double *__restrict__ c0 = V + (size_t)j * ldv;
+    const double *__restrict__ c1 = V + (size_t)j1 * ldv;
+    const double a0 = ca[j], a1 = ca[j + 1], b0 = cb[j], b1 = cb[j + 1];
+    double v0[DRT], v1[DRT];
+#pragma unroll
+    for (int i = 0; i < DRT; ++i) { v0[i] = c0[idx[i]]; v1[i] = c1[idx[i]]; }
+#pragma unroll
+    for (int i = 0; i < DRT; ++i) {
+      pv[i] -= a0 * v0[i];
+      pv[i] -= a1 * v1[i];
+      zv[i] -= b0 * v0[i];
+      zv[i] -= b1 * v1[i];
+    }
+  }
+  double ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < DRT; ++i) {
+    const unsigned r = base + NK_BLOCK * i;
+    if (r < nn) {
+      if (k > 0) pk[r] = pv[i];
+      const double zn = zv[i] - bk * pv[i];
+      zk[r] = zn;
+      ss += zn * zn;
+    }
+  }
+  if (ss_partials != nullptr) {  // uniform: the cycle's last step also needs ‖z_new‖²
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) ss_partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+  }
+  // ---- workgroup 0, after its share of the sweep is on its way: Givens rotation of the column that closed, residual
+  // estimate, stopping test (nothing in this launch waits for it)
+  if (writer && t == 0 && k > 0) {
+    const int jc = k - 1;
+    const double beta = s_beta, gj = s_gj, tol = s_tol;
+    double hk = sh[0];
+#pragma unroll 4
+    for (int i = 0; i < jc; ++i) {
+      const double a = hk, b = sh[i + 1];
+      R[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
+      hk = -ssn[i] * a + scs[i] * b;
+    }
+    const double d = hypot(hk, beta);
+    double c, sgn;
+    if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
+    cs[jc] = c;
+    sn[jc] = sgn;
+    R[(size_t)jc * m + jc] = d;
+    g[jc + 1] = -sgn * gj;
+    g[jc] = c * gj;
+    const double rn = fabs(sgn * gj);
+    ctl->k = k;
+    ctl->rnorm = rn;
+    ctl->hn = beta;
+    ctl->inv_hn = s_sz;
+    int dn = 0;
+    if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; ctl->done = 1; dn = 1; }
+    else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+    else if (beta == 0.0) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+    pub_progress(pub, seq, k, dn);
+  }
+}
+
 // new Hessenberg column → apply old rotations, create the new one, update g and the residual estimate
 // ss_partials != nullptr (single rank): ‖w‖² arrives as nblk per-block partials and is reduced here, saving a launch
 __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, const double *h2, const double *d_ss,
                                                double *R, double *cs, double *sn, double *g, double *s, int m,
                                                const double *__restrict__ ss_partials, int nblk, int pythag,
-                                               double *__restrict__ Hraw) {
+                                               double *__restrict__ Hraw, nk_gmres_pub *pub, uint64_t seq) {
   if (ctl->done) return;
   __shared__ double sh[NK_MAX_NV + 2], sc[NK_MAX_NV + 2], ss_[NK_MAX_NV + 2];
   const int k = ctl->k, t = threadIdx.x;
@@ -377,20 +598,32 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
   ctl->hn = hn;
   ctl->inv_hn = (hn > 0.0) ? 1.0 / hn : 0.0;
   s[k + 1] = ctl->inv_hn;
-  if (!(rn == rn) || isinf(rn) || !(hn == hn)) { ctl->failed = 1; ctl->done = 1; }
-  else if (ctl->tol >= 0.0 && rn <= ctl->tol) { ctl->converged = 1; ctl->done = 1; }
-  else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; }  // happy breakdown
+  int dn = 0;
+  if (!(rn == rn) || isinf(rn) || !(hn == hn)) { ctl->failed = 1; ctl->done = 1; dn = 1; }
+  else if (ctl->tol >= 0.0 && rn <= ctl->tol) { ctl->converged = 1; ctl->done = 1; dn = 1; }
+  else if (hn == 0.0) { ctl->converged = 1; ctl->done = 1; dn = 1; }  // happy breakdown
+  pub_progress(pub, seq, k + 1, dn);
 }
 
 // y = R(0:k,0:k)^{-1} g(0:k), k = ctl->k. R is staged in LDS with batched loads; wave 0 runs the column-oriented
 // recurrence (lane t owns g_t: after y_i is known every lane t < i takes R_ti y_i off its entry) — k dependent steps instead
 // of k²/2 on one lane.
 __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, const double *__restrict__ R,
-                                                   const double *__restrict__ g, double *__restrict__ y, int m) {
+                                                   const double *__restrict__ g, double *__restrict__ y, int m,
+                                                   nk_gmres_pub *pub, uint64_t seq) {
   constexpr int LK = NK_MAX_NV + 1;  // odd stride: the column reads below are conflict-free
   __shared__ double sR[NK_MAX_NV * LK];
   const int k = ctl->k, failed = ctl->failed;
   const int t = threadIdx.x;
+  if (pub != nullptr && t == 0) {  // what the host needs of the control block, then the release of the sequence word
+    pub->k = k;
+    pub->converged = ctl->converged;
+    pub->failed = failed;
+    pub->rnorm0 = ctl->rnorm0;
+    pub->rnorm = ctl->rnorm;
+    __threadfence_system();
+    __hip_atomic_store(&pub->end_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int tot = k * k, kd = k > 0 ? k : 1;
   double gv = g[t < k ? t : 0];
   for (int e0 = 0; e0 < tot; e0 += 1024) {
@@ -453,7 +686,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_TRY(nk_dev_alloc(&G->d_h2, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_Hraw, (size_t)(NK_MAX_NV + 1) * NK_MAX_NV));
   NK_TRY(nk_dev_alloc(&G->d_ca, (size_t)NK_MAX_NV + 2));
-  NK_TRY(nk_dev_alloc(&G->d_tprev, (size_t)NK_MAX_NV + 2));
+  NK_TRY(nk_dev_alloc(&G->d_tprev, (size_t)2 * (NK_MAX_NV + 2)));  // double-buffered by the parity of the step
   NK_TRY(nk_dev_alloc(&G->d_red, (size_t)2 * NK_MAX_NV + 4));
   NK_TRY(nk_dev_alloc(&G->d_cb, (size_t)NK_MAX_NV + 2));
   NK_TRY(nk_dev_alloc(&G->d_s, (size_t)NK_MAX_NV + 2));
@@ -465,6 +698,13 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   NK_TRY(nk_dev_alloc(&G->d_ss, (size_t)4));
   NK_TRY(nk_dev_alloc(&G->d_ctl, (size_t)1));
   NK_HIP(hipHostMalloc((void **)&G->h_ctl, sizeof(nk_gmres_ctl), hipHostMallocDefault));
+  NK_HIP(hipHostMalloc((void **)&G->h_pub, sizeof(nk_gmres_pub), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(G->h_pub, 0, sizeof(nk_gmres_pub));
+  NK_HIP(hipHostGetDevicePointer((void **)&G->h_pub_dev, G->h_pub, 0));
+  {
+    const char *e = getenv("NK_GMRES_RUN_AHEAD");
+    G->run_ahead = e ? atoi(e) : 4;
+  }
   NK_HIP(hipMemset(G->d_ctl, 0, sizeof(nk_gmres_ctl)));
   NK_HIP(hipMemset(G->V, 0, (size_t)G->ldv * (m + 1) * sizeof(double)));
   NK_HIP(hipMemset(G->d_s, 0, (NK_MAX_NV + 2) * sizeof(double)));
@@ -481,6 +721,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
   hipFree(G->cr); hipFree(G->cd); hipFree(G->ct); hipFree(G->cd2);
   hipHostFree(G->h_ctl);
+  hipHostFree(G->h_pub);
   delete G;
   return NK_OK;
 }
@@ -822,6 +1063,11 @@ static bool dcgs2r_full_flush() {
   static const bool full = getenv("NK_DCGS2_FULL_FLUSH") != nullptr;
   return full;
 }
+static double *tprev_buf(nk_gmres *G, int k) { return G->d_tprev + (size_t)(k & 1) * (NK_MAX_NV + 2); }
+static bool dcgs2r_split_tail() {
+  static const bool split = getenv("NK_DCGS2_SPLIT_TAIL") != nullptr;  // A/B switch: the scalar work as its own launch
+  return split;
+}
 static int arnoldi_step_1r(nk_gmres *G, int k, bool last_of_cycle) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n, ldv = G->ldv;
@@ -829,10 +1075,31 @@ static int arnoldi_step_1r(nk_gmres *G, int k, bool last_of_cycle) {
   double *zk = G->V + (size_t)(k + 1) * ldv;
   NK_TRY(op_apply(G, G->V + (size_t)k * ldv, zk, skip, nullptr));  // z = A u on the pending (un-normalised) column
   NK_TRY(nk_blas_dcgs2r_dots(ctx, n, k, false, G->V, ldv, G->d_red, skip));
-  NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, k, 0, (const double *)G->d_red, G->d_s, G->d_Hraw, G->m,
-            G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
   double *ss_out = (last_of_cycle && !dcgs2r_full_flush()) ? G->d_red + (k + 1) : nullptr;  // slot of u·u at the flush
-  NK_TRY(nk_blas_dcgs2r_axpy(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, skip, ss_out));
+  if (dcgs2r_split_tail()) {
+    NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, k, 0, (const double *)G->d_red, G->d_s, G->d_Hraw, G->m,
+              (const double *)tprev_buf(G, k), tprev_buf(G, k + 1), G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb,
+              G->h_pub_dev, G->cycle_seq);
+    NK_TRY(nk_blas_dcgs2r_axpy(ctx, n, k, G->V, ldv, G->d_ca, G->d_cb, skip, ss_out));
+    return NK_OK;
+  }
+  // scalar work in the prologue of the sweep (k_dcgs2r_axpy_tail): one launch less per Arnoldi step
+  const int64_t tile = (int64_t)NK_BLOCK * DRT;
+  const int grid = (int)((n + tile - 1) / tile > 0 ? (n + tile - 1) / tile : 1);
+  {
+    nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 4));
+    double *ssp = ss_out ? ctx->d_partials : (double *)nullptr;
+    if (G->m <= 31)
+      NK_LAUNCH(ctx, k_dcgs2r_axpy_tail<32>, dim3(grid), dim3(NK_BLOCK), n, k, G->V, ldv, G->d_ctl, (const double *)G->d_red,
+                G->d_s, G->d_Hraw, G->m, (const double *)tprev_buf(G, k), tprev_buf(G, k + 1), G->d_R, G->d_cs, G->d_sn,
+                G->d_g, ssp, G->h_pub_dev, G->cycle_seq);
+    else
+      NK_LAUNCH(ctx, k_dcgs2r_axpy_tail<NK_MAX_NV>, dim3(grid), dim3(NK_BLOCK), n, k, G->V, ldv, G->d_ctl,
+                (const double *)G->d_red, G->d_s, G->d_Hraw, G->m, (const double *)tprev_buf(G, k), tprev_buf(G, k + 1),
+                G->d_R, G->d_cs, G->d_sn, G->d_g, ssp, G->h_pub_dev, G->cycle_seq);
+  }
+  NK_HIP(hipGetLastError());
+  if (ss_out) NK_TRY(nk_blas_reduce_one(ctx, ctx->d_partials, grid, ss_out, skip));
   return NK_OK;
 }
 // after the last step of a cycle: the pending column's reduction completes the last Hessenberg column
@@ -843,7 +1110,8 @@ static int arnoldi_flush_1r(nk_gmres *G, int steps) {
   const bool full = dcgs2r_full_flush();
   if (full) NK_TRY(nk_blas_dcgs2r_dots(ctx, G->n, steps, true, G->V, G->ldv, G->d_red, skip));
   NK_LAUNCH(ctx, k_dcgs2r_tail, dim3(1), dim3(256), G->d_ctl, steps, full ? 1 : 2, (const double *)G->d_red, G->d_s,
-            G->d_Hraw, G->m, G->d_tprev, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_ca, G->d_cb);
+            G->d_Hraw, G->m, (const double *)tprev_buf(G, steps), tprev_buf(G, steps + 1), G->d_R, G->d_cs, G->d_sn, G->d_g,
+            G->d_ca, G->d_cb, G->h_pub_dev, G->cycle_seq);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
@@ -878,11 +1146,12 @@ static int arnoldi_step(nk_gmres *G, int k) {
       NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, NK_SUMSQ_PARTIALS_ONLY, skip));
       nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (nv + 1) * ctx->last_red_grid);
       NK_LAUNCH(ctx, k_givens_dcgs2, dim3(1), dim3(1024), G->d_ctl, (const double *)G->d_h, (const double *)ctx->d_partials,
-                ctx->last_red_grid, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, G->d_Hraw, G->d_ca, G->d_cb, G->d_h2);
+                ctx->last_red_grid, G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, G->d_Hraw, G->d_ca, G->d_cb, G->d_h2,
+                G->h_pub_dev, G->cycle_seq);
     } else {
       NK_TRY(nk_blas_fused_axpy_dot(ctx, n, nv, G->V, ldv, G->d_h, G->d_s, wk, G->d_h2, skip));
       NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
-                G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 1, G->d_Hraw);
+                G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 1, G->d_Hraw, G->h_pub_dev, G->cycle_seq);
     }
   } else if (G->ortho == NK_ORTHO_MGS) {
     for (int i = 0; i <= k; ++i) {  // h_i = v_i·w ; w -= h_i v_i ; the last axpy also yields ‖w‖²
@@ -891,7 +1160,8 @@ static int arnoldi_step(nk_gmres *G, int k) {
                                i == k ? G->d_ss : nullptr, skip, nullptr, G->d_s + i));
     }
     NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)nullptr, G->d_ss,
-                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 0, (double *)nullptr);
+                       G->d_R, G->d_cs, G->d_sn, G->d_g, G->d_s, G->m, (const double *)nullptr, 0, 0, (double *)nullptr,
+                       G->h_pub_dev, G->cycle_seq);
   } else {
     const bool dgks = (G->ortho == NK_ORTHO_CGS);
     const int *skip2 = dgks ? &G->d_ctl->pad0 : skip;
@@ -918,7 +1188,7 @@ static int arnoldi_step(nk_gmres *G, int k) {
     NK_TRY(nk_blas_multiaxpy(ctx, n, nv, G->V, ldv, G->d_h2, -1.0, wk, ss_dst, skip2, nullptr, G->d_s));
     NK_LAUNCH(ctx, k_givens, dim3(1), dim3(64), G->d_ctl, G->d_h, (const double *)G->d_h2, G->d_ss, G->d_R, G->d_cs,
               G->d_sn, G->d_g, G->d_s, G->m, fold ? (const double *)ctx->d_partials_ss : (const double *)nullptr,
-              fold ? ctx->last_red_grid : 0, pythag ? 1 : 0, (double *)nullptr);
+              fold ? ctx->last_red_grid : 0, pythag ? 1 : 0, (double *)nullptr, G->h_pub_dev, G->cycle_seq);
   }
   NK_HIP(hipGetLastError());
   return NK_OK;
@@ -934,10 +1204,13 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   const int cap = fixed_iters > 0 ? fixed_iters : maxiter;
   nk_gmres_info inf;
   memset(&inf, 0, sizeof(inf));
-  // r0 = b − A x0, written straight into column 0 of the basis (un-normalised)
+  // r0 = b − A x0, written straight into column 0 of the basis (un-normalised); zero initial guess: b → column 0 and
+  // ‖b‖² in one pass, and the first solution update WRITES x = V y (no memset of x)
+  bool have_ss = false, x_is_zero = false;
   if (!use_x0) {
-    NK_TRY(nk_blas_fill(ctx, n, 0.0, d_x));
-    NK_TRY(nk_blas_copy(ctx, n, d_b, G->V));
+    NK_TRY(nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss));
+    have_ss = true;
+    x_is_zero = true;
   } else {
     if (G->prec_kind) NK_FAIL(NK_E_UNSUPPORTED, "use_x0 with a right preconditioner is not supported");
     NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
@@ -945,43 +1218,66 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   }
   int first = 1;
   int total_iters = 0;
+  volatile nk_gmres_pub *pub = G->h_pub;
   for (;;) {
-    NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
+    if (!have_ss) NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
+    have_ss = false;
+    const uint64_t seq = ++G->cycle_seq;
     NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol,
-                       fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m);
+                       fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m, G->h_pub_dev, seq);
     first = 0;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
-    // The whole cycle is enqueued without host synchronisation; kernels after convergence return at once on the device
-    // flag. With a launch-heavy preconditioner (a multigrid V-cycle is ≈ 70 launches) those no-op launches would dominate
-    // a cycle that converges after one or two steps, so there the flag is read back every `sync_every` steps instead.
+    // The cycle is enqueued without a host synchronisation; kernels after convergence return at once on the device flag.
+    // The device also publishes a progress word (cycle sequence, columns closed, done) in coherent pinned memory, which the
+    // host merely reads: when the solve can stop early (a tolerance is set) the host keeps at most `run_ahead` Arnoldi steps
+    // in the queue ahead of the device and stops enqueueing as soon as `done` shows — otherwise every step after
+    // convergence would still cost its no-op launches (≈ 70 per step with a multigrid V-cycle inside).
     {
       const bool one_red = use_dcgs2r(G);
-      const int sync_every = (G->prec_kind == 3) ? 2 : steps;
+      const int ahead = (fixed_iters > 0 || G->run_ahead <= 0) ? 0 : (G->prec_kind == 3 ? 1 : G->run_ahead);
       bool stopped = false;
-      for (int k = 0; k < steps && !stopped;) {
-        const int kend = (k + sync_every < steps) ? k + sync_every : steps;
-        for (; k < kend; ++k) NK_TRY(one_red ? arnoldi_step_1r(G, k, k == steps - 1) : arnoldi_step(G, k));
-        if (kend < steps) {
-          NK_HIP(hipMemcpyAsync(G->h_ctl, G->d_ctl, sizeof(nk_gmres_ctl), hipMemcpyDeviceToHost, ctx->stream));
-          NK_HIP(hipStreamSynchronize(ctx->stream));
-          stopped = G->h_ctl->done != 0;
+      for (int k = 0; k < steps && !stopped; ++k) {
+        if (ahead > 0) {
+          // column j closes in step j (plain forms) or in step j+1 (one-reduction form): wait until step k−ahead is done
+          const int need = k - ahead - (one_red ? 1 : 0);
+          auto ready = [&] {
+            const uint64_t w = __atomic_load_n(&pub->progress, __ATOMIC_ACQUIRE);
+            if ((w >> 16) != seq) return false;  // k_gmres_begin of this cycle has not run yet
+            if (w & 1) { stopped = true; return true; }
+            return (int)((w >> 1) & 0x7fff) >= need;
+          };
+          if (need >= 0 || k > 0) {
+            if (need >= 0) NK_TRY(nk_spin_wait(ctx, ready, "GMRES progress"));
+            else (void)ready();  // no need to wait yet, but a raised `done` stops the enqueueing
+          }
+          if (stopped) break;
         }
+        NK_TRY(one_red ? arnoldi_step_1r(G, k, k == steps - 1) : arnoldi_step(G, k));
       }
       if (one_red && !stopped) NK_TRY(arnoldi_flush_1r(G, steps));
     }
-    // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns)
-    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m);
+    // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns); the back-substitution also publishes the control
+    // block's outcome to the host
+    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq);
     if (!G->prec_kind) {
-      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s));
+      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
     } else {
-      NK_TRY(nk_blas_fill(ctx, n, 0.0, G->r));
-      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, G->r, nullptr, nullptr, &G->d_ctl->k, G->d_s));
+      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, G->r, nullptr, nullptr, &G->d_ctl->k, G->d_s, true));
       NK_TRY(prec_apply(G, G->r, G->z, nullptr));
-      NK_TRY(nk_blas_axpby(ctx, n, 1.0, G->z, 1.0, d_x));
+      if (x_is_zero) NK_TRY(nk_blas_copy(ctx, n, G->z, d_x));
+      else NK_TRY(nk_blas_axpby(ctx, n, 1.0, G->z, 1.0, d_x));
     }
-    NK_HIP(hipMemcpyAsync(G->h_ctl, G->d_ctl, sizeof(nk_gmres_ctl), hipMemcpyDeviceToHost, ctx->stream));
-    NK_HIP(hipStreamSynchronize(ctx->stream));
-    const nk_gmres_ctl c = *G->h_ctl;
+    x_is_zero = false;
+    NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(&pub->end_seq, __ATOMIC_ACQUIRE) == seq; }, "the end of a GMRES cycle"));
+    nk_gmres_ctl c;
+    memset(&c, 0, sizeof(c));
+    c.k = pub->k;
+    c.converged = pub->converged;
+    c.failed = pub->failed;
+    c.rnorm0 = pub->rnorm0;
+    c.rnorm = pub->rnorm;
+    c.done = (c.converged || c.failed) ? 1 : 0;
+    *G->h_ctl = c;
     total_iters += c.k;
     inf.rnorm0 = c.rnorm0;
     inf.rnorm = c.rnorm;

@@ -88,9 +88,30 @@ struct nk_ctx {
   double *d_partials_ss = nullptr;  // ‖·‖² partials of the axpy kernels (own buffer: survives later multidots)
   int last_red_grid = 0;
   double *d_scal = nullptr;      // 4*NK_MAX_NV doubles of device scalars
-  double *h_pinned = nullptr;    // 4*NK_MAX_NV doubles pinned host
+  double *h_pinned = nullptr;    // 4*NK_MAX_NV doubles pinned host (coherent: kernels publish scalars into it)
+  double *h_pinned_dev = nullptr;  // the same allocation as the device sees it
+  uint64_t *h_seq = nullptr, *h_seq_dev = nullptr;  // sequence word of the last published batch (pinned, coherent)
+  uint64_t seq = 0;
   nk_stats stats{};
 };
+
+// Host side of "a kernel publishes into coherent pinned memory, the host polls": spins on `ready`, checking every few
+// thousand polls that the stream is still alive (a faulted or drained stream must not leave the host spinning).
+template <class Pred>
+static inline int nk_spin_wait(nk_ctx *ctx, Pred ready, const char *what) {
+  for (uint64_t it = 1;; ++it) {
+    if (ready()) return NK_OK;
+    if ((it & 0x3fff) == 0) {
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e == hipSuccess) {
+        if (ready()) return NK_OK;
+        NK_FAIL(NK_E_HIP, "the stream drained but %s never arrived", what);
+      }
+      if (e != hipErrorNotReady) NK_FAIL(NK_E_HIP, "stream error while waiting for %s: %s", what, hipGetErrorString(e));
+    }
+    __builtin_ia32_pause();
+  }
+}
 
 // true when no collective has to be issued (1 rank and not in the NK_FORCE_COLLECTIVES test mode)
 bool nk_ctx_is_single(const nk_ctx *ctx);
@@ -227,7 +248,17 @@ int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ld
                      double *d_h, bool with_self, const int *d_skip, const double *d_scales);
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq /*nullable*/, const int *d_skip,
-                      const int *d_nv /*nullable: device count overrides nv*/, const double *d_scales);
+                      const int *d_nv /*nullable: device count overrides nv*/, const double *d_scales,
+                      bool overwrite = false /* w = sign·V h instead of w += … */);
+constexpr int NK_MR_MAX = 6;  // inner products per nk_blas_multi_reduce launch
+int nk_blas_multi_reduce(nk_ctx *ctx, int64_t n, int ndots, const double *const *xs, const double *const *ys,
+                         const double *amax, const double *extra_partials, int extra_slots, int extra_n, double *d_out);
+int nk_blas_reduce_one(nk_ctx *ctx, const double *partials, int nblk, double *d_out, const int *d_skip);
+// y = x and *d_out = Σ x² (all-reduced) in one pass
+int nk_blas_copy_sumsq(nk_ctx *ctx, int64_t n, const double *x, double *y, double *d_out);
+// d_out[0] = max|x| (NaN-propagating), d_out[1] = Σ x²; optional third slot: Σ of `extra_partials[0..extra_n)` (per-block
+// partial sums another kernel left behind) — one stage-2 launch and one fetch for the Newton driver's three norms
+int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n);
 #define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
 // DCGS2 pass A: correct the pending column V[:,k] by −Σ a_j ṽ_j, turn V[:,k+1] (= s_k·A·pending) into the true next
 // vector by −Σ b_j ṽ_j − b_k·corrected, and return d_h[0..k] = s_j·(ṽ_j·w) over the corrected basis
@@ -264,6 +295,14 @@ struct nk_gmres_ctl {  // lives in device memory, mirrored to pinned host memory
   int done, k, converged, failed, need_reorth, pad0, pad1, pad2;
   double tol, rnorm0, rnorm, inv_hn, hn, wnorm2_before, beta, r0;
 };
+// Written by the device into coherent pinned host memory, polled by the host (no copy, no stream synchronisation):
+//   progress = seq << 16 | k << 1 | done   after k_gmres_begin (k = 0) and after every closed Hessenberg column
+//   end_seq  = seq                          once the cycle's back-substitution has run; the fields below are then valid
+struct nk_gmres_pub {
+  uint64_t progress, end_seq;
+  int k, converged, failed, pad;
+  double rnorm0, rnorm;
+};
 struct nk_gmres {
   nk_ctx *ctx = nullptr;
   int64_t n = 0, ldv = 0;
@@ -275,6 +314,9 @@ struct nk_gmres {
          *d_g = nullptr, *d_y = nullptr, *d_ss = nullptr;
   double *d_s = nullptr;  // s_j: the basis is stored un-normalised, v_j = s_j ṽ_j (lagged normalisation)
   nk_gmres_ctl *d_ctl = nullptr, *h_ctl = nullptr;
+  nk_gmres_pub *h_pub = nullptr, *h_pub_dev = nullptr;
+  uint64_t cycle_seq = 0;
+  int run_ahead = 0;  // > 0: at most that many Arnoldi steps are enqueued ahead of the device (0: whole cycle)
   // operator
   int op_kind = 0;  // 0 none, 1 csr, 2 problem jvp, 3 fn
   nk_csr *A = nullptr;

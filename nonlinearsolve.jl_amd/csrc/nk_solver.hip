@@ -19,10 +19,15 @@ struct nk_solver {
   nk_stats ctx_base{};  // context-wide counters (operator applications, all-reduces, halo exchanges) at (re)initialisation
   nk_options o{};
   int64_t n = 0;
-  // vectors
+  // vectors. The iterate lives in a pool of three buffers: `u` (current) and `best_u` (the retained best iterate of the
+  // safe-best termination modes; may be the same buffer) point into it, and every new iterate / trial point is written
+  // into a buffer that is neither — taking a step or keeping the best iterate is a pointer assignment, never a copy.
+  double *ubuf[3] = {nullptr, nullptr, nullptr};
   double *u = nullptr, *fu = nullptr, *du = nullptr, *best_u = nullptr;
   double *u_trial = nullptr, *fu_trial = nullptr, *du_newton = nullptr, *du_cauchy = nullptr, *Jdu = nullptr,
          *JTfu = nullptr, *c1 = nullptr, *c2 = nullptr, *tr_du = nullptr, *stage = nullptr;
+  bool fu_deferred = false;   // step!(…; evaluate_residual = false) left the residual of the new iterate unevaluated
+  double fnorm2 = 0.0;        // ‖fu‖₂ of the current residual (Eisenstat–Walker reads it without another reduction)
   nk_gmres *G = nullptr;
   nk_csr *J = nullptr;
   bool own_J = false;
@@ -33,7 +38,7 @@ struct nk_solver {
   bool force_stop = false, make_new_jacobian = true;
   nk_stats stats{};
   double total_time = 0.0;
-  uint64_t u_version = 0, best_version = 0;
+  uint64_t u_version = 0;
   // termination cache
   double abstol = 0, reltol = 0, best_obj = 0, initial_obj = 0, fnorm_inf = 0;
   double tc_u0_norm = 0;  // ‖u0‖₂ for the relative stall test
@@ -50,15 +55,17 @@ struct nk_solver {
   std::vector<nk_trace_entry> trace;
 };
 
-// u += du ; partial Σ (u_new − u_old)²  (the stall test's ‖u − uprev‖₂, termination_conditions.jl:311-316)
-__global__ __launch_bounds__(NK_BLOCK) void k_newton_update(int64_t n, const double *__restrict__ du,
-                                                            double *__restrict__ u, double *__restrict__ partials) {
+// u_new = u + sign·du (out of place: the old iterate stays intact in its buffer) ; partial Σ (u_new − u_old)²  (the stall
+// test's ‖u − uprev‖₂, termination_conditions.jl:311-316). sign = −1 takes the linear solve's x as it is (δu = −x).
+__global__ __launch_bounds__(NK_BLOCK) void k_newton_update(int64_t n, double sign, const double *__restrict__ du,
+                                                            const double *__restrict__ u, double *__restrict__ unew,
+                                                            double *__restrict__ partials) {
   __shared__ double sm[4];
   double ss = 0.0;
   const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
   for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
-    const double uo = u[i], un = uo + du[i], d = un - uo;
-    u[i] = un;
+    const double uo = u[i], un = uo + sign * du[i], d = un - uo;
+    unew[i] = un;
     ss += d * d;
   }
 #pragma unroll
@@ -200,6 +207,23 @@ static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BAN
 // ---- scalar helpers (device reductions → pinned host, one synchronisation)
 static int fetch(nk_solver *S, int count, double *out) { return nk_scalars_to_host(S->ctx, S->ctx->d_scal, count, out); }
 static double *slot(nk_solver *S, int i) { return S->ctx->d_scal + i; }
+
+// a pool buffer that holds neither the current nor the retained best iterate
+static double *spare_u(nk_solver *S) {
+  for (double *b : S->ubuf)
+    if (b != S->u && b != S->best_u) return b;
+  return nullptr;  // unreachable: three buffers, at most two in use
+}
+// ‖fu‖∞ and ‖fu‖₂² of the current residual (+ optionally the stall norm's partial sums) → ONE stage-2 launch, one fetch
+static int residual_norms(nk_solver *S, const double *stall_partials, int stall_n, double *step_norm) {
+  double v[3] = {0, 0, 0};
+  NK_TRY(nk_blas_norms_inf2(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n));
+  NK_TRY(fetch(S, stall_partials ? 3 : 2, v));
+  S->fnorm_inf = v[0];
+  S->fnorm2 = sqrt(v[1]);
+  if (step_norm) *step_norm = sqrt(v[2]);
+  return NK_OK;
+}
 
 static int apply_J(nk_solver *S, const double *v, double *out) {
   if (concrete(S)) return nk_csr_spmv_dev(S->J, v, out, nullptr);
@@ -352,8 +376,7 @@ static int tc_check(nk_solver *S, double step_norm, bool *stop) {
   }
   if (tm_best(mode) && objective < S->best_obj) {
     S->best_obj = objective;
-    NK_TRY(nk_blas_copy(S->ctx, S->n, S->u, S->best_u));
-    S->best_version = S->u_version;
+    S->best_u = S->u;  // the buffer stays untouched until a better iterate replaces it (spare_u never hands it out)
   }
   if (objective <= criteria) { S->tc_retcode = NK_RET_SUCCESS; *stop = true; return NK_OK; }
   S->tc_nsteps += 1;
@@ -381,17 +404,13 @@ static int tc_check(nk_solver *S, double step_norm, bool *stop) {
 // update_from_termination_cache! (termination_conditions.jl:440-453)
 static int rollback_to_best(nk_solver *S) {
   if (!tm_best(S->o.termination_mode)) return NK_OK;  // only the *Best modes retain an iterate
-  if (S->best_version == S->u_version) return NK_OK;
-  NK_TRY(nk_blas_copy(S->ctx, S->n, S->best_u, S->u));
+  if (S->best_u == S->u) return NK_OK;  // the last iterate is the best one: its residual is already in fu
+  S->u = S->best_u;
   S->u_version++;
-  S->best_version = S->u_version;
+  S->P->d_u_lin = nullptr;
   NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
   S->stats.nf++;
-  NK_TRY(nk_blas_norm_inf(S->ctx, S->n, S->fu, slot(S, 0)));
-  double v;
-  NK_TRY(fetch(S, 1, &v));
-  S->fnorm_inf = v;
-  return NK_OK;
+  return residual_norms(S, nullptr, 0, nullptr);
 }
 
 // ---- init
@@ -412,13 +431,9 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   S->total_time = 0.0;
   S->trace.clear();
   S->u_version++;
-  NK_TRY(nk_blas_copy(ctx, S->n, S->u, S->best_u));
-  S->best_version = S->u_version;
-  NK_TRY(nk_blas_norm_inf(ctx, S->n, S->fu, slot(S, 0)));
-  NK_TRY(nk_blas_sumsq(ctx, S->n, S->fu, slot(S, 1)));
-  double v[2];
-  NK_TRY(fetch(S, 2, v));
-  S->fnorm_inf = v[0];
+  S->best_u = S->u;
+  S->fu_deferred = false;
+  NK_TRY(residual_norms(S, nullptr, 0, nullptr));
   NK_TRY(tc_reinit(S));
   if (concrete(S)) {  // jacobian.jl:104-118 evaluates J once at init
     NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
@@ -427,7 +442,7 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   }
   NK_TRY(nk_blas_fill(ctx, S->n, 0.0, S->du));  // descent/newton.jl:34-36
   S->eta = S->o.ew_eta0;
-  S->rnorm = S->rnorm_prev = sqrt(v[1]);
+  S->rnorm = S->rnorm_prev = S->fnorm2;
   S->lin_abstol = S->o.lin_abstol >= 0.0 ? S->o.lin_abstol : S->abstol;  // FirstOrder/src/solve.jl:203
   S->lin_reltol = S->o.lin_reltol >= 0.0 ? S->o.lin_reltol : S->reltol;
   if (is_tr(S)) {
@@ -472,17 +487,15 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   S->reltol = opts->reltol > 0.0 ? opts->reltol : DEFAULT_TOL;
   const int64_t n = S->n = P->n_local;
   const size_t na = (size_t)n + 2;
-  NK_TRY(nk_dev_alloc(&S->u, na));
+  for (int b = 0; b < 3; ++b) NK_TRY(nk_dev_alloc(&S->ubuf[b], na));
+  S->u = S->best_u = S->ubuf[0];
   NK_TRY(nk_dev_alloc(&S->fu, na));
   NK_TRY(nk_dev_alloc(&S->du, na));
-  NK_TRY(nk_dev_alloc(&S->best_u, na));
   if (!is_tr(S) && S->o.linesearch) {
-    NK_TRY(nk_dev_alloc(&S->u_trial, na));
     NK_TRY(nk_dev_alloc(&S->fu_trial, na));
     NK_TRY(nk_dev_alloc(&S->Jdu, na));
   }
   if (is_tr(S)) {
-    NK_TRY(nk_dev_alloc(&S->u_trial, na));
     NK_TRY(nk_dev_alloc(&S->fu_trial, na));
     NK_TRY(nk_dev_alloc(&S->du_newton, na));
     NK_TRY(nk_dev_alloc(&S->du_cauchy, na));
@@ -490,7 +503,6 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     NK_TRY(nk_dev_alloc(&S->JTfu, na));
     NK_TRY(nk_dev_alloc(&S->c1, na));
     NK_TRY(nk_dev_alloc(&S->c2, na));
-    NK_TRY(nk_dev_alloc(&S->tr_du, na));
   }
   if (concrete(S)) {
     NK_TRY(nk_problem_jac_csr(P, &S->J));
@@ -514,7 +526,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
   if (!S) return NK_OK;
   hipStreamSynchronize(S->ctx->stream);
   if (S->P) S->P->d_u_lin = nullptr;  // the vectors the problem was linearised at are about to be freed
-  double *bufs[] = {S->u, S->fu, S->du, S->best_u, S->u_trial, S->fu_trial, S->du_newton, S->du_cauchy,
+  double *bufs[] = {S->ubuf[0], S->ubuf[1], S->ubuf[2], S->fu, S->du, S->fu_trial, S->du_newton, S->du_cauchy,
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage};
   for (double *b : bufs) hipFree(b);
   nk_gmres_destroy(S->G);
@@ -529,10 +541,7 @@ static int pre_step_forcing(nk_solver *S, int iter) {
   const nk_options &o = S->o;
   if (iter == 0) {
     S->eta = o.ew_eta0;
-    NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu, slot(S, 0)));
-    double v;
-    NK_TRY(fetch(S, 1, &v));
-    S->rnorm = S->rnorm_prev = sqrt(v);
+    S->rnorm = S->rnorm_prev = S->fnorm2;  // ‖fu‖₂, reduced together with ‖fu‖∞ when the residual was evaluated
   } else {
     const double eta_prev = S->eta;
     S->eta = o.ew_gamma * pow(S->rnorm / S->rnorm_prev, o.ew_alpha);
@@ -547,7 +556,8 @@ static int pre_step_forcing(nk_solver *S, int iter) {
 }
 
 // ---- NewtonDescent.solve! : J δ = fu through GMRES, then δu = −δ  (newton.jl:121-138)
-static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacobian) {
+// negate = false leaves x (δu = −x) in du_out: the plain Newton update then runs with sign −1 and saves a pass
+static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacobian, bool negate = true) {
   S->stats.nsolve++;
   if (direct(S)) {
     // update_A!(cache, ::AbstractFactorization, A, reuse): refactorise unless the caller asked for reuse
@@ -569,7 +579,7 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
     NK_TRY(fetch(S, 2, v));
     S->last_gmres_iters = 0;
     *ok = (v[0] == v[0]) && (sqrt(v[0]) <= 1e-6 * sqrt(v[1]) + 1e-300);
-    if (!*ok) return NK_OK;
+    if (!*ok || !negate) return NK_OK;
     return nk_blas_lincomb(S->ctx, S->n, -1.0, du_out, 0.0, du_out, du_out);
   }
   nk_gmres_info info;
@@ -578,27 +588,55 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
   S->last_gmres_iters = info.iters;
   S->stats.gmres_iters += info.iters;
   *ok = !info.failed;
-  if (!*ok) return NK_OK;
+  if (!*ok || !negate) return NK_OK;
   return nk_blas_lincomb(S->ctx, S->n, -1.0, du_out, 0.0, du_out, du_out);
 }
 
-// ---- Dogleg.solve! (dogleg.jl:86-151). duJJdu = NaN ⇒ "not computed"
-static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out, bool new_jacobian) {
+// c1 = a·g ; c2 = N − c1 ; partial sums of c2·c2 and c1·c2 — the dogleg segment in one pass (dogleg.jl:136-147)
+__global__ __launch_bounds__(NK_BLOCK) void k_dogleg_segment(int64_t n, double a, const double *__restrict__ g,
+                                                             const double *__restrict__ N, double *__restrict__ c1,
+                                                             double *__restrict__ c2, double *__restrict__ partials) {
+  __shared__ double sm[8];
+  double s22 = 0.0, s12 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double x1 = a * g[i], x2 = N[i] - x1;
+    c1[i] = x1;
+    c2[i] = x2;
+    s22 += x2 * x2;
+    s12 += x1 * x2;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s22 += __shfl_xor(s22, o, 64); s12 += __shfl_xor(s12, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = s22; sm[4 + (threadIdx.x >> 6)] = s12; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  }
+}
+
+// ---- Dogleg.solve! (dogleg.jl:86-151). duJJdu = NaN ⇒ "not computed". *have_JTfu: JTfu holds Jᵀfu of this (u, fu).
+static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out, bool new_jacobian, bool *have_JTfu) {
   nk_ctx *ctx = S->ctx;
   const int64_t n = S->n;
   *duJJdu_out = NAN;
+  *have_JTfu = false;
   NK_TRY(newton_descent(S, S->du_newton, ok, new_jacobian));
   if (!*ok) return NK_OK;
   double v[4];
   NK_TRY(nk_blas_sumsq(ctx, n, S->du_newton, slot(S, 0)));
   NK_TRY(fetch(S, 1, v));
   if (sqrt(v[0]) <= S->tr) return nk_blas_copy(ctx, n, S->du_newton, S->du);
-  // δu_cauchy = −Jᵀ fu (steepest.jl:75-77)
-  NK_TRY(apply_JT(S, S->u, S->fu, S->du_cauchy));
-  NK_TRY(nk_blas_lincomb(ctx, n, -1.0, S->du_cauchy, 0.0, S->du_cauchy, S->du_cauchy));
+  // δu_cauchy = −Jᵀ fu (steepest.jl:75-77); Jᵀfu itself is what the trust-region scheme needs again for ρ
+  NK_TRY(apply_JT(S, S->u, S->fu, S->JTfu));
+  *have_JTfu = true;
+  NK_TRY(nk_blas_lincomb(ctx, n, -1.0, S->JTfu, 0.0, S->JTfu, S->du_cauchy));
   NK_TRY(apply_J(S, S->du_cauchy, S->Jdu));
-  NK_TRY(nk_blas_sumsq(ctx, n, S->du_cauchy, slot(S, 0)));
-  NK_TRY(nk_blas_sumsq(ctx, n, S->Jdu, slot(S, 1)));
+  {
+    const double *xs[2] = {S->du_cauchy, S->Jdu}, *ys[2] = {S->du_cauchy, S->Jdu};
+    NK_TRY(nk_blas_multi_reduce(ctx, n, 2, xs, ys, nullptr, nullptr, 0, 0, slot(S, 0)));
+  }
   NK_TRY(fetch(S, 2, v));
   const double l_grad = sqrt(v[0]), dJJd = v[1];
   const double d_cauchy = (l_grad * l_grad * l_grad) / dJJd;
@@ -607,10 +645,13 @@ static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out, bool new_jacobian)
     *duJJdu_out = lam * lam * dJJd;
     return nk_blas_lincomb(ctx, n, lam, S->du_cauchy, 0.0, S->du_cauchy, S->du);
   }
-  NK_TRY(nk_blas_lincomb(ctx, n, d_cauchy / l_grad, S->du_cauchy, 0.0, S->du_cauchy, S->c1));
-  NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->du_newton, -1.0, S->c1, S->c2));
-  NK_TRY(nk_blas_dot(ctx, n, S->c2, S->c2, slot(S, 0)));
-  NK_TRY(nk_blas_dot(ctx, n, S->c1, S->c2, slot(S, 1)));
+  {
+    const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS / 2);
+    NK_LAUNCH(ctx, k_dogleg_segment, dim3(grid), dim3(NK_BLOCK), n, d_cauchy / l_grad, (const double *)S->du_cauchy,
+              (const double *)S->du_newton, S->c1, S->c2, ctx->d_partials_ss);
+    NK_HIP(hipGetLastError());
+    NK_TRY(nk_blas_multi_reduce(ctx, 0, 0, nullptr, nullptr, nullptr, ctx->d_partials_ss, 2, grid, slot(S, 0)));
+  }
   NK_TRY(fetch(S, 2, v));
   const double a = v[0], b = 2.0 * v[1], c = d_cauchy * d_cauchy - S->tr * S->tr;
   const double aux = fmax(0.0, b * b - 4.0 * a * c);
@@ -619,28 +660,57 @@ static int dogleg(nk_solver *S, bool *ok, double *duJJdu_out, bool new_jacobian)
 }
 
 // ---- GenericTrustRegionSchemeCache solve! (trust_region.jl:396-514)
-static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
+// u_trial = u + du with the partial sums of Σ du² and Σ (u_trial − u)² (the latter is the stall test's displacement)
+__global__ __launch_bounds__(NK_BLOCK) void k_tr_trial(int64_t n, const double *__restrict__ u, const double *__restrict__ du,
+                                                       double *__restrict__ ut, double *__restrict__ partials) {
+  __shared__ double sm[8];
+  double sd = 0.0, ss = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double uo = u[i], d = du[i], un = uo + d, e = un - uo;
+    ut[i] = un;
+    sd += d * d;
+    ss += e * e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sd += __shfl_xor(sd, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = sd; sm[4 + (threadIdx.x >> 6)] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  }
+}
+
+// One trial-point kernel, one multi-reduction, ONE fetch: ‖f(u+δu)‖², ‖f‖², δu·Jᵀf, ‖Jδu‖² (unless the dogleg supplied it),
+// ‖f(u+δu)‖∞, ‖δu‖², ‖(u+δu) − u‖² all arrive together (the unfused form issued six two-launch reductions and a copy).
+static int tr_solve(nk_solver *S, double duJJdu, bool have_JTfu, bool *accepted, double *step_norm, double *fnew2_out) {
   nk_ctx *ctx = S->ctx;
   const int64_t n = S->n;
   const int m = S->o.radius_update_scheme;
-  NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->u, 1.0, S->du, S->u_trial));
+  S->u_trial = spare_u(S);
+  const int tgrid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS / 2);
+  NK_LAUNCH(ctx, k_tr_trial, dim3(tgrid), dim3(NK_BLOCK), n, (const double *)S->u, (const double *)S->du, S->u_trial,
+            ctx->d_partials_ss);
+  NK_HIP(hipGetLastError());
+  S->P->d_u_lin = nullptr;  // a buffer the problem may have been linearised at has new contents
   NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
   S->stats.nf++;
   const bool have = !isnan(duJJdu);
-  if (!have) {
-    NK_TRY(apply_J(S, S->du, S->Jdu));
-    NK_TRY(nk_blas_sumsq(ctx, n, S->Jdu, slot(S, 3)));
+  if (!have) NK_TRY(apply_J(S, S->du, S->Jdu));
+  if (!have_JTfu) NK_TRY(apply_JT(S, S->u, S->fu, S->JTfu));
+  double v[7];
+  {
+    const double *xs[4] = {S->fu_trial, S->fu, S->du, S->Jdu}, *ys[4] = {S->fu_trial, S->fu, S->JTfu, S->Jdu};
+    NK_TRY(nk_blas_multi_reduce(ctx, n, have ? 3 : 4, xs, ys, S->fu_trial, ctx->d_partials_ss, 2, tgrid, slot(S, 0)));
+    NK_TRY(fetch(S, (have ? 3 : 4) + 3, v));
   }
-  NK_TRY(apply_JT(S, S->u, S->fu, S->JTfu));
-  NK_TRY(nk_blas_sumsq(ctx, n, S->fu_trial, slot(S, 0)));
-  NK_TRY(nk_blas_sumsq(ctx, n, S->fu, slot(S, 1)));
-  NK_TRY(nk_blas_dot(ctx, n, S->du, S->JTfu, slot(S, 2)));
-  NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 4)));
-  NK_TRY(nk_blas_norm_inf(ctx, n, S->fu_trial, slot(S, 5)));
-  double v[6];
-  NK_TRY(fetch(S, 6, v));
+  const int o = have ? 3 : 4;  // v[o] = ‖f_trial‖∞, v[o+1] = ‖δu‖², v[o+2] = ‖u_trial − u‖²
   if (!have) duJJdu = v[3];
-  const double fnew2 = v[0], f2 = v[1], nd = sqrt(v[4]);
+  const double fnew2 = v[0], f2 = v[1], nd = sqrt(v[o + 1]);
+  const double fnew_inf = v[o];
+  *step_norm = sqrt(v[o + 2]);
+  *fnew2_out = fnew2;
   const double num = (fnew2 - f2) / 2.0, denom = v[2] + duJJdu / 2.0;
   S->rho = num / denom;
   const double rho = S->rho;
@@ -684,6 +754,7 @@ static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
         if (rho >= S->expand_thr && 2 * nd > S->tr) S->p1 = S->p3 * S->p1;
         S->shrink_counter = 0;
       }
+      S->P->d_u_lin = nullptr;
       NK_TRY(apply_JT(S, S->u_trial, S->fu_trial, S->JTfu));
       NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 0)));
       double t;
@@ -702,12 +773,13 @@ static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
     case NK_RUS_BASTIN:
       if (rho > S->step_thr) {
         // retrospective ratio with J at the trial point (trust_region.jl:490-504)
-        NK_TRY(nk_problem_jvp_dev(S->P, S->u_trial, S->tr_du, S->Jdu, nullptr));
+        S->P->d_u_lin = nullptr;
+        NK_TRY(nk_problem_jvp_dev(S->P, S->u_trial, S->du, S->Jdu, nullptr));
         NK_TRY(nk_problem_vjp_dev(S->P, S->u_trial, S->fu_trial, S->JTfu));
         NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 0)));
         NK_TRY(nk_problem_vjp_dev(S->P, S->u_trial, S->Jdu, S->JTfu));
         NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 1)));
-        NK_TRY(nk_blas_sumsq(ctx, n, S->tr_du, slot(S, 2)));
+        NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 2)));
         double t[3];
         NK_TRY(fetch(S, 3, t));
         const double rho2 = num / (t[0] + t[1] / 2.0);
@@ -722,7 +794,7 @@ static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
   }
   S->tr = fmin(S->tr, S->max_tr);
   *accepted = S->last_accepted;
-  S->fnorm_inf = S->last_accepted ? v[5] : S->fnorm_inf;
+  S->fnorm_inf = S->last_accepted ? fnew_inf : S->fnorm_inf;
   return NK_OK;
 }
 
@@ -730,6 +802,8 @@ static int tr_solve(nk_solver *S, double duJJdu, bool *accepted) {
 // sufficient decrease ϕ(α) ≤ ϕ(0) + c₁ α ϕ'(0); quadratic, then cubic interpolation, safeguarded to
 // [ρ_lo α, ρ_hi α]. Every ϕ evaluation is one residual (stats.nf += 1, as the reference's line-search cache does).
 static int ls_phi(nk_solver *S, double alpha, double *phi) {
+  S->u_trial = spare_u(S);
+  S->P->d_u_lin = nullptr;
   NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->u, alpha, S->du, S->u_trial));
   NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
   S->stats.nf++;
@@ -786,10 +860,41 @@ static int backtracking(nk_solver *S, double *alpha_out, bool *failed) {
   return NK_OK;
 }
 
+// check_and_update! (termination_conditions.jl:414-426)
+static int check_and_update(nk_solver *S, double step_norm) {
+  bool stop = false;
+  NK_TRY(tc_check(S, step_norm, &stop));
+  if (stop) {
+    S->retcode = S->tc_retcode;
+    NK_TRY(rollback_to_best(S));
+    S->force_stop = true;
+  }
+  return NK_OK;
+}
+// supports_deferred_residual (FirstOrder/src/solve.jl:303-316): only the unglobalised step, only a residual-only
+// termination mode (AbsTerminationMode / AbsNormTerminationMode, termination_conditions.jl:43-45), only without a trace
+static bool supports_deferred_residual(const nk_solver *S) {
+  if (is_tr(S) || S->o.linesearch) return false;
+  if (!(S->o.termination_mode == TM_ABS || S->o.termination_mode == TM_ABSNORM)) return false;
+  return !S->o.store_trace;
+}
+// refresh_residual! (FirstOrder/src/solve.jl:318-324)
+static int refresh_residual(nk_solver *S) {
+  if (!S->fu_deferred) return NK_OK;
+  S->fu_deferred = false;
+  NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
+  S->stats.nf++;
+  NK_TRY(residual_norms(S, nullptr, 0, nullptr));
+  return check_and_update(S, 0.0);
+}
+
 // ---- InternalAPI.step! (FirstOrder/src/solve.jl:325-465)
-static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/) {
+static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/, bool evaluate_residual = true) {
   nk_ctx *ctx = S->ctx;
   const int64_t n = S->n;
+  // the descent is taken from the residual at the iterate it starts from: settle an outstanding deferral first
+  NK_TRY(refresh_residual(S));  // (as in the reference, the step goes on even if this check terminated the solve)
+  const bool defer_residual = !evaluate_residual && supports_deferred_residual(S);
   bool new_jacobian;
   if ((recompute < 0 || recompute == 1) && S->make_new_jacobian) {
     if (concrete(S)) {
@@ -810,10 +915,12 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
   const bool has_forcing = S->o.forcing == NK_FORCING_EISENSTAT_WALKER2;
   if (has_forcing) NK_TRY(pre_step_forcing(S, S->nsteps));
 
-  bool ok = true;
+  bool ok = true, have_JTfu = false;
   double duJJdu = NAN;
-  if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu, new_jacobian));
-  else NK_TRY(newton_descent(S, S->du, &ok, new_jacobian));
+  // plain Newton step: the update takes x of J x = fu as it is (u − x), sparing the δu = −x pass
+  const bool fold_sign = !is_tr(S) && !S->o.linesearch;
+  if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu, new_jacobian, &have_JTfu));
+  else NK_TRY(newton_descent(S, S->du, &ok, new_jacobian, !fold_sign));
   if (!ok) {
     if (new_jacobian) {
       S->retcode = NK_RET_INTERNAL_LINEAR_SOLVE_FAILED;
@@ -821,31 +928,23 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       return NK_OK;
     }
     S->make_new_jacobian = true;
-    return internal_step(S, 1);
+    return internal_step(S, 1, evaluate_residual);
   }
-  if (has_forcing) {  // post_step_forcing!: ‖fu‖ BEFORE u moves (one-step lag)
+  if (has_forcing) {  // post_step_forcing!: ‖fu‖ BEFORE u moves (one-step lag) — cached with the residual's other norms
     S->rnorm_prev = S->rnorm;
-    NK_TRY(nk_blas_sumsq(ctx, n, S->fu, slot(S, 0)));
-    double v;
-    NK_TRY(fetch(S, 1, &v));
-    S->rnorm = sqrt(v);
+    S->rnorm = S->fnorm2;
   }
   S->make_new_jacobian = true;
   bool accepted = true;
   double step_norm = 0.0, du_norm = NAN;
   if (is_tr(S)) {
-    NK_TRY(nk_blas_copy(ctx, n, S->du, S->tr_du));
-    NK_TRY(tr_solve(S, duJJdu, &accepted));
-    if (accepted) {
-      // ‖u_new − u‖₂ for the stall test, then take the trial point
-      NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->u_trial, -1.0, S->u, S->c1));
-      NK_TRY(nk_blas_sumsq(ctx, n, S->c1, slot(S, 0)));
-      NK_TRY(nk_blas_copy(ctx, n, S->u_trial, S->u));
-      NK_TRY(nk_blas_copy(ctx, n, S->fu_trial, S->fu));
+    double fnew2 = 0.0;
+    NK_TRY(tr_solve(S, duJJdu, have_JTfu, &accepted, &step_norm, &fnew2));
+    if (accepted) {  // take the trial point: pointer assignments, no copies
+      S->u = S->u_trial;
+      double *t = S->fu; S->fu = S->fu_trial; S->fu_trial = t;
+      S->fnorm2 = sqrt(fnew2);
       S->u_version++;
-      double v;
-      NK_TRY(fetch(S, 1, &v));
-      step_norm = sqrt(v);
     } else {
       S->make_new_jacobian = false;
     }
@@ -865,32 +964,31 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       if (alpha != 1.0) NK_TRY(nk_blas_lincomb(ctx, n, alpha, S->du, 0.0, S->du, S->du));  // δu ← α δu, then u += δu
     }
     const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+    double *un = spare_u(S);
     {
-    nk_prof_scope prof_(ctx, NK_K_NEWTON_UPDATE, 24.0 * (double)n);
-    NK_LAUNCH(ctx, k_newton_update, dim3(grid), dim3(NK_BLOCK), n, S->du, S->u, ctx->d_partials);
-    NK_LAUNCH(ctx, k_sum_partials, dim3(1), dim3(NK_BLOCK), ctx->d_partials, grid, slot(S, 1));
+      nk_prof_scope prof_(ctx, NK_K_NEWTON_UPDATE, 24.0 * (double)n);
+      NK_LAUNCH(ctx, k_newton_update, dim3(grid), dim3(NK_BLOCK), n, fold_sign ? -1.0 : 1.0, (const double *)S->du,
+                (const double *)S->u, un, ctx->d_partials_ss);
     }
     NK_HIP(hipGetLastError());
-    NK_TRY(nk_comm_allreduce(ctx, slot(S, 1), 1, 0));
+    S->u = un;
     S->u_version++;
+    S->P->d_u_lin = nullptr;
+    if (defer_residual) {  // the driver asked for it and nothing would observe the difference: refresh_residual! pays later
+      S->fu_deferred = true;
+      return NK_OK;
+    }
     NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
     S->stats.nf++;
-    NK_TRY(nk_blas_norm_inf(ctx, n, S->fu, slot(S, 0)));
-    int cnt = 2;
-    if (S->o.store_trace) { NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 2))); cnt = 3; }
-    double v[3];
-    NK_TRY(fetch(S, cnt, v));
-    S->fnorm_inf = v[0];
-    step_norm = sqrt(v[1]);
-    if (S->o.store_trace) du_norm = sqrt(v[2]);
+    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm));  // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch
+    if (S->o.store_trace) {
+      NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
+      double v;
+      NK_TRY(fetch(S, 1, &v));
+      du_norm = sqrt(v);
+    }
   }
-  bool stop = false;
-  NK_TRY(tc_check(S, step_norm, &stop));
-  if (stop) {
-    S->retcode = S->tc_retcode;
-    NK_TRY(rollback_to_best(S));
-    S->force_stop = true;
-  }
+  NK_TRY(check_and_update(S, step_norm));
   if (S->o.store_trace) {
     nk_trace_entry e;
     memset(&e, 0, sizeof(e));
@@ -913,12 +1011,14 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
   return NK_OK;
 }
 
-extern "C" int nk_solver_step(nk_solver *S) {  // CommonSolve.step! (Base/src/solve.jl:835-859)
+// CommonSolve.step!(cache; recompute_jacobian, evaluate_residual) (Base/src/solve.jl:835-859)
+extern "C" int nk_solver_step_ex(nk_solver *S, int recompute_jacobian, int evaluate_residual) {
   NK_REQUIRE(S, "NULL argument");
+  NK_REQUIRE(recompute_jacobian >= -1 && recompute_jacobian <= 1, "recompute_jacobian must be -1 (nothing), 0 or 1");
   NK_HIP(hipSetDevice(S->ctx->device));
   if (S->force_stop || S->nsteps >= S->o.maxiters) return NK_OK;
   const auto t0 = std::chrono::steady_clock::now();
-  NK_TRY(internal_step(S, -1));
+  NK_TRY(internal_step(S, recompute_jacobian, evaluate_residual != 0));
   S->stats.nsteps++;
   S->nsteps++;
   if (S->o.maxtime > 0.0) {
@@ -931,10 +1031,24 @@ extern "C" int nk_solver_step(nk_solver *S) {  // CommonSolve.step! (Base/src/so
   return NK_OK;
 }
 
+extern "C" int nk_solver_step(nk_solver *S) { return nk_solver_step_ex(S, -1, 1); }
+extern "C" int nk_solver_supports_deferred_residual(nk_solver *S, int *yes) {
+  NK_REQUIRE(S && yes, "NULL argument");
+  *yes = supports_deferred_residual(S) ? 1 : 0;
+  return NK_OK;
+}
+extern "C" int nk_solver_refresh_residual(nk_solver *S) {
+  NK_REQUIRE(S, "NULL argument");
+  NK_HIP(hipSetDevice(S->ctx->device));
+  return refresh_residual(S);
+}
+
 extern "C" int nk_solver_solve(nk_solver *S, int *retcode) {  // _run_cache_to_completion!
   NK_REQUIRE(S, "NULL argument");
   while (!S->force_stop && S->nsteps < S->o.maxiters) NK_TRY(nk_solver_step(S));
   if (S->retcode == NK_RET_DEFAULT) S->retcode = (S->nsteps >= S->o.maxiters) ? NK_RET_MAXITERS : NK_RET_SUCCESS;
+  // a driver may have stepped with evaluate_residual = false: bring the residual forward before it is reported
+  NK_TRY(refresh_residual(S));
   NK_TRY(rollback_to_best(S));
   NK_HIP(hipStreamSynchronize(S->ctx->stream));
   if (retcode) *retcode = S->retcode;

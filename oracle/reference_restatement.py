@@ -909,8 +909,12 @@ class FirstOrderCache:
         else:
             import scipy.sparse.linalg as spla
             if new_jacobian or getattr(self, "_lu", None) is None:
-                self._lu = spla.splu(sp.csc_matrix(self.J))
                 self.stats.nfactors += 1
+                try:  # a singular / non-finite factorisation is LinearSolve's ReturnCode.Failure ⇒ success = false
+                    self._lu = spla.splu(sp.csc_matrix(self.J))
+                except RuntimeError:
+                    self._lu = None
+                    return None
             x = self._lu.solve(self.fu)
             if not np.all(np.isfinite(x)):
                 return None
@@ -1089,14 +1093,38 @@ class FirstOrderCache:
         self.ew_rnorm = L2_NORM(self.fu)
 
     # -- InternalAPI.step! (FirstOrder/src/solve.jl:325-465) + CommonSolve.step! (Base/src/solve.jl:835-859)
-    def step(self, recompute_jacobian=None):
+    def step(self, recompute_jacobian=None, evaluate_residual=True):
         if self.force_stop or self.nsteps >= self.maxiters:
             return
-        self._internal_step(recompute_jacobian)
+        self._internal_step(recompute_jacobian, evaluate_residual)
         self.stats.nsteps += 1
         self.nsteps += 1
 
-    def _internal_step(self, recompute_jacobian=None):
+    # supports_deferred_residual (FirstOrder/src/solve.jl:303-316; residual_only_termination_mode,
+    # termination_conditions.jl:43-45): unglobalised step, AbsTerminationMode / AbsNormTerminationMode, no trace
+    def supports_deferred_residual(self):
+        if self.is_tr or getattr(self.alg, "linesearch", None) is not None:
+            return False
+        if self.tc.mode not in (TM_ABS, TM_ABSNORM):
+            return False
+        return not self.store_trace
+
+    # refresh_residual! (FirstOrder/src/solve.jl:318-324)
+    def refresh_residual(self):
+        if not getattr(self, "fu_deferred", False):
+            return None
+        self.fu_deferred = False
+        self.fu = self.prob.f(self.u)
+        self.stats.nf += 1
+        if self.tc(self.fu, self.u, self.u_cache):   # check_and_update!
+            self.retcode = self.tc.retcode
+            self._rollback_to_best()
+            self.force_stop = True
+        return None
+
+    def _internal_step(self, recompute_jacobian=None, evaluate_residual=True):
+        self.refresh_residual()                      # solve.jl:333
+        defer_residual = (not evaluate_residual) and self.supports_deferred_residual()   # :336-337
         if (recompute_jacobian is None or recompute_jacobian) and self.make_new_jacobian:
             if self.concrete:
                 self.J = self.prob.jac(self.u)
@@ -1116,7 +1144,7 @@ class FirstOrderCache:
                 self.force_stop = True
                 return
             self.make_new_jacobian = True
-            return self._internal_step(True)
+            return self._internal_step(True, evaluate_residual)
         self.du = du
         if self.forcing is not None:
             self._post_step_forcing()
@@ -1143,10 +1171,13 @@ class FirstOrderCache:
                 du = alpha * du
                 self.du = du
             self.u = self.u + du         # @bb axpy!(α, δu, cache.u)
-            self.fu = self.prob.f(self.u)  # Utils.evaluate_f!
-            self.stats.nf += 1
-        # check_and_update! (termination_conditions.jl:414-426)
-        if self.tc(self.fu, self.u, self.u_cache):
+            if not defer_residual:
+                self.fu = self.prob.f(self.u)  # Utils.evaluate_f!
+                self.stats.nf += 1
+        # check_and_update! (termination_conditions.jl:414-426) — or the deferral (solve.jl:448-452)
+        if defer_residual:
+            self.fu_deferred = True
+        elif self.tc(self.fu, self.u, self.u_cache):
             self.retcode = self.tc.retcode
             self._rollback_to_best()
             self.force_stop = True
@@ -1172,6 +1203,7 @@ class FirstOrderCache:
             self.step()
         if self.retcode == DEFAULT:
             self.retcode = MAXITERS if self.nsteps >= self.maxiters else SUCCESS
+        self.refresh_residual()   # Base/src/solve.jl:376-378
         self._rollback_to_best()
         return Solution(self.u.copy(), self.fu.copy(), self.retcode, self.stats, self.trace)
 

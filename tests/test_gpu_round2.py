@@ -1,0 +1,269 @@
+"""GPU parity tests added in round 2 (through the C ABI, against the oracle):
+  * the deferred residual — step!(…; evaluate_residual = false), supports_deferred_residual, refresh_residual!
+    (lib/NonlinearSolveFirstOrder/src/solve.jl:303-340,448-452; test: misc_tests__item7.jl)
+  * the retcodes the round-1 suite never produced on the device: Stalled (step-norm stall and patience stall,
+    termination_conditions.jl:286-316), ShrinkThresholdExceeded (FirstOrder/src/solve.jl:431-435),
+    InternalLinearSolveFailed with and without the recompute-the-Jacobian retry (solve.jl:367-382)
+  * the trust-region step after its scalar work was fused (one trial-point kernel, one multi-reduction, one fetch):
+    accept/reject sequence, radii and iterates vs the oracle for every radius-update scheme."""
+import numpy as np
+import pytest
+
+from oracle import reference_restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _cubic(nls, dev, calls):
+    import torch
+
+    def f(du, u, p):
+        calls[0] += 1
+        du.copy_(u ** 3)
+
+    def jvp(Jv, v, u, p):
+        Jv.copy_(3.0 * u * u * v)
+
+    return nls.NonlinearProblem(nls.NonlinearFunction(f, jvp=jvp), torch.ones(1, dtype=torch.float64, device=dev))
+
+
+def _cubic_oracle(calls):
+    import scipy.sparse as sp
+
+    def f(u):
+        calls[0] += 1
+        return u ** 3
+    return R.FunctionProblem(f, np.array([1.0]), jac=lambda u: sp.diags(3.0 * u ** 2))
+
+
+def test_deferred_residual_offered_only_where_unobservable(nls, dev):
+    calls = [0]
+    G = nls.KrylovJL_GMRES
+    absnorm = nls.AbsNormTerminationMode()
+    assert nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=G()), termination_condition=absnorm).supports_deferred_residual()
+    assert nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=G()),
+                    termination_condition=nls.AbsTerminationMode()).supports_deferred_residual()
+    refusing = [nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=G())),
+                nls.init(_cubic(nls, dev, calls), nls.TrustRegion(linsolve=G()), termination_condition=absnorm),
+                nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=G(), linesearch=nls.BackTracking()),
+                         termination_condition=absnorm),
+                nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=G()), termination_condition=absnorm, store_trace=True)]
+    for c in refusing:
+        assert not c.supports_deferred_residual()
+        calls[0] = 0
+        assert c.refresh_residual() is None and calls[0] == 0
+
+
+def test_deferred_step_that_would_be_misread_evaluates_anyway(nls, dev):
+    calls = [0]
+    c = nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), abstol=1e-300, maxiters=40)
+    while not c.force_stop and c.nsteps < 40:
+        c.step(evaluate_residual=False)
+        c.refresh_residual()
+    assert c.nsteps == 40 and c.retcode != "Stalled"
+
+
+def test_deferred_step_skips_one_residual_and_refresh_pays_it(nls, dev):
+    calls = [0]
+    mk = lambda: nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()),  # noqa: E731
+                          termination_condition=nls.AbsNormTerminationMode())
+    c = mk()
+    calls[0] = 0
+    c.step(evaluate_residual=False)
+    assert calls[0] == 0
+    c.refresh_residual()
+    assert calls[0] == 1
+    c.refresh_residual()
+    assert calls[0] == 1
+    c2 = mk()
+    c2.solve()
+    calls[0] = 0
+    c2.step(evaluate_residual=False)
+    c2.refresh_residual()
+    assert calls[0] == 0
+
+
+def test_deferral_does_not_move_the_iterates(nls, dev):
+    calls, ocalls = [0], [0]
+    mk = lambda: nls.init(_cubic(nls, dev, calls), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()),  # noqa: E731
+                          termination_condition=nls.AbsNormTerminationMode())
+    plain, deferred = mk(), mk()
+    ref = R.init(_cubic_oracle(ocalls), R.NewtonRaphson(), termination_kwargs=dict(mode=R.TM_ABSNORM, max_stalled_steps=None),
+                 store_trace=False)
+    for _ in range(40):
+        plain.step()
+        deferred.step(evaluate_residual=False)
+        deferred.refresh_residual()
+        ref.step(evaluate_residual=False)
+        ref.refresh_residual()
+        up, ud = plain.u.cpu().numpy(), deferred.u.cpu().numpy()
+        assert np.array_equal(up, ud) and np.array_equal(plain.fu.cpu().numpy(), deferred.fu.cpu().numpy())
+        assert plain.retcode == deferred.retcode == R.RETCODE_NAMES[ref.retcode]
+        assert abs(ud[0] - ref.u[0]) <= 1e-13 and plain.nsteps == deferred.nsteps == ref.nsteps
+    assert plain.force_stop and plain.stats.nf == deferred.stats.nf == ref.stats.nf
+
+
+# ----------------------------------------------------------------------------- retcodes
+def _lying_jacobian_problem(nls, dev, fconst=None):
+    """δu = −f / 1e12: the iterate barely moves, the residual stays where it is."""
+    import torch
+
+    def f(du, u, p):
+        if fconst is None:
+            du.copy_(u * u - 2.0)
+        else:
+            du.copy_(0.0 * u + fconst + 1e-30 * u)
+
+    def jvp(Jv, v, u, p):
+        Jv.copy_(1e12 * v)
+
+    return nls.NonlinearProblem(nls.NonlinearFunction(f, jvp=jvp), torch.ones(4, dtype=torch.float64, device=dev))
+
+
+def test_stalled_by_step_norm(nls, dev):
+    """32 consecutive steps with ‖u − u_prev‖₂ ≤ abstol while ‖f‖∞ > abstol ⇒ Stalled on step 33
+    (termination_conditions.jl:303-316, default max_stalled_steps = 32)."""
+    ref = R.solve(R.FunctionProblem(lambda u: u * u - 2.0, np.ones(4), jvp=lambda v, u: 1e12 * v),
+                  R.NewtonRaphson(linsolve=R.KrylovJL_GMRES()), abstol=1e-9, maxiters=200)
+    sol = nls.solve(_lying_jacobian_problem(nls, dev), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), abstol=1e-9, maxiters=200)
+    assert sol.retcode == "Stalled" == R.RETCODE_NAMES[ref.retcode]
+    assert sol.stats.nsteps == ref.stats.nsteps == 33
+
+
+def test_stalled_by_patience(nls, dev):
+    """objective ≤ 3·abstol for more than patience_steps steps with min < 1.3·max ⇒ Stalled (termination_conditions.jl:286-301)."""
+    tk = dict(mode=0, max_stalled_steps=None, patience_steps=10)
+    ref = R.solve(R.FunctionProblem(lambda u: 0 * u + 2e-9 + 1e-30 * u, np.ones(4), jvp=lambda v, u: 1e12 * v),
+                  R.NewtonRaphson(linsolve=R.KrylovJL_GMRES()), abstol=1e-9, maxiters=300, termination_kwargs=tk)
+    sol = nls.solve(_lying_jacobian_problem(nls, dev, 2e-9), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES()), abstol=1e-9,
+                    maxiters=300, termination_kwargs=dict(max_stalled_steps=-1, patience_steps=10))
+    assert sol.retcode == "Stalled" == R.RETCODE_NAMES[ref.retcode]
+    assert sol.stats.nsteps == ref.stats.nsteps == 11
+
+
+@pytest.mark.parametrize("mst", [1, 2, 3])
+def test_shrink_threshold_exceeded(nls, dev, mst):
+    """More than max_shrink_times consecutive shrinks ⇒ ShrinkThresholdExceeded (FirstOrder/src/solve.jl:431-435)."""
+    import scipy.sparse as sp
+    import torch
+    fo = lambda u: np.arctan(5 * u) + 0.5 * np.sin(7 * u)                      # noqa: E731
+    dfo = lambda u: 5.0 / (1.0 + 25.0 * u * u) + 3.5 * np.cos(7 * u)           # noqa: E731
+    ref = R.solve(R.FunctionProblem(fo, 3 * np.ones(3), jac=lambda u: sp.diags(dfo(u))),
+                  R.TrustRegion(linsolve=R.KrylovJL_GMRES(), max_shrink_times=mst), abstol=1e-10, maxiters=100)
+
+    def f(du, u, p):
+        du.copy_(torch.atan(5 * u) + 0.5 * torch.sin(7 * u))
+
+    def jv(Jv, v, u, p):   # diagonal Jacobian: JVP and VJP coincide
+        Jv.copy_((5.0 / (1.0 + 25.0 * u * u) + 3.5 * torch.cos(7 * u)) * v)
+
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(f, jvp=jv, vjp=jv), 3 * torch.ones(3, dtype=torch.float64, device=dev))
+    sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(), max_shrink_times=mst), abstol=1e-10, maxiters=100,
+                    store_trace=True)
+    assert R.RETCODE_NAMES[ref.retcode] == "ShrinkThresholdExceeded" == sol.retcode
+    assert sol.stats.nsteps == ref.stats.nsteps
+    assert [t["accepted"] for t in sol.trace] == [t["accepted"] for t in ref.trace]
+    assert np.allclose([t["trust_region"] for t in sol.trace], [t["trust_region"] for t in ref.trace], rtol=1e-9)
+
+
+def _linear_problem(nls, dev, state):
+    """W z − b with a user `jac` into a tridiagonal jac_prototype; state['poison'] makes the callback hand out NaN."""
+    import scipy.sparse as sp
+    import torch
+    N = 12
+    W = sp.csr_matrix(sp.diags([-np.ones(N - 1), 4.0 * np.ones(N), -np.ones(N - 1)], [-1, 0, 1]))
+    bvec = np.arange(1.0, N + 1)
+    Wd, proto = nls.CSRMatrix.from_scipy(W), nls.CSRMatrix.from_scipy(W)
+    bd, wvals = torch.tensor(bvec, device=dev), torch.tensor(W.data, device=dev)
+
+    def resid(F, z, p):
+        Wd.matvec(z, out=F)
+        F.add_(0.1 * z ** 3).sub_(bd)
+
+    def jac(nzval, z, p):
+        state["jac_calls"] += 1
+        if state["poison"]:
+            nzval.fill_(float("nan"))
+            return
+        nzval.copy_(wvals)
+        # + diag(0.3 z²): the diagonal is the middle entry of each row of the tridiagonal pattern
+        dpos = torch.tensor(np.flatnonzero(W.indices == np.repeat(np.arange(N), np.diff(W.indptr))), device=dev)
+        nzval[dpos] += 0.3 * z * z
+
+    f = nls.NonlinearFunction(resid, jac=jac, jac_prototype=proto)
+    return nls.NonlinearProblem(f, torch.zeros(N, dtype=torch.float64, device=dev)), proto, W, bvec
+
+
+def _linear_oracle(W, bvec, state):
+    import scipy.sparse as sp
+
+    def jac(u):
+        state["jac_calls"] += 1
+        J = sp.csr_matrix(W + sp.diags(0.3 * u * u))
+        if state["poison"]:
+            J = J * np.nan
+        return J
+    return R.FunctionProblem(lambda u: W @ u + 0.1 * u ** 3 - bvec, np.zeros(len(bvec)), jac=jac)
+
+
+@pytest.mark.parametrize("lin", ["gmres_concrete", "direct"])
+def test_linear_solve_failure_with_fresh_jacobian_stops(nls, dev, lin):
+    """A failed linear solve on a Jacobian that was just recomputed ⇒ InternalLinearSolveFailed, force_stop (solve.jl:367-375)."""
+    st, so = dict(poison=False, jac_calls=0), dict(poison=False, jac_calls=0)
+    prob, proto, W, bvec = _linear_problem(nls, dev, st)
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), concrete_jac=True) if lin == "gmres_concrete" else nls.NewtonRaphson()
+    ralg = R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), concrete_jac=True) if lin == "gmres_concrete" else R.NewtonRaphson()
+    c, r = nls.init(prob, alg, abstol=1e-10), R.init(_linear_oracle(W, bvec, so), ralg, abstol=1e-10)
+    c.step(); r.step()
+    st["poison"] = so["poison"] = True
+    c.step(); r.step()
+    assert c.retcode == "InternalLinearSolveFailed" == R.RETCODE_NAMES[r.retcode]
+    assert c.force_stop and r.force_stop and c.nsteps == r.nsteps == 2
+    assert st["jac_calls"] == so["jac_calls"]
+
+
+@pytest.mark.parametrize("retry_works", [True, False])
+def test_linear_solve_failure_on_stale_jacobian_retries_with_a_new_one(nls, dev, retry_works):
+    """step!(…; recompute_jacobian = false) on a Jacobian that makes the linear solve fail: the step recomputes J and tries
+    again (solve.jl:376-382); only a failure on the fresh J ends the solve."""
+    st, so = dict(poison=False, jac_calls=0), dict(poison=False, jac_calls=0)
+    prob, proto, W, bvec = _linear_problem(nls, dev, st)
+    c = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), concrete_jac=True), abstol=1e-10)
+    r = R.init(_linear_oracle(W, bvec, so), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), concrete_jac=True), abstol=1e-10)
+    c.step(); r.step()
+    # spoil the STORED Jacobian (the solver keeps the user's jac_prototype object): the stale J is what fails
+    proto.set_values(np.full(proto.info()["nnz"], np.nan))
+    r.J = r.J * np.nan
+    st["poison"] = so["poison"] = not retry_works
+    n0, m0 = st["jac_calls"], so["jac_calls"]
+    c.step(recompute_jacobian=False); r.step(recompute_jacobian=False)
+    assert st["jac_calls"] - n0 == so["jac_calls"] - m0 == 1          # exactly the retry's evaluation
+    if retry_works:
+        assert c.retcode == R.RETCODE_NAMES[r.retcode] and not c.force_stop
+        assert np.max(np.abs(c.u.cpu().numpy() - r.u)) <= 1e-9
+        assert c.stats.nsolve == r.stats.nsolve == 3                   # one good solve, the failed one, the retry
+    else:
+        assert c.retcode == "InternalLinearSolveFailed" == R.RETCODE_NAMES[r.retcode] and c.force_stop
+
+
+# ----------------------------------------------------------------------------- fused trust-region step vs the oracle
+@pytest.mark.parametrize("scheme", ["Simple", "NLsolve", "NocedalWright", "Hei", "Yuan", "Fan", "Bastin"])
+@pytest.mark.parametrize("concrete", [False, True])
+def test_trust_region_fused_step_matches_oracle(nls, scheme, concrete):
+    N = 12
+    rs = getattr(nls.RadiusUpdateSchemes, scheme)
+    ro = {"Simple": R.SIMPLE, "NLsolve": R.NLSOLVE, "NocedalWright": R.NOCEDAL_WRIGHT, "Hei": R.HEI, "Yuan": R.YUAN,
+          "Fan": R.FAN, "Bastin": R.BASTIN}[scheme]
+    pb = R.Brusselator2D(N)
+    ref = R.solve(pb, R.TrustRegion(linsolve=R.KrylovJL_GMRES(maxiters=600), radius_update_scheme=ro, concrete_jac=concrete),
+                  abstol=1e-9, maxiters=60, lin_x0_zero=True)
+    P = nls.Brusselator2D(N)
+    sol = nls.solve(nls.NonlinearProblem(P, u0=P.initial_guess(device=True)),
+                    nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(maxiters=600), radius_update_scheme=rs, concrete_jac=concrete),
+                    abstol=1e-9, maxiters=60, store_trace=True)
+    assert sol.retcode == R.RETCODE_NAMES[ref.retcode]
+    k = min(len(sol.trace), len(ref.trace), 6)   # the first steps run on well-conditioned linear solves: compare them tightly
+    assert [t["accepted"] for t in sol.trace[:k]] == [t["accepted"] for t in ref.trace[:k]]
+    assert np.allclose([t["trust_region"] for t in sol.trace[:k]], [t["trust_region"] for t in ref.trace[:k]], rtol=1e-6)
+    if sol.retcode == "Success":
+        assert np.max(np.abs(np.asarray(sol.u.cpu()) - ref.u)) <= 1e-7 * max(1.0, np.max(np.abs(ref.u)))

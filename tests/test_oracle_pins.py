@@ -378,3 +378,70 @@ def test_simple_trust_region_restatement():
     # max_shrink_times: a residual with no root shrinks the region until the solver gives up
     x, fx, rc, it = R.simple_trust_region(lambda u, p: u * u + 1.0, lambda u, p: np.diag(2.0 * u), np.array([0.3]), None)
     assert rc in (R.SHRINK_EXCEEDED, R.MAXITERS)
+
+
+# ---- lib/NonlinearSolveFirstOrder/test/misc_tests__item7.jl — the deferred residual (step!(…; evaluate_residual = false),
+# supports_deferred_residual, refresh_residual!; FirstOrder/src/solve.jl:303-340,448-452)
+def _cubic_problem(calls):
+    def f(u):
+        calls[0] += 1
+        return u ** 3
+    return R.FunctionProblem(f, np.array([1.0]), jac=lambda u: sp.diags(3.0 * u ** 2))
+
+
+_ABSNORM = dict(mode=R.TM_ABSNORM, max_stalled_steps=None)
+
+
+def test_deferred_residual_offered_only_where_unobservable():
+    calls = [0]
+    mk = lambda alg, **kw: R.init(_cubic_problem(calls), alg, store_trace=False, **kw)  # noqa: E731
+    assert mk(R.NewtonRaphson(), termination_kwargs=_ABSNORM).supports_deferred_residual()
+    refusing = [mk(R.NewtonRaphson()),                                                   # default mode: stall test
+                mk(R.TrustRegion(), termination_kwargs=_ABSNORM),                        # globalised
+                mk(R.NewtonRaphson(linesearch=R.BackTracking()), termination_kwargs=_ABSNORM),
+                R.init(_cubic_problem(calls), R.NewtonRaphson(), termination_kwargs=_ABSNORM, store_trace=True)]
+    for c in refusing:
+        assert not c.supports_deferred_residual()
+        calls[0] = 0
+        assert c.refresh_residual() is None and calls[0] == 0
+
+
+def test_deferred_step_that_would_be_misread_evaluates_anyway():
+    calls = [0]
+    c = R.init(_cubic_problem(calls), R.NewtonRaphson(), abstol=0.0, maxiters=40, store_trace=False)
+    while not c.force_stop and c.nsteps < c.maxiters:
+        c.step(evaluate_residual=False)
+        c.refresh_residual()
+    assert c.nsteps == 40 and c.retcode != R.STALLED
+
+
+def test_deferred_step_skips_one_residual_and_refresh_pays_it():
+    calls = [0]
+    c = R.init(_cubic_problem(calls), R.NewtonRaphson(), termination_kwargs=_ABSNORM, store_trace=False)
+    calls[0] = 0
+    c.step(evaluate_residual=False)
+    assert calls[0] == 0
+    c.refresh_residual()
+    assert calls[0] == 1
+    c.refresh_residual()
+    assert calls[0] == 1
+    # a step that does nothing defers nothing
+    c2 = R.init(_cubic_problem(calls), R.NewtonRaphson(), termination_kwargs=_ABSNORM, store_trace=False)
+    c2.solve()
+    calls[0] = 0
+    c2.step(evaluate_residual=False)
+    c2.refresh_residual()
+    assert calls[0] == 0
+
+
+def test_deferral_does_not_move_the_iterates():
+    calls = [0]
+    plain = R.init(_cubic_problem(calls), R.NewtonRaphson(), termination_kwargs=_ABSNORM, store_trace=False)
+    deferred = R.init(_cubic_problem(calls), R.NewtonRaphson(), termination_kwargs=_ABSNORM, store_trace=False)
+    for _ in range(40):
+        plain.step()
+        deferred.step(evaluate_residual=False)
+        deferred.refresh_residual()
+        assert np.array_equal(plain.u, deferred.u) and np.array_equal(plain.fu, deferred.fu)
+        assert plain.retcode == deferred.retcode
+    assert plain.force_stop
