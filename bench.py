@@ -91,39 +91,17 @@ def timed_steps(cache, steps, barrier, dist, world, backend, torch):
 
 
 def cpu_baseline(ns, arnoldi, matfree, budget_s):
-    """The oracle's tuned CPU leg on this box's host cores (rank 0, N = 1 only): bounded sample of the same workload."""
-    import numpy as np
-    from oracle import c_oracle as CO
-    CO.build()
-    cores = CO.num_threads()
-    n = ns * ns
-    bytes_per_step = None
-    nnz = 5 * n - 4 * ns
-    b_op = (12.0 * nnz + 4.0 * (n + 1) + 16.0 * n) if not matfree else 24.0 * n
-    # DCGS2-1R: per Arnoldi step k the dot sweep reads k+2 columns, the axpy sweep reads k+2 and writes 2
-    bytes_per_step = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(arnoldi)) + 8.0 * n * (arnoldi + 3) \
-        + 8.0 * nnz + 16.0 * n + 40.0 * n
-    triad = CO.stream_triad(1 << 26, 4)
-    spmv = CO.spmv_rate(ns, 8)
-    z = np.zeros(n)
-    _, _, t1 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, 1, use_csr=not matfree, m=arnoldi)   # also places / warms
-    k = int(max(2, min(200, (0.6 * budget_s) / max(t1, 1e-4))))
-    _, fn, tk = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
-    rate = k / tk
-    CO.set_num_threads(1)
-    k1 = 1 if t1 * cores > 0.2 * budget_s else 2
-    _, _, ts = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k1, use_csr=not matfree, m=arnoldi)
-    CO.set_num_threads(cores)
-    eff = rate * bytes_per_step * 1e-9
-    return {"value": round(rate, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port",
-            "sample": f"{k} fixed-work Newton steps of the same Bratu {ns}x{ns} workload ({arnoldi} Arnoldi steps of delayed-CGS2 "
-                      f"GMRES each), oracle/nk_oracle.c::orc_bratu_newton_fast, OpenMP on {cores} threads, first-touch placement, "
-                      f"{tk:.1f} s",
-            "effective_GBs": round(eff, 1), "stream_triad_GBs": round(triad, 1),
-            "frac_of_stream_triad": round(eff / triad, 3) if triad > 0 else None,
-            "spmv_GBs": round(spmv, 1), "spmv_frac_of_triad": round(spmv / triad, 3) if triad > 0 else None,
-            "single_thread_value": round(k1 / ts, 4), "fnorm_inf_last": float(fn[-1]),
-            "note": "restatement of the reference algorithm (Julia is not installed on this box); a reported baseline, not the target"}
+    """The oracle's tuned CPU leg on this box's host cores (rank 0, N = 1 only): bounded sample of the same workload, in a
+    child process so that the OpenMP runtime starts bound to the cores and waits actively (oracle/cpu_leg.py)."""
+    env = dict(os.environ)
+    env.pop("OMP_NUM_THREADS", None)
+    env.update(OMP_PROC_BIND="close", OMP_PLACES="threads", OMP_WAIT_POLICY="active")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_leg.py"), str(ns), str(arnoldi),
+                          str(int(bool(matfree))), str(budget_s)], env=env, capture_output=True, text=True,
+                         timeout=20 * budget_s + 120)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
 
 def main():

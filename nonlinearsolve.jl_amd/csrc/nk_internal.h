@@ -227,10 +227,17 @@ struct nk_problem {
   nk_csr *user_pattern = nullptr;
   // forward-difference JVP for user problems without a jvp callback: f(u) at the linearisation point, u + εv, f(u + εv)
   double *d_fd_f0 = nullptr, *d_fd_up = nullptr, *d_fd_f1 = nullptr;
+  // operator fallbacks through the Jacobian (prepare_jvp / prepare_vjp, SciMLJacobianOperators.jl:296-362,373-431): a private
+  // copy of the jac_prototype pattern whose values are J(d_u_linJ) — filled by f.jac, or colour-compressed differences
+  nk_csr *lin_J = nullptr;
+  const double *d_u_linJ = nullptr;
   // staging buffers for host-memspace calls
   double *d_tmp[3] = {nullptr, nullptr, nullptr};
 };
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
+// forget what the problem was linearised at: the caller wrote new contents into a buffer it may have been keyed on
+static inline void nk_problem_invalidate(nk_problem *P) { P->d_u_lin = nullptr; P->d_u_linJ = nullptr; }
+int nk_csr_clone_pattern(nk_csr *A, nk_csr **out);  // same pattern and partition, own values (collective on several ranks)
 int nk_problem_jvp_prepare(nk_problem *P, const double *d_u);  // linearise at u (u must stay alive)
 int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
                        const double *d_out_scale = nullptr, const struct nk_spmv_epi *epi = nullptr);

@@ -382,6 +382,7 @@ extern "C" int nk_problem_destroy(nk_problem *P) {
   hipFree(P->d_fd_f1);
   for (double *&t : P->d_tmp) hipFree(t);
   nk_halo_free(&P->halo);
+  nk_csr_destroy(P->lin_J);
   delete P;
   return NK_OK;
 }
@@ -446,6 +447,24 @@ int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f) {
   return NK_OK;
 }
 
+// J(d_u) into the problem's private copy of the jac_prototype pattern: by f.jac when the user supplied it, otherwise by
+// colour-compressed differences of the JVP (the AutoSparse(AutoFiniteDiff) analogue) — what prepare_vjp / prepare_jvp fall
+// back to when there is no vjp / jvp (SciMLJacobianOperators.jl:307-322, 379-392; the reference's own cache is dense)
+static int user_lin_J(nk_problem *P, const double *d_u) {
+  NK_REQUIRE(P->user_pattern, "user problem has neither the operator callback nor a jac_prototype to build J from");
+  if (!P->lin_J) NK_TRY(nk_csr_clone_pattern(P->user_pattern, &P->lin_J));
+  if (P->d_u_linJ == d_u) return NK_OK;
+  if (P->cb.jac_values) {
+    if (P->cb.jac_values(P->user, d_u, P->lin_J->d_val, (void *)P->ctx->stream) != 0)
+      NK_FAIL(NK_E_CALLBACK, "jac_values callback failed");
+    P->lin_J->t_values_stale = true;
+  } else {
+    NK_TRY(nk_problem_jac_colored_dev(P, d_u, P->lin_J));
+  }
+  P->d_u_linJ = d_u;
+  return NK_OK;
+}
+
 int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
   P->d_u_lin = d_u;
   if (P->kind == NK_PROBLEM_BRATU2D) {
@@ -455,6 +474,8 @@ int nk_problem_jvp_prepare(nk_problem *P, const double *d_u) {
                          P->c_exp, d_u, P->d_diag);
     NK_HIP(hipGetLastError());
   }
+  if (P->kind == NK_PROBLEM_USER && !P->cb.jvp && P->cb.jac_values && P->user_pattern)
+    return user_lin_J(P, d_u);  // prepare_jvp's second choice: f.jac, then J·v (SciMLJacobianOperators.jl:379-392)
   if (P->kind == NK_PROBLEM_USER && !P->cb.jvp && P->n_local) {  // forward differences need f at the linearisation point
     if (!P->d_fd_f0) {
       NK_TRY(nk_dev_alloc(&P->d_fd_f0, (size_t)P->n_local + 1));
@@ -495,6 +516,12 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
   ctx->stats.op_applies++;
   if (n == 0) return NK_OK;
   if (P->kind == NK_PROBLEM_BRATU2D && (P->d_u_lin != d_u || !P->d_diag)) NK_TRY(nk_problem_jvp_prepare(P, d_u));
+  const bool jac_jvp = P->kind == NK_PROBLEM_USER && !P->cb.jvp && P->cb.jac_values && P->user_pattern;
+  if (jac_jvp) {
+    if (d_out_scale) NK_FAIL(NK_E_INVALID, "internal: output scale is not supported for callback JVPs");
+    NK_TRY(user_lin_J(P, d_u));
+    return nk_csr_spmv_dev(P->lin_J, d_v, d_jv, d_skip);
+  }
   if (P->kind == NK_PROBLEM_USER && !P->cb.jvp && (P->d_u_lin != d_u || !P->d_fd_f0)) NK_TRY(nk_problem_jvp_prepare(P, d_u));
   nk_prof_scope prof_(ctx, NK_K_JVP, 24.0 * (double)n);
   switch (P->kind) {
@@ -562,7 +589,12 @@ int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
     return NK_OK;
   }
   if (P->kind == NK_PROBLEM_USER) {
-    if (!P->cb.vjp) NK_FAIL(NK_E_UNSUPPORTED, "user problem has no vjp callback");
+    if (!P->cb.vjp) {  // prepare_vjp without f.vjp: f.jac' · v; without f.jac: the finite-difference Jacobian on the pattern
+      NK_REQUIRE(P->user_pattern, "user problem has neither a vjp callback nor a jac_prototype to build Jᵀ from "
+                                  "(prepare_vjp, SciMLJacobianOperators.jl:307-322)");
+      NK_TRY(user_lin_J(P, d_u));
+      return nk_csr_spmv_t_dev(P->lin_J, d_v, d_vj);
+    }
     if (P->cb.vjp(P->user, d_v, d_u, d_vj, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "vjp callback failed");
     return NK_OK;
   }
@@ -750,7 +782,7 @@ static int jvp_any(nk_problem *P, const double *u, const double *v, double *jv, 
   NK_TRY(stage(P, 0, u, memspace, &du));
   NK_TRY(stage(P, 1, v, memspace, &dv));
   NK_TRY(out_begin(P, 2, jv, memspace, &dj));
-  P->d_u_lin = nullptr;  // force re-linearisation: the caller's u may have changed in place
+  nk_problem_invalidate(P);  // force re-linearisation: the caller's u may have changed in place
   NK_TRY(transpose ? nk_problem_vjp_dev(P, du, dv, dj) : nk_problem_jvp_dev(P, du, dv, dj, nullptr));
   return out_end(P, jv, memspace, dj);
 }

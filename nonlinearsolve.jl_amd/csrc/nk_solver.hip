@@ -407,7 +407,7 @@ static int rollback_to_best(nk_solver *S) {
   if (S->best_u == S->u) return NK_OK;  // the last iterate is the best one: its residual is already in fu
   S->u = S->best_u;
   S->u_version++;
-  S->P->d_u_lin = nullptr;
+  nk_problem_invalidate(S->P);
   NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
   S->stats.nf++;
   return residual_norms(S, nullptr, 0, nullptr);
@@ -418,7 +418,7 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   nk_ctx *ctx = S->ctx;
   // the problem's linearisation caches (exp(u) diagonal, f(u) for forward differences) are keyed on the pointer of u:
   // u changes in place between solves, and a new solver may receive a just-freed address — start from "not linearised"
-  S->P->d_u_lin = nullptr;
+  nk_problem_invalidate(S->P);
   NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
   S->stats = nk_stats{};
   S->ctx_base.op_applies = S->ctx->stats.op_applies;
@@ -525,7 +525,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
 extern "C" int nk_solver_destroy(nk_solver *S) {
   if (!S) return NK_OK;
   hipStreamSynchronize(S->ctx->stream);
-  if (S->P) S->P->d_u_lin = nullptr;  // the vectors the problem was linearised at are about to be freed
+  if (S->P) nk_problem_invalidate(S->P);  // the vectors the problem was linearised at are about to be freed
   double *bufs[] = {S->ubuf[0], S->ubuf[1], S->ubuf[2], S->fu, S->du, S->fu_trial, S->du_newton, S->du_cauchy,
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage};
   for (double *b : bufs) hipFree(b);
@@ -693,7 +693,7 @@ static int tr_solve(nk_solver *S, double duJJdu, bool have_JTfu, bool *accepted,
   NK_LAUNCH(ctx, k_tr_trial, dim3(tgrid), dim3(NK_BLOCK), n, (const double *)S->u, (const double *)S->du, S->u_trial,
             ctx->d_partials_ss);
   NK_HIP(hipGetLastError());
-  S->P->d_u_lin = nullptr;  // a buffer the problem may have been linearised at has new contents
+  nk_problem_invalidate(S->P);  // a buffer the problem may have been linearised at has new contents
   NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
   S->stats.nf++;
   const bool have = !isnan(duJJdu);
@@ -754,7 +754,7 @@ static int tr_solve(nk_solver *S, double duJJdu, bool have_JTfu, bool *accepted,
         if (rho >= S->expand_thr && 2 * nd > S->tr) S->p1 = S->p3 * S->p1;
         S->shrink_counter = 0;
       }
-      S->P->d_u_lin = nullptr;
+      nk_problem_invalidate(S->P);
       NK_TRY(apply_JT(S, S->u_trial, S->fu_trial, S->JTfu));
       NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 0)));
       double t;
@@ -773,7 +773,7 @@ static int tr_solve(nk_solver *S, double duJJdu, bool have_JTfu, bool *accepted,
     case NK_RUS_BASTIN:
       if (rho > S->step_thr) {
         // retrospective ratio with J at the trial point (trust_region.jl:490-504)
-        S->P->d_u_lin = nullptr;
+        nk_problem_invalidate(S->P);
         NK_TRY(nk_problem_jvp_dev(S->P, S->u_trial, S->du, S->Jdu, nullptr));
         NK_TRY(nk_problem_vjp_dev(S->P, S->u_trial, S->fu_trial, S->JTfu));
         NK_TRY(nk_blas_sumsq(ctx, n, S->JTfu, slot(S, 0)));
@@ -803,7 +803,7 @@ static int tr_solve(nk_solver *S, double duJJdu, bool have_JTfu, bool *accepted,
 // [ρ_lo α, ρ_hi α]. Every ϕ evaluation is one residual (stats.nf += 1, as the reference's line-search cache does).
 static int ls_phi(nk_solver *S, double alpha, double *phi) {
   S->u_trial = spare_u(S);
-  S->P->d_u_lin = nullptr;
+  nk_problem_invalidate(S->P);
   NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->u, alpha, S->du, S->u_trial));
   NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
   S->stats.nf++;
@@ -973,7 +973,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     NK_HIP(hipGetLastError());
     S->u = un;
     S->u_version++;
-    S->P->d_u_lin = nullptr;
+    nk_problem_invalidate(S->P);
     if (defer_residual) {  // the driver asked for it and nothing would observe the difference: refresh_residual! pays later
       S->fu_deferred = true;
       return NK_OK;

@@ -1,0 +1,49 @@
+"""CPU baseline leg of bench.py (TEST INFRASTRUCTURE: runs the oracle's tuned C/OpenMP restatement on the host cores).
+
+Run as a child process so that the OpenMP runtime starts with its own environment (thread binding, active waiting) —
+`python oracle/cpu_leg.py <grid side> <arnoldi steps> <matfree 0|1> <seconds budget>` prints one JSON object."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ns, arnoldi, matfree, budget_s = int(sys.argv[1]), int(sys.argv[2]), bool(int(sys.argv[3])), float(sys.argv[4])
+    import numpy as np
+    from oracle import c_oracle as CO
+    CO.build()
+    cores = CO.num_threads()
+    n = ns * ns
+    nnz = 5 * n - 4 * ns
+    b_op = (12.0 * nnz + 4.0 * (n + 1) + 16.0 * n) if not matfree else 24.0 * n
+    # DCGS2-1R: at Arnoldi step k the dot sweep reads k+2 columns, the axpy sweep reads k+2 and writes 2; once per Newton
+    # step: x = V y, Jacobian values, update, residual
+    bytes_per_step = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(arnoldi)) + 8.0 * n * (arnoldi + 3) \
+        + 8.0 * nnz + 16.0 * n + 40.0 * n
+    triad = CO.stream_triad(1 << 26, 4)
+    spmv = CO.spmv_rate(ns, 8)
+    z = np.zeros(n)
+    _, _, t1 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, 1, use_csr=not matfree, m=arnoldi)   # also places / warms
+    k = int(max(2, min(400, (0.6 * budget_s) / max(t1, 1e-4))))
+    _, fn, tk = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
+    rate = k / tk
+    CO.set_num_threads(1)
+    k1 = 1 if t1 * cores > 0.2 * budget_s else 2
+    _, _, ts = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k1, use_csr=not matfree, m=arnoldi)
+    eff = rate * bytes_per_step * 1e-9
+    print(json.dumps({
+        "value": round(rate, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port",
+        "sample": f"{k} fixed-work Newton steps of the same Bratu {ns}x{ns} workload ({arnoldi} Arnoldi steps of delayed-CGS2 "
+                  f"GMRES each), oracle/nk_oracle.c::orc_bratu_newton_fast, OpenMP on {cores} threads "
+                  f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, first-touch placement), {tk:.1f} s",
+        "effective_GBs": round(eff, 1), "stream_triad_GBs": round(triad, 1),
+        "frac_of_stream_triad": round(eff / triad, 3) if triad > 0 else None,
+        "spmv_GBs": round(spmv, 1), "spmv_frac_of_triad": round(spmv / triad, 3) if triad > 0 else None,
+        "single_thread_value": round(k1 / ts, 4), "fnorm_inf_last": float(fn[-1]),
+        "note": "restatement of the reference algorithm (Julia is not installed on this box); a reported baseline, not the target"}))
+
+
+if __name__ == "__main__":
+    main()

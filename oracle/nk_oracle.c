@@ -714,7 +714,14 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
       }
       /* ---- GMRES(m), zero initial guess, exactly m Arnoldi steps: v_0 = f/‖f‖ */
       double s0 = 0.0;
-      for (int64_t i = lo; i < hi; ++i) s0 += f[i] * f[i];
+      {
+        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t i = lo;
+        for (; i + 8 <= hi; i += 8)
+          for (int q = 0; q < 8; ++q) s8[q] += f[i + q] * f[i + q];
+        for (; i < hi; ++i) s8[0] += f[i] * f[i];
+        s0 = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      }
       team_sum(part, stride, 1, &s0, red);
       const double beta0 = sqrt(red[0]);
       const double ib = beta0 > 0.0 ? 1.0 / beta0 : 0.0;
@@ -742,19 +749,29 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
         /* dot sweep: red = [V_jᵀu (k), u·u, V_jᵀz (k), u·z] */
         const int cnt = last ? k + 1 : 2 * k + 2;
         for (int q = 0; q < cnt; ++q) mine[q] = 0.0;
+        /* eight independent partial sums per inner product, combined in a fixed order: the compiler can keep them in vector
+         * registers without re-associating anything (a single scalar accumulator is a 4-cycle dependent-add chain per element) */
         for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
           const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
-          double a = 0.0, d = 0.0;
-          for (int64_t i = r0; i < r1; ++i) { a += uk[i] * uk[i]; if (!last) d += uk[i] * zk[i]; }
-          mine[k] += a;
-          if (!last) mine[2 * k + 1] += d;
-          if (!last || 0) {
+          const int len = (int)(r1 - r0), len8 = len & ~7;
+          const double *ut = uk + r0, *zt = zk + r0;
+          {
+            double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < len8; i += 8)
+              for (int q = 0; q < 8; ++q) { a8[q] += ut[i + q] * ut[i + q]; if (!last) d8[q] += ut[i + q] * zt[i + q]; }
+            for (int i = len8; i < len; ++i) { a8[0] += ut[i] * ut[i]; if (!last) d8[0] += ut[i] * zt[i]; }
+            mine[k] += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+            if (!last) mine[2 * k + 1] += ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
+          }
+          if (!last) {
             for (int j = 0; j < k; ++j) {
-              const double *vj = V + (size_t)j * n;
-              double ru = 0.0, rz = 0.0;
-              for (int64_t i = r0; i < r1; ++i) { ru += vj[i] * uk[i]; rz += vj[i] * zk[i]; }
-              mine[j] += ru;
-              mine[k + 1 + j] += rz;
+              const double *vj = V + (size_t)j * n + r0;
+              double u8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+              for (int i = 0; i < len8; i += 8)
+                for (int q = 0; q < 8; ++q) { u8[q] += vj[i + q] * ut[i + q]; z8[q] += vj[i + q] * zt[i + q]; }
+              for (int i = len8; i < len; ++i) { u8[0] += vj[i] * ut[i]; z8[0] += vj[i] * zt[i]; }
+              mine[j] += ((u8[0] + u8[1]) + (u8[2] + u8[3])) + ((u8[4] + u8[5]) + (u8[6] + u8[7]));
+              mine[k + 1 + j] += ((z8[0] + z8[1]) + (z8[2] + z8[3])) + ((z8[4] + z8[5]) + (z8[6] + z8[7]));
             }
           }
         }

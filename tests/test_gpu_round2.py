@@ -262,8 +262,12 @@ def test_trust_region_fused_step_matches_oracle(nls, scheme, concrete):
                     nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(maxiters=600), radius_update_scheme=rs, concrete_jac=concrete),
                     abstol=1e-9, maxiters=60, store_trace=True)
     assert sol.retcode == R.RETCODE_NAMES[ref.retcode]
-    k = min(len(sol.trace), len(ref.trace), 6)   # the first steps run on well-conditioned linear solves: compare them tightly
+    k = min(len(sol.trace), len(ref.trace), 6)
     assert [t["accepted"] for t in sol.trace[:k]] == [t["accepted"] for t in ref.trace[:k]]
-    assert np.allclose([t["trust_region"] for t in sol.trace[:k]], [t["trust_region"] for t in ref.trace[:k]], rtol=1e-6)
+    # radii are compared tightly while the residual is far above the inner solves' tolerance; close to convergence the
+    # schemes that take the radius from ‖Jᵀf(u_trial)‖ or ‖f(u_trial)‖ (Yuan, Fan) inherit the GMRES tolerance (1e-3 relative)
+    for a, b in zip(sol.trace[:k], ref.trace[:k]):
+        tol = 1e-6 if b["fnorm_inf"] > 1e-4 else 2e-2
+        assert abs(a["trust_region"] - b["trust_region"]) <= tol * abs(b["trust_region"]), (scheme, a, b)
     if sol.retcode == "Success":
         assert np.max(np.abs(np.asarray(sol.u.cpu()) - ref.u)) <= 1e-7 * max(1.0, np.max(np.abs(ref.u)))
