@@ -283,16 +283,21 @@ int nk_partition_range(int64_t n_global, int64_t granule, int nranks, int rank,
 int nk_csr_create(nk_ctx *ctx, int64_t nrows_local, int64_t n_global, int64_t row_begin, int64_t nnz,
                   int index_bits, int index_base, const void *rowptr, const void *colind,
                   const double *vals, int memspace, nk_csr **out);
-/* Julia's SparseMatrixCSC{Float64,Int} (colptr,rowval,nzval): converts CSC→CSR once on the host.
- * Single-rank only. */
+/* Julia's SparseMatrixCSC{Float64,Int} (colptr,rowval,nzval) of the WHOLE n × n matrix, as every rank holds it:
+ * converts CSC→CSR once on the host and keeps this rank's row range (nk_partition_range with granule 1, or the
+ * explicit range of the _rows form — whole grid lines for stencil problems). Collective on several ranks. */
 int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
                            const void *colptr, const void *rowval, const double *nzval, nk_csr **out);
+int nk_csr_create_from_csc_rows(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
+                                const void *colptr, const void *rowval, const double *nzval,
+                                int64_t row_begin, int64_t nrows_local, nk_csr **out);
 int nk_csr_destroy(nk_csr *A);
 int nk_csr_set_values(nk_csr *A, const double *vals, int memspace);
 int nk_csr_get_values(nk_csr *A, double *vals, int memspace);
 int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, int64_t *nnz, int64_t *n_halo);
 double *nk_csr_values_device(nk_csr *A);      /* device pointer of the local values (nnz doubles) */
-/* y = A x  (x, y local slices; halo exchanged internally).  nk_spmv_t: y = Aᵀ x. */
+/* y = A x  (x, y local slices; halo exchanged internally).  nk_spmv_t: y = Aᵀ x (the contributions to entries other
+ * ranks own return through the halo plan in reverse and are added in rank order: bitwise reproducible). */
 int nk_spmv(nk_csr *A, const double *x, double *y, int memspace);
 int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace);
 

@@ -110,6 +110,7 @@ SIGNATURES = {
     "nk_partition_range": (_I, [_L, _L, _I, _I, C.POINTER(_L), C.POINTER(_L)]),
     "nk_csr_create": (_I, [_P, _L, _L, _L, _L, _I, _I, _P, _P, _P, _I, _PP]),
     "nk_csr_create_from_csc": (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _PP]),
+    "nk_csr_create_from_csc_rows": (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _L, _L, _PP]),
     "nk_csr_destroy": (_I, [_P]),
     "nk_csr_set_values": (_I, [_P, _P, _I]),
     "nk_csr_get_values": (_I, [_P, _P, _I]),

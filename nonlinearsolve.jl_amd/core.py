@@ -237,16 +237,23 @@ class CSRMatrix:
         return cls.from_arrays(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, ctx=ctx)
 
     @classmethod
-    def from_csc(cls, colptr, rowval, nzval, index_base=1, ctx=None):
-        """Julia's SparseMatrixCSC fields (1-based Int64 by default)."""
+    def from_csc(cls, colptr, rowval, nzval, index_base=1, ctx=None, row_range=None):
+        """Julia's SparseMatrixCSC fields (1-based Int64 by default) of the whole matrix; on several ranks this rank keeps
+        `row_range = (begin, end)` (default: the library's contiguous partition)."""
         ctx = ctx or default_context()
         colptr = np.ascontiguousarray(colptr, dtype=np.int64)
         rowval = np.ascontiguousarray(rowval, dtype=np.int64)
         nz = np.ascontiguousarray(nzval, dtype=np.float64)
         h = C.c_void_p()
-        check(L.lib().nk_csr_create_from_csc(ctx._h, colptr.size - 1, rowval.size, 64, index_base,
-                                             C.c_void_p(colptr.ctypes.data), C.c_void_p(rowval.ctypes.data),
-                                             C.c_void_p(nz.ctypes.data), C.byref(h)))
+        if row_range is None:
+            check(L.lib().nk_csr_create_from_csc(ctx._h, colptr.size - 1, rowval.size, 64, index_base,
+                                                 C.c_void_p(colptr.ctypes.data), C.c_void_p(rowval.ctypes.data),
+                                                 C.c_void_p(nz.ctypes.data), C.byref(h)))
+        else:
+            check(L.lib().nk_csr_create_from_csc_rows(ctx._h, colptr.size - 1, rowval.size, 64, index_base,
+                                                      C.c_void_p(colptr.ctypes.data), C.c_void_p(rowval.ctypes.data),
+                                                      C.c_void_p(nz.ctypes.data), int(row_range[0]),
+                                                      int(row_range[1] - row_range[0]), C.byref(h)))
         return cls(h, ctx)
 
     def info(self):

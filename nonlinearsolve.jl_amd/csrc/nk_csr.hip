@@ -175,7 +175,7 @@ static void build_rowblocks(const std::vector<int32_t> &rowptr, std::vector<int3
 
 int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
                         const std::vector<int32_t> &rowptr, const std::vector<int64_t> &gcol,
-                        const double *vals_host, nk_csr **out) {
+                        const double *vals_host, nk_csr **out, bool local_only) {
   const int64_t nnz = (int64_t)gcol.size();
   NK_REQUIRE(nnz < (1ll << 31) && nrows < (1ll << 31), "local CSR too large for int32 indices");
   nk_csr *A = new nk_csr();
@@ -199,7 +199,7 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   }
   std::sort(halo.begin(), halo.end());
   halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-  if (ctx->nranks == 1 && !halo.empty()) {
+  if ((ctx->nranks == 1 || local_only) && !halo.empty()) {
     NK_FAIL(NK_E_INVALID, "single-rank CSR must be square: column outside the local row range");
   }
   A->halo_gcols = halo;
@@ -266,7 +266,7 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   else if (nnz) NK_HIP(hipMemset(A->d_val, 0, nnz * sizeof(double)));
 
   // ---- halo plan (collective): tell every owner which of its entries we need
-  if (ctx->nranks > 1) {
+  if (ctx->nranks > 1 && !local_only) {
     const int P = ctx->nranks;
     // 1. everyone learns all row ranges: all-reduce a zero vector with our begin in slot `rank`
     std::vector<double> hb(P + 1, 0.0);
@@ -388,11 +388,17 @@ extern "C" int nk_csr_create(nk_ctx *ctx, int64_t nrows_local, int64_t n_global,
   return nk_csr_create_local(ctx, nrows_local, n_global, row_begin, rp32, gc, vv, out);
 }
 
-extern "C" int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
-                                      const void *colptr, const void *rowval, const double *nzval, nk_csr **out) {
+// Julia's SparseMatrixCSC fields as they are (1-based Int64 colptr / rowval / nzval of the WHOLE n × n matrix, present on
+// every rank): this rank keeps the rows [row_begin, row_begin + nrows_local) as its CSR slice; columns stay global and the
+// halo plan is built collectively, exactly as for nk_csr_create.
+extern "C" int nk_csr_create_from_csc_rows(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
+                                           const void *colptr, const void *rowval, const double *nzval,
+                                           int64_t row_begin, int64_t nrows_local, nk_csr **out) {
   NK_REQUIRE(ctx && colptr && rowval && out, "NULL argument");
-  NK_REQUIRE(ctx->nranks == 1, "nk_csr_create_from_csc is single-rank only");
   NK_REQUIRE(index_bits == 32 || index_bits == 64, "index_bits must be 32 or 64");
+  NK_REQUIRE(row_begin >= 0 && nrows_local >= 0 && row_begin + nrows_local <= n, "bad row range");
+  NK_REQUIRE(ctx->nranks > 1 || (row_begin == 0 && nrows_local == n), "a single rank owns every row");
+  NK_HIP(hipSetDevice(ctx->device));
   std::vector<int64_t> cp, rv;
   if (index_bits == 32) {
     widen_indices<int32_t>(colptr, n + 1, index_base, cp);
@@ -402,22 +408,33 @@ extern "C" int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int i
     widen_indices<int64_t>(rowval, nnz, index_base, rv);
   }
   NK_REQUIRE(cp[0] == 0 && cp[n] == nnz, "colptr does not span [0, nnz]");
-  std::vector<int32_t> rp(n + 1, 0);
+  const int64_t lo = row_begin, hi = row_begin + nrows_local;
+  std::vector<int32_t> rp(nrows_local + 1, 0);
+  int64_t nloc = 0;
   for (int64_t k = 0; k < nnz; ++k) {
     NK_REQUIRE(rv[k] >= 0 && rv[k] < n, "row index out of range");
-    rp[rv[k] + 1]++;
+    if (rv[k] >= lo && rv[k] < hi) { rp[rv[k] - lo + 1]++; ++nloc; }
   }
-  for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
-  std::vector<int64_t> gc(nnz);
-  std::vector<double> vals(nnz, 0.0);
+  for (int64_t i = 0; i < nrows_local; ++i) rp[i + 1] += rp[i];
+  std::vector<int64_t> gc(nloc);
+  std::vector<double> vals(nloc, 0.0);
   std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
   for (int64_t c = 0; c < n; ++c)
     for (int64_t k = cp[c]; k < cp[c + 1]; ++k) {
-      const int32_t pos = fill[rv[k]]++;
+      if (rv[k] < lo || rv[k] >= hi) continue;
+      const int32_t pos = fill[rv[k] - lo]++;
       gc[pos] = c;  // columns ascend within each row because c ascends
       if (nzval) vals[pos] = nzval[k];
     }
-  return nk_csr_create_local(ctx, n, n, 0, rp, gc, nzval ? vals.data() : nullptr, out);
+  return nk_csr_create_local(ctx, nrows_local, n, row_begin, rp, gc, nzval ? vals.data() : nullptr, out);
+}
+// the same with the library's default partition (contiguous row ranges, nk_partition_range with granule 1)
+extern "C" int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
+                                      const void *colptr, const void *rowval, const double *nzval, nk_csr **out) {
+  NK_REQUIRE(ctx, "NULL argument");
+  int64_t b = 0, e = n;
+  NK_TRY(nk_partition_range(n, 1, ctx->nranks, ctx->rank, &b, &e));
+  return nk_csr_create_from_csc_rows(ctx, n, nnz, index_bits, index_base, colptr, rowval, nzval, b, e - b, out);
 }
 
 extern "C" int nk_csr_destroy(nk_csr *A) {
@@ -428,6 +445,8 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_val);
   hipFree(A->d_rowblocks);
   hipFree(A->d_tperm);
+  hipFree(A->d_tz);
+  hipFree(A->d_trecv);
   hipFree(A->d_role);
   hipFree(A->d_node);
   hipFree(A->d_xtmp);
@@ -512,20 +531,40 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   return NK_OK;
 }
 
-// ----------------------------------------------------------------------------- transpose (single rank)
+// same pattern, partition and halo plan, own (zeroed) values
+int nk_csr_clone_pattern(nk_csr *A, nk_csr **out) {
+  NK_REQUIRE(A && out, "NULL argument");
+  std::vector<int64_t> gc((size_t)A->nnz);
+  for (int64_t k = 0; k < A->nnz; ++k) {
+    const int32_t c = A->h_col[k];
+    gc[k] = c < A->nrows ? A->row_begin + c : A->halo_gcols[c - A->nrows];
+  }
+  return nk_csr_create_local(A->ctx, A->nrows, A->n_global, A->row_begin, A->h_rowptr, gc, nullptr, out);
+}
+
+// ----------------------------------------------------------------------------- transpose
+// y = Aᵀ x for a row-partitioned A (steepest.jl:75-77, trust_region.jl:410 need Jᵀ fu with a concrete J). The local block
+// [owned | halo] is transposed as a whole: T = blockᵀ has nrows + n_halo rows. Its first nrows outputs are this rank's
+// own contributions to y; the others belong to entries the neighbours own and travel back through the halo plan in
+// reverse (what a rank receives in the forward exchange it now sends, and vice versa). The owners add them to y peer by
+// peer in rank order — a fixed order, so the result is bitwise reproducible.
 __global__ __launch_bounds__(NK_BLOCK) void k_permute_vals(int64_t nnz, const int32_t *__restrict__ perm,
                                                            const double *__restrict__ src, double *__restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
   if (i < nnz) dst[i] = src[perm[i]];
 }
+__global__ __launch_bounds__(NK_BLOCK) void k_scatter_add(int64_t n, const int32_t *__restrict__ idx,
+                                                          const double *__restrict__ v, double *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) y[idx[i]] += v[i];  // a peer asks for each entry at most once: no two lanes share a target
+}
 
 static int build_transpose(nk_csr *A) {
-  NK_REQUIRE(A->ctx->nranks == 1, "transposed SpMV on an assembled CSR is single-rank only (use the matrix-free VJP)");
-  const int64_t n = A->nrows, nnz = A->nnz;
-  std::vector<int32_t> rp(n + 1, 0), perm(nnz);
+  const int64_t n = A->nrows, nnz = A->nnz, nh = (int64_t)A->halo_gcols.size(), nt = n + nh;
+  std::vector<int32_t> rp(nt + 1, 0), perm(nnz);
   std::vector<int64_t> gc(nnz);
   for (int64_t k = 0; k < nnz; ++k) rp[A->h_col[k] + 1]++;
-  for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+  for (int64_t i = 0; i < nt; ++i) rp[i + 1] += rp[i];
   std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
   for (int64_t r = 0; r < n; ++r)
     for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k) {
@@ -533,22 +572,56 @@ static int build_transpose(nk_csr *A) {
       gc[pos] = r;
       perm[pos] = k;
     }
-  NK_TRY(nk_csr_create_local(A->ctx, n, n, 0, rp, gc, nullptr, &A->T));
+  NK_TRY(nk_csr_create_local(A->ctx, nt, nt, 0, rp, gc, nullptr, &A->T, true));
   NK_TRY(nk_dev_alloc(&A->d_tperm, (size_t)nnz));
   if (nnz) NK_HIP(hipMemcpy(A->d_tperm, perm.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nh) {
+    NK_TRY(nk_dev_alloc(&A->d_tz, (size_t)nt + 1));
+    NK_TRY(nk_dev_alloc(&A->d_trecv, (size_t)A->halo.n_send + 1));
+  }
   A->t_values_stale = true;
   return NK_OK;
 }
 
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y) {
+  nk_ctx *ctx = A->ctx;
   if (!A->T) NK_TRY(build_transpose(A));
   if (A->t_values_stale && A->nnz) {
     const int grid = (int)((A->nnz + NK_BLOCK - 1) / NK_BLOCK);
-    NK_LAUNCH(A->ctx, k_permute_vals, dim3(grid), dim3(NK_BLOCK), A->nnz, A->d_tperm, A->d_val,
-                       A->T->d_val);
+    NK_LAUNCH(ctx, k_permute_vals, dim3(grid), dim3(NK_BLOCK), A->nnz, A->d_tperm, A->d_val, A->T->d_val);
     A->t_values_stale = false;
   }
-  return nk_csr_spmv_dev(A->T, d_x, d_y, nullptr);
+  const int64_t n = A->nrows, nh = (int64_t)A->halo_gcols.size();
+  if (nh == 0 && A->halo.n_send == 0) return nk_csr_spmv_dev(A->T, d_x, d_y, nullptr);
+  // T x: (n + nh) outputs. (T's SpMV reads x as a vector of n + nh entries only through its column ids, all < n.)
+  if (nh) {
+    NK_TRY(nk_csr_spmv_dev(A->T, d_x, A->d_tz, nullptr));
+    NK_TRY(nk_blas_copy(ctx, n, A->d_tz, d_y));
+  } else {
+    NK_TRY(nk_csr_spmv_dev(A->T, d_x, d_y, nullptr));
+  }
+  // reverse exchange: my halo slots (grouped by owner, rank order) go to their owners; theirs arrive in my send layout
+  const int P = ctx->nranks;
+  nk_halo &H = A->halo;
+  std::vector<int64_t> so(P), sb(P), ro(P), rb(P);
+  for (int p = 0; p < P; ++p) {
+    so[p] = H.recv_off[p] * 8;
+    sb[p] = (p == ctx->rank) ? 0 : H.recv_cnt[p] * 8;
+    ro[p] = H.send_off[p] * 8;
+    rb[p] = (p == ctx->rank) ? 0 : H.send_cnt[p] * 8;
+  }
+  if (!A->d_trecv && H.n_send) NK_TRY(nk_dev_alloc(&A->d_trecv, (size_t)H.n_send + 1));
+  ctx->stats.halo_exchanges++;
+  NK_TRY(nk_comm_alltoallv(ctx, nh ? (const void *)(A->d_tz + n) : (const void *)d_y, so.data(), sb.data(), A->d_trecv,
+                           ro.data(), rb.data()));
+  for (int p = 0; p < P; ++p) {  // owners accumulate peer by peer, in rank order
+    const int64_t c = (p == ctx->rank) ? 0 : H.send_cnt[p];
+    if (c == 0) continue;
+    NK_LAUNCH(ctx, k_scatter_add, dim3((unsigned)((c + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), c,
+              (const int32_t *)H.d_send_idx + H.send_off[p], (const double *)A->d_trecv + H.send_off[p], d_y);
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
 }
 
 static int stage_in(nk_csr *A, const double *x, int memspace, const double **dx) {

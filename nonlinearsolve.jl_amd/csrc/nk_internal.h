@@ -186,10 +186,12 @@ struct nk_csr {
   std::vector<int64_t> halo_gcols;  // global column of each halo slot
   // host copies of the pattern (needed for transpose / banded LU / colouring)
   std::vector<int32_t> h_rowptr, h_col;
-  // lazily built transpose (single rank)
+  // lazily built transpose of the local block: (nrows + n_halo) × nrows — rows ≥ nrows collect the contributions to
+  // entries other ranks own, which the reverse halo exchange returns to their owners (nk_csr_spmv_t_dev)
   nk_csr *T = nullptr;
   int32_t *d_tperm = nullptr;
   bool t_values_stale = true;
+  double *d_tz = nullptr, *d_trecv = nullptr;  // T·x (nrows + n_halo) and what the peers sent back (n_send)
   // column colouring of the pattern (structurally orthogonal columns), built on first use by coloured assembly
   int ncolors = 0;
   int32_t *d_color = nullptr, *d_nnzcolor = nullptr;
@@ -203,9 +205,11 @@ struct nk_csr {
 int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr,
                     const nk_spmv_epi *epi = nullptr);
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
+// local_only: every column is a local index already (rectangular helper matrices such as the transposed local block):
+// no halo plan is built, i.e. the call is NOT collective
 int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
                         const std::vector<int32_t> &rowptr, const std::vector<int64_t> &gcol,
-                        const double *vals_host, nk_csr **out);
+                        const double *vals_host, nk_csr **out, bool local_only = false);
 
 // ----------------------------------------------------------------------------- problems
 struct nk_problem {

@@ -820,25 +820,25 @@ __global__ __launch_bounds__(NK_BLOCK) void k_decompress(int64_t nrows, const in
     if (colcolor_of_nnz[p] == c) vals[p] = Bc[r];
 }
 
-// greedy distance-2 column colouring on the host pattern, natural order (columns sharing a row get different
-// colours) — SparseMatrixColorings' GreedyColoringAlgorithm() default, [EXT]; computed once per pattern.
-static int csr_ensure_coloring(nk_csr *J) {
-  if (J->ncolors > 0) return NK_OK;
-  const int64_t n = J->nrows, ncols = J->n_global;
-  NK_REQUIRE(J->ctx->nranks == 1 && J->halo_gcols.empty(), "coloured assembly is single-rank in this round");
-  std::vector<int32_t> cnt(ncols + 1, 0);
-  for (int64_t p = 0; p < J->nnz; ++p) cnt[J->h_col[p] + 1]++;
-  for (int64_t c = 0; c < ncols; ++c) cnt[c + 1] += cnt[c];
-  std::vector<int32_t> rows_of_col(J->nnz), fillp(cnt.begin(), cnt.end() - 1);
+// greedy distance-2 column colouring, natural order (columns sharing a row get different colours) —
+// SparseMatrixColorings' GreedyColoringAlgorithm() default, [EXT]. rp/col: a square pattern with n rows.
+static int greedy_column_coloring(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &col,
+                                  std::vector<int32_t> &color) {
+  const int64_t nnz = (int64_t)col.size();
+  std::vector<int32_t> cnt(n + 1, 0);
+  for (int64_t p = 0; p < nnz; ++p) cnt[col[p] + 1]++;
+  for (int64_t c = 0; c < n; ++c) cnt[c + 1] += cnt[c];
+  std::vector<int32_t> rows_of_col(nnz), fillp(cnt.begin(), cnt.end() - 1);
   for (int64_t r = 0; r < n; ++r)
-    for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) rows_of_col[fillp[J->h_col[p]]++] = (int32_t)r;
-  std::vector<int32_t> color(ncols, -1), mark(ncols + 1, -1);
+    for (int32_t p = rp[r]; p < rp[r + 1]; ++p) rows_of_col[fillp[col[p]]++] = (int32_t)r;
+  color.assign(n, -1);
+  std::vector<int32_t> mark(n + 1, -1);
   int ncolors = 0;
-  for (int64_t c = 0; c < ncols; ++c) {
+  for (int64_t c = 0; c < n; ++c) {
     for (int32_t q = cnt[c]; q < cnt[c + 1]; ++q) {
       const int32_t r = rows_of_col[q];
-      for (int32_t p = J->h_rowptr[r]; p < J->h_rowptr[r + 1]; ++p) {
-        const int32_t oc = color[J->h_col[p]];
+      for (int32_t p = rp[r]; p < rp[r + 1]; ++p) {
+        const int32_t oc = color[col[p]];
         if (oc >= 0) mark[oc] = (int32_t)c;
       }
     }
@@ -847,14 +847,80 @@ static int csr_ensure_coloring(nk_csr *J) {
     color[c] = k;
     if (k + 1 > ncolors) ncolors = k + 1;
   }
+  return ncolors;
+}
+
+// the WHOLE pattern of a built-in grid problem in the internal global numbering (every rank can write it down): what a
+// row-partitioned run colours, so that all ranks agree on the colour of every column without communication
+static int grid_global_pattern(const nk_problem *P, std::vector<int32_t> &rp, std::vector<int32_t> &col) {
+  const int R = P->ctx->nranks;
+  const int64_t N = P->ns;
+  rp.clear();
+  col.clear();
+  if (P->kind == NK_PROBLEM_BRATU2D) {
+    for (int64_t j = 0; j < N; ++j)
+      for (int64_t i = 0; i < N; ++i) {
+        const int64_t k = j * N + i;
+        rp.push_back((int32_t)col.size());
+        if (j > 0) col.push_back((int32_t)(k - N));
+        if (i > 0) col.push_back((int32_t)(k - 1));
+        col.push_back((int32_t)k);
+        if (i < N - 1) col.push_back((int32_t)(k + 1));
+        if (j < N - 1) col.push_back((int32_t)(k + N));
+      }
+    rp.push_back((int32_t)col.size());
+    return NK_OK;
+  }
+  if (P->kind == NK_PROBLEM_BRUSSELATOR2D) {
+    for (int p = 0; p < R; ++p) {  // rows in the order of their internal ids: rank, species, grid line, point
+      const int64_t b = N * p / R, e = N * (p + 1) / R;
+      for (int s = 0; s < 2; ++s)
+        for (int64_t j = b; j < e; ++j)
+          for (int64_t i = 0; i < N; ++i) {
+            const int64_t ip1 = (i + 1 == N) ? 0 : i + 1, im1 = (i == 0) ? N - 1 : i - 1;
+            const int64_t jp1 = (j + 1 == N) ? 0 : j + 1, jm1 = (j == 0) ? N - 1 : j - 1;
+            int64_t c[6] = {grid_gidx(N, 2, R, im1, j, s), grid_gidx(N, 2, R, ip1, j, s), grid_gidx(N, 2, R, i, jp1, s),
+                            grid_gidx(N, 2, R, i, jm1, s), grid_gidx(N, 2, R, i, j, s), grid_gidx(N, 2, R, i, j, 1 - s)};
+            std::sort(c, c + 6);
+            rp.push_back((int32_t)col.size());
+            for (int t = 0; t < 6; ++t)
+              if (t == 0 || c[t] != c[t - 1]) col.push_back((int32_t)c[t]);
+          }
+    }
+    rp.push_back((int32_t)col.size());
+    return NK_OK;
+  }
+  NK_FAIL(NK_E_UNSUPPORTED, "coloured assembly on several ranks needs a built-in grid problem (the pattern of a user problem "
+                            "is only known slice by slice)");
+}
+
+// column colours of J's local index space [owned | halo], computed once per pattern
+static int csr_ensure_coloring(nk_problem *P, nk_csr *J) {
+  if (J->ncolors > 0) return NK_OK;
+  const int64_t n = J->nrows, nloc = n + (int64_t)J->halo_gcols.size();
+  std::vector<int32_t> color_loc(nloc > 0 ? nloc : 1, 0);
+  int ncolors = 0;
+  if (J->ctx->nranks == 1) {
+    std::vector<int32_t> color;
+    ncolors = greedy_column_coloring(n, J->h_rowptr, J->h_col, color);
+    for (int64_t c = 0; c < n; ++c) color_loc[c] = color[c];
+  } else {
+    NK_REQUIRE(P->n_global < (1ll << 31), "pattern too large for a 32-bit colouring");
+    std::vector<int32_t> rp, col, color;
+    NK_TRY(grid_global_pattern(P, rp, col));
+    NK_REQUIRE((int64_t)rp.size() - 1 == J->n_global, "pattern/problem size mismatch");
+    ncolors = greedy_column_coloring(J->n_global, rp, col, color);
+    for (int64_t c = 0; c < n; ++c) color_loc[c] = color[J->row_begin + c];
+    for (size_t h = 0; h < J->halo_gcols.size(); ++h) color_loc[n + h] = color[J->halo_gcols[h]];
+  }
   std::vector<int32_t> nnzcolor(J->nnz);
-  for (int64_t p = 0; p < J->nnz; ++p) nnzcolor[p] = color[J->h_col[p]];
-  NK_TRY(nk_dev_alloc(&J->d_color, (size_t)ncols + 1));
+  for (int64_t p = 0; p < J->nnz; ++p) nnzcolor[p] = color_loc[J->h_col[p]];
+  NK_TRY(nk_dev_alloc(&J->d_color, (size_t)n + 1));
   NK_TRY(nk_dev_alloc(&J->d_nnzcolor, (size_t)J->nnz + 1));
-  NK_TRY(nk_dev_alloc(&J->d_seed, (size_t)ncols + 1));
+  NK_TRY(nk_dev_alloc(&J->d_seed, (size_t)n + 1));
   NK_TRY(nk_dev_alloc(&J->d_B, (size_t)n + 1));
-  NK_HIP(hipMemcpy(J->d_color, color.data(), ncols * sizeof(int32_t), hipMemcpyHostToDevice));
-  NK_HIP(hipMemcpy(J->d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n) NK_HIP(hipMemcpy(J->d_color, color_loc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (J->nnz) NK_HIP(hipMemcpy(J->d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
   J->ncolors = ncolors;
   return NK_OK;
 }
@@ -862,7 +928,7 @@ static int csr_ensure_coloring(nk_csr *J) {
 int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J) {
   nk_ctx *ctx = P->ctx;
   NK_REQUIRE(J->nrows == P->n_local && J->n_global == P->n_global, "pattern/problem size mismatch");
-  NK_TRY(csr_ensure_coloring(J));
+  NK_TRY(csr_ensure_coloring(P, J));
   const int64_t n = J->nrows;
   NK_TRY(nk_problem_jvp_prepare(P, d_u));  // the caller's u may have changed in place
   for (int c = 0; c < J->ncolors; ++c) {

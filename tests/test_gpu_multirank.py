@@ -136,6 +136,35 @@ def _worker(rank, world, port, q):
                          abstol=1e-8, maxiters=25)
         assert solb.retcode == "Success" and solb.stats.nsteps == refb.stats.nsteps
         assert np.max(np.abs(solb.u.cpu().numpy() - refb.u[idx])) <= 1e-7
+
+        # ---------------- distributed transposed SpMV: the contributions to entries the other rank owns come back through
+        # the halo plan in reverse (steepest.jl:75-77 / trust_region.jl:410 with a concrete J on several ranks)
+        assert np.allclose(J.rmatvec(vl).cpu().numpy(), (pb.jac(u).T @ v)[b:e], rtol=1e-13, atol=1e-11)
+        Jfull = rb_.jac(ub).tocsr()
+        want = (Jfull.T @ vb)[idx]
+        assert np.allclose(JB.rmatvec(vbl).cpu().numpy(), want, rtol=1e-12, atol=1e-8)
+        assert torch.equal(JB.rmatvec(vbl), JB.rmatvec(vbl))           # fixed accumulation order: bitwise reproducible
+        # ---------------- Julia's SparseMatrixCSC of the whole matrix, ingested slice by slice (collective)
+        Jc = pb.jac(u).tocsc()
+        Jcsc = nls.CSRMatrix.from_csc(Jc.indptr + 1, Jc.indices + 1, Jc.data, index_base=1, row_range=(b, e))
+        assert Jcsc.info()["nrows_local"] == e - b and Jcsc.info()["n_halo"] == ns
+        assert np.allclose(Jcsc.matvec(vl).cpu().numpy(), (pb.jac(u) @ v)[b:e], rtol=1e-13, atol=1e-11)
+        assert np.allclose(Jcsc.rmatvec(vl).cpu().numpy(), (pb.jac(u).T @ v)[b:e], rtol=1e-13, atol=1e-11)
+        # ---------------- colour-compressed assembly on two ranks (one global colouring, computed identically on every
+        # rank) equals the closed-form fill; then config C5 as written: TrustRegion + GMRES on the concrete, coloured J
+        JB2 = PB.jac_csr()
+        ncol = PB.jac_values(ubl, JB2, colored=True)
+        assert 6 <= ncol <= 14 and np.allclose(JB2.values(), JB.values(), rtol=1e-12, atol=1e-10)
+        oc2 = R.init(rb_, R.TrustRegion(linsolve=R.KrylovJL_GMRES(gmres_restart=30, maxiters=4000), concrete_jac=True),
+                     abstol=1e-8, maxiters=25)
+        oc2.lin_reltol, oc2.lin_abstol = 1e-10, 0.0
+        refc = oc2.solve()
+        solc = nls.solve(nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True)),
+                         nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=4000, reltol=1e-10, abstol=0.0),
+                                         concrete_jac=True), abstol=1e-8, maxiters=25, store_trace=True)
+        assert solc.retcode == "Success" == R.RETCODE_NAMES[refc.retcode] and solc.stats.nsteps == refc.stats.nsteps
+        assert [t["accepted"] for t in solc.trace] == [t["accepted"] for t in refc.trace]
+        assert np.max(np.abs(solc.u.cpu().numpy() - refc.u[idx])) <= 1e-7
         q.put((rank, "ok"))
     except Exception:
         import traceback
