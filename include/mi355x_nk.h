@@ -269,6 +269,19 @@ int nk_ctx_profile_query(nk_ctx *ctx, int kernel_id, const char **name, int64_t 
 int nk_comm_unique_id(char id_out[128]);
 int nk_ctx_comm_init_rccl(nk_ctx *ctx, int nranks, int rank, const char id[128]);
 int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, const nk_comm_callbacks *cb);
+/* xGMI-native small collectives on top of either communicator (which keeps serving set-up and large exchanges): every
+ * rank allocates an uncached arena on its GPU and exports it (hipIpcGetMemHandle, 64 bytes); the host language
+ * all-gathers the handles; every rank maps all of them. Afterwards the Krylov all-reduces (≤ 128 doubles) and the halo
+ * exchanges run as ONE small kernel each: a rank stores its partial sums / its halo entries straight into every peer's
+ * arena, releases a sequence flag (system scope), polls the flags of its peers and combines in rank order — bitwise
+ * reproducible, no RCCL launch (≈ 20 µs) on the critical path of an Arnoldi step.
+ *   nk_ctx_comm_peer_handle : allocate the arena (arena_bytes ≤ 0: 64 MiB) and return its IPC handle
+ *   nk_ctx_comm_enable_peer : handles = nranks × 64 bytes in rank order (this rank's own entry is ignored)
+ *   nk_ctx_comm_peer_status : *enabled; *errors = time-outs seen by the device kernels (0 in a healthy run) */
+#define NK_IPC_HANDLE_BYTES 64
+int nk_ctx_comm_peer_handle(nk_ctx *ctx, int64_t arena_bytes, char handle_out[NK_IPC_HANDLE_BYTES]);
+int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles);
+int nk_ctx_comm_peer_status(nk_ctx *ctx, int *enabled, int64_t *errors);
 int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank);
 
 /* contiguous row-range partition used everywhere: rank r owns [r*n/P, (r+1)*n/P) rounded down to a

@@ -117,6 +117,20 @@ class Context:
         self._keep.append(cb)
         check(L.lib().nk_ctx_comm_init_callbacks(self._h, nranks, rank, C.byref(cb)))
 
+    def comm_peer_handle(self, arena_bytes: int = 0) -> bytes:
+        """Allocate this rank's uncached arena and return its 64-byte hipIpc handle (all-gather it, then comm_enable_peer)."""
+        buf = C.create_string_buffer(64)
+        check(L.lib().nk_ctx_comm_peer_handle(self._h, int(arena_bytes), buf))
+        return buf.raw
+
+    def comm_enable_peer(self, handles: bytes):
+        check(L.lib().nk_ctx_comm_enable_peer(self._h, handles))
+
+    def comm_peer_status(self):
+        en, err = C.c_int(), C.c_int64()
+        check(L.lib().nk_ctx_comm_peer_status(self._h, C.byref(en), C.byref(err)))
+        return bool(en.value), int(err.value)
+
     def comm_info(self):
         k, n, r = C.c_int(), C.c_int(), C.c_int()
         check(L.lib().nk_ctx_comm_info(self._h, C.byref(k), C.byref(n), C.byref(r)))

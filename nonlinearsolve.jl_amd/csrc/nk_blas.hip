@@ -776,8 +776,7 @@ int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, c
   NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
   NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out);
   NK_HIP(hipGetLastError());
-  NK_TRY(nk_comm_allreduce(ctx, d_out, 1, 1));
-  return nk_comm_allreduce(ctx, d_out + 1, extra_partials ? 2 : 1, 0);
+  return nk_comm_allreduce_mixed(ctx, d_out, extra_partials ? 3 : 2, 0, 1);  // [max, +, +]: one message on the peer path
 }
 
 // ----------------------------------------------------------------------------- several reductions in one pass
@@ -859,10 +858,7 @@ int nk_blas_multi_reduce(nk_ctx *ctx, int64_t n, int ndots, const double *const 
   NK_LAUNCH(ctx, k_multi_reduce2, dim3(ndots + has_max + extra_slots), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid,
             ndots, has_max, extra_partials, extra_n, d_out);
   NK_HIP(hipGetLastError());
-  if (ndots) NK_TRY(nk_comm_allreduce(ctx, d_out, ndots, 0));
-  if (has_max) NK_TRY(nk_comm_allreduce(ctx, d_out + ndots, 1, 1));
-  if (extra_slots) NK_TRY(nk_comm_allreduce(ctx, d_out + ndots + has_max, extra_slots, 0));
-  return NK_OK;
+  return nk_comm_allreduce_mixed(ctx, d_out, ndots + has_max + extra_slots, ndots, ndots + has_max);
 }
 
 // ----------------------------------------------------------------------------- elementwise

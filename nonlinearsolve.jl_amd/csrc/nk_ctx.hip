@@ -75,11 +75,13 @@ extern "C" int nk_ctx_set_halo_overlap(nk_ctx *ctx, int on) {
   return NK_OK;
 }
 
+static void nk_peer_destroy(nk_ctx *ctx);
 extern "C" int nk_ctx_destroy(nk_ctx *ctx) {
   if (!ctx) return NK_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   nk_comm_destroy(ctx);
+  nk_peer_destroy(ctx);
   hipFree(ctx->d_partials);
   hipFree(ctx->d_partials_ss);
   hipFree(ctx->d_scal);
@@ -190,6 +192,165 @@ extern "C" int nk_partition_range(int64_t n_global, int64_t granule, int nranks,
   return NK_OK;
 }
 
+
+// ----------------------------------------------------------------------------- peer-mapped arenas (hipIpc over xGMI)
+// Layout of every rank's arena: a header (all-reduce flags and slots, error word) and a bump-allocated rest that holds
+// the receive areas of the halo plans. All of it is uncached device memory, so that a kernel polling a flag sees the
+// store a peer GPU made while the kernel was already running.
+struct nk_peer_hdr {
+  uint64_t ar_flag[2][NK_PEER_MAX_RANKS];
+  uint64_t err;
+  uint64_t pad[31];
+  double ar_data[2][NK_PEER_MAX_RANKS][NK_PEER_AR_MAX];
+};
+static_assert(sizeof(nk_peer_hdr) <= NK_PEER_HDR_BYTES, "peer arena header too large");
+constexpr unsigned long long NK_PEER_TIMEOUT_TICKS = 500000000ull;  // 5 s of the 100 MHz wall clock
+
+__device__ __forceinline__ bool peer_wait_ge(const uint64_t *flag, uint64_t seq, uint64_t *err) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    if (wall_clock64() - t0 > NK_PEER_TIMEOUT_TICKS) {  // never hang the GPU: count the time-out and go on
+      atomicAdd((unsigned long long *)err, 1ull);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return true;
+}
+
+// One launch = one all-reduce of `count` ≤ 128 doubles: store my values into my slot of EVERY rank's arena, release my
+// flag there, wait for every rank's flag in MY arena, combine the slots in rank order (elements [max_lo, max_hi) with a
+// NaN-propagating max, the others with +). Slots and flags are double-buffered by the parity of the sequence number: a
+// rank can only be one collective ahead of a peer, because it needs that peer's contribution to finish its own.
+__global__ __launch_bounds__(NK_BLOCK) void k_peer_allreduce(char *const *map, int P, int me, double *buf, int count,
+                                                             int max_lo, int max_hi, uint64_t seq) {
+  const int t = threadIdx.x, par = (int)(seq & 1);
+  double v = (t < count) ? buf[t] : 0.0;
+  for (int p = 0; p < P; ++p) {
+    nk_peer_hdr *h = reinterpret_cast<nk_peer_hdr *>(map[p]);
+    if (t < count) h->ar_data[par][me][t] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t < P) {
+    nk_peer_hdr *h = reinterpret_cast<nk_peer_hdr *>(map[t]);
+    __hip_atomic_store(&h->ar_flag[par][me], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  nk_peer_hdr *mine = reinterpret_cast<nk_peer_hdr *>(map[me]);
+  if (t < P) peer_wait_ge(&mine->ar_flag[par][t], seq, &mine->err);
+  __syncthreads();
+  if (t < count) {
+    const bool mx = (t >= max_lo && t < max_hi);
+    double acc = mine->ar_data[par][0][t];
+    for (int p = 1; p < P; ++p) {
+      const double w = mine->ar_data[par][p][t];
+      if (mx) acc = (acc != acc || w != w) ? __builtin_nan("") : (w > acc ? w : acc);
+      else acc += w;
+    }
+    buf[t] = acc;
+  }
+}
+
+// One launch = one halo exchange: workgroup s serves neighbour s — it stores my entries for that neighbour into the
+// neighbour's receive area (x gathered through the plan's index list, no staging buffer), releases my flag over there,
+// and then waits for that neighbour's flag over here. Every workgroup pushes before it waits, so no cycle can form.
+__global__ __launch_bounds__(NK_BLOCK) void k_peer_halo_xchg(const nk_peer_seg *segs, const int32_t *__restrict__ send_idx,
+                                                             const double *__restrict__ x, uint64_t seq, uint64_t *err) {
+  const nk_peer_seg sg = segs[blockIdx.x];
+  double *dst = sg.dst[seq & 1];
+  const int32_t *idx = send_idx + sg.send_off;
+  for (int64_t i = threadIdx.x; i < sg.send_cnt; i += NK_BLOCK) dst[i] = x[idx[i]];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(sg.flag_remote, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    peer_wait_ge(sg.flag_local, seq, err);
+  }
+}
+
+static void nk_peer_destroy(nk_ctx *ctx) {
+  nk_peer &pr = ctx->peer;
+  for (int p = 0; p < pr.P; ++p)
+    if (p != pr.me && pr.map[p]) hipIpcCloseMemHandle(pr.map[p]);
+  hipFree(pr.d_map);
+  if (pr.arena) hipFree(pr.arena);
+  pr = nk_peer{};
+}
+
+extern "C" int nk_ctx_comm_peer_handle(nk_ctx *ctx, int64_t arena_bytes, char handle_out[NK_IPC_HANDLE_BYTES]) {
+  NK_REQUIRE(ctx && handle_out, "NULL argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == NK_IPC_HANDLE_BYTES, "IPC handle size");
+  NK_HIP(hipSetDevice(ctx->device));
+  nk_peer &pr = ctx->peer;
+  NK_REQUIRE(!pr.arena, "the peer arena exists already");
+  pr.arena_bytes = arena_bytes > 0 ? (size_t)arena_bytes : ((size_t)64 << 20);
+  NK_REQUIRE(pr.arena_bytes >= 2 * NK_PEER_HDR_BYTES, "peer arena too small");
+  void *a = nullptr;
+  // uncached (fine-grained) device memory: stores from a peer GPU must be visible to a kernel that is already polling
+  if (hipExtMallocWithFlags(&a, pr.arena_bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipExtMallocWithFlags(&a, pr.arena_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      NK_FAIL(NK_E_NOMEM, "cannot allocate %zu bytes of uncached / fine-grained device memory for the peer arena", pr.arena_bytes);
+    }
+  }
+  pr.arena = (char *)a;
+  NK_HIP(hipMemset(pr.arena, 0, NK_PEER_HDR_BYTES));
+  NK_HIP(hipDeviceSynchronize());
+  pr.bump = NK_PEER_HDR_BYTES;
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, pr.arena);
+  if (e != hipSuccess) {
+    hipFree(pr.arena);
+    pr.arena = nullptr;
+    NK_FAIL(NK_E_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+  }
+  memcpy(handle_out, &h, NK_IPC_HANDLE_BYTES);
+  return NK_OK;
+}
+
+extern "C" int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles) {
+  NK_REQUIRE(ctx && handles, "NULL argument");
+  nk_peer &pr = ctx->peer;
+  NK_REQUIRE(pr.arena, "call nk_ctx_comm_peer_handle first");
+  NK_REQUIRE(ctx->comm_kind != NK_COMM_NONE && ctx->nranks > 1, "the peer path sits on top of an initialised communicator");
+  NK_REQUIRE(ctx->nranks <= NK_PEER_MAX_RANKS, "at most %d ranks", NK_PEER_MAX_RANKS);
+  NK_HIP(hipSetDevice(ctx->device));
+  pr.P = ctx->nranks;
+  pr.me = ctx->rank;
+  for (int p = 0; p < pr.P; ++p) {
+    if (p == pr.me) { pr.map[p] = pr.arena; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)p * NK_IPC_HANDLE_BYTES, NK_IPC_HANDLE_BYTES);
+    void *q = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      pr.P = p;  // close what was opened
+      NK_FAIL(NK_E_HIP, "hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(e));
+    }
+    pr.map[p] = (char *)q;
+  }
+  NK_TRY(nk_dev_alloc(&pr.d_map, (size_t)NK_PEER_MAX_RANKS));
+  NK_HIP(hipMemcpy(pr.d_map, pr.map, sizeof(char *) * NK_PEER_MAX_RANKS, hipMemcpyHostToDevice));
+  pr.on = true;
+  return NK_OK;
+}
+
+extern "C" int nk_ctx_comm_peer_status(nk_ctx *ctx, int *enabled, int64_t *errors) {
+  NK_REQUIRE(ctx, "NULL argument");
+  if (enabled) *enabled = ctx->peer.on ? 1 : 0;
+  if (errors) {
+    *errors = 0;
+    if (ctx->peer.arena) {
+      uint64_t e = 0;
+      NK_HIP(hipStreamSynchronize(ctx->stream));
+      NK_HIP(hipMemcpy(&e, ctx->peer.arena + offsetof(nk_peer_hdr, err), sizeof(e), hipMemcpyDeviceToHost));
+      *errors = (int64_t)e;
+    }
+  }
+  return NK_OK;
+}
+
 // ----------------------------------------------------------------------------- RCCL through dlopen
 // Only the handful of entry points the Krylov loop needs; resolved at run time so that single-GPU use
 // has no RCCL dependency and so that the process shares whichever librccl the host already loaded.
@@ -295,13 +456,7 @@ bool nk_ctx_is_single(const nk_ctx *ctx) {
   static const bool force = getenv("NK_FORCE_COLLECTIVES") != nullptr;
   return ctx->nranks <= 1 && !(force && ctx->comm_kind != NK_COMM_NONE);
 }
-int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op) {
-  // NK_FORCE_COLLECTIVES=1: issue the collective even on a 1-rank communicator (exercises the RCCL entry points
-  // on a single GPU; used by tests only)
-  static const bool force = getenv("NK_FORCE_COLLECTIVES") != nullptr;
-  if (count <= 0) return NK_OK;
-  if (ctx->nranks <= 1 && !(force && ctx->comm_kind != NK_COMM_NONE)) return NK_OK;
-  ctx->stats.allreduces++;
+static int comm_allreduce_base(nk_ctx *ctx, double *dbuf, int count, int op) {
   if (ctx->comm_kind == NK_COMM_RCCL) {
     NK_RCCL(R.AllReduce(dbuf, dbuf, (size_t)count, RCCL_FLOAT64, op == 1 ? RCCL_MAX : RCCL_SUM,
                         ctx->rccl_comm, ctx->stream));
@@ -313,6 +468,35 @@ int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op) {
     return NK_OK;
   }
   NK_FAIL(NK_E_INVALID, "nranks>1 without a communicator");
+}
+// elements [max_lo, max_hi) are combined with max, all others with +: one message on the peer path, up to three
+// collectives on the base transports
+int nk_comm_allreduce_mixed(nk_ctx *ctx, double *dbuf, int count, int max_lo, int max_hi) {
+  // NK_FORCE_COLLECTIVES=1: issue the collective even on a 1-rank communicator (exercises the RCCL entry points
+  // on a single GPU; used by tests only)
+  static const bool force = getenv("NK_FORCE_COLLECTIVES") != nullptr;
+  if (count <= 0) return NK_OK;
+  if (ctx->nranks <= 1 && !(force && ctx->comm_kind != NK_COMM_NONE)) return NK_OK;
+  if (max_lo < 0) max_lo = 0;
+  if (max_hi > count) max_hi = count;
+  if (max_hi < max_lo) max_hi = max_lo;
+  ctx->stats.allreduces++;
+  if (ctx->peer.on && count <= NK_PEER_AR_MAX) {
+    const uint64_t seq = ++ctx->peer.ar_seq;
+    NK_LAUNCH(ctx, k_peer_allreduce, dim3(1), dim3(NK_BLOCK), (char *const *)ctx->peer.d_map, ctx->peer.P, ctx->peer.me, dbuf,
+              count, max_lo, max_hi, seq);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
+  if (max_lo > 0) NK_TRY(comm_allreduce_base(ctx, dbuf, max_lo, 0));
+  if (max_hi > max_lo) NK_TRY(comm_allreduce_base(ctx, dbuf + max_lo, max_hi - max_lo, 1));
+  if (count > max_hi) NK_TRY(comm_allreduce_base(ctx, dbuf + max_hi, count - max_hi, 0));
+  if ((max_lo > 0) + (max_hi > max_lo) + (count > max_hi) > 1)
+    ctx->stats.allreduces += (max_lo > 0) + (max_hi > max_lo) + (count > max_hi) - 1;
+  return NK_OK;
+}
+int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op) {
+  return op == 1 ? nk_comm_allreduce_mixed(ctx, dbuf, count, 0, count) : nk_comm_allreduce_mixed(ctx, dbuf, count, 0, 0);
 }
 
 int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
@@ -346,6 +530,75 @@ __global__ __launch_bounds__(NK_BLOCK) void k_gather(int64_t n, const int32_t *_
   if (i < n) out[i] = x[idx[i]];
 }
 
+
+// Receive areas of a halo plan inside this rank's arena ([flags | parity 0 | parity 1]) and the neighbour table: where my
+// entries land over there, which flag I raise there, which flag of mine the neighbour raises. The arena offsets are
+// exchanged once through the base transport (an all-reduce of a P × (P + 2) table, every rank filling its row).
+static int halo_setup_peer(nk_ctx *ctx, nk_halo *H) {
+  nk_peer &pr = ctx->peer;
+  const int P = ctx->nranks, me = ctx->rank;
+  const size_t stride = (((size_t)H->n_recv * 8) + 255) & ~(size_t)255;
+  const size_t need = 256 + 2 * stride;
+  const size_t off = (pr.bump + 255) & ~(size_t)255;
+  // every rank must take the same decision: agree on "fits everywhere" first
+  std::vector<double> tab((size_t)P * (P + 3), 0.0);
+  double *row = tab.data() + (size_t)me * (P + 3);
+  row[0] = (double)off;
+  row[1] = (double)stride;
+  row[2] = (off + need <= pr.arena_bytes) ? 0.0 : 1.0;
+  for (int p = 0; p < P; ++p) row[3 + p] = (double)H->recv_off[p];
+  double *d_tab = nullptr;
+  NK_TRY(nk_dev_alloc(&d_tab, tab.size()));
+  NK_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  int st = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
+  if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+  if (st == NK_OK) NK_HIP(hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(d_tab);
+  NK_TRY(st);
+  bool fits = true;
+  for (int p = 0; p < P; ++p) fits = fits && tab[(size_t)p * (P + 3) + 2] == 0.0;
+  if (!fits) {  // the arena is full somewhere: this plan uses the base transport
+    NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)H->n_recv));
+    return NK_OK;
+  }
+  pr.bump = off + need;
+  NK_HIP(hipMemsetAsync(pr.arena + off, 0, 256, ctx->stream));
+  H->recv_buf[0] = reinterpret_cast<double *>(pr.arena + off + 256);
+  H->recv_buf[1] = reinterpret_cast<double *>(pr.arena + off + 256 + stride);
+  H->d_recv = H->recv_buf[0];
+  std::vector<nk_peer_seg> segs;
+  for (int p = 0; p < P; ++p) {
+    if (H->send_cnt[p] == 0 && H->recv_cnt[p] == 0) continue;
+    const double *prow = tab.data() + (size_t)p * (P + 3);
+    const size_t poff = (size_t)prow[0], pstride = (size_t)prow[1];
+    const int64_t there = (int64_t)prow[3 + me];  // where my entries start in p's receive area
+    nk_peer_seg sg;
+    sg.send_off = H->send_off[p];
+    sg.send_cnt = H->send_cnt[p];
+    sg.dst[0] = reinterpret_cast<double *>(pr.map[p] + poff + 256) + there;
+    sg.dst[1] = reinterpret_cast<double *>(pr.map[p] + poff + 256 + pstride) + there;
+    sg.flag_remote = reinterpret_cast<uint64_t *>(pr.map[p] + poff) + me;
+    sg.flag_local = reinterpret_cast<const uint64_t *>(pr.arena + off) + p;
+    segs.push_back(sg);
+  }
+  H->nsegs = (int)segs.size();
+  if (H->nsegs) {
+    NK_HIP(hipMalloc((void **)&H->d_segs, segs.size() * sizeof(nk_peer_seg)));
+    NK_HIP(hipMemcpy(H->d_segs, segs.data(), segs.size() * sizeof(nk_peer_seg), hipMemcpyHostToDevice));
+  }
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  // nobody may push into a receive area before its owner has zeroed the flags: one more collective as a barrier
+  double *d_one = nullptr;
+  NK_TRY(nk_dev_alloc(&d_one, (size_t)1));
+  NK_HIP(hipMemset(d_one, 0, sizeof(double)));
+  st = comm_allreduce_base(ctx, d_one, 1, 0);
+  if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+  hipFree(d_one);
+  NK_TRY(st);
+  H->peer = true;
+  return NK_OK;
+}
+
 int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
                   const std::vector<int64_t> &recv_cnt_per_peer) {
   const int P = ctx->nranks;
@@ -377,14 +630,27 @@ int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t
   }
   NK_TRY(nk_dev_alloc(&H->d_send_idx, (size_t)so));
   NK_TRY(nk_dev_alloc(&H->d_send, (size_t)so));
-  NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)ro));
   if (so) NK_HIP(hipMemcpy(H->d_send_idx, flat.data(), so * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (ctx->peer.on && P > 1) return halo_setup_peer(ctx, H);  // (collective, like every halo set-up on several ranks)
+  NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)ro));
   return NK_OK;
 }
 
 // gather + (optionally on `xstream`) the exchange itself
 static int halo_exchange_on(nk_ctx *ctx, nk_halo *H, const double *d_x_local, hipStream_t xstream) {
   const int P = ctx->nranks;
+  if (H->peer) {  // one launch: push to every neighbour, wait for every neighbour (k_peer_halo_xchg)
+    const uint64_t seq = ++H->seq;
+    ctx->stats.halo_exchanges++;
+    if (H->nsegs) {
+      NK_LAUNCH(ctx, k_peer_halo_xchg, dim3(H->nsegs), dim3(NK_BLOCK), (const nk_peer_seg *)H->d_segs,
+                (const int32_t *)H->d_send_idx, d_x_local, seq,
+                reinterpret_cast<uint64_t *>(ctx->peer.arena + offsetof(nk_peer_hdr, err)));
+      NK_HIP(hipGetLastError());
+    }
+    H->d_recv = H->recv_buf[seq & 1];
+    return NK_OK;
+  }
   const bool direct = H->contig && H->send_cnt[ctx->rank] == 0;  // send from the vector itself
   if (H->n_send && !direct) {
     int grid = (int)((H->n_send + NK_BLOCK - 1) / NK_BLOCK);
@@ -422,10 +688,10 @@ int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
 }
 int nk_halo_exchange_begin(nk_ctx *ctx, nk_halo *H, const double *d_x_local) {
   if (!H->active()) return NK_OK;
-  return halo_exchange_on(ctx, H, d_x_local, ctx->comm_stream);
+  return halo_exchange_on(ctx, H, d_x_local, H->peer ? nullptr : ctx->comm_stream);
 }
 int nk_halo_exchange_end(nk_ctx *ctx, nk_halo *H) {
-  if (!H->active() || ctx->nranks <= 1) return NK_OK;
+  if (!H->active() || ctx->nranks <= 1 || H->peer) return NK_OK;
   NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done, 0));
   return NK_OK;
 }
@@ -433,7 +699,10 @@ int nk_halo_exchange_end(nk_ctx *ctx, nk_halo *H) {
 void nk_halo_free(nk_halo *H) {
   hipFree(H->d_send_idx);
   hipFree(H->d_send);
-  hipFree(H->d_recv);
+  if (!H->peer) hipFree(H->d_recv);  // (peer plans: the receive areas belong to the context's arena)
+  hipFree(H->d_segs);
+  H->d_segs = nullptr;
+  H->peer = false;
   H->d_send_idx = nullptr;
   H->d_send = H->d_recv = nullptr;
   H->n_send = H->n_recv = 0;

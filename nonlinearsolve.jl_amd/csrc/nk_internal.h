@@ -68,8 +68,29 @@ struct nk_prof {
   int64_t count[NK_K_COUNT] = {0};
 };
 
+// peer-mapped arenas (hipIpc over xGMI) for the small collectives of the Krylov loop (nk_ctx.hip)
+constexpr int NK_PEER_MAX_RANKS = 16;
+constexpr int NK_PEER_AR_MAX = 128;                      // doubles per all-reduce message
+constexpr size_t NK_PEER_HDR_BYTES = 65536;              // flags + all-reduce slots + error word
+struct nk_peer_seg {  // one neighbour of a halo plan, as the push / wait kernels see it
+  int64_t send_off, send_cnt;     // into the plan's send index list
+  double *dst[2];                 // the neighbour's receive area for my entries (both parities), in MY address space
+  uint64_t *flag_remote;          // the neighbour's flag for me
+  const uint64_t *flag_local;     // my flag for the neighbour
+};
+struct nk_peer {
+  bool on = false;
+  int P = 0, me = 0;
+  char *arena = nullptr;
+  size_t arena_bytes = 0, bump = 0;
+  char *map[NK_PEER_MAX_RANKS] = {nullptr};   // every rank's arena in my address space (map[me] == arena)
+  char **d_map = nullptr;                     // the same table on the device
+  uint64_t ar_seq = 0;
+};
+
 struct nk_ctx {
   nk_prof prof;
+  nk_peer peer;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -136,6 +157,7 @@ struct nk_prof_scope {
       hipLaunchKernelGGL(kern, grid, block, 0, (ctxp)->stream, __VA_ARGS__);                                \
   } while (0)
 int nk_comm_allreduce(nk_ctx *ctx, double *dbuf, int count, int op /*0 sum,1 max*/);
+int nk_comm_allreduce_mixed(nk_ctx *ctx, double *dbuf, int count, int max_lo, int max_hi);  // [max_lo,max_hi): max, rest: +
 int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const int64_t *sbytes,
                       void *recv, const int64_t *roff, const int64_t *rbytes, hipStream_t stream = nullptr /* ctx->stream */);
 void nk_comm_destroy(nk_ctx *ctx);
@@ -158,6 +180,12 @@ struct nk_halo {
   // sends straight from the vector, no gather launch
   std::vector<int64_t> contig_base;
   bool contig = false;
+  // peer fast path: receive areas (two parities) live in this rank's arena; segs describes the neighbours
+  bool peer = false;
+  double *recv_buf[2] = {nullptr, nullptr};
+  nk_peer_seg *d_segs = nullptr;
+  int nsegs = 0;
+  uint64_t seq = 0;
   bool active() const { return n_send > 0 || n_recv > 0; }
 };
 int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,

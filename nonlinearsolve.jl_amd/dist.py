@@ -8,6 +8,9 @@
   * "torch" : collectives are routed through torch.distributed from C callbacks (nk_comm_callbacks). Works with
     the gloo backend (host staging), which is how the multi-rank code path is exercised on a single GPU
     (2 processes sharing cuda:0) and on CPU-only CI; also usable with nccl as an escape hatch.
+  * "peer"  : one of the above for set-up and large exchanges, plus the xGMI-native fast path for the small collectives of
+    the Krylov loop — every rank exports an uncached arena (hipIpc), torch.distributed all-gathers the 64-byte handles,
+    every rank maps all of them; all-reduces and halo exchanges then run as one small kernel each (csrc/nk_ctx.hip).
 """
 from __future__ import annotations
 
@@ -30,6 +33,10 @@ def init_comm(ctx: core.Context, transport: str | None = None) -> str:
         return "none"
     world, rank = dist.get_world_size(), dist.get_rank()
     transport = transport or os.environ.get("NK_COMM", "rccl" if _backend() == "nccl" else "torch")
+    if transport == "peer":
+        base = init_comm(ctx, os.environ.get("NK_COMM_BASE", "rccl" if _backend() == "nccl" else "torch"))
+        enable_peer(ctx)
+        return "peer+" + base
     if transport == "rccl":
         dev = torch.device("cuda", ctx.device)
         if rank == 0:
@@ -45,6 +52,16 @@ def init_comm(ctx: core.Context, transport: str | None = None) -> str:
         _init_torch_callbacks(ctx, world, rank)
         return "torch"
     raise ValueError(f"unknown transport {transport!r}")
+
+
+def enable_peer(ctx: core.Context, arena_bytes: int = 0):
+    """Layer the peer-mapped fast path over an initialised communicator (collective)."""
+    world = dist.get_world_size()
+    mine = ctx.comm_peer_handle(arena_bytes)
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    ctx.comm_enable_peer(b"".join(parts))
+    dist.barrier()
 
 
 def _init_torch_callbacks(ctx: core.Context, world: int, rank: int):

@@ -24,19 +24,26 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport="torch"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import hashlib
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    digest = {}
+
+    def note(key, arr):   # what the parent compares bit for bit between the transports
+        digest[key] = hashlib.sha1(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
     try:
         import nonlinearsolve_jl_amd as nls
         from oracle import reference_restatement as R
         torch.cuda.set_device(0)
         ctx = nls.Context(device=0)
         nls.set_default_context(ctx)
-        assert nls.dist.init_comm(ctx, "torch") == "torch"
+        assert nls.dist.init_comm(ctx, transport) == ("torch" if transport == "torch" else "peer+torch")
         assert ctx.comm_info() == (2, world, rank)
+        assert ctx.comm_peer_status() == (transport == "peer", 0)
         dev = torch.device("cuda:0")
         rng = np.random.default_rng(7)
 
@@ -63,6 +70,7 @@ def _worker(rank, world, port, q):
             G = nls.GMRES(e - b, restart=30, ortho=ortho).set_operator(J)
             x, gi = G.solve(torch.tensor(rhs[b:e], device=dev), reltol=1e-9, maxiters=3000)
             xg = nls.dist.gather_vector(x, pb.n, b)
+            note("gmres_" + ortho, xg)
             assert gi["converged"] and np.linalg.norm(xg - xref) <= 1e-7 * np.linalg.norm(xref), ortho
             assert abs(gi["iters"] - iref.iters) <= max(3, iref.iters // 20)
         # distributed Newton–Krylov (matrix-free and concrete J) vs the serial oracle
@@ -73,6 +81,7 @@ def _worker(rank, world, port, q):
             sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=nls.EisenstatWalkerForcing2(),
                                                     concrete_jac=concrete), abstol=1e-9, maxiters=50)
             ug = nls.dist.gather_vector(sol.u, pb.n, b)
+            note(f"newton_{concrete}", ug)
             assert sol.retcode == "Success"
             assert np.max(np.abs(ug - ref.u)) <= 1e-7
             assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
@@ -136,6 +145,7 @@ def _worker(rank, world, port, q):
                          abstol=1e-8, maxiters=25)
         assert solb.retcode == "Success" and solb.stats.nsteps == refb.stats.nsteps
         assert np.max(np.abs(solb.u.cpu().numpy() - refb.u[idx])) <= 1e-7
+        note("brusselator_tr", solb.u.cpu().numpy())
 
         # ---------------- distributed transposed SpMV: the contributions to entries the other rank owns come back through
         # the halo plan in reverse (steepest.jl:75-77 / trust_region.jl:410 with a concrete J on several ranks)
@@ -165,26 +175,45 @@ def _worker(rank, world, port, q):
         assert solc.retcode == "Success" == R.RETCODE_NAMES[refc.retcode] and solc.stats.nsteps == refc.stats.nsteps
         assert [t["accepted"] for t in solc.trace] == [t["accepted"] for t in refc.trace]
         assert np.max(np.abs(solc.u.cpu().numpy() - refc.u[idx])) <= 1e-7
-        q.put((rank, "ok"))
+        note("brusselator_tr_concrete", solc.u.cpu().numpy())
+        note("spmv_t", JB.rmatvec(vbl).cpu().numpy())
+        assert ctx.comm_peer_status()[1] == 0        # no device-side time-outs
+        q.put((rank, "ok", digest))
     except Exception:
         import traceback
-        q.put((rank, "FAIL: " + traceback.format_exc()))
+        q.put((rank, "FAIL: " + traceback.format_exc(), {}))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_callback_comm():
+def _run_two_ranks(transport):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=280) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+    return {r[0]: r[2] for r in res}
+
+
+_DIGESTS = {}
+
+
+def test_two_ranks_on_one_gpu_callback_comm():
+    _DIGESTS["torch"] = _run_two_ranks("torch")
+
+
+def test_two_ranks_on_one_gpu_peer_comm():
+    """The same programme with the peer-mapped (hipIpc) all-reduce and halo exchange kernels — the two processes map each
+    other's arenas on the shared GPU — must reproduce the callback transport bit for bit (fixed rank-order combination)."""
+    _DIGESTS["peer"] = _run_two_ranks("peer")
+    if "torch" in _DIGESTS:
+        assert _DIGESTS["peer"] == _DIGESTS["torch"]
 
 
 def _rccl_worker(q):
