@@ -255,6 +255,13 @@ int nk_ctx_set_deterministic(nk_ctx *ctx, int deterministic);
  * computed (off by default; also enabled by NK_HALO_OVERLAP=1 in the environment at context creation). */
 int nk_ctx_set_halo_overlap(nk_ctx *ctx, int on);
 
+/* Device buffers for host languages that have no GPU array type of their own (a Julia session without AMDGPU.jl, plain C):
+ * with them every vector argument of the ABI can be passed with memspace = NK_DEVICE and stays resident between calls.
+ * nk_device_copy kind: 0 host→device, 1 device→host, 2 device→device; ordered on the context's stream, complete on return. */
+int nk_device_alloc(nk_ctx *ctx, int64_t bytes, void **out);
+int nk_device_free(nk_ctx *ctx, void *ptr);
+int nk_device_copy(nk_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind);
+
 /* Per-kernel-family timing (bench.py's roofline numbers). Off by default; when on, every launch of a profiled
  * family is issued with hipExtLaunchKernelGGL start/stop events, i.e. the kernel's own begin/end device
  * timestamps on the context's stream — the quantity rocprofv3's kernel trace reports. `launches` counts logical
@@ -344,6 +351,10 @@ int nk_gmres_set_operator_jvp(nk_gmres *G, nk_problem *P, const double *u, int m
 int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);   /* AbstractSciMLOperator    */
 /* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
 int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
+/* The same two hooks for operators that live in HOST memory (a Julia `mul!` on plain Arrays): the callback receives host
+ * pointers, the library stages the vectors through pinned buffers around every call (2 × 8 n bytes over PCIe each). */
+int nk_gmres_set_operator_fn_host(nk_gmres *G, nk_matvec_fn fn, void *user);
+int nk_gmres_set_right_preconditioner_host(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* Built-in right preconditioner M⁻¹ = p_d(A): `degree` steps of the Chebyshev iteration on [lambda_min, lambda_max]
  * (operator applications only: no inner products, no all-reduce). lambda_max = 0 ⇒ the dominant eigenvalue is
  * bounded by Gershgorin (concrete CSR) or estimated by 30 power iterations ×1.15 (matrix-free / callback

@@ -2,7 +2,9 @@
 #
 # Written against include/mi355x_nk.h. Julia is not installed in the build container, so this file has
 # never been executed; every LinearSolve/SciMLBase internal it touches is marked [EXT] (to confirm against
-# LinearSolve 5.x). The C ABI itself is exercised from Python (ctypes) in tests/.
+# LinearSolve 5.x). The C ABI itself is exercised from Python (ctypes) in tests/, and the exact call sequence of
+# seam 1 below (new A every step → update_tolerances! → solve!, device-pointer callback operator, resident vectors)
+# is replayed by examples/linsolve_seam.c, which the GPU tests run against the oracle.
 #
 # Three seams (SURVEY.md §8b), in the order a maintainer would adopt them:
 #   1. MI355XGMRES           — a `linsolve` backend:  NewtonRaphson(linsolve = MI355XGMRES())
@@ -15,6 +17,7 @@ using LinearAlgebra, SparseArrays
 using SciMLBase: SciMLBase, ReturnCode, NonlinearProblem, NonlinearFunction
 using NonlinearSolveBase: NonlinearSolveBase, AbstractNonlinearSolveAlgorithm, NLStats
 import LinearSolve                       # [EXT]
+import SciMLJacobianOperators            # StatefulJacobianOperator (lib/SciMLJacobianOperators)
 
 const libnk = get(ENV, "MI355X_NK_LIB", "libmi355x_nk.so")
 
@@ -39,6 +42,45 @@ end
 const DEFAULT_CTX = Ref{Union{Nothing, Ctx}}(nothing)
 default_ctx() = something(DEFAULT_CTX[], (DEFAULT_CTX[] = Ctx(); DEFAULT_CTX[]))
 
+# ------------------------------------------------------------------ where a vector lives
+# Every vector argument of the ABI carries a memory-space flag: 0 = host (copied per call), 1 = device (zero copy).
+# `DeviceVector` keeps data resident without any GPU array package (nk_device_alloc / nk_device_copy); with AMDGPU.jl
+# loaded, `ROCArray`s are passed as they are (see the extension block at the end of this file).
+const NK_HOST, NK_DEVICE = Cint(0), Cint(1)
+mutable struct DeviceVector <: AbstractVector{Float64}
+    ptr::Ptr{Float64}
+    n::Int
+    ctx::Ctx
+    function DeviceVector(n::Integer; ctx::Ctx = default_ctx())
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        nkcheck(@ccall libnk.nk_device_alloc(ctx.ptr::Ptr{Cvoid}, (8n)::Int64, out::Ptr{Ptr{Cvoid}})::Cint)
+        v = new(Ptr{Float64}(out[]), n, ctx)
+        finalizer(x -> @ccall(libnk.nk_device_free(x.ctx.ptr::Ptr{Cvoid}, x.ptr::Ptr{Cvoid})::Cint), v)
+        return v
+    end
+end
+Base.size(v::DeviceVector) = (v.n,)
+Base.getindex(::DeviceVector, ::Int) = error("DeviceVector lives on the GPU: copy it with Array(v)")
+function Base.copyto!(d::DeviceVector, h::Array{Float64})
+    GC.@preserve h nkcheck(@ccall libnk.nk_device_copy(d.ctx.ptr::Ptr{Cvoid}, d.ptr::Ptr{Cvoid}, h::Ptr{Float64},
+        (8 * d.n)::Int64, 0::Cint)::Cint)
+    return d
+end
+function Base.copyto!(h::Array{Float64}, d::DeviceVector)
+    GC.@preserve h nkcheck(@ccall libnk.nk_device_copy(d.ctx.ptr::Ptr{Cvoid}, h::Ptr{Float64}, d.ptr::Ptr{Cvoid},
+        (8 * d.n)::Int64, 1::Cint)::Cint)
+    return h
+end
+DeviceVector(h::Array{Float64}; kw...) = copyto!(DeviceVector(length(h); kw...), vec(h))
+Base.Array(d::DeviceVector) = copyto!(Vector{Float64}(undef, d.n), d)
+
+memspace(::Array{Float64}) = NK_HOST
+memspace(::DeviceVector) = NK_DEVICE
+memspace(x::Base.ReshapedArray) = memspace(parent(x))           # `vec`/`reshape` views the reference hands around
+rawptr(x::Array{Float64}) = pointer(x)
+rawptr(x::DeviceVector) = x.ptr
+rawptr(x::Base.ReshapedArray) = rawptr(parent(x))
+
 mutable struct DeviceCSR
     ptr::Ptr{Cvoid}
     n::Int
@@ -53,8 +95,10 @@ function DeviceCSR(A::SparseMatrixCSC{Float64, Int}; ctx = default_ctx())
     finalizer(x -> @ccall(libnk.nk_csr_destroy(x.ptr::Ptr{Cvoid})::Cint), m)
     return m
 end
-function LinearAlgebra.mul!(y::Vector{Float64}, A::DeviceCSR, x::Vector{Float64})
-    GC.@preserve x y nkcheck(@ccall libnk.nk_spmv(A.ptr::Ptr{Cvoid}, x::Ptr{Float64}, y::Ptr{Float64}, 0::Cint)::Cint)
+function LinearAlgebra.mul!(y::AbstractVector{Float64}, A::DeviceCSR, x::AbstractVector{Float64})
+    @assert memspace(x) == memspace(y)
+    GC.@preserve x y nkcheck(@ccall libnk.nk_spmv(A.ptr::Ptr{Cvoid}, rawptr(x)::Ptr{Float64}, rawptr(y)::Ptr{Float64},
+        memspace(x)::Cint)::Cint)
     return y
 end
 
@@ -76,17 +120,29 @@ bratu2d(n; λ = 6.0, scale = 0.0, kw...) = DeviceProblem(2, Float64[n, λ, scale
 brusselator2d(N; A = 3.4, B = 1.0, α = 10.0, dx = 1 / (N - 1), kw...) = DeviceProblem(3, Float64[N, A, B, α, dx]; kw...)
 
 # ------------------------------------------------------------------ seam 2: f / jvp / vjp callbacks
-"""`NonlinearFunction` whose `f`, `jvp`, `vjp` run the built-in device kernels (host arrays in/out).
-Signatures follow lib/SciMLJacobianOperators/test/core_tests__item2.jl:38-40,62-67."""
-function mi355x_function(P::DeviceProblem)
-    f!(du, u, p) = (GC.@preserve du u nkcheck(@ccall libnk.nk_residual(P.ptr::Ptr{Cvoid}, u::Ptr{Float64},
-        du::Ptr{Float64}, 0::Cint)::Cint); nothing)
-    jvp!(Jv, v, u, p) = (GC.@preserve Jv v u nkcheck(@ccall libnk.nk_jvp(P.ptr::Ptr{Cvoid}, u::Ptr{Float64},
-        v::Ptr{Float64}, Jv::Ptr{Float64}, 0::Cint)::Cint); nothing)
-    vjp!(vJ, v, u, p) = (GC.@preserve vJ v u nkcheck(@ccall libnk.nk_vjp(P.ptr::Ptr{Cvoid}, u::Ptr{Float64},
-        v::Ptr{Float64}, vJ::Ptr{Float64}, 0::Cint)::Cint); nothing)
-    return NonlinearFunction{true}(f!; jvp = jvp!, vjp = vjp!)
+"""`NonlinearFunction` whose `f`, `jvp`, `vjp` run the built-in device kernels. The arrays may be host `Array`s (copied
+per call) or resident `DeviceVector`s / `ROCArray`s (zero copy): the memory-space flag follows the argument type.
+Signatures follow lib/SciMLJacobianOperators/test/core_tests__item2.jl:38-40,62-67. The callbacks are callable structs,
+not closures, so that `MI355XGMRES` can recognise the device problem behind `f.jvp` and bind the device JVP directly."""
+struct DeviceResidual; P::DeviceProblem; end
+struct DeviceJVP;      P::DeviceProblem; end
+struct DeviceVJP;      P::DeviceProblem; end
+function (r::DeviceResidual)(du, u, p)
+    GC.@preserve du u nkcheck(@ccall libnk.nk_residual(r.P.ptr::Ptr{Cvoid}, rawptr(u)::Ptr{Float64},
+        rawptr(du)::Ptr{Float64}, memspace(u)::Cint)::Cint)
+    return nothing
 end
+function (j::DeviceJVP)(Jv, v, u, p)
+    GC.@preserve Jv v u nkcheck(@ccall libnk.nk_jvp(j.P.ptr::Ptr{Cvoid}, rawptr(u)::Ptr{Float64}, rawptr(v)::Ptr{Float64},
+        rawptr(Jv)::Ptr{Float64}, memspace(u)::Cint)::Cint)
+    return nothing
+end
+function (j::DeviceVJP)(vJ, v, u, p)
+    GC.@preserve vJ v u nkcheck(@ccall libnk.nk_vjp(j.P.ptr::Ptr{Cvoid}, rawptr(u)::Ptr{Float64}, rawptr(v)::Ptr{Float64},
+        rawptr(vJ)::Ptr{Float64}, memspace(u)::Cint)::Cint)
+    return nothing
+end
+mi355x_function(P::DeviceProblem) = NonlinearFunction{true}(DeviceResidual(P); jvp = DeviceJVP(P), vjp = DeviceVJP(P))
 
 # ------------------------------------------------------------------ seam 1: linsolve backend
 """
@@ -102,10 +158,24 @@ Base.@kwdef struct MI355XGMRES <: LinearSolve.AbstractKrylovSubspaceMethod   # [
 end
 LinearSolve.needs_concrete_A(::MI355XGMRES) = false                           # [EXT]
 
+# nk_gmres_info, field for field (include/mi355x_nk.h)
+struct GMRESInfo
+    iters::Int32; restarts::Int32; converged::Int32; failed::Int32
+    rnorm0::Float64; rnorm::Float64
+end
+
+# An operator the library calls back into: a mutable box (so that `pointer_from_objref` is legal) that the workspace
+# keeps alive for as long as the device GMRES may call it.
+mutable struct OperatorBox
+    A::Any
+    n::Int
+end
 mutable struct GMRESWorkspace
     ptr::Ptr{Cvoid}
     n::Int
     csr::Union{Nothing, DeviceCSR}
+    box::Union{Nothing, OperatorBox}        # keep-alive of the operator behind the C callback
+    precbox::Union{Nothing, OperatorBox}
 end
 const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2, :dcgs2 => 3)
 
@@ -114,48 +184,86 @@ function LinearSolve.init_cacheval(alg::MI355XGMRES, A, b, u, Pl, Pr, maxiters::
     out = Ref{Ptr{Cvoid}}(C_NULL)
     nkcheck(@ccall libnk.nk_gmres_create(default_ctx().ptr::Ptr{Cvoid}, length(b)::Int64,
         alg.gmres_restart::Cint, ORTHO[alg.ortho]::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
-    w = GMRESWorkspace(out[], length(b), nothing)
+    w = GMRESWorkspace(out[], length(b), nothing, nothing, nothing)
     finalizer(x -> @ccall(libnk.nk_gmres_destroy(x.ptr::Ptr{Cvoid})::Cint), w)
     return w
 end
 
-# operator plumbing: a concrete sparse J goes to the device once per `A` assignment; a matrix-free operator
-# (StatefulJacobianOperator, FunctionOperator, …) is applied through a C callback that calls `mul!`.
-function matvec_trampoline(user::Ptr{Cvoid}, x::Ptr{Float64}, y::Ptr{Float64}, stream::Ptr{Cvoid})::Cint
-    A, n = unsafe_pointer_to_objref(user)::Tuple{Any, Int}
-    # device pointers: wrap as ROCArray views (AMDGPU.jl) — or stage through host buffers when A is a host operator
-    xv = unsafe_wrap(Array, x, n); yv = unsafe_wrap(Array, y, n)                 # host-operator variant
+# mul!(y, A, x) for an operator that lives in HOST memory (a Julia `mul!` on plain Arrays — e.g. a
+# StatefulJacobianOperator around CPU closures): registered with nk_gmres_set_operator_fn_host, so the library hands the
+# callback HOST pointers and stages the vectors itself. (The device-pointer variant of the contract, nk_matvec_fn proper,
+# is what the AMDGPU extension below uses; wrapping device pointers in `Array`s would read invalid memory.)
+function host_matvec_trampoline(user::Ptr{Cvoid}, x::Ptr{Float64}, y::Ptr{Float64}, ::Ptr{Cvoid})::Cint
+    box = unsafe_pointer_to_objref(user)::OperatorBox
+    xv = unsafe_wrap(Array, x, box.n); yv = unsafe_wrap(Array, y, box.n)        # host pointers: legal
     try
-        mul!(yv, A, xv)
-        return 0
+        mul!(yv, box.A, xv)
+        return Cint(0)
     catch
-        return 1
+        return Cint(1)
     end
+end
+# ldiv!-style right preconditioner from `precs(A, p) -> (Pl, Pr)` (test/Core/core_tests__item21.jl:10-18), host memory
+function host_prec_trampoline(user::Ptr{Cvoid}, x::Ptr{Float64}, y::Ptr{Float64}, ::Ptr{Cvoid})::Cint
+    box = unsafe_pointer_to_objref(user)::OperatorBox
+    xv = unsafe_wrap(Array, x, box.n); yv = unsafe_wrap(Array, y, box.n)
+    try
+        ldiv!(yv, box.A, xv)
+        return Cint(0)
+    catch
+        return Cint(1)
+    end
+end
+
+# the device problem behind a StatefulJacobianOperator built from `mi355x_function` (seam 2), if any
+device_jvp_of(A) = nothing
+function device_jvp_of(A::SciMLJacobianOperators.StatefulJacobianOperator)      # fields: mode, jac_op, u, p  (:210-224)
+    op = A.jac_op.jvp_op                                                         # JacobianOperator.jvp_op    (:86-96)
+    return op isa DeviceJVP ? op.P : nothing
+end
+
+function set_operator!(w::GMRESWorkspace, A)
+    if A isa SparseMatrixCSC
+        # concrete J: Julia's CSC fields are ingested as they are (the CSC → CSR conversion is one O(nnz) host pass)
+        w.csr = DeviceCSR(A)
+        nkcheck(@ccall libnk.nk_gmres_set_operator_csr(w.ptr::Ptr{Cvoid}, w.csr.ptr::Ptr{Cvoid})::Cint)
+    elseif (P = device_jvp_of(A)) !== nothing
+        # StatefulJacobianOperator whose f.jvp is the device kernel: bind it, no trampoline, nothing crosses PCIe
+        u = A.u
+        GC.@preserve u nkcheck(@ccall libnk.nk_gmres_set_operator_jvp(w.ptr::Ptr{Cvoid}, P.ptr::Ptr{Cvoid},
+            rawptr(u)::Ptr{Float64}, memspace(u)::Cint)::Cint)
+    else
+        w.box = OperatorBox(A, w.n)
+        cb = @cfunction(host_matvec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
+        nkcheck(@ccall libnk.nk_gmres_set_operator_fn_host(w.ptr::Ptr{Cvoid}, cb::Ptr{Cvoid},
+            pointer_from_objref(w.box)::Ptr{Cvoid})::Cint)
+    end
+    return nothing
 end
 
 function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::MI355XGMRES; kwargs...)   # [EXT]
     w = cache.cacheval::GMRESWorkspace
-    A = cache.A
     if cache.isfresh                                                            # [EXT] set by `cache.A = …`
-        if A isa SparseMatrixCSC
-            w.csr = DeviceCSR(A)
-            nkcheck(@ccall libnk.nk_gmres_set_operator_csr(w.ptr::Ptr{Cvoid}, w.csr.ptr::Ptr{Cvoid})::Cint)
-        else
-            cb = @cfunction(matvec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
-            ref = Ref{Any}((A, w.n)); cache.cacheval_keepalive = (cb, ref)      # keep both alive
-            nkcheck(@ccall libnk.nk_gmres_set_operator_fn(w.ptr::Ptr{Cvoid}, cb::Ptr{Cvoid},
-                pointer_from_objref(ref[])::Ptr{Cvoid})::Cint)
+        set_operator!(w, cache.A)
+        Pr = cache.Pr                                                           # [EXT] from `precs(A, p)`
+        if !(Pr isa LinearSolve.IdentityOperator || Pr === LinearAlgebra.I)     # [EXT]
+            w.precbox = OperatorBox(Pr, w.n)
+            pcb = @cfunction(host_prec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
+            nkcheck(@ccall libnk.nk_gmres_set_right_preconditioner_host(w.ptr::Ptr{Cvoid}, pcb::Ptr{Cvoid},
+                pointer_from_objref(w.precbox)::Ptr{Cvoid})::Cint)
         end
         cache.isfresh = false
     end
-    info = Ref(ntuple(_ -> zero(UInt8), 32))        # nk_gmres_info (4×Int32 + 2×Float64)
+    info = Ref(GMRESInfo(0, 0, 0, 0, 0.0, 0.0))
     b, u = cache.b, cache.u
-    GC.@preserve b u nkcheck(@ccall libnk.nk_gmres_solve(w.ptr::Ptr{Cvoid}, b::Ptr{Float64}, u::Ptr{Float64},
-        0::Cint, 0::Cint, cache.abstol::Float64, cache.reltol::Float64, cache.maxiters::Cint, 0::Cint,
-        info::Ptr{Cvoid})::Cint)
-    iters, _, converged, failed = reinterpret(Int32, collect(info[][1:16]))
-    rc = failed != 0 ? ReturnCode.Failure : (converged != 0 ? ReturnCode.Success : ReturnCode.MaxIters)
-    return SciMLBase.build_linear_solution(alg, u, nothing, cache; retcode = rc, iters = Int(iters))
+    @assert memspace(b) == memspace(u)
+    # cache.reltol is what update_tolerances!(cache; reltol = η) set (eisenstat_walker.jl:50,77)
+    GC.@preserve b u w nkcheck(@ccall libnk.nk_gmres_solve(w.ptr::Ptr{Cvoid}, rawptr(b)::Ptr{Float64},
+        rawptr(u)::Ptr{Float64}, memspace(b)::Cint, 0::Cint, cache.abstol::Float64, cache.reltol::Float64,
+        cache.maxiters::Cint, 0::Cint, info::Ptr{GMRESInfo})::Cint)
+    i = info[]
+    rc = i.failed != 0 ? ReturnCode.Failure : (i.converged != 0 ? ReturnCode.Success : ReturnCode.MaxIters)
+    return SciMLBase.build_linear_solution(alg, u, nothing, cache; retcode = rc, iters = Int(i.iters))
 end
 
 # ------------------------------------------------------------------ seam 3: whole-solver plugin
@@ -169,10 +277,36 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     problem::DeviceProblem
     trust_region::Bool = false
     concrete_jac::Bool = false
+    direct::Bool = false                  # linsolve = nothing: banded LU on the device (needs concrete_jac)
     gmres_restart::Int = 30
     gmres_maxiters::Int = 300
-    forcing::Bool = false
-    radius_update_scheme::Int = 0
+    forcing::Bool = false                 # EisenstatWalkerForcing2()
+    radius_update_scheme::Int = 0         # RadiusUpdateSchemes.Simple … Fan (0…6)
+    linesearch::Symbol = :none            # :none | :BackTracking
+    precs::Symbol = :none                 # :none | :chebyshev | :multigrid — the built-ins behind the `precs` hook
+    cheb_degree::Int = 32
+    cheb_ratio::Float64 = 300.0
+    mg_nu::Int = 2
+    mg_coarse::Int = 31
+end
+
+# termination_condition → nk_options.termination_mode / termination_norm and the mode struct's fields
+# (lib/NonlinearSolveBase/src/termination_conditions.jl:243-376; order of include/mi355x_nk.h's nk_termination_mode)
+const TERMINATION_MODES = Dict(:AbsNormSafeBestTerminationMode => 0, :NormTerminationMode => 1, :RelTerminationMode => 2,
+    :RelNormTerminationMode => 3, :RelNormSafeTerminationMode => 4, :RelNormSafeBestTerminationMode => 5,
+    :AbsTerminationMode => 6, :AbsNormTerminationMode => 7, :AbsNormSafeTerminationMode => 8)
+function apply_termination!(o, tc)
+    tc === nothing && return o                       # the solver's default: AbsNormSafeBest(maximum∘abs; max_stalled_steps = 32)
+    o.termination_mode = TERMINATION_MODES[nameof(typeof(tc))]
+    hasproperty(tc, :internalnorm) && (o.termination_norm = tc.internalnorm === LinearAlgebra.norm ? 1 : 0)
+    # an explicitly constructed mode carries max_stalled_steps = nothing unless given
+    o.max_stalled_steps = hasproperty(tc, :max_stalled_steps) && tc.max_stalled_steps !== nothing ? tc.max_stalled_steps : -1
+    for f in (:patience_steps, :patience_objective_multiplier, :min_max_factor)
+        hasproperty(tc, f) && setproperty!(o, f, getproperty(tc, f))
+    end
+    hasproperty(tc, :protective_threshold) && tc.protective_threshold !== nothing &&
+        (o.protective_threshold = tc.protective_threshold)
+    return o
 end
 
 # nk_options mirrors include/mi355x_nk.h field for field (isbits ⇒ passable by Ref)
@@ -201,19 +335,31 @@ const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, R
     ReturnCode.MaxTime, ReturnCode.Failure, ReturnCode.InternalLineSearchFailed)
 
 function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, args...;
-        abstol = nothing, reltol = nothing, maxiters = 1000, kwargs...)
-    o = NKOptions(; algorithm = alg.trust_region ? 1 : 0, linsolve = alg.concrete_jac ? 1 : 0,
+        abstol = nothing, reltol = nothing, maxiters = 1000, maxtime = nothing, termination_condition = nothing,
+        kwargs...)
+    o = NKOptions(; algorithm = alg.trust_region ? 1 : 0,
+        linsolve = alg.direct ? 2 : (alg.concrete_jac ? 1 : 0),
         maxiters = maxiters, abstol = something(abstol, 0.0), reltol = something(reltol, 0.0),
+        maxtime = something(maxtime, 0.0),
         gmres_restart = alg.gmres_restart, gmres_maxiters = alg.gmres_maxiters,
-        forcing = alg.forcing ? 1 : 0, radius_update_scheme = alg.radius_update_scheme)
-    u0 = Vector{Float64}(vec(prob.u0)); u = similar(u0); resid = similar(u0)
+        forcing = alg.forcing ? 1 : 0, radius_update_scheme = alg.radius_update_scheme,
+        linesearch = alg.linesearch === :BackTracking ? 1 : 0,
+        cheb_degree = alg.precs === :chebyshev ? alg.cheb_degree : 0, cheb_ratio = alg.cheb_ratio,
+        mg_nu = alg.precs === :multigrid ? alg.mg_nu : 0, mg_coarse = alg.mg_coarse)
+    apply_termination!(o, termination_condition)
+    # u0 may be a host Array (copied in and out once) or already resident (DeviceVector / ROCArray): no PCIe traffic then
+    u0 = prob.u0 isa Array ? Vector{Float64}(vec(prob.u0)) : vec(prob.u0)
+    ms = memspace(u0)
+    u = ms == NK_HOST ? similar(u0) : DeviceVector(length(u0))
+    resid = ms == NK_HOST ? similar(u0) : DeviceVector(length(u0))
     stats = zeros(Int64, 9); rc = Ref{Cint}(0)
     GC.@preserve u0 u resid stats nkcheck(@ccall libnk.nk_newton_solve(alg.problem.ptr::Ptr{Cvoid},
-        u0::Ptr{Float64}, 0::Cint, Ref(o)::Ptr{Cvoid}, u::Ptr{Float64}, resid::Ptr{Float64},
+        rawptr(u0)::Ptr{Float64}, ms::Cint, Ref(o)::Ptr{Cvoid}, rawptr(u)::Ptr{Float64}, rawptr(resid)::Ptr{Float64},
         stats::Ptr{Int64}, rc::Ptr{Cint})::Cint)
-    return SciMLBase.build_solution(prob, alg, reshape(u, size(prob.u0)), reshape(resid, size(prob.u0));
+    shape(x) = x isa Array ? reshape(x, size(prob.u0)) : x
+    return SciMLBase.build_solution(prob, alg, shape(u), shape(resid);
         retcode = RETCODES[rc[] + 1], stats = NLStats(stats[1], stats[2], stats[3], stats[4], stats[5]),
-        original = (; gmres_iters = stats[6], op_applies = stats[7], allreduces = stats[8]))
+        original = (; gmres_iters = stats[6], op_applies = stats[7], allreduces = stats[8], halo_exchanges = stats[9]))
 end
 
 # ------------------------------------------------------------------------------------------ seam 4: ensembles of small systems
@@ -253,7 +399,26 @@ function vectorized_solve(k::EnsembleKernel, u0::Vector{Float64}, p::Matrix{Floa
     return (; u, resid, retcode = [RETCODES[c + 1] for c in rc], iters)
 end
 
-export Ctx, DeviceCSR, DeviceProblem, bratu2d, brusselator2d, mi355x_function, MI355XGMRES, MI355XNewtonKrylovAlg,
-    EnsembleKernel, vectorized_solve
+# ------------------------------------------------------------------------------------------ AMDGPU.jl arrays (optional)
+# With AMDGPU.jl loaded (as a package extension: ext/MI355XNewtonKrylovAMDGPUExt.jl with AMDGPU as a weak dependency),
+# ROCArrays are passed with memspace = NK_DEVICE, and a device-resident Julia operator can serve as `A` through the
+# device-pointer callback contract (nk_matvec_fn proper): the callback wraps the pointers as ROCArrays — never as Arrays.
+#
+#   module MI355XNewtonKrylovAMDGPUExt
+#   using AMDGPU, LinearAlgebra, MI355XNewtonKrylov
+#   import MI355XNewtonKrylov: memspace, rawptr, NK_DEVICE, OperatorBox
+#   memspace(::ROCArray{Float64}) = NK_DEVICE
+#   rawptr(x::ROCArray{Float64}) = Ptr{Float64}(UInt(pointer(x)))
+#   function device_matvec_trampoline(user::Ptr{Cvoid}, x::Ptr{Float64}, y::Ptr{Float64}, stream::Ptr{Cvoid})::Cint
+#       box = unsafe_pointer_to_objref(user)::OperatorBox
+#       xv = unsafe_wrap(ROCArray, Base.unsafe_convert(AMDGPU.Mem.HIPBuffer ... x), (box.n,))   # [EXT AMDGPU.jl ≥ 1.0]
+#       yv = unsafe_wrap(ROCArray, ..., (box.n,))
+#       try mul!(yv, box.A, xv); AMDGPU.synchronize(); return Cint(0) catch; return Cint(1) end
+#   end
+#   # registered with nk_gmres_set_operator_fn (device pointers) instead of nk_gmres_set_operator_fn_host
+#   end
+
+export Ctx, DeviceVector, DeviceCSR, DeviceProblem, bratu2d, brusselator2d, mi355x_function, MI355XGMRES,
+    MI355XNewtonKrylovAlg, EnsembleKernel, vectorized_solve
 
 end # module

@@ -139,6 +139,11 @@ SIGNATURES = {
     "nk_gmres_set_operator_jvp": (_I, [_P, _P, _P, _I]),
     "nk_gmres_set_operator_fn": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_right_preconditioner": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_operator_fn_host": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_right_preconditioner_host": (_I, [_P, MATVEC_FN, _P]),
+    "nk_device_alloc": (_I, [_P, _L, C.POINTER(C.c_void_p)]),
+    "nk_device_free": (_I, [_P, _P]),
+    "nk_device_copy": (_I, [_P, _P, _P, _L, _I]),
     "nk_gmres_set_chebyshev_preconditioner": (_I, [_P, _I, _D, _D, _D]),
     "nk_gmres_set_multigrid_preconditioner": (_I, [_P, _P, _P, _I, _I, _I]),
     "nk_gmres_get_chebyshev_interval": (_I, [_P, C.POINTER(_D), C.POINTER(_D)]),

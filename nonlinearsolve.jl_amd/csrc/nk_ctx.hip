@@ -107,6 +107,34 @@ extern "C" int nk_ctx_synchronize(nk_ctx *ctx) {
   NK_HIP(hipStreamSynchronize(ctx->stream));
   return NK_OK;
 }
+extern "C" int nk_device_alloc(nk_ctx *ctx, int64_t bytes, void **out) {
+  NK_REQUIRE(ctx && out && bytes >= 0, "bad argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  *out = nullptr;
+  if (bytes == 0) return NK_OK;
+  hipError_t e = hipMalloc(out, (size_t)bytes);
+  if (e != hipSuccess) NK_FAIL(NK_E_NOMEM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+  return NK_OK;
+}
+extern "C" int nk_device_free(nk_ctx *ctx, void *ptr) {
+  NK_REQUIRE(ctx, "NULL argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  if (ptr) {
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_HIP(hipFree(ptr));
+  }
+  return NK_OK;
+}
+extern "C" int nk_device_copy(nk_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind) {
+  NK_REQUIRE(ctx && (bytes == 0 || (dst && src)) && bytes >= 0, "bad argument");
+  NK_REQUIRE(kind >= 0 && kind <= 2, "kind must be 0 (host→device), 1 (device→host) or 2 (device→device)");
+  NK_HIP(hipSetDevice(ctx->device));
+  if (bytes == 0) return NK_OK;
+  const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  NK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, k, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
 extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {
   NK_REQUIRE(ctx, "ctx is NULL");
   ctx->deterministic = d ? 1 : 0;

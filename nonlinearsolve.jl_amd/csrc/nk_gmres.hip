@@ -722,6 +722,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->cr); hipFree(G->cd); hipFree(G->ct); hipFree(G->cd2);
   hipHostFree(G->h_ctl);
   hipHostFree(G->h_pub);
+  if (G->h_stage) hipHostFree(G->h_stage);
   delete G;
   return NK_OK;
 }
@@ -752,12 +753,36 @@ extern "C" int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user
   G->op_kind = 3;
   G->fn = fn;
   G->fn_user = user;
+  G->fn_host = false;
+  return NK_OK;
+}
+// callbacks on host memory (a host language's `mul!` on plain arrays): x down, the call, y up — all on the stream's order
+static int host_callback(nk_gmres *G, nk_matvec_fn fn, void *user, const double *d_x, double *d_y, const char *what) {
+  nk_ctx *ctx = G->ctx;
+  const size_t bytes = (size_t)G->n * sizeof(double);
+  if (!G->h_stage) NK_HIP(hipHostMalloc((void **)&G->h_stage, 2 * bytes + 16, hipHostMallocDefault));
+  NK_HIP(hipMemcpyAsync(G->h_stage, d_x, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  if (fn(user, G->h_stage, G->h_stage + G->n, nullptr) != 0) NK_FAIL(NK_E_CALLBACK, "%s callback failed", what);
+  NK_HIP(hipMemcpyAsync(d_y, G->h_stage + G->n, bytes, hipMemcpyHostToDevice, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next call
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_operator_fn_host(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  NK_TRY(nk_gmres_set_operator_fn(G, fn, user));
+  G->fn_host = true;
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_right_preconditioner_host(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  NK_TRY(nk_gmres_set_right_preconditioner(G, fn, user));
+  G->prec_host = fn != nullptr;
   return NK_OK;
 }
 extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user) {
   NK_REQUIRE(G, "NULL argument");
   G->prec = fn;
   G->prec_user = user;
+  G->prec_host = false;
   G->prec_kind = fn ? 1 : 0;
   if (fn && !G->z) NK_TRY(nk_dev_alloc(&G->z, (size_t)G->ldv));
   return NK_OK;
@@ -772,6 +797,7 @@ static int op_apply_raw(nk_gmres *G, const double *src, double *d_y, const int *
     case 3:
       ctx->stats.op_applies++;
       if (oscale) NK_FAIL(NK_E_INVALID, "internal: output scale with a callback operator");
+      if (G->fn_host) return host_callback(G, G->fn, G->fn_user, src, d_y, "operator");
       if (G->fn(G->fn_user, src, d_y, (void *)ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "operator callback failed");
       return NK_OK;
     default: NK_FAIL(NK_E_INVALID, "GMRES has no operator");
@@ -1013,6 +1039,7 @@ extern "C" int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P,
 static int prec_apply(nk_gmres *G, const double *src, double *dst, const int *d_skip) {
   if (G->prec_kind == 2) return cheb_apply(G, src, dst, d_skip);
   if (G->prec_kind == 3) return nk_mg_apply(G->mg, src, dst, d_skip);
+  if (G->prec_host) return host_callback(G, G->prec, G->prec_user, src, dst, "preconditioner");
   if (G->prec(G->prec_user, src, dst, (void *)G->ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
   return NK_OK;
 }

@@ -366,6 +366,8 @@ struct nk_gmres {
   void *fn_user = nullptr;
   nk_matvec_fn prec = nullptr;
   void *prec_user = nullptr;
+  bool fn_host = false, prec_host = false;  // the callbacks take HOST pointers: vectors are staged through h_stage
+  double *h_stage = nullptr;                // pinned, 2 n doubles
   int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle
   struct nk_mg *mg = nullptr;
   int cheb_degree = 0;

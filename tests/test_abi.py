@@ -138,6 +138,18 @@ def test_plain_c_example_compiles_against_the_header(tmp_path):
     assert exe.exists()
 
 
+def test_linsolve_seam_example_compiles_against_the_header(tmp_path):
+    """examples/linsolve_seam.c — seam 1 replayed in C99 (set A every step → update tolerances → solve!, device-pointer
+    callback operator) — builds with -Werror and links."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "linsolve_seam"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "linsolve_seam.c"),
+                           "-L", os.path.join(root, "nonlinearsolve.jl_amd", "lib"), "-lmi355x_nk", "-lm", "-o", str(exe)])
+    assert exe.exists()
+
+
 def test_julia_binding_matches_the_abi():
     """julia/MI355XNewtonKrylov.jl (the reference-side binding; Julia is not installed here): every symbol it ccalls is
     declared in the header, and its NKOptions mirror lists the fields of nk_options in the same order with the same types."""
@@ -155,3 +167,15 @@ def test_julia_binding_matches_the_abi():
     jl_types = {"Int32": C.c_int32, "Float64": C.c_double}
     expect = [(n, ty) for n, ty in _lib.Options._fields_]
     assert [(n, jl_types[ty]) for n, ty in fields] == expect
+    # the three defects the round-1 review found by reading, and the zero-copy paths it asked for
+    assert "cacheval_keepalive" not in jl                      # LinearCache has no such field: keep-alives live in our workspace
+    assert "mutable struct OperatorBox" in jl and "pointer_from_objref(w.box)" in jl   # never objref of an immutable tuple
+    host_tr = jl[jl.index("function host_matvec_trampoline"):jl.index("function host_prec_trampoline")]
+    assert "unsafe_wrap(Array" in host_tr and "nk_gmres_set_operator_fn_host" in jl    # host pointers only for host operators
+    assert "nk_gmres_set_operator_jvp" in jl and "DeviceJVP" in jl                     # device JVP bound directly
+    assert "memspace(u)::Cint" in jl and "nk_device_alloc" in jl                       # resident vectors: memspace = 1
+    assert all(k in jl for k in ("termination_condition", "linesearch", "precs"))      # forwarded into NKOptions
+    info = jl[jl.index("struct GMRESInfo"):]
+    info = info[:info.index("\nend")]
+    assert re.findall(r"([a-z0-9_]+)::(Int32|Float64)", info) == [(n, "Int32" if t is C.c_int32 else "Float64")
+                                                                   for n, t in _lib.GmresInfo._fields_]

@@ -271,3 +271,33 @@ def test_trust_region_fused_step_matches_oracle(nls, scheme, concrete):
         assert abs(a["trust_region"] - b["trust_region"]) <= tol * abs(b["trust_region"]), (scheme, a, b)
     if sol.retcode == "Success":
         assert np.max(np.abs(np.asarray(sol.u.cpu()) - ref.u)) <= 1e-7 * max(1.0, np.max(np.abs(ref.u)))
+
+
+# ----------------------------------------------------------------------------- seam 1 from plain C
+def test_linsolve_seam_c_caller_matches_oracle(tmp_path):
+    """examples/linsolve_seam.c replays the reference's own call sequence against the linsolve seam
+    (NonlinearSolveBaseLinearSolveExt.jl:16-32,102-115: a new A every step → update_tolerances! → solve!) with a callback
+    operator that receives DEVICE pointers, with the bound device JVP, and with a concrete CSR; vectors stay resident
+    (nk_device_alloc, memspace NK_DEVICE). All three variants must reproduce the oracle's NewtonRaphson + GMRES(30) +
+    EisenstatWalkerForcing2 solve: same number of steps (±1), iterates within 5e-7 (loose inner solves on both sides)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "linsolve_seam"
+    libdir = os.path.join(root, "nonlinearsolve.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "linsolve_seam.c"),
+                           "-L", libdir, "-lmi355x_nk", "-lm", "-o", str(exe)])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    ns = 48
+    out = subprocess.run([str(exe), str(ns), str(tmp_path / "u")], env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ref = R.solve(R.Bratu2D(ns, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2()),
+                  abstol=1e-8, maxiters=50)
+    lines = {l.split(":")[0]: l for l in out.stdout.splitlines() if "steps=" in l}
+    assert set(lines) == {"fn", "jvp", "csr"}, out.stdout
+    for name, line in lines.items():
+        steps = int(line.split("steps=")[1].split()[0])
+        assert abs(steps - ref.stats.nsteps) <= 1 and "failed=0" in line, line
+        u = np.fromfile(str(tmp_path / f"u_{name}.bin"))
+        assert u.size == ns * ns and np.max(np.abs(u - ref.u)) <= 5e-7 * max(1.0, np.max(np.abs(ref.u))), name
+    assert int(lines["fn"].split("callback_applies=")[1]) > 0     # the device-pointer callback really carried the solve
