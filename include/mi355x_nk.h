@@ -73,7 +73,10 @@ typedef enum {
   NK_PROBLEM_USER = 100         /* user callbacks (f, jvp, vjp, jac) — NonlinearFunction fields         */
 } nk_problem_kind;
 
-typedef enum { NK_ALG_NEWTON_RAPHSON = 0, NK_ALG_TRUST_REGION = 1 } nk_algorithm;
+/* NK_ALG_GAUSS_NEWTON: NewtonDescent in NORMAL FORM, JᵀJ δ = Jᵀ f through the normal-form operator — what GaussNewton
+ * (lib/NonlinearSolveFirstOrder/src/gauss_newton.jl:11-23) does on a NonlinearLeastSquaresProblem with a Krylov linsolve
+ * (descent/newton.jl:58-95,107-118; StatefulJacobianNormalFormOperator, SciMLJacobianOperators.jl:252-291). */
+typedef enum { NK_ALG_NEWTON_RAPHSON = 0, NK_ALG_TRUST_REGION = 1, NK_ALG_GAUSS_NEWTON = 2 } nk_algorithm;
 
 /* which operator the Krylov solver sees as A (lib/NonlinearSolveBase/src/jacobian.jl:43-47,90-102) */
 typedef enum {
@@ -348,7 +351,10 @@ int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int ortho, nk_g
 int nk_gmres_destroy(nk_gmres *G);
 int nk_gmres_set_operator_csr(nk_gmres *G, nk_csr *A);                    /* cache.A = SparseMatrix   */
 int nk_gmres_set_operator_jvp(nk_gmres *G, nk_problem *P, const double *u, int memspace); /* Stateful… */
-int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);   /* AbstractSciMLOperator    */
+int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);
+/* on != 0: the operator of the next solves is AᵀA for the CSR / problem operator that is set (normal form: the
+ * transposed half is the distributed transposed SpMV or the problem's VJP); the caller passes b = Aᵀ f. */
+int nk_gmres_set_normal_form(nk_gmres *G, int on);   /* AbstractSciMLOperator    */
 /* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
 int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* The same two hooks for operators that live in HOST memory (a Julia `mul!` on plain Arrays): the callback receives host

@@ -20,7 +20,7 @@ HOST, DEVICE = 0, 1
 RET_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalLinearSolveFailed",
              "ShrinkThresholdExceeded", "MaxTime", "Failure", "InternalLineSearchFailed"]
 PROBLEM_QUADRATIC, PROBLEM_BRATU2D, PROBLEM_BRUSSELATOR2D, PROBLEM_USER = 1, 2, 3, 100
-ALG_NEWTON_RAPHSON, ALG_TRUST_REGION = 0, 1
+ALG_NEWTON_RAPHSON, ALG_TRUST_REGION, ALG_GAUSS_NEWTON = 0, 1, 2
 LINSOLVE_GMRES_MATFREE, LINSOLVE_GMRES_CSR, LINSOLVE_BANDED_LU = 0, 1, 2
 ORTHO_MGS, ORTHO_CGS2, ORTHO_CGS, ORTHO_DCGS2, ORTHO_DCGS2_1R = 0, 1, 2, 3, 4
 FORCING_NONE, FORCING_EW2 = 0, 1
@@ -138,6 +138,7 @@ SIGNATURES = {
     "nk_gmres_set_operator_csr": (_I, [_P, _P]),
     "nk_gmres_set_operator_jvp": (_I, [_P, _P, _P, _I]),
     "nk_gmres_set_operator_fn": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_normal_form": (_I, [_P, _I]),
     "nk_gmres_set_right_preconditioner": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_operator_fn_host": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_right_preconditioner_host": (_I, [_P, MATVEC_FN, _P]),

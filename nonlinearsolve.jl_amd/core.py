@@ -424,7 +424,7 @@ class NonlinearFunction:
 
 
 class NonlinearProblem:
-    """NonlinearProblem(f, u0, p). `f` is a built-in DeviceProblem or a NonlinearFunction of torch callbacks."""
+    """NonlinearProblem(f, u0, p) — also stands in for a square NonlinearLeastSquaresProblem (see the alias below). `f` is a built-in DeviceProblem or a NonlinearFunction of torch callbacks."""
 
     def __init__(self, f, u0=None, p=None, ctx: Optional[Context] = None):
         self.p = p
@@ -589,6 +589,15 @@ class TrustRegion:  # trust_region.jl:25-43
 
 
 @dataclass
+class GaussNewton:  # gauss_newton.jl:11-23: NewtonDescent; on a least-squares problem with a Krylov linsolve: normal form
+    linsolve: Optional[KrylovJL_GMRES] = None
+    concrete_jac: Optional[bool] = None
+    linesearch: Optional[BackTracking] = None
+    forcing: Optional[EisenstatWalkerForcing2] = None
+    name: str = "GaussNewton"
+
+
+@dataclass
 class _TerminationMode:
     """SciMLBase termination modes (lib/NonlinearSolveBase/src/termination_conditions.jl); `internalnorm` is
     "inf" (Base.Fix1(maximum, abs), the reference default) or "l2"."""
@@ -652,6 +661,11 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     check(L.lib().nk_options_default(C.byref(o)))
     ls = alg.linsolve
     o.algorithm = L.ALG_TRUST_REGION if isinstance(alg, TrustRegion) else L.ALG_NEWTON_RAPHSON
+    if isinstance(alg, GaussNewton):
+        if ls is None:
+            raise ValueError("GaussNewton: pass a Krylov linsolve (the normal-form operator JᵀJ is never assembled)")
+        o.algorithm = L.ALG_GAUSS_NEWTON
+        o.termination_norm = 1  # default_termination_mode(::NonlinearLeastSquaresProblem): AbsNormSafeBest on the 2-norm
     if ls is None:
         # linsolve = nothing: LinearSolve's default factorisation of the concrete sparse J → banded LU on device
         o.linsolve = L.LINSOLVE_BANDED_LU
@@ -844,6 +858,9 @@ class FirstOrderCache:
         if self._h:
             L.lib().nk_solver_destroy(self._h)
             self._h = None
+
+
+NonlinearLeastSquaresProblem = NonlinearProblem   # residual count = unknown count on this path (row-partitioned square J)
 
 
 def init(prob: NonlinearProblem, alg, **kw) -> FirstOrderCache:

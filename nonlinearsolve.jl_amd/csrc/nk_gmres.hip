@@ -719,7 +719,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
-  hipFree(G->cr); hipFree(G->cd); hipFree(G->ct); hipFree(G->cd2);
+  hipFree(G->cr); hipFree(G->cd); hipFree(G->ct); hipFree(G->cd2); hipFree(G->nrm_tmp);
   hipHostFree(G->h_ctl);
   hipHostFree(G->h_pub);
   if (G->h_stage) hipHostFree(G->h_stage);
@@ -788,9 +788,29 @@ extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, v
   return NK_OK;
 }
 
+extern "C" int nk_gmres_set_normal_form(nk_gmres *G, int on) {
+  NK_REQUIRE(G, "NULL argument");
+  NK_HIP(hipSetDevice(G->ctx->device));
+  if (on && !G->nrm_tmp) NK_TRY(nk_dev_alloc(&G->nrm_tmp, (size_t)G->ldv));
+  G->normal = on != 0;
+  return NK_OK;
+}
+
 // raw operator: y = scale · A x (no preconditioner)
 static int op_apply_raw(nk_gmres *G, const double *src, double *d_y, const int *d_skip, const double *oscale) {
   nk_ctx *ctx = G->ctx;
+  if (G->normal) {  // AᵀA x: the plain half into a work vector, the transposed half into y (scaled afterwards if asked)
+    NK_REQUIRE(G->op_kind == 1 || G->op_kind == 2, "the normal form needs a CSR or a problem operator");
+    if (G->op_kind == 1) {
+      NK_TRY(nk_csr_spmv_dev(G->A, src, G->nrm_tmp, d_skip));
+      NK_TRY(nk_csr_spmv_t_dev(G->A, G->nrm_tmp, d_y));
+    } else {
+      NK_TRY(nk_problem_jvp_dev(G->P, G->d_u, src, G->nrm_tmp, d_skip));
+      NK_TRY(nk_problem_vjp_dev(G->P, G->d_u, G->nrm_tmp, d_y));
+    }
+    if (oscale) NK_TRY(nk_blas_scale_to(ctx, G->n, oscale, d_y, d_y, d_skip));
+    return NK_OK;
+  }
   switch (G->op_kind) {
     case 1: return nk_csr_spmv_dev(G->A, src, d_y, d_skip, oscale);
     case 2: return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip, oscale);
@@ -858,7 +878,7 @@ static int cheb_apply(nk_gmres *G, const double *src, double *dst, const int *d_
     NK_LAUNCH(ctx, k_cheb_init, dim3(grid), dim3(NK_BLOCK), n, src, 1.0 / theta, G->cr, G->cd, dst, d_skip);
   }
   // concrete CSR operator: the vector update rides in the SpMV's row epilogue (d ping-pongs between two buffers)
-  const bool fuse = (G->op_kind == 1) || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D);
+  const bool fuse = !G->normal && ((G->op_kind == 1) || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D));
   double *dcur = G->cd, *dnext = G->cd2;
   for (int k = 1; k < G->cheb_degree; ++k) {
     const double rho_new = 1.0 / (2.0 * sigma1 - rho);
@@ -930,7 +950,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_gershgorin(int64_t nrows, const in
 static int estimate_lambda(nk_gmres *G, double *lambda) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n;
-  if (G->op_kind == 1) {
+  if (G->op_kind == 1 && !G->normal) {
     nk_csr *A = G->A;
     const int grid = nk_grid_for(A->nrows, NK_BLOCK, NK_MAX_RED_BLOCKS);
     NK_LAUNCH(ctx, k_gershgorin, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col, A->d_val, ctx->d_partials);

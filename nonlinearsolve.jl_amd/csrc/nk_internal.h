@@ -366,6 +366,8 @@ struct nk_gmres {
   void *fn_user = nullptr;
   nk_matvec_fn prec = nullptr;
   void *prec_user = nullptr;
+  bool normal = false;       // operator = AᵀA of the CSR / problem operator (normal form)
+  double *nrm_tmp = nullptr; // A x between the two halves
   bool fn_host = false, prec_host = false;  // the callbacks take HOST pointers: vectors are staged through h_stage
   double *h_stage = nullptr;                // pinned, 2 n doubles
   int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle

@@ -201,6 +201,7 @@ extern "C" int nk_options_default(nk_options *o) {
 static const double DEFAULT_TOL = 3.0e-13;  // common_defaults.jl:44-48
 
 static bool is_tr(const nk_solver *S) { return S->o.algorithm == NK_ALG_TRUST_REGION; }
+static bool normal_form(const nk_solver *S) { return S->o.algorithm == NK_ALG_GAUSS_NEWTON; }
 static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE; }
 static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BANDED_LU; }
 
@@ -460,7 +461,10 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   NK_REQUIRE(P && u0 && opts && out, "NULL argument");
   nk_ctx *ctx = P->ctx;
   NK_HIP(hipSetDevice(ctx->device));
-  NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION, "bad algorithm");
+  NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION ||
+                 opts->algorithm == NK_ALG_GAUSS_NEWTON, "bad algorithm");
+  NK_REQUIRE(!(opts->algorithm == NK_ALG_GAUSS_NEWTON && opts->linsolve == NK_LINSOLVE_BANDED_LU),
+             "GaussNewton in normal form needs a Krylov linsolve (JᵀJ is applied as an operator, never assembled)");
   NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_MATFREE || opts->linsolve == NK_LINSOLVE_GMRES_CSR ||
                  opts->linsolve == NK_LINSOLVE_BANDED_LU,
              "unknown linsolve %d", opts->linsolve);
@@ -495,6 +499,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     NK_TRY(nk_dev_alloc(&S->fu_trial, na));
     NK_TRY(nk_dev_alloc(&S->Jdu, na));
   }
+  if (normal_form(S)) NK_TRY(nk_dev_alloc(&S->JTfu, na));
   if (is_tr(S)) {
     NK_TRY(nk_dev_alloc(&S->fu_trial, na));
     NK_TRY(nk_dev_alloc(&S->du_newton, na));
@@ -583,7 +588,13 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
     return nk_blas_lincomb(S->ctx, S->n, -1.0, du_out, 0.0, du_out, du_out);
   }
   nk_gmres_info info;
-  NK_TRY(nk_gmres_solve_dev(S->G, S->fu, du_out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
+  const double *rhs = S->fu;
+  if (normal_form(S)) {  // JᵀJ δ = Jᵀ fu (descent/newton.jl:107-118)
+    NK_TRY(apply_JT(S, S->u, S->fu, S->JTfu));
+    NK_TRY(nk_gmres_set_normal_form(S->G, 1));
+    rhs = S->JTfu;
+  }
+  NK_TRY(nk_gmres_solve_dev(S->G, rhs, du_out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
                             S->o.gmres_fixed_iters, &info));
   S->last_gmres_iters = info.iters;
   S->stats.gmres_iters += info.iters;

@@ -646,6 +646,15 @@ class NewtonRaphson:  # raphson.jl:30-43
     name: str = "NewtonRaphson"
 
 
+@dataclass
+class GaussNewton:  # gauss_newton.jl:11-23 on a NonlinearLeastSquaresProblem: NewtonDescent in normal form when the
+    linsolve: object = None   # linear solver needs a square A (descent/newton.jl:58-95): JᵀJ δ = Jᵀ f
+    concrete_jac: Optional[bool] = None
+    linesearch: Optional[BackTracking] = None
+    forcing: Optional[EisenstatWalkerForcing2] = None
+    name: str = "GaussNewton"
+
+
 SIMPLE, NLSOLVE, NOCEDAL_WRIGHT, HEI, YUAN, BASTIN, FAN = range(7)
 
 
@@ -899,7 +908,12 @@ class FirstOrderCache:
                 lmax = gershgorin_lambda(self.J)
                 M = chebyshev_preconditioner(lambda v: self._apply_J(v, u_now), lmax / kr.precs.ratio, lmax,
                                              kr.precs.degree)
-            x, info = gmres(lambda v: self._apply_J(v, u_now), self.fu, None, atol=self.lin_abstol,
+            if isinstance(self.alg, GaussNewton):   # normal form (descent/newton.jl:107-118): JᵀJ δ = Jᵀ fu
+                rhs = self._apply_JT(self.fu, u_now)
+                op = lambda v: self._apply_JT(self._apply_J(v, u_now), u_now)  # noqa: E731
+            else:
+                rhs, op = self.fu, (lambda v: self._apply_J(v, u_now))
+            x, info = gmres(op, rhs, None, atol=self.lin_abstol,
                             rtol=self.lin_reltol, restart=kr.gmres_restart, itmax=kr.maxiters,
                             fixed_iters=kr.fixed_iters, ortho=kr.ortho, M=M)
             self.stats.gmres_iters += info.iters

@@ -301,3 +301,24 @@ def test_linsolve_seam_c_caller_matches_oracle(tmp_path):
         u = np.fromfile(str(tmp_path / f"u_{name}.bin"))
         assert u.size == ns * ns and np.max(np.abs(u - ref.u)) <= 5e-7 * max(1.0, np.max(np.abs(ref.u))), name
     assert int(lines["fn"].split("callback_applies=")[1]) > 0     # the device-pointer callback really carried the solve
+
+
+# ----------------------------------------------------------------------------- GaussNewton through the normal-form operator
+@pytest.mark.parametrize("which", ["bratu8", "brus5", "quad"])
+@pytest.mark.parametrize("concrete", [False, True])
+def test_gauss_newton_normal_form_matches_oracle(nls, which, concrete):
+    """GaussNewton(linsolve = KrylovJL_GMRES()) on a (square) least-squares problem: NewtonDescent in normal form,
+    JᵀJ δ = Jᵀ f through the normal-form operator (descent/newton.jl:58-95,107-118; SciMLJacobianOperators.jl:252-291) —
+    matrix-free (JVP then VJP) and on the concrete J (SpMV then transposed SpMV)."""
+    pb, P = {"bratu8": (R.Bratu2D(8), lambda: nls.Bratu2D(8)), "brus5": (R.Brusselator2D(5), lambda: nls.Brusselator2D(5)),
+             "quad": (R.Quadratic(20, 2.0), lambda: nls.Quadratic(20, 2.0))}[which]
+    P = P()
+    tk = dict(mode=0, norm="l2", max_stalled_steps=32)
+    ref = R.solve(pb, R.GaussNewton(linsolve=R.KrylovJL_GMRES(gmres_restart=60, maxiters=600), concrete_jac=concrete),
+                  abstol=1e-9, maxiters=50, termination_kwargs=tk)
+    prob = nls.NonlinearLeastSquaresProblem(P)
+    sol = nls.solve(prob, nls.GaussNewton(linsolve=nls.KrylovJL_GMRES(gmres_restart=60, maxiters=600), concrete_jac=concrete),
+                    abstol=1e-9, maxiters=50)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
+    assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))

@@ -445,3 +445,12 @@ def test_deferral_does_not_move_the_iterates():
         assert np.array_equal(plain.u, deferred.u) and np.array_equal(plain.fu, deferred.fu)
         assert plain.retcode == deferred.retcode
     assert plain.force_stop
+
+
+# ---- GaussNewton (gauss_newton.jl:11-23) in normal form (descent/newton.jl:58-95,107-118): same root as NewtonRaphson
+@pytest.mark.parametrize("prob", [R.Bratu2D(8), R.Brusselator2D(5), R.Quadratic(20, 2.0)])
+def test_gauss_newton_normal_form(prob):
+    tk = dict(mode=0, norm="l2", max_stalled_steps=32)   # default_termination_mode(::NonlinearLeastSquaresProblem)
+    s = R.solve(prob, R.GaussNewton(linsolve=GM(gmres_restart=60, maxiters=600)), abstol=1e-9, maxiters=50, termination_kwargs=tk)
+    ref = R.solve(prob, R.NewtonRaphson(), abstol=1e-10, maxiters=50)
+    assert s.retcode == R.SUCCESS and np.max(np.abs(s.u - ref.u)) <= 1e-8
