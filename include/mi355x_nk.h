@@ -292,6 +292,10 @@ int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, const nk_comm_
 int nk_ctx_comm_peer_handle(nk_ctx *ctx, int64_t arena_bytes, char handle_out[NK_IPC_HANDLE_BYTES]);
 int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles);
 int nk_ctx_comm_peer_status(nk_ctx *ctx, int *enabled, int64_t *errors);
+/* collective: a few all-reduces with known answers; if any rank sees a wrong value or a time-out the fast path is
+ * switched off on every rank (*ok = 0) and the base transport serves all collectives */
+int nk_ctx_comm_peer_selftest(nk_ctx *ctx, int *ok);
+int nk_ctx_comm_peer_disable(nk_ctx *ctx);   /* before any problem / matrix was created on the context */
 int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank);
 
 /* contiguous row-range partition used everywhere: rank r owns [r*n/P, (r+1)*n/P) rounded down to a

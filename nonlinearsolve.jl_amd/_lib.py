@@ -110,6 +110,8 @@ SIGNATURES = {
     "nk_ctx_comm_peer_handle": (_I, [_P, _L, C.c_char_p]),
     "nk_ctx_comm_enable_peer": (_I, [_P, C.c_char_p]),
     "nk_ctx_comm_peer_status": (_I, [_P, C.POINTER(_I), C.POINTER(_L)]),
+    "nk_ctx_comm_peer_selftest": (_I, [_P, C.POINTER(_I)]),
+    "nk_ctx_comm_peer_disable": (_I, [_P]),
     "nk_partition_range": (_I, [_L, _L, _I, _I, C.POINTER(_L), C.POINTER(_L)]),
     "nk_csr_create": (_I, [_P, _L, _L, _L, _L, _I, _I, _P, _P, _P, _I, _PP]),
     "nk_csr_create_from_csc": (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _PP]),

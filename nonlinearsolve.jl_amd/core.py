@@ -126,6 +126,14 @@ class Context:
     def comm_enable_peer(self, handles: bytes):
         check(L.lib().nk_ctx_comm_enable_peer(self._h, handles))
 
+    def comm_peer_disable(self):
+        check(L.lib().nk_ctx_comm_peer_disable(self._h))
+
+    def comm_peer_selftest(self) -> bool:
+        ok = C.c_int()
+        check(L.lib().nk_ctx_comm_peer_selftest(self._h, C.byref(ok)))
+        return bool(ok.value)
+
     def comm_peer_status(self):
         en, err = C.c_int(), C.c_int64()
         check(L.lib().nk_ctx_comm_peer_status(self._h, C.byref(en), C.byref(err)))

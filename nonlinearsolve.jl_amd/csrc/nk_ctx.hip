@@ -237,6 +237,8 @@ constexpr unsigned long long NK_PEER_TIMEOUT_TICKS = 500000000ull;  // 5 s of th
 __device__ __forceinline__ bool peer_wait_ge(const uint64_t *flag, uint64_t seq, uint64_t *err) {
   const unsigned long long t0 = wall_clock64();
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    // once a few waits have timed out the communicator is broken: fail fast instead of spending 5 s on every collective
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) return false;
     if (wall_clock64() - t0 > NK_PEER_TIMEOUT_TICKS) {  // never hang the GPU: count the time-out and go on
       atomicAdd((unsigned long long *)err, 1ull);
       return false;
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_peer_halo_xchg(const nk_peer_seg *
   }
 }
 
+static int comm_allreduce_base(nk_ctx *ctx, double *dbuf, int count, int op);
 static void nk_peer_destroy(nk_ctx *ctx) {
   nk_peer &pr = ctx->peer;
   for (int p = 0; p < pr.P; ++p)
@@ -361,6 +364,51 @@ extern "C" int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles) {
   NK_TRY(nk_dev_alloc(&pr.d_map, (size_t)NK_PEER_MAX_RANKS));
   NK_HIP(hipMemcpy(pr.d_map, pr.map, sizeof(char *) * NK_PEER_MAX_RANKS, hipMemcpyHostToDevice));
   pr.on = true;
+  return NK_OK;
+}
+
+extern "C" int nk_ctx_comm_peer_disable(nk_ctx *ctx) {
+  NK_REQUIRE(ctx, "NULL argument");
+  ctx->peer.on = false;  // plans set up so far keep their transport; new ones use the base transport
+  return NK_OK;
+}
+// A few all-reduces with known answers through the peer path, agreed on by all ranks through the base transport; on any
+// mismatch or time-out the fast path is switched off everywhere (the base transport then serves every collective).
+extern "C" int nk_ctx_comm_peer_selftest(nk_ctx *ctx, int *ok) {
+  NK_REQUIRE(ctx && ok, "NULL argument");
+  *ok = 0;
+  if (!ctx->peer.on) return NK_OK;
+  NK_HIP(hipSetDevice(ctx->device));
+  const int P = ctx->nranks, me = ctx->rank, cnt = 64;
+  std::vector<double> h(cnt);
+  double *d = nullptr;
+  NK_TRY(nk_dev_alloc(&d, (size_t)cnt + 2));
+  int bad = 0;
+  for (int round = 0; round < 4 && !bad; ++round) {
+    for (int i = 0; i < cnt; ++i) h[i] = (double)(me + 1) * (round + 1) + 0.25 * i;
+    NK_HIP(hipMemcpy(d, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+    int st = nk_comm_allreduce_mixed(ctx, d, cnt, 8, 16);  // elements 8..15 with max, the others with +
+    if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+    if (st != NK_OK) { bad = 1; break; }
+    NK_HIP(hipMemcpy(h.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; ++i) {
+      const double sum = (double)(round + 1) * P * (P + 1) / 2.0 + 0.25 * i * P, mx = (double)P * (round + 1) + 0.25 * i;
+      if (h[i] != ((i >= 8 && i < 16) ? mx : sum)) bad = 1;
+    }
+  }
+  int64_t errs = 0;
+  int en = 0;
+  NK_TRY(nk_ctx_comm_peer_status(ctx, &en, &errs));
+  if (errs != 0) bad = 1;
+  double flag = bad ? 1.0 : 0.0;
+  NK_HIP(hipMemcpy(d, &flag, sizeof(double), hipMemcpyHostToDevice));
+  int st = comm_allreduce_base(ctx, d, 1, 1);
+  if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+  if (st == NK_OK) NK_HIP(hipMemcpy(&flag, d, sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(d);
+  NK_TRY(st);
+  if (flag != 0.0) ctx->peer.on = false;
+  *ok = ctx->peer.on ? 1 : 0;
   return NK_OK;
 }
 

@@ -35,8 +35,12 @@ def init_comm(ctx: core.Context, transport: str | None = None) -> str:
     transport = transport or os.environ.get("NK_COMM", "rccl" if _backend() == "nccl" else "torch")
     if transport == "peer":
         base = init_comm(ctx, os.environ.get("NK_COMM_BASE", "rccl" if _backend() == "nccl" else "torch"))
-        enable_peer(ctx)
-        return "peer+" + base
+        try:
+            ok = enable_peer(ctx)
+        except Exception as ex:  # noqa: BLE001 — e.g. no IPC between these devices: every rank fails alike
+            print(f"[nk dist] peer path unavailable on rank {rank}: {ex}")
+            ok = False
+        return ("peer+" + base) if ok else base + "(peer path unavailable)"
     if transport == "rccl":
         dev = torch.device("cuda", ctx.device)
         if rank == 0:
@@ -54,14 +58,29 @@ def init_comm(ctx: core.Context, transport: str | None = None) -> str:
     raise ValueError(f"unknown transport {transport!r}")
 
 
-def enable_peer(ctx: core.Context, arena_bytes: int = 0):
-    """Layer the peer-mapped fast path over an initialised communicator (collective)."""
+def enable_peer(ctx: core.Context, arena_bytes: int = 0) -> bool:
+    """Layer the peer-mapped fast path over an initialised communicator (collective). Every decision is taken by all
+    ranks together: a rank that cannot export or map an arena makes everybody stay on the base transport."""
     world = dist.get_world_size()
-    mine = ctx.comm_peer_handle(arena_bytes)
+    try:
+        mine = ctx.comm_peer_handle(arena_bytes)
+    except Exception as ex:  # noqa: BLE001
+        mine = repr(ex)
     parts = [None] * world
     dist.all_gather_object(parts, mine)
-    ctx.comm_enable_peer(b"".join(parts))
-    dist.barrier()
+    if not all(isinstance(h, bytes) for h in parts):
+        return False
+    try:
+        ctx.comm_enable_peer(b"".join(parts))
+        mapped = True
+    except Exception:  # noqa: BLE001
+        mapped = False
+    flags = [None] * world
+    dist.all_gather_object(flags, mapped)
+    if not all(flags):
+        ctx.comm_peer_disable()
+        return False
+    return ctx.comm_peer_selftest()   # collective verdict: all ranks keep the fast path, or none does
 
 
 def _init_torch_callbacks(ctx: core.Context, world: int, rank: int):
