@@ -1282,26 +1282,35 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     {
       const bool one_red = use_dcgs2r(G);
       const int ahead = (fixed_iters > 0 || G->run_ahead <= 0) ? 0 : (G->prec_kind == 3 ? 1 : G->run_ahead);
+      // Every rank must enqueue the SAME number of steps (each carries collectives): the stop is therefore not "when this
+      // host happens to see `done`" but a function of K, the number of columns closed when the device raised it — a value
+      // all ranks compute identically. A host is never more than ahead + one_red steps past the step that closes column K,
+      // so "enqueue exactly the steps below K + ahead + one_red" is reachable by all of them.
       bool stopped = false;
-      for (int k = 0; k < steps && !stopped; ++k) {
-        if (ahead > 0) {
+      int stop_at = steps;
+      for (int k = 0; k < stop_at; ++k) {
+        if (ahead > 0 && !stopped) {
           // column j closes in step j (plain forms) or in step j+1 (one-reduction form): wait until step k−ahead is done
           const int need = k - ahead - (one_red ? 1 : 0);
           auto ready = [&] {
             const uint64_t w = __atomic_load_n(&pub->progress, __ATOMIC_ACQUIRE);
             if ((w >> 16) != seq) return false;  // k_gmres_begin of this cycle has not run yet
-            if (w & 1) { stopped = true; return true; }
+            if (w & 1) {
+              stopped = true;
+              const int K = (int)((w >> 1) & 0x7fff);
+              stop_at = K + ahead + (one_red ? 1 : 0) < steps ? K + ahead + (one_red ? 1 : 0) : steps;
+              return true;
+            }
             return (int)((w >> 1) & 0x7fff) >= need;
           };
-          if (need >= 0 || k > 0) {
-            if (need >= 0) NK_TRY(nk_spin_wait(ctx, ready, "GMRES progress"));
-            else (void)ready();  // no need to wait yet, but a raised `done` stops the enqueueing
-          }
-          if (stopped) break;
+          if (need >= 0) NK_TRY(nk_spin_wait(ctx, ready, "GMRES progress"));
+          else (void)ready();  // nothing to wait for yet, but a raised `done` fixes the stop
+          if (k >= stop_at) break;
         }
         NK_TRY(one_red ? arnoldi_step_1r(G, k, k == steps - 1) : arnoldi_step(G, k));
       }
-      if (one_red && !stopped) NK_TRY(arnoldi_flush_1r(G, steps));
+      // (the flush is a no-op on the device once `done` is up; whether it is ENQUEUED must not depend on what this host saw)
+      if (one_red && stop_at == steps) NK_TRY(arnoldi_flush_1r(G, steps));
     }
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns); the back-substitution also publishes the control
     // block's outcome to the host

@@ -152,20 +152,42 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp_tile(int ns, int nl, dou
     }
   }
 }
-// values in pattern order [S?][W?][C][E?][N?] (columns ascending); j = global grid line
+// values in pattern order [S?][W?][C][E?][N?] (columns ascending); j = global grid line. A workgroup owns 256 consecutive
+// rows = one contiguous run of ≤ 1280 non-zeros: every thread lays its row's ≤ 5 values out in LDS, then the run goes to
+// memory with lane-contiguous stores (a thread writing its own row straight to memory stores 8 bytes every 40: the first
+// version of this kernel ran at 2.1 TB/s, 24 µs at 1024²).
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
                                                         double c_exp, const double *__restrict__ u,
                                                         const int32_t *__restrict__ rowptr,
                                                         double *__restrict__ vals) {
-  const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
-  if (k >= ns * nl) return;
-  const int64_t jl = k / ns, i = k - jl * ns, j = j0 + jl;
-  int32_t p = rowptr[k];
-  if (j > 0) vals[p++] = -c_lap;
-  if (i > 0) vals[p++] = -c_lap;
-  vals[p++] = 4.0 * c_lap - c_exp * exp(u[k]);
-  if (i < ns - 1) vals[p++] = -c_lap;
-  if (j < ns - 1) vals[p++] = -c_lap;
+  __shared__ double sv[5 * NK_BLOCK];
+  __shared__ int32_t s_p0, s_p1;
+  const int64_t n = ns * nl, r0 = (int64_t)blockIdx.x * NK_BLOCK;
+  const int64_t k = r0 + threadIdx.x;
+  const int64_t rlast = (r0 + NK_BLOCK < n ? r0 + NK_BLOCK : n);
+  if (threadIdx.x == 0) { s_p0 = rowptr[r0]; s_p1 = rowptr[rlast]; }
+  int32_t p = 0;
+  double d = 0.0;
+  int64_t i = 0, j = 0;
+  if (k < n) {
+    const int64_t jl = k / ns;
+    i = k - jl * ns;
+    j = j0 + jl;
+    p = rowptr[k];
+    d = 4.0 * c_lap - c_exp * exp(u[k]);
+  }
+  __syncthreads();
+  const int32_t p0 = s_p0, nnzb = s_p1 - s_p0;
+  if (k < n) {
+    int q = p - p0;
+    if (j > 0) sv[q++] = -c_lap;
+    if (i > 0) sv[q++] = -c_lap;
+    sv[q++] = d;
+    if (i < ns - 1) sv[q++] = -c_lap;
+    if (j < ns - 1) sv[q++] = -c_lap;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < nnzb; q += NK_BLOCK) vals[p0 + q] = sv[q];
 }
 
 // ============================================================================ Brusselator 2-D
