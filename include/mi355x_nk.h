@@ -209,6 +209,11 @@ typedef struct {
    *     new Jacobian like `precs(A, p)`: mg_nu smoothing steps (0 = off), coarsest grid side ≤ mg_coarse (0 → 31) */
   int32_t mg_nu;
   int32_t mg_coarse;
+  /* --- concrete Jacobian of the built-in problems: 0 = closed-form values (what `f.jac` would supply), 1 = the
+   *     colour-compressed assembly of `AutoSparse` + column colouring (ncolors seeded JVPs + decompression,
+   *     lib/NonlinearSolveBase/src/jacobian.jl:244-247) every time the Jacobian is refreshed */
+  int32_t jac_colored;
+  int32_t reserved0;
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)

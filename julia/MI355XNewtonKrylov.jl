@@ -288,6 +288,7 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     cheb_ratio::Float64 = 300.0
     mg_nu::Int = 2
     mg_coarse::Int = 31
+    jac_colored::Bool = false             # concrete J by colour-compressed assembly (AutoSparse analogue) instead of f.jac
 end
 
 # termination_condition → nk_options.termination_mode / termination_norm and the mode struct's fields
@@ -328,6 +329,7 @@ Base.@kwdef mutable struct NKOptions
     cheb_degree::Int32 = 0; linesearch::Int32 = 0; cheb_ratio::Float64 = 0.0
     ls_c1::Float64 = 1e-4; ls_rho_hi::Float64 = 0.5; ls_rho_lo::Float64 = 0.1; ls_order::Int32 = 3; ls_maxiters::Int32 = 1000
     mg_nu::Int32 = 0; mg_coarse::Int32 = 0
+    jac_colored::Int32 = 0; reserved0::Int32 = 0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,
@@ -345,7 +347,8 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
         forcing = alg.forcing ? 1 : 0, radius_update_scheme = alg.radius_update_scheme,
         linesearch = alg.linesearch === :BackTracking ? 1 : 0,
         cheb_degree = alg.precs === :chebyshev ? alg.cheb_degree : 0, cheb_ratio = alg.cheb_ratio,
-        mg_nu = alg.precs === :multigrid ? alg.mg_nu : 0, mg_coarse = alg.mg_coarse)
+        mg_nu = alg.precs === :multigrid ? alg.mg_nu : 0, mg_coarse = alg.mg_coarse,
+        jac_colored = alg.jac_colored ? 1 : 0)
     apply_termination!(o, termination_condition)
     # u0 may be a host Array (copied in and out once) or already resident (DeviceVector / ROCArray): no PCIe traffic then
     u0 = prob.u0 isa Array ? Vector{Float64}(vec(prob.u0)) : vec(prob.u0)

@@ -67,6 +67,7 @@ class Options(C.Structure):
         ("cheb_degree", C.c_int32), ("linesearch", C.c_int32), ("cheb_ratio", C.c_double),
         ("ls_c1", C.c_double), ("ls_rho_hi", C.c_double), ("ls_rho_lo", C.c_double),
         ("ls_order", C.c_int32), ("ls_maxiters", C.c_int32), ("mg_nu", C.c_int32), ("mg_coarse", C.c_int32),
+        ("jac_colored", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

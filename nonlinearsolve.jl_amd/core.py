@@ -577,6 +577,7 @@ class NewtonRaphson:  # raphson.jl:30-43
     forcing: Optional[EisenstatWalkerForcing2] = None
     concrete_jac: Optional[bool] = None
     linesearch: Optional[BackTracking] = None   # `missing` in the reference = no line search
+    jac_colored: bool = False
     name: str = "NewtonRaphson"
 
 
@@ -593,6 +594,7 @@ class TrustRegion:  # trust_region.jl:25-43
     expand_factor: float = 2.0
     max_shrink_times: int = 32
     concrete_jac: Optional[bool] = None
+    jac_colored: bool = False   # concrete J by colour-compressed assembly (sparse AD analogue) instead of closed-form values
     name: str = "TrustRegion"
 
 
@@ -697,6 +699,7 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
         o.mg_nu, o.mg_coarse = int(ls.precs.nu), int(ls.precs.coarse_max)
     elif getattr(ls, "precs", None) is not None:
         o.cheb_degree, o.cheb_ratio = int(ls.precs.degree), float(ls.precs.ratio)
+    o.jac_colored = int(bool(getattr(alg, "jac_colored", False)))
     fo = getattr(alg, "forcing", None)
     if fo is not None:
         o.forcing = L.FORCING_EW2

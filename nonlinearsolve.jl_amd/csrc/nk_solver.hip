@@ -195,6 +195,8 @@ extern "C" int nk_options_default(nk_options *o) {
   o->ls_maxiters = 1000;
   o->mg_nu = 0;
   o->mg_coarse = 0;
+  o->jac_colored = 0;
+  o->reserved0 = 0;
   return NK_OK;
 }
 
@@ -226,6 +228,14 @@ static int residual_norms(nk_solver *S, const double *stall_partials, int stall_
   return NK_OK;
 }
 
+// jac_cache(u) for a concrete J: closed-form values, or — jac_colored — the colour-compressed assembly
+static int refresh_J(nk_solver *S) {
+  if (S->o.jac_colored && S->P->kind != NK_PROBLEM_USER) NK_TRY(nk_problem_jac_colored_dev(S->P, S->u, S->J));
+  else NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
+  S->stats.njacs++;
+  S->lu_valid = false;
+  return NK_OK;
+}
 static int apply_J(nk_solver *S, const double *v, double *out) {
   if (concrete(S)) return nk_csr_spmv_dev(S->J, v, out, nullptr);
   return nk_problem_jvp_dev(S->P, S->u, v, out, nullptr);
@@ -436,11 +446,7 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   S->fu_deferred = false;
   NK_TRY(residual_norms(S, nullptr, 0, nullptr));
   NK_TRY(tc_reinit(S));
-  if (concrete(S)) {  // jacobian.jl:104-118 evaluates J once at init
-    NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
-    S->stats.njacs++;
-    S->lu_valid = false;
-  }
+  if (concrete(S)) NK_TRY(refresh_J(S));  // jacobian.jl:104-118 evaluates J once at init
   NK_TRY(nk_blas_fill(ctx, S->n, 0.0, S->du));  // descent/newton.jl:34-36
   S->eta = S->o.ew_eta0;
   S->rnorm = S->rnorm_prev = S->fnorm2;
@@ -909,9 +915,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
   bool new_jacobian;
   if ((recompute < 0 || recompute == 1) && S->make_new_jacobian) {
     if (concrete(S)) {
-      NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
-      S->stats.njacs++;
-      S->lu_valid = false;
+      NK_TRY(refresh_J(S));
     } else {
       NK_TRY(nk_gmres_set_operator_jvp(S->G, S->P, S->u, NK_DEVICE));  // StatefulJacobianOperator(J, u, p)
     }

@@ -143,3 +143,38 @@ def test_bratu_1024_multigrid_precs_reaches_tolerance_in_a_handful_of_krylov_ite
                                            forcing=nls.EisenstatWalkerForcing2()), abstol=1e-8, maxiters=50)
     assert ch.retcode == "Success" and float((mg.u - ch.u).abs().max()) < 1e-4
     assert abs(float(mg.u.max()) - 0.797) < 2e-3     # the λ = 6 lower-branch solution peaks at ≈ 0.797
+
+
+def test_c5_brusselator512_trust_region_vs_direct_solve_oracle(nls, dev):
+    """Config C5 as BASELINE.json words it, at full size: Brusselator 2-D steady state, N_g = 512 (524 288 unknowns),
+    TrustRegion + GMRES(30) on the concrete sparse Jacobian assembled by colour-compressed sweeps every step (and, second
+    run, closed-form values), Chebyshev polynomial behind the `precs` hook. Compared with the CPU oracle's TrustRegion()
+    with a DIRECT linear solve at the same size (tests/golden/c5_brusselator512_tr_direct.npz, generated by
+    tests/golden/make_c5_golden.py — SuperLU, minutes): same number of steps, same accept/reject sequence, the iterate
+    at 8 192 sample points and its norms within 1e-6 relative (inner solves at rtol 1e-9 vs exact ones), and
+    ‖f(u)‖∞ ≤ abstol confirmed by the C oracle's residual on the whole vector."""
+    import os
+    import torch
+    from oracle import c_oracle as COr
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_brusselator512_tr_direct.npz")
+    g = np.load(path)
+    N = int(g["N"])
+    assert N == 512
+    P = nls.Brusselator2D(N)
+    for colored in (True, False):
+        prob = nls.NonlinearProblem(P, u0=P.initial_guess(device=True))
+        alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=6000, reltol=1e-9, abstol=0.0,
+                                                          precs=nls.ChebyshevPrecs(32, 300.0)),
+                              concrete_jac=True, jac_colored=colored)
+        sol = nls.solve(prob, alg, abstol=1e-8, maxiters=30, store_trace=True)
+        u = sol.u.cpu().numpy()
+        assert sol.retcode == "Success"
+        assert sol.stats.nsteps == int(g["nsteps"])
+        assert [int(t["accepted"]) for t in sol.trace] == list(g["accepted"])
+        assert np.allclose([t["trust_region"] for t in sol.trace], g["trust_region"], rtol=1e-6)
+        scale = float(g["u_inf"])
+        assert np.max(np.abs(u[::int(g["stride"])] - g["u_samples"])) <= 1e-6 * scale
+        assert abs(np.linalg.norm(u) - float(g["u_l2"])) <= 1e-6 * float(g["u_l2"]) and abs(np.max(np.abs(u)) - scale) <= 1e-6 * scale
+        f = COr.brusselator_residual(N, 3.4, 1.0, 10.0, 1.0 / (N - 1), u)
+        assert np.max(np.abs(f)) <= 1e-8
+        assert sol.stats.njacs == sol.stats.nsteps + 1 or sol.stats.njacs >= 1
