@@ -123,37 +123,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
   }
 }
 
-// experiment (NOT bit-compatible with the sequential row sum): 8 lanes per row, shuffle reduction, no LDS
-__global__ __launch_bounds__(NK_BLOCK) void k_spmv_vec8(int64_t nrows, const int32_t *__restrict__ rowptr,
-                                                        const int32_t *__restrict__ col, const double *__restrict__ val,
-                                                        const double *__restrict__ x, const double *__restrict__ xhalo,
-                                                        int32_t nlocal, double *__restrict__ y, const int *d_skip,
-                                                        const double *__restrict__ out_scale) {
-  if (d_skip != nullptr && *d_skip != 0) return;
-  const double os = out_scale ? *out_scale : 1.0;
-  const int lane8 = threadIdx.x & 7;
-  const int64_t gstride = (int64_t)gridDim.x * (NK_BLOCK / 8);
-  for (int64_t r = (int64_t)blockIdx.x * (NK_BLOCK / 8) + (threadIdx.x >> 3); r < nrows; r += gstride) {
-    const int a = rowptr[r], e = rowptr[r + 1];
-    double s = 0.0;
-    for (int k = a + lane8; k < e; k += 8) {
-      const int c = col[k];
-      s += val[k] * ((c < nlocal) ? x[c] : xhalo[c - nlocal]);
-    }
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 1, 64);
-    if (lane8 == 0) y[r] = os * s;
-  }
-}
-
-static int spmv_tile_from_env() {
-  const char *e = getenv("NK_SPMV_TILE");
-  int t = e ? atoi(e) : 1024;  // measured best on MI355X (tools/microbench.py)
-  if (t != 512 && t != 1024 && t != 2048 && t != 4096) t = 1024;
-  return t;
-}
-static int spmv_variant_from_env() {  // 0 rolled, 1 batched loads, 2 rolled/no XCD remap, 3 vec8 experiment
+static int spmv_variant_from_env() {  // 0 rolled, 1 batched loads, 2 rolled/no XCD remap
   const char *e = getenv("NK_SPMV_VARIANT");
   return e ? atoi(e) : 0;
 }
@@ -491,7 +461,7 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   nk_spmv_epi ep{};
   if (epi) ep = *epi;
   // halo overlap: interior row blocks run while the exchange is in flight on the communication stream
-  const bool overlap = A->halo.active() && ctx->halo_overlap && ctx->nranks > 1 && A->variant != 3 &&
+  const bool overlap = A->halo.active() && ctx->halo_overlap && ctx->nranks > 1 &&
                        A->nblocks_interior > 0 && A->nblocks_interior < A->nblocks;
   if (A->halo.active()) NK_TRY(overlap ? nk_halo_exchange_begin(ctx, &A->halo, d_x) : nk_halo_exchange(ctx, &A->halo, d_x));
   ctx->stats.op_applies++;
@@ -507,11 +477,7 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   else if (A->tile == 4096) SPMV_LAUNCH(4096, H, R);      \
   else SPMV_LAUNCH(1024, H, R)
     const bool halo = A->halo.n_recv > 0;
-    if (A->variant == 3 && ep.mode == 0) {
-      const int grid = nk_grid_for(A->nrows, NK_BLOCK / 8, 1 << 20);
-      NK_LAUNCH(ctx, k_spmv_vec8, dim3(grid), dim3(NK_BLOCK), A->nrows, A->d_rowptr, A->d_col, A->d_val, d_x,
-                A->halo.d_recv, (int32_t)A->nrows, d_y, d_skip, d_out_scale);
-    } else {
+    {
       const int nparts = overlap ? 2 : 1;
       for (int part = 0; part < nparts; ++part) {
         const int b0_ = (overlap && part == 1) ? A->nblocks_interior : 0;

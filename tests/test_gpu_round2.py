@@ -322,3 +322,63 @@ def test_gauss_newton_normal_form_matches_oracle(nls, which, concrete):
     assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
     assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
     assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))
+
+
+# ----------------------------------------------------------------------------- prepare_vjp / prepare_jvp fallbacks (a11)
+def _nonsym_problem(dev, n):
+    """A residual with a non-symmetric tridiagonal Jacobian (so that Jᵀv ≠ Jv): f_i = 3u_i − 2u_{i−1} − 0.5u_{i+1} + 0.1u_i³ − b_i"""
+    import torch
+    bvec = torch.linspace(0.5, 1.5, n, dtype=torch.float64, device=dev)
+
+    def F(du, u, p):
+        du.copy_(3.0 * u + 0.1 * u ** 3 - bvec)
+        du[1:] -= 2.0 * u[:-1]
+        du[:-1] -= 0.5 * u[1:]
+
+    def J_dense(u):
+        return np.diag(3.0 + 0.3 * u * u) - 2.0 * np.diag(np.ones(n - 1), -1) - 0.5 * np.diag(np.ones(n - 1), 1)
+
+    def Fo(u):
+        f = 3.0 * u + 0.1 * u ** 3 - np.linspace(0.5, 1.5, n)
+        f[1:] -= 2.0 * u[:-1]
+        f[:-1] -= 0.5 * u[1:]
+        return f
+    return F, Fo, J_dense
+
+
+@pytest.mark.parametrize("with_jac", [True, False])
+def test_vjp_and_jvp_fall_back_to_the_jacobian(nls, dev, with_jac):
+    """prepare_vjp / prepare_jvp without f.vjp / f.jvp (SciMLJacobianOperators.jl:296-362, 373-431): with f.jac the
+    operators are J·v and Jᵀ·v on the jac_prototype pattern; with only a jac_prototype the Jacobian comes from the
+    colour-compressed finite-difference assembly (the AutoSparse(AutoFiniteDiff) analogue). TrustRegion — which needs
+    Jᵀ fu every step — then runs matrix-free on a problem that supplies neither jvp nor vjp."""
+    import scipy.sparse as sp
+    import torch
+    n = 60
+    F, Fo, J_dense = _nonsym_problem(dev, n)
+    pat = sp.csr_matrix(sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1]))
+    proto = nls.CSRMatrix.from_scipy(pat)
+    dpos = torch.tensor(np.flatnonzero(pat.indices == np.repeat(np.arange(n), np.diff(pat.indptr))), device=dev)
+    lpos = torch.tensor(np.flatnonzero(pat.indices == np.repeat(np.arange(n), np.diff(pat.indptr)) - 1), device=dev)
+    upos = torch.tensor(np.flatnonzero(pat.indices == np.repeat(np.arange(n), np.diff(pat.indptr)) + 1), device=dev)
+
+    def jac(nzval, u, p):
+        nzval[dpos] = 3.0 + 0.3 * u * u
+        nzval[lpos] = -2.0
+        nzval[upos] = -0.5
+
+    f = nls.NonlinearFunction(F, jac=jac if with_jac else None, jac_prototype=proto)
+    prob = nls.NonlinearProblem(f, torch.zeros(n, dtype=torch.float64, device=dev))
+    u = np.linspace(-1.0, 1.0, n)
+    v = np.cos(np.arange(n))
+    ud, vd = torch.tensor(u, device=dev), torch.tensor(v, device=dev)
+    Jop = nls.StatefulJacobianOperator(nls.JacobianOperator(prob), ud)
+    tol = 1e-12 if with_jac else 1e-6
+    assert np.max(np.abs((Jop @ vd).cpu().numpy() - J_dense(u) @ v)) <= (tol if with_jac else 1e-6) * 10
+    assert np.max(np.abs((Jop.T @ vd).cpu().numpy() - J_dense(u).T @ v)) <= tol * 10
+    ref = R.solve(R.FunctionProblem(Fo, np.zeros(n), jac=lambda w: sp.csr_matrix(J_dense(w))),
+                  R.TrustRegion(linsolve=R.KrylovJL_GMRES(gmres_restart=60, maxiters=600)), abstol=1e-10, maxiters=50)
+    sol = nls.solve(prob, nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=60, maxiters=600)), abstol=1e-10, maxiters=50)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
+    assert np.max(np.abs(sol.u.cpu().numpy() - ref.u)) <= 1e-7
