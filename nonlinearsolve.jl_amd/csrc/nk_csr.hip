@@ -123,6 +123,12 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
   }
 }
 
+static int spmv_tile_from_env() {
+  const char *e = getenv("NK_SPMV_TILE");
+  int t = e ? atoi(e) : 1024;  // measured best on MI355X (tools/microbench.py)
+  if (t != 512 && t != 1024 && t != 2048 && t != 4096) t = 1024;
+  return t;
+}
 static int spmv_variant_from_env() {  // 0 rolled, 1 batched loads, 2 rolled/no XCD remap
   const char *e = getenv("NK_SPMV_VARIANT");
   return e ? atoi(e) : 0;
