@@ -166,7 +166,7 @@ def test_c5_brusselator512_trust_region_vs_direct_solve_oracle(nls, dev):
     for colored in (True, False):
         prob = nls.NonlinearProblem(P, u0=P.initial_guess(device=True))
         alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=6000, reltol=1e-9, abstol=0.0,
-                                                          precs=nls.ChebyshevPrecs(32, 300.0)),
+                                                          precs=nls.ChebyshevPrecs(128, 1.0e4)),
                               concrete_jac=True, jac_colored=colored)
         sol = nls.solve(prob, alg, abstol=1e-8, maxiters=30, store_trace=True)
         u = sol.u.cpu().numpy()

@@ -382,3 +382,35 @@ def test_vjp_and_jvp_fall_back_to_the_jacobian(nls, dev, with_jac):
     assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
     assert abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
     assert np.max(np.abs(sol.u.cpu().numpy() - ref.u)) <= 1e-7
+
+
+def test_direct_linsolve_falls_back_when_the_band_lu_needs_pivoting(nls, dev):
+    """`linsolve = nothing` on a Jacobian whose LU needs row exchanges (zero main diagonal): the reference's default
+    solver pivots (and falls back LU → QR when a factorisation is unusable), so the solve succeeds there; the device's band
+    LU does not pivot — its a-posteriori check (‖Jx − b‖ ≤ 1e-10‖b‖ after one refinement step) rejects the factorisation
+    and GMRES on the same concrete J takes over instead of reporting InternalLinearSolveFailed."""
+    import scipy.sparse as sp
+    import torch
+    n = 40
+    W = sp.csr_matrix(sp.diags([np.ones(n - 1), 1e-300 * np.ones(n), np.ones(n - 1)], [-1, 0, 1]))   # pattern incl. diagonal
+    Wz = sp.csr_matrix(sp.diags([np.ones(n - 1), np.ones(n - 1)], [-1, 1]))
+    bvec = np.arange(1.0, n + 1)
+    proto = nls.CSRMatrix.from_scipy(W)
+    Wd = nls.CSRMatrix.from_scipy(Wz)
+    bd = torch.tensor(bvec, device=dev)
+    vals = torch.tensor(sp.csr_matrix(W).data, device=dev).clone()
+    vals[torch.tensor(np.flatnonzero(W.indices == np.repeat(np.arange(n), np.diff(W.indptr))), device=dev)] = 0.0
+
+    def resid(F, z, p):
+        Wd.matvec(z, out=F)
+        F.sub_(bd)
+
+    def jac(nzval, z, p):
+        nzval.copy_(vals)
+
+    prob = nls.NonlinearProblem(nls.NonlinearFunction(resid, jac=jac, jac_prototype=proto), torch.zeros(n, dtype=torch.float64, device=dev))
+    sol = nls.solve(prob, nls.NewtonRaphson(), abstol=1e-9)
+    ref = R.solve(R.FunctionProblem(lambda u: Wz @ u - bvec, np.zeros(n), jac=lambda u: Wz), R.NewtonRaphson(), abstol=1e-9)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert sol.stats.nsteps == ref.stats.nsteps
+    assert np.max(np.abs(sol.u.cpu().numpy() - ref.u)) <= 1e-8 * np.max(np.abs(ref.u))
