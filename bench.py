@@ -94,11 +94,10 @@ def cpu_baseline(ns, arnoldi, matfree, budget_s):
     """The oracle's tuned CPU leg on this box's host cores (rank 0, N = 1 only): bounded sample of the same workload, in a
     child process so that the OpenMP runtime starts bound to the cores and waits actively (oracle/cpu_leg.py)."""
     env = dict(os.environ)
-    # one thread per CPU this process may run on (the affinity mask, not the machine's thread count: the GPU box hands the
-    # job a subset), bound in order; places are left to the runtime, which derives them from the same mask
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    env.update(OMP_NUM_THREADS=str(ncpu), OMP_PROC_BIND="close")
-    env.pop("OMP_PLACES", None)
+    # threads spread over the cores of the affinity mask; the leg itself picks the thread count (all hardware threads, half,
+    # a quarter) by the STREAM triad it measures — SMT siblings and container CPU quotas make "all of them" a bad default
+    env.pop("OMP_NUM_THREADS", None)
+    env.update(OMP_PLACES="cores", OMP_PROC_BIND="spread")
     env.pop("OMP_WAIT_POLICY", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_leg.py"), str(ns), str(arnoldi),
                           str(int(bool(matfree))), str(budget_s)], env=env, capture_output=True, text=True,

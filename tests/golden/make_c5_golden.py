@@ -20,6 +20,8 @@ pb = R.Brusselator2D(N)
 t = time.time()
 s = R.solve(pb, R.TrustRegion(), abstol=1e-8, maxiters=30)
 dt = time.time() - t
+print("retcode", R.RETCODE_NAMES[s.retcode], "nsteps", s.stats.nsteps, "fnorm", [r["fnorm_inf"] for r in s.trace],
+      "accepted", [int(r["accepted"]) for r in s.trace], "seconds", round(dt, 1), flush=True)
 assert s.retcode == R.SUCCESS and np.max(np.abs(pb.f(s.u))) <= 1e-8
 out = dict(N=N, nsteps=s.stats.nsteps, accepted=np.array([int(r["accepted"]) for r in s.trace]),
            trust_region=np.array([r["trust_region"] for r in s.trace]), fnorm_inf=np.array([r["fnorm_inf"] for r in s.trace]),
