@@ -93,6 +93,51 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum(const double *__restric
     out[blockIdx.x] = v;
   }
 }
+// Stage-2 reduction AND all-reduce in one launch (several ranks, peer-mapped arenas — nk_ctx.hip): workgroup s sums slot s
+// in the fixed order and stores the sum straight into slot s of EVERY rank's arena; the workgroup that takes the last ticket
+// releases this rank's flag everywhere, waits for every rank's flag here and combines the nslots values in rank order into
+// `out`. The collective part runs even when the cycle is done (d_skip): every rank must execute every collective.
+__global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum_allreduce(const double *__restrict__ partials, int nblk,
+                                                                   double *__restrict__ out, nk_peer_ar_view pv) {
+  __shared__ double sm[4];
+  __shared__ unsigned int s_last;
+  const int par = (int)(pv.seq & 1), slot = blockIdx.x, nslots = gridDim.x;
+  const double *p = partials + (size_t)slot * nblk;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) v += p[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    for (int q = 0; q < pv.P; ++q) reinterpret_cast<nk_peer_hdr *>(pv.map[q])->ar_data[par][pv.me][slot] = v;
+    __threadfence_system();
+    s_last = (atomicAdd(pv.ticket, 1u) == (unsigned)nslots - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup of this rank: every slot of mine has landed everywhere
+  const int t = threadIdx.x;
+  nk_peer_hdr *mine = reinterpret_cast<nk_peer_hdr *>(pv.map[pv.me]);
+  if (t == 0) *pv.ticket = 0u;
+  __threadfence_system();
+  if (t < pv.P) {
+    __hip_atomic_store(&reinterpret_cast<nk_peer_hdr *>(pv.map[t])->ar_flag[par][pv.me], pv.seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&mine->ar_flag[par][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < pv.seq) {
+      if (__hip_atomic_load(&mine->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) break;
+      if (wall_clock64() - t0 > 500000000ull) { atomicAdd((unsigned long long *)&mine->err, 1ull); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (t < nslots) {
+    double acc = mine->ar_data[par][0][t];
+    for (int q = 1; q < pv.P; ++q) acc += mine->ar_data[par][q][t];
+    out[t] = acc;
+  }
+}
 __global__ __launch_bounds__(NK_BLOCK) void k_reduce_nanmax(const double *__restrict__ partials, int nblk,
                                                             double *__restrict__ out, double sign) {
   __shared__ double sm[4];
@@ -563,13 +608,15 @@ int nk_blas_dcgs2r_dots(nk_ctx *ctx, int64_t n, int k, bool flush, const double 
     if (flush) NK_LAUNCH(ctx, k_dcgs2r_dots<false>, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, ctx->d_partials, d_skip);
     else NK_LAUNCH(ctx, k_dcgs2r_dots<true>, dim3(grid), dim3(NK_BLOCK), n, k, V, ldv, ctx->d_partials, d_skip);
   }
+  const nk_peer_ar_view pv = nk_peer_ar_next(ctx, nslots);
   {
     nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
-    NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), ctx->d_partials, grid, d_red, d_skip,
-              (const double *)nullptr, 0);
+    if (pv.seq) NK_LAUNCH(ctx, k_reduce_sum_allreduce, dim3(nslots), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, d_red, pv);
+    else NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), ctx->d_partials, grid, d_red, d_skip,
+                   (const double *)nullptr, 0);
   }
   NK_HIP(hipGetLastError());
-  return nk_comm_allreduce(ctx, d_red, nslots, 0);
+  return pv.seq ? NK_OK : nk_comm_allreduce(ctx, d_red, nslots, 0);
 }
 
 // d_ss_out != nullptr: also ‖z_new‖² (all-reduced) into *d_ss_out — the cycle's last step

@@ -45,17 +45,53 @@ __device__ __forceinline__ void spmv_store_row(int row, double s, double *__rest
   }
 }
 
+// The halo exchange inside the SpMV launch (peer-mapped arenas, several ranks): the first `nsegs` workgroups to be
+// dispatched first store this rank's entries for neighbour s into that neighbour's receive area and release the flag over
+// there; a workgroup whose row block reads halo columns (descriptor index ≥ wait_from — they are ordered last) waits for
+// every neighbour's flag before it gathers. Pushes never wait for anything, so no cycle can form; one launch less per
+// operator application than the separate exchange kernel.
+struct nk_spmv_xchg {
+  const nk_peer_seg *segs = nullptr;
+  const int32_t *send_idx = nullptr;
+  uint64_t *err = nullptr;
+  uint64_t seq = 0;
+  int nsegs = 0, wait_from = 0;
+};
 template <int TILE, bool HALO, bool REMAP>
 __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
     int nblk, const int4 *__restrict__ rowblocks, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
     const double *__restrict__ xhalo, int32_t nlocal, double *__restrict__ y, const int *d_skip,
-    const double *__restrict__ out_scale, const nk_spmv_epi epi, const int16_t *__restrict__ col16, int n16) {
+    const double *__restrict__ out_scale, const nk_spmv_epi epi, const int16_t *__restrict__ col16, int n16,
+    const nk_spmv_xchg xc) {
+  const int b = REMAP ? xcd_remap(blockIdx.x, nblk) : (int)blockIdx.x;
+  if (HALO && xc.segs != nullptr) {  // (uniform per workgroup; runs even when the cycle is done: flags stay in step)
+    if ((int)blockIdx.x < xc.nsegs) {
+      const nk_peer_seg sg = xc.segs[blockIdx.x];
+      double *dst = sg.dst[xc.seq & 1];
+      const int32_t *idx = xc.send_idx + sg.send_off;
+      for (int64_t i = threadIdx.x; i < sg.send_cnt; i += NK_BLOCK) dst[i] = x[idx[i]];
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(sg.flag_remote, xc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (b >= xc.wait_from) {
+      if ((int)threadIdx.x < xc.nsegs) {
+        const uint64_t *fl = xc.segs[threadIdx.x].flag_local;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xc.seq) {
+          if (__hip_atomic_load(xc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) break;
+          if (wall_clock64() - t0 > 500000000ull) { atomicAdd((unsigned long long *)xc.err, 1ull); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+    }
+  }
   if (d_skip != nullptr && *d_skip != 0) return;
   const double os = out_scale ? *out_scale : 1.0;
   __shared__ double prod[TILE];
   __shared__ double red[4];
-  const int b = REMAP ? xcd_remap(blockIdx.x, nblk) : (int)blockIdx.x;
   const int4 desc = rowblocks[b];  // {first row, end row, first nnz, end nnz}: one 16-byte scalar load per block
   const int r0 = desc.x, r1 = desc.y, p0 = desc.z, p1 = desc.w;
   const int nnzb = p1 - p0;
@@ -469,14 +505,31 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
   // halo overlap: interior row blocks run while the exchange is in flight on the communication stream
   const bool overlap = A->halo.active() && ctx->halo_overlap && ctx->nranks > 1 &&
                        A->nblocks_interior > 0 && A->nblocks_interior < A->nblocks;
-  if (A->halo.active()) NK_TRY(overlap ? nk_halo_exchange_begin(ctx, &A->halo, d_x) : nk_halo_exchange(ctx, &A->halo, d_x));
+  // peer-mapped halo plan: the exchange rides inside the SpMV launch (NK_PEER_UNFUSED=1 keeps the separate kernel)
+  static const bool unfused = getenv("NK_PEER_UNFUSED") != nullptr;
+  nk_spmv_xchg xc;
+  const bool inkernel = A->halo.peer && !overlap && !unfused && A->halo.n_recv > 0 && A->halo.nsegs > 0 &&
+                        A->halo.nsegs <= A->nblocks && A->halo.nsegs <= NK_BLOCK;
+  if (inkernel) {
+    nk_halo &H = A->halo;
+    xc.segs = H.d_segs;
+    xc.send_idx = H.d_send_idx;
+    xc.err = nk_peer_err_ptr(ctx);
+    xc.seq = ++H.seq;
+    xc.nsegs = H.nsegs;
+    xc.wait_from = A->nblocks_interior;
+    H.d_recv = H.recv_buf[xc.seq & 1];
+    ctx->stats.halo_exchanges++;
+  } else if (A->halo.active()) {
+    NK_TRY(overlap ? nk_halo_exchange_begin(ctx, &A->halo, d_x) : nk_halo_exchange(ctx, &A->halo, d_x));
+  }
   ctx->stats.op_applies++;
   nk_prof_scope prof_(ctx, NK_K_SPMV, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows);
   if (A->nblocks > 0) {
 #define SPMV_LAUNCH(T, H, R)                                                                                      \
   NK_LAUNCH(ctx, (k_spmv_stream<T, H, R>), dim3(nb_), dim3(NK_BLOCK), nb_,                                         \
             (const int4 *)A->d_rowblocks + b0_, A->d_rowptr, A->d_col, A->d_val, d_x, A->halo.d_recv, (int32_t)A->nrows, \
-            d_y, d_skip, d_out_scale, ep, (const int16_t *)A->d_col16, A->n16 - b0_)
+            d_y, d_skip, d_out_scale, ep, (const int16_t *)A->d_col16, A->n16 - b0_, xc)
 #define SPMV_TILES(H, R)                                  \
   if (A->tile == 512) SPMV_LAUNCH(512, H, R);             \
   else if (A->tile == 2048) SPMV_LAUNCH(2048, H, R);      \

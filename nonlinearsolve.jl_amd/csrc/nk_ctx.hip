@@ -222,16 +222,6 @@ extern "C" int nk_partition_range(int64_t n_global, int64_t granule, int nranks,
 
 
 // ----------------------------------------------------------------------------- peer-mapped arenas (hipIpc over xGMI)
-// Layout of every rank's arena: a header (all-reduce flags and slots, error word) and a bump-allocated rest that holds
-// the receive areas of the halo plans. All of it is uncached device memory, so that a kernel polling a flag sees the
-// store a peer GPU made while the kernel was already running.
-struct nk_peer_hdr {
-  uint64_t ar_flag[2][NK_PEER_MAX_RANKS];
-  uint64_t err;
-  uint64_t pad[31];
-  double ar_data[2][NK_PEER_MAX_RANKS][NK_PEER_AR_MAX];
-};
-static_assert(sizeof(nk_peer_hdr) <= NK_PEER_HDR_BYTES, "peer arena header too large");
 constexpr unsigned long long NK_PEER_TIMEOUT_TICKS = 500000000ull;  // 5 s of the 100 MHz wall clock
 
 __device__ __forceinline__ bool peer_wait_ge(const uint64_t *flag, uint64_t seq, uint64_t *err) {
@@ -299,11 +289,26 @@ __global__ __launch_bounds__(NK_BLOCK) void k_peer_halo_xchg(const nk_peer_seg *
 }
 
 static int comm_allreduce_base(nk_ctx *ctx, double *dbuf, int count, int op);
+uint64_t *nk_peer_err_ptr(nk_ctx *ctx) { return reinterpret_cast<uint64_t *>(ctx->peer.arena + offsetof(nk_peer_hdr, err)); }
+nk_peer_ar_view nk_peer_ar_next(nk_ctx *ctx, int count) {
+  nk_peer_ar_view v{nullptr, 0, 0, 0, nullptr};
+  static const bool unfused = getenv("NK_PEER_UNFUSED") != nullptr;  // A/B switch: reduce and all-reduce as two launches
+  if (!ctx->peer.on || unfused || count > NK_PEER_AR_MAX || ctx->nranks <= 1) return v;
+  v.map = ctx->peer.d_map;
+  v.P = ctx->peer.P;
+  v.me = ctx->peer.me;
+  v.seq = ++ctx->peer.ar_seq;
+  v.ticket = ctx->peer.d_ticket;
+  ctx->stats.allreduces++;
+  return v;
+}
+
 static void nk_peer_destroy(nk_ctx *ctx) {
   nk_peer &pr = ctx->peer;
   for (int p = 0; p < pr.P; ++p)
     if (p != pr.me && pr.map[p]) hipIpcCloseMemHandle(pr.map[p]);
   hipFree(pr.d_map);
+  hipFree(pr.d_ticket);
   if (pr.arena) hipFree(pr.arena);
   pr = nk_peer{};
 }
@@ -363,6 +368,8 @@ extern "C" int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles) {
   }
   NK_TRY(nk_dev_alloc(&pr.d_map, (size_t)NK_PEER_MAX_RANKS));
   NK_HIP(hipMemcpy(pr.d_map, pr.map, sizeof(char *) * NK_PEER_MAX_RANKS, hipMemcpyHostToDevice));
+  NK_TRY(nk_dev_alloc(&pr.d_ticket, (size_t)4));
+  NK_HIP(hipMemset(pr.d_ticket, 0, 4 * sizeof(unsigned int)));
   pr.on = true;
   return NK_OK;
 }

@@ -72,6 +72,16 @@ struct nk_prof {
 constexpr int NK_PEER_MAX_RANKS = 16;
 constexpr int NK_PEER_AR_MAX = 128;                      // doubles per all-reduce message
 constexpr size_t NK_PEER_HDR_BYTES = 65536;              // flags + all-reduce slots + error word
+// Layout of every rank's arena: a header (all-reduce flags and slots, error word) and a bump-allocated rest that holds
+// the receive areas of the halo plans. All of it is uncached device memory, so that a kernel polling a flag sees the
+// store a peer GPU made while the kernel was already running.
+struct nk_peer_hdr {
+  uint64_t ar_flag[2][NK_PEER_MAX_RANKS];
+  uint64_t err;
+  uint64_t pad[31];
+  double ar_data[2][NK_PEER_MAX_RANKS][NK_PEER_AR_MAX];
+};
+static_assert(sizeof(nk_peer_hdr) <= NK_PEER_HDR_BYTES, "peer arena header too large");
 struct nk_peer_seg {  // one neighbour of a halo plan, as the push / wait kernels see it
   int64_t send_off, send_cnt;     // into the plan's send index list
   double *dst[2];                 // the neighbour's receive area for my entries (both parities), in MY address space
@@ -86,7 +96,17 @@ struct nk_peer {
   char *map[NK_PEER_MAX_RANKS] = {nullptr};   // every rank's arena in my address space (map[me] == arena)
   char **d_map = nullptr;                     // the same table on the device
   uint64_t ar_seq = 0;
+  unsigned int *d_ticket = nullptr;           // last-workgroup ticket of the fused reduce + all-reduce kernel
 };
+// the all-reduce slots of the arena header, as nk_blas.hip's fused stage-2 reduction sees them (layout: nk_ctx.hip)
+struct nk_peer_ar_view {
+  char *const *map;   // device table of the arenas
+  int P, me;
+  uint64_t seq;       // 0: no peer path (plain stage-2 reduction)
+  unsigned int *ticket;
+};
+nk_peer_ar_view nk_peer_ar_next(nk_ctx *ctx, int count);
+uint64_t *nk_peer_err_ptr(nk_ctx *ctx);  // the arena's time-out counter (device pointer)  // claims the next sequence number if the fast path applies
 
 struct nk_ctx {
   nk_prof prof;
