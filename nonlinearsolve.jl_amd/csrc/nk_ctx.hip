@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "nk_internal.h"
 
 // ----------------------------------------------------------------------------- errors
@@ -717,6 +719,74 @@ int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t
   if (ctx->peer.on && P > 1) return halo_setup_peer(ctx, H);  // (collective, like every halo set-up on several ranks)
   NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)ro));
   return NK_OK;
+}
+
+int nk_halo_build_from_needs(nk_ctx *ctx, int64_t my_begin, int64_t my_count, const std::vector<int64_t> &needs, nk_halo *H) {
+  const int P = ctx->nranks;
+  NK_REQUIRE(P > 1, "a halo plan needs several ranks");
+  // 1. everyone learns all row ranges: all-reduce a zero vector with our begin in slot `rank`
+  std::vector<double> hb(P + 1, 0.0);
+  hb[ctx->rank] = (double)my_begin;
+  if (ctx->rank == P - 1) hb[P] = (double)(my_begin + my_count);
+  double *d_tmp = nullptr;
+  NK_TRY(nk_dev_alloc(&d_tmp, (size_t)P * P + P + 1));
+  auto tmp_guard = nk_make_guard(d_tmp, [](double *q) { hipFree(q); });
+  NK_HIP(hipMemcpy(d_tmp, hb.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice));
+  NK_TRY(comm_allreduce_base(ctx, d_tmp, P + 1, 0));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  NK_HIP(hipMemcpy(hb.data(), d_tmp, (P + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<int64_t> begin(P + 1);
+  for (int p = 0; p <= P; ++p) begin[p] = (int64_t)hb[p];
+  // 2. needs per owner
+  std::vector<std::vector<int64_t>> need(P);
+  for (int64_t g : needs) {
+    int p = (int)(std::upper_bound(begin.begin(), begin.end(), g) - begin.begin()) - 1;
+    while (p > 0 && begin[p] == begin[p + 1]) --p;  // (empty ranges share a begin)
+    NK_REQUIRE(p >= 0 && p < P && p != ctx->rank, "needed entry %lld has no owner", (long long)g);
+    need[p].push_back(g);
+  }
+  // 3. counts: P×P matrix, row = requester, col = owner
+  std::vector<double> cnt((size_t)P * P, 0.0);
+  for (int p = 0; p < P; ++p) cnt[(size_t)ctx->rank * P + p] = (double)need[p].size();
+  NK_HIP(hipMemcpy(d_tmp, cnt.data(), (size_t)P * P * sizeof(double), hipMemcpyHostToDevice));
+  NK_TRY(comm_allreduce_base(ctx, d_tmp, P * P, 0));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  NK_HIP(hipMemcpy(cnt.data(), d_tmp, (size_t)P * P * sizeof(double), hipMemcpyDeviceToHost));
+  // 4. index lists (int64 global ids): what I need from p ↔ what p needs from me
+  std::vector<int64_t> soff(P, 0), sbytes(P, 0), roff(P, 0), rbytes(P, 0), sendflat;
+  int64_t rtotal = 0;
+  for (int p = 0; p < P; ++p) {
+    soff[p] = (int64_t)sendflat.size() * 8;
+    sbytes[p] = (int64_t)need[p].size() * 8;
+    sendflat.insert(sendflat.end(), need[p].begin(), need[p].end());
+    roff[p] = rtotal * 8;
+    const int64_t c = (int64_t)cnt[(size_t)p * P + ctx->rank];
+    rbytes[p] = c * 8;
+    rtotal += c;
+  }
+  int64_t *d_s = nullptr, *d_r = nullptr;
+  NK_TRY(nk_dev_alloc(&d_s, sendflat.size() + 1));
+  auto s_guard = nk_make_guard(d_s, [](int64_t *q) { hipFree(q); });
+  NK_TRY(nk_dev_alloc(&d_r, (size_t)rtotal + 1));
+  auto r_guard = nk_make_guard(d_r, [](int64_t *q) { hipFree(q); });
+  if (!sendflat.empty()) NK_HIP(hipMemcpy(d_s, sendflat.data(), sendflat.size() * 8, hipMemcpyHostToDevice));
+  NK_TRY(nk_comm_alltoallv(ctx, d_s, soff.data(), sbytes.data(), d_r, roff.data(), rbytes.data()));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int64_t> wanted((size_t)rtotal);
+  if (rtotal) NK_HIP(hipMemcpy(wanted.data(), d_r, (size_t)rtotal * 8, hipMemcpyDeviceToHost));
+  std::vector<std::vector<int32_t>> send_idx(P);
+  std::vector<int64_t> recv_cnt(P, 0);
+  for (int p = 0; p < P; ++p) {
+    const int64_t c = rbytes[p] / 8, o = roff[p] / 8;
+    for (int64_t t = 0; t < c; ++t) {
+      const int64_t g = wanted[o + t];
+      NK_REQUIRE(g >= my_begin && g < my_begin + my_count, "peer %d asked for an entry this rank does not own", p);
+      send_idx[p].push_back((int32_t)(g - my_begin));
+    }
+    recv_cnt[p] = (int64_t)need[p].size();
+  }
+  // needs are sorted by global id and owners are ordered by rank → the receive layout is the order of `needs`
+  return nk_halo_setup(ctx, H, send_idx, recv_cnt);
 }
 
 // gather + (optionally on `xstream`) the exchange itself

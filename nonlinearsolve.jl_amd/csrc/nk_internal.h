@@ -210,6 +210,10 @@ struct nk_halo {
 };
 int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
                   const std::vector<int64_t> &recv_cnt_per_peer);
+// Plan for gathering arbitrary entries of a row-partitioned vector: this rank owns [my_begin, my_begin + my_count) of it
+// and needs the global entries `needs` (sorted, unique, none of them owned). Collective. The receive buffer holds them in
+// the order of `needs`.
+int nk_halo_build_from_needs(nk_ctx *ctx, int64_t my_begin, int64_t my_count, const std::vector<int64_t> &needs, nk_halo *H);
 int nk_halo_exchange(nk_ctx *ctx, nk_halo *H, const double *d_x_local);  // result in H->d_recv
 // split form: begin = gather on the compute stream + exchange on ctx->comm_stream; end = compute stream waits for it
 int nk_halo_exchange_begin(nk_ctx *ctx, nk_halo *H, const double *d_x_local);
@@ -266,6 +270,7 @@ struct nk_problem {
   int64_t n_local = 0, n_global = 0, row_begin = 0;
   double params[8] = {0};
   int nparams = 0;
+  bool replicated = false;  // every rank holds the WHOLE problem (coarsest multigrid level): no partition, no halo
   // grid problems
   int64_t ns = 0;           // side length
   int64_t j0 = 0, j1 = 0;   // owned grid lines [j0, j1)
@@ -286,6 +291,7 @@ struct nk_problem {
   // staging buffers for host-memspace calls
   double *d_tmp[3] = {nullptr, nullptr, nullptr};
 };
+int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, double scale, nk_problem **out);
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
 // forget what the problem was linearised at: the caller wrote new contents into a buffer it may have been keyed on
 static inline void nk_problem_invalidate(nk_problem *P) { P->d_u_lin = nullptr; P->d_u_linJ = nullptr; }

@@ -10,10 +10,16 @@
 //              …); restriction = row-normalised transpose, evaluated as a gather (≤ 5×5 fine points per coarse point)
 //   smoother   ν steps of the Chebyshev iteration on [λmax/4, λmax], λmax = 8·scale/h_l² (Gershgorin for the stencil)
 //   coarsest   banded LU (nk_band.hip) of the assembled coarse Jacobian, refactored whenever u changes
-// Single rank, BRATU2D only in this round. Restated on the CPU by oracle/reference_restatement.py::BratuMultigrid.
+// BRATU2D. Row-partitioned runs (several ranks): every level is partitioned by grid lines like the fine problem (the level
+// problems are ordinary partitioned Bratu objects, so the smoother's stencil JVP brings its own halo exchange); the
+// transfers are tensor products, so only their line direction crosses ranks — a rank gathers the few ghost lines of the
+// other level it needs through a halo plan built once per transfer (the partitions of two levels do not line up exactly);
+// the coarsest level is gathered to every rank (one all-reduce of a zero-padded vector) and solved redundantly.
+// Restated on the CPU by oracle/reference_restatement.py::BratuMultigrid (the arithmetic does not depend on the partition).
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "nk_internal.h"
@@ -29,13 +35,38 @@ struct nk_mg_level {
   double *pw1 = nullptr;     // weight of the right neighbour
   int32_t *rlo = nullptr;    // per coarse index: first fine index of its support
   double *rw = nullptr;      // 5 normalised 1-D weights per coarse index
+  // several ranks: lines owned on this level, and the ghost lines of the neighbouring levels the transfers read
+  int64_t j0 = 0, j1 = 0;    // owned lines [j0, j1)
+  nk_halo gh_c;              // prolongation: ghost lines of the COARSER level's vectors; needed coarse lines [pc_lo, pc_hi)
+  int64_t pc_lo = 0, pc_hi = 0;
+  nk_halo gh_f;              // restriction: ghost lines of THIS level's vectors; needed fine lines [rf_lo, rf_hi)
+  int64_t rf_lo = 0, rf_hi = 0;
 };
+// a vector of one level seen through its owner's lines plus gathered ghost lines: line J (global) lives in `below`
+// (lines [lo, own_lo)), `own` (lines [own_lo, own_hi)) or `above` (lines [own_hi, hi))
+struct mg_lines {
+  const double *below, *own, *above;
+  int lo, hi;      // needed lines [lo, hi) (reads outside are clamped; the callers give them weight 0)
+  int j0, j1;      // owned lines [j0, j1): `own` starts at line j0
+  int a0;          // first ghost line above: max(lo, j1)
+  int n;           // points per line
+  __device__ __forceinline__ double at(int J, int I) const {
+    const int Jc = J < lo ? lo : (J >= hi ? hi - 1 : J);
+    if (Jc < j0) return below[(size_t)(Jc - lo) * n + I];
+    if (Jc < j1) return own[(size_t)(Jc - j0) * n + I];
+    return above[(size_t)(Jc - a0) * n + I];
+  }
+};
+
 struct nk_mg {
   nk_ctx *ctx = nullptr;
   int nu = 2;
   std::vector<nk_mg_level> lv;
   nk_csr *Jc = nullptr;
   nk_bandlu *LU = nullptr;
+  // several ranks: the coarsest level once more, whole on every rank (gathered right-hand side / iterate / solution)
+  nk_problem *Prep = nullptr;
+  double *rep_u = nullptr, *rep_b = nullptr, *rep_x = nullptr;
   // HIP graphs of the V-cycle body, one per early-exit flag pointer (nullptr / the GMRES control block's flag)
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -84,6 +115,52 @@ __global__ __launch_bounds__(NK_BLOCK) void k_mg_restrict(int nf, int nc, const 
   }
   rc[k] = s;
 }
+// the same two transfers on a line-partitioned hierarchy: the thread grid covers the OWNED lines of the target level, the
+// source level is read through mg_lines (owned + ghost lines)
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_prolong_add_dist(int nf, int nc, int jf0, int nlf, const int32_t *__restrict__ I0,
+                                                                  const double *__restrict__ w1, mg_lines ec,
+                                                                  double *__restrict__ xf, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= nf * nlf) return;
+  const int jl = k / nf, i = k - jl * nf, j = jf0 + jl;
+  const int Il = I0[i], Jl = I0[j];
+  const double wi1 = w1[i], wi0 = 1.0 - wi1, wj1 = w1[j], wj0 = 1.0 - wj1;
+  const int ia = Il < 0 ? 0 : Il, ib = Il + 1 >= nc ? nc - 1 : Il + 1;
+  const int ja = Jl < 0 ? 0 : Jl, jb = Jl + 1 >= nc ? nc - 1 : Jl + 1;
+  const double ma = Il >= 0 ? 1.0 : 0.0, mb = Il + 1 < nc ? 1.0 : 0.0, na = Jl >= 0 ? 1.0 : 0.0, nb = Jl + 1 < nc ? 1.0 : 0.0;
+  const double v = wj0 * na * (wi0 * ma * ec.at(ja, ia) + wi1 * mb * ec.at(ja, ib)) +
+                   wj1 * nb * (wi0 * ma * ec.at(jb, ia) + wi1 * mb * ec.at(jb, ib));
+  xf[k] += v;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_restrict_dist(int nf, int nc, int jc0, int nlc, const int32_t *__restrict__ lo,
+                                                               const double *__restrict__ w, mg_lines rf,
+                                                               double *__restrict__ rc, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= nc * nlc) return;
+  const int Jl = k / nc, I = k - Jl * nc, J = jc0 + Jl;
+  const int i0 = lo[I], j0 = lo[J];
+  double s = 0.0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    const int j = min(j0 + b, nf - 1);
+    const double wj = w[J * 5 + b];
+    double row = 0.0;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) row += w[I * 5 + a] * rf.at(j, min(i0 + a, nf - 1));
+    s += wj * row;
+  }
+  rc[k] = s;
+}
+// out[full coarse vector] = 0 except this rank's lines (the all-reduce that follows assembles the whole vector everywhere)
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_scatter_lines(int64_t nfull, int64_t off, int64_t cnt, const double *__restrict__ loc,
+                                                               double *__restrict__ full) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i >= nfull) return;
+  full[i] = (i >= off && i < off + cnt) ? loc[i - off] : 0.0;
+}
+
 // Chebyshev smoother: the first step; the later steps and the residual are fused into the stencil JVP's row epilogue
 // d = r/θ ; x = (zero ? 0 : x) + d ; r_copy = r (optional: the recurrence continues on a private copy of b)
 __global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_first(int64_t n, const double *__restrict__ r, double inv_theta, int zero,
@@ -139,18 +216,41 @@ void nk_mg_destroy(nk_mg *M) {
     hipFree(L.b); hipFree(L.x); hipFree(L.r); hipFree(L.d); hipFree(L.t);
     hipFree(L.pI0); hipFree(L.pw1); hipFree(L.rlo); hipFree(L.rw);
   }
+  for (nk_mg_level &L : M->lv) { nk_halo_free(&L.gh_c); nk_halo_free(&L.gh_f); }
   if (M->LU) nk_bandlu_destroy(M->LU);
   if (M->Jc) nk_csr_destroy(M->Jc);
+  if (M->Prep) nk_problem_destroy(M->Prep);
+  hipFree(M->rep_u); hipFree(M->rep_b); hipFree(M->rep_x);
   for (hipGraphExec_t &g : M->gexec) if (g) hipGraphExecDestroy(g);
   if (M->cap_stream) hipStreamDestroy(M->cap_stream);
   delete M;
 }
 
 // build the hierarchy for problem P (level vectors, transfer tables, level problems); values follow in nk_mg_update
+static mg_lines make_lines(const nk_halo &H, const double *own, int64_t lo, int64_t hi, int64_t j0, int64_t j1, int64_t n) {
+  mg_lines m;
+  const int64_t nb = std::max<int64_t>(0, std::min(hi, j0) - lo);
+  m.below = H.d_recv;
+  m.above = H.d_recv ? H.d_recv + nb * n : nullptr;
+  m.own = own;
+  m.lo = (int)lo; m.hi = (int)hi; m.j0 = (int)j0; m.j1 = (int)j1;
+  m.a0 = (int)std::max(lo, j1);
+  m.n = (int)n;
+  return m;
+}
+// ghost lines [lo, hi) \ [j0, j1) of a level vector with `n` points per line, as global entry ids
+static void ghost_needs(int64_t lo, int64_t hi, int64_t j0, int64_t j1, int64_t n, std::vector<int64_t> &needs) {
+  needs.clear();
+  for (int64_t J = lo; J < hi; ++J) {
+    if (J >= j0 && J < j1) continue;
+    for (int64_t I = 0; I < n; ++I) needs.push_back(J * n + I);
+  }
+}
+
 int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   nk_ctx *ctx = P->ctx;
+  const int R = ctx->nranks;
   NK_REQUIRE(P->kind == NK_PROBLEM_BRATU2D, "the multigrid preconditioner is built for BRATU2D problems");
-  NK_REQUIRE(ctx->nranks == 1, "the multigrid preconditioner is single-rank in this round");
   NK_REQUIRE(P->ns < 46000, "grid too large for 32-bit point indices");
   if (nu <= 0) nu = 2;
   if (coarse_max < 3) coarse_max = 31;  // MI355X, 1024² with set-up: 63 → 13.5 ms, 31 → 10.1, 15 → 9.5, 7 → 9.7
@@ -160,25 +260,31 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   M->nu = nu;
   const double hf = 1.0 / (double)(P->ns + 1);
   const double scale = P->c_lap * hf * hf, lambda = P->params[1];
+  const int64_t min_coarse = std::max<int64_t>(3, 2 * (int64_t)R);  // every rank keeps at least two lines of every level
+  std::vector<std::vector<int32_t>> hI0, hlo;  // host copies of the 1-D transfer tables (ghost-line ranges, several ranks)
   int64_t ns = P->ns;
   for (int l = 0;; ++l) {
     nk_mg_level L;
     L.ns = ns;
-    L.n = ns * ns;
     const double h = 1.0 / (double)(ns + 1);
     L.lmax = 8.0 * scale / (h * h);
     if (l == 0) L.P = P;
     else {
       const double par[3] = {(double)ns, lambda, scale};
       if (nk_problem_create(ctx, NK_PROBLEM_BRATU2D, par, 3, &L.P) != NK_OK) return NK_E_HIP;
-      NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
     }
+    L.j0 = L.P->j0;
+    L.j1 = L.P->j1;
+    L.n = ns * (L.j1 - L.j0);  // local entries (all of them on one rank)
+    if (l > 0) NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
     NK_TRY(nk_dev_alloc(&L.b, (size_t)L.n + 1));
     NK_TRY(nk_dev_alloc(&L.x, (size_t)L.n + 1));
     NK_TRY(nk_dev_alloc(&L.r, (size_t)L.n + 1));
     NK_TRY(nk_dev_alloc(&L.d, (size_t)L.n + 1));
     NK_TRY(nk_dev_alloc(&L.t, (size_t)L.n + 1));
-    const bool coarsest = ns <= coarse_max || ns / 2 < 3;
+    const bool coarsest = ns <= coarse_max || ns / 2 < min_coarse;
+    hI0.emplace_back();
+    hlo.emplace_back();
     if (!coarsest) {
       const int nf = (int)ns, nc = (int)(ns / 2);
       std::vector<int32_t> I0, lo;
@@ -192,33 +298,119 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
       NK_HIP(hipMemcpy(L.pw1, w1.data(), nf * sizeof(double), hipMemcpyHostToDevice));
       NK_HIP(hipMemcpy(L.rlo, lo.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
       NK_HIP(hipMemcpy(L.rw, w.data(), (size_t)nc * 5 * sizeof(double), hipMemcpyHostToDevice));
+      hI0.back() = I0;
+      hlo.back() = lo;
     }
     M->lv.push_back(L);
     if (coarsest) break;
     ns /= 2;
   }
+  if (R > 1) {  // ghost-line plans of the transfers (collective; the same sequence on every rank)
+    for (size_t l = 0; l + 1 < M->lv.size(); ++l) {
+      nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
+      const int64_t nf = F.ns, nc = C.ns;
+      // prolongation: my fine lines read the coarse lines I0[j], I0[j] + 1
+      int64_t lo = nc, hi = 0;
+      for (int64_t j = F.j0; j < F.j1; ++j) {
+        lo = std::min<int64_t>(lo, std::max<int64_t>(0, hI0[l][j]));
+        hi = std::max<int64_t>(hi, std::min<int64_t>(nc, (int64_t)hI0[l][j] + 2));
+      }
+      if (hi < lo) hi = lo;
+      F.pc_lo = lo;
+      F.pc_hi = hi;
+      std::vector<int64_t> needs;
+      ghost_needs(lo, hi, C.j0, C.j1, nc, needs);
+      NK_TRY(nk_halo_build_from_needs(ctx, C.j0 * nc, (C.j1 - C.j0) * nc, needs, &F.gh_c));
+      // restriction: my coarse lines read the fine lines lo[J] … lo[J] + 4 (clamped)
+      lo = nf;
+      hi = 0;
+      for (int64_t J = C.j0; J < C.j1; ++J) {
+        lo = std::min<int64_t>(lo, hlo[l][J]);
+        hi = std::max<int64_t>(hi, std::min<int64_t>(nf - 1, (int64_t)hlo[l][J] + 4) + 1);
+      }
+      if (hi < lo) hi = lo;
+      F.rf_lo = lo;
+      F.rf_hi = hi;
+      ghost_needs(lo, hi, F.j0, F.j1, nf, needs);
+      NK_TRY(nk_halo_build_from_needs(ctx, F.j0 * nf, (F.j1 - F.j0) * nf, needs, &F.gh_f));
+    }
+  }
   nk_mg_level &C = M->lv.back();
   if (M->lv.size() > 1) {
-    NK_TRY(nk_problem_jac_csr(C.P, &M->Jc));
+    if (R > 1) {
+      NK_TRY(nk_problem_create_bratu_replicated(ctx, C.ns, lambda, scale, &M->Prep));
+      NK_TRY(nk_dev_alloc(&M->rep_u, (size_t)(C.ns * C.ns) + 1));
+      NK_TRY(nk_dev_alloc(&M->rep_b, (size_t)(C.ns * C.ns) + 1));
+      NK_TRY(nk_dev_alloc(&M->rep_x, (size_t)(C.ns * C.ns) + 1));
+      NK_TRY(nk_problem_jac_csr(M->Prep, &M->Jc));
+    } else {
+      NK_TRY(nk_problem_jac_csr(C.P, &M->Jc));
+    }
     NK_TRY(nk_bandlu_create(M->Jc, &M->LU));
   }
   *out = guard.release();
   return NK_OK;
 }
 
+// every rank's lines of the coarsest level → the whole vector on every rank (zero-padded scatter + one all-reduce)
+static int mg_gather_coarse(nk_mg *M, const double *loc, double *full) {
+  nk_ctx *ctx = M->ctx;
+  nk_mg_level &C = M->lv.back();
+  const int64_t nfull = C.ns * C.ns;
+  NK_LAUNCH(ctx, k_mg_scatter_lines, g1(nfull), dim3(NK_BLOCK), nfull, C.j0 * C.ns, C.n, loc, full);
+  NK_HIP(hipGetLastError());
+  for (int64_t o = 0; o < nfull; o += 1 << 20) {  // (int-sized messages)
+    const int c = (int)std::min<int64_t>(1 << 20, nfull - o);
+    NK_TRY(nk_comm_allreduce(ctx, full + o, c, 0));
+  }
+  return NK_OK;
+}
+// transfers: F level → coarser level C (restriction of `src`, a level-F vector) and back
+static int mg_restrict(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *src, double *dst, const int *d_skip) {
+  nk_ctx *ctx = M->ctx;
+  if (ctx->nranks == 1) {
+    NK_LAUNCH(ctx, k_mg_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.rlo, (const double *)F.rw, src,
+              dst, d_skip);
+  } else {
+    NK_TRY(nk_halo_exchange(ctx, &F.gh_f, src));
+    const mg_lines ln = make_lines(F.gh_f, src, F.rf_lo, F.rf_hi, F.j0, F.j1, F.ns);
+    NK_LAUNCH(ctx, k_mg_restrict_dist, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (int)C.j0, (int)(C.j1 - C.j0),
+              (const int32_t *)F.rlo, (const double *)F.rw, ln, dst, d_skip);
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+static int mg_prolong_add(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *ec, double *xf, const int *d_skip) {
+  nk_ctx *ctx = M->ctx;
+  if (ctx->nranks == 1) {
+    NK_LAUNCH(ctx, k_mg_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.pI0, (const double *)F.pw1, ec,
+              xf, d_skip);
+  } else {
+    NK_TRY(nk_halo_exchange(ctx, &F.gh_c, ec));
+    const mg_lines ln = make_lines(F.gh_c, ec, F.pc_lo, F.pc_hi, C.j0, C.j1, C.ns);
+    NK_LAUNCH(ctx, k_mg_prolong_add_dist, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (int)F.j0, (int)(F.j1 - F.j0),
+              (const int32_t *)F.pI0, (const double *)F.pw1, ln, xf, d_skip);
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
 // new linearisation point: restrict u down the hierarchy, refresh exp(u_l) of every level, refactor the coarsest J
 int nk_mg_update(nk_mg *M, const double *d_u) {
-  nk_ctx *ctx = M->ctx;
   M->lv[0].u = const_cast<double *>(d_u);
   for (size_t l = 0; l + 1 < M->lv.size(); ++l) {
     nk_mg_level &F = M->lv[l], &Cc = M->lv[l + 1];
-    NK_LAUNCH(ctx, k_mg_restrict, g1(Cc.n), dim3(NK_BLOCK), (int)F.ns, (int)Cc.ns, (const int32_t *)F.rlo, (const double *)F.rw,
-              (const double *)F.u, Cc.u, (const int *)nullptr);
+    NK_TRY(mg_restrict(M, F, Cc, F.u, Cc.u, nullptr));
   }
   for (size_t l = 1; l < M->lv.size(); ++l) NK_TRY(nk_problem_jvp_prepare(M->lv[l].P, M->lv[l].u));
   if (M->LU) {
     nk_mg_level &C = M->lv.back();
-    NK_TRY(nk_problem_jac_values_dev(C.P, C.u, M->Jc));
+    if (M->Prep) {  // several ranks: the coarsest iterate whole on every rank, Jacobian and factorisation redundantly
+      NK_TRY(mg_gather_coarse(M, C.u, M->rep_u));
+      NK_TRY(nk_problem_jac_values_dev(M->Prep, M->rep_u, M->Jc));
+    } else {
+      NK_TRY(nk_problem_jac_values_dev(C.P, C.u, M->Jc));
+    }
     int ok = 0;
     NK_TRY(nk_bandlu_factor(M->LU, M->Jc, &ok));
     NK_REQUIRE(ok, "multigrid: the coarsest Jacobian has a zero pivot");
@@ -288,7 +480,7 @@ int nk_mg_apply(nk_mg *M, const double *src, double *dst, const int *d_skip) {
   }
   NK_TRY(nk_blas_copy(ctx, M->lv[0].n, src, M->lv[0].b));
   static const bool use_graph = !(getenv("NK_MG_GRAPH") && atoi(getenv("NK_MG_GRAPH")) == 0);
-  if (use_graph && !ctx->prof.on && !M->graph_broken) {
+  if (use_graph && !ctx->prof.on && !M->graph_broken && ctx->nranks == 1) {  // (collectives carry per-call sequence numbers)
     const int slot = d_skip ? 1 : 0;
     if (M->gexec[slot] && M->gskip[slot] != d_skip) {  // a different flag pointer: re-capture
       hipGraphExecDestroy(M->gexec[slot]);
@@ -330,17 +522,21 @@ static int mg_vcycle_body(nk_mg *M, const int *d_skip) {
     nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
     NK_TRY(mg_smooth(M, F, true, d_skip));
     NK_TRY(mg_residual(F, F.x, F.r, d_skip));
-    NK_LAUNCH(ctx, k_mg_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.rlo, (const double *)F.rw,
-              (const double *)F.r, C.b, d_skip);
+    NK_TRY(mg_restrict(M, F, C, F.r, C.b, d_skip));
   }
   {
     nk_mg_level &C = M->lv[nl - 1];
-    NK_TRY(nk_bandlu_solve(M->LU, C.b, C.x));
+    if (M->Prep) {
+      NK_TRY(mg_gather_coarse(M, C.b, M->rep_b));
+      NK_TRY(nk_bandlu_solve(M->LU, M->rep_b, M->rep_x));
+      NK_TRY(nk_blas_copy(ctx, C.n, M->rep_x + C.j0 * C.ns, C.x));
+    } else {
+      NK_TRY(nk_bandlu_solve(M->LU, C.b, C.x));
+    }
   }
   for (int l = nl - 2; l >= 0; --l) {
     nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
-    NK_LAUNCH(ctx, k_mg_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.pI0, (const double *)F.pw1,
-              (const double *)C.x, F.x, d_skip);
+    NK_TRY(mg_prolong_add(M, F, C, C.x, F.x, d_skip));
     NK_TRY(mg_smooth(M, F, false, d_skip));
   }
   NK_HIP(hipGetLastError());

@@ -326,7 +326,7 @@ static void halo_lines(const nk_problem *P, int dof_per_node, bool periodic, con
   *lo = *hi = nullptr;
   const nk_ctx *ctx = P->ctx;
   const int R = ctx->nranks, r = ctx->rank;
-  if (R == 1) return;
+  if (R == 1 || P->replicated) return;
   const int below = (r == 0) ? (periodic ? R - 1 : -1) : r - 1;
   const int above = (r == R - 1) ? (periodic ? 0 : -1) : r + 1;
   const int64_t line = P->ns * dof_per_node;
@@ -375,6 +375,28 @@ extern "C" int nk_problem_create(nk_ctx *ctx, int kind, const double *params, in
     NK_FAIL(NK_E_INVALID, "unknown built-in problem kind %d", kind);
   }
   if (st != NK_OK) { delete P; return st; }
+  *out = P;
+  return NK_OK;
+}
+
+// a Bratu problem every rank holds in full (the multigrid's coarsest level, solved redundantly): no partition, no halo
+int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, double scale, nk_problem **out) {
+  nk_problem *P = new nk_problem();
+  P->ctx = ctx;
+  P->kind = NK_PROBLEM_BRATU2D;
+  P->replicated = true;
+  P->nparams = 3;
+  P->params[0] = (double)ns;
+  P->params[1] = lambda;
+  P->params[2] = scale;
+  const double h = 1.0 / (double)(ns + 1), s = (scale == 0.0) ? h * h : scale;
+  P->c_lap = s / (h * h);
+  P->c_exp = s * lambda;
+  P->ns = ns;
+  P->j0 = 0;
+  P->j1 = ns;
+  P->n_local = P->n_global = ns * ns;
+  P->row_begin = 0;
   *out = P;
   return NK_OK;
 }
@@ -670,7 +692,7 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
         if (j < ns - 1) gc.push_back(k + ns);
       }
     rp.push_back((int32_t)gc.size());
-    return nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out);
+    return nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out, P->replicated);
   }
   if (P->kind == NK_PROBLEM_BRUSSELATOR2D) {
     const int64_t N = P->ns, nl = P->j1 - P->j0, nn = N * nl;

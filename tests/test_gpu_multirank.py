@@ -177,6 +177,40 @@ def _worker(rank, world, port, q, transport="torch"):
         assert np.max(np.abs(solc.u.cpu().numpy() - refc.u[idx])) <= 1e-7
         note("brusselator_tr_concrete", solc.u.cpu().numpy())
         note("spmv_t", JB.rmatvec(vbl).cpu().numpy())
+
+        # ---------------- the multigrid V-cycle behind the `precs` hook on a row-partitioned hierarchy: every level split by
+        # grid lines, ghost lines of the neighbouring levels gathered for the transfers, coarsest level solved redundantly —
+        # the arithmetic must not depend on the partition: one V-cycle equals the serial oracle's to rounding, and the
+        # Newton–Krylov solve takes the oracle's step and iteration counts
+        nsm = 96
+        pbm, Pm = R.Bratu2D(nsm, 6.0), nls.Bratu2D(nsm, 6.0)
+        bm, em = Pm.row_begin, Pm.row_begin + Pm.n_local
+        xs = np.arange(1, nsm + 1) / (nsm + 1)
+        X, Y = np.meshgrid(xs, xs)
+        um = (0.8 * np.sin(np.pi * X) * np.sin(np.pi * Y)).ravel()
+        rhs_m = np.random.default_rng(3).standard_normal(pbm.n)
+        Mo = R.BratuMultigrid(pbm, um, 2, 15)
+        Jm = pbm.jac(um)
+        uml = torch.tensor(um[bm:em], device=dev)
+        opm = nls.StatefulJacobianOperator(nls.JacobianOperator(nls.NonlinearProblem(Pm)), uml)
+        Gm = nls.GMRES(em - bm, restart=30).set_operator(opm)
+        Gm.set_multigrid_preconditioner(Pm, uml, nu=2, coarse_max=15)
+        x1, _ = Gm.solve(torch.tensor(rhs_m[bm:em], device=dev), fixed_iters=1)
+        xo1, _ = R.gmres(lambda z: Jm @ z, rhs_m, restart=30, fixed_iters=1, M=Mo, ortho="cgs2")
+        x1g = nls.dist.gather_vector(x1, pbm.n, bm)
+        assert np.linalg.norm(x1g - xo1) <= 1e-10 * np.linalg.norm(xo1)
+        xf, gf = Gm.solve(torch.tensor(rhs_m[bm:em], device=dev), abstol=0.0, reltol=1e-9, maxiters=300)
+        xo, io = R.gmres(lambda z: Jm @ z, rhs_m, rtol=1e-9, restart=30, itmax=300, M=Mo, ortho="cgs2")
+        assert gf["converged"] and abs(gf["iters"] - io.iters) <= 1 and gf["iters"] <= 9
+        note("mg_gmres", nls.dist.gather_vector(xf, pbm.n, bm))
+        refm = R.solve(pbm, R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=R.MultigridPrecs(2, 15)), forcing=R.EisenstatWalkerForcing2()),
+                       abstol=1e-9, maxiters=50)
+        solm = nls.solve(nls.NonlinearProblem(Pm, u0=torch.zeros(em - bm, dtype=torch.float64, device=dev)),
+                         nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 15)),
+                                           forcing=nls.EisenstatWalkerForcing2()), abstol=1e-9, maxiters=50)
+        assert solm.retcode == "Success" and solm.stats.nsteps == refm.stats.nsteps
+        assert abs(solm.stats.gmres_iters - refm.stats.gmres_iters) <= 2
+        assert np.max(np.abs(nls.dist.gather_vector(solm.u, pbm.n, bm) - refm.u)) <= 5e-7
         assert ctx.comm_peer_status()[1] == 0        # no device-side time-outs
         q.put((rank, "ok", digest))
     except Exception:
