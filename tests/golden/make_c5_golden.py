@@ -18,11 +18,13 @@ from oracle import reference_restatement as R  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 pb = R.Brusselator2D(N)
 t = time.time()
-s = R.solve(pb, R.TrustRegion(), abstol=1e-8, maxiters=30)
+# abstol 1e-7: at N_g = 512 the residual itself carries ≈ 1.4e-8 of rounding (α/dx² = 2.6e6 times eps·|u|) — the direct-solve
+# oracle stagnates at ‖f‖∞ = 1.36e-8 with abstol = 1e-8, so the full-size comparison asks for 1e-7
+s = R.solve(pb, R.TrustRegion(), abstol=1e-7, maxiters=30)
 dt = time.time() - t
 print("retcode", R.RETCODE_NAMES[s.retcode], "nsteps", s.stats.nsteps, "fnorm", [r["fnorm_inf"] for r in s.trace],
       "accepted", [int(r["accepted"]) for r in s.trace], "seconds", round(dt, 1), flush=True)
-assert s.retcode == R.SUCCESS and np.max(np.abs(pb.f(s.u))) <= 1e-8
+assert s.retcode == R.SUCCESS and np.max(np.abs(pb.f(s.u))) <= 1e-7
 out = dict(N=N, nsteps=s.stats.nsteps, accepted=np.array([int(r["accepted"]) for r in s.trace]),
            trust_region=np.array([r["trust_region"] for r in s.trace]), fnorm_inf=np.array([r["fnorm_inf"] for r in s.trace]),
            u_l2=np.linalg.norm(s.u), u_inf=np.max(np.abs(s.u)), stride=64, u_samples=s.u[::64].copy(), seconds=dt)
