@@ -618,7 +618,9 @@ double orc_spmv_rate(int64_t ns, int reps) {
   return best;
 }
 
-#define ORC_TILE 2048 /* rows of u, z kept in cache while the columns stream past: long enough for the hardware prefetchers */
+#ifndef ORC_TILE
+#define ORC_TILE 1024 /* rows of u, z kept in L1/L2 while the columns stream past */
+#endif
 #define ORC_MAXM 64
 #define ORC_PAD 8 /* doubles between per-thread reduction rows (false sharing) */
 
