@@ -480,7 +480,9 @@ __global__ __launch_bounds__(DEPTH == 2 ? 512 : 256) void k_band_sweep(int64_t n
 // ----------------------------------------------------------------------------- host side
 int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
   nk_ctx *ctx = A->ctx;
-  NK_REQUIRE(ctx->nranks == 1, "the banded direct solver is single-rank");
+  // a matrix every rank holds in full (the multigrid's coarsest level on several ranks) is factored redundantly
+  NK_REQUIRE(ctx->nranks == 1 || (A->nrows == A->n_global && A->halo_gcols.empty() && !A->halo.active()),
+             "the banded direct solver needs the whole matrix on the rank (row-partitioned matrices: use a Krylov linsolve)");
   int kl = 0, ku = 0;
   for (int64_t r = 0; r < A->nrows; ++r)
     for (int32_t p = A->h_rowptr[r]; p < A->h_rowptr[r + 1]; ++p) {

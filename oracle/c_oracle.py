@@ -66,6 +66,7 @@ def lib():
         L.orc_stream_triad.argtypes = [C.c_int64, C.c_int]
         L.orc_spmv_rate.restype = C.c_double
         L.orc_spmv_rate.argtypes = [C.c_int64, C.c_int]
+        L.orc_phase_times.argtypes = [_d]
         L.orc_bratu_newton_fast.restype = C.c_double
         L.orc_bratu_newton_fast.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, _d]
         _lib = L
@@ -189,3 +190,11 @@ def bratu_newton_fast(ns, lam, scale, u0, nsteps, use_csr=True, m=30):
     if sec < 0:
         raise ValueError("bad restart length")
     return u, fn, sec
+
+
+def phase_times():
+    """Seconds thread 0 spent in [operator, dot sweep, reductions + tail (+ barrier waits), axpy sweep, rest] of the last
+    bratu_newton_fast run (diagnostics)."""
+    out = np.zeros(5)
+    lib().orc_phase_times(out)
+    return out

@@ -622,6 +622,9 @@ double orc_spmv_rate(int64_t ns, int reps) {
 #define ORC_TILE 1024 /* rows of u, z kept in L1/L2 while the columns stream past */
 #endif
 #define ORC_MAXM 64
+/* diagnostics: seconds thread 0 spent in [operator, dot sweep, reductions + scalar tail, axpy sweep, rest of the Newton step] */
+static double g_phase[5];
+void orc_phase_times(double *out) { for (int i = 0; i < 5; ++i) out[i] = g_phase[i]; }
 #define ORC_PAD 8 /* doubles between per-thread reduction rows (false sharing) */
 
 /* all-thread sum of cnt partials; part is [T][stride]; result in out[cnt] on every thread (identical order) */
@@ -701,6 +704,9 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
     for (int64_t i = lo; i < hi; ++i) f[i] = bp.c_lap * lap5(u, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]);
 #pragma omp barrier
     double t0 = now_s();
+    double tp = t0;
+    if (t == 0) for (int i = 0; i < 5; ++i) g_phase[i] = 0.0;
+#define ORC_PHASE(i) do { if (t == 0) { const double tn_ = now_s(); g_phase[i] += tn_ - tp; tp = tn_; } } while (0)
     for (int step = 0; step < nsteps; ++step) {
       /* ---- Jacobian values (f.jac): rows of this thread */
       if (use_csr) {
@@ -732,6 +738,7 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
       g[0] = beta0;
       int kdone = 0;
 #pragma omp barrier
+      ORC_PHASE(4);
       for (int k = 0; k <= m; ++k) {
         const int last = (k == m);
         double *uk = V + (size_t)k * n, *zk = V + (size_t)(k + 1) * n;
@@ -748,6 +755,7 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
               zk[i] = bp.c_lap * lap5(uk, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]) * uk[i];
           }
         }
+        ORC_PHASE(0);
         /* dot sweep: red = [V_jᵀu (k), u·u, V_jᵀz (k), u·z] */
         const int cnt = last ? k + 1 : 2 * k + 2;
         for (int q = 0; q < cnt; ++q) mine[q] = 0.0;
@@ -766,17 +774,34 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
             if (!last) mine[2 * k + 1] += ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
           }
           if (!last) {
-            for (int j = 0; j < k; ++j) {
+            /* four columns at a time share the loads of the u, z tile; `omp simd reduction` lets the compiler keep eight
+             * vector accumulators (its association is fixed by the build, so runs are reproducible) */
+            int j = 0;
+            for (; j + 4 <= k; j += 4) {
+              const double *v0 = V + (size_t)j * n + r0, *v1 = v0 + n, *v2 = v1 + n, *v3 = v2 + n;
+              double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma omp simd reduction(+ : a0, a1, a2, a3, b0, b1, b2, b3)
+              for (int i = 0; i < len; ++i) {
+                const double uu = ut[i], zz = zt[i];
+                a0 += v0[i] * uu; b0 += v0[i] * zz;
+                a1 += v1[i] * uu; b1 += v1[i] * zz;
+                a2 += v2[i] * uu; b2 += v2[i] * zz;
+                a3 += v3[i] * uu; b3 += v3[i] * zz;
+              }
+              mine[j] += a0; mine[j + 1] += a1; mine[j + 2] += a2; mine[j + 3] += a3;
+              mine[k + 1 + j] += b0; mine[k + 2 + j] += b1; mine[k + 3 + j] += b2; mine[k + 4 + j] += b3;
+            }
+            for (; j < k; ++j) {
               const double *vj = V + (size_t)j * n + r0;
-              double u8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-              for (int i = 0; i < len8; i += 8)
-                for (int q = 0; q < 8; ++q) { u8[q] += vj[i + q] * ut[i + q]; z8[q] += vj[i + q] * zt[i + q]; }
-              for (int i = len8; i < len; ++i) { u8[0] += vj[i] * ut[i]; z8[0] += vj[i] * zt[i]; }
-              mine[j] += ((u8[0] + u8[1]) + (u8[2] + u8[3])) + ((u8[4] + u8[5]) + (u8[6] + u8[7]));
-              mine[k + 1 + j] += ((z8[0] + z8[1]) + (z8[2] + z8[3])) + ((z8[4] + z8[5]) + (z8[6] + z8[7]));
+              double a0 = 0, b0 = 0;
+#pragma omp simd reduction(+ : a0, b0)
+              for (int i = 0; i < len; ++i) { a0 += vj[i] * ut[i]; b0 += vj[i] * zt[i]; }
+              mine[j] += a0;
+              mine[k + 1 + j] += b0;
             }
           }
         }
+        ORC_PHASE(1);
         team_sum(part, stride, cnt, mine, red);
         if (k == 0) { /* v_0 is final: only the first projection of A v_0 */
           const double tl = red[1];
@@ -831,16 +856,31 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
         const double tlast = (dval - rg - beta * cc[k]) * isb * isb;
         tprev[k] = tlast;
         const double cbk = cc[k] * isb + tlast;
+        ORC_PHASE(2);
         /* ---- axpy sweep (tile of u, z kept in L1 while the final columns stream past) */
         for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
           const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
           double pu[ORC_TILE], pz[ORC_TILE];
           const int len = (int)(r1 - r0);
           for (int i = 0; i < len; ++i) { pu[i] = uk[r0 + i]; pz[i] = zk[r0 + i] * isb; }
-          for (int j = 0; j < k; ++j) {
-            const double *vj = V + (size_t)j * n + r0;
-            const double a = ca[j], b = cb[j];
-            for (int i = 0; i < len; ++i) { pu[i] -= a * vj[i]; pz[i] -= b * vj[i]; }
+          {
+            int j = 0;
+            for (; j + 4 <= k; j += 4) {  /* four columns per pass over the tile */
+              const double *v0 = V + (size_t)j * n + r0, *v1 = v0 + n, *v2 = v1 + n, *v3 = v2 + n;
+              const double a0 = ca[j], a1 = ca[j + 1], a2 = ca[j + 2], a3 = ca[j + 3];
+              const double b0 = cb[j], b1 = cb[j + 1], b2 = cb[j + 2], b3 = cb[j + 3];
+#pragma omp simd
+              for (int i = 0; i < len; ++i) {
+                pu[i] -= (a0 * v0[i] + a1 * v1[i]) + (a2 * v2[i] + a3 * v3[i]);
+                pz[i] -= (b0 * v0[i] + b1 * v1[i]) + (b2 * v2[i] + b3 * v3[i]);
+              }
+            }
+            for (; j < k; ++j) {
+              const double *vj = V + (size_t)j * n + r0;
+              const double a = ca[j], b = cb[j];
+#pragma omp simd
+              for (int i = 0; i < len; ++i) { pu[i] -= a * vj[i]; pz[i] -= b * vj[i]; }
+            }
           }
           for (int i = 0; i < len; ++i) {
             const double vk = pu[i] * isb;
@@ -848,7 +888,9 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
             zk[r0 + i] = pz[i] - cbk * vk;
           }
         }
+        ORC_PHASE(3);
 #pragma omp barrier
+        ORC_PHASE(2);
       }
       /* ---- y = R⁻¹ g ; x = V y ; u −= x ; f = F(u) ; ‖f‖∞ */
       for (int i = kdone - 1; i >= 0; --i) {
