@@ -15,10 +15,11 @@ def main():
     from oracle import c_oracle as CO
     CO.build()
     # thread count: the runtime offers every hardware thread of the affinity mask, but SMT siblings and a container's CPU
-    # quota make "all of them" a bad default for a streaming code: take the count with which one step of THIS workload runs
+    # quota (the GPU box hands a job far fewer CPUs than its affinity mask lists: beyond ≈ 32 threads the barriers wait on
+    # descheduled threads) make "all of them" a bad default for a streaming code: take the count with which one step of THIS workload runs
     # fastest (and report the STREAM triad measured with the count that is best for the triad)
     avail = CO.num_threads()
-    cands = sorted({max(1, avail // 4), max(1, avail // 2), avail})
+    cands = sorted({max(1, avail // 16), max(1, avail // 8), max(1, avail // 4), max(1, avail // 2), avail})
     z0 = np.zeros(ns * ns)
     best_t, best_dt, triad = avail, float("inf"), 0.0
     for t in cands:
