@@ -21,12 +21,13 @@ def main():
     avail = CO.num_threads()
     cands = sorted({max(1, avail // 16), max(1, avail // 8), max(1, avail // 4), max(1, avail // 2), avail})
     z0 = np.zeros(ns * ns)
-    best_t, best_dt, triad = avail, float("inf"), 0.0
+    best_t, best_dt, triad, scan = avail, float("inf"), 0.0, {}
     for t in cands:
         CO.set_num_threads(t)
         triad = max(triad, CO.stream_triad(1 << 25, 2))
         CO.bratu_newton_fast(ns, 6.0, 0.0, z0, 1, use_csr=not matfree, m=arnoldi)          # placement / warm-up
-        _, _, dt = CO.bratu_newton_fast(ns, 6.0, 0.0, z0, 2, use_csr=not matfree, m=arnoldi)
+        dt = min(CO.bratu_newton_fast(ns, 6.0, 0.0, z0, 2, use_csr=not matfree, m=arnoldi)[2] for _ in range(2)) / 2.0
+        scan[t] = round(1.0 / dt, 2)
         if dt < 0.97 * best_dt:
             best_t, best_dt = t, dt
     CO.set_num_threads(best_t)
@@ -44,6 +45,10 @@ def main():
     _, _, t1 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, 1, use_csr=not matfree, m=arnoldi)   # also places / warms
     k = int(max(2, min(400, (0.6 * budget_s) / max(t1, 1e-4))))
     _, fn, tk = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
+    if k / tk < 0.7 / best_dt:   # a shared host: the sample ran far below what the scan saw a moment ago — take a second one
+        _, fn2, tk2 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
+        if tk2 < tk:
+            fn, tk = fn2, tk2
     rate = k / tk
     CO.set_num_threads(1)
     k1 = 1 if t1 * cores > 0.2 * budget_s else 2
@@ -59,7 +64,7 @@ def main():
         "effective_GBs": round(eff, 1), "stream_triad_GBs": round(triad, 1),
         "frac_of_stream_triad": round(eff / triad, 3) if triad > 0 else None,
         "spmv_GBs": round(spmv, 1), "spmv_frac_of_triad": round(spmv / triad, 3) if triad > 0 else None,
-        "single_thread_value": round(k1 / ts, 4), "fnorm_inf_last": float(fn[-1]),
+        "single_thread_value": round(k1 / ts, 4), "thread_scan_steps_per_s": scan, "fnorm_inf_last": float(fn[-1]),
         "note": "restatement of the reference algorithm (Julia is not installed on this box); a reported baseline, not the target"}))
 
 
