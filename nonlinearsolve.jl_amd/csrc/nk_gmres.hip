@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy_tail(int64_t n, int k,
                                                                const double *__restrict__ tprev_in,
                                                                double *__restrict__ tprev_out, double *R, double *cs,
                                                                double *sn, double *g, double *__restrict__ ss_partials,
-                                                               nk_gmres_pub *pub, uint64_t seq) {
+                                                               nk_gmres_pub *pub, uint64_t seq, int desc) {
   constexpr int NH = MAXM + 2, LH = MAXM + 1;
   __shared__ double sr[NH], sg[NH], sc_[NH], sh[NH], scs[NH], ssn[NH], ssc[NH], ca[NH + 1], cb[NH + 1];
   __shared__ double sH[NH * LH];
@@ -473,7 +473,13 @@ __global__ __launch_bounds__(NK_BLOCK) void k_dcgs2r_axpy_tail(int64_t n, int k,
   const double sz = s_sz, bk = s_bk;
 #pragma unroll
   for (int i = 0; i < DRT; ++i) zv[i] *= sz;
-  for (int j = 0; j < k; j += 2) {
+  // column pairs (j, j+1), j even. `desc`: from the last pair down to the first — the dot sweep that ran just before
+  // this launch read the columns in ascending order, so the highest columns are the ones most recently brought into the
+  // Infinity Cache (256 MiB against a basis of up to 260 MB + the 74 MB matrix at 1024²: a cyclic ascending/ascending
+  // order evicts every line before it is read again, the zig-zag re-reads the freshest ≈ 150 MB).
+  const int npair = (k + 1) >> 1;
+  for (int q = 0; q < npair; ++q) {
+    const int j = 2 * (desc ? npair - 1 - q : q);
     const int j1 = min(j + 1, k - 1);
     const double *__restrict__ c0 = V + (size_t)j * ldv;
     const double *__restrict__ c1 = V + (size_t)j1 * ldv;
@@ -1136,14 +1142,15 @@ static int arnoldi_step_1r(nk_gmres *G, int k, bool last_of_cycle) {
   {
     nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 4));
     double *ssp = ss_out ? ctx->d_partials : (double *)nullptr;
+    static const int desc = getenv("NK_AXPY_DESC") ? atoi(getenv("NK_AXPY_DESC")) : 1;  // NK_AXPY_DESC=0: ascending (A/B)
     if (G->m <= 31)
       NK_LAUNCH(ctx, k_dcgs2r_axpy_tail<32>, dim3(grid), dim3(NK_BLOCK), n, k, G->V, ldv, G->d_ctl, (const double *)G->d_red,
                 G->d_s, G->d_Hraw, G->m, (const double *)tprev_buf(G, k), tprev_buf(G, k + 1), G->d_R, G->d_cs, G->d_sn,
-                G->d_g, ssp, G->h_pub_dev, G->cycle_seq);
+                G->d_g, ssp, G->h_pub_dev, G->cycle_seq, desc);
     else
       NK_LAUNCH(ctx, k_dcgs2r_axpy_tail<NK_MAX_NV>, dim3(grid), dim3(NK_BLOCK), n, k, G->V, ldv, G->d_ctl,
                 (const double *)G->d_red, G->d_s, G->d_Hraw, G->m, (const double *)tprev_buf(G, k), tprev_buf(G, k + 1),
-                G->d_R, G->d_cs, G->d_sn, G->d_g, ssp, G->h_pub_dev, G->cycle_seq);
+                G->d_R, G->d_cs, G->d_sn, G->d_g, ssp, G->h_pub_dev, G->cycle_seq, desc);
   }
   NK_HIP(hipGetLastError());
   if (ss_out) NK_TRY(nk_blas_reduce_one(ctx, ctx->d_partials, grid, ss_out, skip));

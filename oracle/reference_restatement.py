@@ -655,6 +655,21 @@ class GaussNewton:  # gauss_newton.jl:11-23 on a NonlinearLeastSquaresProblem: N
     name: str = "GaussNewton"
 
 
+@dataclass
+class LevenbergMarquardt:  # levenberg_marquardt.jl:37-64: GeodesicAcceleration(DampedNewtonDescent(LM damping)) +
+    linsolve: object = None      # LevenbergMarquardtTrustRegion, concrete_jac = Val(true)
+    damping_initial: float = 1.0
+    alpha_geodesic: float = 0.75
+    disable_geodesic: bool = False
+    damping_increase_factor: float = 2.0
+    damping_decrease_factor: float = 3.0
+    finite_diff_step_geodesic: float = 0.1
+    b_uphill: float = 1.0
+    min_damping_D: float = 1e-8
+    concrete_jac: Optional[bool] = True
+    name: str = "LevenbergMarquardt"
+
+
 SIMPLE, NLSOLVE, NOCEDAL_WRIGHT, HEI, YUAN, BASTIN, FAN = range(7)
 
 
@@ -805,6 +820,7 @@ class FirstOrderCache:
         self.termination_kwargs = termination_kwargs or {}
         self.store_trace = store_trace
         self.is_tr = isinstance(alg, TrustRegion)
+        self.is_lm = isinstance(alg, LevenbergMarquardt)
         ls = alg.linsolve
         self.krylov = ls if isinstance(ls, KrylovJL_GMRES) else None
         # jacobian.jl:43-47 — concrete J needed unless a Krylov method without concrete_jac
@@ -839,6 +855,109 @@ class FirstOrderCache:
         self.lin_abstol = self.abstol
         if self.is_tr:
             self._tr_init(self.u, self.fu)
+        if self.is_lm:
+            self._lm_init(self.u)
+
+    # -- LevenbergMarquardt: damping cache (levenberg_marquardt.jl:72-117), LevenbergMarquardtTrustRegionCache (:204-245),
+    #    GeodesicAccelerationCache (geodesic_acceleration.jl:51-55); also what their reinit! methods restore
+    def _lm_init(self, u):
+        a = self.alg
+        self.lm_lam = float(a.damping_initial)
+        self.lm_lam_factor = float(a.damping_increase_factor)
+        self.lm_DtD = np.full(u.size, float(a.min_damping_D))
+        self.lm_Jdamped = self.lm_lam * self.lm_DtD
+        self.lm_v_cache = np.array(u, copy=True)      # `@bb v = copy(u)` (:212) — the iterate, not a velocity
+        self.lm_norm_v_old = float("inf")
+        self.lm_loss_old = float("inf")               # never written again by the reference (:250-268)
+        self.lm_tr_accepted = False
+        self.lm_geo_accepted = False
+        self.lm_beta = float("nan")
+
+    # DampedNewtonDescent.solve! (descent/damped_newton.jl:224-345) in the two modes a NonlinearProblem reaches:
+    # :normal_form when the linear solver needs a square A (Krylov), :least_squares otherwise (linsolve = nothing → QR of
+    # [J; √(λDᵀD)]). recompute_A = (idx === Val(1)): the velocity solve refreshes DᵀD and the damped matrix, the
+    # acceleration solve reuses them. Returns δu = −x, or None when the linear solve reports failure.
+    def _lm_damped_solve(self, rhs, recompute_A):
+        self.stats.nsolve += 1
+        J = self.J
+        if recompute_A:   # (J !== nothing || new_jacobian) && recompute_A — a concrete J is never `nothing`
+            diag = np.asarray(J.multiply(J).sum(axis=0)).ravel() if sp.issparse(J) else np.sum(np.asarray(J) ** 2, axis=0)
+            self.lm_DtD = np.maximum(self.lm_DtD, diag)   # update_levenberg_marquardt_diagonal!! (:270-293)
+            self.lm_Jdamped = self.lm_lam * self.lm_DtD   # @. J_damped = λ * DᵀD
+        D = self.lm_Jdamped
+        if self.krylov is not None:    # :normal_form — (JᵀJ + λDᵀD) x = Jᵀ rhs
+            kr = self.krylov
+            b = J.T @ rhs
+            op = lambda v: J.T @ (J @ v) + D * v  # noqa: E731
+            x, info = gmres(op, b, None, atol=self.lin_abstol, rtol=self.lin_reltol, restart=kr.gmres_restart,
+                            itmax=kr.maxiters, fixed_iters=kr.fixed_iters, ortho=kr.ortho)
+            self.stats.gmres_iters += info.iters
+            self.last_gmres = info
+            if info.failed:
+                return None
+        else:                          # :least_squares — min ‖[J; √D] x − [rhs; 0]‖ (QR in the reference)
+            n = J.shape[1]
+            if n <= 4000:
+                Jd = J.toarray() if sp.issparse(J) else np.asarray(J)
+                A = np.vstack([Jd, np.diag(np.sqrt(D))])
+                x = np.linalg.lstsq(A, np.concatenate([rhs, np.zeros(n)]), rcond=None)[0]
+            else:                      # large sparse J: the same minimiser through the normal equations (SPQR is [EXT])
+                import scipy.sparse.linalg as spla
+                x = spla.spsolve(sp.csc_matrix(J.T @ J + sp.diags(D)), J.T @ rhs)
+            if not np.all(np.isfinite(x)):
+                return None
+        return -x
+
+    # GeodesicAcceleration.solve! (descent/geodesic_acceleration.jl:98-136); without it the damped Newton step itself
+    def _lm_descent(self):
+        a = self.alg
+        v = self._lm_damped_solve(self.fu, True)
+        if a.disable_geodesic:
+            if v is None:
+                return None, False, None
+            return v, True, v
+        if v is None:            # geodesic's solve! reads `.δu` only: an inner linear-solve failure is not propagated
+            v = self.du.copy()
+        h = float(a.finite_diff_step_geodesic)
+        fu_c = self.prob.f(self.u + h * v)                     # Utils.evaluate_f!! — not counted in stats.nf
+        Jv = self.J @ v
+        fu_c = (2.0 / h) * ((fu_c - self.fu) / h - Jv)
+        acc = self._lm_damped_solve(fu_c, False)
+        if acc is None:
+            acc = np.zeros_like(v)
+        self.lm_geo_accepted = bool(2.0 * L2_NORM(acc) <= L2_NORM(v) * float(a.alpha_geodesic))
+        du = v + acc / 2.0 if self.lm_geo_accepted else self.du  # a rejected step leaves δu as it was
+        return du, self.lm_geo_accepted, v
+
+    # LevenbergMarquardtTrustRegionCache solve! (levenberg_marquardt.jl:247-268)
+    def _lm_tr_solve(self, du, v):
+        norm_v = L2_NORM(v)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            beta = float(np.dot(v, self.lm_v_cache)) / (norm_v * self.lm_norm_v_old)
+        self.lm_beta = beta
+        u_new = self.u + du
+        fu_new = self.prob.f(u_new)
+        self.stats.nf += 1
+        loss = L2_NORM(fu_new)
+        try:
+            lhs = math.pow(1.0 - beta, float(self.alg.b_uphill)) * loss
+        except ValueError:   # negative base, fractional exponent: Julia throws a DomainError here
+            lhs = float("nan")
+        if lhs <= self.lm_loss_old:
+            self.lm_tr_accepted = True
+            self.lm_norm_v_old = norm_v
+            self.lm_v_cache = np.array(v, copy=True)
+        else:
+            self.lm_tr_accepted = False
+        return self.lm_tr_accepted, u_new, fu_new
+
+    # callback_into_cache!(topcache, ::LevenbergMarquardtDampingCache) (levenberg_marquardt.jl:159-168)
+    def _lm_callback(self):
+        geo_ok = True if self.alg.disable_geodesic else self.lm_geo_accepted   # last_step_accepted default: true
+        if self.lm_tr_accepted and geo_ok:
+            self.lm_lam_factor = 1.0 / float(self.alg.damping_decrease_factor)
+        self.lm_lam *= self.lm_lam_factor
+        self.lm_lam_factor = float(self.alg.damping_increase_factor)
 
     # -- trust_region.jl:204-258 (+ defaults :320-384)
     def _tr_defaults(self):
@@ -1148,6 +1267,8 @@ class FirstOrderCache:
             new_jacobian = False
         if self.forcing is not None:
             self._pre_step_forcing(self.nsteps)
+        if self.is_lm:
+            return self._lm_step(new_jacobian, recompute_jacobian, evaluate_residual)
         if self.is_tr:
             du, duJJdu = self._dogleg(new_jacobian, self.trust_region)
         else:
@@ -1204,6 +1325,41 @@ class FirstOrderCache:
                                    rho=self.rho if self.is_tr else float("nan")))
         self.u_cache = self.u.copy()
 
+    # the rest of step! (FirstOrder/src/solve.jl:365-462) for LevenbergMarquardt: Val(:TrustRegion) globalisation with a
+    # cache that has neither `trust_region` nor `shrink_counter`, and a descent that can report success = false
+    def _lm_step(self, new_jacobian, recompute_jacobian, evaluate_residual):
+        du, success, v = self._lm_descent()
+        if du is None:  # DampedNewtonDescent alone: linsolve_success = false
+            if new_jacobian:
+                self.retcode = LINSOLVE_FAILED
+                self.force_stop = True
+                return
+            self.make_new_jacobian = True
+            return self._internal_step(True, evaluate_residual)
+        accepted = False
+        if success:
+            self.du = du
+            self.make_new_jacobian = True
+            accepted, u_new, fu_new = self._lm_tr_solve(du, v)
+            if accepted:
+                self.u = u_new.copy()
+                self.fu = fu_new.copy()
+            else:
+                self.make_new_jacobian = False
+            if self.tc(self.fu, self.u, self.u_cache):
+                self.retcode = self.tc.retcode
+                self._rollback_to_best()
+                self.force_stop = True
+        else:
+            self.make_new_jacobian = False
+        if self.store_trace:
+            self.trace.append(dict(iter=self.nsteps + 1, fnorm_inf=Linf_NORM(self.fu), step_norm2=L2_NORM(self.du),
+                                   eta=self.lin_reltol if self.krylov is not None else float("nan"),
+                                   gmres_iters=self.last_gmres.iters if self.krylov is not None else 0,
+                                   accepted=bool(accepted), trust_region=self.lm_lam, rho=self.lm_beta))
+        self.u_cache = self.u.copy()
+        self._lm_callback()
+
     def _rollback_to_best(self):  # update_from_termination_cache! (termination_conditions.jl:440-453)
         if self.tc.u is None or np.array_equal(self.u, self.tc.u):
             return
@@ -1246,6 +1402,8 @@ class FirstOrderCache:
             self.last_step_accepted = False
             self.trust_region = self.initial_trust_radius
             self.shrink_counter = 0
+        if self.is_lm:
+            self._lm_init(self.u)
 
 
 def init(prob, alg, **kw):
