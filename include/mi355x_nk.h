@@ -76,7 +76,12 @@ typedef enum {
 /* NK_ALG_GAUSS_NEWTON: NewtonDescent in NORMAL FORM, JᵀJ δ = Jᵀ f through the normal-form operator — what GaussNewton
  * (lib/NonlinearSolveFirstOrder/src/gauss_newton.jl:11-23) does on a NonlinearLeastSquaresProblem with a Krylov linsolve
  * (descent/newton.jl:58-95,107-118; StatefulJacobianNormalFormOperator, SciMLJacobianOperators.jl:252-291). */
-typedef enum { NK_ALG_NEWTON_RAPHSON = 0, NK_ALG_TRUST_REGION = 1, NK_ALG_GAUSS_NEWTON = 2 } nk_algorithm;
+/* NK_ALG_LEVENBERG_MARQUARDT: the damped normal equations (JᵀJ + λDᵀD) δ = Jᵀ f through the same normal-form operator
+ * plus a diagonal (DampedNewtonDescent in :normal_form mode, descent/damped_newton.jl:186-200,297-313 — the mode a Krylov
+ * `linsolve` selects), geodesic acceleration (descent/geodesic_acceleration.jl:98-136) and the damping-based trust region
+ * (levenberg_marquardt.jl:159-168,247-268). Needs a concrete J (concrete_jac = Val(true)) and a Krylov linsolve. */
+typedef enum { NK_ALG_NEWTON_RAPHSON = 0, NK_ALG_TRUST_REGION = 1, NK_ALG_GAUSS_NEWTON = 2,
+               NK_ALG_LEVENBERG_MARQUARDT = 3 } nk_algorithm;
 
 /* which operator the Krylov solver sees as A (lib/NonlinearSolveBase/src/jacobian.jl:43-47,90-102) */
 typedef enum {
@@ -213,7 +218,16 @@ typedef struct {
    *     colour-compressed assembly of `AutoSparse` + column colouring (ncolors seeded JVPs + decompression,
    *     lib/NonlinearSolveBase/src/jacobian.jl:244-247) every time the Jacobian is refreshed */
   int32_t jac_colored;
-  int32_t reserved0;
+  /* --- LevenbergMarquardt (lib/NonlinearSolveFirstOrder/src/levenberg_marquardt.jl:37-64; constructor defaults in
+   *     brackets): GeodesicAcceleration(DampedNewtonDescent(LM damping)) + LevenbergMarquardtTrustRegion */
+  int32_t lm_disable_geodesic;          /* [0] 1 = plain damped Newton step (disable_geodesic = Val(true))           */
+  double  lm_damping_initial;           /* [1]    λ₀                                                                  */
+  double  lm_damping_increase_factor;   /* [2]    λ ← 2λ after a step that was not taken                              */
+  double  lm_damping_decrease_factor;   /* [3]    λ ← λ/3 after an accepted step                                      */
+  double  lm_min_damping_D;             /* [1e-8] floor of DᵀD = running max of diag(JᵀJ)                             */
+  double  lm_alpha_geodesic;            /* [0.75] a step is taken only if 2‖a‖ ≤ α‖v‖                                 */
+  double  lm_finite_diff_step_geodesic; /* [0.1]  h of the second directional derivative                              */
+  double  lm_b_uphill;                  /* [1]    uphill moves: (1 − β)^b · ‖f_new‖ ≤ loss_old                        */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -332,6 +346,9 @@ double *nk_csr_values_device(nk_csr *A);      /* device pointer of the local val
  * ranks own return through the halo plan in reverse and are added in rank order: bitwise reproducible). */
 int nk_spmv(nk_csr *A, const double *x, double *y, int memspace);
 int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace);
+/* out_j = Σ_i A_ij² — diag(AᵀA), what LevenbergMarquardt's damping takes its DᵀD from (`sum!(abs2, J_diag_cache, J')`,
+ * levenberg_marquardt.jl:133-148). Row-partitioned matrices: the same reverse halo exchange as nk_spmv_t. */
+int nk_csr_colsumsq(nk_csr *A, double *out, int memspace);
 
 /* ---------------------------------------------------------------- problems (seam 2) */
 /* params: QUADRATIC {n, p}; BRATU2D {n_side, lambda, scale (0 → h², i.e. h²F)};
@@ -364,6 +381,10 @@ int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* on != 0: the operator of the next solves is AᵀA for the CSR / problem operator that is set (normal form: the
  * transposed half is the distributed transposed SpMV or the problem's VJP); the caller passes b = Aᵀ f. */
 int nk_gmres_set_normal_form(nk_gmres *G, int on);   /* AbstractSciMLOperator    */
+/* Damped normal form: the operator becomes AᵀA + lambda·diag(d) (d: DEVICE vector of local length n, kept by reference;
+ * NULL switches the damping off) — `dampen_jacobian!!(J_cache, JᵀJ, λ·DᵀD)` of DampedNewtonDescent's :normal_form mode
+ * (lib/NonlinearSolveBase/src/descent/damped_newton.jl:297-313,356-370) without assembling JᵀJ. */
+int nk_gmres_set_normal_form_damping(nk_gmres *G, const double *d_diag, double lambda);
 /* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
 int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* The same two hooks for operators that live in HOST memory (a Julia `mul!` on plain Arrays): the callback receives host

@@ -289,6 +289,19 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     mg_nu::Int = 2
     mg_coarse::Int = 31
     jac_colored::Bool = false             # concrete J by colour-compressed assembly (AutoSparse analogue) instead of f.jac
+    # :auto (NewtonRaphson, or TrustRegion when trust_region = true) | :GaussNewton | :LevenbergMarquardt — the latter two
+    # solve the (damped) normal equations through the device normal-form operator and need concrete_jac + a Krylov linsolve
+    method::Symbol = :auto
+    # LevenbergMarquardt(; damping_initial, damping_increase_factor, damping_decrease_factor, min_damping_D, α_geodesic,
+    # finite_diff_step_geodesic, b_uphill, disable_geodesic) — levenberg_marquardt.jl:37-64
+    lm_damping_initial::Float64 = 1.0
+    lm_damping_increase_factor::Float64 = 2.0
+    lm_damping_decrease_factor::Float64 = 3.0
+    lm_min_damping_D::Float64 = 1e-8
+    lm_alpha_geodesic::Float64 = 0.75
+    lm_finite_diff_step_geodesic::Float64 = 0.1
+    lm_b_uphill::Float64 = 1.0
+    lm_disable_geodesic::Bool = false
 end
 
 # termination_condition → nk_options.termination_mode / termination_norm and the mode struct's fields
@@ -329,7 +342,10 @@ Base.@kwdef mutable struct NKOptions
     cheb_degree::Int32 = 0; linesearch::Int32 = 0; cheb_ratio::Float64 = 0.0
     ls_c1::Float64 = 1e-4; ls_rho_hi::Float64 = 0.5; ls_rho_lo::Float64 = 0.1; ls_order::Int32 = 3; ls_maxiters::Int32 = 1000
     mg_nu::Int32 = 0; mg_coarse::Int32 = 0
-    jac_colored::Int32 = 0; reserved0::Int32 = 0
+    jac_colored::Int32 = 0; lm_disable_geodesic::Int32 = 0
+    lm_damping_initial::Float64 = 1.0; lm_damping_increase_factor::Float64 = 2.0; lm_damping_decrease_factor::Float64 = 3.0
+    lm_min_damping_D::Float64 = 1e-8; lm_alpha_geodesic::Float64 = 0.75; lm_finite_diff_step_geodesic::Float64 = 0.1
+    lm_b_uphill::Float64 = 1.0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,
@@ -339,8 +355,14 @@ const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, R
 function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, args...;
         abstol = nothing, reltol = nothing, maxiters = 1000, maxtime = nothing, termination_condition = nothing,
         kwargs...)
-    o = NKOptions(; algorithm = alg.trust_region ? 1 : 0,
-        linsolve = alg.direct ? 2 : (alg.concrete_jac ? 1 : 0),
+    algorithm = alg.method === :LevenbergMarquardt ? 3 : alg.method === :GaussNewton ? 2 : (alg.trust_region ? 1 : 0)
+    o = NKOptions(; algorithm = algorithm,
+        linsolve = alg.direct ? 2 : ((alg.concrete_jac || algorithm == 3) ? 1 : 0),
+        lm_disable_geodesic = alg.lm_disable_geodesic ? 1 : 0, lm_damping_initial = alg.lm_damping_initial,
+        lm_damping_increase_factor = alg.lm_damping_increase_factor,
+        lm_damping_decrease_factor = alg.lm_damping_decrease_factor, lm_min_damping_D = alg.lm_min_damping_D,
+        lm_alpha_geodesic = alg.lm_alpha_geodesic, lm_finite_diff_step_geodesic = alg.lm_finite_diff_step_geodesic,
+        lm_b_uphill = alg.lm_b_uphill,
         maxiters = maxiters, abstol = something(abstol, 0.0), reltol = something(reltol, 0.0),
         maxtime = something(maxtime, 0.0),
         gmres_restart = alg.gmres_restart, gmres_maxiters = alg.gmres_maxiters,

@@ -20,7 +20,7 @@ HOST, DEVICE = 0, 1
 RET_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalLinearSolveFailed",
              "ShrinkThresholdExceeded", "MaxTime", "Failure", "InternalLineSearchFailed"]
 PROBLEM_QUADRATIC, PROBLEM_BRATU2D, PROBLEM_BRUSSELATOR2D, PROBLEM_USER = 1, 2, 3, 100
-ALG_NEWTON_RAPHSON, ALG_TRUST_REGION, ALG_GAUSS_NEWTON = 0, 1, 2
+ALG_NEWTON_RAPHSON, ALG_TRUST_REGION, ALG_GAUSS_NEWTON, ALG_LEVENBERG_MARQUARDT = 0, 1, 2, 3
 LINSOLVE_GMRES_MATFREE, LINSOLVE_GMRES_CSR, LINSOLVE_BANDED_LU = 0, 1, 2
 ORTHO_MGS, ORTHO_CGS2, ORTHO_CGS, ORTHO_DCGS2, ORTHO_DCGS2_1R = 0, 1, 2, 3, 4
 FORCING_NONE, FORCING_EW2 = 0, 1
@@ -67,7 +67,10 @@ class Options(C.Structure):
         ("cheb_degree", C.c_int32), ("linesearch", C.c_int32), ("cheb_ratio", C.c_double),
         ("ls_c1", C.c_double), ("ls_rho_hi", C.c_double), ("ls_rho_lo", C.c_double),
         ("ls_order", C.c_int32), ("ls_maxiters", C.c_int32), ("mg_nu", C.c_int32), ("mg_coarse", C.c_int32),
-        ("jac_colored", C.c_int32), ("reserved0", C.c_int32),
+        ("jac_colored", C.c_int32), ("lm_disable_geodesic", C.c_int32),
+        ("lm_damping_initial", C.c_double), ("lm_damping_increase_factor", C.c_double),
+        ("lm_damping_decrease_factor", C.c_double), ("lm_min_damping_D", C.c_double),
+        ("lm_alpha_geodesic", C.c_double), ("lm_finite_diff_step_geodesic", C.c_double), ("lm_b_uphill", C.c_double),
     ]
 
 
@@ -124,6 +127,8 @@ SIGNATURES = {
     "nk_csr_values_device": (_P, [_P]),
     "nk_spmv": (_I, [_P, _P, _P, _I]),
     "nk_spmv_t": (_I, [_P, _P, _P, _I]),
+    "nk_csr_colsumsq": (_I, [_P, _P, _I]),
+    "nk_gmres_set_normal_form_damping": (_I, [_P, _P, C.c_double]),
     "nk_problem_create": (_I, [_P, _I, C.POINTER(_D), _I, _PP]),
     "nk_problem_create_user": (_I, [_P, _L, _L, _L, C.POINTER(UserCallbacks), _P, _P, _PP]),
     "nk_problem_destroy": (_I, [_P]),

@@ -318,6 +318,14 @@ class CSRMatrix:
         check(L.lib().nk_spmv_t(self._h, px, py, ms))
         return y
 
+    def colsumsq(self, like=None):
+        """diag(AᵀA): out_j = Σ_i A_ij² (LevenbergMarquardt's DᵀD source, levenberg_marquardt.jl:133-148)."""
+        n = self.info()["nrows_local"]
+        y = np.empty(n) if like is None else _like(like, n)
+        py, ms, _k = _ptr(y, n)
+        check(L.lib().nk_csr_colsumsq(self._h, py, ms))
+        return y
+
     __matmul__ = matvec
 
     def close(self):
@@ -608,6 +616,22 @@ class GaussNewton:  # gauss_newton.jl:11-23: NewtonDescent; on a least-squares p
 
 
 @dataclass
+class LevenbergMarquardt:  # levenberg_marquardt.jl:37-64 (keyword names of the reference; α_geodesic spelt alpha_geodesic)
+    linsolve: Optional[KrylovJL_GMRES] = None
+    damping_initial: float = 1.0
+    alpha_geodesic: float = 0.75
+    disable_geodesic: bool = False
+    damping_increase_factor: float = 2.0
+    damping_decrease_factor: float = 3.0
+    finite_diff_step_geodesic: float = 0.1
+    b_uphill: float = 1.0
+    min_damping_D: float = 1e-8
+    concrete_jac: Optional[bool] = True   # concrete_jac = Val(true) in the reference's constructor
+    jac_colored: bool = False
+    name: str = "LevenbergMarquardt"
+
+
+@dataclass
 class _TerminationMode:
     """SciMLBase termination modes (lib/NonlinearSolveBase/src/termination_conditions.jl); `internalnorm` is
     "inf" (Base.Fix1(maximum, abs), the reference default) or "l2"."""
@@ -676,12 +700,26 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
             raise ValueError("GaussNewton: pass a Krylov linsolve (the normal-form operator JᵀJ is never assembled)")
         o.algorithm = L.ALG_GAUSS_NEWTON
         o.termination_norm = 1  # default_termination_mode(::NonlinearLeastSquaresProblem): AbsNormSafeBest on the 2-norm
+    if isinstance(alg, LevenbergMarquardt):
+        if ls is None:
+            raise ValueError("LevenbergMarquardt: pass a Krylov linsolve (the damped normal equations JᵀJ + λDᵀD are "
+                             "applied as an operator, never assembled)")
+        o.algorithm = L.ALG_LEVENBERG_MARQUARDT
+        o.lm_disable_geodesic = int(bool(alg.disable_geodesic))
+        o.lm_damping_initial = float(alg.damping_initial)
+        o.lm_damping_increase_factor = float(alg.damping_increase_factor)
+        o.lm_damping_decrease_factor = float(alg.damping_decrease_factor)
+        o.lm_min_damping_D = float(alg.min_damping_D)
+        o.lm_alpha_geodesic = float(alg.alpha_geodesic)
+        o.lm_finite_diff_step_geodesic = float(alg.finite_diff_step_geodesic)
+        o.lm_b_uphill = float(alg.b_uphill)
     if ls is None:
         # linsolve = nothing: LinearSolve's default factorisation of the concrete sparse J → banded LU on device
         o.linsolve = L.LINSOLVE_BANDED_LU
         ls = KrylovJL_GMRES()  # unused Krylov fields keep their defaults
     else:
-        o.linsolve = L.LINSOLVE_GMRES_CSR if alg.concrete_jac else L.LINSOLVE_GMRES_MATFREE
+        o.linsolve = L.LINSOLVE_GMRES_CSR if (alg.concrete_jac or isinstance(alg, LevenbergMarquardt)) \
+            else L.LINSOLVE_GMRES_MATFREE
     o.maxiters = int(maxiters)
     o.abstol = 0.0 if abstol is None else float(abstol)
     o.reltol = 0.0 if reltol is None else float(reltol)

@@ -457,6 +457,7 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_val);
   hipFree(A->d_rowblocks);
   hipFree(A->d_tperm);
+  hipFree(A->d_ones);
   hipFree(A->d_tz);
   hipFree(A->d_trecv);
   hipFree(A->d_role);
@@ -646,6 +647,40 @@ int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y) {
               (const int32_t *)H.d_send_idx + H.send_off[p], (const double *)A->d_trecv + H.send_off[p], d_y);
   }
   NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+// out_j = Σ_i A_ij² = ((A∘A)ᵀ·1)_j — the transposed product with squared values and a vector of ones, so it inherits the
+// fixed summation order and the rank-ordered reverse exchange of nk_csr_spmv_t_dev (bitwise reproducible, any partition)
+__global__ __launch_bounds__(NK_BLOCK) void k_permute_vals_sq(int64_t nnz, const int32_t *__restrict__ perm,
+                                                              const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < nnz) { const double v = src[perm[i]]; dst[i] = v * v; }
+}
+int nk_csr_colsumsq_dev(nk_csr *A, double *d_out) {
+  nk_ctx *ctx = A->ctx;
+  if (!A->T) NK_TRY(build_transpose(A));
+  if (!A->d_ones) {
+    NK_TRY(nk_dev_alloc(&A->d_ones, (size_t)A->nrows + 1));
+    NK_TRY(nk_blas_fill(ctx, A->nrows + 1, 1.0, A->d_ones));
+  }
+  if (A->nnz) {
+    const int grid = (int)((A->nnz + NK_BLOCK - 1) / NK_BLOCK);
+    NK_LAUNCH(ctx, k_permute_vals_sq, dim3(grid), dim3(NK_BLOCK), A->nnz, A->d_tperm, A->d_val, A->T->d_val);
+  }
+  A->t_values_stale = false;                    // T holds the squares for this one product …
+  const int st = nk_csr_spmv_t_dev(A, A->d_ones, d_out);
+  A->t_values_stale = true;                     // … and must be refreshed before the next Aᵀ x
+  return st;
+}
+extern "C" int nk_csr_colsumsq(nk_csr *A, double *out, int memspace) {
+  NK_REQUIRE(A && out, "NULL argument");
+  NK_HIP(hipSetDevice(A->ctx->device));
+  if (memspace == NK_DEVICE) return nk_csr_colsumsq_dev(A, out);
+  if (!A->d_ytmp) NK_TRY(nk_dev_alloc(&A->d_ytmp, (size_t)A->nrows + 1));
+  NK_TRY(nk_csr_colsumsq_dev(A, A->d_ytmp));
+  NK_HIP(hipMemcpyAsync(out, A->d_ytmp, A->nrows * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
+  NK_HIP(hipStreamSynchronize(A->ctx->stream));
   return NK_OK;
 }
 

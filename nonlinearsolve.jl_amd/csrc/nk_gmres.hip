@@ -802,6 +802,23 @@ extern "C" int nk_gmres_set_normal_form(nk_gmres *G, int on) {
   return NK_OK;
 }
 
+extern "C" int nk_gmres_set_normal_form_damping(nk_gmres *G, const double *d_diag, double lambda) {
+  NK_REQUIRE(G, "NULL argument");
+  G->nrm_diag = d_diag;
+  G->nrm_lambda = d_diag ? lambda : 0.0;
+  return NK_OK;
+}
+// y = (y + λ d∘x) · scale — the diagonal of the damped normal form, fused with the lagged-normalisation scale
+__global__ __launch_bounds__(NK_BLOCK) void k_add_diag_scale(int64_t n, double lambda, const double *__restrict__ d,
+                                                             const double *__restrict__ x, double *__restrict__ y,
+                                                             const double *d_scale, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const double sc = d_scale ? *d_scale : 1.0;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride)
+    y[i] = (y[i] + lambda * d[i] * x[i]) * sc;
+}
+
 // raw operator: y = scale · A x (no preconditioner)
 static int op_apply_raw(nk_gmres *G, const double *src, double *d_y, const int *d_skip, const double *oscale) {
   nk_ctx *ctx = G->ctx;
@@ -814,7 +831,14 @@ static int op_apply_raw(nk_gmres *G, const double *src, double *d_y, const int *
       NK_TRY(nk_problem_jvp_dev(G->P, G->d_u, src, G->nrm_tmp, d_skip));
       NK_TRY(nk_problem_vjp_dev(G->P, G->d_u, G->nrm_tmp, d_y));
     }
-    if (oscale) NK_TRY(nk_blas_scale_to(ctx, G->n, oscale, d_y, d_y, d_skip));
+    if (G->nrm_diag) {
+      const int grid = nk_grid_for(G->n, NK_BLOCK * 4, 2048);
+      NK_LAUNCH(ctx, k_add_diag_scale, dim3(grid), dim3(NK_BLOCK), G->n, G->nrm_lambda, G->nrm_diag, src, d_y, oscale,
+                d_skip);
+      NK_HIP(hipGetLastError());
+    } else if (oscale) {
+      NK_TRY(nk_blas_scale_to(ctx, G->n, oscale, d_y, d_y, d_skip));
+    }
     return NK_OK;
   }
   switch (G->op_kind) {

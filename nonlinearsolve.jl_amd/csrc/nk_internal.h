@@ -242,6 +242,7 @@ struct nk_csr {
   // entries other ranks own, which the reverse halo exchange returns to their owners (nk_csr_spmv_t_dev)
   nk_csr *T = nullptr;
   int32_t *d_tperm = nullptr;
+  double *d_ones = nullptr;   // a vector of ones (nk_csr_colsumsq_dev)
   bool t_values_stale = true;
   double *d_tz = nullptr, *d_trecv = nullptr;  // T·x (nrows + n_halo) and what the peers sent back (n_send)
   // column colouring of the pattern (structurally orthogonal columns), built on first use by coloured assembly
@@ -257,6 +258,7 @@ struct nk_csr {
 int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr,
                     const nk_spmv_epi *epi = nullptr);
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
+int nk_csr_colsumsq_dev(nk_csr *A, double *d_out);  // out_j = Σ_i A_ij² (diag AᵀA)
 // local_only: every column is a local index already (rectangular helper matrices such as the transposed local block):
 // no halo plan is built, i.e. the call is NOT collective
 int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,
@@ -394,6 +396,8 @@ struct nk_gmres {
   void *prec_user = nullptr;
   bool normal = false;       // operator = AᵀA of the CSR / problem operator (normal form)
   double *nrm_tmp = nullptr; // A x between the two halves
+  const double *nrm_diag = nullptr;  // damped normal form: AᵀA + nrm_lambda·diag(nrm_diag)
+  double nrm_lambda = 0.0;
   bool fn_host = false, prec_host = false;  // the callbacks take HOST pointers: vectors are staged through h_stage
   double *h_stage = nullptr;                // pinned, 2 n doubles
   int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle

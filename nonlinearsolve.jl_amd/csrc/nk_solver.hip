@@ -5,6 +5,8 @@
 //   lib/NonlinearSolveFirstOrder/src/trust_region.jl:204-258,292-317,320-384,396-514
 //   lib/NonlinearSolveFirstOrder/src/eisenstat_walker.jl:42-107
 //   lib/NonlinearSolveBase/src/termination_conditions.jl:243-336,414-453
+//   lib/NonlinearSolveFirstOrder/src/levenberg_marquardt.jl:37-64,72-168,204-293 (LevenbergMarquardt),
+//   lib/NonlinearSolveBase/src/descent/damped_newton.jl:224-345 (:normal_form mode), geodesic_acceleration.jl:98-136
 // All vectors stay in device memory; per nonlinear step the host reads back a handful of scalars.
 #include <math.h>
 #include <string.h>
@@ -53,6 +55,10 @@ struct nk_solver {
   int shrink_counter = 0;
   bool last_accepted = false;
   int last_gmres_iters = 0;
+  // LevenbergMarquardt: damping cache (λ, λ_factor, DᵀD), geodesic acceleration (v, a), LM trust region (v_cache, ‖v_old‖)
+  double lm_lam = 0, lm_lam_factor = 0, lm_norm_v_old = 0, lm_beta = 0;
+  bool lm_tr_accepted = false, lm_geo_accepted = false;
+  double *lm_dtd = nullptr, *lm_diag = nullptr, *lm_v = nullptr, *lm_a = nullptr, *lm_vcache = nullptr, *lm_rhs = nullptr;
   std::vector<nk_trace_entry> trace;
 };
 
@@ -197,7 +203,14 @@ extern "C" int nk_options_default(nk_options *o) {
   o->mg_nu = 0;
   o->mg_coarse = 0;
   o->jac_colored = 0;
-  o->reserved0 = 0;
+  o->lm_disable_geodesic = 0;  // LevenbergMarquardt() constructor values (levenberg_marquardt.jl:37-43)
+  o->lm_damping_initial = 1.0;
+  o->lm_damping_increase_factor = 2.0;
+  o->lm_damping_decrease_factor = 3.0;
+  o->lm_min_damping_D = 1e-8;
+  o->lm_alpha_geodesic = 0.75;
+  o->lm_finite_diff_step_geodesic = 0.1;
+  o->lm_b_uphill = 1.0;
   return NK_OK;
 }
 
@@ -205,6 +218,7 @@ static const double DEFAULT_TOL = 3.0e-13;  // common_defaults.jl:44-48
 
 static bool is_tr(const nk_solver *S) { return S->o.algorithm == NK_ALG_TRUST_REGION; }
 static bool normal_form(const nk_solver *S) { return S->o.algorithm == NK_ALG_GAUSS_NEWTON; }
+static bool is_lm(const nk_solver *S) { return S->o.algorithm == NK_ALG_LEVENBERG_MARQUARDT; }
 static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE; }
 static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BANDED_LU; }
 
@@ -461,6 +475,17 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
     S->shrink_counter = 0;
     S->last_accepted = false;
   }
+  if (is_lm(S)) {  // init / reinit! of the damping cache, the LM trust region and the geodesic cache
+    S->lm_lam = S->o.lm_damping_initial;                    // levenberg_marquardt.jl:72-89,119-131
+    S->lm_lam_factor = S->o.lm_damping_increase_factor;
+    NK_TRY(nk_blas_fill(ctx, S->n, S->o.lm_min_damping_D, S->lm_dtd));
+    NK_TRY(nk_blas_copy(ctx, S->n, S->u, S->lm_vcache));    // `@bb v = copy(u)` (:212), reinit!: copyto!(v_cache, u0)
+    S->lm_norm_v_old = INFINITY;
+    S->lm_tr_accepted = false;
+    S->lm_geo_accepted = false;
+    S->lm_beta = NAN;
+    S->tr = S->lm_lam;  // what nk_solver_get_scalars reports in the trust-region slot
+  }
   return NK_OK;
 }
 
@@ -469,7 +494,17 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   nk_ctx *ctx = P->ctx;
   NK_HIP(hipSetDevice(ctx->device));
   NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION ||
-                 opts->algorithm == NK_ALG_GAUSS_NEWTON, "bad algorithm");
+                 opts->algorithm == NK_ALG_GAUSS_NEWTON || opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT, "bad algorithm");
+  if (opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT) {
+    NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_CSR,
+               "LevenbergMarquardt needs a concrete Jacobian (concrete_jac = Val(true), levenberg_marquardt.jl:62) and a "
+               "Krylov linsolve: the damped normal equations are applied as an operator, never assembled");
+    NK_REQUIRE(opts->linesearch == 0 && opts->forcing == NK_FORCING_NONE,
+               "LevenbergMarquardt takes neither a line search nor a forcing term (levenberg_marquardt.jl:37-64)");
+    NK_REQUIRE(opts->lm_damping_initial > 0.0 && opts->lm_damping_increase_factor > 0.0 &&
+                   opts->lm_damping_decrease_factor > 0.0 && opts->lm_finite_diff_step_geodesic > 0.0,
+               "LevenbergMarquardt: damping_initial, the damping factors and finite_diff_step_geodesic must be positive");
+  }
   NK_REQUIRE(!(opts->algorithm == NK_ALG_GAUSS_NEWTON && opts->linsolve == NK_LINSOLVE_BANDED_LU),
              "GaussNewton in normal form needs a Krylov linsolve (JᵀJ is applied as an operator, never assembled)");
   NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_MATFREE || opts->linsolve == NK_LINSOLVE_GMRES_CSR ||
@@ -507,6 +542,11 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     NK_TRY(nk_dev_alloc(&S->Jdu, na));
   }
   if (normal_form(S)) NK_TRY(nk_dev_alloc(&S->JTfu, na));
+  if (is_lm(S)) {
+    NK_TRY(nk_dev_alloc(&S->fu_trial, na));
+    NK_TRY(nk_dev_alloc(&S->Jdu, na));
+    for (double **b : {&S->lm_dtd, &S->lm_diag, &S->lm_v, &S->lm_a, &S->lm_vcache, &S->lm_rhs}) NK_TRY(nk_dev_alloc(b, na));
+  }
   if (is_tr(S)) {
     NK_TRY(nk_dev_alloc(&S->fu_trial, na));
     NK_TRY(nk_dev_alloc(&S->du_newton, na));
@@ -539,7 +579,8 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
   hipStreamSynchronize(S->ctx->stream);
   if (S->P) nk_problem_invalidate(S->P);  // the vectors the problem was linearised at are about to be freed
   double *bufs[] = {S->ubuf[0], S->ubuf[1], S->ubuf[2], S->fu, S->du, S->fu_trial, S->du_newton, S->du_cauchy,
-                    S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage, S->stage2};
+                    S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage, S->stage2, S->lm_dtd, S->lm_diag, S->lm_v,
+                    S->lm_a, S->lm_vcache, S->lm_rhs};
   for (double *b : bufs) hipFree(b);
   nk_gmres_destroy(S->G);
   nk_bandlu_destroy(S->B);
@@ -905,6 +946,156 @@ static int backtracking(nk_solver *S, double *alpha_out, bool *failed) {
   return NK_OK;
 }
 
+// ---- LevenbergMarquardt
+// DᵀD ← max(DᵀD, diag(JᵀJ)) — update_levenberg_marquardt_diagonal!! (levenberg_marquardt.jl:270-293)
+__global__ __launch_bounds__(NK_BLOCK) void k_lm_dtd_max(int64_t n, const double *__restrict__ diag, double *__restrict__ dtd) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double a = dtd[i], b = diag[i];
+    dtd[i] = (b > a) ? b : a;  // Base.max would propagate a NaN of diag(JᵀJ); a NaN Jacobian ends the solve as Unstable anyway
+  }
+}
+// fu_c ← (2/h)·((f(u + h v) − fu)/h − J v) — the second directional derivative (geodesic_acceleration.jl:112-117)
+__global__ __launch_bounds__(NK_BLOCK) void k_lm_geo_rhs(int64_t n, double h, const double *__restrict__ fu,
+                                                         const double *__restrict__ Jv, double *__restrict__ fc) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride)
+    fc[i] = (2.0 / h) * ((fc[i] - fu[i]) / h - Jv[i]);
+}
+// DampedNewtonDescent.solve! in :normal_form mode (damped_newton.jl:297-313): (JᵀJ + λDᵀD) x = Jᵀ rhs, δ = −x.
+// recompute_A (the velocity solve, idx = Val(1)) refreshes DᵀD from the current J and fixes the damping λ·DᵀD for this step;
+// the acceleration solve reuses it (:307-309).
+static int lm_damped_solve(nk_solver *S, const double *rhs_f, double *out, bool recompute_A, bool *ok) {
+  nk_ctx *ctx = S->ctx;
+  S->stats.nsolve++;
+  if (recompute_A) {
+    NK_TRY(nk_csr_colsumsq_dev(S->J, S->lm_diag));
+    const int grid = nk_grid_for(S->n, NK_BLOCK * 4, 2048);
+    NK_LAUNCH(ctx, k_lm_dtd_max, dim3(grid), dim3(NK_BLOCK), S->n, (const double *)S->lm_diag, S->lm_dtd);
+    NK_HIP(hipGetLastError());
+    NK_TRY(nk_gmres_set_normal_form(S->G, 1));
+    NK_TRY(nk_gmres_set_normal_form_damping(S->G, S->lm_dtd, S->lm_lam));
+  }
+  NK_TRY(nk_csr_spmv_t_dev(S->J, rhs_f, S->lm_rhs));
+  nk_gmres_info info;
+  NK_TRY(nk_gmres_solve_dev(S->G, S->lm_rhs, out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
+                            S->o.gmres_fixed_iters, &info));
+  S->last_gmres_iters = info.iters;
+  S->stats.gmres_iters += info.iters;
+  *ok = !info.failed;
+  return nk_blas_lincomb(ctx, S->n, -1.0, out, 0.0, out, out);
+}
+// callback_into_cache!(topcache, ::LevenbergMarquardtDampingCache) (levenberg_marquardt.jl:159-168)
+static void lm_callback(nk_solver *S) {
+  const bool geo_ok = S->o.lm_disable_geodesic ? true : S->lm_geo_accepted;  // last_step_accepted default: true
+  if (S->lm_tr_accepted && geo_ok) S->lm_lam_factor = 1.0 / S->o.lm_damping_decrease_factor;
+  S->lm_lam *= S->lm_lam_factor;
+  S->lm_lam_factor = S->o.lm_damping_increase_factor;
+  S->tr = S->lm_lam;
+}
+static int check_and_update(nk_solver *S, double step_norm);
+static int internal_step(nk_solver *S, int recompute, bool evaluate_residual);
+// the rest of step! (FirstOrder/src/solve.jl:365-462) for LevenbergMarquardt: GeodesicAcceleration.solve!
+// (geodesic_acceleration.jl:98-136), LevenbergMarquardtTrustRegionCache solve! (levenberg_marquardt.jl:247-268)
+static int lm_step(nk_solver *S, bool new_jacobian, bool evaluate_residual) {
+  nk_ctx *ctx = S->ctx;
+  const int64_t n = S->n;
+  const bool geo = !S->o.lm_disable_geodesic;
+  bool ok = true, success = true;
+  NK_TRY(lm_damped_solve(S, S->fu, S->lm_v, true, &ok));
+  if (!geo && !ok) {  // DampedNewtonDescent alone reports linsolve_success = false (damped_newton.jl:334-337)
+    if (new_jacobian) {
+      S->retcode = NK_RET_INTERNAL_LINEAR_SOLVE_FAILED;
+      S->force_stop = true;
+      return NK_OK;
+    }
+    S->make_new_jacobian = true;
+    return internal_step(S, 1, evaluate_residual);
+  }
+  double nv2 = NAN;
+  if (geo) {  // (an inner failure is not propagated: geodesic's solve! reads `.δu` of the inner results only)
+    const double h = S->o.lm_finite_diff_step_geodesic;
+    double *uc = spare_u(S);
+    nk_problem_invalidate(S->P);
+    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->u, h, S->lm_v, uc));
+    NK_TRY(nk_problem_residual_dev(S->P, uc, S->fu_trial));  // Utils.evaluate_f!! — not counted in stats.nf
+    NK_TRY(apply_J(S, S->lm_v, S->Jdu));
+    const int grid = nk_grid_for(n, NK_BLOCK * 4, 2048);
+    NK_LAUNCH(ctx, k_lm_geo_rhs, dim3(grid), dim3(NK_BLOCK), n, h, (const double *)S->fu, (const double *)S->Jdu, S->fu_trial);
+    NK_HIP(hipGetLastError());
+    NK_TRY(lm_damped_solve(S, S->fu_trial, S->lm_a, false, &ok));
+    double v[2];
+    const double *xs[2] = {S->lm_v, S->lm_a}, *ys[2] = {S->lm_v, S->lm_a};
+    NK_TRY(nk_blas_multi_reduce(ctx, n, 2, xs, ys, nullptr, nullptr, 0, 0, slot(S, 0)));
+    NK_TRY(fetch(S, 2, v));
+    nv2 = v[0];
+    S->lm_geo_accepted = 2.0 * sqrt(v[1]) <= sqrt(v[0]) * S->o.lm_alpha_geodesic;
+    success = S->lm_geo_accepted;
+    if (success) NK_TRY(nk_blas_lincomb(ctx, n, 1.0, S->lm_v, 0.5, S->lm_a, S->du));  // δu = v + a/2
+  } else {
+    NK_TRY(nk_blas_copy(ctx, n, S->lm_v, S->du));
+  }
+  bool accepted = false;
+  double step_norm = 0.0;
+  if (success) {
+    S->make_new_jacobian = true;
+    // β = cos(v, v_old); trial point; loss = ‖f(u + δu)‖₂ — one trial kernel, one multi-reduction, one fetch
+    S->u_trial = spare_u(S);
+    const int tgrid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS / 2);
+    NK_LAUNCH(ctx, k_tr_trial, dim3(tgrid), dim3(NK_BLOCK), n, (const double *)S->u, (const double *)S->du, S->u_trial,
+              ctx->d_partials_ss);
+    NK_HIP(hipGetLastError());
+    nk_problem_invalidate(S->P);
+    NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
+    S->stats.nf++;
+    double v[6];
+    const double *xs[3] = {S->lm_v, S->lm_v, S->fu_trial}, *ys[3] = {S->lm_vcache, S->lm_v, S->fu_trial};
+    NK_TRY(nk_blas_multi_reduce(ctx, n, 3, xs, ys, S->fu_trial, ctx->d_partials_ss, 2, tgrid, slot(S, 0)));
+    NK_TRY(fetch(S, 6, v));  // v·v_cache, v·v, ‖f_new‖², ‖f_new‖∞, ‖δu‖², ‖u_trial − u‖²
+    (void)nv2;
+    const double norm_v = sqrt(v[1]);
+    const double beta = v[0] / (norm_v * S->lm_norm_v_old);
+    S->lm_beta = beta;
+    const double loss = sqrt(v[2]);
+    const double lhs = pow(1.0 - beta, S->o.lm_b_uphill) * loss;  // NaN for a negative base with a fractional exponent
+    if (lhs <= INFINITY) {  // loss_old is initialised to Inf and never written again by the reference (:206-268)
+      accepted = true;
+      S->lm_norm_v_old = norm_v;
+      double *t = S->lm_vcache; S->lm_vcache = S->lm_v; S->lm_v = t;  // copyto!(v_cache, v)
+      S->u = S->u_trial;
+      t = S->fu; S->fu = S->fu_trial; S->fu_trial = t;
+      S->fnorm2 = loss;
+      S->fnorm_inf = v[3];
+      S->u_version++;
+      step_norm = sqrt(v[5]);
+    } else {
+      S->make_new_jacobian = false;
+    }
+    S->lm_tr_accepted = accepted;
+    NK_TRY(check_and_update(S, step_norm));
+  } else {
+    S->make_new_jacobian = false;
+  }
+  if (S->o.store_trace) {
+    nk_trace_entry e;
+    memset(&e, 0, sizeof(e));
+    e.iter = S->nsteps + 1;
+    e.gmres_iters = S->last_gmres_iters;
+    e.accepted = accepted ? 1 : 0;
+    e.fnorm_inf = S->fnorm_inf;
+    NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
+    double t;
+    NK_TRY(fetch(S, 1, &t));
+    e.step_norm2 = sqrt(t);
+    e.eta = S->lin_reltol;
+    e.trust_region = S->lm_lam;  // the damping in force during this step
+    e.rho = S->lm_beta;
+    S->trace.push_back(e);
+  }
+  lm_callback(S);
+  return NK_OK;
+}
+
 // check_and_update! (termination_conditions.jl:414-426)
 static int check_and_update(nk_solver *S, double step_norm) {
   bool stop = false;
@@ -919,7 +1110,7 @@ static int check_and_update(nk_solver *S, double step_norm) {
 // supports_deferred_residual (FirstOrder/src/solve.jl:303-316): only the unglobalised step, only a residual-only
 // termination mode (AbsTerminationMode / AbsNormTerminationMode, termination_conditions.jl:43-45), only without a trace
 static bool supports_deferred_residual(const nk_solver *S) {
-  if (is_tr(S) || S->o.linesearch) return false;
+  if (is_tr(S) || is_lm(S) || S->o.linesearch) return false;
   if (!(S->o.termination_mode == TM_ABS || S->o.termination_mode == TM_ABSNORM)) return false;
   return !S->o.store_trace;
 }
@@ -934,7 +1125,7 @@ static int refresh_residual(nk_solver *S) {
 }
 
 // ---- InternalAPI.step! (FirstOrder/src/solve.jl:325-465)
-static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/, bool evaluate_residual = true) {
+static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/, bool evaluate_residual) {
   nk_ctx *ctx = S->ctx;
   const int64_t n = S->n;
   // the descent is taken from the residual at the iterate it starts from: settle an outstanding deferral first
@@ -955,6 +1146,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
   } else {
     new_jacobian = false;
   }
+  if (is_lm(S)) return lm_step(S, new_jacobian, evaluate_residual);
   const bool has_forcing = S->o.forcing == NK_FORCING_EISENSTAT_WALKER2;
   if (has_forcing) NK_TRY(pre_step_forcing(S, S->nsteps));
 
@@ -990,6 +1182,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       S->u_version++;
     } else {
       S->make_new_jacobian = false;
+      step_norm = 0.0;  // u did not move: the stall test sees ‖u − u_cache‖₂ = 0 (termination_conditions.jl:311-316)
     }
     if (S->shrink_counter > S->o.max_shrink_times) {
       S->retcode = NK_RET_SHRINK_THRESHOLD_EXCEEDED;

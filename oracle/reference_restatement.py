@@ -933,7 +933,7 @@ class FirstOrderCache:
     def _lm_tr_solve(self, du, v):
         norm_v = L2_NORM(v)
         with np.errstate(invalid="ignore", divide="ignore"):
-            beta = float(np.dot(v, self.lm_v_cache)) / (norm_v * self.lm_norm_v_old)
+            beta = float(np.float64(np.dot(v, self.lm_v_cache)) / (np.float64(norm_v) * np.float64(self.lm_norm_v_old)))
         self.lm_beta = beta
         u_new = self.u + du
         fu_new = self.prob.f(u_new)
@@ -1236,7 +1236,7 @@ class FirstOrderCache:
     # supports_deferred_residual (FirstOrder/src/solve.jl:303-316; residual_only_termination_mode,
     # termination_conditions.jl:43-45): unglobalised step, AbsTerminationMode / AbsNormTerminationMode, no trace
     def supports_deferred_residual(self):
-        if self.is_tr or getattr(self.alg, "linesearch", None) is not None:
+        if self.is_tr or self.is_lm or getattr(self.alg, "linesearch", None) is not None:
             return False
         if self.tc.mode not in (TM_ABS, TM_ABSNORM):
             return False

@@ -163,7 +163,7 @@ def test_julia_binding_matches_the_abi():
     assert not missing, missing
     body = jl[jl.index("mutable struct NKOptions"):]
     body = body[:body.index("\nend")]
-    fields = re.findall(r"([a-z0-9_]+)::(Int32|Float64)", body)
+    fields = re.findall(r"([A-Za-z0-9_]+)::(Int32|Float64)", body)
     jl_types = {"Int32": C.c_int32, "Float64": C.c_double}
     expect = [(n, ty) for n, ty in _lib.Options._fields_]
     assert [(n, jl_types[ty]) for n, ty in fields] == expect

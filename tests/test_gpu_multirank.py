@@ -177,6 +177,20 @@ def _worker(rank, world, port, q, transport="torch"):
         assert np.max(np.abs(solc.u.cpu().numpy() - refc.u[idx])) <= 1e-7
         note("brusselator_tr_concrete", solc.u.cpu().numpy())
         note("spmv_t", JB.rmatvec(vbl).cpu().numpy())
+        # ---------------- LevenbergMarquardt on two ranks: diag(JᵀJ) through the reverse halo exchange, the damped
+        # normal-form operator (SpMV, distributed transposed SpMV, diagonal), geodesic acceleration — vs the serial oracle
+        dJ = JB.colsumsq(like=vbl).cpu().numpy()
+        assert np.allclose(dJ, np.asarray(Jfull.multiply(Jfull).sum(axis=0)).ravel()[idx], rtol=1e-13)
+        kl_ = dict(gmres_restart=60, maxiters=600)
+        Plm = nls.Bratu2D(12)    # (the size of tests/test_gpu_lm.py's single-rank case: 14 steps on the oracle)
+        bl, el = Plm.row_begin, Plm.row_begin + Plm.n_local
+        reflm = R.solve(R.Bratu2D(12), R.LevenbergMarquardt(linsolve=R.KrylovJL_GMRES(**kl_)), abstol=1e-8, maxiters=100)
+        sollm = nls.solve(nls.NonlinearProblem(Plm, u0=torch.zeros(el - bl, dtype=torch.float64, device=dev)),
+                          nls.LevenbergMarquardt(linsolve=nls.KrylovJL_GMRES(**kl_)), abstol=1e-8, maxiters=100, store_trace=True)
+        assert sollm.retcode == "Success" == R.RETCODE_NAMES[reflm.retcode] and sollm.stats.nsteps == reflm.stats.nsteps
+        assert np.allclose([t["trust_region"] for t in sollm.trace], [t["trust_region"] for t in reflm.trace], rtol=1e-12)
+        assert np.max(np.abs(sollm.u.cpu().numpy() - reflm.u[bl:el])) <= 1e-7
+        note("bratu_lm", sollm.u.cpu().numpy())
 
         # ---------------- the multigrid V-cycle behind the `precs` hook on a row-partitioned hierarchy: every level split by
         # grid lines, ghost lines of the neighbouring levels gathered for the transfers, coarsest level solved redundantly —
