@@ -16,6 +16,16 @@
 // other level it needs through a halo plan built once per transfer (the partitions of two levels do not line up exactly);
 // the coarsest level is gathered to every rank (one all-reduce of a zero-padded vector) and solved redundantly.
 // Restated on the CPU by oracle/reference_restatement.py::BratuMultigrid (the arithmetic does not depend on the partition).
+//
+// BRUSSELATOR2D (config C5; single rank): the same V-cycle for the two coupled species on the periodic N × N grid.
+//   levels     N_l = N/2^l while even and > coarse_max (default 8); level operator by rediscretisation with spacing 2^l·dx at
+//              the full-weighting restriction of the linearisation point — each level is a Brusselator problem object, so
+//              the matrix-free JVP kernel serves every level
+//   transfers  nested periodic grids: bilinear prolongation, full-weighting restriction (= ¼ Pᵀ), species by species
+//   smoother   ν Chebyshev steps on −[λmax/4, λmax]: the Jacobian is diffusion dominated with a NEGATIVE spectrum;
+//              λmax = 8α/dx_l² + A + 1 + 2·max|u|·max|v| + max|u|² bounds every Gershgorin disc of every level
+//   coarsest   banded LU of the assembled coarse Jacobian (the reaction block may be indefinite there: solved exactly)
+// Restated by oracle/reference_restatement.py::BrusselatorMultigrid.
 #include <math.h>
 #include <stdlib.h>
 
@@ -60,6 +70,8 @@ struct mg_lines {
 
 struct nk_mg {
   nk_ctx *ctx = nullptr;
+  int kind = 0;              // 0 Bratu (Dirichlet, scalar), 1 Brusselator (periodic, two species)
+  double base_alpha = 0, base_dx = 0, brus_A = 0;  // Brusselator: α, dx of level 0 and the reaction parameter A
   int nu = 2;
   std::vector<nk_mg_level> lv;
   nk_csr *Jc = nullptr;
@@ -176,6 +188,58 @@ __global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_first(int64_t n, const dou
 }
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + NK_BLOCK - 1) / NK_BLOCK)); }
 
+// ---- Brusselator: nested periodic grids, two species stored one after the other (idx = i + N·j + N²·s)
+// r_c = ¼ Pᵀ r_f (full weighting): 1/16 · [1 2 1; 2 4 2; 1 2 1] around the fine point (2I, 2J), periodic
+__global__ __launch_bounds__(NK_BLOCK) void k_mgb_restrict(int nf, const double *__restrict__ rf, double *__restrict__ rc,
+                                                           const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int nc = nf >> 1;
+  const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= 2 * nc * nc) return;
+  const int sp = k / (nc * nc), kk = k - sp * nc * nc, J = kk / nc, I = kk - J * nc;
+  const double *f = rf + (size_t)sp * nf * nf;
+  const int i = 2 * I, j = 2 * J;
+  const int im = (i == 0) ? nf - 1 : i - 1, ip = i + 1, jm = (j == 0) ? nf - 1 : j - 1, jp = j + 1;  // i, j even ⇒ i+1 < nf
+  const double c = f[j * nf + i];
+  const double e = (f[j * nf + im] + f[j * nf + ip]) + (f[jm * nf + i] + f[jp * nf + i]);
+  const double d = (f[jm * nf + im] + f[jm * nf + ip]) + (f[jp * nf + im] + f[jp * nf + ip]);
+  rc[k] = (4.0 * c + 2.0 * e + d) * (1.0 / 16.0);
+}
+// x_f += P e_c (bilinear on the nested periodic grid)
+__global__ __launch_bounds__(NK_BLOCK) void k_mgb_prolong_add(int nf, const double *__restrict__ ec, double *__restrict__ xf,
+                                                              const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int nc = nf >> 1;
+  const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (k >= 2 * nf * nf) return;
+  const int sp = k / (nf * nf), kk = k - sp * nf * nf, j = kk / nf, i = kk - j * nf;
+  const double *c = ec + (size_t)sp * nc * nc;
+  const int I0 = i >> 1, J0 = j >> 1;
+  const int I1 = (i & 1) ? ((I0 + 1 == nc) ? 0 : I0 + 1) : I0, J1 = (j & 1) ? ((J0 + 1 == nc) ? 0 : J0 + 1) : J0;
+  // (an even index reads the same coarse point twice with weight ½ + ½ — the loads stay unconditional)
+  const double v = 0.25 * ((c[J0 * nc + I0] + c[J0 * nc + I1]) + (c[J1 * nc + I0] + c[J1 * nc + I1]));
+  xf[k] += v;
+}
+// one Chebyshev step after the first, unfused: r −= J d (t holds J d); d = c1 d + c2 r; x += d
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_step(int64_t n, double c1, double c2, const double *__restrict__ t,
+                                                           double *__restrict__ r, double *__restrict__ d,
+                                                           double *__restrict__ x, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double rn = r[i] - t[i], dn = c1 * d[i] + c2 * rn;
+  r[i] = rn;
+  d[i] = dn;
+  x[i] += dn;
+}
+// out = b − t
+__global__ __launch_bounds__(NK_BLOCK) void k_mg_sub(int64_t n, const double *__restrict__ b, const double *__restrict__ t,
+                                                     double *__restrict__ out, const int *d_skip) {
+  MG_SKIP(d_skip);
+  const int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (i < n) out[i] = b[i] - t[i];
+}
+
 // ----------------------------------------------------------------------------- setup
 static void interp_tables(int nf, int nc, std::vector<int32_t> &I0, std::vector<double> &w1, std::vector<int32_t> &lo,
                           std::vector<double> &w) {
@@ -247,10 +311,55 @@ static void ghost_needs(int64_t lo, int64_t hi, int64_t j0, int64_t j1, int64_t 
   }
 }
 
+// Brusselator hierarchy (single rank): see the file header
+static int mgb_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
+  nk_ctx *ctx = P->ctx;
+  NK_REQUIRE(ctx->nranks == 1, "the Brusselator multigrid preconditioner runs on one rank (use the Chebyshev precs on several)");
+  NK_REQUIRE(P->ns < 23000, "grid too large for 32-bit point indices");
+  if (nu <= 0) nu = 2;
+  if (coarse_max < 4) coarse_max = 8;
+  nk_mg *M = new nk_mg();
+  auto guard = nk_make_guard(M, [](nk_mg *g) { nk_mg_destroy(g); });
+  M->ctx = ctx;
+  M->kind = 1;
+  M->nu = nu;
+  M->brus_A = P->params[1];
+  M->base_alpha = P->params[3];
+  M->base_dx = P->params[4];
+  int64_t N = P->ns;
+  double dx = P->params[4];
+  for (int l = 0;; ++l) {
+    nk_mg_level L;
+    L.ns = N;
+    L.n = 2 * N * N;
+    L.j0 = 0;
+    L.j1 = N;
+    if (l == 0) L.P = P;
+    else {
+      const double par[5] = {(double)N, P->params[1], P->params[2], P->params[3], dx};
+      if (nk_problem_create(ctx, NK_PROBLEM_BRUSSELATOR2D, par, 5, &L.P) != NK_OK) return NK_E_HIP;
+      NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
+    }
+    for (double **b : {&L.b, &L.x, &L.r, &L.d, &L.t}) NK_TRY(nk_dev_alloc(b, (size_t)L.n + 1));
+    const bool coarsest = N <= coarse_max || (N % 2) != 0 || N / 2 < 4;
+    M->lv.push_back(L);
+    if (coarsest) break;
+    N /= 2;
+    dx *= 2.0;
+  }
+  if (M->lv.size() > 1) {
+    NK_TRY(nk_problem_jac_csr(M->lv.back().P, &M->Jc));
+    NK_TRY(nk_bandlu_create(M->Jc, &M->LU));
+  }
+  *out = guard.release();
+  return NK_OK;
+}
+
 int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   nk_ctx *ctx = P->ctx;
   const int R = ctx->nranks;
-  NK_REQUIRE(P->kind == NK_PROBLEM_BRATU2D, "the multigrid preconditioner is built for BRATU2D problems");
+  if (P->kind == NK_PROBLEM_BRUSSELATOR2D) return mgb_create(P, nu, coarse_max, out);
+  NK_REQUIRE(P->kind == NK_PROBLEM_BRATU2D, "the multigrid preconditioner is built for BRATU2D and BRUSSELATOR2D problems");
   NK_REQUIRE(P->ns < 46000, "grid too large for 32-bit point indices");
   if (nu <= 0) nu = 2;
   if (coarse_max < 3) coarse_max = 31;  // MI355X, 1024² with set-up: 63 → 13.5 ms, 31 → 10.1, 15 → 9.5, 7 → 9.7
@@ -368,7 +477,9 @@ static int mg_gather_coarse(nk_mg *M, const double *loc, double *full) {
 // transfers: F level → coarser level C (restriction of `src`, a level-F vector) and back
 static int mg_restrict(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *src, double *dst, const int *d_skip) {
   nk_ctx *ctx = M->ctx;
-  if (ctx->nranks == 1) {
+  if (M->kind == 1) {
+    NK_LAUNCH(ctx, k_mgb_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, src, dst, d_skip);
+  } else if (ctx->nranks == 1) {
     NK_LAUNCH(ctx, k_mg_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.rlo, (const double *)F.rw, src,
               dst, d_skip);
   } else {
@@ -382,7 +493,9 @@ static int mg_restrict(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *s
 }
 static int mg_prolong_add(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *ec, double *xf, const int *d_skip) {
   nk_ctx *ctx = M->ctx;
-  if (ctx->nranks == 1) {
+  if (M->kind == 1) {
+    NK_LAUNCH(ctx, k_mgb_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, ec, xf, d_skip);
+  } else if (ctx->nranks == 1) {
     NK_LAUNCH(ctx, k_mg_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.pI0, (const double *)F.pw1, ec,
               xf, d_skip);
   } else {
@@ -398,6 +511,21 @@ static int mg_prolong_add(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double
 // new linearisation point: restrict u down the hierarchy, refresh exp(u_l) of every level, refactor the coarsest J
 int nk_mg_update(nk_mg *M, const double *d_u) {
   M->lv[0].u = const_cast<double *>(d_u);
+  if (M->kind == 1) {  // λmax of every level: 8α/dx_l² + the reaction rows' Gershgorin bound at the fine linearisation point
+    nk_ctx *ctx = M->ctx;
+    const int64_t nn = M->lv[0].ns * M->lv[0].ns;
+    NK_TRY(nk_blas_minmax(ctx, nn, d_u, ctx->d_scal));        // (max, −min) of u
+    NK_TRY(nk_blas_minmax(ctx, nn, d_u + nn, ctx->d_scal + 2));  // … of v
+    double v[4];
+    NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 4, v));
+    const double U = fmax(fabs(v[0]), fabs(v[1])), V = fmax(fabs(v[2]), fabs(v[3]));
+    const double rb = M->brus_A + 1.0 + 2.0 * U * V + U * U;
+    double dx = M->base_dx;
+    for (nk_mg_level &L : M->lv) {
+      L.lmax = -(8.0 * M->base_alpha / (dx * dx) + rb);
+      dx *= 2.0;
+    }
+  }
   for (size_t l = 0; l + 1 < M->lv.size(); ++l) {
     nk_mg_level &F = M->lv[l], &Cc = M->lv[l + 1];
     NK_TRY(mg_restrict(M, F, Cc, F.u, Cc.u, nullptr));
@@ -421,7 +549,13 @@ int nk_mg_update(nk_mg *M, const double *d_u) {
 
 // ν Chebyshev steps for J_l x = b on [λmax/4, λmax]; zero_guess: x starts at 0 (then r = b)
 // b − J x in ONE kernel: the stencil JVP's row epilogue subtracts from b (nk_spmv_epi mode 2)
-static int mg_residual(nk_mg_level &L, const double *x, double *out, const int *d_skip) {
+static int mg_residual(nk_mg *M, nk_mg_level &L, const double *x, double *out, const int *d_skip) {
+  if (M->kind == 1) {  // (the Brusselator JVP kernel has no row epilogue: J x, then b − J x)
+    NK_TRY(nk_problem_jvp_dev(L.P, L.u, x, out, d_skip));
+    NK_LAUNCH(M->ctx, k_mg_sub, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.b, (const double *)out, out, d_skip);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
   nk_spmv_epi ep;
   ep.mode = 2;
   ep.r = L.b;
@@ -434,12 +568,23 @@ static int mg_smooth(nk_mg *M, nk_mg_level &L, bool zero_guess, const int *d_ski
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
   double rho = 1.0 / sigma;
   if (!zero_guess) {
-    NK_TRY(mg_residual(L, L.x, L.r, d_skip));
+    NK_TRY(mg_residual(M, L, L.x, L.r, d_skip));
     NK_LAUNCH(ctx, k_mg_cheb_first, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.r, 1.0 / theta, 0, L.d, L.x,
               (double *)nullptr, d_skip);
   } else {  // x0 = 0: r = b; the recurrence below updates r in place, so it gets its own copy in the same sweep
     NK_LAUNCH(ctx, k_mg_cheb_first, g1(L.n), dim3(NK_BLOCK), L.n, (const double *)L.b, 1.0 / theta, 1, L.d, L.x,
               M->nu > 1 ? L.r : (double *)nullptr, d_skip);
+  }
+  if (M->kind == 1) {
+    for (int k = 1; k < M->nu; ++k) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      NK_TRY(nk_problem_jvp_dev(L.P, L.u, L.d, L.t, d_skip));
+      NK_LAUNCH(ctx, k_mg_cheb_step, g1(L.n), dim3(NK_BLOCK), L.n, rho_new * rho, 2.0 * rho_new / delta, (const double *)L.t,
+                L.r, L.d, L.x, d_skip);
+      rho = rho_new;
+    }
+    NK_HIP(hipGetLastError());
+    return NK_OK;
   }
   double *dcur = L.d, *dalt = L.t;
   for (int k = 1; k < M->nu; ++k) {
@@ -480,7 +625,7 @@ int nk_mg_apply(nk_mg *M, const double *src, double *dst, const int *d_skip) {
   }
   NK_TRY(nk_blas_copy(ctx, M->lv[0].n, src, M->lv[0].b));
   static const bool use_graph = !(getenv("NK_MG_GRAPH") && atoi(getenv("NK_MG_GRAPH")) == 0);
-  if (use_graph && !ctx->prof.on && !M->graph_broken && ctx->nranks == 1) {  // (collectives carry per-call sequence numbers)
+  if (use_graph && !ctx->prof.on && !M->graph_broken && ctx->nranks == 1 && M->kind == 0) {  // (Brusselator: λmax moves with u)  // (collectives carry per-call sequence numbers)
     const int slot = d_skip ? 1 : 0;
     if (M->gexec[slot] && M->gskip[slot] != d_skip) {  // a different flag pointer: re-capture
       hipGraphExecDestroy(M->gexec[slot]);
@@ -521,7 +666,7 @@ static int mg_vcycle_body(nk_mg *M, const int *d_skip) {
   for (int l = 0; l + 1 < nl; ++l) {
     nk_mg_level &F = M->lv[l], &C = M->lv[l + 1];
     NK_TRY(mg_smooth(M, F, true, d_skip));
-    NK_TRY(mg_residual(F, F.x, F.r, d_skip));
+    NK_TRY(mg_residual(M, F, F.x, F.r, d_skip));
     NK_TRY(mg_restrict(M, F, C, F.r, C.b, d_skip));
   }
   {
