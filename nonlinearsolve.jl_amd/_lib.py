@@ -162,6 +162,7 @@ SIGNATURES = {
     "nk_lu_factor": (_I, [_P, _P, C.POINTER(_I)]),
     "nk_lu_solve": (_I, [_P, _P, _P, _I]),
     "nk_lu_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L)]),
+    "nk_lu_engine": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "nk_batch_compile_check": (_I, [C.c_char_p, _I, _I, _I, C.POINTER(_L)]),
     "nk_batch_create": (_I, [_P, C.c_char_p, _I, _I, _I, _PP]),
     "nk_batch_destroy": (_I, [_P]),

@@ -1081,7 +1081,10 @@ class BandedLU:
     def info(self):
         kl, ku, by = C.c_int(), C.c_int(), C.c_int64()
         check(L.lib().nk_lu_info(self._h, C.byref(kl), C.byref(ku), C.byref(by)))
-        return dict(kl=kl.value, ku=ku.value, band_bytes=by.value)
+        e, blk, lev = C.c_int(), C.c_int(), C.c_int()
+        check(L.lib().nk_lu_engine(self._h, C.byref(e), C.byref(blk), C.byref(lev)))
+        return dict(kl=kl.value, ku=ku.value, band_bytes=by.value, engine=("band_lu", "block_cyclic_reduction")[e.value],
+                    block=blk.value, levels=lev.value)
 
     def close(self):
         if self._h:

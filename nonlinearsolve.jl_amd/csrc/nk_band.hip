@@ -28,6 +28,8 @@
 // n/NB-long dependency chain, not FP64 throughput (FP64 MFMA has the vector rate on MI355X; it would only relieve the
 // LDS operand traffic of the two 256×32×32 products).
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(DEPTH == 2 ? 512 : 256) void k_band_sweep(int64_t n
 }
 
 // ----------------------------------------------------------------------------- host side
-int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
+int nk_bandlu_create(nk_csr *A, nk_bandlu **out, int engine) {
   nk_ctx *ctx = A->ctx;
   // a matrix every rank holds in full (the multigrid's coarsest level on several ranks) is factored redundantly
   NK_REQUIRE(ctx->nranks == 1 || (A->nrows == A->n_global && A->halo_gcols.empty() && !A->halo.active()),
@@ -491,6 +493,25 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
       if (-d > kl) kl = (int)(-d);
     }
   const int64_t n = A->nrows;
+  // Block cyclic reduction (nk_bcr.hip) wherever the matrix has enough block rows to shorten the dependency chain and its
+  // dense blocks fit: log₂(n/b) levels of batched dense algebra instead of n/32 dependent block columns.
+  {
+    static const bool force_band = getenv("NK_DIRECT") && !strcmp(getenv("NK_DIRECT"), "band");
+    const int b = ((std::max(std::max(kl, ku), 1) + 31) / 32) * 32;
+    if (engine == 0 && !force_band && b <= 512 && (n + b - 1) / b >= 4 && nk_bcr_bytes(n, b) < ((int64_t)24 << 30)) {
+      nk_bandlu *B = new nk_bandlu();
+      auto guard = nk_make_guard(B, [](nk_bandlu *b_) { nk_bandlu_destroy(b_); });
+      B->ctx = ctx;
+      B->n = n;
+      B->kl = kl;
+      B->ku = ku;
+      B->ldab = kl + ku + 1;
+      NK_TRY(nk_dev_alloc(&B->tmp, (size_t)n + 1));
+      NK_TRY(nk_bcr_create(ctx, n, b, &B->bcr));
+      *out = guard.release();
+      return NK_OK;
+    }
+  }
   const size_t band_bytes = (size_t)(kl + ku + 1) * n * sizeof(double);
   NK_REQUIRE(band_bytes < ((size_t)64 << 30), "band storage of %zu bytes is too large (bandwidth %d+%d)", band_bytes, kl, ku);
   NK_REQUIRE((size_t)(NB + kl + 1) * NB * sizeof(double) <= 120 * 1024,
@@ -521,11 +542,13 @@ int nk_bandlu_create(nk_csr *A, nk_bandlu **out) {
 void nk_bandlu_destroy(nk_bandlu *B) {
   if (!B) return;
   hipFree(B->AB); hipFree(B->invL); hipFree(B->invU); hipFree(B->tmp); hipFree(B->d_fail);
+  nk_bcr_destroy(B->bcr);
   delete B;
 }
 
 // copy the CSR values into the band and factor; *ok = 0 when a pivot broke down
 int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok) {
+  if (B->bcr) return nk_bcr_factor(B->bcr, A, ok);
   nk_ctx *ctx = B->ctx;
   const int64_t n = B->n;
   NK_HIP(hipMemsetAsync(B->AB, 0, (size_t)B->ldab * (n + NB + 2) * sizeof(double), ctx->stream));
@@ -551,6 +574,7 @@ int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok) {
 
 // x = A⁻¹ b (device vectors; b and x may alias)
 int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x) {
+  if (B->bcr) return nk_bcr_solve(B->bcr, d_b, d_x);
   nk_ctx *ctx = B->ctx;
   NK_TRY(nk_blas_copy(ctx, B->n, d_b, d_x));
   auto threads = [](int reach) { return std::min(512, std::max(256, ((std::max(reach, NB) + 63) / 64) * 64)); };
@@ -598,6 +622,15 @@ extern "C" int nk_lu_solve(nk_bandlu *B, const double *b, double *x, int memspac
   NK_TRY(nk_bandlu_solve(B, B->tmp, B->tmp));
   NK_HIP(hipMemcpyAsync(x, B->tmp, B->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+int nk_bcr_shape(const struct nk_bcr *S, int *block, int *levels);
+extern "C" int nk_lu_engine(nk_bandlu *B, int *engine, int *block, int *levels) {
+  NK_REQUIRE(B, "NULL argument");
+  if (engine) *engine = B->bcr ? 1 : 0;
+  if (block) *block = 0;
+  if (levels) *levels = 0;
+  if (B->bcr) return nk_bcr_shape(B->bcr, block, levels);
   return NK_OK;
 }
 extern "C" int nk_lu_info(nk_bandlu *B, int *kl, int *ku, int64_t *band_bytes) {

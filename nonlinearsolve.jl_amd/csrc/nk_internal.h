@@ -420,8 +420,16 @@ struct nk_bandlu {
   double *invU = nullptr;  // nblk × 32 × 32: U11⁻¹
   double *tmp = nullptr;
   int *d_fail = nullptr;
+  struct nk_bcr *bcr = nullptr;  // block cyclic reduction engine (nk_bcr.hip); when set, factor/solve go through it
 };
-int nk_bandlu_create(nk_csr *A, nk_bandlu **out);
+// engine: 0 = automatic (block cyclic reduction where it applies, else the band LU), 1 = band LU (NK_DIRECT=band forces it)
+int nk_bandlu_create(nk_csr *A, nk_bandlu **out, int engine = 0);
+struct nk_bcr;
+int nk_bcr_create(nk_ctx *ctx, int64_t n, int b, nk_bcr **out);
+int nk_bcr_factor(nk_bcr *S, nk_csr *A, int *ok);
+int nk_bcr_solve(nk_bcr *S, const double *d_b, double *d_x);
+void nk_bcr_destroy(nk_bcr *S);
+int64_t nk_bcr_bytes(int64_t n, int b);
 void nk_bandlu_destroy(nk_bandlu *B);
 int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok);
 int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x);

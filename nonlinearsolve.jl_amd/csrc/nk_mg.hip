@@ -349,7 +349,7 @@ static int mgb_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   }
   if (M->lv.size() > 1) {
     NK_TRY(nk_problem_jac_csr(M->lv.back().P, &M->Jc));
-    NK_TRY(nk_bandlu_create(M->Jc, &M->LU));
+    NK_TRY(nk_bandlu_create(M->Jc, &M->LU, 1));  // coarsest level: a handful of block columns — the band LU
   }
   *out = guard.release();
   return NK_OK;
@@ -455,7 +455,7 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
     } else {
       NK_TRY(nk_problem_jac_csr(C.P, &M->Jc));
     }
-    NK_TRY(nk_bandlu_create(M->Jc, &M->LU));
+    NK_TRY(nk_bandlu_create(M->Jc, &M->LU, 1));  // coarsest level: a handful of block columns — the band LU
   }
   *out = guard.release();
   return NK_OK;
