@@ -410,9 +410,11 @@ int nk_gmres_solve(nk_gmres *G, const double *b, double *x, int memspace, int us
                    double atol, double rtol, int maxiter, int fixed_iters, nk_gmres_info *info);
 
 /* ---------------------------------------------------------------- direct factorisation (seam 1, `linsolve = nothing`)
- * Banded LU without pivoting of a concrete sparse J on the device; factor once, solve many
+ * Direct factorisation of a concrete banded sparse J on the device; factor once, solve many
  * (reuse_A_if_factorization, lib/NonlinearSolveBase/ext/NonlinearSolveBaseLinearSolveExt.jl:81-86). Single rank.
- * *ok = 0 when a pivot vanished. Lower bandwidth ≤ ~550 (the panel is factored in LDS). */
+ * Engine (nk_lu_engine): block cyclic reduction — batched dense blocks of order b = bandwidth rounded to 32 (b <= 512) on FP64
+ * MFMA, log2(n/b) dependent levels — or, for matrices of fewer than four block rows, a right-looking band LU (lower
+ * bandwidth <= ~550). Pivots are taken on the diagonal; *ok = 0 when one vanished or was not finite. */
 int nk_lu_create(nk_csr *A, nk_lu **out);
 int nk_lu_destroy(nk_lu *F);
 int nk_lu_factor(nk_lu *F, nk_csr *A, int *ok);

@@ -41,6 +41,8 @@ struct bcr_gemm_args {
   double *C; int64_t sC; int ldc;
   int M, N, K;
   double alpha, beta;
+  int tri;  // structural zeros of one operand (level 0 of a banded matrix): 0 none; 1 A upper triangular (A[m][k] = 0 for k < m);
+            // 2 B lower triangular (B[k][n] = 0 for k < n); 3 B upper triangular (k > n); 4 A lower triangular (k > m)
 };
 constexpr int GT = 64, GK = 32, GLD = 80;
 __global__ __launch_bounds__(256) void k_bcr_gemm(bcr_gemm_args g) {
@@ -56,8 +58,14 @@ __global__ __launch_bounds__(256) void k_bcr_gemm(bcr_gemm_args g) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (nk_d4){0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < g.K; k0 += GK) {
-    double av[8], bv[8];
+  // the K range this tile has to visit (whole slabs)
+  int kbeg = 0, kend = g.K;
+  if (g.tri == 1) kbeg = (m0 / GK) * GK;
+  else if (g.tri == 2) kbeg = (n0 / GK) * GK;
+  else if (g.tri == 3) kend = min(g.K, n0 + GT);
+  else if (g.tri == 4) kend = min(g.K, m0 + GT);
+  double av[8], bv[8];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int idx = t + 256 * e;
@@ -68,6 +76,9 @@ __global__ __launch_bounds__(256) void k_bcr_gemm(bcr_gemm_args g) {
       const bool okb = (k0 + kb < g.K) && (n0 + n < g.N);
       bv[e] = okb ? B[(int64_t)(k0 + kb) + (int64_t)(n0 + n) * g.ldb] : 0.0;
     }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
     __syncthreads();  // the previous slab has been consumed
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -76,6 +87,7 @@ __global__ __launch_bounds__(256) void k_bcr_gemm(bcr_gemm_args g) {
       Bs[(idx & 31) * GLD + (idx >> 5)] = bv[e];
     }
     __syncthreads();
+    if (k0 + GK < kend) fetch(k0 + GK);  // the next slab's loads fly while this one is multiplied
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
       const int kr = (kk * 4 + (l >> 4)) * GLD;
@@ -105,22 +117,29 @@ __global__ __launch_bounds__(256) void k_bcr_gemm(bcr_gemm_args g) {
 }
 
 // ----------------------------------------------------------------------------- batched in-place inverse, n ≤ 128
-// Gauss–Jordan on the diagonal pivots, the matrix held in registers: thread (ti, tj) of a 16 × 16 arrangement owns rows
-// 8 ti … 8 ti + 7 and columns 8 tj … 8 tj + 7 (rows/columns ≥ n behave as an identity border). Per pivot k the owners of
+// Gauss–Jordan on the diagonal pivots, the matrix held in registers: thread (ti, tj) of a 16 × 32 arrangement owns rows
+// 8 ti … 8 ti + 7 and columns 4 tj … 4 tj + 3 (rows/columns ≥ n behave as an identity border; 64 entries per thread on 256
+// threads overflowed the VGPR file into AGPRs: 108 µs per inversion). Per pivot k the owners of
 // column k and of row k publish them to LDS (double buffered: ONE barrier per pivot), every thread then applies
-// a_ij ← a_ij − a_ik a_kj / a_kk to its 64 entries; row k, column k and the pivot itself take their Gauss–Jordan values.
+// a_ij ← a_ij − a_ik a_kj / a_kk to its 32 entries; row k, column k and the pivot itself take their Gauss–Jordan values.
 // The local index of row/column k inside its owner (k mod 8) is the unrolled inner loop counter, so every register index is
 // a compile-time constant.
-__global__ __launch_bounds__(256) void k_bcr_inv128(double *__restrict__ mats, int64_t stride, int ld, int n, int *fail) {
+__device__ __forceinline__ double bcr_rcp(double p) {  // v_rcp_f64 + two Newton steps (≈ 1 ulp; a division costs ≈ 5× more)
+  double x = __builtin_amdgcn_rcp(p);
+  x = x * (2.0 - p * x);
+  x = x * (2.0 - p * x);
+  return x;
+}
+__global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, int64_t stride, int ld, int n, int *fail) {
   __shared__ double colb[2][128], rowb[2][128];
   double *__restrict__ M = mats + (int64_t)blockIdx.x * stride;
-  const int t = threadIdx.x, ti = t & 15, tj = t >> 4;
-  double a[8][8];
+  const int t = threadIdx.x, ti = t & 15, tj = t >> 4;  // rows 8 ti …, columns 4 tj … (tj = 0 … 31)
+  double a[8][4];
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int i = ti * 8 + r, j = tj * 8 + c;
+      const int i = ti * 8 + r, j = tj * 4 + c;
       a[r][c] = (i < n && j < n) ? M[(int64_t)i + (int64_t)j * ld] : (i == j ? 1.0 : 0.0);
     }
   bool bad = false;
@@ -130,45 +149,45 @@ __global__ __launch_bounds__(256) void k_bcr_inv128(double *__restrict__ mats, i
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int k = kb * 8 + r, buf = r & 1;
-      if (tj == kb) {
+      const int cj = 2 * kb + (r >> 2), cl = r & 3;  // owner column group and local column of column k
+      if (tj == cj) {
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) colb[buf][ti * 8 + rr] = a[rr][r];
+        for (int rr = 0; rr < 8; ++rr) colb[buf][ti * 8 + rr] = a[rr][cl];
       }
       if (ti == kb) {
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) rowb[buf][tj * 8 + cc] = a[r][cc];
+        for (int cc = 0; cc < 4; ++cc) rowb[buf][tj * 4 + cc] = a[r][cc];
       }
       __syncthreads();
       const double piv = colb[buf][k];
       bad = bad || !(fabs(piv) > 1e-290);  // zero, denormal-small or NaN
-      const double pinv = 1.0 / piv;
-      double mr[8], rk[8];
+      const double pinv = bcr_rcp(piv);
+      double mr[8], rk[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        mr[q] = colb[buf][ti * 8 + q];
-        rk[q] = rowb[buf][tj * 8 + q] * pinv;
-      }
+      for (int q = 0; q < 8; ++q) mr[q] = colb[buf][ti * 8 + q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rk[q] = rowb[buf][tj * 4 + q] * pinv;
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) a[rr][cc] -= mr[rr] * rk[cc];
+        for (int cc = 0; cc < 4; ++cc) a[rr][cc] -= mr[rr] * rk[cc];
       if (ti == kb) {
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) a[r][cc] = rk[cc];
+        for (int cc = 0; cc < 4; ++cc) a[r][cc] = rk[cc];
       }
-      if (tj == kb) {
+      if (tj == cj) {
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) a[rr][r] = -mr[rr] * pinv;
+        for (int rr = 0; rr < 8; ++rr) a[rr][cl] = -mr[rr] * pinv;
       }
-      if (ti == kb && tj == kb) a[r][r] = pinv;
+      if (ti == kb && tj == cj) a[r][cl] = pinv;
     }
   }
   if (bad && t == 0) *fail = 1;
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int i = ti * 8 + r, j = tj * 8 + c;
+      const int i = ti * 8 + r, j = tj * 4 + c;
       if (i < n && j < n) M[(int64_t)i + (int64_t)j * ld] = a[r][c];
     }
 }
@@ -307,7 +326,7 @@ struct nk_bcr {
 
 static int bcr_gemm(nk_bcr *S, int batch, int M, int N, int K, double alpha, const double *A, int64_t sA, int lda,
                     const double *B, int64_t sB, int ldb, double beta, const double *C0, int64_t sC0, int ldc0, double *C,
-                    int64_t sC, int ldc) {
+                    int64_t sC, int ldc, int tri = 0) {
   if (batch <= 0 || M <= 0 || N <= 0) return NK_OK;
   bcr_gemm_args g;
   g.A = A; g.sA = sA; g.lda = lda;
@@ -316,6 +335,7 @@ static int bcr_gemm(nk_bcr *S, int batch, int M, int N, int K, double alpha, con
   g.C = C; g.sC = sC; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K;
   g.alpha = alpha; g.beta = beta;
+  g.tri = tri;
   const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
   for (int b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.y limit
     const int nb = std::min(65535, batch - b0);
@@ -334,7 +354,7 @@ static int bcr_gemm(nk_bcr *S, int batch, int M, int N, int K, double alpha, con
 static int bcr_invert(nk_bcr *S, double *M, int64_t stride, int ld, int n, int batch, int depth) {
   if (batch <= 0) return NK_OK;
   if (n <= 128) {
-    NK_LAUNCH(S->ctx, k_bcr_inv128, dim3(batch), dim3(256), M, stride, ld, n, S->d_fail);
+    NK_LAUNCH(S->ctx, k_bcr_inv128, dim3(batch), dim3(512), M, stride, ld, n, S->d_fail);
     NK_HIP(hipGetLastError());
     return NK_OK;
   }
@@ -445,14 +465,16 @@ int nk_bcr_factor(nk_bcr *S, nk_csr *Acsr, int *ok) {
               (const double *)L.D, N.D);
     NK_HIP(hipMemsetAsync(N.A, 0, (size_t)(m2 * bb) * sizeof(double), ctx->stream));
     NK_HIP(hipMemsetAsync(N.C, 0, (size_t)(m2 * bb) * sizeof(double), ctx->stream));
+    // Level 0 of a banded matrix: A_i is upper and C_i lower triangular — the products skip the K slabs that are all zero.
+    const bool l0 = (l == 0);
     // P_i = A_{2i} D⁻¹_{2i−1} (i = 1 … cP);  D'_i −= P_i C_{2i−1};  A'_i = −P_i A_{2i−1}
-    NK_TRY(bcr_gemm(S, cP, b, b, b, 1.0, L.A + 2 * bb, 2 * bb, b, L.D + bb, 2 * bb, b, 0.0, nullptr, 0, 0, L.P + bb, bb, b));
-    NK_TRY(bcr_gemm(S, cP, b, b, b, -1.0, L.P + bb, bb, b, L.C + bb, 2 * bb, b, 1.0, N.D + bb, bb, b, N.D + bb, bb, b));
-    NK_TRY(bcr_gemm(S, cP, b, b, b, -1.0, L.P + bb, bb, b, L.A + bb, 2 * bb, b, 0.0, nullptr, 0, 0, N.A + bb, bb, b));
+    NK_TRY(bcr_gemm(S, cP, b, b, b, 1.0, L.A + 2 * bb, 2 * bb, b, L.D + bb, 2 * bb, b, 0.0, nullptr, 0, 0, L.P + bb, bb, b, l0 ? 1 : 0));
+    NK_TRY(bcr_gemm(S, cP, b, b, b, -1.0, L.P + bb, bb, b, L.C + bb, 2 * bb, b, 1.0, N.D + bb, bb, b, N.D + bb, bb, b, l0 ? 2 : 0));
+    NK_TRY(bcr_gemm(S, cP, b, b, b, -1.0, L.P + bb, bb, b, L.A + bb, 2 * bb, b, 0.0, nullptr, 0, 0, N.A + bb, bb, b, l0 ? 3 : 0));
     // Q_i = C_{2i} D⁻¹_{2i+1} (i = 0 … cQ − 1);  D'_i −= Q_i A_{2i+1};  C'_i = −Q_i C_{2i+1}
-    NK_TRY(bcr_gemm(S, cQ, b, b, b, 1.0, L.C, 2 * bb, b, L.D + bb, 2 * bb, b, 0.0, nullptr, 0, 0, L.Q, bb, b));
-    NK_TRY(bcr_gemm(S, cQ, b, b, b, -1.0, L.Q, bb, b, L.A + bb, 2 * bb, b, 1.0, N.D, bb, b, N.D, bb, b));
-    NK_TRY(bcr_gemm(S, cQ, b, b, b, -1.0, L.Q, bb, b, L.C + bb, 2 * bb, b, 0.0, nullptr, 0, 0, N.C, bb, b));
+    NK_TRY(bcr_gemm(S, cQ, b, b, b, 1.0, L.C, 2 * bb, b, L.D + bb, 2 * bb, b, 0.0, nullptr, 0, 0, L.Q, bb, b, l0 ? 4 : 0));
+    NK_TRY(bcr_gemm(S, cQ, b, b, b, -1.0, L.Q, bb, b, L.A + bb, 2 * bb, b, 1.0, N.D, bb, b, N.D, bb, b, l0 ? 3 : 0));
+    NK_TRY(bcr_gemm(S, cQ, b, b, b, -1.0, L.Q, bb, b, L.C + bb, 2 * bb, b, 0.0, nullptr, 0, 0, N.C, bb, b, l0 ? 2 : 0));
   }
   NK_HIP(hipGetLastError());
   int h = 0;

@@ -627,7 +627,7 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
     double v[2] = {NAN, 1.0};
     if (lu_ok) {
       NK_TRY(nk_bandlu_solve(S->B, S->fu, du_out));
-      // The band LU does not pivot, so the solve is verified: ‖J x − b‖₂ ≤ 1e-10 ‖b‖₂, with one step of iterative
+      // The direct engines (block cyclic reduction, band LU) pivot on the diagonal only, so the solve is verified: ‖J x − b‖₂ ≤ 1e-10 ‖b‖₂, with one step of iterative
       // refinement before giving up on the factorisation.
       for (int pass = 0; pass < 2; ++pass) {
         NK_TRY(nk_csr_spmv_dev(S->J, du_out, S->stage, nullptr));
