@@ -722,6 +722,8 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
   hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb); hipFree(G->d_tprev); hipFree(G->d_red);
   nk_mg_destroy(G->mg);
+  if (G->gexec) hipGraphExecDestroy(G->gexec);
+  if (G->cap_stream) hipStreamDestroy(G->cap_stream);
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
   hipFree(G->d_g); hipFree(G->d_y); hipFree(G->d_ss); hipFree(G->d_ctl);
   hipFree(G->d_u_own); hipFree(G->d_b); hipFree(G->d_x);
@@ -1272,12 +1274,87 @@ static int arnoldi_step(nk_gmres *G, int k) {
   return NK_OK;
 }
 
+// A/B switch NK_GMRES_GRAPH=1: one fixed-work restart cycle (b → column 0, ≤ m Arnoldi steps of four launches, flush,
+// back-substitution, x = V y: ≈ 125 launches) captured ONCE into a HIP graph and replayed per linear solve, for operators whose
+// arguments do not change between solves (the concrete CSR Jacobian). The kernels' by-value cycle number is the captured one,
+// so the host waits with a stream synchronisation instead of polling the published sequence word. Measured on MI355X
+// (Bratu 1024², 30 Arnoldi steps per Newton step): see DESIGN.md §8 — the eager path keeps the queue full (a launch costs
+// the host 2–4 µs, a step's four kernels run for 64 µs), so the graph has nothing to remove; it stays an opt-in.
+static int gmres_solve_graph(nk_gmres *G, const double *d_b, double *d_x, double atol, double rtol, int steps,
+                             nk_gmres_info *info, bool *used) {
+  nk_ctx *ctx = G->ctx;
+  const int64_t n = G->n, ldv = G->ldv;
+  const int m = G->m;
+  *used = false;
+  const void *key[5] = {d_b, d_x, G->A, G->P, G->d_u};
+  const bool same = G->gexec && G->gsteps == steps && !memcmp(key, G->gkey, sizeof(key));
+  if (!same) {
+    if (G->gexec) { hipGraphExecDestroy(G->gexec); G->gexec = nullptr; }
+    if (!G->cap_stream && hipStreamCreateWithFlags(&G->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+      G->graph_broken = true;
+      return NK_OK;
+    }
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t user_stream = ctx->stream;
+    ctx->stream = G->cap_stream;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(G->cap_stream, hipStreamCaptureModeThreadLocal);
+    int st = (e == hipSuccess) ? NK_OK : NK_E_HIP;
+    const uint64_t seq = ++G->cycle_seq;
+    auto body = [&]() -> int {
+      NK_TRY(nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss));
+      NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol, 1, 1, G->d_g, G->d_s, m, G->h_pub_dev, seq);
+      for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step_1r(G, k, k == steps - 1));
+      NK_TRY(arnoldi_flush_1r(G, steps));
+      NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq);
+      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, true));
+      return NK_OK;
+    };
+    if (st == NK_OK) st = body();
+    if (e == hipSuccess) e = hipStreamEndCapture(G->cap_stream, &graph);
+    ctx->stream = user_stream;
+    if (st == NK_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&G->gexec, graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (st != NK_OK || e != hipSuccess || !G->gexec) {
+      G->gexec = nullptr;
+      G->graph_broken = true;
+      (void)hipGetLastError();
+      return NK_OK;  // the caller falls through to plain launches
+    }
+    memcpy(G->gkey, key, sizeof(key));
+    G->gsteps = steps;
+  }
+  NK_HIP(hipGraphLaunch(G->gexec, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  volatile nk_gmres_pub *pub = G->h_pub;
+  nk_gmres_info inf;
+  memset(&inf, 0, sizeof(inf));
+  inf.iters = pub->k;
+  inf.rnorm0 = pub->rnorm0;
+  inf.rnorm = pub->rnorm;
+  inf.converged = pub->converged;
+  inf.failed = pub->failed;
+  ctx->stats.gmres_iters += inf.iters;
+  if (info) *info = inf;
+  *used = true;
+  return NK_OK;
+}
+
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n, ldv = G->ldv;
   const int m = G->m;
   NK_REQUIRE(G->op_kind != 0, "GMRES has no operator");
+  {
+    static const bool want_graph = getenv("NK_GMRES_GRAPH") && atoi(getenv("NK_GMRES_GRAPH")) != 0;
+    if (want_graph && fixed_iters > 0 && fixed_iters <= m && !use_x0 && nk_ctx_is_single(ctx) && !ctx->prof.on &&
+        !G->prec_kind && !G->normal && G->op_kind != 3 && use_dcgs2r(G) && !G->graph_broken) {
+      bool used = false;
+      NK_TRY(gmres_solve_graph(G, d_b, d_x, atol, rtol, fixed_iters, info, &used));
+      if (used) return NK_OK;
+    }
+  }
   if (maxiter <= 0) maxiter = 300;
   const int cap = fixed_iters > 0 ? fixed_iters : maxiter;
   nk_gmres_info inf;

@@ -406,6 +406,12 @@ struct nk_gmres {
   double cheb_lmin = 0, cheb_lmax = 0;
   double *cr = nullptr, *cd = nullptr, *ct = nullptr, *cd2 = nullptr;  // Chebyshev work vectors (cd/cd2 ping-pong)
   double *d_b = nullptr, *d_x = nullptr;  // staging for host-memspace calls
+  // NK_GMRES_GRAPH=1 (A/B switch): the fixed-work cycle captured once into a HIP graph and replayed
+  hipGraphExec_t gexec = nullptr;
+  hipStream_t cap_stream = nullptr;
+  bool graph_broken = false;
+  const void *gkey[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int gsteps = 0;
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info);
