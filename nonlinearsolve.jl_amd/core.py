@@ -695,15 +695,10 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     check(L.lib().nk_options_default(C.byref(o)))
     ls = alg.linsolve
     o.algorithm = L.ALG_TRUST_REGION if isinstance(alg, TrustRegion) else L.ALG_NEWTON_RAPHSON
-    if isinstance(alg, GaussNewton):
-        if ls is None:
-            raise ValueError("GaussNewton: pass a Krylov linsolve (the normal-form operator JᵀJ is never assembled)")
+    if isinstance(alg, GaussNewton):   # (linsolve = None: a factorising solver takes J δ = f as it is — no normal form)
         o.algorithm = L.ALG_GAUSS_NEWTON
         o.termination_norm = 1  # default_termination_mode(::NonlinearLeastSquaresProblem): AbsNormSafeBest on the 2-norm
-    if isinstance(alg, LevenbergMarquardt):
-        if ls is None:
-            raise ValueError("LevenbergMarquardt: pass a Krylov linsolve (the damped normal equations JᵀJ + λDᵀD are "
-                             "applied as an operator, never assembled)")
+    if isinstance(alg, LevenbergMarquardt):   # (linsolve = None: JᵀJ + λDᵀD is assembled and factorised on the device)
         o.algorithm = L.ALG_LEVENBERG_MARQUARDT
         o.lm_disable_geodesic = int(bool(alg.disable_geodesic))
         o.lm_damping_initial = float(alg.damping_initial)

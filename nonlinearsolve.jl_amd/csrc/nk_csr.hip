@@ -684,6 +684,109 @@ extern "C" int nk_csr_colsumsq(nk_csr *A, double *out, int memspace) {
   return NK_OK;
 }
 
+// ----------------------------------------------------------------------------- assembled normal matrix JᵀJ + λ·diag(d)
+// (DampedNewtonDescent with a FACTORISING linear solver: the reference solves min ‖[J; √(λDᵀD)] x − [f; 0]‖ by QR,
+// descent/damped_newton.jl:258-296; the device factorises the normal equations of the same problem, whose matrix it has to
+// assemble.) Symbolic product once per pattern on the host — for every non-zero (i, j) of JᵀJ the list of pairs (p, q) of J's
+// non-zeros with row(p) = row(q), col(p) = i, col(q) = j, in row order — then one thread per output non-zero sums its
+// products in that fixed order. Single rank.
+struct nk_normal_plan {
+  nk_csr *N = nullptr;          // the pattern of JᵀJ (owned)
+  int32_t *d_ptr = nullptr;     // nnz(N) + 1 offsets into the pair lists
+  int32_t *d_pa = nullptr, *d_pb = nullptr;
+  int32_t *d_diagrow = nullptr; // row of a diagonal non-zero, −1 elsewhere
+};
+__global__ __launch_bounds__(NK_BLOCK) void k_normal_values(int64_t nnzN, const int32_t *__restrict__ ptr,
+                                                            const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
+                                                            const int32_t *__restrict__ diagrow, const double *__restrict__ val,
+                                                            double lambda, const double *__restrict__ d, double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (e >= nnzN) return;
+  double s = 0.0;
+  for (int32_t t = ptr[e]; t < ptr[e + 1]; ++t) s += val[pa[t]] * val[pb[t]];
+  const int32_t dr = diagrow[e];
+  if (dr >= 0 && d != nullptr) s += lambda * d[dr];
+  out[e] = s;
+}
+void nk_normal_plan_destroy(nk_normal_plan *Pn) {
+  if (!Pn) return;
+  if (Pn->N) nk_csr_destroy(Pn->N);
+  hipFree(Pn->d_ptr); hipFree(Pn->d_pa); hipFree(Pn->d_pb); hipFree(Pn->d_diagrow);
+  delete Pn;
+}
+int nk_normal_plan_create(nk_csr *J, nk_normal_plan **out) {
+  nk_ctx *ctx = J->ctx;
+  NK_REQUIRE(ctx->nranks == 1 && J->halo_gcols.empty(), "the assembled normal matrix is built on one rank");
+  const int64_t n = J->nrows;
+  // CSC view of J: for every column the (row, position) pairs in row order
+  std::vector<int32_t> cptr(n + 1, 0), crow(J->nnz), cpos(J->nnz);
+  for (int64_t k = 0; k < J->nnz; ++k) cptr[J->h_col[k] + 1]++;
+  for (int64_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
+  {
+    std::vector<int32_t> fill(cptr.begin(), cptr.end() - 1);
+    for (int64_t r = 0; r < n; ++r)
+      for (int32_t k = J->h_rowptr[r]; k < J->h_rowptr[r + 1]; ++k) {
+        const int32_t pos = fill[J->h_col[k]]++;
+        crow[pos] = (int32_t)r;
+        cpos[pos] = k;
+      }
+  }
+  std::vector<int32_t> rp(n + 1, 0), ptr, pa, pb, diagrow;
+  std::vector<int64_t> gc;
+  std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>> tmp;  // (j, (p, q)) of one output row
+  ptr.push_back(0);
+  for (int64_t i = 0; i < n; ++i) {
+    tmp.clear();
+    for (int32_t c = cptr[i]; c < cptr[i + 1]; ++c) {
+      const int32_t r = crow[c], p = cpos[c];
+      for (int32_t q = J->h_rowptr[r]; q < J->h_rowptr[r + 1]; ++q) tmp.push_back({J->h_col[q], {p, q}});
+    }
+    std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    bool has_diag = false;
+    for (size_t t = 0; t < tmp.size();) {
+      const int32_t j = tmp[t].first;
+      if (j > i && !has_diag) {  // a structurally missing diagonal still receives the damping
+        gc.push_back(i); diagrow.push_back((int32_t)i); ptr.push_back((int32_t)pa.size());
+        has_diag = true;
+      }
+      for (; t < tmp.size() && tmp[t].first == j; ++t) { pa.push_back(tmp[t].second.first); pb.push_back(tmp[t].second.second); }
+      gc.push_back(j);
+      diagrow.push_back(j == i ? (int32_t)i : -1);
+      if (j == i) has_diag = true;
+      ptr.push_back((int32_t)pa.size());
+    }
+    if (!has_diag) { gc.push_back(i); diagrow.push_back((int32_t)i); ptr.push_back((int32_t)pa.size()); }
+    rp[i + 1] = (int32_t)gc.size();
+  }
+  nk_normal_plan *Pn = new nk_normal_plan();
+  auto guard = nk_make_guard(Pn, [](nk_normal_plan *q) { nk_normal_plan_destroy(q); });
+  NK_TRY(nk_csr_create_local(ctx, n, n, 0, rp, gc, nullptr, &Pn->N, true));
+  const size_t nnzN = gc.size(), np = pa.size();
+  NK_TRY(nk_dev_alloc(&Pn->d_ptr, nnzN + 1));
+  NK_TRY(nk_dev_alloc(&Pn->d_pa, np + 1));
+  NK_TRY(nk_dev_alloc(&Pn->d_pb, np + 1));
+  NK_TRY(nk_dev_alloc(&Pn->d_diagrow, nnzN + 1));
+  NK_HIP(hipMemcpy(Pn->d_ptr, ptr.data(), (nnzN + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (np) NK_HIP(hipMemcpy(Pn->d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (np) NK_HIP(hipMemcpy(Pn->d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(hipMemcpy(Pn->d_diagrow, diagrow.data(), nnzN * sizeof(int32_t), hipMemcpyHostToDevice));
+  *out = guard.release();
+  return NK_OK;
+}
+nk_csr *nk_normal_plan_matrix(nk_normal_plan *Pn) { return Pn->N; }
+// N ← JᵀJ + λ·diag(d) (d may be nullptr)
+int nk_normal_plan_values(nk_normal_plan *Pn, nk_csr *J, double lambda, const double *d_diag) {
+  nk_csr *N = Pn->N;
+  if (N->nnz) {
+    NK_LAUNCH(J->ctx, k_normal_values, dim3((unsigned)((N->nnz + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), N->nnz,
+              (const int32_t *)Pn->d_ptr, (const int32_t *)Pn->d_pa, (const int32_t *)Pn->d_pb, (const int32_t *)Pn->d_diagrow,
+              (const double *)J->d_val, lambda, d_diag, N->d_val);
+    NK_HIP(hipGetLastError());
+  }
+  N->t_values_stale = true;
+  return NK_OK;
+}
+
 static int stage_in(nk_csr *A, const double *x, int memspace, const double **dx) {
   if (memspace == NK_DEVICE) {
     *dx = x;

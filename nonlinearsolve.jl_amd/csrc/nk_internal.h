@@ -259,6 +259,12 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
                     const nk_spmv_epi *epi = nullptr);
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
 int nk_csr_colsumsq_dev(nk_csr *A, double *d_out);  // out_j = Σ_i A_ij² (diag AᵀA)
+// assembled normal matrix N = JᵀJ + λ·diag(d) on the pattern of JᵀJ (single rank; nk_csr.hip)
+struct nk_normal_plan;
+int nk_normal_plan_create(nk_csr *J, nk_normal_plan **out);
+nk_csr *nk_normal_plan_matrix(nk_normal_plan *Pn);
+int nk_normal_plan_values(nk_normal_plan *Pn, nk_csr *J, double lambda, const double *d_diag);
+void nk_normal_plan_destroy(nk_normal_plan *Pn);
 // local_only: every column is a local index already (rectangular helper matrices such as the transposed local block):
 // no halo plan is built, i.e. the call is NOT collective
 int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t row_begin,

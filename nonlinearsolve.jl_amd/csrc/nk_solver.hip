@@ -59,6 +59,7 @@ struct nk_solver {
   double lm_lam = 0, lm_lam_factor = 0, lm_norm_v_old = 0, lm_beta = 0;
   bool lm_tr_accepted = false, lm_geo_accepted = false;
   double *lm_dtd = nullptr, *lm_diag = nullptr, *lm_v = nullptr, *lm_a = nullptr, *lm_vcache = nullptr, *lm_rhs = nullptr;
+  nk_normal_plan *nplan = nullptr;  // LevenbergMarquardt with the direct linsolve: the assembled JᵀJ + λDᵀD
   std::vector<nk_trace_entry> trace;
 };
 
@@ -217,7 +218,11 @@ extern "C" int nk_options_default(nk_options *o) {
 static const double DEFAULT_TOL = 3.0e-13;  // common_defaults.jl:44-48
 
 static bool is_tr(const nk_solver *S) { return S->o.algorithm == NK_ALG_TRUST_REGION; }
-static bool normal_form(const nk_solver *S) { return S->o.algorithm == NK_ALG_GAUSS_NEWTON; }
+// GaussNewton: normal form only when the linear solver needs a square A (Krylov); a factorising solver takes J δ = f as it is
+// (needs_square_A(nothing) = false, descent/newton.jl:71, linear_solve.jl:225)
+static bool normal_form(const nk_solver *S) {
+  return S->o.algorithm == NK_ALG_GAUSS_NEWTON && S->o.linsolve != NK_LINSOLVE_BANDED_LU;
+}
 static bool is_lm(const nk_solver *S) { return S->o.algorithm == NK_ALG_LEVENBERG_MARQUARDT; }
 static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE; }
 static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BANDED_LU; }
@@ -496,17 +501,14 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION ||
                  opts->algorithm == NK_ALG_GAUSS_NEWTON || opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT, "bad algorithm");
   if (opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT) {
-    NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_CSR,
-               "LevenbergMarquardt needs a concrete Jacobian (concrete_jac = Val(true), levenberg_marquardt.jl:62) and a "
-               "Krylov linsolve: the damped normal equations are applied as an operator, never assembled");
+    NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_CSR || opts->linsolve == NK_LINSOLVE_BANDED_LU,
+               "LevenbergMarquardt needs a concrete Jacobian (concrete_jac = Val(true), levenberg_marquardt.jl:62)");
     NK_REQUIRE(opts->linesearch == 0 && opts->forcing == NK_FORCING_NONE,
                "LevenbergMarquardt takes neither a line search nor a forcing term (levenberg_marquardt.jl:37-64)");
     NK_REQUIRE(opts->lm_damping_initial > 0.0 && opts->lm_damping_increase_factor > 0.0 &&
                    opts->lm_damping_decrease_factor > 0.0 && opts->lm_finite_diff_step_geodesic > 0.0,
                "LevenbergMarquardt: damping_initial, the damping factors and finite_diff_step_geodesic must be positive");
   }
-  NK_REQUIRE(!(opts->algorithm == NK_ALG_GAUSS_NEWTON && opts->linsolve == NK_LINSOLVE_BANDED_LU),
-             "GaussNewton in normal form needs a Krylov linsolve (JᵀJ is applied as an operator, never assembled)");
   NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_MATFREE || opts->linsolve == NK_LINSOLVE_GMRES_CSR ||
                  opts->linsolve == NK_LINSOLVE_BANDED_LU,
              "unknown linsolve %d", opts->linsolve);
@@ -561,7 +563,12 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     S->own_J = (P->kind != NK_PROBLEM_USER);
   }
   if (direct(S)) {
-    NK_TRY(nk_bandlu_create(S->J, &S->B));
+    if (is_lm(S)) {  // the factorising solver gets the assembled normal matrix JᵀJ + λDᵀD (see lm_damped_solve)
+      NK_TRY(nk_normal_plan_create(S->J, &S->nplan));
+      NK_TRY(nk_bandlu_create(nk_normal_plan_matrix(S->nplan), &S->B));
+    } else {
+      NK_TRY(nk_bandlu_create(S->J, &S->B));
+    }
     NK_TRY(nk_dev_alloc(&S->stage, na));
   } else {
     NK_TRY(nk_gmres_create(ctx, n, S->o.gmres_restart, S->o.gmres_ortho, &S->G));
@@ -584,6 +591,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
   for (double *b : bufs) hipFree(b);
   nk_gmres_destroy(S->G);
   nk_bandlu_destroy(S->B);
+  nk_normal_plan_destroy(S->nplan);
   if (S->own_J) nk_csr_destroy(S->J);
   delete S;
   return NK_OK;
@@ -973,10 +981,28 @@ static int lm_damped_solve(nk_solver *S, const double *rhs_f, double *out, bool 
     const int grid = nk_grid_for(S->n, NK_BLOCK * 4, 2048);
     NK_LAUNCH(ctx, k_lm_dtd_max, dim3(grid), dim3(NK_BLOCK), S->n, (const double *)S->lm_diag, S->lm_dtd);
     NK_HIP(hipGetLastError());
-    NK_TRY(nk_gmres_set_normal_form(S->G, 1));
-    NK_TRY(nk_gmres_set_normal_form_damping(S->G, S->lm_dtd, S->lm_lam));
+    if (direct(S)) {
+      // factorising linear solver: the reference takes the QR least-squares form min ‖[J; √(λDᵀD)] x − [f; 0]‖
+      // (damped_newton.jl:258-296); the device factorises the normal equations of the same problem, JᵀJ + λDᵀD assembled on
+      // the pattern of JᵀJ — same minimiser, the conditioning of J squared
+      NK_TRY(nk_normal_plan_values(S->nplan, S->J, S->lm_lam, S->lm_dtd));
+      int fok = 0;
+      NK_TRY(nk_bandlu_factor(S->B, nk_normal_plan_matrix(S->nplan), &fok));
+      S->stats.nfactors++;
+      S->lu_valid = fok != 0;
+    } else {
+      NK_TRY(nk_gmres_set_normal_form(S->G, 1));
+      NK_TRY(nk_gmres_set_normal_form_damping(S->G, S->lm_dtd, S->lm_lam));
+    }
   }
   NK_TRY(nk_csr_spmv_t_dev(S->J, rhs_f, S->lm_rhs));
+  if (direct(S)) {
+    S->last_gmres_iters = 0;
+    *ok = S->lu_valid;
+    if (!S->lu_valid) return nk_blas_fill(ctx, S->n, 0.0, out);
+    NK_TRY(nk_bandlu_solve(S->B, S->lm_rhs, out));
+    return nk_blas_lincomb(ctx, S->n, -1.0, out, 0.0, out, out);
+  }
   nk_gmres_info info;
   NK_TRY(nk_gmres_solve_dev(S->G, S->lm_rhs, out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
                             S->o.gmres_fixed_iters, &info));

@@ -130,6 +130,30 @@ def test_levenberg_marquardt_reinit_restores_the_damping(nls):
     assert np.array_equal(np.asarray(s1.u), np.asarray(s2.u))
 
 
-def test_levenberg_marquardt_needs_concrete_jacobian_and_krylov(nls):
-    with pytest.raises(ValueError):
-        nls.solve(nls.NonlinearProblem(nls.Quadratic(4, 2.0)), nls.LevenbergMarquardt())
+@pytest.mark.parametrize("which", ["quad", "bratu12", "brus6"])
+@pytest.mark.parametrize("geo", [True, False])
+def test_levenberg_marquardt_default_linsolve_matches_oracle(nls, which, geo):
+    """`LevenbergMarquardt()` as the reference constructs it (linsolve = nothing): a factorising solver — the reference takes
+    the QR least-squares form of the damped step (damped_newton.jl:258-296), the device assembles JᵀJ + λDᵀD on the pattern of
+    JᵀJ and factorises it (block cyclic reduction / band LU); same minimiser, so the same λ sequence, steps and iterate as the
+    oracle's dense least-squares solve."""
+    mk_ref, mk_dev = CASES[which]
+    ref = R.solve(mk_ref(), R.LevenbergMarquardt(disable_geodesic=not geo), abstol=1e-9, maxiters=200)
+    sol = nls.solve(nls.NonlinearProblem(mk_dev(nls)), nls.LevenbergMarquardt(disable_geodesic=not geo), abstol=1e-9,
+                    maxiters=200, store_trace=True)
+    assert sol.retcode == R.RETCODE_NAMES[ref.retcode] == "Success"
+    assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf and sol.stats.njacs == ref.stats.njacs
+    assert sol.stats.gmres_iters == 0 and sol.stats.nfactors == sol.stats.nsteps
+    assert np.allclose([t["trust_region"] for t in sol.trace], [t["trust_region"] for t in ref.trace], rtol=1e-12)
+    assert [t["accepted"] for t in sol.trace] == [t["accepted"] for t in ref.trace]
+    assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))
+
+
+def test_gauss_newton_default_linsolve_is_a_plain_direct_solve(nls):
+    """GaussNewton() with linsolve = nothing on a square problem: no normal form (needs_square_A(nothing) = false,
+    descent/newton.jl:71) — J δ = f through the factorisation, like NewtonRaphson()."""
+    ref = R.solve(R.Bratu2D(16), R.GaussNewton(), abstol=1e-9, maxiters=30,
+                  termination_kwargs=dict(mode=0, norm="l2", max_stalled_steps=32))   # the least-squares default: 2-norm
+    sol = nls.solve(nls.NonlinearLeastSquaresProblem(nls.Bratu2D(16)), nls.GaussNewton(), abstol=1e-9, maxiters=30)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and sol.stats.nsteps == ref.stats.nsteps
+    assert sol.stats.gmres_iters == 0 and np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-9
