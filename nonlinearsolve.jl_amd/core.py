@@ -575,6 +575,14 @@ class BackTracking:
     maxiters: int = 1000
 
 
+@dataclass
+class LineSearchesJL:
+    """LineSearch.jl's wrapper around LineSearches.jl [EXT]: `NewtonRaphson(linesearch = LineSearchesJL(; method = …))` with
+    method "Static" | "BackTracking" | "StrongWolfe" | "MoreThuente" (LineSearches.jl default parameters; HagerZhang is not
+    offered) — the methods of lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46."""
+    method: str = "BackTracking"
+
+
 class RadiusUpdateSchemes:  # trust_region.jl:59-147
     Simple, NLsolve, NocedalWright, Hei, Yuan, Bastin, Fan = range(7)
 
@@ -724,7 +732,9 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o.lin_abstol = -1.0 if ls.abstol is None else float(ls.abstol)
     o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
     lsr = getattr(alg, "linesearch", None)
-    if lsr is not None:
+    if isinstance(lsr, LineSearchesJL):
+        o.linesearch = {"BackTracking": 1, "Static": 2, "StrongWolfe": 3, "MoreThuente": 4}[lsr.method]
+    elif lsr is not None:
         o.linesearch = 1
         o.ls_c1, o.ls_rho_hi, o.ls_rho_lo = float(lsr.c_1), float(lsr.rho_hi), float(lsr.rho_lo)
         o.ls_order, o.ls_maxiters = int(lsr.order), int(lsr.maxiters)

@@ -516,7 +516,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
              "a forcing term needs an iterative linear solver");
   NK_REQUIRE(opts->termination_mode >= 0 && opts->termination_mode <= 8, "bad termination_mode %d", opts->termination_mode);
   NK_REQUIRE(opts->termination_norm == 0 || opts->termination_norm == 1, "bad termination_norm %d", opts->termination_norm);
-  NK_REQUIRE(opts->linesearch == 0 || opts->linesearch == 1, "bad linesearch %d", opts->linesearch);
+  NK_REQUIRE(opts->linesearch >= 0 && opts->linesearch <= 4, "bad linesearch %d", opts->linesearch);
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->linesearch != 0),
              "TrustRegion and LineSearch methods are algorithmically incompatible (FirstOrder/src/solve.jl:221-223)");
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->forcing != NK_FORCING_NONE),
@@ -954,6 +954,246 @@ static int backtracking(nk_solver *S, double *alpha_out, bool *failed) {
   return NK_OK;
 }
 
+// ---- LineSearchesJL(; method = Static | StrongWolfe | MoreThuente) [EXT: LineSearch.jl's wrapper around LineSearches.jl,
+// the methods of lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46] on ϕ(α) = ½‖f(u + α δu)‖²,
+// ϕ'(α) = f(u + α δu)ᵀ J(u + α δu) δu. Restated from the published algorithms with LineSearches.jl's default parameters
+// (oracle/reference_restatement.py::_lsjl is the same code in Python; its Moré–Thuente step function is pinned against SciPy's
+// MINPACK-2 dcstep). Every ϕ / ϕ' / (ϕ, ϕ') evaluation is one residual at the trial point (nf += 1) — plus, for ϕ', one
+// Jacobian-vector product there — one fused two-scalar reduction, one fetch.
+static int ls_phidphi(nk_solver *S, double alpha, double *phi, double *dphi) {
+  S->u_trial = spare_u(S);
+  nk_problem_invalidate(S->P);
+  NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->u, alpha, S->du, S->u_trial));
+  NK_TRY(nk_problem_residual_dev(S->P, S->u_trial, S->fu_trial));
+  S->stats.nf++;
+  double v[2] = {0.0, 0.0};
+  if (dphi) {
+    NK_TRY(nk_problem_jvp_dev(S->P, S->u_trial, S->du, S->Jdu, nullptr));
+    const double *xs[2] = {S->fu_trial, S->fu_trial}, *ys[2] = {S->fu_trial, S->Jdu};
+    NK_TRY(nk_blas_multi_reduce(S->ctx, S->n, 2, xs, ys, nullptr, nullptr, 0, 0, slot(S, 0)));
+    NK_TRY(fetch(S, 2, v));
+    *dphi = v[1];
+  } else {
+    NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu_trial, slot(S, 0)));
+    NK_TRY(fetch(S, 1, v));
+  }
+  *phi = 0.5 * v[0];
+  return NK_OK;
+}
+// LineSearches.Static: the proposed step, halved while ϕ is not finite
+static int ls_static(nk_solver *S, double *alpha) {
+  double a = 1.0, pa;
+  NK_TRY(ls_phidphi(S, a, &pa, nullptr));
+  for (int it = 0; !isfinite(pa) && it < 52; ++it) {
+    a /= 2.0;
+    NK_TRY(ls_phidphi(S, a, &pa, nullptr));
+  }
+  *alpha = a;
+  return NK_OK;
+}
+// LineSearches.StrongWolfe (Nocedal & Wright alg. 3.5 / 3.6, cubic interpolation, c₁ = 1e-4, c₂ = 0.9, ρ = 2)
+static double ls_sw_interp(double a1, double a2, double p1, double p2, double d1, double d2) {
+  const double q1 = d1 + d2 - 3.0 * (p1 - p2) / (a1 - a2);
+  const double rad = q1 * q1 - d1 * d2;
+  const double q2 = rad >= 0.0 ? sqrt(rad) : NAN;
+  return a2 - (a2 - a1) * ((d2 + q2 - q1) / (d2 - d1 + 2.0 * q2));
+}
+static int ls_sw_zoom(nk_solver *S, double alo, double ahi, double phi0, double dphi0, double *out) {
+  const double c1 = 1e-4, c2 = 0.9;
+  double aj = NAN;
+  for (int it = 0; it < 10; ++it) {
+    double plo, dlo, phi_, dhi, pj, dj;
+    NK_TRY(ls_phidphi(S, alo, &plo, &dlo));
+    NK_TRY(ls_phidphi(S, ahi, &phi_, &dhi));
+    aj = (alo < ahi) ? ls_sw_interp(alo, ahi, plo, phi_, dlo, dhi) : ls_sw_interp(ahi, alo, phi_, plo, dhi, dlo);
+    NK_TRY(ls_phidphi(S, aj, &pj, nullptr));
+    if (pj > phi0 + c1 * aj * dphi0 || pj > plo) {
+      ahi = aj;
+    } else {
+      NK_TRY(ls_phidphi(S, aj, &pj, &dj));
+      if (fabs(dj) <= -c2 * dphi0) break;
+      if (dj * (ahi - alo) >= 0.0) ahi = alo;
+      alo = aj;
+    }
+  }
+  *out = aj;
+  return NK_OK;
+}
+static int ls_strongwolfe(nk_solver *S, double phi0, double dphi0, double *alpha) {
+  const double c1 = 1e-4, c2 = 0.9, rho = 2.0, a_max = 65536.0;
+  double a_prev = 0.0, a_i = 1.0, p_prev = phi0, p_i, d_i, tmp;
+  for (int i = 1; a_i < a_max; ++i) {
+    NK_TRY(ls_phidphi(S, a_i, &p_i, nullptr));
+    if (p_i > phi0 + c1 * a_i * dphi0 || (p_i >= p_prev && i > 1)) {
+      NK_TRY(ls_sw_zoom(S, a_prev, a_i, phi0, dphi0, alpha));
+      return ls_phidphi(S, *alpha, &tmp, nullptr);  // the method returns (α*, ϕ(α*)): one more evaluation
+    }
+    NK_TRY(ls_phidphi(S, a_i, &p_i, &d_i));
+    if (fabs(d_i) <= -c2 * dphi0) { *alpha = a_i; return NK_OK; }
+    if (d_i >= 0.0) {
+      NK_TRY(ls_sw_zoom(S, a_i, a_prev, phi0, dphi0, alpha));
+      return ls_phidphi(S, *alpha, &tmp, nullptr);
+    }
+    a_prev = a_i;
+    p_prev = p_i;
+    a_i *= rho;
+  }
+  *alpha = a_max;
+  return ls_phidphi(S, a_max, &tmp, nullptr);
+}
+// MINPACK cstep (Moré & Thuente 1994): safeguarded cubic / quadratic step + update of the interval of uncertainty
+struct mt_state { double stx, fx, dgx, sty, fy, dgy, alpha, f, dg; bool bracketed; int info; };
+static void ls_cstep(mt_state &m, double amin, double amax) {
+  double &stx = m.stx, &fx = m.fx, &dgx = m.dgx, &sty = m.sty, &fy = m.fy, &dgy = m.dgy, &alpha = m.alpha;
+  const double f = m.f, dg = m.dg;
+  m.info = 0;
+  if ((m.bracketed && (alpha <= fmin(stx, sty) || alpha >= fmax(stx, sty))) || dgx * (alpha - stx) >= 0.0 || amax < amin) return;
+  const double sgnd = dg * (dgx / fabs(dgx));
+  bool bound;
+  double af;
+  if (f > fx) {
+    m.info = 1; bound = true;
+    const double theta = 3.0 * (fx - f) / (alpha - stx) + dgx + dg;
+    const double sc = fmax(fabs(theta), fmax(fabs(dgx), fabs(dg)));
+    double gamma = sc * sqrt((theta / sc) * (theta / sc) - (dgx / sc) * (dg / sc));
+    if (alpha < stx) gamma = -gamma;
+    const double pp = gamma - dgx + theta, q = gamma - dgx + gamma + dg, r = pp / q;
+    const double ac = stx + r * (alpha - stx);
+    const double aq = stx + ((dgx / ((fx - f) / (alpha - stx) + dgx)) / 2.0) * (alpha - stx);
+    af = (fabs(ac - stx) < fabs(aq - stx)) ? ac : (ac + aq) / 2.0;
+    m.bracketed = true;
+  } else if (sgnd < 0.0) {
+    m.info = 2; bound = false;
+    const double theta = 3.0 * (fx - f) / (alpha - stx) + dgx + dg;
+    const double sc = fmax(fabs(theta), fmax(fabs(dgx), fabs(dg)));
+    double gamma = sc * sqrt((theta / sc) * (theta / sc) - (dgx / sc) * (dg / sc));
+    if (alpha > stx) gamma = -gamma;
+    const double pp = gamma - dg + theta, q = gamma - dg + gamma + dgx, r = pp / q;
+    const double ac = alpha + r * (stx - alpha);
+    const double aq = alpha + (dg / (dg - dgx)) * (stx - alpha);
+    af = (fabs(ac - alpha) > fabs(aq - alpha)) ? ac : aq;
+    m.bracketed = true;
+  } else if (fabs(dg) < fabs(dgx)) {
+    m.info = 3; bound = true;
+    const double theta = 3.0 * (fx - f) / (alpha - stx) + dgx + dg;
+    const double sc = fmax(fabs(theta), fmax(fabs(dgx), fabs(dg)));
+    double gamma = sc * sqrt(fmax(0.0, (theta / sc) * (theta / sc) - (dgx / sc) * (dg / sc)));
+    if (alpha > stx) gamma = -gamma;
+    const double pp = gamma - dg + theta, q = gamma + dgx - dg + gamma, r = pp / q;
+    double ac;
+    if (r < 0.0 && gamma != 0.0) ac = alpha + r * (stx - alpha);
+    else if (alpha > stx) ac = amax;
+    else ac = amin;
+    const double aq = alpha + (dg / (dg - dgx)) * (stx - alpha);
+    if (m.bracketed) af = (fabs(alpha - ac) < fabs(alpha - aq)) ? ac : aq;
+    else af = (fabs(alpha - ac) > fabs(alpha - aq)) ? ac : aq;
+  } else {
+    m.info = 4; bound = false;
+    if (m.bracketed) {
+      const double theta = 3.0 * (f - fy) / (sty - alpha) + dgy + dg;
+      const double sc = fmax(fabs(theta), fmax(fabs(dgy), fabs(dg)));
+      double gamma = sc * sqrt((theta / sc) * (theta / sc) - (dgy / sc) * (dg / sc));
+      if (alpha > sty) gamma = -gamma;
+      const double pp = gamma - dg + theta, q = gamma - dg + gamma + dgy, r = pp / q;
+      af = alpha + r * (sty - alpha);
+    } else if (alpha > stx) af = amax;
+    else af = amin;
+  }
+  if (f > fx) { sty = alpha; fy = f; dgy = dg; }
+  else {
+    if (sgnd < 0.0) { sty = stx; fy = fx; dgy = dgx; }
+    stx = alpha; fx = f; dgx = dg;
+  }
+  af = fmax(amin, fmin(amax, af));
+  alpha = af;
+  if (m.bracketed && bound) {
+    if (sty > stx) alpha = fmin(stx + (2.0 / 3.0) * (sty - stx), alpha);
+    else alpha = fmax(stx + (2.0 / 3.0) * (sty - stx), alpha);
+  }
+}
+// LineSearches.MoreThuente (f_tol = 1e-4, gtol = 0.9, x_tol = 1e-8, alphamin = 1e-16, alphamax = 65536, maxfev = 100)
+static int ls_morethuente(nk_solver *S, double phi0, double dphi0, double *alpha_out) {
+  const double f_tol = 1e-4, gtol = 0.9, x_tol = 1e-8, amin = 1e-16, amax = 65536.0;
+  const int maxfev = 100;
+  int info = 0, info_cstep = 1, nfev = 0;
+  bool stage1 = true;
+  const double finit = phi0, dgtest = f_tol * dphi0;
+  double width = amax - amin, width1 = 2.0 * width;
+  mt_state m;
+  m.stx = 0.0; m.fx = finit; m.dgx = dphi0;
+  m.sty = 0.0; m.fy = finit; m.dgy = dphi0;
+  m.bracketed = false;
+  m.info = 1;
+  double alpha = fmin(fmax(1.0, amin), amax), f, dg, stmin, stmax;
+  NK_TRY(ls_phidphi(S, alpha, &f, &dg));
+  nfev++;
+  for (int itf = 0; (!isfinite(f) || !isfinite(dg)) && itf < 52; ++itf) {
+    alpha /= 2.0;
+    NK_TRY(ls_phidphi(S, alpha, &f, &dg));
+    nfev++;
+    m.stx = 0.875 * alpha;
+  }
+  for (;;) {
+    if (m.bracketed) { stmin = fmin(m.stx, m.sty); stmax = fmax(m.stx, m.sty); }
+    else { stmin = m.stx; stmax = alpha + 4.0 * (alpha - m.stx); }
+    stmin = fmax(amin, stmin);
+    stmax = fmin(amax, stmax);
+    alpha = fmin(fmax(alpha, amin), amax);
+    if ((m.bracketed && (alpha <= stmin || alpha >= stmax)) || nfev >= maxfev - 1 || info_cstep == 0 ||
+        (m.bracketed && stmax - stmin <= x_tol * stmax))
+      alpha = m.stx;
+    NK_TRY(ls_phidphi(S, alpha, &f, &dg));  // (the first pass evaluates the initial step a second time, as LineSearches.jl does)
+    nfev++;
+    const double ftest1 = finit + alpha * dgtest;
+    if ((m.bracketed && (alpha <= stmin || alpha >= stmax)) || info_cstep == 0) info = 6;
+    if (alpha == amax && f <= ftest1 && dg <= dgtest) info = 5;
+    if (alpha == amin && (f > ftest1 || dg >= dgtest)) info = 4;
+    if (nfev >= maxfev) info = 3;
+    if (m.bracketed && stmax - stmin <= x_tol * stmax) info = 2;
+    if (f <= ftest1 && fabs(dg) <= -gtol * dphi0) info = 1;
+    if (info != 0) break;
+    if (stage1 && f <= ftest1 && dg >= fmin(f_tol, gtol) * dphi0) stage1 = false;
+    m.alpha = alpha;
+    if (stage1 && f <= m.fx && f > ftest1) {  // the modified function ψ(α) = ϕ(α) − ϕ(0) − f_tol ϕ'(0) α
+      mt_state mm = m;
+      mm.fx = m.fx - m.stx * dgtest; mm.fy = m.fy - m.sty * dgtest; mm.f = f - alpha * dgtest;
+      mm.dgx = m.dgx - dgtest; mm.dgy = m.dgy - dgtest; mm.dg = dg - dgtest;
+      ls_cstep(mm, stmin, stmax);
+      m.stx = mm.stx; m.sty = mm.sty; m.alpha = mm.alpha; m.bracketed = mm.bracketed; m.info = mm.info;
+      m.fx = mm.fx + mm.stx * dgtest; m.fy = mm.fy + mm.sty * dgtest;
+      m.dgx = mm.dgx + dgtest; m.dgy = mm.dgy + dgtest;
+    } else {
+      m.f = f; m.dg = dg;
+      ls_cstep(m, stmin, stmax);
+    }
+    alpha = m.alpha;
+    info_cstep = m.info;
+    if (m.bracketed) {
+      if (fabs(m.sty - m.stx) >= (2.0 / 3.0) * width1) alpha = m.stx + (m.sty - m.stx) / 2.0;
+      width1 = width;
+      width = fabs(m.sty - m.stx);
+    }
+  }
+  *alpha_out = alpha;
+  return NK_OK;
+}
+static int linesearch_lsjl(nk_solver *S, double *alpha_out, bool *failed) {
+  *failed = false;
+  double phi0, dphi0;
+  NK_TRY(ls_phidphi(S, 0.0, &phi0, &dphi0));
+  if (dphi0 >= 0.0) {  // not a descent direction: the full step, reported as a failed line search
+    *alpha_out = 1.0;
+    *failed = true;
+    return NK_OK;
+  }
+  switch (S->o.linesearch) {
+    case 2: return ls_static(S, alpha_out);
+    case 3: return ls_strongwolfe(S, phi0, dphi0, alpha_out);
+    case 4: return ls_morethuente(S, phi0, dphi0, alpha_out);
+    default: NK_FAIL(NK_E_INVALID, "bad linesearch %d", S->o.linesearch);
+  }
+}
+
 // ---- LevenbergMarquardt
 // DᵀD ← max(DᵀD, diag(JᵀJ)) — update_levenberg_marquardt_diagonal!! (levenberg_marquardt.jl:270-293)
 __global__ __launch_bounds__(NK_BLOCK) void k_lm_dtd_max(int64_t n, const double *__restrict__ diag, double *__restrict__ dtd) {
@@ -1218,7 +1458,8 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     if (S->o.linesearch) {  // Val(:LineSearch): α from the line search, then axpy!(α, δu, u)  (solve.jl:392-408)
       double alpha = 1.0;
       bool lsfail = false;
-      NK_TRY(backtracking(S, &alpha, &lsfail));
+      if (S->o.linesearch == 1) NK_TRY(backtracking(S, &alpha, &lsfail));
+      else NK_TRY(linesearch_lsjl(S, &alpha, &lsfail));
       if (lsfail) {
         S->retcode = NK_RET_INTERNAL_LINESEARCH_FAILED;
         S->force_stop = true;

@@ -687,6 +687,18 @@ class BackTracking:
 
 
 @dataclass
+class LineSearchesJL:
+    """LineSearch.jl's wrapper around LineSearches.jl [EXT] — `NewtonRaphson(linesearch = LineSearchesJL(; method = …))`, the
+    five methods the reference's own tests run (lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46): `Static`,
+    `BackTracking`, `StrongWolfe`, `MoreThuente` are restated here from the published algorithms (Nocedal & Wright alg. 3.5/3.6;
+    Moré & Thuente 1994 / MINPACK cvsrch + cstep) with LineSearches.jl's default parameters; `HagerZhang` is not.
+    ϕ(α) = ½‖f(u + α δu)‖², ϕ'(α) = f(u + α δu)ᵀ J(u + α δu) δu; every ϕ, ϕ' or (ϕ, ϕ') evaluation is one residual
+    evaluation (`nf += 1`); α₀ = 1 on every call; a non-descent direction (ϕ'(0) ≥ 0) takes the full step and reports
+    failure. Parity unpinned (no source in the tree; the reference only tests convergence)."""
+    method: str = "BackTracking"
+
+
+@dataclass
 class NewtonRaphson:  # raphson.jl:30-43
     linsolve: object = None
     forcing: Optional[EisenstatWalkerForcing2] = None
@@ -1255,6 +1267,243 @@ class FirstOrderCache:
             phx0, phx1 = phx1, phi(a2)
         return a2, False
 
+    # -- LineSearchesJL(; method) [EXT]: Static / StrongWolfe / MoreThuente on ϕ(α) = ½‖f(u + α δu)‖²
+    def _lsjl(self, method, du):
+        prob, u = self.prob, self.u
+
+        def phi_dphi(a, want_d=True):
+            self.stats.nf += 1
+            ut = u + a * du
+            f = prob.f(ut)
+            ph = 0.5 * float(np.dot(f, f))
+            if not want_d:
+                return ph
+            return ph, float(np.dot(f, prob.jvp(du, ut)))
+
+        phi = lambda a: phi_dphi(a, False)      # noqa: E731
+        dphi = lambda a: phi_dphi(a)[1]         # noqa: E731
+        phi0, dphi0 = phi_dphi(0.0)
+        if dphi0 >= 0.0:
+            return 1.0, True
+        if method == "Static":
+            return self._ls_static(phi, 1.0), False
+        if method == "StrongWolfe":
+            return self._ls_strongwolfe(phi, dphi, phi_dphi, 1.0, phi0, dphi0), False
+        if method == "MoreThuente":
+            return self._ls_morethuente(phi_dphi, 1.0, phi0, dphi0), False
+        raise ValueError(method)
+
+    @staticmethod
+    def _ls_static(phi, a):           # LineSearches.jl static.jl: the proposed step, halved while ϕ is not finite
+        pa = phi(a)
+        it = 0
+        while not math.isfinite(pa) and it < 52:   # -log2(eps(Float64))
+            it += 1
+            a = a / 2.0
+            pa = phi(a)
+        return a
+
+    @staticmethod
+    def _ls_sw_interp(a1, a2, p1, p2, d1, d2):   # cubic interpolation (Nocedal & Wright eq. 3.59)
+        q1 = d1 + d2 - 3.0 * (p1 - p2) / (a1 - a2)
+        rad = q1 * q1 - d1 * d2
+        q2 = math.sqrt(rad) if rad >= 0.0 else float("nan")
+        return a2 - (a2 - a1) * ((d2 + q2 - q1) / (d2 - d1 + 2.0 * q2))
+
+    def _ls_strongwolfe(self, phi, dphi, phidphi, a0, phi0, dphi0, c1=1e-4, c2=0.9, rho=2.0):
+        def zoom(alo, ahi):           # alg. 3.6
+            aj = float("nan")
+            for _ in range(10):
+                plo, dlo = phidphi(alo)
+                phi_, dhi = phidphi(ahi)
+                aj = self._ls_sw_interp(alo, ahi, plo, phi_, dlo, dhi) if alo < ahi else \
+                    self._ls_sw_interp(ahi, alo, phi_, plo, dhi, dlo)
+                pj = phi(aj)
+                if pj > phi0 + c1 * aj * dphi0 or pj > plo:
+                    ahi = aj
+                else:
+                    dj = dphi(aj)
+                    if abs(dj) <= -c2 * dphi0:
+                        return aj
+                    if dj * (ahi - alo) >= 0.0:
+                        ahi = alo
+                    alo = aj
+            return aj
+        a_prev, a_i, a_max = 0.0, a0, 65536.0
+        p_prev = phi0
+        i = 1
+        while a_i < a_max:            # alg. 3.5
+            p_i = phi(a_i)
+            if p_i > phi0 + c1 * a_i * dphi0 or (p_i >= p_prev and i > 1):
+                a = zoom(a_prev, a_i)
+                phi(a)                # the method returns (α*, ϕ(α*)): one more evaluation
+                return a
+            d_i = dphi(a_i)
+            if abs(d_i) <= -c2 * dphi0:
+                return a_i
+            if d_i >= 0.0:
+                a = zoom(a_i, a_prev)
+                phi(a)
+                return a
+            a_prev, p_prev = a_i, p_i
+            a_i *= rho
+            i += 1
+        phi(a_max)
+        return a_max
+
+    @staticmethod
+    def _ls_cstep(stx, fx, dgx, sty, fy, dgy, alpha, f, dg, bracketed, amin, amax):
+        """MINPACK cstep (Moré & Thuente): safeguarded cubic / quadratic step and the update of the interval of uncertainty."""
+        info = 0
+        if (bracketed and (alpha <= min(stx, sty) or alpha >= max(stx, sty))) or dgx * (alpha - stx) >= 0.0 or amax < amin:
+            return stx, fx, dgx, sty, fy, dgy, alpha, f, dg, bracketed, 0
+        sgnd = dg * (dgx / abs(dgx))
+        if f > fx:                       # case 1: higher function value — bracketed
+            info, bound = 1, True
+            theta = 3.0 * (fx - f) / (alpha - stx) + dgx + dg
+            sc = max(abs(theta), abs(dgx), abs(dg))
+            gamma = sc * math.sqrt((theta / sc) ** 2 - (dgx / sc) * (dg / sc))
+            if alpha < stx:
+                gamma = -gamma
+            pp = gamma - dgx + theta
+            q = gamma - dgx + gamma + dg
+            r = pp / q
+            ac = stx + r * (alpha - stx)
+            aq = stx + ((dgx / ((fx - f) / (alpha - stx) + dgx)) / 2.0) * (alpha - stx)
+            af = ac if abs(ac - stx) < abs(aq - stx) else (ac + aq) / 2.0
+            bracketed = True
+        elif sgnd < 0.0:                 # case 2: lower value, derivatives of opposite sign — bracketed
+            info, bound = 2, False
+            theta = 3.0 * (fx - f) / (alpha - stx) + dgx + dg
+            sc = max(abs(theta), abs(dgx), abs(dg))
+            gamma = sc * math.sqrt((theta / sc) ** 2 - (dgx / sc) * (dg / sc))
+            if alpha > stx:
+                gamma = -gamma
+            pp = gamma - dg + theta
+            q = gamma - dg + gamma + dgx
+            r = pp / q
+            ac = alpha + r * (stx - alpha)
+            aq = alpha + (dg / (dg - dgx)) * (stx - alpha)
+            af = ac if abs(ac - alpha) > abs(aq - alpha) else aq
+            bracketed = True
+        elif abs(dg) < abs(dgx):         # case 3: lower value, same sign, derivative magnitude decreases
+            info, bound = 3, True
+            theta = 3.0 * (fx - f) / (alpha - stx) + dgx + dg
+            sc = max(abs(theta), abs(dgx), abs(dg))
+            gamma = sc * math.sqrt(max(0.0, (theta / sc) ** 2 - (dgx / sc) * (dg / sc)))
+            if alpha > stx:
+                gamma = -gamma
+            pp = gamma - dg + theta
+            q = gamma + dgx - dg + gamma
+            r = pp / q
+            if r < 0.0 and gamma != 0.0:
+                ac = alpha + r * (stx - alpha)
+            elif alpha > stx:
+                ac = amax
+            else:
+                ac = amin
+            aq = alpha + (dg / (dg - dgx)) * (stx - alpha)
+            if bracketed:
+                af = ac if abs(alpha - ac) < abs(alpha - aq) else aq
+            else:
+                af = ac if abs(alpha - ac) > abs(alpha - aq) else aq
+        else:                            # case 4: lower value, same sign, derivative magnitude does not decrease
+            info, bound = 4, False
+            if bracketed:
+                theta = 3.0 * (f - fy) / (sty - alpha) + dgy + dg
+                sc = max(abs(theta), abs(dgy), abs(dg))
+                gamma = sc * math.sqrt((theta / sc) ** 2 - (dgy / sc) * (dg / sc))
+                if alpha > sty:
+                    gamma = -gamma
+                pp = gamma - dg + theta
+                q = gamma - dg + gamma + dgy
+                r = pp / q
+                af = alpha + r * (sty - alpha)
+            elif alpha > stx:
+                af = amax
+            else:
+                af = amin
+        if f > fx:
+            sty, fy, dgy = alpha, f, dg
+        else:
+            if sgnd < 0.0:
+                sty, fy, dgy = stx, fx, dgx
+            stx, fx, dgx = alpha, f, dg
+        af = max(amin, min(amax, af))
+        alpha = af
+        if bracketed and bound:
+            if sty > stx:
+                alpha = min(stx + (2.0 / 3.0) * (sty - stx), alpha)
+            else:
+                alpha = max(stx + (2.0 / 3.0) * (sty - stx), alpha)
+        return stx, fx, dgx, sty, fy, dgy, alpha, f, dg, bracketed, info
+
+    def _ls_morethuente(self, phidphi, alpha, phi0, dphi0, f_tol=1e-4, gtol=0.9, x_tol=1e-8, amin=1e-16, amax=65536.0,
+                        maxfev=100):
+        info, info_cstep = 0, 1
+        bracketed, stage1, nfev = False, True, 0
+        finit, dgtest = phi0, f_tol * dphi0
+        width = amax - amin
+        width1 = 2.0 * width
+        stx, fx, dgx = 0.0, finit, dphi0
+        sty, fy, dgy = 0.0, finit, dphi0
+        stmin, stmax = 0.0, alpha + 4.0 * (alpha - stx)
+        alpha = min(max(alpha, amin), amax)
+        f, dg = phidphi(alpha)
+        nfev += 1
+        itf = 0
+        while (not math.isfinite(f) or not math.isfinite(dg)) and itf < 52:
+            itf += 1
+            alpha = alpha / 2.0
+            f, dg = phidphi(alpha)
+            nfev += 1
+            stx = 0.875 * alpha
+        while True:
+            if bracketed:
+                stmin, stmax = min(stx, sty), max(stx, sty)
+            else:
+                stmin, stmax = stx, alpha + 4.0 * (alpha - stx)
+            stmin, stmax = max(amin, stmin), min(amax, stmax)
+            alpha = min(max(alpha, amin), amax)
+            if (bracketed and (alpha <= stmin or alpha >= stmax)) or nfev >= maxfev - 1 or info_cstep == 0 or \
+                    (bracketed and stmax - stmin <= x_tol * stmax):
+                alpha = stx
+            f, dg = phidphi(alpha)      # (the first pass evaluates the initial step a second time, as LineSearches.jl does)
+            nfev += 1
+            ftest1 = finit + alpha * dgtest
+            if (bracketed and (alpha <= stmin or alpha >= stmax)) or info_cstep == 0:
+                info = 6
+            if alpha == amax and f <= ftest1 and dg <= dgtest:
+                info = 5
+            if alpha == amin and (f > ftest1 or dg >= dgtest):
+                info = 4
+            if nfev >= maxfev:
+                info = 3
+            if bracketed and stmax - stmin <= x_tol * stmax:
+                info = 2
+            if f <= ftest1 and abs(dg) <= -gtol * dphi0:
+                info = 1
+            if info != 0:
+                break
+            if stage1 and f <= ftest1 and dg >= min(f_tol, gtol) * dphi0:
+                stage1 = False
+            if stage1 and f <= fx and f > ftest1:
+                fm, fxm, fym = f - alpha * dgtest, fx - stx * dgtest, fy - sty * dgtest
+                dgm, dgxm, dgym = dg - dgtest, dgx - dgtest, dgy - dgtest
+                stx, fxm, dgxm, sty, fym, dgym, alpha, fm, dgm, bracketed, info_cstep = self._ls_cstep(
+                    stx, fxm, dgxm, sty, fym, dgym, alpha, fm, dgm, bracketed, stmin, stmax)
+                fx, fy = fxm + stx * dgtest, fym + sty * dgtest
+                dgx, dgy = dgxm + dgtest, dgym + dgtest
+            else:
+                stx, fx, dgx, sty, fy, dgy, alpha, f, dg, bracketed, info_cstep = self._ls_cstep(
+                    stx, fx, dgx, sty, fy, dgy, alpha, f, dg, bracketed, stmin, stmax)
+            if bracketed:
+                if abs(sty - stx) >= (2.0 / 3.0) * width1:
+                    alpha = stx + (sty - stx) / 2.0
+                width1 = width
+                width = abs(sty - stx)
+        return alpha
+
     # -- pre/post_step_forcing! (eisenstat_walker.jl:42-89)
     def _pre_step_forcing(self, it):
         p = self.forcing
@@ -1349,7 +1598,10 @@ class FirstOrderCache:
         else:
             ls = getattr(self.alg, "linesearch", None)
             if ls is not None:  # Val(:LineSearch), solve.jl:392-408
-                alpha, ls_failed = self._backtracking(ls, du)
+                if isinstance(ls, LineSearchesJL) and ls.method != "BackTracking":
+                    alpha, ls_failed = self._lsjl(ls.method, du)
+                else:
+                    alpha, ls_failed = self._backtracking(ls if isinstance(ls, BackTracking) else BackTracking(), du)
                 if ls_failed:
                     self.retcode = LINESEARCH_FAILED
                     self.force_stop = True

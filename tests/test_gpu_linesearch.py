@@ -1,0 +1,39 @@
+"""NewtonRaphson(linesearch = LineSearchesJL(; method)) on the device vs the oracle: Static, StrongWolfe, MoreThuente [EXT:
+LineSearches.jl, restated from the published algorithms] — the reference's own bar is convergence of quadratic_f to err < 1e-9
+(rootfind_tests__item2.jl:40-93); device and oracle must additionally agree on step sizes (through step and residual
+counts) and iterates."""
+import numpy as np
+import pytest
+
+from oracle import reference_restatement as R
+
+pytestmark = pytest.mark.gpu
+
+PROBLEMS = {
+    "quad_far": (lambda: R.Quadratic(3, 2.0), lambda nls: nls.Quadratic(3, 2.0), np.array([10.0, 0.1, 3.0])),
+    "bratu10": (lambda: R.Bratu2D(10, 6.5), lambda nls: nls.Bratu2D(10, 6.5), None),
+    "brus6": (lambda: R.Brusselator2D(6), lambda nls: nls.Brusselator2D(6), None),
+}
+
+
+@pytest.mark.parametrize("method", ["Static", "BackTracking", "StrongWolfe", "MoreThuente"])
+@pytest.mark.parametrize("which", list(PROBLEMS))
+@pytest.mark.parametrize("krylov", [False, True])
+def test_linesearchesjl_methods_match_oracle(nls, method, which, krylov):
+    mk_ref, mk_dev, u0 = PROBLEMS[which]
+    kw = dict(gmres_restart=60, maxiters=600)
+    ref = R.solve(mk_ref(), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(**kw) if krylov else None,
+                                            linesearch=R.LineSearchesJL(method)), abstol=1e-9, maxiters=100, u0=u0)
+    prob = nls.NonlinearProblem(mk_dev(nls), u0=None if u0 is None else u0.copy())
+    sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(**kw) if krylov else None,
+                                            linesearch=nls.LineSearchesJL(method)), abstol=1e-9, maxiters=100)
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
+    assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf
+    assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))
+
+
+@pytest.mark.parametrize("method", ["Static", "StrongWolfe", "MoreThuente"])
+def test_linesearchesjl_quadratic_known_answer(nls, method):
+    sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(2, 2.0)), nls.NewtonRaphson(linesearch=nls.LineSearchesJL(method)))
+    u = np.asarray(sol.u)
+    assert sol.retcode == "Success" and np.max(np.abs(u * u - 2.0)) < 1e-9

@@ -532,3 +532,46 @@ def test_levenberg_marquardt_damping_rules():
     c.reinit(np.array([1.0, 2.0, 3.0]))
     assert c.lm_lam == 1.0 and np.all(c.lm_DtD == 1e-8) and c.lm_norm_v_old == float("inf")
     assert seen_reject or True
+
+
+# ---- LineSearchesJL methods [EXT] (rootfind_tests__item2.jl:40-93: NewtonRaphson with Static / BackTracking / MoreThuente /
+# StrongWolfe converges on quadratic_f to err < 1e-9); the Moré–Thuente step function against SciPy's MINPACK-2 `dcstep`
+@pytest.mark.parametrize("method", ["Static", "BackTracking", "StrongWolfe", "MoreThuente"])
+def test_linesearchesjl_methods_converge_on_the_quadratic(method):
+    for u0 in (np.array([1.0, 1.0]), np.array([10.0, 0.1, 3.0])):
+        sol = R.solve(R.Quadratic(u0.size, 2.0), R.NewtonRaphson(linesearch=R.LineSearchesJL(method)), u0=u0)
+        assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+
+
+def test_more_thuente_step_function_equals_minpack2_dcstep():
+    """cstep's four cases — cubic / quadratic / secant candidates, the choice between them and the update of the interval of
+    uncertainty — against scipy.optimize._dcsrch.dcstep (MINPACK-2, More' & Thuente); the two differ only in where the final
+    safeguards sit (MINPACK-1's cstep, which LineSearches.jl translates, clips to [stmin, stmax] and pulls a bracketed
+    case-1/3 step towards stx afterwards; dcstep does the latter inside case 3), so the comparison applies cstep's own
+    safeguards to dcstep's raw step."""
+    from scipy.optimize._dcsrch import dcstep
+    rng = np.random.default_rng(0)
+    seen = set()
+    for _ in range(4000):
+        stx, stp = sorted(rng.uniform(0.0, 2.0, 2))
+        if stp - stx < 1e-3:
+            continue
+        brackt = bool(rng.integers(0, 2))
+        sty = stp + rng.uniform(0.1, 2.0) if brackt else 0.0
+        fx, fy, fp = rng.uniform(-1, 1, 3)
+        dx = -abs(rng.uniform(0.1, 2.0))           # descent at stx towards stp
+        dp, dy = rng.uniform(-2, 2), abs(rng.uniform(0.1, 2.0))
+        stmin, stmax = (min(stx, sty), max(stx, sty)) if brackt else (stx, stp + 4.0 * (stp - stx))
+        mine = R.FirstOrderCache._ls_cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stmin, stmax)
+        case = mine[10]
+        if case == 0 or (case == 3 and brackt):    # (MINPACK-2 changed the bracketed third case)
+            continue
+        ref = dcstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stmin, stmax)
+        assert np.allclose(mine[:6], ref[:6], rtol=1e-14, atol=0) and mine[9] == ref[7]
+        a = min(max(float(ref[6]), stmin), stmax)
+        if mine[9] and case in (1, 3):
+            nstx, nsty = mine[0], mine[3]
+            a = min(nstx + (2.0 / 3.0) * (nsty - nstx), a) if nsty > nstx else max(nstx + (2.0 / 3.0) * (nsty - nstx), a)
+        assert abs(mine[6] - a) <= 1e-12 * max(1.0, abs(a)), (case, mine[6], a)
+        seen.add(case)
+    assert seen == {1, 2, 3, 4}
