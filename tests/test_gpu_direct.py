@@ -34,6 +34,7 @@ CASES = {
     "bratu256": lambda: _bratu_J(256),               # config C2: b = 256, 256 block rows, 9 levels
     "band_1000_37_20": lambda: _banded(1000, 37, 20, 3),
     "band_5000_200_300": lambda: _banded(5000, 200, 300, 4),   # b = 320: recursion 256 (128 + 128) + 64
+    "band_2100_500_480": lambda: _banded(2100, 500, 480, 5),   # b = 512, the largest block order: 256 (128 + 128) + 256 (128 + 128); 5 block rows
 }
 
 

@@ -824,3 +824,30 @@ def test_plain_c_caller_runs_config_c2(tmp_path):
     lines = [l for l in out.stdout.splitlines() if "retcode=" in l]
     assert len(lines) == 2 and all("retcode=1 " in l for l in lines), out.stdout
     assert "nsteps=3 " in lines[0] and "nfactors=3 " in lines[0]  # C2: 3 Newton steps, 3 factorisations
+
+
+# ------------------------------------------------------------------ degenerate inputs
+def test_gmres_zero_right_hand_side(nls):
+    """b = 0: ‖r₀‖ = 0 ≤ atol + rtol‖r₀‖ — converged at once with x = 0, no Arnoldi step, nothing non-finite (the lagged
+    normalisation must not divide by ‖b‖ = 0)."""
+    p = R.Bratu2D(16)
+    J = p.jac(0.1 * np.random.default_rng(5).standard_normal(p.n))
+    for ortho in ("dcgs2", "cgs2", "mgs"):
+        x, info = nls.GMRES(p.n, restart=20, ortho=ortho).set_operator(nls.CSRMatrix.from_scipy(J)).solve(
+            np.zeros(p.n), abstol=0.0, reltol=1e-8, maxiters=100)
+        xo, io = R.gmres(lambda z: J @ z, np.zeros(p.n), rtol=1e-8, restart=20, itmax=100)
+        assert info["converged"] and not info["failed"] and info["iters"] == io.iters == 0
+        assert np.all(x == 0.0) and np.all(xo == 0.0)
+
+
+@pytest.mark.parametrize("algname", ["NewtonRaphson", "TrustRegion"])
+def test_solver_started_at_the_root(nls, algname):
+    """u0 is already a root: the first step solves J δ = 0, moves nowhere and the termination check reports Success — same
+    step and residual counts as the oracle, u untouched."""
+    root = np.sqrt(2.0) * np.ones(6)
+    kw = dict(linsolve=None)
+    ref = R.solve(R.Quadratic(6, 2.0), getattr(R, algname)(**kw), u0=root.copy(), abstol=1e-9)
+    sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(6, 2.0), u0=root.copy()), getattr(nls, algname)(**kw), abstol=1e-9)
+    assert sol.retcode == R.RETCODE_NAMES[ref.retcode] == "Success"
+    assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf
+    assert np.max(np.abs(np.asarray(sol.u) - root)) <= 1e-12
