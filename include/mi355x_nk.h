@@ -415,7 +415,8 @@ int nk_gmres_solve(nk_gmres *G, const double *b, double *x, int memspace, int us
  * (reuse_A_if_factorization, lib/NonlinearSolveBase/ext/NonlinearSolveBaseLinearSolveExt.jl:81-86). Single rank.
  * Engine (nk_lu_engine): block cyclic reduction — batched dense blocks of order b = bandwidth rounded to 32 (b <= 512) on FP64
  * MFMA, log2(n/b) dependent levels — or, for matrices of fewer than four block rows, a right-looking band LU (lower
- * bandwidth <= ~550). Pivots are taken on the diagonal; *ok = 0 when one vanished or was not finite. */
+ * bandwidth <= ~550). Pivots: on the diagonal first; the cyclic-reduction engine switches to row pivoting inside its dense
+ * blocks when a diagonal pivot vanishes (NK_BCR_PIVOT=auto|always|never); *ok = 0 when the factorisation still broke down. */
 int nk_lu_create(nk_csr *A, nk_lu **out);
 int nk_lu_destroy(nk_lu *F);
 int nk_lu_factor(nk_lu *F, nk_csr *A, int *ok);

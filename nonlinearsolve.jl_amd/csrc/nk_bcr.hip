@@ -13,13 +13,16 @@
 //           up    x_k = D_k⁻¹ (f_k − A_k x_{k−1} − C_k x_{k+1})  for the odd rows of each level
 // Inversion of a block: n ≤ 128 — one workgroup, the matrix in REGISTERS (8 × 8 entries per thread), one LDS broadcast of
 // the pivot row and column and one barrier per pivot; larger blocks — 2 × 2 Schur-complement recursion on halves (two
-// inversions + six GEMMs). Pivots are taken on the diagonal (as in nk_band.hip: the Jacobians of the grid problems are
-// diagonally dominant / M-matrices and so are their Schur complements); a vanishing or non-finite pivot raises the failure
+// inversions + six GEMMs). Partial pivoting INSIDE the blocks inverted by one workgroup (≤ 128; implicit row pivoting, see
+// k_bcr_inv128); no pivoting across the halves of the Schur recursion or across block rows — the Jacobians of the grid problems
+// are diagonally dominant / M-matrices and so are their Schur complements; a vanishing or non-finite pivot raises the failure
 // flag, and the nonlinear driver verifies ‖J x − b‖ after every direct solve (one step of iterative refinement, then GMRES on
 // the same J) — nk_solver.hip, newton_descent.
 // Algorithmic work at C2 (n = 65 536, b = 256, m = 256): ≈ 58 GFLOP of b³ products + 255 block inversions per factorisation
 // (band LU: 8.6 GFLOP); a solve streams every stored block once (≈ 1 GB). Memory: ≈ 8 m b² doubles (1.1 GB at C2).
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -130,8 +133,25 @@ __device__ __forceinline__ double bcr_rcp(double p) {  // v_rcp_f64 + two Newton
   x = x * (2.0 - p * x);
   return x;
 }
+// PIVOT: partial (row) pivoting inside the block, implicit — the pivot of column k is the largest entry among the rows not
+// yet used; no row is moved (a row exchange would need run-time register indices): the pivot row is published from wherever
+// it lives (a predicated select over the eight local rows of its owners), the elimination skips it by position, and the
+// bookkeeping is undone when the result is stored: with p_k the pivot row of column k and σ its inverse, entry (i, j) of the
+// register image is entry (σ(i), p_j) of the inverse. Two barriers per pivot instead of one.
+__device__ __forceinline__ unsigned bcr_wave_max_u32(unsigned v) {  // max over the 64 lanes, uniform result
+  unsigned t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;  // row_shr:1
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;  // row_shr:2
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;  // row_shr:4
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;  // row_shr:8 — lane 15 of a row: the row's max
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;  // row_bcast:15 into rows 1, 3
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;  // row_bcast:31 into rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <bool PIVOT>
 __global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, int64_t stride, int ld, int n, int *fail) {
   __shared__ double colb[2][128], rowb[2][128];
+  __shared__ int prow[128], sigma[128], usedf[128];
   double *__restrict__ M = mats + (int64_t)blockIdx.x * stride;
   const int t = threadIdx.x, ti = t & 15, tj = t >> 4;  // rows 8 ti …, columns 4 tj … (tj = 0 … 31)
   double a[8][4];
@@ -142,6 +162,10 @@ __global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, i
       const int i = ti * 8 + r, j = tj * 4 + c;
       a[r][c] = (i < n && j < n) ? M[(int64_t)i + (int64_t)j * ld] : (i == j ? 1.0 : 0.0);
     }
+  if (PIVOT) {
+    if (t < 128) { usedf[t] = (t >= n) ? 1 : 0; prow[t] = t; sigma[t] = t; }
+    __syncthreads();
+  }
   bool bad = false;
 #pragma unroll 1
   for (int kb = 0; kb < 16; ++kb) {
@@ -154,12 +178,38 @@ __global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, i
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) colb[buf][ti * 8 + rr] = a[rr][cl];
       }
-      if (ti == kb) {
+      int p = k;
+      if (PIVOT) {
+        __syncthreads();
+        // Every wavefront finds the pivot row for itself (same data, same order: same answer). The magnitudes are compared as
+        // float bit patterns (+2; a NaN ranks 1, a used row 0: the choice always falls on an unused row, so the pivot rows form
+        // a permutation whatever the data — the permuted store below relies on that) through a DPP max reduction — six
+        // v_max_u32_dpp; a shuffle butterfly on (double, index) pairs cost 18 LDS round trips per pivot, 3× the whole step.
+        const int l = t & 63;
+        const float f0 = fabsf((float)colb[buf][l]), f1 = fabsf((float)colb[buf][l + 64]);
+        unsigned k0 = (f0 == f0) ? __float_as_uint(f0) + 2u : 1u, k1 = (f1 == f1) ? __float_as_uint(f1) + 2u : 1u;
+        if (usedf[l]) k0 = 0u;
+        if (usedf[l + 64]) k1 = 0u;
+        const unsigned km = bcr_wave_max_u32(k0 > k1 ? k0 : k1);
+        const unsigned long long b0 = __ballot(k0 == km), b1 = __ballot(k1 == km);
+        p = b0 ? (int)__ffsll((long long)b0) - 1 : 64 + (int)__ffsll((long long)b1) - 1;
+        if (t == 0) { prow[k] = p; usedf[p] = 1; }
+        if (ti == (p >> 3)) {
+          const int rp = p & 7;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            double v = a[0][cc];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v = (rp == q) ? a[q][cc] : v;
+            rowb[buf][tj * 4 + cc] = v;
+          }
+        }
+      } else if (ti == kb) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) rowb[buf][tj * 4 + cc] = a[r][cc];
       }
       __syncthreads();
-      const double piv = colb[buf][k];
+      const double piv = colb[buf][p];
       bad = bad || !(fabs(piv) > 1e-290);  // zero, denormal-small or NaN
       const double pinv = bcr_rcp(piv);
       double mr[8], rk[4];
@@ -171,24 +221,51 @@ __global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, i
       for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) a[rr][cc] -= mr[rr] * rk[cc];
-      if (ti == kb) {
+      if (PIVOT) {
+        const int rp = p & 7;
+        const bool prow_owner = (ti == (p >> 3));
+        if (prow_owner) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) a[r][cc] = rk[cc];
-      }
-      if (tj == cj) {
+          for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) a[rr][cl] = -mr[rr] * pinv;
+            for (int cc = 0; cc < 4; ++cc) a[q][cc] = (rp == q) ? rk[cc] : a[q][cc];
+        }
+        if (tj == cj) {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) a[rr][cl] = -mr[rr] * pinv;
+          if (prow_owner) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q][cl] = (rp == q) ? pinv : a[q][cl];
+          }
+        }
+      } else {
+        if (ti == kb) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a[r][cc] = rk[cc];
+        }
+        if (tj == cj) {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) a[rr][cl] = -mr[rr] * pinv;
+        }
+        if (ti == kb && tj == cj) a[r][cl] = pinv;
       }
-      if (ti == kb && tj == cj) a[r][cl] = pinv;
     }
   }
   if (bad && t == 0) *fail = 1;
+  if (PIVOT) {
+    __syncthreads();
+    if (t < n) sigma[prow[t]] = t;
+    __syncthreads();
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int i = ti * 8 + r, j = tj * 4 + c;
-      if (i < n && j < n) M[(int64_t)i + (int64_t)j * ld] = a[r][c];
+      if (i < n && j < n) {
+        if (PIVOT) M[(int64_t)sigma[i] + (int64_t)prow[j] * ld] = a[r][c];
+        else M[(int64_t)i + (int64_t)j * ld] = a[r][c];
+      }
     }
 }
 
@@ -322,6 +399,10 @@ struct nk_bcr {
   double *ws = nullptr;   // workspace of the recursive block inversion: 2 depths × {T, W} × batch × (b/2)²… sized 4·batch·b²/… below
   int64_t ws_slot = 0;    // doubles per (depth, T|W) slot
   int *d_fail = nullptr;
+  // Pivoting policy (NK_BCR_PIVOT = auto | always | never; default auto): the diagonal-pivot inversion is 2.5× faster per
+  // block (87 vs 215 µs: 5.0 vs 7.4 ms per C2 factorisation), so a factorisation starts on it; a vanishing / non-finite pivot —
+  // or the nonlinear driver's residual check failing (nk_bcr_set_pivoting) — switches THIS object to row pivoting for good.
+  bool pivot = false, pivot_locked = false;
 };
 
 static int bcr_gemm(nk_bcr *S, int batch, int M, int N, int K, double alpha, const double *A, int64_t sA, int lda,
@@ -354,7 +435,8 @@ static int bcr_gemm(nk_bcr *S, int batch, int M, int N, int K, double alpha, con
 static int bcr_invert(nk_bcr *S, double *M, int64_t stride, int ld, int n, int batch, int depth) {
   if (batch <= 0) return NK_OK;
   if (n <= 128) {
-    NK_LAUNCH(S->ctx, k_bcr_inv128, dim3(batch), dim3(512), M, stride, ld, n, S->d_fail);
+    if (!S->pivot) NK_LAUNCH(S->ctx, k_bcr_inv128<false>, dim3(batch), dim3(512), M, stride, ld, n, S->d_fail);
+    else NK_LAUNCH(S->ctx, k_bcr_inv128<true>, dim3(batch), dim3(512), M, stride, ld, n, S->d_fail);
     NK_HIP(hipGetLastError());
     return NK_OK;
   }
@@ -429,11 +511,32 @@ int nk_bcr_create(nk_ctx *ctx, int64_t n, int b, nk_bcr **out) {
     NK_TRY(nk_dev_alloc(&S->ws, (size_t)(4 * S->ws_slot)));
   }
   NK_TRY(nk_dev_alloc(&S->d_fail, (size_t)1));
+  {
+    const char *pv = getenv("NK_BCR_PIVOT");
+    if (pv && !strcmp(pv, "always")) S->pivot = true;
+    if (pv && !strcmp(pv, "never")) S->pivot_locked = true;
+  }
   *out = guard.release();
   return NK_OK;
 }
 
+static int bcr_factor_once(nk_bcr *S, nk_csr *Acsr, int *ok);
 int nk_bcr_factor(nk_bcr *S, nk_csr *Acsr, int *ok) {
+  NK_TRY(bcr_factor_once(S, Acsr, ok));
+  if (!*ok && !S->pivot && !S->pivot_locked) {  // a diagonal pivot broke down: this matrix family needs row pivoting
+    S->pivot = true;
+    NK_TRY(bcr_factor_once(S, Acsr, ok));
+  }
+  return NK_OK;
+}
+// 1: switch to row pivoting inside the blocks (returns through *changed whether that is news); the caller refactorises
+int nk_bcr_set_pivoting(nk_bcr *S, int on, int *changed) {
+  const bool want = on != 0 && !S->pivot_locked;
+  if (changed) *changed = (want && !S->pivot) ? 1 : 0;
+  if (want) S->pivot = true;
+  return NK_OK;
+}
+static int bcr_factor_once(nk_bcr *S, nk_csr *Acsr, int *ok) {
   nk_ctx *ctx = S->ctx;
   const int b = S->b;
   const int64_t bb = (int64_t)b * b;

@@ -442,6 +442,7 @@ int nk_bcr_factor(nk_bcr *S, nk_csr *A, int *ok);
 int nk_bcr_solve(nk_bcr *S, const double *d_b, double *d_x);
 void nk_bcr_destroy(nk_bcr *S);
 int64_t nk_bcr_bytes(int64_t n, int b);
+int nk_bcr_set_pivoting(nk_bcr *S, int on, int *changed);
 void nk_bandlu_destroy(nk_bandlu *B);
 int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok);
 int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x);

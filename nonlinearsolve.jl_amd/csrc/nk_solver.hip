@@ -649,6 +649,25 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
         NK_TRY(nk_blas_axpby(S->ctx, S->n, 1.0, S->stage2, 1.0, du_out));
       }
       lu_ok = (v[0] == v[0]) && (sqrt(v[0]) <= 1e-8 * sqrt(v[1]) + 1e-300);
+      if (!lu_ok && S->B->bcr) {  // the diagonal-pivot factorisation was not accurate enough: once more with row pivoting
+        int changed = 0;
+        NK_TRY(nk_bcr_set_pivoting(S->B->bcr, 1, &changed));
+        if (changed) {
+          int fok = 0;
+          NK_TRY(nk_bandlu_factor(S->B, S->J, &fok));
+          S->stats.nfactors++;
+          S->lu_valid = fok != 0;
+          if (fok) {
+            NK_TRY(nk_bandlu_solve(S->B, S->fu, du_out));
+            NK_TRY(nk_csr_spmv_dev(S->J, du_out, S->stage, nullptr));
+            NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->fu, -1.0, S->stage, S->stage));
+            const double *xs[2] = {S->stage, S->fu}, *ys[2] = {S->stage, S->fu};
+            NK_TRY(nk_blas_multi_reduce(S->ctx, S->n, 2, xs, ys, nullptr, nullptr, 0, 0, slot(S, 0)));
+            NK_TRY(fetch(S, 2, v));
+            lu_ok = (v[0] == v[0]) && (sqrt(v[0]) <= 1e-8 * sqrt(v[1]) + 1e-300);
+          }
+        }
+      }
     }
     if (!lu_ok) {
       // The reference's default linear solver falls back (LU → QR) when the factorisation is singular or inaccurate; here

@@ -65,15 +65,41 @@ def test_block_cyclic_reduction_matches_superlu(nls, name):
     F.close()
 
 
+@pytest.mark.parametrize("n,kl,ku", [(1000, 37, 20), (4096, 100, 90)])
+def test_block_cyclic_reduction_pivots_inside_the_blocks(nls, n, kl, ku):
+    """Rows 2i ↔ 2i+1 of a diagonally dominant band matrix exchanged: the diagonal now carries the weak off-diagonal entries,
+    the dominant ones sit next to it — inside the diagonal blocks (the block order is even). The block inversions pivot by
+    rows (implicitly: no row moves, the permutation is undone on the way out), so the factorisation stays accurate. (Policy:
+    a factorisation starts on the faster diagonal-pivot inversion and switches the object to row pivoting when a pivot breaks
+    down — which this matrix does at once; NK_BCR_PIVOT=never shows the failure, =always skips the first attempt.)"""
+    M = _banded(n, kl, ku, 11).tolil()
+    for i in range(0, n, 2):
+        M[i + 1, i] = 0.0        # … so that the exchanged matrix has an exactly ZERO diagonal entry in every even row
+    perm = np.arange(n).reshape(-1, 2)[:, ::-1].ravel()
+    J = sp.csr_matrix(sp.csr_matrix(M)[perm, :])
+    A = nls.CSRMatrix.from_scipy(J)
+    F = nls.BandedLU(A)
+    assert F.info()["engine"] == "block_cyclic_reduction"
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(n)
+    x = F.solve(b)
+    xr = spla.spsolve(sp.csc_matrix(J), b)
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    assert np.linalg.norm(J @ x - b) <= 1e-9 * np.linalg.norm(b)
+    F.close()
+
+
 def test_block_cyclic_reduction_reports_a_singular_block(nls):
-    """A zero diagonal block pivot raises the failure flag (then the Newton driver's fallback takes over)."""
+    """A structurally singular matrix (one column without entries) raises the failure flag (then the Newton driver's fallback
+    takes over)."""
     J = _bratu_J(32).tolil()
-    J[5, :] = 0.0
-    J[5, 6] = 1.0          # row 5 has a zero diagonal: the diagonal pivot vanishes at the first level
-    J = sp.csr_matrix(J + sp.csr_matrix(_bratu_J(32).shape))
-    pattern = sp.csr_matrix(_bratu_J(32))
-    vals = sp.csr_matrix(pattern.multiply(0.0) + J)  # same pattern is not required for this check
-    A = nls.CSRMatrix.from_scipy(sp.csr_matrix(J))
+    J[:, 5] = 0.0
+    J[5, 5] = 0.0
+    A = nls.CSRMatrix.from_scipy(sp.csr_matrix(_bratu_J(32)))      # pattern with the diagonal present
+    vals = sp.csr_matrix(_bratu_J(32)).copy()
+    Jc = sp.csr_matrix(J)
+    dense_vals = np.array([Jc[r, c] for r, c in zip(*vals.nonzero())])
+    A.set_values(dense_vals)
     with pytest.raises(nls.NKError):
         nls.BandedLU(A)
 
