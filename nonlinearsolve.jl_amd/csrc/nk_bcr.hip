@@ -193,7 +193,6 @@ __global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, i
         const unsigned km = bcr_wave_max_u32(k0 > k1 ? k0 : k1);
         const unsigned long long b0 = __ballot(k0 == km), b1 = __ballot(k1 == km);
         p = b0 ? (int)__ffsll((long long)b0) - 1 : 64 + (int)__ffsll((long long)b1) - 1;
-        if (t == 0) { prow[k] = p; usedf[p] = 1; }
         if (ti == (p >> 3)) {
           const int rp = p & 7;
 #pragma unroll
@@ -209,6 +208,8 @@ __global__ __launch_bounds__(512) void k_bcr_inv128(double *__restrict__ mats, i
         for (int cc = 0; cc < 4; ++cc) rowb[buf][tj * 4 + cc] = a[r][cc];
       }
       __syncthreads();
+      // (the bookkeeping is written only now: before the barrier other wavefronts may still be reading usedf for THIS pivot)
+      if (PIVOT && t == 0) { prow[k] = p; usedf[p] = 1; }
       const double piv = colb[buf][p];
       bad = bad || !(fabs(piv) > 1e-290);  // zero, denormal-small or NaN
       const double pinv = bcr_rcp(piv);
