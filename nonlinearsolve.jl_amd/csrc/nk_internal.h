@@ -300,6 +300,8 @@ struct nk_problem {
   double *d_tmp[3] = {nullptr, nullptr, nullptr};
 };
 int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, double scale, nk_problem **out);
+int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out);
+int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi);
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
 // forget what the problem was linearised at: the caller wrote new contents into a buffer it may have been keyed on
 static inline void nk_problem_invalidate(nk_problem *P) { P->d_u_lin = nullptr; P->d_u_linJ = nullptr; }

@@ -17,7 +17,7 @@
 // the coarsest level is gathered to every rank (one all-reduce of a zero-padded vector) and solved redundantly.
 // Restated on the CPU by oracle/reference_restatement.py::BratuMultigrid (the arithmetic does not depend on the partition).
 //
-// BRUSSELATOR2D (config C5; single rank): the same V-cycle for the two coupled species on the periodic N × N grid.
+// BRUSSELATOR2D (config C5): the same V-cycle for the two coupled species on the periodic N × N grid.
 //   levels     N_l = N/2^l while even and > coarse_max (default 8); level operator by rediscretisation with spacing 2^l·dx at
 //              the full-weighting restriction of the linearisation point — each level is a Brusselator problem object, so
 //              the matrix-free JVP kernel serves every level
@@ -189,36 +189,62 @@ __global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_first(int64_t n, const dou
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + NK_BLOCK - 1) / NK_BLOCK)); }
 
 // ---- Brusselator: nested periodic grids, two species stored one after the other (idx = i + N·j + N²·s)
-// r_c = ¼ Pᵀ r_f (full weighting): 1/16 · [1 2 1; 2 4 2; 1 2 1] around the fine point (2I, 2J), periodic
-__global__ __launch_bounds__(NK_BLOCK) void k_mgb_restrict(int nf, const double *__restrict__ rf, double *__restrict__ rc,
+// r_c = ¼ Pᵀ r_f (full weighting): 1/16 · [1 2 1; 2 4 2; 1 2 1] around the fine point (2I, 2J), periodic.
+// Slabs of whole lines (several ranks; every rank's first line is even on every level but the coarsest): coarse local line Jl
+// sits on fine local line 2 Jl; the line below fine line 0 is the lower ghost line `lo` ([species 0 | species 1], nullptr =
+// wrap inside the slab), the line above 2 Jl + 1 is always owned.
+__global__ __launch_bounds__(NK_BLOCK) void k_mgb_restrict(int nf, int nlf, const double *__restrict__ rf,
+                                                           const double *__restrict__ lo, double *__restrict__ rc,
                                                            const int *d_skip) {
   MG_SKIP(d_skip);
-  const int nc = nf >> 1;
+  const int nc = nf >> 1, nlc = nlf >> 1;
   const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
-  if (k >= 2 * nc * nc) return;
-  const int sp = k / (nc * nc), kk = k - sp * nc * nc, J = kk / nc, I = kk - J * nc;
-  const double *f = rf + (size_t)sp * nf * nf;
+  if (k >= 2 * nc * nlc) return;
+  const int sp = k / (nc * nlc), kk = k - sp * nc * nlc, J = kk / nc, I = kk - J * nc;
+  const double *f = rf + (size_t)sp * nf * nlf;
   const int i = 2 * I, j = 2 * J;
-  const int im = (i == 0) ? nf - 1 : i - 1, ip = i + 1, jm = (j == 0) ? nf - 1 : j - 1, jp = j + 1;  // i, j even ⇒ i+1 < nf
+  const int im = (i == 0) ? nf - 1 : i - 1, ip = i + 1, jp = j + 1;  // i, j even ⇒ i + 1 < nf, j + 1 < nlf
+  const double *below = (j > 0) ? f + (size_t)(j - 1) * nf : (lo ? lo + (size_t)sp * nf : f + (size_t)(nlf - 1) * nf);
   const double c = f[j * nf + i];
-  const double e = (f[j * nf + im] + f[j * nf + ip]) + (f[jm * nf + i] + f[jp * nf + i]);
-  const double d = (f[jm * nf + im] + f[jm * nf + ip]) + (f[jp * nf + im] + f[jp * nf + ip]);
+  const double e = (f[j * nf + im] + f[j * nf + ip]) + (below[i] + f[jp * nf + i]);
+  const double d = (below[im] + below[ip]) + (f[jp * nf + im] + f[jp * nf + ip]);
   rc[k] = (4.0 * c + 2.0 * e + d) * (1.0 / 16.0);
 }
-// x_f += P e_c (bilinear on the nested periodic grid)
-__global__ __launch_bounds__(NK_BLOCK) void k_mgb_prolong_add(int nf, const double *__restrict__ ec, double *__restrict__ xf,
+// x_f += P e_c (bilinear on the nested periodic grid); the coarse line above the slab is the upper ghost line `hi`
+__global__ __launch_bounds__(NK_BLOCK) void k_mgb_prolong_add(int nf, int nlf, const double *__restrict__ ec,
+                                                              const double *__restrict__ hi, double *__restrict__ xf,
                                                               const int *d_skip) {
   MG_SKIP(d_skip);
-  const int nc = nf >> 1;
+  const int nc = nf >> 1, nlc = nlf >> 1;
   const int k = blockIdx.x * NK_BLOCK + threadIdx.x;
-  if (k >= 2 * nf * nf) return;
-  const int sp = k / (nf * nf), kk = k - sp * nf * nf, j = kk / nf, i = kk - j * nf;
-  const double *c = ec + (size_t)sp * nc * nc;
+  if (k >= 2 * nf * nlf) return;
+  const int sp = k / (nf * nlf), kk = k - sp * nf * nlf, j = kk / nf, i = kk - j * nf;
+  const double *c = ec + (size_t)sp * nc * nlc;
   const int I0 = i >> 1, J0 = j >> 1;
-  const int I1 = (i & 1) ? ((I0 + 1 == nc) ? 0 : I0 + 1) : I0, J1 = (j & 1) ? ((J0 + 1 == nc) ? 0 : J0 + 1) : J0;
+  const int I1 = (i & 1) ? ((I0 + 1 == nc) ? 0 : I0 + 1) : I0;
   // (an even index reads the same coarse point twice with weight ½ + ½ — the loads stay unconditional)
-  const double v = 0.25 * ((c[J0 * nc + I0] + c[J0 * nc + I1]) + (c[J1 * nc + I0] + c[J1 * nc + I1]));
-  xf[k] += v;
+  const double *l0 = c + (size_t)J0 * nc;
+  const double *l1 = (j & 1) ? ((J0 + 1 < nlc) ? c + (size_t)(J0 + 1) * nc : (hi ? hi + (size_t)sp * nc : c)) : l0;
+  xf[k] += 0.25 * ((l0[I0] + l0[I1]) + (l1[I0] + l1[I1]));
+}
+// coarsest level on several ranks: this rank's lines of both species into the full (i, j, species) vector, zero elsewhere
+__global__ __launch_bounds__(NK_BLOCK) void k_mgb_scatter_lines(int N, int j0, int nl, const double *__restrict__ loc,
+                                                                double *__restrict__ full) {
+  const int64_t e = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (e >= 2ll * N * N) return;
+  const int sp = (int)(e / ((int64_t)N * N));
+  const int64_t kk = e - (int64_t)sp * N * N;
+  const int j = (int)(kk / N), i = (int)(kk - (int64_t)j * N);
+  full[e] = (j >= j0 && j < j0 + nl) ? loc[(size_t)i + (size_t)N * (j - j0) + (size_t)N * nl * sp] : 0.0;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_mgb_take_lines(int N, int j0, int nl, const double *__restrict__ full,
+                                                             double *__restrict__ loc) {
+  const int64_t e = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (e >= 2ll * N * nl) return;
+  const int sp = (int)(e / ((int64_t)N * nl));
+  const int64_t kk = e - (int64_t)sp * N * nl;
+  const int jl = (int)(kk / N), i = (int)(kk - (int64_t)jl * N);
+  loc[e] = full[(size_t)i + (size_t)N * (j0 + jl) + (size_t)N * N * sp];
 }
 // one Chebyshev step after the first, unfused: r −= J d (t holds J d); d = c1 d + c2 r; x += d
 __global__ __launch_bounds__(NK_BLOCK) void k_mg_cheb_step(int64_t n, double c1, double c2, const double *__restrict__ t,
@@ -311,10 +337,13 @@ static void ghost_needs(int64_t lo, int64_t hi, int64_t j0, int64_t j1, int64_t 
   }
 }
 
-// Brusselator hierarchy (single rank): see the file header
+// Brusselator hierarchy: see the file header. Several ranks: every level is split by lines like the fine problem; a level
+// is coarsened only while every rank keeps an even number of lines (then slab boundaries stay even on both levels and the
+// transfers need exactly the problem's own one-line halo: the line below the slab for the restriction, the coarse line above
+// it for the prolongation); the coarsest level is gathered to every rank and solved redundantly.
 static int mgb_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   nk_ctx *ctx = P->ctx;
-  NK_REQUIRE(ctx->nranks == 1, "the Brusselator multigrid preconditioner runs on one rank (use the Chebyshev precs on several)");
+  const int R = ctx->nranks;
   NK_REQUIRE(P->ns < 23000, "grid too large for 32-bit point indices");
   if (nu <= 0) nu = 2;
   if (coarse_max < 4) coarse_max = 8;
@@ -331,24 +360,38 @@ static int mgb_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
   for (int l = 0;; ++l) {
     nk_mg_level L;
     L.ns = N;
-    L.n = 2 * N * N;
-    L.j0 = 0;
-    L.j1 = N;
     if (l == 0) L.P = P;
     else {
       const double par[5] = {(double)N, P->params[1], P->params[2], P->params[3], dx};
       if (nk_problem_create(ctx, NK_PROBLEM_BRUSSELATOR2D, par, 5, &L.P) != NK_OK) return NK_E_HIP;
-      NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
     }
+    L.j0 = L.P->j0;
+    L.j1 = L.P->j1;
+    L.n = 2 * N * (L.j1 - L.j0);
+    if (l > 0) NK_TRY(nk_dev_alloc(&L.u, (size_t)L.n + 1));
     for (double **b : {&L.b, &L.x, &L.r, &L.d, &L.t}) NK_TRY(nk_dev_alloc(b, (size_t)L.n + 1));
-    const bool coarsest = N <= coarse_max || (N % 2) != 0 || N / 2 < 4;
+    // coarsen while the grid halves evenly — on several ranks: while every rank's slab does (N divisible by 2 R, and the
+    // coarse level still has two lines per rank)
+    bool coarsest = N <= coarse_max || (N % 2) != 0 || N / 2 < 4;
+    if (R > 1 && !coarsest) coarsest = (N % (2 * R)) != 0 || N / 2 < 2 * R || (L.j0 % 2) != 0 || ((L.j1 - L.j0) % 2) != 0;
     M->lv.push_back(L);
     if (coarsest) break;
     N /= 2;
     dx *= 2.0;
   }
   if (M->lv.size() > 1) {
-    NK_TRY(nk_problem_jac_csr(M->lv.back().P, &M->Jc));
+    nk_mg_level &C = M->lv.back();
+    if (R > 1) {
+      const double par[5] = {(double)C.ns, P->params[1], P->params[2], P->params[3], dx};
+      NK_TRY(nk_problem_create_brus_replicated(ctx, par, &M->Prep));
+      const size_t nfull = (size_t)(2 * C.ns * C.ns) + 1;
+      NK_TRY(nk_dev_alloc(&M->rep_u, nfull));
+      NK_TRY(nk_dev_alloc(&M->rep_b, nfull));
+      NK_TRY(nk_dev_alloc(&M->rep_x, nfull));
+      NK_TRY(nk_problem_jac_csr(M->Prep, &M->Jc));
+    } else {
+      NK_TRY(nk_problem_jac_csr(C.P, &M->Jc));
+    }
     NK_TRY(nk_bandlu_create(M->Jc, &M->LU, 1));  // coarsest level: a handful of block columns — the band LU
   }
   *out = guard.release();
@@ -465,8 +508,11 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
 static int mg_gather_coarse(nk_mg *M, const double *loc, double *full) {
   nk_ctx *ctx = M->ctx;
   nk_mg_level &C = M->lv.back();
-  const int64_t nfull = C.ns * C.ns;
-  NK_LAUNCH(ctx, k_mg_scatter_lines, g1(nfull), dim3(NK_BLOCK), nfull, C.j0 * C.ns, C.n, loc, full);
+  const int64_t nfull = (M->kind == 1 ? 2 : 1) * C.ns * C.ns;
+  if (M->kind == 1)
+    NK_LAUNCH(ctx, k_mgb_scatter_lines, g1(nfull), dim3(NK_BLOCK), (int)C.ns, (int)C.j0, (int)(C.j1 - C.j0), loc, full);
+  else
+    NK_LAUNCH(ctx, k_mg_scatter_lines, g1(nfull), dim3(NK_BLOCK), nfull, C.j0 * C.ns, C.n, loc, full);
   NK_HIP(hipGetLastError());
   for (int64_t o = 0; o < nfull; o += 1 << 20) {  // (int-sized messages)
     const int c = (int)std::min<int64_t>(1 << 20, nfull - o);
@@ -478,7 +524,9 @@ static int mg_gather_coarse(nk_mg *M, const double *loc, double *full) {
 static int mg_restrict(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *src, double *dst, const int *d_skip) {
   nk_ctx *ctx = M->ctx;
   if (M->kind == 1) {
-    NK_LAUNCH(ctx, k_mgb_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, src, dst, d_skip);
+    const double *lo = nullptr, *hi = nullptr;
+    if (ctx->nranks > 1) NK_TRY(nk_problem_ghost_lines(F.P, src, &lo, &hi));
+    NK_LAUNCH(ctx, k_mgb_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)(F.j1 - F.j0), src, lo, dst, d_skip);
   } else if (ctx->nranks == 1) {
     NK_LAUNCH(ctx, k_mg_restrict, g1(C.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.rlo, (const double *)F.rw, src,
               dst, d_skip);
@@ -494,7 +542,9 @@ static int mg_restrict(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *s
 static int mg_prolong_add(nk_mg *M, nk_mg_level &F, nk_mg_level &C, const double *ec, double *xf, const int *d_skip) {
   nk_ctx *ctx = M->ctx;
   if (M->kind == 1) {
-    NK_LAUNCH(ctx, k_mgb_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, ec, xf, d_skip);
+    const double *lo = nullptr, *hi = nullptr;
+    if (ctx->nranks > 1) NK_TRY(nk_problem_ghost_lines(C.P, ec, &lo, &hi));
+    NK_LAUNCH(ctx, k_mgb_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)(F.j1 - F.j0), ec, hi, xf, d_skip);
   } else if (ctx->nranks == 1) {
     NK_LAUNCH(ctx, k_mg_prolong_add, g1(F.n), dim3(NK_BLOCK), (int)F.ns, (int)C.ns, (const int32_t *)F.pI0, (const double *)F.pw1, ec,
               xf, d_skip);
@@ -513,8 +563,8 @@ int nk_mg_update(nk_mg *M, const double *d_u) {
   M->lv[0].u = const_cast<double *>(d_u);
   if (M->kind == 1) {  // λmax of every level: 8α/dx_l² + the reaction rows' Gershgorin bound at the fine linearisation point
     nk_ctx *ctx = M->ctx;
-    const int64_t nn = M->lv[0].ns * M->lv[0].ns;
-    NK_TRY(nk_blas_minmax(ctx, nn, d_u, ctx->d_scal));        // (max, −min) of u
+    const int64_t nn = M->lv[0].n / 2;                        // this rank's entries of one species
+    NK_TRY(nk_blas_minmax(ctx, nn, d_u, ctx->d_scal));        // (max, −min) of u (all-reduced)
     NK_TRY(nk_blas_minmax(ctx, nn, d_u + nn, ctx->d_scal + 2));  // … of v
     double v[4];
     NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 4, v));
@@ -674,7 +724,11 @@ static int mg_vcycle_body(nk_mg *M, const int *d_skip) {
     if (M->Prep) {
       NK_TRY(mg_gather_coarse(M, C.b, M->rep_b));
       NK_TRY(nk_bandlu_solve(M->LU, M->rep_b, M->rep_x));
-      NK_TRY(nk_blas_copy(ctx, C.n, M->rep_x + C.j0 * C.ns, C.x));
+      if (M->kind == 1)
+        NK_LAUNCH(ctx, k_mgb_take_lines, g1(C.n), dim3(NK_BLOCK), (int)C.ns, (int)C.j0, (int)(C.j1 - C.j0),
+                  (const double *)M->rep_x, C.x);
+      else
+        NK_TRY(nk_blas_copy(ctx, C.n, M->rep_x + C.j0 * C.ns, C.x));
     } else {
       NK_TRY(nk_bandlu_solve(M->LU, C.b, C.x));
     }

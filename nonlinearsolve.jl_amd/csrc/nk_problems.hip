@@ -401,6 +401,33 @@ int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, d
   return NK_OK;
 }
 
+// the same for the Brusselator (multigrid, coarsest level on several ranks)
+int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out) {
+  nk_problem *P = new nk_problem();
+  P->ctx = ctx;
+  P->kind = NK_PROBLEM_BRUSSELATOR2D;
+  P->replicated = true;
+  P->nparams = 5;
+  for (int i = 0; i < 5; ++i) P->params[i] = params5[i];
+  const int64_t N = (int64_t)params5[0];
+  P->ns = N;
+  P->j0 = 0;
+  P->j1 = N;
+  P->n_local = P->n_global = 2 * N * N;
+  P->row_begin = 0;
+  *out = P;
+  return NK_OK;
+}
+// ghost lines of a vector laid out like the problem's unknowns (grid problems on several ranks): exchanges the halo and
+// returns the lines below / above the owned slab ([species 0 line | species 1 line] for the Brusselator); nullptr where the
+// slab wraps onto itself (one rank, replicated problems)
+int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi) {
+  NK_TRY(nk_halo_exchange(P->ctx, &P->halo, d_v));
+  if (P->kind == NK_PROBLEM_BRUSSELATOR2D) halo_lines(P, 2, true, lo, hi);
+  else halo_lines(P, 1, false, lo, hi);
+  return NK_OK;
+}
+
 extern "C" int nk_problem_create_user(nk_ctx *ctx, int64_t n_local, int64_t n_global, int64_t row_begin,
                                       const nk_user_callbacks *cb, void *user, nk_csr *jac_pattern,
                                       nk_problem **out) {
@@ -667,7 +694,6 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
   NK_REQUIRE(P && out, "NULL argument");
   nk_ctx *ctx = P->ctx;
   NK_HIP(hipSetDevice(ctx->device));
-  const int R = ctx->nranks;
   std::vector<int32_t> rp;
   std::vector<int64_t> gc;
   if (P->kind == NK_PROBLEM_QUADRATIC) {
@@ -696,6 +722,7 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
   }
   if (P->kind == NK_PROBLEM_BRUSSELATOR2D) {
     const int64_t N = P->ns, nl = P->j1 - P->j0, nn = N * nl;
+    const int R = P->replicated ? 1 : ctx->nranks;  // (a replicated problem numbers its unknowns like a single rank)
     std::vector<uint8_t> role;
     std::vector<int32_t> node;
     rp.reserve(P->n_local + 1);
@@ -719,7 +746,7 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
           }
         }
     rp.push_back((int32_t)gc.size());
-    NK_TRY(nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out));
+    NK_TRY(nk_csr_create_local(ctx, P->n_local, P->n_global, P->row_begin, rp, gc, nullptr, out, P->replicated));
     nk_csr *Jc = *out;
     NK_TRY(nk_dev_alloc(&Jc->d_role, role.size()));
     NK_TRY(nk_dev_alloc(&Jc->d_node, node.size()));

@@ -192,6 +192,39 @@ def _worker(rank, world, port, q, transport="torch"):
         assert np.max(np.abs(sollm.u.cpu().numpy() - reflm.u[bl:el])) <= 1e-7
         note("bratu_lm", sollm.u.cpu().numpy())
 
+        # ---------------- the Brusselator V-cycle on two ranks: every level split by lines (slab boundaries stay even, the
+        # transfers use the problem's own one-line periodic halo), coarsest level gathered and solved redundantly — one
+        # V-cycle equals the serial oracle's, GMRES and the TrustRegion solve take the oracle's counts
+        Nm = 32
+        rbm, PBm = R.Brusselator2D(Nm), nls.Brusselator2D(Nm)
+        jm0, jm1 = nls.partition_range(Nm, 1, world, rank)
+        idm = np.array([i + Nm * (jm0 + jl) + Nm * Nm * s_ for s_ in range(2) for jl in range(jm1 - jm0) for i in range(Nm)])
+        ubm = rbm.u0() + 0.05 * np.random.default_rng(1).standard_normal(rbm.n)
+        rhsb = np.random.default_rng(2).standard_normal(rbm.n)
+        Mob = R.BrusselatorMultigrid(rbm, ubm, 2, 8)
+        Jbm = rbm.jac(ubm)
+        ubml = torch.tensor(ubm[idm], device=dev)
+        opb = nls.StatefulJacobianOperator(nls.JacobianOperator(nls.NonlinearProblem(PBm)), ubml)
+        Gb = nls.GMRES(idm.size, restart=30).set_operator(opb)
+        Gb.set_multigrid_preconditioner(PBm, ubml, nu=2, coarse_max=8)
+        xb1, _ = Gb.solve(torch.tensor(rhsb[idm], device=dev), fixed_iters=1)
+        xob1, _ = R.gmres(lambda z: Jbm @ z, rhsb, restart=30, fixed_iters=1, M=Mob, ortho="cgs2")
+        assert np.linalg.norm(xb1.cpu().numpy() - xob1[idm]) <= 1e-9 * np.linalg.norm(xob1[idm])
+        xbf, gbf = Gb.solve(torch.tensor(rhsb[idm], device=dev), abstol=0.0, reltol=1e-9, maxiters=300)
+        xob, iob = R.gmres(lambda z: Jbm @ z, rhsb, rtol=1e-9, restart=30, itmax=300, M=Mob, ortho="cgs2")
+        assert gbf["converged"] and abs(gbf["iters"] - iob.iters) <= 1 and gbf["iters"] <= 9
+        note("brus_mg_gmres", xbf.cpu().numpy())
+        kwb = dict(gmres_restart=30, maxiters=300)
+        refbm = R.solve(rbm, R.TrustRegion(linsolve=R.KrylovJL_GMRES(precs=R.MultigridPrecs(2, 8), **kwb), concrete_jac=True),
+                        abstol=1e-8, maxiters=40)
+        solbm = nls.solve(nls.NonlinearProblem(PBm, u0=PBm.initial_guess(device=True)),
+                          nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 8), **kwb), concrete_jac=True),
+                          abstol=1e-8, maxiters=40, store_trace=True)
+        assert solbm.retcode == "Success" == R.RETCODE_NAMES[refbm.retcode] and solbm.stats.nsteps == refbm.stats.nsteps
+        assert [t["accepted"] for t in solbm.trace] == [t["accepted"] for t in refbm.trace]
+        assert np.max(np.abs(solbm.u.cpu().numpy() - refbm.u[idm])) <= 1e-6 * np.max(np.abs(refbm.u))
+        note("brus_mg_tr", solbm.u.cpu().numpy())
+
         # ---------------- the multigrid V-cycle behind the `precs` hook on a row-partitioned hierarchy: every level split by
         # grid lines, ghost lines of the neighbouring levels gathered for the transfers, coarsest level solved redundantly —
         # the arithmetic must not depend on the partition: one V-cycle equals the serial oracle's to rounding, and the
