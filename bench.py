@@ -300,6 +300,30 @@ def main():
             ttt[name] = {"gpu_seconds": round(tg, 4), "gpu_newton_steps": sol2.stats.nsteps,
                          "gpu_gmres_iters": sol2.stats.gmres_iters, "gpu_retcode": sol2.retcode}
 
+    # ---- two more whole solves for the record (extras, not `value`): config C2 on the direct linsolve (block cyclic reduction
+    # on FP64 MFMA) and config C5 with the two-species multigrid V-cycle behind `precs`
+    if ttt is not None:
+        try:
+            def timed(prob_fn, alg, **kw):
+                nls.solve(prob_fn(), alg, **kw)          # warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sol_ = nls.solve(prob_fn(), alg, **kw)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0, sol_
+            tg, s2 = timed(lambda: nls.NonlinearProblem(nls.Bratu2D(256, 6.0)), nls.NewtonRaphson(), abstol=1e-8, maxiters=50)
+            ttt["c2_bratu256_newton_direct"] = {"gpu_seconds": round(tg, 4), "gpu_newton_steps": s2.stats.nsteps,
+                                                "nfactors": s2.stats.nfactors, "gpu_retcode": s2.retcode}
+            PB5 = nls.Brusselator2D(512)
+            alg5 = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, reltol=1e-9, abstol=0.0,
+                                                               precs=nls.MultigridPrecs(2, 16)), concrete_jac=True)
+            tg, s5 = timed(lambda: nls.NonlinearProblem(PB5, u0=PB5.initial_guess(device=True)), alg5, abstol=1e-7, maxiters=30)
+            ttt["c5_brusselator512_trustregion_multigrid"] = {"gpu_seconds": round(tg, 4), "gpu_newton_steps": s5.stats.nsteps,
+                                                              "gpu_gmres_iters": s5.stats.gmres_iters, "gpu_retcode": s5.retcode,
+                                                              "note": "includes init (pattern, hierarchy); |F|inf <= 1e-7"}
+        except Exception as ex:  # noqa: BLE001
+            ttt["extras_error"] = str(ex)
+
     if rank == 0:
         op = "matfree_jvp" if args.matfree else "csr_spmv"
         if args.workload == "c5":

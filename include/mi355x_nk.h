@@ -203,7 +203,7 @@ typedef struct {
    *     interval re-estimated for every new Jacobian (lambda_max by power iteration, lambda_min = max/ratio) */
   int32_t cheb_degree;
   int32_t linesearch;           /* 0 none (missing), 1 BackTracking, 2 LineSearchesJL(Static), 3 LineSearchesJL(StrongWolfe),
-                                   4 LineSearchesJL(MoreThuente) [EXT: LineSearches.jl defaults] — globalisation
+                                   4 LineSearchesJL(MoreThuente), 5 LineSearchesJL(HagerZhang) [EXT: LineSearches.jl defaults] — globalisation
                                    Val(:LineSearch), lib/NonlinearSolveFirstOrder/src/solve.jl:392-408               */
   double  cheb_ratio;           /* ≤1 → 30 */
   /* --- BackTracking line search (LineSearch.jl / LineSearches.jl [EXT]: c_1 = 1e-4, ρ_hi = 0.5, ρ_lo = 0.1,

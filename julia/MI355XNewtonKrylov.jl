@@ -282,7 +282,7 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     gmres_maxiters::Int = 300
     forcing::Bool = false                 # EisenstatWalkerForcing2()
     radius_update_scheme::Int = 0         # RadiusUpdateSchemes.Simple … Fan (0…6)
-    linesearch::Symbol = :none            # :none | :BackTracking | :Static | :StrongWolfe | :MoreThuente (LineSearchesJL methods)
+    linesearch::Symbol = :none            # :none | :BackTracking | :Static | :StrongWolfe | :MoreThuente | :HagerZhang (LineSearchesJL methods)
     precs::Symbol = :none                 # :none | :chebyshev | :multigrid — the built-ins behind the `precs` hook
     cheb_degree::Int = 32
     cheb_ratio::Float64 = 300.0
@@ -367,7 +367,7 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
         maxtime = something(maxtime, 0.0),
         gmres_restart = alg.gmres_restart, gmres_maxiters = alg.gmres_maxiters,
         forcing = alg.forcing ? 1 : 0, radius_update_scheme = alg.radius_update_scheme,
-        linesearch = get(Dict(:BackTracking => 1, :Static => 2, :StrongWolfe => 3, :MoreThuente => 4), alg.linesearch, 0),
+        linesearch = get(Dict(:BackTracking => 1, :Static => 2, :StrongWolfe => 3, :MoreThuente => 4, :HagerZhang => 5), alg.linesearch, 0),
         cheb_degree = alg.precs === :chebyshev ? alg.cheb_degree : 0, cheb_ratio = alg.cheb_ratio,
         mg_nu = alg.precs === :multigrid ? alg.mg_nu : 0, mg_coarse = alg.mg_coarse,
         jac_colored = alg.jac_colored ? 1 : 0)

@@ -578,8 +578,7 @@ class BackTracking:
 @dataclass
 class LineSearchesJL:
     """LineSearch.jl's wrapper around LineSearches.jl [EXT]: `NewtonRaphson(linesearch = LineSearchesJL(; method = …))` with
-    method "Static" | "BackTracking" | "StrongWolfe" | "MoreThuente" (LineSearches.jl default parameters; HagerZhang is not
-    offered) — the methods of lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46."""
+    method "Static" | "BackTracking" | "StrongWolfe" | "MoreThuente" | "HagerZhang" (LineSearches.jl default parameters) — the methods of lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46."""
     method: str = "BackTracking"
 
 
@@ -733,7 +732,7 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
     lsr = getattr(alg, "linesearch", None)
     if isinstance(lsr, LineSearchesJL):
-        o.linesearch = {"BackTracking": 1, "Static": 2, "StrongWolfe": 3, "MoreThuente": 4}[lsr.method]
+        o.linesearch = {"BackTracking": 1, "Static": 2, "StrongWolfe": 3, "MoreThuente": 4, "HagerZhang": 5}[lsr.method]
     elif lsr is not None:
         o.linesearch = 1
         o.ls_c1, o.ls_rho_hi, o.ls_rho_lo = float(lsr.c_1), float(lsr.rho_hi), float(lsr.rho_lo)

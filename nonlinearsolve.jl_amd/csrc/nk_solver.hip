@@ -516,7 +516,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
              "a forcing term needs an iterative linear solver");
   NK_REQUIRE(opts->termination_mode >= 0 && opts->termination_mode <= 8, "bad termination_mode %d", opts->termination_mode);
   NK_REQUIRE(opts->termination_norm == 0 || opts->termination_norm == 1, "bad termination_norm %d", opts->termination_norm);
-  NK_REQUIRE(opts->linesearch >= 0 && opts->linesearch <= 4, "bad linesearch %d", opts->linesearch);
+  NK_REQUIRE(opts->linesearch >= 0 && opts->linesearch <= 5, "bad linesearch %d", opts->linesearch);
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->linesearch != 0),
              "TrustRegion and LineSearch methods are algorithmically incompatible (FirstOrder/src/solve.jl:221-223)");
   NK_REQUIRE(!(opts->algorithm == NK_ALG_TRUST_REGION && opts->forcing != NK_FORCING_NONE),
@@ -973,7 +973,7 @@ static int backtracking(nk_solver *S, double *alpha_out, bool *failed) {
   return NK_OK;
 }
 
-// ---- LineSearchesJL(; method = Static | StrongWolfe | MoreThuente) [EXT: LineSearch.jl's wrapper around LineSearches.jl,
+// ---- LineSearchesJL(; method = Static | StrongWolfe | MoreThuente | HagerZhang) [EXT: LineSearch.jl's wrapper around LineSearches.jl,
 // the methods of lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46] on ϕ(α) = ½‖f(u + α δu)‖²,
 // ϕ'(α) = f(u + α δu)ᵀ J(u + α δu) δu. Restated from the published algorithms with LineSearches.jl's default parameters
 // (oracle/reference_restatement.py::_lsjl is the same code in Python; its Moré–Thuente step function is pinned against SciPy's
@@ -1196,6 +1196,147 @@ static int ls_morethuente(nk_solver *S, double phi0, double dphi0, double *alpha
   *alpha_out = alpha;
   return NK_OK;
 }
+// LineSearches.HagerZhang (Hager & Zhang 2005: bracket B0–B3, secant² S1–S4, update U0–U3 with bisection θ = ½, Wolfe /
+// approximate Wolfe tests; δ = 0.1, σ = 0.9, ρ = 5, ε = 1e-6, γ = 0.66, ≤ 50 iterations, ψ₃ = 0.1). The method's exceptions
+// (non-descent direction, iteration limit, lost bracket) are reported as a failed line search at the best step so far.
+struct hz_state {
+  nk_solver *S;
+  std::vector<double> a, v, d;  // step lengths, ϕ, ϕ′ of every evaluation (index 0: α = 0)
+  double phi_0, dphi_0, phi_lim;
+  bool lost = false;
+};
+static int hz_eval(hz_state &h, double alpha, double *p, double *dp) {
+  NK_TRY(ls_phidphi(h.S, alpha, p, dp));
+  h.a.push_back(alpha); h.v.push_back(*p); h.d.push_back(*dp);
+  return NK_OK;
+}
+static bool hz_wolfe(const hz_state &h, double c, double pc, double dc) {
+  const double delta = 0.1, sigma = 0.9;
+  const bool w1 = delta * h.dphi_0 >= (pc - h.phi_0) / c && dc >= sigma * h.dphi_0;
+  const bool w2 = (2.0 * delta - 1.0) * h.dphi_0 >= dc && dc >= sigma * h.dphi_0 && pc <= h.phi_lim;
+  return w1 || w2;
+}
+static int hz_bisect(hz_state &h, int *ia, int *ib) {
+  double a = h.a[*ia], b = h.a[*ib];
+  while (b - a > nextafter(b, INFINITY) - b) {
+    const double dd = (a + b) / 2.0;
+    double pd, gd;
+    NK_TRY(hz_eval(h, dd, &pd, &gd));
+    const int id = (int)h.a.size() - 1;
+    if (gd >= 0.0) { *ib = id; return NK_OK; }
+    if (pd <= h.phi_lim) { a = dd; *ia = id; }
+    else { b = dd; *ib = id; }
+  }
+  return NK_OK;
+}
+static int hz_update(hz_state &h, int ia, int ib, int ic, int *oa, int *ob) {
+  const double a = h.a[ia], b = h.a[ib], c = h.a[ic];
+  *oa = ia; *ob = ib;
+  if (c < a || c > b) return NK_OK;
+  if (h.d[ic] >= 0.0) { *ob = ic; return NK_OK; }
+  if (h.v[ic] <= h.phi_lim) { *oa = ic; return NK_OK; }
+  *ob = ic;
+  return hz_bisect(h, oa, ob);
+}
+static double hz_secant(double a, double b, double da, double db) { return (a * db - b * da) / (db - da); }
+static int hz_secant2(hz_state &h, int ia, int ib, bool *iswolfe, int *oA, int *oB) {
+  const double a0 = h.a[ia], b0 = h.a[ib], da = h.d[ia], db = h.d[ib];
+  *iswolfe = false;
+  if (!(da < 0.0 && db >= 0.0)) { h.lost = true; *oA = ia; *oB = ib; return NK_OK; }
+  double c = hz_secant(a0, b0, da, db), pc, dc;
+  NK_TRY(hz_eval(h, c, &pc, &dc));
+  int ic = (int)h.a.size() - 1;
+  if (hz_wolfe(h, c, pc, dc)) { *iswolfe = true; *oA = *oB = ic; return NK_OK; }
+  int iA, iB;
+  NK_TRY(hz_update(h, ia, ib, ic, &iA, &iB));
+  const double a = h.a[iA], b = h.a[iB];
+  if (iB == ic) c = hz_secant(h.a[ib], h.a[iB], h.d[ib], h.d[iB]);
+  else if (iA == ic) c = hz_secant(h.a[ia], h.a[iA], h.d[ia], h.d[iA]);
+  if ((iA == ic || iB == ic) && a <= c && c <= b) {
+    NK_TRY(hz_eval(h, c, &pc, &dc));
+    ic = (int)h.a.size() - 1;
+    if (hz_wolfe(h, c, pc, dc)) { *iswolfe = true; *oA = *oB = ic; return NK_OK; }
+    int jA, jB;
+    NK_TRY(hz_update(h, iA, iB, ic, &jA, &jB));
+    iA = jA; iB = jB;
+  }
+  *oA = iA; *oB = iB;
+  return NK_OK;
+}
+static int ls_hagerzhang(nk_solver *S, double phi_0, double dphi_0, double *alpha_out, bool *failed) {
+  const double rho = 5.0, eps_hz = 1e-6, gamma = 0.66, psi3 = 0.1, feps = 2.220446049250313e-16;
+  const int lsmax = 50;
+  double alphamax = INFINITY;
+  *failed = false;
+  if (!(isfinite(phi_0) && isfinite(dphi_0)) || dphi_0 >= feps * fabs(phi_0)) { *alpha_out = 0.0; *failed = true; return NK_OK; }
+  hz_state h;
+  h.S = S;
+  h.a.push_back(0.0); h.v.push_back(phi_0); h.d.push_back(dphi_0);
+  h.phi_0 = phi_0; h.dphi_0 = dphi_0;
+  h.phi_lim = phi_0 + eps_hz * fabs(phi_0);
+  double c = 1.0, phi_c, dphi_c;
+  NK_TRY(ls_phidphi(S, c, &phi_c, &dphi_c));
+  for (int itf = 1; !(isfinite(phi_c) && isfinite(dphi_c)) && itf < 53; ++itf) {
+    c *= psi3;
+    NK_TRY(ls_phidphi(S, c, &phi_c, &dphi_c));
+  }
+  if (!(isfinite(phi_c) && isfinite(dphi_c))) { *alpha_out = 0.0; return NK_OK; }
+  h.a.push_back(c); h.v.push_back(phi_c); h.d.push_back(dphi_c);
+  bool bracketed = false;
+  int ia = 0, ib = 1, it = 1;
+  while (!bracketed && it < lsmax) {  // B0–B3
+    if (dphi_c >= 0.0) {
+      ib = (int)h.a.size() - 1;
+      for (int i = ib - 1; i >= 0; --i)
+        if (h.v[i] <= h.phi_lim) { ia = i; break; }
+      bracketed = true;
+    } else if (h.v.back() > h.phi_lim) {
+      ib = (int)h.a.size() - 1;
+      ia = 0;
+      NK_TRY(hz_bisect(h, &ia, &ib));
+      bracketed = true;
+    } else {
+      const double cold = c;
+      if (nextafter(cold, INFINITY) >= alphamax) { *alpha_out = cold; return NK_OK; }
+      c = fmin(c * rho, alphamax);
+      NK_TRY(ls_phidphi(S, c, &phi_c, &dphi_c));
+      for (int itf = 1; !(isfinite(phi_c) && isfinite(dphi_c)) && c > nextafter(cold, INFINITY) && itf < 53; ++itf) {
+        alphamax = c;
+        c = (cold + c) / 2.0;
+        NK_TRY(ls_phidphi(S, c, &phi_c, &dphi_c));
+      }
+      if (!(isfinite(phi_c) && isfinite(dphi_c))) { *alpha_out = cold; return NK_OK; }
+      if (dphi_c < 0.0 && c == alphamax) { *alpha_out = c; return NK_OK; }
+      h.a.push_back(c); h.v.push_back(phi_c); h.d.push_back(dphi_c);
+    }
+    ++it;
+  }
+  while (it < lsmax) {  // L1–L3
+    const double a = h.a[ia], b = h.a[ib];
+    if (b - a <= nextafter(b, INFINITY) - b) { *alpha_out = a; return NK_OK; }
+    bool isw;
+    int iA, iB;
+    NK_TRY(hz_secant2(h, ia, ib, &isw, &iA, &iB));
+    if (h.lost) { *alpha_out = h.a[ia]; *failed = true; return NK_OK; }
+    if (isw) { *alpha_out = h.a[iA]; return NK_OK; }
+    const double A = h.a[iA], B = h.a[iB];
+    if (B - A < gamma * (b - a)) {
+      if (nextafter(h.v[ia], INFINITY) >= h.v[ib] && nextafter(h.v[iA], INFINITY) >= h.v[iB]) { *alpha_out = A; return NK_OK; }
+      ia = iA; ib = iB;
+    } else {
+      double pc, dc;
+      NK_TRY(hz_eval(h, (A + B) / 2.0, &pc, &dc));
+      int ja, jb;
+      NK_TRY(hz_update(h, iA, iB, (int)h.a.size() - 1, &ja, &jb));
+      ia = ja; ib = jb;
+    }
+    ++it;
+  }
+  *alpha_out = h.a[ia];  // iteration limit: LineSearchException in LineSearches.jl
+  *failed = true;
+  return NK_OK;
+}
+
 static int linesearch_lsjl(nk_solver *S, double *alpha_out, bool *failed) {
   *failed = false;
   double phi0, dphi0;
@@ -1209,6 +1350,7 @@ static int linesearch_lsjl(nk_solver *S, double *alpha_out, bool *failed) {
     case 2: return ls_static(S, alpha_out);
     case 3: return ls_strongwolfe(S, phi0, dphi0, alpha_out);
     case 4: return ls_morethuente(S, phi0, dphi0, alpha_out);
+    case 5: return ls_hagerzhang(S, phi0, dphi0, alpha_out, failed);
     default: NK_FAIL(NK_E_INVALID, "bad linesearch %d", S->o.linesearch);
   }
 }

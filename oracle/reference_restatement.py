@@ -690,8 +690,8 @@ class BackTracking:
 class LineSearchesJL:
     """LineSearch.jl's wrapper around LineSearches.jl [EXT] — `NewtonRaphson(linesearch = LineSearchesJL(; method = …))`, the
     five methods the reference's own tests run (lib/NonlinearSolveFirstOrder/test/rootfind_tests__item2.jl:40-46): `Static`,
-    `BackTracking`, `StrongWolfe`, `MoreThuente` are restated here from the published algorithms (Nocedal & Wright alg. 3.5/3.6;
-    Moré & Thuente 1994 / MINPACK cvsrch + cstep) with LineSearches.jl's default parameters; `HagerZhang` is not.
+    `BackTracking`, `StrongWolfe`, `MoreThuente`, `HagerZhang` are restated here from the published algorithms (Nocedal & Wright
+    alg. 3.5/3.6; Moré & Thuente 1994 / MINPACK cvsrch + cstep; Hager & Zhang 2005) with LineSearches.jl's default parameters.
     ϕ(α) = ½‖f(u + α δu)‖², ϕ'(α) = f(u + α δu)ᵀ J(u + α δu) δu; every ϕ, ϕ' or (ϕ, ϕ') evaluation is one residual
     evaluation (`nf += 1`); α₀ = 1 on every call; a non-descent direction (ϕ'(0) ≥ 0) takes the full step and reports
     failure. Parity unpinned (no source in the tree; the reference only tests convergence)."""
@@ -1291,7 +1291,146 @@ class FirstOrderCache:
             return self._ls_strongwolfe(phi, dphi, phi_dphi, 1.0, phi0, dphi0), False
         if method == "MoreThuente":
             return self._ls_morethuente(phi_dphi, 1.0, phi0, dphi0), False
+        if method == "HagerZhang":
+            return self._ls_hagerzhang(phi_dphi, 1.0, phi0, dphi0)
         raise ValueError(method)
+
+    # LineSearches.HagerZhang (Hager & Zhang 2005, CG_DESCENT line search: bracket B0–B3, secant² S1–S4, update U0–U3 with
+    # bisection θ = ½, (approximate) Wolfe tests T1/T2); δ = 0.1, σ = 0.9, α_max = ∞, ρ = 5, ε = 1e-6, γ = 0.66, at most 50
+    # iterations, ψ₃ = 0.1; `mayterminate` is false (the wrapper never sets it). Returns (α, failed): the method's exceptions
+    # (non-descent direction, iteration limit, lost bracket) are reported as a failed line search at the best step so far.
+    def _ls_hagerzhang(self, phidphi, c, phi_0, dphi_0):
+        delta, sigma, rho, eps_hz, gamma, lsmax, psi3 = 0.1, 0.9, 5.0, 1e-6, 0.66, 50, 0.1
+        alphamax = float("inf")
+        feps = np.finfo(float).eps
+        if not (math.isfinite(phi_0) and math.isfinite(dphi_0)) or dphi_0 >= feps * abs(phi_0):
+            return 0.0, True
+        alphas, values, slopes = [0.0], [phi_0], [dphi_0]
+        phi_lim = phi_0 + eps_hz * abs(phi_0)
+
+        def ev(a):
+            pa, da = phidphi(a)
+            alphas.append(a), values.append(pa), slopes.append(da)
+            return pa, da
+
+        def wolfe(cc, pc, dc):
+            w1 = delta * dphi_0 >= (pc - phi_0) / cc and dc >= sigma * dphi_0
+            w2 = (2.0 * delta - 1.0) * dphi_0 >= dc >= sigma * dphi_0 and pc <= phi_lim
+            return w1 or w2
+
+        def bisect(ia, ib):                       # U3 with θ = ½
+            a, b = alphas[ia], alphas[ib]
+            while b - a > np.spacing(b):
+                d = (a + b) / 2.0
+                pd, gd = ev(d)
+                idd = len(alphas) - 1
+                if gd >= 0.0:
+                    return ia, idd
+                if pd <= phi_lim:
+                    a, ia = d, idd
+                else:
+                    b, ib = d, idd
+            return ia, ib
+
+        def update(ia, ib, ic):                   # U0–U3
+            a, b, cc = alphas[ia], alphas[ib], alphas[ic]
+            if cc < a or cc > b:
+                return ia, ib
+            if slopes[ic] >= 0.0:
+                return ia, ic
+            if values[ic] <= phi_lim:
+                return ic, ib
+            return bisect(ia, ic)
+
+        def secant(a, b, da, db):
+            return (a * db - b * da) / (db - da)
+
+        def secant2(ia, ib):                      # S1–S4
+            a, b, da, db = alphas[ia], alphas[ib], slopes[ia], slopes[ib]
+            if not (da < 0.0 and db >= 0.0):
+                raise ArithmeticError("bracket lost")
+            cc = secant(a, b, da, db)
+            pc, dc = ev(cc)
+            ic = len(alphas) - 1
+            if wolfe(cc, pc, dc):
+                return True, ic, ic
+            iA, iB = update(ia, ib, ic)
+            a, b = alphas[iA], alphas[iB]
+            if iB == ic:
+                cc = secant(alphas[ib], alphas[iB], slopes[ib], slopes[iB])
+            elif iA == ic:
+                cc = secant(alphas[ia], alphas[iA], slopes[ia], slopes[iA])
+            if (iA == ic or iB == ic) and a <= cc <= b:
+                pc, dc = ev(cc)
+                ic = len(alphas) - 1
+                if wolfe(cc, pc, dc):
+                    return True, ic, ic
+                iA, iB = update(iA, iB, ic)
+            return False, iA, iB
+
+        if c <= feps:
+            return 0.0, False
+        phi_c, dphi_c = phidphi(c)
+        itf = 1
+        while not (math.isfinite(phi_c) and math.isfinite(dphi_c)) and itf < 53:
+            itf += 1
+            c *= psi3
+            phi_c, dphi_c = phidphi(c)
+        if not (math.isfinite(phi_c) and math.isfinite(dphi_c)):
+            return 0.0, False
+        alphas.append(c), values.append(phi_c), slopes.append(dphi_c)
+        bracketed, ia, ib, it = False, 0, 1, 1
+        try:
+            while not bracketed and it < lsmax:   # B0–B3
+                if dphi_c >= 0.0:
+                    ib = len(alphas) - 1
+                    for i in range(ib - 1, -1, -1):
+                        if values[i] <= phi_lim:
+                            ia = i
+                            break
+                    bracketed = True
+                elif values[-1] > phi_lim:
+                    ib, ia = len(alphas) - 1, 0
+                    ia, ib = bisect(ia, ib)
+                    bracketed = True
+                else:
+                    cold, phi_cold = c, phi_c
+                    if np.nextafter(cold, np.inf) >= alphamax:
+                        return cold, False
+                    c = min(c * rho, alphamax)
+                    phi_c, dphi_c = phidphi(c)
+                    itf = 1
+                    while not (math.isfinite(phi_c) and math.isfinite(dphi_c)) and c > np.nextafter(cold, np.inf) and itf < 53:
+                        alphamax = c
+                        itf += 1
+                        c = (cold + c) / 2.0
+                        phi_c, dphi_c = phidphi(c)
+                    if not (math.isfinite(phi_c) and math.isfinite(dphi_c)):
+                        return cold, False
+                    if dphi_c < 0.0 and c == alphamax:
+                        return c, False
+                    alphas.append(c), values.append(phi_c), slopes.append(dphi_c)
+                it += 1
+            while it < lsmax:                     # L1–L3
+                a, b = alphas[ia], alphas[ib]
+                if b - a <= np.spacing(b):
+                    return a, False
+                isw, iA, iB = secant2(ia, ib)
+                if isw:
+                    return alphas[iA], False
+                A, B = alphas[iA], alphas[iB]
+                if B - A < gamma * (b - a):
+                    if np.nextafter(values[ia], np.inf) >= values[ib] and np.nextafter(values[iA], np.inf) >= values[iB]:
+                        return A, False
+                    ia, ib = iA, iB
+                else:
+                    cc = (A + B) / 2.0
+                    ev(cc)
+                    ia, ib = update(iA, iB, len(alphas) - 1)
+                it += 1
+        except ArithmeticError:
+            return alphas[ia], True
+        return alphas[ia], True                   # iteration limit: LineSearchException in LineSearches.jl
 
     @staticmethod
     def _ls_static(phi, a):           # LineSearches.jl static.jl: the proposed step, halved while ϕ is not finite

@@ -1,4 +1,4 @@
-"""NewtonRaphson(linesearch = LineSearchesJL(; method)) on the device vs the oracle: Static, StrongWolfe, MoreThuente [EXT:
+"""NewtonRaphson(linesearch = LineSearchesJL(; method)) on the device vs the oracle: Static, StrongWolfe, MoreThuente, HagerZhang [EXT:
 LineSearches.jl, restated from the published algorithms] — the reference's own bar is convergence of quadratic_f to err < 1e-9
 (rootfind_tests__item2.jl:40-93); device and oracle must additionally agree on step sizes (through step and residual
 counts) and iterates."""
@@ -16,7 +16,7 @@ PROBLEMS = {
 }
 
 
-@pytest.mark.parametrize("method", ["Static", "BackTracking", "StrongWolfe", "MoreThuente"])
+@pytest.mark.parametrize("method", ["Static", "BackTracking", "StrongWolfe", "MoreThuente", "HagerZhang"])
 @pytest.mark.parametrize("which", list(PROBLEMS))
 @pytest.mark.parametrize("krylov", [False, True])
 def test_linesearchesjl_methods_match_oracle(nls, method, which, krylov):
@@ -32,7 +32,7 @@ def test_linesearchesjl_methods_match_oracle(nls, method, which, krylov):
     assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))
 
 
-@pytest.mark.parametrize("method", ["Static", "StrongWolfe", "MoreThuente"])
+@pytest.mark.parametrize("method", ["Static", "StrongWolfe", "MoreThuente", "HagerZhang"])
 def test_linesearchesjl_quadratic_known_answer(nls, method):
     sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(2, 2.0)), nls.NewtonRaphson(linesearch=nls.LineSearchesJL(method)))
     u = np.asarray(sol.u)

@@ -536,7 +536,7 @@ def test_levenberg_marquardt_damping_rules():
 
 # ---- LineSearchesJL methods [EXT] (rootfind_tests__item2.jl:40-93: NewtonRaphson with Static / BackTracking / MoreThuente /
 # StrongWolfe converges on quadratic_f to err < 1e-9); the Moré–Thuente step function against SciPy's MINPACK-2 `dcstep`
-@pytest.mark.parametrize("method", ["Static", "BackTracking", "StrongWolfe", "MoreThuente"])
+@pytest.mark.parametrize("method", ["Static", "BackTracking", "StrongWolfe", "MoreThuente", "HagerZhang"])
 def test_linesearchesjl_methods_converge_on_the_quadratic(method):
     for u0 in (np.array([1.0, 1.0]), np.array([10.0, 0.1, 3.0])):
         sol = R.solve(R.Quadratic(u0.size, 2.0), R.NewtonRaphson(linesearch=R.LineSearchesJL(method)), u0=u0)
