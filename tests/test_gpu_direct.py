@@ -65,6 +65,30 @@ def test_block_cyclic_reduction_matches_superlu(nls, name):
     F.close()
 
 
+def test_block_cyclic_reduction_random_shapes(nls):
+    """Seeded sweep over sizes, bandwidths and paddings (block orders 32 … 512, odd and even numbers of block rows, every
+    branch of the Schur recursion), each against SuperLU."""
+    rng = np.random.default_rng(2024)
+    seen = set()
+    for case in range(14):
+        kl, ku = int(rng.integers(1, 500)), int(rng.integers(1, 500))
+        b = ((max(kl, ku) + 31) // 32) * 32
+        n = int(b * rng.integers(4, 12) + rng.integers(-b + 1, b))
+        J = _banded(n, kl, ku, 100 + case)
+        A = nls.CSRMatrix.from_scipy(J)
+        F = nls.BandedLU(A)
+        info = F.info()
+        assert info["engine"] == "block_cyclic_reduction" and info["block"] == b
+        seen.add(b)
+        rhs = rng.standard_normal(n)
+        x = F.solve(rhs)
+        xr = spla.spsolve(sp.csc_matrix(J), rhs)
+        assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr), (case, n, kl, ku)
+        F.close()
+        A.close()
+    assert len(seen) >= 6
+
+
 @pytest.mark.parametrize("n,kl,ku", [(1000, 37, 20), (4096, 100, 90)])
 def test_block_cyclic_reduction_pivots_inside_the_blocks(nls, n, kl, ku):
     """Rows 2i ↔ 2i+1 of a diagonally dominant band matrix exchanged: the diagonal now carries the weak off-diagonal entries,
