@@ -575,3 +575,18 @@ def test_more_thuente_step_function_equals_minpack2_dcstep():
         assert abs(mine[6] - a) <= 1e-12 * max(1.0, abs(a)), (case, mine[6], a)
         seen.add(case)
     assert seen == {1, 2, 3, 4}
+
+
+def test_levenberg_marquardt_root_equals_scipy_minpack():
+    """Second opinion for the LevenbergMarquardt restatement: the Bratu 8×8 and Brusselator 4×4 roots it finds are the roots
+    MINPACK's own Levenberg–Marquardt (scipy.optimize.root(method='lm')) finds from the same start."""
+    import scipy.optimize as so
+    for pb in (R.Bratu2D(8), R.Brusselator2D(4)):
+        ref = so.root(pb.f, pb.u0(), jac=lambda u, pb=pb: pb.jac(u).toarray(), method="lm", options=dict(xtol=1e-14, ftol=1e-14))
+        assert ref.success
+        # (the Krylov form forwards abstol to GMRES on b = Jᵀf and stalls a factor 3–5 above tight tolerances — DESIGN.md §6)
+        for alg, tol in ((R.LevenbergMarquardt(), 1e-10),
+                         (R.LevenbergMarquardt(linsolve=R.KrylovJL_GMRES(gmres_restart=60, maxiters=600)), 1e-8)):
+            sol = R.solve(pb, alg, abstol=tol, maxiters=300)
+            assert sol.retcode == R.SUCCESS
+            assert np.max(np.abs(sol.u - ref.x)) <= 1e-6 * max(1.0, np.max(np.abs(ref.x)))
