@@ -267,6 +267,114 @@ def _worker(rank, world, port, q, transport="torch"):
         dist.destroy_process_group()
 
 
+def _worker4(rank, world, port, q, transport="torch"):
+    """Four ranks on one GPU: every rank has two DISTINCT neighbours (with two ranks the one peer is both), the all-reduce
+    combines four contributions, the periodic Brusselator ring closes over four slabs. A compact pass over the partitioned
+    operators and one solve per algorithm family, each against the serial oracle."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nonlinearsolve_jl_amd as nls
+        from oracle import reference_restatement as R
+        torch.cuda.set_device(0)
+        ctx = nls.Context(device=0)
+        nls.set_default_context(ctx)
+        nls.dist.init_comm(ctx, transport)
+        assert ctx.comm_info()[1:] == (world, rank)
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(11)
+        # Bratu 32²: 8 lines per rank
+        ns = 32
+        pb, P = R.Bratu2D(ns), nls.Bratu2D(ns)
+        b, e = P.row_begin, P.row_begin + P.n_local
+        u, v = 0.2 * rng.standard_normal(pb.n), rng.standard_normal(pb.n)
+        ul, vl = torch.tensor(u[b:e], device=dev), torch.tensor(v[b:e], device=dev)
+        assert np.allclose(P.jvp(vl, ul).cpu().numpy(), pb.jvp(v, u)[b:e], rtol=1e-13, atol=1e-12)
+        J = P.jac_csr()
+        P.jac_values(ul, J)
+        Jo = pb.jac(u)
+        assert np.allclose(J.matvec(vl).cpu().numpy(), (Jo @ v)[b:e], rtol=1e-13, atol=1e-11)
+        assert np.allclose(J.rmatvec(vl).cpu().numpy(), (Jo.T @ v)[b:e], rtol=1e-13, atol=1e-11)
+        assert np.allclose(J.colsumsq(like=vl).cpu().numpy(), np.asarray(Jo.multiply(Jo).sum(axis=0)).ravel()[b:e], rtol=1e-13)
+        rhs = rng.standard_normal(pb.n)
+        xref, iref = R.gmres(lambda z: Jo @ z, rhs, rtol=1e-9, restart=30, itmax=3000)
+        x, gi = nls.GMRES(e - b, restart=30).set_operator(J).solve(torch.tensor(rhs[b:e], device=dev), reltol=1e-9, maxiters=3000)
+        xg = nls.dist.gather_vector(x, pb.n, b)
+        assert gi["converged"] and np.linalg.norm(xg - xref) <= 1e-7 * np.linalg.norm(xref)
+        ref = R.solve(pb, R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2()), abstol=1e-9, maxiters=50)
+        for concrete in (False, True):
+            sol = nls.solve(nls.NonlinearProblem(P, u0=torch.zeros(e - b, dtype=torch.float64, device=dev)),
+                            nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=nls.EisenstatWalkerForcing2(),
+                                              concrete_jac=concrete), abstol=1e-9, maxiters=50)
+            assert sol.retcode == "Success" and abs(sol.stats.nsteps - ref.stats.nsteps) <= 1
+            assert np.max(np.abs(nls.dist.gather_vector(sol.u, pb.n, b) - ref.u)) <= 1e-7
+        # multigrid on four slabs
+        refm = R.solve(pb, R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=R.MultigridPrecs(2, 8)), forcing=R.EisenstatWalkerForcing2()),
+                       abstol=1e-9, maxiters=50)
+        solm = nls.solve(nls.NonlinearProblem(P, u0=torch.zeros(e - b, dtype=torch.float64, device=dev)),
+                         nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 8)),
+                                           forcing=nls.EisenstatWalkerForcing2()), abstol=1e-9, maxiters=50)
+        assert solm.retcode == "Success" and solm.stats.nsteps == refm.stats.nsteps
+        assert np.max(np.abs(nls.dist.gather_vector(solm.u, pb.n, b) - refm.u)) <= 5e-7
+        # LevenbergMarquardt (Krylov normal form) on four slabs of a 12² grid
+        Pl = nls.Bratu2D(12)
+        bl, el = Pl.row_begin, Pl.row_begin + Pl.n_local
+        kl_ = dict(gmres_restart=60, maxiters=600)
+        reflm = R.solve(R.Bratu2D(12), R.LevenbergMarquardt(linsolve=R.KrylovJL_GMRES(**kl_)), abstol=1e-8, maxiters=100)
+        sollm = nls.solve(nls.NonlinearProblem(Pl, u0=torch.zeros(el - bl, dtype=torch.float64, device=dev)),
+                          nls.LevenbergMarquardt(linsolve=nls.KrylovJL_GMRES(**kl_)), abstol=1e-8, maxiters=100)
+        assert sollm.retcode == "Success" and sollm.stats.nsteps == reflm.stats.nsteps
+        assert np.max(np.abs(sollm.u.cpu().numpy() - reflm.u[bl:el])) <= 1e-7
+        # Brusselator 32²: periodic ring over four slabs; concrete (coloured) J, TrustRegion, multigrid precs
+        N = 32
+        rb, PB = R.Brusselator2D(N), nls.Brusselator2D(N)
+        j0, j1 = nls.partition_range(N, 1, world, rank)
+        idx = np.array([i + N * (j0 + jl) + N * N * s_ for s_ in range(2) for jl in range(j1 - j0) for i in range(N)])
+        ub, vb = rb.u0() + 0.05 * rng.standard_normal(rb.n), rng.standard_normal(rb.n)
+        ubl, vbl = torch.tensor(ub[idx], device=dev), torch.tensor(vb[idx], device=dev)
+        assert np.allclose(PB.residual(ubl).cpu().numpy(), rb.f(ub)[idx], rtol=1e-12, atol=1e-9)
+        assert np.allclose(PB.jvp(vbl, ubl).cpu().numpy(), rb.jvp(vb, ub)[idx], rtol=1e-12, atol=1e-8)
+        assert np.allclose(PB.vjp(vbl, ubl).cpu().numpy(), rb.vjp(vb, ub)[idx], rtol=1e-12, atol=1e-8)
+        JB = PB.jac_csr()
+        ncol = PB.jac_values(ubl, JB, colored=True)
+        Jbo = rb.jac(ub).tocsr()
+        assert 6 <= ncol <= 14
+        assert np.allclose(JB.matvec(vbl).cpu().numpy(), (Jbo @ vb)[idx], rtol=1e-12, atol=1e-7)
+        assert np.allclose(JB.rmatvec(vbl).cpu().numpy(), (Jbo.T @ vb)[idx], rtol=1e-12, atol=1e-7)
+        kwb = dict(gmres_restart=30, maxiters=300)
+        refb = R.solve(rb, R.TrustRegion(linsolve=R.KrylovJL_GMRES(precs=R.MultigridPrecs(2, 8), **kwb), concrete_jac=True),
+                       abstol=1e-8, maxiters=40)
+        solb = nls.solve(nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True)),
+                         nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 8), **kwb), concrete_jac=True,
+                                         jac_colored=True), abstol=1e-8, maxiters=40, store_trace=True)
+        assert solb.retcode == "Success" == R.RETCODE_NAMES[refb.retcode] and solb.stats.nsteps == refb.stats.nsteps
+        assert [t["accepted"] for t in solb.trace] == [t["accepted"] for t in refb.trace]
+        assert np.max(np.abs(solb.u.cpu().numpy() - refb.u[idx])) <= 1e-6 * np.max(np.abs(refb.u))
+        assert ctx.comm_peer_status()[1] == 0
+        q.put((rank, "ok", {}))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), {}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,transport", [(4, "torch"), (4, "peer"), (8, "peer")])
+def test_four_and_eight_ranks_on_one_gpu(world, transport):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q, transport)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def _run_two_ranks(transport):
     world = 2
     ctx = mp.get_context("spawn")
