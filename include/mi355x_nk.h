@@ -421,7 +421,7 @@ int nk_lu_create(nk_csr *A, nk_lu **out);
 int nk_lu_destroy(nk_lu *F);
 int nk_lu_factor(nk_lu *F, nk_csr *A, int *ok);
 int nk_lu_solve(nk_lu *F, const double *b, double *x, int memspace);
-int nk_lu_info(nk_lu *F, int *kl, int *ku, int64_t *band_bytes);
+int nk_lu_info(nk_lu *F, int *kl, int *ku, int64_t *band_bytes);   /* band_bytes: device memory held by the factorisation */
 /* which engine the factorisation object runs on: 0 = right-looking band LU (a chain of n/32 dependent block columns),
  * 1 = block cyclic reduction (log2(n/b) levels of batched dense b x b algebra on FP64 MFMA; chosen automatically when the
  * matrix has >= 4 block rows of order b = bandwidth rounded to 32, b <= 512; NK_DIRECT=band in the environment forces 0);

@@ -637,6 +637,10 @@ extern "C" int nk_lu_info(nk_bandlu *B, int *kl, int *ku, int64_t *band_bytes) {
   NK_REQUIRE(B, "NULL argument");
   if (kl) *kl = B->kl;
   if (ku) *ku = B->ku;
-  if (band_bytes) *band_bytes = (int64_t)B->ldab * B->n * 8;
+  if (band_bytes) {
+    int blk = 0, lev = 0;
+    if (B->bcr) nk_bcr_shape(B->bcr, &blk, &lev);
+    *band_bytes = B->bcr ? nk_bcr_bytes(B->n, blk) : (int64_t)B->ldab * B->n * 8;  // device memory of the factorisation
+  }
   return NK_OK;
 }
