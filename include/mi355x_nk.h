@@ -80,8 +80,11 @@ typedef enum {
  * plus a diagonal (DampedNewtonDescent in :normal_form mode, descent/damped_newton.jl:186-200,297-313 — the mode a Krylov
  * `linsolve` selects), geodesic acceleration (descent/geodesic_acceleration.jl:98-136) and the damping-based trust region
  * (levenberg_marquardt.jl:159-168,247-268). Needs a concrete J (concrete_jac = Val(true)) and a Krylov linsolve. */
+/* NK_ALG_PSEUDO_TRANSIENT: DampedNewtonDescent with SwitchedEvolutionRelaxation damping in :simple mode
+ * (descent/damped_newton.jl:283-288): the Newton step on J + α⁻¹ I — the shift is added to the diagonal of the concrete J
+ * (`dampen_jacobian!!`) or to the matrix-free operator. */
 typedef enum { NK_ALG_NEWTON_RAPHSON = 0, NK_ALG_TRUST_REGION = 1, NK_ALG_GAUSS_NEWTON = 2,
-               NK_ALG_LEVENBERG_MARQUARDT = 3 } nk_algorithm;
+               NK_ALG_LEVENBERG_MARQUARDT = 3, NK_ALG_PSEUDO_TRANSIENT = 4 } nk_algorithm;
 
 /* which operator the Krylov solver sees as A (lib/NonlinearSolveBase/src/jacobian.jl:43-47,90-102) */
 typedef enum {
@@ -229,6 +232,10 @@ typedef struct {
   double  lm_alpha_geodesic;            /* [0.75] a step is taken only if 2‖a‖ ≤ α‖v‖                                 */
   double  lm_finite_diff_step_geodesic; /* [0.1]  h of the second directional derivative                              */
   double  lm_b_uphill;                  /* [1]    uphill moves: (1 − β)^b · ‖f_new‖ ≤ loss_old                        */
+  /* --- PseudoTransient (lib/NonlinearSolveFirstOrder/src/pseudo_transient.jl:37-57): (J + α⁻¹ I) δ = f with switched
+   *     evolution relaxation α⁻¹ ← α⁻¹·‖f‖₂/‖f_prev‖₂; mass matrix: identity, or a diagonal through
+   *     nk_solver_set_mass_matrix_diagonal */
+  double  pt_alpha_initial;             /* [1e-3] initial pseudo time step α                                          */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -386,6 +393,12 @@ int nk_gmres_set_normal_form(nk_gmres *G, int on);   /* AbstractSciMLOperator   
  * NULL switches the damping off) — `dampen_jacobian!!(J_cache, JᵀJ, λ·DᵀD)` of DampedNewtonDescent's :normal_form mode
  * (lib/NonlinearSolveBase/src/descent/damped_newton.jl:297-313,356-370) without assembling JᵀJ. */
 int nk_gmres_set_normal_form_damping(nk_gmres *G, const double *d_diag, double lambda);
+/* Shifted operator: A + sigma·I for the operator that is set (0 switches it off) — `J + D` for a matrix-free Jacobian
+ * operator under DampedNewtonDescent (`dampen_jacobian!!(::Any, J::AbstractSciMLOperator, D) = J + D`, damped_newton.jl:349). */
+int nk_gmres_set_shift(nk_gmres *G, double sigma);
+/* … and A + sigma·diag(m) with a DEVICE vector m of local length n (kept by reference; NULL = identity): the damping α⁻¹ M of
+ * PseudoTransient(; mass_matrix = Diagonal(m)) (pseudo_transient.jl:102-120,149). */
+int nk_gmres_set_shift_weights(nk_gmres *G, const double *d_m);
 /* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
 int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* The same two hooks for operators that live in HOST memory (a Julia `mul!` on plain Arrays): the callback receives host
@@ -446,6 +459,9 @@ int nk_solver_refresh_residual(nk_solver *S);
 int nk_solver_solve(nk_solver *S, int *retcode);           /* CommonSolve.solve! */
 int nk_solver_reinit(nk_solver *S, const double *u0, int memspace,
                      const double *params, int nparams);   /* SciMLBase.reinit!(cache, u0; p) */
+/* PseudoTransient(; mass_matrix = Diagonal(m)) (pseudo_transient.jl:37-57): damping α⁻¹·diag(m); m has the local length of u,
+ * is copied, and must be set before the first step (the reference fixes it at init). NULL returns to the identity. */
+int nk_solver_set_mass_matrix_diagonal(nk_solver *S, const double *m, int memspace);
 int nk_solver_get_u(nk_solver *S, double *u, int memspace);
 int nk_solver_get_resid(nk_solver *S, double *f, int memspace);
 int nk_solver_get_stats(nk_solver *S, nk_stats *stats);

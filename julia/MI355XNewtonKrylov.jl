@@ -302,6 +302,8 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     lm_finite_diff_step_geodesic::Float64 = 0.1
     lm_b_uphill::Float64 = 1.0
     lm_disable_geodesic::Bool = false
+    pt_alpha_initial::Float64 = 1e-3      # PseudoTransient(; alpha_initial) — method = :PseudoTransient
+    pt_mass_diagonal::Union{Nothing, Vector{Float64}} = nothing   # PseudoTransient(; mass_matrix = Diagonal(m)); nothing = I
 end
 
 # termination_condition → nk_options.termination_mode / termination_norm and the mode struct's fields
@@ -346,6 +348,7 @@ Base.@kwdef mutable struct NKOptions
     lm_damping_initial::Float64 = 1.0; lm_damping_increase_factor::Float64 = 2.0; lm_damping_decrease_factor::Float64 = 3.0
     lm_min_damping_D::Float64 = 1e-8; lm_alpha_geodesic::Float64 = 0.75; lm_finite_diff_step_geodesic::Float64 = 0.1
     lm_b_uphill::Float64 = 1.0
+    pt_alpha_initial::Float64 = 1e-3
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,
@@ -355,14 +358,14 @@ const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, R
 function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, args...;
         abstol = nothing, reltol = nothing, maxiters = 1000, maxtime = nothing, termination_condition = nothing,
         kwargs...)
-    algorithm = alg.method === :LevenbergMarquardt ? 3 : alg.method === :GaussNewton ? 2 : (alg.trust_region ? 1 : 0)
+    algorithm = alg.method === :PseudoTransient ? 4 : alg.method === :LevenbergMarquardt ? 3 : alg.method === :GaussNewton ? 2 : (alg.trust_region ? 1 : 0)
     o = NKOptions(; algorithm = algorithm,
         linsolve = alg.direct ? 2 : ((alg.concrete_jac || algorithm == 3) ? 1 : 0),
         lm_disable_geodesic = alg.lm_disable_geodesic ? 1 : 0, lm_damping_initial = alg.lm_damping_initial,
         lm_damping_increase_factor = alg.lm_damping_increase_factor,
         lm_damping_decrease_factor = alg.lm_damping_decrease_factor, lm_min_damping_D = alg.lm_min_damping_D,
         lm_alpha_geodesic = alg.lm_alpha_geodesic, lm_finite_diff_step_geodesic = alg.lm_finite_diff_step_geodesic,
-        lm_b_uphill = alg.lm_b_uphill,
+        lm_b_uphill = alg.lm_b_uphill, pt_alpha_initial = alg.pt_alpha_initial,
         maxiters = maxiters, abstol = something(abstol, 0.0), reltol = something(reltol, 0.0),
         maxtime = something(maxtime, 0.0),
         gmres_restart = alg.gmres_restart, gmres_maxiters = alg.gmres_maxiters,
@@ -378,9 +381,27 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
     u = ms == NK_HOST ? similar(u0) : DeviceVector(length(u0))
     resid = ms == NK_HOST ? similar(u0) : DeviceVector(length(u0))
     stats = zeros(Int64, 9); rc = Ref{Cint}(0)
-    GC.@preserve u0 u resid stats nkcheck(@ccall libnk.nk_newton_solve(alg.problem.ptr::Ptr{Cvoid},
-        rawptr(u0)::Ptr{Float64}, ms::Cint, Ref(o)::Ptr{Cvoid}, rawptr(u)::Ptr{Float64}, rawptr(resid)::Ptr{Float64},
-        stats::Ptr{Int64}, rc::Ptr{Cint})::Cint)
+    if alg.pt_mass_diagonal === nothing
+        GC.@preserve u0 u resid stats nkcheck(@ccall libnk.nk_newton_solve(alg.problem.ptr::Ptr{Cvoid},
+            rawptr(u0)::Ptr{Float64}, ms::Cint, Ref(o)::Ptr{Cvoid}, rawptr(u)::Ptr{Float64}, rawptr(resid)::Ptr{Float64},
+            stats::Ptr{Int64}, rc::Ptr{Cint})::Cint)
+    else   # the cache interface, so that the mass matrix can be handed over between init and the first step
+        m = alg.pt_mass_diagonal; h = Ref{Ptr{Cvoid}}(C_NULL)
+        length(m) == length(u0) || throw(DimensionMismatch("mass matrix has $(length(m)) diagonal entries but the problem has $(length(u0)) unknowns"))
+        GC.@preserve u0 nkcheck(@ccall libnk.nk_solver_init(alg.problem.ptr::Ptr{Cvoid}, rawptr(u0)::Ptr{Float64}, ms::Cint,
+            Ref(o)::Ptr{Cvoid}, h::Ptr{Ptr{Cvoid}})::Cint)
+        try
+            GC.@preserve m nkcheck(@ccall libnk.nk_solver_set_mass_matrix_diagonal(h[]::Ptr{Cvoid}, m::Ptr{Float64}, NK_HOST::Cint)::Cint)
+            nkcheck(@ccall libnk.nk_solver_solve(h[]::Ptr{Cvoid}, rc::Ptr{Cint})::Cint)
+            GC.@preserve u resid stats begin
+                nkcheck(@ccall libnk.nk_solver_get_u(h[]::Ptr{Cvoid}, rawptr(u)::Ptr{Float64}, ms::Cint)::Cint)
+                nkcheck(@ccall libnk.nk_solver_get_resid(h[]::Ptr{Cvoid}, rawptr(resid)::Ptr{Float64}, ms::Cint)::Cint)
+                nkcheck(@ccall libnk.nk_solver_get_stats(h[]::Ptr{Cvoid}, stats::Ptr{Int64})::Cint)
+            end
+        finally
+            @ccall libnk.nk_solver_destroy(h[]::Ptr{Cvoid})::Cint
+        end
+    end
     shape(x) = x isa Array ? reshape(x, size(prob.u0)) : x
     return SciMLBase.build_solution(prob, alg, shape(u), shape(resid);
         retcode = RETCODES[rc[] + 1], stats = NLStats(stats[1], stats[2], stats[3], stats[4], stats[5]),

@@ -9,7 +9,7 @@ from .core import (  # noqa: F401
     Context, default_context, set_default_context, partition_range, comm_unique_id,
     CSRMatrix, DeviceProblem, Quadratic, Bratu2D, Brusselator2D,
     NonlinearFunction, NonlinearProblem,
-    KrylovJL_GMRES, ChebyshevPrecs, MultigridPrecs, EisenstatWalkerForcing2, RadiusUpdateSchemes, BackTracking, LineSearchesJL, NewtonRaphson, TrustRegion, GaussNewton, LevenbergMarquardt,
+    KrylovJL_GMRES, ChebyshevPrecs, MultigridPrecs, EisenstatWalkerForcing2, RadiusUpdateSchemes, BackTracking, LineSearchesJL, NewtonRaphson, TrustRegion, GaussNewton, LevenbergMarquardt, PseudoTransient,
     NonlinearLeastSquaresProblem,
     AbsNormSafeBestTerminationMode, NormTerminationMode, RelTerminationMode, RelNormTerminationMode,
     RelNormSafeTerminationMode, RelNormSafeBestTerminationMode, AbsTerminationMode, AbsNormTerminationMode,

@@ -437,6 +437,7 @@ class NonlinearFunction:
     vjp: Optional[Callable] = None
     jac: Optional[Callable] = None
     jac_prototype: Optional[CSRMatrix] = None
+    mass_matrix: object = None   # picked up by PseudoTransient when the algorithm names none (number or diagonal vector)
 
 
 class NonlinearProblem:
@@ -639,6 +640,19 @@ class LevenbergMarquardt:  # levenberg_marquardt.jl:37-64 (keyword names of the 
 
 
 @dataclass
+class PseudoTransient:  # pseudo_transient.jl:37-57
+    """mass_matrix: None / 1.0 (identity), a number λ (λ·I), or a vector m of the local length of u (Diagonal(m)); the
+    damping term is α⁻¹·M. A general (non-diagonal) M would change the sparsity pattern of the damped J — not on this path."""
+    linsolve: Optional[KrylovJL_GMRES] = None
+    alpha_initial: float = 1e-3
+    mass_matrix: object = None
+    concrete_jac: Optional[bool] = None
+    linesearch: Optional[BackTracking] = None
+    jac_colored: bool = False
+    name: str = "PseudoTransient"
+
+
+@dataclass
 class _TerminationMode:
     """SciMLBase termination modes (lib/NonlinearSolveBase/src/termination_conditions.jl); `internalnorm` is
     "inf" (Base.Fix1(maximum, abs), the reference default) or "l2"."""
@@ -705,6 +719,9 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     if isinstance(alg, GaussNewton):   # (linsolve = None: a factorising solver takes J δ = f as it is — no normal form)
         o.algorithm = L.ALG_GAUSS_NEWTON
         o.termination_norm = 1  # default_termination_mode(::NonlinearLeastSquaresProblem): AbsNormSafeBest on the 2-norm
+    if isinstance(alg, PseudoTransient):
+        o.algorithm = L.ALG_PSEUDO_TRANSIENT
+        o.pt_alpha_initial = float(alg.alpha_initial)
     if isinstance(alg, LevenbergMarquardt):   # (linsolve = None: JᵀJ + λDᵀD is assembled and factorised on the device)
         o.algorithm = L.ALG_LEVENBERG_MARQUARDT
         o.lm_disable_geodesic = int(bool(alg.disable_geodesic))
@@ -811,6 +828,20 @@ class FirstOrderCache:
         check(L.lib().nk_solver_init(prob.device_problem._h, p, ms, C.byref(self._opts), C.byref(h)))
         self._h = h
         self.n = prob.device_problem.n_local
+        M = getattr(alg, "mass_matrix", None)
+        if M is None and isinstance(alg, PseudoTransient):   # resolve_ser_mass_matrix(::Nothing, prob): fall back to prob.f's
+            M = getattr(getattr(prob, "f", None), "mass_matrix", None)
+        if M is not None:
+            if np.ndim(M) == 0:
+                M = None if float(M) == 1.0 else np.full(self.n, float(M))       # resolve_ser_mass_matrix: I ≡ nothing
+            elif np.ndim(M) != 1:
+                raise NKError("PseudoTransient(mass_matrix=…): only the identity, λ·I and Diagonal(m) run on the device "
+                              "(a general M changes the sparsity pattern of J + α⁻¹ M)")
+            elif len(M) != self.n:  # DimensionMismatch in the reference (pseudo_transient.jl:110-118)
+                raise NKError(f"mass matrix has {len(M)} diagonal entries but the problem has {self.n} local unknowns")
+            if M is not None:
+                pm, msm, self._mass_keep = _ptr(M, self.n)
+                check(L.lib().nk_solver_set_mass_matrix_diagonal(self._h, pm, msm))
 
     def _out(self, fn):
         if self._u0_is_torch and self.prob.u0.is_cuda:

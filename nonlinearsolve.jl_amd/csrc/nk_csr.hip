@@ -458,6 +458,7 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_rowblocks);
   hipFree(A->d_tperm);
   hipFree(A->d_ones);
+  hipFree(A->d_diagpos);
   hipFree(A->d_tz);
   hipFree(A->d_trecv);
   hipFree(A->d_role);
@@ -681,6 +682,33 @@ extern "C" int nk_csr_colsumsq(nk_csr *A, double *out, int memspace) {
   NK_TRY(nk_csr_colsumsq_dev(A, A->d_ytmp));
   NK_HIP(hipMemcpyAsync(out, A->d_ytmp, A->nrows * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
   NK_HIP(hipStreamSynchronize(A->ctx->stream));
+  return NK_OK;
+}
+
+// A ← A + σ I: `dampen_jacobian!!(J_cache, J, D::Number)` (descent/damped_newton.jl:352-366) on the device CSR
+__global__ __launch_bounds__(NK_BLOCK) void k_add_diag(int64_t nrows, const int32_t *__restrict__ pos, double sigma,
+                                                       const double *__restrict__ m, double *__restrict__ val) {
+  const int64_t r = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
+  if (r < nrows) val[pos[r]] += m ? sigma * m[r] : sigma;
+}
+int nk_csr_add_to_diagonal_dev(nk_csr *A, double sigma, const double *d_m) {
+  if (!A->d_diagpos) {
+    std::vector<int32_t> pos((size_t)A->nrows);
+    for (int64_t r = 0; r < A->nrows; ++r) {
+      int32_t found = -1;
+      for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k)
+        if (A->h_col[k] == r) { found = k; break; }
+      NK_REQUIRE(found >= 0, "row %lld stores no diagonal entry: the damping J + sigma I needs one in the pattern", (long long)r);
+      pos[r] = found;
+    }
+    NK_TRY(nk_dev_alloc(&A->d_diagpos, (size_t)A->nrows + 1));
+    if (A->nrows) NK_HIP(hipMemcpy(A->d_diagpos, pos.data(), A->nrows * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  if (A->nrows)
+    NK_LAUNCH(A->ctx, k_add_diag, dim3((unsigned)((A->nrows + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), A->nrows,
+              (const int32_t *)A->d_diagpos, sigma, d_m, A->d_val);
+  NK_HIP(hipGetLastError());
+  A->t_values_stale = true;
   return NK_OK;
 }
 

@@ -821,8 +821,41 @@ __global__ __launch_bounds__(NK_BLOCK) void k_add_diag_scale(int64_t n, double l
     y[i] = (y[i] + lambda * d[i] * x[i]) * sc;
 }
 
+extern "C" int nk_gmres_set_shift(nk_gmres *G, double sigma) {
+  NK_REQUIRE(G, "NULL argument");
+  G->shift = sigma;
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_shift_weights(nk_gmres *G, const double *d_m) {
+  NK_REQUIRE(G, "NULL argument");
+  G->d_shift_w = d_m;  // borrowed device vector (local rows); NULL = identity
+  return NK_OK;
+}
+// y += scale·σ·(m ⊙ x) — the mass-matrix part of a shifted operator (y already carries scale·A x); m = NULL: identity
+__global__ __launch_bounds__(NK_BLOCK) void k_add_shift(int64_t n, double sigma, const double *__restrict__ m,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        const double *d_scale, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const double c = sigma * (d_scale ? *d_scale : 1.0);
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  if (m == nullptr)
+    for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) y[i] += c * x[i];
+  else
+    for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) y[i] += c * m[i] * x[i];
+}
+
 // raw operator: y = scale · A x (no preconditioner)
+static int op_apply_raw_unshifted(nk_gmres *G, const double *src, double *d_y, const int *d_skip, const double *oscale);
 static int op_apply_raw(nk_gmres *G, const double *src, double *d_y, const int *d_skip, const double *oscale) {
+  NK_TRY(op_apply_raw_unshifted(G, src, d_y, d_skip, oscale));
+  if (G->shift != 0.0) {
+    const int grid = nk_grid_for(G->n, NK_BLOCK * 4, 2048);
+    NK_LAUNCH(G->ctx, k_add_shift, dim3(grid), dim3(NK_BLOCK), G->n, G->shift, G->d_shift_w, src, d_y, oscale, d_skip);
+    NK_HIP(hipGetLastError());
+  }
+  return NK_OK;
+}
+static int op_apply_raw_unshifted(nk_gmres *G, const double *src, double *d_y, const int *d_skip, const double *oscale) {
   nk_ctx *ctx = G->ctx;
   if (G->normal) {  // AᵀA x: the plain half into a work vector, the transposed half into y (scaled afterwards if asked)
     NK_REQUIRE(G->op_kind == 1 || G->op_kind == 2, "the normal form needs a CSR or a problem operator");
@@ -910,7 +943,7 @@ static int cheb_apply(nk_gmres *G, const double *src, double *dst, const int *d_
     NK_LAUNCH(ctx, k_cheb_init, dim3(grid), dim3(NK_BLOCK), n, src, 1.0 / theta, G->cr, G->cd, dst, d_skip);
   }
   // concrete CSR operator: the vector update rides in the SpMV's row epilogue (d ping-pongs between two buffers)
-  const bool fuse = !G->normal && ((G->op_kind == 1) || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D));
+  const bool fuse = !G->normal && G->shift == 0.0 && ((G->op_kind == 1) || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D));
   double *dcur = G->cd, *dnext = G->cd2;
   for (int k = 1; k < G->cheb_degree; ++k) {
     const double rho_new = 1.0 / (2.0 * sigma1 - rho);

@@ -243,6 +243,7 @@ struct nk_csr {
   nk_csr *T = nullptr;
   int32_t *d_tperm = nullptr;
   double *d_ones = nullptr;   // a vector of ones (nk_csr_colsumsq_dev)
+  int32_t *d_diagpos = nullptr;  // position of every row's diagonal entry in val (nk_csr_add_to_diagonal_dev)
   bool t_values_stale = true;
   double *d_tz = nullptr, *d_trecv = nullptr;  // T·x (nrows + n_halo) and what the peers sent back (n_send)
   // column colouring of the pattern (structurally orthogonal columns), built on first use by coloured assembly
@@ -259,6 +260,7 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
                     const nk_spmv_epi *epi = nullptr);
 int nk_csr_spmv_t_dev(nk_csr *A, const double *d_x, double *d_y);
 int nk_csr_colsumsq_dev(nk_csr *A, double *d_out);  // out_j = Σ_i A_ij² (diag AᵀA)
+int nk_csr_add_to_diagonal_dev(nk_csr *A, double sigma, const double *d_m = nullptr);  // A += σ·diag(m) (m NULL: I)  // A ← A + σ I on the stored pattern (the diagonal must be stored)
 // assembled normal matrix N = JᵀJ + λ·diag(d) on the pattern of JᵀJ (single rank; nk_csr.hip)
 struct nk_normal_plan;
 int nk_normal_plan_create(nk_csr *J, nk_normal_plan **out);
@@ -406,6 +408,8 @@ struct nk_gmres {
   double *nrm_tmp = nullptr; // A x between the two halves
   const double *nrm_diag = nullptr;  // damped normal form: AᵀA + nrm_lambda·diag(nrm_diag)
   double nrm_lambda = 0.0;
+  double shift = 0.0;  // operator = A + shift·diag(m) (matrix-free pseudo-transient damping)
+  const double *d_shift_w = nullptr;  // m (borrowed, local rows); NULL = identity
   bool fn_host = false, prec_host = false;  // the callbacks take HOST pointers: vectors are staged through h_stage
   double *h_stage = nullptr;                // pinned, 2 n doubles
   int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle

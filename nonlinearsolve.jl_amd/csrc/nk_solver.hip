@@ -60,6 +60,10 @@ struct nk_solver {
   bool lm_tr_accepted = false, lm_geo_accepted = false;
   double *lm_dtd = nullptr, *lm_diag = nullptr, *lm_v = nullptr, *lm_a = nullptr, *lm_vcache = nullptr, *lm_rhs = nullptr;
   nk_normal_plan *nplan = nullptr;  // LevenbergMarquardt with the direct linsolve: the assembled JᵀJ + λDᵀD
+  // PseudoTransient: SwitchedEvolutionRelaxation cache (α⁻¹, the residual norm it was last scaled with) and the shift that
+  // currently sits on the diagonal of the concrete J
+  double pt_ainv = 0, pt_res = 0, pt_applied = 0;
+  double *pt_mass = nullptr;  // diagonal of the mass matrix M (NULL: identity): the damping is α⁻¹ M
   std::vector<nk_trace_entry> trace;
 };
 
@@ -212,6 +216,7 @@ extern "C" int nk_options_default(nk_options *o) {
   o->lm_alpha_geodesic = 0.75;
   o->lm_finite_diff_step_geodesic = 0.1;
   o->lm_b_uphill = 1.0;
+  o->pt_alpha_initial = 1e-3;  // PseudoTransient() (pseudo_transient.jl:38)
   return NK_OK;
 }
 
@@ -224,6 +229,7 @@ static bool normal_form(const nk_solver *S) {
   return S->o.algorithm == NK_ALG_GAUSS_NEWTON && S->o.linsolve != NK_LINSOLVE_BANDED_LU;
 }
 static bool is_lm(const nk_solver *S) { return S->o.algorithm == NK_ALG_LEVENBERG_MARQUARDT; }
+static bool is_pt(const nk_solver *S) { return S->o.algorithm == NK_ALG_PSEUDO_TRANSIENT; }
 static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE; }
 static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BANDED_LU; }
 
@@ -254,6 +260,7 @@ static int refresh_J(nk_solver *S) {
   else NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
   S->stats.njacs++;
   S->lu_valid = false;
+  S->pt_applied = 0.0;  // fresh values: no damping on the diagonal yet
   return NK_OK;
 }
 static int apply_J(nk_solver *S, const double *v, double *out) {
@@ -480,6 +487,12 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
     S->shrink_counter = 0;
     S->last_accepted = false;
   }
+  if (is_pt(S)) {  // SwitchedEvolutionRelaxationCache init / reinit! (pseudo_transient.jl:107-131)
+    S->pt_ainv = 1.0 / S->o.pt_alpha_initial;
+    S->pt_res = S->fnorm2;
+    S->pt_applied = 0.0;  // (the Jacobian values were just refilled)
+    if (S->G) NK_TRY(nk_gmres_set_shift(S->G, 0.0));
+  }
   if (is_lm(S)) {  // init / reinit! of the damping cache, the LM trust region and the geodesic cache
     S->lm_lam = S->o.lm_damping_initial;                    // levenberg_marquardt.jl:72-89,119-131
     S->lm_lam_factor = S->o.lm_damping_increase_factor;
@@ -499,7 +512,12 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
   nk_ctx *ctx = P->ctx;
   NK_HIP(hipSetDevice(ctx->device));
   NK_REQUIRE(opts->algorithm == NK_ALG_NEWTON_RAPHSON || opts->algorithm == NK_ALG_TRUST_REGION ||
-                 opts->algorithm == NK_ALG_GAUSS_NEWTON || opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT, "bad algorithm");
+                 opts->algorithm == NK_ALG_GAUSS_NEWTON || opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT ||
+                 opts->algorithm == NK_ALG_PSEUDO_TRANSIENT, "bad algorithm");
+  NK_REQUIRE(!(opts->algorithm == NK_ALG_PSEUDO_TRANSIENT && !(opts->pt_alpha_initial > 0.0)),
+             "PseudoTransient: alpha_initial must be positive");
+  NK_REQUIRE(!(opts->algorithm == NK_ALG_PSEUDO_TRANSIENT && opts->forcing != NK_FORCING_NONE),
+             "PseudoTransient takes no forcing term (pseudo_transient.jl:37-57)");
   if (opts->algorithm == NK_ALG_LEVENBERG_MARQUARDT) {
     NK_REQUIRE(opts->linsolve == NK_LINSOLVE_GMRES_CSR || opts->linsolve == NK_LINSOLVE_BANDED_LU,
                "LevenbergMarquardt needs a concrete Jacobian (concrete_jac = Val(true), levenberg_marquardt.jl:62)");
@@ -587,7 +605,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
   if (S->P) nk_problem_invalidate(S->P);  // the vectors the problem was linearised at are about to be freed
   double *bufs[] = {S->ubuf[0], S->ubuf[1], S->ubuf[2], S->fu, S->du, S->fu_trial, S->du_newton, S->du_cauchy,
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage, S->stage2, S->lm_dtd, S->lm_diag, S->lm_v,
-                    S->lm_a, S->lm_vcache, S->lm_rhs};
+                    S->lm_a, S->lm_vcache, S->lm_rhs, S->pt_mass};
   for (double *b : bufs) hipFree(b);
   nk_gmres_destroy(S->G);
   nk_bandlu_destroy(S->B);
@@ -620,6 +638,19 @@ static int pre_step_forcing(nk_solver *S, int iter) {
 // negate = false leaves x (δu = −x) in du_out: the plain Newton update then runs with sign −1 and saves a pass
 static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacobian, bool negate = true) {
   S->stats.nsolve++;
+  if (is_pt(S)) {
+    // SwitchedEvolutionRelaxation solve! (pseudo_transient.jl:152-164): α⁻¹ ← α⁻¹·‖f‖₂/‖f_prev‖₂; then
+    // dampen_jacobian!! (damped_newton.jl:283-288,349-366): the step is taken on J + α⁻¹ I
+    S->pt_ainv *= S->fnorm2 / S->pt_res;
+    S->pt_res = S->fnorm2;
+    if (concrete(S)) {  // the shift lives on the diagonal of the stored values; a re-used J carries the previous one
+      NK_TRY(nk_csr_add_to_diagonal_dev(S->J, S->pt_ainv - S->pt_applied, S->pt_mass));
+      S->pt_applied = S->pt_ainv;
+      S->lu_valid = false;
+    } else {
+      NK_TRY(nk_gmres_set_shift(S->G, S->pt_ainv));
+    }
+  }
   if (direct(S)) {
     // update_A!(cache, ::AbstractFactorization, A, reuse): refactorise unless the caller asked for reuse
     // (ext/NonlinearSolveBaseLinearSolveExt.jl:81-86; reuse_A_if_factorization = !new_jacobian, newton.jl:125)
@@ -929,8 +960,9 @@ static int ls_phi(nk_solver *S, double alpha, double *phi) {
 static int backtracking(nk_solver *S, double *alpha_out, bool *failed) {
   const nk_options &o = S->o;
   *failed = false;
-  // ϕ(0) and ϕ'(0) = fuᵀ (J δu)
-  NK_TRY(apply_J(S, S->du, S->Jdu));
+  // ϕ(0) and ϕ'(0) = fuᵀ (J δu)   (PseudoTransient: the stored J carries the damping α⁻¹ I — take the true product)
+  if (is_pt(S)) NK_TRY(nk_problem_jvp_dev(S->P, S->u, S->du, S->Jdu, nullptr));
+  else NK_TRY(apply_J(S, S->du, S->Jdu));
   NK_TRY(nk_blas_sumsq(S->ctx, S->n, S->fu, slot(S, 0)));
   NK_TRY(nk_blas_dot(S->ctx, S->n, S->fu, S->Jdu, slot(S, 1)));
   double v[2];
@@ -1727,6 +1759,31 @@ extern "C" int nk_solver_reinit(nk_solver *S, const double *u0, int memspace, co
     NK_HIP(hipMemcpyAsync(S->u, u0, S->n * sizeof(double),
                           memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, S->ctx->stream));
   return solver_start(S);
+}
+
+// PseudoTransient(; mass_matrix = Diagonal(m)) (pseudo_transient.jl:37-57,102-120): the damping term becomes α⁻¹ M. The matrix
+// is part of the algorithm, fixed at init in the reference — set it before the first step (NULL returns to the identity).
+extern "C" int nk_solver_set_mass_matrix_diagonal(nk_solver *S, const double *m, int memspace) {
+  NK_REQUIRE(S, "NULL argument");
+  NK_REQUIRE(is_pt(S), "a mass matrix belongs to PseudoTransient (algorithm = NK_ALG_PSEUDO_TRANSIENT)");
+  NK_HIP(hipSetDevice(S->ctx->device));
+  if (S->pt_applied != 0.0 && concrete(S)) {  // take the damping that is on the stored diagonal back off first
+    NK_TRY(nk_csr_add_to_diagonal_dev(S->J, -S->pt_applied, S->pt_mass));
+    S->pt_applied = 0.0;
+    S->lu_valid = false;
+  }
+  if (m == nullptr) {
+    NK_HIP(hipStreamSynchronize(S->ctx->stream));
+    hipFree(S->pt_mass);
+    S->pt_mass = nullptr;
+  } else {
+    if (!S->pt_mass) NK_TRY(nk_dev_alloc(&S->pt_mass, (size_t)S->n + 1));
+    NK_HIP(hipMemcpyAsync(S->pt_mass, m, S->n * sizeof(double),
+                          memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, S->ctx->stream));
+    if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(S->ctx->stream));
+  }
+  if (S->G) NK_TRY(nk_gmres_set_shift_weights(S->G, S->pt_mass));
+  return NK_OK;
 }
 
 static int copy_out(nk_solver *S, const double *src, double *dst, int memspace) {

@@ -731,6 +731,36 @@ class LevenbergMarquardt:  # levenberg_marquardt.jl:37-64: GeodesicAcceleration(
     name: str = "LevenbergMarquardt"
 
 
+@dataclass
+class PseudoTransient:  # pseudo_transient.jl:37-57: DampedNewtonDescent(SwitchedEvolutionRelaxation), no globalisation
+    # mass_matrix (pseudo_transient.jl:102-149): None / 1.0 → identity damping α⁻¹ (resolve_ser_mass_matrix maps I to nothing);
+    # a number λ → λI; a vector → Diagonal; a 2-D array / sparse matrix → general M.  Damping term D = α⁻¹ M.
+    linsolve: object = None
+    alpha_initial: float = 1e-3
+    concrete_jac: Optional[bool] = None
+    linesearch: Optional[BackTracking] = None
+    mass_matrix: object = None
+    name: str = "PseudoTransient"
+
+    def mass(self, n, prob=None):
+        M = self.mass_matrix
+        if M is None:   # resolve_ser_mass_matrix(::Nothing, prob): the NonlinearFunction's own mass matrix, if it has a real one
+            M = getattr(prob, "mass_matrix", None)
+        if M is None:
+            return None
+        if sp.issparse(M):
+            M = sp.csr_matrix(M)
+        elif np.ndim(M) == 0:
+            return None if float(M) == 1.0 else sp.identity(n, format="csr") * float(M)
+        elif np.ndim(M) == 1:
+            M = sp.diags(np.asarray(M, dtype=float)).tocsr()
+        else:
+            M = sp.csr_matrix(np.asarray(M, dtype=float))
+        if M.shape != (n, n):   # DimensionMismatch (pseudo_transient.jl:110-118)
+            raise ValueError(f"mass matrix has size {M.shape} but the problem has {n} unknowns")
+        return M
+
+
 SIMPLE, NLSOLVE, NOCEDAL_WRIGHT, HEI, YUAN, BASTIN, FAN = range(7)
 
 
@@ -918,6 +948,10 @@ class FirstOrderCache:
             self._tr_init(self.u, self.fu)
         if self.is_lm:
             self._lm_init(self.u)
+        self.is_pt = isinstance(self.alg, PseudoTransient)
+        if self.is_pt:   # SwitchedEvolutionRelaxationCache (pseudo_transient.jl:107-124)
+            self.pt_ainv = 1.0 / float(self.alg.alpha_initial)
+            self.pt_res = L2_NORM(self.fu)
 
     # -- LevenbergMarquardt: damping cache (levenberg_marquardt.jl:72-117), LevenbergMarquardtTrustRegionCache (:204-245),
     #    GeodesicAccelerationCache (geodesic_acceleration.jl:51-55); also what their reinit! methods restore
@@ -1077,6 +1111,16 @@ class FirstOrderCache:
     # -- NewtonDescent.solve! (descent/newton.jl:97-141) through LinearSolveJLCache (ext:16-32)
     def _newton_descent(self, new_jacobian):
         self.stats.nsolve += 1
+        shift = 0.0
+        if getattr(self, "is_pt", False):
+            # SwitchedEvolutionRelaxation solve! (pseudo_transient.jl:152-164): α⁻¹ ← α⁻¹·‖f‖/‖f_prev‖, then
+            # dampen_jacobian!!(J_cache, J, α⁻¹) (damped_newton.jl:283-288,352-366): (J + α⁻¹ I) δ = f
+            res = L2_NORM(self.fu)
+            self.pt_ainv = float(np.float64(self.pt_ainv) * (np.float64(res) / np.float64(self.pt_res)))   # 0/0 → NaN as in Julia
+            self.pt_res = res
+            shift = self.pt_ainv
+            Mm = self.alg.mass(self.u.size, self.prob)
+            Dm = (lambda v: shift * v) if Mm is None else (lambda v: shift * (Mm @ v))
         if self.krylov is not None:
             kr = self.krylov
             u_now = self.u
@@ -1093,7 +1137,7 @@ class FirstOrderCache:
                 rhs = self._apply_JT(self.fu, u_now)
                 op = lambda v: self._apply_JT(self._apply_J(v, u_now), u_now)  # noqa: E731
             else:
-                rhs, op = self.fu, (lambda v: self._apply_J(v, u_now))
+                rhs, op = self.fu, ((lambda v: self._apply_J(v, u_now) + Dm(v)) if shift else (lambda v: self._apply_J(v, u_now)))
             x, info = gmres(op, rhs, None, atol=self.lin_abstol,
                             rtol=self.lin_reltol, restart=kr.gmres_restart, itmax=kr.maxiters,
                             fixed_iters=kr.fixed_iters, ortho=kr.ortho, M=M)
@@ -1106,7 +1150,8 @@ class FirstOrderCache:
             if new_jacobian or getattr(self, "_lu", None) is None:
                 self.stats.nfactors += 1
                 try:  # a singular / non-finite factorisation is LinearSolve's ReturnCode.Failure ⇒ success = false
-                    self._lu = spla.splu(sp.csc_matrix(self.J))
+                    self._lu = spla.splu(sp.csc_matrix(self.J + shift * (sp.identity(self.J.shape[0]) if Mm is None else Mm))
+                                         if shift else sp.csc_matrix(self.J))
                 except RuntimeError:
                     self._lu = None
                     return None
@@ -1845,6 +1890,9 @@ class FirstOrderCache:
             self.shrink_counter = 0
         if self.is_lm:
             self._lm_init(self.u)
+        if self.is_pt:   # reinit!: α⁻¹ back to its initial value, the residual norm re-seeded (needs_reset)
+            self.pt_ainv = 1.0 / float(self.alg.alpha_initial)
+            self.pt_res = L2_NORM(self.fu)
 
 
 def init(prob, alg, **kw):

@@ -191,6 +191,17 @@ def _worker(rank, world, port, q, transport="torch"):
         assert np.allclose([t["trust_region"] for t in sollm.trace], [t["trust_region"] for t in reflm.trace], rtol=1e-12)
         assert np.max(np.abs(sollm.u.cpu().numpy() - reflm.u[bl:el])) <= 1e-7
         note("bratu_lm", sollm.u.cpu().numpy())
+        # ---------------- PseudoTransient on two ranks: α⁻¹ from the global ‖f‖₂; the shift rides on the matrix-free
+        # operator and on the diagonal of the distributed CSR (local column index of the owned diagonal)
+        for cj in (None, True):
+            refpt = R.solve(R.Bratu2D(12), R.PseudoTransient(linsolve=R.KrylovJL_GMRES(**kl_), alpha_initial=10.0, concrete_jac=cj),
+                            abstol=1e-9, maxiters=100)
+            solpt = nls.solve(nls.NonlinearProblem(Plm, u0=torch.zeros(el - bl, dtype=torch.float64, device=dev)),
+                              nls.PseudoTransient(linsolve=nls.KrylovJL_GMRES(**kl_), alpha_initial=10.0, concrete_jac=cj),
+                              abstol=1e-9, maxiters=100)
+            assert solpt.retcode == "Success" == R.RETCODE_NAMES[refpt.retcode] and solpt.stats.nsteps == refpt.stats.nsteps
+            assert np.max(np.abs(solpt.u.cpu().numpy() - refpt.u[bl:el])) <= 1e-8
+        note("bratu_pt", solpt.u.cpu().numpy())
 
         # ---------------- the Brusselator V-cycle on two ranks: every level split by lines (slab boundaries stay even, the
         # transfers use the problem's own one-line periodic halo), coarsest level gathered and solved redundantly — one

@@ -590,3 +590,56 @@ def test_levenberg_marquardt_root_equals_scipy_minpack():
             sol = R.solve(pb, alg, abstol=tol, maxiters=300)
             assert sol.retcode == R.SUCCESS
             assert np.max(np.abs(sol.u - ref.x)) <= 1e-6 * max(1.0, np.max(np.abs(ref.x)))
+
+
+# ---- PseudoTransient (pseudo_transient.jl) known answers: rootfind_tests__item5.jl (quadratic, alpha_initial = 10, err < 1e-9),
+# item6 (iterator interface ≈ √p), item7 (every termination condition)
+def test_pseudo_transient_known_answers():
+    for ls in (None, R.KrylovJL_GMRES()):
+        sol = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(linsolve=ls, alpha_initial=10.0), u0=np.array([1.0, 1.0]))
+        assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+    for mode in range(9):
+        sol = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(), u0=np.array([1.0, 1.0]), termination_kwargs=dict(mode=mode))
+        assert np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+    ps = np.linspace(0.01, 2, 200)      # common_rootfind_testing.jl:47-57: start at 0.5, then continue from the previous root
+    c = R.init(R.Quadratic(1, ps[0]), R.PseudoTransient(alpha_initial=10.0), abstol=1e-10, maxiters=100, u0=np.array([0.5]))
+    out = []
+    for p in ps:
+        c.reinit(c.u.copy(), p=p)
+        out.append(c.solve().u[0])
+    assert np.allclose(out, np.sqrt(ps))
+    # rootfind_tests__item21.jl:131-146: reinit! restores α⁻¹ — the identical problem takes identical iterations
+    c = R.init(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=1e-2), abstol=1e-10, u0=np.array([1.0, 1.0]))
+    a0 = c.pt_ainv
+    s1 = c.solve(); n1 = s1.stats.nsteps
+    assert s1.retcode == R.SUCCESS and c.pt_ainv != a0
+    c.reinit(np.array([1.0, 1.0]), p=2.0)
+    assert c.pt_ainv == a0
+    s2 = c.solve()
+    assert s2.retcode == R.SUCCESS and s2.stats.nsteps == n1
+
+
+def test_pseudo_transient_mass_matrix_known_answers():
+    """rootfind_tests__item21.jl: the damping (1/α) M vanishes as α⁻¹ → 0, so every SPD mass matrix lands on √p."""
+    u0 = np.array([1.0, 1.0])
+    base = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=10.0), abstol=1e-10, u0=u0)
+    same = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=10.0, mass_matrix=None), abstol=1e-10, u0=u0)
+    ident = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=10.0, mass_matrix=1.0), abstol=1e-10, u0=u0)   # M = I ≡ nothing
+    assert base.retcode == R.SUCCESS and np.array_equal(base.u, same.u) and np.array_equal(base.u, ident.u)
+    assert base.stats.nsteps == same.stats.nsteps == ident.stats.nsteps
+    for M in (np.array([1.0, 2.0]), np.array([0.5, 5.0]), np.array([[2.0, 0.5], [0.5, 2.0]]), np.array([1.0, 3.0]), 2.0):
+        for ls in (None, R.KrylovJL_GMRES()):
+            sol = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(linsolve=ls, alpha_initial=10.0, mass_matrix=M), abstol=1e-10, u0=u0)
+            assert sol.retcode == R.SUCCESS and np.allclose(sol.u, np.sqrt(2.0), atol=1e-7)
+    # 2I damps twice as hard as I: a different path to the same root (item21:104-113)
+    s2 = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=1e-2, mass_matrix=2.0), abstol=1e-10, u0=u0)
+    s1 = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=1e-2), abstol=1e-10, u0=u0)
+    assert s2.retcode == s1.retcode == R.SUCCESS and s2.stats.nsteps > s1.stats.nsteps
+    # picked up from the problem when the algorithm names none (item21:62-80)
+    q = R.Quadratic(2, 2.0); q.mass_matrix = np.array([1.0, 2.0])
+    auto = R.solve(q, R.PseudoTransient(alpha_initial=10.0), abstol=1e-10, u0=u0)
+    expl = R.solve(R.Quadratic(2, 2.0), R.PseudoTransient(alpha_initial=10.0, mass_matrix=np.array([1.0, 2.0])), abstol=1e-10, u0=u0)
+    assert np.array_equal(auto.u, expl.u) and not np.array_equal(auto.u, base.u)
+    with pytest.raises(ValueError, match="mass matrix has size"):   # item21:165-172
+        R.solve(R.Quadratic(3, 2.0), R.PseudoTransient(alpha_initial=10.0, mass_matrix=np.array([1.0, 2.0])), abstol=1e-10,
+                u0=np.ones(3))
