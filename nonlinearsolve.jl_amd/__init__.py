@@ -20,3 +20,4 @@ from .core import (  # noqa: F401
     GMRES, BandedLU, JacobianOperator, JacVecOperator, VecJacOperator, StatefulJacobianOperator,
     StatefulJacobianNormalFormOperator,
 )
+from .polyalg import NonlinearSolvePolyAlgorithm, RobustMultiNewton, FastShortcutNLLSPolyalg, PolyAlgorithmCache  # noqa: F401

@@ -947,11 +947,17 @@ class FirstOrderCache:
 NonlinearLeastSquaresProblem = NonlinearProblem   # residual count = unknown count on this path (row-partitioned square J)
 
 
-def init(prob: NonlinearProblem, alg, **kw) -> FirstOrderCache:
+def init(prob: NonlinearProblem, alg, **kw):
+    from . import polyalg
+    if isinstance(alg, polyalg.NonlinearSolvePolyAlgorithm):
+        return polyalg.PolyAlgorithmCache(prob, alg, **kw)
     return FirstOrderCache(prob, alg, **kw)
 
 
 def solve(prob: NonlinearProblem, alg, **kw) -> NonlinearSolution:
+    from . import polyalg
+    if isinstance(alg, polyalg.NonlinearSolvePolyAlgorithm):
+        return polyalg.polysolve(prob, alg, **kw)
     cache = FirstOrderCache(prob, alg, **kw)
     try:
         return cache.solve()
@@ -975,8 +981,8 @@ def solve_(cache: FirstOrderCache):  # solve!(cache)
     return cache.solve()
 
 
-def reinit_(cache: FirstOrderCache, u0=None, p=None):  # reinit!(cache, u0; p)
-    return cache.reinit(u0, p)
+def reinit_(cache, u0=None, p=None, **kw):  # reinit!(cache, u0; p[, retain_best])
+    return cache.reinit(u0, p, **kw)
 
 
 # ------------------------------------------------------------------------------------------- linear solve seam

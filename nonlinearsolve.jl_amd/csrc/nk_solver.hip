@@ -452,7 +452,7 @@ static int rollback_to_best(nk_solver *S) {
 }
 
 // ---- init
-static int solver_start(nk_solver *S) {  // everything after u has been set
+static int solver_start(nk_solver *S, bool first = true) {  // everything after u has been set (first = init, else reinit!)
   nk_ctx *ctx = S->ctx;
   // the problem's linearisation caches (exp(u) diagonal, f(u) for forward differences) are keyed on the pointer of u:
   // u changes in place between solves, and a new solver may receive a just-freed address — start from "not linearised"
@@ -473,7 +473,9 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   S->fu_deferred = false;
   NK_TRY(residual_norms(S, nullptr, 0, nullptr));
   NK_TRY(tc_reinit(S));
-  if (concrete(S)) NK_TRY(refresh_J(S));  // jacobian.jl:104-118 evaluates J once at init
+  // jacobian.jl:104-118 evaluates J once at init (njacs = 1 before the first step); reinit! does not (JacobianCache's reinit!
+  // only swaps p, jacobian.jl:184-186) — the first step re-evaluates it either way (make_new_jacobian)
+  if (concrete(S) && first) NK_TRY(refresh_J(S));
   NK_TRY(nk_blas_fill(ctx, S->n, 0.0, S->du));  // descent/newton.jl:34-36
   S->eta = S->o.ew_eta0;
   S->rnorm = S->rnorm_prev = S->fnorm2;
@@ -490,7 +492,7 @@ static int solver_start(nk_solver *S) {  // everything after u has been set
   if (is_pt(S)) {  // SwitchedEvolutionRelaxationCache init / reinit! (pseudo_transient.jl:107-131)
     S->pt_ainv = 1.0 / S->o.pt_alpha_initial;
     S->pt_res = S->fnorm2;
-    S->pt_applied = 0.0;  // (the Jacobian values were just refilled)
+    if (first) S->pt_applied = 0.0;  // (the Jacobian values were just refilled; after reinit! the first step's refill resets it)
     if (S->G) NK_TRY(nk_gmres_set_shift(S->G, 0.0));
   }
   if (is_lm(S)) {  // init / reinit! of the damping cache, the LM trust region and the geodesic cache
@@ -713,6 +715,14 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
       S->stats.gmres_iters += fi.iters;
       S->lu_valid = false;
       *ok = fi.converged && !fi.failed;
+      if (*ok) {  // a lucky breakdown on a singular J "converges" with a non-finite or meaningless x: trust the true residual only
+        NK_TRY(nk_csr_spmv_dev(S->J, du_out, S->stage, nullptr));
+        NK_TRY(nk_blas_lincomb(S->ctx, S->n, 1.0, S->fu, -1.0, S->stage, S->stage));
+        const double *xs[2] = {S->stage, S->fu}, *ys[2] = {S->stage, S->fu};
+        NK_TRY(nk_blas_multi_reduce(S->ctx, S->n, 2, xs, ys, nullptr, nullptr, 0, 0, slot(S, 0)));
+        NK_TRY(fetch(S, 2, v));
+        *ok = (v[0] == v[0]) && (sqrt(v[0]) <= 1e-8 * sqrt(v[1]) + 1e-300);
+      }
       if (!*ok) return NK_OK;
     } else {
       *ok = true;
@@ -1758,7 +1768,7 @@ extern "C" int nk_solver_reinit(nk_solver *S, const double *u0, int memspace, co
   if (u0)
     NK_HIP(hipMemcpyAsync(S->u, u0, S->n * sizeof(double),
                           memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, S->ctx->stream));
-  return solver_start(S);
+  return solver_start(S, false);
 }
 
 // PseudoTransient(; mass_matrix = Diagonal(m)) (pseudo_transient.jl:37-57,102-120): the damping term becomes α⁻¹ M. The matrix

@@ -1990,7 +1990,209 @@ def simple_trust_region(f, jac, u0, p, abstol=None, maxiters=1000, step_threshol
     return x, fx, MAXITERS, maxiters
 
 
+# ----------------------------------------------------------------------------- polyalgorithms
+@dataclass
+class NonlinearSolvePolyAlgorithm:   # lib/NonlinearSolveBase/src/polyalg.jl:62-73: tried in order until one succeeds
+    algs: tuple
+    start_index: int = 1             # 1-based, as in the reference
+
+    def __post_init__(self):
+        self.algs = tuple(self.algs)
+        assert 0 < self.start_index <= len(self.algs)
+
+
+def RobustMultiNewton(concrete_jac=None, linsolve=None):   # lib/NonlinearSolveFirstOrder/src/poly_algs.jl:21-45
+    kw = dict(concrete_jac=concrete_jac, linsolve=linsolve)
+    return NonlinearSolvePolyAlgorithm((
+        TrustRegion(**kw), TrustRegion(radius_update_scheme=BASTIN, **kw), NewtonRaphson(**kw),
+        NewtonRaphson(linesearch=BackTracking(), **kw), TrustRegion(radius_update_scheme=NLSOLVE, **kw),
+        TrustRegion(radius_update_scheme=FAN, **kw)))
+
+
+def FastShortcutNLLSPolyalg(concrete_jac=None, linsolve=None):   # poly_algs.jl:62-88 (LevenbergMarquardt keeps its own concrete_jac)
+    return NonlinearSolvePolyAlgorithm((
+        GaussNewton(linsolve=linsolve, concrete_jac=concrete_jac), LevenbergMarquardt(linsolve=linsolve, disable_geodesic=True),
+        TrustRegion(linsolve=linsolve, concrete_jac=concrete_jac),
+        GaussNewton(linsolve=linsolve, linesearch=BackTracking(), concrete_jac=concrete_jac),
+        TrustRegion(linsolve=linsolve, radius_update_scheme=FAN, concrete_jac=concrete_jac), LevenbergMarquardt(linsolve=linsolve)))
+
+
+RETAIN_REPROBE_INTERVAL = 8   # polyalg.jl:186
+
+
+def findmin_resids(resids, least_squares=False):
+    """polyalg.jl:412-430: index of the smallest ‖fu‖ (∞-norm; 2-norm for least squares); NaN counts as Inf; `None` entries
+    (sub-algorithms never attempted) are skipped; the earliest of equal minima wins."""
+    nrm = (lambda r: float(np.linalg.norm(r, 2))) if least_squares else (lambda r: float(np.max(np.abs(r))) if r.size else 0.0)
+    idx = next(i for i, r in enumerate(resids) if r is not None)
+    f0 = nrm(resids[idx])
+    best, bi = np.inf, -1
+    for j in range(idx + 1, len(resids)):
+        fx = np.inf if resids[j] is None else nrm(resids[j])
+        fx = np.inf if np.isnan(fx) else fx
+        if fx < best:
+            best, bi = fx, j
+    return (best, bi) if (bi >= 0 and best < f0) else (f0, idx)
+
+
+def _sum_stats(parts):
+    out = Stats()
+    for st in parts:
+        for k in ("nf", "njacs", "nfactors", "nsolve", "nsteps", "gmres_iters"):
+            setattr(out, k, getattr(out, k) + getattr(st, k))
+    return out
+
+
+class PolyAlgorithmCache:
+    """NonlinearSolvePolyAlgorithmCache (polyalg.jl:79-121) — `init` builds every sub-cache (:266-311), `solve!` runs them in
+    order from `current` (Base/src/solve.jl:465-614), `reinit!` with best-sub-algorithm retention, wrap-around, periodic
+    re-probe and lazy sub-cache reinitialisation (polyalg.jl:188-244). The reference hands ONE NLStats object to all
+    sub-caches, and every sub-cache `reinit!` zeroes it; restated as: the statistics are summed over the sub-caches that ran
+    since the last reinitialisation of any of them."""
+
+    def __init__(self, prob, alg, least_squares=False, **kw):
+        self.prob, self.alg, self.least_squares = prob, alg, least_squares
+        self.caches = [FirstOrderCache(prob, a, **kw) for a in alg.algs]
+        self.N = len(self.caches)
+        self.best, self.current = -1, alg.start_index
+        self.retain_best, self.start_current, self.wrapped, self.retain_count = False, alg.start_index, False, 0
+        self.deferred = (None, None)
+        self.retcode, self.force_stop, self.nsteps = DEFAULT, False, 0
+        self._ran = []         # sub-caches whose statistics the shared NLStats currently holds
+        self.u0 = np.array(prob.u0() if kw.get("u0") is None else kw["u0"], dtype=np.float64)
+
+    @property
+    def stats(self):
+        return _sum_stats(c.stats for c in self._ran)
+
+    def _note(self, c):
+        if all(c is not r for r in self._ran):
+            self._ran.append(c)
+
+    def _deferred_reinit(self, i):   # polyalg.jl:246-253
+        self.caches[i - 1].reinit(self.deferred[0], self.deferred[1])
+        self._ran = []               # the sub-cache reinit! zeroes the shared statistics
+
+    def reinit(self, u0=None, p=None, retain_best=False):
+        if u0 is None:
+            u0 = self.u0
+        self.u0 = np.array(u0, dtype=np.float64)
+        self.retain_best = retain_best
+        self.retain_count = self.retain_count + 1 if retain_best else 0
+        retained = retain_best and 1 <= self.best <= self.N
+        reprobe = retained and self.best > self.alg.start_index and self.retain_count % RETAIN_REPROBE_INTERVAL == 0
+        self.current = self.best if (retained and not reprobe) else self.alg.start_index
+        self.start_current, self.wrapped = self.current, False
+        if retain_best:
+            self.deferred = (self.u0.copy(), p)
+            self.caches[self.current - 1].reinit(self.u0, p)
+        else:
+            for c in self.caches:
+                c.reinit(self.u0, p)
+        self._ran = []
+        self.nsteps, self.force_stop, self.retcode = 0, False, DEFAULT
+        return self
+
+    def _attempt(self, i):
+        c = self.caches[i - 1]
+        if self.retain_best and i != self.start_current:
+            self._deferred_reinit(i)
+        self._note(c)
+        sol = c.solve()
+        if sol.retcode == SUCCESS:
+            self.best = i
+            self.retcode = sol.retcode
+            return Solution(sol.u, c.fu.copy(), sol.retcode, self.stats, sol.trace)
+        self.current = i + 1
+        return None
+
+    def solve(self):
+        attempted = [False] * self.N
+        for i in range(1, self.N + 1):
+            if i == self.current:
+                attempted[i - 1] = True
+                out = self._attempt(i)
+                if out is not None:
+                    return out
+        if self.retain_best and not self.wrapped and self.start_current > self.alg.start_index:
+            self.wrapped, self.current = True, self.alg.start_index
+        for i in range(1, self.N):
+            if self.wrapped and i == self.current and i < self.start_current:
+                attempted[i - 1] = True
+                out = self._attempt(i)
+                if out is not None:
+                    return out
+        # every rung failed: the lowest residual among the sub-caches wins (:576-612) — `@isdefined(cache_i)` is true for
+        # every i (assigned unconditionally in the first pass), so un-attempted sub-caches compete with their init residual
+        fus = [c.fu for c in self.caches]
+        _m, idx = findmin_resids(fus, self.least_squares)
+        c = self.caches[idx]
+        self.retcode = c.retcode
+        return Solution(c.u.copy(), c.fu.copy(), c.retcode, self.stats, c.trace)
+
+    # -- InternalAPI.step! (polyalg.jl:313-371): one step of the current sub-cache; on its termination record the success or
+    # move up the ladder (wrapping once under retention); past the last rung pick the lowest residual
+    def step(self):
+        if not (1 <= self.current <= self.N):
+            if self.retain_best and not self.wrapped and self.start_current > self.alg.start_index:
+                self.wrapped, self.current = True, self.alg.start_index
+                self._deferred_reinit(self.current)
+                return
+            _m, idx = findmin_resids([c.fu for c in self.caches], self.least_squares)
+            self.best, self.retcode, self.force_stop = idx + 1, self.caches[idx].retcode, True
+            return
+        i = self.current
+        c = self.caches[i - 1]
+        self._note(c)
+        c.step()
+        self.nsteps += 1
+        if c.force_stop or c.nsteps >= c.maxiters:   # !not_terminated(sub-cache)
+            rc = c.retcode if c.retcode != DEFAULT else (MAXITERS if c.nsteps >= c.maxiters else SUCCESS)
+            if rc == SUCCESS:
+                self.best, self.force_stop, self.retcode = i, True, rc
+            elif self.wrapped and i + 1 >= self.start_current:
+                _m, idx = findmin_resids([cc.fu for cc in self.caches], self.least_squares)
+                self.best, self.retcode, self.force_stop = idx + 1, self.caches[idx].retcode, True
+            else:
+                self.current = i + 1
+                if i != self.N and self.retain_best:
+                    self._deferred_reinit(i + 1)
+
+    @property
+    def u(self):
+        return self.caches[min(max(self.current, 1), self.N) - 1].u
+
+    @property
+    def fu(self):
+        return self.caches[min(max(self.current, 1), self.N) - 1].fu
+
+
+def polysolve(prob, alg, least_squares=False, **kw):
+    """`__generated_polysolve` (Base/src/solve.jl:657-790): the one-shot path — each sub-algorithm gets a fresh `__solve` (its
+    cache is built only when the ladder reaches it), all sharing one NLStats; first success wins, else the lowest residual
+    among the sub-algorithms that ran."""
+    sols, ran = [None] * len(alg.algs), []
+    for i in range(alg.start_index, len(alg.algs) + 1):
+        c = FirstOrderCache(prob, alg.algs[i - 1], **kw)
+        sol = c.solve()
+        ran.append(c)
+        sols[i - 1] = sol
+        if sol.retcode == SUCCESS:
+            return Solution(sol.u, sol.resid, sol.retcode, _sum_stats(x.stats for x in ran), sol.trace)
+    _m, idx = findmin_resids([None if s_ is None else s_.resid for s_ in sols], least_squares)
+    sol = sols[idx]
+    return Solution(sol.u, sol.resid, sol.retcode, _sum_stats(x.stats for x in ran), sol.trace)
+
+
+def init(prob, alg, **kw):  # noqa: F811
+    if isinstance(alg, NonlinearSolvePolyAlgorithm):
+        return PolyAlgorithmCache(prob, alg, **kw)
+    return FirstOrderCache(prob, alg, **kw)
+
+
 def solve(prob, alg, **kw):
+    if isinstance(alg, NonlinearSolvePolyAlgorithm):
+        return polysolve(prob, alg, **kw)
     return FirstOrderCache(prob, alg, **kw).solve()
 
 

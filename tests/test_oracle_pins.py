@@ -643,3 +643,87 @@ def test_pseudo_transient_mass_matrix_known_answers():
     with pytest.raises(ValueError, match="mass matrix has size"):   # item21:165-172
         R.solve(R.Quadratic(3, 2.0), R.PseudoTransient(alpha_initial=10.0, mass_matrix=np.array([1.0, 2.0])), abstol=1e-10,
                 u0=np.ones(3))
+
+
+# ---- polyalgorithms (lib/NonlinearSolveBase/src/polyalg.jl, lib/NonlinearSolveFirstOrder/src/poly_algs.jl)
+def _cubic(u0):
+    return R.FunctionProblem(lambda u: u ** 3 - 2.0, u0, jac=lambda u: sp.diags(3.0 * u * u))
+
+
+def test_polyalgorithm_known_answers():
+    """test/PolyAlgorithms/core_tests__item2.jl (direct solve, caching interface, step interface) on the reference's
+    f(u) = u² − 2, u0 = [1, 1], abstol 1e-9 — with the polyalgorithms whose rungs are first-order methods."""
+    for alg in (R.RobustMultiNewton(), R.RobustMultiNewton(linsolve=R.KrylovJL_GMRES()), R.FastShortcutNLLSPolyalg()):
+        sol = R.solve(R.Quadratic(2, 2.0), alg, abstol=1e-9)
+        assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+        c = R.init(R.Quadratic(2, 2.0), alg, abstol=1e-9)
+        assert c.solve().retcode == R.SUCCESS and c.best == 1
+        c.reinit(np.array([1.0, 1.0]))
+        c = R.init(R.Quadratic(2, 2.0), alg, abstol=1e-9)
+        for _ in range(10000):
+            c.step()
+            if c.force_stop:
+                break
+        assert c.retcode == R.SUCCESS
+    # findmin_resids (polyalg.jl:412-430): NaN counts as Inf, `nothing` is skipped, the earliest minimum wins
+    r = [None, np.array([3.0, -4.0]), np.array([np.nan, 0.0]), np.array([4.0, 0.0]), np.array([-1.0, 1.0])]
+    assert R.findmin_resids(r) == (1.0, 4) and R.findmin_resids(r[:4]) == (4.0, 1) and R.findmin_resids(r[:4], True) == (4.0, 3)
+
+
+def test_polyalgorithm_retention():
+    """test/Core/polyalg_retention_tests__item1.jl restated with first-order rungs: on u³ − 2 NewtonRaphson fails from u0 = 0
+    (singular Jacobian) and wins from 100; PseudoTransient (J + α⁻¹I is regular at 0) plays the part of the reference's Broyden."""
+    root = 2.0 ** (1.0 / 3.0)
+    NR, PT = R.NewtonRaphson(), R.PseudoTransient(alpha_initial=1.0)
+    c = R.init(_cubic([0.0]), R.NonlinearSolvePolyAlgorithm((NR, PT)))
+    s1 = c.solve()
+    assert s1.retcode == R.SUCCESS and c.best == 2 and c.caches[0].nsteps > 0
+    n_newton = c.caches[0].nsteps
+    assert s1.stats.nsteps == c.caches[0].stats.nsteps + c.caches[1].stats.nsteps     # one NLStats shared by the rungs
+    c.reinit(np.array([1.2]), retain_best=True)
+    assert c.current == 2
+    s2 = c.solve()
+    assert s2.retcode == R.SUCCESS and abs(s2.u[0] - root) < 1e-6 and c.best == 2 and c.caches[0].nsteps == n_newton
+    assert s2.stats.nsteps == c.caches[1].stats.nsteps                                  # the retained rung's effort only
+    # escalation continues up the ladder when the sticky rung fails
+    c = R.init(_cubic([100.0]), R.NonlinearSolvePolyAlgorithm((NR, PT)))
+    assert c.solve().retcode == R.SUCCESS and c.best == 1
+    c.reinit(np.array([0.0]), retain_best=True)
+    assert c.current == 1
+    s = c.solve()
+    assert s.retcode == R.SUCCESS and abs(s.u[0] - root) < 1e-6 and c.best == 2
+    # wrap-around reaches the skipped cheaper rungs
+    c = R.init(_cubic([0.0]), R.NonlinearSolvePolyAlgorithm((PT, NR)))
+    c.best = 2
+    c.reinit(np.array([0.0]), retain_best=True)
+    assert c.current == 2
+    s = c.solve()
+    assert c.wrapped and s.retcode == R.SUCCESS and abs(s.u[0] - root) < 1e-6 and c.best == 1
+    # … but never below the algorithm's start_index
+    c = R.init(_cubic([0.0]), R.NonlinearSolvePolyAlgorithm((PT, NR), start_index=2))
+    c.best = 2
+    c.reinit(np.array([0.0]), retain_best=True)
+    s = c.solve()
+    assert not c.wrapped and s.retcode != R.SUCCESS and c.caches[0].nsteps == 0
+    # periodic re-probe rediscovers a cheaper sub-algorithm
+    c = R.init(_cubic([1.2]), R.NonlinearSolvePolyAlgorithm((PT, NR)))
+    c.best = 2
+    for _ in range(7):
+        c.reinit(np.array([1.2]), retain_best=True)
+        assert c.current == 2
+    c.reinit(np.array([1.2]), retain_best=True)
+    assert c.current == 1
+    assert c.solve().retcode == R.SUCCESS and c.best == 1
+    c.reinit(np.array([1.2]), retain_best=True)
+    assert c.current == 1
+    # retention off is the status-quo full restart
+    c = R.init(_cubic([0.0]), R.NonlinearSolvePolyAlgorithm((NR, PT)))
+    assert c.solve().retcode == R.SUCCESS and c.best == 2
+    c.reinit(np.array([1.2]))
+    assert c.current == 1 and not c.retain_best
+    s = c.solve()
+    assert s.retcode == R.SUCCESS and abs(s.u[0] - root) < 1e-6 and c.best == 1
+    # every rung fails: the lowest residual is returned with that rung's retcode
+    c = R.init(_cubic([0.0]), R.NonlinearSolvePolyAlgorithm((NR, R.PseudoTransient(alpha_initial=1e-3))), maxiters=3)
+    s = c.solve()
+    assert s.retcode == R.MAXITERS and np.array_equal(s.u, c.caches[1].u) and np.max(np.abs(s.resid)) < 2.0
