@@ -48,7 +48,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"])
     ap.add_argument("--grid", dest="n", type=int, default=0, help="grid side (default: 1024 for c3, 4096 for c4, 512 for c5)")
-    ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs"])
+    ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs", "sstep"])
+    ap.add_argument("--sstep", type=int, default=6, help="--ortho sstep: basis columns per block")
     ap.add_argument("--arnoldi", type=int, default=30)
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
@@ -162,12 +163,12 @@ def main():
         if kind == "c5":
             PB = nls.Brusselator2D(ns)
             prob = nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True))
-            alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho,
+            alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho, sstep=args.sstep,
                                                               fixed_iters=args.arnoldi), concrete_jac=not args.matfree)
         else:
             prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
             prob.u0 = torch.zeros(prob.device_problem.n_local, dtype=torch.float64, device="cuda")
-            alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho,
+            alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho, sstep=args.sstep,
                                                                 fixed_iters=args.arnoldi), concrete_jac=not args.matfree)
         # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
         return prob, nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)

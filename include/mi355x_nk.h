@@ -100,9 +100,14 @@ typedef enum {
   NK_ORTHO_DCGS2 = 3, /* the default: CGS2 arithmetic with delayed re-orthogonalisation — two sweeps over the basis and
                        * (with the built-in linear operators) ONE reduction / all-reduce per Arnoldi step; operators
                        * reached through callbacks keep two reductions (and plain CGS2 when restart > 31)            */
-  NK_ORTHO_DCGS2_1R = 4 /* insist on the one-reduction form (the pending vector's second projection and the new vector's
+  NK_ORTHO_DCGS2_1R = 4, /* insist on the one-reduction form (the pending vector's second projection and the new vector's
                        * first projection share a fused dot sweep; the Hessenberg column and the stopping test lag
                        * one step); falls back like NK_ORTHO_DCGS2 where the operator does not allow it            */
+  NK_ORTHO_SSTEP = 5    /* s-step (communication-avoiding) Arnoldi: s operator applications build a monomial block, which is
+                       * orthogonalised against the basis and within itself by block CGS in Pythagorean form, twice — three
+                       * sweeps over the basis per s columns instead of two per column; the Gram blocks run on the FP64
+                       * matrix cores. Block size: nk_options.gmres_sstep / nk_gmres_set_block_size (default 6). A block
+                       * that loses rank numerically (Cholesky breakdown) makes the solve fall back to NK_ORTHO_DCGS2.      */
 } nk_ortho;
 
 typedef enum { NK_FORCING_NONE = 0, NK_FORCING_EISENSTAT_WALKER2 = 1 } nk_forcing;
@@ -236,6 +241,8 @@ typedef struct {
    *     evolution relaxation α⁻¹ ← α⁻¹·‖f‖₂/‖f_prev‖₂; mass matrix: identity, or a diagonal through
    *     nk_solver_set_mass_matrix_diagonal */
   double  pt_alpha_initial;             /* [1e-3] initial pseudo time step α                                          */
+  int32_t gmres_sstep;                  /* [6]    NK_ORTHO_SSTEP: basis columns per block (1..8)                      */
+  int32_t reserved_tail;                /* [0]    keeps the struct a multiple of 8 bytes                              */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -389,6 +396,8 @@ int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* on != 0: the operator of the next solves is AᵀA for the CSR / problem operator that is set (normal form: the
  * transposed half is the distributed transposed SpMV or the problem's VJP); the caller passes b = Aᵀ f. */
 int nk_gmres_set_normal_form(nk_gmres *G, int on);   /* AbstractSciMLOperator    */
+/* NK_ORTHO_SSTEP: number of basis columns per block, 1..8 (the last block of a cycle is cut to fit the restart length) */
+int nk_gmres_set_block_size(nk_gmres *G, int s);
 /* Damped normal form: the operator becomes AᵀA + lambda·diag(d) (d: DEVICE vector of local length n, kept by reference;
  * NULL switches the damping off) — `dampen_jacobian!!(J_cache, JᵀJ, λ·DᵀD)` of DampedNewtonDescent's :normal_form mode
  * (lib/NonlinearSolveBase/src/descent/damped_newton.jl:297-313,356-370) without assembling JᵀJ. */

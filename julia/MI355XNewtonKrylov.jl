@@ -349,6 +349,7 @@ Base.@kwdef mutable struct NKOptions
     lm_min_damping_D::Float64 = 1e-8; lm_alpha_geodesic::Float64 = 0.75; lm_finite_diff_step_geodesic::Float64 = 0.1
     lm_b_uphill::Float64 = 1.0
     pt_alpha_initial::Float64 = 1e-3
+    gmres_sstep::Int32 = 6; reserved_tail::Int32 = 0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,

@@ -22,7 +22,7 @@ RET_NAMES = ["Default", "Success", "MaxIters", "Unstable", "Stalled", "InternalL
 PROBLEM_QUADRATIC, PROBLEM_BRATU2D, PROBLEM_BRUSSELATOR2D, PROBLEM_USER = 1, 2, 3, 100
 ALG_NEWTON_RAPHSON, ALG_TRUST_REGION, ALG_GAUSS_NEWTON, ALG_LEVENBERG_MARQUARDT, ALG_PSEUDO_TRANSIENT = 0, 1, 2, 3, 4
 LINSOLVE_GMRES_MATFREE, LINSOLVE_GMRES_CSR, LINSOLVE_BANDED_LU = 0, 1, 2
-ORTHO_MGS, ORTHO_CGS2, ORTHO_CGS, ORTHO_DCGS2, ORTHO_DCGS2_1R = 0, 1, 2, 3, 4
+ORTHO_MGS, ORTHO_CGS2, ORTHO_CGS, ORTHO_DCGS2, ORTHO_DCGS2_1R, ORTHO_SSTEP = 0, 1, 2, 3, 4, 5
 FORCING_NONE, FORCING_EW2 = 0, 1
 COMM_NONE, COMM_RCCL, COMM_CALLBACKS = 0, 1, 2
 
@@ -72,6 +72,8 @@ class Options(C.Structure):
         ("lm_damping_decrease_factor", C.c_double), ("lm_min_damping_D", C.c_double),
         ("lm_alpha_geodesic", C.c_double), ("lm_finite_diff_step_geodesic", C.c_double), ("lm_b_uphill", C.c_double),
         ("pt_alpha_initial", C.c_double),
+        ("gmres_sstep", C.c_int32),
+        ("reserved_tail", C.c_int32),
     ]
 
 
@@ -131,6 +133,7 @@ SIGNATURES = {
     "nk_csr_colsumsq": (_I, [_P, _P, _I]),
     "nk_gmres_set_normal_form_damping": (_I, [_P, _P, C.c_double]),
     "nk_gmres_set_shift": (_I, [_P, C.c_double]),
+    "nk_gmres_set_block_size": (_I, [_P, _I]),
     "nk_gmres_set_shift_weights": (_I, [_P, _P]),
     "nk_problem_create": (_I, [_P, _I, C.POINTER(_D), _I, _PP]),
     "nk_problem_create_user": (_I, [_P, _L, _L, _L, C.POINTER(UserCallbacks), _P, _P, _PP]),

@@ -549,8 +549,9 @@ class KrylovJL_GMRES:
     """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
     gmres_restart: int = 30
     maxiters: int = 300
-    ortho: str = "dcgs2"       # "mgs" (Krylov.jl's structure) | "cgs2" | "dcgs2" (= cgs2, delayed 2nd pass) | "cgs"
+    ortho: str = "dcgs2"       # "mgs" (Krylov.jl's structure) | "cgs2" | "dcgs2" (= cgs2, delayed 2nd pass) | "cgs" | "sstep"
     fixed_iters: int = 0
+    sstep: int = 6             # ortho = "sstep": basis columns per block (1..8)
     abstol: Optional[float] = None   # None → the nonlinear tolerances are forwarded (FirstOrder/src/solve.jl:203)
     reltol: Optional[float] = None
     precs: Optional[ChebyshevPrecs] = None
@@ -707,7 +708,8 @@ TERMINATION_CONDITIONS = [  # common/common_rootfind_testing.jl:3-13
     AbsNormSafeBestTerminationMode,
 ]
 
-_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2": L.ORTHO_DCGS2, "dcgs2_1r": L.ORTHO_DCGS2_1R}
+_ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2": L.ORTHO_DCGS2, "dcgs2_1r": L.ORTHO_DCGS2_1R,
+          "sstep": L.ORTHO_SSTEP}
 
 
 def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,
@@ -745,6 +747,7 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o.maxtime = 0.0 if maxtime is None else float(maxtime)
     o.gmres_restart, o.gmres_maxiters = int(ls.gmres_restart), int(ls.maxiters)
     o.gmres_ortho, o.gmres_fixed_iters = _ORTHO[ls.ortho], int(ls.fixed_iters)
+    o.gmres_sstep = int(getattr(ls, "sstep", 6))
     o.lin_abstol = -1.0 if ls.abstol is None else float(ls.abstol)
     o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
     lsr = getattr(alg, "linesearch", None)
@@ -989,10 +992,12 @@ def reinit_(cache, u0=None, p=None, **kw):  # reinit!(cache, u0; p[, retain_best
 class GMRES:
     """nk_gmres: the LinearCache analogue NonlinearSolveBase drives (A, b, u, reltol; solve!)."""
 
-    def __init__(self, n: int, restart: int = 30, ortho: str = "dcgs2", ctx: Optional[Context] = None):
+    def __init__(self, n: int, restart: int = 30, ortho: str = "dcgs2", ctx: Optional[Context] = None, sstep: int = 6):
         self.ctx = ctx or default_context()
         h = C.c_void_p()
         check(L.lib().nk_gmres_create(self.ctx._h, n, restart, _ORTHO[ortho], C.byref(h)))
+        if ortho == "sstep":
+            check(L.lib().nk_gmres_set_block_size(h, int(sstep)))
         self._h, self.n, self._keep = h, n, []
         self.abstol, self.reltol, self.maxiters = 0.0, 1e-8, 300
 

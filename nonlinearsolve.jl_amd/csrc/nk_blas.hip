@@ -639,6 +639,12 @@ int nk_blas_dcgs2r_axpy(nk_ctx *ctx, int64_t n, int k, double *V, int64_t ldv, c
 }
 
 // *d_out = Σ partials[0..nblk) in the fixed stage-2 order, all-reduced
+// nslots sums of nblk partials each (slot-major), one workgroup per slot
+int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip) {
+  NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), partials, nblk, d_out, d_skip, (const double *)nullptr, 0);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
 int nk_blas_reduce_one(nk_ctx *ctx, const double *partials, int nblk, double *d_out, const int *d_skip) {
   NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), partials, nblk, d_out, d_skip, (const double *)nullptr, 0);
   NK_HIP(hipGetLastError());

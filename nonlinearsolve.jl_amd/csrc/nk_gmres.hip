@@ -668,7 +668,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
   if (restart_m <= 0) restart_m = 30;
   NK_REQUIRE(restart_m < NK_MAX_NV, "restart m=%d too large (max %d)", restart_m, NK_MAX_NV - 1);
   NK_REQUIRE(ortho == NK_ORTHO_MGS || ortho == NK_ORTHO_CGS2 || ortho == NK_ORTHO_CGS || ortho == NK_ORTHO_DCGS2 ||
-                 ortho == NK_ORTHO_DCGS2_1R,
+                 ortho == NK_ORTHO_DCGS2_1R || ortho == NK_ORTHO_SSTEP,
              "bad ortho %d", ortho);
   NK_HIP(hipSetDevice(ctx->device));
   nk_gmres *G = new nk_gmres();
@@ -722,6 +722,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
   hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb); hipFree(G->d_tprev); hipFree(G->d_red);
   nk_mg_destroy(G->mg);
+  nk_ss_destroy(G->ss);
   if (G->gexec) hipGraphExecDestroy(G->gexec);
   if (G->cap_stream) hipStreamDestroy(G->cap_stream);
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
@@ -732,6 +733,12 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipHostFree(G->h_pub);
   if (G->h_stage) hipHostFree(G->h_stage);
   delete G;
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_block_size(nk_gmres *G, int s) {
+  NK_REQUIRE(G, "NULL argument");
+  NK_REQUIRE(s >= 1 && s <= 8, "s-step block size %d outside 1..8", s);
+  G->ss_s = s;
   return NK_OK;
 }
 extern "C" int nk_gmres_set_operator_csr(nk_gmres *G, nk_csr *A) {
@@ -1154,6 +1161,10 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
   return op_apply_raw(G, src, d_y, d_skip, oscale);
 }
 
+int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale) {
+  return op_apply(G, d_x, d_y, d_skip, d_scale);
+}
+
 // ----------------------------------------------------------------------------- DCGS2, one reduction per step
 // eligible: built-in linear operators (they take the un-normalised pending column as it is) and no callback preconditioner
 static bool dcgs2r_eligible(const nk_gmres *G) {
@@ -1414,13 +1425,32 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol,
                        fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m, G->h_pub_dev, seq);
     first = 0;
+    const bool x_is_zero_before = x_is_zero;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
     // The cycle is enqueued without a host synchronisation; kernels after convergence return at once on the device flag.
     // The device also publishes a progress word (cycle sequence, columns closed, done) in coherent pinned memory, which the
     // host merely reads: when the solve can stop early (a tolerance is set) the host keeps at most `run_ahead` Arnoldi steps
     // in the queue ahead of the device and stops enqueueing as soon as `done` shows — otherwise every step after
     // convergence would still cost its no-op launches (≈ 70 per step with a multigrid V-cycle inside).
-    {
+    if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
+      // s columns per block (nk_sstep.hip). With a tolerance set and one rank, the host stays one block ahead of the device
+      // and stops enqueueing once the cycle is done; several ranks enqueue the whole cycle (every rank must issue the same
+      // collectives), the kernels past convergence return on the device flag.
+      std::function<bool(int)> wait_progress;
+      if (fixed_iters <= 0 && G->run_ahead > 0 && nk_ctx_is_single(ctx))
+        wait_progress = [&](int need) -> bool {
+          bool is_done = false;
+          auto ready = [&] {
+            const uint64_t w = __atomic_load_n(&pub->progress, __ATOMIC_ACQUIRE);
+            if ((w >> 16) != seq) return false;
+            if (w & 1) { is_done = true; return true; }
+            return (int)((w >> 1) & 0x7fff) >= need;
+          };
+          if (nk_spin_wait(ctx, ready, "GMRES progress") != NK_OK) return false;
+          return !is_done;
+        };
+      NK_TRY(nk_ss_cycle(G, steps, wait_progress));
+    } else {
       const bool one_red = use_dcgs2r(G);
       const int ahead = (fixed_iters > 0 || G->run_ahead <= 0) ? 0 : (G->prec_kind == 3 ? 1 : G->run_ahead);
       // Every rank must enqueue the SAME number of steps (each carries collectives): the stop is therefore not "when this
@@ -1480,6 +1510,18 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     inf.rnorm = c.rnorm;
     inf.converged = c.converged;
     inf.failed = c.failed;
+    if (c.failed == 2 && G->ortho == NK_ORTHO_SSTEP) {
+      // a block of the monomial basis lost rank numerically (Cholesky breakdown): x is untouched by this cycle (y = 0);
+      // redo the rest of the solve with the column-by-column scheme
+      G->ss_breakdowns++;
+      G->ortho = NK_ORTHO_DCGS2;
+      nk_gmres_info rest;
+      NK_TRY(nk_gmres_solve_dev(G, d_b, d_x, x_is_zero_before ? 0 : 1, atol, rtol, cap - (total_iters - c.k), fixed_iters > 0 ? cap - (total_iters - c.k) : 0, &rest));
+      rest.iters += total_iters - c.k;
+      rest.restarts += inf.restarts;
+      if (info) *info = rest;
+      return NK_OK;
+    }
     if (c.failed || c.converged || total_iters >= cap || steps == 0) break;
     inf.restarts++;
     // restart: r = b − A x into column 0

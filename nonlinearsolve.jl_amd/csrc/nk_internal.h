@@ -1,6 +1,7 @@
 // Internal declarations of libmi355x_nk.so (gfx950 only). Not part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -424,9 +425,23 @@ struct nk_gmres {
   bool graph_broken = false;
   const void *gkey[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int gsteps = 0;
+  // NK_ORTHO_SSTEP (nk_sstep.hip): s basis columns per block — matrix powers, then block CGS in Pythagorean form, twice
+  struct nk_sstep *ss = nullptr;
+  int ss_s = 6;           // block size s (1..8)
+  int ss_breakdowns = 0;  // Cholesky breakdowns of a block (the solve was redone with delayed CGS2)
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info);
+
+// s-step Arnoldi (nk_sstep.hip)
+int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale);  // y = scale·A M⁻¹ x
+bool nk_ss_eligible(const nk_gmres *G);
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
+void nk_ss_destroy(struct nk_sstep *W);
+int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
+int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
+                const int *d_skip, int grid);
+int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 
 // ----------------------------------------------------------------------------- banded LU (direct linsolve, C2)
 struct nk_bandlu {

@@ -217,6 +217,8 @@ extern "C" int nk_options_default(nk_options *o) {
   o->lm_finite_diff_step_geodesic = 0.1;
   o->lm_b_uphill = 1.0;
   o->pt_alpha_initial = 1e-3;  // PseudoTransient() (pseudo_transient.jl:38)
+  o->gmres_sstep = 6;
+  o->reserved_tail = 0;
   return NK_OK;
 }
 
@@ -592,6 +594,7 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     NK_TRY(nk_dev_alloc(&S->stage, na));
   } else {
     NK_TRY(nk_gmres_create(ctx, n, S->o.gmres_restart, S->o.gmres_ortho, &S->G));
+    if (S->o.gmres_sstep >= 1 && S->o.gmres_sstep <= 8) NK_TRY(nk_gmres_set_block_size(S->G, S->o.gmres_sstep));
     if (concrete(S)) NK_TRY(nk_gmres_set_operator_csr(S->G, S->J));
   }
   NK_HIP(hipMemcpyAsync(S->u, u0, n * sizeof(double),

@@ -1,0 +1,552 @@
+// s-step (communication-avoiding) Arnoldi for GMRES(m): the basis grows s columns at a time.
+//
+//   matrix powers   W = [A v_k, A² v_k, …, Aˢ v_k] / σ^j          (s operator applications, monomial basis, σ a power of two)
+//   block CGS, Pythagorean form, twice (BCGS-PIP2):
+//     sweep A   [V_k W]ᵀ W                       → C₁ = V_kᵀW, G₁ = WᵀW          one pass over k + s columns
+//     tail 1    R₁ᵀR₁ = G₁ − C₁ᵀC₁ (Cholesky)
+//     sweep B   Q₁ = (W − V_k C₁) R₁⁻¹ in place, and [V_k Q₁]ᵀ Q₁ of the result   one pass (read k + s, write s)
+//     tail 2    R₂ᵀR₂ = G₂ − C₂ᵀC₂ ; C = C₁ + C₂R₁ ; R = R₂R₁ ; the s new Hessenberg columns from (C, R) and the old ones ;
+//               Givens rotations, residual norms, stopping test
+//     sweep C   Q = (Q₁ − V_k C₂) R₂⁻¹ in place                                   one pass
+//
+// Three sweeps over the basis per s columns instead of two per column (delayed CGS2, nk_blas.hip): the basis traffic of a
+// restart cycle falls by 2s/3. The sweeps are HBM-bound; the skinny Gram products [V_k W]ᵀW — (k+s)·s accumulators, far more
+// than a thread can hold — run on the FP64 matrix cores (v_mfma_f64_16x16x4: rows are the reduction dimension, so a wavefront
+// keeps a 16×16 tile of sums in 4 VGPR pairs per lane and needs no cross-lane reduction until the very end).
+//
+// Data movement of a sweep: a workgroup takes tiles of 256 rows (one row per thread, coalesced 2 KB per column per
+// workgroup), applies the update in registers while the columns stream past, parks the tile in LDS (column-major, odd pitch:
+// the MFMA operand reads — 16 columns × 4 rows per instruction — are conflict-free), and the four wavefronts accumulate the
+// Gram tile from LDS. Workgroups are persistent (2 per CU), so the partial sums leave the chip once per launch.
+#include "nk_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+constexpr int SS_R = 256;        // rows per tile = threads per workgroup
+constexpr int SS_P = SS_R + 1;   // LDS pitch in doubles (odd)
+constexpr int SS_MTMAX = 5;      // Gram tiles of 16 rows: k + s ≤ 80
+constexpr int SS_SMAX = 8;
+typedef double ss_d4 __attribute__((ext_vector_type(4)));
+
+// coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
+// then R⁻¹ (S × S, row-major, upper triangular)
+// MTC = 1, 2, 3: k + S ≤ 16·MTC. The k + S values of a thread's row live in registers and the NEXT tile's loads are issued
+// before the matrix-core phase of the current one — the LDS tile bounds the occupancy at 2 workgroups per CU, which then keep
+// ≈ 2 × (k+S) × 2 KB of loads in flight per CU through both phases; the Gram block is exactly MTC tiles of 16 rows.
+// MTC = 0: any k ≤ 80 − S, the columns stream past eight at a time (no prefetch), five Gram tiles.
+template <int S, bool UPDATE, bool GRAM, int MTC>
+__global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__restrict__ V, int64_t ldv,
+                                                   const double *__restrict__ coef, double *__restrict__ partials,
+                                                   const int *d_skip, int ntiles) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  extern __shared__ double sX[];
+  constexpr int NT = MTC > 0 ? MTC : SS_MTMAX;         // Gram tiles this instantiation accumulates
+  constexpr int NVR = MTC > 0 ? 16 * MTC - S : 1;      // basis values a thread holds (k ≤ NVR)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int K = k + S;
+  ss_d4 acc[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
+  double *__restrict__ Wc = V + (size_t)k * ldv;
+  const double *__restrict__ Rinv = coef + (size_t)k * S;
+  double vr[NVR], w[S];
+  auto prefetch = [&](int tile) {
+    const int64_t r = (int64_t)tile * SS_R + t;
+    const int64_t rc = r < n ? r : n - 1;
+#pragma unroll
+    for (int c = 0; c < S; ++c) w[c] = Wc[(size_t)c * ldv + rc];
+    if (MTC > 0) {
+#pragma unroll
+      for (int j = 0; j < NVR; ++j)
+        if (j < k) vr[j] = V[(size_t)j * ldv + rc];
+    }
+  };
+  // operand addresses of the matrix-core phase. Lane (i, q4) supplies A[i][q4] = X[row + q4][16·mt + i] and
+  // B[q4][i] = X[row + q4][k + i]; columns past the end are clamped to the last one: they only feed rows ≥ K / columns ≥ S of
+  // the accumulator tiles, which are never stored — no masks, no branches.
+  const int li = lane & 15, q4 = lane >> 4;
+  const double *pb = sX + (k + (li < S ? li : S - 1)) * SS_P + wv * 64 + q4;
+  const double *pa[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    const int col = mt * 16 + li;
+    pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
+  }
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r = (int64_t)tile * SS_R + t;
+    const bool ok = r < n;
+    if (MTC > 0) {
+#pragma unroll
+      for (int j = 0; j < NVR; ++j) {
+        if (j < k) {
+          if (GRAM) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
+          if (UPDATE) {
+#pragma unroll
+            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], coef[j * S + c], w[c]);
+          }
+        }
+      }
+    } else {
+      const int64_t rc = ok ? r : n - 1;
+      constexpr int U = 8;
+      for (int j0 = 0; j0 < k; j0 += U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u < k ? j0 + u : k - 1;
+          v[u] = V[(size_t)j * ldv + rc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (j0 + u < k) {
+            const int j = j0 + u;
+            if (GRAM) sX[j * SS_P + t] = ok ? v[u] : 0.0;
+            if (UPDATE) {
+#pragma unroll
+              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], coef[j * S + c], w[c]);
+            }
+          }
+        }
+      }
+    }
+    if (UPDATE) {
+      double q[S];
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        double a = 0.0;
+#pragma unroll
+        for (int cc = 0; cc <= c; ++cc) a = __builtin_fma(w[cc], Rinv[cc * S + c], a);
+        q[c] = a;
+      }
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        w[c] = q[c];
+        if (ok) Wc[(size_t)c * ldv + r] = q[c];
+      }
+    }
+    if (GRAM) {
+#pragma unroll
+      for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
+      __syncthreads();
+    }
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);   // in flight through the matrix-core phase
+    if (GRAM) {
+      // 64 rows per wavefront, 4 per instruction; operands of four instructions are requested together
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) {
+        double bb[4], aa[NT][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          bb[u] = pb[(kk + u) * 4];
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) aa[mt][u] = pa[mt][(kk + u) * 4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[mt][u], bb[u], acc[mt], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (GRAM) {
+    // the four wavefronts' tiles → one partial per (basis column, new column) and workgroup; fixed order
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sX[((wv * NT + mt) * 4 + rr) * 64 + lane] = acc[mt][rr];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      const int rr = t >> 6, ln = t & 63;
+      const int mrow = mt * 16 + (ln >> 4) + 4 * rr, ncol = ln & 15;
+      if (mrow < K && ncol < S) {
+        const int e = (mt * 4 + rr) * 64 + ln;
+        const double sum = (sX[e] + sX[NT * 256 + e]) + (sX[2 * NT * 256 + e] + sX[3 * NT * 256 + e]);
+        partials[(size_t)(mrow * S + ncol) * gridDim.x + blockIdx.x] = sum;
+      }
+    }
+  }
+}
+
+static size_t ss_lds_bytes(int k, int s, bool gram) {
+  if (!gram) return 0;
+  const size_t a = (size_t)(k + s) * SS_P, b = (size_t)4 * SS_MTMAX * 256;
+  return (a > b ? a : b) * sizeof(double);
+}
+int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
+  const int ntiles = (int)((n + SS_R - 1) / SS_R);
+  const size_t lds = ss_lds_bytes(k, s, true);
+  const int per_cu = lds > 80 * 1024 ? 1 : 2;
+  int g = ctx->num_cus * per_cu;
+  if (g > ntiles) g = ntiles;
+  return g > 0 ? g : 1;
+}
+
+template <int S>
+static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
+                       const int *d_skip, int grid) {
+  const int ntiles = (int)((n + SS_R - 1) / SS_R);
+  const size_t lds = ss_lds_bytes(k, S, mode != 2);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
+#define SS_GO2(UPD, GRM, KM)                                                                                              \
+  do {                                                                                                                    \
+    if (lds > 64 * 1024)                                                                                                  \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block<S, UPD, GRM, KM>),                            \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
+    if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, k,  \
+                                  V, ldv, coef, partials, d_skip, ntiles);                                           \
+    else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef,     \
+                            partials, d_skip, ntiles);                                                               \
+  } while (0)
+#define SS_GO(UPD, GRM)                                                                                                   \
+  do {                                                                                                                    \
+    if (k + S <= 16) SS_GO2(UPD, GRM, 1);                                                                                 \
+    else if (k + S <= 32) SS_GO2(UPD, GRM, 2);                                                                            \
+    else if (k + S <= 48) SS_GO2(UPD, GRM, 3);                                                                            \
+    else SS_GO2(UPD, GRM, 0);                                                                                             \
+  } while (0)
+  int g = grid;
+  if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
+  else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
+  else {                                    // sweep C: update only — no LDS tile, so the occupancy is not bounded by it
+    g = ctx->num_cus * 6 < ntiles ? ctx->num_cus * 6 : ntiles;
+    SS_GO(true, false);
+  }
+#undef SS_GO
+#undef SS_GO2
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+// mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them
+int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
+                const int *d_skip, int grid) {
+  NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
+             16 * SS_MTMAX);
+  NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
+  switch (s) {
+    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    default: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+  }
+}
+
+// ----------------------------------------------------------------------------- development harness (not in the public header)
+// Runs one sweep on caller data: V (n × (k+s), column-major, leading dimension n, HOST), coef (k·s + s·s, HOST); returns the
+// updated columns, the reduced Gram block ((k+s) × s, row-major) and the average kernel time over `iters` launches.
+extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V_host, const double *coef_host,
+                                double *gram_out, int iters, double *avg_us) {
+  NK_REQUIRE(ctx && V_host, "NULL argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  double *dV = nullptr, *dc = nullptr, *dp = nullptr;
+  const int grid = nk_ss_grid(ctx, n, k, s);
+  const size_t nv = (size_t)n * (k + s), nslots = (size_t)(k + s) * s;
+  NK_TRY(nk_dev_alloc(&dV, nv));
+  NK_TRY(nk_dev_alloc(&dc, (size_t)k * s + s * s + 1));
+  NK_TRY(nk_dev_alloc(&dp, nslots * grid + 1));
+  NK_HIP(hipMemcpy(dV, V_host, nv * sizeof(double), hipMemcpyHostToDevice));
+  if (coef_host) NK_HIP(hipMemcpy(dc, coef_host, ((size_t)k * s + s * s) * sizeof(double), hipMemcpyHostToDevice));
+  NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  NK_HIP(hipMemcpy(V_host, dV, nv * sizeof(double), hipMemcpyDeviceToHost));
+  if (mode != 2 && gram_out) {
+    std::vector<double> hp(nslots * grid);
+    NK_HIP(hipMemcpy(hp.data(), dp, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < nslots; ++e) {
+      double a = 0.0;
+      for (int b = 0; b < grid; ++b) a += hp[e * grid + b];
+      gram_out[e] = a;
+    }
+  }
+  if (iters > 0 && avg_us) {
+    hipEvent_t e0, e1;
+    NK_HIP(hipEventCreate(&e0));
+    NK_HIP(hipEventCreate(&e1));
+    NK_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; ++i) NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid));
+    NK_HIP(hipEventRecord(e1, ctx->stream));
+    NK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    NK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = 1e3 * ms / iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+  }
+  hipFree(dV);
+  hipFree(dc);
+  hipFree(dp);
+  return NK_OK;
+}
+
+// ============================================================================= the block tails (one workgroup)
+__device__ __forceinline__ void ss_pub_progress(nk_gmres_pub *pub, uint64_t seq, int k, int done) {
+  if (pub != nullptr)
+    __hip_atomic_store(&pub->progress, (seq << 16) | ((uint64_t)k << 1) | (uint64_t)(done ? 1 : 0), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr int SS_KMAX = 16 * SS_MTMAX;  // k + s ≤ 80
+
+// Shared by both tails: from the reduced block [V_kᵀX ; XᵀX] (X = the s columns behind V_k; `sc` un-normalised-column
+// scales) the true coefficients Ct = diag(sc)·V_kᵀX, the Cholesky factor R of XᵀX − CtᵀCt (Pythagorean form of ‖X − V Ct‖)
+// and R⁻¹. Returns false on a non-positive or non-finite pivot (the monomial block lost rank numerically).
+__device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, double *Ct /*k×sb*/,
+                          double *Rm /*sb×sb*/, double *Ri /*sb×sb*/, double *Sm /*sb×sb*/, int *s_ok) {
+  const int t = threadIdx.x;
+  for (int e = t; e < k * sb; e += blockDim.x) Ct[e] = sc[e / sb] * red[e];
+  __syncthreads();
+  if (t < sb * sb) {
+    const int a = t / sb, b = t % sb;
+    double s = red[(size_t)(k + a) * sb + b];
+    for (int j = 0; j < k; ++j) s = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s);
+    Sm[t] = s;
+    Rm[t] = 0.0;
+    Ri[t] = 0.0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int ok = 1;
+    for (int a = 0; a < sb && ok; ++a) {  // upper-triangular R with RᵀR = S, row by row
+      double d = Sm[a * sb + a];
+      for (int p = 0; p < a; ++p) d -= Rm[p * sb + a] * Rm[p * sb + a];
+      if (!(d > 0.0) || isinf(d)) { ok = 0; break; }
+      const double raa = sqrt(d);
+      Rm[a * sb + a] = raa;
+      for (int b = a + 1; b < sb; ++b) {
+        double v = 0.5 * (Sm[a * sb + b] + Sm[b * sb + a]);
+        for (int p = 0; p < a; ++p) v -= Rm[p * sb + a] * Rm[p * sb + b];
+        Rm[a * sb + b] = v / raa;
+      }
+    }
+    if (ok) {  // R⁻¹ (upper), column by column
+      for (int b = 0; b < sb; ++b) {
+        Ri[b * sb + b] = 1.0 / Rm[b * sb + b];
+        for (int a = b - 1; a >= 0; --a) {
+          double v = 0.0;
+          for (int p = a + 1; p <= b; ++p) v -= Rm[a * sb + p] * Ri[p * sb + b];
+          Ri[a * sb + b] = v / Rm[a * sb + a];
+        }
+      }
+    }
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// tail 1: coefficients of sweep B; C₁ and R₁ are kept for tail 2; σ estimate for the next cycle from ‖A v‖ of the first block
+__global__ __launch_bounds__(256) void k_ss_tail1(nk_gmres_ctl *ctl, int k, int sb, const double *__restrict__ red,
+                                                  const double *__restrict__ sc, double *__restrict__ coef,
+                                                  double *__restrict__ C1, double *__restrict__ R1, double *scal,
+                                                  nk_gmres_pub *pub, uint64_t seq) {
+  __shared__ double Ct[SS_KMAX * SS_SMAX], Rm[64], Ri[64], Sm[64];
+  __shared__ int s_ok;
+  if (ctl->done) return;
+  const int t = threadIdx.x;
+  const bool ok = ss_factor(k, sb, red, sc, Ct, Rm, Ri, Sm, &s_ok);
+  if (!ok) {
+    if (t == 0) { ctl->failed = 2; ctl->done = 1; ss_pub_progress(pub, seq, ctl->k, 1); }
+    return;
+  }
+  for (int e = t; e < k * sb; e += 256) { C1[e] = Ct[e]; coef[e] = sc[e / sb] * Ct[e]; }
+  if (t < sb * sb) { R1[t] = Rm[t]; coef[(size_t)k * sb + t] = Ri[t]; }
+  if (t == 0 && k == 1) {  // ‖A v₁‖ = σ·√(XᵀX)₀₀: the scale of the next cycle's monomial basis, rounded to a power of two
+    const double est = scal[2] * sqrt(red[(size_t)k * sb]);
+    if (est > 0.0 && !isinf(est)) scal[3] = exp2(rint(log2(est)));
+  }
+}
+
+// tail 2: coefficients of sweep C; C = C₁ + C₂R₁, R = R₂R₁; the s new Hessenberg columns; Givens, residual norms, stopping test.
+// Coordinates in the basis [V_k Q] (K = k + s): X_j (column j of the block, j = 0..s−1) = F[:, j] = [C_j ; R_j], and
+//   A v_k = σ X_0 ;  A X_{j−1} = σ X_j ;  q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}   (j = 1..s−1)
+// so the coordinates of A q_j follow from those of A v_1..A v_{k−1} (the old Hessenberg columns), A v_k and A q_1..A q_{j−1}.
+__global__ __launch_bounds__(256) void k_ss_tail2(nk_gmres_ctl *ctl, int k, int sb, const double *__restrict__ red,
+                                                  double *__restrict__ sc, double *__restrict__ coef,
+                                                  const double *__restrict__ C1, const double *__restrict__ R1,
+                                                  double *__restrict__ H, int m, double *__restrict__ Rg, double *cs, double *sn,
+                                                  double *g, double *scal, nk_gmres_pub *pub, uint64_t seq) {
+  __shared__ double Ct[SS_KMAX * SS_SMAX], Rm[64], Ri[64], Sm[64], R1s[64];
+  __shared__ double F[SS_KMAX * SS_SMAX], NC[SS_SMAX * SS_KMAX];
+  __shared__ int s_ok;
+  const int t = threadIdx.x;
+  if (ctl->done) {
+    if (t == 0) ctl->pad1 = 1;  // the block never started: sweep C has nothing to finish
+    return;
+  }
+  const int K = k + sb;
+  const bool ok = ss_factor(k, sb, red, sc, Ct, Rm, Ri, Sm, &s_ok);
+  if (!ok) {
+    if (t == 0) { ctl->failed = 2; ctl->done = 1; ctl->pad1 = 1; ss_pub_progress(pub, seq, ctl->k, 1); }
+    return;
+  }
+  for (int e = t; e < k * sb; e += 256) coef[e] = sc[e / sb] * Ct[e];
+  if (t < sb * sb) { coef[(size_t)k * sb + t] = Ri[t]; R1s[t] = R1[t]; }
+  __syncthreads();
+  for (int e = t; e < k * sb; e += 256) {  // C = C₁ + C₂ R₁
+    const int j = e / sb, c = e % sb;
+    double v = C1[e];
+    for (int a = 0; a <= c; ++a) v = __builtin_fma(Ct[j * sb + a], R1s[a * sb + c], v);
+    F[e] = v;
+  }
+  if (t < sb * sb) {  // R = R₂ R₁ (upper)
+    const int a = t / sb, c = t % sb;
+    double v = 0.0;
+    for (int p = a; p <= c; ++p) v = __builtin_fma(Rm[a * sb + p], R1s[p * sb + c], v);
+    F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
+  }
+  __syncthreads();
+  const double sigma = scal[2];
+  if (t < K) NC[t] = sigma * F[t * sb];
+  __syncthreads();
+  for (int j = 1; j < sb; ++j) {
+    if (t < K) {
+      const int i = t;
+      double a = sigma * F[i * sb + j];
+      for (int tt = (i > 0 ? i - 1 : 0); tt < k - 1; ++tt) a = __builtin_fma(-H[(size_t)i * m + tt], F[tt * sb + (j - 1)], a);
+      a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
+      for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * SS_KMAX + i], F[(k + q - 1) * sb + (j - 1)], a);
+      NC[j * SS_KMAX + i] = a / F[(k + j - 1) * sb + (j - 1)];
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < sb * K; e += 256) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
+    const int j = e / K, i = e % K, jc = k - 1 + j;
+    if (i <= jc + 1 && jc < m) H[(size_t)i * m + jc] = NC[j * SS_KMAX + i];
+  }
+  if (t == 0) {
+    const double tol = ctl->tol;
+    int closed = 0, dn = 0;
+    for (int j = 0; j < sb && !dn; ++j) {
+      const int jc = k - 1 + j;
+      double *h = &NC[j * SS_KMAX];
+      for (int i = 0; i < jc; ++i) {
+        const double a = h[i], b = h[i + 1];
+        Rg[(size_t)i * m + jc] = cs[i] * a + sn[i] * b;
+        h[i + 1] = -sn[i] * a + cs[i] * b;
+      }
+      const double hk = h[jc], beta = h[jc + 1];
+      const double d = hypot(hk, beta);
+      double c, sg;
+      if (d == 0.0) { c = 1.0; sg = 0.0; } else { c = hk / d; sg = beta / d; }
+      cs[jc] = c;
+      sn[jc] = sg;
+      Rg[(size_t)jc * m + jc] = d;
+      const double gj = g[jc];
+      g[jc + 1] = -sg * gj;
+      g[jc] = c * gj;
+      const double rn = fabs(sg * gj);
+      closed = j + 1;
+      ctl->rnorm = rn;
+      ctl->hn = beta;
+      if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; dn = 1; }
+      else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
+      else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
+    }
+    ctl->k = k - 1 + closed;
+    ctl->pad1 = 0;
+    if (dn) ctl->done = 1;
+    for (int c = 0; c < sb; ++c) sc[k + c] = 1.0;  // the new columns are normalised
+    scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
+    ss_pub_progress(pub, seq, ctl->k, dn);
+  }
+}
+
+// start of a cycle (after k_gmres_begin): the scale of the monomial basis and of the first operator application
+__global__ void k_ss_begin(const double *__restrict__ s, double *scal) {
+  if (threadIdx.x != 0) return;
+  double sigma = scal[3];
+  if (!(sigma > 0.0) || isinf(sigma)) sigma = 1.0;
+  scal[2] = sigma;
+  scal[1] = 1.0 / sigma;
+  scal[0] = s[0] / sigma;
+}
+
+// ============================================================================= one restart cycle, s columns at a time
+struct nk_sstep {
+  int s = 0, grid = 0;
+  double *part = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
+};
+void nk_ss_destroy(nk_sstep *W) {
+  if (!W) return;
+  hipFree(W->part); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
+  delete W;
+}
+static int ss_workspace(nk_gmres *G) {
+  if (G->ss) return NK_OK;
+  nk_sstep *W = new nk_sstep();
+  auto guard = nk_make_guard(W, [](nk_sstep *w) { nk_ss_destroy(w); });
+  const int m = G->m;
+  W->grid = G->ctx->num_cus * 2;
+  const size_t nslots = (size_t)(m + 1 + SS_SMAX) * SS_SMAX;
+  NK_TRY(nk_dev_alloc(&W->part, nslots * W->grid + 1));
+  NK_TRY(nk_dev_alloc(&W->red, nslots + 1));
+  NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
+  NK_TRY(nk_dev_alloc(&W->C1, nslots + 1));
+  NK_TRY(nk_dev_alloc(&W->R1, (size_t)64));
+  NK_TRY(nk_dev_alloc(&W->H, (size_t)(m + 2 + SS_SMAX) * m));
+  NK_TRY(nk_dev_alloc(&W->scal, (size_t)8));
+  NK_HIP(hipMemset(W->scal, 0, 8 * sizeof(double)));
+  NK_HIP(hipMemset(W->H, 0, (size_t)(m + 2 + SS_SMAX) * m * sizeof(double)));
+  G->ss = guard.release();
+  return NK_OK;
+}
+bool nk_ss_eligible(const nk_gmres *G) { return G->m + 1 <= SS_KMAX - 1 && G->n > 0; }
+
+// Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of G->ss_s (the last block may be shorter). k_gmres_begin
+// has run. `wait_progress(need)` (may be empty) blocks the host until `need` columns are closed or the cycle is done and
+// returns false when no further block should be enqueued.
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress) {
+  nk_ctx *ctx = G->ctx;
+  NK_TRY(ss_workspace(G));
+  nk_sstep *W = G->ss;
+  const int64_t n = G->n, ldv = G->ldv;
+  const int s = G->ss_s > 0 ? (G->ss_s > SS_SMAX ? SS_SMAX : G->ss_s) : 6;
+  const int *done = &G->d_ctl->done, *skipC = &G->d_ctl->pad1;
+  const bool single = nk_ctx_is_single(ctx);
+  NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal);
+  int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
+  while (k - 1 < steps) {
+    const int sb = (steps - (k - 1)) < s ? (steps - (k - 1)) : s;
+    if (wait_progress && k > 1 && !wait_progress(k - 1 - s)) break;
+    double *Wk = G->V + (size_t)k * ldv;
+    for (int j = 0; j < sb; ++j)  // matrix powers (right-preconditioned operator), scaled by 1/σ
+      NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1)));
+    const int grid = nk_ss_grid(ctx, n, k, sb);
+    const int nslots = (k + sb) * sb;
+    for (int pass = 0; pass < 2; ++pass) {
+      {
+        nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb + (pass ? sb : 0)));
+        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid));
+      }
+      {
+        nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
+        NK_TRY(nk_blas_reduce_slots(ctx, W->part, grid, nslots, W->red, done));
+      }
+      if (!single) NK_TRY(nk_comm_allreduce(ctx, W->red, nslots, 0));
+      if (pass == 0)
+        NK_LAUNCH(ctx, k_ss_tail1, dim3(1), dim3(256), G->d_ctl, k, sb, (const double *)W->red, (const double *)G->d_s, W->coef,
+                  W->C1, W->R1, W->scal, G->h_pub_dev, G->cycle_seq);
+      else
+        NK_LAUNCH(ctx, k_ss_tail2, dim3(1), dim3(256), G->d_ctl, k, sb, (const double *)W->red, G->d_s, W->coef,
+                  (const double *)W->C1, (const double *)W->R1, W->H, G->m, G->d_R, G->d_cs, G->d_sn, G->d_g, W->scal,
+                  G->h_pub_dev, G->cycle_seq);
+    }
+    {
+      nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 2 * sb));
+      NK_TRY(nk_ss_sweep(ctx, 2, n, k, sb, G->V, ldv, W->coef, W->part, skipC, grid));
+    }
+    NK_HIP(hipGetLastError());
+    k += sb;
+  }
+  return NK_OK;
+}

@@ -307,6 +307,10 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
         assert x0 is None
         z, info = gmres(lambda v: matvec(M(v)), b, None, atol, rtol, restart, itmax, fixed_iters, ortho, allreduce)
         return M(z), info
+    if isinstance(ortho, tuple) and ortho[0] == "sstep":   # ("sstep", s)
+        return gmres_sstep(matvec, b, atol, rtol, restart, itmax, fixed_iters, int(ortho[1]), allreduce, x0)
+    if ortho == "sstep":
+        return gmres_sstep(matvec, b, atol, rtol, restart, itmax, fixed_iters, 6, allreduce, x0)
     ar = allreduce if allreduce is not None else (lambda z: z)
     b = np.asarray(b, dtype=np.float64)
     n = b.size
@@ -504,6 +508,120 @@ def gmres_dcgs2_1r(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=3
             V[k] = vk
             V[k + 1] = w - V[:k].T @ ttop - vk * tlast
             tprev = np.concatenate([ttop, [tlast]])
+        if kdone > 0 and not info.failed:
+            y = np.linalg.solve(np.triu(R[:kdone, :kdone]), g[:kdone]) if kdone > 1 else np.array([g[0] / R[0, 0]])
+            x = x + V[:kdone].T @ y
+        if done or info.iters >= cap:
+            return x, info
+        info.restarts += 1
+        r0 = b - matvec(x)
+        beta0 = math.sqrt(float(ar(np.dot(r0, r0))))
+
+
+class SStepBreakdown(Exception):
+    """A block of the monomial basis lost rank numerically (the Cholesky factorisation of the Pythagorean Gram block failed)."""
+
+
+def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0, s=6,
+                allreduce: Optional[Callable] = None, x0=None):
+    """Restarted GMRES(m) whose Arnoldi process advances s columns at a time — the CPU restatement of csrc/nk_sstep.hip
+    (the device's NK_ORTHO_SSTEP; Hoemmen, "Communication-avoiding Krylov subspace methods", and Carson, Lund, Rozložník,
+    Thomas, "Block Gram–Schmidt algorithms and their stability properties", for BCGS-PIP). Per block: the monomial vectors
+    X_j = A X_{j−1} (X_0 = A v_k; the device scales them by a power of two, which changes nothing in binary floating point),
+    then twice [C ; G] = [V_k X]ᵀ X in ONE reduction, RᵀR = G − CᵀC, X ← (X − V_k C) R⁻¹. With C = C₁ + C₂R₁ and R = R₂R₁ the
+    monomial vectors have the coordinates F_j = [C_j ; R_j] in the new basis [V_k Q], and the Arnoldi relation of the new
+    columns follows from A v_k = X_0, A X_{j−1} = X_j and q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}.
+    Same Krylov space, same minimisation as `gmres`; the iterates differ by rounding (1e-13 relative on the path's Jacobians).
+    The stopping test sees the s columns of a block together. Raises SStepBreakdown where the device falls back to DCGS2."""
+    ar = allreduce if allreduce is not None else (lambda z: z)
+    b = np.asarray(b, dtype=np.float64)
+    n = b.size
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    info = GmresInfo()
+    r0 = b - matvec(x) if x0 is not None and np.any(x) else b.copy()
+    beta0 = math.sqrt(float(ar(np.dot(r0, r0))))
+    info.rnorm0 = info.rnorm = beta0
+    info.residuals.append(beta0)
+    if not math.isfinite(beta0):
+        info.failed = True
+        return x, info
+    eps_stop, cap = (-1.0, int(fixed_iters)) if fixed_iters > 0 else (atol + rtol * beta0, int(itmax))
+    if beta0 == 0.0 or (fixed_iters <= 0 and beta0 <= eps_stop):
+        info.converged = True
+        return x, info
+    m = int(restart)
+
+    def pip(V, X):  # one Pythagorean block projection: the coefficients and the triangular factor, X updated
+        k, sb = V.shape[0], X.shape[0]
+        red = ar(np.concatenate([(V @ X.T).ravel(), (X @ X.T).ravel()]))
+        C, G = red[: k * sb].reshape(k, sb), red[k * sb:].reshape(sb, sb)
+        S = 0.5 * ((G - C.T @ C) + (G - C.T @ C).T)
+        try:
+            Rm = np.linalg.cholesky(S).T
+        except np.linalg.LinAlgError as e:
+            raise SStepBreakdown(str(e))
+        if not np.all(np.isfinite(Rm)):
+            raise SStepBreakdown("non-finite factor")
+        Xn = np.linalg.solve(Rm.T, X - C.T @ V)   # rows of X are vectors: Xᵀ ← (Xᵀ − V_kᵀC) R⁻¹
+        return C, Rm, Xn
+
+    while True:
+        steps = min(m, cap - info.iters)
+        V = np.zeros((m + 1, n))
+        H = np.zeros((m + 2 + s, m))
+        R = np.zeros((m, m))
+        cs, sn, g = np.zeros(m), np.zeros(m), np.zeros(m + 1)
+        V[0] = r0 / beta0
+        g[0] = beta0
+        k, kdone, done = 1, 0, False
+        while k - 1 < steps and not done:
+            sb = min(s, steps - (k - 1))
+            X = np.zeros((sb, n))
+            z = V[k - 1]
+            for j in range(sb):
+                X[j] = matvec(z)
+                z = X[j]
+            C1, R1, X = pip(V[:k], X)
+            C2, R2, X = pip(V[:k], X)
+            V[k: k + sb] = X
+            F = np.vstack([C1 + C2 @ R1, R2 @ R1])        # (k + sb) × sb
+            K = k + sb
+            NC = np.zeros((sb, K))
+            NC[0] = F[:, 0]
+            for j in range(1, sb):
+                a = F[:, j].copy()
+                a[: k] -= H[:k, : k - 1] @ F[: k - 1, j - 1]
+                a -= NC[0] * F[k - 1, j - 1]
+                for q in range(1, j):
+                    a -= NC[q] * F[k + q - 1, j - 1]
+                NC[j] = a / F[k + j - 1, j - 1]
+            for j in range(sb):
+                jc = k - 1 + j
+                H[: jc + 2, jc] = NC[j][: jc + 2]
+                h = NC[j][: jc + 2].copy()
+                for i in range(jc):
+                    tt = cs[i] * h[i] + sn[i] * h[i + 1]
+                    h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]
+                    h[i] = tt
+                dd = math.hypot(h[jc], h[jc + 1])
+                cs[jc], sn[jc] = (1.0, 0.0) if dd == 0.0 else (h[jc] / dd, h[jc + 1] / dd)
+                R[:jc, jc] = h[:jc]
+                R[jc, jc] = dd
+                g[jc + 1] = -sn[jc] * g[jc]
+                g[jc] = cs[jc] * g[jc]
+                info.iters += 1
+                kdone = jc + 1
+                info.rnorm = abs(g[jc + 1])
+                info.residuals.append(info.rnorm)
+                if not math.isfinite(info.rnorm):
+                    info.failed = True
+                    done = True
+                elif (fixed_iters <= 0 and info.rnorm <= eps_stop) or h[jc + 1] == 0.0:
+                    info.converged = True
+                    done = True
+                if done:
+                    break
+            k += sb
         if kdone > 0 and not info.failed:
             y = np.linalg.solve(np.triu(R[:kdone, :kdone]), g[:kdone]) if kdone > 1 else np.array([g[0] / R[0, 0]])
             x = x + V[:kdone].T @ y

@@ -1,2 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_polyalg.py tests/test_gpu_direct.py tests/test_gpu_pseudo_transient.py tests/test_gpu_lm.py tests/test_gpu_solvers.py tests/test_gpu_round2.py -x -q 2>&1 | tail -30 | cut -c1-500
+for o in "--ortho dcgs2" "--ortho sstep --sstep 6" "--ortho sstep --sstep 5" "--ortho sstep --sstep 3" "--ortho sstep --sstep 8"; do
+  timeout 300 python bench.py --cpu-seconds 0 --no-ttt $o 2>&1 | tail -1 | python -c "
+import sys, json
+l = sys.stdin.read().strip()
+try:
+    d = json.loads(l); print('$o', d['value'], d['ms_per_step'], {k: (v['avg_us'], v['launches']) for k, v in d.get('kernels', {}).items()})
+except Exception as e:
+    print('$o', 'ERR', l[-400:])
+"
+done
