@@ -7,11 +7,14 @@
 
 Workload `c3` (default; config C3 of BASELINE.md, the configuration the metric is quoted on): 2-D Bratu n = 1024²
 (N = 1 048 576 unknowns, nnz = 5 238 784, λ = 6, u0 = 0), NewtonRaphson with the *fixed-work* Krylov protocol of
-SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step, zero initial guess, CGS2 orthogonalisation
-(delayed form `dcgs2`: same arithmetic to rounding, 2 sweeps over the basis and one reduction per step) — on the
-assembled CSR Jacobian (values refilled every step, SpMV as the operator). A "step" is one such Newton step: Jacobian
-value fill + 30×(SpMV + CGS2 sweeps) + solution update + u += δu + residual + ‖·‖∞ + termination bookkeeping,
-everything resident in HBM.
+SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step (a 30-column orthonormal Krylov basis, the
+30-dimensional least-squares problem solved through Givens rotations), zero initial guess — on the assembled CSR Jacobian
+(values refilled every step, SpMV as the operator). The Arnoldi process is the s-step form (`--ortho sstep`, s = 6 columns per
+block: 30 SpMVs, then per block three sweeps over the basis with the Gram blocks on the FP64 matrix cores; csrc/nk_sstep.hip) —
+the same Krylov space and the same minimisation as column-by-column CGS2, iterates equal to 1e-12 (tests/test_gpu_sstep.py,
+incl. this very protocol at full size against the C oracle); `--ortho dcgs2` runs the column-by-column form of rounds 1–2
+(delayed CGS2: two sweeps and one reduction per column). A "step" is one such Newton step: Jacobian value fill + 30 SpMVs +
+the orthogonalisation sweeps + solution update + u += δu + residual + ‖·‖∞ + termination bookkeeping, everything resident in HBM.
 
 N > 1 is STRONG scaling on the metric's configuration: the same 1024² problem row-partitioned by grid lines over N
 ranks (halo lines + Krylov inner products over xGMI: peer-mapped buffers, RCCL as fallback); `value` is the plain
@@ -48,7 +51,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"])
     ap.add_argument("--grid", dest="n", type=int, default=0, help="grid side (default: 1024 for c3, 4096 for c4, 512 for c5)")
-    ap.add_argument("--ortho", default="dcgs2", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs", "sstep"])
+    ap.add_argument("--ortho", default="sstep", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs", "sstep"])
     ap.add_argument("--sstep", type=int, default=6, help="--ortho sstep: basis columns per block")
     ap.add_argument("--arnoldi", type=int, default=30)
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
@@ -340,7 +343,7 @@ def main():
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
-                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho,
+                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho if args.ortho != "sstep" else "sstep%d" % args.sstep,
                        "parallelism": f"row-range x{world}", "comm": comm, "halo_overlap": overlap},
             "roofline": roof, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
             "gpu_vs_cpu": round(steps_per_s / cpu["value"], 1) if cpu and "value" in cpu else None,

@@ -28,6 +28,7 @@ constexpr int SS_R = 256;        // rows per tile = threads per workgroup
 constexpr int SS_P = SS_R + 1;   // LDS pitch in doubles (odd)
 constexpr int SS_MTMAX = 5;      // Gram tiles of 16 rows: k + s ≤ 80
 constexpr int SS_SMAX = 8;
+constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
 
 // coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
@@ -74,8 +75,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
     const int col = mt * 16 + li;
     pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
   }
-  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // a workgroup walks CONTIGUOUS tiles: each of its k + S column streams then advances through adjacent 2 KB pieces
+  const int tpw = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile0 = blockIdx.x * tpw, tile1 = min(tile0 + tpw, ntiles);
+  if (tile0 < tile1) prefetch(tile0);
+  for (int tile = tile0; tile < tile1; ++tile) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const bool ok = r < n;
     if (MTC > 0) {
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
       for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
       __syncthreads();
     }
-    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);   // in flight through the matrix-core phase
+    if (tile + 1 < tile1) prefetch(tile + 1);   // in flight through the matrix-core phase
     if (GRAM) {
       // 64 rows per wavefront, 4 per instruction; operands of four instructions are requested together
 #pragma unroll
@@ -182,7 +186,10 @@ static size_t ss_lds_bytes(int k, int s, bool gram) {
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
   const size_t lds = ss_lds_bytes(k, s, true);
-  const int per_cu = lds > 80 * 1024 ? 1 : 2;
+  int per_cu = (int)((size_t)(150 * 1024) / lds);   // the LDS tile bounds the occupancy; 4 workgroups fill the SIMDs' 2 × 256-VGPR slots
+  per_cu = per_cu < 1 ? 1 : (per_cu > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : per_cu);
+  if (k + s > 32 && per_cu > 2) per_cu = 2;   // the register-resident classes hold 16·MTC row values: 228 / 152 / 92 VGPRs
+  else if (k + s > 16 && per_cu > 3) per_cu = 3;
   int g = ctx->num_cus * per_cu;
   if (g > ntiles) g = ntiles;
   return g > 0 ? g : 1;
@@ -377,13 +384,20 @@ __global__ __launch_bounds__(256) void k_ss_tail2(nk_gmres_ctl *ctl, int k, int 
                                                   double *g, double *scal, nk_gmres_pub *pub, uint64_t seq) {
   __shared__ double Ct[SS_KMAX * SS_SMAX], Rm[64], Ri[64], Sm[64], R1s[64];
   __shared__ double F[SS_KMAX * SS_SMAX], NC[SS_SMAX * SS_KMAX];
+  __shared__ double Hs[NK_MAX_NV * NK_MAX_NV];              // the old columns (rows < k, columns < k − 1), pitch k
+  __shared__ double scs[NK_MAX_NV + SS_SMAX], ssn[NK_MAX_NV + SS_SMAX], sg[NK_MAX_NV + SS_SMAX + 1];
   __shared__ int s_ok;
   const int t = threadIdx.x;
   if (ctl->done) {
     if (t == 0) ctl->pad1 = 1;  // the block never started: sweep C has nothing to finish
     return;
   }
-  const int K = k + sb;
+  const int K = k + sb, ko = k - 1;                         // ko old Hessenberg columns / rotations
+  // everything the serial parts below read from global memory, requested up front by all threads (a dependent chain of
+  // uncached loads on one lane cost 29 µs per block in the first version of this kernel)
+  for (int e = t; e < k * ko; e += 256) Hs[e] = H[(size_t)(e / ko) * m + (e % ko)];
+  if (t < ko) { scs[t] = cs[t]; ssn[t] = sn[t]; }
+  if (t <= ko) sg[t] = g[t];
   const bool ok = ss_factor(k, sb, red, sc, Ct, Rm, Ri, Sm, &s_ok);
   if (!ok) {
     if (t == 0) { ctl->failed = 2; ctl->done = 1; ctl->pad1 = 1; ss_pub_progress(pub, seq, ctl->k, 1); }
@@ -412,7 +426,8 @@ __global__ __launch_bounds__(256) void k_ss_tail2(nk_gmres_ctl *ctl, int k, int 
     if (t < K) {
       const int i = t;
       double a = sigma * F[i * sb + j];
-      for (int tt = (i > 0 ? i - 1 : 0); tt < k - 1; ++tt) a = __builtin_fma(-H[(size_t)i * m + tt], F[tt * sb + (j - 1)], a);
+      if (i < k)
+        for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
       a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
       for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * SS_KMAX + i], F[(k + q - 1) * sb + (j - 1)], a);
       NC[j * SS_KMAX + i] = a / F[(k + j - 1) * sb + (j - 1)];
@@ -420,39 +435,54 @@ __global__ __launch_bounds__(256) void k_ss_tail2(nk_gmres_ctl *ctl, int k, int 
     __syncthreads();
   }
   for (int e = t; e < sb * K; e += 256) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
-    const int j = e / K, i = e % K, jc = k - 1 + j;
+    const int j = e / K, i = e % K, jc = ko + j;
     if (i <= jc + 1 && jc < m) H[(size_t)i * m + jc] = NC[j * SS_KMAX + i];
   }
-  if (t == 0) {
+  __syncthreads();
+  if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane
+    const int jc = ko + t;
+    double *h = &NC[t * SS_KMAX];
+    for (int i = 0; i < ko; ++i) {
+      const double a = h[i], b = h[i + 1];
+      Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
+      h[i + 1] = -ssn[i] * a + scs[i] * b;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {  // the rotations this block creates: a chain of sb short steps
     const double tol = ctl->tol;
     int closed = 0, dn = 0;
+    double rn = ctl->rnorm, beta = 0.0;
     for (int j = 0; j < sb && !dn; ++j) {
-      const int jc = k - 1 + j;
+      const int jc = ko + j;
       double *h = &NC[j * SS_KMAX];
-      for (int i = 0; i < jc; ++i) {
+      for (int i = ko; i < jc; ++i) {
         const double a = h[i], b = h[i + 1];
-        Rg[(size_t)i * m + jc] = cs[i] * a + sn[i] * b;
-        h[i + 1] = -sn[i] * a + cs[i] * b;
+        Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
+        h[i + 1] = -ssn[i] * a + scs[i] * b;
       }
-      const double hk = h[jc], beta = h[jc + 1];
+      const double hk = h[jc];
+      beta = h[jc + 1];
       const double d = hypot(hk, beta);
-      double c, sg;
-      if (d == 0.0) { c = 1.0; sg = 0.0; } else { c = hk / d; sg = beta / d; }
-      cs[jc] = c;
-      sn[jc] = sg;
+      double c, sgn;
+      if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
+      scs[jc] = c;
+      ssn[jc] = sgn;
       Rg[(size_t)jc * m + jc] = d;
-      const double gj = g[jc];
-      g[jc + 1] = -sg * gj;
-      g[jc] = c * gj;
-      const double rn = fabs(sg * gj);
+      const double gj = sg[jc];
+      sg[jc + 1] = -sgn * gj;
+      sg[jc] = c * gj;
+      rn = fabs(sgn * gj);
       closed = j + 1;
-      ctl->rnorm = rn;
-      ctl->hn = beta;
       if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; dn = 1; }
       else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
       else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
     }
-    ctl->k = k - 1 + closed;
+    for (int j = 0; j < closed; ++j) { cs[ko + j] = scs[ko + j]; sn[ko + j] = ssn[ko + j]; g[ko + j] = sg[ko + j]; }
+    g[ko + closed] = sg[ko + closed];
+    ctl->rnorm = rn;
+    ctl->hn = beta;
+    ctl->k = ko + closed;
     ctl->pad1 = 0;
     if (dn) ctl->done = 1;
     for (int c = 0; c < sb; ++c) sc[k + c] = 1.0;  // the new columns are normalised
@@ -486,7 +516,7 @@ static int ss_workspace(nk_gmres *G) {
   nk_sstep *W = new nk_sstep();
   auto guard = nk_make_guard(W, [](nk_sstep *w) { nk_ss_destroy(w); });
   const int m = G->m;
-  W->grid = G->ctx->num_cus * 2;
+  W->grid = G->ctx->num_cus * SS_MAX_WG_PER_CU;
   const size_t nslots = (size_t)(m + 1 + SS_SMAX) * SS_SMAX;
   NK_TRY(nk_dev_alloc(&W->part, nslots * W->grid + 1));
   NK_TRY(nk_dev_alloc(&W->red, nslots + 1));
@@ -532,7 +562,11 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
         NK_TRY(nk_blas_reduce_slots(ctx, W->part, grid, nslots, W->red, done));
       }
-      if (!single) NK_TRY(nk_comm_allreduce(ctx, W->red, nslots, 0));
+      if (!single) {  // peer-mapped arenas carry NK_PEER_AR_MAX doubles per message: the block goes in pieces; other transports: one call
+        const int piece = ctx->peer.on ? NK_PEER_AR_MAX : nslots;
+        for (int off = 0; off < nslots; off += piece)
+          NK_TRY(nk_comm_allreduce(ctx, W->red + off, nslots - off < piece ? nslots - off : piece, 0));
+      }
       if (pass == 0)
         NK_LAUNCH(ctx, k_ss_tail1, dim3(1), dim3(256), G->d_ctl, k, sb, (const double *)W->red, (const double *)G->d_s, W->coef,
                   W->C1, W->R1, W->scal, G->h_pub_dev, G->cycle_seq);

@@ -202,6 +202,16 @@ def _worker(rank, world, port, q, transport="torch"):
             assert solpt.retcode == "Success" == R.RETCODE_NAMES[refpt.retcode] and solpt.stats.nsteps == refpt.stats.nsteps
             assert np.max(np.abs(solpt.u.cpu().numpy() - refpt.u[bl:el])) <= 1e-8
         note("bratu_pt", solpt.u.cpu().numpy())
+        # ---------------- s-step GMRES on two ranks: the block Gram partials are reduced locally, then ONE all-reduce of
+        # (k + s)·s values per sweep (two per block of s columns instead of s)
+        refss = R.solve(R.Bratu2D(12), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(**kl_)), abstol=1e-9, maxiters=50)
+        for cj in (None, True):
+            solss = nls.solve(nls.NonlinearProblem(Plm, u0=torch.zeros(el - bl, dtype=torch.float64, device=dev)),
+                              nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(ortho="sstep", sstep=5, **kl_), concrete_jac=cj),
+                              abstol=1e-9, maxiters=50)
+            assert solss.retcode == "Success" == R.RETCODE_NAMES[refss.retcode] and solss.stats.nsteps == refss.stats.nsteps
+            assert np.max(np.abs(solss.u.cpu().numpy() - refss.u[bl:el])) <= 1e-8
+        note("bratu_sstep", solss.u.cpu().numpy())
 
         # ---------------- the Brusselator V-cycle on two ranks: every level split by lines (slab boundaries stay even, the
         # transfers use the problem's own one-line periodic halo), coarsest level gathered and solved redundantly — one

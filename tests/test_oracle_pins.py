@@ -727,3 +727,32 @@ def test_polyalgorithm_retention():
     c = R.init(_cubic([0.0]), R.NonlinearSolvePolyAlgorithm((NR, R.PseudoTransient(alpha_initial=1e-3))), maxiters=3)
     s = c.solve()
     assert s.retcode == R.MAXITERS and np.array_equal(s.u, c.caches[1].u) and np.max(np.abs(s.resid)) < 2.0
+
+
+# ---- s-step GMRES (oracle.gmres_sstep, the restatement of csrc/nk_sstep.hip): the same Krylov minimisation as the
+# column-by-column schemes — pinned against them and against SciPy's GMRES
+def test_sstep_gmres_agrees_with_column_schemes_and_scipy():
+    import scipy.sparse.linalg as spla
+    for P in (R.Bratu2D(24), R.Brusselator2D(12)):
+        u = P.u0() + 0.1 * np.sin(np.arange(P.n) * 0.37)
+        A, b = P.jac(u).tocsr(), P.f(u)
+        for m, cap in ((30, 30), (20, 60)):
+            xm, im = R.gmres(lambda z: A @ z, b, restart=m, fixed_iters=cap, ortho="mgs")
+            for s in (1, 2, 3, 4, 6, 8):
+                x, i = R.gmres(lambda z: A @ z, b, restart=m, fixed_iters=cap, ortho=("sstep", s))
+                assert i.iters == im.iters == cap and i.restarts == im.restarts
+                # (the Hessenberg columns are recovered through the block's triangular factor: the error grows with κ of the
+                #  monomial block, i.e. with s — 4e-11 at s = 6 on the Brusselator's κ(J) = 1.5e4)
+                assert np.linalg.norm(x - xm) <= {1: 1e-11, 2: 1e-11, 3: 1e-11, 4: 1e-10, 6: 5e-10, 8: 2e-8}[s] * np.linalg.norm(xm)
+                assert np.allclose(i.residuals[-1], im.residuals[-1], rtol=1e-7)
+        x, i = R.gmres(lambda z: A @ z, b, restart=30, rtol=1e-10, itmax=2000, ortho="sstep")
+        xs, code = spla.gmres(A, b, rtol=1e-10, restart=30, maxiter=200, atol=0.0)
+        assert i.converged and code == 0 and np.linalg.norm(x - xs) <= 1e-7 * np.linalg.norm(xs)
+        assert np.linalg.norm(b - A @ x) <= 1.001e-10 * np.linalg.norm(b)
+    with pytest.raises(R.SStepBreakdown):      # a rank-one monomial block: where the device falls back to delayed CGS2
+        R.gmres(lambda z: 2.0 * z, np.ones(5), restart=5, ortho="sstep")
+    # power-of-two scaling of the operator (what the device's σ amounts to) leaves the iterate unchanged to rounding
+    P = R.Bratu2D(16); u = P.u0(); A, b = P.jac(u).tocsr(), P.f(u)
+    x1, _ = R.gmres(lambda z: A @ z, b, restart=12, fixed_iters=12, ortho=("sstep", 4))
+    x2, _ = R.gmres(lambda z: (A @ z) * 0.25, b * 0.25, restart=12, fixed_iters=12, ortho=("sstep", 4))
+    assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))

@@ -1,11 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for o in "--ortho dcgs2" "--ortho sstep --sstep 6" "--ortho sstep --sstep 5" "--ortho sstep --sstep 3" "--ortho sstep --sstep 8"; do
-  timeout 300 python bench.py --cpu-seconds 0 --no-ttt $o 2>&1 | tail -1 | python -c "
-import sys, json
-l = sys.stdin.read().strip()
-try:
-    d = json.loads(l); print('$o', d['value'], d['ms_per_step'], {k: (v['avg_us'], v['launches']) for k, v in d.get('kernels', {}).items()})
-except Exception as e:
-    print('$o', 'ERR', l[-400:])
-"
-done
+timeout 120 python -m pytest tests/test_gpu_sstep.py -x -q < /dev/null 2>&1 | tail -3 | cut -c1-300
+timeout 60 python bench.py --cpu-seconds 0 --no-ttt < /dev/null 2>/dev/null | tail -1 | cut -c1-130
