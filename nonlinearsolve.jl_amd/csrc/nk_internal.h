@@ -439,8 +439,9 @@ bool nk_ss_eligible(const nk_gmres *G);
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
+struct ss_tail_args;
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid);
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark);
 int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 
 // ----------------------------------------------------------------------------- banded LU (direct linsolve, C2)

@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 constexpr int SS_R = 256;        // rows per tile = threads per workgroup
@@ -31,18 +32,307 @@ constexpr int SS_SMAX = 8;
 constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
 
+// ============================================================================= the scalar work of a block (one workgroup)
+__device__ __forceinline__ void ss_pub_progress(nk_gmres_pub *pub, uint64_t seq, int k, int done) {
+  if (pub != nullptr)
+    __hip_atomic_store(&pub->progress, (seq << 16) | ((uint64_t)k << 1) | (uint64_t)(done ? 1 : 0), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr int SS_KMAX = 16 * SS_MTMAX;  // k + s ≤ 80
+
+// what the scalar work reads and writes in global memory
+struct ss_tail_args {
+  nk_gmres_ctl *ctl;
+  const double *red;   // the reduced block [V_kᵀX ; XᵀX], (k + s) × s
+  double *sc;          // scales of un-normalised columns (only column 0: 1/β)
+  double *C1, *R1;     // pass 1's factors, kept for pass 2
+  double *H;           // un-rotated Hessenberg columns, row-major with pitch m
+  int m;
+  double *Rg, *cs, *sn, *g, *scal;
+  nk_gmres_pub *pub;
+  uint64_t seq;
+};
+// LDS arrays of the scalar work, carved from one dynamic block
+struct ss_ws {
+  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *F, *NC, *Hs, *scs, *ssn, *sg;
+  int *ok;
+};
+__host__ __device__ inline size_t ss_ws_doubles(int k, int s, bool hess) {
+  size_t d = (size_t)2 * k * s + 4 * 64 + 2;
+  if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 3 * (size_t)(k + s) + 1;
+  return d;
+}
+__device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
+  ss_ws w;
+  w.Ct = b; b += k * s;
+  w.U = b; b += k * s;
+  w.Ri = b; b += 64;
+  w.Rm = b; b += 64;
+  w.Sm = b; b += 64;
+  w.R1s = b; b += 64;
+  w.ok = reinterpret_cast<int *>(b); b += 2;
+  w.F = w.NC = w.Hs = w.scs = w.ssn = w.sg = nullptr;
+  if (hess) {
+    w.F = b; b += (k + s) * s;
+    w.NC = b; b += (k + s) * s;
+    w.Hs = b; b += k * (k > 1 ? k - 1 : 1);
+    w.scs = b; b += k + s;
+    w.ssn = b; b += k + s;
+    w.sg = b;
+  }
+  return w;
+}
+
+// From the reduced block [V_kᵀX ; XᵀX] (X = the s columns behind V_k; `sc` un-normalised-column scales): the true
+// coefficients Ct = diag(sc)·V_kᵀX, the Cholesky factor R of XᵀX − CtᵀCt (Pythagorean form of ‖X − V Ct‖), R⁻¹, and the
+// coefficients U = diag(sc)·Ct the update takes off the stored columns. Returns false on a non-positive or non-finite pivot
+// (the monomial block lost rank numerically). Every workgroup that runs it on the same `red` reaches the same verdict.
+__device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w) {
+  const int t = threadIdx.x;
+  double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
+  for (int e = t; e < k * sb; e += blockDim.x) {
+    const double scj = sc[e / sb], c = scj * red[e];
+    Ct[e] = c;
+    w.U[e] = scj * c;
+  }
+  __syncthreads();
+  if (t < sb * sb) {
+    const int a = t / sb, b = t % sb;
+    double s = red[(size_t)(k + a) * sb + b];
+    for (int j = 0; j < k; ++j) s = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s);
+    Sm[t] = s;
+    Rm[t] = 0.0;
+    Ri[t] = 0.0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    // the s × s factorisation and inverse on one lane, entirely in registers (fixed 8 × 8 frame, compile-time indices)
+    double A[SS_SMAX][SS_SMAX], B[SS_SMAX][SS_SMAX];
+#pragma unroll
+    for (int a = 0; a < SS_SMAX; ++a)
+#pragma unroll
+      for (int b = 0; b < SS_SMAX; ++b) {
+        A[a][b] = (a < sb && b < sb) ? 0.5 * (Sm[a * sb + b] + Sm[b * sb + a]) : (a == b ? 1.0 : 0.0);
+        B[a][b] = 0.0;
+      }
+    int ok = 1;
+#pragma unroll
+    for (int a = 0; a < SS_SMAX; ++a) {  // upper-triangular R with RᵀR = S, row by row, in place (rows ≥ sb: identity)
+      double d = A[a][a];
+#pragma unroll
+      for (int p = 0; p < a; ++p) d -= A[p][a] * A[p][a];
+      if (!(d > 0.0) || isinf(d)) ok = 0;
+      const double raa = sqrt(d), inv = 1.0 / raa;
+      A[a][a] = raa;
+#pragma unroll
+      for (int b = a + 1; b < SS_SMAX; ++b) {
+        double v = A[a][b];
+#pragma unroll
+        for (int p = 0; p < a; ++p) v -= A[p][a] * A[p][b];
+        A[a][b] = v * inv;
+      }
+    }
+    if (ok) {  // R⁻¹ (upper), column by column
+#pragma unroll
+      for (int b = 0; b < SS_SMAX; ++b) {
+        B[b][b] = 1.0 / A[b][b];
+#pragma unroll
+        for (int a = SS_SMAX - 1; a >= 0; --a) {
+          if (a < b) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < SS_SMAX; ++p)
+              if (p > a && p <= b) v -= A[a][p] * B[p][b];
+            B[a][b] = v / A[a][a];
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < SS_SMAX; ++a)
+#pragma unroll
+        for (int b = 0; b < SS_SMAX; ++b)
+          if (a < sb && b < sb) { Rm[a * sb + b] = b >= a ? A[a][b] : 0.0; Ri[a * sb + b] = b >= a ? B[a][b] : 0.0; }
+    }
+    *w.ok = ok;
+  }
+  __syncthreads();
+  return *w.ok != 0;
+}
+
+// after pass 1 (one workgroup): C₁ and R₁ are kept for pass 2; σ estimate for the next cycle from ‖A v‖ of the first block
+__device__ void ss_keep_pass1(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
+  const int t = threadIdx.x;
+  for (int e = t; e < k * sb; e += blockDim.x) ta.C1[e] = w.Ct[e];
+  if (t < sb * sb) ta.R1[t] = w.Rm[t];
+  if (t == 0 && k == 1) {  // ‖A v₁‖ = σ·√(XᵀX)₀₀: the scale of the next cycle's monomial basis, rounded to a power of two
+    const double est = ta.scal[2] * sqrt(ta.red[(size_t)k * sb]);
+    if (est > 0.0 && !isinf(est)) ta.scal[3] = exp2(rint(log2(est)));
+  }
+}
+__device__ void ss_fail(const ss_tail_args &ta) {
+  if (threadIdx.x == 0) {
+    ta.ctl->failed = 2;
+    ta.ctl->done = 1;
+    ta.ctl->pad1 = 1;
+    ss_pub_progress(ta.pub, ta.seq, ta.ctl->k, 1);
+  }
+}
+
+// after pass 2 (one workgroup; ss_factor has run on pass 2's block): C = C₁ + C₂R₁, R = R₂R₁; the s new Hessenberg columns;
+// Givens rotations, residual norms, stopping test.
+// Coordinates in the basis [V_k Q] (K = k + s): X_j (column j of the block, j = 0..s−1) = F[:, j] = [C_j ; R_j], and
+//   A v_k = σ X_0 ;  A X_{j−1} = σ X_j ;  q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}   (j = 1..s−1)
+// so the coordinates of A q_j follow from those of A v_1..A v_{k−1} (the old Hessenberg columns), A v_k and A q_1..A q_{j−1}.
+__device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
+  double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
+  // everything the serial parts read from global memory is requested up front by all threads
+  for (int e = t; e < k * ko; e += nt) Hs[e] = ta.H[(size_t)(e / ko) * m + (e % ko)];
+  for (int e = t; e < ko; e += nt) { scs[e] = ta.cs[e]; ssn[e] = ta.sn[e]; }
+  for (int e = t; e <= ko; e += nt) sg[e] = ta.g[e];
+  if (t < sb * sb) w.R1s[t] = ta.R1[t];
+  const double sigma = ta.scal[2];
+  for (int e = t; e < k * sb; e += nt) F[e] = ta.C1[e];
+  __syncthreads();
+  for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
+    const int j = e / sb, c = e % sb;
+    double v = F[e];
+    for (int a = 0; a <= c; ++a) v = __builtin_fma(w.Ct[j * sb + a], w.R1s[a * sb + c], v);
+    F[e] = v;
+  }
+  if (t < sb * sb) {  // R = R₂ R₁ (upper)
+    const int a = t / sb, c = t % sb;
+    double v = 0.0;
+    for (int p = a; p <= c; ++p) v = __builtin_fma(w.Rm[a * sb + p], w.R1s[p * sb + c], v);
+    F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
+  }
+  __syncthreads();
+  if (t < K) NC[t] = sigma * F[t * sb];
+  __syncthreads();
+  for (int j = 1; j < sb; ++j) {
+    if (t < K) {
+      const int i = t;
+      double a = sigma * F[i * sb + j];
+      if (i < k)
+        for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
+      a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
+      for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * K + i], F[(k + q - 1) * sb + (j - 1)], a);
+      NC[j * K + i] = a / F[(k + j - 1) * sb + (j - 1)];
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < sb * K; e += nt) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
+    const int j = e / K, i = e % K, jc = ko + j;
+    if (i <= jc + 1 && jc < m) ta.H[(size_t)i * m + jc] = NC[j * K + i];
+  }
+  __syncthreads();
+  if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane
+    const int jc = ko + t;
+    double *h = &NC[t * K];
+    for (int i = 0; i < ko; ++i) {
+      const double a = h[i], b = h[i + 1];
+      ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
+      h[i + 1] = -ssn[i] * a + scs[i] * b;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {  // the rotations this block creates: a chain of sb short steps
+    nk_gmres_ctl *ctl = ta.ctl;
+    const double tol = ctl->tol;
+    int closed = 0, dn = 0;
+    double rn = ctl->rnorm, beta = 0.0;
+    for (int j = 0; j < sb && !dn; ++j) {
+      const int jc = ko + j;
+      double *h = &NC[j * K];
+      for (int i = ko; i < jc; ++i) {
+        const double a = h[i], b = h[i + 1];
+        ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
+        h[i + 1] = -ssn[i] * a + scs[i] * b;
+      }
+      const double hk = h[jc];
+      beta = h[jc + 1];
+      const double d = hypot(hk, beta);
+      double c, sgn;
+      if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
+      scs[jc] = c;
+      ssn[jc] = sgn;
+      ta.Rg[(size_t)jc * m + jc] = d;
+      const double gj = sg[jc];
+      sg[jc + 1] = -sgn * gj;
+      sg[jc] = c * gj;
+      rn = fabs(sgn * gj);
+      closed = j + 1;
+      if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; dn = 1; }
+      else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
+      else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
+    }
+    for (int j = 0; j < closed; ++j) { ta.cs[ko + j] = scs[ko + j]; ta.sn[ko + j] = ssn[ko + j]; ta.g[ko + j] = sg[ko + j]; }
+    ta.g[ko + closed] = sg[ko + closed];
+    ctl->rnorm = rn;
+    ctl->hn = beta;
+    ctl->k = ko + closed;
+    if (dn) ctl->done = 1;
+    for (int c = 0; c < sb; ++c) ta.sc[k + c] = 1.0;  // the new columns are normalised
+    ta.scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
+    ss_pub_progress(ta.pub, ta.seq, ctl->k, dn);
+  }
+}
+
+// the scalar work as launches of their own (the streaming size class k + s > 48, and NK_SS_FUSED=0)
+__global__ __launch_bounds__(256) void k_ss_tail1(int k, int sb, double *__restrict__ coef, ss_tail_args ta) {
+  extern __shared__ double s_tail[];
+  if (ta.ctl->done) return;
+  const ss_ws w = ss_ws_carve(s_tail, k, sb, false);
+  if (!ss_factor(k, sb, ta.red, ta.sc, w)) { ss_fail(ta); return; }
+  const int t = threadIdx.x;
+  for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
+  if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
+  ss_keep_pass1(k, sb, w, ta);
+}
+__global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restrict__ coef, ss_tail_args ta) {
+  extern __shared__ double s_tail[];
+  if (ta.ctl->pad1) return;  // (pad1: the cycle was done when this block started, or its first pass failed)
+  const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
+  if (!ss_factor(k, sb, ta.red, ta.sc, w)) { ss_fail(ta); return; }
+  const int t = threadIdx.x;
+  for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
+  if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
+  __syncthreads();
+  ss_hessenberg(k, sb, w, ta);
+}
+
 // coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
 // then R⁻¹ (S × S, row-major, upper triangular)
 // MTC = 1, 2, 3: k + S ≤ 16·MTC. The k + S values of a thread's row live in registers and the NEXT tile's loads are issued
 // before the matrix-core phase of the current one — the LDS tile bounds the occupancy at 2 workgroups per CU, which then keep
 // ≈ 2 × (k+S) × 2 KB of loads in flight per CU through both phases; the Gram block is exactly MTC tiles of 16 rows.
 // MTC = 0: any k ≤ 80 − S, the columns stream past eight at a time (no prefetch), five Gram tiles.
-template <int S, bool UPDATE, bool GRAM, int MTC>
+// FUSE: the scalar work of the block runs inside the sweep that consumes it — EVERY workgroup factors the reduced block itself
+// (≈ 2 KB of L2-resident operands, a few µs once per persistent workgroup) and takes its update coefficients from LDS, so the
+// one-workgroup launches between reduction and sweep disappear; workgroup 0 also keeps pass 1's factors (sweep B) or, after
+// its share of sweep C is on its way, derives the Hessenberg columns, rotations and the stopping test. `mark`: workgroup 0
+// records the skip flag it saw (sweep A stamps "the cycle was done when this block started" for sweep C, which must not look at
+// a flag that workgroup 0 of its own launch may raise).
+template <int S, bool UPDATE, bool GRAM, int MTC, bool FUSE>
 __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__restrict__ V, int64_t ldv,
                                                    const double *__restrict__ coef, double *__restrict__ partials,
-                                                   const int *d_skip, int ntiles) {
-  if (d_skip != nullptr && *d_skip != 0) return;
+                                                   const int *d_skip, int ntiles, ss_tail_args ta, int *mark, int ws_off) {
+  {
+    const int dskip = (d_skip != nullptr) ? *d_skip : 0;
+    if (mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *mark = dskip;
+    if (dskip) return;
+  }
   extern __shared__ double sX[];
+  ss_ws ws;
+  if (FUSE) {
+    ws = ss_ws_carve(sX + ws_off, k, S, !GRAM);
+    if (!ss_factor(k, S, ta.red, ta.sc, ws)) {
+      if (blockIdx.x == 0) ss_fail(ta);
+      return;
+    }
+    if (GRAM && blockIdx.x == 0) ss_keep_pass1(k, S, ws, ta);
+  }
   constexpr int NT = MTC > 0 ? MTC : SS_MTMAX;         // Gram tiles this instantiation accumulates
   constexpr int NVR = MTC > 0 ? 16 * MTC - S : 1;      // basis values a thread holds (k ≤ NVR)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -89,7 +379,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
           if (GRAM) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
           if (UPDATE) {
 #pragma unroll
-            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], coef[j * S + c], w[c]);
+            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], FUSE ? ws.U[j * S + c] : coef[j * S + c], w[c]);
           }
         }
       }
@@ -110,7 +400,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
             if (GRAM) sX[j * SS_P + t] = ok ? v[u] : 0.0;
             if (UPDATE) {
 #pragma unroll
-              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], coef[j * S + c], w[c]);
+              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], FUSE ? ws.U[j * S + c] : coef[j * S + c], w[c]);
             }
           }
         }
@@ -122,7 +412,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
       for (int c = 0; c < S; ++c) {
         double a = 0.0;
 #pragma unroll
-        for (int cc = 0; cc <= c; ++cc) a = __builtin_fma(w[cc], Rinv[cc * S + c], a);
+        for (int cc = 0; cc <= c; ++cc) a = __builtin_fma(w[cc], FUSE ? ws.Ri[cc * S + c] : Rinv[cc * S + c], a);
         q[c] = a;
       }
 #pragma unroll
@@ -176,76 +466,102 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
       }
     }
   }
+  if (FUSE && !GRAM && blockIdx.x == 0) {  // workgroup 0, its share of the sweep issued: the block's Hessenberg columns
+    __syncthreads();
+    ss_hessenberg(k, S, ws, ta);
+  }
 }
 
-static size_t ss_lds_bytes(int k, int s, bool gram) {
+static size_t ss_tile_doubles(int k, int s, bool gram, int nt) {
   if (!gram) return 0;
-  const size_t a = (size_t)(k + s) * SS_P, b = (size_t)4 * SS_MTMAX * 256;
-  return (a > b ? a : b) * sizeof(double);
+  const size_t a = (size_t)(k + s) * SS_P, b = (size_t)4 * nt * 256;
+  return a > b ? a : b;
+}
+static int ss_class(int k, int s) { return k + s <= 16 ? 1 : (k + s <= 32 ? 2 : (k + s <= 48 ? 3 : 0)); }
+static size_t ss_lds_bytes(int k, int s, bool gram) {
+  const int c = ss_class(k, s);
+  return ss_tile_doubles(k, s, gram, c ? c : SS_MTMAX) * sizeof(double);
+}
+bool nk_ss_fusable(int k, int s) {
+  static const bool off = getenv("NK_SS_FUSED") && atoi(getenv("NK_SS_FUSED")) == 0;
+  return !off && ss_class(k, s) != 0;
+}
+// persistent workgroups per CU: bounded by the LDS tile (+ the fused scalar workspace) and the register-resident classes'
+// VGPR footprint (228 / 152 / 92 with the Gram accumulators)
+static int ss_per_cu(int k, int s, size_t lds) {
+  int per_cu = lds ? (int)((size_t)(150 * 1024) / lds) : SS_MAX_WG_PER_CU;
+  per_cu = per_cu < 1 ? 1 : (per_cu > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : per_cu);
+  if (k + s > 32 && per_cu > 2) per_cu = 2;
+  else if (k + s > 16 && per_cu > 3) per_cu = 3;
+  return per_cu;
 }
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  const size_t lds = ss_lds_bytes(k, s, true);
-  int per_cu = (int)((size_t)(150 * 1024) / lds);   // the LDS tile bounds the occupancy; 4 workgroups fill the SIMDs' 2 × 256-VGPR slots
-  per_cu = per_cu < 1 ? 1 : (per_cu > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : per_cu);
-  if (k + s > 32 && per_cu > 2) per_cu = 2;   // the register-resident classes hold 16·MTC row values: 228 / 152 / 92 VGPRs
-  else if (k + s > 16 && per_cu > 3) per_cu = 3;
-  int g = ctx->num_cus * per_cu;
+  const size_t lds = ss_lds_bytes(k, s, true) + (nk_ss_fusable(k, s) ? ss_ws_doubles(k, s, false) * sizeof(double) : 0);
+  int g = ctx->num_cus * ss_per_cu(k, s, lds);
   if (g > ntiles) g = ntiles;
   return g > 0 ? g : 1;
 }
 
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
-                       const int *d_skip, int grid) {
+                       const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  const size_t lds = ss_lds_bytes(k, S, mode != 2);
+  const int cls = ss_class(k, S);
+  const bool fuse = tap != nullptr && mode != 0 && cls != 0;
+  const size_t tile = ss_tile_doubles(k, S, mode != 2, cls ? cls : SS_MTMAX);
+  const size_t lds = (tile + (fuse ? ss_ws_doubles(k, S, mode == 2) : 0)) * sizeof(double);
+  const int ws_off = (int)tile;
+  ss_tail_args ta;
+  std::memset(&ta, 0, sizeof(ta));
+  if (tap) ta = *tap;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
-#define SS_GO2(UPD, GRM, KM)                                                                                              \
+#define SS_GO3(UPD, GRM, KM, FS)                                                                                          \
   do {                                                                                                                    \
     if (lds > 64 * 1024)                                                                                                  \
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block<S, UPD, GRM, KM>),                            \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block<S, UPD, GRM, KM, FS>),                        \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
-    if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, k,  \
-                                  V, ldv, coef, partials, d_skip, ntiles);                                           \
-    else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef,     \
-                            partials, d_skip, ntiles);                                                               \
+    if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
+                                  k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off);                           \
+    else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef, \
+                            partials, d_skip, ntiles, ta, mark, ws_off);                                                  \
   } while (0)
 #define SS_GO(UPD, GRM)                                                                                                   \
   do {                                                                                                                    \
-    if (k + S <= 16) SS_GO2(UPD, GRM, 1);                                                                                 \
-    else if (k + S <= 32) SS_GO2(UPD, GRM, 2);                                                                            \
-    else if (k + S <= 48) SS_GO2(UPD, GRM, 3);                                                                            \
-    else SS_GO2(UPD, GRM, 0);                                                                                             \
+    if (cls == 1) { if (fuse) SS_GO3(UPD, GRM, 1, UPD); else SS_GO3(UPD, GRM, 1, false); }                                \
+    else if (cls == 2) { if (fuse) SS_GO3(UPD, GRM, 2, UPD); else SS_GO3(UPD, GRM, 2, false); }                           \
+    else if (cls == 3) { if (fuse) SS_GO3(UPD, GRM, 3, UPD); else SS_GO3(UPD, GRM, 3, false); }                           \
+    else SS_GO3(UPD, GRM, 0, false);                                                                                      \
   } while (0)
   int g = grid;
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
-  else {                                    // sweep C: update only — no LDS tile, so the occupancy is not bounded by it
-    g = ctx->num_cus * 6 < ntiles ? ctx->num_cus * 6 : ntiles;
+  else {                                    // sweep C: update only — no LDS tile
+    const int per_cu = fuse ? (cls == 1 ? 6 : (cls == 2 ? 4 : 3)) : 6;   // fused: persistent (one prologue per workgroup)
+    g = ctx->num_cus * per_cu < ntiles ? ctx->num_cus * per_cu : ntiles;
     SS_GO(true, false);
   }
 #undef SS_GO
-#undef SS_GO2
+#undef SS_GO3
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
-// mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them
+// mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid) {
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
   switch (s) {
-    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
-    default: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid);
+    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    default: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
   }
 }
 
@@ -264,7 +580,7 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   NK_TRY(nk_dev_alloc(&dp, nslots * grid + 1));
   NK_HIP(hipMemcpy(dV, V_host, nv * sizeof(double), hipMemcpyHostToDevice));
   if (coef_host) NK_HIP(hipMemcpy(dc, coef_host, ((size_t)k * s + s * s) * sizeof(double), hipMemcpyHostToDevice));
-  NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid));
+  NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr));
   NK_HIP(hipStreamSynchronize(ctx->stream));
   NK_HIP(hipMemcpy(V_host, dV, nv * sizeof(double), hipMemcpyDeviceToHost));
   if (mode != 2 && gram_out) {
@@ -281,7 +597,7 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
     NK_HIP(hipEventCreate(&e0));
     NK_HIP(hipEventCreate(&e1));
     NK_HIP(hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters; ++i) NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid));
+    for (int i = 0; i < iters; ++i) NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr));
     NK_HIP(hipEventRecord(e1, ctx->stream));
     NK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -294,201 +610,6 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   hipFree(dc);
   hipFree(dp);
   return NK_OK;
-}
-
-// ============================================================================= the block tails (one workgroup)
-__device__ __forceinline__ void ss_pub_progress(nk_gmres_pub *pub, uint64_t seq, int k, int done) {
-  if (pub != nullptr)
-    __hip_atomic_store(&pub->progress, (seq << 16) | ((uint64_t)k << 1) | (uint64_t)(done ? 1 : 0), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
-constexpr int SS_KMAX = 16 * SS_MTMAX;  // k + s ≤ 80
-
-// Shared by both tails: from the reduced block [V_kᵀX ; XᵀX] (X = the s columns behind V_k; `sc` un-normalised-column
-// scales) the true coefficients Ct = diag(sc)·V_kᵀX, the Cholesky factor R of XᵀX − CtᵀCt (Pythagorean form of ‖X − V Ct‖)
-// and R⁻¹. Returns false on a non-positive or non-finite pivot (the monomial block lost rank numerically).
-__device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, double *Ct /*k×sb*/,
-                          double *Rm /*sb×sb*/, double *Ri /*sb×sb*/, double *Sm /*sb×sb*/, int *s_ok) {
-  const int t = threadIdx.x;
-  for (int e = t; e < k * sb; e += blockDim.x) Ct[e] = sc[e / sb] * red[e];
-  __syncthreads();
-  if (t < sb * sb) {
-    const int a = t / sb, b = t % sb;
-    double s = red[(size_t)(k + a) * sb + b];
-    for (int j = 0; j < k; ++j) s = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s);
-    Sm[t] = s;
-    Rm[t] = 0.0;
-    Ri[t] = 0.0;
-  }
-  __syncthreads();
-  if (t == 0) {
-    int ok = 1;
-    for (int a = 0; a < sb && ok; ++a) {  // upper-triangular R with RᵀR = S, row by row
-      double d = Sm[a * sb + a];
-      for (int p = 0; p < a; ++p) d -= Rm[p * sb + a] * Rm[p * sb + a];
-      if (!(d > 0.0) || isinf(d)) { ok = 0; break; }
-      const double raa = sqrt(d);
-      Rm[a * sb + a] = raa;
-      for (int b = a + 1; b < sb; ++b) {
-        double v = 0.5 * (Sm[a * sb + b] + Sm[b * sb + a]);
-        for (int p = 0; p < a; ++p) v -= Rm[p * sb + a] * Rm[p * sb + b];
-        Rm[a * sb + b] = v / raa;
-      }
-    }
-    if (ok) {  // R⁻¹ (upper), column by column
-      for (int b = 0; b < sb; ++b) {
-        Ri[b * sb + b] = 1.0 / Rm[b * sb + b];
-        for (int a = b - 1; a >= 0; --a) {
-          double v = 0.0;
-          for (int p = a + 1; p <= b; ++p) v -= Rm[a * sb + p] * Ri[p * sb + b];
-          Ri[a * sb + b] = v / Rm[a * sb + a];
-        }
-      }
-    }
-    *s_ok = ok;
-  }
-  __syncthreads();
-  return *s_ok != 0;
-}
-
-// tail 1: coefficients of sweep B; C₁ and R₁ are kept for tail 2; σ estimate for the next cycle from ‖A v‖ of the first block
-__global__ __launch_bounds__(256) void k_ss_tail1(nk_gmres_ctl *ctl, int k, int sb, const double *__restrict__ red,
-                                                  const double *__restrict__ sc, double *__restrict__ coef,
-                                                  double *__restrict__ C1, double *__restrict__ R1, double *scal,
-                                                  nk_gmres_pub *pub, uint64_t seq) {
-  __shared__ double Ct[SS_KMAX * SS_SMAX], Rm[64], Ri[64], Sm[64];
-  __shared__ int s_ok;
-  if (ctl->done) return;
-  const int t = threadIdx.x;
-  const bool ok = ss_factor(k, sb, red, sc, Ct, Rm, Ri, Sm, &s_ok);
-  if (!ok) {
-    if (t == 0) { ctl->failed = 2; ctl->done = 1; ss_pub_progress(pub, seq, ctl->k, 1); }
-    return;
-  }
-  for (int e = t; e < k * sb; e += 256) { C1[e] = Ct[e]; coef[e] = sc[e / sb] * Ct[e]; }
-  if (t < sb * sb) { R1[t] = Rm[t]; coef[(size_t)k * sb + t] = Ri[t]; }
-  if (t == 0 && k == 1) {  // ‖A v₁‖ = σ·√(XᵀX)₀₀: the scale of the next cycle's monomial basis, rounded to a power of two
-    const double est = scal[2] * sqrt(red[(size_t)k * sb]);
-    if (est > 0.0 && !isinf(est)) scal[3] = exp2(rint(log2(est)));
-  }
-}
-
-// tail 2: coefficients of sweep C; C = C₁ + C₂R₁, R = R₂R₁; the s new Hessenberg columns; Givens, residual norms, stopping test.
-// Coordinates in the basis [V_k Q] (K = k + s): X_j (column j of the block, j = 0..s−1) = F[:, j] = [C_j ; R_j], and
-//   A v_k = σ X_0 ;  A X_{j−1} = σ X_j ;  q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}   (j = 1..s−1)
-// so the coordinates of A q_j follow from those of A v_1..A v_{k−1} (the old Hessenberg columns), A v_k and A q_1..A q_{j−1}.
-__global__ __launch_bounds__(256) void k_ss_tail2(nk_gmres_ctl *ctl, int k, int sb, const double *__restrict__ red,
-                                                  double *__restrict__ sc, double *__restrict__ coef,
-                                                  const double *__restrict__ C1, const double *__restrict__ R1,
-                                                  double *__restrict__ H, int m, double *__restrict__ Rg, double *cs, double *sn,
-                                                  double *g, double *scal, nk_gmres_pub *pub, uint64_t seq) {
-  __shared__ double Ct[SS_KMAX * SS_SMAX], Rm[64], Ri[64], Sm[64], R1s[64];
-  __shared__ double F[SS_KMAX * SS_SMAX], NC[SS_SMAX * SS_KMAX];
-  __shared__ double Hs[NK_MAX_NV * NK_MAX_NV];              // the old columns (rows < k, columns < k − 1), pitch k
-  __shared__ double scs[NK_MAX_NV + SS_SMAX], ssn[NK_MAX_NV + SS_SMAX], sg[NK_MAX_NV + SS_SMAX + 1];
-  __shared__ int s_ok;
-  const int t = threadIdx.x;
-  if (ctl->done) {
-    if (t == 0) ctl->pad1 = 1;  // the block never started: sweep C has nothing to finish
-    return;
-  }
-  const int K = k + sb, ko = k - 1;                         // ko old Hessenberg columns / rotations
-  // everything the serial parts below read from global memory, requested up front by all threads (a dependent chain of
-  // uncached loads on one lane cost 29 µs per block in the first version of this kernel)
-  for (int e = t; e < k * ko; e += 256) Hs[e] = H[(size_t)(e / ko) * m + (e % ko)];
-  if (t < ko) { scs[t] = cs[t]; ssn[t] = sn[t]; }
-  if (t <= ko) sg[t] = g[t];
-  const bool ok = ss_factor(k, sb, red, sc, Ct, Rm, Ri, Sm, &s_ok);
-  if (!ok) {
-    if (t == 0) { ctl->failed = 2; ctl->done = 1; ctl->pad1 = 1; ss_pub_progress(pub, seq, ctl->k, 1); }
-    return;
-  }
-  for (int e = t; e < k * sb; e += 256) coef[e] = sc[e / sb] * Ct[e];
-  if (t < sb * sb) { coef[(size_t)k * sb + t] = Ri[t]; R1s[t] = R1[t]; }
-  __syncthreads();
-  for (int e = t; e < k * sb; e += 256) {  // C = C₁ + C₂ R₁
-    const int j = e / sb, c = e % sb;
-    double v = C1[e];
-    for (int a = 0; a <= c; ++a) v = __builtin_fma(Ct[j * sb + a], R1s[a * sb + c], v);
-    F[e] = v;
-  }
-  if (t < sb * sb) {  // R = R₂ R₁ (upper)
-    const int a = t / sb, c = t % sb;
-    double v = 0.0;
-    for (int p = a; p <= c; ++p) v = __builtin_fma(Rm[a * sb + p], R1s[p * sb + c], v);
-    F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
-  }
-  __syncthreads();
-  const double sigma = scal[2];
-  if (t < K) NC[t] = sigma * F[t * sb];
-  __syncthreads();
-  for (int j = 1; j < sb; ++j) {
-    if (t < K) {
-      const int i = t;
-      double a = sigma * F[i * sb + j];
-      if (i < k)
-        for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
-      a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
-      for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * SS_KMAX + i], F[(k + q - 1) * sb + (j - 1)], a);
-      NC[j * SS_KMAX + i] = a / F[(k + j - 1) * sb + (j - 1)];
-    }
-    __syncthreads();
-  }
-  for (int e = t; e < sb * K; e += 256) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
-    const int j = e / K, i = e % K, jc = ko + j;
-    if (i <= jc + 1 && jc < m) H[(size_t)i * m + jc] = NC[j * SS_KMAX + i];
-  }
-  __syncthreads();
-  if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane
-    const int jc = ko + t;
-    double *h = &NC[t * SS_KMAX];
-    for (int i = 0; i < ko; ++i) {
-      const double a = h[i], b = h[i + 1];
-      Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
-      h[i + 1] = -ssn[i] * a + scs[i] * b;
-    }
-  }
-  __syncthreads();
-  if (t == 0) {  // the rotations this block creates: a chain of sb short steps
-    const double tol = ctl->tol;
-    int closed = 0, dn = 0;
-    double rn = ctl->rnorm, beta = 0.0;
-    for (int j = 0; j < sb && !dn; ++j) {
-      const int jc = ko + j;
-      double *h = &NC[j * SS_KMAX];
-      for (int i = ko; i < jc; ++i) {
-        const double a = h[i], b = h[i + 1];
-        Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
-        h[i + 1] = -ssn[i] * a + scs[i] * b;
-      }
-      const double hk = h[jc];
-      beta = h[jc + 1];
-      const double d = hypot(hk, beta);
-      double c, sgn;
-      if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
-      scs[jc] = c;
-      ssn[jc] = sgn;
-      Rg[(size_t)jc * m + jc] = d;
-      const double gj = sg[jc];
-      sg[jc + 1] = -sgn * gj;
-      sg[jc] = c * gj;
-      rn = fabs(sgn * gj);
-      closed = j + 1;
-      if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; dn = 1; }
-      else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
-      else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
-    }
-    for (int j = 0; j < closed; ++j) { cs[ko + j] = scs[ko + j]; sn[ko + j] = ssn[ko + j]; g[ko + j] = sg[ko + j]; }
-    g[ko + closed] = sg[ko + closed];
-    ctl->rnorm = rn;
-    ctl->hn = beta;
-    ctl->k = ko + closed;
-    ctl->pad1 = 0;
-    if (dn) ctl->done = 1;
-    for (int c = 0; c < sb; ++c) sc[k + c] = 1.0;  // the new columns are normalised
-    scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
-    ss_pub_progress(pub, seq, ctl->k, dn);
-  }
 }
 
 // start of a cycle (after k_gmres_begin): the scale of the monomial basis and of the first operator application
@@ -542,6 +663,9 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   const int64_t n = G->n, ldv = G->ldv;
   const int s = G->ss_s > 0 ? (G->ss_s > SS_SMAX ? SS_SMAX : G->ss_s) : 6;
   const int *done = &G->d_ctl->done, *skipC = &G->d_ctl->pad1;
+  ss_tail_args ta;
+  ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.H = W->H; ta.m = G->m;
+  ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
   const bool single = nk_ctx_is_single(ctx);
   NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal);
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
@@ -553,10 +677,13 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1)));
     const int grid = nk_ss_grid(ctx, n, k, sb);
     const int nslots = (k + sb) * sb;
+    // fused: the scalar work between the passes runs in the prologue of the sweep that consumes it (k + s ≤ 48)
+    const bool fused = nk_ss_fusable(k, sb);
     for (int pass = 0; pass < 2; ++pass) {
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb + (pass ? sb : 0)));
-        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid));
+        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid, (pass == 1 && fused) ? &ta : nullptr,
+                           pass == 0 ? &G->d_ctl->pad1 : nullptr));
       }
       {
         nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
@@ -567,17 +694,18 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         for (int off = 0; off < nslots; off += piece)
           NK_TRY(nk_comm_allreduce(ctx, W->red + off, nslots - off < piece ? nslots - off : piece, 0));
       }
-      if (pass == 0)
-        NK_LAUNCH(ctx, k_ss_tail1, dim3(1), dim3(256), G->d_ctl, k, sb, (const double *)W->red, (const double *)G->d_s, W->coef,
-                  W->C1, W->R1, W->scal, G->h_pub_dev, G->cycle_seq);
-      else
-        NK_LAUNCH(ctx, k_ss_tail2, dim3(1), dim3(256), G->d_ctl, k, sb, (const double *)W->red, G->d_s, W->coef,
-                  (const double *)W->C1, (const double *)W->R1, W->H, G->m, G->d_R, G->d_cs, G->d_sn, G->d_g, W->scal,
-                  G->h_pub_dev, G->cycle_seq);
+      if (!fused) {
+        if (pass == 0)
+          hipLaunchKernelGGL(k_ss_tail1, dim3(1), dim3(256), ss_ws_doubles(k, sb, false) * sizeof(double), ctx->stream, k, sb,
+                             W->coef, ta);
+        else
+          hipLaunchKernelGGL(k_ss_tail2, dim3(1), dim3(256), ss_ws_doubles(k, sb, true) * sizeof(double), ctx->stream, k, sb,
+                             W->coef, ta);
+      }
     }
     {
       nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 2 * sb));
-      NK_TRY(nk_ss_sweep(ctx, 2, n, k, sb, G->V, ldv, W->coef, W->part, skipC, grid));
+      NK_TRY(nk_ss_sweep(ctx, 2, n, k, sb, G->V, ldv, W->coef, W->part, skipC, grid, fused ? &ta : nullptr, nullptr));
     }
     NK_HIP(hipGetLastError());
     k += sb;
