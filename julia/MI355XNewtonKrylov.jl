@@ -146,7 +146,7 @@ mi355x_function(P::DeviceProblem) = NonlinearFunction{true}(DeviceResidual(P); j
 
 # ------------------------------------------------------------------ seam 1: linsolve backend
 """
-    MI355XGMRES(; gmres_restart = 30, ortho = :dcgs2)
+    MI355XGMRES(; gmres_restart = 30, ortho = :dcgs2, sstep = 6)
 
 `NewtonRaphson(linsolve = MI355XGMRES())`. NonlinearSolveBase only needs what
 ext/NonlinearSolveBaseLinearSolveExt.jl:16-32,60-115 uses: `needs_concrete_A == false`, a cache with settable
@@ -154,7 +154,8 @@ ext/NonlinearSolveBaseLinearSolveExt.jl:16-32,60-115 uses: `needs_concrete_A == 
 """
 Base.@kwdef struct MI355XGMRES <: LinearSolve.AbstractKrylovSubspaceMethod   # [EXT]
     gmres_restart::Int = 30
-    ortho::Symbol = :dcgs2
+    ortho::Symbol = :dcgs2     # :mgs | :cgs2 | :cgs | :dcgs2 | :sstep (s columns per block, matrix-core Gram blocks)
+    sstep::Int = 6
 end
 LinearSolve.needs_concrete_A(::MI355XGMRES) = false                           # [EXT]
 
@@ -177,13 +178,14 @@ mutable struct GMRESWorkspace
     box::Union{Nothing, OperatorBox}        # keep-alive of the operator behind the C callback
     precbox::Union{Nothing, OperatorBox}
 end
-const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2, :dcgs2 => 3)
+const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2, :dcgs2 => 3, :dcgs2_1r => 4, :sstep => 5)
 
 function LinearSolve.init_cacheval(alg::MI355XGMRES, A, b, u, Pl, Pr, maxiters::Int, abstol, reltol,
         verbose, assumptions)                                                  # [EXT signature]
     out = Ref{Ptr{Cvoid}}(C_NULL)
     nkcheck(@ccall libnk.nk_gmres_create(default_ctx().ptr::Ptr{Cvoid}, length(b)::Int64,
         alg.gmres_restart::Cint, ORTHO[alg.ortho]::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
+    alg.ortho === :sstep && nkcheck(@ccall libnk.nk_gmres_set_block_size(out[]::Ptr{Cvoid}, alg.sstep::Cint)::Cint)
     w = GMRESWorkspace(out[], length(b), nothing, nothing, nothing)
     finalizer(x -> @ccall(libnk.nk_gmres_destroy(x.ptr::Ptr{Cvoid})::Cint), w)
     return w
@@ -280,6 +282,8 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     direct::Bool = false                  # linsolve = nothing: banded LU on the device (needs concrete_jac)
     gmres_restart::Int = 30
     gmres_maxiters::Int = 300
+    ortho::Symbol = :dcgs2                # Arnoldi process: :mgs | :cgs2 | :cgs | :dcgs2 | :sstep
+    sstep::Int = 6                        # ortho = :sstep: basis columns per block
     forcing::Bool = false                 # EisenstatWalkerForcing2()
     radius_update_scheme::Int = 0         # RadiusUpdateSchemes.Simple … Fan (0…6)
     linesearch::Symbol = :none            # :none | :BackTracking | :Static | :StrongWolfe | :MoreThuente | :HagerZhang (LineSearchesJL methods)
@@ -370,6 +374,7 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
         maxiters = maxiters, abstol = something(abstol, 0.0), reltol = something(reltol, 0.0),
         maxtime = something(maxtime, 0.0),
         gmres_restart = alg.gmres_restart, gmres_maxiters = alg.gmres_maxiters,
+        gmres_ortho = ORTHO[alg.ortho], gmres_sstep = alg.sstep,
         forcing = alg.forcing ? 1 : 0, radius_update_scheme = alg.radius_update_scheme,
         linesearch = get(Dict(:BackTracking => 1, :Static => 2, :StrongWolfe => 3, :MoreThuente => 4, :HagerZhang => 5), alg.linesearch, 0),
         cheb_degree = alg.precs === :chebyshev ? alg.cheb_degree : 0, cheb_ratio = alg.cheb_ratio,
