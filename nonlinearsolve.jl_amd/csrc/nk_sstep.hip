@@ -489,7 +489,7 @@ bool nk_ss_fusable(int k, int s) {
 // persistent workgroups per CU: bounded by the LDS tile (+ the fused scalar workspace) and the register-resident classes'
 // VGPR footprint (228 / 152 / 92 with the Gram accumulators)
 static int ss_per_cu(int k, int s, size_t lds) {
-  int per_cu = lds ? (int)((size_t)(150 * 1024) / lds) : SS_MAX_WG_PER_CU;
+  int per_cu = lds ? (int)((size_t)(160 * 1024) / lds) : SS_MAX_WG_PER_CU;   // 160 KB of LDS per CU
   per_cu = per_cu < 1 ? 1 : (per_cu > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : per_cu);
   if (k + s > 32 && per_cu > 2) per_cu = 2;
   else if (k + s > 16 && per_cu > 3) per_cu = 3;
