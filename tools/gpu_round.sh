@@ -10,6 +10,8 @@ timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 400 python bench.py > $O/bench_csr.json 2> $O/bench_csr.err
 timeout 200 python bench.py --matfree --cpu-seconds 0 --no-ttt > $O/bench_matfree.json 2> /dev/null
+timeout 200 python bench.py --ortho dcgs2 --cpu-seconds 0 --no-ttt > $O/bench_csr_dcgs2.json 2> /dev/null
+NK_SS_FUSED=0 timeout 200 python bench.py --cpu-seconds 0 --no-ttt > $O/bench_csr_unfused_tails.json 2> /dev/null
 timeout 200 python bench.py --workload c5 --cpu-seconds 0 --no-ttt > $O/bench_c5_1gpu.json 2> /dev/null
 timeout 200 python bench.py --workload c4 --steps 4 --warmup 1 --cpu-seconds 0 --no-ttt > $O/bench_c4size_1gpu.json 2> /dev/null
 timeout 500 bash tools/profile_round.sh ${TAG}
