@@ -177,3 +177,48 @@ def test_c3_fixed_work_with_sstep_vs_c_oracle(nls, dev):
     uC, fnC, giC, _ = CO.bratu_newton(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=True, m=30, itmax=30, fixed_iters=30, forcing=False)
     assert np.allclose(traces[0], fnC, rtol=1e-6) and np.max(np.abs(us[0] - uC)) <= 1e-9
     assert np.allclose(traces[0], traces[1], rtol=1e-9) and np.max(np.abs(us[0] - us[1])) <= 1e-11
+
+
+def test_sstep_with_callable_operator_and_chebyshev(nls, dev):
+    """Operators reached through callbacks do not fuse the 1/σ scaling (the vector is scaled first, then handed over), and the
+    Chebyshev polynomial preconditioner sits inside every matrix power: both against the oracle's column-by-column GMRES."""
+    import torch
+    P = R.Bratu2D(40)
+    u = P.u0() + 0.1 * np.sin(np.arange(P.n) * 0.37)
+    A, b = P.jac(u).tocsr(), P.f(u)
+    Ad = torch.sparse_csr_tensor(torch.tensor(A.indptr, dtype=torch.int64), torch.tensor(A.indices, dtype=torch.int64),
+                                 torch.tensor(A.data), size=A.shape).to(dev)
+    bd = torch.tensor(b, device=dev)
+    xr, ir = R.gmres(lambda z: A @ z, b, restart=24, fixed_iters=24, ortho="cgs2")
+    G = nls.GMRES(P.n, restart=24, ortho="sstep", sstep=4).set_operator(lambda x: Ad @ x)
+    x, gi = G.solve(bd, fixed_iters=24)
+    assert gi["iters"] == 24 and np.linalg.norm(x.cpu().numpy() - xr) <= 1e-10 * np.linalg.norm(xr)
+    PD = nls.Bratu2D(40)
+    J = PD.jac_csr()
+    PD.jac_values(torch.tensor(u, device=dev), J)
+    lmax = R.gershgorin_lambda(A)
+    M = R.chebyshev_preconditioner(lambda v: A @ v, lmax / 30.0, lmax, 8)
+    xc, ic = R.gmres(lambda z: A @ z, b, rtol=1e-9, restart=30, itmax=200, M=M, ortho="cgs2")
+    Gc = nls.GMRES(P.n, restart=30, ortho="sstep", sstep=5).set_operator(J)
+    Gc.set_chebyshev_preconditioner(8, lmax / 30.0, lmax)
+    x2, g2 = Gc.solve(bd, abstol=0.0, reltol=1e-9, maxiters=200)
+    assert g2["converged"] and np.linalg.norm(x2.cpu().numpy() - xc) <= 1e-7 * np.linalg.norm(xc)
+    assert abs(g2["iters"] - ic.iters) <= 5
+
+
+def test_c5_fixed_work_with_sstep_equals_column_form(nls, dev):
+    """Config C5 at full size (Brusselator 512², TrustRegion, coloured concrete J, 30 Arnoldi steps per step): the s-step and
+    the delayed-CGS2 runs accept/reject alike and keep the same iterate."""
+    outs = []
+    for ortho in ("sstep", "dcgs2"):
+        PB = nls.Brusselator2D(512)
+        cache = nls.init(nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True)),
+                         nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30, ortho=ortho), concrete_jac=True,
+                                         jac_colored=True), abstol=1e-300, maxiters=100, store_trace=True)
+        for _ in range(4):
+            cache.step()
+        outs.append(([t["accepted"] for t in cache.trace], np.array([t["fnorm_inf"] for t in cache.trace]), cache.u.cpu().numpy()))
+        cache.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-7)
+    assert np.max(np.abs(outs[0][2] - outs[1][2])) <= 1e-8 * np.max(np.abs(outs[1][2]))
