@@ -157,3 +157,29 @@ def test_gauss_newton_default_linsolve_is_a_plain_direct_solve(nls):
     sol = nls.solve(nls.NonlinearLeastSquaresProblem(nls.Bratu2D(16)), nls.GaussNewton(), abstol=1e-9, maxiters=30)
     assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and sol.stats.nsteps == ref.stats.nsteps
     assert sol.stats.gmres_iters == 0 and np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-9
+
+
+def test_kwargs_sets_of_the_reference_tests(nls):
+    """rootfind_tests__item11.jl (TrustRegion kwargs) and item18 (LevenbergMarquardt kwargs): the three option sets each, on
+    quadratic_f with u0 = [1, 1], p = 2 — err < 1e-9 and the oracle's step counts (every option reaches the device)."""
+    u0 = np.array([1.0, 1.0])
+    opts = zip([10.0, 100.0, 1000.0], [10.0, 1.0, 0.1], [0.0, 0.01, 0.25], [0.25, 0.3, 0.5], [0.5, 0.8, 0.9], [0.1, 0.3, 0.5],
+               [1.5, 2.0, 3.0], [10, 20, 30])
+    for mtr, itr, st, sht, et, sf, ef, mst in opts:
+        kw = dict(max_trust_radius=mtr, initial_trust_radius=itr, step_threshold=st, shrink_threshold=sht, expand_threshold=et,
+                  shrink_factor=sf, expand_factor=ef, max_shrink_times=mst)
+        ref = R.solve(R.Quadratic(2, 2.0), R.TrustRegion(**kw), u0=u0)
+        sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(2, 2.0), u0=u0), nls.TrustRegion(**kw))
+        assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and sol.stats.nsteps == ref.stats.nsteps
+        assert np.max(np.abs(np.asarray(sol.u) ** 2 - 2.0)) < 1e-9
+    opts = zip([0.5, 2.0, 5.0], [1.5, 3.0, 10.0], [2.0, 5.0, 10.0], [0.02, 0.2, 0.3], [0.6, 0.8, 0.9], [0.0, 1.0, 2.0],
+               [1e-12, 1e-9, 1e-4])
+    for di, dif, ddf, fd, ag, bu, md in opts:
+        kw = dict(damping_initial=di, damping_increase_factor=dif, damping_decrease_factor=ddf, finite_diff_step_geodesic=fd,
+                  alpha_geodesic=ag, b_uphill=bu, min_damping_D=md)
+        ref = R.solve(R.Quadratic(2, 2.0), R.LevenbergMarquardt(**kw), u0=u0, maxiters=10000)
+        sol = nls.solve(nls.NonlinearProblem(nls.Quadratic(2, 2.0), u0=u0), nls.LevenbergMarquardt(**kw), maxiters=10000)
+        # (the device factorises the damped normal equations where the oracle solves the least-squares form: at the default
+        #  abstol the last step or two sit on the rounding floor — 17 against 16 steps on the first set)
+        assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and abs(sol.stats.nsteps - ref.stats.nsteps) <= 3
+        assert np.max(np.abs(np.asarray(sol.u) ** 2 - 2.0)) < 1e-9

@@ -756,3 +756,37 @@ def test_sstep_gmres_agrees_with_column_schemes_and_scipy():
     x1, _ = R.gmres(lambda z: A @ z, b, restart=12, fixed_iters=12, ortho=("sstep", 4))
     x2, _ = R.gmres(lambda z: (A @ z) * 0.25, b * 0.25, restart=12, fixed_iters=12, ortho=("sstep", 4))
     assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))
+
+
+# ---- the remaining known-answer sets of lib/NonlinearSolveFirstOrder/test/rootfind_tests.jl
+def test_trust_region_iterator_kwargs_and_termination_known_answers():
+    """item9 (iterator interface ≈ √p), item11 (the three kwargs sets reach err < 1e-9 on quadratic_f, u0 = [1, 1], p = 2),
+    item13 (every termination condition)."""
+    ps = np.linspace(0.01, 2, 200)
+    c = R.init(R.Quadratic(1, ps[0]), R.TrustRegion(), abstol=1e-10, maxiters=100, u0=np.array([0.5]))
+    out = []
+    for p in ps:                                   # common_rootfind_testing.jl:47-57: continue from the previous root
+        c.reinit(c.u.copy(), p=p)
+        out.append(c.solve().u[0])
+    assert np.allclose(out, np.sqrt(ps))
+    opts = zip([10.0, 100.0, 1000.0], [10.0, 1.0, 0.1], [0.0, 0.01, 0.25], [0.25, 0.3, 0.5], [0.5, 0.8, 0.9], [0.1, 0.3, 0.5],
+               [1.5, 2.0, 3.0], [10, 20, 30])
+    for mtr, itr, st, sht, et, sf, ef, mst in opts:
+        alg = R.TrustRegion(max_trust_radius=mtr, initial_trust_radius=itr, step_threshold=st, shrink_threshold=sht,
+                            expand_threshold=et, shrink_factor=sf, expand_factor=ef, max_shrink_times=mst)
+        sol = R.solve(R.Quadratic(2, 2.0), alg, u0=np.array([1.0, 1.0]))
+        assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+    for mode in range(9):
+        sol = R.solve(R.Quadratic(2, 2.0), R.TrustRegion(), u0=np.array([1.0, 1.0]), termination_kwargs=dict(mode=mode))
+        assert np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+
+
+def test_levenberg_marquardt_kwargs_known_answers():
+    """item18: the three kwargs sets (damping_initial … min_damping_D) reach err < 1e-9 within maxiters = 10000."""
+    opts = zip([0.5, 2.0, 5.0], [1.5, 3.0, 10.0], [2.0, 5.0, 10.0], [0.02, 0.2, 0.3], [0.6, 0.8, 0.9], [0.0, 1.0, 2.0],
+               [1e-12, 1e-9, 1e-4])
+    for di, dif, ddf, fd, ag, bu, md in opts:
+        alg = R.LevenbergMarquardt(damping_initial=di, damping_increase_factor=dif, damping_decrease_factor=ddf,
+                                   finite_diff_step_geodesic=fd, alpha_geodesic=ag, b_uphill=bu, min_damping_D=md)
+        sol = R.solve(R.Quadratic(2, 2.0), alg, u0=np.array([1.0, 1.0]), maxiters=10000)
+        assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
