@@ -113,6 +113,15 @@ def _worker(rank, world, port, ns, q):
         cycles = info_1r.restarts + 1
         assert info_1r.iters + cycles <= n_ar[0] <= info_1r.iters + 2 * cycles + 1
 
+        # (e) the s-step form: per block of s columns TWO all-reduces of (k + s)·s values (the block's projections and its
+        # Gram matrix travel together), β₀ per cycle — 2·⌈30/s⌉ + 1 per full cycle instead of 30 + 2
+        n_ar[0] = 0
+        x_ss, info_ss = R.gmres(matvec_local, bvec[rb:re_], restart=30, fixed_iters=60, ortho=("sstep", 6), allreduce=ar)
+        x_ser60, _ = R.gmres(lambda z: J @ z, bvec, restart=30, fixed_iters=60, ortho="cgs2")
+        assert info_ss.iters == 60 and info_ss.restarts == 1
+        assert np.linalg.norm(x_ss - x_ser60[rb:re_]) <= 1e-9 * np.linalg.norm(x_ser60)
+        assert n_ar[0] == 2 * (2 * 5) + 2
+
         # distributed residual + ∞-norm (max all-reduce) as in the Newton driver
         lo, hi = _exchange_lines(rank, world, u[rb:rb + ns].copy(), u[re_ - ns:re_].copy(), ns)
         f_loc = p.f(u)[rb:re_]
