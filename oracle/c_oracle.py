@@ -69,6 +69,8 @@ def lib():
         L.orc_phase_times.argtypes = [_d]
         L.orc_bratu_newton_fast.restype = C.c_double
         L.orc_bratu_newton_fast.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, _d]
+        L.orc_bratu_newton_fast_sstep.restype = C.c_double
+        L.orc_bratu_newton_fast_sstep.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int, _d]
         _lib = L
     return _lib
 
@@ -189,6 +191,19 @@ def bratu_newton_fast(ns, lam, scale, u0, nsteps, use_csr=True, m=30):
     sec = lib().orc_bratu_newton_fast(ns, lam, scale, u, nsteps, int(use_csr), m, fn)
     if sec < 0:
         raise ValueError("bad restart length")
+    return u, fn, sec
+
+
+def bratu_newton_fast_sstep(ns, lam, scale, u0, nsteps, use_csr=True, m=30, s=6):
+    """The same fixed-work Newton steps with the s-step Arnoldi process (the device's NK_ORTHO_SSTEP; C restatement of
+    reference_restatement.gmres_sstep). Returns (u, fnorm trace, seconds of the step loop)."""
+    u = np.array(u0, dtype=np.float64, copy=True)
+    fn = np.zeros(nsteps)
+    sec = lib().orc_bratu_newton_fast_sstep(ns, lam, scale, u, nsteps, int(use_csr), m, int(s), fn)
+    if sec == -2.0:
+        raise ArithmeticError("a block of the monomial basis lost rank numerically (Cholesky breakdown)")
+    if sec < 0:
+        raise ValueError("bad restart length or block size")
     return u, fn, sec
 
 

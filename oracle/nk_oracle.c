@@ -928,3 +928,274 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
   free(rowptr); free(col); free(rp0); free(c0); free(val); free(V); free(u); free(f); free(x); free(part);
   return elapsed;
 }
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * The same fixed-work Newton step with the s-step Arnoldi process (the device's NK_ORTHO_SSTEP; the NumPy restatement is
+ * oracle/reference_restatement.py::gmres_sstep): per block of sb ≤ s columns the monomial vectors X_j = A X_{j−1}
+ * (X_0 = A v_k), then twice [C ; G] = [V_k X]ᵀX in ONE team reduction, RᵀR = G − CᵀC, X ← (X − V_k C) R⁻¹; the Hessenberg
+ * columns follow from C = C₁ + C₂R₁, R = R₂R₁ and the old columns. Same host-side structure as orc_bratu_newton_fast (one
+ * persistent parallel region, static row partition, first touch, row tiles kept in cache while the columns stream past).
+ * Returns the wall seconds of the step loop, −1 on bad arguments, −2 when a block loses rank numerically (where the device
+ * falls back to the column-by-column scheme). TEST INFRASTRUCTURE / baseline only.
+ */
+#define ORC_SMAX 8
+static int ss_chol_inv(int sb, const double *S, double *Rm, double *Ri) { /* S = RᵀR (upper R), Ri = R⁻¹; row-major sb×sb */
+  for (int e = 0; e < sb * sb; ++e) { Rm[e] = 0.0; Ri[e] = 0.0; }
+  for (int a = 0; a < sb; ++a) {
+    double d = S[a * sb + a];
+    for (int p = 0; p < a; ++p) d -= Rm[p * sb + a] * Rm[p * sb + a];
+    if (!(d > 0.0) || isinf(d)) return 0;
+    const double raa = sqrt(d);
+    Rm[a * sb + a] = raa;
+    for (int b = a + 1; b < sb; ++b) {
+      double v = 0.5 * (S[a * sb + b] + S[b * sb + a]);
+      for (int p = 0; p < a; ++p) v -= Rm[p * sb + a] * Rm[p * sb + b];
+      Rm[a * sb + b] = v / raa;
+    }
+  }
+  for (int b = 0; b < sb; ++b) {
+    Ri[b * sb + b] = 1.0 / Rm[b * sb + b];
+    for (int a = b - 1; a >= 0; --a) {
+      double v = 0.0;
+      for (int p = a + 1; p <= b; ++p) v -= Rm[a * sb + p] * Ri[p * sb + b];
+      Ri[a * sb + b] = v / Rm[a * sb + a];
+    }
+  }
+  return 1;
+}
+double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, double *u_io, int nsteps, int use_csr, int m,
+                                   int s, double *fnorm_inf) {
+  const int64_t n = ns * ns, nnz = orc_bratu_nnz(ns);
+  if (m < 1 || m > ORC_MAXM - 2 || s < 1 || s > ORC_SMAX) return -1.0;
+  const bratu_t bp = bratu_make(ns, lambda, scale);
+  int32_t *rowptr = NULL, *col = NULL, *rp0 = NULL, *c0 = NULL;
+  double *val = NULL;
+  if (use_csr) {
+    rp0 = (int32_t *)malloc((size_t)(n + 1) * 4);
+    c0 = (int32_t *)malloc((size_t)nnz * 4);
+    orc_bratu_pattern(ns, rp0, c0);
+    rowptr = (int32_t *)malloc((size_t)(n + 1) * 4);
+    col = (int32_t *)malloc((size_t)nnz * 4);
+    val = (double *)malloc((size_t)nnz * 8);
+  }
+  double *V = (double *)malloc((size_t)(m + 2) * n * 8);
+  double *u = (double *)malloc((size_t)n * 8), *f = (double *)malloc((size_t)n * 8);
+  const int maxT = orc_num_threads();
+  const int KS = (ORC_MAXM + ORC_SMAX) * ORC_SMAX;  /* entries of a reduced block */
+  const int stride = KS + ORC_PAD;
+  double *part = (double *)calloc((size_t)maxT * stride, 8);
+  double elapsed = 0.0;
+  int broke = 0;
+#pragma omp parallel
+  {
+    const int t = TID(), T = NTHR();
+    int64_t lo, hi;
+    my_rows(n, ns, t, T, &lo, &hi);
+    for (int64_t i = lo; i < hi; ++i) { u[i] = u_io[i]; f[i] = 0.0; }
+    for (int c = 0; c < m + 2; ++c) {
+      double *vc = V + (size_t)c * n;
+      for (int64_t i = lo; i < hi; ++i) vc[i] = 0.0;
+    }
+    if (use_csr) {
+      for (int64_t i = lo; i < hi; ++i) {
+        rowptr[i] = rp0[i];
+        for (int32_t k = rp0[i]; k < rp0[i + 1]; ++k) { col[k] = c0[k]; val[k] = 0.0; }
+      }
+      if (t == 0) rowptr[n] = rp0[n];
+    }
+    /* thread-private Krylov scalars (identical on every thread) */
+    double H[(ORC_MAXM + ORC_SMAX + 2) * ORC_MAXM], R[ORC_MAXM * ORC_MAXM];
+    double cs[ORC_MAXM], sn[ORC_MAXM], g[ORC_MAXM + 1], yv[ORC_MAXM];
+    double mine[(ORC_MAXM + ORC_SMAX) * ORC_SMAX], red[(ORC_MAXM + ORC_SMAX) * ORC_SMAX];
+    double C1[ORC_MAXM * ORC_SMAX], R1[ORC_SMAX * ORC_SMAX], Ct[ORC_MAXM * ORC_SMAX], Rm[ORC_SMAX * ORC_SMAX],
+        Ri[ORC_SMAX * ORC_SMAX], Sm[ORC_SMAX * ORC_SMAX], F[(ORC_MAXM + ORC_SMAX) * ORC_SMAX],
+        NC[ORC_SMAX * (ORC_MAXM + ORC_SMAX)];
+    int bad = 0;
+#pragma omp barrier
+    for (int64_t i = lo; i < hi; ++i) f[i] = bp.c_lap * lap5(u, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]);
+#pragma omp barrier
+    const double t0 = now_s();
+    for (int step = 0; step < nsteps && !bad; ++step) {
+      if (use_csr) {
+        for (int64_t k = lo; k < hi; ++k) {
+          const int64_t i = k % ns, j = k / ns;
+          int64_t p = rowptr[k];
+          if (j > 0) val[p++] = -bp.c_lap;
+          if (i > 0) val[p++] = -bp.c_lap;
+          val[p++] = 4.0 * bp.c_lap - bp.c_exp * exp(u[k]);
+          if (i < ns - 1) val[p++] = -bp.c_lap;
+          if (j < ns - 1) val[p++] = -bp.c_lap;
+        }
+      }
+      double s0 = 0.0;
+      for (int64_t i = lo; i < hi; ++i) s0 += f[i] * f[i];
+      team_sum(part, stride, 1, &s0, red);
+      const double beta0 = sqrt(red[0]);
+      const double ib = beta0 > 0.0 ? 1.0 / beta0 : 0.0;
+      for (int64_t i = lo; i < hi; ++i) V[i] = f[i] * ib;
+      for (int i = 0; i <= m; ++i) g[i] = 0.0;
+      g[0] = beta0;
+      int kdone = 0;
+#pragma omp barrier
+      int k = 1; /* orthonormal columns so far */
+      while (k - 1 < m && !bad) {
+        const int sb = (m - (k - 1)) < s ? (m - (k - 1)) : s, K = k + sb, ko = k - 1;
+        double *X = V + (size_t)k * n;
+        /* ---- matrix powers: X_j = A X_{j−1}, X_0 = A v_k (a barrier after each: the stencil reaches other threads' rows) */
+        for (int j = 0; j < sb; ++j) {
+          const double *src = V + (size_t)(k - 1 + j) * n;
+          double *dst = X + (size_t)j * n;
+          if (use_csr) {
+            for (int64_t i = lo; i < hi; ++i) {
+              double a = 0.0;
+              for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) a += val[q] * src[col[q]];
+              dst[i] = a;
+            }
+          } else {
+            for (int64_t i = lo; i < hi; ++i) dst[i] = bp.c_lap * lap5(src, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]) * src[i];
+          }
+#pragma omp barrier
+        }
+        for (int pass = 0; pass < 2 && !bad; ++pass) {
+          /* ---- [V_k X]ᵀ X on this thread's rows: the X tile stays in cache while the basis columns stream past */
+          const int cnt = K * sb;
+          for (int q = 0; q < cnt; ++q) mine[q] = 0.0;
+          for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
+            const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
+            const int len = (int)(r1 - r0);
+            for (int j = 0; j < K; ++j) {
+              const double *vj = V + (size_t)j * n + r0;
+              for (int c = (j < k ? 0 : j - k); c < sb; ++c) {  /* the Gram part: upper triangle only */
+                const double *xc = X + (size_t)c * n + r0;
+                double a = 0.0;
+#pragma omp simd reduction(+ : a)
+                for (int i = 0; i < len; ++i) a += vj[i] * xc[i];
+                mine[j * sb + c] += a;
+              }
+            }
+          }
+          team_sum(part, stride, cnt, mine, red);
+          /* ---- scalar work (every thread, identical) */
+          for (int j = 0; j < k; ++j)
+            for (int c = 0; c < sb; ++c) Ct[j * sb + c] = red[j * sb + c];
+          for (int a = 0; a < sb; ++a)
+            for (int c = 0; c < sb; ++c) {
+              double v = (c >= a) ? red[(k + a) * sb + c] : red[(k + c) * sb + a];
+              for (int j = 0; j < k; ++j) v -= Ct[j * sb + a] * Ct[j * sb + c];
+              Sm[a * sb + c] = v;
+            }
+          if (!ss_chol_inv(sb, Sm, Rm, Ri)) { bad = 1; break; }
+          /* ---- X ← (X − V_k Ct) R⁻¹ on this thread's rows */
+          for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
+            const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
+            const int len = (int)(r1 - r0);
+            double xt[ORC_SMAX][ORC_TILE];
+            for (int c = 0; c < sb; ++c) {
+              const double *xc = X + (size_t)c * n + r0;
+              for (int i = 0; i < len; ++i) xt[c][i] = xc[i];
+            }
+            for (int j = 0; j < k; ++j) {
+              const double *vj = V + (size_t)j * n + r0;
+              for (int c = 0; c < sb; ++c) {
+                const double cf = Ct[j * sb + c];
+                double *xc = xt[c];
+#pragma omp simd
+                for (int i = 0; i < len; ++i) xc[i] -= cf * vj[i];
+              }
+            }
+            for (int c = sb - 1; c >= 0; --c) {  /* in place, last column first: column c needs the old columns ≤ c */
+              double *xo = X + (size_t)c * n + r0;
+              for (int i = 0; i < len; ++i) {
+                double a = 0.0;
+                for (int cc = 0; cc <= c; ++cc) a += xt[cc][i] * Ri[cc * sb + c];
+                xo[i] = a;
+              }
+            }
+          }
+          if (pass == 0) {
+            for (int e = 0; e < k * sb; ++e) C1[e] = Ct[e];
+            for (int e = 0; e < sb * sb; ++e) R1[e] = Rm[e];
+          }
+#pragma omp barrier
+        }
+        if (bad) break;
+        /* ---- C = C₁ + C₂R₁, R = R₂R₁ → F = [C ; R]; Hessenberg columns; Givens */
+        for (int j = 0; j < k; ++j)
+          for (int c = 0; c < sb; ++c) {
+            double v = C1[j * sb + c];
+            for (int a = 0; a <= c; ++a) v += Ct[j * sb + a] * R1[a * sb + c];
+            F[j * sb + c] = v;
+          }
+        for (int a = 0; a < sb; ++a)
+          for (int c = 0; c < sb; ++c) {
+            double v = 0.0;
+            for (int p = a; p <= c; ++p) v += Rm[a * sb + p] * R1[p * sb + c];
+            F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
+          }
+        for (int i = 0; i < K; ++i) NC[i] = F[i * sb];
+        for (int j = 1; j < sb; ++j)
+          for (int i = 0; i < K; ++i) {
+            double a = F[i * sb + j];
+            if (i < k)
+              for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a -= H[i * ORC_MAXM + tt] * F[tt * sb + (j - 1)];
+            a -= NC[i] * F[(k - 1) * sb + (j - 1)];
+            for (int q = 1; q < j; ++q) a -= NC[q * K + i] * F[(k + q - 1) * sb + (j - 1)];
+            NC[j * K + i] = a / F[(k + j - 1) * sb + (j - 1)];
+          }
+        for (int j = 0; j < sb; ++j) {
+          const int jc = ko + j;
+          double *h = &NC[j * K];
+          for (int i = 0; i <= jc + 1; ++i) H[i * ORC_MAXM + jc] = h[i];
+          for (int i = 0; i < jc; ++i) {
+            const double tt = cs[i] * h[i] + sn[i] * h[i + 1];
+            h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+            h[i] = tt;
+          }
+          const double dd = hypot(h[jc], h[jc + 1]);
+          if (dd == 0.0) { cs[jc] = 1.0; sn[jc] = 0.0; } else { cs[jc] = h[jc] / dd; sn[jc] = h[jc + 1] / dd; }
+          for (int i = 0; i < jc; ++i) R[i * ORC_MAXM + jc] = h[i];
+          R[jc * ORC_MAXM + jc] = dd;
+          g[jc + 1] = -sn[jc] * g[jc];
+          g[jc] = cs[jc] * g[jc];
+          kdone = jc + 1;
+        }
+        k += sb;
+      }
+      if (bad) break;
+      /* ---- y = R⁻¹ g ; x = V y ; u −= x ; f = F(u) ; ‖f‖∞ */
+      for (int i = kdone - 1; i >= 0; --i) {
+        double a = g[i];
+        for (int j = i + 1; j < kdone; ++j) a -= R[i * ORC_MAXM + j] * yv[j];
+        yv[i] = a / R[i * ORC_MAXM + i];
+      }
+      for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
+        const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
+        double acc[ORC_TILE];
+        const int len = (int)(r1 - r0);
+        for (int i = 0; i < len; ++i) acc[i] = 0.0;
+        for (int j = 0; j < kdone; ++j) {
+          const double *vj = V + (size_t)j * n + r0;
+          const double yj = yv[j];
+          for (int i = 0; i < len; ++i) acc[i] += yj * vj[i];
+        }
+        for (int i = 0; i < len; ++i) u[r0 + i] -= acc[i];
+      }
+#pragma omp barrier
+      double mx = 0.0;
+      for (int64_t i = lo; i < hi; ++i) {
+        const double fi = bp.c_lap * lap5(u, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]);
+        f[i] = fi;
+        const double a = fabs(fi);
+        if (a > mx || a != a) mx = a;
+      }
+      mx = team_max(part, stride, mx);
+      if (t == 0) fnorm_inf[step] = mx;
+    }
+    if (bad && t == 0) broke = 1;
+#pragma omp barrier
+    if (t == 0) elapsed = now_s() - t0;
+    for (int64_t i = lo; i < hi; ++i) u_io[i] = u[i];
+  }
+  free(rowptr); free(col); free(rp0); free(c0); free(val); free(V); free(u); free(f); free(part);
+  return broke ? -2.0 : elapsed;
+}

@@ -177,6 +177,10 @@ def test_c3_fixed_work_with_sstep_vs_c_oracle(nls, dev):
     uC, fnC, giC, _ = CO.bratu_newton(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=True, m=30, itmax=30, fixed_iters=30, forcing=False)
     assert np.allclose(traces[0], fnC, rtol=1e-6) and np.max(np.abs(us[0] - uC)) <= 1e-9
     assert np.allclose(traces[0], traces[1], rtol=1e-9) and np.max(np.abs(us[0] - us[1])) <= 1e-11
+    # … and of the C oracle's own s-step restatement (oracle/nk_oracle.c::orc_bratu_newton_fast_sstep): the same arithmetic
+    # at full size, to rounding
+    uS, fnS, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=True, m=30, s=6)
+    assert np.allclose(traces[0], fnS, rtol=1e-9) and np.max(np.abs(us[0] - uS)) <= 1e-10
 
 
 def test_sstep_with_callable_operator_and_chebyshev(nls, dev):

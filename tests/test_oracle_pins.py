@@ -790,3 +790,27 @@ def test_levenberg_marquardt_kwargs_known_answers():
                                    finite_diff_step_geodesic=fd, alpha_geodesic=ag, b_uphill=bu, min_damping_D=md)
         sol = R.solve(R.Quadratic(2, 2.0), alg, u0=np.array([1.0, 1.0]), maxiters=10000)
         assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.u * sol.u - 2.0)) < 1e-9
+
+
+def test_c_oracle_sstep_equals_python_restatement_and_column_form():
+    """oracle/nk_oracle.c::orc_bratu_newton_fast_sstep (the full-size anchor of the device's s-step path) against the NumPy
+    restatement and against the C oracle's delayed-CGS2 leg: the fixed-work protocol, CSR and matrix-free."""
+    from oracle import c_oracle as CO
+    CO.build()
+    for ns in (24, 40):     # (12²: the Krylov space degenerates before 30 columns — a rank-deficient block, tested below)
+        n = ns * ns
+        for use_csr in (True, False):
+            u1, f1, _ = CO.bratu_newton_fast(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30)
+            for s_ in (1, 4, 6):
+                u2, f2, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30, s=s_)
+                assert np.max(np.abs(u1 - u2)) <= 1e-10 and np.allclose(f1, f2, rtol=1e-7)
+        c = R.init(R.Bratu2D(ns, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(fixed_iters=30, maxiters=30, ortho=("sstep", 6))),
+                   abstol=1e-300, maxiters=100, u0=np.zeros(n))
+        for _ in range(4):
+            c.step()
+        u2, _, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=True, m=30, s=6)
+        assert np.max(np.abs(c.u - u2)) <= 1e-10
+    with pytest.raises(ValueError):
+        CO.bratu_newton_fast_sstep(8, 6.0, 0.0, np.zeros(64), 1, m=30, s=9)
+    with pytest.raises(ArithmeticError):   # where the device falls back to the column-by-column scheme
+        CO.bratu_newton_fast_sstep(12, 6.0, 0.0, np.zeros(144), 4, m=30, s=6)
