@@ -226,3 +226,10 @@ def test_c5_fixed_work_with_sstep_equals_column_form(nls, dev):
     assert outs[0][0] == outs[1][0]
     assert np.allclose(outs[0][1], outs[1][1], rtol=1e-7)
     assert np.max(np.abs(outs[0][2] - outs[1][2])) <= 1e-8 * np.max(np.abs(outs[1][2]))
+
+
+def test_block_size_is_validated(nls):
+    with pytest.raises(nls.NKError, match="block size"):
+        nls.GMRES(100, restart=30, ortho="sstep", sstep=9)
+    with pytest.raises(nls.NKError, match="block size"):
+        nls.GMRES(100, restart=30, ortho="sstep", sstep=0)
