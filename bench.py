@@ -52,7 +52,8 @@ def parse_args():
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"])
     ap.add_argument("--grid", dest="n", type=int, default=0, help="grid side (default: 1024 for c3, 4096 for c4, 512 for c5)")
     ap.add_argument("--ortho", default="sstep", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs", "sstep"])
-    ap.add_argument("--sstep", type=int, default=6, help="--ortho sstep: basis columns per block")
+    ap.add_argument("--sstep", type=int, default=0, help="--ortho sstep: basis columns per block (0 = the library's choice: 15 Newton basis, 6 monomial)")
+    ap.add_argument("--sstep-basis", default="auto", choices=["auto", "monomial", "newton"])
     ap.add_argument("--arnoldi", type=int, default=30)
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
@@ -166,12 +167,12 @@ def main():
         if kind == "c5":
             PB = nls.Brusselator2D(ns)
             prob = nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True))
-            alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho, sstep=args.sstep,
+            alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho, sstep=args.sstep, sstep_basis=args.sstep_basis,
                                                               fixed_iters=args.arnoldi), concrete_jac=not args.matfree)
         else:
             prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
             prob.u0 = torch.zeros(prob.device_problem.n_local, dtype=torch.float64, device="cuda")
-            alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho, sstep=args.sstep,
+            alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=args.arnoldi, maxiters=args.arnoldi, ortho=args.ortho, sstep=args.sstep, sstep_basis=args.sstep_basis,
                                                                 fixed_iters=args.arnoldi), concrete_jac=not args.matfree)
         # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
         return prob, nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)
@@ -343,7 +344,7 @@ def main():
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
-                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho if args.ortho != "sstep" else "sstep%d" % args.sstep,
+                       "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho if args.ortho != "sstep" else "sstep_%s_%s" % (args.sstep or "auto", args.sstep_basis),
                        "parallelism": f"row-range x{world}", "comm": comm, "halo_overlap": overlap},
             "roofline": roof, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
             "gpu_vs_cpu": round(steps_per_s / cpu["value"], 1) if cpu and "value" in cpu else None,

@@ -103,12 +103,22 @@ typedef enum {
   NK_ORTHO_DCGS2_1R = 4, /* insist on the one-reduction form (the pending vector's second projection and the new vector's
                        * first projection share a fused dot sweep; the Hessenberg column and the stopping test lag
                        * one step); falls back like NK_ORTHO_DCGS2 where the operator does not allow it            */
-  NK_ORTHO_SSTEP = 5    /* s-step (communication-avoiding) Arnoldi: s operator applications build a monomial block, which is
-                       * orthogonalised against the basis and within itself by block CGS in Pythagorean form, twice — three
-                       * sweeps over the basis per s columns instead of two per column; the Gram blocks run on the FP64
-                       * matrix cores. Block size: nk_options.gmres_sstep / nk_gmres_set_block_size (default 6). A block
-                       * that loses rank numerically (Cholesky breakdown) makes the solve fall back to NK_ORTHO_DCGS2.      */
+  NK_ORTHO_SSTEP = 5    /* s-step (communication-avoiding) Arnoldi: s operator applications build a block of basis vectors
+                       * (A − θ_j I)…(A − θ_0 I) v — Newton basis with Leja-ordered Chebyshev shifts when real bounds of the
+                       * operator's spectrum are known (Gershgorin discs of a CSR operator, the Bratu stencil's closed form,
+                       * nk_gmres_set_spectrum_interval), monomial (θ = 0) otherwise — which is orthogonalised against the
+                       * basis and within itself by block CGS in Pythagorean form, twice: three sweeps over the basis per
+                       * s columns instead of two per column; the Gram blocks run on the FP64 matrix cores. Block size:
+                       * nk_options.gmres_sstep / nk_gmres_set_block_size (0 = automatic: 15 Newton, 6 monomial). A block
+                       * that loses rank numerically (Cholesky breakdown) finishes that solve with NK_ORTHO_DCGS2.           */
 } nk_ortho;
+
+/* basis of an s-step block (nk_options.gmres_sstep_basis / nk_gmres_set_sstep_basis) */
+typedef enum {
+  NK_SS_BASIS_AUTO = 0,     /* Newton where spectrum bounds are known, else monomial */
+  NK_SS_BASIS_MONOMIAL = 1, /* A^j v (block size ≤ 8 advisable: κ grows like ρ^s)     */
+  NK_SS_BASIS_NEWTON = 2    /* insist on the Newton basis (error if no bounds known)  */
+} nk_ss_basis;
 
 typedef enum { NK_FORCING_NONE = 0, NK_FORCING_EISENSTAT_WALKER2 = 1 } nk_forcing;
 
@@ -241,8 +251,8 @@ typedef struct {
    *     evolution relaxation α⁻¹ ← α⁻¹·‖f‖₂/‖f_prev‖₂; mass matrix: identity, or a diagonal through
    *     nk_solver_set_mass_matrix_diagonal */
   double  pt_alpha_initial;             /* [1e-3] initial pseudo time step α                                          */
-  int32_t gmres_sstep;                  /* [6]    NK_ORTHO_SSTEP: basis columns per block (1..8)                      */
-  int32_t reserved_tail;                /* [0]    keeps the struct a multiple of 8 bytes                              */
+  int32_t gmres_sstep;                  /* [0]    NK_ORTHO_SSTEP: basis columns per block (1..16; 0 = automatic)      */
+  int32_t gmres_sstep_basis;            /* [0]    nk_ss_basis                                                         */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -396,8 +406,19 @@ int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user);
 /* on != 0: the operator of the next solves is AᵀA for the CSR / problem operator that is set (normal form: the
  * transposed half is the distributed transposed SpMV or the problem's VJP); the caller passes b = Aᵀ f. */
 int nk_gmres_set_normal_form(nk_gmres *G, int on);   /* AbstractSciMLOperator    */
-/* NK_ORTHO_SSTEP: number of basis columns per block, 1..8 (the last block of a cycle is cut to fit the restart length) */
+/* NK_ORTHO_SSTEP: number of basis columns per block, 1..16; 0 = automatic (15 with the Newton basis, 6 with the monomial
+ * one). The last block of a cycle is cut to fit the restart length. */
 int nk_gmres_set_block_size(nk_gmres *G, int s);
+/* NK_ORTHO_SSTEP: basis of a block (nk_ss_basis) */
+int nk_gmres_set_sstep_basis(nk_gmres *G, int basis);
+/* Real bounds lo < hi of the operator's spectrum (its real part) for operators the library cannot bound itself — callback
+ * and matrix-free operators. They place the Newton-basis shifts of NK_ORTHO_SSTEP; approximate bounds are fine (the
+ * shifts only condition the block, the Krylov space is the same). lo = hi = 0 forgets them. */
+int nk_gmres_set_spectrum_interval(nk_gmres *G, double lo, double hi);
+/* NK_ORTHO_SSTEP diagnostics: the block size in effect (automatic sizes narrow 15 → 8 → 4 after a block lost rank), whether
+ * the last solve built Newton-basis blocks, and how many blocks have lost rank so far (each made its cycle run again —
+ * narrower, or column by column). Any pointer may be NULL. */
+int nk_gmres_get_sstep_state(nk_gmres *G, int *block_size, int *newton_basis, int *breakdowns);
 /* Damped normal form: the operator becomes AᵀA + lambda·diag(d) (d: DEVICE vector of local length n, kept by reference;
  * NULL switches the damping off) — `dampen_jacobian!!(J_cache, JᵀJ, λ·DᵀD)` of DampedNewtonDescent's :normal_form mode
  * (lib/NonlinearSolveBase/src/descent/damped_newton.jl:297-313,356-370) without assembling JᵀJ. */

@@ -154,8 +154,9 @@ ext/NonlinearSolveBaseLinearSolveExt.jl:16-32,60-115 uses: `needs_concrete_A == 
 """
 Base.@kwdef struct MI355XGMRES <: LinearSolve.AbstractKrylovSubspaceMethod   # [EXT]
     gmres_restart::Int = 30
-    ortho::Symbol = :dcgs2     # :mgs | :cgs2 | :cgs | :dcgs2 | :sstep (s columns per block, matrix-core Gram blocks)
-    sstep::Int = 6
+    ortho::Symbol = :sstep     # :mgs | :cgs2 | :cgs | :dcgs2 | :sstep (s columns per block, matrix-core Gram blocks; the default)
+    sstep::Int = 0             # 0 = automatic: 15 with the Newton basis (spectrum bounds known), 6 with the monomial one
+    sstep_basis::Symbol = :auto  # :auto | :monomial | :newton
 end
 LinearSolve.needs_concrete_A(::MI355XGMRES) = false                           # [EXT]
 
@@ -179,13 +180,17 @@ mutable struct GMRESWorkspace
     precbox::Union{Nothing, OperatorBox}
 end
 const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2, :dcgs2 => 3, :dcgs2_1r => 4, :sstep => 5)
+const SS_BASIS = Dict(:auto => 0, :monomial => 1, :newton => 2)
 
 function LinearSolve.init_cacheval(alg::MI355XGMRES, A, b, u, Pl, Pr, maxiters::Int, abstol, reltol,
         verbose, assumptions)                                                  # [EXT signature]
     out = Ref{Ptr{Cvoid}}(C_NULL)
     nkcheck(@ccall libnk.nk_gmres_create(default_ctx().ptr::Ptr{Cvoid}, length(b)::Int64,
         alg.gmres_restart::Cint, ORTHO[alg.ortho]::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
-    alg.ortho === :sstep && nkcheck(@ccall libnk.nk_gmres_set_block_size(out[]::Ptr{Cvoid}, alg.sstep::Cint)::Cint)
+    if alg.ortho === :sstep
+        nkcheck(@ccall libnk.nk_gmres_set_block_size(out[]::Ptr{Cvoid}, alg.sstep::Cint)::Cint)
+        nkcheck(@ccall libnk.nk_gmres_set_sstep_basis(out[]::Ptr{Cvoid}, SS_BASIS[alg.sstep_basis]::Cint)::Cint)
+    end
     w = GMRESWorkspace(out[], length(b), nothing, nothing, nothing)
     finalizer(x -> @ccall(libnk.nk_gmres_destroy(x.ptr::Ptr{Cvoid})::Cint), w)
     return w
@@ -282,8 +287,9 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     direct::Bool = false                  # linsolve = nothing: banded LU on the device (needs concrete_jac)
     gmres_restart::Int = 30
     gmres_maxiters::Int = 300
-    ortho::Symbol = :dcgs2                # Arnoldi process: :mgs | :cgs2 | :cgs | :dcgs2 | :sstep
-    sstep::Int = 6                        # ortho = :sstep: basis columns per block
+    ortho::Symbol = :sstep                # Arnoldi process: :mgs | :cgs2 | :cgs | :dcgs2 | :sstep
+    sstep::Int = 0                        # ortho = :sstep: basis columns per block (0 = automatic)
+    sstep_basis::Symbol = :auto           # :auto | :monomial | :newton
     forcing::Bool = false                 # EisenstatWalkerForcing2()
     radius_update_scheme::Int = 0         # RadiusUpdateSchemes.Simple … Fan (0…6)
     linesearch::Symbol = :none            # :none | :BackTracking | :Static | :StrongWolfe | :MoreThuente | :HagerZhang (LineSearchesJL methods)
@@ -333,7 +339,7 @@ end
 Base.@kwdef mutable struct NKOptions
     algorithm::Int32 = 0; linsolve::Int32 = 0; maxiters::Int32 = 1000; termination_norm::Int32 = 0
     abstol::Float64 = 0.0; reltol::Float64 = 0.0; maxtime::Float64 = 0.0
-    gmres_restart::Int32 = 30; gmres_maxiters::Int32 = 300; gmres_ortho::Int32 = 3; gmres_fixed_iters::Int32 = 0
+    gmres_restart::Int32 = 30; gmres_maxiters::Int32 = 300; gmres_ortho::Int32 = 5; gmres_fixed_iters::Int32 = 0
     lin_abstol::Float64 = -1.0; lin_reltol::Float64 = -1.0
     forcing::Int32 = 0; ew_safeguard::Int32 = 1
     ew_eta0::Float64 = 0.5; ew_eta_max::Float64 = 0.9; ew_gamma::Float64 = 0.9; ew_alpha::Float64 = 2.0
@@ -353,7 +359,7 @@ Base.@kwdef mutable struct NKOptions
     lm_min_damping_D::Float64 = 1e-8; lm_alpha_geodesic::Float64 = 0.75; lm_finite_diff_step_geodesic::Float64 = 0.1
     lm_b_uphill::Float64 = 1.0
     pt_alpha_initial::Float64 = 1e-3
-    gmres_sstep::Int32 = 6; reserved_tail::Int32 = 0
+    gmres_sstep::Int32 = 0; gmres_sstep_basis::Int32 = 0
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,
@@ -374,7 +380,7 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
         maxiters = maxiters, abstol = something(abstol, 0.0), reltol = something(reltol, 0.0),
         maxtime = something(maxtime, 0.0),
         gmres_restart = alg.gmres_restart, gmres_maxiters = alg.gmres_maxiters,
-        gmres_ortho = ORTHO[alg.ortho], gmres_sstep = alg.sstep,
+        gmres_ortho = ORTHO[alg.ortho], gmres_sstep = alg.sstep, gmres_sstep_basis = SS_BASIS[alg.sstep_basis],
         forcing = alg.forcing ? 1 : 0, radius_update_scheme = alg.radius_update_scheme,
         linesearch = get(Dict(:BackTracking => 1, :Static => 2, :StrongWolfe => 3, :MoreThuente => 4, :HagerZhang => 5), alg.linesearch, 0),
         cheb_degree = alg.precs === :chebyshev ? alg.cheb_degree : 0, cheb_ratio = alg.cheb_ratio,

@@ -73,7 +73,7 @@ class Options(C.Structure):
         ("lm_alpha_geodesic", C.c_double), ("lm_finite_diff_step_geodesic", C.c_double), ("lm_b_uphill", C.c_double),
         ("pt_alpha_initial", C.c_double),
         ("gmres_sstep", C.c_int32),
-        ("reserved_tail", C.c_int32),
+        ("gmres_sstep_basis", C.c_int32),
     ]
 
 
@@ -134,6 +134,9 @@ SIGNATURES = {
     "nk_gmres_set_normal_form_damping": (_I, [_P, _P, C.c_double]),
     "nk_gmres_set_shift": (_I, [_P, C.c_double]),
     "nk_gmres_set_block_size": (_I, [_P, _I]),
+    "nk_gmres_set_sstep_basis": (_I, [_P, _I]),
+    "nk_gmres_set_spectrum_interval": (_I, [_P, C.c_double, C.c_double]),
+    "nk_gmres_get_sstep_state": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "nk_gmres_set_shift_weights": (_I, [_P, _P]),
     "nk_problem_create": (_I, [_P, _I, C.POINTER(_D), _I, _PP]),
     "nk_problem_create_user": (_I, [_P, _L, _L, _L, C.POINTER(UserCallbacks), _P, _P, _PP]),

@@ -549,9 +549,10 @@ class KrylovJL_GMRES:
     """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
     gmres_restart: int = 30
     maxiters: int = 300
-    ortho: str = "dcgs2"       # "mgs" (Krylov.jl's structure) | "cgs2" | "dcgs2" (= cgs2, delayed 2nd pass) | "cgs" | "sstep"
+    ortho: str = "sstep"       # "mgs" (Krylov.jl's structure) | "cgs2" | "dcgs2" (= cgs2, delayed 2nd pass) | "cgs" | "sstep" (the library default)
     fixed_iters: int = 0
-    sstep: int = 6             # ortho = "sstep": basis columns per block (1..8)
+    sstep: int = 0             # ortho = "sstep": basis columns per block (1..16); 0 = automatic (15 Newton basis, 6 monomial)
+    sstep_basis: str = "auto"  # "auto" (Newton where the spectrum can be bounded) | "monomial" | "newton"
     abstol: Optional[float] = None   # None → the nonlinear tolerances are forwarded (FirstOrder/src/solve.jl:203)
     reltol: Optional[float] = None
     precs: Optional[ChebyshevPrecs] = None
@@ -708,6 +709,7 @@ TERMINATION_CONDITIONS = [  # common/common_rootfind_testing.jl:3-13
     AbsNormSafeBestTerminationMode,
 ]
 
+_SS_BASIS = {"auto": 0, "monomial": 1, "newton": 2}
 _ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2": L.ORTHO_DCGS2, "dcgs2_1r": L.ORTHO_DCGS2_1R,
           "sstep": L.ORTHO_SSTEP}
 
@@ -747,7 +749,8 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     o.maxtime = 0.0 if maxtime is None else float(maxtime)
     o.gmres_restart, o.gmres_maxiters = int(ls.gmres_restart), int(ls.maxiters)
     o.gmres_ortho, o.gmres_fixed_iters = _ORTHO[ls.ortho], int(ls.fixed_iters)
-    o.gmres_sstep = int(getattr(ls, "sstep", 6))
+    o.gmres_sstep = int(getattr(ls, "sstep", 0))
+    o.gmres_sstep_basis = _SS_BASIS[getattr(ls, "sstep_basis", "auto")]
     o.lin_abstol = -1.0 if ls.abstol is None else float(ls.abstol)
     o.lin_reltol = -1.0 if ls.reltol is None else float(ls.reltol)
     lsr = getattr(alg, "linesearch", None)
@@ -992,12 +995,14 @@ def reinit_(cache, u0=None, p=None, **kw):  # reinit!(cache, u0; p[, retain_best
 class GMRES:
     """nk_gmres: the LinearCache analogue NonlinearSolveBase drives (A, b, u, reltol; solve!)."""
 
-    def __init__(self, n: int, restart: int = 30, ortho: str = "dcgs2", ctx: Optional[Context] = None, sstep: int = 6):
+    def __init__(self, n: int, restart: int = 30, ortho: str = "sstep", ctx: Optional[Context] = None, sstep: int = 0,
+                 sstep_basis: str = "auto"):
         self.ctx = ctx or default_context()
         h = C.c_void_p()
         check(L.lib().nk_gmres_create(self.ctx._h, n, restart, _ORTHO[ortho], C.byref(h)))
         if ortho == "sstep":
             check(L.lib().nk_gmres_set_block_size(h, int(sstep)))
+            check(L.lib().nk_gmres_set_sstep_basis(h, _SS_BASIS[sstep_basis]))
         self._h, self.n, self._keep = h, n, []
         self.abstol, self.reltol, self.maxiters = 0.0, 1e-8, 300
 
@@ -1064,6 +1069,17 @@ class GMRES:
         self._mg_u = (u, keep)  # the hierarchy keeps reading the fine-level u: keep it alive
         check(L.lib().nk_gmres_set_multigrid_preconditioner(self._h, dp._h, pu, ms, int(nu), int(coarse_max)))
         return self
+
+    def set_spectrum_interval(self, lo: float, hi: float):
+        """Real bounds of the operator's spectrum for operators the library cannot bound itself (callbacks, matrix-free):
+        they place the Newton-basis shifts of the s-step Arnoldi process. lo = hi = 0 forgets them."""
+        check(L.lib().nk_gmres_set_spectrum_interval(self._h, float(lo), float(hi)))
+
+    def sstep_state(self):
+        """(block size in effect, Newton basis in the last solve, blocks that lost rank so far) of the s-step process"""
+        bs, nb, bd = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(L.lib().nk_gmres_get_sstep_state(self._h, C.byref(bs), C.byref(nb), C.byref(bd)))
+        return bs.value, bool(nb.value), bd.value
 
     def chebyshev_interval(self):
         a, b = C.c_double(), C.c_double()

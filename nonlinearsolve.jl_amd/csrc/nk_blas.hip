@@ -132,10 +132,10 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum_allreduce(const double 
     }
   }
   __syncthreads();
-  if (t < nslots) {
-    double acc = mine->ar_data[par][0][t];
-    for (int q = 1; q < pv.P; ++q) acc += mine->ar_data[par][q][t];
-    out[t] = acc;
+  for (int e = t; e < nslots; e += NK_BLOCK) {
+    double acc = mine->ar_data[par][0][e];
+    for (int q = 1; q < pv.P; ++q) acc += mine->ar_data[par][q][e];
+    out[e] = acc;
   }
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_reduce_nanmax(const double *__restrict__ partials, int nblk,
@@ -644,6 +644,19 @@ int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslo
   NK_LAUNCH(ctx, k_reduce_sum, dim3(nslots), dim3(NK_BLOCK), partials, nblk, d_out, d_skip, (const double *)nullptr, 0);
   NK_HIP(hipGetLastError());
   return NK_OK;
+}
+// the same, all-reduced over the ranks: ONE launch on the peer path (the stage-2 reduction stores its sums straight into
+// every rank's arena and the last workgroup combines them), reduction + the transport's all-reduce otherwise
+int nk_blas_reduce_slots_allreduce(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip) {
+  if (nk_ctx_is_single(ctx)) return nk_blas_reduce_slots(ctx, partials, nblk, nslots, d_out, d_skip);
+  const nk_peer_ar_view pv = nk_peer_ar_next(ctx, nslots);
+  if (pv.seq) {
+    NK_LAUNCH(ctx, k_reduce_sum_allreduce, dim3(nslots), dim3(NK_BLOCK), partials, nblk, d_out, pv);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
+  NK_TRY(nk_blas_reduce_slots(ctx, partials, nblk, nslots, d_out, d_skip));
+  return nk_comm_allreduce(ctx, d_out, nslots, 0);
 }
 int nk_blas_reduce_one(nk_ctx *ctx, const double *partials, int nblk, double *d_out, const int *d_skip) {
   NK_LAUNCH(ctx, k_reduce_sum, dim3(1), dim3(NK_BLOCK), partials, nblk, d_out, d_skip, (const double *)nullptr, 0);

@@ -31,11 +31,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // every lane issues ALL its col/val loads unconditionally (the arrays are padded by one tile), then all x
 // gathers (out-of-tile lanes gather x[0]), then the LDS writes — TILE/256 independent loads in flight per lane.
 // Row epilogue. mode 0: y[row] = scale·s. mode 1 (fused Chebyshev step, x = d_old): r −= s; d_new = c1·d_old + c2·r;
-// yacc += d_new — saves the separate 56 n-byte vector update and a kernel boundary per polynomial degree.
+// yacc += d_new — saves the separate 56 n-byte vector update and a kernel boundary per polynomial degree. mode 3: shifted.
 __device__ __forceinline__ void spmv_store_row(int row, double s, double *__restrict__ y, const double *out_scale,
                                                double os, const double *__restrict__ x, const nk_spmv_epi &epi) {
   if (epi.mode == 0) {
     y[row] = out_scale ? os * s : s;
+  } else if (epi.mode == 3) {  // Newton-basis step of the s-step Arnoldi process: y = scale·(A x − θ x)
+    const double v = s - (*epi.theta) * x[row];
+    y[row] = out_scale ? os * v : v;
   } else {
     const double rr = epi.r[row] - s;
     epi.r[row] = rr;
@@ -459,6 +462,7 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_tperm);
   hipFree(A->d_ones);
   hipFree(A->d_diagpos);
+  hipFree(A->d_gersh);
   hipFree(A->d_tz);
   hipFree(A->d_trecv);
   hipFree(A->d_role);
@@ -498,6 +502,94 @@ extern "C" int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, i
   return NK_OK;
 }
 extern "C" double *nk_csr_values_device(nk_csr *A) { return A ? A->d_val : nullptr; }
+
+// ----------------------------------------------------------------------------- Gershgorin bounds of the spectrum's real part
+// Every eigenvalue lies in a disc |λ − a_ii| ≤ r_i = Σ_{j≠i} |a_ij|, so Re λ ∈ [min_i (a_ii − r_i), max_i (a_ii + r_i)] — the
+// interval the s-step Arnoldi process places the shifts of its Newton basis on (nk_sstep.hip). Same traversal as the SpMV: a
+// workgroup streams its row block's values and columns with lane-contiguous loads into LDS, then every lane walks one row
+// in CSR order (so the row sums equal a sequential CPU sum bit for bit); max is exact in any order. Halo columns are never
+// the diagonal. Output per block: {max_i −(a_ii − r_i), max_i (a_ii + r_i)}.
+__global__ __launch_bounds__(NK_BLOCK) void k_csr_gershgorin(int nblk, int tile, const int4 *__restrict__ rowblocks,
+                                                             const int32_t *__restrict__ rowptr,
+                                                             const int32_t *__restrict__ col,
+                                                             const double *__restrict__ val, double *__restrict__ part) {
+  extern __shared__ double g_sv[];
+  int32_t *g_sc = reinterpret_cast<int32_t *>(g_sv + tile);
+  __shared__ double red[8];
+  const int b = blockIdx.x;
+  const int4 desc = rowblocks[b];
+  const int r0 = desc.x, r1 = desc.y, p0 = desc.z, p1 = desc.w;
+  const int nnzb = p1 - p0;
+  double mlo = -INFINITY, mhi = -INFINITY;
+  if (nnzb <= tile) {
+    for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
+      g_sv[k] = val[p0 + k];
+      g_sc[k] = col[p0 + k];
+    }
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += NK_BLOCK) {
+      const int a = rowptr[r] - p0, e = rowptr[r + 1] - p0;
+      double rad = 0.0, d = 0.0;
+      for (int k = a; k < e; ++k) {
+        const double v = g_sv[k];
+        if (g_sc[k] == r) d += v;
+        else rad += fabs(v);
+      }
+      mlo = fmax(mlo, -(d - rad));
+      mhi = fmax(mhi, d + rad);
+    }
+  } else {  // a single long row
+    double rad = 0.0, d = 0.0;
+    for (int k = threadIdx.x; k < nnzb; k += NK_BLOCK) {
+      const double v = val[p0 + k];
+      if (col[p0 + k] == r0) d += v;
+      else rad += fabs(v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { rad += __shfl_xor(rad, o, 64); d += __shfl_xor(d, o, 64); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = rad; red[4 + (threadIdx.x >> 6)] = d; }
+    __syncthreads();
+    rad = (red[0] + red[1]) + (red[2] + red[3]);
+    d = (red[4] + red[5]) + (red[6] + red[7]);
+    mlo = -(d - rad);
+    mhi = d + rad;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mlo = fmax(mlo, __shfl_xor(mlo, o, 64)); mhi = fmax(mhi, __shfl_xor(mhi, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mlo; red[4 + (threadIdx.x >> 6)] = mhi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[b] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    part[nblk + b] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  }
+}
+__global__ __launch_bounds__(1024) void k_max2_final(int nblk, const double *__restrict__ part, double *__restrict__ out2) {
+  __shared__ double red[32];
+  double a = -INFINITY, c = -INFINITY;
+  for (int i = threadIdx.x; i < nblk; i += 1024) { a = fmax(a, part[i]); c = fmax(c, part[nblk + i]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a = fmax(a, __shfl_xor(a, o, 64)); c = fmax(c, __shfl_xor(c, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[16 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) { a = fmax(a, red[w]); c = fmax(c, red[16 + w]); }
+    out2[0] = a;
+    out2[1] = c;
+  }
+}
+int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2) {
+  nk_ctx *ctx = A->ctx;
+  NK_REQUIRE(A->nblocks > 0, "Gershgorin bounds of an empty matrix");
+  if (!A->d_gersh) NK_TRY(nk_dev_alloc(&A->d_gersh, (size_t)2 * A->nblocks + 2));
+  nk_prof_scope prof_(ctx, NK_K_OTHER, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1));
+  hipLaunchKernelGGL(k_csr_gershgorin, dim3(A->nblocks), dim3(NK_BLOCK), (size_t)A->tile * 12, ctx->stream, A->nblocks,
+                     A->tile, (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, A->d_gersh);
+  NK_LAUNCH(ctx, k_max2_final, dim3(1), dim3(1024), A->nblocks, (const double *)A->d_gersh, d_out2);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
 
 int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale,
                     const nk_spmv_epi *epi) {

@@ -240,17 +240,16 @@ __device__ __forceinline__ bool peer_wait_ge(const uint64_t *flag, uint64_t seq,
   return true;
 }
 
-// One launch = one all-reduce of `count` ≤ 128 doubles: store my values into my slot of EVERY rank's arena, release my
+// One launch = one all-reduce of `count` ≤ NK_PEER_AR_MAX doubles: store my values into my slot of EVERY rank's arena, release my
 // flag there, wait for every rank's flag in MY arena, combine the slots in rank order (elements [max_lo, max_hi) with a
 // NaN-propagating max, the others with +). Slots and flags are double-buffered by the parity of the sequence number: a
 // rank can only be one collective ahead of a peer, because it needs that peer's contribution to finish its own.
 __global__ __launch_bounds__(NK_BLOCK) void k_peer_allreduce(char *const *map, int P, int me, double *buf, int count,
                                                              int max_lo, int max_hi, uint64_t seq) {
   const int t = threadIdx.x, par = (int)(seq & 1);
-  double v = (t < count) ? buf[t] : 0.0;
-  for (int p = 0; p < P; ++p) {
-    nk_peer_hdr *h = reinterpret_cast<nk_peer_hdr *>(map[p]);
-    if (t < count) h->ar_data[par][me][t] = v;
+  for (int e = t; e < count; e += NK_BLOCK) {
+    const double v = buf[e];
+    for (int p = 0; p < P; ++p) reinterpret_cast<nk_peer_hdr *>(map[p])->ar_data[par][me][e] = v;
   }
   __threadfence_system();
   __syncthreads();
@@ -261,15 +260,15 @@ __global__ __launch_bounds__(NK_BLOCK) void k_peer_allreduce(char *const *map, i
   nk_peer_hdr *mine = reinterpret_cast<nk_peer_hdr *>(map[me]);
   if (t < P) peer_wait_ge(&mine->ar_flag[par][t], seq, &mine->err);
   __syncthreads();
-  if (t < count) {
-    const bool mx = (t >= max_lo && t < max_hi);
-    double acc = mine->ar_data[par][0][t];
+  for (int e = t; e < count; e += NK_BLOCK) {
+    const bool mx = (e >= max_lo && e < max_hi);
+    double acc = mine->ar_data[par][0][e];
     for (int p = 1; p < P; ++p) {
-      const double w = mine->ar_data[par][p][t];
+      const double w = mine->ar_data[par][p][e];
       if (mx) acc = (acc != acc || w != w) ? __builtin_nan("") : (w > acc ? w : acc);
       else acc += w;
     }
-    buf[t] = acc;
+    buf[e] = acc;
   }
 }
 

@@ -35,9 +35,11 @@ __global__ void k_gmres_begin(nk_gmres_ctl *ctl, const double *d_ss, double atol
                               int first, double *g, double *s, int m, nk_gmres_pub *pub, uint64_t seq) {
   if (threadIdx.x != 0) return;
   const double beta = sqrt(*d_ss);
-  if (first) {
-    ctl->rnorm0 = beta;
-    ctl->tol = fixed ? -1.0 : atol + rtol * beta;
+  if (first) {  // 1: a new solve; 2: the cycle after an s-step breakdown — same solve, same tolerance, flags cleared
+    if (first == 1) {
+      ctl->rnorm0 = beta;
+      ctl->tol = fixed ? -1.0 : atol + rtol * beta;
+    }
     ctl->failed = 0;
     ctl->converged = 0;
   }
@@ -737,7 +739,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
 }
 extern "C" int nk_gmres_set_block_size(nk_gmres *G, int s) {
   NK_REQUIRE(G, "NULL argument");
-  NK_REQUIRE(s >= 1 && s <= 8, "s-step block size %d outside 1..8", s);
+  NK_REQUIRE(s >= 0 && s <= 16, "s-step block size %d outside 0..16 (0 = automatic)", s);
   G->ss_s = s;
   return NK_OK;
 }
@@ -1144,8 +1146,19 @@ static bool op_fuses_scale(const nk_gmres *G) {
   return false;
 }
 
-// y = scale · A x (right-preconditioned: A M⁻¹ x); scale may be nullptr (= 1)
-static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale) {
+// y −= scale·θ·x — the shift of a Newton-basis step for operators whose kernels cannot take it in their row epilogue
+__global__ __launch_bounds__(NK_BLOCK) void k_sub_theta(int64_t n, const double *__restrict__ theta,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        const double *d_scale, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const double c = (*theta) * (d_scale ? *d_scale : 1.0);
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) y[i] -= c * x[i];
+}
+
+// y = scale · (A x − θ x) (right-preconditioned: A M⁻¹ x); scale / theta may be nullptr (= 1 / 0)
+static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale,
+                    const double *d_theta = nullptr) {
   nk_ctx *ctx = G->ctx;
   const double *src = d_x;
   const double *oscale = d_scale;
@@ -1154,15 +1167,76 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
     src = G->w;
     oscale = nullptr;
   }
+  const double *src0 = src;
   if (G->prec_kind) {
     NK_TRY(prec_apply(G, src, G->z, d_skip));
     src = G->z;
   }
+  if (d_theta) {
+    // the built-in kernels subtract θ·x[row] in their row epilogue (the diagonal gather they have just made)
+    const bool epi_ok = !G->prec_kind && !G->normal && G->shift == 0.0 &&
+                        (G->op_kind == 1 || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D));
+    if (epi_ok) {
+      nk_spmv_epi ep;
+      ep.mode = 3;
+      ep.theta = d_theta;
+      if (G->op_kind == 1) return nk_csr_spmv_dev(G->A, src, d_y, d_skip, oscale, &ep);
+      return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip, oscale, &ep);
+    }
+    NK_TRY(op_apply_raw(G, src, d_y, d_skip, oscale));
+    const int grid = nk_grid_for(G->n, NK_BLOCK * 4, 2048);
+    NK_LAUNCH(ctx, k_sub_theta, dim3(grid), dim3(NK_BLOCK), G->n, d_theta, src0, d_y, oscale, d_skip);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
   return op_apply_raw(G, src, d_y, d_skip, oscale);
 }
 
-int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale) {
-  return op_apply(G, d_x, d_y, d_skip, d_scale);
+int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale,
+                      const double *d_theta) {
+  return op_apply(G, d_x, d_y, d_skip, d_scale, d_theta);
+}
+
+// Real bounds of the operator's spectrum for the s-step Newton basis, left on the device as {−lo, hi}: Gershgorin discs of
+// a concrete CSR operator, the closed-form discs of the Bratu stencil (diagonal 4c − d_k, radius ≤ 4c), or bounds the caller
+// supplied (nk_gmres_set_spectrum_interval). None for callback operators, preconditioned or normal-form operators.
+__global__ void k_store2(double a, double b, double *out2) {
+  if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
+}
+int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, bool *have) {
+  nk_ctx *ctx = G->ctx;
+  *have = false;
+  if (G->ss_ival_user) {
+    NK_LAUNCH(ctx, k_store2, dim3(1), dim3(64), -G->ss_ival[0], G->ss_ival[1], d_out2);
+    *have = true;
+    return NK_OK;
+  }
+  if (G->prec_kind || G->normal || G->shift != 0.0) return NK_OK;
+  if (G->op_kind == 1 && G->A->nblocks > 0) {
+    NK_TRY(nk_csr_gershgorin_dev(G->A, d_out2));
+  } else if (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D && G->n > 0) {
+    NK_TRY(nk_problem_spectrum_interval_dev(G->P, G->d_u, d_out2));
+  } else {
+    return NK_OK;
+  }
+  if (ctx->nranks > 1) NK_TRY(nk_comm_allreduce(ctx, d_out2, 2, 1));
+  *have = true;
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_spectrum_interval(nk_gmres *G, double lo, double hi) {
+  NK_REQUIRE(G, "NULL argument");
+  if (lo == 0.0 && hi == 0.0) { G->ss_ival_user = false; return NK_OK; }
+  NK_REQUIRE(lo < hi && lo == lo && hi == hi && !std::isinf(lo) && !std::isinf(hi), "spectrum interval needs finite lo < hi");
+  G->ss_ival_user = true;
+  G->ss_ival[0] = lo;
+  G->ss_ival[1] = hi;
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_sstep_basis(nk_gmres *G, int basis) {
+  NK_REQUIRE(G, "NULL argument");
+  NK_REQUIRE(basis == NK_SS_BASIS_AUTO || basis == NK_SS_BASIS_MONOMIAL || basis == NK_SS_BASIS_NEWTON, "bad s-step basis %d", basis);
+  G->ss_basis = basis;
+  return NK_OK;
 }
 
 // ----------------------------------------------------------------------------- DCGS2, one reduction per step
@@ -1401,6 +1475,9 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   }
   if (maxiter <= 0) maxiter = 300;
   const int cap = fixed_iters > 0 ? fixed_iters : maxiter;
+  // a breakdown of the s-step form switches THIS solve to delayed CGS2; the object's choice comes back on every exit
+  struct ortho_guard_t { nk_gmres *g; int o; ~ortho_guard_t() { g->ortho = o; } } ortho_guard{G, G->ortho};
+  if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) NK_TRY(nk_ss_prepare(G));
   nk_gmres_info inf;
   memset(&inf, 0, sizeof(inf));
   // r0 = b − A x0, written straight into column 0 of the basis (un-normalised); zero initial guess: b → column 0 and
@@ -1449,6 +1526,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
           if (nk_spin_wait(ctx, ready, "GMRES progress") != NK_OK) return false;
           return !is_done;
         };
+      G->ss_cycle_idx = inf.restarts;
       NK_TRY(nk_ss_cycle(G, steps, wait_progress));
     } else {
       const bool one_red = use_dcgs2r(G);
@@ -1511,16 +1589,29 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     inf.converged = c.converged;
     inf.failed = c.failed;
     if (c.failed == 2 && G->ortho == NK_ORTHO_SSTEP) {
-      // a block of the monomial basis lost rank numerically (Cholesky breakdown): x is untouched by this cycle (y = 0);
-      // redo the rest of the solve with the column-by-column scheme
+      // a block lost rank numerically (Cholesky breakdown): this cycle left x as it was (y = 0) and its columns do not
+      // count. The REST OF THIS SOLVE runs column by column from the same restart loop — it forms r = b − A x through the raw
+      // operator, so right preconditioners are fine, and the tolerance stays the one fixed by the first cycle; the next solve
+      // tries the s-step form again (ortho_guard restores it).
       G->ss_breakdowns++;
-      G->ortho = NK_ORTHO_DCGS2;
-      nk_gmres_info rest;
-      NK_TRY(nk_gmres_solve_dev(G, d_b, d_x, x_is_zero_before ? 0 : 1, atol, rtol, cap - (total_iters - c.k), fixed_iters > 0 ? cap - (total_iters - c.k) : 0, &rest));
-      rest.iters += total_iters - c.k;
-      rest.restarts += inf.restarts;
-      if (info) *info = rest;
-      return NK_OK;
+      {  // automatic block size: retry with a narrower block (15 → 8 → 4; the object keeps it); otherwise, or once that is
+         // exhausted, column by column
+        const int s_now = nk_ss_block_size(G);
+        if (G->ss_s == 0 && s_now > 4 && G->ss_force_break_cycle < 0) G->ss_s_cap = s_now > 8 ? 8 : 4;
+        else G->ortho = NK_ORTHO_DCGS2;
+      }
+      total_iters -= c.k;
+      inf.failed = 0;
+      first = 2;
+      if (x_is_zero_before) {
+        NK_TRY(nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss));
+        have_ss = true;
+        x_is_zero = true;
+      } else {
+        NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
+        NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
+      }
+      continue;
     }
     if (c.failed || c.converged || total_iters >= cap || steps == 0) break;
     inf.restarts++;

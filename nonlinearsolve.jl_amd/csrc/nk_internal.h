@@ -71,8 +71,8 @@ struct nk_prof {
 
 // peer-mapped arenas (hipIpc over xGMI) for the small collectives of the Krylov loop (nk_ctx.hip)
 constexpr int NK_PEER_MAX_RANKS = 16;
-constexpr int NK_PEER_AR_MAX = 128;                      // doubles per all-reduce message
-constexpr size_t NK_PEER_HDR_BYTES = 65536;              // flags + all-reduce slots + error word
+constexpr int NK_PEER_AR_MAX = 512;                      // doubles per all-reduce message (an s-step block: (k + s)·s ≤ 31·15)
+constexpr size_t NK_PEER_HDR_BYTES = 262144;             // flags + all-reduce slots + error word
 // Layout of every rank's arena: a header (all-reduce flags and slots, error word) and a bump-allocated rest that holds
 // the receive areas of the halo plans. All of it is uncached device memory, so that a kernel polling a flag sees the
 // store a peer GPU made while the kernel was already running.
@@ -183,11 +183,14 @@ int nk_comm_alltoallv(nk_ctx *ctx, const void *send, const int64_t *soff, const 
                       void *recv, const int64_t *roff, const int64_t *rbytes, hipStream_t stream = nullptr /* ctx->stream */);
 void nk_comm_destroy(nk_ctx *ctx);
 
-// optional row epilogue of the SpMV / JVP kernels: mode 1 fuses one Chebyshev-iteration vector update
+// optional row epilogue of the SpMV / JVP kernels: mode 1 fuses one Chebyshev-iteration vector update, mode 2 (stencil JVP
+// only) the residual b − J v, mode 3 a shift read from device memory: y = scale·(A x − θ x) — one step of the s-step Arnoldi
+// process's Newton basis (nk_sstep.hip); x[row] is the diagonal gather the row has just made, so the shift moves no extra bytes
 struct nk_spmv_epi {
   int mode = 0;
   double c1 = 0, c2 = 0;
   double *r = nullptr, *dnew = nullptr, *yacc = nullptr;
+  const double *theta = nullptr;
 };
 
 // ----------------------------------------------------------------------------- halo plan
@@ -245,6 +248,7 @@ struct nk_csr {
   int32_t *d_tperm = nullptr;
   double *d_ones = nullptr;   // a vector of ones (nk_csr_colsumsq_dev)
   int32_t *d_diagpos = nullptr;  // position of every row's diagonal entry in val (nk_csr_add_to_diagonal_dev)
+  double *d_gersh = nullptr;     // per-row-block Gershgorin bounds (nk_csr_gershgorin_dev)
   bool t_values_stale = true;
   double *d_tz = nullptr, *d_trecv = nullptr;  // T·x (nrows + n_halo) and what the peers sent back (n_send)
   // column colouring of the pattern (structurally orthogonal columns), built on first use by coloured assembly
@@ -313,6 +317,7 @@ int nk_problem_jvp_prepare(nk_problem *P, const double *d_u);  // linearise at u
 int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_jv, const int *d_skip,
                        const double *d_out_scale = nullptr, const struct nk_spmv_epi *epi = nullptr);
 int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
+int nk_problem_spectrum_interval_dev(nk_problem *P, const double *d_u, double *d_out2);  // Bratu: {−lo, hi} of the stencil's discs
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
 int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J);  // ncolors JVPs + decompression
 
@@ -427,15 +432,29 @@ struct nk_gmres {
   int gsteps = 0;
   // NK_ORTHO_SSTEP (nk_sstep.hip): s basis columns per block — matrix powers, then block CGS in Pythagorean form, twice
   struct nk_sstep *ss = nullptr;
-  int ss_s = 6;           // block size s (1..8)
-  int ss_breakdowns = 0;  // Cholesky breakdowns of a block (the solve was redone with delayed CGS2)
+  int ss_s = 0;           // block size s (1..16); 0 = automatic: 15 with the Newton basis, 6 with the monomial one
+  int ss_basis = 0;       // NK_SS_BASIS_AUTO / _MONOMIAL / _NEWTON
+  bool ss_ival_user = false;          // the caller supplied real bounds of the operator's spectrum
+  double ss_ival[2] = {0.0, 0.0};
+  int ss_breakdowns = 0;  // Cholesky breakdowns of a block (the rest of that solve ran with delayed CGS2)
+  int ss_s_cap = 0;              // automatic block size only: narrowed (15 → 8 → 4) after a block lost rank; 0 = not narrowed
+  int ss_cycle_idx = 0;          // restart cycle of the current solve (0-based)
+  int ss_force_break_cycle = -1; // development hook (nk_gmres_debug_force_breakdown): that cycle's first block "loses rank"
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info);
 
 // s-step Arnoldi (nk_sstep.hip)
-int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale);  // y = scale·A M⁻¹ x
+// y = scale·(A M⁻¹ x − θ x); d_scale / d_theta (device scalars) may be nullptr (= 1 / 0)
+int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale,
+                      const double *d_theta = nullptr);
+// real bounds [lo, hi] of the operator's spectrum, on the device as {−lo, hi} (all-reduced); false: none are known
+int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, bool *have);
+int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2);   // {−min_i(a_ii − r_i), max_i(a_ii + r_i)} of the local rows
 bool nk_ss_eligible(const nk_gmres *G);
+int nk_ss_prepare(nk_gmres *G);   // once per linear solve: Newton basis (spectrum bounds known) or monomial
+int nk_ss_block_width(int want);
+int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
@@ -443,6 +462,7 @@ struct ss_tail_args;
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
                 const int *d_skip, int grid, const ss_tail_args *tap, int *mark);
 int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
+int nk_blas_reduce_slots_allreduce(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 
 // ----------------------------------------------------------------------------- banded LU (direct linsolve, C2)
 struct nk_bandlu {

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp(int64_t ns, int64_t nl, 
   const double res = c_lap * bratu_lap(v, lo, hi, ns, nl, i, jl, k) - d[k] * vk;
   if (epi.mode == 0) {
     jv[k] = os * res;
+  } else if (epi.mode == 3) {  // Newton-basis step of the s-step Arnoldi process: scale·(J v − θ v)
+    jv[k] = os * (res - (*epi.theta) * vk);
   } else if (epi.mode == 2) {  // fused residual: out = b − J v (b = epi.r)
     jv[k] = epi.r[k] - res;
   } else {  // fused Chebyshev step (v = d_old): r −= J d; d_new = c1 d_old + c2 r; y += d_new
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp_tile(int ns, int nl, dou
     w[r] = v[row + iw];
     e[r] = v[row + ie];
     dg[r] = d[row + i];
-    rr[r] = (epi.mode != 0) ? epi.r[row + i] : 0.0;
+    rr[r] = (epi.mode == 1 || epi.mode == 2) ? epi.r[row + i] : 0.0;
   }
   if (j0 == 0 && lo) col[0] = lo[i];                                  // uniform per workgroup
   const double hiv = (j0 + TY >= nl && hi) ? hi[i] : 0.0;             // line nl: the upper neighbour rank's first line
@@ -140,6 +142,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp_tile(int ns, int nl, dou
       const size_t k = (size_t)jl * ns + i;
       if (epi.mode == 0) {
         jv[k] = os * res;
+      } else if (epi.mode == 3) {  // Newton-basis step of the s-step Arnoldi process: scale·(J v − θ v)
+        jv[k] = os * (res - (*epi.theta) * c);
       } else if (epi.mode == 2) {  // fused residual: out = b − J v (b = epi.r)
         jv[k] = rr[r] - res;
       } else {  // fused Chebyshev step (v = d_old): r −= J d; d_new = c1 d_old + c2 r; y += d_new
@@ -533,6 +537,51 @@ static int user_lin_J(nk_problem *P, const double *d_u) {
     NK_TRY(nk_problem_jac_colored_dev(P, d_u, P->lin_J));
   }
   P->d_u_linJ = d_u;
+  return NK_OK;
+}
+
+// Bounds of the Bratu Jacobian's spectrum from its Gershgorin discs (centre 4c − d_k, radius ≤ 4c, d = c_exp·exp(u)):
+// [−max d, 8c − min d], left on the device as {−lo, hi} = {max d, 8c + max(−d)} for the s-step Newton basis (nk_sstep.hip)
+__global__ __launch_bounds__(NK_BLOCK) void k_minmax_stage1(int64_t n, const double *__restrict__ x, double *__restrict__ part) {
+  __shared__ double red[8];
+  double a = -INFINITY, c = -INFINITY;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const double v = x[i];
+    a = fmax(a, v);
+    c = fmax(c, -v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a = fmax(a, __shfl_xor(a, o, 64)); c = fmax(c, __shfl_xor(c, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    part[gridDim.x + blockIdx.x] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  }
+}
+__global__ __launch_bounds__(256) void k_bratu_interval_final(int nblk, const double *__restrict__ part, double c8,
+                                                              double *__restrict__ out2) {
+  __shared__ double red[8];
+  double a = -INFINITY, c = -INFINITY;
+  for (int i = threadIdx.x; i < nblk; i += 256) { a = fmax(a, part[i]); c = fmax(c, part[nblk + i]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a = fmax(a, __shfl_xor(a, o, 64)); c = fmax(c, __shfl_xor(c, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out2[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    out2[1] = c8 + fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  }
+}
+int nk_problem_spectrum_interval_dev(nk_problem *P, const double *d_u, double *d_out2) {
+  NK_REQUIRE(P->kind == NK_PROBLEM_BRATU2D && P->n_local > 0, "internal: spectrum bounds exist for the Bratu stencil only");
+  nk_ctx *ctx = P->ctx;
+  if (P->d_u_lin != d_u || !P->d_diag) NK_TRY(nk_problem_jvp_prepare(P, d_u));
+  const int grid = nk_grid_for(P->n_local, NK_BLOCK * 4, 1024);
+  NK_LAUNCH(ctx, k_minmax_stage1, dim3(grid), dim3(NK_BLOCK), P->n_local, (const double *)P->d_diag, ctx->d_partials);
+  NK_LAUNCH(ctx, k_bratu_interval_final, dim3(1), dim3(256), grid, (const double *)ctx->d_partials, 8.0 * P->c_lap, d_out2);
+  NK_HIP(hipGetLastError());
   return NK_OK;
 }
 

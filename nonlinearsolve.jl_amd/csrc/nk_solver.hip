@@ -175,7 +175,10 @@ extern "C" int nk_options_default(nk_options *o) {
   o->maxtime = 0.0;
   o->gmres_restart = 30;
   o->gmres_maxiters = 300;
-  o->gmres_ortho = NK_ORTHO_DCGS2;  // CGS2 arithmetic, one sweep over the basis less per step (CGS2 itself if restart > 31)
+  // s-step Arnoldi (Newton basis where the operator's spectrum can be bounded, else monomial): three sweeps over the basis per
+  // block of columns; a block that loses rank finishes that solve with delayed CGS2, and restarts the s-step form cannot serve
+  // (m > 78) run column by column (NK_ORTHO_DCGS2: CGS2 arithmetic, two sweeps and one reduction per column)
+  o->gmres_ortho = NK_ORTHO_SSTEP;
   o->gmres_fixed_iters = 0;
   o->lin_abstol = -1.0;
   o->lin_reltol = -1.0;
@@ -217,8 +220,8 @@ extern "C" int nk_options_default(nk_options *o) {
   o->lm_finite_diff_step_geodesic = 0.1;
   o->lm_b_uphill = 1.0;
   o->pt_alpha_initial = 1e-3;  // PseudoTransient() (pseudo_transient.jl:38)
-  o->gmres_sstep = 6;
-  o->reserved_tail = 0;
+  o->gmres_sstep = 0;
+  o->gmres_sstep_basis = NK_SS_BASIS_AUTO;
   return NK_OK;
 }
 
@@ -594,7 +597,8 @@ extern "C" int nk_solver_init(nk_problem *P, const double *u0, int memspace, con
     NK_TRY(nk_dev_alloc(&S->stage, na));
   } else {
     NK_TRY(nk_gmres_create(ctx, n, S->o.gmres_restart, S->o.gmres_ortho, &S->G));
-    if (S->o.gmres_sstep >= 1 && S->o.gmres_sstep <= 8) NK_TRY(nk_gmres_set_block_size(S->G, S->o.gmres_sstep));
+    NK_TRY(nk_gmres_set_block_size(S->G, S->o.gmres_sstep));   // (validates 0..16)
+    NK_TRY(nk_gmres_set_sstep_basis(S->G, S->o.gmres_sstep_basis));
     if (concrete(S)) NK_TRY(nk_gmres_set_operator_csr(S->G, S->J));
   }
   NK_HIP(hipMemcpyAsync(S->u, u0, n * sizeof(double),

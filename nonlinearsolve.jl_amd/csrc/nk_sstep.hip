@@ -1,6 +1,11 @@
 // s-step (communication-avoiding) Arnoldi for GMRES(m): the basis grows s columns at a time.
 //
-//   matrix powers   W = [A v_k, A² v_k, …, Aˢ v_k] / σ^j          (s operator applications, monomial basis, σ a power of two)
+//   matrix powers   W_j = (A − θ_j I) W_{j−1} / σ, W_{−1} = v_k    (s operator applications; σ a power of two)
+//                   Newton basis: θ_j = Leja-ordered Chebyshev points of a real interval that bounds the operator's spectrum
+//                   (Gershgorin discs of a CSR operator, the stencil's closed form, or the caller's bounds) — the block stays
+//                   well conditioned up to s = 16 (κ ≈ 1e4–1e5 at s = 15 where the monomial basis, θ = 0, breaks down at
+//                   s ≈ 10: Bai, Hu, Reichel, "A Newton basis GMRES implementation"; Hoemmen's thesis §7); the shift rides
+//                   in the operator kernel's row epilogue. Without bounds: monomial basis, s = 6.
 //   block CGS, Pythagorean form, twice (BCGS-PIP2):
 //     sweep A   [V_k W]ᵀ W                       → C₁ = V_kᵀW, G₁ = WᵀW          one pass over k + s columns
 //     tail 1    R₁ᵀR₁ = G₁ − C₁ᵀC₁ (Cholesky)
@@ -28,7 +33,8 @@
 constexpr int SS_R = 256;        // rows per tile = threads per workgroup
 constexpr int SS_P = SS_R + 1;   // LDS pitch in doubles (odd)
 constexpr int SS_MTMAX = 5;      // Gram tiles of 16 rows: k + s ≤ 80
-constexpr int SS_SMAX = 8;
+constexpr int SS_SMAX = 16;      // one 16-wide matrix-core tile of new columns
+constexpr int SS_TH = 8;         // scal[SS_TH + j] = θ_j; scal[0..5): first-application scale, 1/σ, σ, carried σ estimate, Newton flag
 constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
 
@@ -54,11 +60,12 @@ struct ss_tail_args {
 };
 // LDS arrays of the scalar work, carved from one dynamic block
 struct ss_ws {
-  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *F, *NC, *Hs, *scs, *ssn, *sg;
+  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *F, *NC, *Hs, *scs, *ssn, *sg;
   int *ok;
 };
+constexpr int SS_SS = SS_SMAX * SS_SMAX;
 __host__ __device__ inline size_t ss_ws_doubles(int k, int s, bool hess) {
-  size_t d = (size_t)2 * k * s + 4 * 64 + 2;
+  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2;
   if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 3 * (size_t)(k + s) + 1;
   return d;
 }
@@ -66,10 +73,11 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
   ss_ws w;
   w.Ct = b; b += k * s;
   w.U = b; b += k * s;
-  w.Ri = b; b += 64;
-  w.Rm = b; b += 64;
-  w.Sm = b; b += 64;
-  w.R1s = b; b += 64;
+  w.Ri = b; b += SS_SS;
+  w.Rm = b; b += SS_SS;
+  w.Sm = b; b += SS_SS;
+  w.R1s = b; b += SS_SS;
+  w.Gd = b; b += SS_SMAX;
   w.ok = reinterpret_cast<int *>(b); b += 2;
   w.F = w.NC = w.Hs = w.scs = w.ssn = w.sg = nullptr;
   if (hess) {
@@ -85,8 +93,19 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
 
 // From the reduced block [V_kᵀX ; XᵀX] (X = the s columns behind V_k; `sc` un-normalised-column scales): the true
 // coefficients Ct = diag(sc)·V_kᵀX, the Cholesky factor R of XᵀX − CtᵀCt (Pythagorean form of ‖X − V Ct‖), R⁻¹, and the
-// coefficients U = diag(sc)·Ct the update takes off the stored columns. Returns false on a non-positive or non-finite pivot
-// (the monomial block lost rank numerically). Every workgroup that runs it on the same `red` reaches the same verdict.
+// coefficients U = diag(sc)·Ct the update takes off the stored columns. Returns false when the block lost rank numerically:
+// a pivot that is not positive RELATIVE to the column's own squared norm — d ≤ 1e-12 (XᵀX)_aa: the column lies in the span of
+// the others to 1e-6, the block's condition number is beyond 1e6, and the Hessenberg columns recovered through R would carry
+// errors above 1e-10 (a pivot near ε (XᵀX)_aa is rounding noise altogether) — or is not finite.
+// Every workgroup that runs it on the same `red` reaches the same verdict.
+// The s × s factorisation and inverse run on ONE WAVEFRONT in registers: lane b owns column b of a fixed 16 × 16 frame
+// (identity beyond s), rows are compile-time indices, and the entries of other columns arrive by v_readlane on constant
+// lanes — no LDS round trips, no barriers; ≈ 1 µs, once per persistent workgroup.
+__device__ __forceinline__ double ss_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
@@ -99,61 +118,47 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
   if (t < sb * sb) {
     const int a = t / sb, b = t % sb;
     double s = red[(size_t)(k + a) * sb + b];
+    if (a == b) w.Gd[a] = s;
     for (int j = 0; j < k; ++j) s = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s);
     Sm[t] = s;
-    Rm[t] = 0.0;
-    Ri[t] = 0.0;
   }
   __syncthreads();
-  if (t == 0) {
-    // the s × s factorisation and inverse on one lane, entirely in registers (fixed 8 × 8 frame, compile-time indices)
-    double A[SS_SMAX][SS_SMAX], B[SS_SMAX][SS_SMAX];
+  if (t < 64) {
+    const int b = t;
+    double col[SS_SMAX], x[SS_SMAX];
 #pragma unroll
-    for (int a = 0; a < SS_SMAX; ++a)
-#pragma unroll
-      for (int b = 0; b < SS_SMAX; ++b) {
-        A[a][b] = (a < sb && b < sb) ? 0.5 * (Sm[a * sb + b] + Sm[b * sb + a]) : (a == b ? 1.0 : 0.0);
-        B[a][b] = 0.0;
-      }
+    for (int a = 0; a < SS_SMAX; ++a) {
+      const bool in = a < sb && b < sb;
+      const int ab = in ? a * sb + b : 0, ba = in ? b * sb + a : 0;
+      const double v = 0.5 * (Sm[ab] + Sm[ba]);
+      col[a] = in ? v : ((a == b) ? 1.0 : 0.0);
+    }
     int ok = 1;
 #pragma unroll
-    for (int a = 0; a < SS_SMAX; ++a) {  // upper-triangular R with RᵀR = S, row by row, in place (rows ≥ sb: identity)
-      double d = A[a][a];
+    for (int a = 0; a < SS_SMAX; ++a) {  // upper-triangular R with RᵀR = S, row by row (rows ≥ sb: identity)
+      double acc = col[a];
 #pragma unroll
-      for (int p = 0; p < a; ++p) d -= A[p][a] * A[p][a];
-      if (!(d > 0.0) || isinf(d)) ok = 0;
+      for (int p = 0; p < a; ++p) acc -= ss_readlane(col[p], a) * col[p];
+      const double d = ss_readlane(acc, a);
+      const double gaa = a < sb ? w.Gd[a < sb ? a : 0] : 1.0;
+      if (!(d > 1e-12 * gaa) || isinf(d)) ok = 0;
       const double raa = sqrt(d), inv = 1.0 / raa;
-      A[a][a] = raa;
-#pragma unroll
-      for (int b = a + 1; b < SS_SMAX; ++b) {
-        double v = A[a][b];
-#pragma unroll
-        for (int p = 0; p < a; ++p) v -= A[p][a] * A[p][b];
-        A[a][b] = v * inv;
-      }
+      col[a] = (b > a) ? acc * inv : ((b == a) ? raa : 0.0);
     }
-    if (ok) {  // R⁻¹ (upper), column by column
+    // R⁻¹ (upper): lane b solves R x = e_b from the bottom row up; x[p] = 0 for p > b falls out of the recurrence
 #pragma unroll
-      for (int b = 0; b < SS_SMAX; ++b) {
-        B[b][b] = 1.0 / A[b][b];
+    for (int a = SS_SMAX - 1; a >= 0; --a) {
+      double v = (a == b) ? 1.0 : 0.0;
 #pragma unroll
-        for (int a = SS_SMAX - 1; a >= 0; --a) {
-          if (a < b) {
-            double v = 0.0;
-#pragma unroll
-            for (int p = 0; p < SS_SMAX; ++p)
-              if (p > a && p <= b) v -= A[a][p] * B[p][b];
-            B[a][b] = v / A[a][a];
-          }
-        }
-      }
+      for (int p = a + 1; p < SS_SMAX; ++p) v -= ss_readlane(col[a], p) * x[p];
+      x[a] = v / ss_readlane(col[a], a);
+    }
+    if (ok && b < sb) {
 #pragma unroll
       for (int a = 0; a < SS_SMAX; ++a)
-#pragma unroll
-        for (int b = 0; b < SS_SMAX; ++b)
-          if (a < sb && b < sb) { Rm[a * sb + b] = b >= a ? A[a][b] : 0.0; Ri[a * sb + b] = b >= a ? B[a][b] : 0.0; }
+        if (a < sb) { Rm[a * sb + b] = col[a]; Ri[a * sb + b] = (a <= b) ? x[a] : 0.0; }
     }
-    *w.ok = ok;
+    if (t == 0) *w.ok = ok;
   }
   __syncthreads();
   return *w.ok != 0;
@@ -164,7 +169,7 @@ __device__ void ss_keep_pass1(int k, int sb, const ss_ws &w, const ss_tail_args 
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += blockDim.x) ta.C1[e] = w.Ct[e];
   if (t < sb * sb) ta.R1[t] = w.Rm[t];
-  if (t == 0 && k == 1) {  // ‖A v₁‖ = σ·√(XᵀX)₀₀: the scale of the next cycle's monomial basis, rounded to a power of two
+  if (t == 0 && k == 1 && ta.scal[4] == 0.0) {  // ‖A v₁‖ = σ·√(XᵀX)₀₀: the scale of the next cycle's monomial basis, rounded to a power of two
     const double est = ta.scal[2] * sqrt(ta.red[(size_t)k * sb]);
     if (est > 0.0 && !isinf(est)) ta.scal[3] = exp2(rint(log2(est)));
   }
@@ -181,47 +186,60 @@ __device__ void ss_fail(const ss_tail_args &ta) {
 // after pass 2 (one workgroup; ss_factor has run on pass 2's block): C = C₁ + C₂R₁, R = R₂R₁; the s new Hessenberg columns;
 // Givens rotations, residual norms, stopping test.
 // Coordinates in the basis [V_k Q] (K = k + s): X_j (column j of the block, j = 0..s−1) = F[:, j] = [C_j ; R_j], and
-//   A v_k = σ X_0 ;  A X_{j−1} = σ X_j ;  q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}   (j = 1..s−1)
+//   A v_k = σ X_0 + θ_0 v_k ;  A X_{j−1} = σ X_j + θ_j X_{j−1} ;
+//   q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}   (j = 1..s−1)     (θ = 0: the monomial basis)
 // so the coordinates of A q_j follow from those of A v_1..A v_{k−1} (the old Hessenberg columns), A v_k and A q_1..A q_{j−1}.
 __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
   const int t = threadIdx.x, nt = blockDim.x;
   const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
   double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
   // everything the serial parts read from global memory is requested up front by all threads
+  #pragma unroll 1
   for (int e = t; e < k * ko; e += nt) Hs[e] = ta.H[(size_t)(e / ko) * m + (e % ko)];
+  #pragma unroll 1
   for (int e = t; e < ko; e += nt) { scs[e] = ta.cs[e]; ssn[e] = ta.sn[e]; }
+  #pragma unroll 1
   for (int e = t; e <= ko; e += nt) sg[e] = ta.g[e];
   if (t < sb * sb) w.R1s[t] = ta.R1[t];
   const double sigma = ta.scal[2];
+  const double *__restrict__ th = ta.scal + SS_TH;
+  #pragma unroll 1
   for (int e = t; e < k * sb; e += nt) F[e] = ta.C1[e];
   __syncthreads();
+  #pragma unroll 1
   for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
     const int j = e / sb, c = e % sb;
     double v = F[e];
+    #pragma unroll 1
     for (int a = 0; a <= c; ++a) v = __builtin_fma(w.Ct[j * sb + a], w.R1s[a * sb + c], v);
     F[e] = v;
   }
   if (t < sb * sb) {  // R = R₂ R₁ (upper)
     const int a = t / sb, c = t % sb;
     double v = 0.0;
+    #pragma unroll 1
     for (int p = a; p <= c; ++p) v = __builtin_fma(w.Rm[a * sb + p], w.R1s[p * sb + c], v);
     F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
   }
   __syncthreads();
-  if (t < K) NC[t] = sigma * F[t * sb];
+  if (t < K) NC[t] = sigma * F[t * sb] + (t == k - 1 ? th[0] : 0.0);
   __syncthreads();
+  #pragma unroll 1
   for (int j = 1; j < sb; ++j) {
     if (t < K) {
       const int i = t;
-      double a = sigma * F[i * sb + j];
+      double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
       if (i < k)
+        #pragma unroll 1
         for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
       a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
+      #pragma unroll 1
       for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * K + i], F[(k + q - 1) * sb + (j - 1)], a);
       NC[j * K + i] = a / F[(k + j - 1) * sb + (j - 1)];
     }
     __syncthreads();
   }
+  #pragma unroll 1
   for (int e = t; e < sb * K; e += nt) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
     const int j = e / K, i = e % K, jc = ko + j;
     if (i <= jc + 1 && jc < m) ta.H[(size_t)i * m + jc] = NC[j * K + i];
@@ -230,6 +248,7 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane
     const int jc = ko + t;
     double *h = &NC[t * K];
+    #pragma unroll 1
     for (int i = 0; i < ko; ++i) {
       const double a = h[i], b = h[i + 1];
       ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
@@ -242,9 +261,11 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
     const double tol = ctl->tol;
     int closed = 0, dn = 0;
     double rn = ctl->rnorm, beta = 0.0;
+    #pragma unroll 1
     for (int j = 0; j < sb && !dn; ++j) {
       const int jc = ko + j;
       double *h = &NC[j * K];
+      #pragma unroll 1
       for (int i = ko; i < jc; ++i) {
         const double a = h[i], b = h[i + 1];
         ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
@@ -267,12 +288,14 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
       else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
       else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
     }
+    #pragma unroll 1
     for (int j = 0; j < closed; ++j) { ta.cs[ko + j] = scs[ko + j]; ta.sn[ko + j] = ssn[ko + j]; ta.g[ko + j] = sg[ko + j]; }
     ta.g[ko + closed] = sg[ko + closed];
     ctl->rnorm = rn;
     ctl->hn = beta;
     ctl->k = ko + closed;
     if (dn) ctl->done = 1;
+    #pragma unroll 1
     for (int c = 0; c < sb; ++c) ta.sc[k + c] = 1.0;  // the new columns are normalised
     ta.scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
     ss_pub_progress(ta.pub, ta.seq, ctl->k, dn);
@@ -372,6 +395,12 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
   for (int tile = tile0; tile < tile1; ++tile) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const bool ok = r < n;
+    // The fused forms take their coefficients from LDS (wave-uniform broadcast reads). They are loop invariant, and hoisting
+    // all k·S + S² of them into registers costs the wide blocks their occupancy (S = 15: 256 VGPRs + 68 AGPRs, one workgroup
+    // per CU): an opaque zero offset per tile keeps the reads inside the loop.
+    int cofs = 0;
+    if (FUSE && S > 8) asm volatile("" : "+s"(cofs));
+    const double *__restrict__ Uf = FUSE ? ws.U + cofs : nullptr, *__restrict__ Rif = FUSE ? ws.Ri + cofs : nullptr;
     if (MTC > 0) {
 #pragma unroll
       for (int j = 0; j < NVR; ++j) {
@@ -379,7 +408,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
           if (GRAM) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
           if (UPDATE) {
 #pragma unroll
-            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], FUSE ? ws.U[j * S + c] : coef[j * S + c], w[c]);
+            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], FUSE ? Uf[j * S + c] : coef[j * S + c], w[c]);
           }
         }
       }
@@ -400,7 +429,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
             if (GRAM) sX[j * SS_P + t] = ok ? v[u] : 0.0;
             if (UPDATE) {
 #pragma unroll
-              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], FUSE ? ws.U[j * S + c] : coef[j * S + c], w[c]);
+              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], FUSE ? Uf[j * S + c] : coef[j * S + c], w[c]);
             }
           }
         }
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
       for (int c = 0; c < S; ++c) {
         double a = 0.0;
 #pragma unroll
-        for (int cc = 0; cc <= c; ++cc) a = __builtin_fma(w[cc], FUSE ? ws.Ri[cc * S + c] : Rinv[cc * S + c], a);
+        for (int cc = 0; cc <= c; ++cc) a = __builtin_fma(w[cc], FUSE ? Rif[cc * S + c] : Rinv[cc * S + c], a);
         q[c] = a;
       }
 #pragma unroll
@@ -538,7 +567,8 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
   else {                                    // sweep C: update only — no LDS tile
-    const int per_cu = fuse ? (cls == 1 ? 6 : (cls == 2 ? 4 : 3)) : 6;   // fused: persistent (one prologue per workgroup)
+    // fused: persistent (one prologue per workgroup), as many as the register footprint lets a CU hold (tools/kernel_resources.py)
+    const int per_cu = fuse ? (S > 8 ? (cls == 3 ? 2 : 3) : (cls == 1 ? 6 : (cls == 2 ? 4 : 3))) : 6;
     g = ctx->num_cus * per_cu < ntiles ? ctx->num_cus * per_cu : ntiles;
     SS_GO(true, false);
   }
@@ -561,8 +591,19 @@ int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64
     case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
     case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
     case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    default: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    default: NK_FAIL(NK_E_INVALID, "internal: no s-step sweep for a block of %d columns", s);
   }
+}
+// widths the sweeps are compiled for; any other block is cut into these (the last block of a cycle, odd block sizes)
+int nk_ss_block_width(int want) {
+  if (want >= 15) return 15;
+  if (want >= 12) return 12;
+  if (want >= 10) return 10;
+  return want > 8 ? 8 : want;
 }
 
 // ----------------------------------------------------------------------------- development harness (not in the public header)
@@ -612,24 +653,85 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   return NK_OK;
 }
 
-// start of a cycle (after k_gmres_begin): the scale of the monomial basis and of the first operator application
-__global__ void k_ss_begin(const double *__restrict__ s, double *scal) {
+// start of a cycle (after k_gmres_begin): the shifts and the scale of the block basis, the scale of the first operator
+// application. newton: `ival` = {−lo, hi} bounds the spectrum; θ_j = c + h·t_j with t the Leja-ordered Chebyshev points of
+// [−1, 1] and σ = the interval's capacity h/2 rounded to a power of two (exact in binary floating point; the basis
+// polynomials then stay O(1) on the interval). Degenerate bounds fall back to the monomial basis: θ = 0, σ ≈ ‖A v₁‖.
+__global__ void k_ss_begin(const double *__restrict__ s, double *scal, const double *__restrict__ ival,
+                           const double *__restrict__ nodes, int ns) {
   if (threadIdx.x != 0) return;
   double sigma = scal[3];
+  double newton = 0.0;
+  if (ival != nullptr) {
+    const double lo = -ival[0], hi = ival[1];
+    const double c = 0.5 * (lo + hi), h = 0.5 * (hi - lo);
+    if (h > 0.0 && !isinf(h) && c == c && !isinf(c)) {
+      for (int j = 0; j < ns; ++j) scal[SS_TH + j] = c + h * nodes[j];
+      sigma = exp2(rint(log2(0.5 * h)));
+      newton = 1.0;
+    }
+  }
+  if (newton == 0.0)
+    for (int j = 0; j < SS_SMAX; ++j) scal[SS_TH + j] = 0.0;
   if (!(sigma > 0.0) || isinf(sigma)) sigma = 1.0;
+  scal[4] = newton;
+  scal[3] = sigma;
   scal[2] = sigma;
   scal[1] = 1.0 / sigma;
   scal[0] = s[0] / sigma;
+}
+
+// development hook (not in the public header): the first block of restart cycle `cycle` of the next solves reports a
+// Cholesky breakdown — exercises the column-by-column fall-back where no natural breakdown can be arranged (cycle ≥ 1, with a
+// preconditioner); −1 switches it off
+__global__ void k_ss_force_fail(nk_gmres_ctl *ctl, nk_gmres_pub *pub, uint64_t seq) {
+  if (threadIdx.x != 0) return;
+  ctl->failed = 2;
+  ctl->done = 1;
+  ctl->pad1 = 1;
+  ss_pub_progress(pub, seq, ctl->k, 1);
+}
+extern "C" int nk_gmres_debug_force_breakdown(nk_gmres *G, int cycle) {
+  NK_REQUIRE(G, "NULL argument");
+  G->ss_force_break_cycle = cycle;
+  return NK_OK;
+}
+
+// Chebyshev points of [−1, 1] in Leja order: t_0 = the point of largest modulus, t_j = the point that maximises
+// Π_{i<j} |t − t_i| (ties: the first in the list cos((2i+1)π/2s), i = 0..s−1). A prefix of a Leja sequence is again well
+// spread, so a shorter last block uses the first points of the same list.
+extern "C" int nk_ss_leja_nodes(int s, double *out) {
+  if (s < 1 || s > SS_SMAX || !out) return NK_E_INVALID;
+  double pts[SS_SMAX];
+  bool used[SS_SMAX];
+  for (int i = 0; i < s; ++i) { pts[i] = cos((2.0 * i + 1.0) * M_PI / (2.0 * s)); used[i] = false; }
+  for (int j = 0; j < s; ++j) {
+    int best = -1;
+    double bv = -1.0;
+    for (int i = 0; i < s; ++i) {
+      if (used[i]) continue;
+      double v = (j == 0) ? fabs(pts[i]) : 1.0;
+      for (int q = 0; q < j; ++q) v *= fabs(pts[i] - out[q]);
+      if (v > bv) { bv = v; best = i; }
+    }
+    used[best] = true;
+    out[j] = pts[best];
+  }
+  return NK_OK;
 }
 
 // ============================================================================= one restart cycle, s columns at a time
 struct nk_sstep {
   int s = 0, grid = 0;
   double *part = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
+  double *ival = nullptr, *nodes = nullptr;  // {−lo, hi} of the spectrum; Leja-ordered Chebyshev points for nodes_s columns
+  int nodes_s = 0;
+  bool newton = false;                       // this solve builds Newton-basis blocks
 };
 void nk_ss_destroy(nk_sstep *W) {
   if (!W) return;
   hipFree(W->part); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
+  hipFree(W->ival); hipFree(W->nodes);
   delete W;
 }
 static int ss_workspace(nk_gmres *G) {
@@ -643,38 +745,90 @@ static int ss_workspace(nk_gmres *G) {
   NK_TRY(nk_dev_alloc(&W->red, nslots + 1));
   NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
   NK_TRY(nk_dev_alloc(&W->C1, nslots + 1));
-  NK_TRY(nk_dev_alloc(&W->R1, (size_t)64));
+  NK_TRY(nk_dev_alloc(&W->R1, (size_t)SS_SS));
   NK_TRY(nk_dev_alloc(&W->H, (size_t)(m + 2 + SS_SMAX) * m));
-  NK_TRY(nk_dev_alloc(&W->scal, (size_t)8));
-  NK_HIP(hipMemset(W->scal, 0, 8 * sizeof(double)));
+  NK_TRY(nk_dev_alloc(&W->scal, (size_t)SS_TH + SS_SMAX));
+  NK_TRY(nk_dev_alloc(&W->ival, (size_t)2));
+  NK_TRY(nk_dev_alloc(&W->nodes, (size_t)SS_SMAX));
+  NK_HIP(hipMemset(W->scal, 0, (SS_TH + SS_SMAX) * sizeof(double)));
   NK_HIP(hipMemset(W->H, 0, (size_t)(m + 2 + SS_SMAX) * m * sizeof(double)));
   G->ss = guard.release();
   return NK_OK;
 }
 bool nk_ss_eligible(const nk_gmres *G) { return G->m + 1 <= SS_KMAX - 1 && G->n > 0; }
 
-// Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of G->ss_s (the last block may be shorter). k_gmres_begin
-// has run. `wait_progress(need)` (may be empty) blocks the host until `need` columns are closed or the cycle is done and
-// returns false when no further block should be enqueued.
+// Once per linear solve: choose the block basis. Newton basis when real bounds of the operator's spectrum are at hand
+// (nk_gmres_spectrum_interval_dev: they are computed on the device and stay there — the shifts are formed by k_ss_begin, no
+// host round trip), monomial otherwise or on request.
+int nk_ss_prepare(nk_gmres *G) {
+  NK_TRY(ss_workspace(G));
+  nk_sstep *W = G->ss;
+  W->newton = false;
+  if (G->ss_basis == NK_SS_BASIS_MONOMIAL) return NK_OK;
+  bool have = false;
+  NK_TRY(nk_gmres_spectrum_interval_dev(G, W->ival, &have));
+  if (!have) {
+    if (G->ss_basis == NK_SS_BASIS_NEWTON)
+      NK_FAIL(NK_E_UNSUPPORTED, "s-step Newton basis: no bounds of this operator's spectrum are known "
+                                "(nk_gmres_set_spectrum_interval supplies them)");
+    return NK_OK;
+  }
+  W->newton = true;
+  return NK_OK;
+}
+// the block size in effect: the caller's, else 15 with the Newton basis and 6 with the monomial one — narrowed to 8, then 4,
+// once a block of this object has lost rank (a start vector concentrated in a corner of the spectrum, bounds much wider than
+// the spectrum: κ of the block grows with its width)
+int nk_ss_block_size(const nk_gmres *G) {
+  if (G->ss_s > 0) return G->ss_s > SS_SMAX ? SS_SMAX : G->ss_s;
+  const int s = (G->ss && G->ss->newton) ? 15 : 6;
+  return (G->ss_s_cap > 0 && G->ss_s_cap < s) ? G->ss_s_cap : s;
+}
+
+extern "C" int nk_gmres_get_sstep_state(nk_gmres *G, int *block_size, int *newton_basis, int *breakdowns) {
+  NK_REQUIRE(G, "NULL argument");
+  if (block_size) *block_size = nk_ss_block_size(G);
+  if (newton_basis) *newton_basis = (G->ss && G->ss->newton) ? 1 : 0;
+  if (breakdowns) *breakdowns = G->ss_breakdowns;
+  return NK_OK;
+}
+
+// Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of ≤ s (cut to the widths the sweeps are compiled for;
+// the last block may be shorter). k_gmres_begin has run. `wait_progress(need)` (may be empty) blocks the host until `need`
+// columns are closed or the cycle is done and returns false when no further block should be enqueued.
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress) {
   nk_ctx *ctx = G->ctx;
   NK_TRY(ss_workspace(G));
   nk_sstep *W = G->ss;
   const int64_t n = G->n, ldv = G->ldv;
-  const int s = G->ss_s > 0 ? (G->ss_s > SS_SMAX ? SS_SMAX : G->ss_s) : 6;
+  const int s = nk_ss_block_size(G);
+  if (W->newton && W->nodes_s != s) {
+    double h_nodes[SS_SMAX] = {0};
+    NK_TRY(nk_ss_leja_nodes(s, h_nodes));
+    NK_HIP(hipMemcpyAsync(W->nodes, h_nodes, SS_SMAX * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));  // (h_nodes is a stack array; once per block size)
+    W->nodes_s = s;
+  }
   const int *done = &G->d_ctl->done, *skipC = &G->d_ctl->pad1;
   ss_tail_args ta;
   ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.H = W->H; ta.m = G->m;
   ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
-  const bool single = nk_ctx_is_single(ctx);
-  NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal);
+  NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal,
+            W->newton ? (const double *)W->ival : (const double *)nullptr, (const double *)W->nodes, s);
+  if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
+    NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
+  int prev_sb = s;
   while (k - 1 < steps) {
-    const int sb = (steps - (k - 1)) < s ? (steps - (k - 1)) : s;
-    if (wait_progress && k > 1 && !wait_progress(k - 1 - s)) break;
+    int sb = (steps - (k - 1)) < s ? (steps - (k - 1)) : s;
+    sb = nk_ss_block_width(sb);
+    if (k + sb > 48 && sb > 8) sb = 8;  // the streaming size class keeps its scalar workspace within the LDS
+    if (wait_progress && k > 1 && !wait_progress(k - 1 - prev_sb)) break;
+    prev_sb = sb;
     double *Wk = G->V + (size_t)k * ldv;
-    for (int j = 0; j < sb; ++j)  // matrix powers (right-preconditioned operator), scaled by 1/σ
-      NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1)));
+    for (int j = 0; j < sb; ++j)  // the block's basis vectors: (A − θ_j I) applied s times (right-preconditioned operator), scaled by 1/σ
+      NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1),
+                               W->newton ? W->scal + SS_TH + j : nullptr));
     const int grid = nk_ss_grid(ctx, n, k, sb);
     const int nslots = (k + sb) * sb;
     // fused: the scalar work between the passes runs in the prologue of the sweep that consumes it (k + s ≤ 48)
@@ -687,20 +841,19 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       }
       {
         nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
-        NK_TRY(nk_blas_reduce_slots(ctx, W->part, grid, nslots, W->red, done));
-      }
-      if (!single) {  // peer-mapped arenas carry NK_PEER_AR_MAX doubles per message: the block goes in pieces; other transports: one call
-        const int piece = ctx->peer.on ? NK_PEER_AR_MAX : nslots;
-        for (int off = 0; off < nslots; off += piece)
-          NK_TRY(nk_comm_allreduce(ctx, W->red + off, nslots - off < piece ? nslots - off : piece, 0));
+        NK_TRY(nk_blas_reduce_slots_allreduce(ctx, W->part, grid, nslots, W->red, done));  // (k + s)·s values, one message
       }
       if (!fused) {
-        if (pass == 0)
-          hipLaunchKernelGGL(k_ss_tail1, dim3(1), dim3(256), ss_ws_doubles(k, sb, false) * sizeof(double), ctx->stream, k, sb,
-                             W->coef, ta);
-        else
-          hipLaunchKernelGGL(k_ss_tail2, dim3(1), dim3(256), ss_ws_doubles(k, sb, true) * sizeof(double), ctx->stream, k, sb,
-                             W->coef, ta);
+        const size_t lds = ss_ws_doubles(k, sb, pass == 1) * sizeof(double);
+        if (pass == 0) {
+          if (lds > 64 * 1024)
+            NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_tail1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(k_ss_tail1, dim3(1), dim3(256), lds, ctx->stream, k, sb, W->coef, ta);
+        } else {
+          if (lds > 64 * 1024)
+            NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_tail2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(k_ss_tail2, dim3(1), dim3(256), lds, ctx->stream, k, sb, W->coef, ta);
+        }
       }
     }
     {

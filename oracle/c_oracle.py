@@ -71,6 +71,11 @@ def lib():
         L.orc_bratu_newton_fast.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, _d]
         L.orc_bratu_newton_fast_sstep.restype = C.c_double
         L.orc_bratu_newton_fast_sstep.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int, _d]
+        L.orc_bratu_newton_fast_sstep2.restype = C.c_double
+        L.orc_bratu_newton_fast_sstep2.argtypes = [C.c_int64, C.c_double, C.c_double, _d, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, _d]
+        L.orc_leja_nodes.restype = None
+        L.orc_leja_nodes.argtypes = [C.c_int, _d]
         _lib = L
     return _lib
 
@@ -194,17 +199,25 @@ def bratu_newton_fast(ns, lam, scale, u0, nsteps, use_csr=True, m=30):
     return u, fn, sec
 
 
-def bratu_newton_fast_sstep(ns, lam, scale, u0, nsteps, use_csr=True, m=30, s=6):
+def bratu_newton_fast_sstep(ns, lam, scale, u0, nsteps, use_csr=True, m=30, s=6, basis="monomial"):
     """The same fixed-work Newton steps with the s-step Arnoldi process (the device's NK_ORTHO_SSTEP; C restatement of
-    reference_restatement.gmres_sstep). Returns (u, fnorm trace, seconds of the step loop)."""
+    reference_restatement.gmres_sstep). basis = "newton": Leja-ordered Chebyshev shifts on the Gershgorin interval of every
+    Jacobian (the device's default for this operator, with s = 15). Returns (u, fnorm trace, seconds of the step loop)."""
     u = np.array(u0, dtype=np.float64, copy=True)
     fn = np.zeros(nsteps)
-    sec = lib().orc_bratu_newton_fast_sstep(ns, lam, scale, u, nsteps, int(use_csr), m, int(s), fn)
+    sec = lib().orc_bratu_newton_fast_sstep2(ns, lam, scale, u, nsteps, int(use_csr), m, int(s),
+                                             {"monomial": 0, "newton": 1}[basis], fn)
     if sec == -2.0:
         raise ArithmeticError("a block of the monomial basis lost rank numerically (Cholesky breakdown)")
     if sec < 0:
         raise ValueError("bad restart length or block size")
     return u, fn, sec
+
+
+def leja_nodes(s):
+    out = np.zeros(16)
+    lib().orc_leja_nodes(int(s), out)
+    return out[:s]
 
 
 def phase_times():

@@ -938,13 +938,15 @@ double orc_bratu_newton_fast(int64_t ns, double lambda, double scale, double *u_
  * Returns the wall seconds of the step loop, −1 on bad arguments, −2 when a block loses rank numerically (where the device
  * falls back to the column-by-column scheme). TEST INFRASTRUCTURE / baseline only.
  */
-#define ORC_SMAX 8
-static int ss_chol_inv(int sb, const double *S, double *Rm, double *Ri) { /* S = RᵀR (upper R), Ri = R⁻¹; row-major sb×sb */
+#define ORC_SMAX 16
+/* S = RᵀR (upper R), Ri = R⁻¹; row-major sb×sb. Gd = the diagonal of XᵀX before the projection: a pivot that is not positive
+ * relative to it (d ≤ 1e-12 (XᵀX)_aa) means the block lost rank numerically — the device's test (csrc/nk_sstep.hip::ss_factor) */
+static int ss_chol_inv(int sb, const double *S, const double *Gd, double *Rm, double *Ri) {
   for (int e = 0; e < sb * sb; ++e) { Rm[e] = 0.0; Ri[e] = 0.0; }
   for (int a = 0; a < sb; ++a) {
     double d = S[a * sb + a];
     for (int p = 0; p < a; ++p) d -= Rm[p * sb + a] * Rm[p * sb + a];
-    if (!(d > 0.0) || isinf(d)) return 0;
+    if (!(d > 1e-12 * Gd[a]) || isinf(d)) return 0;
     const double raa = sqrt(d);
     Rm[a * sb + a] = raa;
     for (int b = a + 1; b < sb; ++b) {
@@ -963,10 +965,41 @@ static int ss_chol_inv(int sb, const double *S, double *Rm, double *Ri) { /* S =
   }
   return 1;
 }
-double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, double *u_io, int nsteps, int use_csr, int m,
-                                   int s, double *fnorm_inf) {
+/* Chebyshev points of [−1, 1] in Leja order (csrc/nk_sstep.hip::nk_ss_leja_nodes, same loop) */
+void orc_leja_nodes(int s, double *out) {
+  double pts[ORC_SMAX];
+  int used[ORC_SMAX];
+  for (int i = 0; i < s; ++i) { pts[i] = cos((2.0 * i + 1.0) * 3.14159265358979323846 / (2.0 * s)); used[i] = 0; }
+  for (int j = 0; j < s; ++j) {
+    int best = -1;
+    double bv = -1.0;
+    for (int i = 0; i < s; ++i) {
+      if (used[i]) continue;
+      double v = (j == 0) ? fabs(pts[i]) : 1.0;
+      for (int q = 0; q < j; ++q) v *= fabs(pts[i] - out[q]);
+      if (v > bv) { bv = v; best = i; }
+    }
+    used[best] = 1;
+    out[j] = pts[best];
+  }
+}
+/* block widths the device's sweeps are compiled for (csrc/nk_sstep.hip::nk_ss_block_width) */
+static int ss_block_width(int want) {
+  if (want >= 15) return 15;
+  if (want >= 12) return 12;
+  if (want >= 10) return 10;
+  return want > 8 ? 8 : want;
+}
+/* basis: 0 = monomial X_j = A X_{j−1}; 1 = Newton X_j = (A − θ_j I) X_{j−1} / σ with θ = Leja-ordered Chebyshev points of
+ * the Gershgorin interval of J (CSR: the discs of the assembled rows; matrix-free: [−max d, 8c − min d], d = c_exp·eᵘ) and
+ * σ = (hi − lo)/4 rounded to a power of two — recomputed for every Jacobian, as the device does. */
+double orc_bratu_newton_fast_sstep2(int64_t ns, double lambda, double scale, double *u_io, int nsteps, int use_csr, int m,
+                                    int s, int basis, double *fnorm_inf) {
   const int64_t n = ns * ns, nnz = orc_bratu_nnz(ns);
-  if (m < 1 || m > ORC_MAXM - 2 || s < 1 || s > ORC_SMAX) return -1.0;
+  if (m < 1 || m > ORC_MAXM - 2 || s < 1 || s > ORC_SMAX || (s > 8 && s != ss_block_width(s) && s != 16)) return -1.0;
+  if (s == 16) return -1.0;
+  double nodes[ORC_SMAX] = {0};
+  if (basis) orc_leja_nodes(s, nodes);
   const bratu_t bp = bratu_make(ns, lambda, scale);
   int32_t *rowptr = NULL, *col = NULL, *rp0 = NULL, *c0 = NULL;
   double *val = NULL;
@@ -1009,7 +1042,9 @@ double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, doub
     double mine[(ORC_MAXM + ORC_SMAX) * ORC_SMAX], red[(ORC_MAXM + ORC_SMAX) * ORC_SMAX];
     double C1[ORC_MAXM * ORC_SMAX], R1[ORC_SMAX * ORC_SMAX], Ct[ORC_MAXM * ORC_SMAX], Rm[ORC_SMAX * ORC_SMAX],
         Ri[ORC_SMAX * ORC_SMAX], Sm[ORC_SMAX * ORC_SMAX], F[(ORC_MAXM + ORC_SMAX) * ORC_SMAX],
-        NC[ORC_SMAX * (ORC_MAXM + ORC_SMAX)];
+        NC[ORC_SMAX * (ORC_MAXM + ORC_SMAX)], Gd[ORC_SMAX], th[ORC_SMAX];
+    double sigma = 1.0, isig = 1.0;
+    for (int j = 0; j < ORC_SMAX; ++j) th[j] = 0.0;
     int bad = 0;
 #pragma omp barrier
     for (int64_t i = lo; i < hi; ++i) f[i] = bp.c_lap * lap5(u, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]);
@@ -1027,6 +1062,38 @@ double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, doub
           if (j < ns - 1) val[p++] = -bp.c_lap;
         }
       }
+      if (basis) { /* bounds of J's spectrum → shifts and scale of the block basis */
+        double mlo = -INFINITY, mhi = -INFINITY;
+        if (use_csr) {
+          for (int64_t i = lo; i < hi; ++i) {
+            double rad = 0.0, d = 0.0;
+            for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+              if (col[q] == i) d += val[q];
+              else rad += fabs(val[q]);
+            }
+            if (-(d - rad) > mlo) mlo = -(d - rad);
+            if (d + rad > mhi) mhi = d + rad;
+          }
+        } else {
+          for (int64_t i = lo; i < hi; ++i) {
+            const double d = bp.c_exp * exp(u[i]);
+            if (d > mlo) mlo = d;
+            if (-d > mhi) mhi = -d;
+          }
+        }
+        mlo = team_max(part, stride, mlo);
+        mhi = team_max(part, stride, mhi);
+        if (!use_csr) mhi = 8.0 * bp.c_lap + mhi;
+        const double ilo = -mlo, ihi = mhi, cc = 0.5 * (ilo + ihi), hh = 0.5 * (ihi - ilo);
+        if (hh > 0.0 && !isinf(hh)) {
+          for (int j = 0; j < s; ++j) th[j] = cc + hh * nodes[j];
+          sigma = exp2(rint(log2(0.5 * hh)));
+        } else {
+          for (int j = 0; j < s; ++j) th[j] = 0.0;
+          sigma = 1.0;
+        }
+        isig = 1.0 / sigma;
+      }
       double s0 = 0.0;
       for (int64_t i = lo; i < hi; ++i) s0 += f[i] * f[i];
       team_sum(part, stride, 1, &s0, red);
@@ -1039,20 +1106,24 @@ double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, doub
 #pragma omp barrier
       int k = 1; /* orthonormal columns so far */
       while (k - 1 < m && !bad) {
-        const int sb = (m - (k - 1)) < s ? (m - (k - 1)) : s, K = k + sb, ko = k - 1;
+        const int sb = ss_block_width((m - (k - 1)) < s ? (m - (k - 1)) : s), K = k + sb, ko = k - 1;
         double *X = V + (size_t)k * n;
         /* ---- matrix powers: X_j = A X_{j−1}, X_0 = A v_k (a barrier after each: the stencil reaches other threads' rows) */
         for (int j = 0; j < sb; ++j) {
           const double *src = V + (size_t)(k - 1 + j) * n;
           double *dst = X + (size_t)j * n;
+          const double thj = th[j];
           if (use_csr) {
             for (int64_t i = lo; i < hi; ++i) {
               double a = 0.0;
               for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) a += val[q] * src[col[q]];
-              dst[i] = a;
+              dst[i] = basis ? isig * (a - thj * src[i]) : a;
             }
           } else {
-            for (int64_t i = lo; i < hi; ++i) dst[i] = bp.c_lap * lap5(src, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]) * src[i];
+            for (int64_t i = lo; i < hi; ++i) {
+              const double a = bp.c_lap * lap5(src, ns, i % ns, i / ns) - bp.c_exp * exp(u[i]) * src[i];
+              dst[i] = basis ? isig * (a - thj * src[i]) : a;
+            }
           }
 #pragma omp barrier
         }
@@ -1084,7 +1155,8 @@ double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, doub
               for (int j = 0; j < k; ++j) v -= Ct[j * sb + a] * Ct[j * sb + c];
               Sm[a * sb + c] = v;
             }
-          if (!ss_chol_inv(sb, Sm, Rm, Ri)) { bad = 1; break; }
+          for (int a = 0; a < sb; ++a) Gd[a] = red[(k + a) * sb + a];
+          if (!ss_chol_inv(sb, Sm, Gd, Rm, Ri)) { bad = 1; break; }
           /* ---- X ← (X − V_k Ct) R⁻¹ on this thread's rows */
           for (int64_t r0 = lo; r0 < hi; r0 += ORC_TILE) {
             const int64_t r1 = r0 + ORC_TILE < hi ? r0 + ORC_TILE : hi;
@@ -1132,10 +1204,10 @@ double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, doub
             for (int p = a; p <= c; ++p) v += Rm[a * sb + p] * R1[p * sb + c];
             F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
           }
-        for (int i = 0; i < K; ++i) NC[i] = F[i * sb];
+        for (int i = 0; i < K; ++i) NC[i] = sigma * F[i * sb] + (i == k - 1 ? th[0] : 0.0);
         for (int j = 1; j < sb; ++j)
           for (int i = 0; i < K; ++i) {
-            double a = F[i * sb + j];
+            double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
             if (i < k)
               for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a -= H[i * ORC_MAXM + tt] * F[tt * sb + (j - 1)];
             a -= NC[i] * F[(k - 1) * sb + (j - 1)];
@@ -1198,4 +1270,8 @@ double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, doub
   }
   free(rowptr); free(col); free(rp0); free(c0); free(val); free(V); free(u); free(f); free(part);
   return broke ? -2.0 : elapsed;
+}
+double orc_bratu_newton_fast_sstep(int64_t ns, double lambda, double scale, double *u_io, int nsteps, int use_csr, int m,
+                                   int s, double *fnorm_inf) {
+  return orc_bratu_newton_fast_sstep2(ns, lambda, scale, u_io, nsteps, use_csr, m, s, 0, fnorm_inf);
 }

@@ -307,8 +307,10 @@ def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=3
         assert x0 is None
         z, info = gmres(lambda v: matvec(M(v)), b, None, atol, rtol, restart, itmax, fixed_iters, ortho, allreduce)
         return M(z), info
-    if isinstance(ortho, tuple) and ortho[0] == "sstep":   # ("sstep", s)
-        return gmres_sstep(matvec, b, atol, rtol, restart, itmax, fixed_iters, int(ortho[1]), allreduce, x0)
+    if isinstance(ortho, tuple) and ortho[0] == "sstep":   # ("sstep", s) monomial | ("sstep", s, "newton", (lo, hi))
+        interval = ortho[3] if len(ortho) > 3 and ortho[2] == "newton" else None
+        s_blk = int(ortho[1]) if int(ortho[1]) > 0 else (15 if interval is not None else 6)
+        return gmres_sstep(matvec, b, atol, rtol, restart, itmax, fixed_iters, s_blk, allreduce, x0, interval=interval)
     if ortho == "sstep":
         return gmres_sstep(matvec, b, atol, rtol, restart, itmax, fixed_iters, 6, allreduce, x0)
     ar = allreduce if allreduce is not None else (lambda z: z)
@@ -522,8 +524,48 @@ class SStepBreakdown(Exception):
     """A block of the monomial basis lost rank numerically (the Cholesky factorisation of the Pythagorean Gram block failed)."""
 
 
+def leja_chebyshev_nodes(s):
+    """Chebyshev points of [−1, 1] in Leja order (csrc/nk_sstep.hip::nk_ss_leja_nodes, the same loop): t_0 the point of
+    largest modulus, t_j the point maximising Π_{i<j} |t − t_i|; ties go to the first point of cos((2i+1)π/2s), i = 0..s−1."""
+    pts = [math.cos((2.0 * i + 1.0) * math.pi / (2.0 * s)) for i in range(s)]
+    used, out = [False] * s, []
+    for j in range(s):
+        best, bv = -1, -1.0
+        for i in range(s):
+            if used[i]:
+                continue
+            v = abs(pts[i]) if j == 0 else 1.0
+            for q in range(j):
+                v *= abs(pts[i] - out[q])
+            if v > bv:
+                bv, best = v, i
+        used[best] = True
+        out.append(pts[best])
+    return np.array(out)
+
+
+def gershgorin_interval(A):
+    """[min_i (a_ii − r_i), max_i (a_ii + r_i)], r_i = Σ_{j≠i} |a_ij|: bounds of the real part of A's spectrum — where the
+    device places the shifts of the s-step Newton basis for a concrete CSR operator (csrc/nk_csr.hip::k_csr_gershgorin)."""
+    A = sp.csr_matrix(A)
+    d = A.diagonal()
+    rad = np.asarray(abs(A).sum(axis=1)).ravel() - np.abs(d)
+    return float(np.min(d - rad)), float(np.max(d + rad))
+
+
+def sstep_block_width(want):
+    """widths the device's sweeps are compiled for (csrc/nk_sstep.hip::nk_ss_block_width); other blocks are cut into these"""
+    if want >= 15:
+        return 15
+    if want >= 12:
+        return 12
+    if want >= 10:
+        return 10
+    return 8 if want > 8 else want
+
+
 def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0, s=6,
-                allreduce: Optional[Callable] = None, x0=None):
+                allreduce: Optional[Callable] = None, x0=None, interval=None):
     """Restarted GMRES(m) whose Arnoldi process advances s columns at a time — the CPU restatement of csrc/nk_sstep.hip
     (the device's NK_ORTHO_SSTEP; Hoemmen, "Communication-avoiding Krylov subspace methods", and Carson, Lund, Rozložník,
     Thomas, "Block Gram–Schmidt algorithms and their stability properties", for BCGS-PIP). Per block: the monomial vectors
@@ -532,8 +574,19 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
     monomial vectors have the coordinates F_j = [C_j ; R_j] in the new basis [V_k Q], and the Arnoldi relation of the new
     columns follows from A v_k = X_0, A X_{j−1} = X_j and q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}.
     Same Krylov space, same minimisation as `gmres`; the iterates differ by rounding (1e-13 relative on the path's Jacobians).
-    The stopping test sees the s columns of a block together. Raises SStepBreakdown where the device falls back to DCGS2."""
+    The stopping test sees the s columns of a block together. Raises SStepBreakdown where the device falls back to DCGS2.
+    interval = (lo, hi), real bounds of the operator's spectrum: NEWTON basis X_j = (A − θ_j I) X_{j−1} / σ with
+    θ_j = c + h·t_j (t the Leja-ordered Chebyshev points, c / h centre / half width) and σ = h/2 rounded to a power of two
+    (Bai, Hu, Reichel 1994; Hoemmen 2010 §7.3) — then A v_k = σ X_0 + θ_0 v_k and A X_{j−1} = σ X_j + θ_j X_{j−1}, and the
+    block stays well conditioned up to s = 16 (the monomial basis, interval = None, breaks down near s = 10)."""
     ar = allreduce if allreduce is not None else (lambda z: z)
+    theta, sigma = np.zeros(max(int(s), 1)), 1.0
+    if interval is not None:
+        lo_, hi_ = float(interval[0]), float(interval[1])
+        c_, h_ = 0.5 * (lo_ + hi_), 0.5 * (hi_ - lo_)
+        if h_ > 0.0 and math.isfinite(h_) and math.isfinite(c_):
+            theta = c_ + h_ * leja_chebyshev_nodes(int(s))
+            sigma = 2.0 ** round(math.log2(0.5 * h_))   # (rint: ties to even, as the device's rint)
     b = np.asarray(b, dtype=np.float64)
     n = b.size
     x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
@@ -562,6 +615,9 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
             raise SStepBreakdown(str(e))
         if not np.all(np.isfinite(Rm)):
             raise SStepBreakdown("non-finite factor")
+        # the device's verdict (ss_factor): a pivot below 1e-12 of the column's own squared norm — the block's κ is beyond 1e6
+        if np.any(np.diag(Rm) ** 2 <= 1e-12 * np.diag(G)):
+            raise SStepBreakdown("pivot below 1e-12 of the column's squared norm")
         Xn = np.linalg.solve(Rm.T, X - C.T @ V)   # rows of X are vectors: Xᵀ ← (Xᵀ − V_kᵀC) R⁻¹
         return C, Rm, Xn
 
@@ -575,11 +631,13 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
         g[0] = beta0
         k, kdone, done = 1, 0, False
         while k - 1 < steps and not done:
-            sb = min(s, steps - (k - 1))
+            sb = sstep_block_width(min(s, steps - (k - 1)))
+            if k + sb > 48 and sb > 8:
+                sb = 8
             X = np.zeros((sb, n))
             z = V[k - 1]
             for j in range(sb):
-                X[j] = matvec(z)
+                X[j] = (matvec(z) - theta[j] * z) / sigma if interval is not None else matvec(z)
                 z = X[j]
             C1, R1, X = pip(V[:k], X)
             C2, R2, X = pip(V[:k], X)
@@ -587,9 +645,10 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
             F = np.vstack([C1 + C2 @ R1, R2 @ R1])        # (k + sb) × sb
             K = k + sb
             NC = np.zeros((sb, K))
-            NC[0] = F[:, 0]
+            NC[0] = sigma * F[:, 0]
+            NC[0, k - 1] += theta[0]
             for j in range(1, sb):
-                a = F[:, j].copy()
+                a = sigma * F[:, j] + theta[j] * F[:, j - 1]
                 a[: k] -= H[:k, : k - 1] @ F[: k - 1, j - 1]
                 a -= NC[0] * F[k - 1, j - 1]
                 for q in range(1, j):
@@ -1256,9 +1315,21 @@ class FirstOrderCache:
                 op = lambda v: self._apply_JT(self._apply_J(v, u_now), u_now)  # noqa: E731
             else:
                 rhs, op = self.fu, ((lambda v: self._apply_J(v, u_now) + Dm(v)) if shift else (lambda v: self._apply_J(v, u_now)))
+            ortho = kr.ortho
+            if isinstance(ortho, tuple) and ortho[0] == "sstep" and len(ortho) == 3 and ortho[2] in ("auto", "newton"):
+                # the device's choice (nk_ss_prepare): Newton basis where it can bound the spectrum — Gershgorin discs of a
+                # concrete J, the closed form of the Bratu stencil — and no preconditioner / normal form / shift is in the way
+                interval = None
+                if M is None and not shift and not isinstance(self.alg, GaussNewton):
+                    if self.concrete:
+                        interval = gershgorin_interval(self.J)
+                    elif isinstance(self.prob, Bratu2D):
+                        d_ = self.prob.c_exp * np.exp(u_now)
+                        interval = (-float(np.max(d_)), 8.0 * self.prob.c_lap - float(np.min(d_)))
+                ortho = ("sstep", ortho[1], "newton", interval) if interval is not None else ("sstep", ortho[1])
             x, info = gmres(op, rhs, None, atol=self.lin_abstol,
                             rtol=self.lin_reltol, restart=kr.gmres_restart, itmax=kr.maxiters,
-                            fixed_iters=kr.fixed_iters, ortho=kr.ortho, M=M)
+                            fixed_iters=kr.fixed_iters, ortho=ortho, M=M)
             self.stats.gmres_iters += info.iters
             self.last_gmres = info
             if info.failed:

@@ -3,6 +3,8 @@
 The reference is Julia (not installed) and holds no golden vectors; its own tests are outcome/tolerance tests.
 Each test below restates one of those known-answer tests for the path against the oracle, or
 cross-checks the oracle against SciPy as an independent second opinion."""
+import math
+
 import numpy as np
 import pytest
 import scipy.optimize
@@ -814,3 +816,70 @@ def test_c_oracle_sstep_equals_python_restatement_and_column_form():
         CO.bratu_newton_fast_sstep(8, 6.0, 0.0, np.zeros(64), 1, m=30, s=9)
     with pytest.raises(ArithmeticError):   # where the device falls back to the column-by-column scheme
         CO.bratu_newton_fast_sstep(12, 6.0, 0.0, np.zeros(144), 4, m=30, s=6)
+
+
+# ---- the Newton basis of the s-step process (Leja-ordered Chebyshev shifts on real bounds of the spectrum)
+def test_sstep_newton_basis_agrees_with_column_schemes_up_to_s16():
+    """oracle.gmres_sstep(interval=…) — the restatement of the device's default block basis — against MGS: the same Krylov
+    minimisation for every block size the device is compiled for, where the monomial basis breaks down (s ≥ 10)."""
+    for P, tol in ((R.Bratu2D(24), 5e-11), (R.Brusselator2D(12), 2e-9)):
+        u = P.u0() + 0.1 * np.sin(np.arange(P.n) * 0.37)
+        A, b = P.jac(u).tocsr(), P.f(u)
+        iv = R.gershgorin_interval(A)
+        ev = np.linalg.eigvals(A.toarray())
+        assert iv[0] <= ev.real.min() and ev.real.max() <= iv[1]          # Gershgorin: bounds of the real part
+        for m, cap in ((30, 30), (20, 60)):
+            xm, im = R.gmres(lambda z: A @ z, b, restart=m, fixed_iters=cap, ortho="mgs")
+            for s in (1, 6, 8, 10, 12, 13, 15, 16, 0):
+                x, i = R.gmres(lambda z: A @ z, b, restart=m, fixed_iters=cap, ortho=("sstep", s, "newton", iv))
+                assert i.iters == im.iters == cap and i.restarts == im.restarts
+                assert np.linalg.norm(x - xm) <= tol * np.linalg.norm(xm), (type(P).__name__, m, s)
+                assert np.allclose(i.residuals[-1], im.residuals[-1], rtol=1e-6)
+        with pytest.raises(R.SStepBreakdown):   # the monomial block of the same width has lost rank long before
+            R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15))
+        x, i = R.gmres(lambda z: A @ z, b, restart=30, rtol=1e-10, itmax=2000, ortho=("sstep", 0, "newton", iv))
+        x2, i2 = R.gmres(lambda z: A @ z, b, restart=30, rtol=1e-10, itmax=2000, ortho="cgs2")
+        assert i.converged and i.iters == i2.iters and np.linalg.norm(x - x2) <= 1e-8 * np.linalg.norm(x2)
+    # bounds need not be tight — a 1.5× too wide interval costs the block conditioning (the iterate moves by 4e-9) — but they are
+    # no free parameter: with a smooth right-hand side (u = 0: the residual is a constant vector, all of it in the lowest modes)
+    # a 3× too wide interval lets a block of 15 lose rank, where a block of 8 is still fine (the device narrows its automatic
+    # block size 15 → 8 → 4 on such a breakdown)
+    P = R.Bratu2D(24); u = P.u0(); A, b = P.jac(u).tocsr(), P.f(u)
+    lo, hi = R.gershgorin_interval(A)
+    x1, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo, hi)))
+    w = 0.25 * (hi - lo)
+    x2, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo - w, hi + w)))
+    assert np.linalg.norm(x1 - x2) <= 1e-8 * np.linalg.norm(x1)
+    with pytest.raises(R.SStepBreakdown):
+        R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo - (hi - lo), hi + (hi - lo))))
+    x3, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 8, "newton", (lo - 2 * w, hi + 2 * w)))
+    assert np.linalg.norm(x1 - x3) <= 1e-9 * np.linalg.norm(x1)
+    # Leja ordering: first the point of largest modulus, then its mirror image, then the centre
+    t = R.leja_chebyshev_nodes(15)
+    assert abs(abs(t[0]) - math.cos(math.pi / 30)) < 1e-15 and abs(t[1] + t[0]) < 1e-15 and abs(t[2]) < 1e-15
+    assert sorted(np.round(t, 12)) == sorted(np.round(np.cos((2 * np.arange(15) + 1) * np.pi / 30), 12))
+
+
+def test_c_oracle_newton_basis_equals_python_restatement_and_column_form():
+    """oracle/nk_oracle.c::orc_bratu_newton_fast_sstep2 with basis = Newton (the full-size anchor of the device's DEFAULT path)
+    against the NumPy restatement driven through the Newton solver with the automatic basis choice, and against the C
+    oracle's delayed-CGS2 leg — CSR (Gershgorin discs of the assembled rows) and matrix-free (the stencil's closed form)."""
+    from oracle import c_oracle as CO
+    CO.build()
+    for s in range(1, 16):
+        assert np.array_equal(CO.leja_nodes(s), R.leja_chebyshev_nodes(s))
+    for ns in (24, 40):
+        n = ns * ns
+        for use_csr in (True, False):
+            u1, f1, _ = CO.bratu_newton_fast(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30)
+            for s_ in (6, 10, 12, 15):
+                u2, f2, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30, s=s_, basis="newton")
+                assert np.max(np.abs(u1 - u2)) <= 1e-10 and np.allclose(f1, f2, rtol=1e-7)
+            c = R.init(R.Bratu2D(ns, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(fixed_iters=30, maxiters=30,
+                                                                                      ortho=("sstep", 0, "auto")),
+                                                            concrete_jac=use_csr),
+                       abstol=1e-300, maxiters=100, u0=np.zeros(n))
+            for _ in range(4):
+                c.step()
+            u2, _, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30, s=15, basis="newton")
+            assert np.max(np.abs(c.u - u2)) <= 1e-10
