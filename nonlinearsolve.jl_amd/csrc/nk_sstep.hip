@@ -37,6 +37,8 @@ constexpr int SS_SMAX = 16;      // one 16-wide matrix-core tile of new columns
 constexpr int SS_TH = 8;         // scal[SS_TH + j] = θ_j; scal[0..5): first-application scale, 1/σ, σ, carried σ estimate, Newton flag
 constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
+__device__ unsigned long long *g_ss_stamp = nullptr;   // development: phase time stamps of the scalar work (nk_ss_debug_stamps)
+#define SS_STAMP(i) do { if (g_ss_stamp != nullptr && threadIdx.x == 0) g_ss_stamp[i] = wall_clock64(); } while (0)
 
 // ============================================================================= the scalar work of a block (one workgroup)
 __device__ __forceinline__ void ss_pub_progress(nk_gmres_pub *pub, uint64_t seq, int k, int done) {
@@ -52,6 +54,7 @@ struct ss_tail_args {
   const double *red;   // the reduced block [V_kᵀX ; XᵀX], (k + s) × s
   double *sc;          // scales of un-normalised columns (only column 0: 1/β)
   double *C1, *R1;     // pass 1's factors, kept for pass 2
+  double *C2, *R2;     // pass 2's factors, left for the workgroup that derives the Hessenberg columns inside sweep C
   double *H;           // un-rotated Hessenberg columns, row-major with pitch m
   int m;
   double *Rg, *cs, *sn, *g, *scal;
@@ -60,12 +63,12 @@ struct ss_tail_args {
 };
 // LDS arrays of the scalar work, carved from one dynamic block
 struct ss_ws {
-  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *F, *NC, *Hs, *scs, *ssn, *sg;
+  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *Fr, *Fx, *F, *NC, *Hs, *scs, *ssn, *sg;
   int *ok;
 };
 constexpr int SS_SS = SS_SMAX * SS_SMAX;
 __host__ __device__ inline size_t ss_ws_doubles(int k, int s, bool hess) {
-  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2;
+  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2 + 2 * SS_SMAX * (SS_SMAX + 1);
   if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 3 * (size_t)(k + s) + 1;
   return d;
 }
@@ -78,6 +81,8 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
   w.Sm = b; b += SS_SS;
   w.R1s = b; b += SS_SS;
   w.Gd = b; b += SS_SMAX;
+  w.Fr = b; b += SS_SMAX * (SS_SMAX + 1);
+  w.Fx = b; b += SS_SMAX * (SS_SMAX + 1);
   w.ok = reinterpret_cast<int *>(b); b += 2;
   w.F = w.NC = w.Hs = w.scs = w.ssn = w.sg = nullptr;
   if (hess) {
@@ -98,67 +103,68 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
 // the others to 1e-6, the block's condition number is beyond 1e6, and the Hessenberg columns recovered through R would carry
 // errors above 1e-10 (a pivot near ε (XᵀX)_aa is rounding noise altogether) — or is not finite.
 // Every workgroup that runs it on the same `red` reaches the same verdict.
-// The s × s factorisation and inverse run on ONE WAVEFRONT in registers: lane b owns column b of a fixed 16 × 16 frame
-// (identity beyond s), rows are compile-time indices, and the entries of other columns arrive by v_readlane on constant
-// lanes — no LDS round trips, no barriers; ≈ 1 µs, once per persistent workgroup.
-__device__ __forceinline__ double ss_readlane(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
+// The s × s factorisation and inverse are latency, not work: a dependent FP64 operation costs a lone wavefront ≈ 10 cycles, and
+// the first version (one wavefront, lane b owning column b, v_readlane broadcasts: ≈ 1300 serial operations) took 12 µs. Here
+// the 256 threads own one entry (a, b) of a fixed 16 × 16 frame each (identity beyond s): right-looking S = Uᵀ D U — 16 steps
+// of three LDS reads, one refined v_rcp and one FMA per thread —, R = D^½ U, then R⁻¹ row by row from the bottom (row a: 16
+// threads, one ≤ 15-term dot product each). ≈ 35 dependent steps instead of 1300.
+constexpr int SS_FP = SS_SMAX + 1;   // pitch of the frame in LDS
+__device__ __forceinline__ double ss_rcp(double d) {   // 1/d to the last bit or two: v_rcp_f64 + two Newton steps
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
 }
 __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
+  double *F = w.Fr;   // 16 × 17 frame: the factor in progress
   for (int e = t; e < k * sb; e += blockDim.x) {
     const double scj = sc[e / sb], c = scj * red[e];
     Ct[e] = c;
     w.U[e] = scj * c;
   }
+  if (t == 0) *w.ok = 1;
   __syncthreads();
+  SS_STAMP(5);
   if (t < sb * sb) {
     const int a = t / sb, b = t % sb;
-    double s = red[(size_t)(k + a) * sb + b];
-    if (a == b) w.Gd[a] = s;
-    for (int j = 0; j < k; ++j) s = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s);
-    Sm[t] = s;
+    double s0 = red[(size_t)(k + a) * sb + b], s1 = 0.0;
+    if (a == b) w.Gd[a] = s0;
+    int j = 0;
+    for (; j + 1 < k; j += 2) {   // two independent chains
+      s0 = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s0);
+      s1 = __builtin_fma(-Ct[(j + 1) * sb + a], Ct[(j + 1) * sb + b], s1);
+    }
+    if (j < k) s0 = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s0);
+    Sm[t] = s0 + s1;
   }
   __syncthreads();
-  if (t < 64) {
-    const int b = t;
-    double col[SS_SMAX], x[SS_SMAX];
-#pragma unroll
-    for (int a = 0; a < SS_SMAX; ++a) {
-      const bool in = a < sb && b < sb;
-      const int ab = in ? a * sb + b : 0, ba = in ? b * sb + a : 0;
-      const double v = 0.5 * (Sm[ab] + Sm[ba]);
-      col[a] = in ? v : ((a == b) ? 1.0 : 0.0);
+  const int a = (t >> 4) & (SS_SMAX - 1), b = t & (SS_SMAX - 1);   // (blockDim.x = 256: one entry per thread)
+  const bool in = a < sb && b < sb;
+  double val = in ? 0.5 * (Sm[in ? a * sb + b : 0] + Sm[in ? b * sb + a : 0]) : ((a == b) ? 1.0 : 0.0);
+  F[a * SS_FP + b] = val;
+  __syncthreads();
+  SS_STAMP(6);
+#pragma unroll 1
+  for (int p = 0; p < SS_SMAX; ++p) {   // after step p: row p holds T_pb = D_p U_pb (b ≥ p), the trailing block is updated
+    const double d = F[p * SS_FP + p], fpa = F[p * SS_FP + a], fpb = F[p * SS_FP + b];
+    if (t == 0 && p < sb && (!(d > 1e-12 * w.Gd[p]) || isinf(d))) *w.ok = 0;
+    if (a > p && b >= a) {
+      val = __builtin_fma(-(fpa * ss_rcp(d)), fpb, val);
+      F[a * SS_FP + b] = val;
     }
-    int ok = 1;
-#pragma unroll
-    for (int a = 0; a < SS_SMAX; ++a) {  // upper-triangular R with RᵀR = S, row by row (rows ≥ sb: identity)
-      double acc = col[a];
-#pragma unroll
-      for (int p = 0; p < a; ++p) acc -= ss_readlane(col[p], a) * col[p];
-      const double d = ss_readlane(acc, a);
-      const double gaa = a < sb ? w.Gd[a < sb ? a : 0] : 1.0;
-      if (!(d > 1e-12 * gaa) || isinf(d)) ok = 0;
-      const double raa = sqrt(d), inv = 1.0 / raa;
-      col[a] = (b > a) ? acc * inv : ((b == a) ? raa : 0.0);
-    }
-    // R⁻¹ (upper): lane b solves R x = e_b from the bottom row up; x[p] = 0 for p > b falls out of the recurrence
-#pragma unroll
-    for (int a = SS_SMAX - 1; a >= 0; --a) {
-      double v = (a == b) ? 1.0 : 0.0;
-#pragma unroll
-      for (int p = a + 1; p < SS_SMAX; ++p) v -= ss_readlane(col[a], p) * x[p];
-      x[a] = v / ss_readlane(col[a], a);
-    }
-    if (ok && b < sb) {
-#pragma unroll
-      for (int a = 0; a < SS_SMAX; ++a)
-        if (a < sb) { Rm[a * sb + b] = col[a]; Ri[a * sb + b] = (a <= b) ? x[a] : 0.0; }
-    }
-    if (t == 0) *w.ok = ok;
+    __syncthreads();
+  }
+  // R = D^½ U (upper; zero below the diagonal). The sweeps apply R⁻¹ by forward substitution, row by row of the tile
+  // (q_c = (w_c − Σ_{cc<c} q_cc R_cc,c) / R_cc: the same 120 multiply-adds as a product with an explicit inverse, whose
+  // 16 dependent steps were the longest phase of this routine): `Ri` carries R in that form — reciprocal diagonal.
+  const double da = F[a * SS_FP + a];
+  const double isq = 1.0 / sqrt(da);
+  const double rab = (b >= a) ? val * isq : 0.0;     // val = T_ab for b ≥ a (row a was final after step a − 1)
+  if (in) {
+    Rm[a * sb + b] = rab;
+    Ri[a * sb + b] = (b == a) ? isq : rab;
   }
   __syncthreads();
   return *w.ok != 0;
@@ -194,52 +200,41 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
   double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
   // everything the serial parts read from global memory is requested up front by all threads
-  #pragma unroll 1
   for (int e = t; e < k * ko; e += nt) Hs[e] = ta.H[(size_t)(e / ko) * m + (e % ko)];
-  #pragma unroll 1
   for (int e = t; e < ko; e += nt) { scs[e] = ta.cs[e]; ssn[e] = ta.sn[e]; }
-  #pragma unroll 1
   for (int e = t; e <= ko; e += nt) sg[e] = ta.g[e];
   if (t < sb * sb) w.R1s[t] = ta.R1[t];
   const double sigma = ta.scal[2];
   const double *__restrict__ th = ta.scal + SS_TH;
-  #pragma unroll 1
   for (int e = t; e < k * sb; e += nt) F[e] = ta.C1[e];
   __syncthreads();
-  #pragma unroll 1
   for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
     const int j = e / sb, c = e % sb;
     double v = F[e];
-    #pragma unroll 1
     for (int a = 0; a <= c; ++a) v = __builtin_fma(w.Ct[j * sb + a], w.R1s[a * sb + c], v);
     F[e] = v;
   }
   if (t < sb * sb) {  // R = R₂ R₁ (upper)
     const int a = t / sb, c = t % sb;
     double v = 0.0;
-    #pragma unroll 1
     for (int p = a; p <= c; ++p) v = __builtin_fma(w.Rm[a * sb + p], w.R1s[p * sb + c], v);
     F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
   }
   __syncthreads();
   if (t < K) NC[t] = sigma * F[t * sb] + (t == k - 1 ? th[0] : 0.0);
   __syncthreads();
-  #pragma unroll 1
   for (int j = 1; j < sb; ++j) {
     if (t < K) {
       const int i = t;
       double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
       if (i < k)
-        #pragma unroll 1
         for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
       a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
-      #pragma unroll 1
       for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * K + i], F[(k + q - 1) * sb + (j - 1)], a);
       NC[j * K + i] = a / F[(k + j - 1) * sb + (j - 1)];
     }
     __syncthreads();
   }
-  #pragma unroll 1
   for (int e = t; e < sb * K; e += nt) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
     const int j = e / K, i = e % K, jc = ko + j;
     if (i <= jc + 1 && jc < m) ta.H[(size_t)i * m + jc] = NC[j * K + i];
@@ -248,7 +243,6 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane
     const int jc = ko + t;
     double *h = &NC[t * K];
-    #pragma unroll 1
     for (int i = 0; i < ko; ++i) {
       const double a = h[i], b = h[i + 1];
       ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
@@ -261,11 +255,9 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
     const double tol = ctl->tol;
     int closed = 0, dn = 0;
     double rn = ctl->rnorm, beta = 0.0;
-    #pragma unroll 1
     for (int j = 0; j < sb && !dn; ++j) {
       const int jc = ko + j;
       double *h = &NC[j * K];
-      #pragma unroll 1
       for (int i = ko; i < jc; ++i) {
         const double a = h[i], b = h[i + 1];
         ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
@@ -288,14 +280,12 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
       else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
       else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
     }
-    #pragma unroll 1
     for (int j = 0; j < closed; ++j) { ta.cs[ko + j] = scs[ko + j]; ta.sn[ko + j] = ssn[ko + j]; ta.g[ko + j] = sg[ko + j]; }
     ta.g[ko + closed] = sg[ko + closed];
     ctl->rnorm = rn;
     ctl->hn = beta;
     ctl->k = ko + closed;
     if (dn) ctl->done = 1;
-    #pragma unroll 1
     for (int c = 0; c < sb; ++c) ta.sc[k + c] = 1.0;  // the new columns are normalised
     ta.scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
     ss_pub_progress(ta.pub, ta.seq, ctl->k, dn);
@@ -326,7 +316,7 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
 }
 
 // coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
-// then R⁻¹ (S × S, row-major, upper triangular)
+// then R (S × S, row-major, upper triangular, its diagonal replaced by the reciprocals: the form the substitution takes)
 // MTC = 1, 2, 3: k + S ≤ 16·MTC. The k + S values of a thread's row live in registers and the NEXT tile's loads are issued
 // before the matrix-core phase of the current one — the LDS tile bounds the occupancy at 2 workgroups per CU, which then keep
 // ≈ 2 × (k+S) × 2 KB of loads in flight per CU through both phases; the Gram block is exactly MTC tiles of 16 rows.
@@ -347,15 +337,6 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
     if (dskip) return;
   }
   extern __shared__ double sX[];
-  ss_ws ws;
-  if (FUSE) {
-    ws = ss_ws_carve(sX + ws_off, k, S, !GRAM);
-    if (!ss_factor(k, S, ta.red, ta.sc, ws)) {
-      if (blockIdx.x == 0) ss_fail(ta);
-      return;
-    }
-    if (GRAM && blockIdx.x == 0) ss_keep_pass1(k, S, ws, ta);
-  }
   constexpr int NT = MTC > 0 ? MTC : SS_MTMAX;         // Gram tiles this instantiation accumulates
   constexpr int NVR = MTC > 0 ? 16 * MTC - S : 1;      // basis values a thread holds (k ≤ NVR)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -365,16 +346,21 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
   for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
   double *__restrict__ Wc = V + (size_t)k * ldv;
   const double *__restrict__ Rinv = coef + (size_t)k * S;
-  double vr[NVR], w[S];
-  auto prefetch = [&](int tile) {
+  // DB: two register sets — the NEXT tile's k + S loads are issued before the current tile is touched, so they are in flight
+  // through the update, the LDS traffic AND the matrix-core phase (one set: only through the matrix-core phase; with 15-column
+  // blocks the multiply-adds of a tile are ≈ 40 % of its memory time and did not overlap with it). The LDS tile bounds these
+  // kernels at 2–3 workgroups per CU, so the extra VGPRs are free.
+  constexpr bool DB = MTC > 0 && S > 8;
+  double vr[NVR], w[S], vr2[NVR], w2[S];   // (the second set is dead code without DB)
+  auto prefetch = [&](double (&vrx)[NVR], double (&wx)[S], int tile) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const int64_t rc = r < n ? r : n - 1;
 #pragma unroll
-    for (int c = 0; c < S; ++c) w[c] = Wc[(size_t)c * ldv + rc];
+    for (int c = 0; c < S; ++c) wx[c] = Wc[(size_t)c * ldv + rc];
     if (MTC > 0) {
 #pragma unroll
       for (int j = 0; j < NVR; ++j)
-        if (j < k) vr[j] = V[(size_t)j * ldv + rc];
+        if (j < k) vrx[j] = V[(size_t)j * ldv + rc];
     }
   };
   // operand addresses of the matrix-core phase. Lane (i, q4) supplies A[i][q4] = X[row + q4][16·mt + i] and
@@ -389,18 +375,15 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
     pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
   }
   // a workgroup walks CONTIGUOUS tiles: each of its k + S column streams then advances through adjacent 2 KB pieces
-  const int tpw = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int tile0 = blockIdx.x * tpw, tile1 = min(tile0 + tpw, ntiles);
-  if (tile0 < tile1) prefetch(tile0);
-  for (int tile = tile0; tile < tile1; ++tile) {
+  // (sweep C with the Hessenberg duty: workgroup 0 streams nothing — its scalar work, ≈ 20 µs of dependent chains, then
+  // hides behind the others' share instead of extending the launch)
+  const bool hw = FUSE && !GRAM && gridDim.x > 1;
+  const int nwk = (int)gridDim.x - (hw ? 1 : 0), me = (int)blockIdx.x - (hw ? 1 : 0);
+  const int tpw = (ntiles + nwk - 1) / nwk;
+  const int tile0 = me >= 0 ? me * tpw : 0, tile1 = me >= 0 ? min(tile0 + tpw, ntiles) : 0;
+  auto process = [&](double (&vr)[NVR], double (&w)[S], int tile, auto &&mid) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const bool ok = r < n;
-    // The fused forms take their coefficients from LDS (wave-uniform broadcast reads). They are loop invariant, and hoisting
-    // all k·S + S² of them into registers costs the wide blocks their occupancy (S = 15: 256 VGPRs + 68 AGPRs, one workgroup
-    // per CU): an opaque zero offset per tile keeps the reads inside the loop.
-    int cofs = 0;
-    if (FUSE && S > 8) asm volatile("" : "+s"(cofs));
-    const double *__restrict__ Uf = FUSE ? ws.U + cofs : nullptr, *__restrict__ Rif = FUSE ? ws.Ri + cofs : nullptr;
     if (MTC > 0) {
 #pragma unroll
       for (int j = 0; j < NVR; ++j) {
@@ -408,7 +391,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
           if (GRAM) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
           if (UPDATE) {
 #pragma unroll
-            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], FUSE ? Uf[j * S + c] : coef[j * S + c], w[c]);
+            for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-vr[j], coef[j * S + c], w[c]);
           }
         }
       }
@@ -429,33 +412,32 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
             if (GRAM) sX[j * SS_P + t] = ok ? v[u] : 0.0;
             if (UPDATE) {
 #pragma unroll
-              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], FUSE ? Uf[j * S + c] : coef[j * S + c], w[c]);
+              for (int c = 0; c < S; ++c) w[c] = __builtin_fma(-v[u], coef[j * S + c], w[c]);
             }
           }
         }
       }
     }
     if (UPDATE) {
-      double q[S];
+      // q = w R⁻¹ by forward substitution (Rinv: R with a reciprocal diagonal): as soon as q_cc is known it leaves every later
+      // column — S(S−1)/2 independent multiply-adds behind a dependent chain of S multiplications
 #pragma unroll
-      for (int c = 0; c < S; ++c) {
-        double a = 0.0;
+      for (int cc = 0; cc < S; ++cc) {
+        const double q = w[cc] * Rinv[cc * S + cc];
+        w[cc] = q;
 #pragma unroll
-        for (int cc = 0; cc <= c; ++cc) a = __builtin_fma(w[cc], FUSE ? Rif[cc * S + c] : Rinv[cc * S + c], a);
-        q[c] = a;
+        for (int c = cc + 1; c < S; ++c) w[c] = __builtin_fma(-q, Rinv[cc * S + c], w[c]);
       }
 #pragma unroll
-      for (int c = 0; c < S; ++c) {
-        w[c] = q[c];
-        if (ok) Wc[(size_t)c * ldv + r] = q[c];
-      }
+      for (int c = 0; c < S; ++c)
+        if (ok) Wc[(size_t)c * ldv + r] = w[c];
     }
     if (GRAM) {
 #pragma unroll
       for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
       __syncthreads();
     }
-    if (tile + 1 < tile1) prefetch(tile + 1);   // in flight through the matrix-core phase
+    mid();   // (one register set: the next tile's loads go out here, in flight through the matrix-core phase)
     if (GRAM) {
       // 64 rows per wavefront, 4 per instruction; operands of four instructions are requested together
 #pragma unroll
@@ -475,6 +457,20 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
       }
       __syncthreads();
     }
+  };
+  if (tile0 < tile1) prefetch(vr, w, tile0);
+  if constexpr (DB) {
+    for (int tile = tile0; tile < tile1; tile += 2) {
+      if (tile + 1 < tile1) prefetch(vr2, w2, tile + 1);
+      process(vr, w, tile, [] {});
+      if (tile + 1 < tile1) {
+        if (tile + 2 < tile1) prefetch(vr, w, tile + 2);
+        process(vr2, w2, tile + 1, [] {});
+      }
+    }
+  } else {
+    for (int tile = tile0; tile < tile1; ++tile)
+      process(vr, w, tile, [&] { if (tile + 1 < tile1) prefetch(vr, w, tile + 1); });
   }
   if (GRAM) {
     // the four wavefronts' tiles → one partial per (basis column, new column) and workgroup; fixed order
@@ -496,6 +492,9 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
     }
   }
   if (FUSE && !GRAM && blockIdx.x == 0) {  // workgroup 0, its share of the sweep issued: the block's Hessenberg columns
+    const ss_ws ws = ss_ws_carve(sX + ws_off, k, S, true);
+    for (int e = t; e < k * S; e += SS_R) ws.Ct[e] = ta.C2[e];      // pass 2's factors, left by the reduction's last workgroup
+    if (t < S * S) ws.Rm[t] = ta.R2[t];
     __syncthreads();
     ss_hessenberg(k, S, ws, ta);
   }
@@ -526,7 +525,7 @@ static int ss_per_cu(int k, int s, size_t lds) {
 }
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  const size_t lds = ss_lds_bytes(k, s, true) + (nk_ss_fusable(k, s) ? ss_ws_doubles(k, s, false) * sizeof(double) : 0);
+  const size_t lds = ss_lds_bytes(k, s, true);
   int g = ctx->num_cus * ss_per_cu(k, s, lds);
   if (g > ntiles) g = ntiles;
   return g > 0 ? g : 1;
@@ -537,9 +536,12 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
                        const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
   const int cls = ss_class(k, S);
-  const bool fuse = tap != nullptr && mode != 0 && cls != 0;
+  // "fused" now names ONE thing: sweep C whose workgroup 0 derives the block's Hessenberg columns while the others stream
+  // (its LDS: the scalar workspace). The update coefficients always arrive through scalar loads from `coef`, where the
+  // reduction's last workgroup (k_ss_reduce_factor) or the tail kernels left them.
+  const bool fuse = tap != nullptr && mode == 2 && cls != 0;
   const size_t tile = ss_tile_doubles(k, S, mode != 2, cls ? cls : SS_MTMAX);
-  const size_t lds = (tile + (fuse ? ss_ws_doubles(k, S, mode == 2) : 0)) * sizeof(double);
+  const size_t lds = (tile + (fuse ? ss_ws_doubles(k, S, true) : 0)) * sizeof(double);
   const int ws_off = (int)tile;
   ss_tail_args ta;
   std::memset(&ta, 0, sizeof(ta));
@@ -558,18 +560,19 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   } while (0)
 #define SS_GO(UPD, GRM)                                                                                                   \
   do {                                                                                                                    \
-    if (cls == 1) { if (fuse) SS_GO3(UPD, GRM, 1, UPD); else SS_GO3(UPD, GRM, 1, false); }                                \
-    else if (cls == 2) { if (fuse) SS_GO3(UPD, GRM, 2, UPD); else SS_GO3(UPD, GRM, 2, false); }                           \
-    else if (cls == 3) { if (fuse) SS_GO3(UPD, GRM, 3, UPD); else SS_GO3(UPD, GRM, 3, false); }                           \
+    if (cls == 1) { if (fuse) SS_GO3(UPD, GRM, 1, (UPD && !GRM)); else SS_GO3(UPD, GRM, 1, false); }                      \
+    else if (cls == 2) { if (fuse) SS_GO3(UPD, GRM, 2, (UPD && !GRM)); else SS_GO3(UPD, GRM, 2, false); }                 \
+    else if (cls == 3) { if (fuse) SS_GO3(UPD, GRM, 3, (UPD && !GRM)); else SS_GO3(UPD, GRM, 3, false); }                 \
     else SS_GO3(UPD, GRM, 0, false);                                                                                      \
   } while (0)
   int g = grid;
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
   else {                                    // sweep C: update only — no LDS tile
-    // fused: persistent (one prologue per workgroup), as many as the register footprint lets a CU hold (tools/kernel_resources.py)
-    const int per_cu = fuse ? (S > 8 ? (cls == 3 ? 2 : 3) : (cls == 1 ? 6 : (cls == 2 ? 4 : 3))) : 6;
+    // as many workgroups as the register footprint lets a CU hold (tools/kernel_resources.py), + the Hessenberg workgroup
+    const int per_cu = S > 8 ? (cls == 2 ? 3 : (cls == 3 ? 2 : 4)) : 6;
     g = ctx->num_cus * per_cu < ntiles ? ctx->num_cus * per_cu : ntiles;
+    if (fuse) g += 1;
     SS_GO(true, false);
   }
 #undef SS_GO
@@ -606,8 +609,125 @@ int nk_ss_block_width(int want) {
   return want > 8 ? 8 : want;
 }
 
+// ----------------------------------------------------------------------------- stage-2 reduction + the block's scalar work
+// One launch after a Gram sweep: workgroup e sums partial block entry e in the fixed order (as k_reduce_sum); the workgroup
+// that takes the last ticket then factors the reduced block (ss_factor, ≈ 2 µs on one wavefront) and leaves the update
+// coefficients [U ; R⁻¹] in `coef` for the next sweep's scalar loads — pass 0 also keeps C₁, R₁, pass 1 leaves C₂, R₂ for the
+// Hessenberg workgroup of sweep C. (Every persistent workgroup of the consuming sweep factored the block itself in round 2:
+// with blocks of 15 columns that prologue cost 15 µs per sweep and the LDS-resident coefficients 25 % of the update sweeps'
+// rate.) Several ranks on peer-mapped arenas: the same launch is also the all-reduce (k_reduce_sum_allreduce's protocol):
+// every workgroup stores its sum into every rank's arena, the last one releases the flags, waits, combines in rank order.
+template <bool PEER>
+__global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restrict__ partials, int nblk, int nslots,
+                                                           double *__restrict__ red, const int *d_skip, unsigned int *ticket,
+                                                           int k, int sb, int pass, double *__restrict__ coef, ss_tail_args ta,
+                                                           nk_peer_ar_view pv) {
+  extern __shared__ double s_rf[];
+  __shared__ unsigned int s_last;
+  const int skip = (d_skip != nullptr) ? *d_skip : 0;
+  const int t = threadIdx.x, slot = blockIdx.x;
+  if (slot == 0) SS_STAMP(0);
+  // one wavefront per entry (four entries per workgroup): fixed order — lane l adds partials l, l + 64, …, then the
+  // butterfly —, and one ticket per workgroup (465 same-address atomics of a workgroup-per-entry launch took 6 µs)
+  const int wv = t >> 6, lane = t & 63;
+  const int entry = slot * 4 + wv;
+  double v = 0.0;
+  if (entry < nslots) {
+    const double *p = partials + (size_t)entry * nblk;
+    for (int base = 0; base < nblk; base += 512) {   // eight loads in flight per lane (a rolled loop made eight round trips)
+      double x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + lane + 64 * j;
+        x[j] = p[i < nblk ? i : nblk - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += (base + lane + 64 * j < nblk) ? x[j] : 0.0;
+    }
+  }
+  if (skip && !PEER) return;   // (the flag was requested together with the partials: one round trip; a collective runs on
+                               //  every rank even when the cycle is done)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (lane == 0 && entry < nslots) {
+    if (PEER) {
+      const int par = (int)(pv.seq & 1);
+      for (int q = 0; q < pv.P; ++q) reinterpret_cast<nk_peer_hdr *>(pv.map[q])->ar_data[par][pv.me][entry] = v;
+      __threadfence_system();
+    } else {
+      red[entry] = v;
+      __threadfence();
+    }
+  }
+  __syncthreads();
+  if (t == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  SS_STAMP(1);
+  if (t == 0) *ticket = 0u;   // (for the next launch: the kernel boundary publishes it)
+  if (PEER) {
+    const int par = (int)(pv.seq & 1);
+    nk_peer_hdr *mine = reinterpret_cast<nk_peer_hdr *>(pv.map[pv.me]);
+    __threadfence_system();
+    if (t < pv.P) {
+      __hip_atomic_store(&reinterpret_cast<nk_peer_hdr *>(pv.map[t])->ar_flag[par][pv.me], pv.seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(&mine->ar_flag[par][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < pv.seq) {
+        if (__hip_atomic_load(&mine->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) break;
+        if (wall_clock64() - t0 > 500000000ull) { atomicAdd((unsigned long long *)&mine->err, 1ull); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    for (int e = t; e < nslots; e += SS_R) {
+      double acc = mine->ar_data[par][0][e];
+      for (int q = 1; q < pv.P; ++q) acc += mine->ar_data[par][q][e];
+      red[e] = acc;
+    }
+    __threadfence();
+    __syncthreads();
+    if (skip) return;
+  }
+  // ---- the last workgroup: every entry of the reduced block is in `red` (written by other workgroups: read past the L1)
+  const ss_ws w = ss_ws_carve(s_rf + (size_t)nslots, k, sb, false);
+  for (int e = t; e < nslots; e += SS_R) s_rf[e] = __builtin_nontemporal_load(&red[e]);
+  __syncthreads();
+  SS_STAMP(2);
+  ta.red = s_rf;
+  if (!ss_factor(k, sb, s_rf, ta.sc, w)) { ss_fail(ta); return; }
+  SS_STAMP(3);
+  for (int e = t; e < k * sb; e += SS_R) coef[e] = w.U[e];
+  if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
+  if (pass == 0) {
+    ss_keep_pass1(k, sb, w, ta);
+  } else {
+    for (int e = t; e < k * sb; e += SS_R) ta.C2[e] = w.Ct[e];
+    if (t < sb * sb) ta.R2[t] = w.Rm[t];
+  }
+  SS_STAMP(4);
+}
+extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
+  static unsigned long long *d_st = nullptr;
+  if (enable && !d_st) {
+    if (hipMalloc(&d_st, 8 * sizeof(unsigned long long)) != hipSuccess) return NK_E_NOMEM;
+    hipMemset(d_st, 0, 8 * sizeof(unsigned long long));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ss_stamp), &d_st, sizeof(d_st));
+  }
+  if (!enable && d_st) {
+    unsigned long long *z = nullptr;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ss_stamp), &z, sizeof(z));
+  }
+  if (out5 && d_st) {
+    hipDeviceSynchronize();
+    hipMemcpy(out5, d_st, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  }
+  return NK_OK;
+}
+
 // ----------------------------------------------------------------------------- development harness (not in the public header)
-// Runs one sweep on caller data: V (n × (k+s), column-major, leading dimension n, HOST), coef (k·s + s·s, HOST); returns the
+// Runs one sweep on caller data: V (n × (k+s), column-major, leading dimension n, HOST), coef = [U ; R] (k·s + s·s, HOST; the
+// sweep computes X ← (X − V U) R⁻¹); returns the
 // updated columns, the reduced Gram block ((k+s) × s, row-major) and the average kernel time over `iters` launches.
 extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V_host, const double *coef_host,
                                 double *gram_out, int iters, double *avg_us) {
@@ -620,7 +740,11 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   NK_TRY(nk_dev_alloc(&dc, (size_t)k * s + s * s + 1));
   NK_TRY(nk_dev_alloc(&dp, nslots * grid + 1));
   NK_HIP(hipMemcpy(dV, V_host, nv * sizeof(double), hipMemcpyHostToDevice));
-  if (coef_host) NK_HIP(hipMemcpy(dc, coef_host, ((size_t)k * s + s * s) * sizeof(double), hipMemcpyHostToDevice));
+  if (coef_host) {  // [U ; R] as the caller wrote them → R with a reciprocal diagonal, as the sweeps take it
+    std::vector<double> hc(coef_host, coef_host + (size_t)k * s + (size_t)s * s);
+    for (int c = 0; c < s; ++c) hc[(size_t)k * s + (size_t)c * s + c] = 1.0 / hc[(size_t)k * s + (size_t)c * s + c];
+    NK_HIP(hipMemcpy(dc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr));
   NK_HIP(hipStreamSynchronize(ctx->stream));
   NK_HIP(hipMemcpy(V_host, dV, nv * sizeof(double), hipMemcpyDeviceToHost));
@@ -724,6 +848,8 @@ extern "C" int nk_ss_leja_nodes(int s, double *out) {
 struct nk_sstep {
   int s = 0, grid = 0;
   double *part = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
+  double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup)
+  unsigned int *ticket = nullptr;            // last-workgroup ticket of k_ss_reduce_factor
   double *ival = nullptr, *nodes = nullptr;  // {−lo, hi} of the spectrum; Leja-ordered Chebyshev points for nodes_s columns
   int nodes_s = 0;
   bool newton = false;                       // this solve builds Newton-basis blocks
@@ -731,7 +857,7 @@ struct nk_sstep {
 void nk_ss_destroy(nk_sstep *W) {
   if (!W) return;
   hipFree(W->part); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
-  hipFree(W->ival); hipFree(W->nodes);
+  hipFree(W->ival); hipFree(W->nodes); hipFree(W->C2); hipFree(W->R2); hipFree(W->ticket);
   delete W;
 }
 static int ss_workspace(nk_gmres *G) {
@@ -746,6 +872,10 @@ static int ss_workspace(nk_gmres *G) {
   NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
   NK_TRY(nk_dev_alloc(&W->C1, nslots + 1));
   NK_TRY(nk_dev_alloc(&W->R1, (size_t)SS_SS));
+  NK_TRY(nk_dev_alloc(&W->C2, nslots + 1));
+  NK_TRY(nk_dev_alloc(&W->R2, (size_t)SS_SS));
+  NK_TRY(nk_dev_alloc(&W->ticket, (size_t)2));
+  NK_HIP(hipMemset(W->ticket, 0, 2 * sizeof(unsigned int)));
   NK_TRY(nk_dev_alloc(&W->H, (size_t)(m + 2 + SS_SMAX) * m));
   NK_TRY(nk_dev_alloc(&W->scal, (size_t)SS_TH + SS_SMAX));
   NK_TRY(nk_dev_alloc(&W->ival, (size_t)2));
@@ -811,7 +941,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   }
   const int *done = &G->d_ctl->done, *skipC = &G->d_ctl->pad1;
   ss_tail_args ta;
-  ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.H = W->H; ta.m = G->m;
+  ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.C2 = W->C2; ta.R2 = W->R2; ta.H = W->H; ta.m = G->m;
   ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
   NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal,
             W->newton ? (const double *)W->ival : (const double *)nullptr, (const double *)W->nodes, s);
@@ -831,19 +961,43 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
                                W->newton ? W->scal + SS_TH + j : nullptr));
     const int grid = nk_ss_grid(ctx, n, k, sb);
     const int nslots = (k + sb) * sb;
-    // fused: the scalar work between the passes runs in the prologue of the sweep that consumes it (k + s ≤ 48)
-    const bool fused = nk_ss_fusable(k, sb);
+    // fused: the block's scalar work rides in the stage-2 reduction (its last workgroup factors the reduced block and leaves
+    // the update coefficients for the next sweep's scalar loads) and in sweep C (workgroup 0: the Hessenberg columns) — one
+    // rank, or several on peer-mapped arenas (the reduction is then the all-reduce as well). Other transports and the
+    // streaming size class (k + s > 48): reduction, all-reduce and the scalar work as launches of their own.
+    bool fused = nk_ss_fusable(k, sb);
     for (int pass = 0; pass < 2; ++pass) {
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb + (pass ? sb : 0)));
-        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid, (pass == 1 && fused) ? &ta : nullptr,
+        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid, nullptr,
                            pass == 0 ? &G->d_ctl->pad1 : nullptr));
       }
-      {
-        nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
-        NK_TRY(nk_blas_reduce_slots_allreduce(ctx, W->part, grid, nslots, W->red, done));  // (k + s)·s values, one message
+      nk_peer_ar_view pv{nullptr, 0, 0, 0, nullptr};
+      if (fused && !nk_ctx_is_single(ctx)) {
+        pv = nk_peer_ar_next(ctx, nslots);
+        if (!pv.seq) fused = false;
       }
-      if (!fused) {
+      if (fused) {
+        nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
+        const size_t lds = ((size_t)nslots + ss_ws_doubles(k, sb, false)) * sizeof(double);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
+        if (pv.seq) {
+          if (ev) hipExtLaunchKernelGGL(k_ss_reduce_factor<true>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, e0, e1, 0,
+                                        (const double *)W->part, grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
+          else hipLaunchKernelGGL(k_ss_reduce_factor<true>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, (const double *)W->part,
+                                  grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
+        } else {
+          if (ev) hipExtLaunchKernelGGL(k_ss_reduce_factor<false>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, e0, e1, 0,
+                                        (const double *)W->part, grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
+          else hipLaunchKernelGGL(k_ss_reduce_factor<false>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, (const double *)W->part,
+                                  grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
+        }
+      } else {
+        {
+          nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
+          NK_TRY(nk_blas_reduce_slots_allreduce(ctx, W->part, grid, nslots, W->red, done));  // (k + s)·s values, one message
+        }
         const size_t lds = ss_ws_doubles(k, sb, pass == 1) * sizeof(double);
         if (pass == 0) {
           if (lds > 64 * 1024)

@@ -22,8 +22,9 @@ def _sweep(nls, mode, n, k, s, rng):
                   C.POINTER(C.c_double)]
     V = np.asfortranarray(rng.standard_normal((n, k + s)))
     U = rng.standard_normal((k, s)) * 0.1
-    Rinv = np.triu(rng.standard_normal((s, s))) + 2 * np.eye(s)
-    coef = np.concatenate([U.ravel(), Rinv.ravel()])
+    Rup = np.triu(rng.standard_normal((s, s))) * 0.3 + 2 * np.eye(s)    # the block's triangular factor R
+    Rinv = np.linalg.inv(Rup)
+    coef = np.concatenate([U.ravel(), Rup.ravel()])
     V0, gram, us = V.copy(), np.zeros((k + s, s)), C.c_double(0)
     assert f(nls.default_context()._h, mode, n, k, s, V.ctypes.data, coef.ctypes.data, gram.ctypes.data, 0, C.byref(us)) == 0, \
         L.lib().nk_last_error()
@@ -200,8 +201,9 @@ def test_breakdown_in_a_later_cycle_finishes_column_by_column(nls, dev, prec, cy
     ud, bd = torch.tensor(u, device=dev), torch.tensor(b, device=dev)
     J = PD.jac_csr()
     PD.jac_values(ud, J)
-    m, rtol = 6, 1e-9
-    G = nls.GMRES(P.n, restart=m, ortho="sstep", sstep=3).set_operator(J)
+    # (the V-cycle converges in a handful of iterations: short cycles; unpreconditioned GMRES needs long ones to converge at all)
+    m, sblk, rtol, cap = {"multigrid": (2, 2, 1e-9, 600), "chebyshev": (6, 3, 1e-9, 600), "none": (20, 6, 1e-5, 4000)}[prec]
+    G = nls.GMRES(P.n, restart=m, ortho="sstep", sstep=sblk).set_operator(J)
     M = None
     if prec == "chebyshev":
         lmax = R.gershgorin_lambda(A)
@@ -210,21 +212,22 @@ def test_breakdown_in_a_later_cycle_finishes_column_by_column(nls, dev, prec, cy
     elif prec == "multigrid":
         G.set_multigrid_preconditioner(PD, ud, nu=1, coarse_max=12)
         M = R.BratuMultigrid(P, u, 1, 12)
-    x0, g0 = G.solve(bd, abstol=0.0, reltol=rtol, maxiters=600)
+    x0, g0 = G.solve(bd, abstol=0.0, reltol=rtol, maxiters=cap)
     assert g0["converged"] and g0["restarts"] >= 3, g0
     f = L.lib().nk_gmres_debug_force_breakdown
     f.argtypes = [C.c_void_p, C.c_int]
     assert f(G._h, cycle) == 0
-    x1, g1 = G.solve(bd, abstol=0.0, reltol=rtol, maxiters=600)
+    x1, g1 = G.solve(bd, abstol=0.0, reltol=rtol, maxiters=cap)
     assert g1["converged"] and not g1["failed"]
     x1 = x1.cpu().numpy()
     assert np.linalg.norm(b - A @ x1) <= 1.001 * rtol * np.linalg.norm(b)          # the FIRST cycle's tolerance, not a re-based one
-    assert np.linalg.norm(x1 - x0.cpu().numpy()) <= 1e-6 * np.linalg.norm(x1)
+    # (two different Krylov paths to the same residual level: the iterates agree to rtol·κ(J))
+    assert np.linalg.norm(x1 - x0.cpu().numpy()) <= (1e-6 if rtol <= 1e-9 else 0.05) * np.linalg.norm(x1)
     # the oracle's column-by-column GMRES takes the same number of iterations (the discarded cycle is not counted)
-    xo, io = R.gmres(lambda z: A @ z, b, rtol=rtol, restart=m, itmax=600, M=M, ortho="cgs2")
+    xo, io = R.gmres(lambda z: A @ z, b, rtol=rtol, restart=m, itmax=cap, M=M, ortho="cgs2")
     assert abs(g1["iters"] - io.iters) <= m
     assert f(G._h, -1) == 0
-    x2, g2 = G.solve(bd, abstol=0.0, reltol=rtol, maxiters=600)                      # the s-step form is back
+    x2, g2 = G.solve(bd, abstol=0.0, reltol=rtol, maxiters=cap)                      # the s-step form is back
     assert g2["iters"] == g0["iters"] and np.array_equal(x2.cpu().numpy(), x0.cpu().numpy())
 
 
