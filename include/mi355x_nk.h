@@ -45,7 +45,9 @@ typedef enum {
   NK_E_RCCL = -3,      /* RCCL error or librccl not loadable */
   NK_E_NOMEM = -4,
   NK_E_UNSUPPORTED = -5,
-  NK_E_CALLBACK = -6   /* a user callback returned non-zero */
+  NK_E_CALLBACK = -6,  /* a user callback returned non-zero */
+  NK_E_SINGULAR = -7,  /* a preconditioner could not be built: zero / non-finite diagonal entry or ILU(0) pivot */
+  NK_E_COMM = -8       /* a peer-mapped collective timed out (a rank stalled or died): results of this call are not valid */
 } nk_status;
 
 typedef enum { NK_HOST = 0, NK_DEVICE = 1 } nk_memspace;
@@ -253,6 +255,10 @@ typedef struct {
   double  pt_alpha_initial;             /* [1e-3] initial pseudo time step α                                          */
   int32_t gmres_sstep;                  /* [0]    NK_ORTHO_SSTEP: basis columns per block (1..16; 0 = automatic)      */
   int32_t gmres_sstep_basis;            /* [0]    nk_ss_basis                                                         */
+  /* --- a built-in preconditioner object on the concrete J, rebuilt numerically for every new Jacobian like `precs(A, p)`
+   *     (needs a concrete-J linsolve): 0 none, 1 Jacobi, 2 ILU(0) in the matrix's ordering, 3 ILU(0) multicolour */
+  int32_t precond_kind;                 /* [0]                                                                        */
+  int32_t precond_side;                 /* [1]    nk_side: the reference's tutorial precs return (Pl, I): left        */
 } nk_options;
 
 /* in-place callbacks of a user problem: NonlinearFunction{true}(f!; jvp, vjp, jac)
@@ -308,6 +314,14 @@ int nk_ctx_set_halo_overlap(nk_ctx *ctx, int on);
 int nk_device_alloc(nk_ctx *ctx, int64_t bytes, void **out);
 int nk_device_free(nk_ctx *ctx, void *ptr);
 int nk_device_copy(nk_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind);
+/* BLAS-1 on resident vectors (DEVICE pointers, local length n) for host languages whose resident vector type is a library
+ * buffer (Julia's DeviceVector): y = a x + b y; y = a; x·y; ‖x‖₂ (which = 2) / ‖x‖∞ (which = 0). Reductions are all-reduced
+ * over the ranks and returned on the host (blocking) — what `@bb axpy!`, `copyto!` and the termination norms of the
+ * reference's step! need (lib/NonlinearSolveFirstOrder/src/solve.jl:403,438,460). */
+int nk_vec_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y);
+int nk_vec_fill(nk_ctx *ctx, int64_t n, double a, double *y);
+int nk_vec_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *result);
+int nk_vec_norm(nk_ctx *ctx, int64_t n, const double *x, int which, double *result);
 
 /* Per-kernel-family timing (bench.py's roofline numbers). Off by default; when on, every launch of a profiled
  * family is issued with hipExtLaunchKernelGGL start/stop events, i.e. the kernel's own begin/end device
@@ -364,6 +378,10 @@ int nk_csr_create_from_csc_rows(nk_ctx *ctx, int64_t n, int64_t nnz, int index_b
                                 int64_t row_begin, int64_t nrows_local, nk_csr **out);
 int nk_csr_destroy(nk_csr *A);
 int nk_csr_set_values(nk_csr *A, const double *vals, int memspace);
+/* New values for a matrix created by nk_csr_create_from_csc(_rows), given in the CSC order of that call (Julia:
+ * `nonzeros(J)` of the SparseMatrixCSC `f.jac(J, u, p)` refreshes every Newton step): one gather on the device through the
+ * permutation remembered at creation — no new conversion, no new pattern upload. nnz_csc = length of nzval. */
+int nk_csr_set_values_csc(nk_csr *A, const double *nzval, int64_t nnz_csc, int memspace);
 int nk_csr_get_values(nk_csr *A, double *vals, int memspace);
 int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, int64_t *nnz, int64_t *n_halo);
 double *nk_csr_values_device(nk_csr *A);      /* device pointer of the local values (nnz doubles) */
@@ -429,8 +447,43 @@ int nk_gmres_set_shift(nk_gmres *G, double sigma);
 /* … and A + sigma·diag(m) with a DEVICE vector m of local length n (kept by reference; NULL = identity): the damping α⁻¹ M of
  * PseudoTransient(; mass_matrix = Diagonal(m)) (pseudo_transient.jl:102-120,149). */
 int nk_gmres_set_shift_weights(nk_gmres *G, const double *d_m);
-/* right preconditioner x = M⁻¹ z applied as a device callback (precs hook, test/Core/core_tests__item21.jl) */
+/* ---- preconditioners: the `precs(A, p) -> (Pl, Pr)` hook of the LinearSolve interface
+ * (lib/NonlinearSolveBase/src/linear_solve.jl:195-199 wrap_preconditioners; test/Core/core_tests__item21.jl:10-18;
+ *  docs/src/tutorials/large_systems.md:252-316, whose `precs` return `(Pl, I)`). GMRES solves Pl⁻¹ A Pr⁻¹ (Pr x) = Pl⁻¹ b:
+ * the Arnoldi process runs on Pl⁻¹ A Pr⁻¹, and with a left preconditioner the stopping test
+ * ‖Pl⁻¹(b − A x)‖ ≤ atol + rtol·‖Pl⁻¹(b − A x₀)‖ and nk_gmres_info.rnorm0 / rnorm refer to the PRECONDITIONED residual, as in
+ * Krylov.jl's gmres [EXT]. Either side takes a callback (device or host pointers) or a built-in object; fn / P = NULL removes
+ * that side. Callbacks must be linear maps y = P⁻¹ x. */
+/* right preconditioner x = Pr⁻¹ z applied as a device callback */
 int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
+/* left preconditioner y = Pl⁻¹ r applied as a device callback */
+int nk_gmres_set_left_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user);
+int nk_gmres_set_left_preconditioner_host(nk_gmres *G, nk_matvec_fn fn, void *user);
+/* a built-in preconditioner object (below) on either side; the object stays the caller's (it must outlive its use here,
+ * and nk_precond_update is the caller's to call when the matrix values change) */
+typedef enum { NK_SIDE_RIGHT = 0, NK_SIDE_LEFT = 1 } nk_side;
+typedef struct nk_precond nk_precond;
+int nk_gmres_set_preconditioner(nk_gmres *G, int side, nk_precond *P);
+
+/* Preconditioner objects built from a CSR matrix (csrc/nk_precond.hip) — what `precs(A, p)` returns for a general sparse
+ * Jacobian (the reference's tutorial fills the slot with IncompleteLU.ilu(W) / an algebraic multigrid):
+ *   Jacobi: M = diag(A).  ILU(0): A ≈ LU on the pattern of A, no fill, no pivoting, of the rank's LOCAL square block (halo
+ *   columns dropped: block-Jacobi ILU(0) across ranks, no communication in the apply). Rows are scheduled by dependency levels;
+ *   NK_ILU_NATURAL keeps the matrix's ordering (the classical preconditioner; a lexicographic stencil has 2n − 1 levels, walked
+ *   inside one persistent workgroup — milliseconds per application at n = 1024²), NK_ILU_MULTICOLOR permutes the rows by a
+ *   greedy colouring of the pattern (as many levels as colours, one wide launch each: the GPU form).
+ * nk_precond_update refactorises for the matrix's current values; NK_E_SINGULAR on a zero pivot. x, y: local length n. */
+typedef enum { NK_PRECOND_JACOBI = 1, NK_PRECOND_ILU0 = 2 } nk_precond_kind;
+typedef enum { NK_ILU_NATURAL = 0, NK_ILU_MULTICOLOR = 1 } nk_ilu_ordering;
+int nk_precond_create_jacobi(nk_csr *A, nk_precond **out);
+int nk_precond_create_ilu0(nk_csr *A, int ordering, nk_precond **out);
+int nk_precond_update(nk_precond *P);
+int nk_precond_apply(nk_precond *P, const double *x, double *y, int memspace);   /* y = M⁻¹ x */
+int nk_precond_info(nk_precond *P, int *kind, int *levels_lower, int *levels_upper, int *ncolors);
+/* the ILU(0) factors in the (permuted) ordering, for inspection: CSR of the local block — L strictly below the diagonal
+ * (unit diagonal implied), U on and above — and perm[permuted row] = original row. Any pointer may be NULL. */
+int nk_precond_ilu0_factors(nk_precond *P, int64_t *nnz, int32_t *rowptr, int32_t *col, double *val, int32_t *perm);
+int nk_precond_destroy(nk_precond *P);
 /* The same two hooks for operators that live in HOST memory (a Julia `mul!` on plain Arrays): the callback receives host
  * pointers, the library stages the vectors through pinned buffers around every call (2 × 8 n bytes over PCIe each). */
 int nk_gmres_set_operator_fn_host(nk_gmres *G, nk_matvec_fn fn, void *user);
@@ -495,6 +548,18 @@ int nk_solver_set_mass_matrix_diagonal(nk_solver *S, const double *m, int memspa
 int nk_solver_get_u(nk_solver *S, double *u, int memspace);
 int nk_solver_get_resid(nk_solver *S, double *f, int memspace);
 int nk_solver_get_stats(nk_solver *S, nk_stats *stats);
+/* The `precs(A, p) -> (Pl, Pr)` hook at solver level (KrylovJL_GMRES(precs = …); test/Core/core_tests__item21.jl:10-37):
+ * `fn` is called once when it is installed — LinearSolve evaluates precs when the linear cache is built [EXT] — and then
+ * right after every Jacobian refresh (a new `A` marks the LinearSolve cache fresh: lib/NonlinearSolveBase/ext/
+ * NonlinearSolveBaseLinearSolveExt.jl:64-111), before that step's linear solve; never by nk_solver_reinit. It receives the
+ * solver's GMRES object — install Pl / Pr on it with nk_gmres_set_left/right_preconditioner(_host) or
+ * nk_gmres_set_preconditioner —, the concrete Jacobian (NULL on the matrix-free path) and the iterate (DEVICE pointer, local
+ * length n: the `u` of LinearSolveParameters(u, p)). Non-zero return = NK_E_CALLBACK. fn = NULL removes the hook. */
+typedef int (*nk_precs_fn)(void *user, nk_gmres *G, nk_csr *A, const double *u);
+int nk_solver_set_precs(nk_solver *S, nk_precs_fn fn, void *user);
+/* the solver's GMRES object and concrete Jacobian (NULL where the linsolve has none), e.g. to build preconditioner objects on */
+nk_gmres *nk_solver_gmres(nk_solver *S);
+nk_csr *nk_solver_jacobian(nk_solver *S);
 int nk_solver_get_retcode(nk_solver *S, int *retcode, int *nsteps, int *force_stop);
 int nk_solver_get_scalars(nk_solver *S, double *fnorm_inf, double *trust_region, double *eta);
 int nk_solver_get_trace(nk_solver *S, nk_trace_entry *rows, int capacity, int *nrows);

@@ -73,6 +73,40 @@ function Base.copyto!(h::Array{Float64}, d::DeviceVector)
 end
 DeviceVector(h::Array{Float64}; kw...) = copyto!(DeviceVector(length(h); kw...), vec(h))
 Base.Array(d::DeviceVector) = copyto!(Vector{Float64}(undef, d.n), d)
+# The in-place vector algebra of the reference's step! on resident data, through nk_vec_* (include/mi355x_nk.h):
+# `copyto!`, `axpy!` / `axpby!` (`@bb axpy!(α, δu, u)`, FirstOrder/src/solve.jl:403,438,460), `rmul!`, `fill!`, `dot`, `norm`,
+# `similar`. General broadcast expressions (`@. u = u + α * δu`) need a GPU array package: with AMDGPU.jl loaded, use
+# ROCArrays (ext/MI355XNewtonKrylovAMDGPUExt.jl) — they go through the same ABI with memspace = NK_DEVICE.
+Base.similar(d::DeviceVector) = DeviceVector(d.n; ctx = d.ctx)
+Base.similar(d::DeviceVector, ::Type{Float64}) = DeviceVector(d.n; ctx = d.ctx)
+function Base.copyto!(dst::DeviceVector, src::DeviceVector)
+    @assert dst.n == src.n
+    nkcheck(@ccall libnk.nk_device_copy(dst.ctx.ptr::Ptr{Cvoid}, dst.ptr::Ptr{Cvoid}, src.ptr::Ptr{Cvoid}, (8 * dst.n)::Int64, 2::Cint)::Cint)
+    return dst
+end
+Base.copy(d::DeviceVector) = copyto!(similar(d), d)
+function LinearAlgebra.axpby!(a::Real, x::DeviceVector, b::Real, y::DeviceVector)
+    @assert x.n == y.n
+    nkcheck(@ccall libnk.nk_vec_axpby(y.ctx.ptr::Ptr{Cvoid}, y.n::Int64, Float64(a)::Float64, x.ptr::Ptr{Float64}, Float64(b)::Float64, y.ptr::Ptr{Float64})::Cint)
+    return y
+end
+LinearAlgebra.axpy!(a::Real, x::DeviceVector, y::DeviceVector) = axpby!(a, x, 1.0, y)
+LinearAlgebra.rmul!(y::DeviceVector, a::Real) = axpby!(0.0, y, a, y)
+function Base.fill!(y::DeviceVector, a::Real)
+    nkcheck(@ccall libnk.nk_vec_fill(y.ctx.ptr::Ptr{Cvoid}, y.n::Int64, Float64(a)::Float64, y.ptr::Ptr{Float64})::Cint)
+    return y
+end
+function LinearAlgebra.dot(x::DeviceVector, y::DeviceVector)
+    r = Ref(0.0)
+    nkcheck(@ccall libnk.nk_vec_dot(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, y.ptr::Ptr{Float64}, r::Ptr{Float64})::Cint)
+    return r[]
+end
+function LinearAlgebra.norm(x::DeviceVector, p::Real = 2)
+    (p == 2 || p == Inf) || error("DeviceVector: norm(x, 2) and norm(x, Inf)")
+    r = Ref(0.0)
+    nkcheck(@ccall libnk.nk_vec_norm(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, (p == 2 ? 2 : 0)::Cint, r::Ptr{Float64})::Cint)
+    return r[]
+end
 
 memspace(::Array{Float64}) = NK_HOST
 memspace(::DeviceVector) = NK_DEVICE
@@ -84,6 +118,8 @@ rawptr(x::Base.ReshapedArray) = rawptr(parent(x))
 mutable struct DeviceCSR
     ptr::Ptr{Cvoid}
     n::Int
+    colptr::Vector{Int}      # the pattern this object was built from: a new Jacobian with the same pattern only refreshes values
+    rowval::Vector{Int}
 end
 """Upload a `SparseMatrixCSC{Float64,Int}` as it is (1-based Int64 colptr/rowval): converted to CSR once."""
 function DeviceCSR(A::SparseMatrixCSC{Float64, Int}; ctx = default_ctx())
@@ -91,8 +127,16 @@ function DeviceCSR(A::SparseMatrixCSC{Float64, Int}; ctx = default_ctx())
     GC.@preserve A nkcheck(@ccall libnk.nk_csr_create_from_csc(ctx.ptr::Ptr{Cvoid}, size(A, 1)::Int64,
         nnz(A)::Int64, 64::Cint, 1::Cint, A.colptr::Ptr{Int64}, A.rowval::Ptr{Int64}, A.nzval::Ptr{Float64},
         out::Ptr{Ptr{Cvoid}})::Cint)
-    m = DeviceCSR(out[], size(A, 1))
+    m = DeviceCSR(out[], size(A, 1), A.colptr, A.rowval)    # (shared with A, not copied: the pattern arrays of a Jacobian do not change)
     finalizer(x -> @ccall(libnk.nk_csr_destroy(x.ptr::Ptr{Cvoid})::Cint), m)
+    return m
+end
+same_pattern(m::DeviceCSR, A::SparseMatrixCSC{Float64, Int}) =
+    size(A, 1) == m.n && (A.colptr === m.colptr || A.colptr == m.colptr) && (A.rowval === m.rowval || A.rowval == m.rowval)
+"""New values in `nonzeros(A)` order for the pattern the matrix was created with: one gather on the device
+(nk_csr_set_values_csc) instead of a new CSC → CSR conversion and pattern upload."""
+function update_values!(m::DeviceCSR, A::SparseMatrixCSC{Float64, Int})
+    GC.@preserve A nkcheck(@ccall libnk.nk_csr_set_values_csc(m.ptr::Ptr{Cvoid}, A.nzval::Ptr{Float64}, nnz(A)::Int64, NK_HOST::Cint)::Cint)
     return m
 end
 function LinearAlgebra.mul!(y::AbstractVector{Float64}, A::DeviceCSR, x::AbstractVector{Float64})
@@ -118,6 +162,34 @@ function DeviceProblem(kind::Integer, params::Vector{Float64}; ctx = default_ctx
 end
 bratu2d(n; λ = 6.0, scale = 0.0, kw...) = DeviceProblem(2, Float64[n, λ, scale]; kw...)
 brusselator2d(N; A = 3.4, B = 1.0, α = 10.0, dx = 1 / (N - 1), kw...) = DeviceProblem(3, Float64[N, A, B, α, dx]; kw...)
+
+# ------------------------------------------------------------------ preconditioner objects (what `precs(A, p)` may return)
+"""`DeviceILU0(A::DeviceCSR; ordering = :multicolor)` / `DeviceJacobi(A)`: nk_precond objects — usable as `Pl` or `Pr` of
+`MI355XGMRES` without a host round trip per application, and as `ldiv!(y, P, x)` on host or resident vectors."""
+mutable struct DevicePreconditioner
+    ptr::Ptr{Cvoid}
+    A::DeviceCSR
+end
+function DeviceILU0(A::DeviceCSR; ordering::Symbol = :multicolor)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    nkcheck(@ccall libnk.nk_precond_create_ilu0(A.ptr::Ptr{Cvoid}, (ordering === :natural ? 0 : 1)::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
+    p = DevicePreconditioner(out[], A)
+    finalizer(x -> @ccall(libnk.nk_precond_destroy(x.ptr::Ptr{Cvoid})::Cint), p)
+    return p
+end
+function DeviceJacobi(A::DeviceCSR)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    nkcheck(@ccall libnk.nk_precond_create_jacobi(A.ptr::Ptr{Cvoid}, out::Ptr{Ptr{Cvoid}})::Cint)
+    p = DevicePreconditioner(out[], A)
+    finalizer(x -> @ccall(libnk.nk_precond_destroy(x.ptr::Ptr{Cvoid})::Cint), p)
+    return p
+end
+update!(P::DevicePreconditioner) = (nkcheck(@ccall libnk.nk_precond_update(P.ptr::Ptr{Cvoid})::Cint); P)
+function LinearAlgebra.ldiv!(y::AbstractVector{Float64}, P::DevicePreconditioner, x::AbstractVector{Float64})
+    @assert memspace(x) == memspace(y)
+    GC.@preserve x y nkcheck(@ccall libnk.nk_precond_apply(P.ptr::Ptr{Cvoid}, rawptr(x)::Ptr{Float64}, rawptr(y)::Ptr{Float64}, memspace(x)::Cint)::Cint)
+    return y
+end
 
 # ------------------------------------------------------------------ seam 2: f / jvp / vjp callbacks
 """`NonlinearFunction` whose `f`, `jvp`, `vjp` run the built-in device kernels. The arrays may be host `Array`s (copied
@@ -177,7 +249,8 @@ mutable struct GMRESWorkspace
     n::Int
     csr::Union{Nothing, DeviceCSR}
     box::Union{Nothing, OperatorBox}        # keep-alive of the operator behind the C callback
-    precbox::Union{Nothing, OperatorBox}
+    precbox::Union{Nothing, OperatorBox}    # … of Pr
+    lprecbox::Union{Nothing, OperatorBox}   # … of Pl
 end
 const ORTHO = Dict(:mgs => 0, :cgs2 => 1, :cgs => 2, :dcgs2 => 3, :dcgs2_1r => 4, :sstep => 5)
 const SS_BASIS = Dict(:auto => 0, :monomial => 1, :newton => 2)
@@ -191,7 +264,7 @@ function LinearSolve.init_cacheval(alg::MI355XGMRES, A, b, u, Pl, Pr, maxiters::
         nkcheck(@ccall libnk.nk_gmres_set_block_size(out[]::Ptr{Cvoid}, alg.sstep::Cint)::Cint)
         nkcheck(@ccall libnk.nk_gmres_set_sstep_basis(out[]::Ptr{Cvoid}, SS_BASIS[alg.sstep_basis]::Cint)::Cint)
     end
-    w = GMRESWorkspace(out[], length(b), nothing, nothing, nothing)
+    w = GMRESWorkspace(out[], length(b), nothing, nothing, nothing, nothing)
     finalizer(x -> @ccall(libnk.nk_gmres_destroy(x.ptr::Ptr{Cvoid})::Cint), w)
     return w
 end
@@ -229,16 +302,31 @@ function device_jvp_of(A::SciMLJacobianOperators.StatefulJacobianOperator)      
     return op isa DeviceJVP ? op.P : nothing
 end
 
+# Operators / preconditioners whose `mul!` / `ldiv!` work on resident (ROCArray) vectors declare it — `on_device(::MyOp) = true`
+# — and are then called through the device-pointer contract by the AMDGPU extension (ext/MI355XNewtonKrylovAMDGPUExt.jl),
+# which provides the two methods below; without the extension they error instead of reading device memory from the host.
+on_device(A) = false
+bind_device_operator!(w, A) = error("device-resident Julia operators need AMDGPU.jl (load it to activate the extension)")
+bind_device_preconditioner!(w, side, P) = error("device-resident Julia preconditioners need AMDGPU.jl (load it to activate the extension)")
+
 function set_operator!(w::GMRESWorkspace, A)
     if A isa SparseMatrixCSC
-        # concrete J: Julia's CSC fields are ingested as they are (the CSC → CSR conversion is one O(nnz) host pass)
-        w.csr = DeviceCSR(A)
+        # concrete J: Julia's CSC fields are ingested as they are (the CSC → CSR conversion is one O(nnz) host pass) — ONCE per
+        # pattern: the Jacobian of the next Newton step has the same colptr / rowval and only refreshes the values (one gather
+        # on the device, nk_csr_set_values_csc; round 2 re-ingested and re-uploaded the whole matrix every step)
+        if w.csr !== nothing && same_pattern(w.csr, A)
+            update_values!(w.csr, A)
+        else
+            w.csr = DeviceCSR(A)
+        end
         nkcheck(@ccall libnk.nk_gmres_set_operator_csr(w.ptr::Ptr{Cvoid}, w.csr.ptr::Ptr{Cvoid})::Cint)
     elseif (P = device_jvp_of(A)) !== nothing
         # StatefulJacobianOperator whose f.jvp is the device kernel: bind it, no trampoline, nothing crosses PCIe
         u = A.u
         GC.@preserve u nkcheck(@ccall libnk.nk_gmres_set_operator_jvp(w.ptr::Ptr{Cvoid}, P.ptr::Ptr{Cvoid},
             rawptr(u)::Ptr{Float64}, memspace(u)::Cint)::Cint)
+    elseif on_device(A)
+        bind_device_operator!(w, A)
     else
         w.box = OperatorBox(A, w.n)
         cb = @cfunction(host_matvec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
@@ -248,17 +336,42 @@ function set_operator!(w::GMRESWorkspace, A)
     return nothing
 end
 
+const NK_SIDE_RIGHT, NK_SIDE_LEFT = Cint(0), Cint(1)
+is_identity(P) = P === nothing || P === LinearAlgebra.I || P isa LinearSolve.IdentityOperator ||      # [EXT]
+    (P isa LinearAlgebra.UniformScaling && isone(P.λ))
+function bind_preconditioner!(w::GMRESWorkspace, side::Cint, P)
+    if is_identity(P)
+        nkcheck(@ccall libnk.nk_gmres_set_preconditioner(w.ptr::Ptr{Cvoid}, side::Cint, C_NULL::Ptr{Cvoid})::Cint)
+        side == NK_SIDE_LEFT ? (w.lprecbox = nothing) : (w.precbox = nothing)
+    elseif P isa DevicePreconditioner
+        box = OperatorBox(P, w.n)                                                # keep-alive only
+        side == NK_SIDE_LEFT ? (w.lprecbox = box) : (w.precbox = box)
+        nkcheck(@ccall libnk.nk_gmres_set_preconditioner(w.ptr::Ptr{Cvoid}, side::Cint, P.ptr::Ptr{Cvoid})::Cint)
+    elseif on_device(P)
+        bind_device_preconditioner!(w, side, P)
+    else
+        box = OperatorBox(P, w.n)
+        side == NK_SIDE_LEFT ? (w.lprecbox = box) : (w.precbox = box)
+        pcb = @cfunction(host_prec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
+        if side == NK_SIDE_LEFT
+            nkcheck(@ccall libnk.nk_gmres_set_left_preconditioner_host(w.ptr::Ptr{Cvoid}, pcb::Ptr{Cvoid}, pointer_from_objref(box)::Ptr{Cvoid})::Cint)
+        else
+            nkcheck(@ccall libnk.nk_gmres_set_right_preconditioner_host(w.ptr::Ptr{Cvoid}, pcb::Ptr{Cvoid}, pointer_from_objref(box)::Ptr{Cvoid})::Cint)
+        end
+    end
+    return nothing
+end
+
 function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::MI355XGMRES; kwargs...)   # [EXT]
     w = cache.cacheval::GMRESWorkspace
     if cache.isfresh                                                            # [EXT] set by `cache.A = …`
         set_operator!(w, cache.A)
-        Pr = cache.Pr                                                           # [EXT] from `precs(A, p)`
-        if !(Pr isa LinearSolve.IdentityOperator || Pr === LinearAlgebra.I)     # [EXT]
-            w.precbox = OperatorBox(Pr, w.n)
-            pcb = @cfunction(host_prec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}))
-            nkcheck(@ccall libnk.nk_gmres_set_right_preconditioner_host(w.ptr::Ptr{Cvoid}, pcb::Ptr{Cvoid},
-                pointer_from_objref(w.precbox)::Ptr{Cvoid})::Cint)
-        end
+        # `precs(A, p) -> (Pl, Pr)` [EXT: LinearSolve re-evaluates it for a fresh A and stores the pair in the cache]. BOTH sides
+        # are bound — the reference's own documented precs return `(Pl, I)` (docs/src/tutorials/large_systems.md:257,284-287):
+        # a DevicePreconditioner goes in as an object (no host round trip per application), anything else with `ldiv!` through
+        # the host trampoline, identities remove that side.
+        bind_preconditioner!(w, NK_SIDE_LEFT, cache.Pl)
+        bind_preconditioner!(w, NK_SIDE_RIGHT, cache.Pr)
         cache.isfresh = false
     end
     info = Ref(GMRESInfo(0, 0, 0, 0, 0.0, 0.0))
@@ -293,7 +406,8 @@ Base.@kwdef struct MI355XNewtonKrylovAlg <: AbstractNonlinearSolveAlgorithm
     forcing::Bool = false                 # EisenstatWalkerForcing2()
     radius_update_scheme::Int = 0         # RadiusUpdateSchemes.Simple … Fan (0…6)
     linesearch::Symbol = :none            # :none | :BackTracking | :Static | :StrongWolfe | :MoreThuente | :HagerZhang (LineSearchesJL methods)
-    precs::Symbol = :none                 # :none | :chebyshev | :multigrid — the built-ins behind the `precs` hook
+    precs::Symbol = :none                 # :none | :chebyshev | :multigrid | :jacobi | :ilu0 | :ilu0_natural — the built-ins behind the `precs` hook
+    precs_side::Symbol = :left            # :jacobi / :ilu0: which side (the reference's tutorial precs return (Pl, I))
     cheb_degree::Int = 32
     cheb_ratio::Float64 = 300.0
     mg_nu::Int = 2
@@ -335,7 +449,8 @@ function apply_termination!(o, tc)
     return o
 end
 
-# nk_options mirrors include/mi355x_nk.h field for field (isbits ⇒ passable by Ref)
+# nk_options mirrors include/mi355x_nk.h field for field. (A mutable struct of plain bits: `Ref(o)` is a pointer to its fields,
+# valid for the duration of the @ccall that receives it.)
 Base.@kwdef mutable struct NKOptions
     algorithm::Int32 = 0; linsolve::Int32 = 0; maxiters::Int32 = 1000; termination_norm::Int32 = 0
     abstol::Float64 = 0.0; reltol::Float64 = 0.0; maxtime::Float64 = 0.0
@@ -360,6 +475,7 @@ Base.@kwdef mutable struct NKOptions
     lm_b_uphill::Float64 = 1.0
     pt_alpha_initial::Float64 = 1e-3
     gmres_sstep::Int32 = 0; gmres_sstep_basis::Int32 = 0
+    precond_kind::Int32 = 0; precond_side::Int32 = 1
 end
 
 const RETCODES = (ReturnCode.Default, ReturnCode.Success, ReturnCode.MaxIters, ReturnCode.Unstable,
@@ -385,7 +501,9 @@ function SciMLBase.__solve(prob::NonlinearProblem, alg::MI355XNewtonKrylovAlg, a
         linesearch = get(Dict(:BackTracking => 1, :Static => 2, :StrongWolfe => 3, :MoreThuente => 4, :HagerZhang => 5), alg.linesearch, 0),
         cheb_degree = alg.precs === :chebyshev ? alg.cheb_degree : 0, cheb_ratio = alg.cheb_ratio,
         mg_nu = alg.precs === :multigrid ? alg.mg_nu : 0, mg_coarse = alg.mg_coarse,
-        jac_colored = alg.jac_colored ? 1 : 0)
+        jac_colored = alg.jac_colored ? 1 : 0,
+        precond_kind = get(Dict(:jacobi => 1, :ilu0_natural => 2, :ilu0 => 3), alg.precs, 0),
+        precond_side = alg.precs_side === :right ? 0 : 1)
     apply_termination!(o, termination_condition)
     # u0 may be a host Array (copied in and out once) or already resident (DeviceVector / ROCArray): no PCIe traffic then
     u0 = prob.u0 isa Array ? Vector{Float64}(vec(prob.u0)) : vec(prob.u0)
@@ -458,25 +576,11 @@ function vectorized_solve(k::EnsembleKernel, u0::Vector{Float64}, p::Matrix{Floa
 end
 
 # ------------------------------------------------------------------------------------------ AMDGPU.jl arrays (optional)
-# With AMDGPU.jl loaded (as a package extension: ext/MI355XNewtonKrylovAMDGPUExt.jl with AMDGPU as a weak dependency),
-# ROCArrays are passed with memspace = NK_DEVICE, and a device-resident Julia operator can serve as `A` through the
-# device-pointer callback contract (nk_matvec_fn proper): the callback wraps the pointers as ROCArrays — never as Arrays.
-#
-#   module MI355XNewtonKrylovAMDGPUExt
-#   using AMDGPU, LinearAlgebra, MI355XNewtonKrylov
-#   import MI355XNewtonKrylov: memspace, rawptr, NK_DEVICE, OperatorBox
-#   memspace(::ROCArray{Float64}) = NK_DEVICE
-#   rawptr(x::ROCArray{Float64}) = Ptr{Float64}(UInt(pointer(x)))
-#   function device_matvec_trampoline(user::Ptr{Cvoid}, x::Ptr{Float64}, y::Ptr{Float64}, stream::Ptr{Cvoid})::Cint
-#       box = unsafe_pointer_to_objref(user)::OperatorBox
-#       xv = unsafe_wrap(ROCArray, Base.unsafe_convert(AMDGPU.Mem.HIPBuffer ... x), (box.n,))   # [EXT AMDGPU.jl ≥ 1.0]
-#       yv = unsafe_wrap(ROCArray, ..., (box.n,))
-#       try mul!(yv, box.A, xv); AMDGPU.synchronize(); return Cint(0) catch; return Cint(1) end
-#   end
-#   # registered with nk_gmres_set_operator_fn (device pointers) instead of nk_gmres_set_operator_fn_host
-#   end
+# ext/MI355XNewtonKrylovAMDGPUExt.jl (a package extension, AMDGPU as a weak dependency): ROCArrays pass through every entry
+# point with memspace = NK_DEVICE, and device-resident Julia operators / preconditioners serve through the device-pointer
+# callback contract (nk_matvec_fn proper).
 
 export Ctx, DeviceVector, DeviceCSR, DeviceProblem, bratu2d, brusselator2d, mi355x_function, MI355XGMRES,
-    MI355XNewtonKrylovAlg, EnsembleKernel, vectorized_solve
+    MI355XNewtonKrylovAlg, EnsembleKernel, vectorized_solve, DevicePreconditioner, DeviceILU0, DeviceJacobi, update!, update_values!
 
 end # module

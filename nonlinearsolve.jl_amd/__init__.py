@@ -9,7 +9,8 @@ from .core import (  # noqa: F401
     Context, default_context, set_default_context, partition_range, comm_unique_id,
     CSRMatrix, DeviceProblem, Quadratic, Bratu2D, Brusselator2D,
     NonlinearFunction, NonlinearProblem,
-    KrylovJL_GMRES, ChebyshevPrecs, MultigridPrecs, EisenstatWalkerForcing2, RadiusUpdateSchemes, BackTracking, LineSearchesJL, NewtonRaphson, TrustRegion, GaussNewton, LevenbergMarquardt, PseudoTransient,
+    KrylovJL_GMRES, ChebyshevPrecs, MultigridPrecs, ObjectPrecs, LinearSolveParameters, Preconditioner, JacobiPreconditioner,
+    ILU0Preconditioner, IDENTITY, EisenstatWalkerForcing2, RadiusUpdateSchemes, BackTracking, LineSearchesJL, NewtonRaphson, TrustRegion, GaussNewton, LevenbergMarquardt, PseudoTransient,
     NonlinearLeastSquaresProblem,
     AbsNormSafeBestTerminationMode, NormTerminationMode, RelTerminationMode, RelNormTerminationMode,
     RelNormSafeTerminationMode, RelNormSafeBestTerminationMode, AbsTerminationMode, AbsNormTerminationMode,

@@ -74,6 +74,8 @@ class Options(C.Structure):
         ("pt_alpha_initial", C.c_double),
         ("gmres_sstep", C.c_int32),
         ("gmres_sstep_basis", C.c_int32),
+        ("precond_kind", C.c_int32),
+        ("precond_side", C.c_int32),
     ]
 
 
@@ -81,6 +83,7 @@ RESIDUAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 JVP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 JACVALS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 MATVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+PRECS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)   # (user, nk_gmres*, nk_csr*, u)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                            C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
@@ -119,6 +122,10 @@ SIGNATURES = {
     "nk_ctx_comm_peer_status": (_I, [_P, C.POINTER(_I), C.POINTER(_L)]),
     "nk_ctx_comm_peer_selftest": (_I, [_P, C.POINTER(_I)]),
     "nk_ctx_comm_peer_disable": (_I, [_P]),
+    "nk_vec_axpby": (_I, [_P, _L, _D, _P, _D, _P]),
+    "nk_vec_fill": (_I, [_P, _L, _D, _P]),
+    "nk_vec_dot": (_I, [_P, _L, _P, _P, C.POINTER(_D)]),
+    "nk_vec_norm": (_I, [_P, _L, _P, _I, C.POINTER(_D)]),
     "nk_partition_range": (_I, [_L, _L, _I, _I, C.POINTER(_L), C.POINTER(_L)]),
     "nk_csr_create": (_I, [_P, _L, _L, _L, _L, _I, _I, _P, _P, _P, _I, _PP]),
     "nk_csr_create_from_csc": (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _PP]),
@@ -126,6 +133,7 @@ SIGNATURES = {
     "nk_csr_destroy": (_I, [_P]),
     "nk_csr_set_values": (_I, [_P, _P, _I]),
     "nk_csr_get_values": (_I, [_P, _P, _I]),
+    "nk_csr_set_values_csc": (_I, [_P, _P, _L, _I]),
     "nk_csr_info": (_I, [_P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_L)]),
     "nk_csr_values_device": (_P, [_P]),
     "nk_spmv": (_I, [_P, _P, _P, _I]),
@@ -159,6 +167,19 @@ SIGNATURES = {
     "nk_gmres_set_right_preconditioner": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_operator_fn_host": (_I, [_P, MATVEC_FN, _P]),
     "nk_gmres_set_right_preconditioner_host": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_left_preconditioner": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_left_preconditioner_host": (_I, [_P, MATVEC_FN, _P]),
+    "nk_gmres_set_preconditioner": (_I, [_P, _I, _P]),
+    "nk_precond_create_jacobi": (_I, [_P, _PP]),
+    "nk_precond_create_ilu0": (_I, [_P, _I, _PP]),
+    "nk_precond_update": (_I, [_P]),
+    "nk_precond_apply": (_I, [_P, _P, _P, _I]),
+    "nk_precond_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "nk_precond_ilu0_factors": (_I, [_P, C.POINTER(_L), _P, _P, _P, _P]),
+    "nk_precond_destroy": (_I, [_P]),
+    "nk_solver_set_precs": (_I, [_P, PRECS_FN, _P]),
+    "nk_solver_gmres": (_P, [_P]),
+    "nk_solver_jacobian": (_P, [_P]),
     "nk_device_alloc": (_I, [_P, _L, C.POINTER(C.c_void_p)]),
     "nk_device_free": (_I, [_P, _P]),
     "nk_device_copy": (_I, [_P, _P, _P, _L, _I]),

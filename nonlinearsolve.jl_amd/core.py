@@ -258,6 +258,16 @@ class CSRMatrix:
         A.sort_indices()
         return cls.from_arrays(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, ctx=ctx)
 
+    def set_values_csc(self, nzval):
+        """New values in the CSC order of `from_csc` (Julia: `nonzeros(J)` after `f.jac(J, u, p)`): one gather on the device
+        through the permutation remembered at creation — no new conversion, no new pattern upload."""
+        if _is_torch(nzval) and nzval.is_cuda:
+            check(L.lib().nk_csr_set_values_csc(self._h, C.c_void_p(nzval.data_ptr()), int(nzval.numel()), L.DEVICE))
+        else:
+            v = np.ascontiguousarray(nzval.cpu().numpy() if _is_torch(nzval) else nzval, dtype=np.float64)
+            check(L.lib().nk_csr_set_values_csc(self._h, C.c_void_p(v.ctypes.data), int(v.size), L.HOST))
+        return self
+
     @classmethod
     def from_csc(cls, colptr, rowval, nzval, index_base=1, ctx=None, row_range=None):
         """Julia's SparseMatrixCSC fields (1-based Int64 by default) of the whole matrix; on several ranks this rank keeps
@@ -545,6 +555,102 @@ class MultigridPrecs:
 
 
 @dataclass
+class LinearSolveParameters:
+    """lib/NonlinearSolveBase/src/linear_solve.jl:1-4: what `precs(A, p)` receives as p — the current iterate u (a device
+    tensor) and the nonlinear problem's parameters p."""
+    u: object
+    p: object
+
+
+class Preconditioner:
+    """nk_precond: a preconditioner object built from a CSRMatrix on the device — what a `precs(A, p)` returns for a general
+    sparse Jacobian (docs/src/tutorials/large_systems.md:252-316 fills the slot with IncompleteLU.ilu / an algebraic
+    multigrid). Usable as Pl or Pr of the device GMRES and standalone (`apply`)."""
+
+    def __init__(self, handle, A):
+        self._h, self.A, self.n = handle, A, None
+
+    def update(self):
+        """refactorise for the matrix's current values (`precs` is re-evaluated for every new A)"""
+        check(L.lib().nk_precond_update(self._h))
+        return self
+
+    def apply(self, x):
+        """y = M⁻¹ x (device tensor in → device tensor out; NumPy in → NumPy out)"""
+        if _is_torch(x):
+            y = torch.empty_like(x)
+            check(L.lib().nk_precond_apply(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                           L.DEVICE if x.is_cuda else L.HOST))
+            return y
+        xa = np.ascontiguousarray(x, dtype=np.float64)
+        ya = np.empty_like(xa)
+        check(L.lib().nk_precond_apply(self._h, C.c_void_p(xa.ctypes.data), C.c_void_p(ya.ctypes.data), L.HOST))
+        return ya
+
+    __call__ = apply
+
+    def info(self):
+        k, ll, lu, nc = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(L.lib().nk_precond_info(self._h, C.byref(k), C.byref(ll), C.byref(lu), C.byref(nc)))
+        return dict(kind={1: "jacobi", 2: "ilu0"}[k.value], levels_lower=ll.value, levels_upper=lu.value, ncolors=nc.value)
+
+    def close(self):
+        if self._h:
+            L.lib().nk_precond_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class JacobiPreconditioner(Preconditioner):
+    """M = diag(A)"""
+
+    def __init__(self, A: "CSRMatrix"):
+        h = C.c_void_p()
+        check(L.lib().nk_precond_create_jacobi(A._h, C.byref(h)))
+        super().__init__(h, A)
+
+
+class ILU0Preconditioner(Preconditioner):
+    """A ≈ LU on the pattern of A (no fill, no pivoting) of the rank's local block, level-scheduled on the device.
+    ordering = "natural": the classical preconditioner in the matrix's ordering (a lexicographic stencil is a dependency chain
+    of 2n − 1 levels: milliseconds per application at n = 1024²); "multicolor": rows permuted by a greedy colouring (as many
+    levels as colours — the GPU form)."""
+
+    def __init__(self, A: "CSRMatrix", ordering: str = "multicolor"):
+        h = C.c_void_p()
+        check(L.lib().nk_precond_create_ilu0(A._h, {"natural": 0, "multicolor": 1}[ordering], C.byref(h)))
+        super().__init__(h, A)
+        self.ordering = ordering
+
+    def factors(self):
+        """(L, U, perm) as SciPy CSR matrices in the permuted ordering: perm[permuted row] = original row."""
+        import scipy.sparse as sp
+        nnz = C.c_int64(0)
+        check(L.lib().nk_precond_ilu0_factors(self._h, C.byref(nnz), None, None, None, None))
+        n = self.A.shape[0]
+        rp, ci = np.zeros(n + 1, dtype=np.int32), np.zeros(nnz.value, dtype=np.int32)
+        v, perm = np.zeros(nnz.value), np.zeros(n, dtype=np.int32)
+        check(L.lib().nk_precond_ilu0_factors(self._h, None, C.c_void_p(rp.ctypes.data), C.c_void_p(ci.ctypes.data),
+                                              C.c_void_p(v.ctypes.data), C.c_void_p(perm.ctypes.data)))
+        M = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        return sp.tril(M, -1).tocsr() + sp.identity(n, format="csr"), sp.triu(M, 0).tocsr(), perm
+
+
+@dataclass
+class ObjectPrecs:
+    """`precs` through nk_options: a built-in object (kind = "jacobi" | "ilu0" | "ilu0_natural") on the concrete Jacobian,
+    refactorised inside the solver for every new J — no callback into the host language. side = "left" as the reference's
+    tutorial precs (`(Pl, I)`), or "right"."""
+    kind: str = "ilu0"
+    side: str = "left"
+
+
+@dataclass
 class KrylovJL_GMRES:
     """LinearSolve.KrylovJL_GMRES stand-in executed by the device GMRES (protocol: SURVEY.md §8d)."""
     gmres_restart: int = 30
@@ -555,7 +661,10 @@ class KrylovJL_GMRES:
     sstep_basis: str = "auto"  # "auto" (Newton where the spectrum can be bounded) | "monomial" | "newton"
     abstol: Optional[float] = None   # None → the nonlinear tolerances are forwarded (FirstOrder/src/solve.jl:203)
     reltol: Optional[float] = None
-    precs: Optional[ChebyshevPrecs] = None
+    # `precs`: a callable precs(A, p::LinearSolveParameters) -> (Pl, Pr) as in the reference (re-evaluated for every new A;
+    # Pl / Pr: None (identity), a Preconditioner object, or a callable y = P⁻¹ x on device tensors), or one of the built-in
+    # descriptors ChebyshevPrecs / MultigridPrecs (right) / ObjectPrecs (either side)
+    precs: object = None
 
 
 @dataclass
@@ -760,10 +869,16 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
         o.linesearch = 1
         o.ls_c1, o.ls_rho_hi, o.ls_rho_lo = float(lsr.c_1), float(lsr.rho_hi), float(lsr.rho_lo)
         o.ls_order, o.ls_maxiters = int(lsr.order), int(lsr.maxiters)
-    if isinstance(getattr(ls, "precs", None), MultigridPrecs):
-        o.mg_nu, o.mg_coarse = int(ls.precs.nu), int(ls.precs.coarse_max)
-    elif getattr(ls, "precs", None) is not None:
-        o.cheb_degree, o.cheb_ratio = int(ls.precs.degree), float(ls.precs.ratio)
+    precs = getattr(ls, "precs", None)
+    if isinstance(precs, MultigridPrecs):
+        o.mg_nu, o.mg_coarse = int(precs.nu), int(precs.coarse_max)
+    elif isinstance(precs, ChebyshevPrecs):
+        o.cheb_degree, o.cheb_ratio = int(precs.degree), float(precs.ratio)
+    elif isinstance(precs, ObjectPrecs):
+        o.precond_kind = {"jacobi": 1, "ilu0_natural": 2, "ilu0": 3, "ilu0_multicolor": 3}[precs.kind]
+        o.precond_side = {"right": 0, "left": 1}[precs.side]
+    elif precs is not None and not callable(precs):
+        raise TypeError("KrylovJL_GMRES(precs=…): a callable precs(A, p) -> (Pl, Pr) or a built-in descriptor")
     o.jac_colored = int(bool(getattr(alg, "jac_colored", False)))
     fo = getattr(alg, "forcing", None)
     if fo is not None:
@@ -834,6 +949,7 @@ class FirstOrderCache:
         check(L.lib().nk_solver_init(prob.device_problem._h, p, ms, C.byref(self._opts), C.byref(h)))
         self._h = h
         self.n = prob.device_problem.n_local
+        self._install_precs_hook()
         M = getattr(alg, "mass_matrix", None)
         if M is None and isinstance(alg, PseudoTransient):   # resolve_ser_mass_matrix(::Nothing, prob): fall back to prob.f's
             M = getattr(getattr(prob, "f", None), "mass_matrix", None)
@@ -927,6 +1043,39 @@ class FirstOrderCache:
         check(L.lib().nk_solver_refresh_residual(self._h))
         return None
 
+    def _install_precs_hook(self):
+        """KrylovJL_GMRES(precs = callable): `precs(A, LinearSolveParameters(u, p)) -> (Pl, Pr)` is evaluated when the
+        linear cache is built and again for every new Jacobian (never by reinit!) — the protocol test/Core/
+        core_tests__item21.jl pins through its call counts. A = the concrete Jacobian (a CSRMatrix view of the solver's J),
+        or the StatefulJacobianOperator of the matrix-free path."""
+        ls = getattr(self.alg, "linsolve", None)
+        precs = getattr(ls, "precs", None)
+        if precs is None or isinstance(precs, (ChebyshevPrecs, MultigridPrecs, ObjectPrecs)) or not callable(precs):
+            return
+        n, prob = self.n, self.prob
+        self._precs_keep = []
+
+        def hook(user, gh, ah, uptr):
+            try:
+                u = _view(uptr, n)
+                if ah:
+                    A = CSRMatrix(C.c_void_p(ah), prob.ctx, owned=False)
+                else:
+                    A = StatefulJacobianOperator(JacobianOperator(prob), u)
+                out = precs(A, LinearSolveParameters(u, prob.p))
+                Pl, Pr = out if isinstance(out, tuple) else (out, None)
+                keep = []
+                _install_preconditioner(C.c_void_p(gh), "left", Pl, n, keep)
+                _install_preconditioner(C.c_void_p(gh), "right", Pr, n, keep)
+                self._precs_keep = keep      # (the previous pair may be released now: the GMRES object holds the new one)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._precs_fn = L.PRECS_FN(hook)
+        check(L.lib().nk_solver_set_precs(self._h, self._precs_fn, None))
+
     def solve(self) -> NonlinearSolution:
         r = C.c_int()
         check(L.lib().nk_solver_solve(self._h, C.byref(r)))
@@ -992,6 +1141,47 @@ def reinit_(cache, u0=None, p=None, **kw):  # reinit!(cache, u0; p[, retain_best
 
 
 # ------------------------------------------------------------------------------------------- linear solve seam
+def _install_preconditioner(gh, side: str, M, n: int, keep: list):
+    """Pl or Pr on the nk_gmres `gh`: None / identity removes that side; a Preconditioner object goes in as it is (no host
+    round trip per application); any other callable y = P⁻¹ x on device tensors becomes a device callback."""
+    lib = L.lib()
+    left = side == "left"
+    if M is None or M is IDENTITY:
+        check(lib.nk_gmres_set_preconditioner(gh, 1 if left else 0, None))
+        return
+    if isinstance(M, Preconditioner):
+        keep.append(M)
+        check(lib.nk_gmres_set_preconditioner(gh, 1 if left else 0, M._h))
+        return
+    if not callable(M):
+        raise TypeError(f"a preconditioner must be None, a Preconditioner or a callable, not {type(M)}")
+
+    def cb(user, x, y, stream):
+        try:
+            _view(y, n).copy_(M(_view(x, n)))
+            return 0
+        except Exception:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+    fn = L.MATVEC_FN(cb)
+    keep.append(fn)
+    check((lib.nk_gmres_set_left_preconditioner if left else lib.nk_gmres_set_right_preconditioner)(gh, fn, None))
+
+
+class _Identity:
+    """LinearAlgebra.I as a preconditioner (what the reference's DummyPreconditioners returns)"""
+
+    def __call__(self, x):
+        return x
+
+    def __repr__(self):
+        return "I"
+
+
+IDENTITY = _Identity()
+
+
 class GMRES:
     """nk_gmres: the LinearCache analogue NonlinearSolveBase drives (A, b, u, reltol; solve!)."""
 
@@ -1054,6 +1244,17 @@ class GMRES:
         fn = L.MATVEC_FN(cb)
         self._keep.append(fn)
         check(L.lib().nk_gmres_set_right_preconditioner(self._h, fn, None))
+        return self
+
+    def set_left_preconditioner(self, M):
+        """Pl of `precs(A, p) -> (Pl, Pr)`: GMRES runs on Pl⁻¹ A Pr⁻¹ and stops on the preconditioned residual. M: None, a
+        Preconditioner object, or a callable y = Pl⁻¹ x on device tensors."""
+        _install_preconditioner(self._h, "left", M, self.n, self._keep)
+        return self
+
+    def set_preconditioner(self, P, side: str = "left"):
+        """a Preconditioner object (JacobiPreconditioner / ILU0Preconditioner) on either side"""
+        _install_preconditioner(self._h, side, P, self.n, self._keep)
         return self
 
     def set_chebyshev_preconditioner(self, degree: int, lambda_min: float = 0.0, lambda_max: float = 0.0,

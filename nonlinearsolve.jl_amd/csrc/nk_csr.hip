@@ -441,7 +441,49 @@ extern "C" int nk_csr_create_from_csc_rows(nk_ctx *ctx, int64_t n, int64_t nnz, 
       gc[pos] = c;  // columns ascend within each row because c ascends
       if (nzval) vals[pos] = nzval[k];
     }
-  return nk_csr_create_local(ctx, nrows_local, n, row_begin, rp, gc, nzval ? vals.data() : nullptr, out);
+  NK_TRY(nk_csr_create_local(ctx, nrows_local, n, row_begin, rp, gc, nzval ? vals.data() : nullptr, out));
+  // remember where every local entry sits in the CSC value array: nk_csr_set_values_csc then refreshes the values of a new
+  // Jacobian with one gather instead of a new conversion (entries keep their order inside a row through nk_csr_create_local)
+  {
+    nk_csr *A = *out;
+    std::vector<int32_t> src(nloc > 0 ? nloc : 1, 0);
+    std::vector<int32_t> fill2(rp.begin(), rp.end() - 1);
+    for (int64_t c = 0; c < n; ++c)
+      for (int64_t k = cp[c]; k < cp[c + 1]; ++k)
+        if (rv[k] >= lo && rv[k] < hi) src[fill2[rv[k] - lo]++] = (int32_t)k;
+    A->csc_nnz = nnz;
+    if (nnz < (1ll << 31) && nk_dev_alloc(&A->d_csc_src, (size_t)nloc + 1) == NK_OK && nloc > 0)
+      NK_HIP(hipMemcpy(A->d_csc_src, src.data(), nloc * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return NK_OK;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_gather_values(int64_t nnz, const int32_t *__restrict__ src,
+                                                            const double *__restrict__ in, double *__restrict__ val) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t e = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; e < nnz; e += stride) val[e] = in[src[e]];
+}
+// New values for a matrix that came in through nk_csr_create_from_csc(_rows), in the CSC order of that call (Julia:
+// `nonzeros(A)` of a SparseMatrixCSC with the same pattern — what `f.jac(J, u, p)` refreshes every Newton step).
+extern "C" int nk_csr_set_values_csc(nk_csr *A, const double *nzval, int64_t nnz_csc, int memspace) {
+  NK_REQUIRE(A && nzval, "NULL argument");
+  NK_REQUIRE(A->d_csc_src != nullptr, "the matrix was not created from CSC arrays");
+  NK_REQUIRE(nnz_csc == A->csc_nnz, "nzval has %lld entries, the CSC pattern had %lld", (long long)nnz_csc, (long long)A->csc_nnz);
+  nk_ctx *ctx = A->ctx;
+  NK_HIP(hipSetDevice(ctx->device));
+  const double *d_in = nzval;
+  if (memspace != NK_DEVICE) {
+    if (!A->d_csc_stage) NK_TRY(nk_dev_alloc(&A->d_csc_stage, (size_t)A->csc_nnz + 1));
+    NK_HIP(hipMemcpyAsync(A->d_csc_stage, nzval, A->csc_nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    d_in = A->d_csc_stage;
+  }
+  if (A->nnz > 0) {
+    NK_LAUNCH(ctx, k_gather_values, dim3(nk_grid_for(A->nnz, NK_BLOCK * 4, 4096)), dim3(NK_BLOCK), A->nnz,
+              (const int32_t *)A->d_csc_src, d_in, A->d_val);
+    NK_HIP(hipGetLastError());
+  }
+  if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(ctx->stream));   // the caller's host array may change after the call
+  A->t_values_stale = true;
+  return NK_OK;
 }
 // the same with the library's default partition (contiguous row ranges, nk_partition_range with granule 1)
 extern "C" int nk_csr_create_from_csc(nk_ctx *ctx, int64_t n, int64_t nnz, int index_bits, int index_base,
@@ -463,6 +505,8 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_ones);
   hipFree(A->d_diagpos);
   hipFree(A->d_gersh);
+  hipFree(A->d_csc_src);
+  hipFree(A->d_csc_stage);
   hipFree(A->d_tz);
   hipFree(A->d_trecv);
   hipFree(A->d_role);

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "nk_internal.h"
+#include <cmath>
 
 // ----------------------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -135,6 +136,38 @@ extern "C" int nk_device_copy(nk_ctx *ctx, void *dst, const void *src, int64_t b
   const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   NK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, k, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+// ---- BLAS-1 on resident vectors (DEVICE pointers of local length n): what a host language needs to move a library-owned
+// buffer through the reference's step! without a GPU array package of its own — `@bb axpy!(α, δu, u)`, `copyto!`, the norms of
+// the termination test (lib/NonlinearSolveFirstOrder/src/solve.jl:403,438,460). Reductions are all-reduced over the ranks and
+// returned on the host (blocking).
+extern "C" int nk_vec_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
+  NK_REQUIRE(ctx && (n == 0 || (x && y)) && n >= 0, "bad argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  return n ? nk_blas_axpby(ctx, n, a, x, b, y) : NK_OK;
+}
+extern "C" int nk_vec_fill(nk_ctx *ctx, int64_t n, double a, double *y) {
+  NK_REQUIRE(ctx && (n == 0 || y) && n >= 0, "bad argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  return n ? nk_blas_fill(ctx, n, a, y) : NK_OK;
+}
+extern "C" int nk_vec_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *result) {
+  NK_REQUIRE(ctx && x && y && result && n >= 0, "bad argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  NK_TRY(nk_blas_dot(ctx, n, x, y, ctx->d_scal));
+  return nk_scalars_to_host(ctx, ctx->d_scal, 1, result);
+}
+extern "C" int nk_vec_norm(nk_ctx *ctx, int64_t n, const double *x, int which /* 2: ‖x‖₂, 0: ‖x‖∞ */, double *result) {
+  NK_REQUIRE(ctx && x && result && n >= 0 && (which == 0 || which == 2), "bad argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  if (which == 0) {
+    NK_TRY(nk_blas_norm_inf(ctx, n, x, ctx->d_scal));
+    return nk_scalars_to_host(ctx, ctx->d_scal, 1, result);
+  }
+  NK_TRY(nk_blas_sumsq(ctx, n, x, ctx->d_scal));
+  NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 1, result));
+  *result = sqrt(*result);
   return NK_OK;
 }
 extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {

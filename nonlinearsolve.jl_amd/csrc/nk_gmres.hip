@@ -721,7 +721,7 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
 }
 extern "C" int nk_gmres_destroy(nk_gmres *G) {
   if (!G) return NK_OK;
-  hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r);
+  hipFree(G->V); hipFree(G->w); hipFree(G->z); hipFree(G->r); hipFree(G->lz);
   hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb); hipFree(G->d_tprev); hipFree(G->d_red);
   nk_mg_destroy(G->mg);
   nk_ss_destroy(G->ss);
@@ -800,8 +800,48 @@ extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, v
   G->prec = fn;
   G->prec_user = user;
   G->prec_host = false;
+  G->rprec_obj = nullptr;
   G->prec_kind = fn ? 1 : 0;
   if (fn && !G->z) NK_TRY(nk_dev_alloc(&G->z, (size_t)G->ldv));
+  return NK_OK;
+}
+
+extern "C" int nk_gmres_set_left_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  NK_REQUIRE(G, "NULL argument");
+  NK_HIP(hipSetDevice(G->ctx->device));
+  G->lprec = fn;
+  G->lprec_user = user;
+  G->lprec_host = false;
+  G->lprec_obj = nullptr;
+  G->lprec_kind = fn ? 1 : 0;
+  if (fn && !G->lz) NK_TRY(nk_dev_alloc(&G->lz, (size_t)G->ldv));
+  return NK_OK;
+}
+extern "C" int nk_gmres_set_left_preconditioner_host(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  NK_TRY(nk_gmres_set_left_preconditioner(G, fn, user));
+  G->lprec_host = fn != nullptr;
+  return NK_OK;
+}
+// a built-in preconditioner object (nk_precond.hip) on either side; NULL removes what sits on that side
+extern "C" int nk_gmres_set_preconditioner(nk_gmres *G, int side, nk_precond *P) {
+  NK_REQUIRE(G, "NULL argument");
+  NK_REQUIRE(side == NK_SIDE_LEFT || side == NK_SIDE_RIGHT, "bad preconditioner side %d", side);
+  NK_REQUIRE(!P || nk_precond_size(P) == G->n, "preconditioner size %lld != GMRES size %lld",
+             (long long)(P ? nk_precond_size(P) : 0), (long long)G->n);
+  NK_HIP(hipSetDevice(G->ctx->device));
+  if (side == NK_SIDE_LEFT) {
+    G->lprec = nullptr;
+    G->lprec_host = false;
+    G->lprec_obj = P;
+    G->lprec_kind = P ? 4 : 0;
+    if (P && !G->lz) NK_TRY(nk_dev_alloc(&G->lz, (size_t)G->ldv));
+  } else {
+    G->prec = nullptr;
+    G->prec_host = false;
+    G->rprec_obj = P;
+    G->prec_kind = P ? 4 : 0;
+    if (P && !G->z) NK_TRY(nk_dev_alloc(&G->z, (size_t)G->ldv));
+  }
   return NK_OK;
 }
 
@@ -1072,7 +1112,7 @@ extern "C" int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, do
   NK_REQUIRE(G, "NULL argument");
   NK_REQUIRE(G->op_kind != 0, "set the operator before the preconditioner");
   if (degree <= 0) {
-    G->prec_kind = G->prec ? 1 : 0;
+    G->prec_kind = G->rprec_obj ? 4 : (G->prec ? 1 : 0);
     return NK_OK;
   }
   NK_HIP(hipSetDevice(G->ctx->device));
@@ -1109,7 +1149,7 @@ extern "C" int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P,
                                                      int coarse_max) {
   NK_REQUIRE(G, "NULL argument");
   if (nu <= 0 || !P) {  // remove
-    G->prec_kind = G->prec ? 1 : 0;
+    G->prec_kind = G->rprec_obj ? 4 : (G->prec ? 1 : 0);
     return NK_OK;
   }
   NK_REQUIRE(u, "NULL argument");
@@ -1130,9 +1170,16 @@ extern "C" int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P,
   return NK_OK;
 }
 
+static int lprec_apply(nk_gmres *G, const double *src, double *dst, const int *d_skip) {
+  if (G->lprec_kind == 4) return nk_precond_apply_dev(G->lprec_obj, src, dst, d_skip);
+  if (G->lprec_host) return host_callback(G, G->lprec, G->lprec_user, src, dst, "left preconditioner");
+  if (G->lprec(G->lprec_user, src, dst, (void *)G->ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "left preconditioner failed");
+  return NK_OK;
+}
 static int prec_apply(nk_gmres *G, const double *src, double *dst, const int *d_skip) {
   if (G->prec_kind == 2) return cheb_apply(G, src, dst, d_skip);
   if (G->prec_kind == 3) return nk_mg_apply(G->mg, src, dst, d_skip);
+  if (G->prec_kind == 4) return nk_precond_apply_dev(G->rprec_obj, src, dst, d_skip);
   if (G->prec_host) return host_callback(G, G->prec, G->prec_user, src, dst, "preconditioner");
   if (G->prec(G->prec_user, src, dst, (void *)G->ctx->stream) != 0) NK_FAIL(NK_E_CALLBACK, "preconditioner failed");
   return NK_OK;
@@ -1174,7 +1221,7 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
   }
   if (d_theta) {
     // the built-in kernels subtract θ·x[row] in their row epilogue (the diagonal gather they have just made)
-    const bool epi_ok = !G->prec_kind && !G->normal && G->shift == 0.0 &&
+    const bool epi_ok = !G->prec_kind && !G->lprec_kind && !G->normal && G->shift == 0.0 &&
                         (G->op_kind == 1 || (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D));
     if (epi_ok) {
       nk_spmv_epi ep;
@@ -1183,11 +1230,17 @@ static int op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_sk
       if (G->op_kind == 1) return nk_csr_spmv_dev(G->A, src, d_y, d_skip, oscale, &ep);
       return nk_problem_jvp_dev(G->P, G->d_u, src, d_y, d_skip, oscale, &ep);
     }
-    NK_TRY(op_apply_raw(G, src, d_y, d_skip, oscale));
+    double *dst = G->lprec_kind ? G->lz : d_y;
+    NK_TRY(op_apply_raw(G, src, dst, d_skip, oscale));
+    if (G->lprec_kind) NK_TRY(lprec_apply(G, G->lz, d_y, d_skip));
     const int grid = nk_grid_for(G->n, NK_BLOCK * 4, 2048);
     NK_LAUNCH(ctx, k_sub_theta, dim3(grid), dim3(NK_BLOCK), G->n, d_theta, src0, d_y, oscale, d_skip);
     NK_HIP(hipGetLastError());
     return NK_OK;
+  }
+  if (G->lprec_kind) {   // Pl⁻¹ (A Pr⁻¹ x): the raw product into a work vector, the left solve into the basis column
+    NK_TRY(op_apply_raw(G, src, G->lz, d_skip, oscale));
+    return lprec_apply(G, G->lz, d_y, d_skip);
   }
   return op_apply_raw(G, src, d_y, d_skip, oscale);
 }
@@ -1211,7 +1264,7 @@ int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, bool *have) {
     *have = true;
     return NK_OK;
   }
-  if (G->prec_kind || G->normal || G->shift != 0.0) return NK_OK;
+  if (G->prec_kind || G->lprec_kind || G->normal || G->shift != 0.0) return NK_OK;
   if (G->op_kind == 1 && G->A->nblocks > 0) {
     NK_TRY(nk_csr_gershgorin_dev(G->A, d_out2));
   } else if (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D && G->n > 0) {
@@ -1243,7 +1296,8 @@ extern "C" int nk_gmres_set_sstep_basis(nk_gmres *G, int basis) {
 // eligible: built-in linear operators (they take the un-normalised pending column as it is) and no callback preconditioner
 static bool dcgs2r_eligible(const nk_gmres *G) {
   const bool op_ok = (G->op_kind == 1) || (G->op_kind == 2 && G->P->kind != NK_PROBLEM_USER);
-  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2 || G->prec_kind == 3) && G->m <= NK_MAX_NV - 2 &&
+  return op_ok && (G->prec_kind == 0 || G->prec_kind == 2 || G->prec_kind == 3 || G->prec_kind == 4) &&
+         (G->lprec_kind == 0 || G->lprec_kind == 4) && G->m <= NK_MAX_NV - 2 &&
          G->n <= (int64_t)NK_MAX_ROW_TILES * NK_BLOCK * 8;
 }
 static bool use_dcgs2r(const nk_gmres *G) {
@@ -1467,7 +1521,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   {
     static const bool want_graph = getenv("NK_GMRES_GRAPH") && atoi(getenv("NK_GMRES_GRAPH")) != 0;
     if (want_graph && fixed_iters > 0 && fixed_iters <= m && !use_x0 && nk_ctx_is_single(ctx) && !ctx->prof.on &&
-        !G->prec_kind && !G->normal && G->op_kind != 3 && use_dcgs2r(G) && !G->graph_broken) {
+        !G->prec_kind && !G->lprec_kind && !G->normal && G->op_kind != 3 && use_dcgs2r(G) && !G->graph_broken) {
       bool used = false;
       NK_TRY(gmres_solve_graph(G, d_b, d_x, atol, rtol, fixed_iters, info, &used));
       if (used) return NK_OK;
@@ -1483,14 +1537,29 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   // r0 = b − A x0, written straight into column 0 of the basis (un-normalised); zero initial guess: b → column 0 and
   // ‖b‖² in one pass, and the first solution update WRITES x = V y (no memset of x)
   bool have_ss = false, x_is_zero = false;
+  // with a left preconditioner every residual that enters the basis is Pl⁻¹(b − A x): the norms of the solve are preconditioned
+  auto residual_to_v0 = [&]() -> int {   // column 0 ← Pl⁻¹ (b − A x), x in the original space
+    NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
+    if (G->lprec_kind) {
+      NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->r));
+      return lprec_apply(G, G->r, G->V, nullptr);
+    }
+    return nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V);
+  };
+  auto rhs_to_v0 = [&]() -> int {        // column 0 ← Pl⁻¹ b and its squared norm (zero initial guess)
+    if (G->lprec_kind) {
+      NK_TRY(lprec_apply(G, d_b, G->V, nullptr));
+      return nk_blas_sumsq(ctx, n, G->V, G->d_ss);
+    }
+    return nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss);
+  };
   if (!use_x0) {
-    NK_TRY(nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss));
+    NK_TRY(rhs_to_v0());
     have_ss = true;
     x_is_zero = true;
   } else {
     if (G->prec_kind) NK_FAIL(NK_E_UNSUPPORTED, "use_x0 with a right preconditioner is not supported");
-    NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
-    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
+    NK_TRY(residual_to_v0());
   }
   int first = 1;
   int total_iters = 0;
@@ -1604,20 +1673,18 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
       inf.failed = 0;
       first = 2;
       if (x_is_zero_before) {
-        NK_TRY(nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss));
+        NK_TRY(rhs_to_v0());
         have_ss = true;
         x_is_zero = true;
       } else {
-        NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
-        NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
+        NK_TRY(residual_to_v0());
       }
       continue;
     }
     if (c.failed || c.converged || total_iters >= cap || steps == 0) break;
     inf.restarts++;
-    // restart: r = b − A x into column 0
-    NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));  // A x directly: x lives in the original space
-    NK_TRY(nk_blas_lincomb(ctx, n, 1.0, d_b, -1.0, G->r, G->V));
+    // restart: r = Pl⁻¹(b − A x) into column 0 (A x directly: x lives in the original space)
+    NK_TRY(residual_to_v0());
   }
   inf.iters = total_iters;
   ctx->stats.gmres_iters += total_iters;

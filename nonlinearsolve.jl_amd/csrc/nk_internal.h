@@ -249,6 +249,9 @@ struct nk_csr {
   double *d_ones = nullptr;   // a vector of ones (nk_csr_colsumsq_dev)
   int32_t *d_diagpos = nullptr;  // position of every row's diagonal entry in val (nk_csr_add_to_diagonal_dev)
   double *d_gersh = nullptr;     // per-row-block Gershgorin bounds (nk_csr_gershgorin_dev)
+  int32_t *d_csc_src = nullptr;  // created from CSC arrays: index of every local entry in that call's nzval
+  double *d_csc_stage = nullptr; // staging for host nzval (nk_csr_set_values_csc)
+  int64_t csc_nnz = 0;
   bool t_values_stale = true;
   double *d_tz = nullptr, *d_trecv = nullptr;  // T·x (nrows + n_halo) and what the peers sent back (n_send)
   // column colouring of the pattern (structurally orthogonal columns), built on first use by coloured assembly
@@ -418,7 +421,15 @@ struct nk_gmres {
   const double *d_shift_w = nullptr;  // m (borrowed, local rows); NULL = identity
   bool fn_host = false, prec_host = false;  // the callbacks take HOST pointers: vectors are staged through h_stage
   double *h_stage = nullptr;                // pinned, 2 n doubles
-  int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle
+  int prec_kind = 0;  // 0 none, 1 callback, 2 built-in Chebyshev polynomial, 3 built-in multigrid V-cycle, 4 nk_precond object
+  struct nk_precond *rprec_obj = nullptr;
+  // left preconditioner: Arnoldi runs on Pl⁻¹ A Pr⁻¹, residual norms are the preconditioned ones
+  int lprec_kind = 0; // 0 none, 1 callback, 4 nk_precond object
+  nk_matvec_fn lprec = nullptr;
+  void *lprec_user = nullptr;
+  bool lprec_host = false;
+  struct nk_precond *lprec_obj = nullptr;
+  double *lz = nullptr;  // A Pr⁻¹ x before Pl⁻¹
   struct nk_mg *mg = nullptr;
   int cheb_degree = 0;
   double cheb_lmin = 0, cheb_lmax = 0;
@@ -443,6 +454,10 @@ struct nk_gmres {
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info);
+
+// preconditioner objects (nk_precond.hip)
+int nk_precond_apply_dev(struct nk_precond *P, const double *d_x, double *d_y, const int *d_skip);
+int64_t nk_precond_size(struct nk_precond *P);
 
 // s-step Arnoldi (nk_sstep.hip)
 // y = scale·(A M⁻¹ x − θ x); d_scale / d_theta (device scalars) may be nullptr (= 1 / 0)

@@ -65,6 +65,10 @@ struct nk_solver {
   double pt_ainv = 0, pt_res = 0, pt_applied = 0;
   double *pt_mass = nullptr;  // diagonal of the mass matrix M (NULL: identity): the damping is α⁻¹ M
   std::vector<nk_trace_entry> trace;
+  // preconditioning behind the `precs` hook: a built-in object on the concrete J (nk_options.precond_kind) and / or a callback
+  nk_precond *prec_obj = nullptr;
+  nk_precs_fn precs = nullptr;
+  void *precs_user = nullptr;
 };
 
 // u_new = u + sign·du (out of place: the old iterate stays intact in its buffer) ; partial Σ (u_new − u_old)²  (the stall
@@ -222,6 +226,8 @@ extern "C" int nk_options_default(nk_options *o) {
   o->pt_alpha_initial = 1e-3;  // PseudoTransient() (pseudo_transient.jl:38)
   o->gmres_sstep = 0;
   o->gmres_sstep_basis = NK_SS_BASIS_AUTO;
+  o->precond_kind = 0;
+  o->precond_side = NK_SIDE_LEFT;
   return NK_OK;
 }
 
@@ -617,6 +623,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
                     S->lm_a, S->lm_vcache, S->lm_rhs, S->pt_mass};
   for (double *b : bufs) hipFree(b);
   nk_gmres_destroy(S->G);
+  nk_precond_destroy(S->prec_obj);
   nk_bandlu_destroy(S->B);
   nk_normal_plan_destroy(S->nplan);
   if (S->own_J) nk_csr_destroy(S->J);
@@ -1600,6 +1607,35 @@ static int refresh_residual(nk_solver *S) {
   return check_and_update(S, 0.0);
 }
 
+// precs(A, p) for the Jacobian just refreshed: the built-in object is refactorised (created on first use) and installed on
+// its side; the caller's hook then installs whatever it returns
+static int refresh_precs(nk_solver *S) {
+  if (S->o.precond_kind) {
+    if (!S->prec_obj) {
+      NK_REQUIRE(concrete(S) && S->J, "nk_options.precond_kind needs a concrete-J linsolve");
+      if (S->o.precond_kind == 1) NK_TRY(nk_precond_create_jacobi(S->J, &S->prec_obj));
+      else NK_TRY(nk_precond_create_ilu0(S->J, S->o.precond_kind == 3 ? NK_ILU_MULTICOLOR : NK_ILU_NATURAL, &S->prec_obj));
+    } else {
+      NK_TRY(nk_precond_update(S->prec_obj));
+    }
+    NK_TRY(nk_gmres_set_preconditioner(S->G, S->o.precond_side == NK_SIDE_RIGHT ? NK_SIDE_RIGHT : NK_SIDE_LEFT, S->prec_obj));
+  }
+  if (S->precs && S->precs(S->precs_user, S->G, concrete(S) ? S->J : nullptr, S->u) != 0)
+    NK_FAIL(NK_E_CALLBACK, "precs callback failed");
+  return NK_OK;
+}
+extern "C" int nk_solver_set_precs(nk_solver *S, nk_precs_fn fn, void *user) {
+  NK_REQUIRE(S, "NULL argument");
+  NK_REQUIRE(!fn || S->G, "precs needs a Krylov linsolve");
+  S->precs = fn;
+  S->precs_user = user;
+  // LinearSolve evaluates precs when the linear cache is built [EXT]: once now, for the operator the cache was built with
+  if (fn && fn(user, S->G, concrete(S) ? S->J : nullptr, S->u) != 0) NK_FAIL(NK_E_CALLBACK, "precs callback failed");
+  return NK_OK;
+}
+extern "C" nk_gmres *nk_solver_gmres(nk_solver *S) { return S ? S->G : nullptr; }
+extern "C" nk_csr *nk_solver_jacobian(nk_solver *S) { return S ? S->J : nullptr; }
+
 // ---- InternalAPI.step! (FirstOrder/src/solve.jl:325-465)
 static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 true*/, bool evaluate_residual) {
   nk_ctx *ctx = S->ctx;
@@ -1619,6 +1655,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       NK_TRY(nk_gmres_set_chebyshev_preconditioner(S->G, S->o.cheb_degree, 0.0, 0.0, S->o.cheb_ratio));
     if (!direct(S) && S->o.mg_nu > 0)
       NK_TRY(nk_gmres_set_multigrid_preconditioner(S->G, S->P, S->u, NK_DEVICE, S->o.mg_nu, S->o.mg_coarse));
+    if (!direct(S)) NK_TRY(refresh_precs(S));
   } else {
     new_jacobian = false;
   }

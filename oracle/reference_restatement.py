@@ -298,11 +298,21 @@ def gershgorin_lambda(J) -> float:
 
 
 def gmres(matvec: Callable, b, x0=None, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0,
-          ortho="mgs", allreduce: Optional[Callable] = None, M: Optional[Callable] = None):
+          ortho="mgs", allreduce: Optional[Callable] = None, M: Optional[Callable] = None, Ml: Optional[Callable] = None):
     """Restarted GMRES(m) with MGS Arnoldi and Givens rotations, right-hand side b, zero (or given)
     initial guess.  Stop when the recurrence residual ≤ atol + rtol*‖r0‖ or after itmax Arnoldi steps.
     fixed_iters>0: run exactly that many Arnoldi steps (tolerances ignored).
     `allreduce(x)` (optional) sums partial inner products across ranks (distributed oracle, tests only)."""
+    if Ml is not None:
+        # left preconditioning — the Pl of `precs(A, p) -> (Pl, Pr)` (lib/NonlinearSolveBase/src/linear_solve.jl:195-199;
+        # docs/src/tutorials/large_systems.md:257,284-287 return `(Pl, I)`): GMRES on Pl⁻¹ A (Pr⁻¹) with the right-hand side
+        # Pl⁻¹ b; the Arnoldi residual, the stopping test ‖Pl⁻¹(b − A x)‖ ≤ atol + rtol·‖Pl⁻¹ r₀‖ and the reported norms are the
+        # PRECONDITIONED ones, as in Krylov.jl's gmres [EXT]. Composes with a right preconditioner M.
+        op = (lambda v: Ml(matvec(M(v)))) if M is not None else (lambda v: Ml(matvec(v)))
+        if x0 is not None and M is not None:
+            raise NotImplementedError("x0 with a right preconditioner")
+        z, info = gmres(op, Ml(np.asarray(b, dtype=np.float64)), x0, atol, rtol, restart, itmax, fixed_iters, ortho, allreduce)
+        return (M(z) if M is not None else z), info
     if M is not None:  # right preconditioning: solve (A M⁻¹) z = b, x = M⁻¹ z  (zero initial guess only)
         assert x0 is None
         z, info = gmres(lambda v: matvec(M(v)), b, None, atol, rtol, restart, itmax, fixed_iters, ortho, allreduce)
@@ -551,6 +561,98 @@ def gershgorin_interval(A):
     d = A.diagonal()
     rad = np.asarray(abs(A).sum(axis=1)).ravel() - np.abs(d)
     return float(np.min(d - rad)), float(np.max(d + rad))
+
+
+# ----------------------------------------------------------------------------- preconditioner objects (csrc/nk_precond.hip)
+def multicolor_permutation(A):
+    """Greedy distance-1 colouring of the symmetrised pattern in natural order (smallest free colour), rows then ordered by
+    (colour, original index): perm[permuted row] = original row, and the number of colours — csrc/nk_precond.hip::multicolor_perm."""
+    A = sp.csr_matrix(A)
+    S = (A + A.T).tocsr()
+    n = A.shape[0]
+    color = -np.ones(n, dtype=np.int64)
+    nc = 0
+    for i in range(n):
+        nb = S.indices[S.indptr[i]:S.indptr[i + 1]]
+        used = set(int(color[j]) for j in nb if j != i and color[j] >= 0)
+        c = 0
+        while c in used:
+            c += 1
+        color[i] = c
+        nc = max(nc, c + 1)
+    return np.argsort(color, kind="stable").astype(np.int64), nc
+
+
+def ilu0(A, perm=None):
+    """ILU(0): A[perm][:, perm] ≈ L U on the pattern of A — no fill, no pivoting, L unit lower — by the sequential IKJ
+    algorithm (Saad, Iterative Methods, Alg. 10.4), each row's updates in ascending column order: the operations of
+    csrc/nk_precond.hip::ilu_factor_row in the same order. Returns (L, U) as CSR. The defining property — (L U)_ij = A_ij on
+    the pattern — pins it independently of any implementation."""
+    A = sp.csr_matrix(A, dtype=np.float64)
+    if perm is not None:
+        A = A[perm][:, perm].tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    rp, ci, lu = A.indptr, A.indices, A.data.copy()
+    dg = np.empty(n, dtype=np.int64)
+    for i in range(n):
+        row = ci[rp[i]:rp[i + 1]]
+        d = np.searchsorted(row, i)
+        if d >= row.size or row[d] != i:
+            raise ArithmeticError(f"ILU(0): row {i} has no stored diagonal entry")
+        dg[i] = rp[i] + d
+    for i in range(n):
+        for p in range(rp[i], dg[i]):
+            k = ci[p]
+            piv = lu[dg[k]]
+            l = lu[p] / piv
+            lu[p] = l
+            q, s_ = p + 1, dg[k] + 1
+            qe, se = rp[i + 1], rp[k + 1]
+            while q < qe and s_ < se:
+                if ci[q] == ci[s_]:
+                    lu[q] -= l * lu[s_]
+                    q += 1
+                    s_ += 1
+                elif ci[q] < ci[s_]:
+                    q += 1
+                else:
+                    s_ += 1
+        if lu[dg[i]] == 0.0 or not math.isfinite(lu[dg[i]]):
+            raise ArithmeticError("ILU(0): zero or non-finite pivot")
+    Mx = sp.csr_matrix((lu, ci.copy(), rp.copy()), shape=(n, n))
+    return (sp.tril(Mx, -1) + sp.identity(n)).tocsr(), sp.triu(Mx, 0).tocsr()
+
+
+def ilu0_preconditioner(A, ordering="multicolor"):
+    """x ↦ M⁻¹ x with M = Pᵀ L U P, the ILU(0) of A in the chosen ordering ("natural" | "multicolor") — what
+    nls.ILU0Preconditioner applies on the device (two sparse triangular solves in the permuted numbering)."""
+    import scipy.sparse.linalg as spla
+    perm = multicolor_permutation(A)[0] if ordering == "multicolor" else None
+    Lf, Uf = ilu0(A, perm)
+    Lc, Uc = sp.csr_matrix(Lf), sp.csr_matrix(Uf)
+
+    def apply(x):
+        x = np.asarray(x, dtype=np.float64)
+        xb = x if perm is None else x[perm]
+        z = spla.spsolve_triangular(Uc, spla.spsolve_triangular(Lc, xb, lower=True, unit_diagonal=True), lower=False)
+        if perm is None:
+            return z
+        out = np.empty_like(z)
+        out[perm] = z
+        return out
+    return apply
+
+
+def jacobi_preconditioner(A):
+    d = sp.csr_matrix(A).diagonal()
+    return lambda x: np.asarray(x, dtype=np.float64) / d
+
+
+@dataclass
+class LinearSolveParameters:   # lib/NonlinearSolveBase/src/linear_solve.jl:1-4
+    u: object
+    p: object
 
 
 def sstep_block_width(want):
@@ -839,6 +941,14 @@ class KrylovJL_GMRES:
 
 
 @dataclass
+class ObjectPrecs:
+    """precs through a built-in object on the concrete J (nk_options.precond_kind): kind = "jacobi" | "ilu0" (multicolour) |
+    "ilu0_natural"; side = "left" (the reference's tutorial precs return `(Pl, I)`) or "right"."""
+    kind: str = "ilu0"
+    side: str = "left"
+
+
+@dataclass
 class DirectSolve:
     """linsolve = nothing on a sparse J: LinearSolve default sparse LU (KLU/UMFPACK [EXT]) → SuperLU."""
 
@@ -1112,6 +1222,13 @@ class FirstOrderCache:
             self.J = prob.jac(self.u)  # jacobian.jl:104-118 (evaluated once "to get the type")
             self.stats.njacs += 1
         self.du = np.zeros_like(self.u)  # descent/newton.jl:34-36
+        kr0 = getattr(self, "krylov", None)
+        if kr0 is not None and callable(kr0.precs) and not getattr(self, "_precs_inited", False):
+            # construct_linear_solver → init(linprob, linsolve; …) (linear_solve.jl:74-118): LinearSolve evaluates
+            # `precs(A, p)` when it builds the cache [EXT]; p = LinearSolveParameters(u, prob.p) (:1-4). reinit! does not
+            # rebuild the cache (FirstOrder/src/solve.jl:108-133 → reinit!(lincache; p) only swaps p): no call there.
+            self._precs_inited = True
+            kr0.precs(self.J if self.concrete else self._operator_view(self.u), LinearSolveParameters(self.u, getattr(prob, "p", None)))
         self.trace = []
         self.eta = float("nan")
         forcing = getattr(self.alg, "forcing", None)
@@ -1277,6 +1394,10 @@ class FirstOrderCache:
         self.last_step_accepted = False
         self.tr_du_cache = np.zeros_like(u)
 
+    def _operator_view(self, u):
+        """what `precs` receives as A on the matrix-free path: the StatefulJacobianOperator (a callable v ↦ J(u) v here)"""
+        return lambda v: self.prob.jvp(v, u)
+
     # -- operators (jacobian.jl:237-262, SciMLJacobianOperators.jl:238-243)
     def _apply_J(self, v, u):
         self.stats_op = getattr(self, "stats_op", 0) + 1
@@ -1301,10 +1422,24 @@ class FirstOrderCache:
         if self.krylov is not None:
             kr = self.krylov
             u_now = self.u
-            M = None
+            M, Ml = None, None
             if isinstance(kr.precs, MultigridPrecs):  # precs(A, p) re-evaluated at the current u
                 MG = BrusselatorMultigrid if isinstance(self.prob, Brusselator2D) else BratuMultigrid
                 M = MG(self.prob, u_now, kr.precs.nu, kr.precs.coarse_max)
+            elif isinstance(kr.precs, ObjectPrecs):   # a built-in object refactorised for the current concrete J
+                assert self.concrete, "ObjectPrecs needs a concrete J"
+                Pm = jacobi_preconditioner(self.J) if kr.precs.kind == "jacobi" else \
+                    ilu0_preconditioner(self.J, "natural" if kr.precs.kind == "ilu0_natural" else "multicolor")
+                M, Ml = (Pm, None) if kr.precs.side == "right" else (None, Pm)
+            elif callable(kr.precs):
+                # the `precs(A, p) -> (Pl, Pr)` hook: a new A marks the LinearSolve cache fresh (ext/NonlinearSolveBase
+                # LinearSolveExt.jl:64-111 update_A! → set_lincache_A!), and LinearSolve re-evaluates precs for a fresh A
+                # [EXT] — once per linear solve with a new Jacobian; pinned by test/Core/core_tests__item21.jl:10-37.
+                if new_jacobian or getattr(self, "_precs_pair", None) is None:
+                    out = kr.precs(self.J if self.concrete else self._operator_view(u_now),
+                                   LinearSolveParameters(u_now, getattr(self.prob, "p", None)))
+                    self._precs_pair = out if isinstance(out, tuple) else (out, None)
+                Ml, M = self._precs_pair      # wrap_preconditioners (linear_solve.jl:195-199): nothing → identity
             elif kr.precs is not None:  # precs(A, p) re-evaluated for the current J (concrete J: Gershgorin bound)
                 assert self.concrete, "the oracle's Chebyshev precs needs a concrete J (Gershgorin bound)"
                 lmax = gershgorin_lambda(self.J)
@@ -1320,7 +1455,7 @@ class FirstOrderCache:
                 # the device's choice (nk_ss_prepare): Newton basis where it can bound the spectrum — Gershgorin discs of a
                 # concrete J, the closed form of the Bratu stencil — and no preconditioner / normal form / shift is in the way
                 interval = None
-                if M is None and not shift and not isinstance(self.alg, GaussNewton):
+                if M is None and Ml is None and not shift and not isinstance(self.alg, GaussNewton):
                     if self.concrete:
                         interval = gershgorin_interval(self.J)
                     elif isinstance(self.prob, Bratu2D):
@@ -1329,7 +1464,7 @@ class FirstOrderCache:
                 ortho = ("sstep", ortho[1], "newton", interval) if interval is not None else ("sstep", ortho[1])
             x, info = gmres(op, rhs, None, atol=self.lin_abstol,
                             rtol=self.lin_reltol, restart=kr.gmres_restart, itmax=kr.maxiters,
-                            fixed_iters=kr.fixed_iters, ortho=ortho, M=M)
+                            fixed_iters=kr.fixed_iters, ortho=ortho, M=M, Ml=Ml)
             self.stats.gmres_iters += info.iters
             self.last_gmres = info
             if info.failed:

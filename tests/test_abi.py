@@ -179,3 +179,84 @@ def test_julia_binding_matches_the_abi():
     info = info[:info.index("\nend")]
     assert re.findall(r"([a-z0-9_]+)::(Int32|Float64)", info) == [(n, "Int32" if t is C.c_int32 else "Float64")
                                                                    for n, t in _lib.GmresInfo._fields_]
+
+
+def _header_prototypes(header):
+    """name → (return type, [parameter types]) of every function declared in include/mi355x_nk.h (comments stripped)."""
+    txt = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*(?:\s*\*+)?)\s*\b(nk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        if "typedef" in txt[max(0, m.start() - 12):m.start()]:
+            continue
+        params = [] if args in ("", "void") else [a.strip() for a in _split_top(args)]
+        protos[name] = (ret.strip(), params)
+    return protos
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _c_class(decl):
+    """coarse class of a C parameter declaration: pointer / int32 / int64 / double / fnptr"""
+    d = decl.strip()
+    if "(*" in d or re.search(r"\bnk_[a-z_]+_fn\b", d):
+        return "ptr"
+    if "*" in d or "[" in d:
+        return "ptr"
+    base = re.sub(r"\b(const|unsigned)\b", "", d).split()
+    ty = base[0] if base else ""
+    return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64", "uint64_t": "i64"}.get(ty, ty)
+
+
+_JL_CLASS = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Float64": "f64", "Cstring": "ptr", "Cdouble": "f64"}
+
+
+def _jl_class(ty):
+    ty = ty.strip()
+    return "ptr" if ty.startswith("Ptr{") or ty.startswith("Ref{") else _JL_CLASS.get(ty, ty)
+
+
+def test_every_julia_ccall_matches_the_header_signature():
+    """Every `@ccall libnk.f(arg::T, …)::R` of the Julia binding AND of its AMDGPU extension against the prototype in
+    include/mi355x_nk.h: the function exists, takes that many arguments, and every argument / the return value has the matching
+    C type class (pointer, 32-bit int, 64-bit int, double). Julia is not installed here: this is what stands between the
+    binding and an ABI drift."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "mi355x_nk.h")).read()
+    protos = _header_prototypes(header)
+    assert len(protos) >= 110 and "nk_gmres_solve" in protos and "nk_precond_create_ilu0" in protos
+    ncalls = 0
+    for rel in ("julia/MI355XNewtonKrylov.jl", "julia/ext/MI355XNewtonKrylovAMDGPUExt.jl"):
+        jl = open(os.path.join(root, rel)).read()
+        for m in re.finditer(r"@ccall\s*\(?\s*libnk\.(nk_[a-z0-9_]+)\(", jl):
+            name = m.group(1)
+            i, depth = m.end(), 1
+            while depth:                      # the balanced argument list
+                depth += jl[i] == "("
+                depth -= jl[i] == ")"
+                i += 1
+            args = _split_top(jl[m.end():i - 1])
+            ret = re.match(r"\s*::\s*([A-Za-z0-9_{}]+)", jl[i:])
+            assert name in protos, f"{rel}: {name} is not declared in the header"
+            cret, cparams = protos[name]
+            assert len(args) == len(cparams), f"{rel}: {name} called with {len(args)} arguments, the header declares {len(cparams)}: {cparams}"
+            for a, cp in zip(args, cparams):
+                jt = a.rsplit("::", 1)[1] if "::" in a else None
+                assert jt is not None, f"{rel}: {name}: argument `{a.strip()}` carries no type"
+                assert _jl_class(jt) == _c_class(cp), f"{rel}: {name}: `{a.strip()}` vs `{cp}`"
+            assert ret is not None and _jl_class(ret.group(1)) == _c_class(cret + " x"), f"{rel}: {name}: return type"
+            ncalls += 1
+    assert ncalls >= 50

