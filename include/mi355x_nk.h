@@ -314,14 +314,11 @@ int nk_ctx_set_halo_overlap(nk_ctx *ctx, int on);
 int nk_device_alloc(nk_ctx *ctx, int64_t bytes, void **out);
 int nk_device_free(nk_ctx *ctx, void *ptr);
 int nk_device_copy(nk_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind);
-/* BLAS-1 on resident vectors (DEVICE pointers, local length n) for host languages whose resident vector type is a library
- * buffer (Julia's DeviceVector): y = a x + b y; y = a; x·y; ‖x‖₂ (which = 2) / ‖x‖∞ (which = 0). Reductions are all-reduced
- * over the ranks and returned on the host (blocking) — what `@bb axpy!`, `copyto!` and the termination norms of the
- * reference's step! need (lib/NonlinearSolveFirstOrder/src/solve.jl:403,438,460). */
+/* In-place updates of resident vectors (DEVICE pointers, local length n) for host languages whose resident vector type is a
+ * library buffer (Julia's DeviceVector): y = a x + b y and y = a — with nk_dot / nk_nrm2 / nk_norm_inf / nk_axpy below, what
+ * `@bb axpy!`, `copyto!` and the termination norms of the reference's step! need (FirstOrder/src/solve.jl:403,438,460). */
 int nk_vec_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y);
 int nk_vec_fill(nk_ctx *ctx, int64_t n, double a, double *y);
-int nk_vec_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *result);
-int nk_vec_norm(nk_ctx *ctx, int64_t n, const double *x, int which, double *result);
 
 /* Per-kernel-family timing (bench.py's roofline numbers). Off by default; when on, every launch of a profiled
  * family is issued with hipExtLaunchKernelGGL start/stop events, i.e. the kernel's own begin/end device

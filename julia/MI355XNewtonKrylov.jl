@@ -73,7 +73,7 @@ function Base.copyto!(h::Array{Float64}, d::DeviceVector)
 end
 DeviceVector(h::Array{Float64}; kw...) = copyto!(DeviceVector(length(h); kw...), vec(h))
 Base.Array(d::DeviceVector) = copyto!(Vector{Float64}(undef, d.n), d)
-# The in-place vector algebra of the reference's step! on resident data, through nk_vec_* (include/mi355x_nk.h):
+# The in-place vector algebra of the reference's step! on resident data, through nk_vec_axpby / nk_vec_fill / nk_dot / nk_nrm2 / nk_norm_inf (include/mi355x_nk.h):
 # `copyto!`, `axpy!` / `axpby!` (`@bb axpy!(α, δu, u)`, FirstOrder/src/solve.jl:403,438,460), `rmul!`, `fill!`, `dot`, `norm`,
 # `similar`. General broadcast expressions (`@. u = u + α * δu`) need a GPU array package: with AMDGPU.jl loaded, use
 # ROCArrays (ext/MI355XNewtonKrylovAMDGPUExt.jl) — they go through the same ABI with memspace = NK_DEVICE.
@@ -98,13 +98,17 @@ function Base.fill!(y::DeviceVector, a::Real)
 end
 function LinearAlgebra.dot(x::DeviceVector, y::DeviceVector)
     r = Ref(0.0)
-    nkcheck(@ccall libnk.nk_vec_dot(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, y.ptr::Ptr{Float64}, r::Ptr{Float64})::Cint)
+    nkcheck(@ccall libnk.nk_dot(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, y.ptr::Ptr{Float64}, r::Ptr{Float64})::Cint)
     return r[]
 end
 function LinearAlgebra.norm(x::DeviceVector, p::Real = 2)
     (p == 2 || p == Inf) || error("DeviceVector: norm(x, 2) and norm(x, Inf)")
     r = Ref(0.0)
-    nkcheck(@ccall libnk.nk_vec_norm(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, (p == 2 ? 2 : 0)::Cint, r::Ptr{Float64})::Cint)
+    if p == 2
+        nkcheck(@ccall libnk.nk_nrm2(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, r::Ptr{Float64})::Cint)
+    else
+        nkcheck(@ccall libnk.nk_norm_inf(x.ctx.ptr::Ptr{Cvoid}, x.n::Int64, x.ptr::Ptr{Float64}, r::Ptr{Float64})::Cint)
+    end
     return r[]
 end
 

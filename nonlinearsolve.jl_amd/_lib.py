@@ -124,8 +124,6 @@ SIGNATURES = {
     "nk_ctx_comm_peer_disable": (_I, [_P]),
     "nk_vec_axpby": (_I, [_P, _L, _D, _P, _D, _P]),
     "nk_vec_fill": (_I, [_P, _L, _D, _P]),
-    "nk_vec_dot": (_I, [_P, _L, _P, _P, C.POINTER(_D)]),
-    "nk_vec_norm": (_I, [_P, _L, _P, _I, C.POINTER(_D)]),
     "nk_partition_range": (_I, [_L, _L, _I, _I, C.POINTER(_L), C.POINTER(_L)]),
     "nk_csr_create": (_I, [_P, _L, _L, _L, _L, _I, _I, _P, _P, _P, _I, _PP]),
     "nk_csr_create_from_csc": (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _PP]),

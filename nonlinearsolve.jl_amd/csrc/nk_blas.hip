@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_sum_allreduce(const double 
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&mine->ar_flag[par][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < pv.seq) {
       if (__hip_atomic_load(&mine->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) break;
-      if (wall_clock64() - t0 > 500000000ull) { atomicAdd((unsigned long long *)&mine->err, 1ull); break; }
+      if (wall_clock64() - t0 > nk_peer_timeout(&mine->err)) { atomicAdd((unsigned long long *)&mine->err, 1ull); break; }
       __builtin_amdgcn_s_sleep(2);
     }
   }

@@ -139,9 +139,8 @@ extern "C" int nk_device_copy(nk_ctx *ctx, void *dst, const void *src, int64_t b
   return NK_OK;
 }
 // ---- BLAS-1 on resident vectors (DEVICE pointers of local length n): what a host language needs to move a library-owned
-// buffer through the reference's step! without a GPU array package of its own — `@bb axpy!(α, δu, u)`, `copyto!`, the norms of
-// the termination test (lib/NonlinearSolveFirstOrder/src/solve.jl:403,438,460). Reductions are all-reduced over the ranks and
-// returned on the host (blocking).
+// buffer through the reference's step! without a GPU array package of its own — `@bb axpy!(α, δu, u)`, `copyto!`
+// (lib/NonlinearSolveFirstOrder/src/solve.jl:403,438,460); the reductions are nk_dot / nk_nrm2 / nk_norm_inf (nk_blas.hip).
 extern "C" int nk_vec_axpby(nk_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
   NK_REQUIRE(ctx && (n == 0 || (x && y)) && n >= 0, "bad argument");
   NK_HIP(hipSetDevice(ctx->device));
@@ -151,24 +150,6 @@ extern "C" int nk_vec_fill(nk_ctx *ctx, int64_t n, double a, double *y) {
   NK_REQUIRE(ctx && (n == 0 || y) && n >= 0, "bad argument");
   NK_HIP(hipSetDevice(ctx->device));
   return n ? nk_blas_fill(ctx, n, a, y) : NK_OK;
-}
-extern "C" int nk_vec_dot(nk_ctx *ctx, int64_t n, const double *x, const double *y, double *result) {
-  NK_REQUIRE(ctx && x && y && result && n >= 0, "bad argument");
-  NK_HIP(hipSetDevice(ctx->device));
-  NK_TRY(nk_blas_dot(ctx, n, x, y, ctx->d_scal));
-  return nk_scalars_to_host(ctx, ctx->d_scal, 1, result);
-}
-extern "C" int nk_vec_norm(nk_ctx *ctx, int64_t n, const double *x, int which /* 2: ‖x‖₂, 0: ‖x‖∞ */, double *result) {
-  NK_REQUIRE(ctx && x && result && n >= 0 && (which == 0 || which == 2), "bad argument");
-  NK_HIP(hipSetDevice(ctx->device));
-  if (which == 0) {
-    NK_TRY(nk_blas_norm_inf(ctx, n, x, ctx->d_scal));
-    return nk_scalars_to_host(ctx, ctx->d_scal, 1, result);
-  }
-  NK_TRY(nk_blas_sumsq(ctx, n, x, ctx->d_scal));
-  NK_TRY(nk_scalars_to_host(ctx, ctx->d_scal, 1, result));
-  *result = sqrt(*result);
-  return NK_OK;
 }
 extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {
   NK_REQUIRE(ctx, "ctx is NULL");
@@ -257,14 +238,13 @@ extern "C" int nk_partition_range(int64_t n_global, int64_t granule, int nranks,
 
 
 // ----------------------------------------------------------------------------- peer-mapped arenas (hipIpc over xGMI)
-constexpr unsigned long long NK_PEER_TIMEOUT_TICKS = 500000000ull;  // 5 s of the 100 MHz wall clock
 
 __device__ __forceinline__ bool peer_wait_ge(const uint64_t *flag, uint64_t seq, uint64_t *err) {
   const unsigned long long t0 = wall_clock64();
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
     // once a few waits have timed out the communicator is broken: fail fast instead of spending 5 s on every collective
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) return false;
-    if (wall_clock64() - t0 > NK_PEER_TIMEOUT_TICKS) {  // never hang the GPU: count the time-out and go on
+    if (wall_clock64() - t0 > nk_peer_timeout(err)) {  // never hang the GPU: count the time-out and go on
       atomicAdd((unsigned long long *)err, 1ull);
       return false;
     }
@@ -366,6 +346,12 @@ extern "C" int nk_ctx_comm_peer_handle(nk_ctx *ctx, int64_t arena_bytes, char ha
   }
   pr.arena = (char *)a;
   NK_HIP(hipMemset(pr.arena, 0, NK_PEER_HDR_BYTES));
+  {  // the bound of every device-side wait (a rank stalled by a host callback, a JIT, a first kernel load): NK_PEER_TIMEOUT_MS
+    const char *e = getenv("NK_PEER_TIMEOUT_MS");
+    const double ms = e ? atof(e) : 5000.0;
+    const uint64_t ticks = (uint64_t)((ms > 1.0 ? ms : 1.0) * 1e5);
+    NK_HIP(hipMemcpy(pr.arena + offsetof(nk_peer_hdr, timeout_ticks), &ticks, sizeof(ticks), hipMemcpyHostToDevice));
+  }
   NK_HIP(hipDeviceSynchronize());
   pr.bump = NK_PEER_HDR_BYTES;
   hipIpcMemHandle_t h;

@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
 // of k²/2 on one lane.
 __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, const double *__restrict__ R,
                                                    const double *__restrict__ g, double *__restrict__ y, int m,
-                                                   nk_gmres_pub *pub, uint64_t seq) {
+                                                   nk_gmres_pub *pub, uint64_t seq, const uint64_t *peer_err) {
   constexpr int LK = NK_MAX_NV + 1;  // odd stride: the column reads below are conflict-free
   __shared__ double sR[NK_MAX_NV * LK];
   const int k = ctl->k, failed = ctl->failed;
@@ -629,6 +629,9 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
     pub->failed = failed;
     pub->rnorm0 = ctl->rnorm0;
     pub->rnorm = ctl->rnorm;
+    // time-outs of the peer-mapped collectives so far (a rank stalled for longer than the bound: its contribution to an
+    // all-reduce or a halo was missing) — the host fails the solve with NK_E_COMM instead of returning numbers built on them
+    pub->pad = peer_err ? (int)(__hip_atomic_load(peer_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fffffff) : 0;
     __threadfence_system();
     __hip_atomic_store(&pub->end_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1478,7 +1481,8 @@ static int gmres_solve_graph(nk_gmres *G, const double *d_b, double *d_x, double
       NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol, 1, 1, G->d_g, G->d_s, m, G->h_pub_dev, seq);
       for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step_1r(G, k, k == steps - 1));
       NK_TRY(arnoldi_flush_1r(G, steps));
-      NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq);
+      NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
+              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr));
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, true));
       return NK_OK;
     };
@@ -1632,7 +1636,8 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     }
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns); the back-substitution also publishes the control
     // block's outcome to the host
-    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq);
+    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
+              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr));
     if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
     } else {
@@ -1643,6 +1648,9 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     }
     x_is_zero = false;
     NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(&pub->end_seq, __ATOMIC_ACQUIRE) == seq; }, "the end of a GMRES cycle"));
+    if (pub->pad != 0)
+      NK_FAIL(NK_E_COMM, "%d peer-mapped collective(s) timed out (a rank stalled beyond NK_PEER_TIMEOUT_MS or died): the "
+                         "reductions / halos of this solve are not valid", (int)pub->pad);
     nk_gmres_ctl c;
     memset(&c, 0, sizeof(c));
     c.k = pub->k;

@@ -79,7 +79,8 @@ constexpr size_t NK_PEER_HDR_BYTES = 262144;             // flags + all-reduce s
 struct nk_peer_hdr {
   uint64_t ar_flag[2][NK_PEER_MAX_RANKS];
   uint64_t err;
-  uint64_t pad[31];
+  uint64_t timeout_ticks;   // bound of every device-side wait, in ticks of the 100 MHz wall clock (NK_PEER_TIMEOUT_MS; default 5 s)
+  uint64_t pad[30];
   double ar_data[2][NK_PEER_MAX_RANKS][NK_PEER_AR_MAX];
 };
 static_assert(sizeof(nk_peer_hdr) <= NK_PEER_HDR_BYTES, "peer arena header too large");
@@ -107,6 +108,11 @@ struct nk_peer_ar_view {
   unsigned int *ticket;
 };
 nk_peer_ar_view nk_peer_ar_next(nk_ctx *ctx, int count);
+// bound of a device-side wait: the word behind the arena's error counter (err[1]); 5 s if the arena predates it
+__device__ __forceinline__ unsigned long long nk_peer_timeout(const uint64_t *err) {
+  const unsigned long long t = err[1];
+  return t ? t : 500000000ull;
+}
 uint64_t *nk_peer_err_ptr(nk_ctx *ctx);  // the arena's time-out counter (device pointer)  // claims the next sequence number if the fast path applies
 
 struct nk_ctx {

@@ -212,6 +212,36 @@ def _worker(rank, world, port, q, transport="torch"):
             assert solss.retcode == "Success" == R.RETCODE_NAMES[refss.retcode] and solss.stats.nsteps == refss.stats.nsteps
             assert np.max(np.abs(solss.u.cpu().numpy() - refss.u[bl:el])) <= 1e-8
         note("bratu_sstep", solss.u.cpu().numpy())
+        # the library default (Newton basis, 15 columns per block): the bounds of the spectrum — Gershgorin discs of the local
+        # rows / the stencil's closed form — are all-reduced (max) over the ranks before the shifts are formed on every rank
+        for cj in (None, True):
+            sold = nls.solve(nls.NonlinearProblem(Plm, u0=torch.zeros(el - bl, dtype=torch.float64, device=dev)),
+                             nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(**kl_), concrete_jac=cj), abstol=1e-9, maxiters=50)
+            assert sold.retcode == "Success" and sold.stats.nsteps == refss.stats.nsteps
+            assert np.max(np.abs(sold.u.cpu().numpy() - refss.u[bl:el])) <= 1e-8
+        note("bratu_sstep_newton15", sold.u.cpu().numpy())
+        # ---------------- ILU(0) / Jacobi objects on a row-partitioned matrix: the factorisation of the rank's LOCAL square block
+        # (halo columns dropped — block-Jacobi ILU(0) across ranks, no communication in the apply), as Pl of the distributed
+        # GMRES, against the oracle's GMRES with the block-diagonal preconditioner assembled from the same row ranges
+        import scipy.sparse as sp_
+        Ag = sp_.csr_matrix(pb.jac(u))
+        rng_all = [nls.partition_range(ns * ns, ns, world, r_) for r_ in range(world)]
+        blocks = [R.ilu0_preconditioner(Ag[b_:e_, b_:e_].tocsr(), "natural") for b_, e_ in rng_all]
+
+        def Mblock(x_):
+            return np.concatenate([blk(x_[b_:e_]) for blk, (b_, e_) in zip(blocks, rng_all)])
+        Milu = nls.ILU0Preconditioner(J, ordering="natural")
+        xt = rng.standard_normal(pb.n)
+        assert np.max(np.abs(Milu.apply(torch.tensor(xt[b:e], device=dev)).cpu().numpy() - Mblock(xt)[b:e])) <= 1e-12 * np.max(np.abs(Mblock(xt)))
+        xlo, ilo = R.gmres(lambda z: Ag @ z, rhs, rtol=1e-9, restart=30, itmax=3000, ortho="cgs2", Ml=Mblock)
+        for ortho in ("sstep", "dcgs2"):
+            Gl = nls.GMRES(e - b, restart=30, ortho=ortho).set_operator(J).set_preconditioner(Milu, side="left")
+            xl_, gl_ = Gl.solve(torch.tensor(rhs[b:e], device=dev), reltol=1e-9, maxiters=3000)
+            xlg = nls.dist.gather_vector(xl_, pb.n, b)
+            assert gl_["converged"] and abs(gl_["iters"] - ilo.iters) <= 6 and ilo.iters < iref.iters / 2
+            assert np.linalg.norm(xlg - xlo) <= 1e-6 * np.linalg.norm(xlo)
+            assert abs(gl_["rnorm0"] - np.linalg.norm(Mblock(rhs))) <= 1e-9 * gl_["rnorm0"]    # the preconditioned norm, all-reduced
+        note("gmres_left_ilu0", xlg)
 
         # ---------------- the Brusselator V-cycle on two ranks: every level split by lines (slab boundaries stay even, the
         # transfers use the problem's own one-line periodic halo), coarsest level gathered and solved redundantly — one
@@ -424,6 +454,61 @@ def test_two_ranks_on_one_gpu_peer_comm():
     _DIGESTS["peer"] = _run_two_ranks("peer")
     if "torch" in _DIGESTS:
         assert _DIGESTS["peer"] == _DIGESTS["torch"]
+
+
+def _timeout_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NK_PEER_TIMEOUT_MS="300")
+    import time
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nonlinearsolve_jl_amd as nls
+        torch.cuda.set_device(0)
+        ctx = nls.Context(device=0)
+        nls.set_default_context(ctx)
+        assert nls.dist.init_comm(ctx, "peer") == "peer+torch"
+        dev = torch.device("cuda:0")
+        P = nls.Bratu2D(24)
+        nl = P.n_local
+        J = P.jac_csr()
+        P.jac_values(torch.zeros(nl, dtype=torch.float64, device=dev), J)
+        G = nls.GMRES(nl, restart=10).set_operator(J)
+        b = torch.ones(nl, dtype=torch.float64, device=dev)
+        x, gi = G.solve(b, fixed_iters=10)                    # both ranks in step: fine
+        assert ctx.comm_peer_status()[1] == 0
+        dist.barrier()
+        if rank == 1:
+            time.sleep(2.5)                                   # a stalled rank: far beyond the 0.3 s bound
+        msg = "no error"
+        try:
+            G.solve(b, fixed_iters=10)
+        except nls.NKError as ex:
+            msg = str(ex)
+        # the rank that waited saw the time-out and its solve FAILED with NK_E_COMM instead of returning numbers built on a
+        # missing contribution (round 2: counted, ignored, Success)
+        q.put((rank, msg, ctx.comm_peer_status()[1]))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), -1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_stalled_rank_fails_the_solve_instead_of_corrupting_it():
+    """Peer-mapped collectives bound every device-side wait (NK_PEER_TIMEOUT_MS); a time-out is counted in the arena AND
+    surfaces at the next host synchronisation point of the solve as NK_E_COMM (k_backsolve publishes the counter)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=200) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+    assert "timed out" in res[0][1] and res[0][2] > 0, res
 
 
 def _rccl_worker(q):

@@ -294,7 +294,9 @@ def test_linsolve_seam_c_caller_matches_oracle(tmp_path):
     ref = R.solve(R.Bratu2D(ns, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2()),
                   abstol=1e-8, maxiters=50)
     lines = {l.split(":")[0]: l for l in out.stdout.splitlines() if "steps=" in l}
-    assert set(lines) == {"fn", "jvp", "csr"}, out.stdout
+    assert set(lines) == {"fn", "jvp", "csr", "precs"}, out.stdout   # precs: Pl = device ILU(0), re-evaluated for every new A
+    it = {k: int(v.split("gmres_iters=")[1].split()[0]) for k, v in lines.items()}
+    assert it["precs"] < it["csr"] / 2                               # the left preconditioner did precondition
     for name, line in lines.items():
         steps = int(line.split("steps=")[1].split()[0])
         assert abs(steps - ref.stats.nsteps) <= 1 and "failed=0" in line, line
