@@ -181,3 +181,82 @@ def test_c5_brusselator512_trust_region_vs_direct_solve_oracle(nls, dev):
         f = COr.brusselator_residual(N, 3.4, 1.0, 10.0, 1.0 / (N - 1), u)
         assert np.max(np.abs(f)) <= 1e-7
         assert sol.stats.njacs == sol.stats.nsteps + 1 or sol.stats.njacs >= 1
+
+
+# ----------------------------------------------------------------------------- config C4 at its full size (4096², 16.8 M unknowns)
+@pytest.mark.parametrize("ortho", ["sstep", "dcgs2"])
+def test_c4_fixed_work_newton_vs_c_oracle_at_full_size(nls, dev, ortho):
+    """C4 at 4096² on one GPU, the headline protocol (assembled CSR, 30 Arnoldi steps per Newton step), four Newton steps: ‖F‖∞
+    after every step (rtol 1e-6) and the iterate (1e-9) of the C oracle's restatement of the SAME arithmetic — the s-step form
+    with the Newton basis (15 columns per block: the library default) and delayed CGS2."""
+    import torch
+    ns, nst = 4096, 4
+    n = ns * ns
+    kw = {} if ortho == "sstep" else dict(ortho="dcgs2")
+    cache = nls.init(nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(n, dtype=torch.float64, device=dev)),
+                     nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30, **kw), concrete_jac=True),
+                     abstol=1e-300, maxiters=100, store_trace=True)
+    for _ in range(nst):
+        cache.step()
+    fn = np.array([t["fnorm_inf"] for t in cache.trace])
+    u = cache.u.cpu().numpy()
+    cache.close()
+    if ortho == "sstep":
+        uC, fnC, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), nst, use_csr=True, m=30, s=15, basis="newton")
+    else:
+        uC, fnC, _ = CO.bratu_newton_fast(ns, 6.0, 0.0, np.zeros(n), nst, use_csr=True, m=30)
+    assert np.allclose(fn, fnC, rtol=1e-6), (fn, fnC)
+    assert np.max(np.abs(u - uC)) <= 1e-9
+    assert np.all(np.diff(fn) < 0)                                     # monotone descent of the fixed-work protocol
+
+
+def test_c4_multigrid_solve_counts_and_residual_at_full_size(nls, dev):
+    """The solve BASELINE.md quotes for 4096² — NewtonRaphson + Eisenstat–Walker + GMRES(30) with the geometric V-cycle behind
+    `precs`: 3 Newton steps / 3 Krylov iterations. At 2048² the whole solve against the NumPy oracle's BratuMultigrid (steps,
+    iterations, iterate); at 4096², where the SciPy hierarchy would take minutes and ≈ 8 GB, the mesh-independent counts and the
+    residual of the returned iterate evaluated by the C oracle's own kernel (a size-independent property: ‖F(u)‖∞ ≤ abstol)."""
+    import torch
+    from oracle import reference_restatement as R
+    outs = {}
+    for ns in (2048, 4096):
+        n = ns * ns
+        alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=nls.MultigridPrecs(2, 31)),
+                                forcing=nls.EisenstatWalkerForcing2())
+        sol = nls.solve(nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(n, dtype=torch.float64, device=dev)), alg,
+                        abstol=1e-8, maxiters=50)
+        assert sol.retcode == "Success"
+        u = sol.u.cpu().numpy()
+        assert np.max(np.abs(CO.bratu_residual(ns, 6.0, 0.0, u))) <= 1e-8          # the oracle's residual of the device's root
+        outs[ns] = (sol.stats.nsteps, sol.stats.gmres_iters, u)
+    assert outs[4096][0] == 3 and outs[4096][1] <= 4 and outs[2048][0] == outs[4096][0]   # mesh-independent
+    ref = R.solve(R.Bratu2D(2048, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(gmres_restart=30, maxiters=300,
+                                                                                     precs=R.MultigridPrecs(2, 31), ortho="cgs2"),
+                                                          forcing=R.EisenstatWalkerForcing2()), abstol=1e-8, maxiters=50)
+    assert R.RETCODE_NAMES[ref.retcode] == "Success" and ref.stats.nsteps == outs[2048][0]
+    assert abs(ref.stats.gmres_iters - outs[2048][1]) <= 1
+    assert np.max(np.abs(outs[2048][2] - ref.u)) <= 5e-7
+    # the two grids discretise the same boundary-value problem: the maxima agree to O(h²)
+    assert abs(outs[4096][2].max() - outs[2048][2].max()) <= 1e-5
+
+
+def test_c4_two_ranks_through_the_bench_code_path(tmp_path):
+    """`bench.py --gpus 2 --workload c4` (two processes sharing this GPU, gloo rendezvous, peer-mapped arenas): the residual after
+    the same fixed-work steps equals the single-rank run's — the partitioned 4096² path end to end, as the driver launches it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--workload", "c4", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-ttt", "--no-weak", "--no-profile-pass"]
+    outs = {}
+    for g in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(g)] + common, env=env, capture_output=True,
+                           text=True, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[g] = json.loads(lines[-1])
+    a, b = outs[1]["check"]["fnorm_inf_after_timed_steps"], outs[2]["check"]["fnorm_inf_after_timed_steps"]
+    assert outs[2]["n_gpus"] == 2 and outs[2]["config"]["unknowns_global"] == 4096 * 4096
+    assert abs(a - b) <= 1e-9 * abs(a), (a, b)
+    assert outs[2]["check"]["allreduces"] > 0 and outs[2]["check"]["halo_exchanges"] > 0
