@@ -20,51 +20,80 @@ def main():
     # fastest (and report the STREAM triad measured with the count that is best for the triad)
     avail = CO.num_threads()
     cands = sorted({max(1, avail // 16), max(1, avail // 8), max(1, avail // 4), max(1, avail // 2), avail})
-    z0 = np.zeros(ns * ns)
-    best_t, best_dt, triad, scan = avail, float("inf"), 0.0, {}
+    n = ns * ns
+    nnz = 5 * n - 4 * ns
+    z0 = np.zeros(n)
+    use_csr = not matfree
+
+    def run(alg, k):
+        """k fixed-work Newton steps with one of the two Arnoldi processes the device has; returns the step loop's seconds"""
+        if alg == "dcgs2":
+            return CO.bratu_newton_fast(ns, 6.0, 0.0, z0, k, use_csr=use_csr, m=arnoldi)
+        return CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, z0, k, use_csr=use_csr, m=arnoldi, s=15, basis="newton")
+
+    # ---- thread scan with SUSTAINED samples (≈ 0.4 s each, not two steps: a container's CPU quota lets a burst of all threads
+    # run several times faster than the same threads can run for a second — round 2's two-step scan saw 194 steps/s where the
+    # 9 s sample then ran 42)
+    scan, triad = {}, 0.0
+    best_t, best_rate = avail, 0.0
+    per_scan = max(0.25, 0.03 * budget_s)
     for t in cands:
         CO.set_num_threads(t)
         triad = max(triad, CO.stream_triad(1 << 25, 2))
-        CO.bratu_newton_fast(ns, 6.0, 0.0, z0, 1, use_csr=not matfree, m=arnoldi)          # placement / warm-up
-        dt = min(CO.bratu_newton_fast(ns, 6.0, 0.0, z0, 2, use_csr=not matfree, m=arnoldi)[2] for _ in range(2)) / 2.0
-        scan[t] = round(1.0 / dt, 2)
-        if dt < 0.97 * best_dt:
-            best_t, best_dt = t, dt
+        t1 = run("dcgs2", 1)[2]                                   # placement / warm-up, and a first estimate
+        k = int(max(3, min(400, per_scan / max(t1, 1e-4))))
+        rate = k / run("dcgs2", k)[2]
+        scan[t] = round(rate, 2)
+        if rate > 1.03 * best_rate:
+            best_t, best_rate = t, rate
     CO.set_num_threads(best_t)
     cores = best_t
-    n = ns * ns
-    nnz = 5 * n - 4 * ns
     b_op = (12.0 * nnz + 4.0 * (n + 1) + 16.0 * n) if not matfree else 24.0 * n
-    # DCGS2-1R: at Arnoldi step k the dot sweep reads k+2 columns, the axpy sweep reads k+2 and writes 2; once per Newton
-    # step: x = V y, Jacobian values, update, residual
-    bytes_per_step = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(arnoldi)) + 8.0 * n * (arnoldi + 3) \
-        + 8.0 * nnz + 16.0 * n + 40.0 * n
+    # bytes of a fixed-work step. delayed CGS2: at Arnoldi step k the dot sweep reads k+2 columns, the axpy sweep reads k+2 and
+    # writes 2. s-step (blocks of 15 behind k = 1, 16 columns): three sweeps over k + 15 columns + two writes of 15 per block.
+    # Once per Newton step: x = V y, Jacobian values, update, residual
+    once = 8.0 * n * (arnoldi + 3) + 8.0 * nnz + 16.0 * n + 40.0 * n
+    bytes_per_step = {
+        "dcgs2": sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(arnoldi)) + once,
+        "sstep": arnoldi * b_op + sum(8.0 * n * (3 * (k + 15) + 2 * 15) for k in (1, 16)) + once}
     triad = max(triad, CO.stream_triad(1 << 26, 3))
     spmv = CO.spmv_rate(ns, 8)
-    z = np.zeros(n)
-    _, _, t1 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, 1, use_csr=not matfree, m=arnoldi)   # also places / warms
-    k = int(max(2, min(400, (0.6 * budget_s) / max(t1, 1e-4))))
-    _, fn, tk = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
-    if k / tk < 0.7 / best_dt:   # a shared host: the sample ran far below what the scan saw a moment ago — take a second one
-        _, fn2, tk2 = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k, use_csr=not matfree, m=arnoldi)
-        if tk2 < tk:
-            fn, tk = fn2, tk2
-    rate = k / tk
+    # ---- the samples: for each Arnoldi process 5 runs of ≥ 50 steps (budget permitting) at the chosen thread count; the
+    # median is the figure, min / max beside it
+    algs = ["dcgs2", "sstep"] if arnoldi == 30 else ["dcgs2"]
+    per_sample = 0.8 * budget_s / (5 * len(algs))
+    samples, fn_last = {}, None
+    for alg in algs:
+        t1 = run(alg, 1)[2]
+        k = int(max(5, min(400, per_sample / max(t1, 1e-4))))
+        k = max(k, 50) if 50 * t1 <= 2.5 * per_sample else k
+        rates = []
+        for _ in range(5):
+            _, fn, tk = run(alg, k)
+            rates.append(k / tk)
+            fn_last = float(fn[-1])
+        rates.sort()
+        samples[alg] = {"median": round(rates[2], 3), "min": round(rates[0], 3), "max": round(rates[-1], 3), "steps_per_sample": k,
+                        "effective_GBs": round(rates[2] * bytes_per_step[alg] * 1e-9, 1)}
+    best_alg = max(samples, key=lambda a: samples[a]["median"])
+    rate = samples[best_alg]["median"]
     CO.set_num_threads(1)
-    k1 = 1 if t1 * cores > 0.2 * budget_s else 2
-    _, _, ts = CO.bratu_newton_fast(ns, 6.0, 0.0, z, k1, use_csr=not matfree, m=arnoldi)
+    _, _, ts = run("dcgs2", 1)
     CO.set_num_threads(cores)
-    eff = rate * bytes_per_step * 1e-9
+    eff = samples[best_alg]["effective_GBs"]
     print(json.dumps({
-        "value": round(rate, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port",
-        "sample": f"{k} fixed-work Newton steps of the same Bratu {ns}x{ns} workload ({arnoldi} Arnoldi steps of delayed-CGS2 "
-                  f"GMRES each), oracle/nk_oracle.c::orc_bratu_newton_fast, OpenMP on {cores} of {avail} hardware threads "
-                  f"(count chosen by timing the workload itself; OMP_PLACES={os.environ.get('OMP_PLACES')}, "
-                  f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, first-touch placement), {tk:.1f} s",
-        "effective_GBs": round(eff, 1), "stream_triad_GBs": round(triad, 1),
+        "value": round(rate, 4), "unit": "newton_steps/s", "cores": cores, "kind": "port", "algorithm": best_alg,
+        "sample": f"median of 5 runs of {samples[best_alg]['steps_per_sample']} fixed-work Newton steps of the same Bratu {ns}x{ns} workload "
+                  f"({arnoldi} Arnoldi steps of GMRES each; the faster of the device's two Arnoldi processes restated in C: "
+                  f"delayed CGS2 = oracle/nk_oracle.c::orc_bratu_newton_fast, s-step with the Newton basis = …_sstep2), OpenMP on "
+                  f"{cores} of {avail} hardware threads (count chosen by sustained samples of the workload itself; "
+                  f"OMP_PLACES={os.environ.get('OMP_PLACES')}, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, first-touch placement)",
+        "samples": samples, "effective_GBs": eff, "stream_triad_GBs": round(triad, 1),
         "frac_of_stream_triad": round(eff / triad, 3) if triad > 0 else None,
         "spmv_GBs": round(spmv, 1), "spmv_frac_of_triad": round(spmv / triad, 3) if triad > 0 else None,
-        "single_thread_value": round(k1 / ts, 4), "thread_scan_steps_per_s": scan, "fnorm_inf_last": float(fn[-1]),
+        "single_thread_value": round(1.0 / ts, 4), "thread_scan_steps_per_s": scan,
+        "thread_scan_best": max(scan.values()), "sample_over_scan_best": round(samples["dcgs2"]["median"] / max(scan.values()), 3),
+        "fnorm_inf_last": fn_last,
         "note": "restatement of the reference algorithm (Julia is not installed on this box); a reported baseline, not the target"}))
 
 
