@@ -187,6 +187,7 @@ def main():
     ctx = nls.Context(device=dev_index)
     nls.set_default_context(ctx)
     comm = "none"
+    selfchecks = None
     if world > 1:
         # Transport of the library's small collectives, in order of preference: peer-mapped buffers over xGMI
         # (hipIpc; "peer"), the library's own RCCL communicator ("rccl"), torch.distributed callbacks ("torch").
@@ -200,6 +201,24 @@ def main():
                 print(f"[bench] transport {tr!r} failed on rank {rank}: {ex}", file=sys.stderr)
         if comm == "none":
             raise SystemExit("no communicator could be initialised")
+        # known-answer self-check of that transport before anything is timed (tools/multi_gpu_selfcheck.py): all-reduces, the
+        # halo exchange inside the SpMV, three Newton steps against one rank. A failing peer path is switched off on ALL ranks
+        # (the base transport then serves every collective) and checked again; a failing base transport ends the run.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from multi_gpu_selfcheck import selfcheck
+        selfchecks = []
+        try:
+            sc = selfcheck(nls, ctx, torch, dist, comm)
+        except Exception as ex:  # noqa: BLE001
+            sc = {"transport": comm, "ok": False, "error": str(ex)}
+        selfchecks.append(sc)
+        if not sc["ok"] and comm.startswith("peer+"):
+            ctx.comm_peer_disable()
+            comm = comm[len("peer+"):] + "(peer path failed its self-check)"
+            sc = selfcheck(nls, ctx, torch, dist, comm)
+            selfchecks.append(sc)
+        if not selfchecks[-1]["ok"]:
+            raise SystemExit(f"multi-GPU self-check failed on transport {comm!r}: {selfchecks}")
 
     def barrier():
         if world > 1:
@@ -404,7 +423,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
                        "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho if args.ortho != "sstep" else "sstep_%s_%s" % (args.sstep or "auto", args.sstep_basis),
-                       "parallelism": f"row-range x{world}", "comm": comm, "halo_overlap": overlap},
+                       "parallelism": f"row-range x{world}", "comm": comm, "comm_selfcheck": selfchecks, "halo_overlap": overlap},
             "roofline": roof, "roofline_step": roof_step, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
             # against the BEST figure the CPU leg produced (its sustained median or its thread scan, whichever is higher)
             "gpu_vs_cpu": round(steps_per_s / max(cpu["value"], cpu.get("thread_scan_best", 0.0)), 1) if cpu and "value" in cpu else None,

@@ -347,6 +347,10 @@ int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, const nk_comm_
 int nk_ctx_comm_peer_handle(nk_ctx *ctx, int64_t arena_bytes, char handle_out[NK_IPC_HANDLE_BYTES]);
 int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles);
 int nk_ctx_comm_peer_status(nk_ctx *ctx, int *enabled, int64_t *errors);
+/* the communicator's all-reduce on a DEVICE buffer, in place (op 0 = sum, 1 = max), through whatever transport the context
+ * holds (peer-mapped arenas up to 512 values, RCCL, callbacks); blocking. For self-checks of a multi-GPU set-up
+ * (tools/multi_gpu_selfcheck.py) and for host code that needs a global reduction of its own. */
+int nk_ctx_comm_allreduce(nk_ctx *ctx, double *buf, int count, int op);
 /* collective: a few all-reduces with known answers; if any rank sees a wrong value or a time-out the fast path is
  * switched off on every rank (*ok = 0) and the base transport serves all collectives */
 int nk_ctx_comm_peer_selftest(nk_ctx *ctx, int *ok);

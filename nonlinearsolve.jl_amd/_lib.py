@@ -122,6 +122,7 @@ SIGNATURES = {
     "nk_ctx_comm_peer_status": (_I, [_P, C.POINTER(_I), C.POINTER(_L)]),
     "nk_ctx_comm_peer_selftest": (_I, [_P, C.POINTER(_I)]),
     "nk_ctx_comm_peer_disable": (_I, [_P]),
+    "nk_ctx_comm_allreduce": (_I, [_P, _P, _I, _I]),
     "nk_vec_axpby": (_I, [_P, _L, _D, _P, _D, _P]),
     "nk_vec_fill": (_I, [_P, _L, _D, _P]),
     "nk_partition_range": (_I, [_L, _L, _I, _I, C.POINTER(_L), C.POINTER(_L)]),

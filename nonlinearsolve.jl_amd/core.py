@@ -139,6 +139,11 @@ class Context:
         check(L.lib().nk_ctx_comm_peer_status(self._h, C.byref(en), C.byref(err)))
         return bool(en.value), int(err.value)
 
+    def allreduce(self, x, op: str = "sum"):
+        """in-place all-reduce of a float64 device tensor over the ranks, through the context's transport; returns x"""
+        check(L.lib().nk_ctx_comm_allreduce(self._h, C.c_void_p(x.data_ptr()), int(x.numel()), {"sum": 0, "max": 1}[op]))
+        return x
+
     def comm_info(self):
         k, n, r = C.c_int(), C.c_int(), C.c_int()
         check(L.lib().nk_ctx_comm_info(self._h, C.byref(k), C.byref(n), C.byref(r)))

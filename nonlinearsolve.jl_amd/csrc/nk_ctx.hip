@@ -151,6 +151,15 @@ extern "C" int nk_vec_fill(nk_ctx *ctx, int64_t n, double a, double *y) {
   NK_HIP(hipSetDevice(ctx->device));
   return n ? nk_blas_fill(ctx, n, a, y) : NK_OK;
 }
+// the communicator's all-reduce on a DEVICE buffer (in place), through whatever transport the context holds — for self-checks
+// of a multi-GPU set-up (tools/multi_gpu_selfcheck.py) and for host-language code that needs a global reduction of its own
+extern "C" int nk_ctx_comm_allreduce(nk_ctx *ctx, double *buf, int count, int op) {
+  NK_REQUIRE(ctx && buf && count > 0 && (op == 0 || op == 1), "bad argument");
+  NK_HIP(hipSetDevice(ctx->device));
+  NK_TRY(nk_comm_allreduce(ctx, buf, count, op));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
 extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {
   NK_REQUIRE(ctx, "ctx is NULL");
   ctx->deterministic = d ? 1 : 0;

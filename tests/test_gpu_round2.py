@@ -303,7 +303,7 @@ def test_linsolve_seam_c_caller_matches_oracle(tmp_path):
         #  looser one for the true residual the nonlinear iteration watches: a few more, cheaper Newton steps to the same root)
         assert (abs(steps - ref.stats.nsteps) <= 1 if name != "precs" else steps <= ref.stats.nsteps + 6) and "failed=0" in line, line
         u = np.fromfile(str(tmp_path / f"u_{name}.bin"))
-        assert u.size == ns * ns and np.max(np.abs(u - ref.u)) <= 5e-7 * max(1.0, np.max(np.abs(ref.u))), name
+        assert u.size == ns * ns and np.max(np.abs(u - ref.u)) <= (5e-7 if name != "precs" else 2e-6) * max(1.0, np.max(np.abs(ref.u))), name
     assert int(lines["fn"].split("callback_applies=")[1]) > 0     # the device-pointer callback really carried the solve
 
 
