@@ -482,7 +482,7 @@ extern "C" int nk_csr_set_values_csc(nk_csr *A, const double *nzval, int64_t nnz
     NK_HIP(hipGetLastError());
   }
   if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(ctx->stream));   // the caller's host array may change after the call
-  A->t_values_stale = true;
+  A->t_values_stale = true; A->bounds_valid = false;
   return NK_OK;
 }
 // the same with the library's default partition (contiguous row ranges, nk_partition_range with granule 1)
@@ -505,6 +505,7 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_ones);
   hipFree(A->d_diagpos);
   hipFree(A->d_gersh);
+  hipFree(A->d_bounds);
   hipFree(A->d_csc_src);
   hipFree(A->d_csc_stage);
   hipFree(A->d_tz);
@@ -527,7 +528,7 @@ extern "C" int nk_csr_set_values(nk_csr *A, const double *vals, int memspace) {
   NK_HIP(hipMemcpyAsync(A->d_val, vals, A->nnz * sizeof(double),
                         memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, A->ctx->stream));
   if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(A->ctx->stream));
-  A->t_values_stale = true;
+  A->t_values_stale = true; A->bounds_valid = false;
   return NK_OK;
 }
 extern "C" int nk_csr_get_values(nk_csr *A, double *vals, int memspace) {
@@ -545,7 +546,10 @@ extern "C" int nk_csr_info(nk_csr *A, int64_t *nrows_local, int64_t *n_global, i
   if (n_halo) *n_halo = (int64_t)A->halo_gcols.size();
   return NK_OK;
 }
-extern "C" double *nk_csr_values_device(nk_csr *A) { return A ? A->d_val : nullptr; }
+extern "C" double *nk_csr_values_device(nk_csr *A) {
+  if (A) A->raw_exposed = true;   // the caller may write the values behind the library's back: cached spectrum bounds are off
+  return A ? A->d_val : nullptr;
+}
 
 // ----------------------------------------------------------------------------- Gershgorin bounds of the spectrum's real part
 // Every eigenvalue lies in a disc |λ − a_ii| ≤ r_i = Σ_{j≠i} |a_ij|, so Re λ ∈ [min_i (a_ii − r_i), max_i (a_ii + r_i)] — the
@@ -623,10 +627,27 @@ __global__ __launch_bounds__(1024) void k_max2_final(int nblk, const double *__r
     out2[1] = c;
   }
 }
-int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2) {
+int nk_csr_bounds_from_partials(nk_csr *A, const double *d_part, int nblk) {
+  if (!A->d_bounds) NK_TRY(nk_dev_alloc(&A->d_bounds, (size_t)2));
+  NK_LAUNCH(A->ctx, k_max2_final, dim3(1), dim3(1024), nblk, d_part, A->d_bounds);
+  NK_HIP(hipGetLastError());
+  A->bounds_valid = true;
+  return NK_OK;
+}
+int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2, const double **where) {
   nk_ctx *ctx = A->ctx;
   NK_REQUIRE(A->nblocks > 0, "Gershgorin bounds of an empty matrix");
-  if (!A->d_gersh) NK_TRY(nk_dev_alloc(&A->d_gersh, (size_t)2 * A->nblocks + 2));
+  if (A->bounds_valid && !A->raw_exposed && A->d_bounds && ctx->nranks == 1) {   // the fill kernel computed the discs on the fly
+    *where = A->d_bounds;
+    return NK_OK;
+  }
+  *where = d_out2;
+  if (!A->d_gersh || A->gersh_cap < 2 * A->nblocks) {
+    hipFree(A->d_gersh);
+    A->d_gersh = nullptr;
+    NK_TRY(nk_dev_alloc(&A->d_gersh, (size_t)2 * A->nblocks + 2));
+    A->gersh_cap = 2 * A->nblocks + 2;
+  }
   nk_prof_scope prof_(ctx, NK_K_OTHER, 12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1));
   hipLaunchKernelGGL(k_csr_gershgorin, dim3(A->nblocks), dim3(NK_BLOCK), (size_t)A->tile * 12, ctx->stream, A->nblocks,
                      A->tile, (const int4 *)A->d_rowblocks, A->d_rowptr, A->d_col, A->d_val, A->d_gersh);
@@ -742,7 +763,7 @@ static int build_transpose(nk_csr *A) {
     NK_TRY(nk_dev_alloc(&A->d_tz, (size_t)nt + 1));
     NK_TRY(nk_dev_alloc(&A->d_trecv, (size_t)A->halo.n_send + 1));
   }
-  A->t_values_stale = true;
+  A->t_values_stale = true; A->bounds_valid = false;
   return NK_OK;
 }
 
@@ -807,7 +828,7 @@ int nk_csr_colsumsq_dev(nk_csr *A, double *d_out) {
   }
   A->t_values_stale = false;                    // T holds the squares for this one product …
   const int st = nk_csr_spmv_t_dev(A, A->d_ones, d_out);
-  A->t_values_stale = true;                     // … and must be refreshed before the next Aᵀ x
+  A->t_values_stale = true; A->bounds_valid = false;                     // … and must be refreshed before the next Aᵀ x
   return st;
 }
 extern "C" int nk_csr_colsumsq(nk_csr *A, double *out, int memspace) {
@@ -844,7 +865,7 @@ int nk_csr_add_to_diagonal_dev(nk_csr *A, double sigma, const double *d_m) {
     NK_LAUNCH(A->ctx, k_add_diag, dim3((unsigned)((A->nrows + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), A->nrows,
               (const int32_t *)A->d_diagpos, sigma, d_m, A->d_val);
   NK_HIP(hipGetLastError());
-  A->t_values_stale = true;
+  A->t_values_stale = true; A->bounds_valid = false;
   return NK_OK;
 }
 
@@ -947,7 +968,7 @@ int nk_normal_plan_values(nk_normal_plan *Pn, nk_csr *J, double lambda, const do
               (const double *)J->d_val, lambda, d_diag, N->d_val);
     NK_HIP(hipGetLastError());
   }
-  N->t_values_stale = true;
+  N->t_values_stale = true; N->bounds_valid = false;
   return NK_OK;
 }
 

@@ -1259,9 +1259,10 @@ int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_
 __global__ void k_store2(double a, double b, double *out2) {
   if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
 }
-int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, bool *have) {
+int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, const double **where, bool *have) {
   nk_ctx *ctx = G->ctx;
   *have = false;
+  *where = d_out2;
   if (G->ss_ival_user) {
     NK_LAUNCH(ctx, k_store2, dim3(1), dim3(64), -G->ss_ival[0], G->ss_ival[1], d_out2);
     *have = true;
@@ -1269,7 +1270,11 @@ int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, bool *have) {
   }
   if (G->prec_kind || G->lprec_kind || G->normal || G->shift != 0.0) return NK_OK;
   if (G->op_kind == 1 && G->A->nblocks > 0) {
-    NK_TRY(nk_csr_gershgorin_dev(G->A, d_out2));
+    NK_TRY(nk_csr_gershgorin_dev(G->A, d_out2, where));
+    if (*where != d_out2) {   // the Jacobian fill left them (one rank): nothing to compute, nothing to reduce
+      *have = true;
+      return NK_OK;
+    }
   } else if (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D && G->n > 0) {
     NK_TRY(nk_problem_spectrum_interval_dev(G->P, G->d_u, d_out2));
   } else {
@@ -1600,6 +1605,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
           return !is_done;
         };
       G->ss_cycle_idx = inf.restarts;
+      G->ss_grow = fixed_iters <= 0;
       NK_TRY(nk_ss_cycle(G, steps, wait_progress));
     } else {
       const bool one_red = use_dcgs2r(G);

@@ -255,6 +255,9 @@ struct nk_csr {
   double *d_ones = nullptr;   // a vector of ones (nk_csr_colsumsq_dev)
   int32_t *d_diagpos = nullptr;  // position of every row's diagonal entry in val (nk_csr_add_to_diagonal_dev)
   double *d_gersh = nullptr;     // per-row-block Gershgorin bounds (nk_csr_gershgorin_dev)
+  double *d_bounds = nullptr;    // {−lo, hi} left by a fill kernel that computes the discs on the fly (valid while bounds_valid)
+  int gersh_cap = 0;             // doubles allocated behind d_gersh
+  bool bounds_valid = false, raw_exposed = false;  // raw_exposed: nk_csr_values_device handed the value array out — never trust a cache
   int32_t *d_csc_src = nullptr;  // created from CSC arrays: index of every local entry in that call's nzval
   double *d_csc_stage = nullptr; // staging for host nzval (nk_csr_set_values_csc)
   int64_t csc_nnz = 0;
@@ -456,6 +459,7 @@ struct nk_gmres {
   int ss_breakdowns = 0;  // Cholesky breakdowns of a block (the rest of that solve ran with delayed CGS2)
   int ss_s_cap = 0;              // automatic block size only: narrowed (15 → 8 → 4) after a block lost rank; 0 = not narrowed
   int ss_cycle_idx = 0;          // restart cycle of the current solve (0-based)
+  bool ss_grow = false;          // this solve stops on a tolerance: automatic block sizes start small and double (4, 8, 15 …)
   int ss_force_break_cycle = -1; // development hook (nk_gmres_debug_force_breakdown): that cycle's first block "loses rank"
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
@@ -470,8 +474,11 @@ int64_t nk_precond_size(struct nk_precond *P);
 int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale,
                       const double *d_theta = nullptr);
 // real bounds [lo, hi] of the operator's spectrum, on the device as {−lo, hi} (all-reduced); false: none are known
-int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, bool *have);
-int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2);   // {−min_i(a_ii − r_i), max_i(a_ii + r_i)} of the local rows
+int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, const double **where, bool *have);
+// {−min_i(a_ii − r_i), max_i(a_ii + r_i)} of the local rows: *where = the matrix's cached bounds (left by a fused fill kernel)
+// or d_out2 after a pass over the matrix
+int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2, const double **where);
+int nk_csr_bounds_from_partials(nk_csr *A, const double *d_part, int nblk);   // fill kernels: {max −lo, max hi} per block → cache
 bool nk_ss_eligible(const nk_gmres *G);
 int nk_ss_prepare(nk_gmres *G);   // once per linear solve: Newton basis (spectrum bounds known) or monomial
 int nk_ss_block_width(int want);

@@ -163,8 +163,9 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp_tile(int ns, int nl, dou
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
                                                         double c_exp, const double *__restrict__ u,
                                                         const int32_t *__restrict__ rowptr,
-                                                        double *__restrict__ vals) {
+                                                        double *__restrict__ vals, double *__restrict__ gpart) {
   __shared__ double sv[5 * NK_BLOCK];
+  __shared__ double sg[8];
   __shared__ int32_t s_p0, s_p1;
   const int64_t n = ns * nl, r0 = (int64_t)blockIdx.x * NK_BLOCK;
   const int64_t k = r0 + threadIdx.x;
@@ -192,6 +193,28 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, 
   }
   __syncthreads();
   for (int q = threadIdx.x; q < nnzb; q += NK_BLOCK) vals[p0 + q] = sv[q];
+  if (gpart != nullptr) {
+    // the row's Gershgorin disc on the fly — centre d, radius = the |off-diagonals| added in CSR order (S, W, E, N), exactly as
+    // k_csr_gershgorin's pass over the finished matrix would (bitwise the same bounds, 19 µs and 67 MB less per Jacobian)
+    double mlo = -INFINITY, mhi = -INFINITY;
+    if (k < n) {
+      double rad = 0.0;
+      if (j > 0) rad += c_lap;
+      if (i > 0) rad += c_lap;
+      if (i < ns - 1) rad += c_lap;
+      if (j < ns - 1) rad += c_lap;
+      mlo = -(d - rad);
+      mhi = d + rad;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mlo = fmax(mlo, __shfl_xor(mlo, o, 64)); mhi = fmax(mhi, __shfl_xor(mhi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sg[threadIdx.x >> 6] = mlo; sg[4 + (threadIdx.x >> 6)] = mhi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      gpart[blockIdx.x] = fmax(fmax(sg[0], sg[1]), fmax(sg[2], sg[3]));
+      gpart[gridDim.x + blockIdx.x] = fmax(fmax(sg[4], sg[5]), fmax(sg[6], sg[7]));
+    }
+  }
 }
 
 // ============================================================================ Brusselator 2-D
@@ -532,7 +555,7 @@ static int user_lin_J(nk_problem *P, const double *d_u) {
   if (P->cb.jac_values) {
     if (P->cb.jac_values(P->user, d_u, P->lin_J->d_val, (void *)P->ctx->stream) != 0)
       NK_FAIL(NK_E_CALLBACK, "jac_values callback failed");
-    P->lin_J->t_values_stale = true;
+    P->lin_J->t_values_stale = true; P->lin_J->bounds_valid = false;
   } else {
     NK_TRY(nk_problem_jac_colored_dev(P, d_u, P->lin_J));
   }
@@ -815,7 +838,7 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
-  J->t_values_stale = true;
+  J->t_values_stale = true; J->bounds_valid = false;
   if (n == 0) return NK_OK;
   nk_prof_scope prof_(ctx, NK_K_JACFILL, 8.0 * (double)J->nnz + 8.0 * (double)n);
   switch (P->kind) {
@@ -823,9 +846,26 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
       NK_LAUNCH(ctx, k_quad_jac, dim3(grid1(n)), dim3(NK_BLOCK), n, d_u, J->d_val);
       break;
     case NK_PROBLEM_BRATU2D:
-      NK_LAUNCH(ctx, k_bratu_jac, dim3(grid1(n)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->j0,
-                         P->c_lap, P->c_exp, d_u, J->d_rowptr, J->d_val);
+    {
+      // one rank: the fill also leaves the Gershgorin bounds of the new Jacobian (the s-step Newton basis asks for them before
+      // every linear solve); several ranks: the bounds are all-reduced, computed on demand
+      const int g = grid1(n);
+      double *gpart = nullptr;
+      if (ctx->nranks == 1 && J->nblocks > 0) {
+        if (!J->d_gersh || J->gersh_cap < 2 * g) {
+          hipFree(J->d_gersh);
+          J->d_gersh = nullptr;
+          const int cap = 2 * (g > J->nblocks ? g : J->nblocks) + 2;
+          NK_TRY(nk_dev_alloc(&J->d_gersh, (size_t)cap));
+          J->gersh_cap = cap;
+        }
+        gpart = J->d_gersh;
+      }
+      NK_LAUNCH(ctx, k_bratu_jac, dim3(g), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->j0, P->c_lap, P->c_exp, d_u, J->d_rowptr,
+                J->d_val, gpart);
+      if (gpart) NK_TRY(nk_csr_bounds_from_partials(J, gpart, g));
       break;
+    }
     case NK_PROBLEM_BRUSSELATOR2D: {
       NK_REQUIRE(J->d_role && J->d_node, "CSR was not created by nk_problem_jac_csr for a Brusselator problem");
       const nk_csr *ex = J;
@@ -1057,7 +1097,7 @@ int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J) {
     NK_LAUNCH(ctx, k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), n, J->d_rowptr, J->d_nnzcolor, c, J->d_B, J->d_val);
   }
   NK_HIP(hipGetLastError());
-  J->t_values_stale = true;
+  J->t_values_stale = true; J->bounds_valid = false;
   return NK_OK;
 }
 

@@ -851,6 +851,7 @@ struct nk_sstep {
   double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup)
   unsigned int *ticket = nullptr;            // last-workgroup ticket of k_ss_reduce_factor
   double *ival = nullptr, *nodes = nullptr;  // {−lo, hi} of the spectrum; Leja-ordered Chebyshev points for nodes_s columns
+  const double *ival_use = nullptr;          // where this solve's bounds are: `ival`, or the matrix's cache (left by its fill kernel)
   int nodes_s = 0;
   bool newton = false;                       // this solve builds Newton-basis blocks
 };
@@ -896,7 +897,7 @@ int nk_ss_prepare(nk_gmres *G) {
   W->newton = false;
   if (G->ss_basis == NK_SS_BASIS_MONOMIAL) return NK_OK;
   bool have = false;
-  NK_TRY(nk_gmres_spectrum_interval_dev(G, W->ival, &have));
+  NK_TRY(nk_gmres_spectrum_interval_dev(G, W->ival, &W->ival_use, &have));
   if (!have) {
     if (G->ss_basis == NK_SS_BASIS_NEWTON)
       NK_FAIL(NK_E_UNSUPPORTED, "s-step Newton basis: no bounds of this operator's spectrum are known "
@@ -944,13 +945,21 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.C2 = W->C2; ta.R2 = W->R2; ta.H = W->H; ta.m = G->m;
   ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
   NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal,
-            W->newton ? (const double *)W->ival : (const double *)nullptr, (const double *)W->nodes, s);
+            W->newton ? W->ival_use : (const double *)nullptr, (const double *)W->nodes, s);
   if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
   int prev_sb = s;
+  // A solve that stops on a tolerance may need 2 iterations or 200: a block's operator applications past the column that meets
+  // the tolerance are wasted (a multigrid V-cycle each, under that preconditioner). Automatic block sizes therefore start small
+  // in every cycle and double — 4, 8, 15, 15 … with the Newton basis, 2, 4, 6, 6 … with the monomial one —: a solve that needs
+  // k iterations applies the operator < 2k times, and one that fills the cycle builds most of it in full-width blocks. The
+  // fixed-work protocol and explicit block sizes take full blocks from the start.
+  int grow = (G->ss_s == 0 && G->ss_grow) ? (W->newton ? 4 : 2) : s;
   while (k - 1 < steps) {
     int sb = (steps - (k - 1)) < s ? (steps - (k - 1)) : s;
+    if (grow < sb) sb = grow;
+    grow = grow * 2 > s ? s : grow * 2;
     sb = nk_ss_block_width(sb);
     if (k + sb > 48 && sb > 8) sb = 8;  // the streaming size class keeps its scalar workspace within the LDS
     if (wait_progress && k > 1 && !wait_progress(k - 1 - prev_sb)) break;
