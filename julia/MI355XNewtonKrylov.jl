@@ -233,6 +233,10 @@ Base.@kwdef struct MI355XGMRES <: LinearSolve.AbstractKrylovSubspaceMethod   # [
     ortho::Symbol = :sstep     # :mgs | :cgs2 | :cgs | :dcgs2 | :sstep (s columns per block, matrix-core Gram blocks; the default)
     sstep::Int = 0             # 0 = automatic: 15 with the Newton basis (spectrum bounds known), 6 with the monomial one
     sstep_basis::Symbol = :auto  # :auto | :monomial | :newton
+    # `precs(A, p::LinearSolveParameters) -> (Pl, Pr)`, as on LinearSolve's Krylov algorithms: LinearSolve evaluates it when it
+    # builds the cache (`hasproperty(alg, :precs)` in its `init` [EXT]) and this module's `solve!` re-evaluates it for every
+    # fresh `A` (what KrylovJL's `solve!` does under `cache.precsisfresh` [EXT]); core_tests__item21.jl:10-37 pins the protocol
+    precs::Any = nothing
 end
 LinearSolve.needs_concrete_A(::MI355XGMRES) = false                           # [EXT]
 
@@ -374,8 +378,9 @@ function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::MI355XGMRES; kwar
         # are bound — the reference's own documented precs return `(Pl, I)` (docs/src/tutorials/large_systems.md:257,284-287):
         # a DevicePreconditioner goes in as an object (no host round trip per application), anything else with `ldiv!` through
         # the host trampoline, identities remove that side.
-        bind_preconditioner!(w, NK_SIDE_LEFT, cache.Pl)
-        bind_preconditioner!(w, NK_SIDE_RIGHT, cache.Pr)
+        Pl, Pr = alg.precs === nothing ? (cache.Pl, cache.Pr) : alg.precs(cache.A, cache.p)   # a fresh A: precs is re-evaluated
+        bind_preconditioner!(w, NK_SIDE_LEFT, Pl)                              # (`nothing` and `I` count as identities)
+        bind_preconditioner!(w, NK_SIDE_RIGHT, Pr)
         cache.isfresh = false
     end
     info = Ref(GMRESInfo(0, 0, 0, 0, 0.0, 0.0))

@@ -1540,6 +1540,16 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   const int cap = fixed_iters > 0 ? fixed_iters : maxiter;
   // a breakdown of the s-step form switches THIS solve to delayed CGS2; the object's choice comes back on every exit
   struct ortho_guard_t { nk_gmres *g; int o; ~ortho_guard_t() { g->ortho = o; } } ortho_guard{G, G->ortho};
+  // Where the automatic choice (block size 0) does NOT take the s-step form, although the object asks for it:
+  //  * a solve that stops on a tolerance under a preconditioner — such solves need a handful of iterations, every operator
+  //    application past the column that meets the tolerance is a wasted V-cycle / triangular solve, and the sweeps the blocks
+  //    save are small change next to the preconditioner (measured: the multigrid solves of configs C3 / C4 / C5 took 2× as long
+  //    in blocks of ≥ 2) — the column-by-column form with its one-step run-ahead serves them;
+  //  * the normal-form operator JᵀJ (+ λDᵀD): its monomial blocks square an already squared condition number.
+  // An explicit block size is honoured everywhere; the fixed-work protocol always builds full blocks.
+  if (G->ortho == NK_ORTHO_SSTEP && G->ss_s == 0 &&
+      ((fixed_iters <= 0 && (G->prec_kind || G->lprec_kind)) || G->normal))
+    G->ortho = NK_ORTHO_DCGS2;
   if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) NK_TRY(nk_ss_prepare(G));
   nk_gmres_info inf;
   memset(&inf, 0, sizeof(inf));
