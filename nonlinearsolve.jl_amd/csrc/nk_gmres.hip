@@ -1654,6 +1654,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     // block's outcome to the host
     NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
               (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr));
+    if (G->ortho == NK_ORTHO_SSTEP) NK_TRY(nk_ss_fix_solution_coefficients(G));   // (the last block never got its second update)
     if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
     } else {

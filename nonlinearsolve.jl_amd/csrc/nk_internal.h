@@ -459,6 +459,7 @@ struct nk_gmres {
   int ss_breakdowns = 0;  // Cholesky breakdowns of a block (the rest of that solve ran with delayed CGS2)
   int ss_s_cap = 0;              // automatic block size only: narrowed (15 → 8 → 4) after a block lost rank; 0 = not narrowed
   int ss_cycle_idx = 0;          // restart cycle of the current solve (0-based)
+  int ss_last_k0 = 0, ss_last_sb = 0;   // the cycle's last block was left at its first pass (no sweep C): k_ss_fix_y adapts y
   bool ss_grow = false;          // this solve stops on a tolerance: automatic block sizes start small and double (4, 8, 15 …)
   int ss_force_break_cycle = -1; // development hook (nk_gmres_debug_force_breakdown): that cycle's first block "loses rank"
 };
@@ -482,6 +483,7 @@ int nk_csr_bounds_from_partials(nk_csr *A, const double *d_part, int nblk);   //
 bool nk_ss_eligible(const nk_gmres *G);
 int nk_ss_prepare(nk_gmres *G);   // once per linear solve: Newton basis (spectrum bounds known) or monomial
 int nk_ss_block_width(int want);
+int nk_ss_fix_solution_coefficients(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
 void nk_ss_destroy(struct nk_sstep *W);

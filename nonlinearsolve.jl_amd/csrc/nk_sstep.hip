@@ -309,10 +309,47 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
   const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
   if (!ss_factor(k, sb, ta.red, ta.sc, w)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
-  for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
-  if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
+  for (int e = t; e < k * sb; e += 256) { coef[e] = w.U[e]; ta.C2[e] = w.Ct[e]; }
+  if (t < sb * sb) { coef[(size_t)k * sb + t] = w.Ri[t]; ta.R2[t] = w.Rm[t]; }
   __syncthreads();
   ss_hessenberg(k, sb, w, ta);
+}
+// the Hessenberg columns of a block as a launch of its own: the LAST block of a cycle, whose third sweep is never run (below)
+__global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta) {
+  extern __shared__ double s_tail[];
+  if (ta.ctl->pad1) return;
+  const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
+  const int t = threadIdx.x;
+  for (int e = t; e < k * sb; e += 256) w.Ct[e] = ta.C2[e];
+  if (t < sb * sb) w.Rm[t] = ta.R2[t];
+  __syncthreads();
+  ss_hessenberg(k, sb, w, ta);
+}
+// The last block of a cycle never gets its second update (sweep C): its columns Q = (Q₁ − V_k C₂) R₂⁻¹ are used once more only —
+// in x += [V_k Q] y —, and that product can be taken from the columns as pass 1 left them:
+//     [V_k Q] y = V_k (y_k − C₂ b) + Q₁ b,   b = R₂⁻¹ y_Q
+// (a restart forms r = b − A x afresh and starts a new basis). One sweep over k + 2s columns less per cycle — 386 MB of the
+// 1.7 GB the sweeps of a 1024² cycle moved — for an s × s triangular solve and a k × s product on one wavefront.
+// k0 = columns in front of the block, sb = its width; y is zero from ctl->k on, so b has y_Q's support.
+__global__ __launch_bounds__(64) void k_ss_fix_y(const nk_gmres_ctl *ctl, int k0, int sb, const double *__restrict__ C2,
+                                                 const double *__restrict__ R2, double *__restrict__ y) {
+  __shared__ double b[SS_SMAX];
+  if (ctl->failed == 2 || ctl->k <= k0) return;   // a breakdown leaves y = 0; a cycle that ended before this block has nothing in it
+  const int t = threadIdx.x;
+  if (t == 0) {
+    for (int c = sb - 1; c >= 0; --c) {           // back substitution with the upper-triangular R₂
+      double v = (k0 + c < ctl->k) ? y[k0 + c] : 0.0;
+      for (int cc = c + 1; cc < sb; ++cc) v -= R2[c * sb + cc] * b[cc];
+      b[c] = v / R2[c * sb + c];
+    }
+    for (int c = 0; c < sb; ++c) y[k0 + c] = b[c];
+  }
+  __syncthreads();
+  for (int j = t; j < k0; j += 64) {
+    double v = y[j];
+    for (int c = 0; c < sb; ++c) v -= C2[j * sb + c] * b[c];
+    y[j] = v;
+  }
 }
 
 // coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
@@ -924,6 +961,21 @@ extern "C" int nk_gmres_get_sstep_state(nk_gmres *G, int *block_size, int *newto
   return NK_OK;
 }
 
+static bool ss_skip_last_sweep() {
+  static const bool off = getenv("NK_SS_LAST_SWEEP") && atoi(getenv("NK_SS_LAST_SWEEP")) != 0;   // A/B switch: run it anyway
+  return !off;
+}
+// after the back-substitution of a cycle whose last block was left at its first pass: y → coefficients on the stored columns
+int nk_ss_fix_solution_coefficients(nk_gmres *G) {
+  if (G->ss_last_sb <= 0 || !G->ss) return NK_OK;
+  nk_sstep *W = G->ss;
+  NK_LAUNCH(G->ctx, k_ss_fix_y, dim3(1), dim3(64), (const nk_gmres_ctl *)G->d_ctl, G->ss_last_k0, G->ss_last_sb, (const double *)W->C2,
+            (const double *)W->R2, G->d_y);
+  NK_HIP(hipGetLastError());
+  G->ss_last_sb = 0;
+  return NK_OK;
+}
+
 // Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of ≤ s (cut to the widths the sweeps are compiled for;
 // the last block may be shorter). k_gmres_begin has run. `wait_progress(need)` (may be empty) blocks the host until `need`
 // columns are closed or the cycle is done and returns false when no further block should be enqueued.
@@ -948,6 +1000,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
             W->newton ? W->ival_use : (const double *)nullptr, (const double *)W->nodes, s);
   if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
+  G->ss_last_sb = 0;
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
   int prev_sb = s;
   // A solve that stops on a tolerance may need 2 iterations or 200: a block's operator applications past the column that meets
@@ -1019,9 +1072,26 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         }
       }
     }
-    {
+    const bool last_block = (k - 1 + sb >= steps) && ss_skip_last_sweep();
+    if (!last_block) {
       nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 2 * sb));
       NK_TRY(nk_ss_sweep(ctx, 2, n, k, sb, G->V, ldv, W->coef, W->part, skipC, grid, fused ? &ta : nullptr, nullptr));
+    } else {
+      // the cycle's last block: no third sweep (k_ss_fix_y turns y into coefficients on the columns as they are); its Hessenberg
+      // columns — the work of sweep C's workgroup 0, or already done by k_ss_tail2 on the unfused path — as a launch of their own
+      if (fused) {
+        const size_t lds = ss_ws_doubles(k, sb, true) * sizeof(double);
+        if (lds > 64 * 1024)
+          NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_hess), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (k + sb) * sb);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
+          hipExtLaunchKernelGGL(k_ss_hess, dim3(1), dim3(256), lds, ctx->stream, e0, e1, 0, k, sb, ta);
+        else
+          hipLaunchKernelGGL(k_ss_hess, dim3(1), dim3(256), lds, ctx->stream, k, sb, ta);
+      }
+      G->ss_last_k0 = k;
+      G->ss_last_sb = sb;
     }
     NK_HIP(hipGetLastError());
     k += sb;
