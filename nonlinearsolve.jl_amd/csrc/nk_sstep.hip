@@ -206,8 +206,10 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   if (t < sb * sb) w.R1s[t] = ta.R1[t];
   const double sigma = ta.scal[2];
   const double *__restrict__ th = ta.scal + SS_TH;
+  SS_STAMP(8);
   for (int e = t; e < k * sb; e += nt) F[e] = ta.C1[e];
   __syncthreads();
+  SS_STAMP(9);
   for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
     const int j = e / sb, c = e % sb;
     double v = F[e];
@@ -223,18 +225,33 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   __syncthreads();
   if (t < K) NC[t] = sigma * F[t * sb] + (t == k - 1 ? th[0] : 0.0);
   __syncthreads();
-  for (int j = 1; j < sb; ++j) {
-    if (t < K) {
-      const int i = t;
-      double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
-      if (i < k)
-        for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
-      a = __builtin_fma(-NC[i], F[(k - 1) * sb + (j - 1)], a);
-      for (int q = 1; q < j; ++q) a = __builtin_fma(-NC[q * K + i], F[(k + q - 1) * sb + (j - 1)], a);
-      NC[j * K + i] = a / F[(k + j - 1) * sb + (j - 1)];
+  SS_STAMP(10);
+  // Coordinates of A q_j, j = 1..sb−1: NC_j = (σF_j + θ_j F_{j−1} − H_old F_{j−1}[:k] − Σ_{q<j} NC_q · Fb(q, j−1)) / R_{j−1,j−1}
+  // with Fb(0, c) = F[k−1][c] and Fb(q, c) = R[q−1][c]. The part that does not involve other NC columns is a (K × k)(k × sb)
+  // product — all (j, i) entries at once —, the rest a triangular solve with K right-hand sides: right-looking, NC_q leaves
+  // every later column as soon as it is final. Per entry the multiply-adds run in the order of the column-by-column
+  // recurrence this replaces (one entry per thread and step: 14 dependent steps of one multiply-add instead of 14 steps of
+  // ≤ 30: measured 14.6 → ≈ 2 µs at k = 16, s = 15).
+  const int npair = (sb - 1) * K;
+  for (int e = t; e < npair; e += nt) {
+    const int j = 1 + e / K, i = e % K;
+    double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
+    if (i < k)
+      for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
+    NC[j * K + i] = a;
+  }
+  __syncthreads();
+  for (int q = 0; q + 1 < sb; ++q) {
+    const int frow = (q == 0) ? (k - 1) : (k + q - 1);
+    for (int e = t; e < (sb - 1 - q) * K; e += nt) {
+      const int j = q + 1 + e / K, i = e % K;
+      double a = __builtin_fma(-NC[q * K + i], F[frow * sb + (j - 1)], NC[j * K + i]);
+      if (j == q + 1) a /= F[(k + j - 1) * sb + (j - 1)];    // its last term: the column is final
+      NC[j * K + i] = a;
     }
     __syncthreads();
   }
+  SS_STAMP(11);
   for (int e = t; e < sb * K; e += nt) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
     const int j = e / K, i = e % K, jc = ko + j;
     if (i <= jc + 1 && jc < m) ta.H[(size_t)i * m + jc] = NC[j * K + i];
@@ -250,27 +267,56 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
     }
   }
   __syncthreads();
-  if (t == 0) {  // the rotations this block creates: a chain of sb short steps
+  SS_STAMP(12);
+  // The rotations this block creates: rotation i comes from new column i after the rotations before it — a chain of sb steps —,
+  // but every rotation is applied to all LATER columns at once (lane j owns column j): sb steps of one hypot + one rotation
+  // instead of thread 0 walking sb²/2 rotations (measured 16.3 → ≈ 3 µs at s = 15). All sb rotations are formed; which columns
+  // count (the first that meets the tolerance closes the cycle) is decided by the scalar pass behind it.
+  double *betas = w.Gd;   // (free here: ss_factor is done with it)
+  if (t < 64) {
+    // one wavefront, LDS only, no workgroup barriers: lanes run in lockstep and a wavefront's LDS operations complete in order;
+    // the rotated entries stay in the column (row jc of column t: its final R entry), global stores follow the loop
+    for (int i = 0; i < sb; ++i) {
+      const int jc = ko + i;
+      if (t == i) {
+        const double hk = NC[i * K + jc], beta = NC[i * K + jc + 1];
+        double d = sqrt(__builtin_fma(hk, hk, beta * beta));
+        if (!(d > 1e-150 && d < 1e150)) d = hypot(hk, beta);        // (scaled evaluation only where the plain one may be off)
+        double c, sgn;
+        if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
+        scs[jc] = c;
+        ssn[jc] = sgn;
+        betas[i] = beta;
+        NC[i * K + jc] = d;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (t > i && t < sb) {
+        double *h = &NC[t * K];
+        const double a = h[jc], b = h[jc + 1], c = scs[jc], sgn = ssn[jc];
+        h[jc] = c * a + sgn * b;
+        h[jc + 1] = -sgn * a + c * b;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < sb * sb; e += nt) {   // R entries of the block's own rows: rotated values above the diagonal, d on it
+    const int i = e / sb, tt = e % sb;
+    if (tt >= i) ta.Rg[(size_t)(ko + i) * m + (ko + tt)] = NC[tt * K + ko + i];
+  }
+  if (t == 0) {
     nk_gmres_ctl *ctl = ta.ctl;
     const double tol = ctl->tol;
     int closed = 0, dn = 0;
     double rn = ctl->rnorm, beta = 0.0;
     for (int j = 0; j < sb && !dn; ++j) {
       const int jc = ko + j;
-      double *h = &NC[j * K];
-      for (int i = ko; i < jc; ++i) {
-        const double a = h[i], b = h[i + 1];
-        ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
-        h[i + 1] = -ssn[i] * a + scs[i] * b;
-      }
-      const double hk = h[jc];
-      beta = h[jc + 1];
-      const double d = hypot(hk, beta);
-      double c, sgn;
-      if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
-      scs[jc] = c;
-      ssn[jc] = sgn;
-      ta.Rg[(size_t)jc * m + jc] = d;
+      const double c = scs[jc], sgn = ssn[jc];
+      beta = betas[j];
       const double gj = sg[jc];
       sg[jc + 1] = -sgn * gj;
       sg[jc] = c * gj;
@@ -290,6 +336,7 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
     ta.scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
     ss_pub_progress(ta.pub, ta.seq, ctl->k, dn);
   }
+  SS_STAMP(13);
 }
 
 // the scalar work as launches of their own (the streaming size class k + s > 48, and NK_SS_FUSED=0)
@@ -747,8 +794,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
 extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   static unsigned long long *d_st = nullptr;
   if (enable && !d_st) {
-    if (hipMalloc(&d_st, 8 * sizeof(unsigned long long)) != hipSuccess) return NK_E_NOMEM;
-    hipMemset(d_st, 0, 8 * sizeof(unsigned long long));
+    if (hipMalloc(&d_st, 16 * sizeof(unsigned long long)) != hipSuccess) return NK_E_NOMEM;
+    hipMemset(d_st, 0, 16 * sizeof(unsigned long long));
     hipMemcpyToSymbol(HIP_SYMBOL(g_ss_stamp), &d_st, sizeof(d_st));
   }
   if (!enable && d_st) {
@@ -757,7 +804,7 @@ extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   }
   if (out5 && d_st) {
     hipDeviceSynchronize();
-    hipMemcpy(out5, d_st, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipMemcpy(out5, d_st, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   }
   return NK_OK;
 }

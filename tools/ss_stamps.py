@@ -13,7 +13,7 @@ prob.u0 = torch.zeros(ns * ns, dtype=torch.float64, device="cuda")
 cache = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30), concrete_jac=True), abstol=1e-300, maxiters=10**9)
 for _ in range(3):
     cache.step()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 f(1, out)
 for _ in range(3):
     cache.step()
@@ -22,3 +22,5 @@ for _ in range(3):
     names = ["kernel start(wg0)", "last ticket", "red in LDS", "factor done", "end", "f:Ct/U done", "f:frame ready", "(unused)"]
     base = v[0]
     print({n: round((x - base) / 100.0, 2) for n, x in zip(names, v)})
+    hn = ["hess: start", "C1 loaded", "F = [C; R] ready", "recurrence done", "H stored + old rotations", "new rotations done"]
+    print({n: round((x - v[8]) / 100.0, 2) for n, x in zip(hn, v[8:14])})
