@@ -456,7 +456,9 @@ class NonlinearFunction:
 
 
 class NonlinearProblem:
-    """NonlinearProblem(f, u0, p) — also stands in for a square NonlinearLeastSquaresProblem (see the alias below). `f` is a built-in DeviceProblem or a NonlinearFunction of torch callbacks."""
+    """NonlinearProblem(f, u0, p). `f` is a built-in DeviceProblem or a NonlinearFunction of torch callbacks.
+    (NonlinearLeastSquaresProblem below is the same container with `least_squares = True`.)"""
+    least_squares = False
 
     def __init__(self, f, u0=None, p=None, ctx: Optional[Context] = None):
         self.p = p
@@ -829,14 +831,16 @@ _ORTHO = {"mgs": L.ORTHO_MGS, "cgs2": L.ORTHO_CGS2, "cgs": L.ORTHO_CGS, "dcgs2":
 
 
 def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,
-             termination_condition=None) -> L.Options:
+             termination_condition=None, least_squares=False) -> L.Options:
     o = L.Options()
     check(L.lib().nk_options_default(C.byref(o)))
     ls = alg.linsolve
     o.algorithm = L.ALG_TRUST_REGION if isinstance(alg, TrustRegion) else L.ALG_NEWTON_RAPHSON
+    if least_squares:
+        o.termination_norm = 1  # default_termination_mode(::NonlinearLeastSquaresProblem): AbsNormSafeBest on the 2-norm
     if isinstance(alg, GaussNewton):   # (linsolve = None: a factorising solver takes J δ = f as it is — no normal form)
         o.algorithm = L.ALG_GAUSS_NEWTON
-        o.termination_norm = 1  # default_termination_mode(::NonlinearLeastSquaresProblem): AbsNormSafeBest on the 2-norm
+        o.termination_norm = 1  # (Gauss–Newton is defined on least-squares problems only)
     if isinstance(alg, PseudoTransient):
         o.algorithm = L.ALG_PSEUDO_TRANSIENT
         o.pt_alpha_initial = float(alg.alpha_initial)
@@ -947,7 +951,7 @@ class FirstOrderCache:
                  store_trace=False, termination_kwargs=None, termination_condition=None):
         self.prob, self.alg = prob, alg
         self._opts = _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kwargs,
-                              termination_condition)
+                              termination_condition, least_squares=getattr(prob, "least_squares", False))
         self._u0_is_torch = _is_torch(prob.u0)
         p, ms, _k = _ptr(prob.u0, prob.device_problem.n_local)
         h = C.c_void_p()
@@ -1104,20 +1108,25 @@ class FirstOrderCache:
             self._h = None
 
 
-NonlinearLeastSquaresProblem = NonlinearProblem   # residual count = unknown count on this path (row-partitioned square J)
+class NonlinearLeastSquaresProblem(NonlinearProblem):
+    """NonlinearLeastSquaresProblem(f, u0, p): residual count = unknown count on this path (row-partitioned square J). What the
+    type changes is what the reference derives from it: the default termination mode measures the residual in the 2-norm
+    (default_termination_mode(::NonlinearLeastSquaresProblem)) for EVERY algorithm, and a polyalgorithm's best-of fallback ranks
+    its sub-solvers by the 2-norm (findmin_resids, NonlinearSolveBase/src/polyalg.jl)."""
+    least_squares = True
 
 
 def init(prob: NonlinearProblem, alg, **kw):
     from . import polyalg
     if isinstance(alg, polyalg.NonlinearSolvePolyAlgorithm):
-        return polyalg.PolyAlgorithmCache(prob, alg, **kw)
+        return polyalg.PolyAlgorithmCache(prob, alg, least_squares=getattr(prob, "least_squares", False), **kw)
     return FirstOrderCache(prob, alg, **kw)
 
 
 def solve(prob: NonlinearProblem, alg, **kw) -> NonlinearSolution:
     from . import polyalg
     if isinstance(alg, polyalg.NonlinearSolvePolyAlgorithm):
-        return polyalg.polysolve(prob, alg, **kw)
+        return polyalg.polysolve(prob, alg, least_squares=getattr(prob, "least_squares", False), **kw)
     cache = FirstOrderCache(prob, alg, **kw)
     try:
         return cache.solve()

@@ -157,3 +157,36 @@ def test_all_rungs_fail_returns_lowest_residual(nls, dev):
             c.close()
         assert sol.retcode == "MaxIters" == R.RETCODE_NAMES[ref.retcode] and _same_stats(sol.stats, ref.stats)
         assert abs(float(sol.u[0]) - ref.u[0]) <= 1e-12 and abs(float(sol.resid[0]) - ref.resid[0]) <= 1e-10
+
+
+def test_least_squares_problem_type_drives_the_norms(nls):
+    """A NonlinearLeastSquaresProblem is a type of its own: every algorithm's default termination measures the residual in
+    the 2-norm (default_termination_mode(::NonlinearLeastSquaresProblem)) and a polyalgorithm's best-of fallback ranks its
+    rungs by the 2-norm (findmin_resids with least squares, NonlinearSolveBase/src/polyalg.jl) — LM and the ladders, not only
+    Gauss–Newton."""
+    assert issubclass(nls.NonlinearLeastSquaresProblem, nls.NonlinearProblem) and nls.NonlinearLeastSquaresProblem is not nls.NonlinearProblem
+    tk = dict(mode=0, norm="l2", max_stalled_steps=32)
+    lm, rlm = nls.LevenbergMarquardt(linsolve=nls.KrylovJL_GMRES()), R.LevenbergMarquardt(linsolve=R.KrylovJL_GMRES())
+    for ab in (1e-3, 1e-5, 1e-7):   # (‖f‖₂ = 20 ‖f‖∞ here: the 2-norm needs one step more at each of these tolerances)
+        ref2 = R.solve(R.Quadratic(400, 2.0), rlm, abstol=ab, maxiters=200, termination_kwargs=tk)
+        refi = R.solve(R.Quadratic(400, 2.0), rlm, abstol=ab, maxiters=200)
+        s2 = nls.solve(nls.NonlinearLeastSquaresProblem(nls.Quadratic(400, 2.0)), lm, abstol=ab, maxiters=200)
+        si = nls.solve(nls.NonlinearProblem(nls.Quadratic(400, 2.0)), lm, abstol=ab, maxiters=200)
+        assert s2.retcode == si.retcode == "Success"
+        assert s2.stats.nsteps == ref2.stats.nsteps == refi.stats.nsteps + 1 == si.stats.nsteps + 1
+        assert np.linalg.norm(np.asarray(s2.resid)) <= ab and np.max(np.abs(np.asarray(si.resid))) <= ab
+    # a ladder none of whose rungs can finish: the winner is the oracle's under the 2-norm ranking, through both entries
+    kw = dict(gmres_restart=30, maxiters=300)
+    def ladder(M):
+        return M.NonlinearSolvePolyAlgorithm((M.NewtonRaphson(linsolve=M.KrylovJL_GMRES(**kw)), M.TrustRegion(linsolve=M.KrylovJL_GMRES(**kw)),
+                                              M.LevenbergMarquardt(linsolve=M.KrylovJL_GMRES(**kw))))
+    ref = R.solve(R.Brusselator2D(6), ladder(R), abstol=1e-12, maxiters=2, least_squares=True, termination_kwargs=tk)
+    sol = nls.solve(nls.NonlinearLeastSquaresProblem(nls.Brusselator2D(6)), ladder(nls), abstol=1e-12, maxiters=2)
+    assert sol.retcode == R.RETCODE_NAMES[ref.retcode] != "Success" and _same_stats(sol.stats, ref.stats)
+    assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))
+    c = nls.init(nls.NonlinearLeastSquaresProblem(nls.Brusselator2D(6)), ladder(nls), abstol=1e-12, maxiters=2)
+    rc = R.init(R.Brusselator2D(6), ladder(R), abstol=1e-12, maxiters=2, least_squares=True, termination_kwargs=tk)
+    assert c.least_squares and all(cc._opts.termination_norm == 1 for cc in c.caches)
+    s, rs = nls.solve_(c), rc.solve()
+    assert c.best == rc.best and s.retcode == R.RETCODE_NAMES[rs.retcode]
+    c.close()
