@@ -789,6 +789,15 @@ __global__ __launch_bounds__(NK_BLOCK) void k_copy_sumsq(int64_t n, const double
   s = block_sum(s, sm);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
+// stage 1 alone: y = x and the per-workgroup partial sums of Σ x² in ctx->d_partials[0..grid) — for a consumer kernel that
+// reduces them itself, in k_reduce_sum's order (one rank)
+int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out) {
+  const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
+  NK_LAUNCH(ctx, k_copy_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, y, ctx->d_partials);
+  NK_HIP(hipGetLastError());
+  *grid_out = grid;
+  return NK_OK;
+}
 int nk_blas_copy_sumsq(nk_ctx *ctx, int64_t n, const double *x, double *y, double *d_out) {
   const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
   NK_LAUNCH(ctx, k_copy_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, y, ctx->d_partials);
@@ -818,9 +827,11 @@ __global__ __launch_bounds__(NK_BLOCK) void k_absmax_sumsq(int64_t n, const doub
     partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
   }
 }
+// h_dst != nullptr: the results also go to coherent pinned host memory and the sequence word is released (what k_publish does
+// as a launch of its own — the once-per-step norms of the Newton driver save that launch on one rank)
 __global__ __launch_bounds__(NK_BLOCK) void k_reduce_inf2(const double *__restrict__ partials, int nblk,
                                                           const double *__restrict__ extra, int extra_n,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, double *h_dst, uint64_t *h_seq, uint64_t seq) {
   __shared__ double sm[12];
   double m = -__builtin_inf(), s = 0.0, e = 0.0;
   for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) { m = nanmax(m, partials[i]); s += partials[nblk + i]; }
@@ -832,17 +843,48 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_inf2(const double *__restri
   if ((threadIdx.x & 63) == 0) { sm[w] = m; sm[4 + w] = s; sm[8 + w] = e; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = nanmax(nanmax(sm[0], sm[1]), nanmax(sm[2], sm[3]));
-    out[1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
-    if (extra != nullptr) out[2] = (sm[8] + sm[9]) + (sm[10] + sm[11]);
+    const double o0 = nanmax(nanmax(sm[0], sm[1]), nanmax(sm[2], sm[3]));
+    const double o1 = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+    const double o2 = (sm[8] + sm[9]) + (sm[10] + sm[11]);
+    out[0] = o0;
+    out[1] = o1;
+    if (extra != nullptr) out[2] = o2;
+    if (h_dst != nullptr) {
+      h_dst[0] = o0;
+      h_dst[1] = o1;
+      if (extra != nullptr) h_dst[2] = o2;
+      __threadfence_system();
+      __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n) {
   const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
   NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
-  NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out);
+  NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
+            (double *)nullptr, (uint64_t *)nullptr, (uint64_t)0);
   NK_HIP(hipGetLastError());
   return nk_comm_allreduce_mixed(ctx, d_out, extra_partials ? 3 : 2, 0, 1);  // [max, +, +]: one message on the peer path
+}
+// the same, with the 2–3 results delivered to the host (`h_out`): on one rank the stage-2 launch publishes them itself
+int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
+                               double *h_out) {
+  const int count = extra_partials ? 3 : 2;
+  static const bool legacy = getenv("NK_FETCH_MEMCPY") != nullptr || getenv("NK_NORMS_SEPARATE_PUBLISH") != nullptr;
+  if (!nk_ctx_is_single(ctx) || legacy) {
+    NK_TRY(nk_blas_norms_inf2(ctx, n, x, d_out, extra_partials, extra_n));
+    return nk_scalars_to_host(ctx, d_out, count, h_out);
+  }
+  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+  const uint64_t seq = ++ctx->seq;
+  NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
+  NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
+            ctx->h_pinned_dev, ctx->h_seq_dev, seq);
+  NK_HIP(hipGetLastError());
+  volatile uint64_t *hs = ctx->h_seq;
+  NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(hs, __ATOMIC_ACQUIRE) == seq; }, "published norms"));
+  for (int i = 0; i < count; ++i) h_out[i] = ctx->h_pinned[i];
+  return NK_OK;
 }
 
 // ----------------------------------------------------------------------------- several reductions in one pass

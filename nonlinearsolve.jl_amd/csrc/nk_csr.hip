@@ -482,7 +482,7 @@ extern "C" int nk_csr_set_values_csc(nk_csr *A, const double *nzval, int64_t nnz
     NK_HIP(hipGetLastError());
   }
   if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(ctx->stream));   // the caller's host array may change after the call
-  A->t_values_stale = true; A->bounds_valid = false;
+  A->t_values_stale = true; A->bounds_valid = false; A->bounds_pending = false;
   return NK_OK;
 }
 // the same with the library's default partition (contiguous row ranges, nk_partition_range with granule 1)
@@ -528,7 +528,7 @@ extern "C" int nk_csr_set_values(nk_csr *A, const double *vals, int memspace) {
   NK_HIP(hipMemcpyAsync(A->d_val, vals, A->nnz * sizeof(double),
                         memspace == NK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, A->ctx->stream));
   if (memspace != NK_DEVICE) NK_HIP(hipStreamSynchronize(A->ctx->stream));
-  A->t_values_stale = true; A->bounds_valid = false;
+  A->t_values_stale = true; A->bounds_valid = false; A->bounds_pending = false;
   return NK_OK;
 }
 extern "C" int nk_csr_get_values(nk_csr *A, double *vals, int memspace) {
@@ -627,17 +627,36 @@ __global__ __launch_bounds__(1024) void k_max2_final(int nblk, const double *__r
     out2[1] = c;
   }
 }
+// a fill kernel left {max −lo, max hi} per block: the reduction into d_bounds waits for the first reader — the s-step form's
+// begin kernel folds it in (nk_csr_take_pending_bounds), anyone else gets a k_max2_final launch
 int nk_csr_bounds_from_partials(nk_csr *A, const double *d_part, int nblk) {
   if (!A->d_bounds) NK_TRY(nk_dev_alloc(&A->d_bounds, (size_t)2));
-  NK_LAUNCH(A->ctx, k_max2_final, dim3(1), dim3(1024), nblk, d_part, A->d_bounds);
-  NK_HIP(hipGetLastError());
+  A->bounds_part = d_part;
+  A->bounds_nblk = nblk;
+  A->bounds_pending = true;
   A->bounds_valid = true;
   return NK_OK;
+}
+static int csr_settle_bounds(nk_csr *A) {
+  if (!A->bounds_pending) return NK_OK;
+  NK_LAUNCH(A->ctx, k_max2_final, dim3(1), dim3(1024), A->bounds_nblk, A->bounds_part, A->d_bounds);
+  NK_HIP(hipGetLastError());
+  A->bounds_pending = false;
+  return NK_OK;
+}
+bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst) {
+  if (!(A->bounds_valid && A->bounds_pending && !A->raw_exposed && A->d_bounds && A->ctx->nranks == 1)) return false;
+  *part = A->bounds_part;
+  *nblk = A->bounds_nblk;
+  *dst = A->d_bounds;
+  A->bounds_pending = false;   // (the caller's kernel, next in the stream, performs the reduction)
+  return true;
 }
 int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2, const double **where) {
   nk_ctx *ctx = A->ctx;
   NK_REQUIRE(A->nblocks > 0, "Gershgorin bounds of an empty matrix");
   if (A->bounds_valid && !A->raw_exposed && A->d_bounds && ctx->nranks == 1) {   // the fill kernel computed the discs on the fly
+    NK_TRY(csr_settle_bounds(A));
     *where = A->d_bounds;
     return NK_OK;
   }
@@ -763,7 +782,7 @@ static int build_transpose(nk_csr *A) {
     NK_TRY(nk_dev_alloc(&A->d_tz, (size_t)nt + 1));
     NK_TRY(nk_dev_alloc(&A->d_trecv, (size_t)A->halo.n_send + 1));
   }
-  A->t_values_stale = true; A->bounds_valid = false;
+  A->t_values_stale = true; A->bounds_valid = false; A->bounds_pending = false;
   return NK_OK;
 }
 
@@ -828,7 +847,7 @@ int nk_csr_colsumsq_dev(nk_csr *A, double *d_out) {
   }
   A->t_values_stale = false;                    // T holds the squares for this one product …
   const int st = nk_csr_spmv_t_dev(A, A->d_ones, d_out);
-  A->t_values_stale = true; A->bounds_valid = false;                     // … and must be refreshed before the next Aᵀ x
+  A->t_values_stale = true; A->bounds_valid = false; A->bounds_pending = false;                     // … and must be refreshed before the next Aᵀ x
   return st;
 }
 extern "C" int nk_csr_colsumsq(nk_csr *A, double *out, int memspace) {
@@ -865,7 +884,7 @@ int nk_csr_add_to_diagonal_dev(nk_csr *A, double sigma, const double *d_m) {
     NK_LAUNCH(A->ctx, k_add_diag, dim3((unsigned)((A->nrows + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), A->nrows,
               (const int32_t *)A->d_diagpos, sigma, d_m, A->d_val);
   NK_HIP(hipGetLastError());
-  A->t_values_stale = true; A->bounds_valid = false;
+  A->t_values_stale = true; A->bounds_valid = false; A->bounds_pending = false;
   return NK_OK;
 }
 
@@ -968,7 +987,7 @@ int nk_normal_plan_values(nk_normal_plan *Pn, nk_csr *J, double lambda, const do
               (const double *)J->d_val, lambda, d_diag, N->d_val);
     NK_HIP(hipGetLastError());
   }
-  N->t_values_stale = true; N->bounds_valid = false;
+  N->t_values_stale = true; N->bounds_valid = false; N->bounds_pending = false;
   return NK_OK;
 }
 

@@ -34,29 +34,7 @@ __device__ __forceinline__ void pub_progress(nk_gmres_pub *pub, uint64_t seq, in
 __global__ void k_gmres_begin(nk_gmres_ctl *ctl, const double *d_ss, double atol, double rtol, int fixed,
                               int first, double *g, double *s, int m, nk_gmres_pub *pub, uint64_t seq) {
   if (threadIdx.x != 0) return;
-  const double beta = sqrt(*d_ss);
-  if (first) {  // 1: a new solve; 2: the cycle after an s-step breakdown — same solve, same tolerance, flags cleared
-    if (first == 1) {
-      ctl->rnorm0 = beta;
-      ctl->tol = fixed ? -1.0 : atol + rtol * beta;
-    }
-    ctl->failed = 0;
-    ctl->converged = 0;
-  }
-  ctl->beta = beta;
-  ctl->rnorm = beta;
-  ctl->k = 0;
-  ctl->need_reorth = 0;
-  ctl->pad0 = 0;
-  const int bad = !(beta == beta) || isinf(beta);
-  if (bad) ctl->failed = 1;
-  if (!bad && (beta == 0.0 || (ctl->tol >= 0.0 && beta <= ctl->tol))) ctl->converged = 1;
-  ctl->done = (ctl->failed || ctl->converged) ? 1 : 0;
-  ctl->inv_hn = (beta > 0.0 && !bad) ? 1.0 / beta : 0.0;
-  s[0] = ctl->inv_hn;
-  g[0] = beta;
-  for (int i = 1; i <= m; ++i) g[i] = 0.0;
-  pub_progress(pub, seq, 0, ctl->done);
+  nk_gmres_begin_body(ctl, *d_ss, atol, rtol, fixed, first, g, s, m, pub, seq);
 }
 
 // DGKS test after the first projection: re-orthogonalise iff ‖w'‖² < ½‖w‖². pad0 is the "skip pass 2" flag.
@@ -616,11 +594,16 @@ __global__ __launch_bounds__(64) void k_givens(nk_gmres_ctl *ctl, double *h, con
 // y = R(0:k,0:k)^{-1} g(0:k), k = ctl->k. R is staged in LDS with batched loads; wave 0 runs the column-oriented
 // recurrence (lane t owns g_t: after y_i is known every lane t < i takes R_ti y_i off its entry) — k dependent steps instead
 // of k²/2 on one lane.
+// `fx` (s-step form, sb > 0): the cycle's last block was left at its first pass (nk_sstep.hip: no third sweep) — its columns
+// Q = (Q₁ − V C₂) R₂⁻¹ enter x += [V Q] y through the columns as they are: [V Q] y = V (y_k − C₂ b) + Q₁ b, b = R₂⁻¹ y_Q. The
+// same wavefront turns y into those coefficients (an sb × sb triangular solve and a k0 × sb product; a launch of its own took
+// 9 µs on one lane).
 __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, const double *__restrict__ R,
                                                    const double *__restrict__ g, double *__restrict__ y, int m,
-                                                   nk_gmres_pub *pub, uint64_t seq, const uint64_t *peer_err) {
+                                                   nk_gmres_pub *pub, uint64_t seq, const uint64_t *peer_err, const nk_ss_fix fx) {
   constexpr int LK = NK_MAX_NV + 1;  // odd stride: the column reads below are conflict-free
   __shared__ double sR[NK_MAX_NV * LK];
+  __shared__ double sC2[NK_MAX_NV * 16], sR2[16 * 16];
   const int k = ctl->k, failed = ctl->failed;
   const int t = threadIdx.x;
   if (pub != nullptr && t == 0) {  // what the host needs of the control block, then the release of the sequence word
@@ -651,6 +634,11 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
     for (int q = 0; q < 4; ++q)
       if (at[q] >= 0) sR[at[q]] = rv[q];
   }
+  const int fk0 = fx.k0, fsb = (fx.sb > 0 && !failed && k > fx.k0) ? fx.sb : 0;   // (a cycle that ended before the block: nothing of it in y)
+  if (fsb > 0) {
+    for (int e = t; e < fk0 * fsb; e += 256) sC2[e] = fx.C2[e];
+    if (t < fsb * fsb) sR2[t] = fx.R2[t];
+  }
   __syncthreads();
   if (t >= 64) return;
   if (t >= k) gv = 0.0;
@@ -659,6 +647,19 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
       const double yi = __shfl(gv, i, 64) / sR[i * LK + i];
       if (t < i) gv -= sR[t * LK + i] * yi;
       if (t == i) gv = yi;
+    }
+    if (fsb > 0) {
+      for (int c = fsb - 1; c >= 0; --c) {             // b = R₂⁻¹ y_Q on lanes k0 … k0 + sb − 1 (y is zero from k on)
+        const double bc = __shfl(gv, fk0 + c, 64) / sR2[c * fsb + c];
+        if (t >= fk0 && t < fk0 + c) gv -= sR2[(t - fk0) * fsb + c] * bc;
+        if (t == fk0 + c) gv = bc;
+      }
+      double acc = 0.0;
+      for (int c = 0; c < fsb; ++c) {
+        const double bc = __shfl(gv, fk0 + c, 64);
+        if (t < fk0) acc += sC2[t * fsb + c] * bc;
+      }
+      if (t < fk0) gv -= acc;
     }
   } else {
     gv = 0.0;
@@ -1487,7 +1488,7 @@ static int gmres_solve_graph(nk_gmres *G, const double *d_b, double *d_x, double
       for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step_1r(G, k, k == steps - 1));
       NK_TRY(arnoldi_flush_1r(G, steps));
       NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
-              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr));
+              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr), nk_ss_fix{0, 0, nullptr, nullptr});
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, true));
       return NK_OK;
     };
@@ -1556,6 +1557,9 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   // r0 = b − A x0, written straight into column 0 of the basis (un-normalised); zero initial guess: b → column 0 and
   // ‖b‖² in one pass, and the first solution update WRITES x = V y (no memset of x)
   bool have_ss = false, x_is_zero = false;
+  static const bool fused_begin_off = getenv("NK_SS_FUSED_BEGIN") && atoi(getenv("NK_SS_FUSED_BEGIN")) == 0;   // A/B switch
+  bool ss_from_partials = false;   // ‖b‖² is still per-workgroup partial sums in ctx->d_partials
+  int ss_grid = 0;
   // with a left preconditioner every residual that enters the basis is Pl⁻¹(b − A x): the norms of the solve are preconditioned
   auto residual_to_v0 = [&]() -> int {   // column 0 ← Pl⁻¹ (b − A x), x in the original space
     NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
@@ -1569,6 +1573,11 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     if (G->lprec_kind) {
       NK_TRY(lprec_apply(G, d_b, G->V, nullptr));
       return nk_blas_sumsq(ctx, n, G->V, G->d_ss);
+    }
+    if (!fused_begin_off && nk_ctx_is_single(ctx) && G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
+      // the s-step form's begin kernel reduces the partial sums itself (one rank)
+      ss_from_partials = true;
+      return nk_blas_copy_sumsq_stage1(ctx, n, d_b, G->V, &ss_grid);
     }
     return nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss);
   };
@@ -1587,8 +1596,16 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     if (!have_ss) NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
     have_ss = false;
     const uint64_t seq = ++G->cycle_seq;
-    NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol,
-                       fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m, G->h_pub_dev, seq);
+    if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
+      NK_TRY(nk_ss_begin_cycle(G, atol, rtol, fixed_iters > 0 ? 1 : 0, first, seq,
+                               ss_from_partials ? (const double *)ctx->d_partials : nullptr, ss_grid));
+    } else {
+      if (ss_from_partials)   // (a breakdown switched the solve to the column form between rhs → column 0 and this cycle)
+        NK_TRY(nk_blas_reduce_slots_allreduce(ctx, ctx->d_partials, ss_grid, 1, G->d_ss, nullptr));
+      NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol,
+                fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m, G->h_pub_dev, seq);
+    }
+    ss_from_partials = false;
     first = 0;
     const bool x_is_zero_before = x_is_zero;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
@@ -1653,8 +1670,8 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns); the back-substitution also publishes the control
     // block's outcome to the host
     NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
-              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr));
-    if (G->ortho == NK_ORTHO_SSTEP) NK_TRY(nk_ss_fix_solution_coefficients(G));   // (the last block never got its second update)
+              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr),
+              G->ortho == NK_ORTHO_SSTEP ? nk_ss_take_last_block(G) : nk_ss_fix{0, 0, nullptr, nullptr});
     if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
     } else {

@@ -257,6 +257,9 @@ struct nk_csr {
   double *d_gersh = nullptr;     // per-row-block Gershgorin bounds (nk_csr_gershgorin_dev)
   double *d_bounds = nullptr;    // {−lo, hi} left by a fill kernel that computes the discs on the fly (valid while bounds_valid)
   int gersh_cap = 0;             // doubles allocated behind d_gersh
+  const double *bounds_part = nullptr;   // a fill kernel's {max −lo, max hi} per block, not reduced into d_bounds yet
+  int bounds_nblk = 0;
+  bool bounds_pending = false;
   bool bounds_valid = false, raw_exposed = false;  // raw_exposed: nk_csr_values_device handed the value array out — never trust a cache
   int32_t *d_csc_src = nullptr;  // created from CSC arrays: index of every local entry in that call's nzval
   double *d_csc_stage = nullptr; // staging for host nzval (nk_csr_set_values_csc)
@@ -483,7 +486,49 @@ int nk_csr_bounds_from_partials(nk_csr *A, const double *d_part, int nblk);   //
 bool nk_ss_eligible(const nk_gmres *G);
 int nk_ss_prepare(nk_gmres *G);   // once per linear solve: Newton basis (spectrum bounds known) or monomial
 int nk_ss_block_width(int want);
-int nk_ss_fix_solution_coefficients(nk_gmres *G);
+// start of a restart cycle (thread 0 of k_gmres_begin / of the s-step form's k_ss_cycle_begin): β = ‖r₀‖ from its square,
+// tolerance of a new solve, flags, the first column's scale, the right-hand side of the small least-squares problem
+#ifdef __HIPCC__
+__device__ __forceinline__ void nk_gmres_begin_body(nk_gmres_ctl *ctl, double ss, double atol, double rtol, int fixed, int first,
+                                                    double *g, double *s, int m, nk_gmres_pub *pub, uint64_t seq) {
+  const double beta = sqrt(ss);
+  if (first) {  // 1: a new solve; 2: the cycle after an s-step breakdown — same solve, same tolerance, flags cleared
+    if (first == 1) {
+      ctl->rnorm0 = beta;
+      ctl->tol = fixed ? -1.0 : atol + rtol * beta;
+    }
+    ctl->failed = 0;
+    ctl->converged = 0;
+  }
+  ctl->beta = beta;
+  ctl->rnorm = beta;
+  ctl->k = 0;
+  ctl->need_reorth = 0;
+  ctl->pad0 = 0;
+  const int bad = !(beta == beta) || isinf(beta);
+  if (bad) ctl->failed = 1;
+  if (!bad && (beta == 0.0 || (ctl->tol >= 0.0 && beta <= ctl->tol))) ctl->converged = 1;
+  ctl->done = (ctl->failed || ctl->converged) ? 1 : 0;
+  ctl->inv_hn = (beta > 0.0 && !bad) ? 1.0 / beta : 0.0;
+  s[0] = ctl->inv_hn;
+  g[0] = beta;
+  for (int i = 1; i <= m; ++i) g[i] = 0.0;
+  if (pub != nullptr)
+    __hip_atomic_store(&pub->progress, (seq << 16) | (uint64_t)(ctl->done ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+// s-step form: the cycle's begin kernel (gmres begin + the block basis' shifts and scales; on one rank also the stage-2
+// reductions of ‖b‖² and of the Jacobian fill's Gershgorin partials, which are launches of their own otherwise)
+int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
+                      int ss_grid);
+// fill kernels' Gershgorin partials not reduced yet: hands them to a caller that reduces them into *dst in its own kernel
+bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
+int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
+int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
+                               double *h_out);
+// the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
+struct nk_ss_fix { int k0, sb; const double *C2, *R2; };
+nk_ss_fix nk_ss_take_last_block(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
 void nk_ss_destroy(struct nk_sstep *W);

@@ -555,7 +555,7 @@ static int user_lin_J(nk_problem *P, const double *d_u) {
   if (P->cb.jac_values) {
     if (P->cb.jac_values(P->user, d_u, P->lin_J->d_val, (void *)P->ctx->stream) != 0)
       NK_FAIL(NK_E_CALLBACK, "jac_values callback failed");
-    P->lin_J->t_values_stale = true; P->lin_J->bounds_valid = false;
+    P->lin_J->t_values_stale = true; P->lin_J->bounds_valid = false; P->lin_J->bounds_pending = false;
   } else {
     NK_TRY(nk_problem_jac_colored_dev(P, d_u, P->lin_J));
   }
@@ -838,7 +838,7 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
-  J->t_values_stale = true; J->bounds_valid = false;
+  J->t_values_stale = true; J->bounds_valid = false; J->bounds_pending = false;
   if (n == 0) return NK_OK;
   nk_prof_scope prof_(ctx, NK_K_JACFILL, 8.0 * (double)J->nnz + 8.0 * (double)n);
   switch (P->kind) {
@@ -1097,7 +1097,7 @@ int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J) {
     NK_LAUNCH(ctx, k_decompress, dim3(grid1(n)), dim3(NK_BLOCK), n, J->d_rowptr, J->d_nnzcolor, c, J->d_B, J->d_val);
   }
   NK_HIP(hipGetLastError());
-  J->t_values_stale = true; J->bounds_valid = false;
+  J->t_values_stale = true; J->bounds_valid = false; J->bounds_pending = false;
   return NK_OK;
 }
 

@@ -257,8 +257,7 @@ static double *spare_u(nk_solver *S) {
 // ‖fu‖∞ and ‖fu‖₂² of the current residual (+ optionally the stall norm's partial sums) → ONE stage-2 launch, one fetch
 static int residual_norms(nk_solver *S, const double *stall_partials, int stall_n, double *step_norm) {
   double v[3] = {0, 0, 0};
-  NK_TRY(nk_blas_norms_inf2(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n));
-  NK_TRY(fetch(S, stall_partials ? 3 : 2, v));
+  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v));
   S->fnorm_inf = v[0];
   S->fnorm2 = sqrt(v[1]);
   if (step_norm) *step_norm = sqrt(v[2]);

@@ -376,28 +376,8 @@ __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta)
 // in x += [V_k Q] y —, and that product can be taken from the columns as pass 1 left them:
 //     [V_k Q] y = V_k (y_k − C₂ b) + Q₁ b,   b = R₂⁻¹ y_Q
 // (a restart forms r = b − A x afresh and starts a new basis). One sweep over k + 2s columns less per cycle — 386 MB of the
-// 1.7 GB the sweeps of a 1024² cycle moved — for an s × s triangular solve and a k × s product on one wavefront.
-// k0 = columns in front of the block, sb = its width; y is zero from ctl->k on, so b has y_Q's support.
-__global__ __launch_bounds__(64) void k_ss_fix_y(const nk_gmres_ctl *ctl, int k0, int sb, const double *__restrict__ C2,
-                                                 const double *__restrict__ R2, double *__restrict__ y) {
-  __shared__ double b[SS_SMAX];
-  if (ctl->failed == 2 || ctl->k <= k0) return;   // a breakdown leaves y = 0; a cycle that ended before this block has nothing in it
-  const int t = threadIdx.x;
-  if (t == 0) {
-    for (int c = sb - 1; c >= 0; --c) {           // back substitution with the upper-triangular R₂
-      double v = (k0 + c < ctl->k) ? y[k0 + c] : 0.0;
-      for (int cc = c + 1; cc < sb; ++cc) v -= R2[c * sb + cc] * b[cc];
-      b[c] = v / R2[c * sb + c];
-    }
-    for (int c = 0; c < sb; ++c) y[k0 + c] = b[c];
-  }
-  __syncthreads();
-  for (int j = t; j < k0; j += 64) {
-    double v = y[j];
-    for (int c = 0; c < sb; ++c) v -= C2[j * sb + c] * b[c];
-    y[j] = v;
-  }
-}
+// 1.7 GB the sweeps of a 1024² cycle moved — for an s × s triangular solve and a k × s product inside the back-substitution
+// kernel (k_backsolve's `fx`, nk_gmres.hip).
 
 // coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
 // then R (S × S, row-major, upper triangular, its diagonal replaced by the reciprocals: the form the substitution takes)
@@ -598,26 +578,27 @@ bool nk_ss_fusable(int k, int s) {
   static const bool off = getenv("NK_SS_FUSED") && atoi(getenv("NK_SS_FUSED")) == 0;
   return !off && ss_class(k, s) != 0;
 }
-// persistent workgroups per CU: bounded by the LDS tile (+ the fused scalar workspace) and the register-resident classes'
-// VGPR footprint (228 / 152 / 92 with the Gram accumulators)
-static int ss_per_cu(int k, int s, size_t lds) {
-  int per_cu = lds ? (int)((size_t)(160 * 1024) / lds) : SS_MAX_WG_PER_CU;   // 160 KB of LDS per CU
-  per_cu = per_cu < 1 ? 1 : (per_cu > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : per_cu);
-  if (k + s > 32 && per_cu > 2) per_cu = 2;
-  else if (k + s > 16 && per_cu > 3) per_cu = 3;
-  return per_cu;
+// persistent workgroups per CU = what the runtime says a CU holds of the instance that will run (LDS tile and register
+// footprint: 190–196 VGPRs for the Gram sweeps of a 15-column block behind 16 columns — two workgroups, not the three a table
+// of size classes once said; the third of every CU ran as a second round on a third of the chip), queried once per shape
+int nk_ss_sweep_occupancy(nk_ctx *ctx, int mode, int k, int s);
+static int ss_per_cu(nk_ctx *ctx, int k, int s) {
+  static const int forced = getenv("NK_SS_PER_CU") ? atoi(getenv("NK_SS_PER_CU")) : 0;   // A/B switch
+  if (forced > 0) return forced > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : forced;
+  const int a = nk_ss_sweep_occupancy(ctx, 0, k, s), b = nk_ss_sweep_occupancy(ctx, 1, k, s);
+  int per_cu = a < b ? a : b;
+  return per_cu < 1 ? 1 : (per_cu > SS_MAX_WG_PER_CU ? SS_MAX_WG_PER_CU : per_cu);
 }
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  const size_t lds = ss_lds_bytes(k, s, true);
-  int g = ctx->num_cus * ss_per_cu(k, s, lds);
+  int g = ctx->num_cus * ss_per_cu(ctx, k, s);
   if (g > ntiles) g = ntiles;
   return g > 0 ? g : 1;
 }
 
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
-                       const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
+                       const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out = nullptr) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
   const int cls = ss_class(k, S);
   // "fused" now names ONE thing: sweep C whose workgroup 0 derives the block's Hessenberg columns while the others stream
@@ -631,13 +612,15 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   std::memset(&ta, 0, sizeof(ta));
   if (tap) ta = *tap;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
+  const bool ev = !occ_out && ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
 #define SS_GO3(UPD, GRM, KM, FS)                                                                                          \
   do {                                                                                                                    \
     if (lds > 64 * 1024)                                                                                                  \
       NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block<S, UPD, GRM, KM, FS>),                        \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
-    if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
+    if (occ_out) {                                                                                                        \
+      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block<S, UPD, GRM, KM, FS>, SS_R, lds));          \
+    } else if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
                                   k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off);                           \
     else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef, \
                             partials, d_skip, ntiles, ta, mark, ws_off);                                                  \
@@ -653,10 +636,13 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
   else {                                    // sweep C: update only — no LDS tile
-    // as many workgroups as the register footprint lets a CU hold (tools/kernel_resources.py), + the Hessenberg workgroup
-    const int per_cu = S > 8 ? (cls == 2 ? 3 : (cls == 3 ? 2 : 4)) : 6;
-    g = ctx->num_cus * per_cu < ntiles ? ctx->num_cus * per_cu : ntiles;
-    if (fuse) g += 1;
+    // as many workgroups as the register footprint lets a CU hold (≤ 6), + the Hessenberg workgroup
+    if (!occ_out) {
+      int per_cu = nk_ss_sweep_occupancy(ctx, 2, k, S);
+      per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
+      g = ctx->num_cus * per_cu < ntiles ? ctx->num_cus * per_cu : ntiles;
+      if (fuse) g += 1;
+    }
     SS_GO(true, false);
   }
 #undef SS_GO
@@ -665,25 +651,46 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   return NK_OK;
 }
 // mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
-int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
+static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
+                             const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out) {
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
   switch (s) {
-    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
-    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark);
+    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
     default: NK_FAIL(NK_E_INVALID, "internal: no s-step sweep for a block of %d columns", s);
   }
+}
+int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
+  return ss_sweep_dispatch(ctx, mode, n, k, s, V, ldv, coef, partials, d_skip, grid, tap, mark, nullptr);
+}
+// workgroups of sweep `mode` for a block of s columns behind k that a CU holds at once (cached per shape)
+int nk_ss_sweep_occupancy(nk_ctx *ctx, int mode, int k, int s) {
+  static int cache[3][SS_SMAX + 1][16 * SS_MTMAX + 1];
+  if (mode < 0 || mode > 2 || s < 1 || s > SS_SMAX || k < 0 || k + s > 16 * SS_MTMAX) return 1;
+  int &c = cache[mode][s][k + s];
+  if (c == 0) {
+    int occ = 0;
+    ss_tail_args ta;
+    std::memset(&ta, 0, sizeof(ta));
+    // (sweep C is asked about in its fused form when the shape has one: the Hessenberg workspace is part of its LDS)
+    if (ss_sweep_dispatch(ctx, mode, 1, k, s, nullptr, 0, nullptr, nullptr, nullptr, 1, (mode == 2 && ss_class(k, s) != 0) ? &ta : nullptr,
+                          nullptr, &occ) != NK_OK || occ < 1)
+      occ = 1;
+    c = occ;
+  }
+  return c;
 }
 // widths the sweeps are compiled for; any other block is cut into these (the last block of a cycle, odd block sizes)
 int nk_ss_block_width(int want) {
@@ -740,11 +747,20 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
       __threadfence_system();
     } else {
       red[entry] = v;
-      __threadfence();
     }
   }
+  // hand-off to the last workgroup (any XCD): plain stores → barrier → ONE agent-scope release (+ the wait the compiler may
+  // drop behind it) → ticket; the workgroup that takes the last ticket → ONE agent-scope acquire → barrier → loads
   __syncthreads();
-  if (t == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  if (t == 0) {
+    if (!PEER) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned int last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_last = last;
+  }
   __syncthreads();
   if (!s_last) return;
   SS_STAMP(1);
@@ -861,20 +877,80 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   return NK_OK;
 }
 
-// start of a cycle (after k_gmres_begin): the shifts and the scale of the block basis, the scale of the first operator
-// application. newton: `ival` = {−lo, hi} bounds the spectrum; θ_j = c + h·t_j with t the Leja-ordered Chebyshev points of
-// [−1, 1] and σ = the interval's capacity h/2 rounded to a power of two (exact in binary floating point; the basis
-// polynomials then stay O(1) on the interval). Degenerate bounds fall back to the monomial basis: θ = 0, σ ≈ ‖A v₁‖.
-__global__ void k_ss_begin(const double *__restrict__ s, double *scal, const double *__restrict__ ival,
-                           const double *__restrict__ nodes, int ns) {
-  if (threadIdx.x != 0) return;
+// Start of a cycle, s-step form — ONE launch for what were up to four (k_reduce_sum of ‖b‖², k_max2_final of the Jacobian
+// fill's Gershgorin partials, k_gmres_begin, the block basis' set-up):
+//  * ss_part != nullptr (one rank, zero initial guess): ‖b‖² is still per-workgroup partial sums — summed here in
+//    k_reduce_sum's order (bit-identical);
+//  * bpart != nullptr (one rank): {max −lo, max hi} per row block → `ival` (the matrix's bounds cache), max is order-free;
+//  * thread 0: the cycle's begin (nk_gmres_begin_body), then the shifts and the scale of the block basis and the scale of the
+//    first operator application. newton: `ival` = {−lo, hi} bounds the spectrum; θ_j = c + h·t_j with t the Leja-ordered
+//    Chebyshev points of [−1, 1] and σ = the interval's capacity h/2 rounded to a power of two (exact in binary floating point;
+//    the basis polynomials then stay O(1) on the interval). Degenerate bounds fall back to the monomial basis: θ = 0, σ ≈ ‖A v₁‖.
+struct ss_begin_args {
+  nk_gmres_ctl *ctl;
+  double *d_ss, *g, *s, *scal, *ival;
+  const double *ss_part, *bpart, *nodes;
+  nk_gmres_pub *pub;
+  uint64_t seq;
+  double atol, rtol;
+  int fixed, first, m, ss_grid, bnblk, ns, newton;
+};
+__global__ __launch_bounds__(256) void k_ss_cycle_begin(const ss_begin_args a) {
+  __shared__ double sm[12];
+  const int t = threadIdx.x, wv = t >> 6;
+  double v = 0.0, blo = -INFINITY, bhi = -INFINITY;
+  if (a.ss_part != nullptr)
+    for (int i = t; i < a.ss_grid; i += 256) v += a.ss_part[i];
+  if (a.bpart != nullptr) {
+    for (int base = 0; base < a.bnblk; base += 2048) {   // sixteen loads in flight per lane (a rolled loop: one round trip each)
+      double x[8], y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + t + 256 * j, ic = i < a.bnblk ? i : a.bnblk - 1;   // (clamped: max is idempotent)
+        x[j] = a.bpart[ic];
+        y[j] = a.bpart[a.bnblk + ic];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { blo = fmax(blo, x[j]); bhi = fmax(bhi, y[j]); }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o, 64);
+    blo = fmax(blo, __shfl_xor(blo, o, 64));
+    bhi = fmax(bhi, __shfl_xor(bhi, o, 64));
+  }
+  if ((t & 63) == 0) { sm[wv] = v; sm[4 + wv] = blo; sm[8 + wv] = bhi; }
+  __syncthreads();
+  if (t != 0) return;
+  double ss;
+  if (a.ss_part != nullptr) {
+    ss = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    *a.d_ss = ss;
+  } else {
+    ss = *a.d_ss;
+  }
+  double lo_neg = 0.0, hi = 0.0;
+  if (a.newton) {
+    if (a.bpart != nullptr) {
+      lo_neg = fmax(fmax(sm[4], sm[5]), fmax(sm[6], sm[7]));
+      hi = fmax(fmax(sm[8], sm[9]), fmax(sm[10], sm[11]));
+      a.ival[0] = lo_neg;
+      a.ival[1] = hi;
+    } else {
+      lo_neg = a.ival[0];
+      hi = a.ival[1];
+    }
+  }
+  nk_gmres_begin_body(a.ctl, ss, a.atol, a.rtol, a.fixed, a.first, a.g, a.s, a.m, a.pub, a.seq);
+  double *scal = a.scal;
   double sigma = scal[3];
   double newton = 0.0;
-  if (ival != nullptr) {
-    const double lo = -ival[0], hi = ival[1];
+  if (a.newton) {
+    const double lo = -lo_neg;
     const double c = 0.5 * (lo + hi), h = 0.5 * (hi - lo);
     if (h > 0.0 && !isinf(h) && c == c && !isinf(c)) {
-      for (int j = 0; j < ns; ++j) scal[SS_TH + j] = c + h * nodes[j];
+      for (int j = 0; j < a.ns; ++j) scal[SS_TH + j] = c + h * a.nodes[j];
       sigma = exp2(rint(log2(0.5 * h)));
       newton = 1.0;
     }
@@ -886,7 +962,7 @@ __global__ void k_ss_begin(const double *__restrict__ s, double *scal, const dou
   scal[3] = sigma;
   scal[2] = sigma;
   scal[1] = 1.0 / sigma;
-  scal[0] = s[0] / sigma;
+  scal[0] = a.s[0] / sigma;
 }
 
 // development hook (not in the public header): the first block of restart cycle `cycle` of the next solves reports a
@@ -936,6 +1012,8 @@ struct nk_sstep {
   unsigned int *ticket = nullptr;            // last-workgroup ticket of k_ss_reduce_factor
   double *ival = nullptr, *nodes = nullptr;  // {−lo, hi} of the spectrum; Leja-ordered Chebyshev points for nodes_s columns
   const double *ival_use = nullptr;          // where this solve's bounds are: `ival`, or the matrix's cache (left by its fill kernel)
+  const double *bpart = nullptr;             // the fill kernel's per-block bounds, to be reduced into ival_use by the next begin kernel
+  int bnblk = 0;
   int nodes_s = 0;
   bool newton = false;                       // this solve builds Newton-basis blocks
 };
@@ -981,6 +1059,16 @@ int nk_ss_prepare(nk_gmres *G) {
   W->newton = false;
   if (G->ss_basis == NK_SS_BASIS_MONOMIAL) return NK_OK;
   bool have = false;
+  W->bpart = nullptr;
+  {  // a concrete Jacobian whose fill kernel left per-block Gershgorin bounds: this solve's first begin kernel reduces them
+    double *dst = nullptr;
+    if (!G->ss_ival_user && !G->prec_kind && !G->lprec_kind && !G->normal && G->shift == 0.0 && G->op_kind == 1 &&
+        G->A->nblocks > 0 && nk_csr_take_pending_bounds(G->A, &W->bpart, &W->bnblk, &dst)) {
+      W->ival_use = dst;
+      W->newton = true;
+      return NK_OK;
+    }
+  }
   NK_TRY(nk_gmres_spectrum_interval_dev(G, W->ival, &W->ival_use, &have));
   if (!have) {
     if (G->ss_basis == NK_SS_BASIS_NEWTON)
@@ -1012,14 +1100,43 @@ static bool ss_skip_last_sweep() {
   static const bool off = getenv("NK_SS_LAST_SWEEP") && atoi(getenv("NK_SS_LAST_SWEEP")) != 0;   // A/B switch: run it anyway
   return !off;
 }
-// after the back-substitution of a cycle whose last block was left at its first pass: y → coefficients on the stored columns
-int nk_ss_fix_solution_coefficients(nk_gmres *G) {
-  if (G->ss_last_sb <= 0 || !G->ss) return NK_OK;
-  nk_sstep *W = G->ss;
-  NK_LAUNCH(G->ctx, k_ss_fix_y, dim3(1), dim3(64), (const nk_gmres_ctl *)G->d_ctl, G->ss_last_k0, G->ss_last_sb, (const double *)W->C2,
-            (const double *)W->R2, G->d_y);
-  NK_HIP(hipGetLastError());
+// for the back-substitution of a cycle whose last block was left at its first pass: what turns y into coefficients on the
+// stored columns (k_backsolve, nk_gmres.hip)
+nk_ss_fix nk_ss_take_last_block(nk_gmres *G) {
+  nk_ss_fix fx{0, 0, nullptr, nullptr};
+  if (G->ss_last_sb > 0 && G->ss) {
+    fx.k0 = G->ss_last_k0;
+    fx.sb = G->ss_last_sb;
+    fx.C2 = G->ss->C2;
+    fx.R2 = G->ss->R2;
+  }
   G->ss_last_sb = 0;
+  return fx;
+}
+
+// The cycle's begin kernel (k_ss_cycle_begin). ss_partials: ‖b‖² as per-workgroup partial sums (one rank), else G->d_ss holds it.
+int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
+                      int ss_grid) {
+  nk_ctx *ctx = G->ctx;
+  NK_TRY(ss_workspace(G));
+  nk_sstep *W = G->ss;
+  const int s = nk_ss_block_size(G);
+  if (W->newton && W->nodes_s != s) {
+    double h_nodes[SS_SMAX] = {0};
+    NK_TRY(nk_ss_leja_nodes(s, h_nodes));
+    NK_HIP(hipMemcpyAsync(W->nodes, h_nodes, SS_SMAX * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));  // (h_nodes is a stack array; once per block size)
+    W->nodes_s = s;
+  }
+  ss_begin_args a;
+  a.ctl = G->d_ctl; a.d_ss = G->d_ss; a.g = G->d_g; a.s = G->d_s; a.scal = W->scal;
+  a.ival = const_cast<double *>(W->newton ? W->ival_use : (const double *)W->ival);
+  a.ss_part = ss_partials; a.bpart = W->newton ? W->bpart : nullptr; a.nodes = W->nodes;
+  a.pub = G->h_pub_dev; a.seq = seq; a.atol = atol; a.rtol = rtol;
+  a.fixed = fixed; a.first = first; a.m = G->m; a.ss_grid = ss_grid; a.bnblk = W->bnblk; a.ns = s; a.newton = W->newton ? 1 : 0;
+  NK_LAUNCH(ctx, k_ss_cycle_begin, dim3(1), dim3(256), a);
+  NK_HIP(hipGetLastError());
+  W->bpart = nullptr;   // (reduced by this launch; later cycles of the solve read the bounds where it left them)
   return NK_OK;
 }
 
@@ -1032,19 +1149,10 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   nk_sstep *W = G->ss;
   const int64_t n = G->n, ldv = G->ldv;
   const int s = nk_ss_block_size(G);
-  if (W->newton && W->nodes_s != s) {
-    double h_nodes[SS_SMAX] = {0};
-    NK_TRY(nk_ss_leja_nodes(s, h_nodes));
-    NK_HIP(hipMemcpyAsync(W->nodes, h_nodes, SS_SMAX * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    NK_HIP(hipStreamSynchronize(ctx->stream));  // (h_nodes is a stack array; once per block size)
-    W->nodes_s = s;
-  }
   const int *done = &G->d_ctl->done, *skipC = &G->d_ctl->pad1;
   ss_tail_args ta;
   ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.C2 = W->C2; ta.R2 = W->R2; ta.H = W->H; ta.m = G->m;
   ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
-  NK_LAUNCH(ctx, k_ss_begin, dim3(1), dim3(64), (const double *)G->d_s, W->scal,
-            W->newton ? W->ival_use : (const double *)nullptr, (const double *)W->nodes, s);
   if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
   G->ss_last_sb = 0;
