@@ -9,12 +9,16 @@ Workload `c3` (default; config C3 of BASELINE.md, the configuration the metric i
 (N = 1 048 576 unknowns, nnz = 5 238 784, λ = 6, u0 = 0), NewtonRaphson with the *fixed-work* Krylov protocol of
 SURVEY.md §8d — exactly 30 Arnoldi steps of GMRES(30) per Newton step (a 30-column orthonormal Krylov basis, the
 30-dimensional least-squares problem solved through Givens rotations), zero initial guess — on the assembled CSR Jacobian
-(values refilled every step, SpMV as the operator). The Arnoldi process is the s-step form (`--ortho sstep`, s = 6 columns per
-block: 30 SpMVs, then per block three sweeps over the basis with the Gram blocks on the FP64 matrix cores; csrc/nk_sstep.hip) —
-the same Krylov space and the same minimisation as column-by-column CGS2, iterates equal to 1e-12 (tests/test_gpu_sstep.py,
-incl. this very protocol at full size against the C oracle); `--ortho dcgs2` runs the column-by-column form of rounds 1–2
-(delayed CGS2: two sweeps and one reduction per column). A "step" is one such Newton step: Jacobian value fill + 30 SpMVs +
-the orthogonalisation sweeps + solution update + u += δu + residual + ‖·‖∞ + termination bookkeeping, everything resident in HBM.
+(values refilled every step, SpMV as the operator). The Arnoldi process is the LIBRARY DEFAULT: the s-step form with the
+automatic block size and basis (`--ortho sstep --sstep 0 --sstep-basis auto`) — two blocks of 15 Newton-basis columns per cycle
+(shifts = Leja-ordered Chebyshev points of the Jacobian's Gershgorin interval), 30 SpMVs, per block three sweeps over the basis
+with the Gram blocks on the FP64 matrix cores, the last block left at its first pass (csrc/nk_sstep.hip) — the same Krylov space
+and the same minimisation as column-by-column CGS2, iterates equal to 1e-10 over 20 Newton steps (tests/test_gpu_sstep.py: this
+very protocol at full size against the C oracle); `--ortho dcgs2` runs the column-by-column form of rounds 1–2 (delayed CGS2:
+two sweeps and one reduction per column), `--sstep 6 --sstep-basis monomial` round 2's blocks. A "step" is one such Newton step:
+Jacobian value fill + 30 SpMVs + the orthogonalisation sweeps + solution update + u += δu + residual + ‖·‖∞ + termination
+bookkeeping, everything resident in HBM. Defaults: 100 timed steps after 5 warm-up steps (≈ 0.1 s of GPU time; the CPU leg's
+bounded sample and the time-to-tolerance extras dominate the wall clock of the default run).
 
 N > 1 is STRONG scaling on the metric's configuration: the same 1024² problem row-partitioned by grid lines over N
 ranks (halo lines + Krylov inner products over xGMI: peer-mapped buffers, RCCL as fallback); `value` is the plain
@@ -22,11 +26,13 @@ global Newton steps/s. `--workload c4` is Bratu 4096² (config C4), `--workload 
 step (config C5) — both row-partitioned over N ranks as well. A weak-scaling run (every rank owns ≈1024² unknowns of a
 (1024·√N)² grid) is reported under the extra key `weak_scaling` when N > 1.
 
-Extra objects on the JSON line: `roofline` (CSR SpMV kernel, HIP-event timed on the launch stream in a second,
-instrumented pass of the same K steps), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
-tuned C/OpenMP restatement of the same step — first-touch placement, one persistent parallel region, the same
-delayed-CGS2 — timed on this box's host cores on a bounded sample, next to the box's STREAM triad, its CSR SpMV rate
-and a single-thread figure).
+Extra objects on the JSON line: `roofline` (the time-dominant kernel family of the step — the CSR SpMV — HIP-event timed on
+the launch stream in a second, instrumented pass of the same K steps; `traffic` from the newest PMC summary under profiles/),
+`roofline_step` (bytes every kernel of the step must move ÷ ms_per_step), `step_time_stats` (median / p10 / p90 of the per-step
+times from one event per step inside the timed region), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
+tuned C/OpenMP restatements of the same step — delayed CGS2 and the Newton-basis s-step form, median of 5 sustained samples
+each at a thread count chosen by sustained samples; value = the faster — next to the box's STREAM triad, its CSR SpMV rate and
+a single-thread figure), `config.comm_selfcheck` for N > 1 (tools/multi_gpu_selfcheck.py's verdict on the negotiated transport).
 """
 import argparse
 import json
