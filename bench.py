@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling run")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance extras")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto: at N = 1 measure roofline.traffic in this run (two short rocprofv3 --pmc child passes of this "
+                         "script: FETCH_SIZE, WRITE_SIZE); falls back to the newest PMC summary under profiles/")
     return ap.parse_args()
 
 
@@ -88,6 +91,52 @@ def self_launch(args):
 
 
 STEP_STATS = {}
+
+
+def live_pmc_traffic(args, kname):
+    """HBM bytes per launch of kernel `kname` from the PMC counters, measured in THIS run: two short child passes of this script
+    under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in passes of their own, kernel trace only — the
+    collection MI355X_MICROARCH.md prescribes), traffic = (2·FETCH_SIZE + WRITE_SIZE)·1024: both counters are in KiB and on gfx950
+    FETCH_SIZE tallies 64 B per 128-B request of a coalesced stream. Returns (None, None) when rocprofv3 is missing or a pass
+    fails or times out — the caller then reads the newest committed summary."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--no-profile-pass",
+             "--no-ttt", "--pmc", "off", "--workload", args.workload, "--ortho", args.ortho, "--sstep", str(args.sstep),
+             "--sstep-basis", args.sstep_basis, "--arnoldi", str(args.arnoldi)]
+    if args.n:
+        child += ["--grid", str(args.n)]
+    if args.matfree:
+        child += ["--matfree"]
+    env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_CHILD="1")
+    vals = {}
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="nk_pmc_", dir="/tmp")
+            try:
+                subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+                acc = []
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r.get("Counter_Name") == counter and r.get("Kernel_Name", "").replace("void ", "").startswith(kname):
+                            acc.append(float(r["Counter_Value"]))
+                if not acc:
+                    return None, None
+                vals[counter] = sum(acc) / len(acc)
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception:  # noqa: BLE001
+        return None, None
+    traffic = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    return traffic, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes of 8 steps, "
+                     f"{time.perf_counter() - t0:.0f} s), (2·F + W)·1024")
 
 
 def timed_steps(cache, steps, barrier, dist, world, backend, torch):
@@ -271,22 +320,26 @@ def main():
     if dom in kernels:
         k = kernels[dom]
         kname = "k_spmv_stream" if dom == "spmv" else "k_bratu_jvp"
-        # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE/WRITE_SIZE,
-        # separate --pmc runs, gfx950 ×2 correction on FETCH_SIZE — tools/pmc_summary.py). bench.py cannot collect
-        # PMC counters itself; the same kernel at the same size is a per-launch constant. null if no profile.
+        # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 ×2 correction on
+        # FETCH_SIZE): measured in this run by two short rocprofv3 child passes (live_pmc_traffic); if that is not possible,
+        # the newest summary committed under profiles/ (the same kernel at the same size is a per-launch constant); else null.
         traffic, tsrc = None, None
-        try:
-            import glob
-            tag = {"c3": "", "c4": "c4size_1gpu_"}.get(args.workload)
-            cand = sorted(c for c in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_pmc.json"))
-                          if tag is not None and (("c4size" in c) == (tag != "")))
-            if cand and world == 1 and not args.n:
-                pm = json.load(open(cand[-1]))
-                for key, v in pm.items():
-                    if key.startswith(kname):
-                        traffic, tsrc = int(v["hbm_bytes_per_launch"]), os.path.basename(cand[-1])
-        except Exception:  # noqa: BLE001
-            pass
+        under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if args.pmc == "auto" and world == 1 and not os.environ.get("BENCH_PMC_CHILD") and not under_profiler:
+            traffic, tsrc = live_pmc_traffic(args, kname)
+        if traffic is None:
+            try:
+                import glob
+                tag = {"c3": "", "c4": "c4size_1gpu_"}.get(args.workload)
+                cand = sorted(c for c in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_pmc.json"))
+                              if tag is not None and (("c4size" in c) == (tag != "")))
+                if cand and world == 1 and not args.n:
+                    pm = json.load(open(cand[-1]))
+                    for key, v in pm.items():
+                        if key.startswith(kname):
+                            traffic, tsrc = int(v["hbm_bytes_per_launch"]), "committed summary profiles/" + os.path.basename(cand[-1])
+            except Exception:  # noqa: BLE001
+                pass
         roof = {"kernel": kname, "bound": "hbm",
                 "achieved": round(k["gbps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k["gbps"] / HBM_PEAK_GBS, 4),

@@ -8,8 +8,8 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
-timeout 400 python bench.py > $O/bench_csr.json 2> $O/bench_csr.err
-B="--cpu-seconds 0 --no-ttt"
+timeout 700 python bench.py > $O/bench_csr.json 2> $O/bench_csr.err
+B="--cpu-seconds 0 --no-ttt --pmc off"
 timeout 200 python bench.py $B --matfree > $O/bench_matfree.json 2> /dev/null
 timeout 200 python bench.py $B --ortho dcgs2 > $O/bench_csr_dcgs2.json 2> /dev/null
 timeout 200 python bench.py $B --sstep 6 --sstep-basis monomial > $O/bench_csr_sstep6_monomial.json 2> /dev/null
