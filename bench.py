@@ -121,7 +121,7 @@ def live_pmc_traffic(args, kname):
             d = tempfile.mkdtemp(prefix="nk_pmc_", dir="/tmp")
             try:
                 subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
-                               cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+                               cwd="/tmp", env=env, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
                 acc = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
