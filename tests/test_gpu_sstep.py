@@ -343,3 +343,55 @@ def test_block_size_is_validated(nls):
     with pytest.raises(nls.NKError, match="block size"):
         nls.GMRES(100, restart=30, ortho="sstep", sstep=-1)
     nls.GMRES(100, restart=30, ortho="sstep", sstep=0)   # automatic
+
+
+def _convection_diffusion(n, peclet, scale_rows=False):
+    """−Δu + (β·∇)u on an n × n grid, first-order upwind: a nonsymmetric M-matrix whose spectrum leaves the real axis as the
+    cell Péclet number grows; optionally with rows scaled over two decades (Gershgorin bounds far wider than the bulk of the
+    spectrum; restarted GMRES(30) then needs ≈ 1000 iterations)."""
+    import scipy.sparse as sp
+    h = 1.0 / (n + 1)
+    e = np.ones(n)
+    T = sp.diags([-e[:-1], 2 * e, -e[:-1]], [-1, 0, 1]) / h ** 2
+    bx, by = peclet * 2.0 / h, 0.5 * peclet * 2.0 / h
+    Cx = sp.diags([-e[:-1], e], [-1, 0]) * (bx / h)          # upwind differences (β > 0)
+    Cy = sp.diags([-e[:-1], e], [-1, 0]) * (by / h)
+    I = sp.identity(n)
+    A = (sp.kron(I, T + Cx) + sp.kron(T + Cy, I)).tocsr()
+    if scale_rows:
+        d = 10.0 ** (2.0 * np.arange(n * n) / (n * n) - 1.0)
+        A = (sp.diags(d) @ A).tocsr()
+    return A
+
+
+@pytest.mark.parametrize("case", ["peclet0.5", "peclet5", "peclet50", "rows_scaled_1e2"])
+def test_default_sstep_on_user_matrices_with_complex_spectra_and_bad_scaling(nls, dev, case):
+    """The library default (s-step, automatic block size, Newton basis on the REAL Gershgorin interval) on general user CSR
+    matrices the built-in problems do not cover: convection-dominated nonsymmetric operators (eigenvalues off the real axis —
+    the real interval is then only the projection of the discs) and a matrix whose rows are scaled over two decades (bounds
+    far wider than the bulk of the spectrum: blocks may lose rank, the solve narrows them and, if need be, finishes column by column).
+    Whatever the blocks do, the answer is the column-by-column GMRES's: same residual history end point, same solution."""
+    import torch
+    A = _convection_diffusion(40, {"peclet0.5": 0.5, "peclet5": 5.0, "peclet50": 50.0, "rows_scaled_1e2": 2.0}[case],
+                              scale_rows=(case == "rows_scaled_1e2"))
+    n = A.shape[0]
+    b = A @ np.sin(np.arange(n) * 0.05) + 1.0
+    J = nls.CSRMatrix.from_scipy(A)
+    rtol = 1e-8
+    xr, ir = R.gmres(lambda z: A @ z, b, restart=30, rtol=rtol, atol=0.0, itmax=4000, ortho="cgs2")
+    out = {}
+    for ortho in ("sstep", "dcgs2"):
+        G = nls.GMRES(n, restart=30, ortho=ortho).set_operator(J)
+        x, gi = G.solve(torch.tensor(b, device=dev), reltol=rtol, abstol=0.0, maxiters=4000)
+        out[ortho] = (x.cpu().numpy(), gi, G.sstep_state() if ortho == "sstep" else None)
+        G.close()
+    xs, gs, st = out["sstep"]
+    xd, gd, _ = out["dcgs2"]
+    assert gs["converged"] and gd["converged"] and ir.converged, (gs, gd)
+    for x in (xs, xd):   # both reach the tolerance in the TRUE residual (the recurrence residual of a restarted solve is re-based)
+        assert np.linalg.norm(b - A @ x) <= 5.0 * rtol * np.linalg.norm(b)
+    # restarted GMRES(30) near stagnation is sensitive to rounding in its iteration count, not in what it converges to
+    scale = np.linalg.norm(xr)
+    assert np.linalg.norm(xs - xr) <= 1e-5 * scale and np.linalg.norm(xd - xr) <= 1e-5 * scale
+    assert gs["iters"] <= 1.5 * gd["iters"] + 60, (gs["iters"], gd["iters"], st)
+    J.close()
