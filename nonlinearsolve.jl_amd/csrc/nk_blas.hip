@@ -866,14 +866,25 @@ int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, c
   NK_HIP(hipGetLastError());
   return nk_comm_allreduce_mixed(ctx, d_out, extra_partials ? 3 : 2, 0, 1);  // [max, +, +]: one message on the peer path
 }
+__global__ __launch_bounds__(NK_BLOCK) void k_publish(const double *__restrict__ src, int count, double *h_dst, uint64_t *h_seq,
+                                                      uint64_t seq);
 // the same, with the 2–3 results delivered to the host (`h_out`): on one rank the stage-2 launch publishes them itself
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
-                               double *h_out) {
+                               double *h_out, const std::function<int()> &before_wait) {
   const int count = extra_partials ? 3 : 2;
   static const bool legacy = getenv("NK_FETCH_MEMCPY") != nullptr || getenv("NK_NORMS_SEPARATE_PUBLISH") != nullptr;
   if (!nk_ctx_is_single(ctx) || legacy) {
     NK_TRY(nk_blas_norms_inf2(ctx, n, x, d_out, extra_partials, extra_n));
-    return nk_scalars_to_host(ctx, d_out, count, h_out);
+    if (legacy) return nk_scalars_to_host(ctx, d_out, count, h_out);
+    // several ranks: the publish is a launch of its own; work the caller wants in the queue behind it goes in before the wait
+    const uint64_t seq = ++ctx->seq;
+    NK_LAUNCH(ctx, k_publish, dim3(1), dim3(NK_BLOCK), (const double *)d_out, count, ctx->h_pinned_dev, ctx->h_seq_dev, seq);
+    NK_HIP(hipGetLastError());
+    if (before_wait) NK_TRY(before_wait());
+    volatile uint64_t *hs = ctx->h_seq;
+    NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(hs, __ATOMIC_ACQUIRE) == seq; }, "published norms"));
+    for (int i = 0; i < count; ++i) h_out[i] = ctx->h_pinned[i];
+    return NK_OK;
   }
   const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
   const uint64_t seq = ++ctx->seq;
@@ -881,6 +892,7 @@ int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *
   NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
             ctx->h_pinned_dev, ctx->h_seq_dev, seq);
   NK_HIP(hipGetLastError());
+  if (before_wait) NK_TRY(before_wait());   // (the host's round trip for these scalars then overlaps with that work)
   volatile uint64_t *hs = ctx->h_seq;
   NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(hs, __ATOMIC_ACQUIRE) == seq; }, "published norms"));
   for (int i = 0; i < count; ++i) h_out[i] = ctx->h_pinned[i];

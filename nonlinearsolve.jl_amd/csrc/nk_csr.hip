@@ -735,6 +735,23 @@ int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip
 }
 
 // same pattern, partition and halo plan, own (zeroed) values
+nk_csr_valstate nk_csr_get_valstate(const nk_csr *A) {
+  nk_csr_valstate v;
+  v.d_val = A->d_val; v.d_gersh = A->d_gersh; v.gersh_cap = A->gersh_cap;
+  v.t_values_stale = A->t_values_stale; v.bounds_valid = A->bounds_valid; v.bounds_pending = A->bounds_pending;
+  v.bounds_part = A->bounds_part; v.bounds_nblk = A->bounds_nblk;
+  return v;
+}
+void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v) {
+  A->d_val = v.d_val; A->d_gersh = v.d_gersh; A->gersh_cap = v.gersh_cap;
+  A->t_values_stale = v.t_values_stale; A->bounds_valid = v.bounds_valid; A->bounds_pending = v.bounds_pending;
+  A->bounds_part = v.bounds_part; A->bounds_nblk = v.bounds_nblk;
+}
+int nk_csr_alloc_values(nk_csr *A, double **out) {
+  NK_TRY(nk_dev_alloc(out, (size_t)A->nnz + SPMV_TILE_MAX));
+  NK_HIP(hipMemset(*out, 0, ((size_t)A->nnz + SPMV_TILE_MAX) * sizeof(double)));
+  return NK_OK;
+}
 int nk_csr_clone_pattern(nk_csr *A, nk_csr **out) {
   NK_REQUIRE(A && out, "NULL argument");
   std::vector<int64_t> gc((size_t)A->nnz);

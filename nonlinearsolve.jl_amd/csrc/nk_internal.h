@@ -300,6 +300,7 @@ struct nk_problem {
   int64_t n_local = 0, n_global = 0, row_begin = 0;
   double params[8] = {0};
   int nparams = 0;
+  uint64_t params_version = 0;   // bumped by nk_problem_set_params (anything derived from the parameters and cached elsewhere checks it)
   bool replicated = false;  // every rank holds the WHOLE problem (coarsest multigrid level): no partition, no halo
   // grid problems
   int64_t ns = 0;           // side length
@@ -521,11 +522,24 @@ __device__ __forceinline__ void nk_gmres_begin_body(nk_gmres_ctl *ctl, double ss
 // reductions of ‖b‖² and of the Jacobian fill's Gershgorin partials, which are launches of their own otherwise)
 int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
                       int ss_grid);
+// Everything of a CSR matrix that belongs to one SET OF VALUES on its fixed pattern: the value array, the fill kernel's
+// Gershgorin partials and the flags of the caches derived from the values. Swapping it lets a second value set be filled
+// behind the back of the live one (the Newton driver's speculative Jacobian fill, nk_solver.hip) and take its place later.
+struct nk_csr_valstate {
+  double *d_val = nullptr, *d_gersh = nullptr;
+  int gersh_cap = 0;
+  bool t_values_stale = true, bounds_valid = false, bounds_pending = false;
+  const double *bounds_part = nullptr;
+  int bounds_nblk = 0;
+};
+nk_csr_valstate nk_csr_get_valstate(const nk_csr *A);
+void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v);
+int nk_csr_alloc_values(nk_csr *A, double **out);   // a zero-padded value array of A's size (freed with hipFree)
 // fill kernels' Gershgorin partials not reduced yet: hands them to a caller that reduces them into *dst in its own kernel
 bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
 int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
-                               double *h_out);
+                               double *h_out, const std::function<int()> &before_wait = nullptr);
 // the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
 struct nk_ss_fix { int k0, sb; const double *C2, *R2; };
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G);

@@ -500,6 +500,7 @@ extern "C" int nk_problem_set_params(nk_problem *P, const double *params, int np
     NK_REQUIRE((int64_t)params[0] == P->ns, "cannot change the grid size");
   }
   for (int i = 0; i < nparams; ++i) P->params[i] = params[i];
+  P->params_version++;
   if (P->kind == NK_PROBLEM_BRATU2D) {
     const double h = 1.0 / (double)(P->ns + 1);
     const double sc = nparams >= 3 ? params[2] : 0.0, s = (sc == 0.0) ? h * h : sc;

@@ -67,6 +67,12 @@ struct nk_solver {
   std::vector<nk_trace_entry> trace;
   // preconditioning behind the `precs` hook: a built-in object on the concrete J (nk_options.precond_kind) and / or a callback
   nk_precond *prec_obj = nullptr;
+  // speculative Jacobian fill (plain Newton on a built-in problem with a concrete J): the NEXT step's J(u_new) is written into a
+  // second value set while the host waits for this step's norms — the queue is not empty during the termination test's round
+  // trip. The live J is untouched until the next step takes the set (refresh_J); a solve that terminates never sees it.
+  bool spec_valid = false;
+  uint64_t spec_version = 0, spec_params = 0;
+  nk_csr_valstate spec_state{};                 // the filled set (valid) / the spare buffers (not valid)
   nk_precs_fn precs = nullptr;
   void *precs_user = nullptr;
 };
@@ -255,9 +261,10 @@ static double *spare_u(nk_solver *S) {
   return nullptr;  // unreachable: three buffers, at most two in use
 }
 // ‖fu‖∞ and ‖fu‖₂² of the current residual (+ optionally the stall norm's partial sums) → ONE stage-2 launch, one fetch
-static int residual_norms(nk_solver *S, const double *stall_partials, int stall_n, double *step_norm) {
+static int residual_norms(nk_solver *S, const double *stall_partials, int stall_n, double *step_norm,
+                          const std::function<int()> &before_wait = nullptr) {
   double v[3] = {0, 0, 0};
-  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v));
+  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v, before_wait));
   S->fnorm_inf = v[0];
   S->fnorm2 = sqrt(v[1]);
   if (step_norm) *step_norm = sqrt(v[2]);
@@ -265,9 +272,42 @@ static int residual_norms(nk_solver *S, const double *stall_partials, int stall_
 }
 
 // jac_cache(u) for a concrete J: closed-form values, or — jac_colored — the colour-compressed assembly
+static bool speculation_allowed(const nk_solver *S) {
+  static const bool off = (getenv("NK_SPECULATIVE_JAC") && atoi(getenv("NK_SPECULATIVE_JAC")) == 0) || getenv("NK_GMRES_GRAPH");
+  return !off && S->o.algorithm == NK_ALG_NEWTON_RAPHSON && !S->o.linesearch && S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE &&
+         S->P->kind != NK_PROBLEM_USER && !S->o.jac_colored && S->precs == nullptr && S->J != nullptr && !S->J->raw_exposed;
+}
+// J(u) of the iterate just formed into the spare value set (enqueued behind the step's last kernels, before the host waits)
+static int speculate_J(nk_solver *S) {
+  S->spec_valid = false;
+  if (!speculation_allowed(S)) return NK_OK;
+  nk_csr *J = S->J;
+  if (!S->spec_state.d_val) NK_TRY(nk_csr_alloc_values(J, &S->spec_state.d_val));
+  const nk_csr_valstate live = nk_csr_get_valstate(J);
+  nk_csr_valstate spare = S->spec_state;
+  spare.t_values_stale = true; spare.bounds_valid = false; spare.bounds_pending = false;
+  nk_csr_set_valstate(J, spare);
+  const int rc = nk_problem_jac_values_dev(S->P, S->u, J);
+  S->spec_state = nk_csr_get_valstate(J);       // (the fill may have grown the partials buffer)
+  nk_csr_set_valstate(J, live);
+  if (rc != NK_OK) return rc;
+  S->spec_valid = true;
+  S->spec_version = S->u_version;
+  S->spec_params = S->P->params_version;
+  return NK_OK;
+}
 static int refresh_J(nk_solver *S) {
-  if (S->o.jac_colored && S->P->kind != NK_PROBLEM_USER) NK_TRY(nk_problem_jac_colored_dev(S->P, S->u, S->J));
-  else NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
+  if (S->spec_valid && S->spec_version == S->u_version && S->spec_params == S->P->params_version && speculation_allowed(S)) {
+    // the values of J(u) are already there: the two sets change places (the old live buffers are the next spare ones)
+    const nk_csr_valstate live = nk_csr_get_valstate(S->J);
+    nk_csr_set_valstate(S->J, S->spec_state);
+    S->spec_state = live;
+    S->spec_valid = false;
+  } else {
+    S->spec_valid = false;
+    if (S->o.jac_colored && S->P->kind != NK_PROBLEM_USER) NK_TRY(nk_problem_jac_colored_dev(S->P, S->u, S->J));
+    else NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
+  }
   S->stats.njacs++;
   S->lu_valid = false;
   S->pt_applied = 0.0;  // fresh values: no damping on the diagonal yet
@@ -621,6 +661,8 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage, S->stage2, S->lm_dtd, S->lm_diag, S->lm_v,
                     S->lm_a, S->lm_vcache, S->lm_rhs, S->pt_mass};
   for (double *b : bufs) hipFree(b);
+  hipFree(S->spec_state.d_val);     // (whichever value set is the spare one now; the live one belongs to J)
+  hipFree(S->spec_state.d_gersh);
   nk_gmres_destroy(S->G);
   nk_precond_destroy(S->prec_obj);
   nk_bandlu_destroy(S->B);
@@ -1729,7 +1771,9 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     }
     NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
     S->stats.nf++;
-    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm));  // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch
+    // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch — and behind the kernels that produce them, before the host waits, the next step's
+    // Jacobian values (speculate_J)
+    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm, [S]() -> int { return speculate_J(S); }));
     if (S->o.store_trace) {
       NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
       double v;

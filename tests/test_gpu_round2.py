@@ -418,3 +418,45 @@ def test_direct_linsolve_falls_back_when_the_band_lu_needs_pivoting(nls, dev):
     assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
     assert sol.stats.nsteps == ref.stats.nsteps
     assert np.max(np.abs(sol.u.cpu().numpy() - ref.u)) <= 1e-8 * np.max(np.abs(ref.u))
+
+
+def test_speculative_jacobian_fill_is_invisible(nls, dev):
+    """Plain Newton on a built-in problem with a concrete J writes the NEXT step's J(u_new) into a second value set while the
+    host waits for the step's norms (csrc/nk_solver.hip: speculate_J). Nothing of it may show: after every step the solver's J
+    holds the values at the iterate that step STARTED from (as the reference's cache does: J is evaluated at the top of
+    `step!`, FirstOrder/src/solve.jl:330-350), the Jacobian count follows the steps, a `reinit!` with new parameters starts from
+    a fresh J, and a parameter change between two steps is honoured."""
+    import ctypes as C
+    import torch
+    from nonlinearsolve_jl_amd import _lib as L
+    ns = 24
+    Pr = R.Bratu2D(ns, 6.0)
+    cache = nls.init(nls.NonlinearProblem(nls.Bratu2D(ns, 6.0)), nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), concrete_jac=True),
+                     abstol=1e-12, maxiters=50)
+    J = nls.CSRMatrix(L.lib().nk_solver_jacobian(cache._h), cache.prob.ctx, owned=False)
+
+    def jac_at(P, u):
+        A = P.jac(np.asarray(u)).tocsr()
+        A.sort_indices()
+        return A.data
+    for i in range(4):
+        u_prev = np.asarray(cache.u).copy()
+        cache.step()
+        assert np.max(np.abs(J.values() - jac_at(Pr, u_prev))) <= 1e-13 * np.max(np.abs(J.values())), i
+        assert cache.stats.njacs == i + 2          # (one at init: the cache is built with J(u0), FirstOrder/src/solve.jl:171-186)
+    # a parameter change between two steps: the set filled ahead (for λ = 6) must not be taken
+    u_prev = np.asarray(cache.u).copy()
+    cache.prob.device_problem.set_params([ns, 3.0, 0.0])
+    cache.step()
+    assert np.max(np.abs(J.values() - jac_at(R.Bratu2D(ns, 3.0), u_prev))) <= 1e-13 * np.max(np.abs(J.values()))
+    # reinit! (new u0) after a finished solve: same steps and solution as a cache built from scratch
+    cache.prob.device_problem.set_params([ns, 6.0, 0.0])
+    nls.reinit_(cache, np.zeros(ns * ns))
+    s1 = nls.solve_(cache)
+    rc = R.init(R.Bratu2D(ns, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), concrete_jac=True), abstol=1e-12, maxiters=50)
+    rc.solve()
+    rc.reinit(np.zeros(ns * ns))          # (reinit! does not evaluate a Jacobian: jacobian.jl:184-186)
+    ref = rc.solve()
+    assert s1.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and s1.stats.nsteps == ref.stats.nsteps
+    assert s1.stats.njacs == ref.stats.njacs and np.max(np.abs(np.asarray(s1.u) - ref.u)) <= 1e-9
+    cache.close()
