@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_publish(const double *__restrict__
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst) {
+int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst, const std::function<int()> &before_wait) {
   NK_REQUIRE(count <= NK_BLOCK && count <= 4 * NK_MAX_NV, "too many scalars");
   static const bool legacy = getenv("NK_FETCH_MEMCPY") != nullptr;  // A/B switch: copy + synchronise
   if (legacy) {
@@ -1070,6 +1070,7 @@ int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_ds
     const uint64_t seq = ++ctx->seq;
     NK_LAUNCH(ctx, k_publish, dim3(1), dim3(NK_BLOCK), d_src, count, ctx->h_pinned_dev, ctx->h_seq_dev, seq);
     NK_HIP(hipGetLastError());
+    if (before_wait) NK_TRY(before_wait());   // (work the caller wants in the queue while the host waits)
     volatile uint64_t *hs = ctx->h_seq;
     NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(hs, __ATOMIC_ACQUIRE) == seq; }, "published scalars"));
   }

@@ -378,7 +378,8 @@ int nk_blas_copy(nk_ctx *ctx, int64_t n, const double *x, double *y);
 int nk_blas_fill(nk_ctx *ctx, int64_t n, double a, double *y);
 // z = a*x + b*y (three-operand)
 int nk_blas_lincomb(nk_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z);
-int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst);  // synchronises
+int nk_scalars_to_host(nk_ctx *ctx, const double *d_src, int count, double *h_dst,
+                       const std::function<int()> &before_wait = nullptr);  // synchronises
 int nk_blas_minmax(nk_ctx *ctx, int64_t n, const double *x, double *d_out2 /*min,max*/);
 
 // ----------------------------------------------------------------------------- multigrid preconditioner (nk_mg.hip)

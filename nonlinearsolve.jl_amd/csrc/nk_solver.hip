@@ -72,6 +72,7 @@ struct nk_solver {
   // trip. The live J is untouched until the next step takes the set (refresh_J); a solve that terminates never sees it.
   bool spec_valid = false;
   uint64_t spec_version = 0, spec_params = 0;
+  const double *spec_u = nullptr;               // the iterate the set was filled at
   nk_csr_valstate spec_state{};                 // the filled set (valid) / the spare buffers (not valid)
   nk_precs_fn precs = nullptr;
   void *precs_user = nullptr;
@@ -251,7 +252,9 @@ static bool concrete(const nk_solver *S) { return S->o.linsolve != NK_LINSOLVE_G
 static bool direct(const nk_solver *S) { return S->o.linsolve == NK_LINSOLVE_BANDED_LU; }
 
 // ---- scalar helpers (device reductions → pinned host, one synchronisation)
-static int fetch(nk_solver *S, int count, double *out) { return nk_scalars_to_host(S->ctx, S->ctx->d_scal, count, out); }
+static int fetch(nk_solver *S, int count, double *out, const std::function<int()> &before_wait = nullptr) {
+  return nk_scalars_to_host(S->ctx, S->ctx->d_scal, count, out, before_wait);
+}
 static double *slot(nk_solver *S, int i) { return S->ctx->d_scal + i; }
 
 // a pool buffer that holds neither the current nor the retained best iterate
@@ -274,11 +277,14 @@ static int residual_norms(nk_solver *S, const double *stall_partials, int stall_
 // jac_cache(u) for a concrete J: closed-form values, or — jac_colored — the colour-compressed assembly
 static bool speculation_allowed(const nk_solver *S) {
   static const bool off = (getenv("NK_SPECULATIVE_JAC") && atoi(getenv("NK_SPECULATIVE_JAC")) == 0) || getenv("NK_GMRES_GRAPH");
+  // (TrustRegion — the fill at the trial point before the host knows whether it is accepted — was measured on config C5: no
+  //  gain, the set is wasted on every rejected step; not enabled)
   return !off && S->o.algorithm == NK_ALG_NEWTON_RAPHSON && !S->o.linesearch && S->o.linsolve != NK_LINSOLVE_GMRES_MATFREE &&
          S->P->kind != NK_PROBLEM_USER && !S->o.jac_colored && S->precs == nullptr && S->J != nullptr && !S->J->raw_exposed;
 }
 // J(u) of the iterate just formed into the spare value set (enqueued behind the step's last kernels, before the host waits)
-static int speculate_J(nk_solver *S) {
+// (`version`: the iterate's version at which the set may be taken)
+static int speculate_J(nk_solver *S, const double *u_at, uint64_t version) {
   S->spec_valid = false;
   if (!speculation_allowed(S)) return NK_OK;
   nk_csr *J = S->J;
@@ -287,17 +293,19 @@ static int speculate_J(nk_solver *S) {
   nk_csr_valstate spare = S->spec_state;
   spare.t_values_stale = true; spare.bounds_valid = false; spare.bounds_pending = false;
   nk_csr_set_valstate(J, spare);
-  const int rc = nk_problem_jac_values_dev(S->P, S->u, J);
+  const int rc = nk_problem_jac_values_dev(S->P, u_at, J);
   S->spec_state = nk_csr_get_valstate(J);       // (the fill may have grown the partials buffer)
   nk_csr_set_valstate(J, live);
   if (rc != NK_OK) return rc;
   S->spec_valid = true;
-  S->spec_version = S->u_version;
+  S->spec_version = version;
+  S->spec_u = u_at;
   S->spec_params = S->P->params_version;
   return NK_OK;
 }
 static int refresh_J(nk_solver *S) {
-  if (S->spec_valid && S->spec_version == S->u_version && S->spec_params == S->P->params_version && speculation_allowed(S)) {
+  if (S->spec_valid && S->spec_version == S->u_version && S->spec_u == S->u && S->spec_params == S->P->params_version &&
+      speculation_allowed(S)) {
     // the values of J(u) are already there: the two sets change places (the old live buffers are the next spare ones)
     const nk_csr_valstate live = nk_csr_get_valstate(S->J);
     nk_csr_set_valstate(S->J, S->spec_state);
@@ -1699,6 +1707,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     if (!direct(S)) NK_TRY(refresh_precs(S));
   } else {
     new_jacobian = false;
+    S->spec_valid = false;   // (a value set filled ahead is only ever taken by the step that follows its fill)
   }
   if (is_lm(S)) return lm_step(S, new_jacobian, evaluate_residual);
   const bool has_forcing = S->o.forcing == NK_FORCING_EISENSTAT_WALKER2;
@@ -1773,7 +1782,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     S->stats.nf++;
     // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch — and behind the kernels that produce them, before the host waits, the next step's
     // Jacobian values (speculate_J)
-    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm, [S]() -> int { return speculate_J(S); }));
+    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm, [S]() -> int { return speculate_J(S, S->u, S->u_version); }));
     if (S->o.store_trace) {
       NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
       double v;
