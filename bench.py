@@ -17,7 +17,7 @@ and the same minimisation as column-by-column CGS2, iterates equal to 1e-10 over
 very protocol at full size against the C oracle); `--ortho dcgs2` runs the column-by-column form of rounds 1–2 (delayed CGS2:
 two sweeps and one reduction per column), `--sstep 6 --sstep-basis monomial` round 2's blocks. A "step" is one such Newton step:
 Jacobian value fill + 30 SpMVs + the orthogonalisation sweeps + solution update + u += δu + residual + ‖·‖∞ + termination
-bookkeeping, everything resident in HBM. Defaults: 100 timed steps after 5 warm-up steps (≈ 0.1 s of GPU time; the CPU leg's
+bookkeeping, everything resident in HBM. Defaults: 300 timed steps after 20 warm-up steps (≈ 0.3 s of GPU time; the CPU leg's
 bounded sample and the time-to-tolerance extras dominate the wall clock of the default run).
 
 N > 1 is STRONG scaling on the metric's configuration: the same 1024² problem row-partitioned by grid lines over N
@@ -53,8 +53,8 @@ HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"])
     ap.add_argument("--grid", dest="n", type=int, default=0, help="grid side (default: 1024 for c3, 4096 for c4, 512 for c5)")
     ap.add_argument("--ortho", default="sstep", choices=["cgs2", "dcgs2", "dcgs2_1r", "cgs", "mgs", "sstep"])
