@@ -897,7 +897,12 @@ struct ss_begin_args {
 };
 __global__ __launch_bounds__(256) void k_ss_cycle_begin(const ss_begin_args a) {
   __shared__ double sm[12];
+  __shared__ double sh_ch[3];   // centre, half width, Newton basis in effect
   const int t = threadIdx.x, wv = t >> 6;
+  // (requested before the reductions: a lone thread's loads behind its own stores cost a round trip each — the 15 shifts alone
+  //  were 7 of this launch's 12 µs)
+  const double node_t = (t < SS_SMAX) ? a.nodes[t] : 0.0;
+  const double sigma_old = (t == 0) ? a.scal[3] : 0.0;
   double v = 0.0, blo = -INFINITY, bhi = -INFINITY;
   if (a.ss_part != nullptr)
     for (int i = t; i < a.ss_grid; i += 256) v += a.ss_part[i];
@@ -922,7 +927,7 @@ __global__ __launch_bounds__(256) void k_ss_cycle_begin(const ss_begin_args a) {
   }
   if ((t & 63) == 0) { sm[wv] = v; sm[4 + wv] = blo; sm[8 + wv] = bhi; }
   __syncthreads();
-  if (t != 0) return;
+  if (t == 0) {
   double ss;
   if (a.ss_part != nullptr) {
     ss = (sm[0] + sm[1]) + (sm[2] + sm[3]);
@@ -944,25 +949,32 @@ __global__ __launch_bounds__(256) void k_ss_cycle_begin(const ss_begin_args a) {
   }
   nk_gmres_begin_body(a.ctl, ss, a.atol, a.rtol, a.fixed, a.first, a.g, a.s, a.m, a.pub, a.seq);
   double *scal = a.scal;
-  double sigma = scal[3];
-  double newton = 0.0;
+  double sigma = sigma_old;
+  double newton = 0.0, c = 0.0, h = 0.0;
   if (a.newton) {
     const double lo = -lo_neg;
-    const double c = 0.5 * (lo + hi), h = 0.5 * (hi - lo);
+    c = 0.5 * (lo + hi);
+    h = 0.5 * (hi - lo);
     if (h > 0.0 && !isinf(h) && c == c && !isinf(c)) {
-      for (int j = 0; j < a.ns; ++j) scal[SS_TH + j] = c + h * a.nodes[j];
       sigma = exp2(rint(log2(0.5 * h)));
       newton = 1.0;
     }
   }
-  if (newton == 0.0)
-    for (int j = 0; j < SS_SMAX; ++j) scal[SS_TH + j] = 0.0;
+  sh_ch[0] = c; sh_ch[1] = h; sh_ch[2] = newton;
   if (!(sigma > 0.0) || isinf(sigma)) sigma = 1.0;
   scal[4] = newton;
   scal[3] = sigma;
   scal[2] = sigma;
   scal[1] = 1.0 / sigma;
-  scal[0] = a.s[0] / sigma;
+  {  // s[0] as nk_gmres_begin_body has just stored it (recomputed: reading it back is a memory round trip)
+    const double beta = sqrt(ss);
+    const bool bad = !(beta == beta) || isinf(beta);
+    scal[0] = ((beta > 0.0 && !bad) ? 1.0 / beta : 0.0) / sigma;
+  }
+  }
+  __syncthreads();
+  if (t < SS_SMAX)   // the shifts, one lane each
+    a.scal[SS_TH + t] = (sh_ch[2] != 0.0 && t < a.ns) ? sh_ch[0] + sh_ch[1] * node_t : 0.0;
 }
 
 // development hook (not in the public header): the first block of restart cycle `cycle` of the next solves reports a
