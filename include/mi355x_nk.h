@@ -390,6 +390,15 @@ double *nk_csr_values_device(nk_csr *A);      /* device pointer of the local val
  * ranks own return through the halo plan in reverse and are added in rank order: bitwise reproducible). */
 int nk_spmv(nk_csr *A, const double *x, double *y, int memspace);
 int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace);
+/* Matrix powers — the s operator applications an s-step Arnoldi block makes back to back (the `mul!(Jv, A, v)` of
+ * lib/SciMLJacobianOperators/src/SciMLJacobianOperators.jl:238-243, s times in a row on a concrete J):
+ *   Y[:, p] = scale·(A Y[:, p−1] − θ_p Y[:, p−1]),  p = 0 … s−1,  Y[:, −1] = x   (theta: s host values, NULL = plain powers;
+ * ldy ≥ local rows). A banded matrix small enough to be held in the chip's vector registers (≤ #CUs × 6144 rows, ≤ 5 / 8 / 16
+ * entries per row, columns within ±1024 rows of their band; one rank) takes ONE launch that reads the matrix once
+ * (*resident = 1, csrc/nk_powers.hip); any other matrix takes s streaming SpMV launches. The columns are bit-identical
+ * either way. NK_SPMV_POWERS=0 disables the resident kernel. */
+int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy, int s, const double *theta, double scale, int memspace,
+                  int *resident);
 /* out_j = Σ_i A_ij² — diag(AᵀA), what LevenbergMarquardt's damping takes its DᵀD from (`sum!(abs2, J_diag_cache, J')`,
  * levenberg_marquardt.jl:133-148). Row-partitioned matrices: the same reverse halo exchange as nk_spmv_t. */
 int nk_csr_colsumsq(nk_csr *A, double *out, int memspace);

@@ -325,6 +325,22 @@ class CSRMatrix:
         check(L.lib().nk_spmv(self._h, px, py, ms))
         return y
 
+    def powers(self, x, s, theta=None, scale=1.0):
+        """Matrix powers Y[:, p] = scale·(A − θ_p I) Y[:, p−1], Y[:, −1] = x (theta None: plain powers) — the s operator
+        applications of an s-step Arnoldi block. Returns (Y as an (s, n) array whose row p is power p, resident) where
+        `resident` says whether the one-launch kernel that holds the matrix in registers ran (csrc/nk_powers.hip)."""
+        n = self.info()["nrows_local"]
+        px, ms, _k = _ptr(x, n)
+        Y = _like(x, n * s)
+        pY, _ms2, _k2 = _ptr(Y, n * s)
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        if th is not None and th.size != s:
+            raise ValueError("theta must have s entries")
+        res = C.c_int(0)
+        check(L.lib().nk_csr_powers(self._h, px, pY, n, int(s), None if th is None else C.c_void_p(th.ctypes.data),
+                                    float(scale), ms, C.byref(res)))
+        return Y.reshape(s, n), bool(res.value)
+
     def rmatvec(self, x, out=None):
         n = self.info()["nrows_local"]
         px, ms, _k = _ptr(x, n)

@@ -518,6 +518,7 @@ extern "C" int nk_csr_destroy(nk_csr *A) {
   hipFree(A->d_nnzcolor);
   hipFree(A->d_seed);
   hipFree(A->d_B);
+  nk_powers_plan_destroy(A->pw);
   nk_halo_free(&A->halo);
   if (A->T) nk_csr_destroy(A->T);
   delete A;

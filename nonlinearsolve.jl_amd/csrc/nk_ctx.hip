@@ -168,7 +168,7 @@ extern "C" int nk_ctx_set_deterministic(nk_ctx *ctx, int d) {
 
 // ----------------------------------------------------------------------------- kernel-family profiling
 static const char *k_names[NK_K_COUNT] = {"spmv", "multidot", "multiaxpy", "jvp", "residual", "scale",
-                                          "reduce_small", "jacfill", "newton_update", "other"};
+                                          "reduce_small", "jacfill", "newton_update", "other", "spmv_powers"};
 void nk_prof_scope_begin(nk_ctx *ctx, int id, double bytes) {
   ctx->prof.cur_id = id;
   ctx->prof.cur_bytes = bytes;

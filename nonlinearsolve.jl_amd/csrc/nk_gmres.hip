@@ -1253,6 +1253,18 @@ int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_
                       const double *d_theta) {
   return op_apply(G, d_x, d_y, d_skip, d_scale, d_theta);
 }
+// s applications of the shifted, scaled operator in a row — Y[:, j] = scale_j·(A − θ_j I) Y[:, j−1], Y[:, −1] = x; scale_0 =
+// d_scale[0], later ones d_scale[1] — as ONE launch of the resident matrix-powers kernel (nk_powers.hip) when the operator is a
+// plain CSR matrix that kernel can hold on the chip; *done = false: the caller applies the operator column by column
+int nk_gmres_op_powers(nk_gmres *G, const double *d_x, double *d_Y, int64_t ldy, int s, const int *d_skip, const double *d_scale,
+                       const double *d_theta, bool *done) {
+  *done = false;
+  if (s < 2 || G->op_kind != 1 || G->prec_kind || G->lprec_kind || G->normal || G->shift != 0.0) return NK_OK;
+  if (!nk_csr_powers_ready(G->A)) return NK_OK;
+  NK_TRY(nk_csr_powers_dev(G->A, d_x, d_Y, ldy, s, d_scale, d_scale + 1, d_theta, d_skip));
+  *done = true;
+  return NK_OK;
+}
 
 // Real bounds of the operator's spectrum for the s-step Newton basis, left on the device as {−lo, hi}: Gershgorin discs of
 // a concrete CSR operator, the closed-form discs of the Bratu stencil (diagonal 4c − d_k, radius ≤ 4c), or bounds the caller
@@ -1682,6 +1694,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     }
     x_is_zero = false;
     NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(&pub->end_seq, __ATOMIC_ACQUIRE) == seq; }, "the end of a GMRES cycle"));
+    if (G->op_kind == 1 && G->A) NK_TRY(nk_csr_powers_check(G->A));
     if (pub->pad != 0)
       NK_FAIL(NK_E_COMM, "%d peer-mapped collective(s) timed out (a rank stalled beyond NK_PEER_TIMEOUT_MS or died): the "
                          "reductions / halos of this solve are not valid", (int)pub->pad);

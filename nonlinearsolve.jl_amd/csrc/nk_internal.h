@@ -55,7 +55,7 @@ constexpr int NK_MAX_NV = 64;          // max simultaneous dot products (restart
 // per-kernel-family timing with HIP events on the launch stream (bench/roofline evidence; off by default)
 enum nk_kernel_id {
   NK_K_SPMV = 0, NK_K_MULTIDOT, NK_K_MULTIAXPY, NK_K_JVP, NK_K_RESIDUAL, NK_K_SCALE, NK_K_REDUCE_SMALL,
-  NK_K_JACFILL, NK_K_NEWTON_UPDATE, NK_K_OTHER, NK_K_COUNT
+  NK_K_JACFILL, NK_K_NEWTON_UPDATE, NK_K_OTHER, NK_K_POWERS, NK_K_COUNT
 };
 struct nk_prof {
   bool on = false;
@@ -274,7 +274,17 @@ struct nk_csr {
   // problem-specific device tables attached by nk_problem_jac_csr (freed with the matrix)
   uint8_t *d_role = nullptr;   // Brusselator: role of every non-zero
   int32_t *d_node = nullptr;   // Brusselator: grid node of every non-zero's row
+  // resident matrix-powers kernel (nk_powers.hip): built on first use; NULL = the matrix is not eligible
+  struct nk_powers_plan *pw = nullptr;
+  bool pw_tried = false;
 };
+// s operator applications in one launch with the matrix held in registers (nk_powers.hip):
+//   Y[:, p] = os_p·(A Y[:, p−1] − θ_p Y[:, p−1]),  Y[:, −1] = x0,  os_0 = *d_scal_first, os_p = *d_scal_rest (NULL = 1), θ NULL = 0
+bool nk_csr_powers_ready(nk_csr *A);   // the matrix has a plan (built on first call) and no launch has timed out
+int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, int s, const double *d_scal_first,
+                      const double *d_scal_rest, const double *d_theta, const int *d_skip);
+int nk_csr_powers_check(nk_csr *A);    // NK_E_HIP once if a launch timed out (the plan is then off for good)
+void nk_powers_plan_destroy(struct nk_powers_plan *P);
 // d_out_scale (nullable): y = (*d_out_scale) · A x   (lagged normalisation of the Krylov basis)
 int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr,
                     const nk_spmv_epi *epi = nullptr);
@@ -479,6 +489,8 @@ int64_t nk_precond_size(struct nk_precond *P);
 // y = scale·(A M⁻¹ x − θ x); d_scale / d_theta (device scalars) may be nullptr (= 1 / 0)
 int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_skip, const double *d_scale,
                       const double *d_theta = nullptr);
+int nk_gmres_op_powers(nk_gmres *G, const double *d_x, double *d_Y, int64_t ldy, int s, const int *d_skip, const double *d_scale,
+                       const double *d_theta, bool *done);
 // real bounds [lo, hi] of the operator's spectrum, on the device as {−lo, hi} (all-reduced); false: none are known
 int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, const double **where, bool *have);
 // {−min_i(a_ii − r_i), max_i(a_ii + r_i)} of the local rows: *where = the matrix's cached bounds (left by a fused fill kernel)

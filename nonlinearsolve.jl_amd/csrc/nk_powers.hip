@@ -1,0 +1,344 @@
+// Matrix powers with the matrix RESIDENT ON THE CHIP: Y_p = os_p·(A Y_{p−1} − θ_p Y_{p−1}), p = 0 … s−1, Y_{−1} = x, in ONE
+// launch — the s operator applications an s-step Arnoldi block makes back to back (nk_sstep.hip) with nothing in between.
+//
+// Why: the streaming SpMV (nk_csr.hip) reads the whole matrix for every application — 15 × 74 MB per block at 1024², 2.2 GB of
+// the 3.9 GB a fixed-work Newton step moves. An MI355X has 256 CUs × 512 KB of vector registers = 128 MB; a matrix of up to
+// ≈ 8 M non-zeros fits there. So: one 1024-thread workgroup per CU owns a BAND of 1024·RPT consecutive rows and loads its
+// slice of val / col into registers ONCE per launch (thread t holds rows t, t + 1024, … of its band, ≤ W entries each, in CSR
+// order). The band's slice of the current vector lives in LDS ([halo above | own rows | halo below], two buffers); a power is
+// RPT·W LDS gathers and multiply-adds per thread, one 8-byte store per row into the basis column — and the only data that
+// crosses workgroups are the ≤ 1024 rows either neighbour band reads (a grid line of the 5-point stencil): the boundary rows
+// are stored write-through (`sc1`), a per-band flag word is released behind them, the neighbour polls it and reads the rows
+// with `sc1` loads (MI355X_MICROARCH.md, hand-off forms). No grid-wide synchronisation, no second read of the matrix.
+// HBM traffic per power: the 8 n bytes of the new column. Row sums are formed exactly as the streaming kernel forms them
+// (products rounded, added in CSR order from 0.0, same epilogue), so the columns are BIT-IDENTICAL to s streaming launches.
+//
+// Eligibility (host, once per pattern — nk_csr_powers_plan): one rank, no halo; rows ≤ #CUs × 1024 × RPT_max; every row ≤ W
+// entries; every column of band b inside [first row of b − 1024, last row of b + 1024]. Everything else keeps the streaming
+// kernel. All workgroups must be resident at once (grid ≤ #CUs, one per CU by its LDS footprint); every wait is bounded by a
+// wall-clock time-out that raises the plan's error word (host-visible), after which the object falls back for good.
+#include <algorithm>
+#include <stdlib.h>
+
+#include "nk_internal.h"
+
+constexpr int PW_T = 1024;          // threads per workgroup = rows per slice
+constexpr int PW_HALO = 1024;       // rows a band may read from either neighbour
+constexpr int PW_FLAG_STRIDE = 16;  // uint64 words between two bands' flags (128 B)
+constexpr int PW_NXCD = 8;
+
+struct pw_args {
+  int nrows, nb, s, variant;
+  const int32_t *rowptr, *col;
+  const double *val;
+  const double *x0;
+  double *Y;
+  int64_t ldy;
+  const double *scal_first, *scal_rest, *theta;
+  const int *d_skip;
+  uint64_t *flags;
+  uint64_t base;   // band b has published power p ⇔ flags[b] ≥ base + p + 1 (base grows with every launch: no reset)
+  uint64_t *err;   // [0] time-outs (sticky), [1] bound of a wait in ticks of the 100 MHz wall clock
+};
+
+__device__ __forceinline__ int pw_band_of(int bid, int nb) {   // block b runs on XCD b % 8: neighbouring bands share an L2
+  const int q = nb / PW_NXCD, r = nb % PW_NXCD;
+  const int x = bid % PW_NXCD, k = bid / PW_NXCD;
+  return x * q + (x < r ? x : r) + k;
+}
+__device__ __forceinline__ void pw_store_sc1(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double pw_load_sc1(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+// one lane: until *f ≥ target; false on a time-out (ours or anybody's)
+__device__ __forceinline__ bool pw_wait(const uint64_t *f, uint64_t target, uint64_t *err) {
+  if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+  const unsigned long long t0 = wall_clock64(), lim = err[1];
+  for (unsigned it = 1;; ++it) {
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((it & 63u) == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+      if (wall_clock64() - t0 > lim) {   // (a plain store: the word lives in pinned host memory, sticky, any non-zero value will do)
+        __hip_atomic_store(err, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+      }
+    }
+  }
+}
+// order in which a power visits the band's slices: the two the neighbours read first, the interior ones behind them
+template <int RPT>
+__device__ __forceinline__ constexpr int pw_slice(int q) {
+  return q == 0 ? 0 : (q == 1 ? RPT - 1 : q - 1);
+}
+
+template <int RPT, int W>
+__global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
+  if (a.d_skip != nullptr && *a.d_skip != 0) return;
+  extern __shared__ double pw_x[];
+  __shared__ int s_abort;
+  constexpr int RB = PW_T * RPT, XN = RB + 2 * PW_HALO;
+  constexpr int NBND = RPT > 1 ? 2 : 1;   // slices a neighbour reads
+  const int t = threadIdx.x;
+  const int b = pw_band_of(blockIdx.x, a.nb);
+  const int r0 = b * RB;
+  double *xa = pw_x, *xb = pw_x + XN;
+
+  // ---- the band's matrix slice → registers (once per launch); val / col are padded by a tile, so k0 + j stays in bounds
+  double v[RPT][W];
+  int ci[RPT][W];
+  int len[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = r0 + t + PW_T * i;
+    const int rc = r < a.nrows ? r : a.nrows - 1;
+    const int k0 = a.rowptr[rc], k1 = a.rowptr[rc + 1];
+    len[i] = r < a.nrows ? k1 - k0 : 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      v[i][j] = a.val[k0 + j];
+      const int c = a.col[k0 + j];
+      ci[i][j] = (j < len[i]) ? c - (r0 - PW_HALO) : PW_HALO + t + PW_T * i;   // (slots past the row's end: never summed)
+    }
+  }
+  for (int idx = t; idx < XN; idx += PW_T) {
+    const int g = r0 - PW_HALO + idx;
+    xa[idx] = (g >= 0 && g < a.nrows) ? a.x0[g] : 0.0;
+    xb[idx] = 0.0;
+  }
+  if (t == 0) s_abort = 0;
+  __syncthreads();
+
+  const bool shifted = a.theta != nullptr;
+  for (int p = 0; p < a.s; ++p) {
+    const double *xin = (p & 1) ? xb : xa;
+    double *xout = (p & 1) ? xa : xb;
+    const double *osp = (p == 0) ? a.scal_first : a.scal_rest;
+    const double os = osp ? *osp : 1.0;
+    const double th = shifted ? a.theta[p] : 0.0;
+    double *ycol = a.Y + (int64_t)p * a.ldy;
+    const bool pub = p + 1 < a.s;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = pw_slice<RPT>(q);
+      const int lr = t + PW_T * i, r = r0 + lr;
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const double pr = v[i][j] * xin[ci[i][j]];
+        sum = (j < len[i]) ? sum + pr : sum;
+      }
+      double out = shifted ? sum - th * xin[PW_HALO + lr] : sum;
+      out = osp ? os * out : out;
+      if (r < a.nrows) {
+        xout[PW_HALO + lr] = out;
+        if (q < NBND) pw_store_sc1(ycol + r, out);   // rows a neighbour band reads: write-through
+        else ycol[r] = out;
+      }
+      if (pub && a.variant == 0 && q == NBND - 1) {   // publish as early as possible: behind the boundary slices
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0)
+          __hip_atomic_store(a.flags + (size_t)b * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (!pub) break;
+    if (a.variant != 0) {   // publish behind the whole band: the interior rows overlap the boundary rows' write-through
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0)
+        __hip_atomic_store(a.flags + (size_t)b * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the neighbours' boundary rows of power p → the halo parts of the next input buffer
+    if (t == 0 && b > 0) {
+      if (!pw_wait(a.flags + (size_t)(b - 1) * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+    }
+    if (t == 64 && b + 1 < a.nb) {
+      if (!pw_wait(a.flags + (size_t)(b + 1) * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    {
+      const int gu = r0 - PW_HALO + t, gd = r0 + RB + t;
+      double hu = 0.0, hd = 0.0;
+      if (b > 0) hu = pw_load_sc1(ycol + gu);
+      if (gd < a.nrows) hd = pw_load_sc1(ycol + gd);
+      xout[t] = hu;
+      xout[PW_HALO + RB + t] = hd;
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------- host side
+struct nk_powers_plan {
+  int rpt = 0, w = 0, nb = 0;
+  uint64_t *d_flags = nullptr;
+  uint64_t *h_err = nullptr, *h_err_dev = nullptr;   // pinned, coherent: {time-outs, bound in ticks}
+  uint64_t epoch = 0;
+  bool broken = false;
+};
+void nk_powers_plan_destroy(nk_powers_plan *P) {
+  if (!P) return;
+  hipFree(P->d_flags);
+  if (P->h_err) hipHostFree(P->h_err);
+  delete P;
+}
+static int pw_variant() {
+  static const int v = getenv("NK_PW_VARIANT") ? atoi(getenv("NK_PW_VARIANT")) : 0;
+  return v;
+}
+static bool pw_enabled() {
+  static const bool on = !(getenv("NK_SPMV_POWERS") && atoi(getenv("NK_SPMV_POWERS")) == 0);
+  return on;
+}
+
+template <int RPT, int W>
+static int pw_launch(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
+  constexpr size_t lds = (size_t)2 * (PW_T * RPT + 2 * PW_HALO) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    attr_set = true;
+  }
+  if (query) {
+    NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers<RPT, W>, PW_T, lds));
+    return NK_OK;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
+    hipExtLaunchKernelGGL((k_spmv_powers<RPT, W>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
+  else
+    hipLaunchKernelGGL((k_spmv_powers<RPT, W>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+static int pw_dispatch(nk_ctx *ctx, int rpt, int w, const pw_args &a, bool query, int *occ) {
+#define PW_CASE(R, WW) if (rpt == R && w == WW) return pw_launch<R, WW>(ctx, a, query, occ)
+  PW_CASE(1, 5); PW_CASE(2, 5); PW_CASE(4, 5); PW_CASE(6, 5);
+  PW_CASE(1, 8); PW_CASE(2, 8);
+  PW_CASE(1, 16);
+#undef PW_CASE
+  NK_FAIL(NK_E_INVALID, "internal: no matrix-powers kernel for %d rows per thread × %d entries per row", rpt, w);
+}
+
+// Builds (once per pattern) the plan of the resident matrix-powers kernel; A->pw stays NULL when the matrix is not eligible.
+static int pw_plan(nk_csr *A) {
+  if (A->pw_tried) return NK_OK;
+  A->pw_tried = true;
+  nk_ctx *ctx = A->ctx;
+  if (!pw_enabled() || ctx->nranks != 1 || !A->halo_gcols.empty() || A->nrows < 1 || A->nnz < 1) return NK_OK;
+  const int64_t n = A->nrows;
+  int maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) maxlen = std::max(maxlen, (int)(A->h_rowptr[r + 1] - A->h_rowptr[r]));
+  const int w = maxlen <= 5 ? 5 : (maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 0));
+  if (!w) return NK_OK;
+  const int64_t per_cu = (n + ctx->num_cus - 1) / ctx->num_cus;
+  const int need = (int)((per_cu + PW_T - 1) / PW_T);
+  const int rpt = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 6 ? 6 : 0)));
+  if (!rpt) return NK_OK;
+  if ((w == 8 && rpt > 2) || (w == 16 && rpt > 1)) return NK_OK;   // register budget (128 VGPRs at 1024 threads): RPT·W ≤ 30 slots
+  const int64_t rb = (int64_t)PW_T * rpt;
+  const int nb = (int)((n + rb - 1) / rb);
+  for (int64_t r = 0; r < n; ++r) {   // every column of a band within one slice of its neighbours
+    const int64_t b0 = (r / rb) * rb, lo = b0 - PW_HALO, hi = b0 + rb + PW_HALO;
+    for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k)
+      if (A->h_col[k] < lo || A->h_col[k] >= hi) return NK_OK;
+  }
+  pw_args probe{};
+  int occ = 0;
+  NK_TRY(pw_dispatch(ctx, rpt, w, probe, true, &occ));
+  if (occ < 1 || nb > ctx->num_cus * occ) return NK_OK;
+  nk_powers_plan *P = new nk_powers_plan();
+  auto guard = nk_make_guard(P, [](nk_powers_plan *p) { nk_powers_plan_destroy(p); });
+  P->rpt = rpt; P->w = w; P->nb = nb;
+  NK_TRY(nk_dev_alloc(&P->d_flags, (size_t)nb * PW_FLAG_STRIDE));
+  NK_HIP(hipMemset(P->d_flags, 0, (size_t)nb * PW_FLAG_STRIDE * sizeof(uint64_t)));
+  NK_HIP(hipHostMalloc((void **)&P->h_err, 2 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
+  NK_HIP(hipHostGetDevicePointer((void **)&P->h_err_dev, P->h_err, 0));
+  P->h_err[0] = 0;
+  {
+    const char *e = getenv("NK_PW_TIMEOUT_MS");
+    const double ms = e ? atof(e) : 250.0;
+    P->h_err[1] = (uint64_t)((ms > 1.0 ? ms : 1.0) * 1.0e5);   // 100 MHz wall clock
+  }
+  A->pw = guard.release();
+  return NK_OK;
+}
+bool nk_csr_powers_ready(nk_csr *A) {
+  if (!A->pw_tried && pw_plan(A) != NK_OK) return false;
+  return A->pw != nullptr && !A->pw->broken && A->pw->h_err[0] == 0;
+}
+// a time-out of an earlier launch (workgroups not resident together?): the plan is off for good; NK_E_HIP once
+int nk_csr_powers_check(nk_csr *A) {
+  if (!A->pw || A->pw->broken || A->pw->h_err[0] == 0) return NK_OK;
+  A->pw->broken = true;
+  NK_FAIL(NK_E_HIP, "resident matrix-powers kernel: a workgroup waited longer than NK_PW_TIMEOUT_MS for its neighbour band "
+                    "(NK_SPMV_POWERS=0 keeps the streaming SpMV)");
+}
+int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, int s, const double *d_scal_first,
+                      const double *d_scal_rest, const double *d_theta, const int *d_skip) {
+  NK_REQUIRE(nk_csr_powers_ready(A), "internal: matrix powers on a matrix without a plan");
+  NK_REQUIRE(s >= 1 && s <= 200, "matrix powers: 1 ≤ s ≤ 200");
+  nk_ctx *ctx = A->ctx;
+  nk_powers_plan *P = A->pw;
+  pw_args a;
+  a.nrows = (int)A->nrows; a.nb = P->nb; a.s = s; a.variant = pw_variant();
+  a.rowptr = A->d_rowptr; a.col = A->d_col; a.val = A->d_val;
+  a.x0 = d_x0; a.Y = d_Y; a.ldy = ldy;
+  a.scal_first = d_scal_first; a.scal_rest = d_scal_rest; a.theta = d_theta; a.d_skip = d_skip;
+  a.flags = P->d_flags; a.base = (++P->epoch) << 8; a.err = P->h_err_dev;
+  ctx->stats.op_applies += s;
+  nk_prof_scope prof_(ctx, NK_K_POWERS,
+                      (double)s * (12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows));
+  return pw_dispatch(ctx, P->rpt, P->w, a, false, nullptr);
+}
+
+// Y[:, p] = scale·(A − θ_p I) Y[:, p−1], Y[:, −1] = x (θ = NULL: plain powers). The resident kernel where the matrix is
+// eligible (*resident = 1), s streaming launches otherwise — bit-identical either way.
+extern "C" int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy, int s, const double *theta, double scale,
+                             int memspace, int *resident) {
+  NK_REQUIRE(A && x && Y && s >= 1 && s <= 64 && ldy >= A->nrows, "bad argument");
+  nk_ctx *ctx = A->ctx;
+  NK_HIP(hipSetDevice(ctx->device));
+  const int64_t n = A->nrows;
+  double *dx = nullptr, *dY = nullptr, *dsc = nullptr;
+  auto cleanup = [&]() { if (memspace != NK_DEVICE) { hipFree(dx); hipFree(dY); } hipFree(dsc); };
+  if (memspace == NK_DEVICE) { dx = const_cast<double *>(x); dY = Y; }
+  else {
+    NK_TRY(nk_dev_alloc(&dx, (size_t)n));
+    if (nk_dev_alloc(&dY, (size_t)ldy * s) != NK_OK) { cleanup(); return NK_E_NOMEM; }
+    NK_HIP(hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (nk_dev_alloc(&dsc, (size_t)s + 1) != NK_OK) { cleanup(); return NK_E_NOMEM; }
+  std::vector<double> hs((size_t)s + 1, 0.0);
+  hs[0] = scale;
+  if (theta) for (int p = 0; p < s; ++p) hs[1 + p] = theta[p];
+  hipMemcpy(dsc, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice);
+  const bool res = nk_csr_powers_ready(A);
+  int rc = NK_OK;
+  if (res) {
+    rc = nk_csr_powers_dev(A, dx, dY, ldy, s, dsc, dsc, theta ? dsc + 1 : nullptr, nullptr);
+  } else {
+    for (int p = 0; p < s && rc == NK_OK; ++p) {
+      nk_spmv_epi ep;
+      if (theta) { ep.mode = 3; ep.theta = dsc + 1 + p; }
+      rc = nk_csr_spmv_dev(A, p == 0 ? dx : dY + (size_t)(p - 1) * ldy, dY + (size_t)p * ldy, nullptr, dsc, &ep);
+    }
+  }
+  if (rc == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { nk_set_error("stream error in nk_csr_powers"); rc = NK_E_HIP; }
+  if (rc == NK_OK) rc = nk_csr_powers_check(A);
+  if (rc == NK_OK && memspace != NK_DEVICE)
+    if (hipMemcpy(Y, dY, (size_t)ldy * s * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = NK_E_HIP;
+  cleanup();
+  if (resident) *resident = res ? 1 : 0;
+  return rc;
+}

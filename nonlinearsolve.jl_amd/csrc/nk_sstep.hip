@@ -1185,7 +1185,12 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     if (wait_progress && k > 1 && !wait_progress(k - 1 - prev_sb)) break;
     prev_sb = sb;
     double *Wk = G->V + (size_t)k * ldv;
-    for (int j = 0; j < sb; ++j)  // the block's basis vectors: (A − θ_j I) applied s times (right-preconditioned operator), scaled by 1/σ
+    // the block's basis vectors: (A − θ_j I) applied s times (right-preconditioned operator), scaled by 1/σ — in one launch
+    // with the matrix held on the chip where that applies (nk_powers.hip), else one operator launch per column
+    bool powers = false;
+    NK_TRY(nk_gmres_op_powers(G, G->V + (size_t)(k - 1) * ldv, Wk, ldv, sb, done, W->scal, W->newton ? W->scal + SS_TH : nullptr,
+                              &powers));
+    for (int j = 0; j < sb && !powers; ++j)
       NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1),
                                W->newton ? W->scal + SS_TH + j : nullptr));
     const int grid = nk_ss_grid(ctx, n, k, sb);

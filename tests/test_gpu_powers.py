@@ -1,0 +1,144 @@
+"""Resident matrix-powers kernel (csrc/nk_powers.hip) — the s operator applications of an s-step Arnoldi block in ONE launch,
+the matrix held in registers, neighbouring row bands handing their boundary rows over through write-through stores and flags.
+
+Parity bar: BIT-IDENTICAL to s applications of the sequential CPU row sum of the C oracle (`CO.spmv`, the same bar as the
+streaming SpMV, tests/test_gpu_kernels.py::test_spmv_bratu_bit_exact) with the Newton-basis epilogue
+y = scale·(A x − θ x) formed as the streaming kernel forms it — every word of every column is compared, repeatedly (the
+hand-off is a race if it is wrong: MI355X_MICROARCH.md asks for tests under uneven load that check every word)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import reference_restatement as R
+from oracle import c_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+def _powers_ref(J, x, s, theta, scale):
+    """s sequential applications with the oracle's CSR-order row sum; epilogue as nk_csr.hip::spmv_store_row (mode 3 / 0)."""
+    ip, ix, dv = J.indptr.astype(np.int32), J.indices.astype(np.int32), J.data
+    out = np.empty((s, x.size))
+    cur = x
+    for p in range(s):
+        y = CO.spmv(ip, ix, dv, cur)
+        if theta is not None:
+            y = y - theta[p] * cur
+        y = scale * y
+        out[p] = y
+        cur = y
+    return out
+
+
+def _banded(n, half_bw, per_row, seed):
+    """random banded matrix: 1 … per_row entries per row (ragged) within ±half_bw of the diagonal, diagonal always stored"""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    off = rng.integers(-half_bw, half_bw + 1, size=n * per_row)
+    off[::per_row] = 0
+    c = np.clip(r + off, 0, n - 1)
+    keep = rng.random(n * per_row) < 0.7
+    keep[::per_row] = True
+    A = sp.csr_matrix((rng.standard_normal(int(keep.sum())) * 0.3, (r[keep], c[keep])), shape=(n, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("ns,s", [(8, 3), (64, 15), (200, 15), (257, 7), (512, 15), (1024, 15)])
+def test_resident_powers_bratu_bit_exact(nls, dev, ns, s):
+    """Bratu Jacobians from 64 rows (one band) to config C3's 1024² (256 bands × 4096 rows, the headline matrix)."""
+    import torch
+    p = R.Bratu2D(ns)
+    rng = np.random.default_rng(ns)
+    J = p.jac(rng.standard_normal(p.n) * 0.1)
+    A = nls.CSRMatrix.from_scipy(J)
+    x = rng.standard_normal(p.n)
+    lam = float(abs(J).sum(axis=1).max())
+    theta = (0.5 + 0.4 * np.cos(np.arange(s))) * lam
+    scale = 2.0 / lam
+    ref = _powers_ref(J, x, s, theta, scale)
+    dx = torch.tensor(x, device=dev)
+    for rep in range(3):   # repeated launches: the flag epochs must keep the launches apart
+        Y, resident = A.powers(dx, s, theta=theta, scale=scale)
+        assert resident, "Bratu Jacobians up to 1024² are the matrices this kernel is for"
+        assert np.array_equal(Y.cpu().numpy(), ref), f"rep {rep}: first differing power " \
+            f"{int(np.argmax((Y.cpu().numpy() != ref).any(axis=1)))}"
+    Yh, resident = A.powers(x, 4, theta=None, scale=1.0)   # host vectors, plain powers
+    assert resident and np.array_equal(Yh, _powers_ref(J, x, 4, None, 1.0))
+
+
+@pytest.mark.parametrize("n,hbw,per_row", [(5000, 3, 5), (70000, 1000, 5), (300000, 1024, 8), (150000, 700, 16),
+                                            (1048576, 1024, 5), (1300000, 900, 4)])
+def test_resident_powers_random_banded(nls, dev, n, hbw, per_row):
+    """Ragged rows (1 … W entries), partial last band, every register layout (1 / 2 / 4 / 6 rows per thread; 5 / 8 / 16 slots)."""
+    import torch
+    A = _banded(n, hbw, per_row, seed=n % 97)
+    M = nls.CSRMatrix.from_scipy(A)
+    x = np.random.default_rng(5).standard_normal(n)
+    s = 6
+    theta = np.linspace(-0.3, 0.4, s)
+    ref = _powers_ref(A, x, s, theta, 0.7)
+    Y, resident = M.powers(torch.tensor(x, device=dev), s, theta=theta, scale=0.7)
+    assert resident
+    assert np.array_equal(Y.cpu().numpy(), ref)
+
+
+def test_streaming_fallback_for_ineligible_matrices(nls, dev):
+    """wide band, long rows, too many rows: s streaming launches, same bits"""
+    import torch
+    for A in (_banded(20000, 5000, 5, 1), _banded(3000, 40, 24, 2)):
+        M = nls.CSRMatrix.from_scipy(A)
+        x = np.random.default_rng(6).standard_normal(A.shape[0])
+        theta = np.array([0.1, -0.2, 0.3])
+        Y, resident = M.powers(torch.tensor(x, device=dev), 3, theta=theta, scale=1.5)
+        assert not resident
+        assert np.array_equal(Y.cpu().numpy(), _powers_ref(A, x, 3, theta, 1.5))
+
+
+def test_resident_powers_under_uneven_load(nls, dev):
+    """a second stream keeps part of the chip busy while the band hand-offs run: every word of 15 powers, 20 launches"""
+    import torch
+    p = R.Bratu2D(512)
+    rng = np.random.default_rng(11)
+    J = p.jac(rng.standard_normal(p.n) * 0.1)
+    A = nls.CSRMatrix.from_scipy(J)
+    x = rng.standard_normal(p.n)
+    lam = float(abs(J).sum(axis=1).max())
+    theta = (0.5 + 0.4 * np.cos(np.arange(15))) * lam
+    ref = _powers_ref(J, x, 15, theta, 2.0 / lam)
+    dx = torch.tensor(x, device=dev)
+    side = torch.cuda.Stream()
+    big = torch.randn(1 << 24, device=dev, dtype=torch.float64)
+    for rep in range(20):
+        with torch.cuda.stream(side):
+            for _ in range(rep % 4):
+                big = big * 1.0000001
+        Y, resident = A.powers(dx, 15, theta=theta, scale=2.0 / lam)
+        assert resident and np.array_equal(Y.cpu().numpy(), ref), rep
+    torch.cuda.synchronize()
+
+
+def test_sstep_gmres_with_resident_powers_equals_streaming(nls, dev, monkeypatch):
+    """the s-step solver's iterates do not depend on which kernel built the block: NK_SPMV_POWERS=0 in a child process"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, nonlinearsolve_jl_amd as nls\n"
+        "prob = nls.NonlinearProblem(nls.Bratu2D(256, 6.0))\n"
+        "alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho='sstep', fixed_iters=30),"
+        " concrete_jac=True)\n"
+        "cache = nls.init(prob, alg, abstol=1e-300, maxiters=50)\n"
+        "for _ in range(3): cache.step()\n"
+        "u = cache.u\n"
+        "u = np.asarray(u.cpu() if hasattr(u, 'cpu') else u)\n"
+        "import hashlib; print('HASH', hashlib.sha256(u.tobytes()).hexdigest(), float(np.abs(u).max()))\n")
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, NK_SPMV_POWERS=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert outs[0] == outs[1], outs
