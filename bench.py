@@ -38,6 +38,7 @@ import argparse
 import json
 import math
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -45,6 +46,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import step_model  # noqa: E402  (tools/step_model.py: the launches of a fixed-work Newton step and their bytes)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
@@ -66,6 +69,7 @@ def parse_args():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling run")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance extras")
+    ap.add_argument("--no-spmv-hbm", action="store_true", help="skip the HBM-resident SpMV measurement (Bratu 4096², ≈ 10 s)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: at N = 1 measure roofline.traffic in this run (two short rocprofv3 --pmc child passes of this "
                          "script: FETCH_SIZE, WRITE_SIZE); falls back to the newest PMC summary under profiles/")
@@ -125,7 +129,7 @@ def live_pmc_traffic(args, kname):
                 acc = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
-                        if r.get("Counter_Name") == counter and r.get("Kernel_Name", "").replace("void ", "").startswith(kname):
+                        if r.get("Counter_Name") == counter and re.match(kname, r.get("Kernel_Name", "").replace("void ", "")):
                             acc.append(float(r["Counter_Value"]))
                 if not acc:
                     return None, None
@@ -164,33 +168,50 @@ def timed_steps(cache, steps, barrier, dist, world, backend, torch):
     return dt
 
 
-def sstep_blocks(arnoldi, s):
-    """(k, width) of the blocks the s-step cycle builds (csrc/nk_sstep.hip::nk_ss_cycle / nk_ss_block_width)"""
-    out, k = [], 1
-    while k - 1 < arnoldi:
-        w = min(s, arnoldi - (k - 1))
-        w = 15 if w >= 15 else 12 if w >= 12 else 10 if w >= 10 else min(w, 8)
-        if k + w > 48 and w > 8:
-            w = 8
-        out.append((k, w))
-        k += w
-    return out
-
-
-def algorithmic_bytes_per_step(args, n, nnz, newton_basis):
-    """HBM bytes one fixed-work Newton step has to move (every array touched once per kernel that needs it)"""
-    b_op = 24.0 * n if args.matfree else 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
-    m = args.arnoldi
+def bytes_per_step(args, n, nnz, newton_basis, resident_powers):
+    """(HBM bytes the launched kernels of one fixed-work Newton step must move, the same with every operator application
+    charged at SURVEY.md §8(d)'s CSR-SpMV figure) — tools/step_model.py lists the launches one by one; the column-by-column
+    forms keep the closed formula of DESIGN.md §5"""
     if args.ortho == "sstep":
         s = args.sstep or (15 if newton_basis else 6)
-        sweeps = sum(8.0 * n * (3 * (k + w) + 2 * w) for k, w in sstep_blocks(m, s))     # A: k+w read; B, C: k+w read + w written
-        krylov = m * b_op + sweeps
-        bounds = 0.0 if not newton_basis else (12.0 * nnz + 4.0 * n if not args.matfree else 8.0 * n)   # Gershgorin pass per Jacobian
-    else:
-        krylov = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(m))    # delayed CGS2: two sweeps per column
-        bounds = 0.0
-    once = 8.0 * n * (m + 2) + (0.0 if args.matfree else 8.0 * nnz + 8.0 * n) + 16.0 * n + 24.0 * n + 16.0 * n + 16.0 * n
-    return krylov + bounds + once
+        return step_model.step_bytes(n, nnz, arnoldi=args.arnoldi, s=s, matfree=args.matfree, resident_powers=resident_powers,
+                                     newton_basis=newton_basis)
+    b_op = 24.0 * n if args.matfree else step_model.spmv_bytes(n, nnz)
+    m = args.arnoldi
+    krylov = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(m))    # delayed CGS2: two sweeps per column
+    once = 8.0 * n * (m + 2) + (0.0 if args.matfree else 8.0 * nnz + 8.0 * n) + 16.0 * n + 24.0 * n + 16.0 * n + 8.0 * n
+    return krylov + once, krylov + once
+
+
+def spmv_hbm_resident(nls, torch, ctx, reps=30):
+    """The streaming CSR SpMV where NOTHING is cache resident: Bratu 4096² (1.07 GB of matrix against the 256 MiB Infinity
+    Cache), the kernel's own begin→end timestamps, median of `reps` launches — the HBM-level figure next to the 1024² ones."""
+    ns = 4096
+    P = nls.Bratu2D(ns, 6.0)
+    n = ns * ns
+    u = torch.zeros(n, dtype=torch.float64, device="cuda")
+    v = torch.randn(n, dtype=torch.float64, device="cuda")
+    J = P.jac_csr()
+    P.jac_values(u, J)
+    y = torch.empty_like(v)
+    ts = []
+    by = 0.0
+    for i in range(5 + reps):
+        ctx.profile_enable(True)
+        J.matvec(v, out=y)
+        r = ctx.profile_report()["spmv"]
+        by = r["bytes"] / r["launches"]
+        if i >= 5:
+            ts.append(r["avg_us"])
+    ctx.profile_enable(False)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    del J, P, u, v, y
+    torch.cuda.empty_cache()
+    return {"kernel": "k_spmv_stream", "grid": ns, "algorithmic_bytes_per_launch": int(by), "median_us": round(med, 2),
+            "achieved": round(by / med / 1e3, 1), "unit": "GB/s", "frac": round(by / med / 1e3 / HBM_PEAK_GBS, 4),
+            "frac_of_achievable_6.29TBs": round(by / med / 1e3 / HBM_ACHIEVABLE_GBS, 4), "launches": reps,
+            "note": "Bratu 4096² Jacobian (1.07 GB): nothing fits the Infinity Cache — the streaming kernel against HBM itself"}
 
 
 def cpu_baseline(ns, arnoldi, matfree, budget_s):
@@ -315,45 +336,67 @@ def main():
         kernels = ctx.profile_report()
         ctx.profile_enable(False)
     step_stats = dict(STEP_STATS)
-    dom = "spmv" if not args.matfree else "jvp"
+    # ---- `roofline`: the TIME-DOMINANT kernel family of the step (with the matrix-powers kernel holding the matrix on the chip
+    # that is no longer the SpMV but the s-step process's Gram sweeps). achieved = algorithmic bytes ÷ HIP-event time of the
+    # family's launches; traffic = HBM bytes per launch from the PMC counters, measured in this run where possible.
+    FAMILY = {"spmv": ("k_spmv_stream", r"k_spmv_stream<"),
+              "spmv_powers": ("k_spmv_powers", r"k_spmv_powers<"),
+              "jvp": ("k_bratu_jvp", r"k_bratu_jvp"),
+              "multidot": ("k_ss_block<S, *, GRAM = true, …> (s-step sweeps A and B: Gram blocks on the FP64 matrix cores)"
+                           if args.ortho == "sstep" else "k_dcgs2r_dots", r"k_ss_block<\d+, (true|false), true" if args.ortho == "sstep" else r"k_dcgs2r_dots"),
+              "multiaxpy": ("k_ss_block<S, true, false, …> + k_multiaxpy (sweep C, x = V y)" if args.ortho == "sstep" else "k_dcgs2r_axpy_tail",
+                            r"(k_ss_block<\d+, true, false|k_multiaxpy)" if args.ortho == "sstep" else r"k_dcgs2r_axpy")}
     roof = None
-    if dom in kernels:
-        k = kernels[dom]
-        kname = "k_spmv_stream" if dom == "spmv" else "k_bratu_jvp"
-        # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 ×2 correction on
-        # FETCH_SIZE): measured in this run by two short rocprofv3 child passes (live_pmc_traffic); if that is not possible,
-        # the newest summary committed under profiles/ (the same kernel at the same size is a per-launch constant); else null.
-        traffic, tsrc = None, None
-        under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
-        if args.pmc == "auto" and world == 1 and not os.environ.get("BENCH_PMC_CHILD") and not under_profiler:
-            traffic, tsrc = live_pmc_traffic(args, kname)
-        if traffic is None:
-            try:
-                import glob
-                tag = {"c3": "", "c4": "c4size_1gpu_"}.get(args.workload)
-                cand = sorted(c for c in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_pmc.json"))
-                              if tag is not None and (("c4size" in c) == (tag != "")))
-                if cand and world == 1 and not args.n:
-                    pm = json.load(open(cand[-1]))
-                    for key, v in pm.items():
-                        if key.startswith(kname):
-                            traffic, tsrc = int(v["hbm_bytes_per_launch"]), "committed summary profiles/" + os.path.basename(cand[-1])
-            except Exception:  # noqa: BLE001
-                pass
-        roof = {"kernel": kname, "bound": "hbm",
+    heavy = {k: v for k, v in kernels.items() if k in FAMILY}
+    dom = max(heavy, key=lambda k: heavy[k]["total_ms"]) if heavy else None
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    can_pmc = args.pmc == "auto" and world == 1 and not os.environ.get("BENCH_PMC_CHILD") and not under_profiler
+
+    def family_roofline(fam):
+        k = kernels[fam]
+        kname, pattern = FAMILY[fam]
+        traffic, tsrc = (live_pmc_traffic(args, pattern) if can_pmc else (None, None))
+        return {"kernel": kname, "family": fam, "bound": "hbm",
                 "achieved": round(k["gbps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k["gbps"] / HBM_PEAK_GBS, 4),
                 "frac_of_achievable_6.29TBs": round(k["gbps"] / HBM_ACHIEVABLE_GBS, 4),
                 "traffic": traffic, "traffic_source": tsrc, "launches": k["launches"],
-                "avg_us": round(k["avg_us"], 2),
+                "avg_us": round(k["avg_us"], 2), "share_of_step_time": None,
                 "timing": "hipExtLaunchKernelGGL start/stop events (kernel begin→end on the launch stream)",
                 "algorithmic_bytes_per_launch": int(k["bytes"] / k["launches"])}
+
+    if dom:
+        roof = family_roofline(dom)
+    # ---- the operator itself (the metric's second half: SpMV GB/s against the HBM roofline), whatever dominates the step
+    roof_spmv = None
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.matfree:
+        roof_spmv = {}
+        if "spmv_powers" in kernels:
+            k = kernels["spmv_powers"]
+            per = int(round(k["bytes"] / k["launches"] / step_model.spmv_bytes(n_global, 5 * n_global - 4 * ns)))
+            roof_spmv["resident_matrix_powers"] = {
+                "kernel": "k_spmv_powers", "applications_per_launch": per, "avg_us": round(k["avg_us"], 2),
+                "us_per_application": round(k["avg_us"] / max(per, 1), 2),
+                "achieved": round(k["gbps"], 1), "unit": "GB/s", "frac": round(k["gbps"] / HBM_PEAK_GBS, 4),
+                "hbm_bytes_per_launch_model": int(12.0 * (5 * n_global - 4 * ns) + 4.0 * (n_global + 1) + 8.0 * n_global * (per + 1)),
+                "note": "algorithmic CSR bytes (SURVEY.md §8d: 80 N per application) ÷ time — above the HBM peak because the matrix "
+                        "is read ONCE per launch and held in the vector registers (csrc/nk_powers.hip); the HBM-level figure of "
+                        "the streaming kernel is `streaming_hbm_resident`"}
+        if "spmv" in kernels:
+            roof_spmv["streaming_in_solver"] = {k_: v_ for k_, v_ in family_roofline("spmv").items() if k_ != "share_of_step_time"}
+        if not args.no_spmv_hbm and not os.environ.get("BENCH_PMC_CHILD"):
+            try:
+                roof_spmv["streaming_hbm_resident"] = spmv_hbm_resident(nls, torch, ctx)
+            except Exception as ex:  # noqa: BLE001
+                roof_spmv["streaming_hbm_resident"] = {"error": str(ex)}
     ksum = {name: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "GB/s": round(v["gbps"], 1),
                    "frac_of_8TBs": round(v["gbps"] / HBM_PEAK_GBS, 4), "share_of_step_time": None}
             for name, v in kernels.items()}
     tot = sum(v["total_ms"] for v in kernels.values()) or 1.0
     for name, v in kernels.items():
         ksum[name]["share_of_step_time"] = round(v["total_ms"] / tot, 4)
+    if roof is not None:
+        roof["share_of_step_time"] = ksum[roof["family"]]["share_of_step_time"]
 
     # ---- N > 1 on the CSR operator with the RCCL transport: try the SpMV with its halo exchange overlapped with the
     # interior row blocks (second stream + events). Reported only if faster, under a watchdog.
@@ -455,15 +498,21 @@ def main():
     if args.workload != "c5":
         nnz_l = 5 * n_global - 4 * ns
         newton_basis = args.ortho == "sstep" and args.sstep_basis != "monomial"
-        bps = algorithmic_bytes_per_step(args, n_global, nnz_l, newton_basis)
-        gbs = bps / (dt / args.steps) * 1e-9
+        hbm_b, alg_b = bytes_per_step(args, n_global, nnz_l, newton_basis, "spmv_powers" in kernels)
+        sec = dt / args.steps
+        gbs, gbs_alg = hbm_b / sec * 1e-9, alg_b / sec * 1e-9
         fam = max(ksum, key=lambda kname: ksum[kname]["share_of_step_time"] or 0.0) if ksum else None
-        roof_step = {"bound": "hbm", "algorithmic_bytes_per_step": int(bps), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * world,
+        roof_step = {"bound": "hbm", "hbm_bytes_per_step": int(hbm_b), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * world,
                      "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 4),
                      "frac_of_achievable_6.29TBs": round(gbs / (HBM_ACHIEVABLE_GBS * world), 4),
-                     "floor_ms_at_6.29TBs": round(bps / (HBM_ACHIEVABLE_GBS * world * 1e9) * 1e3, 4),
+                     "floor_ms_at_6.29TBs": round(hbm_b / (HBM_ACHIEVABLE_GBS * world * 1e9) * 1e3, 4),
+                     "algorithmic_bytes_per_step": int(alg_b), "achieved_algorithmic": round(gbs_alg, 1),
+                     "frac_algorithmic": round(gbs_alg / (HBM_PEAK_GBS * world), 4),
                      "time_dominant_family": fam, "time_dominant_share": ksum[fam]["share_of_step_time"] if fam else None,
-                     "note": "whole step: bytes every kernel of a fixed-work Newton step must move ÷ the measured ms_per_step"}
+                     "note": "whole step. hbm_bytes_per_step: what the LAUNCHED kernels must move between HBM and the chip "
+                             "(tools/step_model.py lists them; the resident matrix-powers kernel reads the matrix once per block) ÷ "
+                             "ms_per_step → frac. algorithmic_bytes_per_step: the same with every operator application charged at "
+                             "the CSR SpMV's 80 N bytes (SURVEY.md §8d) → frac_algorithmic, which on-chip reuse can push past 1"}
     if rank == 0:
         op = "matfree_jvp" if args.matfree else "csr_spmv"
         if args.workload == "c5":
@@ -483,7 +532,7 @@ def main():
             "config": {"workload": wl, "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
                        "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho if args.ortho != "sstep" else "sstep_%s_%s" % (args.sstep or "auto", args.sstep_basis),
                        "parallelism": f"row-range x{world}", "comm": comm, "comm_selfcheck": selfchecks, "halo_overlap": overlap},
-            "roofline": roof, "roofline_step": roof_step, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
+            "roofline": roof, "roofline_spmv": roof_spmv, "roofline_step": roof_step, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
             # against the BEST figure the CPU leg produced (its sustained median or its thread scan, whichever is higher)
             "gpu_vs_cpu": round(steps_per_s / max(cpu["value"], cpu.get("thread_scan_best", 0.0)), 1) if cpu and "value" in cpu else None,
             "check": {"fnorm_inf_after_timed_steps": fnorm, "gmres_iters": stats.gmres_iters,

@@ -1037,6 +1037,13 @@ class FirstOrderCache:
         return b.value
 
     @property
+    def eta(self):
+        """the Eisenstat–Walker forcing cache's η (`cache.forcing_cache.η`, eisenstat_walker.jl:32-39)"""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(L.lib().nk_solver_get_scalars(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return c.value
+
+    @property
     def fnorm_inf(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         check(L.lib().nk_solver_get_scalars(self._h, C.byref(a), C.byref(b), C.byref(c)))

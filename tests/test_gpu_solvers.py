@@ -851,3 +851,26 @@ def test_solver_started_at_the_root(nls, algname):
     assert sol.retcode == R.RETCODE_NAMES[ref.retcode] == "Success"
     assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf
     assert np.max(np.abs(np.asarray(sol.u) - root)) <= 1e-12
+
+
+def test_eisenstat_walker_state_is_reset_by_reinit_misc_tests_item6(nls):
+    """lib/NonlinearSolveFirstOrder/test/misc_tests__item6.jl:9-17 on the device solver (the oracle's pin of the same name is
+    tests/test_oracle_pins.py): η off η₀ after solve!, back on η₀ after reinit!(cache; p = 3.0), the re-solve ≈ √3 — and the η
+    history of both solves equal to the oracle's."""
+    ew = nls.EisenstatWalkerForcing2()
+    prob = nls.NonlinearProblem(nls.Quadratic(2, 2.0), u0=np.array([1.0, 1.0]))
+    c = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(), forcing=ew))
+    oc = R.init(R.Quadratic(2, 2.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(), forcing=R.EisenstatWalkerForcing2()),
+                u0=np.array([1.0, 1.0]))
+    assert c.eta == ew.eta0
+    sol, osol = c.solve(), oc.solve()
+    assert sol.retcode == "Success" and sol.stats.nsteps == osol.stats.nsteps
+    assert c.eta != ew.eta0 and abs(c.eta - oc.ew_eta) <= 1e-12 * max(1.0, abs(oc.ew_eta))
+    c.reinit(p=3.0)
+    oc.reinit(p=3.0)
+    assert c.eta == ew.eta0 == oc.ew_eta
+    sol2, osol2 = c.solve(), oc.solve()
+    assert sol2.retcode == "Success" and np.allclose(np.asarray(sol2.u), np.sqrt(3.0))
+    assert np.allclose(np.asarray(sol2.u), osol2.u, rtol=1e-12) and sol2.stats.nsteps == osol2.stats.nsteps
+    assert abs(c.eta - oc.ew_eta) <= 1e-12 * max(1.0, abs(oc.ew_eta))
+    c.close()

@@ -1004,3 +1004,17 @@ def test_newton_with_ilu0_as_left_preconditioner_large_systems_tutorial():
     sol_mc = run(R.ObjectPrecs("ilu0", "left"))        # the multicolour ordering: a weaker M (more iterations), the same root
     assert sol_mc.retcode == R.SUCCESS and sol_mc.stats.nsteps == ref.stats.nsteps
     assert sol.stats.gmres_iters < sol_mc.stats.gmres_iters < 4 * sol.stats.gmres_iters
+
+
+# ---- misc_tests__item6.jl:9-17 — the Eisenstat–Walker state: η has moved off η₀ after a solve, `reinit!(cache; p = 3.0)`
+# puts it back (eisenstat_walker.jl:104-107) and the re-solve answers the NEW problem
+def test_eisenstat_walker_state_is_reset_by_reinit_misc_tests_item6():
+    ew = R.EisenstatWalkerForcing2()
+    c = R.init(R.Quadratic(2, 2.0), R.NewtonRaphson(linsolve=GM(), forcing=ew), u0=np.array([1.0, 1.0]))
+    assert c.ew_eta == ew.eta0                      # InternalAPI.init: η = η₀ (eisenstat_walker.jl:92-101)
+    sol = c.solve()
+    assert sol.retcode == R.SUCCESS                 # @test SciMLBase.successful_retcode(sol)
+    assert c.ew_eta != ew.eta0                      # @test fc.η != fc.p.η₀
+    c.reinit(p=3.0)                                 # reinit!(cache; p = 3.0): u0 = the cache's current u
+    assert c.ew_eta == ew.eta0                      # @test fc.η == fc.p.η₀
+    assert np.allclose(c.solve().u, np.sqrt(3.0))   # @test solve!(cache).u ≈ [sqrt(3.0), sqrt(3.0)]

@@ -1,0 +1,84 @@
+"""The launches of ONE fixed-work Newton step of bench.py's default protocol (Bratu, NewtonRaphson, GMRES(m) with exactly m
+Arnoldi steps, the s-step Arnoldi process) and the bytes each of them has to move — the table `roofline_step` of the bench line
+is computed from, and the one tests/test_step_model.py checks kernel by kernel against the rocprofv3 timeline committed under
+profiles/ (so the model cannot charge for work the code no longer launches — round 3's line did).
+
+Two byte counts per launch:
+* `hbm`  — what the launch must move between HBM and the chip given what it keeps on the chip (the resident matrix-powers
+  kernel reads the matrix once per block, csrc/nk_powers.hip);
+* `alg`  — SURVEY.md §8(d)'s algorithmic figure: every operator application charged at the CSR SpMV's 12 nnz + 4 (n + 1) + 16 n
+  bytes however it is executed (what `roofline.achieved` of an SpMV-type kernel is computed from).
+For every kernel except the resident matrix powers the two are equal.
+"""
+
+
+def sstep_blocks(arnoldi, s):
+    """(k, width) of the blocks the s-step cycle builds (csrc/nk_sstep.hip::nk_ss_cycle / nk_ss_block_width)"""
+    out, k = [], 1
+    while k - 1 < arnoldi:
+        w = min(s, arnoldi - (k - 1))
+        w = 15 if w >= 15 else 12 if w >= 12 else 10 if w >= 10 else min(w, 8)
+        if k + w > 48 and w > 8:
+            w = 8
+        out.append((k, w))
+        k += w
+    return out
+
+
+def spmv_bytes(n, nnz):
+    return 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
+
+
+def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True):
+    """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order"""
+    m = arnoldi
+    L = []
+
+    def add(name, hbm, alg=None):
+        L.append((name, float(hbm), float(hbm if alg is None else alg)))
+
+    if not matfree:
+        add("k_bratu_jac", 8.0 * nnz + 8.0 * n)                 # u in, values out (the Gershgorin partials ride along)
+    add("k_copy_sumsq", 16.0 * n)                               # b → column 0, ‖b‖²
+    add("k_ss_cycle_begin", 0)
+    b_op = 24.0 * n if matfree else spmv_bytes(n, nnz)
+    blocks = sstep_blocks(m, s)
+    for bi, (k, w) in enumerate(blocks):
+        if resident_powers and not matfree and w >= 2:
+            # the matrix once, the start column once, w new columns written
+            add("k_spmv_powers", 12.0 * nnz + 4.0 * (n + 1) + 8.0 * n + 8.0 * n * w, w * b_op)
+        else:
+            for _ in range(w):
+                add("k_bratu_jvp" if matfree else "k_spmv_stream", b_op)
+        add("k_ss_block<A>", 8.0 * n * (k + w))                 # Gram of [V X]ᵀX: k + w columns read
+        add("k_ss_reduce_factor", 0)
+        add("k_ss_block<B>", 8.0 * n * (k + 2 * w))             # update (k + w read, w written) + Gram of the result
+        add("k_ss_reduce_factor", 0)
+        if bi + 1 < len(blocks):
+            add("k_ss_block<C>", 8.0 * n * (k + 2 * w))         # second update
+        else:
+            add("k_ss_hess", 0)                                 # the cycle's last block is left at its first pass
+    add("k_backsolve", 0)
+    add("k_multiaxpy", 8.0 * n * (m + 2))                       # x = V y: m + 1 columns read, x written
+    add("k_newton_update", 24.0 * n)
+    add("k_bratu_residual", 16.0 * n)
+    add("k_absmax_sumsq", 8.0 * n)
+    add("k_reduce_inf2", 0)
+    return L
+
+
+def step_bytes(*a, **kw):
+    L = step_launches(*a, **kw)
+    return sum(x[1] for x in L), sum(x[2] for x in L)
+
+
+def canonical(kernel_name):
+    """a rocprofv3 kernel name → the model's name (sweeps: A = Gram only, B = update + Gram, C = update only)"""
+    import re
+    nm = re.sub(r"^void ", "", kernel_name)
+    nm = re.sub(r"\(.*$", "", nm)
+    if nm.startswith("k_ss_block<"):
+        f = [x.strip() for x in nm[len("k_ss_block<"):].rstrip(">").split(",")]
+        upd, gram = f[1] in ("true", "1"), f[2] in ("true", "1")
+        return "k_ss_block<%s>" % ("A" if (gram and not upd) else "B" if (gram and upd) else "C")
+    return re.sub(r"<.*$", "", nm)
