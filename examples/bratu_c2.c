@@ -1,6 +1,6 @@
 /* Plain C against the C ABI (no Python, no C++): config C2 of BASELINE.json — 2-D Bratu 256², NewtonRaphson with the
  * concrete sparse Jacobian and the direct (banded LU) linsolve — followed by the same problem through the matrix-free
- * Newton–Krylov path. This is what a `ccall` binding does (julia/MI355XNewtonKrylov.jl), written out in C.
+ * Newton–Krylov path. This is what a `ccall` binding does (julia/src/MI355XNewtonKrylov.jl), written out in C.
  *
  *   gcc -std=c99 -Iinclude examples/bratu_c2.c -Lnonlinearsolve.jl_amd/lib -lmi355x_nk -lm -o bratu_c2
  *   LD_LIBRARY_PATH=nonlinearsolve.jl_amd/lib ./bratu_c2 [n_side]

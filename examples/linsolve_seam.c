@@ -4,7 +4,7 @@
  * matrix-free path, lib/NonlinearSolveBase/src/jacobian.jl:260-262), :113-115 (update_tolerances!, pushed by
  * EisenstatWalkerForcing2 before every solve, lib/NonlinearSolveFirstOrder/src/eisenstat_walker.jl:50,77) — with the
  * Newton loop of lib/NonlinearSolveFirstOrder/src/solve.jl:325-465 written out on the host. This is what
- * julia/MI355XNewtonKrylov.jl's MI355XGMRES does through `ccall`, minus Julia.
+ * julia/src/MI355XNewtonKrylov.jl's MI355XGMRES does through `ccall`, minus Julia.
  *
  * Three ways of handing `A` over, all with the vectors RESIDENT on the device (memspace = NK_DEVICE, buffers from
  * nk_device_alloc — a host language without a GPU array type needs nothing else):

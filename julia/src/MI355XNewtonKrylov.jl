@@ -131,12 +131,14 @@ function DeviceCSR(A::SparseMatrixCSC{Float64, Int}; ctx = default_ctx())
     GC.@preserve A nkcheck(@ccall libnk.nk_csr_create_from_csc(ctx.ptr::Ptr{Cvoid}, size(A, 1)::Int64,
         nnz(A)::Int64, 64::Cint, 1::Cint, A.colptr::Ptr{Int64}, A.rowval::Ptr{Int64}, A.nzval::Ptr{Float64},
         out::Ptr{Ptr{Cvoid}})::Cint)
-    m = DeviceCSR(out[], size(A, 1), A.colptr, A.rowval)    # (shared with A, not copied: the pattern arrays of a Jacobian do not change)
+    # the pattern is COPIED: `same_pattern` must notice a Jacobian whose structure was changed in place with the same nnz
+    # (arrays reused) — sharing them made every such matrix compare equal to itself and gather through a stale permutation
+    m = DeviceCSR(out[], size(A, 1), copy(A.colptr), copy(A.rowval))
     finalizer(x -> @ccall(libnk.nk_csr_destroy(x.ptr::Ptr{Cvoid})::Cint), m)
     return m
 end
 same_pattern(m::DeviceCSR, A::SparseMatrixCSC{Float64, Int}) =
-    size(A, 1) == m.n && (A.colptr === m.colptr || A.colptr == m.colptr) && (A.rowval === m.rowval || A.rowval == m.rowval)
+    size(A, 1) == m.n && A.colptr == m.colptr && A.rowval == m.rowval      # contents, always (two O(nnz) integer compares)
 """New values in `nonzeros(A)` order for the pattern the matrix was created with: one gather on the device
 (nk_csr_set_values_csc) instead of a new CSC → CSR conversion and pattern upload."""
 function update_values!(m::DeviceCSR, A::SparseMatrixCSC{Float64, Int})

@@ -151,11 +151,11 @@ def test_linsolve_seam_example_compiles_against_the_header(tmp_path):
 
 
 def test_julia_binding_matches_the_abi():
-    """julia/MI355XNewtonKrylov.jl (the reference-side binding; Julia is not installed here): every symbol it ccalls is
+    """julia/src/MI355XNewtonKrylov.jl (the reference-side binding; Julia is not installed here): every symbol it ccalls is
     declared in the header, and its NKOptions mirror lists the fields of nk_options in the same order with the same types."""
     from nonlinearsolve_jl_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    jl = open(os.path.join(root, "julia", "MI355XNewtonKrylov.jl")).read()
+    jl = open(os.path.join(root, "julia", "src", "MI355XNewtonKrylov.jl")).read()
     header = open(os.path.join(root, "include", "mi355x_nk.h")).read()
     called = set(re.findall(r"libnk\.(nk_[a-z0-9_]+)\(", jl))
     assert len(called) >= 15
@@ -239,7 +239,7 @@ def test_every_julia_ccall_matches_the_header_signature():
     protos = _header_prototypes(header)
     assert len(protos) >= 110 and "nk_gmres_solve" in protos and "nk_precond_create_ilu0" in protos
     ncalls = 0
-    for rel in ("julia/MI355XNewtonKrylov.jl", "julia/ext/MI355XNewtonKrylovAMDGPUExt.jl"):
+    for rel in ("julia/src/MI355XNewtonKrylov.jl", "julia/ext/MI355XNewtonKrylovAMDGPUExt.jl"):
         jl = open(os.path.join(root, rel)).read()
         for m in re.finditer(r"@ccall\s*\(?\s*libnk\.(nk_[a-z0-9_]+)\(", jl):
             name = m.group(1)
@@ -260,3 +260,55 @@ def test_every_julia_ccall_matches_the_header_signature():
             assert ret is not None and _jl_class(ret.group(1)) == _c_class(cret + " x"), f"{rel}: {name}: return type"
             ncalls += 1
     assert ncalls >= 50
+
+
+def test_julia_package_manifest_declares_what_the_sources_load():
+    """julia/ is a package (Next #5): Project.toml with name / uuid / [deps] / [weakdeps] / [extensions] / [compat]
+    after the reference's own manifest (/root/reference/Project.toml:32-68), the module under src/, the AMDGPU extension under
+    ext/. Every package a `using` / `import` of the two files names is declared ([deps] for src/, [deps] ∪ [weakdeps] ∪ the
+    package itself for ext/), every dependency has a [compat] entry, the extension's trigger is a weak dependency, and the
+    UUIDs that can be checked against the reference's manifests agree with them."""
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proj = tomli.load(open(os.path.join(root, "julia", "Project.toml"), "rb"))
+    assert proj["name"] == "MI355XNewtonKrylov" and re.fullmatch(r"[0-9a-f]{8}(-[0-9a-f]{4}){3}-[0-9a-f]{12}", proj["uuid"])
+    deps, weak, ext = proj["deps"], proj["weakdeps"], proj["extensions"]
+    assert os.path.exists(os.path.join(root, "julia", "src", proj["name"] + ".jl"))
+    for name, trig in ext.items():
+        assert os.path.exists(os.path.join(root, "julia", "ext", name + ".jl"))
+        for t in ([trig] if isinstance(trig, str) else trig):
+            assert t in weak, f"extension {name} is triggered by {t}, which is not a weak dependency"
+
+    def loaded(rel):
+        src = open(os.path.join(root, rel)).read()
+        src = re.sub(r"#[^\n]*", "", src)
+        out = set()
+        for m in re.finditer(r"^\s*(?:using|import)\s+([^\n]+)", src, flags=re.M):
+            for part in m.group(1).split(":")[0].split(","):
+                out.add(part.strip().split(".")[0])
+        return out - {""}
+    assert loaded("julia/src/MI355XNewtonKrylov.jl") <= set(deps), loaded("julia/src/MI355XNewtonKrylov.jl") - set(deps)
+    ext_loaded = loaded("julia/ext/MI355XNewtonKrylovAMDGPUExt.jl")
+    assert ext_loaded <= set(deps) | set(weak) | {proj["name"]}, ext_loaded
+    assert "AMDGPU" in ext_loaded
+    for d in list(deps) + list(weak):
+        assert d in proj["compat"], f"no [compat] entry for {d}"
+    assert "julia" in proj["compat"]
+    ref = "/root/reference"
+    if os.path.isdir(ref):   # the UUIDs the reference's own manifests carry
+        known = {}
+        for rel in ("Project.toml", "lib/NonlinearSolveBase/Project.toml", "lib/SciMLJacobianOperators/Project.toml"):
+            t = tomli.load(open(os.path.join(ref, rel), "rb"))
+            known[t["name"]] = t["uuid"]
+            for sec in ("deps", "weakdeps", "extras"):
+                known.update(t.get(sec, {}))
+        for d, u in deps.items():
+            assert d in known and known[d] == u, f"[deps] {d}: {u} vs the reference's {known.get(d)}"
+        assert proj["compat"]["LinearSolve"] == tomli.load(open(os.path.join(ref, "Project.toml"), "rb"))["compat"]["LinearSolve"]
+    # the ADVICE r03 finding: the device trampolines order their work on the stream the library hands over
+    extsrc = open(os.path.join(root, "julia", "ext", "MI355XNewtonKrylovAMDGPUExt.jl")).read()
+    for tr in ("device_matvec_trampoline", "device_prec_trampoline"):
+        body = extsrc[extsrc.index("function " + tr):]
+        body = body[:body.index("\nend")]
+        assert "on_library_stream(stream)" in body, f"{tr} ignores the stream it is handed"
+    assert "hipStreamWaitEvent" in extsrc and "hipEventRecord" in extsrc
