@@ -650,9 +650,11 @@ bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, doubl
   *part = A->bounds_part;
   *nblk = A->bounds_nblk;
   *dst = A->d_bounds;
-  A->bounds_pending = false;   // (the caller's kernel, next in the stream, performs the reduction)
+  // (bounds_pending stays set until the caller has ENQUEUED the kernel that performs the reduction —
+  //  nk_csr_commit_pending_bounds: a solve that fails before that must not leave d_bounds marked as reduced)
   return true;
 }
+void nk_csr_commit_pending_bounds(nk_csr *A) { A->bounds_pending = false; }
 int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2, const double **where) {
   nk_ctx *ctx = A->ctx;
   NK_REQUIRE(A->nblocks > 0, "Gershgorin bounds of an empty matrix");

@@ -1695,9 +1695,14 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     x_is_zero = false;
     NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(&pub->end_seq, __ATOMIC_ACQUIRE) == seq; }, "the end of a GMRES cycle"));
     if (G->op_kind == 1 && G->A) NK_TRY(nk_csr_powers_check(G->A));
-    if (pub->pad != 0)
+    if (pub->pad != G->peer_err_seen) {
+      // the arena's counter is cumulative and sticky: a time-out fails THIS solve (its reductions / halos are not valid);
+      // the next one starts from the value seen here, so one transient stall does not condemn the context for good
+      const int fresh = (int)pub->pad - G->peer_err_seen;
+      G->peer_err_seen = (int)pub->pad;
       NK_FAIL(NK_E_COMM, "%d peer-mapped collective(s) timed out (a rank stalled beyond NK_PEER_TIMEOUT_MS or died): the "
-                         "reductions / halos of this solve are not valid", (int)pub->pad);
+                         "reductions / halos of this solve are not valid", fresh);
+    }
     nk_gmres_ctl c;
     memset(&c, 0, sizeof(c));
     c.k = pub->k;

@@ -476,6 +476,7 @@ struct nk_gmres {
   int ss_cycle_idx = 0;          // restart cycle of the current solve (0-based)
   int ss_last_k0 = 0, ss_last_sb = 0;   // the cycle's last block was left at its first pass (no sweep C): k_ss_fix_y adapts y
   bool ss_grow = false;          // this solve stops on a tolerance: automatic block sizes start small and double (4, 8, 15 …)
+  int peer_err_seen = 0;         // the peer arena's cumulative time-out count as of the last cycle this object waited for
   int ss_force_break_cycle = -1; // development hook (nk_gmres_debug_force_breakdown): that cycle's first block "loses rank"
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
@@ -550,6 +551,7 @@ void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v);
 int nk_csr_alloc_values(nk_csr *A, double **out);   // a zero-padded value array of A's size (freed with hipFree)
 // fill kernels' Gershgorin partials not reduced yet: hands them to a caller that reduces them into *dst in its own kernel
 bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
+void nk_csr_commit_pending_bounds(nk_csr *A);   // the caller's reducing kernel is enqueued: the partials are no longer pending
 int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
                                double *h_out, const std::function<int()> &before_wait = nullptr);

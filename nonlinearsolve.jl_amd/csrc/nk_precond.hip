@@ -410,7 +410,7 @@ extern "C" int nk_precond_update(nk_precond *P) {
   int fail = 0;
   NK_HIP(hipMemcpyAsync(&fail, P->d_fail, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  P->factored = true;
+  P->factored = (fail == 0);   // factors with a zero / non-finite pivot are not usable: apply refuses until a good update
   if (fail) NK_FAIL(NK_E_SINGULAR, P->kind == NK_PRECOND_JACOBI ? "Jacobi preconditioner: zero or non-finite diagonal entry"
                                                                  : "ILU(0): zero or non-finite pivot (no pivoting)");
   return NK_OK;
@@ -421,6 +421,8 @@ int nk_precond_apply_dev(nk_precond *P, const double *d_x, double *d_y, const in
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n;
   if (n == 0) return NK_OK;
+  if (!P->factored)
+    NK_FAIL(NK_E_SINGULAR, "preconditioner object has no valid factors (its last update met a zero or non-finite pivot)");
   if (P->kind == NK_PRECOND_JACOBI) {
     nk_prof_scope prof_(ctx, NK_K_OTHER, 24.0 * (double)n);
     NK_LAUNCH(ctx, k_jacobi_apply, dim3(nk_grid_for(n, NK_BLOCK * 4, 4096)), dim3(NK_BLOCK), n, (const double *)P->d_dinv, d_x,

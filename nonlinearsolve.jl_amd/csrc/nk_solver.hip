@@ -1659,7 +1659,9 @@ static int refresh_residual(nk_solver *S) {
 // precs(A, p) for the Jacobian just refreshed: the built-in object is refactorised (created on first use) and installed on
 // its side; the caller's hook then installs whatever it returns
 static int refresh_precs(nk_solver *S) {
-  if (S->o.precond_kind) {
+  // M ≈ J is a preconditioner for J, not for JᵀJ (+ λDᵀD): LevenbergMarquardt / GaussNewton / normal-form solves leave the
+  // built-in objects alone (a user's `precs` sees the operator it is asked about and may do better)
+  if (S->o.precond_kind && !normal_form(S) && !is_lm(S)) {
     if (!S->prec_obj) {
       NK_REQUIRE(concrete(S) && S->J, "nk_options.precond_kind needs a concrete-J linsolve");
       if (S->o.precond_kind == 1) NK_TRY(nk_precond_create_jacobi(S->J, &S->prec_obj));

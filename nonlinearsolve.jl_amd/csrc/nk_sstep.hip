@@ -1148,6 +1148,7 @@ int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int firs
   a.fixed = fixed; a.first = first; a.m = G->m; a.ss_grid = ss_grid; a.bnblk = W->bnblk; a.ns = s; a.newton = W->newton ? 1 : 0;
   NK_LAUNCH(ctx, k_ss_cycle_begin, dim3(1), dim3(256), a);
   NK_HIP(hipGetLastError());
+  if (a.bpart != nullptr && G->op_kind == 1 && G->A) nk_csr_commit_pending_bounds(G->A);
   W->bpart = nullptr;   // (reduced by this launch; later cycles of the solve read the bounds where it left them)
   return NK_OK;
 }

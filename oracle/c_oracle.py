@@ -9,16 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libnk_oracle.so")
-_SO_V4 = os.path.join(_HERE, "libnk_oracle_v4.so")
 _lib = None
-
-
-def _has_avx512():
-    try:
-        flags = open("/proc/cpuinfo").read()
-    except OSError:
-        return False
-    return all(f" {k}" in flags for k in ("avx512f", "avx512dq", "avx512bw", "avx512vl", "avx512cd"))
 
 _d = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -26,10 +17,9 @@ _i = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force=False):
     src = os.path.join(_HERE, "nk_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src) or not os.path.exists(_SO_V4) \
-            or os.path.getmtime(_SO_V4) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libnk_oracle.so", "libnk_oracle_v4.so"], stdout=subprocess.DEVNULL)
-    return _SO_V4 if (_has_avx512() and os.environ.get("NK_ORACLE_ISA", "") != "v3") else _SO
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libnk_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
 
 
 def lib():
