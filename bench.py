@@ -111,7 +111,7 @@ def live_pmc_traffic(args, kname):
     if exe is None:
         return None, None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--no-profile-pass",
-             "--no-ttt", "--pmc", "off", "--workload", args.workload, "--ortho", args.ortho, "--sstep", str(args.sstep),
+             "--no-ttt", "--no-spmv-hbm", "--pmc", "off", "--workload", args.workload, "--ortho", args.ortho, "--sstep", str(args.sstep),
              "--sstep-basis", args.sstep_basis, "--arnoldi", str(args.arnoldi)]
     if args.n:
         child += ["--grid", str(args.n)]

@@ -256,7 +256,8 @@ typedef struct {
   int32_t gmres_sstep;                  /* [0]    NK_ORTHO_SSTEP: basis columns per block (1..16; 0 = automatic)      */
   int32_t gmres_sstep_basis;            /* [0]    nk_ss_basis                                                         */
   /* --- a built-in preconditioner object on the concrete J, rebuilt numerically for every new Jacobian like `precs(A, p)`
-   *     (needs a concrete-J linsolve): 0 none, 1 Jacobi, 2 ILU(0) in the matrix's ordering, 3 ILU(0) multicolour */
+   *     (needs a concrete-J linsolve): 0 none, 1 Jacobi, 2 ILU(0) in the matrix's ordering, 3 ILU(0) multicolour,
+   *     4 aggregation algebraic multigrid (nk_precond_create_amg with its defaults) */
   int32_t precond_kind;                 /* [0]                                                                        */
   int32_t precond_side;                 /* [1]    nk_side: the reference's tutorial precs return (Pl, I): left        */
 } nk_options;
@@ -483,10 +484,29 @@ int nk_gmres_set_preconditioner(nk_gmres *G, int side, nk_precond *P);
  *   inside one persistent workgroup — milliseconds per application at n = 1024²), NK_ILU_MULTICOLOR permutes the rows by a
  *   greedy colouring of the pattern (as many levels as colours, one wide launch each: the GPU form).
  * nk_precond_update refactorises for the matrix's current values; NK_E_SINGULAR on a zero pivot. x, y: local length n. */
-typedef enum { NK_PRECOND_JACOBI = 1, NK_PRECOND_ILU0 = 2 } nk_precond_kind;
+typedef enum { NK_PRECOND_JACOBI = 1, NK_PRECOND_ILU0 = 2, NK_PRECOND_AMG = 3 } nk_precond_kind;
 typedef enum { NK_ILU_NATURAL = 0, NK_ILU_MULTICOLOR = 1 } nk_ilu_ordering;
 int nk_precond_create_jacobi(nk_csr *A, nk_precond **out);
 int nk_precond_create_ilu0(nk_csr *A, int ordering, nk_precond **out);
+/* Aggregation algebraic multigrid built from the matrix alone (csrc/nk_amg.hip) — the tutorial's
+ * `precs = (A, p) -> (aspreconditioner(ruge_stuben(A)), I)` slot (docs/src/tutorials/large_systems.md:276-316): pairwise
+ * aggregation (`passes` times per level: aggregates of ≤ 2^passes rows; strength threshold `theta`) fixed at creation from the
+ * values of that moment, piecewise-constant transfers, Galerkin coarse matrices, `nu` Chebyshev steps on D⁻¹A over
+ * [λmax / cheb_ratio, λmax] before and after, the coarse correction over-corrected by `overcorrection`, levels down to
+ * ≤ coarse_max (≤ 128) rows, inverted densely. nk_precond_update keeps the aggregates and refreshes every number on the
+ * device (Galerkin sums, D⁻¹, Gershgorin bounds, the coarse inverse) for the matrix's current values. A fixed linear
+ * operator: usable as Pl or Pr. Several ranks: the rank's local block (block-Jacobi AMG). params NULL or zero fields:
+ * defaults (nu 2, passes 2, theta 0.25, overcorrection 1.8, cheb_ratio 4, coarse_max 128). */
+typedef struct nk_amg_params {
+  int32_t nu, passes, coarse_max, reserved;
+  double theta, overcorrection, cheb_ratio;
+} nk_amg_params;
+int nk_amg_params_default(nk_amg_params *p);
+int nk_precond_create_amg(nk_csr *A, const nk_amg_params *params, nk_precond **out);
+/* the hierarchy, for inspection: *levels (coarsest included); sizes / nnzs / lmax: up to `cap` entries each (NULL: skipped) */
+int nk_precond_amg_info(nk_precond *P, int *levels, int cap, int64_t *sizes, int64_t *nnzs, double *lmax);
+/* row → coarse row of level `level` (`count` = that level's rows; the coarsest level has none: NK_E_INVALID) */
+int nk_precond_amg_aggregates(nk_precond *P, int level, int32_t *agg, int64_t count);
 int nk_precond_update(nk_precond *P);
 int nk_precond_apply(nk_precond *P, const double *x, double *y, int memspace);   /* y = M⁻¹ x */
 int nk_precond_info(nk_precond *P, int *kind, int *levels_lower, int *levels_upper, int *ncolors);

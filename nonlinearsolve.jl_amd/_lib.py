@@ -36,6 +36,11 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class AMGParams(C.Structure):
+    _fields_ = [("nu", C.c_int32), ("passes", C.c_int32), ("coarse_max", C.c_int32), ("reserved", C.c_int32),
+                ("theta", C.c_double), ("overcorrection", C.c_double), ("cheb_ratio", C.c_double)]
+
+
 class GmresInfo(C.Structure):
     _fields_ = [("iters", C.c_int32), ("restarts", C.c_int32), ("converged", C.c_int32), ("failed", C.c_int32),
                 ("rnorm0", C.c_double), ("rnorm", C.c_double)]
@@ -172,6 +177,10 @@ SIGNATURES = {
     "nk_gmres_set_preconditioner": (_I, [_P, _I, _P]),
     "nk_precond_create_jacobi": (_I, [_P, _PP]),
     "nk_precond_create_ilu0": (_I, [_P, _I, _PP]),
+    "nk_amg_params_default": (_I, [_P]),
+    "nk_precond_create_amg": (_I, [_P, _P, _PP]),
+    "nk_precond_amg_info": (_I, [_P, C.POINTER(_I), _I, _P, _P, _P]),
+    "nk_precond_amg_aggregates": (_I, [_P, _I, _P, _L]),
     "nk_precond_update": (_I, [_P]),
     "nk_precond_apply": (_I, [_P, _P, _P, _I]),
     "nk_precond_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

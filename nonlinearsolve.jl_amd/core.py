@@ -615,7 +615,7 @@ class Preconditioner:
     def info(self):
         k, ll, lu, nc = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(L.lib().nk_precond_info(self._h, C.byref(k), C.byref(ll), C.byref(lu), C.byref(nc)))
-        return dict(kind={1: "jacobi", 2: "ilu0"}[k.value], levels_lower=ll.value, levels_upper=lu.value, ncolors=nc.value)
+        return dict(kind={1: "jacobi", 2: "ilu0", 3: "amg"}[k.value], levels_lower=ll.value, levels_upper=lu.value, ncolors=nc.value)
 
     def close(self):
         if self._h:
@@ -664,9 +664,38 @@ class ILU0Preconditioner(Preconditioner):
         return sp.tril(M, -1).tocsr() + sp.identity(n, format="csr"), sp.triu(M, 0).tocsr(), perm
 
 
+class AMGPreconditioner(Preconditioner):
+    """Aggregation algebraic multigrid built from the matrix alone (csrc/nk_amg.hip) — what the reference's tutorial returns from
+    `precs(A, p)` as Pl for a large sparse Jacobian (`aspreconditioner(ruge_stuben(A))`, docs/src/tutorials/large_systems.md:276-316):
+    pairwise aggregation (aggregates of ≤ 2^passes rows, fixed at creation), Galerkin coarse matrices refreshed on the device by
+    `update()`, ν Chebyshev steps on D⁻¹A per side, over-corrected coarse correction, dense inverse on the ≤ 128 coarsest rows."""
+
+    def __init__(self, A: "CSRMatrix", nu: int = 0, passes: int = 0, theta: float = 0.0, overcorrection: float = 0.0,
+                 cheb_ratio: float = 0.0, coarse_max: int = 0):
+        prm = L.AMGParams(int(nu), int(passes), int(coarse_max), 0, float(theta), float(overcorrection), float(cheb_ratio))
+        h = C.c_void_p()
+        check(L.lib().nk_precond_create_amg(A._h, C.byref(prm), C.byref(h)))
+        super().__init__(h, A)
+
+    def hierarchy(self):
+        """[(rows, non-zeros, Gershgorin bound of D⁻¹A)] per level, finest first, coarsest last"""
+        nl = C.c_int(0)
+        check(L.lib().nk_precond_amg_info(self._h, C.byref(nl), 0, None, None, None))
+        n, z, lm = (C.c_int64 * nl.value)(), (C.c_int64 * nl.value)(), (C.c_double * nl.value)()
+        check(L.lib().nk_precond_amg_info(self._h, C.byref(nl), nl.value, n, z, lm))
+        return [(int(n[i]), int(z[i]), float(lm[i])) for i in range(nl.value)]
+
+    def aggregates(self, level: int):
+        """row → coarse row of `level` (NumPy int32)"""
+        rows = self.hierarchy()[level][0]
+        out = np.empty(rows, dtype=np.int32)
+        check(L.lib().nk_precond_amg_aggregates(self._h, int(level), C.c_void_p(out.ctypes.data), rows))
+        return out
+
+
 @dataclass
 class ObjectPrecs:
-    """`precs` through nk_options: a built-in object (kind = "jacobi" | "ilu0" | "ilu0_natural") on the concrete Jacobian,
+    """`precs` through nk_options: a built-in object (kind = "jacobi" | "ilu0" | "ilu0_natural" | "amg") on the concrete Jacobian,
     refactorised inside the solver for every new J — no callback into the host language. side = "left" as the reference's
     tutorial precs (`(Pl, I)`), or "right"."""
     kind: str = "ilu0"
@@ -900,7 +929,7 @@ def _options(alg, abstol, reltol, maxiters, maxtime, store_trace, termination_kw
     elif isinstance(precs, ChebyshevPrecs):
         o.cheb_degree, o.cheb_ratio = int(precs.degree), float(precs.ratio)
     elif isinstance(precs, ObjectPrecs):
-        o.precond_kind = {"jacobi": 1, "ilu0_natural": 2, "ilu0": 3, "ilu0_multicolor": 3}[precs.kind]
+        o.precond_kind = {"jacobi": 1, "ilu0_natural": 2, "ilu0": 3, "ilu0_multicolor": 3, "amg": 4}[precs.kind]
         o.precond_side = {"right": 0, "left": 1}[precs.side]
     elif precs is not None and not callable(precs):
         raise TypeError("KrylovJL_GMRES(precs=…): a callable precs(A, p) -> (Pl, Pr) or a built-in descriptor")

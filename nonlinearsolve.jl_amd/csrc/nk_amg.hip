@@ -1,0 +1,519 @@
+// Aggregation algebraic multigrid built from a CSR matrix ALONE — the `precs(A, p)` slot the reference's tutorial fills with
+// AlgebraicMultigrid.jl's ruge_stuben / smoothed_aggregation as Pl (docs/src/tutorials/large_systems.md:276-316): the
+// preconditioner that makes a GENERAL sparse Jacobian at n = 1e6 converge in a handful of Krylov iterations (ILU(0) and
+// Jacobi do not: DESIGN.md §5d; the geometric V-cycle of nk_mg.hip knows the two built-in grids only).
+//
+//   coarsening   pairwise aggregation, `passes` times per level (aggregates of ≤ 2^passes rows): rows in natural order, an
+//                unmatched row takes its unmatched neighbour of largest strength s_ij = −a_ij·sign(a_ii) if s_ij ≥ θ·max_k s_ik.
+//                HOST, once per pattern (from the values at creation); the aggregates are kept for the object's life.
+//   transfers    piecewise constant: restriction = sum over an aggregate's rows (ascending), prolongation = injection.
+//   coarse A     Galerkin TᵀA T: every coarse entry = the sum of the fine entries it covers, in ascending position — a gather
+//                plan per level, one thread per coarse entry: bitwise reproducible, refreshed on the DEVICE for every new A.
+//   smoother     ν Chebyshev steps on D⁻¹A over [λmax/ratio, λmax], λmax = max_i Σ_j |a_ij| / |a_ii| (device reduction);
+//                the steps ride in the CSR SpMV's row epilogue (modes 1 / 2 / 4 of nk_spmv_epi: no separate vector pass).
+//   coarsest     ≤ 128 rows: dense inverse by the in-register Gauss–Jordan of nk_bcr.hip (row pivoting), applied as one
+//                GEMV launch; if coarsening stalls above that, 4ν smoothing steps.
+//   cycle        V, with the coarse correction over-corrected by ω (1.8): plain aggregation under-estimates smooth error by
+//                about a factor of two. A fixed linear operator — plain GMRES may use it on either side.
+// Several ranks: the rank's LOCAL square block (halo columns dropped) — block-Jacobi AMG, no communication in the apply.
+// CPU restatement: oracle/reference_restatement.py::AggregationAMG (same aggregates, V-cycle equal to 1e-12 relative).
+#include "nk_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+struct amg_level {
+  int64_t n = 0, nnz = 0, nc = 0;
+  nk_csr *A = nullptr;       // level matrix (level 0: the caller's matrix, or a private copy of its local block)
+  bool own_A = false;
+  int32_t *d_agg = nullptr;                      // row → coarse row
+  int32_t *d_aggptr = nullptr, *d_aggmem = nullptr;   // coarse row → its rows, ascending
+  int32_t *d_gptr = nullptr, *d_gidx = nullptr;       // coarse entry → the fine entries it sums, ascending
+  double *d_dinv = nullptr;
+  double *b = nullptr, *x = nullptr, *r = nullptr, *d0 = nullptr, *d1 = nullptr;   // work vectors (level 0: b, x are the caller's)
+  double lmax = 1.0;
+  std::vector<int32_t> h_agg;
+};
+struct nk_amg {
+  nk_ctx *ctx = nullptr;
+  nk_csr *A = nullptr;
+  nk_amg_params prm{};
+  std::vector<amg_level> lv;   // lv.back() is the coarsest level (no aggregates)
+  int32_t *d_src0 = nullptr;   // level 0 is a private local block: position of its entries in A->d_val
+  bool dense = false;
+  double *d_inv = nullptr;     // coarsest level: dense inverse, column-major, leading dimension ldinv (n rounded up to 8)
+  int ldinv = 0;
+  double *d_lmax = nullptr, *d_lpart = nullptr;
+  int *d_fail = nullptr, *d_nparts = nullptr;
+  std::vector<int> nparts;     // workgroups of k_amg_diag per level (= partial maxima to reduce)
+  int lpart_stride = 0;
+  bool ready = false;
+};
+
+extern "C" int nk_amg_params_default(nk_amg_params *p) {
+  NK_REQUIRE(p, "NULL argument");
+  p->nu = 2; p->passes = 2; p->coarse_max = 128; p->reserved = 0;
+  p->theta = 0.25; p->overcorrection = 1.8; p->cheb_ratio = 4.0;
+  return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- host: aggregates and Galerkin patterns
+struct host_csr {
+  int64_t n = 0;
+  std::vector<int32_t> rp, ci;
+  std::vector<double> v;
+};
+static void pairwise_pass(const host_csr &A, double theta, std::vector<int32_t> &cid, int32_t &nc) {
+  const int64_t n = A.n;
+  cid.assign(n, -1);
+  nc = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (cid[i] >= 0) continue;
+    double dg = 0.0;
+    for (int32_t k = A.rp[i]; k < A.rp[i + 1]; ++k) if (A.ci[k] == i) dg += A.v[k];
+    const double sg = dg < 0.0 ? -1.0 : 1.0;
+    double smax = 0.0, bv = 0.0;
+    int32_t best = -1;
+    for (int32_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+      const int32_t j = A.ci[k];
+      if (j == i) continue;
+      const double sv = -A.v[k] * sg;
+      if (sv > smax) smax = sv;
+      if (cid[j] < 0 && sv > bv) { bv = sv; best = j; }
+    }
+    cid[i] = nc;
+    if (best >= 0 && bv >= theta * smax) cid[best] = nc;
+    ++nc;
+  }
+}
+// C = TᵀA T for the aggregate map cid (columns sorted); emap[k] = the entry of C fine entry k is summed into (values: ascending k)
+static void galerkin_host(const host_csr &A, const std::vector<int32_t> &cid, int32_t nc, host_csr &C, std::vector<int32_t> &emap) {
+  const int64_t n = A.n, nnz = (int64_t)A.ci.size();
+  std::vector<int32_t> mptr(nc + 1, 0), mem(n);
+  for (int64_t i = 0; i < n; ++i) mptr[cid[i] + 1]++;
+  for (int32_t I = 0; I < nc; ++I) mptr[I + 1] += mptr[I];
+  {
+    std::vector<int32_t> fill(mptr.begin(), mptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) mem[fill[cid[i]]++] = (int32_t)i;
+  }
+  C.n = nc;
+  C.rp.assign(nc + 1, 0);
+  C.ci.clear();
+  C.v.clear();
+  emap.assign(nnz, -1);
+  std::vector<std::pair<int32_t, int32_t>> tmp;   // (coarse column, fine entry)
+  for (int32_t I = 0; I < nc; ++I) {
+    tmp.clear();
+    for (int32_t t = mptr[I]; t < mptr[I + 1]; ++t) {
+      const int32_t i = mem[t];
+      for (int32_t k = A.rp[i]; k < A.rp[i + 1]; ++k) tmp.push_back({cid[A.ci[k]], k});
+    }
+    std::sort(tmp.begin(), tmp.end());   // by column, then by fine position
+    for (size_t t = 0; t < tmp.size();) {
+      const int32_t J = tmp[t].first;
+      const int32_t e = (int32_t)C.ci.size();
+      C.ci.push_back(J);
+      C.v.push_back(0.0);
+      for (; t < tmp.size() && tmp[t].first == J; ++t) emap[tmp[t].second] = e;
+    }
+    C.rp[I + 1] = (int32_t)C.ci.size();
+  }
+  for (int64_t k = 0; k < nnz; ++k) C.v[emap[k]] += A.v[k];   // ascending k
+}
+
+// ----------------------------------------------------------------------------- device kernels
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_gather(int64_t nnz, const int32_t *__restrict__ src, const double *__restrict__ in,
+                                                         double *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t e = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; e < nnz; e += stride) out[e] = in[src[e]];
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_galerkin(int64_t nnzc, const int32_t *__restrict__ gptr, const int32_t *__restrict__ gidx,
+                                                           const double *__restrict__ fine, double *__restrict__ coarse) {
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t e = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; e < nnzc; e += stride) {
+    double s = 0.0;
+    for (int32_t t = gptr[e]; t < gptr[e + 1]; ++t) s += fine[gidx[t]];
+    coarse[e] = s;
+  }
+}
+// dinv_i = 1 / a_ii; per-block maximum of Σ_j |a_ij| / |a_ii| (the Gershgorin bound of D⁻¹A)
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_diag(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       const double *__restrict__ val, double *__restrict__ dinv,
+                                                       double *__restrict__ part, int *fail) {
+  __shared__ double red[4];
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  double m = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; r < n; r += stride) {
+    double d = 0.0, s = 0.0;
+    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      const double v = val[p];
+      if (col[p] == r) d += v;
+      s += fabs(v);
+    }
+    if (d == 0.0 || d != d || isinf(d)) *fail = 1;
+    dinv[r] = 1.0 / d;
+    m = fmax(m, s / fabs(d));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_lmax_final(int nlev, int stride, const int *__restrict__ nparts,
+                                                             const double *__restrict__ part, double *__restrict__ lmax) {
+  __shared__ double red[4];
+  for (int l = 0; l < nlev; ++l) {
+    double m = 0.0;
+    for (int i = threadIdx.x; i < nparts[l]; i += NK_BLOCK) m = fmax(m, part[(size_t)l * stride + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) lmax[l] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  }
+}
+// the coarsest matrix as a dense column-major ld × ld array, ld = n rounded up to a multiple of 8 with an identity border (the
+// pivoting Gauss–Jordan of nk_bcr.hip walks its pivots in groups of eight)
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_dense_fill(int n, int ld, const int32_t *__restrict__ rowptr,
+                                                             const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                             double *__restrict__ M) {
+  for (int64_t e = threadIdx.x; e < (int64_t)ld * ld; e += NK_BLOCK) M[e] = 0.0;
+  __syncthreads();
+  for (int r = threadIdx.x; r < ld; r += NK_BLOCK) {
+    if (r >= n) { M[(int64_t)r + (int64_t)r * ld] = 1.0; continue; }
+    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) M[(int64_t)r + (int64_t)col[p] * ld] += val[p];
+  }
+}
+// x = M b, M dense column-major (leading dimension ld), n ≤ 128: lanes run along the rows, coalesced
+__global__ __launch_bounds__(128) void k_amg_dense_apply(int n, int ld, const double *__restrict__ M, const double *__restrict__ b,
+                                                         double *__restrict__ x, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  __shared__ double sb[128];
+  const int t = threadIdx.x;
+  if (t < n) sb[t] = b[t];
+  __syncthreads();
+  if (t >= n) return;
+  double s = 0.0;
+  for (int j = 0; j < n; ++j) s += M[(int64_t)t + (int64_t)j * ld] * sb[j];
+  x[t] = s;
+}
+// first Chebyshev step. zero = 1: from x = 0 (r ← b, d = D⁻¹b/θ, x = d); zero = 0: r holds b − A x (d = D⁻¹r/θ, x += d)
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_cheb_first(int64_t n, int zero, const double *__restrict__ b,
+                                                             const double *__restrict__ dinv, double inv_theta,
+                                                             double *__restrict__ r, double *__restrict__ d, double *__restrict__ x,
+                                                             const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) {
+    if (zero) {
+      const double bb = b[i], dd = dinv[i] * bb * inv_theta;
+      r[i] = bb;
+      d[i] = dd;
+      x[i] = dd;
+    } else {
+      const double dd = dinv[i] * r[i] * inv_theta;
+      d[i] = dd;
+      x[i] += dd;
+    }
+  }
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_restrict(int64_t nc, const int32_t *__restrict__ aggptr, const int32_t *__restrict__ aggmem,
+                                                           const double *__restrict__ r, double *__restrict__ bc, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t I = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; I < nc; I += stride) {
+    double s = 0.0;
+    for (int32_t t = aggptr[I]; t < aggptr[I + 1]; ++t) s += r[aggmem[t]];
+    bc[I] = s;
+  }
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_prolong(int64_t n, const int32_t *__restrict__ agg, const double *__restrict__ xc,
+                                                          double omega, double *__restrict__ x, const int *d_skip) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < n; i += stride) x[i] += omega * xc[agg[i]];
+}
+
+// ----------------------------------------------------------------------------- create / destroy
+void nk_amg_destroy(nk_amg *M) {
+  if (!M) return;
+  for (size_t l = 0; l < M->lv.size(); ++l) {
+    amg_level &L = M->lv[l];
+    if (L.own_A && L.A) nk_csr_destroy(L.A);
+    hipFree(L.d_agg); hipFree(L.d_aggptr); hipFree(L.d_aggmem); hipFree(L.d_gptr); hipFree(L.d_gidx); hipFree(L.d_dinv);
+    if (l > 0) { hipFree(L.b); hipFree(L.x); }
+    hipFree(L.r); hipFree(L.d0); hipFree(L.d1);
+  }
+  hipFree(M->d_src0); hipFree(M->d_inv); hipFree(M->d_lmax); hipFree(M->d_lpart); hipFree(M->d_fail); hipFree(M->d_nparts);
+  delete M;
+}
+template <class T>
+static int upload(T **dst, const std::vector<T> &src) {
+  NK_TRY(nk_dev_alloc(dst, src.size() + 1));
+  if (!src.empty()) NK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return NK_OK;
+}
+int nk_amg_create(nk_csr *A, const nk_amg_params *prm, nk_amg **out) {
+  nk_ctx *ctx = A->ctx;
+  nk_amg *M = new nk_amg();
+  auto guard = nk_make_guard(M, [](nk_amg *m) { nk_amg_destroy(m); });
+  M->ctx = ctx;
+  M->A = A;
+  nk_amg_params_default(&M->prm);
+  if (prm) {
+    if (prm->nu > 0) M->prm.nu = prm->nu;
+    if (prm->passes > 0) M->prm.passes = prm->passes;
+    if (prm->coarse_max > 0) M->prm.coarse_max = prm->coarse_max;
+    if (prm->theta > 0.0) M->prm.theta = prm->theta;
+    if (prm->overcorrection > 0.0) M->prm.overcorrection = prm->overcorrection;
+    if (prm->cheb_ratio > 1.0) M->prm.cheb_ratio = prm->cheb_ratio;
+  }
+  NK_REQUIRE(M->prm.nu <= 16 && M->prm.passes <= 4 && M->prm.coarse_max <= 128, "AMG: nu ≤ 16, passes ≤ 4, coarse_max ≤ 128");
+  const int64_t n = A->nrows;
+  // ---- level 0 on the host: the rank's local square block with the values of this moment
+  host_csr H;
+  H.n = n;
+  std::vector<double> vals((size_t)A->nnz);
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  if (A->nnz) NK_HIP(hipMemcpy(vals.data(), A->d_val, A->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  const bool has_halo = !A->halo_gcols.empty();
+  std::vector<int32_t> src0;
+  H.rp.assign(n + 1, 0);
+  for (int64_t r = 0; r < n; ++r) {
+    for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k)
+      if (A->h_col[k] < n) { H.ci.push_back(A->h_col[k]); H.v.push_back(vals[k]); if (has_halo) src0.push_back(k); }
+    H.rp[r + 1] = (int32_t)H.ci.size();
+  }
+  for (int64_t r = 0; r < n; ++r)   // sorted columns are part of the contract of the aggregation order
+    for (int32_t k = H.rp[r] + 1; k < H.rp[r + 1]; ++k)
+      NK_REQUIRE(H.ci[k] > H.ci[k - 1], "AMG: the columns of row %lld are not sorted / unique", (long long)r);
+  // ---- coarsen
+  std::vector<host_csr> mats;
+  mats.push_back(std::move(H));
+  std::vector<std::vector<int32_t>> aggs, emaps;
+  while (mats.back().n > M->prm.coarse_max && (int)mats.size() < 24) {
+    const host_csr &F = mats.back();
+    std::vector<int32_t> agg((size_t)F.n);
+    std::iota(agg.begin(), agg.end(), 0);
+    host_csr cur = F;
+    int32_t nc = 0;
+    for (int p = 0; p < M->prm.passes; ++p) {
+      std::vector<int32_t> cid, em;
+      pairwise_pass(cur, M->prm.theta, cid, nc);
+      host_csr nxt;
+      galerkin_host(cur, cid, nc, nxt, em);
+      cur = std::move(nxt);
+      for (auto &a : agg) a = cid[a];
+    }
+    if ((double)nc > 0.8 * (double)F.n) break;   // coarsening stalled: this level is the coarsest
+    host_csr C;
+    std::vector<int32_t> emap;
+    galerkin_host(F, agg, nc, C, emap);          // one-stage sums: what a value refresh recomputes
+    aggs.push_back(std::move(agg));
+    emaps.push_back(std::move(emap));
+    mats.push_back(std::move(C));
+  }
+  // ---- device objects
+  const int nlev = (int)mats.size();
+  M->lv.resize(nlev);
+  for (int l = 0; l < nlev; ++l) {
+    amg_level &L = M->lv[l];
+    const host_csr &F = mats[l];
+    L.n = F.n;
+    L.nnz = (int64_t)F.ci.size();
+    if (l == 0 && !has_halo) {
+      L.A = A;
+    } else {
+      std::vector<int64_t> gc(F.ci.begin(), F.ci.end());
+      NK_TRY(nk_csr_create_local(ctx, F.n, F.n, 0, F.rp, gc, nullptr, &L.A, true));
+      L.own_A = true;
+    }
+    NK_TRY(nk_dev_alloc(&L.d_dinv, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.r, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.d0, (size_t)L.n + 1));
+    NK_TRY(nk_dev_alloc(&L.d1, (size_t)L.n + 1));
+    if (l > 0) {
+      NK_TRY(nk_dev_alloc(&L.b, (size_t)L.n + 1));
+      NK_TRY(nk_dev_alloc(&L.x, (size_t)L.n + 1));
+    }
+    if (l + 1 < nlev) {
+      const std::vector<int32_t> &agg = aggs[l], &emap = emaps[l];
+      L.nc = mats[l + 1].n;
+      L.h_agg = agg;
+      std::vector<int32_t> aptr(L.nc + 1, 0), amem((size_t)L.n);
+      for (int64_t i = 0; i < L.n; ++i) aptr[agg[i] + 1]++;
+      for (int64_t I = 0; I < L.nc; ++I) aptr[I + 1] += aptr[I];
+      {
+        std::vector<int32_t> fill(aptr.begin(), aptr.end() - 1);
+        for (int64_t i = 0; i < L.n; ++i) amem[fill[agg[i]]++] = (int32_t)i;
+      }
+      const int64_t nnzc = (int64_t)mats[l + 1].ci.size();
+      std::vector<int32_t> gptr(nnzc + 1, 0), gidx((size_t)L.nnz);
+      for (int64_t k = 0; k < L.nnz; ++k) gptr[emap[k] + 1]++;
+      for (int64_t e = 0; e < nnzc; ++e) gptr[e + 1] += gptr[e];
+      {
+        std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
+        for (int64_t k = 0; k < L.nnz; ++k) gidx[fill[emap[k]]++] = (int32_t)k;
+      }
+      NK_TRY(upload(&L.d_agg, agg));
+      NK_TRY(upload(&L.d_aggptr, aptr));
+      NK_TRY(upload(&L.d_aggmem, amem));
+      NK_TRY(upload(&L.d_gptr, gptr));
+      NK_TRY(upload(&L.d_gidx, gidx));
+    }
+  }
+  if (has_halo) NK_TRY(upload(&M->d_src0, src0));
+  M->dense = M->lv.back().n <= M->prm.coarse_max;
+  M->ldinv = (int)((M->lv.back().n + 7) / 8 * 8);
+  if (M->dense && M->lv.back().n > 0) NK_TRY(nk_dev_alloc(&M->d_inv, (size_t)M->ldinv * M->ldinv));
+  M->lpart_stride = 1024;
+  M->nparts.assign(nlev, 0);
+  for (int l = 0; l < nlev; ++l) M->nparts[l] = M->lv[l].n > 0 ? nk_grid_for(M->lv[l].n, NK_BLOCK, M->lpart_stride) : 0;
+  NK_TRY(upload(&M->d_nparts, M->nparts));
+  NK_TRY(nk_dev_alloc(&M->d_lpart, (size_t)nlev * M->lpart_stride));
+  NK_TRY(nk_dev_alloc(&M->d_lmax, (size_t)nlev + 1));
+  NK_TRY(nk_dev_alloc(&M->d_fail, (size_t)2));
+  NK_TRY(nk_amg_update(M));
+  *out = guard.release();
+  return NK_OK;
+}
+
+// the numbers of the hierarchy for the matrix's CURRENT values (same pattern): Galerkin sums, D⁻¹, λmax, the coarse inverse
+int nk_amg_update(nk_amg *M) {
+  nk_ctx *ctx = M->ctx;
+  const int nlev = (int)M->lv.size();
+  M->ready = false;
+  NK_HIP(hipMemsetAsync(M->d_fail, 0, 2 * sizeof(int), ctx->stream));
+  if (M->d_src0 && M->lv[0].nnz > 0)
+    NK_LAUNCH(ctx, k_amg_gather, dim3(nk_grid_for(M->lv[0].nnz, NK_BLOCK * 4, 4096)), dim3(NK_BLOCK), M->lv[0].nnz,
+              (const int32_t *)M->d_src0, (const double *)M->A->d_val, M->lv[0].A->d_val);
+  for (int l = 0; l < nlev; ++l) {
+    amg_level &L = M->lv[l];
+    if (L.n == 0) continue;
+    nk_prof_scope prof_(ctx, NK_K_OTHER, 12.0 * (double)L.nnz + 12.0 * (double)L.n);
+    NK_LAUNCH(ctx, k_amg_diag, dim3(M->nparts[l]), dim3(NK_BLOCK), L.n, (const int32_t *)L.A->d_rowptr, (const int32_t *)L.A->d_col,
+              (const double *)L.A->d_val, L.d_dinv, M->d_lpart + (size_t)l * M->lpart_stride, M->d_fail);
+    if (l + 1 < nlev) {
+      amg_level &Cn = M->lv[l + 1];
+      NK_LAUNCH(ctx, k_amg_galerkin, dim3(nk_grid_for(Cn.nnz, NK_BLOCK, 4096)), dim3(NK_BLOCK), Cn.nnz, (const int32_t *)L.d_gptr,
+                (const int32_t *)L.d_gidx, (const double *)L.A->d_val, Cn.A->d_val);
+      Cn.A->t_values_stale = true; Cn.A->bounds_valid = false; Cn.A->bounds_pending = false;
+    }
+  }
+  NK_LAUNCH(ctx, k_amg_lmax_final, dim3(1), dim3(NK_BLOCK), nlev, M->lpart_stride, (const int *)M->d_nparts, (const double *)M->d_lpart,
+            M->d_lmax);
+  amg_level &Lc = M->lv.back();
+  if (M->dense && Lc.n > 0) {
+    NK_LAUNCH(ctx, k_amg_dense_fill, dim3(1), dim3(NK_BLOCK), (int)Lc.n, M->ldinv, (const int32_t *)Lc.A->d_rowptr,
+              (const int32_t *)Lc.A->d_col, (const double *)Lc.A->d_val, M->d_inv);
+    NK_TRY(nk_dense_invert128_dev(ctx, M->d_inv, M->ldinv, M->ldinv, M->d_fail + 1));
+  }
+  std::vector<double> lm(nlev, 1.0);
+  int fail[2] = {0, 0};
+  NK_HIP(hipMemcpyAsync(lm.data(), M->d_lmax, nlev * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipMemcpyAsync(fail, M->d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  NK_HIP(hipGetLastError());
+  if (fail[0]) NK_FAIL(NK_E_SINGULAR, "AMG: zero or non-finite diagonal entry on some level");
+  if (fail[1]) NK_FAIL(NK_E_SINGULAR, "AMG: the coarsest-level matrix is singular");
+  for (int l = 0; l < nlev; ++l) {
+    if (!(lm[l] > 0.0) || !std::isfinite(lm[l])) NK_FAIL(NK_E_SINGULAR, "AMG: no finite Gershgorin bound on level %d", l);
+    M->lv[l].lmax = lm[l];
+  }
+  M->ready = true;
+  return NK_OK;
+}
+
+// ----------------------------------------------------------------------------- apply: one V-cycle
+// steps 2 … nsteps of the Chebyshev iteration on level L (the first step is k_amg_cheb_first); the current correction ends in *dcur
+static int amg_cheb_rest(nk_amg *M, amg_level &L, int nsteps, double **dcur, double **dnext, const int *d_skip) {
+  const double lmin = L.lmax / M->prm.cheb_ratio, theta = 0.5 * (L.lmax + lmin), delta = 0.5 * (L.lmax - lmin);
+  const double sigma1 = theta / delta;
+  double rho = 1.0 / sigma1;
+  for (int k = 1; k < nsteps; ++k) {
+    const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+    nk_spmv_epi ep;
+    ep.mode = 1;
+    ep.c1 = rho_new * rho;
+    ep.c2 = 2.0 * rho_new / delta;
+    ep.r = L.r;
+    ep.dnew = *dnext;
+    ep.yacc = L.x;
+    ep.dinv = L.d_dinv;
+    NK_TRY(nk_csr_spmv_dev(L.A, *dcur, nullptr, d_skip, nullptr, &ep));   // r −= A d; d' = c1 d + c2 D⁻¹ r; x += d'
+    std::swap(*dcur, *dnext);
+    rho = rho_new;
+  }
+  return NK_OK;
+}
+int nk_amg_apply_dev(nk_amg *M, const double *d_b, double *d_x, const int *d_skip) {
+  nk_ctx *ctx = M->ctx;
+  if (!M->ready) NK_FAIL(NK_E_SINGULAR, "AMG: the hierarchy has no valid numbers (its last update failed)");
+  const int nlev = (int)M->lv.size();
+  if (M->lv[0].n == 0) return NK_OK;
+  M->lv[0].b = const_cast<double *>(d_b);
+  M->lv[0].x = d_x;
+  const int nu = M->prm.nu;
+  auto grid = [](int64_t n) { return dim3(nk_grid_for(n, NK_BLOCK * 4, 4096)); };
+  std::vector<double *> dcur(nlev), dnext(nlev);
+  auto coarsest = [&](amg_level &L) -> int {
+    if (M->dense) {
+      NK_LAUNCH(ctx, k_amg_dense_apply, dim3(1), dim3(128), (int)L.n, M->ldinv, (const double *)M->d_inv, (const double *)L.b, L.x, d_skip);
+      return NK_OK;
+    }
+    const double lmin = L.lmax / M->prm.cheb_ratio, theta = 0.5 * (L.lmax + lmin);
+    double *dc = L.d0, *dn = L.d1;
+    NK_LAUNCH(ctx, k_amg_cheb_first, grid(L.n), dim3(NK_BLOCK), L.n, 1, (const double *)L.b, (const double *)L.d_dinv, 1.0 / theta, L.r,
+              dc, L.x, d_skip);
+    return amg_cheb_rest(M, L, 4 * nu, &dc, &dn, d_skip);
+  };
+  for (int l = 0; l + 1 < nlev; ++l) {   // ---- down: pre-smooth from zero, residual, restrict
+    amg_level &L = M->lv[l];
+    const double lmin = L.lmax / M->prm.cheb_ratio, theta = 0.5 * (L.lmax + lmin);
+    dcur[l] = L.d0; dnext[l] = L.d1;
+    nk_prof_scope prof_(ctx, NK_K_OTHER, 40.0 * (double)L.n);
+    NK_LAUNCH(ctx, k_amg_cheb_first, grid(L.n), dim3(NK_BLOCK), L.n, 1, (const double *)L.b, (const double *)L.d_dinv, 1.0 / theta, L.r,
+              dcur[l], L.x, d_skip);
+    NK_TRY(amg_cheb_rest(M, L, nu, &dcur[l], &dnext[l], d_skip));
+    nk_spmv_epi ep;
+    ep.mode = 4;
+    ep.r = L.r;
+    NK_TRY(nk_csr_spmv_dev(L.A, dcur[l], nullptr, d_skip, nullptr, &ep));                  // r −= A d: now r = b − A x
+    NK_LAUNCH(ctx, k_amg_restrict, grid(L.nc), dim3(NK_BLOCK), L.nc, (const int32_t *)L.d_aggptr, (const int32_t *)L.d_aggmem,
+              (const double *)L.r, M->lv[l + 1].b, d_skip);
+  }
+  NK_TRY(coarsest(M->lv.back()));
+  for (int l = nlev - 2; l >= 0; --l) {   // ---- up: over-corrected prolongation, post-smooth
+    amg_level &L = M->lv[l];
+    const double lmin = L.lmax / M->prm.cheb_ratio, theta = 0.5 * (L.lmax + lmin);
+    nk_prof_scope prof_(ctx, NK_K_OTHER, 40.0 * (double)L.n);
+    NK_LAUNCH(ctx, k_amg_prolong, grid(L.n), dim3(NK_BLOCK), L.n, (const int32_t *)L.d_agg, (const double *)M->lv[l + 1].x,
+              M->prm.overcorrection, L.x, d_skip);
+    nk_spmv_epi ep;
+    ep.mode = 2;
+    ep.r = L.b;
+    NK_TRY(nk_csr_spmv_dev(L.A, L.x, L.r, d_skip, nullptr, &ep));                          // r = b − A x
+    NK_LAUNCH(ctx, k_amg_cheb_first, grid(L.n), dim3(NK_BLOCK), L.n, 0, (const double *)L.b, (const double *)L.d_dinv, 1.0 / theta, L.r,
+              dcur[l], L.x, d_skip);
+    NK_TRY(amg_cheb_rest(M, L, nu, &dcur[l], &dnext[l], d_skip));
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int nk_amg_levels(const nk_amg *M) { return (int)M->lv.size(); }
+int nk_amg_level_info(const nk_amg *M, int l, int64_t *n, int64_t *nnz, double *lmax) {
+  if (l < 0 || l >= (int)M->lv.size()) return NK_E_INVALID;
+  if (n) *n = M->lv[l].n;
+  if (nnz) *nnz = M->lv[l].nnz;
+  if (lmax) *lmax = M->lv[l].lmax;
+  return NK_OK;
+}
+const int32_t *nk_amg_aggregates(const nk_amg *M, int l) {
+  if (l < 0 || l + 1 >= (int)M->lv.size()) return nullptr;
+  return M->lv[l].h_agg.data();
+}

@@ -457,6 +457,13 @@ static int bcr_invert(nk_bcr *S, double *M, int64_t stride, int ld, int n, int b
   return NK_OK;
 }
 
+int nk_dense_invert128_dev(nk_ctx *ctx, double *d_M, int ld, int n, int *d_fail) {
+  NK_REQUIRE(n >= 1 && n <= 128 && ld >= n, "dense inverse: 1 ≤ n ≤ 128");
+  NK_LAUNCH(ctx, k_bcr_inv128<true>, dim3(1), dim3(512), d_M, (int64_t)0, ld, n, d_fail);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
 void nk_bcr_destroy(nk_bcr *S) {
   if (!S) return;
   for (size_t l = 0; l < S->lv.size(); ++l) {

@@ -31,7 +31,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // every lane issues ALL its col/val loads unconditionally (the arrays are padded by one tile), then all x
 // gathers (out-of-tile lanes gather x[0]), then the LDS writes — TILE/256 independent loads in flight per lane.
 // Row epilogue. mode 0: y[row] = scale·s. mode 1 (fused Chebyshev step, x = d_old): r −= s; d_new = c1·d_old + c2·r;
-// yacc += d_new — saves the separate 56 n-byte vector update and a kernel boundary per polynomial degree. mode 3: shifted.
+// yacc += d_new — saves the separate 56 n-byte vector update and a kernel boundary per polynomial degree (epi.dinv: the step
+// runs on D⁻¹A — the algebraic multigrid's smoother, nk_amg.hip). mode 2: y = b − A x. mode 3: shifted. mode 4: r −= A x.
 __device__ __forceinline__ void spmv_store_row(int row, double s, double *__restrict__ y, const double *out_scale,
                                                double os, const double *__restrict__ x, const nk_spmv_epi &epi) {
   if (epi.mode == 0) {
@@ -39,10 +40,14 @@ __device__ __forceinline__ void spmv_store_row(int row, double s, double *__rest
   } else if (epi.mode == 3) {  // Newton-basis step of the s-step Arnoldi process: y = scale·(A x − θ x)
     const double v = s - (*epi.theta) * x[row];
     y[row] = out_scale ? os * v : v;
-  } else {
+  } else if (epi.mode == 2) {  // fused residual: y = b − A x (b = epi.r), as the stencil kernels' mode 2
+    y[row] = epi.r[row] - s;
+  } else if (epi.mode == 4) {  // residual update only: r −= A x
+    epi.r[row] -= s;
+  } else {                     // Chebyshev step (x = d_old); with epi.dinv on D⁻¹A (the multigrid smoothers)
     const double rr = epi.r[row] - s;
     epi.r[row] = rr;
-    const double dn = epi.c1 * x[row] + epi.c2 * rr;
+    const double dn = epi.c1 * x[row] + epi.c2 * (epi.dinv ? epi.dinv[row] * rr : rr);
     epi.dnew[row] = dn;
     epi.yacc[row] += dn;
   }

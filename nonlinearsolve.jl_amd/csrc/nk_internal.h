@@ -197,6 +197,7 @@ struct nk_spmv_epi {
   double c1 = 0, c2 = 0;
   double *r = nullptr, *dnew = nullptr, *yacc = nullptr;
   const double *theta = nullptr;
+  const double *dinv = nullptr;   // mode 1 (CSR kernel): the step runs on D⁻¹A. CSR modes 2 / 4: y = r − A x / r −= A x
 };
 
 // ----------------------------------------------------------------------------- halo plan
@@ -481,6 +482,18 @@ struct nk_gmres {
 };
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info);
+
+// aggregation algebraic multigrid built from a CSR matrix (nk_amg.hip); the object behind nk_precond_create_amg
+struct nk_amg;
+int nk_amg_create(nk_csr *A, const nk_amg_params *prm, nk_amg **out);
+int nk_amg_update(nk_amg *M);                       // new values, same pattern
+int nk_amg_apply_dev(nk_amg *M, const double *d_b, double *d_x, const int *d_skip);   // x = one V-cycle applied to b (b ≠ x)
+void nk_amg_destroy(nk_amg *M);
+int nk_amg_levels(const nk_amg *M);
+int nk_amg_level_info(const nk_amg *M, int l, int64_t *n, int64_t *nnz, double *lmax);
+const int32_t *nk_amg_aggregates(const nk_amg *M, int l);   // host: row → coarse row of level l (NULL on the coarsest)
+// in-place inverse of ONE dense n × n matrix, n ≤ 128, column-major with leading dimension ld, row pivoting (nk_bcr.hip)
+int nk_dense_invert128_dev(nk_ctx *ctx, double *d_M, int ld, int n, int *d_fail);
 
 // preconditioner objects (nk_precond.hip)
 int nk_precond_apply_dev(struct nk_precond *P, const double *d_x, double *d_y, const int *d_skip);

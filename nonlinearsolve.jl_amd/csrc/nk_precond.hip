@@ -6,6 +6,7 @@
 //   NK_PRECOND_JACOBI   M = diag(A)
 //   NK_PRECOND_ILU0     A ≈ L U on the pattern of A (no fill, no pivoting; L unit lower), of the rank's LOCAL square block
 //                       (halo columns are dropped: block-Jacobi ILU(0) across ranks — no communication in the apply).
+//   NK_PRECOND_AMG      aggregation algebraic multigrid (nk_amg.hip) — the scalable one of the three.
 //
 // ILU(0) on a GPU is a scheduling problem: row i of the factorisation (and of both triangular solves) can start when the
 // rows it refers to are done. Rows are grouped into LEVELS (level(i) = 1 + max level of the rows i depends on); a level is a
@@ -49,6 +50,8 @@ struct nk_precond {
   double *d_y = nullptr, *d_z = nullptr, *d_xin = nullptr, *d_xout = nullptr;
   int *d_fail = nullptr;
   bool factored = false;
+  // algebraic multigrid (nk_amg.hip)
+  struct nk_amg *amg = nullptr;
 };
 
 // ----------------------------------------------------------------------------- Jacobi
@@ -364,8 +367,35 @@ extern "C" int nk_precond_create_ilu0(nk_csr *A, int ordering, nk_precond **out)
   *out = guard.release();
   return NK_OK;
 }
+extern "C" int nk_precond_create_amg(nk_csr *A, const nk_amg_params *params, nk_precond **out) {
+  nk_precond *P = nullptr;
+  NK_TRY(precond_new(A, NK_PRECOND_AMG, out, &P));
+  auto guard = nk_make_guard(P, [](nk_precond *p) { nk_precond_destroy(p); });
+  NK_TRY(nk_amg_create(A, params, &P->amg));   // (creates the hierarchy and its numbers for the current values)
+  P->factored = true;
+  *out = guard.release();
+  return NK_OK;
+}
+extern "C" int nk_precond_amg_info(nk_precond *P, int *levels, int cap, int64_t *sizes, int64_t *nnzs, double *lmax) {
+  NK_REQUIRE(P && P->kind == NK_PRECOND_AMG && P->amg, "not an AMG preconditioner");
+  const int nl = nk_amg_levels(P->amg);
+  if (levels) *levels = nl;
+  for (int l = 0; l < nl && l < cap; ++l)
+    NK_TRY(nk_amg_level_info(P->amg, l, sizes ? sizes + l : nullptr, nnzs ? nnzs + l : nullptr, lmax ? lmax + l : nullptr));
+  return NK_OK;
+}
+extern "C" int nk_precond_amg_aggregates(nk_precond *P, int level, int32_t *agg, int64_t count) {
+  NK_REQUIRE(P && P->kind == NK_PRECOND_AMG && P->amg && agg, "not an AMG preconditioner");
+  const int32_t *h = nk_amg_aggregates(P->amg, level);
+  int64_t n = 0;
+  NK_REQUIRE(h && nk_amg_level_info(P->amg, level, &n, nullptr, nullptr) == NK_OK && n == count,
+             "AMG: level %d has no aggregates or not %lld rows", level, (long long)count);
+  memcpy(agg, h, (size_t)n * sizeof(int32_t));
+  return NK_OK;
+}
 extern "C" int nk_precond_destroy(nk_precond *P) {
   if (!P) return NK_OK;
+  nk_amg_destroy(P->amg);
   hipFree(P->d_dinv); hipFree(P->d_perm); hipFree(P->d_rp); hipFree(P->d_ci); hipFree(P->d_dg); hipFree(P->d_src);
   hipFree(P->d_lu); hipFree(P->d_planptr); hipFree(P->d_planq); hipFree(P->d_plans);
   hipFree(P->d_rowsL); hipFree(P->d_ptrL); hipFree(P->d_rowsU); hipFree(P->d_ptrU);
@@ -381,6 +411,12 @@ extern "C" int nk_precond_update(nk_precond *P) {
   NK_HIP(hipSetDevice(ctx->device));
   nk_csr *A = P->A;
   const int64_t n = P->n;
+  if (P->kind == NK_PRECOND_AMG) {
+    P->factored = false;
+    NK_TRY(nk_amg_update(P->amg));
+    P->factored = true;
+    return NK_OK;
+  }
   NK_HIP(hipMemsetAsync(P->d_fail, 0, sizeof(int), ctx->stream));
   if (n > 0) {
     if (P->kind == NK_PRECOND_JACOBI) {
@@ -423,6 +459,13 @@ int nk_precond_apply_dev(nk_precond *P, const double *d_x, double *d_y, const in
   if (n == 0) return NK_OK;
   if (!P->factored)
     NK_FAIL(NK_E_SINGULAR, "preconditioner object has no valid factors (its last update met a zero or non-finite pivot)");
+  if (P->kind == NK_PRECOND_AMG) {
+    if (d_x != d_y) return nk_amg_apply_dev(P->amg, d_x, d_y, d_skip);
+    // in place: the V-cycle reads b while it builds x
+    if (!P->d_xin) NK_TRY(nk_dev_alloc(&P->d_xin, (size_t)n + 1));
+    NK_HIP(hipMemcpyAsync(P->d_xin, d_x, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return nk_amg_apply_dev(P->amg, P->d_xin, d_y, d_skip);
+  }
   if (P->kind == NK_PRECOND_JACOBI) {
     nk_prof_scope prof_(ctx, NK_K_OTHER, 24.0 * (double)n);
     NK_LAUNCH(ctx, k_jacobi_apply, dim3(nk_grid_for(n, NK_BLOCK * 4, 4096)), dim3(NK_BLOCK), n, (const double *)P->d_dinv, d_x,
@@ -479,7 +522,7 @@ extern "C" int nk_precond_apply(nk_precond *P, const double *x, double *y, int m
 extern "C" int nk_precond_info(nk_precond *P, int *kind, int *levels_lower, int *levels_upper, int *ncolors) {
   NK_REQUIRE(P, "NULL argument");
   if (kind) *kind = P->kind;
-  if (levels_lower) *levels_lower = P->kind == NK_PRECOND_ILU0 ? (int)P->h_ptrL.size() - 1 : 0;
+  if (levels_lower) *levels_lower = P->kind == NK_PRECOND_ILU0 ? (int)P->h_ptrL.size() - 1 : (P->kind == NK_PRECOND_AMG ? nk_amg_levels(P->amg) : 0);
   if (levels_upper) *levels_upper = P->kind == NK_PRECOND_ILU0 ? (int)P->h_ptrU.size() - 1 : 0;
   if (ncolors) *ncolors = P->ncolors;
   return NK_OK;

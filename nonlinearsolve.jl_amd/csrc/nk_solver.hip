@@ -1665,6 +1665,7 @@ static int refresh_precs(nk_solver *S) {
     if (!S->prec_obj) {
       NK_REQUIRE(concrete(S) && S->J, "nk_options.precond_kind needs a concrete-J linsolve");
       if (S->o.precond_kind == 1) NK_TRY(nk_precond_create_jacobi(S->J, &S->prec_obj));
+      else if (S->o.precond_kind == 4) NK_TRY(nk_precond_create_amg(S->J, nullptr, &S->prec_obj));
       else NK_TRY(nk_precond_create_ilu0(S->J, S->o.precond_kind == 3 ? NK_ILU_MULTICOLOR : NK_ILU_NATURAL, &S->prec_obj));
     } else {
       NK_TRY(nk_precond_update(S->prec_obj));

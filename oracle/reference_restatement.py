@@ -649,6 +649,187 @@ def jacobi_preconditioner(A):
     return lambda x: np.asarray(x, dtype=np.float64) / d
 
 
+# ----------------------------------------------------------------------------- aggregation algebraic multigrid
+# The slot the reference's tutorial fills with AlgebraicMultigrid.jl's ruge_stuben / smoothed_aggregation returned from
+# `precs(A, p)` as Pl (docs/src/tutorials/large_systems.md:276-316) [EXT package; its arithmetic is not in the tree]: a
+# multigrid preconditioner built from the sparse Jacobian ALONE. What the device builds (csrc/nk_amg.hip), restated:
+#   * coarsening by PAIRWISE AGGREGATION, `passes` times per level (aggregates of ≤ 2^passes rows): rows in natural order; an
+#     unmatched row i takes the unmatched neighbour j with the largest strength s_ij = −a_ij·sign(a_ii) (couplings of the sign
+#     opposite to the diagonal; first in CSR order on ties) provided s_ij ≥ θ·max_k s_ik, else stays a singleton; the next
+#     pass works on the Galerkin matrix of the pairs;
+#   * piecewise-constant prolongation T (one 1 per row), Galerkin coarse matrices TᵀA T — every coarse entry the sum of the
+#     fine entries it covers, in ascending order of their position in the fine value array;
+#   * levels until ≤ coarse_max rows (or until a level shrinks by less than 20 %); the coarsest matrix is inverted (dense) —
+#     if coarsening stalled above coarse_max rows it is smoothed 4ν times instead;
+#   * V-cycle: ν Chebyshev steps on D⁻¹A over [λmax/ratio, λmax], λmax = max_i Σ_j |a_ij| / |a_ii| (Gershgorin), before and
+#     after; the coarse correction is OVER-CORRECTED by ω (plain aggregation under-estimates smooth error by about a factor of
+#     two; 1.8 is the measured optimum on the 5-point Laplacian and the Brusselator) — x += ω·T x_c.
+# A fixed linear operator (fixed degree, fixed hierarchy), so it serves plain GMRES on either side. New values on the same
+# pattern (a new Jacobian) refresh the numbers — Galerkin sums, D⁻¹, λmax, the coarse inverse — and keep the aggregates.
+def amg_pairwise_pass(rp, ci, v, theta):
+    n = len(rp) - 1
+    cid = -np.ones(n, dtype=np.int64)
+    nc = 0
+    for i in range(n):
+        if cid[i] >= 0:
+            continue
+        a, e = rp[i], rp[i + 1]
+        cols, vals = ci[a:e], v[a:e]
+        dg = vals[cols == i].sum() if np.any(cols == i) else 0.0
+        sg = -1.0 if dg < 0 else 1.0
+        smax, best, bv = 0.0, -1, 0.0
+        for k in range(e - a):
+            j = cols[k]
+            if j == i:
+                continue
+            sv = -vals[k] * sg
+            if sv > smax:
+                smax = sv
+            if cid[j] < 0 and sv > bv:
+                bv, best = sv, j
+        cid[i] = nc
+        if best >= 0 and bv >= theta * smax:
+            cid[best] = nc
+        nc += 1
+    return cid, nc
+
+
+def amg_galerkin(rp, ci, v, cid, nc):
+    """TᵀA T for the aggregate map cid: (rowptr, col, val, entry_map) — entry_map[k] = the coarse entry fine entry k is summed
+    into; values summed in ascending k"""
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    key = cid[rows] * np.int64(nc) + cid[ci]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    first = np.ones(len(ks), dtype=bool)
+    first[1:] = ks[1:] != ks[:-1]
+    eid = np.cumsum(first) - 1
+    emap = np.empty(len(ks), dtype=np.int64)
+    emap[order] = eid
+    ukey = ks[first]
+    crow, ccol = ukey // nc, ukey % nc
+    crp = np.zeros(nc + 1, dtype=np.int64)
+    np.add.at(crp, crow + 1, 1)
+    crp = np.cumsum(crp)
+    cv = np.zeros(len(ukey))
+    np.add.at(cv, emap, v)          # sequential, in ascending k
+    return crp, ccol.astype(np.int64), cv, emap
+
+
+class AggregationAMG:
+    def __init__(self, A, nu=2, passes=2, theta=0.25, overcorrection=1.8, cheb_ratio=4.0, coarse_max=128, max_levels=24):
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        self.nu, self.passes, self.theta, self.omega = int(nu), int(passes), float(theta), float(overcorrection)
+        self.ratio, self.coarse_max = float(cheb_ratio), int(coarse_max)
+        self.levels = []      # dicts: rp, ci (pattern), agg (row → coarse row), nc, emap (fine entry → coarse entry)
+        rp, ci, v = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
+        while len(rp) - 1 > self.coarse_max and len(self.levels) < max_levels:
+            n = len(rp) - 1
+            agg = np.arange(n, dtype=np.int64)
+            crp, cci, cv = rp, ci, v
+            for _ in range(self.passes):
+                cid, nc = amg_pairwise_pass(crp, cci, cv, self.theta)
+                crp, cci, cv, _e = amg_galerkin(crp, cci, cv, cid, nc)
+                agg = cid[agg]
+            if nc > 0.8 * n:
+                break
+            nrp, nci, nv, emap = amg_galerkin(rp, ci, v, agg, nc)   # one-stage sums: what a value refresh recomputes
+            self.levels.append(dict(rp=rp, ci=ci, agg=agg, nc=nc, emap=emap, n=n))
+            rp, ci, v = nrp, nci, nv
+        self.coarse = dict(rp=rp, ci=ci, n=len(rp) - 1)
+        self.update(A)
+
+    def sizes(self):
+        return [L["n"] for L in self.levels] + [self.coarse["n"]]
+
+    def _values_on_pattern(self, A):
+        """A's values laid out on the creation-time pattern (SciPy drops entries that happen to be exactly zero — the device's
+        pattern is structural and keeps them: a matrix whose pattern is a SUBSET of the creation pattern is padded with zeros)"""
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        rp, ci = (self.levels[0] if self.levels else self.coarse)["rp"], (self.levels[0] if self.levels else self.coarse)["ci"]
+        if A.nnz == len(ci) and np.array_equal(A.indptr, rp) and np.array_equal(A.indices, ci):
+            return A.data.astype(np.float64)
+        n = len(rp) - 1
+        pk = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp)) * n + ci
+        ak = np.repeat(np.arange(n, dtype=np.int64), np.diff(A.indptr)) * n + A.indices
+        pos = np.searchsorted(pk, ak)
+        if np.any(pos >= len(pk)) or np.any(pk[np.minimum(pos, len(pk) - 1)] != ak):
+            raise ValueError("AMG update: the matrix has entries outside the pattern the hierarchy was built on")
+        v = np.zeros(len(ci))
+        v[pos] = A.data
+        return v
+
+    def update(self, A):
+        """new values on the creation-time pattern"""
+        v = self._values_on_pattern(A)
+        for L in self.levels:
+            self._numbers(L, v)
+            nv = np.zeros(int(L["emap"].max()) + 1 if len(L["emap"]) else 0)
+            np.add.at(nv, L["emap"], v)
+            v = nv
+        C_ = self.coarse
+        self._numbers(C_, v)
+        C_["dense"] = C_["n"] <= self.coarse_max
+        if C_["dense"]:
+            C_["inv"] = np.linalg.inv(C_["A"].toarray()) if C_["n"] else np.zeros((0, 0))
+        return self
+
+    @staticmethod
+    def _numbers(L, v):
+        n = L["n"]
+        A = sp.csr_matrix((v, L["ci"], L["rp"]), shape=(n, n))
+        d = A.diagonal()
+        if np.any(d == 0.0) or not np.all(np.isfinite(d)):
+            raise ArithmeticError("AMG: zero or non-finite diagonal entry")
+        L["A"], L["dinv"] = A, 1.0 / d
+        L["lmax"] = float(np.max(np.asarray(abs(A).sum(axis=1)).ravel() / np.abs(d))) if n else 1.0
+
+    def _cheb(self, L, b, x, nsteps):
+        """nsteps Chebyshev steps on D⁻¹A from x (None: zero); returns (x, r_lagged, d): r is the residual BEFORE the last d"""
+        lmax = L["lmax"]
+        lmin = lmax / self.ratio
+        th, de = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        s1 = th / de
+        rho = 1.0 / s1
+        A, dinv = L["A"], L["dinv"]
+        if x is None:
+            r = b.copy()
+            d = dinv * r * (1.0 / th)
+            x = d.copy()
+        else:
+            r = b - A @ x
+            d = dinv * r * (1.0 / th)
+            x = x + d
+        for _ in range(1, nsteps):
+            rho_new = 1.0 / (2.0 * s1 - rho)
+            r = r - A @ d
+            d = (rho_new * rho) * d + (2.0 * rho_new / de) * (dinv * r)
+            x = x + d
+            rho = rho_new
+        return x, r, d
+
+    def apply(self, b, level=0):
+        b = np.asarray(b, dtype=np.float64)
+        if level == len(self.levels):
+            C_ = self.coarse
+            if C_["dense"]:
+                return C_["inv"] @ b
+            return self._cheb(C_, b, None, 4 * self.nu)[0]
+        L = self.levels[level]
+        x, r, d = self._cheb(L, b, None, self.nu)
+        r = r - L["A"] @ d                                   # b − A x
+        bc = np.zeros(L["nc"])
+        np.add.at(bc, L["agg"], r)                           # Tᵀ r, members in ascending row order
+        xc = self.apply(bc, level + 1)
+        x = x + self.omega * xc[L["agg"]]
+        return self._cheb(L, b, x, self.nu)[0]
+
+    __call__ = apply
+
+
 @dataclass
 class LinearSolveParameters:   # lib/NonlinearSolveBase/src/linear_solve.jl:1-4
     u: object
@@ -943,7 +1124,7 @@ class KrylovJL_GMRES:
 @dataclass
 class ObjectPrecs:
     """precs through a built-in object on the concrete J (nk_options.precond_kind): kind = "jacobi" | "ilu0" (multicolour) |
-    "ilu0_natural"; side = "left" (the reference's tutorial precs return `(Pl, I)`) or "right"."""
+    "ilu0_natural" | "amg" (AggregationAMG); side = "left" (the reference's tutorial precs return `(Pl, I)`) or "right"."""
     kind: str = "ilu0"
     side: str = "left"
 
@@ -1428,8 +1609,27 @@ class FirstOrderCache:
                 M = MG(self.prob, u_now, kr.precs.nu, kr.precs.coarse_max)
             elif isinstance(kr.precs, ObjectPrecs):   # a built-in object refactorised for the current concrete J
                 assert self.concrete, "ObjectPrecs needs a concrete J"
-                Pm = jacobi_preconditioner(self.J) if kr.precs.kind == "jacobi" else \
-                    ilu0_preconditioner(self.J, "natural" if kr.precs.kind == "ilu0_natural" else "multicolor")
+                if kr.precs.kind == "amg":   # aggregates fixed when the object is built, numbers refreshed for every new J
+                    if getattr(self, "_amg", None) is None:
+                        # the device builds the hierarchy on the STRUCTURAL pattern of J (entries that are zero at this u included)
+                        S = sp.csr_matrix(self.prob.jac(np.full(self.prob.n, 0.37)))
+                        S.sort_indices()
+                        Jf = sp.csr_matrix(self.J)
+                        Jf.sort_indices()
+                        if S.nnz != Jf.nnz:
+                            n_ = S.shape[0]
+                            pk = np.repeat(np.arange(n_, dtype=np.int64), np.diff(S.indptr)) * n_ + S.indices
+                            ak = np.repeat(np.arange(n_, dtype=np.int64), np.diff(Jf.indptr)) * n_ + Jf.indices
+                            vv = np.zeros(S.nnz)
+                            vv[np.searchsorted(pk, ak)] = Jf.data
+                            Jf = sp.csr_matrix((vv, S.indices.copy(), S.indptr.copy()), shape=S.shape)
+                        self._amg = AggregationAMG(Jf)
+                    elif new_jacobian:
+                        self._amg.update(self.J)
+                    Pm = self._amg
+                else:
+                    Pm = jacobi_preconditioner(self.J) if kr.precs.kind == "jacobi" else \
+                        ilu0_preconditioner(self.J, "natural" if kr.precs.kind == "ilu0_natural" else "multicolor")
                 M, Ml = (Pm, None) if kr.precs.side == "right" else (None, Pm)
             elif callable(kr.precs):
                 # the `precs(A, p) -> (Pl, Pr)` hook: a new A marks the LinearSolve cache fresh (ext/NonlinearSolveBase

@@ -1,0 +1,185 @@
+"""Aggregation algebraic multigrid (csrc/nk_amg.hip) — the `precs(A, p)` slot the reference's tutorial fills with an algebraic
+multigrid as Pl (docs/src/tutorials/large_systems.md:276-316), built from the CSR matrix ALONE — against its CPU restatement
+oracle/reference_restatement.py::AggregationAMG: the same aggregates (integer-exact), the same hierarchy, the V-cycle equal to
+1e-11 relative, GMRES iteration for iteration, whole Newton solves step for step; and at config C3's full size (Bratu 1024²,
+the Jacobian ingested as a CSR matrix — no geometric knowledge reaches the preconditioner) the bar VERDICT r03 set: ‖h²F‖∞ ≤ 1e-8
+in ≤ 15 Krylov iterations per Newton step."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import reference_restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(x):
+    return np.asarray(x.cpu() if hasattr(x, "cpu") else x)
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def _cases():
+    rng = np.random.default_rng(3)
+    pb = R.Bratu2D(48)
+    yield "bratu48", pb.jac(rng.standard_normal(pb.n) * 0.2).tocsr()
+    pr = R.Brusselator2D(32)
+    yield "brusselator32", pr.jac(pr.u0()).tocsr()
+    # an unstructured, non-symmetric, diagonally dominant matrix with ragged rows
+    n = 3000
+    B = sp.random(n, n, density=0.002, random_state=5, format="csr")
+    B.data = -np.abs(B.data)
+    A = (B + sp.diags(np.asarray(abs(B).sum(axis=1)).ravel() + 0.5)).tocsr()
+    A.sort_indices()
+    yield "random3000", A
+
+
+@pytest.mark.parametrize("name,A", list(_cases()), ids=[c[0] for c in _cases()])
+def test_hierarchy_aggregates_and_vcycle_match_the_oracle(nls, dev, name, A):
+    import torch
+    M = nls.CSRMatrix.from_scipy(A)
+    P = nls.AMGPreconditioner(M)
+    O = R.AggregationAMG(A)
+    h = P.hierarchy()
+    assert [x[0] for x in h] == O.sizes()
+    for l, L in enumerate(O.levels):
+        assert np.array_equal(P.aggregates(l), L["agg"].astype(np.int32)), f"aggregates of level {l}"
+        assert h[l][1] == L["A"].nnz and abs(h[l][2] - L["lmax"]) <= 1e-12 * L["lmax"]
+    assert h[-1][1] == O.coarse["A"].nnz
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        b = rng.standard_normal(A.shape[0])
+        y = P.apply(torch.tensor(b, device=dev)).cpu().numpy()
+        assert _rel(y, O(b)) <= 1e-11
+        assert _rel(P.apply(b), O(b)) <= 1e-11           # host vectors
+    # a fixed LINEAR operator (plain GMRES may use it on either side)
+    b, c = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    assert _rel(P.apply(b + 2.0 * c), P.apply(b) + 2.0 * P.apply(c)) <= 1e-12
+    # new values on the same pattern: the aggregates stay, every number is refreshed on the device
+    A2 = A.copy()
+    A2.data = A.data * (1.0 + 0.1 * rng.random(A.nnz))
+    M.set_values(A2.data)
+    P.update()
+    O.update(A2)
+    b = rng.standard_normal(A.shape[0])
+    assert _rel(P.apply(b), O(b)) <= 1e-11
+    assert np.array_equal(P.aggregates(0), O.levels[0]["agg"].astype(np.int32))
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+@pytest.mark.parametrize("ortho", ["dcgs2", "sstep"])
+def test_gmres_with_amg_matches_the_oracle(nls, dev, side, ortho):
+    import torch
+    pb = R.Bratu2D(96)
+    A = pb.jac(np.full(pb.n, 0.3)).tocsr()
+    b = np.random.default_rng(2).standard_normal(pb.n)
+    O = R.AggregationAMG(A)
+    kw = dict(Ml=O) if side == "left" else dict(M=O)
+    xo, io = R.gmres(lambda v: A @ v, b, restart=30, rtol=1e-10, itmax=200, ortho="cgs2", **kw)
+    J = nls.CSRMatrix.from_scipy(A)
+    P = nls.AMGPreconditioner(J)
+    G = nls.GMRES(pb.n, restart=30, ortho=ortho).set_operator(J).set_preconditioner(P, side=side)
+    x, g = G.solve(torch.tensor(b, device=dev), abstol=0.0, reltol=1e-10, maxiters=200)
+    assert g["converged"] and io.converged
+    assert abs(g["iters"] - io.iters) <= 1, (g["iters"], io.iters)
+    assert io.iters <= 25                                            # multigrid, not a smoother: a few dozen iterations to 1e-10
+    assert _rel(x.cpu().numpy(), xo) <= 1e-8
+
+
+@pytest.mark.parametrize("how", ["options", "callable_object"])
+def test_newton_with_amg_precs_matches_the_oracle(nls, dev, how):
+    """large_systems.md:276-287 on the device: NewtonRaphson(linsolve = KrylovJL_GMRES(precs = algebraicmultigrid), concrete_jac = true)
+    on the Brusselator of sparsity_tests__item1.jl:7-55 (N = 32) — Pl returned from a Python `precs` as a device object that is
+    `update()`d for every new Jacobian, and through nk_options with no host callback — against the oracle: steps, iterations, root."""
+    PB = nls.Brusselator2D(32)
+    state, calls = {}, []
+    if how == "callable_object":
+        def algebraicmultigrid(W, p=None):
+            calls.append(1)
+            assert isinstance(W, nls.CSRMatrix) and isinstance(p, nls.LinearSolveParameters)
+            if "M" not in state:
+                state["M"] = nls.AMGPreconditioner(W)
+            else:
+                state["M"].update()
+            return state["M"], None
+        precs = algebraicmultigrid
+    else:
+        precs = nls.ObjectPrecs("amg", "left")
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=precs, gmres_restart=30, maxiters=300, reltol=1e-8, abstol=0.0),
+                            concrete_jac=True)
+    sol = nls.solve(nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True)), alg, abstol=1e-8, maxiters=50)
+    oc = R.init(R.Brusselator2D(32), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=R.ObjectPrecs("amg", "left"), gmres_restart=30,
+                                                                                maxiters=300, ortho="cgs2"), concrete_jac=True),
+                abstol=1e-8, maxiters=50)
+    oc.lin_reltol, oc.lin_abstol = 1e-8, 0.0
+    ref = oc.solve()
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and sol.stats.nsteps == ref.stats.nsteps
+    assert abs(sol.stats.gmres_iters - ref.stats.gmres_iters) <= sol.stats.nsteps
+    assert sol.stats.gmres_iters <= 20 * sol.stats.nsteps
+    assert float(np.max(np.abs(_np(sol.resid)))) <= 1e-8          # sparsity_tests__item1.jl:54: ‖resid‖∞ < 1e-8
+    assert np.max(np.abs(_np(sol.u) - ref.u)) <= 1e-7 * np.max(np.abs(ref.u))
+    if calls:
+        assert len(calls) == sol.stats.nsteps + 1
+
+
+def test_user_function_with_csr_jacobian_and_amg(nls, dev):
+    """A USER problem — residual and Jacobian values as callbacks on device tensors, `jac_prototype` a CSR pattern — with the AMG
+    built from that matrix: Bratu 128² written by hand (the library's stencil kernels are not involved), Eisenstat–Walker."""
+    import torch
+    ns = 128
+    pb = R.Bratu2D(ns)
+    J0 = pb.jac(np.zeros(pb.n)).tocsr()
+    J0.sort_indices()
+    rows_np = np.repeat(np.arange(pb.n), np.diff(J0.indptr))
+    lap_np = J0.data + np.where(rows_np == J0.indices, pb.c_exp, 0.0)    # J(0) = c_lap·Δ − c_exp·I: the Laplacian part
+    diag_mask = torch.tensor(rows_np == J0.indices, device=dev)
+    lap = torch.tensor(lap_np, device=dev)
+    Jt = torch.sparse_csr_tensor(torch.tensor(J0.indptr, dtype=torch.int64), torch.tensor(J0.indices, dtype=torch.int64),
+                                 lap.clone(), size=(pb.n, pb.n), device=dev)
+
+    def F(du, u, p):
+        du.copy_(torch.mv(Jt, u) - pb.c_exp * torch.exp(u))
+
+    def JAC(Jv, u, p):   # values in the prototype's CSR order
+        v = lap.clone()
+        v[diag_mask] -= pb.c_exp * torch.exp(u)
+        Jv.copy_(v)
+
+    f = nls.NonlinearFunction(F, jac=JAC, jac_prototype=nls.CSRMatrix.from_scipy(J0))
+    prob = nls.NonlinearProblem(f, torch.zeros(pb.n, dtype=torch.float64, device=dev), None)
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.ObjectPrecs("amg", "left"), gmres_restart=30, maxiters=300),
+                            forcing=nls.EisenstatWalkerForcing2(), concrete_jac=True)
+    sol = nls.solve(prob, alg, abstol=1e-8, maxiters=50)
+    ref = R.solve(pb, R.NewtonRaphson(linsolve=None), abstol=1e-10, maxiters=50)
+    assert sol.retcode == "Success"
+    assert sol.stats.gmres_iters <= 15 * sol.stats.nsteps
+    assert np.max(np.abs(_np(sol.u) - ref.u)) <= 1e-7 * max(1.0, np.max(np.abs(ref.u)))
+
+
+def test_bratu_1024_as_a_csr_matrix_converges_in_15_iterations_per_newton_step(nls, dev):
+    """config C3's full size: NewtonRaphson + GMRES(30) + Eisenstat–Walker on the assembled CSR Jacobian with the AMG object as Pl
+    (built from the CSR matrix inside the solver: nk_options.precond_kind = 4) to ‖h²F‖∞ ≤ 1e-8 — the unpreconditioned protocol
+    stalls at 2.7e-6 after 15 000 iterations, ILU(0) does not reach 1e-8 in 3000."""
+    import time
+    import torch
+    prob = nls.NonlinearProblem(nls.Bratu2D(1024, 6.0))
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.ObjectPrecs("amg", "left"), gmres_restart=30, maxiters=300),
+                            forcing=nls.EisenstatWalkerForcing2(), concrete_jac=True)
+    sol = nls.solve(prob, alg, abstol=1e-8, maxiters=50)            # includes the hierarchy's set-up (host aggregation)
+    assert sol.retcode == "Success", sol.retcode
+    assert float(np.max(np.abs(_np(sol.resid)))) <= 1e-8
+    assert sol.stats.gmres_iters <= 15 * sol.stats.nsteps, (sol.stats.gmres_iters, sol.stats.nsteps)
+    # the same root as the geometric V-cycle's solve (tests/test_gpu_fullsize.py pins that one against the C oracle)
+    alg_g = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.MultigridPrecs(2, 31), gmres_restart=30, maxiters=300),
+                              forcing=nls.EisenstatWalkerForcing2(), concrete_jac=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sol_g = nls.solve(nls.NonlinearProblem(nls.Bratu2D(1024, 6.0)), alg_g, abstol=1e-8, maxiters=50)
+    torch.cuda.synchronize()
+    del t0
+    # both solves stop at ‖h²F‖∞ ≤ 1e-8; ‖(h²J)⁻¹‖ ≈ 1 / (2π²h²) ≈ 5e4 at this size, so two such iterates may differ by ≈ 1e-3·1e-8·…:
+    # the bound below is the conditioning's, not the solver's (the 4-step geometric and the 9-step AMG solve differ by 6e-6)
+    assert float(np.max(np.abs(_np(sol.u) - _np(sol_g.u)))) <= 1e-4 * float(np.max(np.abs(_np(sol_g.u))))
+    print(f"AMG: {sol.stats.nsteps} Newton steps, {sol.stats.gmres_iters} Krylov iterations; geometric: {sol_g.stats.nsteps} / {sol_g.stats.gmres_iters}")

@@ -12,7 +12,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 12 --warmup 3 --cpu-seconds 0 --no-profile-pass --no-ttt --pmc off $EXTRA"
+CMD="python $REPO/bench.py --steps 12 --warmup 3 --cpu-seconds 0 --no-profile-pass --no-ttt --no-spmv-hbm --pmc off $EXTRA"
 rm -rf /tmp/kt /tmp/pf /tmp/pw /tmp/merge
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o fetch -- $CMD > /dev/null 2>&1

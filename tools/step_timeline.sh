@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $REPO/bench.py --steps 12 --warmup 3 --cpu-seconds 0 --no-profile-pass --no-ttt --pmc off "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $REPO/bench.py --steps 12 --warmup 3 --cpu-seconds 0 --no-profile-pass --no-ttt --no-spmv-hbm --pmc off "$@" > /dev/null 2>&1
 F=$(find /tmp/tl -name "tl_kernel_trace.csv" | head -1)
 python $REPO/tools/step_timeline.py "$F" > $OUT/${TAG}_step_timeline.md
 tail -25 $OUT/${TAG}_step_timeline.md
