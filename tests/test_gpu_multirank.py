@@ -91,6 +91,25 @@ def _worker(rank, world, port, q, transport="torch"):
             bound = sol.stats.gmres_iters + 24 * (sol.stats.nsteps + 1)   # (two reductions per step would exceed it)
             assert sol.stats.allreduces <= bound, (sol.stats.allreduces, sol.stats.gmres_iters, sol.stats.nsteps, bound)
 
+        # ---------------- synchronisation points of the headline protocol, counted (the Krylov inner products are
+        # the path's only collective). One fixed-work Newton step = GMRES(30) in two s-step blocks of 15: ONE all-reduce per Gram
+        # sweep (A and B of each block; the cycle's last block has no sweep C) = 4, + the Gershgorin bounds of the new Jacobian
+        # (max), + ‖b‖² at the cycle's start, + the update's ‖δu‖₂, + the step's norm batch (‖f‖∞, Σf²) = 8; 31 halo exchanges
+        # (30 operator applications + the residual). Column by column it is 30 + a handful. BASELINE.md §6 prices the 8-GPU
+        # strong-scaling point with these numbers: a change of them is a change of the scaling model and must be deliberate.
+        probc = nls.NonlinearProblem(P, u0=torch.zeros(e - b, dtype=torch.float64, device=dev))
+        cch = nls.init(probc, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, fixed_iters=30),
+                                                concrete_jac=True), abstol=1e-300, maxiters=10 ** 6)
+        cch.step()
+        a0, h0 = cch.stats.allreduces, cch.stats.halo_exchanges
+        for _ in range(3):
+            cch.step()
+        per_step = (cch.stats.allreduces - a0) / 3.0
+        halo_step = (cch.stats.halo_exchanges - h0) / 3.0
+        # (peer-mapped arenas: one launch fewer carries a collective — 7; the callback transport issues every one of the 8 itself)
+        assert per_step == (7.0 if transport == "peer" else 8.0) and halo_step == 31.0, f"PERSTEP={per_step} HALOSTEP={halo_step}"
+        cch.close()
+
         # ---------------- halo exchange overlapped with the interior row blocks (second stream + events): a grid large
         # enough to have both interior and boundary row blocks; every result is bitwise equal to the serial-exchange path
         ns2 = 64
