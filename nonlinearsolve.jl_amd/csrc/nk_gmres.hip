@@ -1259,9 +1259,16 @@ int nk_gmres_op_apply(nk_gmres *G, const double *d_x, double *d_y, const int *d_
 int nk_gmres_op_powers(nk_gmres *G, const double *d_x, double *d_Y, int64_t ldy, int s, const int *d_skip, const double *d_scale,
                        const double *d_theta, bool *done) {
   *done = false;
-  if (s < 2 || G->op_kind != 1 || G->prec_kind || G->lprec_kind || G->normal || G->shift != 0.0) return NK_OK;
-  if (!nk_csr_powers_ready(G->A)) return NK_OK;
-  NK_TRY(nk_csr_powers_dev(G->A, d_x, d_Y, ldy, s, d_scale, d_scale + 1, d_theta, d_skip));
+  if (s < 2 || G->prec_kind || G->lprec_kind || G->normal || G->shift != 0.0) return NK_OK;
+  if (G->op_kind == 1) {
+    if (!nk_csr_powers_ready(G->A)) return NK_OK;
+    NK_TRY(nk_csr_powers_dev(G->A, d_x, d_Y, ldy, s, d_scale, d_scale + 1, d_theta, d_skip));
+  } else if (G->op_kind == 2 && G->P->kind == NK_PROBLEM_BRATU2D) {   // the matrix-free stencil operator: rows generated
+    if (!nk_problem_powers_ready(G->P)) return NK_OK;
+    NK_TRY(nk_problem_powers_dev(G->P, G->d_u, d_x, d_Y, ldy, s, d_scale, d_scale + 1, d_theta, d_skip));
+  } else {
+    return NK_OK;
+  }
   *done = true;
   return NK_OK;
 }
@@ -1695,6 +1702,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     x_is_zero = false;
     NK_TRY(nk_spin_wait(ctx, [&] { return __atomic_load_n(&pub->end_seq, __ATOMIC_ACQUIRE) == seq; }, "the end of a GMRES cycle"));
     if (G->op_kind == 1 && G->A) NK_TRY(nk_csr_powers_check(G->A));
+    if (G->op_kind == 2 && G->P) NK_TRY(nk_problem_powers_check(G->P));
     if (pub->pad != G->peer_err_seen) {
       // the arena's counter is cumulative and sticky: a time-out fails THIS solve (its reductions / halos are not valid);
       // the next one starts from the value seen here, so one transient stall does not condemn the context for good

@@ -332,7 +332,14 @@ struct nk_problem {
   const double *d_u_linJ = nullptr;
   // staging buffers for host-memspace calls
   double *d_tmp[3] = {nullptr, nullptr, nullptr};
+  // resident matrix-powers kernel for the matrix-free Bratu operator (nk_powers.hip); NULL = not eligible
+  struct nk_powers_plan *pw = nullptr;
+  bool pw_tried = false;
 };
+bool nk_problem_powers_ready(nk_problem *P);
+int nk_problem_powers_dev(nk_problem *P, const double *d_u, const double *d_x0, double *d_Y, int64_t ldy, int s,
+                          const double *d_scal_first, const double *d_scal_rest, const double *d_theta, const int *d_skip);
+int nk_problem_powers_check(nk_problem *P);
 int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, double scale, nk_problem **out);
 int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out);
 int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi);

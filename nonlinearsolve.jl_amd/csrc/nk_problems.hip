@@ -475,6 +475,7 @@ extern "C" int nk_problem_create_user(nk_ctx *ctx, int64_t n_local, int64_t n_gl
 extern "C" int nk_problem_destroy(nk_problem *P) {
   if (!P) return NK_OK;
   hipFree(P->d_diag);
+  nk_powers_plan_destroy(P->pw);
   hipFree(P->d_fd_f0);
   hipFree(P->d_fd_up);
   hipFree(P->d_fd_f1);

@@ -142,3 +142,38 @@ def test_sstep_gmres_with_resident_powers_equals_streaming(nls, dev, monkeypatch
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
     assert outs[0] == outs[1], outs
+
+
+def test_matrix_free_operator_takes_the_resident_kernel_too(nls, dev):
+    """config C3 as BASELINE.json words it (matrix-free JacVecOperator): the stencil Jacobian's rows are GENERATED into the kernel's
+    registers instead of loaded — the s-step solver's iterates against the per-column JVP launches (NK_SPMV_POWERS=0), to rounding
+    (the generated row sums add the five products in CSR order, the stencil kernel factors c_lap out: 1e-13 relative per product)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, nonlinearsolve_jl_amd as nls\n"
+        "ctx = nls.default_context()\n"
+        "prob = nls.NonlinearProblem(nls.Bratu2D(256, 6.0))\n"
+        "alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho='sstep', fixed_iters=30),"
+        " concrete_jac=False)\n"
+        "cache = nls.init(prob, alg, abstol=1e-300, maxiters=50)\n"
+        "ctx.profile_enable(True)\n"
+        "for _ in range(3): cache.step()\n"
+        "rep = ctx.profile_report()\n"
+        "u = cache.u\n"
+        "u = np.asarray(u.cpu() if hasattr(u, 'cpu') else u)\n"
+        "np.save(__import__('sys').argv[1], u)\n"
+        "print('FAMILIES', sorted(rep))\n")
+    outs = []
+    import tempfile
+    for flag in ("1", "0"):
+        with tempfile.NamedTemporaryFile(suffix=".npy") as tf:
+            env = dict(os.environ, NK_SPMV_POWERS=flag)
+            r = subprocess.run([sys.executable, "-c", code, tf.name], env=env, capture_output=True, text=True, timeout=300,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert r.returncode == 0, r.stderr[-2000:]
+            fam = [l for l in r.stdout.splitlines() if l.startswith("FAMILIES")][-1]
+            assert ("spmv_powers" in fam) == (flag == "1") and ("'jvp'" in fam) == (flag == "0"), fam
+            outs.append(np.load(tf.name))
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-10 * np.max(np.abs(outs[1]))
