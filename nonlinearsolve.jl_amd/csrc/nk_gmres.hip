@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
                                                    nk_gmres_pub *pub, uint64_t seq, const uint64_t *peer_err, const nk_ss_fix fx) {
   constexpr int LK = NK_MAX_NV + 1;  // odd stride: the column reads below are conflict-free
   __shared__ double sR[NK_MAX_NV * LK];
-  __shared__ double sC2[NK_MAX_NV * 16], sR2[16 * 16];
+  __shared__ double sC2[NK_SS_NFIX][NK_MAX_NV * 16], sR2[NK_SS_NFIX][16 * 16];
   const int k = ctl->k, failed = ctl->failed;
   const int t = threadIdx.x;
   if (pub != nullptr && t == 0) {  // what the host needs of the control block, then the release of the sequence word
@@ -634,10 +634,10 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
     for (int q = 0; q < 4; ++q)
       if (at[q] >= 0) sR[at[q]] = rv[q];
   }
-  const int fk0 = fx.k0, fsb = (fx.sb > 0 && !failed && k > fx.k0) ? fx.sb : 0;   // (a cycle that ended before the block: nothing of it in y)
-  if (fsb > 0) {
-    for (int e = t; e < fk0 * fsb; e += 256) sC2[e] = fx.C2[e];
-    if (t < fsb * fsb) sR2[t] = fx.R2[t];
+  for (int bq = 0; bq < fx.n; ++bq) {   // (a cycle that ended before a block: nothing of it in y)
+    if (failed || k <= fx.k0[bq]) continue;
+    for (int e = t; e < fx.k0[bq] * fx.sb[bq]; e += 256) sC2[bq][e] = fx.C2[bq][e];
+    if (t < fx.sb[bq] * fx.sb[bq]) sR2[bq][t] = fx.R2[bq][t];
   }
   __syncthreads();
   if (t >= 64) return;
@@ -648,16 +648,20 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
       if (t < i) gv -= sR[t * LK + i] * yi;
       if (t == i) gv = yi;
     }
-    if (fsb > 0) {
+    // the blocks left at their first pass, last first: coefficients on [V_true Q] → on V_true and the block's stored columns
+    for (int bq = fx.n - 1; bq >= 0; --bq) {
+      const int fk0 = fx.k0[bq], fsb = fx.sb[bq];
+      if (k <= fk0) continue;
+      const double *c2 = sC2[bq], *r2 = sR2[bq];
       for (int c = fsb - 1; c >= 0; --c) {             // b = R₂⁻¹ y_Q on lanes k0 … k0 + sb − 1 (y is zero from k on)
-        const double bc = __shfl(gv, fk0 + c, 64) / sR2[c * fsb + c];
-        if (t >= fk0 && t < fk0 + c) gv -= sR2[(t - fk0) * fsb + c] * bc;
+        const double bc = __shfl(gv, fk0 + c, 64) / r2[c * fsb + c];
+        if (t >= fk0 && t < fk0 + c) gv -= r2[(t - fk0) * fsb + c] * bc;
         if (t == fk0 + c) gv = bc;
       }
       double acc = 0.0;
       for (int c = 0; c < fsb; ++c) {
         const double bc = __shfl(gv, fk0 + c, 64);
-        if (t < fk0) acc += sC2[t * fsb + c] * bc;
+        if (t < fk0) acc += c2[t * fsb + c] * bc;
       }
       if (t < fk0) gv -= acc;
     }
@@ -1507,7 +1511,7 @@ static int gmres_solve_graph(nk_gmres *G, const double *d_b, double *d_x, double
       for (int k = 0; k < steps; ++k) NK_TRY(arnoldi_step_1r(G, k, k == steps - 1));
       NK_TRY(arnoldi_flush_1r(G, steps));
       NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
-              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr), nk_ss_fix{0, 0, nullptr, nullptr});
+              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr), nk_ss_fix{});
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, true));
       return NK_OK;
     };
@@ -1690,7 +1694,7 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
     // block's outcome to the host
     NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
               (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr),
-              G->ortho == NK_ORTHO_SSTEP ? nk_ss_take_last_block(G) : nk_ss_fix{0, 0, nullptr, nullptr});
+              G->ortho == NK_ORTHO_SSTEP ? nk_ss_take_last_block(G) : nk_ss_fix{});
     if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
     } else {

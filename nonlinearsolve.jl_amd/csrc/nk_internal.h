@@ -421,6 +421,18 @@ struct nk_gmres_pub {
   int k, converged, failed, pad;
   double rnorm0, rnorm;
 };
+// Blocks of the cycle whose stored columns were left at their FIRST pass (no sweep C): Q = (Q₁ − V_true C₂) R₂⁻¹ is never
+// formed — everything that needs the true basis goes through (C₂, R₂): the back-substitution turns y into coefficients on the
+// stored columns (block by block, last first), the next blocks' Gram products are carried into true coordinates
+constexpr int NK_SS_NFIX = 3;   // (k_backsolve keeps their factors in 64 KB of static LDS next to the Hessenberg factor)
+struct nk_ss_fix {
+  int n;
+  int k0[NK_SS_NFIX], sb[NK_SS_NFIX];
+  const double *C2[NK_SS_NFIX], *R2[NK_SS_NFIX];
+  // the same two factors in the form the NEXT blocks' reductions apply without dependent steps: Wi = R₂⁻¹ (sb × sb, upper) and
+  // D = C₂ R₂⁻¹ (k0 × sb), left by the workgroup that derives the block's Hessenberg columns
+  const double *Wi[NK_SS_NFIX], *D[NK_SS_NFIX];
+};
 struct nk_gmres {
   nk_ctx *ctx = nullptr;
   int64_t n = 0, ldv = 0;
@@ -482,7 +494,7 @@ struct nk_gmres {
   int ss_breakdowns = 0;  // Cholesky breakdowns of a block (the rest of that solve ran with delayed CGS2)
   int ss_s_cap = 0;              // automatic block size only: narrowed (15 → 8 → 4) after a block lost rank; 0 = not narrowed
   int ss_cycle_idx = 0;          // restart cycle of the current solve (0-based)
-  int ss_last_k0 = 0, ss_last_sb = 0;   // the cycle's last block was left at its first pass (no sweep C): k_ss_fix_y adapts y
+  nk_ss_fix ss_fix{};            // blocks of the running cycle left at their first pass (no sweep C): k_backsolve adapts y
   bool ss_grow = false;          // this solve stops on a tolerance: automatic block sizes start small and double (4, 8, 15 …)
   int peer_err_seen = 0;         // the peer arena's cumulative time-out count as of the last cycle this object waited for
   int ss_force_break_cycle = -1; // development hook (nk_gmres_debug_force_breakdown): that cycle's first block "loses rank"
@@ -576,7 +588,6 @@ int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
                                double *h_out, const std::function<int()> &before_wait = nullptr);
 // the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
-struct nk_ss_fix { int k0, sb; const double *C2, *R2; };
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
@@ -584,7 +595,7 @@ void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
 struct ss_tail_args;
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid, const ss_tail_args *tap, int *mark);
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk = 0, int hs = 0);
 int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 int nk_blas_reduce_slots_allreduce(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 

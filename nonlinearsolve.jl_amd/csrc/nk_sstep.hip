@@ -60,16 +60,23 @@ struct ss_tail_args {
   double *Rg, *cs, *sn, *g, *scal;
   nk_gmres_pub *pub;
   uint64_t seq;
+  // implicit second pass: the earlier blocks of this cycle whose stored columns were left at their first pass (their C₂, R₂
+  // carry stored inner products into true coordinates and true coefficients back onto the stored columns), and the block
+  // whose last STORED column started this block's matrix powers (usb = 0: the powers started from a true basis vector)
+  nk_ss_fix fix;
+  int uk0, usb;
+  const double *uC2, *uR2;
+  double *Wi, *D;      // this block's R₂⁻¹ and C₂R₂⁻¹, written next to its Hessenberg columns when it is left at its first pass
 };
 // LDS arrays of the scalar work, carved from one dynamic block
 struct ss_ws {
-  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *Fr, *Fx, *F, *NC, *Hs, *scs, *ssn, *sg;
+  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *Fr, *Fx, *F, *NC, *Hs, *scs, *ssn, *sg, *fC2, *fR2, *uu;
   int *ok;
 };
 constexpr int SS_SS = SS_SMAX * SS_SMAX;
 __host__ __device__ inline size_t ss_ws_doubles(int k, int s, bool hess) {
-  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2 + 2 * SS_SMAX * (SS_SMAX + 1);
-  if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 3 * (size_t)(k + s) + 1;
+  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2 + 2 * SS_SMAX * (SS_SMAX + 1) + (size_t)k * SS_SMAX + SS_SS;
+  if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 4 * (size_t)(k + s) + 1;
   return d;
 }
 __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
@@ -84,14 +91,17 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
   w.Fr = b; b += SS_SMAX * (SS_SMAX + 1);
   w.Fx = b; b += SS_SMAX * (SS_SMAX + 1);
   w.ok = reinterpret_cast<int *>(b); b += 2;
-  w.F = w.NC = w.Hs = w.scs = w.ssn = w.sg = nullptr;
+  w.fC2 = b; b += k * SS_SMAX;
+  w.fR2 = b; b += SS_SS;
+  w.F = w.NC = w.Hs = w.scs = w.ssn = w.sg = w.uu = nullptr;
   if (hess) {
     w.F = b; b += (k + s) * s;
     w.NC = b; b += (k + s) * s;
     w.Hs = b; b += k * (k > 1 ? k - 1 : 1);
     w.scs = b; b += k + s;
     w.ssn = b; b += k + s;
-    w.sg = b;
+    w.sg = b; b += k + s + 1;
+    w.uu = b;
   }
   return w;
 }
@@ -115,17 +125,103 @@ __device__ __forceinline__ double ss_rcp(double d) {   // 1/d to the last bit or
   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   return r;
 }
-__device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w) {
+// Implicit second pass. A block (k0, sp) whose stored columns S_b were left at their first pass relates to the true basis by
+// S_b = V_true[:k0] C₂ + Q_b R₂. With Wi = R₂⁻¹ and D = C₂ Wi (left in global memory by the workgroup that derived the block's
+// Hessenberg columns: ss_fix_prepare) both directions are plain products — no dependent steps in the reductions' critical path:
+//   stored inner products → true:   Q_bᵀX = Wiᵀ (S_bᵀX) − Dᵀ (V_true[:k0]ᵀX)       (rows above the block already true: blocks in order)
+//   true coefficients → stored:     W[:k0] −= D W_b ;  W_b ← Wi W_b                 (blocks last first)
+// P / Wm: k × sb, row-major, rows = basis columns. tmp: sp × sb scratch.
+__device__ void ss_fix_to_true(int sb, int k0, int sp, const double *__restrict__ Dg, const double *__restrict__ Wig, double *P,
+                               double *sD, double *sWi, bool load) {
+  const int t = threadIdx.x;
+  if (load) {   // (a global round trip: skipped when the block's factors are in LDS already)
+    for (int e = t; e < k0 * sp; e += blockDim.x) sD[e] = Dg[e];
+    if (t < sp * sp) sWi[t] = Wig[t];
+    __syncthreads();
+  }
+  const int a = t / sb, c = t % sb;
+  const bool own = t < sp * sb;
+  double val = 0.0;
+  if (own) {
+    for (int p = 0; p <= a; ++p) val = __builtin_fma(sWi[p * sp + a], P[(k0 + p) * sb + c], val);     // (Wiᵀ P_b)[a][c]
+    for (int i = 0; i < k0; ++i) val = __builtin_fma(-sD[i * sp + a], P[i * sb + c], val);
+  }
+  __syncthreads();
+  if (own) P[(k0 + a) * sb + c] = val;
+  __syncthreads();
+}
+__device__ void ss_fix_to_stored(int sb, int k0, int sp, const double *__restrict__ Dg, const double *__restrict__ Wig, double *Wm,
+                                 double *sD, double *sWi, bool load) {
+  const int t = threadIdx.x;
+  if (load) {
+    for (int e = t; e < k0 * sp; e += blockDim.x) sD[e] = Dg[e];
+    if (t < sp * sp) sWi[t] = Wig[t];
+    __syncthreads();
+  }
+  for (int e = t; e < k0 * sb; e += blockDim.x) {      // W[:k0] −= D W_b (the OLD W_b)
+    const int i = e / sb, cc = e % sb;
+    double v = Wm[e];
+    for (int q = 0; q < sp; ++q) v = __builtin_fma(-sD[i * sp + q], Wm[(k0 + q) * sb + cc], v);
+    Wm[e] = v;
+  }
+  const int a = t / sb, c = t % sb;
+  const bool own = t < sp * sb;
+  double val = 0.0;
+  if (own)
+    for (int p = a; p < sp; ++p) val = __builtin_fma(sWi[a * sp + p], Wm[(k0 + p) * sb + c], val);    // (Wi W_b)[a][c]
+  __syncthreads();
+  if (own) Wm[(k0 + a) * sb + c] = val;
+  __syncthreads();
+}
+// Wi = R₂⁻¹ and D = C₂ Wi of a block left at its first pass (k0 rows above it, sp columns), from its pass-2 factors in LDS
+// (Ct: C₂, k0 × sp; Rm: R₂, sp × sp upper) into global memory. Column j of Wi by back substitution, one lane per column.
+__device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *Rm, double *scratch /* sp × sp */, double *Wig,
+                               double *Dg) {
+  const int t = threadIdx.x;
+  if (t < sp) {
+    const int j = t;
+    for (int a = sp - 1; a >= 0; --a) {
+      double v = (a == j) ? 1.0 : 0.0;
+      if (a <= j) {
+        for (int p = a + 1; p <= j; ++p) v = __builtin_fma(-Rm[a * sp + p], scratch[p * sp + j], v);
+        v /= Rm[a * sp + a];
+      } else {
+        v = 0.0;
+      }
+      scratch[a * sp + j] = v;
+    }
+  }
+  __syncthreads();
+  if (t < sp * sp) Wig[t] = scratch[t];
+  for (int e = t; e < k0 * sp; e += blockDim.x) {
+    const int i = e / sp, a = e % sp;
+    double v = 0.0;
+    for (int p = 0; p <= a; ++p) v = __builtin_fma(Ct[i * sp + p], scratch[p * sp + a], v);
+    Dg[e] = v;
+  }
+  __syncthreads();
+}
+__device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w,
+                          const nk_ss_fix &fix) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
   double *F = w.Fr;   // 16 × 17 frame: the factor in progress
   for (int e = t; e < k * sb; e += blockDim.x) {
     const double scj = sc[e / sb], c = scj * red[e];
     Ct[e] = c;
-    w.U[e] = scj * c;
+    if (fix.n == 0) w.U[e] = scj * c;
   }
   if (t == 0) *w.ok = 1;
   __syncthreads();
+  if (fix.n > 0) {   // (uniform) stored → true coordinates for the factorisation; true → stored coefficients for the update
+    for (int bq = 0; bq < fix.n; ++bq) ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], Ct, w.fC2, w.fR2, true);
+    for (int e = t; e < k * sb; e += blockDim.x) w.U[e] = Ct[e];
+    __syncthreads();
+    for (int bq = fix.n - 1; bq >= 0; --bq)   // (the last block carried to true coordinates is still in LDS)
+      ss_fix_to_stored(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], w.U, w.fC2, w.fR2, bq != fix.n - 1);
+    for (int e = t; e < k * sb; e += blockDim.x) w.U[e] *= sc[e / sb];
+    __syncthreads();
+  }
   SS_STAMP(5);
   if (t < sb * sb) {
     const int a = t / sb, b = t % sb;
@@ -223,7 +319,21 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
     F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
   }
   __syncthreads();
-  if (t < K) NC[t] = sigma * F[t * sb] + (t == k - 1 ? th[0] : 0.0);
+  // A·(the column the powers started from) = σ X_0 + θ_0·(that column). It is the true basis vector v_k (u = e_k) — or, after a
+  // block left at its first pass, that block's last STORED column = V_true u, u = [C₂ ; R₂][:, last]: then
+  // A v_k = (σ F_0 + θ_0 u − Σ_{i<k} u_i A v_i) / u_k, with A v_i the old Hessenberg columns.
+  if (t < k) w.uu[t] = ta.usb > 0 ? (t < ta.uk0 ? ta.uC2[t * ta.usb + ta.usb - 1] : ta.uR2[(t - ta.uk0) * ta.usb + ta.usb - 1])
+                                  : (t == k - 1 ? 1.0 : 0.0);
+  __syncthreads();
+  if (t < K) {
+    double a = sigma * F[t * sb];
+    if (t < k) {
+      a = __builtin_fma(th[0], w.uu[t], a);
+      if (ta.usb > 0)
+        for (int tt = (t > 0 ? t - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[t * ko + tt], w.uu[tt], a);
+    }
+    NC[t] = ta.usb > 0 ? a / w.uu[k - 1] : a;
+  }
   __syncthreads();
   SS_STAMP(10);
   // Coordinates of A q_j, j = 1..sb−1: NC_j = (σF_j + θ_j F_{j−1} − H_old F_{j−1}[:k] − Σ_{q<j} NC_q · Fb(q, j−1)) / R_{j−1,j−1}
@@ -344,7 +454,7 @@ __global__ __launch_bounds__(256) void k_ss_tail1(int k, int sb, double *__restr
   extern __shared__ double s_tail[];
   if (ta.ctl->done) return;
   const ss_ws w = ss_ws_carve(s_tail, k, sb, false);
-  if (!ss_factor(k, sb, ta.red, ta.sc, w)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
@@ -354,7 +464,7 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
   extern __shared__ double s_tail[];
   if (ta.ctl->pad1) return;  // (pad1: the cycle was done when this block started, or its first pass failed)
   const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
-  if (!ss_factor(k, sb, ta.red, ta.sc, w)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) { coef[e] = w.U[e]; ta.C2[e] = w.Ct[e]; }
   if (t < sb * sb) { coef[(size_t)k * sb + t] = w.Ri[t]; ta.R2[t] = w.Rm[t]; }
@@ -362,15 +472,20 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
   ss_hessenberg(k, sb, w, ta);
 }
 // the Hessenberg columns of a block as a launch of its own: the LAST block of a cycle, whose third sweep is never run (below)
+// (shared by k_ss_hess and the sweeps that host this work in their workgroup 0)
+__device__ void ss_hess_block(int k, int sb, double *lds, const ss_tail_args &ta) {
+  const ss_ws w = ss_ws_carve(lds, k, sb, true);
+  const int t = threadIdx.x;
+  for (int e = t; e < k * sb; e += blockDim.x) w.Ct[e] = ta.C2[e];      // pass 2's factors, left by the reduction's last workgroup
+  if (t < sb * sb) w.Rm[t] = ta.R2[t];
+  __syncthreads();
+  if (ta.Wi != nullptr) ss_fix_prepare(k, sb, w.Ct, w.Rm, w.Sm, ta.Wi, ta.D);   // (Sm is free: ss_factor is not run here)
+  ss_hessenberg(k, sb, w, ta);
+}
 __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta) {
   extern __shared__ double s_tail[];
   if (ta.ctl->pad1) return;
-  const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
-  const int t = threadIdx.x;
-  for (int e = t; e < k * sb; e += 256) w.Ct[e] = ta.C2[e];
-  if (t < sb * sb) w.Rm[t] = ta.R2[t];
-  __syncthreads();
-  ss_hessenberg(k, sb, w, ta);
+  ss_hess_block(k, sb, s_tail, ta);
 }
 // The last block of a cycle never gets its second update (sweep C): its columns Q = (Q₁ − V_k C₂) R₂⁻¹ are used once more only —
 // in x += [V_k Q] y —, and that product can be taken from the columns as pass 1 left them:
@@ -394,7 +509,7 @@ __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta)
 template <int S, bool UPDATE, bool GRAM, int MTC, bool FUSE>
 __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__restrict__ V, int64_t ldv,
                                                    const double *__restrict__ coef, double *__restrict__ partials,
-                                                   const int *d_skip, int ntiles, ss_tail_args ta, int *mark, int ws_off) {
+                                                   const int *d_skip, int ntiles, ss_tail_args ta, int *mark, int ws_off, int hk, int hs) {
   {
     const int dskip = (d_skip != nullptr) ? *d_skip : 0;
     if (mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *mark = dskip;
@@ -441,7 +556,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
   // a workgroup walks CONTIGUOUS tiles: each of its k + S column streams then advances through adjacent 2 KB pieces
   // (sweep C with the Hessenberg duty: workgroup 0 streams nothing — its scalar work, ≈ 20 µs of dependent chains, then
   // hides behind the others' share instead of extending the launch)
-  const bool hw = FUSE && !GRAM && gridDim.x > 1;
+  const bool hw = FUSE && gridDim.x > 1;
   const int nwk = (int)gridDim.x - (hw ? 1 : 0), me = (int)blockIdx.x - (hw ? 1 : 0);
   const int tpw = (ntiles + nwk - 1) / nwk;
   const int tile0 = me >= 0 ? me * tpw : 0, tile1 = me >= 0 ? min(tile0 + tpw, ntiles) : 0;
@@ -555,12 +670,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
       }
     }
   }
-  if (FUSE && !GRAM && blockIdx.x == 0) {  // workgroup 0, its share of the sweep issued: the block's Hessenberg columns
-    const ss_ws ws = ss_ws_carve(sX + ws_off, k, S, true);
-    for (int e = t; e < k * S; e += SS_R) ws.Ct[e] = ta.C2[e];      // pass 2's factors, left by the reduction's last workgroup
-    if (t < S * S) ws.Rm[t] = ta.R2[t];
-    __syncthreads();
-    ss_hessenberg(k, S, ws, ta);
+  // workgroup 0, its share of the sweep issued (none when there are others): the Hessenberg columns of the block (hk, hs) —
+  // sweep C: this block's; sweep A: those of the PREVIOUS block, which was left at its first pass (implicit second pass)
+  if (FUSE && blockIdx.x == 0) {
+    if (GRAM) __syncthreads();
+    ss_hess_block(hk, hs, sX + ws_off, ta);
   }
 }
 
@@ -598,16 +712,22 @@ int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
 
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
-                       const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out = nullptr) {
+                       const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out = nullptr, int hk = 0,
+                       int hs = 0) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
   const int cls = ss_class(k, S);
-  // "fused" now names ONE thing: sweep C whose workgroup 0 derives the block's Hessenberg columns while the others stream
-  // (its LDS: the scalar workspace). The update coefficients always arrive through scalar loads from `coef`, where the
-  // reduction's last workgroup (k_ss_reduce_factor) or the tail kernels left them.
-  const bool fuse = tap != nullptr && mode == 2 && cls != 0;
+  // "fused": a sweep whose workgroup 0 derives a block's Hessenberg columns while the others stream (its LDS: the scalar
+  // workspace) — sweep C for its own block (hk = k, hs = S), sweep A for the PREVIOUS block when that was left at its first
+  // pass (hk, hs: that block). The update coefficients always arrive through scalar loads from `coef`, where the reduction's
+  // last workgroup (k_ss_reduce_factor) or the tail kernels left them.
+  const bool fuse = tap != nullptr && (mode == 2 || mode == 0) && cls != 0;
+  if (mode == 2) { hk = k; hs = S; }
   const size_t tile = ss_tile_doubles(k, S, mode != 2, cls ? cls : SS_MTMAX);
-  const size_t lds = (tile + (fuse ? ss_ws_doubles(k, S, true) : 0)) * sizeof(double);
-  const int ws_off = (int)tile;
+  // (the hosting workgroup streams no tiles — or, alone in the grid, is done with its tile when the scalar work starts: the
+  //  workspace OVERLAYS the tile, so hosting costs the sweep no occupancy)
+  const size_t wsd = fuse ? ss_ws_doubles(hk, hs, true) : 0;
+  const size_t lds = (tile > wsd ? tile : wsd) * sizeof(double);
+  const int ws_off = 0;
   ss_tail_args ta;
   std::memset(&ta, 0, sizeof(ta));
   if (tap) ta = *tap;
@@ -621,15 +741,15 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
     if (occ_out) {                                                                                                        \
       NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block<S, UPD, GRM, KM, FS>, SS_R, lds));          \
     } else if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
-                                  k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off);                           \
+                                  k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off, hk, hs);                   \
     else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef, \
-                            partials, d_skip, ntiles, ta, mark, ws_off);                                                  \
+                            partials, d_skip, ntiles, ta, mark, ws_off, hk, hs);                                          \
   } while (0)
 #define SS_GO(UPD, GRM)                                                                                                   \
   do {                                                                                                                    \
-    if (cls == 1) { if (fuse) SS_GO3(UPD, GRM, 1, (UPD && !GRM)); else SS_GO3(UPD, GRM, 1, false); }                      \
-    else if (cls == 2) { if (fuse) SS_GO3(UPD, GRM, 2, (UPD && !GRM)); else SS_GO3(UPD, GRM, 2, false); }                 \
-    else if (cls == 3) { if (fuse) SS_GO3(UPD, GRM, 3, (UPD && !GRM)); else SS_GO3(UPD, GRM, 3, false); }                 \
+    if (cls == 1) { if (fuse) SS_GO3(UPD, GRM, 1, (UPD != GRM)); else SS_GO3(UPD, GRM, 1, false); }                       \
+    else if (cls == 2) { if (fuse) SS_GO3(UPD, GRM, 2, (UPD != GRM)); else SS_GO3(UPD, GRM, 2, false); }                  \
+    else if (cls == 3) { if (fuse) SS_GO3(UPD, GRM, 3, (UPD != GRM)); else SS_GO3(UPD, GRM, 3, false); }                  \
     else SS_GO3(UPD, GRM, 0, false);                                                                                      \
   } while (0)
   int g = grid;
@@ -652,28 +772,28 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
 }
 // mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
 static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                             const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out) {
+                             const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out, int hk = 0, int hs = 0) {
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
   switch (s) {
-    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
-    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out);
+    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
     default: NK_FAIL(NK_E_INVALID, "internal: no s-step sweep for a block of %d columns", s);
   }
 }
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid, const ss_tail_args *tap, int *mark) {
-  return ss_sweep_dispatch(ctx, mode, n, k, s, V, ldv, coef, partials, d_skip, grid, tap, mark, nullptr);
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk, int hs) {
+  return ss_sweep_dispatch(ctx, mode, n, k, s, V, ldv, coef, partials, d_skip, grid, tap, mark, nullptr, hk, hs);
 }
 // workgroups of sweep `mode` for a block of s columns behind k that a CU holds at once (cached per shape)
 int nk_ss_sweep_occupancy(nk_ctx *ctx, int mode, int k, int s) {
@@ -736,8 +856,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
       for (int j = 0; j < 8; ++j) v += (base + lane + 64 * j < nblk) ? x[j] : 0.0;
     }
   }
-  if (skip && !PEER) return;   // (the flag was requested together with the partials: one round trip; a collective runs on
-                               //  every rank even when the cycle is done)
+  // (the flag was requested together with the partials: one round trip; a collective runs on every rank even when the cycle
+  //  is done.) The cycle may have ended INSIDE the sweep in front of this launch — a sweep A that hosts the previous block's
+  //  Hessenberg columns and stopping test —: the sweeps and Hessenberg launches behind a skipped reduction look at pad1.
+  if (skip && slot == 0 && t == 0) ta.ctl->pad1 = 1;
+  if (skip && !PEER) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (lane == 0 && entry < nslots) {
@@ -795,7 +918,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
   __syncthreads();
   SS_STAMP(2);
   ta.red = s_rf;
-  if (!ss_factor(k, sb, s_rf, ta.sc, w)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, s_rf, ta.sc, w, ta.fix)) { ss_fail(ta); return; }
   SS_STAMP(3);
   for (int e = t; e < k * sb; e += SS_R) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
@@ -804,6 +927,9 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
   } else {
     for (int e = t; e < k * sb; e += SS_R) ta.C2[e] = w.Ct[e];
     if (t < sb * sb) ta.R2[t] = w.Rm[t];
+    // the next block's matrix powers start from a column of unit scale (ss_hessenberg says the same — but where this block is
+    // left at its first pass its Hessenberg columns are derived AFTER the next block's powers were launched)
+    if (t == 0) ta.scal[0] = 1.0 / ta.scal[2];
   }
   SS_STAMP(4);
 }
@@ -1020,7 +1146,10 @@ extern "C" int nk_ss_leja_nodes(int s, double *out) {
 struct nk_sstep {
   int s = 0, grid = 0;
   double *part = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
-  double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup)
+  double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup), one slot per block
+  double *Wi = nullptr, *D = nullptr;        // R₂⁻¹ and C₂R₂⁻¹ of the blocks left at their first pass (same slots)
+  size_t c2_stride = 0;
+  int nblk_slots = 0;
   unsigned int *ticket = nullptr;            // last-workgroup ticket of k_ss_reduce_factor
   double *ival = nullptr, *nodes = nullptr;  // {−lo, hi} of the spectrum; Leja-ordered Chebyshev points for nodes_s columns
   const double *ival_use = nullptr;          // where this solve's bounds are: `ival`, or the matrix's cache (left by its fill kernel)
@@ -1032,7 +1161,7 @@ struct nk_sstep {
 void nk_ss_destroy(nk_sstep *W) {
   if (!W) return;
   hipFree(W->part); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
-  hipFree(W->ival); hipFree(W->nodes); hipFree(W->C2); hipFree(W->R2); hipFree(W->ticket);
+  hipFree(W->ival); hipFree(W->nodes); hipFree(W->C2); hipFree(W->R2); hipFree(W->ticket); hipFree(W->Wi); hipFree(W->D);
   delete W;
 }
 static int ss_workspace(nk_gmres *G) {
@@ -1047,8 +1176,13 @@ static int ss_workspace(nk_gmres *G) {
   NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
   NK_TRY(nk_dev_alloc(&W->C1, nslots + 1));
   NK_TRY(nk_dev_alloc(&W->R1, (size_t)SS_SS));
-  NK_TRY(nk_dev_alloc(&W->C2, nslots + 1));
-  NK_TRY(nk_dev_alloc(&W->R2, (size_t)SS_SS));
+  // pass 2's factors, one slot per block of a cycle: blocks left at their first pass need theirs until the back-substitution
+  W->c2_stride = nslots + 1;
+  W->nblk_slots = m + 2;
+  NK_TRY(nk_dev_alloc(&W->C2, W->c2_stride * W->nblk_slots));
+  NK_TRY(nk_dev_alloc(&W->R2, (size_t)SS_SS * W->nblk_slots));
+  NK_TRY(nk_dev_alloc(&W->Wi, (size_t)SS_SS * W->nblk_slots));
+  NK_TRY(nk_dev_alloc(&W->D, W->c2_stride * W->nblk_slots));
   NK_TRY(nk_dev_alloc(&W->ticket, (size_t)2));
   NK_HIP(hipMemset(W->ticket, 0, 2 * sizeof(unsigned int)));
   NK_TRY(nk_dev_alloc(&W->H, (size_t)(m + 2 + SS_SMAX) * m));
@@ -1108,6 +1242,13 @@ extern "C" int nk_gmres_get_sstep_state(nk_gmres *G, int *block_size, int *newto
   return NK_OK;
 }
 
+// Implicit second pass (A/B switch NK_SS_IMPLICIT=0): a block that is not the cycle's last is left at its first pass as well —
+// no sweep C; the next blocks carry their Gram products through its (C₂, R₂) (ss_fix_to_true / _to_stored), its Hessenberg
+// columns are a launch of their own, the back-substitution adapts y block by block. One sweep over k + 2s columns less per block.
+static bool ss_implicit_on() {
+  static const bool off = getenv("NK_SS_IMPLICIT") && atoi(getenv("NK_SS_IMPLICIT")) == 0;
+  return !off;
+}
 static bool ss_skip_last_sweep() {
   static const bool off = getenv("NK_SS_LAST_SWEEP") && atoi(getenv("NK_SS_LAST_SWEEP")) != 0;   // A/B switch: run it anyway
   return !off;
@@ -1115,14 +1256,8 @@ static bool ss_skip_last_sweep() {
 // for the back-substitution of a cycle whose last block was left at its first pass: what turns y into coefficients on the
 // stored columns (k_backsolve, nk_gmres.hip)
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G) {
-  nk_ss_fix fx{0, 0, nullptr, nullptr};
-  if (G->ss_last_sb > 0 && G->ss) {
-    fx.k0 = G->ss_last_k0;
-    fx.sb = G->ss_last_sb;
-    fx.C2 = G->ss->C2;
-    fx.R2 = G->ss->R2;
-  }
-  G->ss_last_sb = 0;
+  nk_ss_fix fx = G->ss_fix;
+  G->ss_fix = nk_ss_fix{};
   return fx;
 }
 
@@ -1153,6 +1288,19 @@ int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int firs
   return NK_OK;
 }
 
+static int ss_launch_hess(nk_ctx *ctx, int k, int sb, const ss_tail_args &ta) {
+  const size_t lds = ss_ws_doubles(k, sb, true) * sizeof(double);
+  if (lds > 64 * 1024)
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_hess), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (k + sb) * sb);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
+    hipExtLaunchKernelGGL(k_ss_hess, dim3(1), dim3(256), lds, ctx->stream, e0, e1, 0, k, sb, ta);
+  else
+    hipLaunchKernelGGL(k_ss_hess, dim3(1), dim3(256), lds, ctx->stream, k, sb, ta);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
 // Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of ≤ s (cut to the widths the sweeps are compiled for;
 // the last block may be shorter). k_gmres_begin has run. `wait_progress(need)` (may be empty) blocks the host until `need`
 // columns are closed or the cycle is done and returns false when no further block should be enqueued.
@@ -1164,11 +1312,17 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   const int s = nk_ss_block_size(G);
   const int *done = &G->d_ctl->done, *skipC = &G->d_ctl->pad1;
   ss_tail_args ta;
+  std::memset(&ta, 0, sizeof(ta));
   ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.C2 = W->C2; ta.R2 = W->R2; ta.H = W->H; ta.m = G->m;
   ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
+  G->ss_fix = nk_ss_fix{};
+  int blk = 0;            // index of the block within the cycle = its slot of pass-2 factors
+  int prev_k0 = 0, prev_sb2 = 0;  // the previous block if it was left at its first pass (prev_sb2 = 0: it was not)
+  ss_tail_args pend_ta;           // … and, while its Hessenberg columns wait for a sweep A to host them, its arguments
+  std::memset(&pend_ta, 0, sizeof(pend_ta));
+  int pend_k = 0, pend_sb = 0;
   if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
-  G->ss_last_sb = 0;
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
   int prev_sb = s;
   // A solve that stops on a tolerance may need 2 iterations or 200: a block's operator applications past the column that meets
@@ -1201,11 +1355,26 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     // rank, or several on peer-mapped arenas (the reduction is then the all-reduce as well). Other transports and the
     // streaming size class (k + s > 48): reduction, all-reduce and the scalar work as launches of their own.
     bool fused = nk_ss_fusable(k, sb);
+    if (pend_sb > 0 && !fused) {   // nobody to host it: the previous block's Hessenberg columns as a launch of their own
+      NK_TRY(ss_launch_hess(ctx, pend_k, pend_sb, pend_ta));
+      pend_sb = 0;
+    }
+    // this block's slot of pass-2 factors; the blocks before it that were left at their first pass; the start vector's origin
+    NK_REQUIRE(blk < W->nblk_slots, "internal: more s-step blocks in a cycle than factor slots");
+    ta.C2 = W->C2 + (size_t)blk * W->c2_stride;
+    ta.R2 = W->R2 + (size_t)blk * SS_SS;
+    ta.fix = G->ss_fix;
+    ta.usb = prev_sb2; ta.uk0 = prev_k0;
+    ta.uC2 = prev_sb2 ? W->C2 + (size_t)(blk - 1) * W->c2_stride : nullptr;
+    ta.uR2 = prev_sb2 ? W->R2 + (size_t)(blk - 1) * SS_SS : nullptr;
+    ta.Wi = nullptr; ta.D = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb + (pass ? sb : 0)));
-        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid, nullptr,
-                           pass == 0 ? &G->d_ctl->pad1 : nullptr));
+        const bool host_prev = pass == 0 && pend_sb > 0 && fused;   // sweep A hosts the previous block's Hessenberg columns
+        NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid, host_prev ? &pend_ta : nullptr,
+                           pass == 0 ? &G->d_ctl->pad1 : nullptr, pend_k, pend_sb));
+        if (host_prev) pend_sb = 0;
       }
       nk_peer_ar_view pv{nullptr, 0, 0, 0, nullptr};
       if (fused && !nk_ctx_is_single(ctx)) {
@@ -1246,28 +1415,37 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       }
     }
     const bool last_block = (k - 1 + sb >= steps) && ss_skip_last_sweep();
-    if (!last_block) {
+    // left at its first pass: the cycle's last block always; any other block of the fused size classes while the list has room
+    const bool implicit = !last_block && fused && ss_implicit_on() && G->ss_fix.n < NK_SS_NFIX - 1;
+    if (!last_block && !implicit) {
       nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 2 * sb));
       NK_TRY(nk_ss_sweep(ctx, 2, n, k, sb, G->V, ldv, W->coef, W->part, skipC, grid, fused ? &ta : nullptr, nullptr));
     } else {
-      // the cycle's last block: no third sweep (k_ss_fix_y turns y into coefficients on the columns as they are); its Hessenberg
-      // columns — the work of sweep C's workgroup 0, or already done by k_ss_tail2 on the unfused path — as a launch of their own
-      if (fused) {
-        const size_t lds = ss_ws_doubles(k, sb, true) * sizeof(double);
-        if (lds > 64 * 1024)
-          NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_hess), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * (k + sb) * sb);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
-          hipExtLaunchKernelGGL(k_ss_hess, dim3(1), dim3(256), lds, ctx->stream, e0, e1, 0, k, sb, ta);
-        else
-          hipLaunchKernelGGL(k_ss_hess, dim3(1), dim3(256), lds, ctx->stream, k, sb, ta);
+      // left at its first pass: no third sweep (k_backsolve turns y into coefficients on the columns as they are; later blocks
+      // carry their Gram products through this block's factors). Its Hessenberg columns — the work of sweep C's workgroup 0,
+      // or already done by k_ss_tail2 on the unfused path —: the cycle's last block as a launch of its own, any other block
+      // inside the NEXT block's sweep A (which also leaves Wi, D for the reductions behind it).
+      if (implicit) {
+        ta.Wi = W->Wi + (size_t)blk * SS_SS;
+        ta.D = W->D + (size_t)blk * W->c2_stride;
+        pend_ta = ta; pend_k = k; pend_sb = sb;
+      } else if (fused) {
+        NK_TRY(ss_launch_hess(ctx, k, sb, ta));
       }
-      G->ss_last_k0 = k;
-      G->ss_last_sb = sb;
+      {
+        nk_ss_fix &fx = G->ss_fix;
+        NK_REQUIRE(fx.n < NK_SS_NFIX, "internal: too many s-step blocks left at their first pass");
+        fx.k0[fx.n] = k; fx.sb[fx.n] = sb; fx.C2[fx.n] = ta.C2; fx.R2[fx.n] = ta.R2;
+        fx.Wi[fx.n] = implicit ? ta.Wi : nullptr; fx.D[fx.n] = implicit ? ta.D : nullptr;
+        fx.n++;
+      }
     }
     NK_HIP(hipGetLastError());
+    prev_k0 = k;
+    prev_sb2 = (last_block || implicit) ? sb : 0;
     k += sb;
+    ++blk;
   }
+  if (pend_sb > 0) NK_TRY(ss_launch_hess(ctx, pend_k, pend_sb, pend_ta));   // (the host stopped enqueueing blocks early)
   return NK_OK;
 }

@@ -29,25 +29,27 @@ def _timeline_kernels(path):
 def test_model_lists_exactly_the_launches_of_the_committed_timeline(path):
     ks = _timeline_kernels(path)
     assert ks, path
-    resident = "k_spmv_powers" in ks
-    model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15, resident_powers=resident)]
+    resident, implicit = "k_spmv_powers" in ks, "k_ss_block<C>" not in ks
+    model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15, resident_powers=resident, implicit=implicit)]
     assert ks == model, f"{os.path.basename(path)}: the step launches\n{ks}\nthe model charges for\n{model}"
 
 
 def test_byte_counts_of_the_headline_step():
     spmv = 12 * NNZ + 4 * (N + 1) + 16 * N
     assert spmv == 83_836_932     # SURVEY.md §8(d) / VERDICT r03: the figure every SpMV GB/s is computed from
-    hbm_s, alg_s = step_model.step_bytes(N, NNZ, resident_powers=False)
+    hbm_s, alg_s = step_model.step_bytes(N, NNZ, resident_powers=False, implicit=False)
     assert hbm_s == alg_s
     # 30 SpMVs + sweeps A1 B1 C1 A2 B2 (16, 31, 31, 31, 46 columns of 8 n bytes) + fill, b → v0, x = V y, update, residual, norm
     sweeps = 8 * N * (16 + 31 + 31 + 31 + 46)
     once = (8 * NNZ + 8 * N) + 16 * N + 8 * N * 32 + 24 * N + 16 * N + 8 * N
     assert hbm_s == 30 * spmv + sweeps + once
     assert abs(hbm_s - 4.21e9) < 0.02e9          # the judge's own count of the launched work
-    hbm_r, alg_r = step_model.step_bytes(N, NNZ, resident_powers=True)
+    hbm_r, alg_r = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=False)
     assert alg_r == alg_s                        # the algorithmic figure does not depend on how the operator is executed
     per_block = 12 * NNZ + 4 * (N + 1) + 8 * N + 8 * N * 15
     assert hbm_r == hbm_s - 30 * spmv + 2 * per_block
+    hbm_i, alg_i = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True)     # no sweep C for the first block either
+    assert hbm_i == hbm_r - 8 * N * 31 and alg_i == alg_r - 8 * N * 31
 
 
 def test_canonical_names():

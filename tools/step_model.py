@@ -29,7 +29,7 @@ def spmv_bytes(n, nnz):
     return 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
 
 
-def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True):
+def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True):
     """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order"""
     m = arnoldi
     L = []
@@ -44,9 +44,9 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
     b_op = 24.0 * n if matfree else spmv_bytes(n, nnz)
     blocks = sstep_blocks(m, s)
     for bi, (k, w) in enumerate(blocks):
-        if resident_powers and not matfree and w >= 2:
-            # the matrix once, the start column once, w new columns written
-            add("k_spmv_powers", 12.0 * nnz + 4.0 * (n + 1) + 8.0 * n + 8.0 * n * w, w * b_op)
+        if resident_powers and w >= 2:
+            # the matrix once (matrix-free: the diagonal d = c·exp(u) once), the start column once, w new columns written
+            add("k_spmv_powers", (8.0 * n if matfree else 12.0 * nnz + 4.0 * (n + 1)) + 8.0 * n + 8.0 * n * w, w * b_op)
         else:
             for _ in range(w):
                 add("k_bratu_jvp" if matfree else "k_spmv_stream", b_op)
@@ -54,10 +54,10 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
         add("k_ss_reduce_factor", 0)
         add("k_ss_block<B>", 8.0 * n * (k + 2 * w))             # update (k + w read, w written) + Gram of the result
         add("k_ss_reduce_factor", 0)
-        if bi + 1 < len(blocks):
-            add("k_ss_block<C>", 8.0 * n * (k + 2 * w))         # second update
+        if bi + 1 < len(blocks) and not implicit:
+            add("k_ss_block<C>", 8.0 * n * (k + 2 * w))         # second update (NK_SS_IMPLICIT=0)
         else:
-            add("k_ss_hess", 0)                                 # the cycle's last block is left at its first pass
+            add("k_ss_hess", 0)                                 # the block is left at its first pass: no third sweep
     add("k_backsolve", 0)
     add("k_multiaxpy", 8.0 * n * (m + 2))                       # x = V y: m + 1 columns read, x written
     add("k_newton_update", 24.0 * n)
