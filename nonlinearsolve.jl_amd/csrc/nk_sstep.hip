@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
   for (int e = t; e < k * sb; e += 256) { coef[e] = w.U[e]; ta.C2[e] = w.Ct[e]; }
   if (t < sb * sb) { coef[(size_t)k * sb + t] = w.Ri[t]; ta.R2[t] = w.Rm[t]; }
   __syncthreads();
+  if (ta.Wi != nullptr) ss_fix_prepare(k, sb, w.Ct, w.Rm, w.Sm, ta.Wi, ta.D);   // the block is left at its first pass
   ss_hessenberg(k, sb, w, ta);
 }
 // the Hessenberg columns of a block as a launch of its own: the LAST block of a cycle, whose third sweep is never run (below)
@@ -1367,7 +1368,12 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     ta.usb = prev_sb2; ta.uk0 = prev_k0;
     ta.uC2 = prev_sb2 ? W->C2 + (size_t)(blk - 1) * W->c2_stride : nullptr;
     ta.uR2 = prev_sb2 ? W->R2 + (size_t)(blk - 1) * SS_SS : nullptr;
-    ta.Wi = nullptr; ta.D = nullptr;
+    // left at its first pass (no sweep C): the cycle's last block always; any other block while the list has room — whatever
+    // the transport and the size class, so that every path runs the same arithmetic (results are compared bit for bit)
+    const bool last_block = (k - 1 + sb >= steps) && ss_skip_last_sweep();
+    const bool implicit = !last_block && ss_implicit_on() && G->ss_fix.n < NK_SS_NFIX - 1;
+    ta.Wi = implicit ? W->Wi + (size_t)blk * SS_SS : nullptr;
+    ta.D = implicit ? W->D + (size_t)blk * W->c2_stride : nullptr;
     for (int pass = 0; pass < 2; ++pass) {
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb + (pass ? sb : 0)));
@@ -1414,9 +1420,6 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         }
       }
     }
-    const bool last_block = (k - 1 + sb >= steps) && ss_skip_last_sweep();
-    // left at its first pass: the cycle's last block always; any other block of the fused size classes while the list has room
-    const bool implicit = !last_block && fused && ss_implicit_on() && G->ss_fix.n < NK_SS_NFIX - 1;
     if (!last_block && !implicit) {
       nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (k + 2 * sb));
       NK_TRY(nk_ss_sweep(ctx, 2, n, k, sb, G->V, ldv, W->coef, W->part, skipC, grid, fused ? &ta : nullptr, nullptr));
@@ -1425,13 +1428,11 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       // carry their Gram products through this block's factors). Its Hessenberg columns — the work of sweep C's workgroup 0,
       // or already done by k_ss_tail2 on the unfused path —: the cycle's last block as a launch of its own, any other block
       // inside the NEXT block's sweep A (which also leaves Wi, D for the reductions behind it).
-      if (implicit) {
-        ta.Wi = W->Wi + (size_t)blk * SS_SS;
-        ta.D = W->D + (size_t)blk * W->c2_stride;
+      if (implicit && fused) {
         pend_ta = ta; pend_k = k; pend_sb = sb;
       } else if (fused) {
         NK_TRY(ss_launch_hess(ctx, k, sb, ta));
-      }
+      }   // (unfused: k_ss_tail2 has derived the Hessenberg columns — and Wi, D — already)
       {
         nk_ss_fix &fx = G->ss_fix;
         NK_REQUIRE(fx.n < NK_SS_NFIX, "internal: too many s-step blocks left at their first pass");
