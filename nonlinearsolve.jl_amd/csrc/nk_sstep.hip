@@ -202,7 +202,7 @@ __device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *R
   __syncthreads();
 }
 __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w,
-                          const nk_ss_fix &fix) {
+                          const nk_ss_fix &fix, bool fix0_in_lds = false) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
   double *F = w.Fr;   // 16 × 17 frame: the factor in progress
@@ -214,7 +214,8 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
   if (t == 0) *w.ok = 1;
   __syncthreads();
   if (fix.n > 0) {   // (uniform) stored → true coordinates for the factorisation; true → stored coefficients for the update
-    for (int bq = 0; bq < fix.n; ++bq) ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], Ct, w.fC2, w.fR2, true);
+    for (int bq = 0; bq < fix.n; ++bq)
+      ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], Ct, w.fC2, w.fR2, !(bq == 0 && fix0_in_lds));
     for (int e = t; e < k * sb; e += blockDim.x) w.U[e] = Ct[e];
     __syncthreads();
     for (int bq = fix.n - 1; bq >= 0; --bq)   // (the last block carried to true coordinates is still in LDS)
@@ -300,6 +301,8 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   for (int e = t; e < ko; e += nt) { scs[e] = ta.cs[e]; ssn[e] = ta.sn[e]; }
   for (int e = t; e <= ko; e += nt) sg[e] = ta.g[e];
   if (t < sb * sb) w.R1s[t] = ta.R1[t];
+  if (t < k) w.uu[t] = ta.usb > 0 ? (t < ta.uk0 ? ta.uC2[t * ta.usb + ta.usb - 1] : ta.uR2[(t - ta.uk0) * ta.usb + ta.usb - 1])
+                                  : (t == k - 1 ? 1.0 : 0.0);
   const double sigma = ta.scal[2];
   const double *__restrict__ th = ta.scal + SS_TH;
   SS_STAMP(8);
@@ -322,10 +325,7 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   // A·(the column the powers started from) = σ X_0 + θ_0·(that column). It is the true basis vector v_k (u = e_k) — or, after a
   // block left at its first pass, that block's last STORED column = V_true u, u = [C₂ ; R₂][:, last]: then
   // A v_k = (σ F_0 + θ_0 u − Σ_{i<k} u_i A v_i) / u_k, with A v_i the old Hessenberg columns.
-  if (t < k) w.uu[t] = ta.usb > 0 ? (t < ta.uk0 ? ta.uC2[t * ta.usb + ta.usb - 1] : ta.uR2[(t - ta.uk0) * ta.usb + ta.usb - 1])
-                                  : (t == k - 1 ? 1.0 : 0.0);
-  __syncthreads();
-  if (t < K) {
+  if (t < K) {   // (u was requested with the first loads of this routine)
     double a = sigma * F[t * sb];
     if (t < k) {
       a = __builtin_fma(th[0], w.uu[t], a);
@@ -916,10 +916,14 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
   // ---- the last workgroup: every entry of the reduced block is in `red` (written by other workgroups: read past the L1)
   const ss_ws w = ss_ws_carve(s_rf + (size_t)nslots, k, sb, false);
   for (int e = t; e < nslots; e += SS_R) s_rf[e] = __builtin_nontemporal_load(&red[e]);
+  if (ta.fix.n > 0) {   // the first block left at its first pass: its Wi, D ride in the same round trip as the reduced block
+    for (int e = t; e < ta.fix.k0[0] * ta.fix.sb[0]; e += SS_R) w.fC2[e] = ta.fix.D[0][e];
+    if (t < ta.fix.sb[0] * ta.fix.sb[0]) w.fR2[t] = ta.fix.Wi[0][t];
+  }
   __syncthreads();
   SS_STAMP(2);
   ta.red = s_rf;
-  if (!ss_factor(k, sb, s_rf, ta.sc, w, ta.fix)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, s_rf, ta.sc, w, ta.fix, true)) { ss_fail(ta); return; }
   SS_STAMP(3);
   for (int e = t; e < k * sb; e += SS_R) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
