@@ -458,7 +458,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_ttt and args.workload == "c3":
         prob2 = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0), u0=torch.zeros(n_local, dtype=torch.float64, device="cuda"))
         ttt = {"protocol": "NewtonRaphson+GMRES(30)+EisenstatWalkerForcing2 to |h^2 F|inf<=1e-8"}
-        for name, precs in (("chebyshev_32_300", nls.ChebyshevPrecs(32, 300.0)), ("multigrid_2_31", nls.MultigridPrecs(2, 31))):
+        for name, precs in (("chebyshev_32_300", nls.ChebyshevPrecs(32, 300.0)), ("multigrid_2_31", nls.MultigridPrecs(2, 31)),
+                            ("amg_from_the_csr_matrix_alone", nls.ObjectPrecs("amg", "left"))):
+            if args.matfree and isinstance(precs, nls.ObjectPrecs):
+                continue   # (a preconditioner OBJECT is built from a concrete J)
             alg2 = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=300, precs=precs),
                                      forcing=nls.EisenstatWalkerForcing2(), concrete_jac=not args.matfree)
             nls.solve(prob2, alg2, abstol=1e-8, maxiters=50)  # warm-up (allocations, first-touch)

@@ -10,7 +10,9 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q < /dev/null > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" < /dev/null 2>&1 | tail -1 | tee $O/smoke.txt
+B0="--cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --steps 100 --warmup 10"
 timeout 700 python bench.py < /dev/null > $O/bench_csr.json 2> $O/bench_csr.err
+NK_SS_IMPLICIT=0 timeout 200 python bench.py $B0 < /dev/null > $O/bench_csr_explicit_second_pass.json 2> /dev/null
 B="--cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --steps 100 --warmup 10"
 NK_SPMV_POWERS=0 timeout 200 python bench.py $B < /dev/null > $O/bench_csr_streaming_spmv.json 2> /dev/null
 timeout 200 python bench.py $B --matfree < /dev/null > $O/bench_matfree.json 2> /dev/null
@@ -20,6 +22,11 @@ if [ "$MODE" = "full" ]; then
   timeout 300 python bench.py $B --workload c4 --steps 10 --warmup 2 < /dev/null > $O/bench_c4size_1gpu.json 2> /dev/null
   timeout 700 bash tools/profile_round.sh ${TAG}_c4size_1gpu --workload c4 --steps 4 --warmup 1 < /dev/null
   timeout 300 python tools/spmv_bench.py 100 < /dev/null > $O/spmv_bench.jsonl 2>/dev/null
+  timeout 300 python tools/amg_time.py < /dev/null > $O/amg_time.txt 2>&1
+  timeout 200 python tools/ss_stamps.py < /dev/null > $O/ss_stamps.txt 2>/dev/null
+  for n in 2 8; do
+    BENCH_BACKEND=gloo NK_COMM=peer timeout 500 python bench.py --gpus $n --steps 20 --warmup 3 $B --no-weak < /dev/null > $O/bench_x${n}_peer_shared_gpu.json 2> $O/bench_x${n}.err
+  done
 fi
 timeout 500 bash tools/profile_round.sh ${TAG} < /dev/null
 timeout 300 bash tools/step_timeline.sh ${TAG} < /dev/null

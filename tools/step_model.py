@@ -54,10 +54,12 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
         add("k_ss_reduce_factor", 0)
         add("k_ss_block<B>", 8.0 * n * (k + 2 * w))             # update (k + w read, w written) + Gram of the result
         add("k_ss_reduce_factor", 0)
-        if bi + 1 < len(blocks) and not implicit:
-            add("k_ss_block<C>", 8.0 * n * (k + 2 * w))         # second update (NK_SS_IMPLICIT=0)
+        if bi + 1 < len(blocks):
+            if not implicit:
+                add("k_ss_block<C>", 8.0 * n * (k + 2 * w))     # second update (NK_SS_IMPLICIT=0)
+            # implicit second pass: no third sweep, and the block's Hessenberg columns are derived inside the next sweep A
         else:
-            add("k_ss_hess", 0)                                 # the block is left at its first pass: no third sweep
+            add("k_ss_hess", 0)                                 # the cycle's last block: its Hessenberg columns, own launch
     add("k_backsolve", 0)
     add("k_multiaxpy", 8.0 * n * (m + 2))                       # x = V y: m + 1 columns read, x written
     add("k_newton_update", 24.0 * n)
