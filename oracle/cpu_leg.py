@@ -46,6 +46,18 @@ def main():
         scan[t] = round(rate, 2)
         if rate > 1.03 * best_rate:
             best_t, best_rate = t, rate
+    # … and the scan's winner is VALIDATED before it is used: a scan sample can still be a burst (seen in round 4: 247 steps/s in
+    # the scan at 128 threads, 24 sustained). Candidates in the scan's order take one longer run each (≈ 8 % of the budget); the
+    # first whose sustained rate keeps ≥ 70 % of its scan figure wins, else the one with the best sustained rate.
+    validated = {}
+    for t in sorted(scan, key=lambda q: -scan[q])[:4]:
+        CO.set_num_threads(t)
+        t1 = run("dcgs2", 1)[2]
+        k = int(max(5, min(400, 0.08 * budget_s / max(t1, 1e-4))))
+        validated[t] = k / run("dcgs2", k)[2]
+        if validated[t] >= 0.7 * scan[t]:
+            break
+    best_t = max(validated, key=lambda q: validated[q])
     CO.set_num_threads(best_t)
     cores = best_t
     b_op = (12.0 * nnz + 4.0 * (n + 1) + 16.0 * n) if not matfree else 24.0 * n
@@ -92,7 +104,9 @@ def main():
         "frac_of_stream_triad": round(eff / triad, 3) if triad > 0 else None,
         "spmv_GBs": round(spmv, 1), "spmv_frac_of_triad": round(spmv / triad, 3) if triad > 0 else None,
         "single_thread_value": round(1.0 / ts, 4), "thread_scan_steps_per_s": scan,
+        "thread_count_validation_steps_per_s": {str(k_): round(v_, 2) for k_, v_ in validated.items()},
         "thread_scan_best": max(scan.values()), "sample_over_scan_best": round(samples["dcgs2"]["median"] / max(scan.values()), 3),
+        "sample_over_scan_at_chosen_count": round(samples["dcgs2"]["median"] / scan[cores], 3),
         "fnorm_inf_last": fn_last,
         "note": "restatement of the reference algorithm (Julia is not installed on this box); a reported baseline, not the target"}))
 
