@@ -1545,8 +1545,28 @@ static int gmres_solve_graph(nk_gmres *G, const double *d_b, double *d_x, double
   return NK_OK;
 }
 
+static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol, int maxiter,
+                            int fixed_iters, nk_gmres_info *info);
+// The resident matrix-powers kernel needs all its workgroups on the chip at once; when something else holds compute units for
+// longer than its time-out (another process, a long kernel of the caller's on a second stream) a launch gives up, the columns of
+// that block are garbage and the solve reports NK_E_HIP. The plan is then off for good — and a solve that started from x = 0 (every
+// Newton step's) is simply run again on the streaming kernel instead of handing the failure to the caller.
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info) {
+  const bool had_plan = (G->op_kind == 1 && G->A && nk_csr_powers_ready(G->A)) ||
+                        (G->op_kind == 2 && G->P && G->P->kind == NK_PROBLEM_BRATU2D && nk_problem_powers_ready(G->P));
+  const int rc = gmres_solve_once(G, d_b, d_x, use_x0, atol, rtol, maxiter, fixed_iters, info);
+  if (rc == NK_E_HIP && had_plan && !use_x0) {
+    const bool now = (G->op_kind == 1 && nk_csr_powers_ready(G->A)) || (G->op_kind == 2 && nk_problem_powers_ready(G->P));
+    if (!now && hipStreamQuery(G->ctx->stream) != hipErrorUnknown) {   // the plan broke in this solve; the stream is alive
+      hipStreamSynchronize(G->ctx->stream);
+      return gmres_solve_once(G, d_b, d_x, 0, atol, rtol, maxiter, fixed_iters, info);
+    }
+  }
+  return rc;
+}
+static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol, int maxiter,
+                            int fixed_iters, nk_gmres_info *info) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n, ldv = G->ldv;
   const int m = G->m;

@@ -28,7 +28,7 @@ constexpr int PW_FLAG_STRIDE = 16;  // uint64 words between two bands' flags (12
 constexpr int PW_NXCD = 8;
 
 struct pw_args {
-  int nrows, nb, s, variant;
+  int nrows, nb, s, variant;   // variant bit 8 (development hook): band 0 never publishes — its neighbour times out
   const int32_t *rowptr, *col;
   const double *val;
   const double *x0;
@@ -205,16 +205,16 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
         if (q < NBND) pw_store_sc1(ycol + r, out);   // rows a neighbour band reads: write-through
         else ycol[r] = out;
       }
-      if (pub && a.variant == 0 && q == NBND - 1) {   // publish as early as possible: behind the boundary slices
+      if (pub && (a.variant & 255) == 0 && q == NBND - 1) {   // publish as early as possible: behind the boundary slices
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0)
+        if (t == 0 && !((a.variant & 256) && b == 0))
           __hip_atomic_store(a.flags + (size_t)b * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (!pub) break;
-    if (a.variant != 0) {   // publish behind the whole band: the interior rows overlap the boundary rows' write-through
+    if ((a.variant & 255) != 0) {   // publish behind the whole band: the interior rows overlap the boundary rows' write-through
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t == 0)
@@ -258,7 +258,11 @@ void nk_powers_plan_destroy(nk_powers_plan *P) {
 }
 static int pw_variant() {
   static const int v = getenv("NK_PW_VARIANT") ? atoi(getenv("NK_PW_VARIANT")) : 0;
-  return v;
+  // development hook: NK_PW_DEBUG_STALL_LAUNCH = n makes band 0 of the process's n-th launch withhold its flag (the time-out path)
+  static const long stall = getenv("NK_PW_DEBUG_STALL_LAUNCH") ? atol(getenv("NK_PW_DEBUG_STALL_LAUNCH")) : -1;
+  static long launches = 0;
+  ++launches;
+  return (v & 255) | ((stall > 0 && launches == stall) ? 256 : 0);
 }
 static bool pw_enabled() {
   static const bool on = !(getenv("NK_SPMV_POWERS") && atoi(getenv("NK_SPMV_POWERS")) == 0);

@@ -177,3 +177,34 @@ def test_matrix_free_operator_takes_the_resident_kernel_too(nls, dev):
             assert ("spmv_powers" in fam) == (flag == "1") and ("'jvp'" in fam) == (flag == "0"), fam
             outs.append(np.load(tf.name))
     assert np.max(np.abs(outs[0] - outs[1])) <= 1e-10 * np.max(np.abs(outs[1]))
+
+
+def test_a_timed_out_launch_is_noticed_and_the_solve_rerun_on_the_streaming_kernel(nls, dev):
+    """The resident kernel needs every workgroup on the chip at once; if one never shows up (something else holds its compute
+    unit) its neighbours give up after NK_PW_TIMEOUT_MS instead of hanging the GPU, the columns of that launch are garbage — and the
+    library notices: the plan is switched off, the linear solve (x0 = 0: every Newton step's) is run again on the streaming kernel,
+    the caller sees the same iterates as with NK_SPMV_POWERS=0. Provoked by the development hook that makes band 0 of one
+    launch withhold its flag."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, hashlib, nonlinearsolve_jl_amd as nls\n"
+        "prob = nls.NonlinearProblem(nls.Bratu2D(128, 6.0))\n"
+        "alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho='sstep', fixed_iters=30), concrete_jac=True)\n"
+        "cache = nls.init(prob, alg, abstol=1e-300, maxiters=50)\n"
+        "for _ in range(4): cache.step()\n"
+        "u = cache.u\n"
+        "u = np.asarray(u.cpu() if hasattr(u, 'cpu') else u)\n"
+        "ctx = nls.default_context(); ctx.profile_enable(True); cache.step(); fam = sorted(ctx.profile_report())\n"
+        "print('FAMILIES', fam)\n"
+        "print('HASH', hashlib.sha256(u.tobytes()).hexdigest())\n")
+    outs = {}
+    for name, env in (("stalled", dict(NK_PW_DEBUG_STALL_LAUNCH="5", NK_PW_TIMEOUT_MS="20")), ("streaming", dict(NK_SPMV_POWERS="0"))):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][-1]
+        fam = [l for l in r.stdout.splitlines() if l.startswith("FAMILIES")][-1]
+        assert "'spmv'" in fam and "spmv_powers" not in fam, (name, fam)    # after the time-out the object keeps the streaming kernel
+    assert outs["stalled"] == outs["streaming"], outs
