@@ -67,6 +67,7 @@ struct ss_tail_args {
   int uk0, usb;
   const double *uC2, *uR2;
   double *Wi, *D;      // this block's R₂⁻¹ and C₂R₂⁻¹, written next to its Hessenberg columns when it is left at its first pass
+  double ptol;         // rank-loss bar of the factorisation: a pivot ≤ ptol·(XᵀX)_aa is a breakdown (1e-12; 1e-8 with the implicit second pass)
 };
 // LDS arrays of the scalar work, carved from one dynamic block
 struct ss_ws {
@@ -109,7 +110,7 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
 // From the reduced block [V_kᵀX ; XᵀX] (X = the s columns behind V_k; `sc` un-normalised-column scales): the true
 // coefficients Ct = diag(sc)·V_kᵀX, the Cholesky factor R of XᵀX − CtᵀCt (Pythagorean form of ‖X − V Ct‖), R⁻¹, and the
 // coefficients U = diag(sc)·Ct the update takes off the stored columns. Returns false when the block lost rank numerically:
-// a pivot that is not positive RELATIVE to the column's own squared norm — d ≤ 1e-12 (XᵀX)_aa: the column lies in the span of
+// a pivot that is not positive RELATIVE to the column's own squared norm — d ≤ ptol·(XᵀX)_aa, ptol = 1e-12 (1e-8 with the implicit second pass): the column lies in the span of
 // the others to 1e-6, the block's condition number is beyond 1e6, and the Hessenberg columns recovered through R would carry
 // errors above 1e-10 (a pivot near ε (XᵀX)_aa is rounding noise altogether) — or is not finite.
 // Every workgroup that runs it on the same `red` reaches the same verdict.
@@ -202,7 +203,7 @@ __device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *R
   __syncthreads();
 }
 __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w,
-                          const nk_ss_fix &fix, bool fix0_in_lds = false) {
+                          const nk_ss_fix &fix, double ptol, bool fix0_in_lds = false) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
   double *F = w.Fr;   // 16 × 17 frame: the factor in progress
@@ -246,7 +247,7 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
 #pragma unroll 1
   for (int p = 0; p < SS_SMAX; ++p) {   // after step p: row p holds T_pb = D_p U_pb (b ≥ p), the trailing block is updated
     const double d = F[p * SS_FP + p], fpa = F[p * SS_FP + a], fpb = F[p * SS_FP + b];
-    if (t == 0 && p < sb && (!(d > 1e-12 * w.Gd[p]) || isinf(d))) *w.ok = 0;
+    if (t == 0 && p < sb && (!(d > ptol * w.Gd[p]) || isinf(d))) *w.ok = 0;
     if (a > p && b >= a) {
       val = __builtin_fma(-(fpa * ss_rcp(d)), fpb, val);
       F[a * SS_FP + b] = val;
@@ -267,6 +268,25 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
   return *w.ok != 0;
 }
 
+// Implicit second pass: how far pass 1 left the block from orthonormal — max(|C₂|, |R₂ − I|) over pass 2's factors (in LDS:
+// w.Ct k × sb, w.Rm sb × sb). Uniform verdict: true = the block may stay at its first pass.
+__device__ bool ss_first_pass_departure_ok(int k, int sb, const ss_ws &w, double bar) {
+  const int t = threadIdx.x;
+  double m = 0.0;
+  for (int e = t; e < k * sb; e += blockDim.x) m = fmax(m, fabs(w.Ct[e]));
+  if (t < sb * sb) {
+    const int a = t / sb, c = t % sb;
+    m = fmax(m, fabs(w.Rm[t] - (a == c ? 1.0 : 0.0)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  __syncthreads();
+  if ((t & 63) == 0) w.Gd[t >> 6] = m;
+  __syncthreads();
+  m = fmax(fmax(w.Gd[0], w.Gd[1]), fmax(w.Gd[2], w.Gd[3]));
+  __syncthreads();
+  return m <= bar && m == m;
+}
 // after pass 1 (one workgroup): C₁ and R₁ are kept for pass 2; σ estimate for the next cycle from ‖A v‖ of the first block
 __device__ void ss_keep_pass1(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
   const int t = threadIdx.x;
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(256) void k_ss_tail1(int k, int sb, double *__restr
   extern __shared__ double s_tail[];
   if (ta.ctl->done) return;
   const ss_ws w = ss_ws_carve(s_tail, k, sb, false);
-  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix, ta.ptol)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
@@ -464,7 +484,8 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
   extern __shared__ double s_tail[];
   if (ta.ctl->pad1) return;  // (pad1: the cycle was done when this block started, or its first pass failed)
   const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
-  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix, ta.ptol)) { ss_fail(ta); return; }
+  if (ta.Wi != nullptr && !ss_first_pass_departure_ok(k, sb, w, 0.1)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) { coef[e] = w.U[e]; ta.C2[e] = w.Ct[e]; }
   if (t < sb * sb) { coef[(size_t)k * sb + t] = w.Ri[t]; ta.R2[t] = w.Rm[t]; }
@@ -923,13 +944,14 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
   __syncthreads();
   SS_STAMP(2);
   ta.red = s_rf;
-  if (!ss_factor(k, sb, s_rf, ta.sc, w, ta.fix, true)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, s_rf, ta.sc, w, ta.fix, ta.ptol, true)) { ss_fail(ta); return; }
   SS_STAMP(3);
   for (int e = t; e < k * sb; e += SS_R) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
   if (pass == 0) {
     ss_keep_pass1(k, sb, w, ta);
   } else {
+    if (ta.Wi != nullptr && !ss_first_pass_departure_ok(k, sb, w, 0.1)) { ss_fail(ta); return; }   // (left at its first pass only if that pass was good)
     for (int e = t; e < k * sb; e += SS_R) ta.C2[e] = w.Ct[e];
     if (t < sb * sb) ta.R2[t] = w.Rm[t];
     // the next block's matrix powers start from a column of unit scale (ss_hessenberg says the same — but where this block is
@@ -1321,6 +1343,15 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   ta.ctl = G->d_ctl; ta.red = W->red; ta.sc = G->d_s; ta.C1 = W->C1; ta.R1 = W->R1; ta.C2 = W->C2; ta.R2 = W->R2; ta.H = W->H; ta.m = G->m;
   ta.Rg = G->d_R; ta.cs = G->d_cs; ta.sn = G->d_sn; ta.g = G->d_g; ta.scal = W->scal; ta.pub = G->h_pub_dev; ta.seq = G->cycle_seq;
   G->ss_fix = nk_ss_fix{};
+  // Blocks are left at their first pass with the NEWTON basis only (monomial blocks of 6–8 columns live near the rank-loss bar
+  // and keep the explicit second update), and only while the first pass leaves them NEARLY orthonormal: the Hessenberg recovery
+  // of the next block starts from a stored column, a combination u of true basis vectors whose images carry this block's
+  // recovery errors — harmless for u ≈ e_k, amplified column by column when pass 1 was far off (a block within a factor of ≈ 30
+  // of losing rank: oracle, Arnoldi residual 5e-2 against 1e-7 for the explicit update at a departure of 0.75, equal up to 0.2).
+  // ss_first_pass_departure measures max(|C₂|, |R₂ − I|) in the reduction's tail; above 0.1 the block counts as broken and
+  // takes the fall-back (narrower blocks), exactly like a lost pivot.
+  const bool implicit_mode = ss_implicit_on() && W->newton;
+  ta.ptol = 1e-12;
   int blk = 0;            // index of the block within the cycle = its slot of pass-2 factors
   int prev_k0 = 0, prev_sb2 = 0;  // the previous block if it was left at its first pass (prev_sb2 = 0: it was not)
   ss_tail_args pend_ta;           // … and, while its Hessenberg columns wait for a sweep A to host them, its arguments
@@ -1375,7 +1406,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     // left at its first pass (no sweep C): the cycle's last block always; any other block while the list has room — whatever
     // the transport and the size class, so that every path runs the same arithmetic (results are compared bit for bit)
     const bool last_block = (k - 1 + sb >= steps) && ss_skip_last_sweep();
-    const bool implicit = !last_block && ss_implicit_on() && G->ss_fix.n < NK_SS_NFIX - 1;
+    const bool implicit = !last_block && implicit_mode && G->ss_fix.n < NK_SS_NFIX - 1;
     ta.Wi = implicit ? W->Wi + (size_t)blk * SS_SS : nullptr;
     ta.D = implicit ? W->D + (size_t)blk * W->c2_stride : nullptr;
     for (int pass = 0; pass < 2; ++pass) {

@@ -848,7 +848,7 @@ def sstep_block_width(want):
 
 
 def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0, s=6,
-                allreduce: Optional[Callable] = None, x0=None, interval=None):
+                allreduce: Optional[Callable] = None, x0=None, interval=None, implicit=True):
     """Restarted GMRES(m) whose Arnoldi process advances s columns at a time — the CPU restatement of csrc/nk_sstep.hip
     (the device's NK_ORTHO_SSTEP; Hoemmen, "Communication-avoiding Krylov subspace methods", and Carson, Lund, Rozložník,
     Thomas, "Block Gram–Schmidt algorithms and their stability properties", for BCGS-PIP). Per block: the monomial vectors
@@ -861,8 +861,34 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
     interval = (lo, hi), real bounds of the operator's spectrum: NEWTON basis X_j = (A − θ_j I) X_{j−1} / σ with
     θ_j = c + h·t_j (t the Leja-ordered Chebyshev points, c / h centre / half width) and σ = h/2 rounded to a power of two
     (Bai, Hu, Reichel 1994; Hoemmen 2010 §7.3) — then A v_k = σ X_0 + θ_0 v_k and A X_{j−1} = σ X_j + θ_j X_{j−1}, and the
-    block stays well conditioned up to s = 16 (the monomial basis, interval = None, breaks down near s = 10)."""
+    block stays well conditioned up to s = 16 (the monomial basis, interval = None, breaks down near s = 10).
+    implicit = True (the device's default since round 4, NK_SS_IMPLICIT): NO block is updated a second time. A block's stored
+    columns S_b = Q₁ relate to the true basis by S_b = V_true[:k0] C₂ + Q_b R₂ (pass 2's factors), and everything that needs the
+    true basis goes through that relation: later blocks carry their inner products with stored columns into true coordinates
+    (Q_bᵀX = R₂⁻ᵀ(S_bᵀX − C₂ᵀ V_true[:k0]ᵀX), blocks in order) and their projection coefficients back onto the stored columns
+    (b = R₂⁻¹W_b, W[:k0] −= C₂ b, blocks last first); the next block's powers start from the last STORED column s = V_true u,
+    u = [C₂ ; R₂][:, last], so that A v_k = (σF₀ + θ₀u − Σ_{i<k} u_i A v_i)/u_k; the solution update x += S ŷ takes ŷ from y by the
+    same block-by-block map. implicit = False: every block but the cycle's last gets the explicit second update (rounds 2–3).
+    Mathematically the same iterates (1e-15 … 2e-13 apart on the path's Jacobians, tests/test_oracle_pins.py)."""
     ar = allreduce if allreduce is not None else (lambda z: z)
+    # (the device takes the implicit form with the NEWTON basis only: monomial blocks of 6–8 columns live at pivot ratios of
+    #  1e-9 … 1e-12, below the bar the implicit form needs — they keep the explicit second update and the 1e-12 bar)
+    implicit = bool(implicit) and interval is not None
+    fix = []   # (k0, sb, C2, R2) of the blocks of the running cycle left at their first pass
+
+    def to_true(P):
+        P = P.copy()
+        for (k0_, s_, C2_, R2_) in fix:
+            P[k0_:k0_ + s_] = np.linalg.solve(R2_.T, P[k0_:k0_ + s_] - C2_.T @ P[:k0_])
+        return P
+
+    def to_stored(Wc):
+        Wc = Wc.copy()
+        for (k0_, s_, C2_, R2_) in reversed(fix):
+            bv = np.linalg.solve(R2_, Wc[k0_:k0_ + s_])
+            Wc[:k0_] -= C2_ @ bv
+            Wc[k0_:k0_ + s_] = bv
+        return Wc
     theta, sigma = np.zeros(max(int(s), 1)), 1.0
     if interval is not None:
         lo_, hi_ = float(interval[0]), float(interval[1])
@@ -887,10 +913,10 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
         return x, info
     m = int(restart)
 
-    def pip(V, X):  # one Pythagorean block projection: the coefficients and the triangular factor, X updated
+    def pip(V, X):  # one Pythagorean block projection: the coefficients and the triangular factor, X updated (V: STORED columns)
         k, sb = V.shape[0], X.shape[0]
         red = ar(np.concatenate([(V @ X.T).ravel(), (X @ X.T).ravel()]))
-        C, G = red[: k * sb].reshape(k, sb), red[k * sb:].reshape(sb, sb)
+        C, G = to_true(red[: k * sb].reshape(k, sb)), red[k * sb:].reshape(sb, sb)
         S = 0.5 * ((G - C.T @ C) + (G - C.T @ C).T)
         try:
             Rm = np.linalg.cholesky(S).T
@@ -901,7 +927,7 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
         # the device's verdict (ss_factor): a pivot below 1e-12 of the column's own squared norm — the block's κ is beyond 1e6
         if np.any(np.diag(Rm) ** 2 <= 1e-12 * np.diag(G)):
             raise SStepBreakdown("pivot below 1e-12 of the column's squared norm")
-        Xn = np.linalg.solve(Rm.T, X - C.T @ V)   # rows of X are vectors: Xᵀ ← (Xᵀ − V_kᵀC) R⁻¹
+        Xn = np.linalg.solve(Rm.T, X - to_stored(C).T @ V)   # rows of X are vectors: Xᵀ ← (Xᵀ − V_kᵀC) R⁻¹ (C on the stored columns)
         return C, Rm, Xn
 
     while True:
@@ -913,6 +939,7 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
         V[0] = r0 / beta0
         g[0] = beta0
         k, kdone, done = 1, 0, False
+        fix.clear()
         while k - 1 < steps and not done:
             sb = sstep_block_width(min(s, steps - (k - 1)))
             if k + sb > 48 and sb > 8:
@@ -923,13 +950,30 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
                 X[j] = (matvec(z) - theta[j] * z) / sigma if interval is not None else matvec(z)
                 z = X[j]
             C1, R1, X = pip(V[:k], X)
-            C2, R2, X = pip(V[:k], X)
-            V[k: k + sb] = X
+            C2, R2, X2 = pip(V[:k], X)
+            u = np.zeros(k)
+            u[k - 1] = 1.0
+            if fix and fix[-1][0] + fix[-1][1] == k:          # the powers started from the previous block's last STORED column
+                u = np.concatenate([fix[-1][2][:, -1], fix[-1][3][:, -1]])
+            last = (k - 1 + sb >= steps)
+            if implicit and not last and max(float(np.max(np.abs(C2))), float(np.max(np.abs(R2 - np.eye(sb))))) > 0.1:
+                # a block may stay at its first pass only if that pass left it NEARLY orthonormal: the next block's Hessenberg
+                # recovery starts from a stored column, a combination u of true basis vectors whose images carry this block's
+                # recovery errors — harmless for u ≈ e_k, amplified column by column otherwise (Arnoldi residual 5e-2 against
+                # 1e-7 for the explicit update at a departure of 0.75; equal up to 0.2). The device counts it as a breakdown.
+                raise SStepBreakdown("first pass too far from orthonormal for the implicit second pass")
+            if implicit or last:   # (the device leaves a cycle's last block at its first pass in either mode: k_backsolve adapts y)
+                V[k: k + sb] = X
+                fix.append((k, sb, C2, R2))
+            else:
+                V[k: k + sb] = X2
             F = np.vstack([C1 + C2 @ R1, R2 @ R1])        # (k + sb) × sb
             K = k + sb
             NC = np.zeros((sb, K))
-            NC[0] = sigma * F[:, 0]
-            NC[0, k - 1] += theta[0]
+            a0 = sigma * F[:, 0]
+            a0[:k] += theta[0] * u
+            a0[:k] -= H[:k, : k - 1] @ u[: k - 1]
+            NC[0] = a0 / u[k - 1]
             for j in range(1, sb):
                 a = sigma * F[:, j] + theta[j] * F[:, j - 1]
                 a[: k] -= H[:k, : k - 1] @ F[: k - 1, j - 1]
@@ -966,7 +1010,12 @@ def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300,
             k += sb
         if kdone > 0 and not info.failed:
             y = np.linalg.solve(np.triu(R[:kdone, :kdone]), g[:kdone]) if kdone > 1 else np.array([g[0] / R[0, 0]])
-            x = x + V[:kdone].T @ y
+            Kst = (fix[-1][0] + fix[-1][1]) if fix else kdone      # stored columns behind the coefficients
+            Kst = max(Kst, kdone)
+            w_ = np.zeros(Kst)
+            w_[:kdone] = y
+            w_ = to_stored(w_.reshape(-1, 1)).ravel()             # y on the true basis → coefficients on the stored columns
+            x = x + V[:Kst].T @ w_
         if done or info.iters >= cap:
             return x, info
         info.restarts += 1

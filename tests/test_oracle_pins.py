@@ -840,19 +840,30 @@ def test_sstep_newton_basis_agrees_with_column_schemes_up_to_s16():
         x, i = R.gmres(lambda z: A @ z, b, restart=30, rtol=1e-10, itmax=2000, ortho=("sstep", 0, "newton", iv))
         x2, i2 = R.gmres(lambda z: A @ z, b, restart=30, rtol=1e-10, itmax=2000, ortho="cgs2")
         assert i.converged and i.iters == i2.iters and np.linalg.norm(x - x2) <= 1e-8 * np.linalg.norm(x2)
-    # bounds need not be tight — a 1.5× too wide interval costs the block conditioning (the iterate moves by 4e-9) — but they are
+    # bounds need not be tight — a 1.4× too wide interval costs the block conditioning (the iterate moves by 1e-9) — but they are
     # no free parameter: with a smooth right-hand side (u = 0: the residual is a constant vector, all of it in the lowest modes)
-    # a 3× too wide interval lets a block of 15 lose rank, where a block of 8 is still fine (the device narrows its automatic
-    # block size 15 → 8 → 4 on such a breakdown)
+    # a 1.5× too wide interval leaves the first pass of a block of 15 so far from orthonormal (max(|C₂|, |R₂ − I|) = 0.75 > 0.1)
+    # that the implicit second pass refuses it (the explicit form still returns 4e-9 there and loses a pivot at 1.8×), where a
+    # block of 8 is still fine (the device narrows its automatic block size 15 → 8 → 4 on such a breakdown)
     P = R.Bratu2D(24); u = P.u0(); A, b = P.jac(u).tocsr(), P.f(u)
     lo, hi = R.gershgorin_interval(A)
     x1, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo, hi)))
-    w = 0.25 * (hi - lo)
+    w = 0.15 * (hi - lo)                                            # (departure of the first pass: 0.01; 0.22 at 0.2×, 0.75 at 0.25×)
     x2, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo - w, hi + w)))
-    assert np.linalg.norm(x1 - x2) <= 1e-8 * np.linalg.norm(x1)
-    with pytest.raises(R.SStepBreakdown):
-        R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo - (hi - lo), hi + (hi - lo))))
-    x3, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 8, "newton", (lo - 2 * w, hi + 2 * w)))
+    assert np.linalg.norm(x1 - x2) <= 1e-9 * np.linalg.norm(x1)
+    for f in (0.25, 1.0):
+        with pytest.raises(R.SStepBreakdown):
+            R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", (lo - f * (hi - lo), hi + f * (hi - lo))))
+    x8, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 8, "newton", (lo - 0.25 * (hi - lo), hi + 0.25 * (hi - lo))))
+    assert np.linalg.norm(x1 - x8) <= 1e-8 * np.linalg.norm(x1)
+    # the explicit second pass (rounds 2–3, NK_SS_IMPLICIT=0) and the implicit one are the same iterates wherever both accept a block
+    xe, _ = R.gmres_sstep(lambda z: A @ z, b, restart=30, fixed_iters=30, s=15, interval=(lo, hi), implicit=False)
+    xi, _ = R.gmres_sstep(lambda z: A @ z, b, restart=30, fixed_iters=30, s=15, interval=(lo, hi), implicit=True)
+    assert np.linalg.norm(xe - xi) <= 1e-12 * np.linalg.norm(xe)
+    xe, ie = R.gmres_sstep(lambda z: A @ z, b, restart=30, rtol=1e-9, itmax=400, s=8, interval=(lo, hi), implicit=False)
+    xi, ii = R.gmres_sstep(lambda z: A @ z, b, restart=30, rtol=1e-9, itmax=400, s=8, interval=(lo, hi), implicit=True)
+    assert ie.iters == ii.iters and np.linalg.norm(xe - xi) <= 1e-10 * np.linalg.norm(xe)   # 4 blocks per cycle: 3 left implicit
+    x3, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 8, "newton", (lo - 0.4 * (hi - lo), hi + 0.4 * (hi - lo))))
     assert np.linalg.norm(x1 - x3) <= 1e-9 * np.linalg.norm(x1)
     # Leja ordering: first the point of largest modulus, then its mirror image, then the centre
     t = R.leja_chebyshev_nodes(15)
