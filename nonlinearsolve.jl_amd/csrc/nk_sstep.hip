@@ -528,10 +528,19 @@ __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta)
 // its share of sweep C is on its way, derives the Hessenberg columns, rotations and the stopping test. `mark`: workgroup 0
 // records the skip flag it saw (sweep A stamps "the cycle was done when this block started" for sweep C, which must not look at
 // a flag that workgroup 0 of its own launch may raise).
-template <int S, bool UPDATE, bool GRAM, int MTC, bool FUSE>
-__global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__restrict__ V, int64_t ldv,
-                                                   const double *__restrict__ coef, double *__restrict__ partials,
+// KC > 0: k is the compile-time constant KC (the shapes of the default cycle, 15-column blocks behind 1 and 16 columns). With a
+// run-time k every basis column's load and its S multiply-adds sit behind a uniform branch `j < k`, and the wait-count pass
+// then cannot tell how many loads are outstanding: it waits for vmcnt(0) in front of the first use of the CURRENT register set
+// — i.e. for the NEXT tile's loads it has just issued (round 4, read in the ISA: the double buffering never overlapped anything
+// inside a workgroup), and every column's coefficients are a scalar-load round trip of their own. Straight-line code lets it
+// count (vmcnt(k + S) …) and batch the scalar loads.
+template <int S, bool UPDATE, bool GRAM, int MTC, bool FUSE, int KC = 0>
+__global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *__restrict__ V, int64_t ldv,
+                                                   const double *__restrict__ coef_in, double *__restrict__ partials,
                                                    const int *d_skip, int ntiles, ss_tail_args ta, int *mark, int ws_off, int hk, int hs) {
+  const int k = KC > 0 ? KC : k_rt;
+  const bool bar = (ws_off & 1) != 0;   // development switch NK_SS_BARRIERS=1: the per-tile workgroup barriers of rounds 2–3
+  ws_off = 0;
   {
     const int dskip = (d_skip != nullptr) ? *d_skip : 0;
     if (mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *mark = dskip;
@@ -546,7 +555,6 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
   double *__restrict__ Wc = V + (size_t)k * ldv;
-  const double *__restrict__ Rinv = coef + (size_t)k * S;
   // DB: two register sets — the NEXT tile's k + S loads are issued before the current tile is touched, so they are in flight
   // through the update, the LDS traffic AND the matrix-core phase (one set: only through the matrix-core phase; with 15-column
   // blocks the multiply-adds of a tile are ≈ 40 % of its memory time and did not overlap with it). The LDS tile bounds these
@@ -582,9 +590,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
   const int nwk = (int)gridDim.x - (hw ? 1 : 0), me = (int)blockIdx.x - (hw ? 1 : 0);
   const int tpw = (ntiles + nwk - 1) / nwk;
   const int tile0 = me >= 0 ? me * tpw : 0, tile1 = me >= 0 ? min(tile0 + tpw, ntiles) : 0;
-  auto process = [&](double (&vr)[NVR], double (&w)[S], int tile, auto &&mid) {
+  auto process = [&](double (&vr)[NVR], double (&w)[S], int tile, bool valid, auto &&mid) {
     const int64_t r = (int64_t)tile * SS_R + t;
-    const bool ok = r < n;
+    const bool ok = valid && r < n;
+    const double *__restrict__ coef = coef_in;
+    const double *__restrict__ Rinv = coef + (size_t)k * S;
     if (MTC > 0) {
 #pragma unroll
       for (int j = 0; j < NVR; ++j) {
@@ -636,7 +646,9 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
     if (GRAM) {
 #pragma unroll
       for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
-      __syncthreads();
+      // (no workgroup barrier: a wavefront's matrix-core operands are the 64 rows it has just written itself — LDS executes a
+      //  wavefront's instructions in order — so the four wavefronts of a workgroup run through their tiles independently)
+      if (bar) __syncthreads();
     }
     mid();   // (one register set: the next tile's loads go out here, in flight through the matrix-core phase)
     if (GRAM) {
@@ -656,25 +668,36 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
           for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[mt][u], bb[u], acc[mt], 0, 0, 0);
         }
       }
-      __syncthreads();
+      if (bar) __syncthreads();
     }
   };
   if (tile0 < tile1) prefetch(vr, w, tile0);
-  if constexpr (DB) {
+  if constexpr (DB && KC > 0) {
+    // straight-line pipeline: every prefetch is issued unconditionally (past the end: the workgroup's last tile again, a cache
+    // hit) and an odd tile count runs its phantom tile with all rows masked (zeros into the Gram block, no stores) — no branch
+    // around a batch of loads, so the wait in front of a register set's first use is vmcnt(loads issued behind it), not 0
+    for (int tile = tile0; tile < tile1; tile += 2) {
+      prefetch(vr2, w2, tile + 1 < tile1 ? tile + 1 : tile1 - 1);
+      process(vr, w, tile, true, [] {});
+      prefetch(vr, w, tile + 2 < tile1 ? tile + 2 : tile1 - 1);
+      process(vr2, w2, tile + 1, tile + 1 < tile1, [] {});
+    }
+  } else if constexpr (DB) {
     for (int tile = tile0; tile < tile1; tile += 2) {
       if (tile + 1 < tile1) prefetch(vr2, w2, tile + 1);
-      process(vr, w, tile, [] {});
+      process(vr, w, tile, true, [] {});
       if (tile + 1 < tile1) {
         if (tile + 2 < tile1) prefetch(vr, w, tile + 2);
-        process(vr2, w2, tile + 1, [] {});
+        process(vr2, w2, tile + 1, true, [] {});
       }
     }
   } else {
     for (int tile = tile0; tile < tile1; ++tile)
-      process(vr, w, tile, [&] { if (tile + 1 < tile1) prefetch(vr, w, tile + 1); });
+      process(vr, w, tile, true, [&] { if (tile + 1 < tile1) prefetch(vr, w, tile + 1); });
   }
   if (GRAM) {
     // the four wavefronts' tiles → one partial per (basis column, new column) and workgroup; fixed order
+    __syncthreads();   // (the scratch overlays rows the other wavefronts may still be reading)
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
 #pragma unroll
@@ -697,6 +720,174 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k, double *__r
   if (FUSE && blockIdx.x == 0) {
     if (GRAM) __syncthreads();
     ss_hess_block(hk, hs, sX + ws_off, ta);
+  }
+}
+
+// Sweep B of the default cycle's shapes with the UPDATE on the matrix cores as well (round 4). X ← (X − V U) R⁻¹ is one
+// product of the tile [V X] (256 rows × (k + S) columns, already staged in LDS for the Gram block) with the (k + S) × S matrix
+//     T = [ −U N ; N ],  N = R⁻¹ (upper triangular, formed once per workgroup from the reduction's U and R),
+// i.e. (k + S)/4 v_mfma_f64_16x16x4 per 16 rows instead of k·S + S(S+1)/2 multiply-adds per row whose k·S + S² coefficients
+// had to come through scalar loads (≈ 135 round trips per tile with a run-time k; hoisted, spilled into VGPR lanes and read back
+// with ≈ 9 v_readlane per multiply-add with a compile-time k). The loop body has no scalar memory traffic and no branch around
+// its loads: both register sets' waits are exact (vmcnt(k + 2S) …), so the next tile's k + S loads are in flight through the
+// whole of the current tile. A wavefront's operands are the 64 rows it staged itself: no workgroup barrier inside the loop.
+// Same contract as k_ss_block<S, true, true, …>: `coef` = U (k × S) then R (S × S, reciprocal diagonal); the updated columns go
+// back to V[:, k..k+S) and the Gram block [V Q]ᵀQ to `partials`. Rounding differs from the substitution form in the last bits
+// (explicit inverse: the same ε κ(R) bound; pass 2 of the block scheme repairs both alike).
+template <int S, int KC>
+__global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restrict__ V, int64_t ldv,
+                                                      const double *__restrict__ coef, double *__restrict__ partials,
+                                                      const int *d_skip, int ntiles, int *mark) {
+  {
+    const int dskip = (d_skip != nullptr) ? *d_skip : 0;
+    if (mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *mark = dskip;
+    if (dskip) return;
+  }
+  extern __shared__ double sX[];
+  constexpr int k = KC, K = KC + S, NT = (K + 15) / 16, NKS = (K + 3) / 4;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, q4 = lane >> 4;
+  double *__restrict__ Wc = V + (size_t)k * ldv;
+  const int nwk = (int)gridDim.x, me = (int)blockIdx.x;
+  const int tpw = (ntiles + nwk - 1) / nwk;
+  const int tile0 = me * tpw, tile1 = min(tile0 + tpw, ntiles);
+  double vr[KC], w[S], vr2[KC], w2[S];
+  auto prefetch = [&](double (&vrx)[KC], double (&wx)[S], int tile) {
+    const int64_t r = (int64_t)tile * SS_R + t;
+    const int64_t rc = r < n ? r : n - 1;
+#pragma unroll
+    for (int c = 0; c < S; ++c) wx[c] = Wc[(size_t)c * ldv + rc];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * ldv + rc];
+  };
+  if (tile0 < tile1) prefetch(vr, w, tile0);   // in flight while T is formed
+  // ---- T = [−U N ; N] in LDS (the tile is not in use yet), then each lane's share of it as matrix-core B operands
+  double tb[NKS];
+  {
+    double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + 256;
+    for (int e = t; e < k * S + S * S; e += SS_R) sX[e] = coef[e];
+    __syncthreads();
+    if (t < S) {   // row t of N: n R = e_t by forward substitution (R's diagonal arrives as reciprocals)
+      double nr[S];
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        double a = (c == t) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < c; ++c2) a = __builtin_fma(-nr[c2], sR[c2 * S + c], a);
+        nr[c] = (c < t) ? 0.0 : a * sR[c * S + c];
+      }
+#pragma unroll
+      for (int c = 0; c < S; ++c) sN[t * 16 + c] = nr[c];
+    }
+    __syncthreads();
+    for (int e = t; e < 4 * NKS * 16; e += SS_R) {
+      const int j = e >> 4, c = e & 15;
+      double v = 0.0;
+      if (c < S) {
+        if (j < k) {
+          double a = 0.0;
+          for (int c2 = 0; c2 <= c; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
+          v = -a;
+        } else if (j < K) {
+          v = sN[(j - k) * 16 + c];
+        }
+      }
+      sT[e] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) tb[ks] = sT[(4 * ks + q4) * 16 + li];
+    __syncthreads();   // (the scratch overlays the tile)
+  }
+  ss_d4 acc[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
+  // operand addresses. Update: lane (i, q4) supplies A[i][q4] = [V X][row0 + i][4·ks + q4]. Gram: as in k_ss_block.
+  const double *pu[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int col = 4 * ks + q4;
+    pu[ks] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + li;   // (T's rows ≥ K are zero: any finite operand will do)
+  }
+  const double *pb = sX + (k + (li < S ? li : S - 1)) * SS_P + wv * 64 + q4;
+  const double *pa[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    const int col = mt * 16 + li;
+    pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
+  }
+  double *pq = sX + (k + (li < S ? li : S - 1)) * SS_P + wv * 64 + q4;   // where lane (i, q4) puts Q[row0 + q4 + 4·rr][i]
+  auto process = [&](double (&vr)[KC], double (&w)[S], int tile, bool valid) {
+    const int64_t r = (int64_t)tile * SS_R + t;
+    const bool ok = valid && r < n;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
+#pragma unroll
+    for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
+    // the update: 16 rows per instruction group, the result back into the X columns of the same rows
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ss_d4 q = ss_d4{0.0, 0.0, 0.0, 0.0};
+      double a[NKS];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) a[ks] = pu[ks][g * 16];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) q = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], tb[ks], q, 0, 0, 0);
+      if (li < S) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pq[g * 16 + 4 * rr] = q[rr];
+      }
+    }
+    // the updated columns leave through the row-per-thread layout (coalesced)
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      const double qv = sX[(k + c) * SS_P + t];
+      if (ok) Wc[(size_t)c * ldv + r] = qv;
+    }
+    // Gram block [V Q]ᵀQ: 64 rows per wavefront, 4 per instruction
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+      double bb[4], aa[NT][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bb[u] = pb[(kk + u) * 4];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) aa[mt][u] = pa[mt][(kk + u) * 4];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[mt][u], bb[u], acc[mt], 0, 0, 0);
+      }
+    }
+  };
+  // (sched_barrier: the machine scheduler otherwise sinks a prefetch below the LDS staging of the set it is meant to overlap
+  //  with — one register set less, and nothing in flight while a tile is staged)
+  for (int tile = tile0; tile < tile1; tile += 2) {
+    prefetch(vr2, w2, tile + 1 < tile1 ? tile + 1 : tile1 - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    process(vr, w, tile, true);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch(vr, w, tile + 2 < tile1 ? tile + 2 : tile1 - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    process(vr2, w2, tile + 1, tile + 1 < tile1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();   // (the scratch overlays rows the other wavefronts may still be reading)
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) sX[((wv * NT + mt) * 4 + rr) * 64 + lane] = acc[mt][rr];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    const int rr = t >> 6, ln = t & 63;
+    const int mrow = mt * 16 + (ln >> 4) + 4 * rr, ncol = ln & 15;
+    if (mrow < K && ncol < S) {
+      const int e = (mt * 4 + rr) * 64 + ln;
+      const double sum = (sX[e] + sX[NT * 256 + e]) + (sX[2 * NT * 256 + e] + sX[3 * NT * 256 + e]);
+      partials[(size_t)(mrow * S + ncol) * gridDim.x + blockIdx.x] = sum;
+    }
   }
 }
 
@@ -749,23 +940,32 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   //  workspace OVERLAYS the tile, so hosting costs the sweep no occupancy)
   const size_t wsd = fuse ? ss_ws_doubles(hk, hs, true) : 0;
   const size_t lds = (tile > wsd ? tile : wsd) * sizeof(double);
-  const int ws_off = 0;
+  static const int ws_off = (getenv("NK_SS_BARRIERS") && atoi(getenv("NK_SS_BARRIERS")) != 0) ? 1 : 0;
   ss_tail_args ta;
   std::memset(&ta, 0, sizeof(ta));
   if (tap) ta = *tap;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool ev = !occ_out && ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
-#define SS_GO3(UPD, GRM, KM, FS)                                                                                          \
+#define SS_GO4(UPD, GRM, KM, FS, KCC)                                                                                     \
   do {                                                                                                                    \
     if (lds > 64 * 1024)                                                                                                  \
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block<S, UPD, GRM, KM, FS>),                        \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block<S, UPD, GRM, KM, FS, KCC>),                   \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
     if (occ_out) {                                                                                                        \
-      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block<S, UPD, GRM, KM, FS>, SS_R, lds));          \
-    } else if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
+      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block<S, UPD, GRM, KM, FS, KCC>, SS_R, lds));     \
+    } else if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
                                   k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off, hk, hs);                   \
-    else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef, \
+    else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef, \
                             partials, d_skip, ntiles, ta, mark, ws_off, hk, hs);                                          \
+  } while (0)
+  // the default cycle's shapes (blocks of 15 behind 1 and 16 columns) run the instances with a compile-time k
+#define SS_GO3(UPD, GRM, KM, FS)                                                                                          \
+  do {                                                                                                                    \
+    if constexpr (S == 15 && KM == 1 && !UPD) {                                                                           \
+      if (k == 1 && kc_on) SS_GO4(UPD, GRM, KM, FS, 1); else SS_GO4(UPD, GRM, KM, FS, 0);                                 \
+    } else if constexpr (S == 15 && KM == 2 && !UPD) {                                                                    \
+      if (k == 16 && kc_on) SS_GO4(UPD, GRM, KM, FS, 16); else SS_GO4(UPD, GRM, KM, FS, 0);                               \
+    } else SS_GO4(UPD, GRM, KM, FS, 0);                                                                                   \
   } while (0)
 #define SS_GO(UPD, GRM)                                                                                                   \
   do {                                                                                                                    \
@@ -775,6 +975,28 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
     else SS_GO3(UPD, GRM, 0, false);                                                                                      \
   } while (0)
   int g = grid;
+  if constexpr (S == 15) {
+    static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);   // A/B switch
+    if (mode == 1 && mm_on && (k == 1 || k == 16)) {
+#define SS_MM(KCC)                                                                                                        \
+  do {                                                                                                                    \
+    if (lds > 64 * 1024)                                                                                                  \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_mm<S, KCC>),                                  \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
+    if (occ_out) {                                                                                                        \
+      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_mm<S, KCC>, SS_R, lds));                    \
+    } else if (ev) hipExtLaunchKernelGGL((k_ss_block_mm<S, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
+                                         ldv, coef, partials, d_skip, ntiles, mark);                                      \
+    else hipLaunchKernelGGL((k_ss_block_mm<S, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials,    \
+                            d_skip, ntiles, mark);                                                                        \
+  } while (0)
+      if (k == 1) SS_MM(1); else SS_MM(16);
+#undef SS_MM
+      NK_HIP(hipGetLastError());
+      return NK_OK;
+    }
+  }
+  static const bool kc_on = !(getenv("NK_SS_KCONST") && atoi(getenv("NK_SS_KCONST")) == 0);   // A/B switch
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
   else {                                    // sweep C: update only — no LDS tile
@@ -789,6 +1011,7 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   }
 #undef SS_GO
 #undef SS_GO3
+#undef SS_GO4
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

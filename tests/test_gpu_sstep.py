@@ -108,6 +108,38 @@ def test_sstep_newton_basis_matches_oracle_and_cgs2(nls, dev, which, s):
             torch.tensor(b, device=dev), fixed_iters=30)
 
 
+def test_sstep_block_left_at_its_first_pass_only_if_that_pass_was_good(nls, dev):
+    """The implicit second pass and its limit: with a smooth right-hand side (u = 0) and bounds 1.3× too wide a block
+    of 15 is still left at its first pass (departure 0.01) and the device reproduces the oracle; at 1.5× the first pass is 0.75
+    away from orthonormal — the oracle raises, the device counts a broken block, narrows 15 → 8 and returns the CGS2 iterate."""
+    import torch
+    P = R.Bratu2D(24)
+    u = P.u0()
+    A, b = P.jac(u).tocsr(), P.f(u)
+    lo, hi = R.gershgorin_interval(A)
+    Ad = torch.sparse_csr_tensor(torch.tensor(A.indptr, dtype=torch.int64), torch.tensor(A.indices, dtype=torch.int64),
+                                 torch.tensor(A.data), size=A.shape).to(dev)
+    bd = torch.tensor(b, device=dev)
+    xr, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho="cgs2")
+    for f, accepted in ((0.0, True), (0.15, True), (0.25, False)):
+        iv = (lo - f * (hi - lo), hi + f * (hi - lo))
+        G = nls.GMRES(P.n, restart=30, ortho="sstep", sstep_basis="newton").set_operator(lambda z: Ad @ z)
+        G.set_spectrum_interval(*iv)
+        x, gi = G.solve(bd, fixed_iters=30)
+        x = x.cpu().numpy()
+        bs, newton, broken = G.sstep_state()
+        assert gi["iters"] == 30 and newton
+        assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr)
+        if accepted:
+            xo, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", iv))
+            assert (bs, broken) == (15, 0) and np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
+        else:
+            with pytest.raises(R.SStepBreakdown, match="first pass"):
+                R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 15, "newton", iv))
+            x8, _ = R.gmres(lambda z: A @ z, b, restart=30, fixed_iters=30, ortho=("sstep", 8, "newton", iv))
+            assert (bs, broken) == (8, 1) and np.linalg.norm(x - x8) <= 1e-9 * np.linalg.norm(x8)
+
+
 def test_leja_nodes_and_interval_match_the_oracle(nls, dev):
     import ctypes as C
     from nonlinearsolve_jl_amd import _lib as L
