@@ -37,6 +37,7 @@ constexpr int SS_SMAX = 16;      // one 16-wide matrix-core tile of new columns
 constexpr int SS_TH = 8;         // scal[SS_TH + j] = θ_j; scal[0..5): first-application scale, 1/σ, σ, carried σ estimate, Newton flag
 constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ss_u2 __attribute__((ext_vector_type(2)));
 __device__ unsigned long long *g_ss_stamp = nullptr;   // development: phase time stamps of the scalar work (nk_ss_debug_stamps)
 #define SS_STAMP(i) do { if (g_ss_stamp != nullptr && threadIdx.x == 0) g_ss_stamp[i] = wall_clock64(); } while (0)
 
@@ -676,6 +677,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
     // straight-line pipeline: every prefetch is issued unconditionally (past the end: the workgroup's last tile again, a cache
     // hit) and an odd tile count runs its phantom tile with all rows masked (zeros into the Gram block, no stores) — no branch
     // around a batch of loads, so the wait in front of a register set's first use is vmcnt(loads issued behind it), not 0
+    // (requesting a set again right after it is staged — two tiles ahead — measured 1–2 µs SLOWER for the read-only sweep on
+    //  the same box: 27.1 / 48.3 against 26.0 / 46.1 µs behind 1 / 16 columns; the update sweep below keeps that order)
     for (int tile = tile0; tile < tile1; tile += 2) {
       prefetch(vr2, w2, tile + 1 < tile1 ? tile + 1 : tile1 - 1);
       process(vr, w, tile, true, [] {});
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   const int tpw = (ntiles + nwk - 1) / nwk;
   const int tile0 = me * tpw, tile1 = min(tile0 + tpw, ntiles);
   double vr[KC], w[S], vr2[KC], w2[S];
-  auto prefetch = [&](double (&vrx)[KC], double (&wx)[S], int tile) {
+  auto prefetch = [&](double (&vrx)[KC], double (&wx)[S], int tile) __attribute__((always_inline)) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const int64_t rc = r < n ? r : n - 1;
 #pragma unroll
@@ -759,7 +762,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
 #pragma unroll
     for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * ldv + rc];
   };
-  if (tile0 < tile1) prefetch(vr, w, tile0);   // in flight while T is formed
+  if (tile0 < tile1) {   // both register sets are in flight while T is formed
+    prefetch(vr, w, tile0);
+    prefetch(vr2, w2, tile0 + 1 < tile1 ? tile0 + 1 : tile1 - 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   // ---- T = [−U N ; N] in LDS (the tile is not in use yet), then each lane's share of it as matrix-core B operands
   double tb[NKS];
   {
@@ -815,14 +822,25 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
     const int col = mt * 16 + li;
     pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
   }
-  double *pq = sX + (k + (li < S ? li : S - 1)) * SS_P + wv * 64 + q4;   // where lane (i, q4) puts Q[row0 + q4 + 4·rr][i]
-  auto process = [&](double (&vr)[KC], double (&w)[S], int tile, bool valid) {
+  // where lane (i, q4) puts Q[row0 + q4 + 4·rr][i] (i = 15, the padding column of the 16-wide product: a spare column K of the
+  // tile — no branch)
+  double *pq = sX + (k + li) * SS_P + wv * 64 + q4;
+  // the block's columns as ONE raw buffer (the launcher checks that S·ldv·8 fits 32 bits)
+  const unsigned ldvb = (unsigned)ldv * 8u;
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)Wc, 0, (int)(unsigned)(((int64_t)(S - 1) * ldv + n) * 8), 0x00020000);
+  auto process = [&](double (&vr)[KC], double (&w)[S], int tile, bool valid, int next) __attribute__((always_inline)) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const bool ok = valid && r < n;
 #pragma unroll
     for (int j = 0; j < KC; ++j) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
 #pragma unroll
     for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
+    // the set is staged: request it again for the tile after next (past the end: the last tile once more, a cache hit) — every
+    // load then has two tiles' time to land. (sched_barrier: the machine scheduler otherwise sinks the loads to their uses.)
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch(vr, w, next);
+    __builtin_amdgcn_sched_barrier(0);
     // the update: 16 rows per instruction group, the result back into the X columns of the same rows
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -832,16 +850,19 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
       for (int ks = 0; ks < NKS; ++ks) a[ks] = pu[ks][g * 16];
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) q = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], tb[ks], q, 0, 0, 0);
-      if (li < S) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) pq[g * 16 + 4 * rr] = q[rr];
-      }
+      for (int rr = 0; rr < 4; ++rr) pq[g * 16 + 4 * rr] = q[rr];
     }
-    // the updated columns leave through the row-per-thread layout (coalesced)
+    // the updated columns leave through the row-per-thread layout (coalesced). Buffer stores: a lane without a row (ragged last
+    // tile, the phantom tile of an odd count) carries an out-of-range offset and the hardware drops it — `if (ok) store` is a
+    // branch around the stores, behind which the wait-count pass no longer knows how many operations follow a register set's
+    // loads and waits for the stores it has just issued at the top of the next tile.
+    const unsigned rbyte = (unsigned)r * 8u;
 #pragma unroll
     for (int c = 0; c < S; ++c) {
       const double qv = sX[(k + c) * SS_P + t];
-      if (ok) Wc[(size_t)c * ldv + r] = qv;
+      const unsigned off = ok ? (unsigned)c * ldvb + rbyte : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u2, qv), wrs, (int)off, 0, 0);
     }
     // Gram block [V Q]ᵀQ: 64 rows per wavefront, 4 per instruction
 #pragma unroll
@@ -860,17 +881,15 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
       }
     }
   };
-  // (sched_barrier: the machine scheduler otherwise sinks a prefetch below the LDS staging of the set it is meant to overlap
-  //  with — one register set less, and nothing in flight while a tile is staged)
-  for (int tile = tile0; tile < tile1; tile += 2) {
-    prefetch(vr2, w2, tile + 1 < tile1 ? tile + 1 : tile1 - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    process(vr, w, tile, true);
-    __builtin_amdgcn_sched_barrier(0);
-    prefetch(vr, w, tile + 2 < tile1 ? tile + 2 : tile1 - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    process(vr2, w2, tile + 1, tile + 1 < tile1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto pair = [&](int tile) __attribute__((always_inline)) {
+    process(vr, w, tile, true, tile + 2 < tile1 ? tile + 2 : tile1 - 1);
+    process(vr2, w2, tile + 1, tile + 1 < tile1, tile + 3 < tile1 ? tile + 3 : tile1 - 1);
+  };
+  // (first pair peeled: at the loop header the outstanding-load state of the entry edge then equals the back edge's, and the
+  //  waits inside the loop are the steady state's vmcnt(46 … 61) instead of the prologue's vmcnt(31 …))
+  if (tile0 < tile1) {
+    pair(tile0);
+    for (int tile = tile0 + 2; tile < tile1; tile += 2) pair(tile);
   }
   __syncthreads();   // (the scratch overlays rows the other wavefronts may still be reading)
 #pragma unroll
@@ -940,7 +959,6 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   //  workspace OVERLAYS the tile, so hosting costs the sweep no occupancy)
   const size_t wsd = fuse ? ss_ws_doubles(hk, hs, true) : 0;
   const size_t lds = (tile > wsd ? tile : wsd) * sizeof(double);
-  static const int ws_off = (getenv("NK_SS_BARRIERS") && atoi(getenv("NK_SS_BARRIERS")) != 0) ? 1 : 0;
   ss_tail_args ta;
   std::memset(&ta, 0, sizeof(ta));
   if (tap) ta = *tap;
@@ -974,10 +992,12 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
     else if (cls == 3) { if (fuse) SS_GO3(UPD, GRM, 3, (UPD != GRM)); else SS_GO3(UPD, GRM, 3, false); }                  \
     else SS_GO3(UPD, GRM, 0, false);                                                                                      \
   } while (0)
+  static const int ws_off = (getenv("NK_SS_BARRIERS") && atoi(getenv("NK_SS_BARRIERS")) != 0) ? 1 : 0;
   int g = grid;
   if constexpr (S == 15) {
     static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);   // A/B switch
-    if (mode == 1 && mm_on && (k == 1 || k == 16)) {
+    if (mode == 1 && mm_on && (k == 1 || k == 16) && (occ_out || (int64_t)S * ldv * 8 < ((int64_t)1 << 32) - 8)) {
+      const size_t lds = (size_t)(k + S + 1) * SS_P * sizeof(double);   // the tile + the spare column
 #define SS_MM(KCC)                                                                                                        \
   do {                                                                                                                    \
     if (lds > 64 * 1024)                                                                                                  \
