@@ -69,7 +69,8 @@ def test_resident_powers_bratu_bit_exact(nls, dev, ns, s):
 
 
 @pytest.mark.parametrize("n,hbw,per_row", [(5000, 3, 5), (70000, 1000, 5), (300000, 1024, 8), (150000, 700, 16),
-                                            (1048576, 1024, 5), (1300000, 900, 4)])
+                                            (1048576, 1024, 5), (1300000, 900, 4), (500000, 1000, 5), (523000, 1024, 3),
+                                            (1040000, 17, 5)])
 def test_resident_powers_random_banded(nls, dev, n, hbw, per_row):
     """Ragged rows (1 … W entries), partial last band, every register layout (1 / 2 / 4 / 6 rows per thread; 5 / 8 / 16 slots)."""
     import torch
@@ -96,10 +97,12 @@ def test_streaming_fallback_for_ineligible_matrices(nls, dev):
         assert np.array_equal(Y.cpu().numpy(), _powers_ref(A, x, 3, theta, 1.5))
 
 
-def test_resident_powers_under_uneven_load(nls, dev):
-    """a second stream keeps part of the chip busy while the band hand-offs run: every word of 15 powers, 20 launches"""
+@pytest.mark.parametrize("ns", [512, 1024])
+def test_resident_powers_under_uneven_load(nls, dev, ns):
+    """a second stream keeps part of the chip busy while the band hand-offs run: every word of 15 powers, 20 launches
+    (512²: bands of one slice; 1024²: the headline shape, four)"""
     import torch
-    p = R.Bratu2D(512)
+    p = R.Bratu2D(ns)
     rng = np.random.default_rng(11)
     J = p.jac(rng.standard_normal(p.n) * 0.1)
     A = nls.CSRMatrix.from_scipy(J)
