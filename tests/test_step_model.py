@@ -55,6 +55,8 @@ def test_byte_counts_of_the_headline_step():
 def test_canonical_names():
     assert step_model.canonical("void k_ss_block<15, false, true, 1, false>(long, int, double*)") == "k_ss_block<A>"
     assert step_model.canonical("k_ss_block<15, true, true, 2, false>") == "k_ss_block<B>"
+    assert step_model.canonical("void k_ss_block_mm<15, 16>(long, double*, long)") == "k_ss_block<B>"
+    assert step_model.canonical("k_ss_block<15, false, true, 2, true, 16>") == "k_ss_block<A>"
     assert step_model.canonical("k_ss_block<15, true, false, 1, true>") == "k_ss_block<C>"
     assert step_model.canonical("k_spmv_stream<1024, false, true>") == "k_spmv_stream"
     assert step_model.canonical("void k_spmv_powers<4, 5>(pw_args)") == "k_spmv_powers"
