@@ -43,6 +43,8 @@ struct pw_args {
   int ns;
   double c_lap;
   const double *diag;
+  // k_spmv_powers_seg: SEG segments of seg_len rows each (nb bands per segment), bands of a segment on a ring or not
+  int seg_len, ring;
 };
 
 __device__ __forceinline__ int pw_band_of(int bid, int nb) {   // block b runs on XCD b % 8: neighbouring bands share an L2
@@ -242,9 +244,139 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
   }
 }
 
+// The same kernel for matrices that are banded only SEGMENT BY SEGMENT: n = SEG·M rows, segment σ = rows [σM, (σ+1)M) — the
+// species of a reaction–diffusion system in the reference's (i, j, species) ordering (docs/src/tutorials/large_systems.md: the
+// Brusselator couples u(i, j) with v(i, j), M rows apart) — and / or whose bands close to a RING (periodic boundaries: the first
+// grid line couples with the last). A workgroup owns band b OF EVERY SEGMENT (rows σM + b·RB … of each), so the coupling
+// between segments never leaves the workgroup; its vector buffer is SEG × [halo above | RB own rows | halo below]; the hand-off
+// is the one of k_spmv_powers per segment (one flag per band behind all of them), with band 0's upper neighbour being band
+// nb − 1 on a ring. A column c of a row of band b maps to segment c / M, offset (c mod M) − b·RB, shifted by ±M on a ring when
+// that brings it into [−1024, RB + 1024) — fixed at load time, the power loop is the plain one. Bit-identical row sums as before.
+template <int RPS, int W, int SEG>
+__global__ __launch_bounds__(PW_T) void k_spmv_powers_seg(const pw_args a) {
+  if (a.d_skip != nullptr && *a.d_skip != 0) return;
+  extern __shared__ double pw_x[];
+  __shared__ int s_abort;
+  constexpr int RB = PW_T * RPS, XS = RB + 2 * PW_HALO, XN = SEG * XS, NSL = SEG * RPS;
+  static_assert(W <= 8, "the slices are staged through LDS");
+  const int t = threadIdx.x;
+  const int b = pw_band_of(blockIdx.x, a.nb);
+  const int M = a.seg_len, b0 = b * RB;
+  const bool ring = a.ring != 0;
+  double *xa = pw_x, *xb = pw_x + XN;
+
+  double v[NSL][W];
+  int ci[NSL][W];
+  int len[NSL];
+  {
+    double *sv = pw_x;
+    int *sc = reinterpret_cast<int *>(pw_x + (size_t)PW_T * W);
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int sg = i / RPS, j = i % RPS;
+      const int lfirst = b0 + PW_T * j;                 // the slice's first row within its segment
+      const bool any = lfirst < M;                       // (uniform)
+      const bool valid = lfirst + t < M;
+      const int rfirst = sg * M + lfirst, r = rfirst + t;
+      const int rc = valid ? r : (any ? sg * M + M - 1 : 0);
+      const int k0 = a.rowptr[rc], k1 = a.rowptr[rc + 1];
+      const int rl = any ? sg * M + (lfirst + PW_T <= M ? lfirst + PW_T : M) : 0;
+      const int kb = any ? a.rowptr[rfirst] : 0, ke = any ? a.rowptr[rl] : 0;
+      len[i] = valid ? k1 - k0 : 0;
+#pragma unroll
+      for (int jj = 0; jj < W; ++jj) {
+        const int e = t + PW_T * jj;
+        if (kb + e < ke) { sv[e] = a.val[kb + e]; sc[e] = a.col[kb + e]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < W; ++jj) {
+        const int e = (jj < len[i]) ? k0 - kb + jj : 0;
+        const double vv = sv[e];
+        const int c = sc[e];
+        const int sgc = SEG > 1 ? c / M : 0;
+        int d = c - sgc * M - b0;
+        if (ring) d = d < -PW_HALO ? d + M : (d >= RB + PW_HALO ? d - M : d);
+        v[i][jj] = (jj < len[i]) ? vv : 0.0;
+        ci[i][jj] = (jj < len[i]) ? sgc * XS + PW_HALO + d : sg * XS + PW_HALO + PW_T * j + t;
+      }
+      __syncthreads();
+    }
+  }
+  for (int idx = t; idx < XN; idx += PW_T) {
+    const int sg = idx / XS;
+    int l = b0 - PW_HALO + (idx - sg * XS);
+    if (ring) l = l < 0 ? l + M : (l >= M ? l - M : l);
+    xa[idx] = (l >= 0 && l < M) ? a.x0[sg * M + l] : 0.0;
+    xb[idx] = 0.0;
+  }
+  if (t == 0) s_abort = 0;
+  __syncthreads();
+
+  const bool shifted = a.theta != nullptr;
+  const int nup = b > 0 ? b - 1 : (ring ? a.nb - 1 : -1), ndn = b + 1 < a.nb ? b + 1 : (ring ? 0 : -1);
+  for (int p = 0; p < a.s; ++p) {
+    const double *xin = (p & 1) ? xb : xa;
+    double *xout = (p & 1) ? xa : xb;
+    const double *osp = (p == 0) ? a.scal_first : a.scal_rest;
+    const double os = osp ? *osp : 1.0;
+    const double th = shifted ? a.theta[p] : 0.0;
+    double *ycol = a.Y + (int64_t)p * a.ldy;
+    const bool pub = p + 1 < a.s;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int sg = i / RPS, j = i % RPS;
+      const int lrow = b0 + PW_T * j + t, own = sg * XS + PW_HALO + PW_T * j + t;
+      double sum = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < W; ++jj) {
+        const double pr = v[i][jj] * xin[ci[i][jj]];
+        sum = (jj < len[i]) ? sum + pr : sum;
+      }
+      double out = shifted ? sum - th * xin[own] : sum;
+      out = osp ? os * out : out;
+      if (lrow < M) {
+        xout[own] = out;
+        if (pub && (j == 0 || j == RPS - 1)) pw_store_sc1(ycol + sg * M + lrow, out);   // rows a neighbour band reads
+        else ycol[sg * M + lrow] = out;
+      }
+    }
+    if (!pub) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0 && !((a.variant & 256) && b == 0))
+      __hip_atomic_store(a.flags + (size_t)b * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0 && nup >= 0) {
+      if (!pw_wait(a.flags + (size_t)nup * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+    }
+    if (t == 64 && ndn >= 0) {
+      if (!pw_wait(a.flags + (size_t)ndn * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    {
+      double hu[SEG], hd[SEG];
+      int lu = b0 - PW_HALO + t, ld = b0 + RB + t;
+      if (ring) { lu = lu < 0 ? lu + M : lu; ld = ld >= M ? ld - M : ld; }
+#pragma unroll
+      for (int sg = 0; sg < SEG; ++sg) {
+        hu[sg] = (nup >= 0 && lu >= 0 && lu < M) ? pw_load_sc1(ycol + sg * M + lu) : 0.0;
+        hd[sg] = (ndn >= 0 && ld < M) ? pw_load_sc1(ycol + sg * M + ld) : 0.0;
+      }
+#pragma unroll
+      for (int sg = 0; sg < SEG; ++sg) {
+        xout[sg * XS + t] = hu[sg];
+        xout[sg * XS + PW_HALO + RB + t] = hd[sg];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------------------- host side
 struct nk_powers_plan {
   int rpt = 0, w = 0, nb = 0;
+  int seg = 0, ring = 0, seg_len = 0;   // seg > 0: k_spmv_powers_seg<rpt, w, seg> (rpt slices per segment and band)
   uint64_t *d_flags = nullptr;
   uint64_t *h_err = nullptr, *h_err_dev = nullptr;   // pinned, coherent: {time-outs, bound in ticks}
   uint64_t epoch = 0;
@@ -307,6 +439,43 @@ static int pw_dispatch(nk_ctx *ctx, int rpt, int w, const pw_args &a, bool query
   NK_FAIL(NK_E_INVALID, "internal: no matrix-powers kernel for %d rows per thread × %d entries per row", rpt, w);
 }
 
+template <int RPS, int W, int SEG>
+static int pw_launch_seg(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
+  constexpr size_t lds_x = (size_t)2 * SEG * (PW_T * RPS + 2 * PW_HALO) * sizeof(double), lds_m = (size_t)PW_T * W * 12;
+  constexpr size_t lds = lds_x > lds_m ? lds_x : lds_m;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers_seg<RPS, W, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    attr_set = true;
+  }
+  if (query) {
+    NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers_seg<RPS, W, SEG>, PW_T, lds));
+    return NK_OK;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
+    hipExtLaunchKernelGGL((k_spmv_powers_seg<RPS, W, SEG>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
+  else
+    hipLaunchKernelGGL((k_spmv_powers_seg<RPS, W, SEG>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+// (slices per segment, slots per row, segments) the segmented kernel is compiled for: SEG·RPS·W ≤ 20 register-resident slots
+static bool pw_seg_shape(int rps, int w, int seg) {
+  if (seg == 1) return (w == 5 && (rps == 1 || rps == 2 || rps == 4)) || (w == 8 && (rps == 1 || rps == 2));
+  if (seg == 2) return (w == 5 && (rps == 1 || rps == 2)) || (w == 8 && rps == 1);
+  return false;
+}
+static int pw_dispatch_seg(nk_ctx *ctx, int rps, int w, int seg, const pw_args &a, bool query, int *occ) {
+#define PW_SEG(R, WW, SG) if (rps == R && w == WW && seg == SG) return pw_launch_seg<R, WW, SG>(ctx, a, query, occ)
+  PW_SEG(1, 5, 1); PW_SEG(2, 5, 1); PW_SEG(4, 5, 1); PW_SEG(1, 8, 1); PW_SEG(2, 8, 1);
+  PW_SEG(1, 5, 2); PW_SEG(2, 5, 2); PW_SEG(1, 8, 2);
+#undef PW_SEG
+  NK_FAIL(NK_E_INVALID, "internal: no segmented matrix-powers kernel for %d slices × %d slots × %d segments", rps, w, seg);
+}
+
 static int pw_plan_new(int rpt, int w, int nb, nk_powers_plan **out) {
   nk_powers_plan *P = new nk_powers_plan();
   auto guard = nk_make_guard(P, [](nk_powers_plan *p) { nk_powers_plan_destroy(p); });
@@ -343,16 +512,47 @@ static int pw_plan(nk_csr *A) {
   if ((w == 8 && rpt > 2) || (w == 16 && rpt > 1)) return NK_OK;   // register budget (128 VGPRs at 1024 threads): RPT·W ≤ 30 slots
   const int64_t rb = (int64_t)PW_T * rpt;
   const int nb = (int)((n + rb - 1) / rb);
-  for (int64_t r = 0; r < n; ++r) {   // every column of a band within one slice of its neighbours
+  bool plain = true;
+  for (int64_t r = 0; r < n && plain; ++r) {   // every column of a band within one slice of its neighbours
     const int64_t b0 = (r / rb) * rb, lo = b0 - PW_HALO, hi = b0 + rb + PW_HALO;
     for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k)
-      if (A->h_col[k] < lo || A->h_col[k] >= hi) return NK_OK;
+      if (A->h_col[k] < lo || A->h_col[k] >= hi) { plain = false; break; }
   }
   pw_args probe{};
   int occ = 0;
-  NK_TRY(pw_dispatch(ctx, rpt, w, probe, true, &occ));
-  if (occ < 1 || nb > ctx->num_cus * occ) return NK_OK;
-  NK_TRY(pw_plan_new(rpt, w, nb, &A->pw));
+  if (plain) {
+    NK_TRY(pw_dispatch(ctx, rpt, w, probe, true, &occ));
+    if (occ < 1 || nb > ctx->num_cus * occ) return NK_OK;
+    NK_TRY(pw_plan_new(rpt, w, nb, &A->pw));
+    return NK_OK;
+  }
+  // banded segment by segment and / or on a ring (k_spmv_powers_seg): one segment on a ring, two segments, two on rings
+  for (int lay = 0; lay < 3; ++lay) {
+    const int seg = lay == 0 ? 1 : 2, ring = lay == 1 ? 0 : 1;
+    if (n % seg) continue;
+    const int64_t M = n / seg, pc = (M + ctx->num_cus - 1) / ctx->num_cus;
+    const int nd = (int)((pc + PW_T - 1) / PW_T);
+    const int rps = nd <= 1 ? 1 : (nd <= 2 ? 2 : (nd <= 4 ? 4 : 0));
+    if (!rps || !pw_seg_shape(rps, w, seg)) continue;
+    const int64_t RB = (int64_t)PW_T * rps;
+    if (ring && (M % RB)) continue;                 // (a ragged last band has no well-defined ring neighbour rows)
+    const int nbs = (int)((M + RB - 1) / RB);
+    bool ok = true;
+    for (int64_t r = 0; r < n && ok; ++r) {
+      const int64_t b0 = ((r % M) / RB) * RB;
+      for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k) {
+        int64_t d = (int64_t)A->h_col[k] % M - b0;
+        if (ring) d = d < -PW_HALO ? d + M : (d >= RB + PW_HALO ? d - M : d);
+        if (d < -PW_HALO || d >= RB + PW_HALO) { ok = false; break; }
+      }
+    }
+    if (!ok) continue;
+    NK_TRY(pw_dispatch_seg(ctx, rps, w, seg, probe, true, &occ));
+    if (occ < 1 || nbs > ctx->num_cus * occ) continue;
+    NK_TRY(pw_plan_new(rps, w, nbs, &A->pw));
+    A->pw->seg = seg; A->pw->ring = ring; A->pw->seg_len = (int)M;
+    return NK_OK;
+  }
   return NK_OK;
 }
 bool nk_csr_powers_ready(nk_csr *A) {
@@ -372,7 +572,7 @@ int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, i
   NK_REQUIRE(s >= 1 && s <= 200, "matrix powers: 1 ≤ s ≤ 200");
   nk_ctx *ctx = A->ctx;
   nk_powers_plan *P = A->pw;
-  pw_args a;
+  pw_args a{};
   a.nrows = (int)A->nrows; a.nb = P->nb; a.s = s; a.variant = pw_variant();
   a.rowptr = A->d_rowptr; a.col = A->d_col; a.val = A->d_val;
   a.x0 = d_x0; a.Y = d_Y; a.ldy = ldy;
@@ -381,6 +581,10 @@ int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, i
   ctx->stats.op_applies += s;
   nk_prof_scope prof_(ctx, NK_K_POWERS,
                       (double)s * (12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows));
+  if (P->seg > 0) {
+    a.seg_len = P->seg_len; a.ring = P->ring;
+    return pw_dispatch_seg(ctx, P->rpt, P->w, P->seg, a, false, nullptr);
+  }
   return pw_dispatch(ctx, P->rpt, P->w, a, false, nullptr);
 }
 

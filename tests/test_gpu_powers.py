@@ -85,6 +85,69 @@ def test_resident_powers_random_banded(nls, dev, n, hbw, per_row):
     assert np.array_equal(Y.cpu().numpy(), ref)
 
 
+def _periodic_laplacian(N, seed):
+    """5-point Laplacian on an N × N torus with a random positive diagonal shift: banded only on a RING of bands"""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(N * N).reshape(N, N)
+    rows, cols, vals = [], [], []
+    for dj, di, w in ((0, 0, 4.0), (0, 1, -1.0), (0, -1, -1.0), (1, 0, -1.0), (-1, 0, -1.0)):
+        rows.append(idx.ravel())
+        cols.append(np.roll(np.roll(idx, -dj, axis=0), -di, axis=1).ravel())
+        vals.append(np.full(N * N, w) + (rng.random(N * N) if (dj, di) == (0, 0) else 0.0))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N * N, N * N))
+    A.sort_indices()
+    return A
+
+
+def _two_segments(M, hbw, seed):
+    """n = 2 M rows: two banded segments (≤ 3 entries within ±hbw, ragged) coupled row by row (r ↔ r ± M, and a few rows away)"""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for sgm in range(2):
+        r = np.repeat(np.arange(M, dtype=np.int64), 3)
+        off = rng.integers(-hbw, hbw + 1, size=3 * M)
+        off[::3] = 0
+        c = np.clip(r + off, 0, M - 1)
+        keep = rng.random(3 * M) < 0.75
+        keep[::3] = True
+        blocks.append(sp.csr_matrix((rng.standard_normal(int(keep.sum())) * 0.3, (r[keep], c[keep])), shape=(M, M)))
+    cpl = [sp.diags(rng.standard_normal(M) * 0.2, 0, shape=(M, M)).tocsr() for _ in range(2)]
+    cpl[0] = cpl[0] + sp.diags(rng.standard_normal(M - 3) * 0.1, 3, shape=(M, M))     # u_r ← v_{r+3}
+    A = sp.bmat([[blocks[0], cpl[0]], [cpl[1], blocks[1]]], format="csr")
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("case", ["brusselator64", "brusselator512", "torus256", "torus1024", "two_segments", "two_segments_small"])
+def test_resident_powers_segmented_and_ring_layouts(nls, dev, case):
+    """Matrices that are banded only segment by segment (the species of a reaction–diffusion system in (i, j, species) order: the
+    Brusselator of config C5 / docs/src/tutorials/large_systems.md) and / or on a ring (periodic boundaries): the workgroup that
+    owns band b of EVERY segment keeps the coupling on the chip — k_spmv_powers_seg, bit-identical to streaming launches."""
+    import torch
+    rng = np.random.default_rng(3)
+    if case.startswith("brusselator"):
+        P = R.Brusselator2D(int(case[len("brusselator"):]))
+        A = P.jac(P.u0() + 0.1 * rng.standard_normal(P.n)).tocsr()     # periodic 5-point stencil per species + the u ↔ v coupling
+    elif case.startswith("torus"):
+        A = _periodic_laplacian(int(case[len("torus"):]), 4)
+    else:
+        A = _two_segments(300000 if case == "two_segments" else 5000, 1000 if case == "two_segments" else 40, 5)
+    A.sort_indices()
+    n = A.shape[0]
+    M = nls.CSRMatrix.from_scipy(A)
+    x = rng.standard_normal(n)
+    lam = float(abs(A).sum(axis=1).max())
+    s = 15 if n > 100000 else 6
+    theta = (0.5 + 0.4 * np.cos(np.arange(s))) * lam
+    ref = _powers_ref(A, x, s, theta, 2.0 / lam)
+    dx = torch.tensor(x, device=dev)
+    for rep in range(3):
+        Y, resident = M.powers(dx, s, theta=theta, scale=2.0 / lam)
+        assert resident, case
+        assert np.array_equal(Y.cpu().numpy(), ref), (case, rep)
+
+
 def test_streaming_fallback_for_ineligible_matrices(nls, dev):
     """wide band, long rows, too many rows: s streaming launches, same bits"""
     import torch
@@ -145,6 +208,36 @@ def test_sstep_gmres_with_resident_powers_equals_streaming(nls, dev, monkeypatch
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
     assert outs[0] == outs[1], outs
+
+
+def test_brusselator_trust_region_with_resident_powers_equals_streaming(nls, dev):
+    """config C5's shape (Brusselator, TrustRegion + s-step GMRES on the CSR Jacobian): the segmented resident kernel builds the
+    blocks — same iterates, bit for bit, as with NK_SPMV_POWERS=0"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, nonlinearsolve_jl_amd as nls\n"
+        "ctx = nls.default_context()\n"
+        "prob = nls.NonlinearProblem(nls.Brusselator2D(128))\n"
+        "alg = nls.TrustRegion(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho='sstep', fixed_iters=30),"
+        " concrete_jac=True)\n"
+        "cache = nls.init(prob, alg, abstol=1e-300, maxiters=50)\n"
+        "ctx.profile_enable(True)\n"
+        "for _ in range(3): cache.step()\n"
+        "rep = ctx.profile_report()\n"
+        "u = cache.u\n"
+        "u = np.asarray(u.cpu() if hasattr(u, 'cpu') else u)\n"
+        "import hashlib; print('HASH', hashlib.sha256(u.tobytes()).hexdigest(), float(np.abs(u).max()), 'spmv_powers' in rep)\n")
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, NK_SPMV_POWERS=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1].split())
+    assert outs[0][1:3] == outs[1][1:3], outs
+    assert outs[0][3] == "True" and outs[1][3] == "False", outs
 
 
 def test_matrix_free_operator_takes_the_resident_kernel_too(nls, dev):
