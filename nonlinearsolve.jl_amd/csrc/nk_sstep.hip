@@ -674,8 +674,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
   };
   if (tile0 < tile1) prefetch(vr, w, tile0);
   if constexpr (DB && KC > 0) {
-    // straight-line pipeline: every prefetch is issued unconditionally (past the end: the workgroup's last tile again, a cache
-    // hit) and an odd tile count runs its phantom tile with all rows masked (zeros into the Gram block, no stores) — no branch
+    // straight-line pipeline: every prefetch is issued unconditionally (past the end: the workgroup's last tile again; the update sweep below reads 2 KB of column 0 instead — measured neutral to
+    // 0.6 µs slower here) and an odd tile count runs its phantom tile with all rows masked (zeros into the Gram block, no stores) — no branch
     // around a batch of loads, so the wait in front of a register set's first use is vmcnt(loads issued behind it), not 0
     // (requesting a set again right after it is staged — two tiles ahead — measured 1–2 µs SLOWER for the read-only sweep on
     //  the same box: 27.1 / 48.3 against 26.0 / 46.1 µs behind 1 / 16 columns; the update sweep below keeps that order)
@@ -754,17 +754,22 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   const int tpw = (ntiles + nwk - 1) / nwk;
   const int tile0 = me * tpw, tile1 = min(tile0 + tpw, ntiles);
   double vr[KC], w[S], vr2[KC], w2[S];
+  // (tile < 0: a prefetch past the workgroup's last tile — issued all the same, so that the waits stay exact — reads 2 KB of
+  //  column 0 k + S times over: its own last tile again was 62 KB per workgroup, 32 MB over the grid = the whole L2, +9 % HBM
+  //  reads by the counters)
   auto prefetch = [&](double (&vrx)[KC], double (&wx)[S], int tile) __attribute__((always_inline)) {
-    const int64_t r = (int64_t)tile * SS_R + t;
+    const int64_t r = (int64_t)(tile < 0 ? tile0 : tile) * SS_R + t;
     const int64_t rc = r < n ? r : n - 1;
+    const size_t cs = tile < 0 ? 0 : (size_t)ldv;
+    const double *__restrict__ Wr = tile < 0 ? V : Wc;
 #pragma unroll
-    for (int c = 0; c < S; ++c) wx[c] = Wc[(size_t)c * ldv + rc];
+    for (int c = 0; c < S; ++c) wx[c] = Wr[(size_t)c * cs + rc];
 #pragma unroll
-    for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * ldv + rc];
+    for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * cs + rc];
   };
   if (tile0 < tile1) {   // both register sets are in flight while T is formed
     prefetch(vr, w, tile0);
-    prefetch(vr2, w2, tile0 + 1 < tile1 ? tile0 + 1 : tile1 - 1);
+    prefetch(vr2, w2, tile0 + 1 < tile1 ? tile0 + 1 : -1);
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- T = [−U N ; N] in LDS (the tile is not in use yet), then each lane's share of it as matrix-core B operands
@@ -882,8 +887,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
     }
   };
   auto pair = [&](int tile) __attribute__((always_inline)) {
-    process(vr, w, tile, true, tile + 2 < tile1 ? tile + 2 : tile1 - 1);
-    process(vr2, w2, tile + 1, tile + 1 < tile1, tile + 3 < tile1 ? tile + 3 : tile1 - 1);
+    process(vr, w, tile, true, tile + 2 < tile1 ? tile + 2 : -1);
+    process(vr2, w2, tile + 1, tile + 1 < tile1, tile + 3 < tile1 ? tile + 3 : -1);
   };
   // (first pair peeled: at the loop header the outstanding-load state of the entry edge then equals the back edge's, and the
   //  waits inside the loop are the steady state's vmcnt(46 … 61) instead of the prologue's vmcnt(31 …))

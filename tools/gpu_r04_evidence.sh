@@ -17,6 +17,10 @@ B="--cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --steps 100 --warmup 10"
 NK_SPMV_POWERS=0 timeout 200 python bench.py $B < /dev/null > $O/bench_csr_streaming_spmv.json 2> /dev/null
 timeout 200 python bench.py $B --matfree < /dev/null > $O/bench_matfree.json 2> /dev/null
 timeout 200 python bench.py $B --workload c5 < /dev/null > $O/bench_c5_1gpu.json 2> /dev/null
+NK_SPMV_POWERS=0 timeout 200 python bench.py $B --workload c5 < /dev/null > $O/bench_c5_1gpu_streaming_spmv.json 2> /dev/null
+NK_SS_MM=0 NK_SS_KCONST=0 timeout 200 python bench.py $B0 < /dev/null > $O/bench_csr_round3_sweeps.json 2> /dev/null
+( echo "== round-3 sweep kernels (NK_SS_MM=0 NK_SS_KCONST=0)"; NK_SS_MM=0 NK_SS_KCONST=0 timeout 200 python tools/sweep_shapes_bench.py 1048576 16777216 2>&1 | grep sweep;
+  echo "== round-4 sweep kernels (default)"; timeout 200 python tools/sweep_shapes_bench.py 1048576 16777216 2>&1 | grep sweep ) > $O/sweep_shapes.txt
 if [ "$MODE" = "full" ]; then
   timeout 200 python bench.py $B --ortho dcgs2 < /dev/null > $O/bench_csr_dcgs2.json 2> /dev/null
   timeout 300 python bench.py $B --workload c4 --steps 10 --warmup 2 < /dev/null > $O/bench_c4size_1gpu.json 2> /dev/null
