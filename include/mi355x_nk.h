@@ -396,10 +396,17 @@ int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace);
  *   Y[:, p] = scale·(A Y[:, p−1] − θ_p Y[:, p−1]),  p = 0 … s−1,  Y[:, −1] = x   (theta: s host values, NULL = plain powers;
  * ldy ≥ local rows). A banded matrix small enough to be held in the chip's vector registers (≤ #CUs × 6144 rows, ≤ 5 / 8 / 16
  * entries per row, columns within ±1024 rows of their band; one rank) takes ONE launch that reads the matrix once
- * (*resident = 1, csrc/nk_powers.hip); any other matrix takes s streaming SpMV launches. The columns are bit-identical
- * either way. NK_SPMV_POWERS=0 disables the resident kernel. */
+ * (*resident = 1, csrc/nk_powers.hip) — also a matrix made of two equal segments that is banded segment by segment (the
+ * (i, j, species) ordering of a two-species system, docs/src/tutorials/large_systems.md) and / or whose bands close to a ring
+ * (periodic boundaries); any other matrix takes s streaming SpMV launches. The columns are bit-identical either way.
+ * NK_SPMV_POWERS=0 disables the resident kernel. */
 int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy, int s, const double *theta, double scale, int memspace,
                   int *resident);
+/* Which form of the resident kernel a CSR PATTERN (global column ids, one rank) fits on a device with num_cus compute units —
+ * host arithmetic only, no device needed: layout[0] = 0 none (streaming launches), 1 plain bands, 2 segments and / or ring;
+ * [1] slices of 1024 rows per band (and segment), [2] register slots per row (5 / 8 / 16), [3] bands (= workgroups),
+ * [4] segments, [5] 1 = the bands of a segment close to a ring. (The device additionally needs all bands resident at once.) */
+int nk_csr_powers_layout(int64_t nrows, const int32_t *rowptr, const int32_t *col, int num_cus, int layout[6]);
 /* out_j = Σ_i A_ij² — diag(AᵀA), what LevenbergMarquardt's damping takes its DᵀD from (`sum!(abs2, J_diag_cache, J')`,
  * levenberg_marquardt.jl:133-148). Row-partitioned matrices: the same reverse halo exchange as nk_spmv_t. */
 int nk_csr_colsumsq(nk_csr *A, double *out, int memspace);

@@ -143,6 +143,7 @@ SIGNATURES = {
     "nk_spmv": (_I, [_P, _P, _P, _I]),
     "nk_spmv_t": (_I, [_P, _P, _P, _I]),
     "nk_csr_powers": (_I, [_P, _P, _P, _L, _I, _P, _D, _I, _P]),
+    "nk_csr_powers_layout": (_I, [_L, _P, _P, _I, _P]),
     "nk_csr_colsumsq": (_I, [_P, _P, _I]),
     "nk_gmres_set_normal_form_damping": (_I, [_P, _P, C.c_double]),
     "nk_gmres_set_shift": (_I, [_P, C.c_double]),

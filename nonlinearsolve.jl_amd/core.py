@@ -341,6 +341,19 @@ class CSRMatrix:
                                     float(scale), ms, C.byref(res)))
         return Y.reshape(s, n), bool(res.value)
 
+    @staticmethod
+    def powers_layout(A, num_cus: int = 256):
+        """Which form of the resident matrix-powers kernel a SciPy CSR pattern fits on a device with `num_cus` compute units
+        (host arithmetic only, nk_csr_powers_layout): dict(kind = 'none' | 'bands' | 'segments', slices, slots, bands, segments, ring)"""
+        import numpy as _np
+        A = A.tocsr()
+        rp = _np.ascontiguousarray(A.indptr, dtype=_np.int32)
+        ci = _np.ascontiguousarray(A.indices, dtype=_np.int32)
+        out = (C.c_int * 6)()
+        check(L.lib().nk_csr_powers_layout(int(A.shape[0]), C.c_void_p(rp.ctypes.data), C.c_void_p(ci.ctypes.data), int(num_cus), out))
+        return {"kind": ("none", "bands", "segments")[out[0]], "slices": out[1], "slots": out[2], "bands": out[3],
+                "segments": out[4], "ring": bool(out[5])}
+
     def rmatvec(self, x, out=None):
         n = self.info()["nrows_local"]
         px, ms, _k = _ptr(x, n)

@@ -494,64 +494,90 @@ static int pw_plan_new(int rpt, int w, int nb, nk_powers_plan **out) {
   return NK_OK;
 }
 
+// Which layout of the resident kernel a pattern fits — host arithmetic only (no device): candidates in the order plain bands, one
+// segment on a ring, two segments, two segments on rings. `skip` candidates have been rejected by the caller (occupancy).
+struct pw_layout {
+  int kind = 0;   // 0 none, 1 plain bands (k_spmv_powers), 2 segments / ring (k_spmv_powers_seg)
+  int rpt = 0, w = 0, nb = 0, seg = 0, ring = 0;
+  int64_t M = 0;
+};
+static pw_layout pw_find_layout(int64_t n, const int32_t *rowptr, const int32_t *col, int num_cus, int skip) {
+  pw_layout L;
+  if (n < 1 || num_cus < 1) return L;
+  int maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) maxlen = std::max(maxlen, (int)(rowptr[r + 1] - rowptr[r]));
+  const int w = maxlen <= 5 ? 5 : (maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 0));
+  if (!w) return L;
+  for (int lay = skip; lay < 4; ++lay) {
+    if (lay == 0) {   // plain bands of 1024·rpt rows, every column of a band within one slice of it
+      const int64_t per_cu = (n + num_cus - 1) / num_cus;
+      const int need = (int)((per_cu + PW_T - 1) / PW_T);
+      const int rpt = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 6 ? 6 : 0)));
+      if (!rpt) continue;
+      if ((w == 8 && rpt > 2) || (w == 16 && rpt > 1)) continue;   // register budget (128 VGPRs at 1024 threads): RPT·W ≤ 30 slots
+      const int64_t rb = (int64_t)PW_T * rpt;
+      bool ok = true;
+      for (int64_t r = 0; r < n && ok; ++r) {
+        const int64_t b0 = (r / rb) * rb, lo = b0 - PW_HALO, hi = b0 + rb + PW_HALO;
+        for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+          if (col[k] < lo || col[k] >= hi) { ok = false; break; }
+      }
+      if (!ok) continue;
+      L.kind = 1; L.rpt = rpt; L.w = w; L.nb = (int)((n + rb - 1) / rb); L.seg = 1; L.ring = 0; L.M = n;
+      return L;
+    }
+    // banded segment by segment and / or on a ring (k_spmv_powers_seg)
+    const int seg = lay == 1 ? 1 : 2, ring = lay == 2 ? 0 : 1;
+    if (n % seg) continue;
+    const int64_t M = n / seg, pc = (M + num_cus - 1) / num_cus;
+    const int nd = (int)((pc + PW_T - 1) / PW_T);
+    const int rps = nd <= 1 ? 1 : (nd <= 2 ? 2 : (nd <= 4 ? 4 : 0));
+    if (!rps || !pw_seg_shape(rps, w, seg)) continue;
+    const int64_t RB = (int64_t)PW_T * rps;
+    if (ring && (M % RB)) continue;                 // (a ragged last band has no well-defined ring neighbour rows)
+    bool ok = true;
+    for (int64_t r = 0; r < n && ok; ++r) {
+      const int64_t b0 = ((r % M) / RB) * RB;
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        if (col[k] < 0 || col[k] >= n) { ok = false; break; }
+        int64_t d = (int64_t)col[k] % M - b0;
+        if (ring) d = d < -PW_HALO ? d + M : (d >= RB + PW_HALO ? d - M : d);
+        if (d < -PW_HALO || d >= RB + PW_HALO) { ok = false; break; }
+      }
+    }
+    if (!ok) continue;
+    L.kind = 2; L.rpt = rps; L.w = w; L.nb = (int)((M + RB - 1) / RB); L.seg = seg; L.ring = ring; L.M = M;
+    return L;
+  }
+  return L;
+}
+static int pw_layout_index(const pw_layout &L) { return L.kind == 1 ? 0 : (L.seg == 1 ? 1 : (L.ring ? 3 : 2)); }
+extern "C" int nk_csr_powers_layout(int64_t nrows, const int32_t *rowptr, const int32_t *col, int num_cus, int layout[6]) {
+  NK_REQUIRE(rowptr && col && layout && nrows >= 0 && num_cus >= 1, "bad argument");
+  const pw_layout L = pw_find_layout(nrows, rowptr, col, num_cus, 0);
+  layout[0] = L.kind; layout[1] = L.rpt; layout[2] = L.w; layout[3] = L.nb; layout[4] = L.seg; layout[5] = L.ring;
+  return NK_OK;
+}
+
 // Builds (once per pattern) the plan of the resident matrix-powers kernel; A->pw stays NULL when the matrix is not eligible.
 static int pw_plan(nk_csr *A) {
   if (A->pw_tried) return NK_OK;
   A->pw_tried = true;
   nk_ctx *ctx = A->ctx;
   if (!pw_enabled() || ctx->nranks != 1 || !A->halo_gcols.empty() || A->nrows < 1 || A->nnz < 1) return NK_OK;
-  const int64_t n = A->nrows;
-  int maxlen = 0;
-  for (int64_t r = 0; r < n; ++r) maxlen = std::max(maxlen, (int)(A->h_rowptr[r + 1] - A->h_rowptr[r]));
-  const int w = maxlen <= 5 ? 5 : (maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 0));
-  if (!w) return NK_OK;
-  const int64_t per_cu = (n + ctx->num_cus - 1) / ctx->num_cus;
-  const int need = (int)((per_cu + PW_T - 1) / PW_T);
-  const int rpt = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 6 ? 6 : 0)));
-  if (!rpt) return NK_OK;
-  if ((w == 8 && rpt > 2) || (w == 16 && rpt > 1)) return NK_OK;   // register budget (128 VGPRs at 1024 threads): RPT·W ≤ 30 slots
-  const int64_t rb = (int64_t)PW_T * rpt;
-  const int nb = (int)((n + rb - 1) / rb);
-  bool plain = true;
-  for (int64_t r = 0; r < n && plain; ++r) {   // every column of a band within one slice of its neighbours
-    const int64_t b0 = (r / rb) * rb, lo = b0 - PW_HALO, hi = b0 + rb + PW_HALO;
-    for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k)
-      if (A->h_col[k] < lo || A->h_col[k] >= hi) { plain = false; break; }
-  }
   pw_args probe{};
-  int occ = 0;
-  if (plain) {
-    NK_TRY(pw_dispatch(ctx, rpt, w, probe, true, &occ));
-    if (occ < 1 || nb > ctx->num_cus * occ) return NK_OK;
-    NK_TRY(pw_plan_new(rpt, w, nb, &A->pw));
-    return NK_OK;
-  }
-  // banded segment by segment and / or on a ring (k_spmv_powers_seg): one segment on a ring, two segments, two on rings
-  for (int lay = 0; lay < 3; ++lay) {
-    const int seg = lay == 0 ? 1 : 2, ring = lay == 1 ? 0 : 1;
-    if (n % seg) continue;
-    const int64_t M = n / seg, pc = (M + ctx->num_cus - 1) / ctx->num_cus;
-    const int nd = (int)((pc + PW_T - 1) / PW_T);
-    const int rps = nd <= 1 ? 1 : (nd <= 2 ? 2 : (nd <= 4 ? 4 : 0));
-    if (!rps || !pw_seg_shape(rps, w, seg)) continue;
-    const int64_t RB = (int64_t)PW_T * rps;
-    if (ring && (M % RB)) continue;                 // (a ragged last band has no well-defined ring neighbour rows)
-    const int nbs = (int)((M + RB - 1) / RB);
-    bool ok = true;
-    for (int64_t r = 0; r < n && ok; ++r) {
-      const int64_t b0 = ((r % M) / RB) * RB;
-      for (int32_t k = A->h_rowptr[r]; k < A->h_rowptr[r + 1]; ++k) {
-        int64_t d = (int64_t)A->h_col[k] % M - b0;
-        if (ring) d = d < -PW_HALO ? d + M : (d >= RB + PW_HALO ? d - M : d);
-        if (d < -PW_HALO || d >= RB + PW_HALO) { ok = false; break; }
-      }
+  for (int skip = 0; skip < 4;) {
+    const pw_layout L = pw_find_layout(A->nrows, A->h_rowptr.data(), A->h_col.data(), ctx->num_cus, skip);
+    if (!L.kind) return NK_OK;
+    int occ = 0;   // all workgroups must be resident at once
+    if (L.kind == 1) NK_TRY(pw_dispatch(ctx, L.rpt, L.w, probe, true, &occ));
+    else NK_TRY(pw_dispatch_seg(ctx, L.rpt, L.w, L.seg, probe, true, &occ));
+    if (occ >= 1 && L.nb <= ctx->num_cus * occ) {
+      NK_TRY(pw_plan_new(L.rpt, L.w, L.nb, &A->pw));
+      if (L.kind == 2) { A->pw->seg = L.seg; A->pw->ring = L.ring; A->pw->seg_len = (int)L.M; }
+      return NK_OK;
     }
-    if (!ok) continue;
-    NK_TRY(pw_dispatch_seg(ctx, rps, w, seg, probe, true, &occ));
-    if (occ < 1 || nbs > ctx->num_cus * occ) continue;
-    NK_TRY(pw_plan_new(rps, w, nbs, &A->pw));
-    A->pw->seg = seg; A->pw->ring = ring; A->pw->seg_len = (int)M;
-    return NK_OK;
+    skip = pw_layout_index(L) + 1;
   }
   return NK_OK;
 }
