@@ -48,6 +48,35 @@ def test_block_sweeps_match_numpy(nls, n, k, s):
         _sweep(nls, mode, n, k, s, rng)
 
 
+@pytest.mark.parametrize("k", [1, 16, 7])
+def test_update_sweep_with_an_ill_conditioned_factor(nls, k):
+    """X ← (X − V U) R⁻¹ with κ(R) = 1e5 (pivot ratio 1e-10: two decades above the rank-loss bar): the matrix-core form of the
+    default cycle's shapes (k = 1, 16: one product with [−U N ; N], N = R⁻¹ explicit) and the substitution form (k = 7) both stay
+    within a few ε κ(R) of the float64 reference — what pass 2 of the block scheme then repairs."""
+    from nonlinearsolve_jl_amd import _lib as L
+    f = L.lib().nk_ss_sweep_test
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                  C.POINTER(C.c_double)]
+    rng = np.random.default_rng(k)
+    n, s = 30000, 15
+    V = np.asfortranarray(rng.standard_normal((n, k + s)))
+    U = rng.standard_normal((k, s)) * 0.1
+    Q, _ = np.linalg.qr(rng.standard_normal((s, s)))
+    Rup = np.linalg.qr(Q @ np.diag(np.logspace(0, -5, s)) @ Q.T)[1]
+    Rup = Rup * np.sign(np.diag(Rup))[:, None]                      # positive diagonal, κ₂(R) = 1e5
+    coef = np.concatenate([U.ravel(), Rup.ravel()])
+    V0, gram, us = V.copy(), np.zeros((k + s, s)), C.c_double(0)
+    assert f(nls.default_context()._h, 1, n, k, s, V.ctypes.data, coef.ctypes.data, gram.ctypes.data, 0, C.byref(us)) == 0, \
+        L.lib().nk_last_error()
+    W = V0[:, k:] - V0[:, :k] @ U
+    ref = np.linalg.solve(Rup.T, W.T).T
+    err = np.max(np.abs(V[:, k:] - ref)) / np.max(np.abs(ref))
+    assert err <= 4 * np.finfo(float).eps * 1e5, err
+    gref = np.concatenate([V0[:, :k], V[:, k:]], axis=1).T @ V[:, k:]      # the Gram block of what the sweep actually wrote
+    assert np.max(np.abs(gram - gref)) <= 1e-12 * np.max(np.abs(gref))
+
+
 def _pair(nls, dev, which):
     import torch
     if which == "bratu":
