@@ -915,6 +915,222 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   }
 }
 
+// GROUNDWORK (round 4, not yet used by the solver — DESIGN §9 item 3): the sweeps of ONE block of 17 … 32 columns, i.e. a whole
+// GMRES(30) cycle as a single block behind its start vector. The same kernel as k_ss_block_mm with TWO 16-wide matrix-core tiles
+// of new columns: T = [−U N ; N] is (k + S) × S with S up to 32, the update takes (k + S)/4 × 2 products per 16 rows, the Gram
+// block [V Q]ᵀQ is ⌈(k + S)/16⌉ × 2 accumulator tiles; the LDS tile has k + 32 columns (two spare columns take the padding
+// lanes). UPDATE = false: sweep A (Gram block of the raw columns only). Reached through the development harness
+// (nk_ss_sweep_test) for measurement and parity; the block's scalar work (ss_factor / ss_hessenberg for s > 16) does not exist yet.
+template <int S, int KC, bool UPDATE>
+__global__ __launch_bounds__(SS_R, 2) void k_ss_block_wide(int64_t n, double *__restrict__ V, int64_t ldv,
+                                                        const double *__restrict__ coef, double *__restrict__ partials,
+                                                        const int *d_skip, int ntiles) {
+  if (d_skip != nullptr && *d_skip != 0) return;
+  static_assert(S > 16 && S <= 32, "two 16-wide tiles of new columns");
+  extern __shared__ double sX[];
+  constexpr int k = KC, K = KC + S, NT = (K + 15) / 16, NKS = (K + 3) / 4, NN = 2, SP = 32;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, q4 = lane >> 4;
+  double *__restrict__ Wc = V + (size_t)k * ldv;
+  const int nwk = (int)gridDim.x, me = (int)blockIdx.x;
+  const int tpw = (ntiles + nwk - 1) / nwk;
+  const int tile0 = me * tpw, tile1 = min(tile0 + tpw, ntiles);
+  double vr[KC], w[S], vr2[KC], w2[S];
+  auto prefetch = [&](double (&vrx)[KC], double (&wx)[S], int tile) __attribute__((always_inline)) {
+    const int64_t r = (int64_t)(tile < 0 ? tile0 : tile) * SS_R + t;
+    const int64_t rc = r < n ? r : n - 1;
+    const size_t cs = tile < 0 ? 0 : (size_t)ldv;
+    const double *__restrict__ Wr = tile < 0 ? V : Wc;
+#pragma unroll
+    for (int c = 0; c < S; ++c) wx[c] = Wr[(size_t)c * cs + rc];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * cs + rc];
+  };
+  if (tile0 < tile1) {
+    prefetch(vr, w, tile0);
+    prefetch(vr2, w2, tile0 + 1 < tile1 ? tile0 + 1 : -1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double tb[UPDATE ? NKS : 1][NN];
+  if constexpr (UPDATE) {
+    double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + SP * SP;
+    for (int e = t; e < k * S + S * S; e += SS_R) sX[e] = coef[e];
+    for (int e = t; e < SP * SP; e += SS_R) sN[e] = 0.0;
+    __syncthreads();
+    if (t < S) {   // row t of N = R⁻¹ (R's diagonal arrives as reciprocals); sequential in c, LDS-resident (no register array)
+      for (int c = t; c < S; ++c) {
+        double a = (c == t) ? 1.0 : 0.0;
+        for (int c2 = t; c2 < c; ++c2) a = __builtin_fma(-sN[t * SP + c2], sR[c2 * S + c], a);
+        sN[t * SP + c] = a * sR[c * S + c];
+      }
+    }
+    __syncthreads();
+    for (int e = t; e < 4 * NKS * SP; e += SS_R) {
+      const int j = e / SP, c = e % SP;
+      double v = 0.0;
+      if (c < S) {
+        if (j < k) {
+          double a = 0.0;
+          for (int c2 = 0; c2 <= c; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * SP + c], a);
+          v = -a;
+        } else if (j < K) {
+          v = sN[(j - k) * SP + c];
+        }
+      }
+      sT[e] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int nn = 0; nn < NN; ++nn) tb[ks][nn] = sT[(4 * ks + q4) * SP + 16 * nn + li];
+    }
+    __syncthreads();
+  }
+  ss_d4 acc[NT][NN];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int nn = 0; nn < NN; ++nn) acc[mt][nn] = ss_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const double *pu[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int col = 4 * ks + q4;
+    pu[ks] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + li;
+  }
+  const double *pb[NN];
+  double *pq[NN];
+#pragma unroll
+  for (int nn = 0; nn < NN; ++nn) {
+    const int c = 16 * nn + li;
+    pb[nn] = sX + (k + (c < S ? c : S - 1)) * SS_P + wv * 64 + q4;
+    pq[nn] = sX + (k + c) * SS_P + wv * 64 + q4;   // (c ≥ S: the spare columns of the tile)
+  }
+  const double *pa[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    const int col = mt * 16 + li;
+    pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
+  }
+  const unsigned ldvb = (unsigned)ldv * 8u;
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)Wc, 0, (int)(unsigned)(((int64_t)(S - 1) * ldv + n) * 8), 0x00020000);
+  auto process = [&](double (&vr)[KC], double (&w)[S], int tile, bool valid, int next) __attribute__((always_inline)) {
+    const int64_t r = (int64_t)tile * SS_R + t;
+    const bool ok = valid && r < n;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
+#pragma unroll
+    for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch(vr, w, next);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (UPDATE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ss_d4 q[NN];
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) q[nn] = ss_d4{0.0, 0.0, 0.0, 0.0};
+        double a[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) a[ks] = pu[ks][g * 16];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn) q[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], tb[ks][nn], q[nn], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) pq[nn][g * 16 + 4 * rr] = q[nn][rr];
+        }
+      }
+      const unsigned rbyte = (unsigned)r * 8u;
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        const double qv = sX[(k + c) * SS_P + t];
+        const unsigned off = ok ? (unsigned)c * ldvb + rbyte : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u2, qv), wrs, (int)off, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+      double bb[NN][4], aa[NT][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) bb[nn][u] = pb[nn][(kk + u) * 4];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) aa[mt][u] = pa[mt][(kk + u) * 4];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn)
+            acc[mt][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[mt][u], bb[nn][u], acc[mt][nn], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto pair = [&](int tile) __attribute__((always_inline)) {
+    process(vr, w, tile, true, tile + 2 < tile1 ? tile + 2 : -1);
+    process(vr2, w2, tile + 1, tile + 1 < tile1, tile + 3 < tile1 ? tile + 3 : -1);
+  };
+  if (tile0 < tile1) {
+    pair(tile0);
+    for (int tile = tile0 + 2; tile < tile1; tile += 2) pair(tile);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int nn = 0; nn < NN; ++nn) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sX[(((wv * NT + mt) * NN + nn) * 4 + rr) * 64 + lane] = acc[mt][nn][rr];
+    }
+  }
+  __syncthreads();
+  constexpr int WSTR = NT * NN * 256;   // one wavefront's accumulators
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int nn = 0; nn < NN; ++nn) {
+      const int rr = t >> 6, ln = t & 63;
+      const int mrow = mt * 16 + (ln >> 4) + 4 * rr, ncol = 16 * nn + (ln & 15);
+      if (mrow < K && ncol < S) {
+        const int e = ((mt * NN + nn) * 4 + rr) * 64 + ln;
+        const double sum = (sX[e] + sX[WSTR + e]) + (sX[2 * WSTR + e] + sX[3 * WSTR + e]);
+        partials[(size_t)(mrow * S + ncol) * gridDim.x + blockIdx.x] = sum;
+      }
+    }
+  }
+}
+// the wide block's shape: one block of 30 columns behind the cycle's start vector
+static bool ss_wide_shape(int k, int s) { return k == 1 && s == 30; }
+static int ss_launch_wide(nk_ctx *ctx, int mode, int64_t n, double *V, int64_t ldv, const double *coef, double *partials,
+                          const int *d_skip, int grid, int *occ_out) {
+  const size_t lds = (size_t)(1 + 32) * SS_P * sizeof(double);
+  const int ntiles = (int)((n + SS_R - 1) / SS_R);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool ev = !occ_out && ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
+#define SS_WIDE(UPD)                                                                                                      \
+  do {                                                                                                                    \
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_wide<30, 1, UPD>),                              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
+    if (occ_out) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_wide<30, 1, UPD>, SS_R, lds));   \
+    else if (ev) hipExtLaunchKernelGGL((k_ss_block_wide<30, 1, UPD>), dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
+                                       ldv, coef, partials, d_skip, ntiles);                                              \
+    else hipLaunchKernelGGL((k_ss_block_wide<30, 1, UPD>), dim3(grid), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials, \
+                            d_skip, ntiles);                                                                              \
+  } while (0)
+  if (mode == 0) SS_WIDE(false); else SS_WIDE(true);
+#undef SS_WIDE
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
 static size_t ss_tile_doubles(int k, int s, bool gram, int nt) {
   if (!gram) return 0;
   const size_t a = (size_t)(k + s) * SS_P, b = (size_t)4 * nt * 256;
@@ -944,9 +1160,21 @@ static int ss_per_cu(nk_ctx *ctx, int k, int s) {
 // tiles, so a CU is busy for per_cu·⌈tiles / (CUs·per_cu)⌉ of them: with 4096 tiles (n = 2²⁰) on 256 CUs three workgroups per CU
 // (what the 15-column block behind one column fits) make that 18 where two or four make it 16 — measured 25.6 → 24.2 and
 // 47.4 → 45.7 µs for sweeps A and B of that shape with two. The largest count that reaches the minimum is taken.
+static int ss_launch_wide(nk_ctx *ctx, int mode, int64_t n, double *V, int64_t ldv, const double *coef, double *partials,
+                          const int *d_skip, int grid, int *occ_out);
+static bool ss_wide_shape(int k, int s);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  const int occ = ss_per_cu(ctx, k, s);
+  int occ;
+  if (ss_wide_shape(k, s)) {
+    int oa = 0, ob = 0;
+    if (ss_launch_wide(ctx, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, 1, &oa) != NK_OK || oa < 1) oa = 1;
+    if (ss_launch_wide(ctx, 1, 1, nullptr, 0, nullptr, nullptr, nullptr, 1, &ob) != NK_OK || ob < 1) ob = 1;
+    occ = oa < ob ? oa : ob;
+    if (occ > SS_MAX_WG_PER_CU) occ = SS_MAX_WG_PER_CU;
+  } else {
+    occ = ss_per_cu(ctx, k, s);
+  }
   int best = occ;
   int64_t best_cost = INT64_MAX;
   for (int p = occ; p >= 1; --p) {
@@ -1055,6 +1283,11 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
 // mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
 static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
                              const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out, int hk = 0, int hs = 0) {
+  if (ss_wide_shape(k, s)) {   // groundwork: the sweeps of a 30-column block (harness only)
+    NK_REQUIRE(mode == 0 || mode == 1, "wide block: sweeps A and B only");
+    NK_REQUIRE(occ_out || (int64_t)s * ldv * 8 < ((int64_t)1 << 32) - 8, "wide block: the block's columns must fit one 4 GiB buffer");
+    return ss_launch_wide(ctx, mode, n, V, ldv, coef, partials, d_skip, grid, occ_out);
+  }
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
