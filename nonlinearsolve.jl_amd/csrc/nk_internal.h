@@ -593,6 +593,7 @@ int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
+int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting);   // sweep A's own grid (read-only: one workgroup per CU)
 struct ss_tail_args;
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
                 const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk = 0, int hs = 0);

@@ -1186,6 +1186,20 @@ int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   if (g > ntiles) g = ntiles;
   return g > 0 ? g : 1;
 }
+// Sweep A (read-only) of the default cycle's shapes runs ONE workgroup per CU — measured on the same box, stand-alone:
+// 24.1 → 22.0 µs behind one column, 45.9 → 42.1 µs behind 16 (6.1–6.2 TB/s; the writing sweep B gains nothing from it). When it
+// hosts the previous block's Hessenberg work the hosting workgroup is one of these (it streams nothing and has a CU to itself:
+// 49 µs; as a 257th workgroup beside a streaming one 54 µs, inside a grid of 512 52 µs — the hosted scalar work, ≈ 45 µs under
+// load against 29 µs as a launch of its own, is what that launch waits for, not its 255 streaming workgroups).
+// Other shapes: the grid of sweep B.
+int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting) {
+  static const bool off = getenv("NK_SS_GRID_A") && atoi(getenv("NK_SS_GRID_A")) == 0;   // A/B switch
+  static const bool kc_off = getenv("NK_SS_KCONST") && atoi(getenv("NK_SS_KCONST")) == 0;
+  const int ntiles = (int)((n + SS_R - 1) / SS_R);
+  if (off || kc_off || s != 15 || (k != 1 && k != 16) || ntiles < 2 * ctx->num_cus) return nk_ss_grid(ctx, n, k, s);
+  static const int host_extra = getenv("NK_SS_GRID_A_HOST") ? atoi(getenv("NK_SS_GRID_A_HOST")) : 0;   // A/B switch (1: a 257th workgroup)
+  return ctx->num_cus + (hosting ? host_extra : 0);
+}
 
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
@@ -1480,7 +1494,7 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   NK_REQUIRE(ctx && V_host, "NULL argument");
   NK_HIP(hipSetDevice(ctx->device));
   double *dV = nullptr, *dc = nullptr, *dp = nullptr;
-  const int grid = nk_ss_grid(ctx, n, k, s);
+  const int grid = mode == 0 ? nk_ss_grid_a(ctx, n, k, s, false) : nk_ss_grid(ctx, n, k, s);
   const size_t nv = (size_t)n * (k + s), nslots = (size_t)(k + s) * s;
   NK_TRY(nk_dev_alloc(&dV, nv));
   NK_TRY(nk_dev_alloc(&dc, (size_t)k * s + s * s + 1));
@@ -1902,10 +1916,13 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     const bool implicit = !last_block && implicit_mode && G->ss_fix.n < NK_SS_NFIX - 1;
     ta.Wi = implicit ? W->Wi + (size_t)blk * SS_SS : nullptr;
     ta.D = implicit ? W->D + (size_t)blk * W->c2_stride : nullptr;
+    const int grid_b = grid;
     for (int pass = 0; pass < 2; ++pass) {
+      int grid = grid_b;   // (of THIS pass: the sweep, and the reduction behind it, which sums one partial per workgroup)
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb + (pass ? sb : 0)));
         const bool host_prev = pass == 0 && pend_sb > 0 && fused;   // sweep A hosts the previous block's Hessenberg columns
+        if (pass == 0) grid = nk_ss_grid_a(ctx, n, k, sb, host_prev);
         NK_TRY(nk_ss_sweep(ctx, pass, n, k, sb, G->V, ldv, W->coef, W->part, done, grid, host_prev ? &pend_ta : nullptr,
                            pass == 0 ? &G->d_ctl->pad1 : nullptr, pend_k, pend_sb));
         if (host_prev) pend_sb = 0;
