@@ -313,21 +313,27 @@ __device__ void ss_fail(const ss_tail_args &ta) {
 //   A v_k = σ X_0 + θ_0 v_k ;  A X_{j−1} = σ X_j + θ_j X_{j−1} ;
 //   q_j = (X_{j−1} − V_k C_{j−1} − Σ_{i<j} q_i R_{i,j−1}) / R_{j−1,j−1}   (j = 1..s−1)     (θ = 0: the monomial basis)
 // so the coordinates of A q_j follow from those of A v_1..A v_{k−1} (the old Hessenberg columns), A v_k and A q_1..A q_{j−1}.
-__device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
+// everything the serial parts of ss_hessenberg read from global memory, requested up front by all threads (no barrier behind it:
+// the caller's next barrier publishes it)
+__device__ void ss_hess_load(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
   const int t = threadIdx.x, nt = blockDim.x;
-  const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
-  double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
-  // everything the serial parts read from global memory is requested up front by all threads
-  for (int e = t; e < k * ko; e += nt) Hs[e] = ta.H[(size_t)(e / ko) * m + (e % ko)];
-  for (int e = t; e < ko; e += nt) { scs[e] = ta.cs[e]; ssn[e] = ta.sn[e]; }
-  for (int e = t; e <= ko; e += nt) sg[e] = ta.g[e];
+  const int ko = k - 1, m = ta.m;
+  for (int e = t; e < k * ko; e += nt) w.Hs[e] = ta.H[(size_t)(e / ko) * m + (e % ko)];
+  for (int e = t; e < ko; e += nt) { w.scs[e] = ta.cs[e]; w.ssn[e] = ta.sn[e]; }
+  for (int e = t; e <= ko; e += nt) w.sg[e] = ta.g[e];
   if (t < sb * sb) w.R1s[t] = ta.R1[t];
   if (t < k) w.uu[t] = ta.usb > 0 ? (t < ta.uk0 ? ta.uC2[t * ta.usb + ta.usb - 1] : ta.uR2[(t - ta.uk0) * ta.usb + ta.usb - 1])
                                   : (t == k - 1 ? 1.0 : 0.0);
+  for (int e = t; e < k * sb; e += nt) w.F[e] = ta.C1[e];
+}
+__device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta, bool loaded = false) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
+  double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
+  if (!loaded) ss_hess_load(k, sb, w, ta);
   const double sigma = ta.scal[2];
   const double *__restrict__ th = ta.scal + SS_TH;
   SS_STAMP(8);
-  for (int e = t; e < k * sb; e += nt) F[e] = ta.C1[e];
   __syncthreads();
   SS_STAMP(9);
   for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
@@ -501,9 +507,10 @@ __device__ void ss_hess_block(int k, int sb, double *lds, const ss_tail_args &ta
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += blockDim.x) w.Ct[e] = ta.C2[e];      // pass 2's factors, left by the reduction's last workgroup
   if (t < sb * sb) w.Rm[t] = ta.R2[t];
+  ss_hess_load(k, sb, w, ta);   // (the same round trip: hosted beside streaming workgroups a round trip is ≈ 4 µs)
   __syncthreads();
   if (ta.Wi != nullptr) ss_fix_prepare(k, sb, w.Ct, w.Rm, w.Sm, ta.Wi, ta.D);   // (Sm is free: ss_factor is not run here)
-  ss_hessenberg(k, sb, w, ta);
+  ss_hessenberg(k, sb, w, ta, true);
 }
 __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta) {
   extern __shared__ double s_tail[];
