@@ -313,10 +313,17 @@ __global__ __launch_bounds__(NK_BLOCK) void k_peer_halo_xchg(const nk_peer_seg *
 
 static int comm_allreduce_base(nk_ctx *ctx, double *dbuf, int count, int op);
 uint64_t *nk_peer_err_ptr(nk_ctx *ctx) { return reinterpret_cast<uint64_t *>(ctx->peer.arena + offsetof(nk_peer_hdr, err)); }
+static bool peer_ar_unfused() {
+  static const bool unfused = getenv("NK_PEER_UNFUSED") != nullptr;  // A/B switch: reduce and all-reduce as two launches
+  return unfused;
+}
+// would nk_peer_ar_next(ctx, count) take the fast path? (no side effect)
+bool nk_peer_ar_available(nk_ctx *ctx, int count) {
+  return ctx->peer.on && !peer_ar_unfused() && count <= NK_PEER_AR_MAX && ctx->nranks > 1;
+}
 nk_peer_ar_view nk_peer_ar_next(nk_ctx *ctx, int count) {
   nk_peer_ar_view v{nullptr, 0, 0, 0, nullptr};
-  static const bool unfused = getenv("NK_PEER_UNFUSED") != nullptr;  // A/B switch: reduce and all-reduce as two launches
-  if (!ctx->peer.on || unfused || count > NK_PEER_AR_MAX || ctx->nranks <= 1) return v;
+  if (!nk_peer_ar_available(ctx, count)) return v;
   v.map = ctx->peer.d_map;
   v.P = ctx->peer.P;
   v.me = ctx->peer.me;

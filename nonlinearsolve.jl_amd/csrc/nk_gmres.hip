@@ -1651,6 +1651,7 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
     ss_from_partials = false;
     first = 0;
     const bool x_is_zero_before = x_is_zero;
+    bool ss_backsolved = false;
     const int steps = (cap - total_iters) < m ? (cap - total_iters) : m;
     // The cycle is enqueued without a host synchronisation; kernels after convergence return at once on the device flag.
     // The device also publishes a progress word (cycle sequence, columns closed, done) in coherent pinned memory, which the
@@ -1676,7 +1677,7 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
         };
       G->ss_cycle_idx = inf.restarts;
       G->ss_grow = fixed_iters <= 0;
-      NK_TRY(nk_ss_cycle(G, steps, wait_progress));
+      NK_TRY(nk_ss_cycle(G, steps, wait_progress, &ss_backsolved));
     } else {
       const bool one_red = use_dcgs2r(G);
       const int ahead = (fixed_iters > 0 || G->run_ahead <= 0) ? 0 : (G->prec_kind == 3 ? 1 : G->run_ahead);
@@ -1712,9 +1713,11 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
     }
     // x += M⁻¹ V y  (coefficients y_j s_j on the un-normalised columns); the back-substitution also publishes the control
     // block's outcome to the host
-    NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
-              (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr),
-              G->ortho == NK_ORTHO_SSTEP ? nk_ss_take_last_block(G) : nk_ss_fix{});
+    // (s-step form: the cycle's last scalar launch may have back-substituted already — nk_sstep.hip)
+    if (!ss_backsolved)
+      NK_LAUNCH(ctx, k_backsolve, dim3(1), dim3(256), G->d_ctl, G->d_R, G->d_g, G->d_y, m, G->h_pub_dev, seq,
+                (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr),
+                G->ortho == NK_ORTHO_SSTEP ? nk_ss_take_last_block(G) : nk_ss_fix{});
     if (!G->prec_kind) {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
     } else {

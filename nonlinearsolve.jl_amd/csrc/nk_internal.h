@@ -71,8 +71,8 @@ struct nk_prof {
 
 // peer-mapped arenas (hipIpc over xGMI) for the small collectives of the Krylov loop (nk_ctx.hip)
 constexpr int NK_PEER_MAX_RANKS = 16;
-constexpr int NK_PEER_AR_MAX = 512;                      // doubles per all-reduce message (an s-step block: (k + s)·s ≤ 31·15)
-constexpr size_t NK_PEER_HDR_BYTES = 262144;             // flags + all-reduce slots + error word
+constexpr int NK_PEER_AR_MAX = 1024;                     // doubles per all-reduce message (two s-step blocks in one message: 2·(k + s)·s ≤ 2·31·15)
+constexpr size_t NK_PEER_HDR_BYTES = 524288;             // flags + all-reduce slots + error word
 // Layout of every rank's arena: a header (all-reduce flags and slots, error word) and a bump-allocated rest that holds
 // the receive areas of the halo plans. All of it is uncached device memory, so that a kernel polling a flag sees the
 // store a peer GPU made while the kernel was already running.
@@ -108,6 +108,7 @@ struct nk_peer_ar_view {
   unsigned int *ticket;
 };
 nk_peer_ar_view nk_peer_ar_next(nk_ctx *ctx, int count);
+bool nk_peer_ar_available(nk_ctx *ctx, int count);   // would nk_peer_ar_next take the fast path? (no side effect)
 // bound of a device-side wait: the word behind the arena's error counter (err[1]); 5 s if the arena predates it
 __device__ __forceinline__ unsigned long long nk_peer_timeout(const uint64_t *err) {
   const unsigned long long t = err[1];
@@ -590,7 +591,7 @@ int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *
 // the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
-int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress);
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
 int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting);   // sweep A's own grid (read-only: one workgroup per CU)

@@ -72,12 +72,12 @@ struct ss_tail_args {
 };
 // LDS arrays of the scalar work, carved from one dynamic block
 struct ss_ws {
-  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *Fr, *Fx, *F, *NC, *Hs, *scs, *ssn, *sg, *fC2, *fR2, *uu;
+  double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *Fr, *Fx, *F, *NC, *Hs, *scs, *ssn, *sg, *uu;
   int *ok;
 };
 constexpr int SS_SS = SS_SMAX * SS_SMAX;
 __host__ __device__ inline size_t ss_ws_doubles(int k, int s, bool hess) {
-  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2 + 2 * SS_SMAX * (SS_SMAX + 1) + (size_t)k * SS_SMAX + SS_SS;
+  size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2 + 2 * SS_SMAX * (SS_SMAX + 1);
   if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 4 * (size_t)(k + s) + 1;
   return d;
 }
@@ -93,8 +93,6 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
   w.Fr = b; b += SS_SMAX * (SS_SMAX + 1);
   w.Fx = b; b += SS_SMAX * (SS_SMAX + 1);
   w.ok = reinterpret_cast<int *>(b); b += 2;
-  w.fC2 = b; b += k * SS_SMAX;
-  w.fR2 = b; b += SS_SS;
   w.F = w.NC = w.Hs = w.scs = w.ssn = w.sg = w.uu = nullptr;
   if (hess) {
     w.F = b; b += (k + s) * s;
@@ -133,14 +131,8 @@ __device__ __forceinline__ double ss_rcp(double d) {   // 1/d to the last bit or
 //   stored inner products → true:   Q_bᵀX = Wiᵀ (S_bᵀX) − Dᵀ (V_true[:k0]ᵀX)       (rows above the block already true: blocks in order)
 //   true coefficients → stored:     W[:k0] −= D W_b ;  W_b ← Wi W_b                 (blocks last first)
 // P / Wm: k × sb, row-major, rows = basis columns. tmp: sp × sb scratch.
-__device__ void ss_fix_to_true(int sb, int k0, int sp, const double *__restrict__ Dg, const double *__restrict__ Wig, double *P,
-                               double *sD, double *sWi, bool load) {
+__device__ void ss_fix_to_true(int sb, int k0, int sp, const double *sD, const double *sWi, double *P) {
   const int t = threadIdx.x;
-  if (load) {   // (a global round trip: skipped when the block's factors are in LDS already)
-    for (int e = t; e < k0 * sp; e += blockDim.x) sD[e] = Dg[e];
-    if (t < sp * sp) sWi[t] = Wig[t];
-    __syncthreads();
-  }
   const int a = t / sb, c = t % sb;
   const bool own = t < sp * sb;
   double val = 0.0;
@@ -152,15 +144,9 @@ __device__ void ss_fix_to_true(int sb, int k0, int sp, const double *__restrict_
   if (own) P[(k0 + a) * sb + c] = val;
   __syncthreads();
 }
-__device__ void ss_fix_to_stored(int sb, int k0, int sp, const double *__restrict__ Dg, const double *__restrict__ Wig, double *Wm,
-                                 double *sD, double *sWi, bool load) {
+__device__ void ss_fix_to_stored(int sb, int k0, int sp, const double *sD, const double *sWi, double *Wm) {
   const int t = threadIdx.x;
-  if (load) {
-    for (int e = t; e < k0 * sp; e += blockDim.x) sD[e] = Dg[e];
-    if (t < sp * sp) sWi[t] = Wig[t];
-    __syncthreads();
-  }
-  for (int e = t; e < k0 * sb; e += blockDim.x) {      // W[:k0] −= D W_b (the OLD W_b)
+  for (int e = t; e < k0 * sb; e += SS_R) {      // W[:k0] −= D W_b (the OLD W_b)
     const int i = e / sb, cc = e % sb;
     double v = Wm[e];
     for (int q = 0; q < sp; ++q) v = __builtin_fma(-sD[i * sp + q], Wm[(k0 + q) * sb + cc], v);
@@ -175,10 +161,46 @@ __device__ void ss_fix_to_stored(int sb, int k0, int sp, const double *__restric
   if (own) Wm[(k0 + a) * sb + c] = val;
   __syncthreads();
 }
+// The factors of the blocks left at their first pass as the scalar work reads them: in LDS, one slot per block (the struct lives in
+// LDS as well — indexing a kernel argument by a run-time block number would put it in scratch memory). A slot is filled from global
+// memory (ss_fixc_request: all slots in ONE round trip, together with the reduced block) or, for the block whose second
+// factorisation has just been done by this workgroup, by ss_fix_prepare.
+struct ss_fixc {
+  int n;
+  int k0[NK_SS_NFIX], sb[NK_SS_NFIX];
+  double *D[NK_SS_NFIX], *Wi[NK_SS_NFIX];
+};
+__host__ __device__ inline size_t ss_fixc_doubles(const nk_ss_fix &fix) {
+  size_t d = 0;
+#pragma unroll
+  for (int q = 0; q < NK_SS_NFIX; ++q)
+    if (q < fix.n) d += (size_t)fix.k0[q] * fix.sb[q] + (size_t)fix.sb[q] * fix.sb[q];
+  return d;
+}
+// carve the slots out of `b` (uniform; thread 0 writes the struct, the caller's next barrier publishes it) and request the
+// slots' contents — all but the last `skip_last` blocks' (those are computed here)
+__device__ inline double *ss_fixc_request(ss_fixc *fc, const nk_ss_fix &fix, double *b, int skip_last, bool c2r2 = false) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NK_SS_NFIX; ++q) {
+    if (q < fix.n) {
+      double *sD = b; b += fix.k0[q] * fix.sb[q];
+      double *sWi = b; b += fix.sb[q] * fix.sb[q];
+      if (t == 0) { fc->k0[q] = fix.k0[q]; fc->sb[q] = fix.sb[q]; fc->D[q] = sD; fc->Wi[q] = sWi; }
+      if (q < fix.n - skip_last) {
+        const double *gD = c2r2 ? fix.C2[q] : fix.D[q], *gWi = c2r2 ? fix.R2[q] : fix.Wi[q];
+        for (int e = t; e < fix.k0[q] * fix.sb[q]; e += SS_R) sD[e] = gD[e];
+        if (t < fix.sb[q] * fix.sb[q]) sWi[t] = gWi[t];
+      }
+    }
+  }
+  if (t == 0) fc->n = fix.n;
+  return b;
+}
 // Wi = R₂⁻¹ and D = C₂ Wi of a block left at its first pass (k0 rows above it, sp columns), from its pass-2 factors in LDS
 // (Ct: C₂, k0 × sp; Rm: R₂, sp × sp upper) into global memory. Column j of Wi by back substitution, one lane per column.
 __device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *Rm, double *scratch /* sp × sp */, double *Wig,
-                               double *Dg) {
+                               double *Dg, double *sWiout = nullptr, double *sDout = nullptr) {
   const int t = threadIdx.x;
   if (t < sp) {
     const int j = t;
@@ -194,35 +216,37 @@ __device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *R
     }
   }
   __syncthreads();
-  if (t < sp * sp) Wig[t] = scratch[t];
-  for (int e = t; e < k0 * sp; e += blockDim.x) {
+  if (t < sp * sp) {
+    Wig[t] = scratch[t];
+    if (sWiout != nullptr) sWiout[t] = scratch[t];
+  }
+  for (int e = t; e < k0 * sp; e += SS_R) {
     const int i = e / sp, a = e % sp;
     double v = 0.0;
     for (int p = 0; p <= a; ++p) v = __builtin_fma(Ct[i * sp + p], scratch[p * sp + a], v);
     Dg[e] = v;
+    if (sDout != nullptr) sDout[e] = v;
   }
   __syncthreads();
 }
 __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w,
-                          const nk_ss_fix &fix, double ptol, bool fix0_in_lds = false) {
+                          const ss_fixc &fix, int nfix, double ptol) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
   double *F = w.Fr;   // 16 × 17 frame: the factor in progress
-  for (int e = t; e < k * sb; e += blockDim.x) {
+  for (int e = t; e < k * sb; e += SS_R) {
     const double scj = sc[e / sb], c = scj * red[e];
     Ct[e] = c;
-    if (fix.n == 0) w.U[e] = scj * c;
+    if (nfix == 0) w.U[e] = scj * c;
   }
   if (t == 0) *w.ok = 1;
   __syncthreads();
-  if (fix.n > 0) {   // (uniform) stored → true coordinates for the factorisation; true → stored coefficients for the update
-    for (int bq = 0; bq < fix.n; ++bq)
-      ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], Ct, w.fC2, w.fR2, !(bq == 0 && fix0_in_lds));
-    for (int e = t; e < k * sb; e += blockDim.x) w.U[e] = Ct[e];
+  if (nfix > 0) {   // (uniform) stored → true coordinates for the factorisation; true → stored coefficients for the update
+    for (int bq = 0; bq < nfix; ++bq) ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], Ct);
+    for (int e = t; e < k * sb; e += SS_R) w.U[e] = Ct[e];
     __syncthreads();
-    for (int bq = fix.n - 1; bq >= 0; --bq)   // (the last block carried to true coordinates is still in LDS)
-      ss_fix_to_stored(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], w.U, w.fC2, w.fR2, bq != fix.n - 1);
-    for (int e = t; e < k * sb; e += blockDim.x) w.U[e] *= sc[e / sb];
+    for (int bq = nfix - 1; bq >= 0; --bq) ss_fix_to_stored(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], w.U);
+    for (int e = t; e < k * sb; e += SS_R) w.U[e] *= sc[e / sb];
     __syncthreads();
   }
   SS_STAMP(5);
@@ -239,7 +263,7 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
     Sm[t] = s0 + s1;
   }
   __syncthreads();
-  const int a = (t >> 4) & (SS_SMAX - 1), b = t & (SS_SMAX - 1);   // (blockDim.x = 256: one entry per thread)
+  const int a = (t >> 4) & (SS_SMAX - 1), b = t & (SS_SMAX - 1);   // (SS_R = 256: one entry per thread)
   const bool in = a < sb && b < sb;
   double val = in ? 0.5 * (Sm[in ? a * sb + b : 0] + Sm[in ? b * sb + a : 0]) : ((a == b) ? 1.0 : 0.0);
   F[a * SS_FP + b] = val;
@@ -274,7 +298,7 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
 __device__ bool ss_first_pass_departure_ok(int k, int sb, const ss_ws &w, double bar) {
   const int t = threadIdx.x;
   double m = 0.0;
-  for (int e = t; e < k * sb; e += blockDim.x) m = fmax(m, fabs(w.Ct[e]));
+  for (int e = t; e < k * sb; e += SS_R) m = fmax(m, fabs(w.Ct[e]));
   if (t < sb * sb) {
     const int a = t / sb, c = t % sb;
     m = fmax(m, fabs(w.Rm[t] - (a == c ? 1.0 : 0.0)));
@@ -289,23 +313,24 @@ __device__ bool ss_first_pass_departure_ok(int k, int sb, const ss_ws &w, double
   return m <= bar && m == m;
 }
 // after pass 1 (one workgroup): C₁ and R₁ are kept for pass 2; σ estimate for the next cycle from ‖A v‖ of the first block
-__device__ void ss_keep_pass1(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
+__device__ void ss_keep_pass1(int k, int sb, const ss_ws &w, const ss_tail_args &ta, const double *red) {
   const int t = threadIdx.x;
-  for (int e = t; e < k * sb; e += blockDim.x) ta.C1[e] = w.Ct[e];
+  for (int e = t; e < k * sb; e += SS_R) ta.C1[e] = w.Ct[e];
   if (t < sb * sb) ta.R1[t] = w.Rm[t];
   if (t == 0 && k == 1 && ta.scal[4] == 0.0) {  // ‖A v₁‖ = σ·√(XᵀX)₀₀: the scale of the next cycle's monomial basis, rounded to a power of two
-    const double est = ta.scal[2] * sqrt(ta.red[(size_t)k * sb]);
+    const double est = ta.scal[2] * sqrt(red[(size_t)k * sb]);
     if (est > 0.0 && !isinf(est)) ta.scal[3] = exp2(rint(log2(est)));
   }
 }
-__device__ void ss_fail(const ss_tail_args &ta) {
+__device__ void ss_fail(nk_gmres_ctl *ctl, nk_gmres_pub *pub, uint64_t seq) {
   if (threadIdx.x == 0) {
-    ta.ctl->failed = 2;
-    ta.ctl->done = 1;
-    ta.ctl->pad1 = 1;
-    ss_pub_progress(ta.pub, ta.seq, ta.ctl->k, 1);
+    ctl->failed = 2;
+    ctl->done = 1;
+    ctl->pad1 = 1;
+    ss_pub_progress(pub, seq, ctl->k, 1);
   }
 }
+__device__ void ss_fail(const ss_tail_args &ta) { ss_fail(ta.ctl, ta.pub, ta.seq); }
 
 // after pass 2 (one workgroup; ss_factor has run on pass 2's block): C = C₁ + C₂R₁, R = R₂R₁; the s new Hessenberg columns;
 // Givens rotations, residual norms, stopping test.
@@ -316,7 +341,7 @@ __device__ void ss_fail(const ss_tail_args &ta) {
 // everything the serial parts of ss_hessenberg read from global memory, requested up front by all threads (no barrier behind it:
 // the caller's next barrier publishes it)
 __device__ void ss_hess_load(int k, int sb, const ss_ws &w, const ss_tail_args &ta) {
-  const int t = threadIdx.x, nt = blockDim.x;
+  const int t = threadIdx.x, nt = SS_R;
   const int ko = k - 1, m = ta.m;
   for (int e = t; e < k * ko; e += nt) w.Hs[e] = ta.H[(size_t)(e / ko) * m + (e % ko)];
   for (int e = t; e < ko; e += nt) { w.scs[e] = ta.cs[e]; w.ssn[e] = ta.sn[e]; }
@@ -325,17 +350,34 @@ __device__ void ss_hess_load(int k, int sb, const ss_ws &w, const ss_tail_args &
   if (t < k) w.uu[t] = ta.usb > 0 ? (t < ta.uk0 ? ta.uC2[t * ta.usb + ta.usb - 1] : ta.uR2[(t - ta.uk0) * ta.usb + ta.usb - 1])
                                   : (t == k - 1 ? 1.0 : 0.0);
   for (int e = t; e < k * sb; e += nt) w.F[e] = ta.C1[e];
+  // the shifts, σ and the tolerance (w.Fx is free during the Hessenberg work): a lone thread's loads behind the serial parts
+  // cost a memory round trip each
+  if (t < SS_SMAX) w.Fx[t] = ta.scal[SS_TH + t];
+  if (t == SS_SMAX) w.Fx[SS_SMAX] = ta.scal[2];
+  if (t == SS_SMAX + 1) w.Fx[SS_SMAX + 1] = ta.ctl->tol;
 }
-__device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta, bool loaded = false) {
-  const int t = threadIdx.x, nt = blockDim.x;
+// sR (optional, pitch LK): an LDS copy of the rotated factor's new columns, for a back-substitution in the same workgroup.
+// raise_pad1: a verdict that ends the cycle also voids the block whose sweeps are in flight (deferred second pass: this block's
+// Hessenberg columns are derived while the NEXT block is under way).
+__device__ __forceinline__ double ss_readlane(double v, int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// verdict (optional, LDS): {columns closed so far, converged, failed, residual norm} as thread 0 has just stored them in the
+// control block — for the same workgroup's back-substitution, which must not read them back through the cache.
+__device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta, bool loaded = false, double *sR = nullptr,
+                              int LK = 0, bool raise_pad1 = false, double *verdict = nullptr) {
+  const int t = threadIdx.x, nt = SS_R;
   const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
   double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
   if (!loaded) ss_hess_load(k, sb, w, ta);
-  const double sigma = ta.scal[2];
-  const double *__restrict__ th = ta.scal + SS_TH;
   SS_STAMP(8);
   __syncthreads();
   SS_STAMP(9);
+  const double sigma = w.Fx[SS_SMAX];
+  const double *th = w.Fx;
   for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
     const int j = e / sb, c = e % sb;
     double v = F[e];
@@ -399,7 +441,9 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
     double *h = &NC[t * K];
     for (int i = 0; i < ko; ++i) {
       const double a = h[i], b = h[i + 1];
-      ta.Rg[(size_t)i * m + jc] = scs[i] * a + ssn[i] * b;
+      const double rij = scs[i] * a + ssn[i] * b;
+      ta.Rg[(size_t)i * m + jc] = rij;
+      if (sR != nullptr) sR[i * LK + jc] = rij;
       h[i + 1] = -ssn[i] * a + scs[i] * b;
     }
   }
@@ -411,45 +455,56 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   // count (the first that meets the tolerance closes the cycle) is decided by the scalar pass behind it.
   double *betas = w.Gd;   // (free here: ss_factor is done with it)
   if (t < 64) {
-    // one wavefront, LDS only, no workgroup barriers: lanes run in lockstep and a wavefront's LDS operations complete in order;
-    // the rotated entries stay in the column (row jc of column t: its final R entry), global stores follow the loop
-    for (int i = 0; i < sb; ++i) {
-      const int jc = ko + i;
-      if (t == i) {
-        const double hk = NC[i * K + jc], beta = NC[i * K + jc + 1];
+    // one wavefront, in REGISTERS: lane j owns column j — the entry the previous rotation left in row ko + i (`carry`) and the
+    // column's rows below it as the recurrence left them (`bv`, requested up front); rotation i is formed from lane i's pair by
+    // every lane in lockstep and lane i's result is broadcast with v_readlane. No LDS round trip and no fence inside the chain
+    // (round 4 kept the columns in LDS: two LDS round trips + four fences per rotation, 11 µs for 15 of them).
+    const int col = t < sb ? t : sb - 1;   // (lanes ≥ sb shadow the last column; nothing of theirs is stored)
+    const double *h = &NC[col * K + ko];
+    double carry = h[0];
+    double bv[SS_SMAX], outR[SS_SMAX];
+#pragma unroll
+    for (int i = 0; i < SS_SMAX; ++i) {
+      bv[i] = (i < sb) ? h[i + 1] : 0.0;
+      outR[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < SS_SMAX; ++i) {
+      if (i < sb) {   // (uniform)
+        const double hk = carry, beta = bv[i];
         double d = sqrt(__builtin_fma(hk, hk, beta * beta));
         if (!(d > 1e-150 && d < 1e150)) d = hypot(hk, beta);        // (scaled evaluation only where the plain one may be off)
         double c, sgn;
         if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
-        scs[jc] = c;
-        ssn[jc] = sgn;
-        betas[i] = beta;
-        NC[i * K + jc] = d;
+        const double ci = ss_readlane(c, i), si = ss_readlane(sgn, i);
+        if (t == i) {
+          scs[ko + i] = c;
+          ssn[ko + i] = sgn;
+          betas[i] = beta;
+          outR[i] = d;
+        } else if (t > i) {
+          outR[i] = ci * hk + si * beta;
+          carry = -si * hk + ci * beta;
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (t > i && t < sb) {
-        double *h = &NC[t * K];
-        const double a = h[jc], b = h[jc + 1], c = scs[jc], sgn = ssn[jc];
-        h[jc] = c * a + sgn * b;
-        h[jc + 1] = -sgn * a + c * b;
+    }
+    // R entries of the block's own rows: rotated values above the diagonal, d on it
+    if (t < sb) {
+#pragma unroll
+      for (int i = 0; i < SS_SMAX; ++i) {
+        if (i <= t) {
+          ta.Rg[(size_t)(ko + i) * m + (ko + t)] = outR[i];
+          if (sR != nullptr) sR[(ko + i) * LK + (ko + t)] = outR[i];
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
   __syncthreads();
-  for (int e = t; e < sb * sb; e += nt) {   // R entries of the block's own rows: rotated values above the diagonal, d on it
-    const int i = e / sb, tt = e % sb;
-    if (tt >= i) ta.Rg[(size_t)(ko + i) * m + (ko + tt)] = NC[tt * K + ko + i];
-  }
   if (t == 0) {
     nk_gmres_ctl *ctl = ta.ctl;
-    const double tol = ctl->tol;
-    int closed = 0, dn = 0;
-    double rn = ctl->rnorm, beta = 0.0;
+    const double tol = w.Fx[SS_SMAX + 1];
+    int closed = 0, dn = 0, cv = 0, fl = 0;
+    double rn = 0.0, beta = 0.0;   // (sb ≥ 1: both are set by the first column)
     for (int j = 0; j < sb && !dn; ++j) {
       const int jc = ko + j;
       const double c = scs[jc], sgn = ssn[jc];
@@ -459,16 +514,20 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
       sg[jc] = c * gj;
       rn = fabs(sgn * gj);
       closed = j + 1;
-      if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; dn = 1; }
-      else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; dn = 1; }
-      else if (beta == 0.0) { ctl->converged = 1; dn = 1; }
+      if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; fl = 1; dn = 1; }
+      else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; cv = 1; dn = 1; }
+      else if (beta == 0.0) { ctl->converged = 1; cv = 1; dn = 1; }
     }
+    if (verdict != nullptr) { verdict[0] = (double)(ko + closed); verdict[1] = (double)cv; verdict[2] = (double)fl; verdict[3] = rn; }
     for (int j = 0; j < closed; ++j) { ta.cs[ko + j] = scs[ko + j]; ta.sn[ko + j] = ssn[ko + j]; ta.g[ko + j] = sg[ko + j]; }
     ta.g[ko + closed] = sg[ko + closed];
     ctl->rnorm = rn;
     ctl->hn = beta;
     ctl->k = ko + closed;
-    if (dn) ctl->done = 1;
+    if (dn) {
+      ctl->done = 1;
+      if (raise_pad1) ctl->pad1 = 1;
+    }
     for (int c = 0; c < sb; ++c) ta.sc[k + c] = 1.0;  // the new columns are normalised
     ta.scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
     ss_pub_progress(ta.pub, ta.seq, ctl->k, dn);
@@ -479,19 +538,25 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
 // the scalar work as launches of their own (the streaming size class k + s > 48, and NK_SS_FUSED=0)
 __global__ __launch_bounds__(256) void k_ss_tail1(int k, int sb, double *__restrict__ coef, ss_tail_args ta) {
   extern __shared__ double s_tail[];
+  __shared__ ss_fixc s_fc;
   if (ta.ctl->done) return;
   const ss_ws w = ss_ws_carve(s_tail, k, sb, false);
-  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix, ta.ptol)) { ss_fail(ta); return; }
+  ss_fixc_request(&s_fc, ta.fix, s_tail + ss_ws_doubles(k, sb, false), 0);
+  __syncthreads();
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, s_fc, ta.fix.n, ta.ptol)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
-  ss_keep_pass1(k, sb, w, ta);
+  ss_keep_pass1(k, sb, w, ta, ta.red);
 }
 __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restrict__ coef, ss_tail_args ta) {
   extern __shared__ double s_tail[];
+  __shared__ ss_fixc s_fc;
   if (ta.ctl->pad1) return;  // (pad1: the cycle was done when this block started, or its first pass failed)
   const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
-  if (!ss_factor(k, sb, ta.red, ta.sc, w, ta.fix, ta.ptol)) { ss_fail(ta); return; }
+  ss_fixc_request(&s_fc, ta.fix, s_tail + ss_ws_doubles(k, sb, true), 0);
+  __syncthreads();
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, s_fc, ta.fix.n, ta.ptol)) { ss_fail(ta); return; }
   if (ta.Wi != nullptr && !ss_first_pass_departure_ok(k, sb, w, 0.1)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) { coef[e] = w.U[e]; ta.C2[e] = w.Ct[e]; }
@@ -502,15 +567,15 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
 }
 // the Hessenberg columns of a block as a launch of its own: the LAST block of a cycle, whose third sweep is never run (below)
 // (shared by k_ss_hess and the sweeps that host this work in their workgroup 0)
-__device__ void ss_hess_block(int k, int sb, double *lds, const ss_tail_args &ta) {
+__device__ void ss_hess_block(int k, int sb, double *lds, const ss_tail_args &ta, bool raise_pad1 = false) {
   const ss_ws w = ss_ws_carve(lds, k, sb, true);
   const int t = threadIdx.x;
-  for (int e = t; e < k * sb; e += blockDim.x) w.Ct[e] = ta.C2[e];      // pass 2's factors, left by the reduction's last workgroup
+  for (int e = t; e < k * sb; e += SS_R) w.Ct[e] = ta.C2[e];      // pass 2's factors, left by the reduction's last workgroup
   if (t < sb * sb) w.Rm[t] = ta.R2[t];
   ss_hess_load(k, sb, w, ta);   // (the same round trip: hosted beside streaming workgroups a round trip is ≈ 4 µs)
   __syncthreads();
   if (ta.Wi != nullptr) ss_fix_prepare(k, sb, w.Ct, w.Rm, w.Sm, ta.Wi, ta.D);   // (Sm is free: ss_factor is not run here)
-  ss_hessenberg(k, sb, w, ta, true);
+  ss_hessenberg(k, sb, w, ta, true, nullptr, 0, raise_pad1);
 }
 __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta) {
   extern __shared__ double s_tail[];
@@ -744,10 +809,13 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
 // Same contract as k_ss_block<S, true, true, …>: `coef` = U (k × S) then R (S × S, reciprocal diagonal); the updated columns go
 // back to V[:, k..k+S) and the Gram block [V Q]ᵀQ to `partials`. Rounding differs from the substitution form in the last bits
 // (explicit inverse: the same ε κ(R) bound; pass 2 of the block scheme repairs both alike).
-template <int S, int KC>
+// HOST: workgroup 0 streams no tiles — it derives the Hessenberg columns, rotations and stopping test of the PREVIOUS block
+// (hk, hs), whose second factorisation was deferred into the launch in front of this sweep (its workspace overlays the tile);
+// the other workgroups share the tiles evenly (⌊tiles/(grid − 1)⌋ or one more).
+template <int S, int KC, bool HOST>
 __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restrict__ V, int64_t ldv,
                                                       const double *__restrict__ coef, double *__restrict__ partials,
-                                                      const int *d_skip, int ntiles, int *mark) {
+                                                      const int *d_skip, int ntiles, int *mark, ss_tail_args hta, int hk, int hs) {
   {
     const int dskip = (d_skip != nullptr) ? *d_skip : 0;
     if (mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *mark = dskip;
@@ -756,10 +824,17 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   extern __shared__ double sX[];
   constexpr int k = KC, K = KC + S, NT = (K + 15) / 16, NKS = (K + 3) / 4;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, q4 = lane >> 4;
+  if (HOST && blockIdx.x == 0) {
+    for (int e = t; e < K * S; e += SS_R) partials[(size_t)e * gridDim.x] = 0.0;
+    ss_hess_block(hk, hs, sX, hta, true);
+    return;
+  }
   double *__restrict__ Wc = V + (size_t)k * ldv;
-  const int nwk = (int)gridDim.x, me = (int)blockIdx.x;
+  const int nwk = (int)gridDim.x - (HOST ? 1 : 0), me = (int)blockIdx.x - (HOST ? 1 : 0);
   const int tpw = (ntiles + nwk - 1) / nwk;
-  const int tile0 = me * tpw, tile1 = min(tile0 + tpw, ntiles);
+  const int tq = ntiles / nwk, tr = ntiles - tq * nwk;
+  const int tile0 = HOST ? me * tq + min(me, tr) : me * tpw;
+  const int tile1 = HOST ? tile0 + tq + (me < tr ? 1 : 0) : min(tile0 + tpw, ntiles);
   double vr[KC], w[S], vr2[KC], w2[S];
   // (tile < 0: a prefetch past the workgroup's last tile — issued all the same, so that the waits stay exact — reads 2 KB of
   //  column 0 k + S times over: its own last tile again was 62 KB per workgroup, 32 MB over the grid = the whole L2, +9 % HBM
@@ -922,222 +997,6 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   }
 }
 
-// GROUNDWORK (round 4, not yet used by the solver — DESIGN §9 item 3): the sweeps of ONE block of 17 … 32 columns, i.e. a whole
-// GMRES(30) cycle as a single block behind its start vector. The same kernel as k_ss_block_mm with TWO 16-wide matrix-core tiles
-// of new columns: T = [−U N ; N] is (k + S) × S with S up to 32, the update takes (k + S)/4 × 2 products per 16 rows, the Gram
-// block [V Q]ᵀQ is ⌈(k + S)/16⌉ × 2 accumulator tiles; the LDS tile has k + 32 columns (two spare columns take the padding
-// lanes). UPDATE = false: sweep A (Gram block of the raw columns only). Reached through the development harness
-// (nk_ss_sweep_test) for measurement and parity; the block's scalar work (ss_factor / ss_hessenberg for s > 16) does not exist yet.
-template <int S, int KC, bool UPDATE>
-__global__ __launch_bounds__(SS_R, 2) void k_ss_block_wide(int64_t n, double *__restrict__ V, int64_t ldv,
-                                                        const double *__restrict__ coef, double *__restrict__ partials,
-                                                        const int *d_skip, int ntiles) {
-  if (d_skip != nullptr && *d_skip != 0) return;
-  static_assert(S > 16 && S <= 32, "two 16-wide tiles of new columns");
-  extern __shared__ double sX[];
-  constexpr int k = KC, K = KC + S, NT = (K + 15) / 16, NKS = (K + 3) / 4, NN = 2, SP = 32;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, q4 = lane >> 4;
-  double *__restrict__ Wc = V + (size_t)k * ldv;
-  const int nwk = (int)gridDim.x, me = (int)blockIdx.x;
-  const int tpw = (ntiles + nwk - 1) / nwk;
-  const int tile0 = me * tpw, tile1 = min(tile0 + tpw, ntiles);
-  double vr[KC], w[S], vr2[KC], w2[S];
-  auto prefetch = [&](double (&vrx)[KC], double (&wx)[S], int tile) __attribute__((always_inline)) {
-    const int64_t r = (int64_t)(tile < 0 ? tile0 : tile) * SS_R + t;
-    const int64_t rc = r < n ? r : n - 1;
-    const size_t cs = tile < 0 ? 0 : (size_t)ldv;
-    const double *__restrict__ Wr = tile < 0 ? V : Wc;
-#pragma unroll
-    for (int c = 0; c < S; ++c) wx[c] = Wr[(size_t)c * cs + rc];
-#pragma unroll
-    for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * cs + rc];
-  };
-  if (tile0 < tile1) {
-    prefetch(vr, w, tile0);
-    prefetch(vr2, w2, tile0 + 1 < tile1 ? tile0 + 1 : -1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  double tb[UPDATE ? NKS : 1][NN];
-  if constexpr (UPDATE) {
-    double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + SP * SP;
-    for (int e = t; e < k * S + S * S; e += SS_R) sX[e] = coef[e];
-    for (int e = t; e < SP * SP; e += SS_R) sN[e] = 0.0;
-    __syncthreads();
-    if (t < S) {   // row t of N = R⁻¹ (R's diagonal arrives as reciprocals); sequential in c, LDS-resident (no register array)
-      for (int c = t; c < S; ++c) {
-        double a = (c == t) ? 1.0 : 0.0;
-        for (int c2 = t; c2 < c; ++c2) a = __builtin_fma(-sN[t * SP + c2], sR[c2 * S + c], a);
-        sN[t * SP + c] = a * sR[c * S + c];
-      }
-    }
-    __syncthreads();
-    for (int e = t; e < 4 * NKS * SP; e += SS_R) {
-      const int j = e / SP, c = e % SP;
-      double v = 0.0;
-      if (c < S) {
-        if (j < k) {
-          double a = 0.0;
-          for (int c2 = 0; c2 <= c; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * SP + c], a);
-          v = -a;
-        } else if (j < K) {
-          v = sN[(j - k) * SP + c];
-        }
-      }
-      sT[e] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-      for (int nn = 0; nn < NN; ++nn) tb[ks][nn] = sT[(4 * ks + q4) * SP + 16 * nn + li];
-    }
-    __syncthreads();
-  }
-  ss_d4 acc[NT][NN];
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {
-#pragma unroll
-    for (int nn = 0; nn < NN; ++nn) acc[mt][nn] = ss_d4{0.0, 0.0, 0.0, 0.0};
-  }
-  const double *pu[NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int col = 4 * ks + q4;
-    pu[ks] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + li;
-  }
-  const double *pb[NN];
-  double *pq[NN];
-#pragma unroll
-  for (int nn = 0; nn < NN; ++nn) {
-    const int c = 16 * nn + li;
-    pb[nn] = sX + (k + (c < S ? c : S - 1)) * SS_P + wv * 64 + q4;
-    pq[nn] = sX + (k + c) * SS_P + wv * 64 + q4;   // (c ≥ S: the spare columns of the tile)
-  }
-  const double *pa[NT];
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {
-    const int col = mt * 16 + li;
-    pa[mt] = sX + (col < K ? col : K - 1) * SS_P + wv * 64 + q4;
-  }
-  const unsigned ldvb = (unsigned)ldv * 8u;
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc((void *)Wc, 0, (int)(unsigned)(((int64_t)(S - 1) * ldv + n) * 8), 0x00020000);
-  auto process = [&](double (&vr)[KC], double (&w)[S], int tile, bool valid, int next) __attribute__((always_inline)) {
-    const int64_t r = (int64_t)tile * SS_R + t;
-    const bool ok = valid && r < n;
-#pragma unroll
-    for (int j = 0; j < KC; ++j) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
-#pragma unroll
-    for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
-    __builtin_amdgcn_sched_barrier(0);
-    prefetch(vr, w, next);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (UPDATE) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        ss_d4 q[NN];
-#pragma unroll
-        for (int nn = 0; nn < NN; ++nn) q[nn] = ss_d4{0.0, 0.0, 0.0, 0.0};
-        double a[NKS];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) a[ks] = pu[ks][g * 16];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-          for (int nn = 0; nn < NN; ++nn) q[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], tb[ks][nn], q[nn], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nn = 0; nn < NN; ++nn) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) pq[nn][g * 16 + 4 * rr] = q[nn][rr];
-        }
-      }
-      const unsigned rbyte = (unsigned)r * 8u;
-#pragma unroll
-      for (int c = 0; c < S; ++c) {
-        const double qv = sX[(k + c) * SS_P + t];
-        const unsigned off = ok ? (unsigned)c * ldvb + rbyte : 0xFFFFFFFFu;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u2, qv), wrs, (int)off, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4) {
-      double bb[NN][4], aa[NT][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int nn = 0; nn < NN; ++nn) bb[nn][u] = pb[nn][(kk + u) * 4];
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) aa[mt][u] = pa[mt][(kk + u) * 4];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-#pragma unroll
-          for (int nn = 0; nn < NN; ++nn)
-            acc[mt][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[mt][u], bb[nn][u], acc[mt][nn], 0, 0, 0);
-        }
-      }
-    }
-  };
-  auto pair = [&](int tile) __attribute__((always_inline)) {
-    process(vr, w, tile, true, tile + 2 < tile1 ? tile + 2 : -1);
-    process(vr2, w2, tile + 1, tile + 1 < tile1, tile + 3 < tile1 ? tile + 3 : -1);
-  };
-  if (tile0 < tile1) {
-    pair(tile0);
-    for (int tile = tile0 + 2; tile < tile1; tile += 2) pair(tile);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {
-#pragma unroll
-    for (int nn = 0; nn < NN; ++nn) {
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) sX[(((wv * NT + mt) * NN + nn) * 4 + rr) * 64 + lane] = acc[mt][nn][rr];
-    }
-  }
-  __syncthreads();
-  constexpr int WSTR = NT * NN * 256;   // one wavefront's accumulators
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {
-#pragma unroll
-    for (int nn = 0; nn < NN; ++nn) {
-      const int rr = t >> 6, ln = t & 63;
-      const int mrow = mt * 16 + (ln >> 4) + 4 * rr, ncol = 16 * nn + (ln & 15);
-      if (mrow < K && ncol < S) {
-        const int e = ((mt * NN + nn) * 4 + rr) * 64 + ln;
-        const double sum = (sX[e] + sX[WSTR + e]) + (sX[2 * WSTR + e] + sX[3 * WSTR + e]);
-        partials[(size_t)(mrow * S + ncol) * gridDim.x + blockIdx.x] = sum;
-      }
-    }
-  }
-}
-// the wide block's shape: one block of 30 columns behind the cycle's start vector
-static bool ss_wide_shape(int k, int s) { return k == 1 && s == 30; }
-static int ss_launch_wide(nk_ctx *ctx, int mode, int64_t n, double *V, int64_t ldv, const double *coef, double *partials,
-                          const int *d_skip, int grid, int *occ_out) {
-  const size_t lds = (size_t)(1 + 32) * SS_P * sizeof(double);
-  const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool ev = !occ_out && ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
-#define SS_WIDE(UPD)                                                                                                      \
-  do {                                                                                                                    \
-    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_wide<30, 1, UPD>),                              \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
-    if (occ_out) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_wide<30, 1, UPD>, SS_R, lds));   \
-    else if (ev) hipExtLaunchKernelGGL((k_ss_block_wide<30, 1, UPD>), dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
-                                       ldv, coef, partials, d_skip, ntiles);                                              \
-    else hipLaunchKernelGGL((k_ss_block_wide<30, 1, UPD>), dim3(grid), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials, \
-                            d_skip, ntiles);                                                                              \
-  } while (0)
-  if (mode == 0) SS_WIDE(false); else SS_WIDE(true);
-#undef SS_WIDE
-  NK_HIP(hipGetLastError());
-  return NK_OK;
-}
-
 static size_t ss_tile_doubles(int k, int s, bool gram, int nt) {
   if (!gram) return 0;
   const size_t a = (size_t)(k + s) * SS_P, b = (size_t)4 * nt * 256;
@@ -1167,21 +1026,9 @@ static int ss_per_cu(nk_ctx *ctx, int k, int s) {
 // tiles, so a CU is busy for per_cu·⌈tiles / (CUs·per_cu)⌉ of them: with 4096 tiles (n = 2²⁰) on 256 CUs three workgroups per CU
 // (what the 15-column block behind one column fits) make that 18 where two or four make it 16 — measured 25.6 → 24.2 and
 // 47.4 → 45.7 µs for sweeps A and B of that shape with two. The largest count that reaches the minimum is taken.
-static int ss_launch_wide(nk_ctx *ctx, int mode, int64_t n, double *V, int64_t ldv, const double *coef, double *partials,
-                          const int *d_skip, int grid, int *occ_out);
-static bool ss_wide_shape(int k, int s);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
-  int occ;
-  if (ss_wide_shape(k, s)) {
-    int oa = 0, ob = 0;
-    if (ss_launch_wide(ctx, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, 1, &oa) != NK_OK || oa < 1) oa = 1;
-    if (ss_launch_wide(ctx, 1, 1, nullptr, 0, nullptr, nullptr, nullptr, 1, &ob) != NK_OK || ob < 1) ob = 1;
-    occ = oa < ob ? oa : ob;
-    if (occ > SS_MAX_WG_PER_CU) occ = SS_MAX_WG_PER_CU;
-  } else {
-    occ = ss_per_cu(ctx, k, s);
-  }
+  const int occ = ss_per_cu(ctx, k, s);
   int best = occ;
   int64_t best_cost = INT64_MAX;
   for (int p = occ; p >= 1; --p) {
@@ -1263,26 +1110,33 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   if constexpr (S == 15) {
     static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);   // A/B switch
     if (mode == 1 && mm_on && (k == 1 || k == 16) && (occ_out || (int64_t)S * ldv * 8 < ((int64_t)1 << 32) - 8)) {
-      const size_t lds = (size_t)(k + S + 1) * SS_P * sizeof(double);   // the tile + the spare column
-#define SS_MM(KCC)                                                                                                        \
+      const size_t tile_b = (size_t)(k + S + 1) * SS_P * sizeof(double);   // the tile + the spare column
+      // tap: workgroup 0 hosts the previous block's Hessenberg work (hk, hs); its workspace overlays the tile it does not use
+      const bool hostB = tap != nullptr && !occ_out;
+      NK_REQUIRE(!hostB || g > 1, "internal: a hosting sweep B needs a second workgroup");
+      const size_t ws_b = hostB ? ss_ws_doubles(hk, hs, true) * sizeof(double) : 0;
+      const size_t lds = tile_b > ws_b ? tile_b : ws_b;
+#define SS_MM(KCC, HST)                                                                                                   \
   do {                                                                                                                    \
     if (lds > 64 * 1024)                                                                                                  \
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_mm<S, KCC>),                                  \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_mm<S, KCC, HST>),                             \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
     if (occ_out) {                                                                                                        \
-      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_mm<S, KCC>, SS_R, lds));                    \
-    } else if (ev) hipExtLaunchKernelGGL((k_ss_block_mm<S, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
-                                         ldv, coef, partials, d_skip, ntiles, mark);                                      \
-    else hipLaunchKernelGGL((k_ss_block_mm<S, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials,    \
-                            d_skip, ntiles, mark);                                                                        \
+      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_mm<S, KCC, HST>, SS_R, lds));               \
+    } else if (ev) hipExtLaunchKernelGGL((k_ss_block_mm<S, KCC, HST>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
+                                         ldv, coef, partials, d_skip, ntiles, mark, ta, hk, hs);                          \
+    else hipLaunchKernelGGL((k_ss_block_mm<S, KCC, HST>), dim3(g), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials, \
+                            d_skip, ntiles, mark, ta, hk, hs);                                                            \
   } while (0)
-      if (k == 1) SS_MM(1); else SS_MM(16);
+      if (hostB) { if (k == 1) SS_MM(1, true); else SS_MM(16, true); }
+      else { if (k == 1) SS_MM(1, false); else SS_MM(16, false); }
 #undef SS_MM
       NK_HIP(hipGetLastError());
       return NK_OK;
     }
   }
   static const bool kc_on = !(getenv("NK_SS_KCONST") && atoi(getenv("NK_SS_KCONST")) == 0);   // A/B switch
+  NK_REQUIRE(!(mode == 1 && tap != nullptr), "internal: sweep B of this shape (k = %d, s = %d) cannot host a Hessenberg workgroup", k, S);
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
   else {                                    // sweep C: update only — no LDS tile
@@ -1304,11 +1158,6 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
 // mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
 static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
                              const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out, int hk = 0, int hs = 0) {
-  if (ss_wide_shape(k, s)) {   // groundwork: the sweeps of a 30-column block (harness only)
-    NK_REQUIRE(mode == 0 || mode == 1, "wide block: sweeps A and B only");
-    NK_REQUIRE(occ_out || (int64_t)s * ldv * 8 < ((int64_t)1 << 32) - 8, "wide block: the block's columns must fit one 4 GiB buffer");
-    return ss_launch_wide(ctx, mode, n, V, ldv, coef, partials, d_skip, grid, occ_out);
-  }
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
@@ -1356,47 +1205,171 @@ int nk_ss_block_width(int want) {
   return want > 8 ? 8 : want;
 }
 
-// ----------------------------------------------------------------------------- stage-2 reduction + the block's scalar work
-// One launch after a Gram sweep: workgroup e sums partial block entry e in the fixed order (as k_reduce_sum); the workgroup
-// that takes the last ticket then factors the reduced block (ss_factor, ≈ 2 µs on one wavefront) and leaves the update
-// coefficients [U ; R⁻¹] in `coef` for the next sweep's scalar loads — pass 0 also keeps C₁, R₁, pass 1 leaves C₂, R₂ for the
-// Hessenberg workgroup of sweep C. (Every persistent workgroup of the consuming sweep factored the block itself in round 2:
-// with blocks of 15 columns that prologue cost 15 µs per sweep and the LDS-resident coefficients 25 % of the update sweeps'
-// rate.) Several ranks on peer-mapped arenas: the same launch is also the all-reduce (k_reduce_sum_allreduce's protocol):
-// every workgroup stores its sum into every rank's arena, the last one releases the flags, waits, combines in rank order.
+// ----------------------------------------------------------------------------- the scalar work of the block scheme: one launch
+// Everything between two sweeps that is NOT a sweep, in one kind of launch (round 5; rounds 3–4: k_ss_reduce_factor after every
+// sweep + k_ss_hess + k_backsolve, 121 µs of a 532 µs Newton step in seven one-workgroup critical sections).
+//   * stage-2 reduction: one wavefront per entry of up to TWO partial Gram blocks — set 0: this block's sweep A (its first
+//     pass), set 1: the PREVIOUS block's sweep B (its second pass, deferred: nothing in front of the next block's sweep A needs
+//     those factors, so that block's reduce-and-factor launch is gone and the reduction rides here) — fixed order, one ticket
+//     per workgroup; several ranks on peer-mapped arenas: this is also the all-reduce (ONE message for both sets);
+//   * the workgroup that draws the last ticket requests EVERYTHING its serial phases will read in one round trip (both reduced
+//     blocks, the column scales, the earlier blocks' factors, the Hessenberg work's inputs, the rotated factor for the
+//     back-substitution) and then runs, as the job's bits say:
+//       SSJ_F2    the pending block's second factorisation (+ the first-pass departure test when it is left at that pass) → C₂, R₂
+//       SSJ_PREP  its Wi = R₂⁻¹, D = C₂R₂⁻¹ (what the next blocks' reductions apply), kept in LDS for the factorisation below
+//       SSJ_COEF2 … and the coefficients of an explicit third sweep (blocks that are not left at their first pass)
+//       SSJ_F1    this block's first factorisation → the coefficients of sweep B, C₁, R₁
+//       SSJ_HESS  the pending block's Hessenberg columns, rotations and stopping test (otherwise: hosted by a sweep)
+//       SSJ_BACK  the cycle's back-substitution, the outcome published to the host (the cycle's LAST launch of this kind:
+//                 reduce → factor → Hessenberg → y without leaving the workgroup's LDS — three launches and their global
+//                 round trips in rounds 3–4).
+// A failure (lost pivot, departure) or a cycle that was done before this launch skips everything but the back-substitution.
+constexpr int SSJ_F1 = 1, SSJ_F2 = 2, SSJ_HESS = 4, SSJ_BACK = 8, SSJ_COEF2 = 16, SSJ_PREP = 32;
+struct ss_job {
+  const double *part0, *part1;
+  int nblk0, nblk1, nslots0, nslots1;
+  int k0, sb0, k1, sb1;   // [0]: this block (first pass); [1]: the pending block (second pass)
+  int mode, m;
+  double *red, *coef;
+  const int *d_skip;
+  unsigned int *ticket;
+  nk_gmres_ctl *ctl;          // (what both blocks' argument sets share)
+  const double *sc;
+  nk_gmres_pub *pub;
+  uint64_t seq;
+  nk_ss_fix cfix;             // the earlier blocks whose factors the factorisations apply: this block's list (SSJ_F1), else the pending block's
+  double *y;                  // SSJ_BACK
+  const double *Rg, *g;
+  const uint64_t *peer_err;
+  nk_ss_fix bfx;              // SSJ_BACK: the blocks left at their first pass (the pending block is the last of them)
+};
+struct ss_job_lds { size_t sc, fix, w1, w0, sR, sg, verdict, bfix, total; int LK; };
+__host__ __device__ inline ss_job_lds ss_job_layout(const ss_job &j) {
+  ss_job_lds L;
+  const bool f1 = (j.mode & SSJ_F1) != 0, f2 = (j.mode & SSJ_F2) != 0, hs = (j.mode & SSJ_HESS) != 0, bk = (j.mode & SSJ_BACK) != 0;
+  size_t o = (size_t)j.nslots0 + j.nslots1;
+  L.sc = o; o += (size_t)((f1 && j.k0 > j.k1) ? j.k0 : (f2 ? j.k1 : j.k0)) + 1;
+  L.fix = o; o += ss_fixc_doubles(j.cfix);
+  L.w1 = o; o += f2 ? ss_ws_doubles(j.k1, j.sb1, hs) : 0;
+  L.w0 = o; o += f1 ? ss_ws_doubles(j.k0, j.sb0, false) : 0;
+  L.LK = j.m | 1;
+  L.sR = o; o += bk ? (size_t)j.m * L.LK : 0;
+  L.sg = o; o += bk ? (size_t)j.m + 2 : 0;
+  L.verdict = o; o += 8;
+  L.bfix = o; o += bk ? ss_fixc_doubles(j.bfx) : 0;
+  L.total = o;
+  return L;
+}
+// y = R⁻¹ g on one wavefront (lane t owns g_t; reciprocal diagonal up front, the pivot broadcast with v_readlane), then the
+// blocks left at their first pass, last first: coefficients on [V_true Q] → on V_true and the block's stored columns
+// (nk_gmres.hip's k_backsolve, on operands that are in LDS already). bc: (C₂, R₂) per block.
+__device__ void ss_backsolve(int k, int failed, const double *sR, int LK, const double *sg, double *y, int m, const ss_fixc &bc) {
+  const int t = threadIdx.x;
+  if (t >= 64) return;
+  double gv = (t < k) ? sg[t] : 0.0;
+  if (!failed) {
+    const double rd = (t < k) ? 1.0 / sR[t * LK + t] : 0.0;
+    for (int i = k - 1; i >= 0; --i) {
+      const double yi = ss_readlane(gv * rd, i);
+      if (t < i) gv = __builtin_fma(-sR[t * LK + i], yi, gv);
+      if (t == i) gv = yi;
+    }
+    for (int bq = bc.n - 1; bq >= 0; --bq) {
+      const int fk0 = bc.k0[bq], fsb = bc.sb[bq];
+      if (k <= fk0) continue;   // (a cycle that ended before the block: nothing of it in y)
+      const double *c2 = bc.D[bq], *r2 = bc.Wi[bq];
+      const int cc = t - fk0;
+      const double rd2 = (cc >= 0 && cc < fsb) ? 1.0 / r2[cc * fsb + cc] : 0.0;
+      for (int c = fsb - 1; c >= 0; --c) {             // b = R₂⁻¹ y_Q on lanes k0 … k0 + sb − 1 (y is zero from k on)
+        const double bcv = ss_readlane(gv * rd2, fk0 + c);
+        if (t >= fk0 && t < fk0 + c) gv = __builtin_fma(-r2[(t - fk0) * fsb + c], bcv, gv);
+        if (t == fk0 + c) gv = bcv;
+      }
+      double acc = 0.0;
+      for (int c = 0; c < fsb; ++c) {
+        const double bcv = ss_readlane(gv, fk0 + c);
+        if (t < fk0) acc = __builtin_fma(c2[t * fsb + c], bcv, acc);
+      }
+      if (t < fk0) gv -= acc;
+    }
+  } else {
+    gv = 0.0;
+  }
+  if (t < m) y[t] = gv;
+}
+__device__ void ss_publish_outcome(nk_gmres_pub *pub, uint64_t seq, const uint64_t *peer_err, int k, int converged, int failed,
+                                   double rnorm0, double rnorm) {
+  if (pub == nullptr) return;
+  pub->k = k;
+  pub->converged = converged;
+  pub->failed = failed;
+  pub->rnorm0 = rnorm0;
+  pub->rnorm = rnorm;
+  pub->pad = peer_err ? (int)(__hip_atomic_load(peer_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fffffff) : 0;
+  __threadfence_system();
+  __hip_atomic_store(&pub->end_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// requests of the back-substitution: the rotated factor, g, the earlier blocks' (C₂, R₂) (all but the last `skip_last`)
+__device__ void ss_back_request(const ss_job &j, const ss_job_lds &L, double *lds, ss_fixc *bc, int skip_last) {
+  const int t = threadIdx.x, m = j.m;
+  double *sR = lds + L.sR, *sg = lds + L.sg;
+  for (int e = t; e < m * m; e += SS_R) {
+    const int i = e / m, c = e - i * m;
+    sR[i * L.LK + c] = j.Rg[(size_t)i * m + c];
+  }
+  for (int e = t; e <= m; e += SS_R) sg[e] = j.g[e];
+  if (t == 0) lds[L.verdict + 4] = j.ctl->rnorm0;
+  ss_fixc_request(bc, j.bfx, lds + L.bfix, skip_last, true);
+}
+// the back-substitution alone (the cycle was done before this launch): every operand from global memory
+__device__ void ss_back_only(const ss_job &j, const ss_job_lds &L, double *lds, ss_fixc *bc) {
+  ss_back_request(j, L, lds, bc, 0);
+  double *vd = lds + L.verdict;
+  if (threadIdx.x == 0) {
+    vd[0] = (double)j.ctl->k; vd[1] = (double)j.ctl->converged; vd[2] = (double)j.ctl->failed; vd[3] = j.ctl->rnorm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ss_publish_outcome(j.pub, j.seq, j.peer_err, (int)vd[0], (int)vd[1], (int)vd[2], vd[4], vd[3]);
+  ss_backsolve((int)vd[0], (int)vd[2], lds + L.sR, L.LK, lds + L.sg, j.y, j.m, *bc);
+}
 template <bool PEER>
-__global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restrict__ partials, int nblk, int nslots,
-                                                           double *__restrict__ red, const int *d_skip, unsigned int *ticket,
-                                                           int k, int sb, int pass, double *__restrict__ coef, ss_tail_args ta,
-                                                           nk_peer_ar_view pv) {
+__global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_args ta0, const ss_tail_args ta1, const nk_peer_ar_view pv) {
   extern __shared__ double s_rf[];
   __shared__ unsigned int s_last;
-  const int skip = (d_skip != nullptr) ? *d_skip : 0;
+  __shared__ ss_fixc s_fc, s_bc;
+  const int skip = (j.d_skip != nullptr) ? *j.d_skip : 0;
   const int t = threadIdx.x, slot = blockIdx.x;
+  const bool f1 = (j.mode & SSJ_F1) != 0, f2 = (j.mode & SSJ_F2) != 0, hs = (j.mode & SSJ_HESS) != 0, bk = (j.mode & SSJ_BACK) != 0;
   if (slot == 0) SS_STAMP(0);
   // one wavefront per entry (four entries per workgroup): fixed order — lane l adds partials l, l + 64, …, then the
   // butterfly —, and one ticket per workgroup (465 same-address atomics of a workgroup-per-entry launch took 6 µs)
   const int wv = t >> 6, lane = t & 63;
-  const int entry = slot * 4 + wv;
+  const int entry = slot * 4 + wv, nslots = j.nslots0 + j.nslots1;
   double v = 0.0;
   if (entry < nslots) {
-    const double *p = partials + (size_t)entry * nblk;
+    const bool first = entry < j.nslots0;
+    const int nblk = first ? j.nblk0 : j.nblk1;
+    const double *p = first ? j.part0 + (size_t)entry * nblk : j.part1 + (size_t)(entry - j.nslots0) * nblk;
     for (int base = 0; base < nblk; base += 512) {   // eight loads in flight per lane (a rolled loop made eight round trips)
       double x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = base + lane + 64 * j;
-        x[j] = p[i < nblk ? i : nblk - 1];
+      for (int q = 0; q < 8; ++q) {
+        const int i = base + lane + 64 * q;
+        x[q] = p[i < nblk ? i : nblk - 1];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v += (base + lane + 64 * j < nblk) ? x[j] : 0.0;
+      for (int q = 0; q < 8; ++q) v += (base + lane + 64 * q < nblk) ? x[q] : 0.0;
     }
   }
   // (the flag was requested together with the partials: one round trip; a collective runs on every rank even when the cycle
-  //  is done.) The cycle may have ended INSIDE the sweep in front of this launch — a sweep A that hosts the previous block's
-  //  Hessenberg columns and stopping test —: the sweeps and Hessenberg launches behind a skipped reduction look at pad1.
-  if (skip && slot == 0 && t == 0) ta.ctl->pad1 = 1;
-  if (skip && !PEER) return;
+  //  is done.) The cycle may have ended INSIDE a sweep in front of this launch (a hosted Hessenberg workgroup's stopping test):
+  //  the sweeps and Hessenberg launches behind a skipped job look at pad1.
+  const ss_job_lds L = ss_job_layout(j);
+  if (skip && slot == 0 && t == 0) j.ctl->pad1 = 1;
+  if (skip && !PEER) {
+    if (bk && slot == 0) ss_back_only(j, L, s_rf, &s_bc);
+    return;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (lane == 0 && entry < nslots) {
@@ -1405,7 +1378,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
       for (int q = 0; q < pv.P; ++q) reinterpret_cast<nk_peer_hdr *>(pv.map[q])->ar_data[par][pv.me][entry] = v;
       __threadfence_system();
     } else {
-      red[entry] = v;
+      j.red[entry] = v;
     }
   }
   // hand-off to the last workgroup (any XCD): plain stores → barrier → ONE agent-scope release (+ the wait the compiler may
@@ -1416,14 +1389,14 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const unsigned int last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    const unsigned int last = (atomicAdd(j.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
   SS_STAMP(1);
-  if (t == 0) *ticket = 0u;   // (for the next launch: the kernel boundary publishes it)
+  if (t == 0) *j.ticket = 0u;   // (for the next launch: the kernel boundary publishes it)
   if (PEER) {
     const int par = (int)(pv.seq & 1);
     nk_peer_hdr *mine = reinterpret_cast<nk_peer_hdr *>(pv.map[pv.me]);
@@ -1439,40 +1412,87 @@ __global__ __launch_bounds__(SS_R) void k_ss_reduce_factor(const double *__restr
       }
     }
     __syncthreads();
-    for (int e = t; e < nslots; e += SS_R) {
+    for (int e = t; e < nslots; e += SS_R) {   // combined in rank order, straight into LDS
       double acc = mine->ar_data[par][0][e];
       for (int q = 1; q < pv.P; ++q) acc += mine->ar_data[par][q][e];
-      red[e] = acc;
+      s_rf[e] = acc;
     }
-    __threadfence();
-    __syncthreads();
-    if (skip) return;
+    if (skip) {
+      __syncthreads();
+      if (bk) ss_back_only(j, L, s_rf, &s_bc);
+      return;
+    }
+  } else {
+    // every entry of the reduced blocks is in `red` (written by other workgroups: read past the L1)
+    for (int e = t; e < nslots; e += SS_R) s_rf[e] = __builtin_nontemporal_load(&j.red[e]);
   }
-  // ---- the last workgroup: every entry of the reduced block is in `red` (written by other workgroups: read past the L1)
-  const ss_ws w = ss_ws_carve(s_rf + (size_t)nslots, k, sb, false);
-  for (int e = t; e < nslots; e += SS_R) s_rf[e] = __builtin_nontemporal_load(&red[e]);
-  if (ta.fix.n > 0) {   // the first block left at its first pass: its Wi, D ride in the same round trip as the reduced block
-    for (int e = t; e < ta.fix.k0[0] * ta.fix.sb[0]; e += SS_R) w.fC2[e] = ta.fix.D[0][e];
-    if (t < ta.fix.sb[0] * ta.fix.sb[0]) w.fR2[t] = ta.fix.Wi[0][t];
-  }
+  // ---- the last workgroup. Everything the serial phases read from global memory rides in the same round trip.
+  const double *red0 = s_rf, *red1 = s_rf + j.nslots0;
+  double *s_sc = s_rf + L.sc, *vd = s_rf + L.verdict;
+  const int ksc = (f1 && j.k0 > j.k1) ? j.k0 : (f2 ? j.k1 : j.k0);
+  for (int e = t; e < ksc; e += SS_R) s_sc[e] = j.sc[e];
+  const bool prep = f2 && (j.mode & SSJ_PREP) != 0 && ta1.Wi != nullptr;
+  ss_fixc_request(&s_fc, j.cfix, s_rf + L.fix, (f1 && prep) ? 1 : 0);   // (the pending block's slot is filled below)
+  ss_ws w1, w0;
+  if (f2) w1 = ss_ws_carve(s_rf + L.w1, j.k1, j.sb1, hs);
+  if (f1) w0 = ss_ws_carve(s_rf + L.w0, j.k0, j.sb0, false);
+  if (f2 && hs) ss_hess_load(j.k1, j.sb1, w1, ta1);
+  if (bk) ss_back_request(j, L, s_rf, &s_bc, f2 ? 1 : 0);
   __syncthreads();
   SS_STAMP(2);
-  ta.red = s_rf;
-  if (!ss_factor(k, sb, s_rf, ta.sc, w, ta.fix, ta.ptol, true)) { ss_fail(ta); return; }
-  SS_STAMP(3);
-  for (int e = t; e < k * sb; e += SS_R) coef[e] = w.U[e];
-  if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
-  if (pass == 0) {
-    ss_keep_pass1(k, sb, w, ta);
-  } else {
-    if (ta.Wi != nullptr && !ss_first_pass_departure_ok(k, sb, w, 0.1)) { ss_fail(ta); return; }   // (left at its first pass only if that pass was good)
-    for (int e = t; e < k * sb; e += SS_R) ta.C2[e] = w.Ct[e];
-    if (t < sb * sb) ta.R2[t] = w.Rm[t];
-    // the next block's matrix powers start from a column of unit scale (ss_hessenberg says the same — but where this block is
-    // left at its first pass its Hessenberg columns are derived AFTER the next block's powers were launched)
-    if (t == 0) ta.scal[0] = 1.0 / ta.scal[2];
+  bool alive = true;
+  if (f2) {
+    alive = ss_factor(j.k1, j.sb1, red1, s_sc, w1, s_fc, ta1.fix.n, ta1.ptol);
+    // (left at its first pass only if that pass was good)
+    if (alive && ta1.Wi != nullptr && !ss_first_pass_departure_ok(j.k1, j.sb1, w1, 0.1)) alive = false;
+    if (alive) {
+      for (int e = t; e < j.k1 * j.sb1; e += SS_R) ta1.C2[e] = w1.Ct[e];
+      if (t < j.sb1 * j.sb1) ta1.R2[t] = w1.Rm[t];
+      if (j.mode & SSJ_COEF2) {
+        for (int e = t; e < j.k1 * j.sb1; e += SS_R) j.coef[e] = w1.U[e];
+        if (t < j.sb1 * j.sb1) j.coef[(size_t)j.k1 * j.sb1 + t] = w1.Ri[t];
+      }
+      // the next block's matrix powers start from a column of unit scale
+      if (t == 0) ta1.scal[0] = 1.0 / ta1.scal[2];
+      if (prep) {
+        const int q = ta1.fix.n;   // the pending block's slot in this block's list (= its position among the earlier blocks)
+        ss_fix_prepare(j.k1, j.sb1, w1.Ct, w1.Rm, w1.Sm, ta1.Wi, ta1.D, f1 ? s_fc.Wi[q] : nullptr, f1 ? s_fc.D[q] : nullptr);
+      }
+    }
   }
+  SS_STAMP(3);
+  if (alive && f1) {
+    if (f2) {   // the pending block's columns are normalised (its Hessenberg work, which says so in `sc`, may not have run yet)
+      for (int e = j.k1 + t; e < j.k0; e += SS_R) s_sc[e] = 1.0;
+      __syncthreads();
+    }
+    alive = ss_factor(j.k0, j.sb0, red0, s_sc, w0, s_fc, ta0.fix.n, ta0.ptol);
+    if (alive) {
+      for (int e = t; e < j.k0 * j.sb0; e += SS_R) j.coef[e] = w0.U[e];
+      if (t < j.sb0 * j.sb0) j.coef[(size_t)j.k0 * j.sb0 + t] = w0.Ri[t];
+      ss_keep_pass1(j.k0, j.sb0, w0, ta0, red0);
+      if (t == 0) ta0.scal[0] = 1.0 / ta0.scal[2];   // (this block's powers have run; the next block's start from a unit column)
+    }
+  }
+  if (!alive) ss_fail(j.ctl, j.pub, j.seq);
   SS_STAMP(4);
+  if (alive && hs) ss_hessenberg(j.k1, j.sb1, w1, ta1, true, bk ? s_rf + L.sR : nullptr, L.LK, f1, bk ? vd : nullptr);
+  if (bk) {
+    __syncthreads();
+    if (t == 0) {
+      if (!(alive && hs)) {   // (a failure inside this launch: the columns closed before this block count, x stays as it is)
+        vd[0] = (double)j.ctl->k; vd[1] = 0.0; vd[2] = alive ? (double)j.ctl->failed : 2.0; vd[3] = j.ctl->rnorm;
+      }
+      ss_publish_outcome(j.pub, j.seq, j.peer_err, (int)vd[0], (int)vd[1], (int)vd[2], vd[4], vd[3]);
+    }
+    if (alive && f2 && t == 0) {   // the pending block's (C₂, R₂): in LDS already
+      const int q = j.bfx.n - 1;
+      s_bc.D[q] = w1.Ct;
+      s_bc.Wi[q] = w1.Rm;
+    }
+    __syncthreads();
+    ss_backsolve((int)vd[0], (int)vd[2], s_rf + L.sR, L.LK, (alive && hs) ? w1.sg : s_rf + L.sg, j.y, j.m, s_bc);
+  }
 }
 extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   static unsigned long long *d_st = nullptr;
@@ -1686,12 +1706,12 @@ extern "C" int nk_ss_leja_nodes(int s, double *out) {
 // ============================================================================= one restart cycle, s columns at a time
 struct nk_sstep {
   int s = 0, grid = 0;
-  double *part = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
+  double *part = nullptr, *part2 = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
   double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup), one slot per block
   double *Wi = nullptr, *D = nullptr;        // R₂⁻¹ and C₂R₂⁻¹ of the blocks left at their first pass (same slots)
   size_t c2_stride = 0;
   int nblk_slots = 0;
-  unsigned int *ticket = nullptr;            // last-workgroup ticket of k_ss_reduce_factor
+  unsigned int *ticket = nullptr;            // last-workgroup ticket of k_ss_job
   double *ival = nullptr, *nodes = nullptr;  // {−lo, hi} of the spectrum; Leja-ordered Chebyshev points for nodes_s columns
   const double *ival_use = nullptr;          // where this solve's bounds are: `ival`, or the matrix's cache (left by its fill kernel)
   const double *bpart = nullptr;             // the fill kernel's per-block bounds, to be reduced into ival_use by the next begin kernel
@@ -1701,7 +1721,7 @@ struct nk_sstep {
 };
 void nk_ss_destroy(nk_sstep *W) {
   if (!W) return;
-  hipFree(W->part); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
+  hipFree(W->part); hipFree(W->part2); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
   hipFree(W->ival); hipFree(W->nodes); hipFree(W->C2); hipFree(W->R2); hipFree(W->ticket); hipFree(W->Wi); hipFree(W->D);
   delete W;
 }
@@ -1713,13 +1733,15 @@ static int ss_workspace(nk_gmres *G) {
   W->grid = G->ctx->num_cus * SS_MAX_WG_PER_CU;
   const size_t nslots = (size_t)(m + 1 + SS_SMAX) * SS_SMAX;
   NK_TRY(nk_dev_alloc(&W->part, nslots * W->grid + 1));
-  NK_TRY(nk_dev_alloc(&W->red, nslots + 1));
+  NK_TRY(nk_dev_alloc(&W->part2, nslots * W->grid + 1));   // sweep B's partial blocks while their reduction is deferred
+  NK_TRY(nk_dev_alloc(&W->red, 2 * nslots + 1));   // (a launch may reduce two partial blocks)
   NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
-  NK_TRY(nk_dev_alloc(&W->C1, nslots + 1));
-  NK_TRY(nk_dev_alloc(&W->R1, (size_t)SS_SS));
-  // pass 2's factors, one slot per block of a cycle: blocks left at their first pass need theirs until the back-substitution
+  // the factors of both passes, one slot per block of a cycle: blocks left at their first pass need pass 2's until the
+  // back-substitution, and a block's Hessenberg columns (which need pass 1's) may be derived while the next block is under way
   W->c2_stride = nslots + 1;
   W->nblk_slots = m + 2;
+  NK_TRY(nk_dev_alloc(&W->C1, W->c2_stride * W->nblk_slots));
+  NK_TRY(nk_dev_alloc(&W->R1, (size_t)SS_SS * W->nblk_slots));
   NK_TRY(nk_dev_alloc(&W->C2, W->c2_stride * W->nblk_slots));
   NK_TRY(nk_dev_alloc(&W->R2, (size_t)SS_SS * W->nblk_slots));
   NK_TRY(nk_dev_alloc(&W->Wi, (size_t)SS_SS * W->nblk_slots));
@@ -1842,11 +1864,62 @@ static int ss_launch_hess(nk_ctx *ctx, int k, int sb, const ss_tail_args &ta) {
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
+// One launch of the block scheme's scalar work (k_ss_job): grid = one wavefront per entry of the partial blocks it reduces.
+static int ss_launch_job(nk_ctx *ctx, const ss_job &j, const ss_tail_args &ta0, const ss_tail_args &ta1) {
+  const int nslots = j.nslots0 + j.nslots1;
+  NK_REQUIRE(nslots > 0, "internal: an s-step job without a block to reduce");
+  nk_peer_ar_view pv{nullptr, 0, 0, 0, nullptr};
+  if (!nk_ctx_is_single(ctx)) {
+    pv = nk_peer_ar_next(ctx, nslots);
+    NK_REQUIRE(pv.seq != 0, "internal: the fused s-step reduction needs the peer-mapped arenas (%d values)", nslots);
+  }
+  const ss_job_lds L = ss_job_layout(j);
+  const size_t lds = L.total * sizeof(double);
+  NK_REQUIRE(lds <= 160 * 1024, "internal: the s-step scalar work needs %zu bytes of LDS", lds);
+  const int grid = (nslots + 3) / 4;
+  nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * ((double)j.nslots0 * j.nblk0 + (double)j.nslots1 * j.nblk1));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
+  if (pv.seq) {
+    if (lds > 64 * 1024)
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_job<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ev) hipExtLaunchKernelGGL(k_ss_job<true>, dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, j, ta0, ta1, pv);
+    else hipLaunchKernelGGL(k_ss_job<true>, dim3(grid), dim3(SS_R), lds, ctx->stream, j, ta0, ta1, pv);
+  } else {
+    if (lds > 64 * 1024)
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_job<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ev) hipExtLaunchKernelGGL(k_ss_job<false>, dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, j, ta0, ta1, pv);
+    else hipLaunchKernelGGL(k_ss_job<false>, dim3(grid), dim3(SS_R), lds, ctx->stream, j, ta0, ta1, pv);
+  }
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+// Sweep B of this shape can host a Hessenberg workgroup (the matrix-core form of the default cycle's shapes)
+static bool ss_b_can_host(int64_t ldv, int k, int s) {
+  static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);
+  static const bool host_on = !(getenv("NK_SS_HOST_B") && atoi(getenv("NK_SS_HOST_B")) == 0);   // A/B switch
+  return host_on && mm_on && s == 15 && (k == 1 || k == 16) && (int64_t)s * ldv * 8 < ((int64_t)1 << 32) - 8;
+}
+
 // Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of ≤ s (cut to the widths the sweeps are compiled for;
 // the last block may be shorter). k_gmres_begin has run. `wait_progress(need)` (may be empty) blocks the host until `need`
 // columns are closed or the cycle is done and returns false when no further block should be enqueued.
-int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress) {
+// *backsolved: the cycle's back-substitution (y, the outcome published to the host) rode in the cycle's last scalar launch —
+// the caller must not launch k_backsolve.
+//
+// Round 5 — the DEFERRED second factorisation (NK_SS_DEFER, default on; with the implicit second pass on the fused path). A block
+// left at its first pass needs its pass-2 factors (C₂, R₂) only where the NEXT block's reduction carries inner products through
+// them — not in front of the next block's matrix powers (which start from the stored column) and not in front of its sweep A (a
+// Gram block of stored columns). So sweep B's partial Gram block is not reduced by a launch of its own: the next block's
+// reduce-and-factor launch sums BOTH partial blocks, factors the previous block's second pass, prepares Wi and D in LDS, then factors
+// this block's first pass through them. The previous block's Hessenberg columns, rotations and stopping test follow in the same
+// workgroup (a solve that stops on a tolerance: the verdict arrives where it did before) or ride in workgroup 0 of this block's
+// sweep B (the fixed-work protocol: off the critical path). The cycle's last block is closed by one launch that reduces,
+// factors, derives the Hessenberg columns and back-substitutes without leaving the workgroup. Per GMRES(30) cycle of two blocks:
+// 3 scalar launches instead of 6 (4 × k_ss_reduce_factor, k_ss_hess, k_backsolve), 3 all-reduces instead of 4 on several ranks.
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved) {
   nk_ctx *ctx = G->ctx;
+  if (backsolved) *backsolved = false;
   NK_TRY(ss_workspace(G));
   nk_sstep *W = G->ss;
   const int64_t n = G->n, ldv = G->ldv;
@@ -1865,12 +1938,41 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   // ss_first_pass_departure measures max(|C₂|, |R₂ − I|) in the reduction's tail; above 0.1 the block counts as broken and
   // takes the fall-back (narrower blocks), exactly like a lost pivot.
   const bool implicit_mode = ss_implicit_on() && W->newton;
+  static const bool defer_off = getenv("NK_SS_DEFER") && atoi(getenv("NK_SS_DEFER")) == 0;            // A/B switches
+  static const bool tail_back_off = getenv("NK_SS_TAIL_BACK") && atoi(getenv("NK_SS_TAIL_BACK")) == 0;
+  static const int hess_where = getenv("NK_SS_DEFER_HESS") ? atoi(getenv("NK_SS_DEFER_HESS")) : -1;   // 0: in the job, 1: hosted by sweep B
+  // several ranks: the fused scalar launches are also the all-reduce — on peer-mapped arenas only
+  const bool peer_ok = nk_ctx_is_single(ctx) || nk_peer_ar_available(ctx, 2 * (SS_KMAX / 2 + SS_SMAX) * SS_SMAX);
+  const bool deferred = !defer_off && implicit_mode && peer_ok && nk_ss_fusable(1, 1);
+  const bool fixed_work = !G->ss_grow;
   ta.ptol = 1e-12;
+  ss_job jb;   // what every scalar launch of this cycle shares
+  std::memset(&jb, 0, sizeof(jb));
+  jb.m = G->m; jb.red = W->red; jb.coef = W->coef; jb.d_skip = done; jb.ticket = W->ticket;
+  jb.ctl = G->d_ctl; jb.sc = G->d_s; jb.pub = G->h_pub_dev; jb.seq = G->cycle_seq;
+  jb.y = G->d_y; jb.Rg = G->d_R; jb.g = G->d_g;
+  jb.peer_err = ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr;
   int blk = 0;            // index of the block within the cycle = its slot of pass-2 factors
   int prev_k0 = 0, prev_sb2 = 0;  // the previous block if it was left at its first pass (prev_sb2 = 0: it was not)
   ss_tail_args pend_ta;           // … and, while its Hessenberg columns wait for a sweep A to host them, its arguments
   std::memset(&pend_ta, 0, sizeof(pend_ta));
   int pend_k = 0, pend_sb = 0;
+  // deferred form: the block whose sweep B has run and whose second factorisation has not (its partial Gram block: W->part2)
+  struct { bool on; int k, sb, grid; ss_tail_args ta; } dp;
+  std::memset(&dp, 0, sizeof(dp));
+  // closes the pending block in a launch of its own: second factorisation, Wi / D, Hessenberg columns — and, at the cycle's end,
+  // the back-substitution
+  auto close_pending = [&](bool with_back) -> int {
+    ss_job j = jb;
+    j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
+    j.mode = SSJ_F2 | SSJ_PREP | SSJ_HESS | (with_back ? SSJ_BACK : 0);
+    j.cfix = dp.ta.fix;
+    if (with_back) j.bfx = G->ss_fix;
+    NK_TRY(ss_launch_job(ctx, j, dp.ta, dp.ta));
+    dp.on = false;
+    if (with_back && backsolved) *backsolved = true;
+    return NK_OK;
+  };
   if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
@@ -1904,13 +2006,15 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     // the update coefficients for the next sweep's scalar loads) and in sweep C (workgroup 0: the Hessenberg columns) — one
     // rank, or several on peer-mapped arenas (the reduction is then the all-reduce as well). Other transports and the
     // streaming size class (k + s > 48): reduction, all-reduce and the scalar work as launches of their own.
-    bool fused = nk_ss_fusable(k, sb);
+    const bool fused = nk_ss_fusable(k, sb) && peer_ok;
     if (pend_sb > 0 && !fused) {   // nobody to host it: the previous block's Hessenberg columns as a launch of their own
       NK_TRY(ss_launch_hess(ctx, pend_k, pend_sb, pend_ta));
       pend_sb = 0;
     }
-    // this block's slot of pass-2 factors; the blocks before it that were left at their first pass; the start vector's origin
+    // this block's slots of factors; the blocks before it that were left at their first pass; the start vector's origin
     NK_REQUIRE(blk < W->nblk_slots, "internal: more s-step blocks in a cycle than factor slots");
+    ta.C1 = W->C1 + (size_t)blk * W->c2_stride;
+    ta.R1 = W->R1 + (size_t)blk * SS_SS;
     ta.C2 = W->C2 + (size_t)blk * W->c2_stride;
     ta.R2 = W->R2 + (size_t)blk * SS_SS;
     ta.fix = G->ss_fix;
@@ -1923,6 +2027,51 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     const bool implicit = !last_block && implicit_mode && G->ss_fix.n < NK_SS_NFIX - 1;
     ta.Wi = implicit ? W->Wi + (size_t)blk * SS_SS : nullptr;
     ta.D = implicit ? W->D + (size_t)blk * W->c2_stride : nullptr;
+    const bool defer_this = deferred && fused && (last_block || implicit);
+    if (dp.on && !defer_this) NK_TRY(close_pending(false));   // (this block takes the older form: nobody to carry the pending one)
+    if (defer_this) {
+      // ---- sweep A, the job [second factorisation of the pending block ; first factorisation of this one], sweep B
+      const int grid_a = nk_ss_grid_a(ctx, n, k, sb, false);
+      {
+        nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb));
+        NK_TRY(nk_ss_sweep(ctx, 0, n, k, sb, G->V, ldv, W->coef, W->part, done, grid_a, nullptr, &G->d_ctl->pad1, 0, 0));
+      }
+      // where the pending block's Hessenberg columns are derived: in workgroup 0 of this block's sweep B when nothing can stop
+      // the cycle early (fixed work) and that sweep has the hosting form; else in the job itself (the verdict arrives before sweep B)
+      const bool host_b = dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) && (hess_where < 0 ? fixed_work : hess_where == 1);
+      {
+        ss_job j = jb;
+        j.part0 = W->part; j.nblk0 = grid_a; j.nslots0 = nslots; j.k0 = k; j.sb0 = sb;
+        j.mode = SSJ_F1;
+        j.cfix = ta.fix;
+        if (dp.on) {
+          j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
+          j.mode |= SSJ_F2 | SSJ_PREP | (host_b ? 0 : SSJ_HESS);
+        }
+        NK_TRY(ss_launch_job(ctx, j, ta, dp.on ? dp.ta : ta));
+      }
+      {
+        nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + 2 * sb));
+        ss_tail_args hta = dp.ta;
+        hta.Wi = nullptr; hta.D = nullptr;   // (prepared by the job already)
+        NK_TRY(nk_ss_sweep(ctx, 1, n, k, sb, G->V, ldv, W->coef, W->part2, done, grid, host_b ? &hta : nullptr, nullptr,
+                           host_b ? dp.k : 0, host_b ? dp.sb : 0));
+      }
+      dp.on = true; dp.k = k; dp.sb = sb; dp.grid = grid; dp.ta = ta;
+      {
+        nk_ss_fix &fx = G->ss_fix;
+        NK_REQUIRE(fx.n < NK_SS_NFIX, "internal: too many s-step blocks left at their first pass");
+        fx.k0[fx.n] = k; fx.sb[fx.n] = sb; fx.C2[fx.n] = ta.C2; fx.R2[fx.n] = ta.R2;
+        fx.Wi[fx.n] = implicit ? ta.Wi : nullptr; fx.D[fx.n] = implicit ? ta.D : nullptr;
+        fx.n++;
+      }
+      NK_HIP(hipGetLastError());
+      prev_k0 = k;
+      prev_sb2 = sb;
+      k += sb;
+      ++blk;
+      continue;
+    }
     const int grid_b = grid;
     for (int pass = 0; pass < 2; ++pass) {
       int grid = grid_b;   // (of THIS pass: the sweep, and the reduction behind it, which sums one partial per workgroup)
@@ -1934,33 +2083,23 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
                            pass == 0 ? &G->d_ctl->pad1 : nullptr, pend_k, pend_sb));
         if (host_prev) pend_sb = 0;
       }
-      nk_peer_ar_view pv{nullptr, 0, 0, 0, nullptr};
-      if (fused && !nk_ctx_is_single(ctx)) {
-        pv = nk_peer_ar_next(ctx, nslots);
-        if (!pv.seq) fused = false;
-      }
       if (fused) {
-        nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
-        const size_t lds = ((size_t)nslots + ss_ws_doubles(k, sb, false)) * sizeof(double);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
-        if (pv.seq) {
-          if (ev) hipExtLaunchKernelGGL(k_ss_reduce_factor<true>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, e0, e1, 0,
-                                        (const double *)W->part, grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
-          else hipLaunchKernelGGL(k_ss_reduce_factor<true>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, (const double *)W->part,
-                                  grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
-        } else {
-          if (ev) hipExtLaunchKernelGGL(k_ss_reduce_factor<false>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, e0, e1, 0,
-                                        (const double *)W->part, grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
-          else hipLaunchKernelGGL(k_ss_reduce_factor<false>, dim3((nslots + 3) / 4), dim3(SS_R), lds, ctx->stream, (const double *)W->part,
-                                  grid, nslots, W->red, done, W->ticket, k, sb, pass, W->coef, ta, pv);
+        ss_job j = jb;
+        j.cfix = ta.fix;
+        if (pass == 0) {
+          j.part0 = W->part; j.nblk0 = grid; j.nslots0 = nslots; j.k0 = k; j.sb0 = sb;
+          j.mode = SSJ_F1;
+        } else {   // the block's own second factorisation: coefficients for sweep C, C₂ / R₂ for whoever derives its Hessenberg columns
+          j.part1 = W->part; j.nblk1 = grid; j.nslots1 = nslots; j.k1 = k; j.sb1 = sb;
+          j.mode = SSJ_F2 | SSJ_COEF2;
         }
+        NK_TRY(ss_launch_job(ctx, j, ta, ta));
       } else {
         {
           nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
           NK_TRY(nk_blas_reduce_slots_allreduce(ctx, W->part, grid, nslots, W->red, done));  // (k + s)·s values, one message
         }
-        const size_t lds = ss_ws_doubles(k, sb, pass == 1) * sizeof(double);
+        const size_t lds = (ss_ws_doubles(k, sb, pass == 1) + ss_fixc_doubles(ta.fix)) * sizeof(double);
         if (pass == 0) {
           if (lds > 64 * 1024)
             NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_tail1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2000,5 +2139,6 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     ++blk;
   }
   if (pend_sb > 0) NK_TRY(ss_launch_hess(ctx, pend_k, pend_sb, pend_ta));   // (the host stopped enqueueing blocks early)
+  if (dp.on) NK_TRY(close_pending(!tail_back_off && backsolved != nullptr));
   return NK_OK;
 }

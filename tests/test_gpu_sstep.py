@@ -48,15 +48,6 @@ def test_block_sweeps_match_numpy(nls, n, k, s):
         _sweep(nls, mode, n, k, s, rng)
 
 
-@pytest.mark.parametrize("n", [70001, 300, 1 << 18])
-def test_wide_block_sweeps_match_numpy(nls, n):
-    """Groundwork for ONE block of 30 columns per GMRES(30) cycle (not used by the solver yet): sweeps A and B
-    with two 16-wide matrix-core tiles of new columns (k_ss_block_wide<30, 1, ·>), ragged last tiles, odd tile counts."""
-    rng = np.random.default_rng(n)
-    for mode in (0, 1):
-        _sweep(nls, mode, n, 1, 30, rng)
-
-
 @pytest.mark.parametrize("k", [1, 16, 7])
 def test_update_sweep_with_an_ill_conditioned_factor(nls, k):
     """X ← (X − V U) R⁻¹ with κ(R) = 1e5 (pivot ratio 1e-10: two decades above the rank-loss bar): the matrix-core form of the

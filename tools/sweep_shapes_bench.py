@@ -38,11 +38,9 @@ def run(mode, n, k, s, iters):
     return eV, eg, us.value
 
 
-args = [a for a in sys.argv[1:] if a != "--wide"]
-wide = "--wide" in sys.argv[1:]      # + the groundwork shape: ONE block of 30 columns behind the start vector
-sizes = [int(a) for a in args] or [1 << 20]
+sizes = [int(a) for a in sys.argv[1:]] or [1 << 20]
 for n in sizes:
-    for (k, s) in ((1, 15), (16, 15)) + (((1, 30),) if wide else ()):
+    for (k, s) in ((1, 15), (16, 15)):
         for mode in (0, 1):
             eV, eg, us = run(mode, n, k, s, 30 if n <= (1 << 21) else 8)
             by = 8.0 * n * ((k + s) + (s if mode else 0))
