@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355x_nk.so")
+LIB_PATH = os.environ.get("NK_LIB_PATH") or os.path.join(_HERE, "lib", "libmi355x_nk.so")   # (NK_LIB_PATH: development builds)
 CSRC = os.path.join(_HERE, "csrc")
 
 

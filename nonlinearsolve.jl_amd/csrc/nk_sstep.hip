@@ -38,8 +38,18 @@ constexpr int SS_TH = 8;         // scal[SS_TH + j] = θ_j; scal[0..5): first-ap
 constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ss_u2 __attribute__((ext_vector_type(2)));
-__device__ unsigned long long *g_ss_stamp = nullptr;   // development: phase time stamps of the scalar work (nk_ss_debug_stamps)
-#define SS_STAMP(i) do { if (g_ss_stamp != nullptr && threadIdx.x == 0) g_ss_stamp[i] = wall_clock64(); } while (0)
+// development: phase time stamps of the scalar work (nk_ss_debug_stamps, tools/ss_stamps.py) — in builds with -DNK_SS_STAMPS only
+// (make STAMPS=1): even switched off at run time a stamp is a load of the pointer, i.e. a memory round trip of ≈ 0.7 µs in the
+// middle of a latency-bound workgroup — thirteen of them sat in the cycle's last launch through round 4
+__device__ unsigned long long *g_ss_stamp = nullptr;
+__device__ int g_ss_stamp_bank = 0;   // 16 stamps per kind of scalar launch (0: first factorisation only, 1: both, 2: the cycle's last)
+#ifdef NK_SS_STAMPS
+// (into LDS: a stamp is one s_memrealtime and one DS write; k_ss_job's last workgroup copies them out behind its work)
+__shared__ unsigned long long s_ss_stamps[16];
+#define SS_STAMP(i) do { if (threadIdx.x == 0) s_ss_stamps[i] = wall_clock64(); } while (0)
+#else
+#define SS_STAMP(i) do { } while (0)
+#endif
 
 // ============================================================================= the scalar work of a block (one workgroup)
 __device__ __forceinline__ void ss_pub_progress(nk_gmres_pub *pub, uint64_t seq, int k, int done) {
@@ -74,15 +84,33 @@ struct ss_tail_args {
 struct ss_ws {
   double *Ct, *U, *Ri, *Rm, *Sm, *R1s, *Gd, *Fr, *Fx, *F, *NC, *Hs, *scs, *ssn, *sg, *uu;
   int *ok;
+  int o0;   // offset of the workspace (= of Ct) in the LDS block it was carved from, in doubles (ss_ws_off)
 };
+// offsets of the arrays that are addressed as LDS offsets (asynchronous loads, the back-substitution), relative to ss_ws::o0
+struct ss_ws_offs { int Rm, R1s, Fx, F, Hs, scs, ssn, sg, uu; };
+__host__ __device__ inline ss_ws_offs ss_ws_off(int k, int s) {
+  ss_ws_offs o;
+  int b = 2 * k * s + SS_SMAX * SS_SMAX;   // Ct, U, Ri
+  o.Rm = b; b += 2 * SS_SMAX * SS_SMAX;    // Rm, Sm
+  o.R1s = b; b += SS_SMAX * SS_SMAX + SS_SMAX + SS_SMAX * (SS_SMAX + 1);   // R1s, Gd, Fr
+  o.Fx = b; b += SS_SMAX * (SS_SMAX + 1) + 2;   // Fx, ok
+  o.F = b; b += 2 * (k + s) * s;           // F, NC
+  o.Hs = b; b += k * (k > 1 ? k - 1 : 1);
+  o.scs = b; b += k + s;
+  o.ssn = b; b += k + s;
+  o.sg = b; b += k + s + 1;
+  o.uu = b;
+  return o;
+}
 constexpr int SS_SS = SS_SMAX * SS_SMAX;
 __host__ __device__ inline size_t ss_ws_doubles(int k, int s, bool hess) {
   size_t d = (size_t)2 * k * s + 4 * SS_SS + SS_SMAX + 2 + 2 * SS_SMAX * (SS_SMAX + 1);
   if (hess) d += (size_t)2 * (k + s) * s + (size_t)k * (k > 1 ? k - 1 : 1) + 4 * (size_t)(k + s) + 1;
   return d;
 }
-__device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess) {
+__device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess, int o0 = 0) {
   ss_ws w;
+  w.o0 = o0;
   w.Ct = b; b += k * s;
   w.U = b; b += k * s;
   w.Ri = b; b += SS_SS;
@@ -131,10 +159,11 @@ __device__ __forceinline__ double ss_rcp(double d) {   // 1/d to the last bit or
 //   stored inner products → true:   Q_bᵀX = Wiᵀ (S_bᵀX) − Dᵀ (V_true[:k0]ᵀX)       (rows above the block already true: blocks in order)
 //   true coefficients → stored:     W[:k0] −= D W_b ;  W_b ← Wi W_b                 (blocks last first)
 // P / Wm: k × sb, row-major, rows = basis columns. tmp: sp × sb scratch.
+// (thread maps: (t >> 4, t & 15) — a division by a run-time block width is ≈ 40 instructions of a single wavefront's issue time)
 __device__ void ss_fix_to_true(int sb, int k0, int sp, const double *sD, const double *sWi, double *P) {
   const int t = threadIdx.x;
-  const int a = t / sb, c = t % sb;
-  const bool own = t < sp * sb;
+  const int a = t >> 4, c = t & 15;
+  const bool own = a < sp && c < sb;
   double val = 0.0;
   if (own) {
     for (int p = 0; p <= a; ++p) val = __builtin_fma(sWi[p * sp + a], P[(k0 + p) * sb + c], val);     // (Wiᵀ P_b)[a][c]
@@ -146,14 +175,15 @@ __device__ void ss_fix_to_true(int sb, int k0, int sp, const double *sD, const d
 }
 __device__ void ss_fix_to_stored(int sb, int k0, int sp, const double *sD, const double *sWi, double *Wm) {
   const int t = threadIdx.x;
-  for (int e = t; e < k0 * sb; e += SS_R) {      // W[:k0] −= D W_b (the OLD W_b)
-    const int i = e / sb, cc = e % sb;
-    double v = Wm[e];
-    for (int q = 0; q < sp; ++q) v = __builtin_fma(-sD[i * sp + q], Wm[(k0 + q) * sb + cc], v);
-    Wm[e] = v;
+  const int a = t >> 4, c = t & 15;
+  if (c < sb) {
+    for (int i = a; i < k0; i += 16) {      // W[:k0] −= D W_b (the OLD W_b)
+      double v = Wm[i * sb + c];
+      for (int q = 0; q < sp; ++q) v = __builtin_fma(-sD[i * sp + q], Wm[(k0 + q) * sb + c], v);
+      Wm[i * sb + c] = v;
+    }
   }
-  const int a = t / sb, c = t % sb;
-  const bool own = t < sp * sb;
+  const bool own = a < sp && c < sb;
   double val = 0.0;
   if (own)
     for (int p = a; p < sp; ++p) val = __builtin_fma(sWi[a * sp + p], Wm[(k0 + p) * sb + c], val);    // (Wi W_b)[a][c]
@@ -165,10 +195,12 @@ __device__ void ss_fix_to_stored(int sb, int k0, int sp, const double *sD, const
 // LDS as well — indexing a kernel argument by a run-time block number would put it in scratch memory). A slot is filled from global
 // memory (ss_fixc_request: all slots in ONE round trip, together with the reduced block) or, for the block whose second
 // factorisation has just been done by this workgroup, by ss_fix_prepare.
+// (offsets from the workgroup's dynamic LDS block, not pointers: a pointer read back from LDS is a generic one, and every access
+//  through it a FLAT instruction — measured 5 µs in the back-substitution's 60 steps)
 struct ss_fixc {
   int n;
   int k0[NK_SS_NFIX], sb[NK_SS_NFIX];
-  double *D[NK_SS_NFIX], *Wi[NK_SS_NFIX];
+  int oD[NK_SS_NFIX], oWi[NK_SS_NFIX];
 };
 __host__ __device__ inline size_t ss_fixc_doubles(const nk_ss_fix &fix) {
   size_t d = 0;
@@ -179,14 +211,15 @@ __host__ __device__ inline size_t ss_fixc_doubles(const nk_ss_fix &fix) {
 }
 // carve the slots out of `b` (uniform; thread 0 writes the struct, the caller's next barrier publishes it) and request the
 // slots' contents — all but the last `skip_last` blocks' (those are computed here)
-__device__ inline double *ss_fixc_request(ss_fixc *fc, const nk_ss_fix &fix, double *b, int skip_last, bool c2r2 = false) {
+__device__ inline void ss_fixc_request(ss_fixc *fc, const nk_ss_fix &fix, double *lds, int off, int skip_last, bool c2r2 = false) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < NK_SS_NFIX; ++q) {
     if (q < fix.n) {
-      double *sD = b; b += fix.k0[q] * fix.sb[q];
-      double *sWi = b; b += fix.sb[q] * fix.sb[q];
-      if (t == 0) { fc->k0[q] = fix.k0[q]; fc->sb[q] = fix.sb[q]; fc->D[q] = sD; fc->Wi[q] = sWi; }
+      const int oD = off; off += fix.k0[q] * fix.sb[q];
+      const int oWi = off; off += fix.sb[q] * fix.sb[q];
+      double *sD = lds + oD, *sWi = lds + oWi;
+      if (t == 0) { fc->k0[q] = fix.k0[q]; fc->sb[q] = fix.sb[q]; fc->oD[q] = oD; fc->oWi[q] = oWi; }
       if (q < fix.n - skip_last) {
         const double *gD = c2r2 ? fix.C2[q] : fix.D[q], *gWi = c2r2 ? fix.R2[q] : fix.Wi[q];
         for (int e = t; e < fix.k0[q] * fix.sb[q]; e += SS_R) sD[e] = gD[e];
@@ -195,12 +228,11 @@ __device__ inline double *ss_fixc_request(ss_fixc *fc, const nk_ss_fix &fix, dou
     }
   }
   if (t == 0) fc->n = fix.n;
-  return b;
 }
 // Wi = R₂⁻¹ and D = C₂ Wi of a block left at its first pass (k0 rows above it, sp columns), from its pass-2 factors in LDS
 // (Ct: C₂, k0 × sp; Rm: R₂, sp × sp upper) into global memory. Column j of Wi by back substitution, one lane per column.
 __device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *Rm, double *scratch /* sp × sp */, double *Wig,
-                               double *Dg, double *sWiout = nullptr, double *sDout = nullptr) {
+                               double *Dg, bool to_lds = false, double *sWiout = nullptr, double *sDout = nullptr) {
   const int t = threadIdx.x;
   if (t < sp) {
     const int j = t;
@@ -218,40 +250,45 @@ __device__ void ss_fix_prepare(int k0, int sp, const double *Ct, const double *R
   __syncthreads();
   if (t < sp * sp) {
     Wig[t] = scratch[t];
-    if (sWiout != nullptr) sWiout[t] = scratch[t];
+    if (to_lds) sWiout[t] = scratch[t];
   }
   for (int e = t; e < k0 * sp; e += SS_R) {
     const int i = e / sp, a = e % sp;
     double v = 0.0;
     for (int p = 0; p <= a; ++p) v = __builtin_fma(Ct[i * sp + p], scratch[p * sp + a], v);
     Dg[e] = v;
-    if (sDout != nullptr) sDout[e] = v;
+    if (to_lds) sDout[e] = v;
   }
   __syncthreads();
 }
 __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const double *__restrict__ sc, const ss_ws &w,
-                          const ss_fixc &fix, int nfix, double ptol) {
+                          const ss_fixc &fix, int nfix, double ptol, double *lds) {
   const int t = threadIdx.x;
   double *Ct = w.Ct, *Rm = w.Rm, *Ri = w.Ri, *Sm = w.Sm;
   double *F = w.Fr;   // 16 × 17 frame: the factor in progress
-  for (int e = t; e < k * sb; e += SS_R) {
-    const double scj = sc[e / sb], c = scj * red[e];
-    Ct[e] = c;
-    if (nfix == 0) w.U[e] = scj * c;
+  const int ta4 = t >> 4, tc = t & 15;
+  if (tc < sb) {
+    for (int r = ta4; r < k; r += 16) {
+      const int e = r * sb + tc;
+      const double scj = sc[r], c = scj * red[e];
+      Ct[e] = c;
+      if (nfix == 0) w.U[e] = scj * c;
+    }
   }
   if (t == 0) *w.ok = 1;
   __syncthreads();
   if (nfix > 0) {   // (uniform) stored → true coordinates for the factorisation; true → stored coefficients for the update
-    for (int bq = 0; bq < nfix; ++bq) ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], Ct);
+    for (int bq = 0; bq < nfix; ++bq) ss_fix_to_true(sb, fix.k0[bq], fix.sb[bq], lds + fix.oD[bq], lds + fix.oWi[bq], Ct);
     for (int e = t; e < k * sb; e += SS_R) w.U[e] = Ct[e];
     __syncthreads();
-    for (int bq = nfix - 1; bq >= 0; --bq) ss_fix_to_stored(sb, fix.k0[bq], fix.sb[bq], fix.D[bq], fix.Wi[bq], w.U);
-    for (int e = t; e < k * sb; e += SS_R) w.U[e] *= sc[e / sb];
+    for (int bq = nfix - 1; bq >= 0; --bq) ss_fix_to_stored(sb, fix.k0[bq], fix.sb[bq], lds + fix.oD[bq], lds + fix.oWi[bq], w.U);
+    if (tc < sb)
+      for (int r = ta4; r < k; r += 16) w.U[r * sb + tc] *= sc[r];
     __syncthreads();
   }
   SS_STAMP(5);
-  if (t < sb * sb) {
-    const int a = t / sb, b = t % sb;
+  if (ta4 < sb && tc < sb) {
+    const int a = ta4, b = tc;
     double s0 = red[(size_t)(k + a) * sb + b], s1 = 0.0;
     if (a == b) w.Gd[a] = s0;
     int j = 0;
@@ -260,7 +297,7 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
       s1 = __builtin_fma(-Ct[(j + 1) * sb + a], Ct[(j + 1) * sb + b], s1);
     }
     if (j < k) s0 = __builtin_fma(-Ct[j * sb + a], Ct[j * sb + b], s0);
-    Sm[t] = s0 + s1;
+    Sm[a * sb + b] = s0 + s1;
   }
   __syncthreads();
   const int a = (t >> 4) & (SS_SMAX - 1), b = t & (SS_SMAX - 1);   // (SS_R = 256: one entry per thread)
@@ -269,12 +306,23 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
   F[a * SS_FP + b] = val;
   __syncthreads();
   SS_STAMP(6);
+  // Two pivots per barrier: every thread re-derives what step p would have left in row p + 1 (its diagonal and the two entries
+  // it needs: the same expressions the owning threads evaluate — bit-identical to one pivot per step) and applies both rank-1
+  // updates behind one round of LDS reads. Eight barrier-separated steps instead of sixteen (≈ 0.24 µs each).
 #pragma unroll 1
-  for (int p = 0; p < SS_SMAX; ++p) {   // after step p: row p holds T_pb = D_p U_pb (b ≥ p), the trailing block is updated
-    const double d = F[p * SS_FP + p], fpa = F[p * SS_FP + a], fpb = F[p * SS_FP + b];
-    if (t == 0 && p < sb && (!(d > ptol * w.Gd[p]) || isinf(d))) *w.ok = 0;
+  for (int p = 0; p < SS_SMAX; p += 2) {   // after a step: rows p, p + 1 hold T_pb = D_p U_pb (b ≥ p), the trailing block is updated
+    const double d0 = F[p * SS_FP + p], f0a = F[p * SS_FP + a], f0b = F[p * SS_FP + b], f01 = F[p * SS_FP + p + 1];
+    const double d1r = F[(p + 1) * SS_FP + p + 1], f1ar = F[(p + 1) * SS_FP + a], f1br = F[(p + 1) * SS_FP + b];
+    const double l01 = f01 * ss_rcp(d0);
+    const double d1 = __builtin_fma(-l01, f01, d1r);
+    const double f1a = __builtin_fma(-l01, f0a, f1ar), f1b = __builtin_fma(-l01, f0b, f1br);
+    if (t == 0) {
+      if (p < sb && (!(d0 > ptol * w.Gd[p]) || isinf(d0))) *w.ok = 0;
+      if (p + 1 < sb && (!(d1 > ptol * w.Gd[p + 1]) || isinf(d1))) *w.ok = 0;
+    }
     if (a > p && b >= a) {
-      val = __builtin_fma(-(fpa * ss_rcp(d)), fpb, val);
+      val = __builtin_fma(-(f0a * ss_rcp(d0)), f0b, val);
+      if (a > p + 1) val = __builtin_fma(-(f1a * ss_rcp(d1)), f1b, val);
       F[a * SS_FP + b] = val;
     }
     __syncthreads();
@@ -299,9 +347,9 @@ __device__ bool ss_first_pass_departure_ok(int k, int sb, const ss_ws &w, double
   const int t = threadIdx.x;
   double m = 0.0;
   for (int e = t; e < k * sb; e += SS_R) m = fmax(m, fabs(w.Ct[e]));
-  if (t < sb * sb) {
-    const int a = t / sb, c = t % sb;
-    m = fmax(m, fabs(w.Rm[t] - (a == c ? 1.0 : 0.0)));
+  {
+    const int a = t >> 4, c = t & 15;
+    if (a < sb && c < sb) m = fmax(m, fabs(w.Rm[a * sb + c] - (a == c ? 1.0 : 0.0)));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
@@ -356,10 +404,11 @@ __device__ void ss_hess_load(int k, int sb, const ss_ws &w, const ss_tail_args &
   if (t == SS_SMAX) w.Fx[SS_SMAX] = ta.scal[2];
   if (t == SS_SMAX + 1) w.Fx[SS_SMAX + 1] = ta.ctl->tol;
 }
-// sR (optional, pitch LK): an LDS copy of the rotated factor's new columns, for a back-substitution in the same workgroup.
+// sR, verdict (LK > 0 only; pitch LK): an LDS copy of the rotated factor's new columns, for a back-substitution in the same workgroup.
 // raise_pad1: a verdict that ends the cycle also voids the block whose sweeps are in flight (deferred second pass: this block's
 // Hessenberg columns are derived while the NEXT block is under way).
 __device__ __forceinline__ double ss_readlane(double v, int lane) {
+  lane = __builtin_amdgcn_readfirstlane(lane);   // (uniform by construction; the compiler cannot always see it)
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), lane);
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
@@ -378,17 +427,20 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   SS_STAMP(9);
   const double sigma = w.Fx[SS_SMAX];
   const double *th = w.Fx;
-  for (int e = t; e < k * sb; e += nt) {  // C = C₁ + C₂ R₁
-    const int j = e / sb, c = e % sb;
-    double v = F[e];
-    for (int a = 0; a <= c; ++a) v = __builtin_fma(w.Ct[j * sb + a], w.R1s[a * sb + c], v);
-    F[e] = v;
-  }
-  if (t < sb * sb) {  // R = R₂ R₁ (upper)
-    const int a = t / sb, c = t % sb;
-    double v = 0.0;
-    for (int p = a; p <= c; ++p) v = __builtin_fma(w.Rm[a * sb + p], w.R1s[p * sb + c], v);
-    F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
+  // (thread maps without a division by a run-time width: (t >> 4, t & 15) over sb ≤ 16 columns, (t >> 5, t & 31) over rows)
+  const int t4 = t >> 4, c4 = t & 15;
+  if (c4 < sb) {
+    for (int j = t4; j < k; j += 16) {  // C = C₁ + C₂ R₁
+      double v = F[j * sb + c4];
+      for (int a = 0; a <= c4; ++a) v = __builtin_fma(w.Ct[j * sb + a], w.R1s[a * sb + c4], v);
+      F[j * sb + c4] = v;
+    }
+    if (t4 < sb) {  // R = R₂ R₁ (upper)
+      const int a = t4, c = c4;
+      double v = 0.0;
+      for (int p = a; p <= c; ++p) v = __builtin_fma(w.Rm[a * sb + p], w.R1s[p * sb + c], v);
+      F[(k + a) * sb + c] = (c >= a) ? v : 0.0;
+    }
   }
   __syncthreads();
   // A·(the column the powers started from) = σ X_0 + θ_0·(that column). It is the true basis vector v_k (u = e_k) — or, after a
@@ -411,41 +463,54 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   // every later column as soon as it is final. Per entry the multiply-adds run in the order of the column-by-column
   // recurrence this replaces (one entry per thread and step: 14 dependent steps of one multiply-add instead of 14 steps of
   // ≤ 30: measured 14.6 → ≈ 2 µs at k = 16, s = 15).
-  const int npair = (sb - 1) * K;
-  for (int e = t; e < npair; e += nt) {
-    const int j = 1 + e / K, i = e % K;
-    double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
-    if (i < k)
-      for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
-    NC[j * K + i] = a;
+  const int t5 = t >> 5, r5 = t & 31;
+  for (int j = 1 + t5; j < sb; j += 8) {
+    for (int i = r5; i < K; i += 32) {
+      double a = sigma * F[i * sb + j] + th[j] * F[i * sb + (j - 1)];
+      if (i < k)
+        for (int tt = (i > 0 ? i - 1 : 0); tt < ko; ++tt) a = __builtin_fma(-Hs[i * ko + tt], F[tt * sb + (j - 1)], a);
+      NC[j * K + i] = a;
+    }
   }
+  // (a thread's entries keep their (column offset, row) through all steps: the divisions by K are done once; the final division of
+  //  a column is a multiplication by a reciprocal formed up front — a division inside the step is ≈ 300 cycles of its ≈ 500)
+  double *rdiag = w.Gd;   // (free until the rotations)
+  if (t < sb - 1) rdiag[t] = 1.0 / F[(k + t) * sb + t];
   __syncthreads();
+#pragma unroll 1
   for (int q = 0; q + 1 < sb; ++q) {
     const int frow = (q == 0) ? (k - 1) : (k + q - 1);
-    for (int e = t; e < (sb - 1 - q) * K; e += nt) {
-      const int j = q + 1 + e / K, i = e % K;
-      double a = __builtin_fma(-NC[q * K + i], F[frow * sb + (j - 1)], NC[j * K + i]);
-      if (j == q + 1) a /= F[(k + j - 1) * sb + (j - 1)];    // its last term: the column is final
-      NC[j * K + i] = a;
+    const double rdq = rdiag[q];
+    for (int jj = t5; jj < sb - 1 - q; jj += 8) {   // (a thread's entries keep their (column offset, row) through all steps)
+      const int j = q + 1 + jj;
+      const double fj = F[frow * sb + (j - 1)];
+      for (int i = r5; i < K; i += 32) {
+        double a = __builtin_fma(-NC[q * K + i], fj, NC[j * K + i]);
+        if (jj == 0) a *= rdq;    // its last term: the column is final
+        NC[j * K + i] = a;
+      }
     }
     __syncthreads();
   }
   SS_STAMP(11);
-  for (int e = t; e < sb * K; e += nt) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
-    const int j = e / K, i = e % K, jc = ko + j;
-    if (i <= jc + 1 && jc < m) ta.H[(size_t)i * m + jc] = NC[j * K + i];
+  for (int j = t5; j < sb; j += 8) {  // the un-rotated columns (rows ≤ column + 1; the rest is rounding noise)
+    const int jc = ko + j;
+    for (int i = r5; i < K; i += 32)
+      if (i <= jc + 1 && jc < m) ta.H[(size_t)i * m + jc] = NC[j * K + i];
   }
-  __syncthreads();
-  if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane
+  __syncthreads();   // (the rotations below overwrite an entry of every column)
+  if (t < sb) {  // the rotations of earlier blocks: every new column on its own lane, the entry under way in a register
     const int jc = ko + t;
     double *h = &NC[t * K];
+    double a = h[0];
     for (int i = 0; i < ko; ++i) {
-      const double a = h[i], b = h[i + 1];
-      const double rij = scs[i] * a + ssn[i] * b;
+      const double b = h[i + 1], c = scs[i], sn = ssn[i];
+      const double rij = c * a + sn * b;
       ta.Rg[(size_t)i * m + jc] = rij;
-      if (sR != nullptr) sR[i * LK + jc] = rij;
-      h[i + 1] = -ssn[i] * a + scs[i] * b;
+      if (LK > 0) sR[i * LK + jc] = rij;
+      a = -sn * a + c * b;
     }
+    h[ko] = a;
   }
   __syncthreads();
   SS_STAMP(12);
@@ -453,85 +518,87 @@ __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args 
   // but every rotation is applied to all LATER columns at once (lane j owns column j): sb steps of one hypot + one rotation
   // instead of thread 0 walking sb²/2 rotations (measured 16.3 → ≈ 3 µs at s = 15). All sb rotations are formed; which columns
   // count (the first that meets the tolerance closes the cycle) is decided by the scalar pass behind it.
-  double *betas = w.Gd;   // (free here: ss_factor is done with it)
   if (t < 64) {
-    // one wavefront, in REGISTERS: lane j owns column j — the entry the previous rotation left in row ko + i (`carry`) and the
-    // column's rows below it as the recurrence left them (`bv`, requested up front); rotation i is formed from lane i's pair by
-    // every lane in lockstep and lane i's result is broadcast with v_readlane. No LDS round trip and no fence inside the chain
-    // (round 4 kept the columns in LDS: two LDS round trips + four fences per rotation, 11 µs for 15 of them).
+    // one wavefront, lane j owns column j: the entry the previous rotation left in row ko + i (`carry`, a register) and the
+    // column's next row as the recurrence left it (requested from LDS one step ahead: off the chain). Rotation i is formed by
+    // EVERY lane from lane i's pair (two v_readlane: the branch on the pair's magnitude is uniform) — c = h·r, s = β·r, d = x·r
+    // with r = x^(−½) from v_rsq_f64 and two Newton steps, x = h² + β²: a dozen dependent operations where sqrt and two
+    // divisions are ≈ 70 (round 4: lane i alone, through LDS with four fences per rotation: 11 µs for 15; formed from each lane's
+    // own pair the finished columns' stale entries sent the wavefront through the scaled hypot on every step). A ROLLED loop: the
+    // code runs once from a cold instruction cache, the unrolled form was fetched byte by byte.
     const int col = t < sb ? t : sb - 1;   // (lanes ≥ sb shadow the last column; nothing of theirs is stored)
     const double *h = &NC[col * K + ko];
-    double carry = h[0];
-    double bv[SS_SMAX], outR[SS_SMAX];
-#pragma unroll
-    for (int i = 0; i < SS_SMAX; ++i) {
-      bv[i] = (i < sb) ? h[i + 1] : 0.0;
-      outR[i] = 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < SS_SMAX; ++i) {
-      if (i < sb) {   // (uniform)
-        const double hk = carry, beta = bv[i];
-        double d = sqrt(__builtin_fma(hk, hk, beta * beta));
-        if (!(d > 1e-150 && d < 1e150)) d = hypot(hk, beta);        // (scaled evaluation only where the plain one may be off)
-        double c, sgn;
-        if (d == 0.0) { c = 1.0; sgn = 0.0; } else { c = hk / d; sgn = beta / d; }
-        const double ci = ss_readlane(c, i), si = ss_readlane(sgn, i);
-        if (t == i) {
-          scs[ko + i] = c;
-          ssn[ko + i] = sgn;
-          betas[i] = beta;
-          outR[i] = d;
-        } else if (t > i) {
-          outR[i] = ci * hk + si * beta;
-          carry = -si * hk + ci * beta;
-        }
-      }
-    }
-    // R entries of the block's own rows: rotated values above the diagonal, d on it
-    if (t < sb) {
-#pragma unroll
-      for (int i = 0; i < SS_SMAX; ++i) {
-        if (i <= t) {
-          ta.Rg[(size_t)(ko + i) * m + (ko + t)] = outR[i];
-          if (sR != nullptr) sR[(ko + i) * LK + (ko + t)] = outR[i];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (t == 0) {
-    nk_gmres_ctl *ctl = ta.ctl;
+    double carry = h[0], bnext = h[1];
+    // the residual recurrence g_{j+1} = −s_j g_j, g_j ← c_j g_j and the stopping test ride in the same loop: the rotation is the
+    // same number in every lane, so every lane carries g and the verdict (round 4: thread 0 walked the columns afterwards, eight LDS
+    // round trips and five global stores each: 4.2 µs)
     const double tol = w.Fx[SS_SMAX + 1];
+    double gcur = sg[ko], rn = 0.0, beta_l = 0.0;
     int closed = 0, dn = 0, cv = 0, fl = 0;
-    double rn = 0.0, beta = 0.0;   // (sb ≥ 1: both are set by the first column)
-    for (int j = 0; j < sb && !dn; ++j) {
-      const int jc = ko + j;
-      const double c = scs[jc], sgn = ssn[jc];
-      beta = betas[j];
-      const double gj = sg[jc];
-      sg[jc + 1] = -sgn * gj;
-      sg[jc] = c * gj;
-      rn = fabs(sgn * gj);
-      closed = j + 1;
-      if (!(rn == rn) || isinf(rn) || !(beta == beta)) { ctl->failed = 1; fl = 1; dn = 1; }
-      else if (tol >= 0.0 && rn <= tol) { ctl->converged = 1; cv = 1; dn = 1; }
-      else if (beta == 0.0) { ctl->converged = 1; cv = 1; dn = 1; }
+#pragma unroll 1
+    for (int i = 0; i < sb; ++i) {
+      const double b = bnext;
+      if (i + 2 <= sb) bnext = h[i + 2];
+      const double hk = ss_readlane(carry, i), beta = ss_readlane(b, i);
+      const double x = __builtin_fma(hk, hk, beta * beta);
+      double ci, si, d;
+      if (x > 1e-280 && x < 1e280) {
+        double r = __builtin_amdgcn_rsq(x);
+        r = __builtin_fma(0.5 * r, __builtin_fma(-(x * r), r, 1.0), r);
+        r = __builtin_fma(0.5 * r, __builtin_fma(-(x * r), r, 1.0), r);
+        ci = hk * r; si = beta * r; d = x * r;
+      } else {   // zero, tiny, huge or not a number: the scaled evaluation
+        d = hypot(hk, beta);
+        if (d == 0.0) { ci = 1.0; si = 0.0; } else { ci = hk / d; si = beta / d; }
+      }
+      double outv = d;
+      if (t != i) {
+        outv = ci * carry + si * b;
+        carry = -si * carry + ci * b;
+      }
+      if (t >= i && t < sb) {   // R entries of the block's own rows: rotated values above the diagonal, d on it
+        ta.Rg[(size_t)(ko + i) * m + (ko + t)] = outv;
+        if (LK > 0) sR[(ko + i) * LK + (ko + t)] = outv;
+      }
+      if (!dn) {   // (uniform) column ko + i counts
+        const double gnext = -si * gcur;
+        if (t == i) {
+          scs[ko + i] = ci;
+          ssn[ko + i] = si;
+          sg[ko + i] = ci * gcur;
+        }
+        rn = fabs(gnext);
+        beta_l = beta;
+        closed = i + 1;
+        if (!(rn == rn) || isinf(rn) || !(beta == beta)) { fl = 1; dn = 1; }
+        else if (tol >= 0.0 && rn <= tol) { cv = 1; dn = 1; }
+        else if (beta == 0.0) { cv = 1; dn = 1; }
+        gcur = gnext;
+      }
     }
-    if (verdict != nullptr) { verdict[0] = (double)(ko + closed); verdict[1] = (double)cv; verdict[2] = (double)fl; verdict[3] = rn; }
-    for (int j = 0; j < closed; ++j) { ta.cs[ko + j] = scs[ko + j]; ta.sn[ko + j] = ssn[ko + j]; ta.g[ko + j] = sg[ko + j]; }
-    ta.g[ko + closed] = sg[ko + closed];
-    ctl->rnorm = rn;
-    ctl->hn = beta;
-    ctl->k = ko + closed;
-    if (dn) {
-      ctl->done = 1;
-      if (raise_pad1) ctl->pad1 = 1;
+    if (t == 0) sg[ko + closed] = gcur;
+    // what the next blocks, the back-substitution and the host read — the closed columns' rotations and residuals by their lanes
+    if (t < closed) { ta.cs[ko + t] = scs[ko + t]; ta.sn[ko + t] = ssn[ko + t]; ta.g[ko + t] = sg[ko + t]; }
+    if (t < sb) ta.sc[k + t] = 1.0;   // the new columns are normalised
+    if (t == 0) {
+      nk_gmres_ctl *ctl = ta.ctl;
+      if (LK > 0) { verdict[0] = (double)(ko + closed); verdict[1] = (double)cv; verdict[2] = (double)fl; verdict[3] = rn; }
+      ta.g[ko + closed] = gcur;
+      if (fl) ctl->failed = 1;
+      if (cv) ctl->converged = 1;
+      ctl->rnorm = rn;
+      ctl->hn = beta_l;
+      ctl->k = ko + closed;
+      if (dn) {
+        ctl->done = 1;
+        if (raise_pad1) ctl->pad1 = 1;
+      }
+      ta.scal[0] = 1.0 / sigma;   // the next block starts from a normalised column
+      ss_pub_progress(ta.pub, ta.seq, ko + closed, dn);
     }
-    for (int c = 0; c < sb; ++c) ta.sc[k + c] = 1.0;  // the new columns are normalised
-    ta.scal[0] = 1.0 / sigma;                          // the next block starts from a normalised column
-    ss_pub_progress(ta.pub, ta.seq, ctl->k, dn);
   }
+  SS_STAMP(7);
+  __syncthreads();
   SS_STAMP(13);
 }
 
@@ -541,9 +608,9 @@ __global__ __launch_bounds__(256) void k_ss_tail1(int k, int sb, double *__restr
   __shared__ ss_fixc s_fc;
   if (ta.ctl->done) return;
   const ss_ws w = ss_ws_carve(s_tail, k, sb, false);
-  ss_fixc_request(&s_fc, ta.fix, s_tail + ss_ws_doubles(k, sb, false), 0);
+  ss_fixc_request(&s_fc, ta.fix, s_tail, (int)ss_ws_doubles(k, sb, false), 0);
   __syncthreads();
-  if (!ss_factor(k, sb, ta.red, ta.sc, w, s_fc, ta.fix.n, ta.ptol)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, s_fc, ta.fix.n, ta.ptol, s_tail)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) coef[e] = w.U[e];
   if (t < sb * sb) coef[(size_t)k * sb + t] = w.Ri[t];
@@ -554,9 +621,9 @@ __global__ __launch_bounds__(256) void k_ss_tail2(int k, int sb, double *__restr
   __shared__ ss_fixc s_fc;
   if (ta.ctl->pad1) return;  // (pad1: the cycle was done when this block started, or its first pass failed)
   const ss_ws w = ss_ws_carve(s_tail, k, sb, true);
-  ss_fixc_request(&s_fc, ta.fix, s_tail + ss_ws_doubles(k, sb, true), 0);
+  ss_fixc_request(&s_fc, ta.fix, s_tail, (int)ss_ws_doubles(k, sb, true), 0);
   __syncthreads();
-  if (!ss_factor(k, sb, ta.red, ta.sc, w, s_fc, ta.fix.n, ta.ptol)) { ss_fail(ta); return; }
+  if (!ss_factor(k, sb, ta.red, ta.sc, w, s_fc, ta.fix.n, ta.ptol, s_tail)) { ss_fail(ta); return; }
   if (ta.Wi != nullptr && !ss_first_pass_departure_ok(k, sb, w, 0.1)) { ss_fail(ta); return; }
   const int t = threadIdx.x;
   for (int e = t; e < k * sb; e += 256) { coef[e] = w.U[e]; ta.C2[e] = w.Ct[e]; }
@@ -1243,57 +1310,115 @@ struct ss_job {
   const uint64_t *peer_err;
   nk_ss_fix bfx;              // SSJ_BACK: the blocks left at their first pass (the pending block is the last of them)
 };
-struct ss_job_lds { size_t sc, fix, w1, w0, sR, sg, verdict, bfix, total; int LK; };
-__host__ __device__ inline ss_job_lds ss_job_layout(const ss_job &j) {
+struct ss_job_lds { size_t sc, fix, w1, w0, sR, sg, verdict, bfix, rdv, total; int LK; };
+__host__ __device__ inline ss_job_lds ss_job_layout(const ss_job &j, int mode) {
   ss_job_lds L;
-  const bool f1 = (j.mode & SSJ_F1) != 0, f2 = (j.mode & SSJ_F2) != 0, hs = (j.mode & SSJ_HESS) != 0, bk = (j.mode & SSJ_BACK) != 0;
+  const bool f1 = (mode & SSJ_F1) != 0, f2 = (mode & SSJ_F2) != 0, hs = (mode & SSJ_HESS) != 0, bk = (mode & SSJ_BACK) != 0;
   size_t o = (size_t)j.nslots0 + j.nslots1;
   L.sc = o; o += (size_t)((f1 && j.k0 > j.k1) ? j.k0 : (f2 ? j.k1 : j.k0)) + 1;
   L.fix = o; o += ss_fixc_doubles(j.cfix);
   L.w1 = o; o += f2 ? ss_ws_doubles(j.k1, j.sb1, hs) : 0;
   L.w0 = o; o += f1 ? ss_ws_doubles(j.k0, j.sb0, false) : 0;
-  L.LK = j.m | 1;
+  L.LK = j.m;   // (the LDS copy keeps the global pitch: it arrives through lane-linear LDS-direct loads)
   L.sR = o; o += bk ? (size_t)j.m * L.LK : 0;
   L.sg = o; o += bk ? (size_t)j.m + 2 : 0;
   L.verdict = o; o += 8;
   L.bfix = o; o += bk ? ss_fixc_doubles(j.bfx) : 0;
+  L.rdv = o; o += bk ? (size_t)j.m + 16 * NK_SS_NFIX : 0;   // reciprocal diagonals of the back-substitution's factors
   L.total = o;
   return L;
 }
-// y = R⁻¹ g on one wavefront (lane t owns g_t; reciprocal diagonal up front, the pivot broadcast with v_readlane), then the
-// blocks left at their first pass, last first: coefficients on [V_true Q] → on V_true and the block's stored columns
-// (nk_gmres.hip's k_backsolve, on operands that are in LDS already). bc: (C₂, R₂) per block.
-__device__ void ss_backsolve(int k, int failed, const double *sR, int LK, const double *sg, double *y, int m, const ss_fixc &bc) {
+// y = R⁻¹ g, then the blocks left at their first pass, last first: coefficients on [V_true Q] → on V_true and the block's stored
+// columns (nk_gmres.hip's k_backsolve, on operands that are in LDS already). bc: (C₂, R₂) per block; rdv: k + 16 per block doubles.
+// The serial part runs on one wavefront at ONE instruction per ≈ 5 cycles — what counts is the number of instructions per step
+// (round 5's first form: 30 per step, 90 steps, 9 µs). So everything that is not the chain is done up front by the whole workgroup:
+// the reciprocal diagonals, and every triangular factor scaled by them with its diagonal and lower part zeroed — a step of a solve
+// is then {the next entry's LDS read (one step ahead), two v_readlane, one multiply-add}: no division, no select, no mask.
+// (Not inlined: inlined into k_ss_job the compiler of ROCm 7.2 stops with "Illegal instruction detected: V_CMP_NE_U32_e32 0,
+//  $src_shared_base" — a null test of a generic pointer it has itself proven to be an LDS one; the LDS block and the block list
+//  arrive as address-space-3 pointers so that every access stays a DS instruction.) All 256 threads call it.
+typedef __attribute__((address_space(3))) double *ss_lds_ptr;
+typedef const __attribute__((address_space(3))) ss_fixc *ss_lds_fixc;
+__device__ __noinline__ void ss_backsolve(int k, int failed, int oR, int LK, int og, int ordv, double *y, int m, ss_lds_fixc bcp,
+                                          ss_lds_ptr lds) {
   const int t = threadIdx.x;
+  k = __builtin_amdgcn_readfirstlane(k); failed = __builtin_amdgcn_readfirstlane(failed);
+  oR = __builtin_amdgcn_readfirstlane(oR); LK = __builtin_amdgcn_readfirstlane(LK); og = __builtin_amdgcn_readfirstlane(og);
+  ordv = __builtin_amdgcn_readfirstlane(ordv); m = __builtin_amdgcn_readfirstlane(m);
+  const int nb = __builtin_amdgcn_readfirstlane(bcp->n);
+  ss_lds_ptr sR = lds + oR, sg = lds + og, rdv = lds + ordv;
+  if (failed) {
+    if (t < m) y[t] = 0.0;
+    return;
+  }
+  // reciprocal diagonals
+  if (t < k) rdv[t] = 1.0 / sR[t * LK + t];
+  for (int bq = 0; bq < nb; ++bq) {
+    const int fsb = __builtin_amdgcn_readfirstlane(bcp->sb[bq]), oW = __builtin_amdgcn_readfirstlane(bcp->oWi[bq]);
+    const int u = t - 64 - 16 * bq;
+    if (u >= 0 && u < fsb) rdv[k + 16 * bq + u] = 1.0 / lds[oW + u * fsb + u];
+  }
+  __syncthreads();
+  // scaled strictly upper parts, the rest zero
+  for (int r = t >> 5; r < k; r += 8) {
+    const double rd = rdv[r];
+    for (int c = t & 31; c < k; c += 32) {
+      const double v = sR[r * LK + c];
+      sR[r * LK + c] = c > r ? v * rd : 0.0;
+    }
+  }
+  for (int bq = 0; bq < nb; ++bq) {
+    const int fsb = __builtin_amdgcn_readfirstlane(bcp->sb[bq]), oW = __builtin_amdgcn_readfirstlane(bcp->oWi[bq]);
+    const int a = t >> 4, c = t & 15;
+    if (a < fsb && c < fsb) {
+      const double v = lds[oW + a * fsb + c];
+      lds[oW + a * fsb + c] = c > a ? v * rdv[k + 16 * bq + a] : 0.0;
+    }
+  }
+  __syncthreads();
   if (t >= 64) return;
-  double gv = (t < k) ? sg[t] : 0.0;
-  if (!failed) {
-    const double rd = (t < k) ? 1.0 / sR[t * LK + t] : 0.0;
-    for (int i = k - 1; i >= 0; --i) {
-      const double yi = ss_readlane(gv * rd, i);
-      if (t < i) gv = __builtin_fma(-sR[t * LK + i], yi, gv);
-      if (t == i) gv = yi;
+  double gv = (t < k) ? sg[t] * rdv[t] : 0.0;
+  if (k > 0) {
+    ss_lds_ptr row = sR + (t < k ? t : k - 1) * LK;   // (lanes ≥ k: the last row — all zero now)
+    // eight steps per round: their eight entries are requested together (one LDS latency per round, not per step); steps past
+    // the end multiply a zero
+#pragma unroll 1
+    for (int i0 = k - 1; i0 >= 1; i0 -= 8) {
+      double rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = (i0 - u >= 1) ? row[i0 - u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gv = __builtin_fma(-rv[u], ss_readlane(gv, i0 - u >= 1 ? i0 - u : 0), gv);
     }
-    for (int bq = bc.n - 1; bq >= 0; --bq) {
-      const int fk0 = bc.k0[bq], fsb = bc.sb[bq];
-      if (k <= fk0) continue;   // (a cycle that ended before the block: nothing of it in y)
-      const double *c2 = bc.D[bq], *r2 = bc.Wi[bq];
-      const int cc = t - fk0;
-      const double rd2 = (cc >= 0 && cc < fsb) ? 1.0 / r2[cc * fsb + cc] : 0.0;
-      for (int c = fsb - 1; c >= 0; --c) {             // b = R₂⁻¹ y_Q on lanes k0 … k0 + sb − 1 (y is zero from k on)
-        const double bcv = ss_readlane(gv * rd2, fk0 + c);
-        if (t >= fk0 && t < fk0 + c) gv = __builtin_fma(-r2[(t - fk0) * fsb + c], bcv, gv);
-        if (t == fk0 + c) gv = bcv;
-      }
-      double acc = 0.0;
-      for (int c = 0; c < fsb; ++c) {
-        const double bcv = ss_readlane(gv, fk0 + c);
-        if (t < fk0) acc = __builtin_fma(c2[t * fsb + c], bcv, acc);
-      }
-      if (t < fk0) gv -= acc;
+  }
+#pragma unroll 1
+  for (int bq = nb - 1; bq >= 0; --bq) {
+    const int fk0 = __builtin_amdgcn_readfirstlane(bcp->k0[bq]), fsb = __builtin_amdgcn_readfirstlane(bcp->sb[bq]);
+    const int oW = __builtin_amdgcn_readfirstlane(bcp->oWi[bq]), oD = __builtin_amdgcn_readfirstlane(bcp->oD[bq]);
+    if (k <= fk0) continue;   // (a cycle that ended before the block: nothing of it in y)
+    const int cc = t - fk0;
+    const bool inb = cc >= 0 && cc < fsb;
+    ss_lds_ptr r2row = lds + oW + (inb ? cc : fsb - 1) * fsb;   // (other lanes: the last row — all zero now)
+    ss_lds_ptr c2row = lds + oD + (t < fk0 ? t : 0) * fsb;
+    if (inb) gv *= rdv[k + 16 * bq + cc];
+#pragma unroll 1
+    for (int c0 = fsb - 1; c0 >= 1; c0 -= 8) {       // b = R₂⁻¹ y_Q on lanes k0 … k0 + sb − 1 (y is zero from k on)
+      double rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = (c0 - u >= 1) ? r2row[c0 - u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gv = __builtin_fma(-rv[u], ss_readlane(gv, fk0 + (c0 - u >= 1 ? c0 - u : 0)), gv);
     }
-  } else {
-    gv = 0.0;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < fsb; c0 += 8) {
+      double cvv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cvv[u] = (c0 + u < fsb) ? c2row[c0 + u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_fma(cvv[u], ss_readlane(gv, fk0 + (c0 + u < fsb ? c0 + u : 0)), acc);
+    }
+    if (t < fk0) gv -= acc;
   }
   if (t < m) y[t] = gv;
 }
@@ -1319,10 +1444,10 @@ __device__ void ss_back_request(const ss_job &j, const ss_job_lds &L, double *ld
   }
   for (int e = t; e <= m; e += SS_R) sg[e] = j.g[e];
   if (t == 0) lds[L.verdict + 4] = j.ctl->rnorm0;
-  ss_fixc_request(bc, j.bfx, lds + L.bfix, skip_last, true);
+  ss_fixc_request(bc, j.bfx, lds, (int)L.bfix, skip_last, true);
 }
 // the back-substitution alone (the cycle was done before this launch): every operand from global memory
-__device__ void ss_back_only(const ss_job &j, const ss_job_lds &L, double *lds, ss_fixc *bc) {
+__device__ void ss_back_only(const ss_job &j, const ss_job_lds &L, double *lds, ss_fixc *bc, ss_lds_ptr lds3, ss_lds_fixc bc3) {
   ss_back_request(j, L, lds, bc, 0);
   double *vd = lds + L.verdict;
   if (threadIdx.x == 0) {
@@ -1330,17 +1455,115 @@ __device__ void ss_back_only(const ss_job &j, const ss_job_lds &L, double *lds, 
   }
   __syncthreads();
   if (threadIdx.x == 0) ss_publish_outcome(j.pub, j.seq, j.peer_err, (int)vd[0], (int)vd[1], (int)vd[2], vd[4], vd[3]);
-  ss_backsolve((int)vd[0], (int)vd[2], lds + L.sR, L.LK, lds + L.sg, j.y, j.m, *bc);
+  ss_backsolve((int)vd[0], (int)vd[2], (int)L.sR, L.LK, (int)L.sg, (int)L.rdv, j.y, j.m, bc3, lds3);
 }
-template <bool PEER>
+// ---- ONE memory round trip for everything the last workgroup's serial phases read from global memory.
+// A loop `for (e = t; e < count; e += 256) lds[e] = global[e]` makes one round trip PER ITERATION and per list (the LDS store
+// behind a load waits for it, the next load sits behind the store): 8.9 µs for the 15 lists of the cycle's last launch. Staging
+// every list through registers instead (all requests, then all stores) needs the lists unrolled — and this code runs ONCE per
+// launch on one workgroup, from a cold instruction cache: straight-line code is paid for per byte fetched (measured: the
+// unrolled form was slower than the loops). So the lists go through the LDS-direct loads of gfx950 (global_load_lds_dword: a
+// wavefront's 64 lanes deliver 64 consecutive dwords at a wave-uniform LDS base, every lane from its own global address):
+// compact rolled loops that only ISSUE — nothing waits until the barrier behind all of them (which carries vmcnt(0)).
+template <class F>
+__device__ __forceinline__ void ss_gather_async(unsigned lbase /* LDS byte address */, int count, F src_of /* e → const double * */) {
+  const int t = threadIdx.x, lane = t & 63;
+  for (int d0 = t - lane; d0 < 2 * count; d0 += SS_R) {   // d0: the wavefront's first dword of this round
+    const int d = d0 + lane;
+    const unsigned la = __builtin_amdgcn_readfirstlane(lbase + 4u * (unsigned)d0);   // (M0: wave-uniform)
+    if (d < 2 * count) {
+      const double *p = src_of(d >> 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)p + 4 * (d & 1)),
+                                       (__attribute__((address_space(3))) void *)(size_t)la, 4, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ void ss_fixc_carve(ss_fixc *fc, const nk_ss_fix &fix, int off) {
+#pragma unroll
+  for (int q = 0; q < NK_SS_NFIX; ++q) {
+    if (q < fix.n) {
+      const int oD = off; off += fix.k0[q] * fix.sb[q];
+      const int oWi = off; off += fix.sb[q] * fix.sb[q];
+      if (threadIdx.x == 0) { fc->k0[q] = fix.k0[q]; fc->sb[q] = fix.sb[q]; fc->oD[q] = oD; fc->oWi[q] = oWi; }
+    }
+  }
+  if (threadIdx.x == 0) fc->n = fix.n;
+}
+// the cached factors of a list of blocks: its first `nload` slots from global memory ((D, Wi), or (C₂, R₂))
+__device__ __forceinline__ void ss_fixc_gather(const nk_ss_fix &fix, unsigned b /* LDS byte address */, int nload, bool c2r2) {
+#pragma unroll
+  for (int q = 0; q < NK_SS_NFIX; ++q) {
+    if (q < fix.n) {
+      const unsigned sD = b; b += 8u * (unsigned)(fix.k0[q] * fix.sb[q]);
+      const unsigned sWi = b; b += 8u * (unsigned)(fix.sb[q] * fix.sb[q]);
+      if (q < nload) {
+        const double *gD = c2r2 ? fix.C2[q] : fix.D[q], *gW = c2r2 ? fix.R2[q] : fix.Wi[q];
+        ss_gather_async(sD, fix.k0[q] * fix.sb[q], [=](int e) { return gD + e; });
+        ss_gather_async(sWi, fix.sb[q] * fix.sb[q], [=](int e) { return gW + e; });
+      }
+    }
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void ss_job_request(const ss_job &j, const ss_tail_args &ta1, const ss_job_lds &L, double *lds, ss_fixc *fc,
+                                               ss_fixc *bc, const ss_ws &w1, bool peer, unsigned lds0 /* LDS byte address of `lds` */) {
+  constexpr bool f1 = (MODE & SSJ_F1) != 0, f2 = (MODE & SSJ_F2) != 0, hs = f2 && (MODE & SSJ_HESS) != 0, bk = (MODE & SSJ_BACK) != 0;
+  const int t = threadIdx.x;
+  const bool prep = f2 && (MODE & SSJ_PREP) != 0 && ta1.Wi != nullptr;
+  const ss_ws_offs wo = ss_ws_off(f2 ? j.k1 : 0, f2 ? j.sb1 : 0);
+  auto at = [=](int o) { return lds0 + 8u * (unsigned)(w1.o0 + o); };   // (an array of the pending block's workspace as an LDS address)
+  ss_fixc_carve(fc, j.cfix, (int)L.fix);
+  if (bk) ss_fixc_carve(bc, j.bfx, (int)L.bfix);
+  if (!peer) {   // both reduced blocks (written by other workgroups: the acquire behind the ticket has invalidated the L1)
+    const double *red = j.red;
+    ss_gather_async(lds0, j.nslots0 + j.nslots1, [=](int e) { return red + e; });
+  }
+  {
+    const int ksc = (f1 && j.k0 > j.k1) ? j.k0 : (f2 ? j.k1 : j.k0);
+    const double *sc = j.sc;
+    ss_gather_async(lds0 + 8u * (unsigned)L.sc, ksc, [=](int e) { return sc + e; });
+  }
+  ss_fixc_gather(j.cfix, lds0 + 8u * (unsigned)L.fix, j.cfix.n - ((f1 && prep) ? 1 : 0), false);   // (the pending block's slot is computed here)
+  if (hs) {   // what ss_hess_load requests
+    const int k = j.k1, sb = j.sb1, ko = k - 1, m = j.m;
+    const double *pH = ta1.H, *pcs = ta1.cs, *psn = ta1.sn, *pg = j.g, *pR1 = ta1.R1, *pC1 = ta1.C1, *scal = ta1.scal;
+    const double *ptol = &j.ctl->tol;
+    ss_gather_async(at(wo.Hs), k * ko, [=](int e) { return pH + (size_t)(e / ko) * m + (e % ko); });
+    ss_gather_async(at(wo.scs), ko, [=](int e) { return pcs + e; });
+    ss_gather_async(at(wo.ssn), ko, [=](int e) { return psn + e; });
+    ss_gather_async(at(wo.sg), ko + 1, [=](int e) { return pg + e; });
+    ss_gather_async(at(wo.R1s), sb * sb, [=](int e) { return pR1 + e; });
+    ss_gather_async(at(wo.F), k * sb, [=](int e) { return pC1 + e; });
+    ss_gather_async(at(wo.Fx), SS_SMAX + 2, [=](int e) { return e < SS_SMAX ? scal + SS_TH + e : (e == SS_SMAX ? scal + 2 : ptol); });
+    if (ta1.usb > 0) {
+      const int usb = ta1.usb, uk0 = ta1.uk0;
+      const double *puC = ta1.uC2, *puR = ta1.uR2;
+      ss_gather_async(at(wo.uu), k, [=](int e) { return e < uk0 ? puC + e * usb + usb - 1 : puR + (e - uk0) * usb + usb - 1; });
+    } else if (t < k) {
+      w1.uu[t] = (t == k - 1) ? 1.0 : 0.0;
+    }
+  }
+  if (bk) {   // the rotated factor (pitch m in LDS as well), g, ‖r₀‖, the earlier blocks' (C₂, R₂)
+    const int m = j.m;
+    const double *pRg = j.Rg, *pg = j.g, *prn0 = &j.ctl->rnorm0;
+    // (the block's own columns are written by the Hessenberg work of this launch: rows ko … of the old columns are never read)
+    ss_gather_async(lds0 + 8u * (unsigned)L.sR, (hs ? j.k1 - 1 : m) * m, [=](int e) { return pRg + e; });
+    ss_gather_async(lds0 + 8u * (unsigned)L.sg, m + 1, [=](int e) { return pg + e; });
+    ss_gather_async(lds0 + 8u * (unsigned)(L.verdict + 4), 1, [=](int e) { return prn0 + e; });
+    ss_fixc_gather(j.bfx, lds0 + 8u * (unsigned)L.bfix, j.bfx.n - (f2 ? 1 : 0), true);
+  }
+}
+// MODE: the job's bits at compile time — each combination the cycle uses is an instance of its own. This code runs once per
+// launch from a cold instruction cache: what an instance does not do must not be in it.
+template <bool PEER, int MODE>
 __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_args ta0, const ss_tail_args ta1, const nk_peer_ar_view pv) {
   extern __shared__ double s_rf[];
   __shared__ unsigned int s_last;
   __shared__ ss_fixc s_fc, s_bc;
   const int skip = (j.d_skip != nullptr) ? *j.d_skip : 0;
   const int t = threadIdx.x, slot = blockIdx.x;
-  const bool f1 = (j.mode & SSJ_F1) != 0, f2 = (j.mode & SSJ_F2) != 0, hs = (j.mode & SSJ_HESS) != 0, bk = (j.mode & SSJ_BACK) != 0;
-  if (slot == 0) SS_STAMP(0);
+  constexpr bool f1 = (MODE & SSJ_F1) != 0, f2 = (MODE & SSJ_F2) != 0, hs = f2 && (MODE & SSJ_HESS) != 0, bk = (MODE & SSJ_BACK) != 0;
+  SS_STAMP(0);
   // one wavefront per entry (four entries per workgroup): fixed order — lane l adds partials l, l + 64, …, then the
   // butterfly —, and one ticket per workgroup (465 same-address atomics of a workgroup-per-entry launch took 6 µs)
   const int wv = t >> 6, lane = t & 63;
@@ -1364,10 +1587,14 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
   // (the flag was requested together with the partials: one round trip; a collective runs on every rank even when the cycle
   //  is done.) The cycle may have ended INSIDE a sweep in front of this launch (a hosted Hessenberg workgroup's stopping test):
   //  the sweeps and Hessenberg launches behind a skipped job look at pad1.
-  const ss_job_lds L = ss_job_layout(j);
+  const ss_job_lds L = ss_job_layout(j, MODE);
+  // (the LDS block and the block list as address-space-3 pointers, taken from the symbols themselves: a cast of a generic
+  //  pointer further down trips the compiler — see ss_backsolve)
+  const ss_lds_ptr lds3 = (ss_lds_ptr)s_rf;
+  const ss_lds_fixc bc3 = (ss_lds_fixc)&s_bc;
   if (skip && slot == 0 && t == 0) j.ctl->pad1 = 1;
   if (skip && !PEER) {
-    if (bk && slot == 0) ss_back_only(j, L, s_rf, &s_bc);
+    if (bk && slot == 0) ss_back_only(j, L, s_rf, &s_bc, lds3, bc3);
     return;
   }
 #pragma unroll
@@ -1419,36 +1646,30 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
     }
     if (skip) {
       __syncthreads();
-      if (bk) ss_back_only(j, L, s_rf, &s_bc);
+      if (bk) ss_back_only(j, L, s_rf, &s_bc, lds3, bc3);
       return;
     }
-  } else {
-    // every entry of the reduced blocks is in `red` (written by other workgroups: read past the L1)
-    for (int e = t; e < nslots; e += SS_R) s_rf[e] = __builtin_nontemporal_load(&j.red[e]);
   }
-  // ---- the last workgroup. Everything the serial phases read from global memory rides in the same round trip.
+  // ---- the last workgroup. Everything the serial phases read from global memory rides in the same round trip: both reduced
+  // blocks (written by other workgroups: read past the L1), the column scales, the earlier blocks' factors (the pending
+  // block's slot is filled below), the Hessenberg work's inputs, the back-substitution's
   const double *red0 = s_rf, *red1 = s_rf + j.nslots0;
   double *s_sc = s_rf + L.sc, *vd = s_rf + L.verdict;
-  const int ksc = (f1 && j.k0 > j.k1) ? j.k0 : (f2 ? j.k1 : j.k0);
-  for (int e = t; e < ksc; e += SS_R) s_sc[e] = j.sc[e];
-  const bool prep = f2 && (j.mode & SSJ_PREP) != 0 && ta1.Wi != nullptr;
-  ss_fixc_request(&s_fc, j.cfix, s_rf + L.fix, (f1 && prep) ? 1 : 0);   // (the pending block's slot is filled below)
-  ss_ws w1, w0;
-  if (f2) w1 = ss_ws_carve(s_rf + L.w1, j.k1, j.sb1, hs);
-  if (f1) w0 = ss_ws_carve(s_rf + L.w0, j.k0, j.sb0, false);
-  if (f2 && hs) ss_hess_load(j.k1, j.sb1, w1, ta1);
-  if (bk) ss_back_request(j, L, s_rf, &s_bc, f2 ? 1 : 0);
+  const bool prep = f2 && (MODE & SSJ_PREP) != 0 && ta1.Wi != nullptr;
+  const ss_ws w1 = ss_ws_carve(s_rf + L.w1, f2 ? j.k1 : 0, f2 ? j.sb1 : 0, hs, (int)L.w1);
+  const ss_ws w0 = ss_ws_carve(s_rf + L.w0, f1 ? j.k0 : 0, f1 ? j.sb0 : 0, false, (int)L.w0);
+  ss_job_request<MODE>(j, ta1, L, s_rf, &s_fc, &s_bc, w1, PEER, (unsigned)(size_t)(__attribute__((address_space(3))) char *)s_rf);
   __syncthreads();
   SS_STAMP(2);
   bool alive = true;
   if (f2) {
-    alive = ss_factor(j.k1, j.sb1, red1, s_sc, w1, s_fc, ta1.fix.n, ta1.ptol);
+    alive = ss_factor(j.k1, j.sb1, red1, s_sc, w1, s_fc, ta1.fix.n, ta1.ptol, s_rf);
     // (left at its first pass only if that pass was good)
     if (alive && ta1.Wi != nullptr && !ss_first_pass_departure_ok(j.k1, j.sb1, w1, 0.1)) alive = false;
     if (alive) {
       for (int e = t; e < j.k1 * j.sb1; e += SS_R) ta1.C2[e] = w1.Ct[e];
       if (t < j.sb1 * j.sb1) ta1.R2[t] = w1.Rm[t];
-      if (j.mode & SSJ_COEF2) {
+      if (MODE & SSJ_COEF2) {
         for (int e = t; e < j.k1 * j.sb1; e += SS_R) j.coef[e] = w1.U[e];
         if (t < j.sb1 * j.sb1) j.coef[(size_t)j.k1 * j.sb1 + t] = w1.Ri[t];
       }
@@ -1456,7 +1677,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
       if (t == 0) ta1.scal[0] = 1.0 / ta1.scal[2];
       if (prep) {
         const int q = ta1.fix.n;   // the pending block's slot in this block's list (= its position among the earlier blocks)
-        ss_fix_prepare(j.k1, j.sb1, w1.Ct, w1.Rm, w1.Sm, ta1.Wi, ta1.D, f1 ? s_fc.Wi[q] : nullptr, f1 ? s_fc.D[q] : nullptr);
+        ss_fix_prepare(j.k1, j.sb1, w1.Ct, w1.Rm, w1.Sm, ta1.Wi, ta1.D, f1, s_rf + (f1 ? s_fc.oWi[q] : 0), s_rf + (f1 ? s_fc.oD[q] : 0));
       }
     }
   }
@@ -1466,7 +1687,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
       for (int e = j.k1 + t; e < j.k0; e += SS_R) s_sc[e] = 1.0;
       __syncthreads();
     }
-    alive = ss_factor(j.k0, j.sb0, red0, s_sc, w0, s_fc, ta0.fix.n, ta0.ptol);
+    alive = ss_factor(j.k0, j.sb0, red0, s_sc, w0, s_fc, ta0.fix.n, ta0.ptol, s_rf);
     if (alive) {
       for (int e = t; e < j.k0 * j.sb0; e += SS_R) j.coef[e] = w0.U[e];
       if (t < j.sb0 * j.sb0) j.coef[(size_t)j.k0 * j.sb0 + t] = w0.Ri[t];
@@ -1476,7 +1697,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
   }
   if (!alive) ss_fail(j.ctl, j.pub, j.seq);
   SS_STAMP(4);
-  if (alive && hs) ss_hessenberg(j.k1, j.sb1, w1, ta1, true, bk ? s_rf + L.sR : nullptr, L.LK, f1, bk ? vd : nullptr);
+  if (alive && hs) ss_hessenberg(j.k1, j.sb1, w1, ta1, true, s_rf + L.sR, bk ? L.LK : 0, f1, vd);
   if (bk) {
     __syncthreads();
     if (t == 0) {
@@ -1487,18 +1708,26 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
     }
     if (alive && f2 && t == 0) {   // the pending block's (C₂, R₂): in LDS already
       const int q = j.bfx.n - 1;
-      s_bc.D[q] = w1.Ct;
-      s_bc.Wi[q] = w1.Rm;
+      s_bc.oD[q] = w1.o0;
+      s_bc.oWi[q] = w1.o0 + ss_ws_off(j.k1, j.sb1).Rm;
     }
     __syncthreads();
-    ss_backsolve((int)vd[0], (int)vd[2], s_rf + L.sR, L.LK, (alive && hs) ? w1.sg : s_rf + L.sg, j.y, j.m, s_bc);
+    SS_STAMP(14);
+    ss_backsolve((int)vd[0], (int)vd[2], (int)L.sR, L.LK, (alive && hs) ? w1.o0 + ss_ws_off(j.k1, j.sb1).sg : (int)L.sg, (int)L.rdv, j.y, j.m, bc3, lds3);
+    SS_STAMP(15);
   }
+#ifdef NK_SS_STAMPS
+  if (t == 0 && g_ss_stamp != nullptr) {
+    const int bank = bk ? 2 : ((f1 && f2) ? 1 : 0);
+    for (int i = 0; i < 16; ++i) g_ss_stamp[16 * bank + i] = s_ss_stamps[i];
+  }
+#endif
 }
 extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   static unsigned long long *d_st = nullptr;
   if (enable && !d_st) {
-    if (hipMalloc(&d_st, 16 * sizeof(unsigned long long)) != hipSuccess) return NK_E_NOMEM;
-    hipMemset(d_st, 0, 16 * sizeof(unsigned long long));
+    if (hipMalloc(&d_st, 48 * sizeof(unsigned long long)) != hipSuccess) return NK_E_NOMEM;
+    hipMemset(d_st, 0, 48 * sizeof(unsigned long long));
     hipMemcpyToSymbol(HIP_SYMBOL(g_ss_stamp), &d_st, sizeof(d_st));
   }
   if (!enable && d_st) {
@@ -1507,7 +1736,7 @@ extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   }
   if (out5 && d_st) {
     hipDeviceSynchronize();
-    hipMemcpy(out5, d_st, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipMemcpy(out5, d_st, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   }
   return NK_OK;
 }
@@ -1873,24 +2102,36 @@ static int ss_launch_job(nk_ctx *ctx, const ss_job &j, const ss_tail_args &ta0, 
     pv = nk_peer_ar_next(ctx, nslots);
     NK_REQUIRE(pv.seq != 0, "internal: the fused s-step reduction needs the peer-mapped arenas (%d values)", nslots);
   }
-  const ss_job_lds L = ss_job_layout(j);
+  const ss_job_lds L = ss_job_layout(j, j.mode);
   const size_t lds = L.total * sizeof(double);
   NK_REQUIRE(lds <= 160 * 1024, "internal: the s-step scalar work needs %zu bytes of LDS", lds);
   const int grid = (nslots + 3) / 4;
   nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * ((double)j.nslots0 * j.nblk0 + (double)j.nslots1 * j.nblk1));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool ev = ctx->prof.on && nk_prof_next(ctx, &e0, &e1);
-  if (pv.seq) {
-    if (lds > 64 * 1024)
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_job<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (ev) hipExtLaunchKernelGGL(k_ss_job<true>, dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, j, ta0, ta1, pv);
-    else hipLaunchKernelGGL(k_ss_job<true>, dim3(grid), dim3(SS_R), lds, ctx->stream, j, ta0, ta1, pv);
-  } else {
-    if (lds > 64 * 1024)
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_job<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (ev) hipExtLaunchKernelGGL(k_ss_job<false>, dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, j, ta0, ta1, pv);
-    else hipLaunchKernelGGL(k_ss_job<false>, dim3(grid), dim3(SS_R), lds, ctx->stream, j, ta0, ta1, pv);
+#define SS_JOB_GO(PR, MD)                                                                                                          \
+  do {                                                                                                                             \
+    if (lds > 64 * 1024)                                                                                                           \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_job<PR, MD>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                 (int)lds));                                                                                       \
+    if (ev) hipExtLaunchKernelGGL((k_ss_job<PR, MD>), dim3(grid), dim3(SS_R), lds, ctx->stream, e0, e1, 0, j, ta0, ta1, pv);       \
+    else hipLaunchKernelGGL((k_ss_job<PR, MD>), dim3(grid), dim3(SS_R), lds, ctx->stream, j, ta0, ta1, pv);                        \
+  } while (0)
+#define SS_JOB_MODE(MD)                                                                                                            \
+  case MD:                                                                                                                         \
+    if (pv.seq) SS_JOB_GO(true, MD); else SS_JOB_GO(false, MD);                                                                    \
+    break
+  switch (j.mode) {   // the combinations nk_ss_cycle uses
+    SS_JOB_MODE(SSJ_F1);                                            // a block's first factorisation
+    SS_JOB_MODE(SSJ_F1 | SSJ_F2 | SSJ_PREP);                        // … behind the pending block's second (its Hessenberg work: hosted by sweep B)
+    SS_JOB_MODE(SSJ_F1 | SSJ_F2 | SSJ_PREP | SSJ_HESS);             // … and its Hessenberg columns here
+    SS_JOB_MODE(SSJ_F2 | SSJ_PREP | SSJ_HESS);                      // the pending block closed in a launch of its own
+    SS_JOB_MODE(SSJ_F2 | SSJ_PREP | SSJ_HESS | SSJ_BACK);           // the cycle's last launch
+    SS_JOB_MODE(SSJ_F2 | SSJ_COEF2);                                // a block with an explicit third sweep
+    default: NK_FAIL(NK_E_INVALID, "internal: no s-step scalar launch for mode %d", j.mode);
   }
+#undef SS_JOB_MODE
+#undef SS_JOB_GO
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

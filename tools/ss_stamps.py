@@ -1,5 +1,8 @@
-"""Development: where the time of the s-step block's scalar work goes (phase stamps of k_ss_reduce_factor's last workgroup,
-100 MHz wall clock). python tools/ss_stamps.py"""
+"""(needs the stamps build: make -C nonlinearsolve.jl_amd/csrc stamps; NK_LIB_PATH=nonlinearsolve.jl_amd/lib/libmi355x_nk_stamps.so)
+Development: where the time of the s-step block's scalar work goes — phase stamps of k_ss_job's last workgroup (100 MHz wall
+clock), one bank per kind of launch: the first block's (first factorisation only), the second block's (the pending block's second
+factorisation + this block's first), the cycle's last (second factorisation, Hessenberg columns, back-substitution).
+python tools/ss_stamps.py"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,14 +16,18 @@ prob.u0 = torch.zeros(ns * ns, dtype=torch.float64, device="cuda")
 cache = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30), concrete_jac=True), abstol=1e-300, maxiters=10**9)
 for _ in range(3):
     cache.step()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 48)()
 f(1, out)
+names = {0: "start(wg0)", 1: "last ticket", 2: "operands in LDS", 5: "f:Ct/U done (last factorisation)", 6: "f:frame ready", 3: "second factorisation (+Wi, D) done",
+         4: "first factorisation done", 8: "hess: start", 9: "hess: after barrier", 10: "hess: A v_k", 11: "hess: recurrence done",
+         12: "hess: H stored + old rotations", 7: "hess: rotations done", 13: "hess: rotations + verdict", 14: "outcome published", 15: "y done"}
 for _ in range(3):
     cache.step()
     f(1, out)
     v = list(out)
-    names = ["kernel start(wg0)", "last ticket", "red in LDS", "factor done", "end", "f:Ct/U done", "f:frame ready", "(unused)"]
-    base = v[0]
-    print({n: round((x - base) / 100.0, 2) for n, x in zip(names, v)})
-    hn = ["hess: start", "C1 loaded", "F = [C; R] ready", "recurrence done", "H stored + old rotations", "new rotations done"]
-    print({n: round((x - v[8]) / 100.0, 2) for n, x in zip(hn, v[8:14])})
+    for bank, what in enumerate(("first block", "second block", "cycle's last launch")):
+        b = v[16 * bank:16 * bank + 16]
+        if b[0] == 0:
+            continue
+        order = sorted((x, i) for i, x in enumerate(b) if x >= b[0] and i in names and (x - b[0]) < 100000)
+        print(what + ": " + ", ".join(f"{names[i]} {round((x - b[0]) / 100.0, 2)}" for x, i in order))
