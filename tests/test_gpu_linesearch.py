@@ -28,7 +28,12 @@ def test_linesearchesjl_methods_match_oracle(nls, method, which, krylov):
     sol = nls.solve(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(**kw) if krylov else None,
                                             linesearch=nls.LineSearchesJL(method)), abstol=1e-9, maxiters=100)
     assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode]
-    assert sol.stats.nsteps == ref.stats.nsteps and sol.stats.nf == ref.stats.nf
+    assert sol.stats.nsteps == ref.stats.nsteps
+    # function evaluations: equal with the direct solve. With GMRES the search direction agrees with the oracle's to the linear
+    # solver's tolerance only (≈ 1e-13 relative: a different, equally valid rounding of the Givens rotations and the
+    # back-substitution), and the bracketing tests of a line search compare ϕ values at that level: one evaluation more or less
+    # (§8(c): counts equal ± 1 under an identical protocol)
+    assert abs(sol.stats.nf - ref.stats.nf) <= (1 if krylov else 0), (sol.stats.nf, ref.stats.nf)
     assert np.max(np.abs(np.asarray(sol.u) - ref.u)) <= 1e-8 * max(1.0, np.max(np.abs(ref.u)))
 
 
