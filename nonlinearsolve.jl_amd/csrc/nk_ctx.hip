@@ -718,6 +718,56 @@ static int halo_setup_peer(nk_ctx *ctx, nk_halo *H) {
   return NK_OK;
 }
 
+// see nk_internal.h. Layout of a rank's block (offset `off` in its arena): flag from above, flag from below (128 bytes apart),
+// then 4 × 1024 doubles from above, 4 × 1024 from below.
+int nk_peer_powers_setup(nk_ctx *ctx, bool eligible, nk_peer_powers *out, bool *ok) {
+  *ok = false;
+  nk_peer &pr = ctx->peer;
+  const int P = ctx->nranks, me = ctx->rank;
+  constexpr size_t AREA = (size_t)4 * 1024 * sizeof(double), NEED = 256 + 2 * AREA;
+  const size_t off = pr.on ? ((pr.bump + 255) & ~(size_t)255) : 0;
+  std::vector<double> tab((size_t)P * 2, 0.0);
+  tab[(size_t)me * 2 + 0] = (double)off;
+  tab[(size_t)me * 2 + 1] = (eligible && pr.on && off + NEED <= pr.arena_bytes) ? 0.0 : 1.0;
+  double *d_tab = nullptr;
+  NK_TRY(nk_dev_alloc(&d_tab, tab.size()));
+  NK_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  int st = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
+  if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+  if (st == NK_OK) NK_HIP(hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(d_tab);
+  NK_TRY(st);
+  for (int p = 0; p < P; ++p)
+    if (tab[(size_t)p * 2 + 1] != 0.0) return NK_OK;   // somebody cannot: nobody does
+  pr.bump = off + NEED;
+  NK_HIP(hipMemsetAsync(pr.arena + off, 0, 256, ctx->stream));
+  out->myflag_up = reinterpret_cast<uint64_t *>(pr.arena + off);
+  out->myflag_dn = reinterpret_cast<uint64_t *>(pr.arena + off + 128);
+  out->recv_up = reinterpret_cast<double *>(pr.arena + off + 256);
+  out->recv_dn = reinterpret_cast<double *>(pr.arena + off + 256 + AREA);
+  if (me > 0) {   // my first slice is the rank above's "from below"
+    const size_t poff = (size_t)tab[(size_t)(me - 1) * 2];
+    out->flag_up = reinterpret_cast<uint64_t *>(pr.map[me - 1] + poff + 128);
+    out->push_up = reinterpret_cast<double *>(pr.map[me - 1] + poff + 256 + AREA);
+  }
+  if (me + 1 < P) {
+    const size_t poff = (size_t)tab[(size_t)(me + 1) * 2];
+    out->flag_dn = reinterpret_cast<uint64_t *>(pr.map[me + 1] + poff);
+    out->push_dn = reinterpret_cast<double *>(pr.map[me + 1] + poff + 256);
+  }
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  // nobody may push into an area before its owner has zeroed the flags: one more collective as a barrier
+  double *d_one = nullptr;
+  NK_TRY(nk_dev_alloc(&d_one, (size_t)1));
+  NK_HIP(hipMemset(d_one, 0, sizeof(double)));
+  st = comm_allreduce_base(ctx, d_one, 1, 0);
+  if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+  hipFree(d_one);
+  NK_TRY(st);
+  *ok = true;
+  return NK_OK;
+}
+
 int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t>> &send_idx_per_peer,
                   const std::vector<int64_t> &recv_cnt_per_peer) {
   const int P = ctx->nranks;

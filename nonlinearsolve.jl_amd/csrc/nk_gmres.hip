@@ -640,29 +640,52 @@ __global__ __launch_bounds__(256) void k_backsolve(const nk_gmres_ctl *ctl, cons
     if (t < fx.sb[bq] * fx.sb[bq]) sR2[bq][t] = fx.R2[bq][t];
   }
   __syncthreads();
+  // The arithmetic of nk_sstep.hip's ss_backsolve, operation for operation (the s-step cycle's last scalar launch back-substitutes
+  // itself where it can; the transports are compared bit for bit): reciprocal diagonals, every triangular factor scaled by them
+  // with its diagonal and lower part zeroed, then chains of multiply-adds.
+  __shared__ double rdv[NK_MAX_NV + 16 * NK_SS_NFIX];
+  if (!failed) {
+    if (t < k) rdv[t] = 1.0 / sR[t * LK + t];
+    for (int bq = 0; bq < fx.n; ++bq) {
+      const int u = t - 64 - 16 * bq;
+      if (k > fx.k0[bq] && u >= 0 && u < fx.sb[bq]) rdv[NK_MAX_NV + 16 * bq + u] = 1.0 / sR2[bq][u * fx.sb[bq] + u];
+    }
+  }
+  __syncthreads();
+  if (!failed) {
+    for (int r = t >> 5; r < k; r += 8) {
+      const double rd = rdv[r];
+      for (int c = t & 31; c < k; c += 32) {
+        const double v = sR[r * LK + c];
+        sR[r * LK + c] = c > r ? v * rd : 0.0;
+      }
+    }
+    for (int bq = 0; bq < fx.n; ++bq) {
+      const int fsb = fx.sb[bq], a = t >> 4, c = t & 15;
+      if (k > fx.k0[bq] && a < fsb && c < fsb) {
+        const double v = sR2[bq][a * fsb + c];
+        sR2[bq][a * fsb + c] = c > a ? v * rdv[NK_MAX_NV + 16 * bq + a] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
   if (t >= 64) return;
   if (t >= k) gv = 0.0;
   if (!failed) {
-    for (int i = k - 1; i >= 0; --i) {
-      const double yi = __shfl(gv, i, 64) / sR[i * LK + i];
-      if (t < i) gv -= sR[t * LK + i] * yi;
-      if (t == i) gv = yi;
-    }
+    if (t < k) gv *= rdv[t];
+    const double *row = sR + (t < k ? t : (k > 0 ? k - 1 : 0)) * LK;   // (lanes ≥ k: the last row — all zero now)
+    for (int i = k - 1; i >= 1; --i) gv = __builtin_fma(-row[i], __shfl(gv, i, 64), gv);
     // the blocks left at their first pass, last first: coefficients on [V_true Q] → on V_true and the block's stored columns
     for (int bq = fx.n - 1; bq >= 0; --bq) {
       const int fk0 = fx.k0[bq], fsb = fx.sb[bq];
       if (k <= fk0) continue;
-      const double *c2 = sC2[bq], *r2 = sR2[bq];
-      for (int c = fsb - 1; c >= 0; --c) {             // b = R₂⁻¹ y_Q on lanes k0 … k0 + sb − 1 (y is zero from k on)
-        const double bc = __shfl(gv, fk0 + c, 64) / r2[c * fsb + c];
-        if (t >= fk0 && t < fk0 + c) gv -= r2[(t - fk0) * fsb + c] * bc;
-        if (t == fk0 + c) gv = bc;
-      }
+      const int cc = t - fk0;
+      const bool inb = cc >= 0 && cc < fsb;
+      const double *r2row = sR2[bq] + (inb ? cc : fsb - 1) * fsb, *c2row = sC2[bq] + (t < fk0 ? t : 0) * fsb;
+      if (inb) gv *= rdv[NK_MAX_NV + 16 * bq + cc];
+      for (int c = fsb - 1; c >= 1; --c) gv = __builtin_fma(-r2row[c], __shfl(gv, fk0 + c, 64), gv);   // b = R₂⁻¹ y_Q
       double acc = 0.0;
-      for (int c = 0; c < fsb; ++c) {
-        const double bc = __shfl(gv, fk0 + c, 64);
-        if (t < fk0) acc += c2[t * fsb + c] * bc;
-      }
+      for (int c = 0; c < fsb; ++c) acc = __builtin_fma(c2row[c], __shfl(gv, fk0 + c, 64), acc);
       if (t < fk0) gv -= acc;
     }
   } else {

@@ -109,6 +109,16 @@ struct nk_peer_ar_view {
 };
 nk_peer_ar_view nk_peer_ar_next(nk_ctx *ctx, int count);
 bool nk_peer_ar_available(nk_ctx *ctx, int count);   // would nk_peer_ar_next take the fast path? (no side effect)
+// Receive areas of the resident matrix-powers kernel on several ranks (nk_powers.hip): per rank two areas of 4 × 1024 doubles
+// (from the rank above / below) and a flag word each, carved from the arena. COLLECTIVE: every rank passes whether its share of
+// the matrix is eligible; *ok is the common verdict (all eligible and the areas fit everywhere).
+struct nk_peer_powers {
+  double *push_up = nullptr, *push_dn = nullptr;           // the neighbours' areas for my slices, in my address space
+  uint64_t *flag_up = nullptr, *flag_dn = nullptr;         // the neighbours' flags for me
+  double *recv_up = nullptr, *recv_dn = nullptr;           // my areas
+  uint64_t *myflag_up = nullptr, *myflag_dn = nullptr;
+};
+int nk_peer_powers_setup(nk_ctx *ctx, bool eligible, nk_peer_powers *out, bool *ok);
 // bound of a device-side wait: the word behind the arena's error counter (err[1]); 5 s if the arena predates it
 __device__ __forceinline__ unsigned long long nk_peer_timeout(const uint64_t *err) {
   const unsigned long long t = err[1];

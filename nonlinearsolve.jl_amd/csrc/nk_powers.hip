@@ -45,6 +45,20 @@ struct pw_args {
   const double *diag;
   // k_spmv_powers_seg: SEG segments of seg_len rows each (nb bands per segment), bands of a segment on a ring or not
   int seg_len, ring;
+  // several ranks (k_spmv_powers<…, PEER = true>): the matrix is row-partitioned, rank r's first band and rank r − 1's last band
+  // are neighbours like any two bands — their boundary slices change hands through the peer-mapped arenas (system-scope stores
+  // into the neighbour's receive area, a flag released behind them; what nk_csr.hip's in-launch halo exchange does per
+  // operator application, here once per power inside ONE launch)
+  struct {
+    int up, dn;                          // there is a rank above / below
+    const int32_t *halo_vl;              // halo slot → row relative to this rank's first row (negative: above)
+    double *push_up, *push_dn;           // the neighbours' receive areas for my slices (4 buffers of PW_T), in MY address space
+    uint64_t *flag_up, *flag_dn;         // the neighbours' flags for me
+    const double *recv_up, *recv_dn;     // my receive areas (4 buffers of PW_T each)
+    const uint64_t *myflag_up, *myflag_dn;
+    uint64_t *err;                       // the arena's time-out counter (nk_peer_timeout)
+    int ebuf;                            // buffer pair of this launch: (epoch & 1)·2 — a neighbour is never two launches ahead
+  } pr;
 };
 
 __device__ __forceinline__ int pw_band_of(int bid, int nb) {   // block b runs on XCD b % 8: neighbouring bands share an L2
@@ -76,15 +90,40 @@ __device__ __forceinline__ bool pw_wait(const uint64_t *f, uint64_t target, uint
     }
   }
 }
+// a neighbour RANK's flag (system scope); same contract as pw_wait, the bound is the arena's
+__device__ __forceinline__ bool pw_wait_peer(const uint64_t *f, uint64_t target, uint64_t *perr, uint64_t *err) {
+  if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= target) return true;
+  const unsigned long long t0 = wall_clock64(), lim = nk_peer_timeout(perr);
+  for (unsigned it = 1;; ++it) {
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= target) return true;
+    if ((it & 63u) == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+      if (__hip_atomic_load(perr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4 || wall_clock64() - t0 > lim) {
+        atomicAdd((unsigned long long *)perr, 1ull);
+        __hip_atomic_store(err, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void pw_store_sys(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double pw_load_sys(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM));
+}
 // order in which a power visits the band's slices: the two the neighbours read first, the interior ones behind them
 template <int RPT>
 __device__ __forceinline__ constexpr int pw_slice(int q) {
   return q == 0 ? 0 : (q == 1 ? RPT - 1 : q - 1);
 }
 
-template <int RPT, int W, int GEN>
+template <int RPT, int W, int GEN, bool PEER = false>
 __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
-  if (a.d_skip != nullptr && *a.d_skip != 0) return;
+  if (a.d_skip != nullptr && *a.d_skip != 0) return;   // (the flag is replicated: every rank takes the same branch)
   extern __shared__ double pw_x[];
   __shared__ int s_abort;
   constexpr int RB = PW_T * RPT, XN = RB + 2 * PW_HALO;
@@ -93,6 +132,8 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
   const int b = pw_band_of(blockIdx.x, a.nb);
   const int r0 = b * RB;
   double *xa = pw_x, *xb = pw_x + XN;
+  // PEER: the first band's upper and the last band's lower neighbour are bands of other ranks
+  const bool pup = PEER && b == 0 && a.pr.up != 0, pdn = PEER && b == a.nb - 1 && a.pr.dn != 0;
 
   // ---- the band's matrix slice → registers (once per launch). A slice's entries are contiguous in val / col: the workgroup
   // streams them with lane-contiguous loads into LDS (the vector buffers are idle until the first power) and every thread then
@@ -140,7 +181,8 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         v[i][j] = a.val[k0 + j];
-        const int c = a.col[k0 + j];
+        int c = a.col[k0 + j];
+        if (PEER && (pup || pdn) && j < len[i] && c >= a.nrows) c = a.pr.halo_vl[c - a.nrows];
         ci[i][j] = (j < len[i]) ? c - (r0 - PW_HALO) : PW_HALO + t + PW_T * i;
       }
     }
@@ -166,7 +208,8 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
       for (int j = 0; j < W; ++j) {
         const int e = (j < len[i]) ? k0 - kb + j : 0;
         const double vv = sv[e];
-        const int c = sc[e];
+        int c = sc[e];
+        if (PEER && (pup || pdn) && j < len[i] && c >= a.nrows) c = a.pr.halo_vl[c - a.nrows];   // a halo slot → its row next door
         v[i][j] = (j < len[i]) ? vv : 0.0;
         ci[i][j] = (j < len[i]) ? c - (r0 - PW_HALO) : PW_HALO + t + PW_T * i;   // (slots past the row's end: never summed)
       }
@@ -180,6 +223,23 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
   }
   if (t == 0) s_abort = 0;
   __syncthreads();
+  if (PEER && (pup || pdn)) {
+    // the start vector's rows next door: my first / last slice goes to the neighbour rank, its last / first comes back
+    // (buffer ebuf + 0; "power −1" is published as the launch's base value itself)
+    if (pup) pw_store_sys(a.pr.push_up + (size_t)a.pr.ebuf * PW_T + t, a.x0[t]);
+    if (pdn) pw_store_sys(a.pr.push_dn + (size_t)a.pr.ebuf * PW_T + t, a.x0[a.nrows - PW_T + t]);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0 && pup) __hip_atomic_store(a.pr.flag_up, a.base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 64 && pdn) __hip_atomic_store(a.pr.flag_dn, a.base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0 && pup && !pw_wait_peer(a.pr.myflag_up, a.base, a.pr.err, a.err)) s_abort = 1;
+    if (t == 64 && pdn && !pw_wait_peer(a.pr.myflag_dn, a.base, a.pr.err, a.err)) s_abort = 1;
+    __syncthreads();
+    if (s_abort) return;
+    if (pup) xa[t] = pw_load_sys(a.pr.recv_up + (size_t)a.pr.ebuf * PW_T + t);
+    if (pdn) xa[PW_HALO + RB + t] = pw_load_sys(a.pr.recv_dn + (size_t)a.pr.ebuf * PW_T + t);
+    __syncthreads();
+  }
 
   const bool shifted = a.theta != nullptr;
   for (int p = 0; p < a.s; ++p) {
@@ -207,28 +267,51 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
         if (q < NBND) pw_store_sc1(ycol + r, out);   // rows a neighbour band reads: write-through
         else ycol[r] = out;
       }
+      if (PEER && pub) {   // … and the slice a neighbour RANK reads: into its receive area (buffer ebuf + (p + 1) mod 2)
+        const size_t boff = (size_t)(a.pr.ebuf + ((p + 1) & 1)) * PW_T + t;
+        if (pup && i == 0) pw_store_sys(a.pr.push_up + boff, out);
+        if (pdn && i == RPT - 1) pw_store_sys(a.pr.push_dn + boff, out);
+      }
       if (pub && (a.variant & 255) == 0 && q == NBND - 1) {   // publish as early as possible: behind the boundary slices
+        if (PEER && (pup || pdn)) __threadfence_system();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0 && !((a.variant & 256) && b == 0))
           __hip_atomic_store(a.flags + (size_t)b * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
+        if (PEER) {
+          if (t == 64 && pup) __hip_atomic_store(a.pr.flag_up, a.base + (uint64_t)p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (t == 128 && pdn) __hip_atomic_store(a.pr.flag_dn, a.base + (uint64_t)p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
     if (!pub) break;
     if ((a.variant & 255) != 0) {   // publish behind the whole band: the interior rows overlap the boundary rows' write-through
+      if (PEER && (pup || pdn)) __threadfence_system();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t == 0)
         __hip_atomic_store(a.flags + (size_t)b * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+      if (PEER) {
+        if (t == 64 && pup) __hip_atomic_store(a.pr.flag_up, a.base + (uint64_t)p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == 128 && pdn) __hip_atomic_store(a.pr.flag_dn, a.base + (uint64_t)p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     // ---- the neighbours' boundary rows of power p → the halo parts of the next input buffer
-    if (t == 0 && b > 0) {
-      if (!pw_wait(a.flags + (size_t)(b - 1) * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+    if (t == 0) {
+      if (b > 0) {
+        if (!pw_wait(a.flags + (size_t)(b - 1) * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+      } else if (PEER && pup) {
+        if (!pw_wait_peer(a.pr.myflag_up, a.base + (uint64_t)p + 1, a.pr.err, a.err)) s_abort = 1;
+      }
     }
-    if (t == 64 && b + 1 < a.nb) {
-      if (!pw_wait(a.flags + (size_t)(b + 1) * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+    if (t == 64) {
+      if (b + 1 < a.nb) {
+        if (!pw_wait(a.flags + (size_t)(b + 1) * PW_FLAG_STRIDE, a.base + (uint64_t)p + 1, a.err)) s_abort = 1;
+      } else if (PEER && pdn) {
+        if (!pw_wait_peer(a.pr.myflag_dn, a.base + (uint64_t)p + 1, a.pr.err, a.err)) s_abort = 1;
+      }
     }
     __syncthreads();
     if (s_abort) return;
@@ -236,7 +319,9 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
       const int gu = r0 - PW_HALO + t, gd = r0 + RB + t;
       double hu = 0.0, hd = 0.0;
       if (b > 0) hu = pw_load_sc1(ycol + gu);
+      else if (PEER && pup) hu = pw_load_sys(a.pr.recv_up + (size_t)(a.pr.ebuf + ((p + 1) & 1)) * PW_T + t);
       if (gd < a.nrows) hd = pw_load_sc1(ycol + gd);
+      else if (PEER && pdn) hd = pw_load_sys(a.pr.recv_dn + (size_t)(a.pr.ebuf + ((p + 1) & 1)) * PW_T + t);
       xout[t] = hu;
       xout[PW_HALO + RB + t] = hd;
     }
@@ -381,10 +466,15 @@ struct nk_powers_plan {
   uint64_t *h_err = nullptr, *h_err_dev = nullptr;   // pinned, coherent: {time-outs, bound in ticks}
   uint64_t epoch = 0;
   bool broken = false;
+  // several ranks: the neighbours' and my receive areas in the peer-mapped arenas, the halo slots' rows next door
+  bool peer = false;
+  nk_peer_powers pp;
+  int32_t *d_halo_vl = nullptr;
 };
 void nk_powers_plan_destroy(nk_powers_plan *P) {
   if (!P) return;
   hipFree(P->d_flags);
+  hipFree(P->d_halo_vl);
   if (P->h_err) hipHostFree(P->h_err);
   delete P;
 }
@@ -401,30 +491,36 @@ static bool pw_enabled() {
   return on;
 }
 
-template <int RPT, int W, int GEN>
+// (the LDS limit is an attribute of the function ON A DEVICE: set on every call — a process-wide "done" flag left a second
+//  context on another GPU at the default 64 KB)
+template <int RPT, int W, int GEN, bool PEER = false>
 static int pw_launch(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
   constexpr size_t lds_x = (size_t)2 * (PW_T * RPT + 2 * PW_HALO) * sizeof(double), lds_m = (W > 8 || GEN == 1) ? 0 : (size_t)PW_T * W * 12;
   constexpr size_t lds = lds_x > lds_m ? lds_x : lds_m;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lds > 64 * 1024)
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    attr_set = true;
-  }
+  if (lds > 64 * 1024)
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN, PEER>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (query) {
-    NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers<RPT, W, GEN>, PW_T, lds));
+    NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers<RPT, W, GEN, PEER>, PW_T, lds));
     return NK_OK;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
-    hipExtLaunchKernelGGL((k_spmv_powers<RPT, W, GEN>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
   else
-    hipLaunchKernelGGL((k_spmv_powers<RPT, W, GEN>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
-static int pw_dispatch(nk_ctx *ctx, int rpt, int w, const pw_args &a, bool query, int *occ, int gen = 0) {
+static int pw_dispatch(nk_ctx *ctx, int rpt, int w, const pw_args &a, bool query, int *occ, int gen = 0, bool peer = false) {
+  if (peer) {   // several ranks (stored matrices)
+#define PW_PEER(R, WW) if (rpt == R && w == WW) return pw_launch<R, WW, 0, true>(ctx, a, query, occ)
+    PW_PEER(1, 5); PW_PEER(2, 5); PW_PEER(4, 5); PW_PEER(6, 5);
+    PW_PEER(1, 8); PW_PEER(2, 8);
+    PW_PEER(1, 16);
+#undef PW_PEER
+    NK_FAIL(NK_E_INVALID, "internal: no matrix-powers kernel for %d rows per thread × %d entries per row", rpt, w);
+  }
 #define PW_CASE(R, WW) if (rpt == R && w == WW) return pw_launch<R, WW, 0>(ctx, a, query, occ)
   if (gen == 1) {
     if (rpt == 1) return pw_launch<1, 5, 1>(ctx, a, query, occ);
@@ -443,13 +539,9 @@ template <int RPS, int W, int SEG>
 static int pw_launch_seg(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
   constexpr size_t lds_x = (size_t)2 * SEG * (PW_T * RPS + 2 * PW_HALO) * sizeof(double), lds_m = (size_t)PW_T * W * 12;
   constexpr size_t lds = lds_x > lds_m ? lds_x : lds_m;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lds > 64 * 1024)
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers_seg<RPS, W, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    attr_set = true;
-  }
+  if (lds > 64 * 1024)
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers_seg<RPS, W, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
   if (query) {
     NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers_seg<RPS, W, SEG>, PW_T, lds));
     return NK_OK;
@@ -560,11 +652,52 @@ extern "C" int nk_csr_powers_layout(int64_t nrows, const int32_t *rowptr, const 
 }
 
 // Builds (once per pattern) the plan of the resident matrix-powers kernel; A->pw stays NULL when the matrix is not eligible.
+// Several ranks (COLLECTIVE — every rank reaches this with its share of the same matrix): the plain band layout on every rank,
+// whole bands, and every halo column within one slice of the rank's first / last row — i.e. owned by the rank next door, among
+// its last / first 1024 rows. The ranks agree (nk_peer_powers_setup); a single "no" keeps the streaming kernel everywhere.
+static int pw_plan_ranks(nk_csr *A) {
+  nk_ctx *ctx = A->ctx;
+  const int64_t n = A->nrows;
+  const int nh = (int)A->halo_gcols.size();
+  std::vector<int32_t> hvl(nh > 0 ? nh : 1, 0), vcol;
+  bool ok = pw_enabled() && ctx->peer.on && n >= PW_T && A->nnz >= 1;
+  static const bool ranks_off = getenv("NK_PW_RANKS") && atoi(getenv("NK_PW_RANKS")) == 0;   // A/B switch
+  ok = ok && !ranks_off;
+  for (int h = 0; h < nh && ok; ++h) {
+    const int64_t vl = A->halo_gcols[h] - A->row_begin;
+    ok = (vl < 0 && vl >= -PW_HALO && ctx->rank > 0) || (vl >= n && vl < n + PW_HALO && ctx->rank + 1 < ctx->nranks);
+    hvl[h] = (int32_t)vl;
+  }
+  pw_layout L;
+  if (ok) {
+    vcol.resize(A->h_col.size());
+    for (size_t k = 0; k < vcol.size(); ++k) vcol[k] = A->h_col[k] < n ? A->h_col[k] : hvl[A->h_col[k] - n];
+    L = pw_find_layout(n, A->h_rowptr.data(), vcol.data(), ctx->num_cus, 0);
+    ok = L.kind == 1 && n % ((int64_t)PW_T * L.rpt) == 0;
+    if (ok) {
+      pw_args probe{};
+      int occ = 0;
+      NK_TRY(pw_dispatch(ctx, L.rpt, L.w, probe, true, &occ, 0, true));
+      ok = occ >= 1 && L.nb <= ctx->num_cus * occ;
+    }
+  }
+  nk_peer_powers pp;
+  bool all = false;
+  NK_TRY(nk_peer_powers_setup(ctx, ok, &pp, &all));
+  if (!all) return NK_OK;
+  NK_TRY(pw_plan_new(L.rpt, L.w, L.nb, &A->pw));
+  A->pw->peer = true;
+  A->pw->pp = pp;
+  NK_HIP(hipMalloc((void **)&A->pw->d_halo_vl, hvl.size() * sizeof(int32_t)));
+  NK_HIP(hipMemcpy(A->pw->d_halo_vl, hvl.data(), hvl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return NK_OK;
+}
 static int pw_plan(nk_csr *A) {
   if (A->pw_tried) return NK_OK;
   A->pw_tried = true;
   nk_ctx *ctx = A->ctx;
-  if (!pw_enabled() || ctx->nranks != 1 || !A->halo_gcols.empty() || A->nrows < 1 || A->nnz < 1) return NK_OK;
+  if (ctx->nranks > 1) return pw_plan_ranks(A);
+  if (!pw_enabled() || !A->halo_gcols.empty() || A->nrows < 1 || A->nnz < 1) return NK_OK;
   pw_args probe{};
   for (int skip = 0; skip < 4;) {
     const pw_layout L = pw_find_layout(A->nrows, A->h_rowptr.data(), A->h_col.data(), ctx->num_cus, skip);
@@ -610,6 +743,16 @@ int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, i
   if (P->seg > 0) {
     a.seg_len = P->seg_len; a.ring = P->ring;
     return pw_dispatch_seg(ctx, P->rpt, P->w, P->seg, a, false, nullptr);
+  }
+  if (P->peer) {
+    a.pr.up = ctx->rank > 0; a.pr.dn = ctx->rank + 1 < ctx->nranks;
+    a.pr.halo_vl = P->d_halo_vl;
+    a.pr.push_up = P->pp.push_up; a.pr.push_dn = P->pp.push_dn; a.pr.flag_up = P->pp.flag_up; a.pr.flag_dn = P->pp.flag_dn;
+    a.pr.recv_up = P->pp.recv_up; a.pr.recv_dn = P->pp.recv_dn; a.pr.myflag_up = P->pp.myflag_up; a.pr.myflag_dn = P->pp.myflag_dn;
+    a.pr.err = nk_peer_err_ptr(ctx);
+    a.pr.ebuf = (int)(P->epoch & 1) * 2;
+    ctx->stats.halo_exchanges++;   // (ONE exchange protocol per launch: s − 1 hand-offs inside it)
+    return pw_dispatch(ctx, P->rpt, P->w, a, false, nullptr, 0, true);
   }
   return pw_dispatch(ctx, P->rpt, P->w, a, false, nullptr);
 }

@@ -2183,7 +2183,8 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   static const bool tail_back_off = getenv("NK_SS_TAIL_BACK") && atoi(getenv("NK_SS_TAIL_BACK")) == 0;
   static const int hess_where = getenv("NK_SS_DEFER_HESS") ? atoi(getenv("NK_SS_DEFER_HESS")) : -1;   // 0: in the job, 1: hosted by sweep B
   // several ranks: the fused scalar launches are also the all-reduce — on peer-mapped arenas only
-  const bool peer_ok = nk_ctx_is_single(ctx) || nk_peer_ar_available(ctx, 2 * (SS_KMAX / 2 + SS_SMAX) * SS_SMAX);
+  // (one message may carry two partial blocks: ≤ 2·(steps + 1)·s values — 930 for GMRES(30) in blocks of 15)
+  const bool peer_ok = nk_ctx_is_single(ctx) || nk_peer_ar_available(ctx, 2 * (steps + 1) * s);
   const bool deferred = !defer_off && implicit_mode && peer_ok && nk_ss_fusable(1, 1);
   const bool fixed_work = !G->ss_grow;
   ta.ptol = 1e-12;

@@ -106,8 +106,9 @@ def _worker(rank, world, port, q, transport="torch"):
             cch.step()
         per_step = (cch.stats.allreduces - a0) / 3.0
         halo_step = (cch.stats.halo_exchanges - h0) / 3.0
-        # (peer-mapped arenas: one launch fewer carries a collective — 7; the callback transport issues every one of the 8 itself)
-        assert per_step == (7.0 if transport == "peer" else 8.0) and halo_step == 31.0, f"PERSTEP={per_step} HALOSTEP={halo_step}"
+        # (peer-mapped arenas: one launch fewer carries a collective, and — round 5 — a block's second factorisation rides in the
+        #  next block's scalar launch: 3 messages for the 4 Gram blocks — 6; the callback transport issues every one of the 8 itself)
+        assert per_step == (6.0 if transport == "peer" else 8.0) and halo_step == 31.0, f"PERSTEP={per_step} HALOSTEP={halo_step}"
         cch.close()
 
         # ---------------- halo exchange overlapped with the interior row blocks (second stream + events): a grid large
@@ -562,3 +563,83 @@ def test_rccl_entry_points_world1():
     res = q.get(timeout=280)
     p.join(timeout=60)
     assert res == "ok", res
+
+
+# ----------------------------------------------------------------------------- the resident matrix-powers kernel on several ranks
+def _powers_worker(rank, world, port, q, ns, pw_ranks):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NK_PW_RANKS=pw_ranks)
+    import hashlib
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nonlinearsolve_jl_amd as nls
+        from oracle import reference_restatement as R
+        from tests.test_gpu_powers import _powers_ref
+        torch.cuda.set_device(0)
+        ctx = nls.Context(device=0)
+        nls.set_default_context(ctx)
+        assert nls.dist.init_comm(ctx, "peer") == "peer+torch"
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(ns)
+        pb, P = R.Bratu2D(ns), nls.Bratu2D(ns)
+        b, e = P.row_begin, P.row_begin + P.n_local
+        u = 0.1 * rng.standard_normal(pb.n)
+        Jg = pb.jac(u).tocsr()
+        J = P.jac_csr()
+        P.jac_values(torch.tensor(u[b:e], device=dev), J)
+        x = rng.standard_normal(pb.n)
+        lam = float(abs(Jg).sum(axis=1).max())
+        s = 15
+        theta = (0.5 + 0.4 * np.cos(np.arange(s))) * lam
+        scale = 2.0 / lam
+        ref = _powers_ref(Jg, x, s, theta, scale)[:, b:e]
+        xl = torch.tensor(x[b:e], device=dev)
+        for rep in range(3):   # (repeated launches: epochs and buffer pairs keep them apart)
+            Y, resident = J.powers(xl, s, theta=theta, scale=scale)
+            assert resident == (pw_ranks == "1"), (resident, pw_ranks)
+            assert np.array_equal(Y.cpu().numpy(), ref), f"rep {rep}: first differing power " \
+                f"{int(np.argmax((Y.cpu().numpy() != ref).any(axis=1)))}"
+        # the headline protocol on the partitioned matrix: the blocks' operator applications are ONE launch with ONE exchange
+        # protocol each — 2 per fixed-work step of two blocks, + the residual's exchange (31 with the streaming kernel)
+        prob = nls.NonlinearProblem(P, u0=torch.zeros(e - b, dtype=torch.float64, device=dev))
+        cch = nls.init(prob, nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, fixed_iters=30),
+                                               concrete_jac=True), abstol=1e-300, maxiters=10 ** 6)
+        cch.step()
+        h0 = cch.stats.halo_exchanges
+        for _ in range(3):
+            cch.step()
+        halo_step = (cch.stats.halo_exchanges - h0) / 3.0
+        assert halo_step == (3.0 if pw_ranks == "1" else 31.0), halo_step
+        ug = nls.dist.gather_vector(cch.u, pb.n, b)
+        digest = hashlib.sha1(np.ascontiguousarray(ug).tobytes()).hexdigest()
+        cch.close()
+        assert ctx.comm_peer_status()[1] == 0
+        q.put((rank, "ok", digest))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), ""))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ns", [(2, 64), (4, 64), (8, 128), (2, 512)])
+def test_resident_matrix_powers_on_several_ranks(world, ns):
+    """nk_powers.hip with the matrix row-partitioned over 2 / 4 / 8 ranks (processes on one GPU, peer-mapped arenas): a rank's
+    first / last band hands its boundary slice to the rank next door through that rank's arena. Every column equals the serial
+    oracle's bit for bit; four fixed-work Newton steps leave the SAME iterate as with the streaming kernel (NK_PW_RANKS=0);
+    one exchange protocol per launch instead of one per operator application."""
+    out = {}
+    for pw_ranks in ("1", "0"):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_powers_worker, args=(r, world, port, q, ns, pw_ranks)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=280) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+        assert all(r[1] == "ok" for r in res), res
+        out[pw_ranks] = {r[2] for r in res}
+    assert out["1"] == out["0"] and len(out["1"]) == 1
