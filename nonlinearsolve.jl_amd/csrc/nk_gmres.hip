@@ -756,6 +756,7 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   hipFree(G->d_Hraw); hipFree(G->d_ca); hipFree(G->d_cb); hipFree(G->d_tprev); hipFree(G->d_red);
   nk_mg_destroy(G->mg);
   nk_ss_destroy(G->ss);
+  hipFree(G->x0_keep);
   if (G->gexec) hipGraphExecDestroy(G->gexec);
   if (G->cap_stream) hipStreamDestroy(G->cap_stream);
   hipFree(G->d_h); hipFree(G->d_h2); hipFree(G->d_s); hipFree(G->d_R); hipFree(G->d_cs); hipFree(G->d_sn);
@@ -1576,14 +1577,23 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
 // Newton step's) is simply run again on the streaming kernel instead of handing the failure to the caller.
 int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol,
                        int maxiter, int fixed_iters, nk_gmres_info *info) {
+  // (a plan that timed out in an earlier solve comes back with this one: nk_powers.hip)
+  if (G->op_kind == 1 && G->A) nk_csr_powers_rearm(G->A);
+  if (G->op_kind == 2 && G->P) nk_problem_powers_rearm(G->P);
   const bool had_plan = (G->op_kind == 1 && G->A && nk_csr_powers_ready(G->A)) ||
                         (G->op_kind == 2 && G->P && G->P->kind == NK_PROBLEM_BRATU2D && nk_problem_powers_ready(G->P));
+  // a warm start is kept aside while a resident plan is in play: a torn launch leaves garbage in x
+  if (had_plan && use_x0) {
+    if (!G->x0_keep) NK_TRY(nk_dev_alloc(&G->x0_keep, (size_t)G->n + 1));
+    NK_HIP(hipMemcpyAsync(G->x0_keep, d_x, G->n * sizeof(double), hipMemcpyDeviceToDevice, G->ctx->stream));
+  }
   const int rc = gmres_solve_once(G, d_b, d_x, use_x0, atol, rtol, maxiter, fixed_iters, info);
-  if (rc == NK_E_HIP && had_plan && !use_x0) {
+  if (rc == NK_E_HIP && had_plan) {
     const bool now = (G->op_kind == 1 && nk_csr_powers_ready(G->A)) || (G->op_kind == 2 && nk_problem_powers_ready(G->P));
     if (!now && hipStreamQuery(G->ctx->stream) != hipErrorUnknown) {   // the plan broke in this solve; the stream is alive
       hipStreamSynchronize(G->ctx->stream);
-      return gmres_solve_once(G, d_b, d_x, 0, atol, rtol, maxiter, fixed_iters, info);
+      if (use_x0) NK_HIP(hipMemcpyAsync(d_x, G->x0_keep, G->n * sizeof(double), hipMemcpyDeviceToDevice, G->ctx->stream));
+      return gmres_solve_once(G, d_b, d_x, use_x0, atol, rtol, maxiter, fixed_iters, info);
     }
   }
   return rc;

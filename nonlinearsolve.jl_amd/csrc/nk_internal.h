@@ -295,7 +295,8 @@ struct nk_csr {
 bool nk_csr_powers_ready(nk_csr *A);   // the matrix has a plan (built on first call) and no launch has timed out
 int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, int s, const double *d_scal_first,
                       const double *d_scal_rest, const double *d_theta, const int *d_skip);
-int nk_csr_powers_check(nk_csr *A);    // NK_E_HIP once if a launch timed out (the plan is then off for good)
+int nk_csr_powers_check(nk_csr *A);    // NK_E_HIP once if a launch timed out (the plan is parked)
+void nk_csr_powers_rearm(nk_csr *A);   // a parked plan comes back (one rank, fewer than three time-outs so far)
 void nk_powers_plan_destroy(struct nk_powers_plan *P);
 // d_out_scale (nullable): y = (*d_out_scale) · A x   (lagged normalisation of the Krylov basis)
 int nk_csr_spmv_dev(nk_csr *A, const double *d_x, double *d_y, const int *d_skip, const double *d_out_scale = nullptr,
@@ -351,6 +352,7 @@ bool nk_problem_powers_ready(nk_problem *P);
 int nk_problem_powers_dev(nk_problem *P, const double *d_u, const double *d_x0, double *d_Y, int64_t ldy, int s,
                           const double *d_scal_first, const double *d_scal_rest, const double *d_theta, const int *d_skip);
 int nk_problem_powers_check(nk_problem *P);
+void nk_problem_powers_rearm(nk_problem *P);
 int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, double scale, nk_problem **out);
 int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out);
 int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi);
@@ -449,6 +451,7 @@ struct nk_gmres {
   int64_t n = 0, ldv = 0;
   int m = 30, ortho = NK_ORTHO_CGS2;
   double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
+  double *x0_keep = nullptr;   // the warm start of a solve that runs on a resident matrix-powers plan (restored if a launch is torn)
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,

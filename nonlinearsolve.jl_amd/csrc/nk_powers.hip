@@ -19,6 +19,7 @@
 // wall-clock time-out that raises the plan's error word (host-visible), after which the object falls back for good.
 #include <algorithm>
 #include <stdlib.h>
+#include <vector>
 
 #include "nk_internal.h"
 
@@ -466,6 +467,7 @@ struct nk_powers_plan {
   uint64_t *h_err = nullptr, *h_err_dev = nullptr;   // pinned, coherent: {time-outs, bound in ticks}
   uint64_t epoch = 0;
   bool broken = false;
+  int strikes = 0;   // launches that timed out so far: the plan comes back with the next linear solve, three strikes switch it off for good
   // several ranks: the neighbours' and my receive areas in the peer-mapped arenas, the halo slots' rows next door
   bool peer = false;
   nk_peer_powers pp;
@@ -481,10 +483,24 @@ void nk_powers_plan_destroy(nk_powers_plan *P) {
 static int pw_variant() {
   static const int v = getenv("NK_PW_VARIANT") ? atoi(getenv("NK_PW_VARIANT")) : 0;
   // development hook: NK_PW_DEBUG_STALL_LAUNCH = n makes band 0 of the process's n-th launch withhold its flag (the time-out path)
-  static const long stall = getenv("NK_PW_DEBUG_STALL_LAUNCH") ? atol(getenv("NK_PW_DEBUG_STALL_LAUNCH")) : -1;
+  // (a comma-separated list: several torn launches)
+  static const std::vector<long> stalls = [] {
+    std::vector<long> v;
+    const char *e = getenv("NK_PW_DEBUG_STALL_LAUNCH");
+    while (e && *e) {
+      char *end = nullptr;
+      const long x = strtol(e, &end, 10);
+      if (end == e) break;
+      v.push_back(x);
+      e = (*end == ',') ? end + 1 : end;
+    }
+    return v;
+  }();
   static long launches = 0;
   ++launches;
-  return (v & 255) | ((stall > 0 && launches == stall) ? 256 : 0);
+  bool stall = false;
+  for (long x : stalls) stall = stall || (x > 0 && launches == x);
+  return (v & 255) | (stall ? 256 : 0);
 }
 static bool pw_enabled() {
   static const bool on = !(getenv("NK_SPMV_POWERS") && atoi(getenv("NK_SPMV_POWERS")) == 0);
@@ -718,13 +734,25 @@ bool nk_csr_powers_ready(nk_csr *A) {
   if (!A->pw_tried && pw_plan(A) != NK_OK) return false;
   return A->pw != nullptr && !A->pw->broken && A->pw->h_err[0] == 0;
 }
-// a time-out of an earlier launch (workgroups not resident together?): the plan is off for good; NK_E_HIP once
+// a time-out of an earlier launch (workgroups not resident together: another stream or process held compute units): the plan is
+// parked — NK_E_HIP once, the caller reruns what it can on the streaming kernel
 int nk_csr_powers_check(nk_csr *A) {
   if (!A->pw || A->pw->broken || A->pw->h_err[0] == 0) return NK_OK;
   A->pw->broken = true;
+  A->pw->strikes++;
   NK_FAIL(NK_E_HIP, "resident matrix-powers kernel: a workgroup waited longer than NK_PW_TIMEOUT_MS for its neighbour band "
                     "(NK_SPMV_POWERS=0 keeps the streaming SpMV)");
 }
+// … and comes back with the next linear solve (what held the compute units is usually gone by then): the error word is cleared,
+// the flags need nothing (they are monotone: the next launch's base lies above everything a torn launch left behind). After three
+// time-outs the matrix keeps the streaming kernel. One rank only: on several ranks every rank would have to take the same decision.
+static void pw_rearm(nk_powers_plan *P) {
+  if (!P || !P->broken || P->peer || P->strikes >= 3) return;
+  P->h_err[0] = 0;
+  P->broken = false;
+}
+void nk_csr_powers_rearm(nk_csr *A) { if (A) pw_rearm(A->pw); }
+void nk_problem_powers_rearm(nk_problem *P) { if (P) pw_rearm(P->pw); }
 int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, int s, const double *d_scal_first,
                       const double *d_scal_rest, const double *d_theta, const int *d_skip) {
   NK_REQUIRE(nk_csr_powers_ready(A), "internal: matrix powers on a matrix without a plan");
@@ -784,6 +812,7 @@ bool nk_problem_powers_ready(nk_problem *P) {
 int nk_problem_powers_check(nk_problem *P) {
   if (!P->pw || P->pw->broken || P->pw->h_err[0] == 0) return NK_OK;
   P->pw->broken = true;
+  P->pw->strikes++;
   NK_FAIL(NK_E_HIP, "resident matrix-powers kernel (matrix-free): a workgroup waited longer than NK_PW_TIMEOUT_MS for its "
                     "neighbour band (NK_SPMV_POWERS=0 keeps the per-column JVP)");
 }
@@ -825,22 +854,31 @@ extern "C" int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy,
   hs[0] = scale;
   if (theta) for (int p = 0; p < s; ++p) hs[1 + p] = theta[p];
   hipMemcpy(dsc, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice);
+  nk_csr_powers_rearm(A);
   const bool res = nk_csr_powers_ready(A);
+  bool res_used = res;
   int rc = NK_OK;
-  if (res) {
-    rc = nk_csr_powers_dev(A, dx, dY, ldy, s, dsc, dsc, theta ? dsc + 1 : nullptr, nullptr);
-  } else {
-    for (int p = 0; p < s && rc == NK_OK; ++p) {
+  auto streaming = [&]() -> int {
+    int r = NK_OK;
+    for (int p = 0; p < s && r == NK_OK; ++p) {
       nk_spmv_epi ep;
       if (theta) { ep.mode = 3; ep.theta = dsc + 1 + p; }
-      rc = nk_csr_spmv_dev(A, p == 0 ? dx : dY + (size_t)(p - 1) * ldy, dY + (size_t)p * ldy, nullptr, dsc, &ep);
+      r = nk_csr_spmv_dev(A, p == 0 ? dx : dY + (size_t)(p - 1) * ldy, dY + (size_t)p * ldy, nullptr, dsc, &ep);
     }
-  }
+    return r;
+  };
+  rc = res ? nk_csr_powers_dev(A, dx, dY, ldy, s, dsc, dsc, theta ? dsc + 1 : nullptr, nullptr) : streaming();
   if (rc == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { nk_set_error("stream error in nk_csr_powers"); rc = NK_E_HIP; }
-  if (rc == NK_OK) rc = nk_csr_powers_check(A);
+  if (rc == NK_OK && res && nk_csr_powers_check(A) != NK_OK) {
+    // the resident launch timed out (its workgroups were not on the chip together): the columns are garbage — the s streaming
+    // launches produce the same bits (one rank; on several ranks the others are in the same launch and time out as well)
+    res_used = false;
+    rc = streaming();
+    if (rc == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { nk_set_error("stream error in nk_csr_powers"); rc = NK_E_HIP; }
+  }
   if (rc == NK_OK && memspace != NK_DEVICE)
     if (hipMemcpy(Y, dY, (size_t)ldy * s * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = NK_E_HIP;
   cleanup();
-  if (resident) *resident = res ? 1 : 0;
+  if (resident) *resident = res_used ? 1 : 0;
   return rc;
 }

@@ -278,9 +278,10 @@ def test_matrix_free_operator_takes_the_resident_kernel_too(nls, dev):
 def test_a_timed_out_launch_is_noticed_and_the_solve_rerun_on_the_streaming_kernel(nls, dev):
     """The resident kernel needs every workgroup on the chip at once; if one never shows up (something else holds its compute
     unit) its neighbours give up after NK_PW_TIMEOUT_MS instead of hanging the GPU, the columns of that launch are garbage — and the
-    library notices: the plan is switched off, the linear solve (x0 = 0: every Newton step's) is run again on the streaming kernel,
-    the caller sees the same iterates as with NK_SPMV_POWERS=0. Provoked by the development hook that makes band 0 of one
-    launch withhold its flag."""
+    library notices: the plan is parked, the linear solve is run again on the streaming kernel, the caller sees the same iterates as
+    with NK_SPMV_POWERS=0. The plan comes back with the next linear solve (what held the compute units is usually gone by then);
+    three torn launches switch it off for the life of the matrix. Provoked by the development hook that makes band 0 of chosen
+    launches withhold its flag."""
     import os
     import subprocess
     import sys
@@ -289,18 +290,46 @@ def test_a_timed_out_launch_is_noticed_and_the_solve_rerun_on_the_streaming_kern
         "prob = nls.NonlinearProblem(nls.Bratu2D(128, 6.0))\n"
         "alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho='sstep', fixed_iters=30), concrete_jac=True)\n"
         "cache = nls.init(prob, alg, abstol=1e-300, maxiters=50)\n"
-        "for _ in range(4): cache.step()\n"
+        "for _ in range(8): cache.step()\n"
         "u = cache.u\n"
         "u = np.asarray(u.cpu() if hasattr(u, 'cpu') else u)\n"
         "ctx = nls.default_context(); ctx.profile_enable(True); cache.step(); fam = sorted(ctx.profile_report())\n"
         "print('FAMILIES', fam)\n"
         "print('HASH', hashlib.sha256(u.tobytes()).hexdigest())\n")
     outs = {}
-    for name, env in (("stalled", dict(NK_PW_DEBUG_STALL_LAUNCH="5", NK_PW_TIMEOUT_MS="20")), ("streaming", dict(NK_SPMV_POWERS="0"))):
+    # one torn launch (the 5th: the third step's first block): parked, rerun, back for the fourth step;
+    # three of them (launches 5, 8, 11 — each in a later solve): the ninth step still runs the streaming kernel
+    for name, env in (("stalled", dict(NK_PW_DEBUG_STALL_LAUNCH="5", NK_PW_TIMEOUT_MS="20")),
+                      ("stalled3", dict(NK_PW_DEBUG_STALL_LAUNCH="5,8,11", NK_PW_TIMEOUT_MS="20")),
+                      ("streaming", dict(NK_SPMV_POWERS="0"))):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][-1]
         fam = [l for l in r.stdout.splitlines() if l.startswith("FAMILIES")][-1]
-        assert "'spmv'" in fam and "spmv_powers" not in fam, (name, fam)    # after the time-out the object keeps the streaming kernel
-    assert outs["stalled"] == outs["streaming"], outs
+        assert ("spmv_powers" in fam) == (name == "stalled"), (name, fam)
+    assert outs["stalled"] == outs["streaming"] == outs["stalled3"], outs
+
+
+def test_a_torn_launch_of_the_public_entry_point_falls_back_to_streaming_launches():
+    """nk_csr_powers itself: the launch that times out is answered with the s streaming launches — same bits, resident = False —
+    instead of an error; the next call is resident again."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, scipy.sparse as sp, torch, nonlinearsolve_jl_amd as nls\n"
+        "from oracle import reference_restatement as R\n"
+        "from tests.test_gpu_powers import _powers_ref\n"
+        "p = R.Bratu2D(64); rng = np.random.default_rng(1); J = p.jac(rng.standard_normal(p.n) * 0.1)\n"
+        "A = nls.CSRMatrix.from_scipy(J); x = rng.standard_normal(p.n); ref = _powers_ref(J, x, 7, None, 0.01)\n"
+        "flags = []\n"
+        "for rep in range(3):\n"
+        "    Y, res = A.powers(torch.tensor(x, device='cuda'), 7, theta=None, scale=0.01)\n"
+        "    assert np.array_equal(Y.cpu().numpy(), ref), rep\n"
+        "    flags.append(bool(res))\n"
+        "print('FLAGS', flags)\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NK_PW_DEBUG_STALL_LAUNCH="2", NK_PW_TIMEOUT_MS="20"),
+                       capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FLAGS [True, False, True]" in r.stdout, r.stdout
