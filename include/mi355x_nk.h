@@ -491,10 +491,17 @@ int nk_gmres_set_preconditioner(nk_gmres *G, int side, nk_precond *P);
  *   inside one persistent workgroup — milliseconds per application at n = 1024²), NK_ILU_MULTICOLOR permutes the rows by a
  *   greedy colouring of the pattern (as many levels as colours, one wide launch each: the GPU form).
  * nk_precond_update refactorises for the matrix's current values; NK_E_SINGULAR on a zero pivot. x, y: local length n. */
-typedef enum { NK_PRECOND_JACOBI = 1, NK_PRECOND_ILU0 = 2, NK_PRECOND_AMG = 3 } nk_precond_kind;
+typedef enum { NK_PRECOND_JACOBI = 1, NK_PRECOND_ILU0 = 2, NK_PRECOND_AMG = 3, NK_PRECOND_ILUT = 4 } nk_precond_kind;
 typedef enum { NK_ILU_NATURAL = 0, NK_ILU_MULTICOLOR = 1 } nk_ilu_ordering;
 int nk_precond_create_jacobi(nk_csr *A, nk_precond **out);
 int nk_precond_create_ilu0(nk_csr *A, int ordering, nk_precond **out);
+/* ILU with a drop tolerance — the tutorial's `incompletelu(W, p) = (ilu(W, τ = 50.0), I)` (docs/src/tutorials/large_systems.md:252-260;
+ * IncompleteLU.jl [EXT]): Crout ILU (Li, Saad, Chow 2003), A ≈ (I + L) U with fill; an off-diagonal entry of U's row k / L's column
+ * k is kept if its magnitude BEFORE the division by the pivot is ≥ tau (absolute; tau = 0: the complete LU without pivoting). The
+ * factorisation runs on the HOST for every nk_precond_update (its pattern depends on the numbers — the reference's runs on the
+ * CPU as well), of the rank's local block; the triangular solves of every application run on the device, level-scheduled from the
+ * factors' pattern. nk_precond_ilu0_factors returns its factors as well. NK_E_SINGULAR on a zero pivot. */
+int nk_precond_create_ilut(nk_csr *A, double tau, nk_precond **out);
 /* Aggregation algebraic multigrid built from the matrix alone (csrc/nk_amg.hip) — the tutorial's
  * `precs = (A, p) -> (aspreconditioner(ruge_stuben(A)), I)` slot (docs/src/tutorials/large_systems.md:276-316): pairwise
  * aggregation (`passes` times per level: aggregates of ≤ 2^passes rows; strength threshold `theta`) fixed at creation from the

@@ -10,7 +10,7 @@ from .core import (  # noqa: F401
     CSRMatrix, DeviceProblem, Quadratic, Bratu2D, Brusselator2D,
     NonlinearFunction, NonlinearProblem,
     KrylovJL_GMRES, ChebyshevPrecs, MultigridPrecs, ObjectPrecs, LinearSolveParameters, Preconditioner, JacobiPreconditioner,
-    ILU0Preconditioner, AMGPreconditioner, IDENTITY, EisenstatWalkerForcing2, RadiusUpdateSchemes, BackTracking, LineSearchesJL, NewtonRaphson, TrustRegion, GaussNewton, LevenbergMarquardt, PseudoTransient,
+    ILU0Preconditioner, ILUTPreconditioner, AMGPreconditioner, IDENTITY, EisenstatWalkerForcing2, RadiusUpdateSchemes, BackTracking, LineSearchesJL, NewtonRaphson, TrustRegion, GaussNewton, LevenbergMarquardt, PseudoTransient,
     NonlinearLeastSquaresProblem,
     AbsNormSafeBestTerminationMode, NormTerminationMode, RelTerminationMode, RelNormTerminationMode,
     RelNormSafeTerminationMode, RelNormSafeBestTerminationMode, AbsTerminationMode, AbsNormTerminationMode,

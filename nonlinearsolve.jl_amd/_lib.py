@@ -178,6 +178,7 @@ SIGNATURES = {
     "nk_gmres_set_preconditioner": (_I, [_P, _I, _P]),
     "nk_precond_create_jacobi": (_I, [_P, _PP]),
     "nk_precond_create_ilu0": (_I, [_P, _I, _PP]),
+    "nk_precond_create_ilut": (_I, [_P, _D, _PP]),
     "nk_amg_params_default": (_I, [_P]),
     "nk_precond_create_amg": (_I, [_P, _P, _PP]),
     "nk_precond_amg_info": (_I, [_P, C.POINTER(_I), _I, _P, _P, _P]),

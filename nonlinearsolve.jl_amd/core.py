@@ -628,7 +628,7 @@ class Preconditioner:
     def info(self):
         k, ll, lu, nc = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(L.lib().nk_precond_info(self._h, C.byref(k), C.byref(ll), C.byref(lu), C.byref(nc)))
-        return dict(kind={1: "jacobi", 2: "ilu0", 3: "amg"}[k.value], levels_lower=ll.value, levels_upper=lu.value, ncolors=nc.value)
+        return dict(kind={1: "jacobi", 2: "ilu0", 3: "amg", 4: "ilut"}[k.value], levels_lower=ll.value, levels_upper=lu.value, ncolors=nc.value)
 
     def close(self):
         if self._h:
@@ -675,6 +675,19 @@ class ILU0Preconditioner(Preconditioner):
                                               C.c_void_p(v.ctypes.data), C.c_void_p(perm.ctypes.data)))
         M = sp.csr_matrix((v, ci, rp), shape=(n, n))
         return sp.tril(M, -1).tocsr() + sp.identity(n, format="csr"), sp.triu(M, 0).tocsr(), perm
+
+
+class ILUTPreconditioner(ILU0Preconditioner):
+    """Crout ILU with the drop tolerance `tau` — the tutorial's `incompletelu(W, p) = (ilu(W, τ = 50.0), I)`
+    (docs/src/tutorials/large_systems.md:252-260): A ≈ (I + L) U with fill, an entry kept if its magnitude before the division by
+    the pivot is ≥ tau. Factorised on the host for every `update()` (the pattern depends on the numbers; the reference's
+    IncompleteLU.jl runs on the CPU as well), applied on the device by two level-scheduled triangular solves."""
+
+    def __init__(self, A: "CSRMatrix", tau: float):
+        h = C.c_void_p()
+        check(L.lib().nk_precond_create_ilut(A._h, float(tau), C.byref(h)))
+        Preconditioner.__init__(self, h, A)
+        self.ordering, self.tau = "natural", float(tau)
 
 
 class AMGPreconditioner(Preconditioner):

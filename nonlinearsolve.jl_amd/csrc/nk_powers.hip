@@ -521,9 +521,18 @@ static int pw_launch(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
     return NK_OK;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  // NK_PW_COOP=1: a cooperative launch — the runtime refuses a grid that cannot be resident on an EMPTY device and keeps cooperative
+  // launches of different streams apart; it does not keep ordinary kernels of other streams off the compute units (the time-out
+  // stays the safety net). Measured: profiles/r05_*_powers_coop_ab.txt.
+  static const bool coop = getenv("NK_PW_COOP") && atoi(getenv("NK_PW_COOP")) != 0;
   if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
     hipExtLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
-  else
+  else if (coop) {
+    pw_args ac = a;
+    void *args[] = {(void *)&ac};
+    NK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), args,
+                                      (unsigned int)lds, ctx->stream));
+  } else
     hipLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
   NK_HIP(hipGetLastError());
   return NK_OK;

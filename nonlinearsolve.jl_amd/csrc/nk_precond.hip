@@ -25,6 +25,7 @@
 #include "nk_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -50,6 +51,8 @@ struct nk_precond {
   double *d_y = nullptr, *d_z = nullptr, *d_xin = nullptr, *d_xout = nullptr;
   int *d_fail = nullptr;
   bool factored = false;
+  // ILU(τ): the drop tolerance; the factors' pattern is a function of the values, so every update re-plans (ilut_update)
+  double tau = 0.0;
   // algebraic multigrid (nk_amg.hip)
   struct nk_amg *amg = nullptr;
 };
@@ -325,6 +328,188 @@ static int ilu_symbolic(nk_precond *P) {
   return NK_OK;
 }
 
+// ----------------------------------------------------------------------------- ILU(τ): Crout ILU with a drop tolerance
+// The tutorial's OTHER precs, `incompletelu(W, p) = (ilu(W, τ = 50.0), I)` (docs/src/tutorials/large_systems.md:252-260;
+// IncompleteLU.jl [EXT: not in the tree] implements Li, Saad, Chow, "Crout versions of ILU for general sparse matrices", SIAM J.
+// Sci. Comput. 25 (2003)): A ≈ (I + L) U with fill, by the Crout order — step k forms row k of U and column k of L from the
+// rows / columns finished before it —
+//     z = A[k, k:] − Σ_{i<k, l_ki ≠ 0} l_ki · U[i, k:]          u_kk = z_k ;  u_kj = z_j kept if |z_j| ≥ τ  (j > k)
+//     w = A[k+1:, k] − Σ_{i<k, u_ik ≠ 0} u_ik · L[k+1:, i]       l_ik = w_i / u_kk kept if |w_i| ≥ τ          (i > k)
+// (the drop test compares the entry BEFORE the division by the pivot, absolutely — IncompleteLU.jl's rule as far as it can be told
+// without its source; oracle/reference_restatement.py::ilut restates exactly this). τ = 0 is the complete LU without pivoting.
+// The factorisation is sequential and its pattern depends on the numbers: it runs on the HOST for every new Jacobian — as the
+// reference's does — on the rank's local block (halo columns dropped: block-Jacobi across ranks); the two triangular solves of
+// every application run on the device, level-scheduled from the factors' actual pattern with the kernels of ILU(0).
+static int ilut_update(nk_precond *P) {
+  nk_csr *A = P->A;
+  nk_ctx *ctx = P->ctx;
+  const int64_t n = A->nrows;
+  NK_REQUIRE((int64_t)A->h_rowptr.size() == n + 1, "ILU(τ): the matrix keeps no host copy of its pattern");
+  const std::vector<int32_t> &rp0 = A->h_rowptr, &ci0 = A->h_col;
+  std::vector<double> av((size_t)A->nnz);
+  NK_HIP(hipMemcpyAsync(av.data(), A->d_val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  const double tau = P->tau;
+  // the local block by columns (for the L columns): CSC with ascending rows
+  std::vector<int32_t> cp(n + 1, 0), cr;
+  std::vector<double> cv;
+  {
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t p = rp0[i]; p < rp0[i + 1]; ++p)
+        if (ci0[p] < n) cp[ci0[p] + 1]++;
+    for (int64_t j = 0; j < n; ++j) cp[j + 1] += cp[j];
+    cr.resize(cp[n]);
+    cv.resize(cp[n]);
+    std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t p = rp0[i]; p < rp0[i + 1]; ++p)
+        if (ci0[p] < n) { const int32_t q = fill[ci0[p]]++; cr[q] = (int32_t)i; cv[q] = av[p]; }
+  }
+  // U by rows (diagonal first, then ascending columns), L by columns (ascending rows); and, for the Crout sums, for every row k the
+  // finished L entries in it (column i, value) and for every column k the finished U entries in it (row i, value)
+  struct ent { int32_t idx; double v; };
+  std::vector<std::vector<ent>> Urow(n), Lcol(n), Lrow(n), Ucol(n);
+  std::vector<double> diag(n, 0.0);
+  std::vector<double> wz(n, 0.0);
+  std::vector<char> mark(n, 0);
+  std::vector<int32_t> idx;
+  // where the entries ≥ k of U's row i / L's column i begin (k only grows: the cursors only advance)
+  std::vector<int32_t> ufirst(n, 0), lfirst(n, 0);
+  for (int64_t k = 0; k < n; ++k) {
+    // ---- row k of U
+    idx.clear();
+    bool has_diag = false;
+    for (int32_t p = rp0[k]; p < rp0[k + 1]; ++p) {
+      const int32_t j = ci0[p];
+      if (j < k || j >= n) continue;
+      if (!mark[j]) { mark[j] = 1; idx.push_back(j); wz[j] = 0.0; }
+      wz[j] += av[p];
+      if (j == k) has_diag = true;
+    }
+    NK_REQUIRE(has_diag, "ILU(τ): row %lld has no stored diagonal entry", (long long)k);
+    for (const ent &l : Lrow[k]) {             // ascending i (the columns were finished in that order)
+      const int32_t i = l.idx;
+      const std::vector<ent> &ur = Urow[i];
+      int32_t &f = ufirst[i];
+      while (f < (int32_t)ur.size() && ur[f].idx < k) ++f;
+      for (int32_t q = f; q < (int32_t)ur.size(); ++q) {
+        const int32_t j = ur[q].idx;
+        if (!mark[j]) { mark[j] = 1; idx.push_back(j); wz[j] = 0.0; }
+        wz[j] -= l.v * ur[q].v;
+      }
+    }
+    const double piv = wz[k];
+    if (piv == 0.0 || !std::isfinite(piv)) {
+      for (int32_t j : idx) mark[j] = 0;
+      P->factored = false;
+      NK_FAIL(NK_E_SINGULAR, "ILU(τ): zero or non-finite pivot in row %lld (no pivoting)", (long long)k);
+    }
+    diag[k] = piv;
+    std::sort(idx.begin(), idx.end());
+    for (int32_t j : idx) {
+      mark[j] = 0;
+      if (j > k && std::fabs(wz[j]) >= tau && wz[j] != 0.0) {
+        Urow[k].push_back({j, wz[j]});
+        Ucol[j].push_back({(int32_t)k, wz[j]});
+      }
+    }
+    // ---- column k of L
+    idx.clear();
+    for (int32_t p = cp[k]; p < cp[k + 1]; ++p) {
+      const int32_t r = cr[p];
+      if (r <= k) continue;
+      if (!mark[r]) { mark[r] = 1; idx.push_back(r); wz[r] = 0.0; }
+      wz[r] += cv[p];
+    }
+    for (const ent &u : Ucol[k]) {             // ascending i
+      const int32_t i = u.idx;
+      const std::vector<ent> &lc = Lcol[i];
+      int32_t &f = lfirst[i];
+      while (f < (int32_t)lc.size() && lc[f].idx <= k) ++f;
+      for (int32_t q = f; q < (int32_t)lc.size(); ++q) {
+        const int32_t r = lc[q].idx;
+        if (!mark[r]) { mark[r] = 1; idx.push_back(r); wz[r] = 0.0; }
+        wz[r] -= u.v * lc[q].v;
+      }
+    }
+    std::sort(idx.begin(), idx.end());
+    for (int32_t r : idx) {
+      mark[r] = 0;
+      if (std::fabs(wz[r]) >= tau && wz[r] != 0.0) {
+        const double l = wz[r] / piv;
+        Lcol[k].push_back({r, l});
+        Lrow[r].push_back({(int32_t)k, l});
+      }
+    }
+  }
+  // ---- the factors as ONE row-major matrix [L strictly lower | diagonal | U strictly upper], columns ascending: what the
+  // level-scheduled kernels of ILU(0) walk
+  std::vector<int32_t> rp(n + 1, 0), ci, dg(n, 0);
+  std::vector<double> lu;
+  for (int64_t i = 0; i < n; ++i) {
+    for (const ent &l : Lrow[i]) { ci.push_back(l.idx); lu.push_back(l.v); }
+    dg[i] = (int32_t)ci.size();
+    ci.push_back((int32_t)i);
+    lu.push_back(diag[i]);
+    for (const ent &u : Urow[i]) { ci.push_back(u.idx); lu.push_back(u.v); }
+    rp[i + 1] = (int32_t)ci.size();
+  }
+  P->nnzp = (int64_t)ci.size();
+  auto levels = [&](bool lower, std::vector<int32_t> &rows, std::vector<int32_t> &ptr) {
+    std::vector<int32_t> lev(n, 0);
+    int32_t nlev = 0;
+    if (lower) {
+      for (int64_t i = 0; i < n; ++i) {
+        int32_t l = 0;
+        for (int32_t p = rp[i]; p < dg[i]; ++p) l = std::max(l, lev[ci[p]] + 1);
+        lev[i] = l;
+        nlev = std::max(nlev, l + 1);
+      }
+    } else {
+      for (int64_t i = n - 1; i >= 0; --i) {
+        int32_t l = 0;
+        for (int32_t p = dg[i] + 1; p < rp[i + 1]; ++p) l = std::max(l, lev[ci[p]] + 1);
+        lev[i] = l;
+        nlev = std::max(nlev, l + 1);
+      }
+    }
+    ptr.assign(nlev + 1, 0);
+    for (int64_t i = 0; i < n; ++i) ptr[lev[i] + 1]++;
+    for (int32_t l = 0; l < nlev; ++l) ptr[l + 1] += ptr[l];
+    rows.resize(n);
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) rows[fill[lev[i]]++] = (int32_t)i;
+  };
+  std::vector<int32_t> rowsL, rowsU;
+  levels(true, rowsL, P->h_ptrL);
+  levels(false, rowsU, P->h_ptrU);
+  auto chain_pays = [&](const std::vector<int32_t> &ptr) {
+    const int nlev = (int)ptr.size() - 1;
+    double chain_us = 0.0;
+    for (int l = 0; l < nlev; ++l) chain_us += 1.0 * ((ptr[l + 1] - ptr[l] + ILU_CHAIN_THREADS - 1) / ILU_CHAIN_THREADS);
+    return nlev > 16 && chain_us < 5.0 * nlev;
+  };
+  P->chainL = chain_pays(P->h_ptrL);
+  P->chainU = chain_pays(P->h_ptrU);
+  // (the pattern changes with the values: the device copies are replaced)
+  hipFree(P->d_rp); hipFree(P->d_ci); hipFree(P->d_dg); hipFree(P->d_lu);
+  hipFree(P->d_rowsL); hipFree(P->d_ptrL); hipFree(P->d_rowsU); hipFree(P->d_ptrU);
+  P->d_rp = P->d_ci = P->d_dg = P->d_rowsL = P->d_ptrL = P->d_rowsU = P->d_ptrU = nullptr;
+  P->d_lu = nullptr;
+  NK_TRY(upload(&P->d_rp, rp));
+  NK_TRY(upload(&P->d_ci, ci));
+  NK_TRY(upload(&P->d_dg, dg));
+  NK_TRY(upload(&P->d_rowsL, rowsL));
+  NK_TRY(upload(&P->d_ptrL, P->h_ptrL));
+  NK_TRY(upload(&P->d_rowsU, rowsU));
+  NK_TRY(upload(&P->d_ptrU, P->h_ptrU));
+  NK_TRY(upload(&P->d_lu, lu));
+  if (!P->d_y) NK_TRY(nk_dev_alloc(&P->d_y, (size_t)n + 1));
+  if (!P->d_z) NK_TRY(nk_dev_alloc(&P->d_z, (size_t)n + 1));
+  P->factored = true;
+  return NK_OK;
+}
+
 static ilu_dev ilu_view(const nk_precond *P) {
   ilu_dev d;
   d.rp = P->d_rp; d.ci = P->d_ci; d.dg = P->d_dg; d.perm = P->d_perm;
@@ -363,6 +548,16 @@ extern "C" int nk_precond_create_ilu0(nk_csr *A, int ordering, nk_precond **out)
   auto guard = nk_make_guard(P, [](nk_precond *p) { nk_precond_destroy(p); });
   P->ordering = ordering;
   NK_TRY(ilu_symbolic(P));
+  NK_TRY(nk_precond_update(P));
+  *out = guard.release();
+  return NK_OK;
+}
+extern "C" int nk_precond_create_ilut(nk_csr *A, double tau, nk_precond **out) {
+  NK_REQUIRE(tau >= 0.0 && std::isfinite(tau), "ILU(τ): the drop tolerance must be finite and ≥ 0");
+  nk_precond *P = nullptr;
+  NK_TRY(precond_new(A, NK_PRECOND_ILUT, out, &P));
+  auto guard = nk_make_guard(P, [](nk_precond *p) { nk_precond_destroy(p); });
+  P->tau = tau;
   NK_TRY(nk_precond_update(P));
   *out = guard.release();
   return NK_OK;
@@ -416,6 +611,10 @@ extern "C" int nk_precond_update(nk_precond *P) {
     NK_TRY(nk_amg_update(P->amg));
     P->factored = true;
     return NK_OK;
+  }
+  if (P->kind == NK_PRECOND_ILUT) {
+    P->factored = false;
+    return ilut_update(P);
   }
   NK_HIP(hipMemsetAsync(P->d_fail, 0, sizeof(int), ctx->stream));
   if (n > 0) {
@@ -522,15 +721,16 @@ extern "C" int nk_precond_apply(nk_precond *P, const double *x, double *y, int m
 extern "C" int nk_precond_info(nk_precond *P, int *kind, int *levels_lower, int *levels_upper, int *ncolors) {
   NK_REQUIRE(P, "NULL argument");
   if (kind) *kind = P->kind;
-  if (levels_lower) *levels_lower = P->kind == NK_PRECOND_ILU0 ? (int)P->h_ptrL.size() - 1 : (P->kind == NK_PRECOND_AMG ? nk_amg_levels(P->amg) : 0);
-  if (levels_upper) *levels_upper = P->kind == NK_PRECOND_ILU0 ? (int)P->h_ptrU.size() - 1 : 0;
+  const bool ilu = P->kind == NK_PRECOND_ILU0 || P->kind == NK_PRECOND_ILUT;
+  if (levels_lower) *levels_lower = ilu ? (int)P->h_ptrL.size() - 1 : (P->kind == NK_PRECOND_AMG ? nk_amg_levels(P->amg) : 0);
+  if (levels_upper) *levels_upper = ilu ? (int)P->h_ptrU.size() - 1 : 0;
   if (ncolors) *ncolors = P->ncolors;
   return NK_OK;
 }
 // the factors in the permuted ordering, for parity tests: CSR of the local block (rowptr n+1, cols and values nnz — L strictly
 // below the diagonal with its unit diagonal implied, U on and above) and the permutation (permuted row → original row)
 extern "C" int nk_precond_ilu0_factors(nk_precond *P, int64_t *nnz, int32_t *rowptr, int32_t *col, double *val, int32_t *perm) {
-  NK_REQUIRE(P && P->kind == NK_PRECOND_ILU0, "not an ILU(0) preconditioner");
+  NK_REQUIRE(P && (P->kind == NK_PRECOND_ILU0 || P->kind == NK_PRECOND_ILUT), "not an incomplete-LU preconditioner");
   NK_HIP(hipSetDevice(P->ctx->device));
   NK_HIP(hipStreamSynchronize(P->ctx->stream));
   if (nnz) *nnz = P->nnzp;

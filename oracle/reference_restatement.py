@@ -644,6 +644,82 @@ def ilu0_preconditioner(A, ordering="multicolor"):
     return apply
 
 
+def ilut(A, tau):
+    """Crout ILU with a drop tolerance — the tutorial's `ilu(W, τ = 50.0)` (docs/src/tutorials/large_systems.md:252-260;
+    IncompleteLU.jl [EXT — not in /root/reference; restated from Li, Saad, Chow, "Crout versions of ILU for general sparse
+    matrices", SIAM J. Sci. Comput. 25 (2003), with IncompleteLU.jl's absolute drop rule as far as it can be told without its
+    source: parity unpinned]). A ≈ (I + L) U; step k forms
+        z = A[k, k:] − Σ_{i<k} l_ki U[i, k:]        u_kk = z_k,  u_kj = z_j kept if |z_j| ≥ τ (j > k)
+        w = A[k+1:, k] − Σ_{i<k} u_ik L[k+1:, i]     l_ik = w_i / u_kk kept if |w_i| ≥ τ (i > k)
+    — the test compares the entry BEFORE the division by the pivot. Sums run over ascending i (csrc/nk_precond.hip::ilut_update
+    does the same). Returns (L, U) as CSR, L with its unit diagonal. Defining properties that pin it independently of any
+    implementation: τ = 0 gives the complete LU (L U = A), and every kept entry equals the exact Crout recurrence on the kept
+    pattern."""
+    A = sp.csr_matrix(A, dtype=np.float64)
+    A.sum_duplicates()
+    A.sort_indices()
+    n = A.shape[0]
+    Ac = A.tocsc()
+    Ac.sort_indices()
+    Urow = [dict() for _ in range(n)]     # strictly upper entries of U's rows
+    Lcol = [dict() for _ in range(n)]     # strictly lower entries of L's columns
+    Lrow = [[] for _ in range(n)]         # (i, l_ki) of row k, ascending i
+    Ucol = [[] for _ in range(n)]         # (i, u_ik) of column k, ascending i
+    diag = np.zeros(n)
+    for k in range(n):
+        z = {}
+        for j, v in zip(A.indices[A.indptr[k]:A.indptr[k + 1]], A.data[A.indptr[k]:A.indptr[k + 1]]):
+            if j >= k:
+                z[j] = z.get(j, 0.0) + v
+        if k not in z:
+            raise ArithmeticError(f"ILU(τ): row {k} has no stored diagonal entry")
+        for i, lki in Lrow[k]:
+            for j, uij in Urow[i].items():
+                if j >= k:
+                    z[j] = z.get(j, 0.0) - lki * uij
+        piv = z[k]
+        if piv == 0.0 or not math.isfinite(piv):
+            raise ArithmeticError("ILU(τ): zero or non-finite pivot")
+        diag[k] = piv
+        for j in sorted(z):
+            if j > k and abs(z[j]) >= tau and z[j] != 0.0:
+                Urow[k][j] = z[j]
+                Ucol[j].append((k, z[j]))
+        w = {}
+        for r, v in zip(Ac.indices[Ac.indptr[k]:Ac.indptr[k + 1]], Ac.data[Ac.indptr[k]:Ac.indptr[k + 1]]):
+            if r > k:
+                w[r] = w.get(r, 0.0) + v
+        for i, uik in Ucol[k]:
+            for r, lri in Lcol[i].items():
+                if r > k:
+                    w[r] = w.get(r, 0.0) - uik * lri
+        for r in sorted(w):
+            if abs(w[r]) >= tau and w[r] != 0.0:
+                l = w[r] / piv
+                Lcol[k][r] = l
+                Lrow[r].append((k, l))
+    rows, cols, vals = [], [], []
+    for k in range(n):
+        for r, l in Lcol[k].items():
+            rows.append(r); cols.append(k); vals.append(l)
+    Lm = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)) + sp.identity(n, format="csr")
+    rows, cols, vals = list(range(n)), list(range(n)), list(diag)
+    for k in range(n):
+        for j, u in Urow[k].items():
+            rows.append(k); cols.append(j); vals.append(u)
+    Um = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    return Lm.tocsr(), Um.tocsr()
+
+
+def ilut_preconditioner(A, tau):
+    """x ↦ U⁻¹ (I + L)⁻¹ x with the Crout ILU(τ) factors of A — what nls.ILUTPreconditioner applies on the device."""
+    import scipy.sparse.linalg as spla
+    Lf, Uf = ilut(A, tau)
+    Lc, Uc = sp.csr_matrix(Lf), sp.csr_matrix(Uf)
+    return lambda x: spla.spsolve_triangular(Uc, spla.spsolve_triangular(Lc, np.asarray(x, dtype=np.float64), lower=True,
+                                                                          unit_diagonal=True), lower=False)
+
+
 def jacobi_preconditioner(A):
     d = sp.csr_matrix(A).diagonal()
     return lambda x: np.asarray(x, dtype=np.float64) / d

@@ -265,3 +265,82 @@ def test_csc_value_refresh_matches_a_fresh_ingest(nls, dev):
         J.set_values_csc(A2.data[:-1])
     with pytest.raises(nls.NKError, match="CSC"):
         nls.CSRMatrix.from_scipy(A1.tocsr()).set_values_csc(A2.data)
+
+
+# ----------------------------------------------------------------------------- ILU with a drop tolerance (the tutorial's other precs)
+@pytest.mark.parametrize("case", ["random", "brusselator"])
+def test_ilut_factors_and_apply_match_the_oracle(nls, dev, case):
+    """nk_precond_create_ilut: Crout ILU(τ) of the host (as IncompleteLU.jl's runs on the CPU) against the NumPy restatement — the
+    same pattern, the factors to 1e-12, the device's level-scheduled triangular solves against SciPy's; τ = 0 is the complete LU;
+    `update()` re-plans for new values (the pattern is a function of the numbers)."""
+    import torch
+    rng = np.random.default_rng(3)
+    if case == "random":
+        n = 400
+        A = (sp.random(n, n, density=0.02, random_state=5, format="csr") + sp.diags(3.0 + rng.random(n))).tocsr()
+        tau = 0.05
+    else:
+        pb = R.Brusselator2D(16)
+        A = pb.jac(pb.u0() + 0.05 * rng.standard_normal(pb.n)).tocsr()
+        tau = 50.0
+    A.sort_indices()
+    M = nls.CSRMatrix.from_scipy(A)
+    P = nls.ILUTPreconditioner(M, tau)
+    Lo, Uo = R.ilut(A, tau)
+    Ld, Ud, perm = P.factors()
+    assert np.array_equal(perm, np.arange(A.shape[0]))
+    for Fd, Fo in ((Ld, Lo), (Ud, Uo)):
+        Fd.sort_indices(); Fo.sort_indices()
+        assert np.array_equal(Fd.indptr, Fo.indptr) and np.array_equal(Fd.indices, Fo.indices)
+        assert np.max(np.abs(Fd.data - Fo.data)) <= 1e-12 * np.max(np.abs(Fo.data))
+    assert Lo.nnz + Uo.nnz > A.nnz or case == "random"                  # fill is kept
+    x = rng.standard_normal(A.shape[0])
+    want = R.ilut_preconditioner(A, tau)(x)
+    got = P.apply(torch.tensor(x, device=dev)).cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want))
+    assert P.info()["kind"] == "ilut" and P.info()["levels_lower"] >= 1
+    # τ = 0: the complete LU (no pivoting) — M⁻¹ A x = x
+    P0 = nls.ILUTPreconditioner(M, 0.0)
+    L0, U0, _ = P0.factors()
+    assert abs(L0 @ U0 - A).max() <= 1e-11 * abs(A).max()
+    # new values, same object
+    A2 = A.copy(); A2.data = A.data * (1.0 + 0.1 * rng.standard_normal(A.nnz)) ; A2 = (A2 + sp.diags(np.full(A.shape[0], 0.5 * abs(A).max()))).tocsr()
+    A2.sort_indices()
+    if A2.nnz == A.nnz:
+        M.set_values(A2.data)
+        P.update()
+        want2 = R.ilut_preconditioner(A2, tau)(x)
+        got2 = P.apply(torch.tensor(x, device=dev)).cpu().numpy()
+        assert np.max(np.abs(got2 - want2)) <= 1e-11 * np.max(np.abs(want2))
+
+
+def test_newton_with_ilut_as_left_preconditioner_as_in_the_tutorial(nls, dev):
+    """docs/src/tutorials/large_systems.md:252-260: `incompletelu(W, p = nothing) = (ilu(W, τ = 50.0), LinearAlgebra.I)`,
+    NewtonRaphson(linsolve = KrylovJL_GMRES(precs = incompletelu), concrete_jac = true) on the Brusselator (N = 32) — the device
+    object returned from a Python `precs` against the oracle's solve with the restated factors: steps, root, Krylov iterations;
+    and the fill pays: far fewer iterations than ILU(0) in the same ordering."""
+    PB = nls.Brusselator2D(32)
+    state = {}
+
+    def incompletelu(W, p=None):
+        if "M" not in state:
+            state["M"] = nls.ILUTPreconditioner(W, 50.0)
+        else:
+            state["M"].update()
+        return state["M"], None
+
+    kw = dict(gmres_restart=30, maxiters=3000)
+    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=incompletelu, reltol=1e-8, abstol=0.0, **kw), concrete_jac=True)
+    sol = nls.solve(nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True)), alg, abstol=1e-8, maxiters=50)
+    oc = R.init(R.Brusselator2D(32), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(precs=lambda W, p: (R.ilut_preconditioner(W, 50.0), None),
+                                                                                ortho="cgs2", **kw), concrete_jac=True),
+                abstol=1e-8, maxiters=50)
+    oc.lin_reltol, oc.lin_abstol = 1e-8, 0.0
+    ref = oc.solve()
+    assert sol.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and sol.stats.nsteps == ref.stats.nsteps
+    assert abs(sol.stats.gmres_iters - ref.stats.gmres_iters) <= 0.1 * ref.stats.gmres_iters + 3 * sol.stats.nsteps
+    assert np.max(np.abs(np.asarray(sol.u.cpu()) - ref.u)) <= 1e-7 * np.max(np.abs(ref.u))
+    ilu0 = nls.solve(nls.NonlinearProblem(PB, u0=PB.initial_guess(device=True)),
+                     nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(precs=nls.ObjectPrecs("ilu0_natural", "left"), reltol=1e-8, abstol=0.0, **kw),
+                                       concrete_jac=True), abstol=1e-8, maxiters=50)
+    assert sol.stats.gmres_iters < 0.6 * ilu0.stats.gmres_iters, (sol.stats.gmres_iters, ilu0.stats.gmres_iters)

@@ -1029,3 +1029,30 @@ def test_eisenstat_walker_state_is_reset_by_reinit_misc_tests_item6():
     c.reinit(p=3.0)                                 # reinit!(cache; p = 3.0): u0 = the cache's current u
     assert c.ew_eta == ew.eta0                      # @test fc.η == fc.p.η₀
     assert np.allclose(c.solve().u, np.sqrt(3.0))   # @test solve!(cache).u ≈ [sqrt(3.0), sqrt(3.0)]
+
+
+def test_ilut_restatement_is_pinned_by_its_defining_properties():
+    """oracle.ilut (Crout ILU with a drop tolerance; IncompleteLU.jl is not in /root/reference): τ = 0 is the complete LU without
+    pivoting; for τ > 0 the product (I + L) U reproduces A on every KEPT position and on A's own pattern up to the dropped
+    fill's products (the ILU property: the error matrix lives on dropped positions); fill grows as τ falls."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    n = 120
+    A = (sp.random(n, n, density=0.04, random_state=2, format="csr") + sp.diags(4.0 + rng.random(n))).tocsr()
+    L0, U0 = R.ilut(A, 0.0)
+    assert abs(L0 @ U0 - A).max() <= 1e-12 * abs(A).max()
+    nnz = []
+    for tau in (0.3, 0.05, 0.005):
+        Lf, Uf = R.ilut(A, tau)
+        assert abs(sp.tril(Uf, -1)).sum() == 0 and abs(sp.triu(Lf, 1)).sum() == 0 and np.allclose(Lf.diagonal(), 1.0)
+        kept = ((Lf - sp.identity(n)) + Uf).tocsr()
+        E = (Lf @ Uf - A).tocsr()
+        # on kept positions the recurrence is exact: (L U)_ij = a_ij
+        Ek = E.multiply(kept != 0)
+        assert abs(Ek).max() <= 1e-12 * abs(A).max()
+        nnz.append(kept.nnz)
+    assert nnz[0] <= nnz[1] <= nnz[2] <= L0.nnz + U0.nnz - n
+    # the preconditioned operator approaches the identity as τ → 0
+    x = rng.standard_normal(n)
+    errs = [np.linalg.norm(R.ilut_preconditioner(A, tau)(A @ x) - x) for tau in (0.3, 0.05, 0.0)]
+    assert errs[2] <= 1e-10 and errs[1] <= errs[0]
