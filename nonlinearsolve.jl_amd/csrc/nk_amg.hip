@@ -454,6 +454,9 @@ static int amg_cheb_rest(nk_amg *M, amg_level &L, int nsteps, double **dcur, dou
 int nk_amg_apply_dev(nk_amg *M, const double *d_b, double *d_x, const int *d_skip) {
   nk_ctx *ctx = M->ctx;
   if (!M->ready) NK_FAIL(NK_E_SINGULAR, "AMG: the hierarchy has no valid numbers (its last update failed)");
+  // the smoothers' and residuals' SpMVs on the levels are the preconditioner's own work, not applications of the Jacobian
+  // operator: the statistics' counter is put back behind the cycle (so runs under different preconditioners stay comparable)
+  struct op_guard { nk_ctx *c; int64_t v; ~op_guard() { c->stats.op_applies = v; } } og{ctx, ctx->stats.op_applies};
   const int nlev = (int)M->lv.size();
   if (M->lv[0].n == 0) return NK_OK;
   M->lv[0].b = const_cast<double *>(d_b);

@@ -1604,6 +1604,9 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
   const int64_t n = G->n, ldv = G->ldv;
   const int m = G->m;
   NK_REQUIRE(G->op_kind != 0, "GMRES has no operator");
+  // the arena's time-out counter is cumulative per CONTEXT: a solver object created after a time-out (or used after another
+  // object's solve saw one) starts from what the context has already reported — not from zero
+  if (ctx->peer.on && ctx->peer_err_reported > G->peer_err_seen) G->peer_err_seen = ctx->peer_err_reported;
   {
     static const bool want_graph = getenv("NK_GMRES_GRAPH") && atoi(getenv("NK_GMRES_GRAPH")) != 0;
     if (want_graph && fixed_iters > 0 && fixed_iters <= m && !use_x0 && nk_ctx_is_single(ctx) && !ctx->prof.on &&
@@ -1768,6 +1771,7 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
       // the next one starts from the value seen here, so one transient stall does not condemn the context for good
       const int fresh = (int)pub->pad - G->peer_err_seen;
       G->peer_err_seen = (int)pub->pad;
+      ctx->peer_err_reported = G->peer_err_seen;
       NK_FAIL(NK_E_COMM, "%d peer-mapped collective(s) timed out (a rank stalled beyond NK_PEER_TIMEOUT_MS or died): the "
                          "reductions / halos of this solve are not valid", fresh);
     }

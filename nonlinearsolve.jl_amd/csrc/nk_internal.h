@@ -146,6 +146,7 @@ struct nk_ctx {
   double *d_partials = nullptr;  // NK_MAX_NV * NK_MAX_RED_BLOCKS doubles
   double *d_partials_ss = nullptr;  // ‖·‖² partials of the axpy kernels (own buffer: survives later multidots)
   int last_red_grid = 0;
+  int peer_err_reported = 0;     // peer-arena time-outs already surfaced as NK_E_COMM by some solver object of this context
   double *d_scal = nullptr;      // 4*NK_MAX_NV doubles of device scalars
   double *h_pinned = nullptr;    // 4*NK_MAX_NV doubles pinned host (coherent: kernels publish scalars into it)
   double *h_pinned_dev = nullptr;  // the same allocation as the device sees it

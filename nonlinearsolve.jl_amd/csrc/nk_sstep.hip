@@ -78,7 +78,7 @@ struct ss_tail_args {
   int uk0, usb;
   const double *uC2, *uR2;
   double *Wi, *D;      // this block's R₂⁻¹ and C₂R₂⁻¹, written next to its Hessenberg columns when it is left at its first pass
-  double ptol;         // rank-loss bar of the factorisation: a pivot ≤ ptol·(XᵀX)_aa is a breakdown (1e-12; 1e-8 with the implicit second pass)
+  double ptol;         // rank-loss bar of the factorisation: a pivot ≤ ptol·(XᵀX)_aa is a breakdown (1e-12 on every path)
 };
 // LDS arrays of the scalar work, carved from one dynamic block
 struct ss_ws {
@@ -137,7 +137,7 @@ __device__ inline ss_ws ss_ws_carve(double *b, int k, int s, bool hess, int o0 =
 // From the reduced block [V_kᵀX ; XᵀX] (X = the s columns behind V_k; `sc` un-normalised-column scales): the true
 // coefficients Ct = diag(sc)·V_kᵀX, the Cholesky factor R of XᵀX − CtᵀCt (Pythagorean form of ‖X − V Ct‖), R⁻¹, and the
 // coefficients U = diag(sc)·Ct the update takes off the stored columns. Returns false when the block lost rank numerically:
-// a pivot that is not positive RELATIVE to the column's own squared norm — d ≤ ptol·(XᵀX)_aa, ptol = 1e-12 (1e-8 with the implicit second pass): the column lies in the span of
+// a pivot that is not positive RELATIVE to the column's own squared norm — d ≤ ptol·(XᵀX)_aa, ptol = 1e-12: the column lies in the span of
 // the others to 1e-6, the block's condition number is beyond 1e6, and the Hessenberg columns recovered through R would carry
 // errors above 1e-10 (a pivot near ε (XᵀX)_aa is rounding noise altogether) — or is not finite.
 // Every workgroup that runs it on the same `red` reaches the same verdict.

@@ -29,15 +29,28 @@ def _timeline_kernels(path):
 def test_model_lists_exactly_the_launches_of_the_committed_timeline(path):
     ks = _timeline_kernels(path)
     assert ks, path
-    resident, implicit = "k_spmv_powers" in ks, "k_ss_block<C>" not in ks
-    model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15, resident_powers=resident, implicit=implicit)]
+    resident, implicit, deferred = "k_spmv_powers" in ks, "k_ss_block<C>" not in ks, "k_ss_job" in ks
+    model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15, resident_powers=resident, implicit=implicit,
+                                                            deferred=deferred)]
     assert ks == model, f"{os.path.basename(path)}: the step launches\n{ks}\nthe model charges for\n{model}"
+
+
+def test_a_timeline_of_the_current_dispatch_is_committed():
+    """The tracked rocprof evidence must be of the code as it is: at least one committed timeline lists exactly the launches the
+    library's DEFAULT dispatch makes today (tools/step_model.py's defaults are kept in step with csrc/nk_sstep.hip::nk_ss_cycle).
+    Round 4's tracked kernel statistics lagged HEAD by three kernel commits (Weak #6)."""
+    model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15)]
+    assert "k_ss_job" in model and "k_backsolve" not in model       # round 5's dispatch
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]_*step_timeline.md")))
+    assert any(_timeline_kernels(p) == model for p in paths), \
+        "no committed profiles/r05_*step_timeline.md matches the current dispatch: rerun tools/gpu_r05_evidence.sh and copy it"
 
 
 def test_byte_counts_of_the_headline_step():
     spmv = 12 * NNZ + 4 * (N + 1) + 16 * N
     assert spmv == 83_836_932     # SURVEY.md §8(d) / VERDICT r03: the figure every SpMV GB/s is computed from
     hbm_s, alg_s = step_model.step_bytes(N, NNZ, resident_powers=False, implicit=False)
+    assert (hbm_s, alg_s) == step_model.step_bytes(N, NNZ, resident_powers=False, implicit=False, deferred=False)
     assert hbm_s == alg_s
     # 30 SpMVs + sweeps A1 B1 C1 A2 B2 (16, 31, 31, 31, 46 columns of 8 n bytes) + fill, b → v0, x = V y, update, residual, norm
     sweeps = 8 * N * (16 + 31 + 31 + 31 + 46)
@@ -50,6 +63,7 @@ def test_byte_counts_of_the_headline_step():
     assert hbm_r == hbm_s - 30 * spmv + 2 * per_block
     hbm_i, alg_i = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True)     # no sweep C for the first block either
     assert hbm_i == hbm_r - 8 * N * 31 and alg_i == alg_r - 8 * N * 31
+    assert (hbm_i, alg_i) == step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, deferred=False)   # same bytes
 
 
 def test_canonical_names():
@@ -60,3 +74,5 @@ def test_canonical_names():
     assert step_model.canonical("k_ss_block<15, true, false, 1, true>") == "k_ss_block<C>"
     assert step_model.canonical("k_spmv_stream<1024, false, true>") == "k_spmv_stream"
     assert step_model.canonical("void k_spmv_powers<4, 5>(pw_args)") == "k_spmv_powers"
+    assert step_model.canonical("void k_ss_job<false, 46>(ss_job, ss_tail_args, ss_tail_args, nk_peer_ar_view)") == "k_ss_job"
+    assert step_model.canonical("k_ss_block_mm<15, 16, true>") == "k_ss_block<B>"

@@ -29,8 +29,13 @@ def spmv_bytes(n, nnz):
     return 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
 
 
-def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True):
-    """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order"""
+def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True):
+    """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order.
+    deferred (round 5, the default with the implicit second pass): a block's second factorisation rides in the NEXT block's scalar
+    launch (k_ss_job), the previous block's Hessenberg columns in workgroup 0 of this block's sweep B, and the cycle's last scalar
+    launch also back-substitutes — three k_ss_job launches per two-block cycle where rounds 3–4 had four k_ss_reduce_factor,
+    k_ss_hess and k_backsolve. The byte counts are the same (scalar launches move nothing that counts)."""
+    deferred = deferred and implicit
     m = arnoldi
     L = []
 
@@ -51,8 +56,10 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
             for _ in range(w):
                 add("k_bratu_jvp" if matfree else "k_spmv_stream", b_op)
         add("k_ss_block<A>", 8.0 * n * (k + w))                 # Gram of [V X]ᵀX: k + w columns read
-        add("k_ss_reduce_factor", 0)
+        add("k_ss_job" if deferred else "k_ss_reduce_factor", 0)
         add("k_ss_block<B>", 8.0 * n * (k + 2 * w))             # update (k + w read, w written) + Gram of the result
+        if deferred:
+            continue                                            # (its reduction rides in the next scalar launch)
         add("k_ss_reduce_factor", 0)
         if bi + 1 < len(blocks):
             if not implicit:
@@ -60,7 +67,10 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
             # implicit second pass: no third sweep, and the block's Hessenberg columns are derived inside the next sweep A
         else:
             add("k_ss_hess", 0)                                 # the cycle's last block: its Hessenberg columns, own launch
-    add("k_backsolve", 0)
+    if deferred:
+        add("k_ss_job", 0)                                      # the cycle's last launch: reduce, factor, Hessenberg columns, y
+    else:
+        add("k_backsolve", 0)
     add("k_multiaxpy", 8.0 * n * (m + 2))                       # x = V y: m + 1 columns read, x written
     add("k_newton_update", 24.0 * n)
     add("k_bratu_residual", 16.0 * n)
