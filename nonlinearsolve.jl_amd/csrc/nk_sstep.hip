@@ -1465,7 +1465,7 @@ __device__ void ss_back_only(const ss_job &j, const ss_job_lds &L, double *lds, 
 // unrolled form was slower than the loops). So the lists go through the LDS-direct loads of gfx950 (global_load_lds_dword: a
 // wavefront's 64 lanes deliver 64 consecutive dwords at a wave-uniform LDS base, every lane from its own global address):
 // compact rolled loops that only ISSUE — nothing waits until the barrier behind all of them (which carries vmcnt(0)).
-template <class F>
+template <class F, int AUX = 0>
 __device__ __forceinline__ void ss_gather_async(unsigned lbase /* LDS byte address */, int count, F src_of /* e → const double * */) {
   const int t = threadIdx.x, lane = t & 63;
   for (int d0 = t - lane; d0 < 2 * count; d0 += SS_R) {   // d0: the wavefront's first dword of this round
@@ -1474,7 +1474,7 @@ __device__ __forceinline__ void ss_gather_async(unsigned lbase /* LDS byte addre
     if (d < 2 * count) {
       const double *p = src_of(d >> 1);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)p + 4 * (d & 1)),
-                                       (__attribute__((address_space(3))) void *)(size_t)la, 4, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(size_t)la, 4, 0, AUX);
     }
   }
 }
@@ -1516,7 +1516,8 @@ __device__ __forceinline__ void ss_job_request(const ss_job &j, const ss_tail_ar
   if (bk) ss_fixc_carve(bc, j.bfx, (int)L.bfix);
   if (!peer) {   // both reduced blocks (written by other workgroups: the acquire behind the ticket has invalidated the L1)
     const double *red = j.red;
-    ss_gather_async(lds0, j.nslots0 + j.nslots1, [=](int e) { return red + e; });
+    auto src = [=](int e) { return red + e; };
+    ss_gather_async<decltype(src), 16>(lds0, j.nslots0 + j.nslots1, src);   // (sc1: written write-through by other workgroups of this launch)
   }
   {
     const int ksc = (f1 && j.k0 > j.k1) ? j.k0 : (f2 ? j.k1 : j.k0);
@@ -1604,22 +1605,17 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
       const int par = (int)(pv.seq & 1);
       for (int q = 0; q < pv.P; ++q) reinterpret_cast<nk_peer_hdr *>(pv.map[q])->ar_data[par][pv.me][entry] = v;
       __threadfence_system();
-    } else {
-      j.red[entry] = v;
-    }
-  }
-  // hand-off to the last workgroup (any XCD): plain stores → barrier → ONE agent-scope release (+ the wait the compiler may
-  // drop behind it) → ticket; the workgroup that takes the last ticket → ONE agent-scope acquire → barrier → loads
-  __syncthreads();
-  if (t == 0) {
-    if (!PEER) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    } else {   // write-through: the hand-off below needs no L2 write-back
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(&j.red[entry]), (unsigned long long)__double_as_longlong(v),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const unsigned int last = (atomicAdd(j.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_last = last;
   }
+  // hand-off to the last workgroup (any XCD): write-through (sc1) stores, drained by their wavefronts → barrier → ticket; the
+  // workgroup that takes the last ticket reads them with sc1 loads (MI355X_MICROARCH.md: "sc1 payload → drained → flag"; rounds
+  // 3–4: plain stores + an agent-scope release fence = an L2 write-back behind a sweep that left the L2 full of dirty lines)
+  __syncthreads();
+  if (t == 0) s_last = (atomicAdd(j.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
   SS_STAMP(1);
