@@ -456,3 +456,47 @@ def test_default_sstep_on_user_matrices_with_complex_spectra_and_bad_scaling(nls
     assert np.linalg.norm(xs - xr) <= 1e-5 * scale and np.linalg.norm(xd - xr) <= 1e-5 * scale
     assert gs["iters"] <= 1.5 * gd["iters"] + 60, (gs["iters"], gd["iters"], st)
     J.close()
+
+
+# ----------------------------------------------------------------------------- the forms behind the A/B switches stay tested
+_SWITCH_CODE = (
+    "import numpy as np, torch, nonlinearsolve_jl_amd as nls\n"
+    "out = {}\n"
+    "for name, ns, kw in (('fixed', 96, dict(fixed_iters=30, maxiters=30)), ('tol', 24, dict(maxiters=600, reltol=1e-13, abstol=0.0))):\n"
+    "    prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))\n"
+    "    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, ortho='sstep', **kw), concrete_jac=True)\n"
+    "    cache = nls.init(prob, alg, abstol=1e-300, maxiters=50)\n"
+    "    for _ in range(4): cache.step()\n"
+    "    u = cache.u\n"
+    "    out[name] = np.asarray(u.cpu() if hasattr(u, 'cpu') else u)\n"
+    "np.savez(OUT, **out)\n")
+
+
+@pytest.mark.parametrize("env", [dict(NK_SS_DEFER="0"), dict(NK_SS_DEFER_HESS="0"), dict(NK_SS_DEFER_HESS="1"),
+                                 dict(NK_SS_TAIL_BACK="0"), dict(NK_SS_HOST_B="0"), dict(NK_SS_IMPLICIT="0"),
+                                 dict(NK_SS_FUSED="0")])
+def test_every_form_behind_an_ab_switch_reaches_the_same_iterates(env):
+    """The s-step cycle's forms that the defaults do not take — the second factorisation in a launch of its own (round 4's cycle),
+    the Hessenberg work inside the scalar launch / hosted by sweep B whatever the protocol, the back-substitution as a launch of
+    its own, the explicit third sweep, the unfused scalar launches — are the same arithmetic in another order: four Newton steps
+    (fixed work at 96², and GMRES to a tight tolerance at 24² — tight and small so that the linear solves are converged, not cut
+    off at the iteration cap: two restarted solves cut off there differ by what rounding does to ten restart cycles) leave iterates
+    equal to the default's to rounding."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, e in (("default", {}), ("switched", env)):
+        with tempfile.NamedTemporaryFile(suffix=".npz") as tf:
+            code = _SWITCH_CODE.replace("OUT", repr(tf.name))
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **e), capture_output=True, text=True, timeout=300,
+                               cwd=root)
+            assert r.returncode == 0, r.stderr[-2000:]
+            d = np.load(tf.name)
+            res[name] = {k: d[k] for k in d.files}
+    for k in res["default"]:
+        a, b = res["default"][k], res["switched"][k]
+        assert np.max(np.abs(a - b)) <= (1e-10 if k == "fixed" else 1e-9) * max(1.0, float(np.max(np.abs(a)))), \
+            (env, k, float(np.max(np.abs(a - b))))
