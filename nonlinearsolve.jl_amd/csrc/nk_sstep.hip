@@ -656,6 +656,34 @@ __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta)
 // 1.7 GB the sweeps of a 1024² cycle moved — for an s × s triangular solve and a k × s product inside the back-substitution
 // kernel (k_backsolve's `fx`, nk_gmres.hip).
 
+// The scalar work of the block scheme as ONE kind of launch (k_ss_job, behind the sweeps): what a job does
+constexpr int SSJ_F1 = 1, SSJ_F2 = 2, SSJ_HESS = 4, SSJ_BACK = 8, SSJ_COEF2 = 16, SSJ_PREP = 32;
+struct ss_job {
+  const double *part0, *part1;
+  int nblk0, nblk1, nslots0, nslots1;
+  int k0, sb0, k1, sb1;   // [0]: this block (first pass); [1]: the pending block (second pass)
+  int mode, m;
+  double *red, *coef;
+  const int *d_skip;
+  unsigned int *ticket;
+  nk_gmres_ctl *ctl;          // (what both blocks' argument sets share)
+  const double *sc;
+  nk_gmres_pub *pub;
+  uint64_t seq;
+  nk_ss_fix cfix;             // the earlier blocks whose factors the factorisations apply: this block's list (SSJ_F1), else the pending block's
+  double *y;                  // SSJ_BACK
+  const double *Rg, *g;
+  const uint64_t *peer_err;
+  nk_ss_fix bfx;              // SSJ_BACK: the blocks left at their first pass (the pending block is the last of them)
+  int host_wgs;               // the job rides in the LAST host_wgs workgroups of a sweep A (k_ss_block): 0 = a launch of its own
+};
+struct ss_job_lds { size_t sc, fix, w1, w0, sR, sg, verdict, bfix, rdv, total; int LK; };
+__host__ __device__ inline ss_job_lds ss_job_layout(const ss_job &j, int mode);
+// (defined behind the sweeps; a sweep A may host it)
+template <bool PEER, int MODE>
+__device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args &ta0, const ss_tail_args &ta1, const nk_peer_ar_view &pv,
+                                            int slot, int nwg, double *s_rf);
+
 // coef (UPDATE): U (k × S, row-major: the coefficients the update takes off, scales of un-normalised columns folded in),
 // then R (S × S, row-major, upper triangular, its diagonal replaced by the reciprocals: the form the substitution takes)
 // MTC = 1, 2, 3: k + S ≤ 16·MTC. The k + S values of a thread's row live in registers and the NEXT tile's loads are issued
@@ -677,8 +705,14 @@ __global__ __launch_bounds__(256) void k_ss_hess(int k, int sb, ss_tail_args ta)
 template <int S, bool UPDATE, bool GRAM, int MTC, bool FUSE, int KC = 0>
 __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *__restrict__ V, int64_t ldv,
                                                    const double *__restrict__ coef_in, double *__restrict__ partials,
-                                                   const int *d_skip, int ntiles, ss_tail_args ta, int *mark, int ws_off, int hk, int hs) {
+                                                   const int *d_skip, int ntiles, ss_tail_args ta, int *mark, int ws_off, int hk, int hs,
+                                                   const ss_job hj) {
   const int k = KC > 0 ? KC : k_rt;
+  // JOBHOST (sweep A of the default cycle's second block): the LAST hj.host_wgs workgroups stream nothing — they are the
+  // scalar launch that closes the PREVIOUS block (reduction of its sweep B's partial Gram block, second factorisation, Wi / D,
+  // Hessenberg columns and stopping test: ss_job_body), hidden behind this sweep; `ta` is that block's argument set
+  constexpr bool JOBHOST = FUSE && GRAM && !UPDATE && KC == 16;
+  const int njob = JOBHOST ? hj.host_wgs : 0;
   const bool bar = (ws_off & 1) != 0;   // development switch NK_SS_BARRIERS=1: the per-tile workgroup barriers of rounds 2–3
   ws_off = 0;
   {
@@ -687,6 +721,14 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
     if (dskip) return;
   }
   extern __shared__ double sX[];
+  if constexpr (JOBHOST) {
+    if (njob > 0 && (int)blockIdx.x >= (int)gridDim.x - njob) {
+      ss_job_body<false, SSJ_F2 | SSJ_PREP | SSJ_HESS>(hj, ta, ta, nk_peer_ar_view{nullptr, 0, 0, 0, nullptr},
+                                                       (int)blockIdx.x - ((int)gridDim.x - njob), njob, sX);
+      return;
+    }
+  }
+  const int gstream = (int)gridDim.x - njob;           // workgroups that stream (= the pitch of the partial blocks)
   constexpr int NT = MTC > 0 ? MTC : SS_MTMAX;         // Gram tiles this instantiation accumulates
   constexpr int NVR = MTC > 0 ? 16 * MTC - S : 1;      // basis values a thread holds (k ≤ NVR)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -726,8 +768,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
   // a workgroup walks CONTIGUOUS tiles: each of its k + S column streams then advances through adjacent 2 KB pieces
   // (sweep C with the Hessenberg duty: workgroup 0 streams nothing — its scalar work, ≈ 20 µs of dependent chains, then
   // hides behind the others' share instead of extending the launch)
-  const bool hw = FUSE && gridDim.x > 1;
-  const int nwk = (int)gridDim.x - (hw ? 1 : 0), me = (int)blockIdx.x - (hw ? 1 : 0);
+  const bool hw = FUSE && gstream > 1 && njob == 0;
+  const int nwk = gstream - (hw ? 1 : 0), me = (int)blockIdx.x - (hw ? 1 : 0);
   const int tpw = (ntiles + nwk - 1) / nwk;
   const int tile0 = me >= 0 ? me * tpw : 0, tile1 = me >= 0 ? min(tile0 + tpw, ntiles) : 0;
   auto process = [&](double (&vr)[NVR], double (&w)[S], int tile, bool valid, auto &&mid) {
@@ -853,13 +895,13 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
       if (mrow < K && ncol < S) {
         const int e = (mt * 4 + rr) * 64 + ln;
         const double sum = (sX[e] + sX[NT * 256 + e]) + (sX[2 * NT * 256 + e] + sX[3 * NT * 256 + e]);
-        partials[(size_t)(mrow * S + ncol) * gridDim.x + blockIdx.x] = sum;
+        partials[(size_t)(mrow * S + ncol) * gstream + blockIdx.x] = sum;
       }
     }
   }
   // workgroup 0, its share of the sweep issued (none when there are others): the Hessenberg columns of the block (hk, hs) —
   // sweep C: this block's; sweep A: those of the PREVIOUS block, which was left at its first pass (implicit second pass)
-  if (FUSE && blockIdx.x == 0) {
+  if (FUSE && blockIdx.x == 0 && njob == 0) {
     if (GRAM) __syncthreads();
     ss_hess_block(hk, hs, sX + ws_off, ta);
   }
@@ -1125,7 +1167,7 @@ int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting) {
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
                        const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out = nullptr, int hk = 0,
-                       int hs = 0) {
+                       int hs = 0, const ss_job *hjp = nullptr) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
   const int cls = ss_class(k, S);
   // "fused": a sweep whose workgroup 0 derives a block's Hessenberg columns while the others stream (its LDS: the scalar
@@ -1137,7 +1179,10 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   const size_t tile = ss_tile_doubles(k, S, mode != 2, cls ? cls : SS_MTMAX);
   // (the hosting workgroup streams no tiles — or, alone in the grid, is done with its tile when the scalar work starts: the
   //  workspace OVERLAYS the tile, so hosting costs the sweep no occupancy)
-  const size_t wsd = fuse ? ss_ws_doubles(hk, hs, true) : 0;
+  ss_job hjv;
+  std::memset(&hjv, 0, sizeof(hjv));
+  if (hjp) hjv = *hjp;   // sweep A hosting a scalar launch in its last workgroups (the caller has checked ss_a_can_host_job)
+  const size_t wsd = hjp ? ss_job_layout(hjv, hjv.mode).total : (fuse ? ss_ws_doubles(hk, hs, true) : 0);
   const size_t lds = (tile > wsd ? tile : wsd) * sizeof(double);
   ss_tail_args ta;
   std::memset(&ta, 0, sizeof(ta));
@@ -1152,9 +1197,9 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
     if (occ_out) {                                                                                                        \
       NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block<S, UPD, GRM, KM, FS, KCC>, SS_R, lds));     \
     } else if (ev) hipExtLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, \
-                                  k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off, hk, hs);                   \
+                                  k, V, ldv, coef, partials, d_skip, ntiles, ta, mark, ws_off, hk, hs, hjv);              \
     else hipLaunchKernelGGL((k_ss_block<S, UPD, GRM, KM, FS, KCC>), dim3(g), dim3(SS_R), lds, ctx->stream, n, k, V, ldv, coef, \
-                            partials, d_skip, ntiles, ta, mark, ws_off, hk, hs);                                          \
+                            partials, d_skip, ntiles, ta, mark, ws_off, hk, hs, hjv);                                     \
   } while (0)
   // the default cycle's shapes (blocks of 15 behind 1 and 16 columns) run the instances with a compile-time k
 #define SS_GO3(UPD, GRM, KM, FS)                                                                                          \
@@ -1173,7 +1218,7 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
     else SS_GO3(UPD, GRM, 0, false);                                                                                      \
   } while (0)
   static const int ws_off = (getenv("NK_SS_BARRIERS") && atoi(getenv("NK_SS_BARRIERS")) != 0) ? 1 : 0;
-  int g = grid;
+  int g = grid + (hjp ? hjv.host_wgs : 0);
   if constexpr (S == 15) {
     static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);   // A/B switch
     if (mode == 1 && mm_on && (k == 1 || k == 16) && (occ_out || (int64_t)S * ldv * 8 < ((int64_t)1 << 32) - 8)) {
@@ -1224,28 +1269,34 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
 }
 // mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
 static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                             const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out, int hk = 0, int hs = 0) {
+                             const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out, int hk = 0, int hs = 0,
+                             const ss_job *hjp = nullptr) {
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
   switch (s) {
-    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
-    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs);
+    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     default: NK_FAIL(NK_E_INVALID, "internal: no s-step sweep for a block of %d columns", s);
   }
 }
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
                 const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk, int hs) {
   return ss_sweep_dispatch(ctx, mode, n, k, s, V, ldv, coef, partials, d_skip, grid, tap, mark, nullptr, hk, hs);
+}
+// sweep A of a block whose last `hj.host_wgs` workgroups are the scalar launch that closes the previous block (ss_a_can_host_job)
+static int ss_sweep_a_hosting_job(nk_ctx *ctx, int64_t n, int k, int s, double *V, int64_t ldv, double *partials, const int *d_skip,
+                                  int grid, const ss_tail_args &pend_ta, int *mark, const ss_job &hj) {
+  return ss_sweep_dispatch(ctx, 0, n, k, s, V, ldv, nullptr, partials, d_skip, grid, &pend_ta, mark, nullptr, 0, 0, &hj);
 }
 // workgroups of sweep `mode` for a block of s columns behind k that a CU holds at once (cached per shape)
 int nk_ss_sweep_occupancy(nk_ctx *ctx, int mode, int k, int s) {
@@ -1291,26 +1342,6 @@ int nk_ss_block_width(int want) {
 //                 reduce → factor → Hessenberg → y without leaving the workgroup's LDS — three launches and their global
 //                 round trips in rounds 3–4).
 // A failure (lost pivot, departure) or a cycle that was done before this launch skips everything but the back-substitution.
-constexpr int SSJ_F1 = 1, SSJ_F2 = 2, SSJ_HESS = 4, SSJ_BACK = 8, SSJ_COEF2 = 16, SSJ_PREP = 32;
-struct ss_job {
-  const double *part0, *part1;
-  int nblk0, nblk1, nslots0, nslots1;
-  int k0, sb0, k1, sb1;   // [0]: this block (first pass); [1]: the pending block (second pass)
-  int mode, m;
-  double *red, *coef;
-  const int *d_skip;
-  unsigned int *ticket;
-  nk_gmres_ctl *ctl;          // (what both blocks' argument sets share)
-  const double *sc;
-  nk_gmres_pub *pub;
-  uint64_t seq;
-  nk_ss_fix cfix;             // the earlier blocks whose factors the factorisations apply: this block's list (SSJ_F1), else the pending block's
-  double *y;                  // SSJ_BACK
-  const double *Rg, *g;
-  const uint64_t *peer_err;
-  nk_ss_fix bfx;              // SSJ_BACK: the blocks left at their first pass (the pending block is the last of them)
-};
-struct ss_job_lds { size_t sc, fix, w1, w0, sR, sg, verdict, bfix, rdv, total; int LK; };
 __host__ __device__ inline ss_job_lds ss_job_layout(const ss_job &j, int mode) {
   ss_job_lds L;
   const bool f1 = (mode & SSJ_F1) != 0, f2 = (mode & SSJ_F2) != 0, hs = (mode & SSJ_HESS) != 0, bk = (mode & SSJ_BACK) != 0;
@@ -1556,21 +1587,28 @@ __device__ __forceinline__ void ss_job_request(const ss_job &j, const ss_tail_ar
 }
 // MODE: the job's bits at compile time — each combination the cycle uses is an instance of its own. This code runs once per
 // launch from a cold instruction cache: what an instance does not do must not be in it.
+// (slot, nwg: this workgroup's place among the job's workgroups — a launch of its own: (blockIdx.x, gridDim.x); hosted by a sweep A:
+//  the sweep's last nwg workgroups, each of which then walks several rounds of entries)
 template <bool PEER, int MODE>
-__global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_args ta0, const ss_tail_args ta1, const nk_peer_ar_view pv) {
-  extern __shared__ double s_rf[];
+__device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args &ta0, const ss_tail_args &ta1, const nk_peer_ar_view &pv,
+                                            int slot, int nwg, double *s_rf) {
   __shared__ unsigned int s_last;
   __shared__ ss_fixc s_fc, s_bc;
   const int skip = (j.d_skip != nullptr) ? *j.d_skip : 0;
-  const int t = threadIdx.x, slot = blockIdx.x;
+  const int t = threadIdx.x;
   constexpr bool f1 = (MODE & SSJ_F1) != 0, f2 = (MODE & SSJ_F2) != 0, hs = f2 && (MODE & SSJ_HESS) != 0, bk = (MODE & SSJ_BACK) != 0;
   SS_STAMP(0);
   // one wavefront per entry (four entries per workgroup): fixed order — lane l adds partials l, l + 64, …, then the
   // butterfly —, and one ticket per workgroup (465 same-address atomics of a workgroup-per-entry launch took 6 µs)
   const int wv = t >> 6, lane = t & 63;
-  const int entry = slot * 4 + wv, nslots = j.nslots0 + j.nslots1;
-  double v = 0.0;
-  if (entry < nslots) {
+  const int nslots = j.nslots0 + j.nslots1;
+  const ss_job_lds L = ss_job_layout(j, MODE);
+  // (the LDS block and the block list as address-space-3 pointers, taken from the symbols themselves: a cast of a generic
+  //  pointer further down trips the compiler — see ss_backsolve)
+  const ss_lds_ptr lds3 = (ss_lds_ptr)s_rf;
+  const ss_lds_fixc bc3 = (ss_lds_fixc)&s_bc;
+  for (int entry = slot * 4 + wv; entry < nslots; entry += nwg * 4) {   // (a launch of its own: one round)
+    double v = 0.0;
     const bool first = entry < j.nslots0;
     const int nblk = first ? j.nblk0 : j.nblk1;
     const double *p = first ? j.part0 + (size_t)entry * nblk : j.part1 + (size_t)(entry - j.nslots0) * nblk;
@@ -1584,38 +1622,33 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
 #pragma unroll
       for (int q = 0; q < 8; ++q) v += (base + lane + 64 * q < nblk) ? x[q] : 0.0;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) {
+      if (PEER) {
+        const int par = (int)(pv.seq & 1);
+        for (int q = 0; q < pv.P; ++q) reinterpret_cast<nk_peer_hdr *>(pv.map[q])->ar_data[par][pv.me][entry] = v;
+        __threadfence_system();
+      } else {   // write-through: the hand-off below needs no L2 write-back
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&j.red[entry]), (unsigned long long)__double_as_longlong(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
   }
   // (the flag was requested together with the partials: one round trip; a collective runs on every rank even when the cycle
   //  is done.) The cycle may have ended INSIDE a sweep in front of this launch (a hosted Hessenberg workgroup's stopping test):
   //  the sweeps and Hessenberg launches behind a skipped job look at pad1.
-  const ss_job_lds L = ss_job_layout(j, MODE);
-  // (the LDS block and the block list as address-space-3 pointers, taken from the symbols themselves: a cast of a generic
-  //  pointer further down trips the compiler — see ss_backsolve)
-  const ss_lds_ptr lds3 = (ss_lds_ptr)s_rf;
-  const ss_lds_fixc bc3 = (ss_lds_fixc)&s_bc;
   if (skip && slot == 0 && t == 0) j.ctl->pad1 = 1;
   if (skip && !PEER) {
     if (bk && slot == 0) ss_back_only(j, L, s_rf, &s_bc, lds3, bc3);
     return;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  if (lane == 0 && entry < nslots) {
-    if (PEER) {
-      const int par = (int)(pv.seq & 1);
-      for (int q = 0; q < pv.P; ++q) reinterpret_cast<nk_peer_hdr *>(pv.map[q])->ar_data[par][pv.me][entry] = v;
-      __threadfence_system();
-    } else {   // write-through: the hand-off below needs no L2 write-back
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(&j.red[entry]), (unsigned long long)__double_as_longlong(v),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
   // hand-off to the last workgroup (any XCD): write-through (sc1) stores, drained by their wavefronts → barrier → ticket; the
   // workgroup that takes the last ticket reads them with sc1 loads (MI355X_MICROARCH.md: "sc1 payload → drained → flag"; rounds
   // 3–4: plain stores + an agent-scope release fence = an L2 write-back behind a sweep that left the L2 full of dirty lines)
   __syncthreads();
-  if (t == 0) s_last = (atomicAdd(j.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  if (t == 0) s_last = (atomicAdd(j.ticket, 1u) == (unsigned)nwg - 1u) ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
   SS_STAMP(1);
@@ -1718,6 +1751,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_a
     for (int i = 0; i < 16; ++i) g_ss_stamp[16 * bank + i] = s_ss_stamps[i];
   }
 #endif
+}
+template <bool PEER, int MODE>
+__global__ __launch_bounds__(SS_R) void k_ss_job(const ss_job j, const ss_tail_args ta0, const ss_tail_args ta1, const nk_peer_ar_view pv) {
+  extern __shared__ double s_rf[];
+  ss_job_body<PEER, MODE>(j, ta0, ta1, pv, blockIdx.x, gridDim.x, s_rf);
 }
 extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   static unsigned long long *d_st = nullptr;
@@ -2138,6 +2176,21 @@ static bool ss_b_can_host(int64_t ldv, int k, int s) {
   return host_on && mm_on && s == 15 && (k == 1 || k == 16) && (int64_t)s * ldv * 8 < ((int64_t)1 << 32) - 8;
 }
 
+// Sweep A of this shape can host the scalar launch that closes the previous block in extra workgroups (k_ss_block's JOBHOST
+// instance: the compile-time-k form of the default cycle's second block). One rank only: a hosted job cannot wait for peers
+// while the streaming workgroups of its own launch hold the chip.
+// The job's workgroups take the place of streaming ones (the sweep's LDS tile admits two workgroups per CU and the grid fills
+// them: workgroups added to a full grid start when the sweep is over).
+static int ss_host_a_wgs() {
+  static const int n = getenv("NK_SS_HOST_A_WGS") ? atoi(getenv("NK_SS_HOST_A_WGS")) : 20;   // 240 entries: three rounds of 4 × 20 wavefronts (8 left the job longer than the sweep, 30 cost the sweep)
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+static bool ss_a_can_host_job(nk_ctx *ctx, int k, int s) {
+  static const bool host_on = !(getenv("NK_SS_HOST_A") && atoi(getenv("NK_SS_HOST_A")) == 0);   // A/B switch
+  static const bool kc_on = !(getenv("NK_SS_KCONST") && atoi(getenv("NK_SS_KCONST")) == 0);
+  return host_on && kc_on && nk_ctx_is_single(ctx) && s == 15 && k == 16 && ss_class(k, s) == 2;
+}
+
 // Enqueues the Arnoldi part of one cycle: `steps` columns in blocks of ≤ s (cut to the widths the sweeps are compiled for;
 // the last block may be shorter). k_gmres_begin has run. `wait_progress(need)` (may be empty) blocks the host until `need`
 // columns are closed or the cycle is done and returns false when no further block should be enqueued.
@@ -2269,24 +2322,37 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     if (dp.on && !defer_this) NK_TRY(close_pending(false));   // (this block takes the older form: nobody to carry the pending one)
     if (defer_this) {
       // ---- sweep A, the job [second factorisation of the pending block ; first factorisation of this one], sweep B
-      const int grid_a = nk_ss_grid_a(ctx, n, k, sb, false);
+      int grid_a = nk_ss_grid_a(ctx, n, k, sb, false);
+      // the fixed-work protocol, second block of the default cycle: the pending block is closed (reduction, second factorisation,
+      // Wi / D, Hessenberg columns) by extra workgroups of THIS sweep — nothing it writes is read by the streaming ones — and the
+      // launch behind the sweep only factors this block's first pass
+      const bool host_a = dp.on && grid_a > 4 * ss_host_a_wgs() && fixed_work && hess_where < 0 && ss_a_can_host_job(ctx, k, sb);
+      if (host_a) grid_a -= ss_host_a_wgs();   // (streaming workgroups: the pitch of the partial blocks)
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + sb));
-        NK_TRY(nk_ss_sweep(ctx, 0, n, k, sb, G->V, ldv, W->coef, W->part, done, grid_a, nullptr, &G->d_ctl->pad1, 0, 0));
+        if (host_a) {
+          ss_job hj = jb;
+          hj.part1 = W->part2; hj.nblk1 = dp.grid; hj.nslots1 = (dp.k + dp.sb) * dp.sb; hj.k1 = dp.k; hj.sb1 = dp.sb;
+          hj.mode = SSJ_F2 | SSJ_PREP | SSJ_HESS;
+          hj.cfix = dp.ta.fix;
+          hj.host_wgs = ss_host_a_wgs();
+          NK_TRY(ss_sweep_a_hosting_job(ctx, n, k, sb, G->V, ldv, W->part, done, grid_a, dp.ta, &G->d_ctl->pad1, hj));
+        } else
+          NK_TRY(nk_ss_sweep(ctx, 0, n, k, sb, G->V, ldv, W->coef, W->part, done, grid_a, nullptr, &G->d_ctl->pad1, 0, 0));
       }
       // where the pending block's Hessenberg columns are derived: in workgroup 0 of this block's sweep B when nothing can stop
       // the cycle early (fixed work) and that sweep has the hosting form; else in the job itself (the verdict arrives before sweep B)
-      const bool host_b = dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) && (hess_where < 0 ? fixed_work : hess_where == 1);
+      const bool host_b = !host_a && dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) && (hess_where < 0 ? fixed_work : hess_where == 1);
       {
         ss_job j = jb;
         j.part0 = W->part; j.nblk0 = grid_a; j.nslots0 = nslots; j.k0 = k; j.sb0 = sb;
         j.mode = SSJ_F1;
         j.cfix = ta.fix;
-        if (dp.on) {
+        if (dp.on && !host_a) {
           j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
           j.mode |= SSJ_F2 | SSJ_PREP | (host_b ? 0 : SSJ_HESS);
         }
-        NK_TRY(ss_launch_job(ctx, j, ta, dp.on ? dp.ta : ta));
+        NK_TRY(ss_launch_job(ctx, j, ta, (dp.on && !host_a) ? dp.ta : ta));
       }
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + 2 * sb));

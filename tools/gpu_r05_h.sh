@@ -1,0 +1,19 @@
+# round 5, pass H: sweep A hosts the job that closes the first block — parity, A/B lines, timeline
+set -x
+TAG=${1:-r05_h}
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$TAG; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_sstep.py tests/test_gpu_solvers.py -q -x < /dev/null > $O/pytest_core.log 2>&1; tail -8 $O/pytest_core.log
+B="--cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --steps 200 --warmup 20 --no-profile-pass"
+for rep in 1 2; do
+timeout 200 python bench.py $B < /dev/null > $O/bench_default_$rep.json 2> $O/bench_default.err
+NK_SS_HOST_A=0 timeout 200 python bench.py $B < /dev/null > $O/bench_nohosta_$rep.json 2> /dev/null
+done
+timeout 200 python bench.py $B --matfree < /dev/null > $O/bench_matfree.json 2> /dev/null
+timeout 200 python bench.py $B --workload c5 < /dev/null > $O/bench_c5.json 2> /dev/null
+timeout 300 bash tools/step_timeline.sh ${TAG} < /dev/null
+for f in $O/bench_*.json; do python -c "
+import json,sys
+try:
+    d=json.loads([x for x in open('$f') if x.startswith('{')][-1]); print('$f', d['value'], d['n_gpus'], d['ms_per_step'])
+except Exception as e: print('$f FAILED', e)"; done
