@@ -512,11 +512,13 @@ int nk_precond_create_ilut(nk_csr *A, double tau, nk_precond **out);
  * operator: usable as Pl or Pr. Several ranks: the rank's local block (block-Jacobi AMG). params NULL or zero fields:
  * defaults (nu 2, passes 2, theta 0.25, overcorrection 1.8, cheb_ratio 4, coarse_max 128). */
 typedef struct nk_amg_params {
-  int32_t nu, passes, coarse_max, reserved;
+  int32_t nu, passes, coarse_max, matching;
   double theta, overcorrection, cheb_ratio;
 } nk_amg_params;
 int nk_amg_params_default(nk_amg_params *p);
 int nk_precond_create_amg(nk_csr *A, const nk_amg_params *params, nk_precond **out);
+/* how the aggregates were formed: 1 = the sequential pairwise pass (host set-up), 2 = handshaking (device set-up) */
+int nk_precond_amg_matching(nk_precond *P, int *matching);
 /* the hierarchy, for inspection: *levels (coarsest included); sizes / nnzs / lmax: up to `cap` entries each (NULL: skipped) */
 int nk_precond_amg_info(nk_precond *P, int *levels, int cap, int64_t *sizes, int64_t *nnzs, double *lmax);
 /* row → coarse row of level `level` (`count` = that level's rows; the coarsest level has none: NK_E_INVALID) */

@@ -37,7 +37,7 @@ class Stats(C.Structure):
 
 
 class AMGParams(C.Structure):
-    _fields_ = [("nu", C.c_int32), ("passes", C.c_int32), ("coarse_max", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("nu", C.c_int32), ("passes", C.c_int32), ("coarse_max", C.c_int32), ("matching", C.c_int32),
                 ("theta", C.c_double), ("overcorrection", C.c_double), ("cheb_ratio", C.c_double)]
 
 
@@ -183,6 +183,7 @@ SIGNATURES = {
     "nk_precond_create_amg": (_I, [_P, _P, _PP]),
     "nk_precond_amg_info": (_I, [_P, C.POINTER(_I), _I, _P, _P, _P]),
     "nk_precond_amg_aggregates": (_I, [_P, _I, _P, _L]),
+    "nk_precond_amg_matching": (_I, [_P, C.POINTER(_I)]),
     "nk_precond_update": (_I, [_P]),
     "nk_precond_apply": (_I, [_P, _P, _P, _I]),
     "nk_precond_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

@@ -693,12 +693,15 @@ class ILUTPreconditioner(ILU0Preconditioner):
 class AMGPreconditioner(Preconditioner):
     """Aggregation algebraic multigrid built from the matrix alone (csrc/nk_amg.hip) — what the reference's tutorial returns from
     `precs(A, p)` as Pl for a large sparse Jacobian (`aspreconditioner(ruge_stuben(A))`, docs/src/tutorials/large_systems.md:276-316):
-    pairwise aggregation (aggregates of ≤ 2^passes rows, fixed at creation), Galerkin coarse matrices refreshed on the device by
+    pairwise aggregation (aggregates of ≤ 2^passes rows, formed on the device at creation), Galerkin coarse matrices refreshed on the device by
     `update()`, ν Chebyshev steps on D⁻¹A per side, over-corrected coarse correction, dense inverse on the ≤ 128 coarsest rows."""
 
     def __init__(self, A: "CSRMatrix", nu: int = 0, passes: int = 0, theta: float = 0.0, overcorrection: float = 0.0,
-                 cheb_ratio: float = 0.0, coarse_max: int = 0):
-        prm = L.AMGParams(int(nu), int(passes), int(coarse_max), 0, float(theta), float(overcorrection), float(cheb_ratio))
+                 cheb_ratio: float = 0.0, coarse_max: int = 0, matching: str = "auto"):
+        # matching: "auto" (the device set-up's handshaking on one rank, the host's sequential pass on a rank's local block),
+        # "greedy" (host) or "handshake" (device)
+        mt = {"auto": 0, "greedy": 1, "handshake": 2}[matching]
+        prm = L.AMGParams(int(nu), int(passes), int(coarse_max), mt, float(theta), float(overcorrection), float(cheb_ratio))
         h = C.c_void_p()
         check(L.lib().nk_precond_create_amg(A._h, C.byref(prm), C.byref(h)))
         super().__init__(h, A)
@@ -710,6 +713,13 @@ class AMGPreconditioner(Preconditioner):
         n, z, lm = (C.c_int64 * nl.value)(), (C.c_int64 * nl.value)(), (C.c_double * nl.value)()
         check(L.lib().nk_precond_amg_info(self._h, C.byref(nl), nl.value, n, z, lm))
         return [(int(n[i]), int(z[i]), float(lm[i])) for i in range(nl.value)]
+
+    @property
+    def matching(self) -> str:
+        """how the aggregates were formed: "greedy" (sequential pairwise pass, host set-up) or "handshake" (device set-up)"""
+        m = C.c_int(0)
+        check(L.lib().nk_precond_amg_matching(self._h, C.byref(m)))
+        return {1: "greedy", 2: "handshake"}[m.value]
 
     def aggregates(self, level: int):
         """row → coarse row of `level` (NumPy int32)"""

@@ -525,6 +525,7 @@ int nk_amg_apply_dev(nk_amg *M, const double *d_b, double *d_x, const int *d_ski
 void nk_amg_destroy(nk_amg *M);
 int nk_amg_levels(const nk_amg *M);
 int nk_amg_level_info(const nk_amg *M, int l, int64_t *n, int64_t *nnz, double *lmax);
+int nk_amg_matching(const nk_amg *M);   // 1 = sequential pairwise pass (host set-up), 2 = handshaking (device set-up)
 const int32_t *nk_amg_aggregates(const nk_amg *M, int l);   // host: row → coarse row of level l (NULL on the coarsest)
 // in-place inverse of ONE dense n × n matrix, n ≤ 128, column-major with leading dimension ld, row pivoting (nk_bcr.hip)
 int nk_dense_invert128_dev(nk_ctx *ctx, double *d_M, int ld, int n, int *d_fail);

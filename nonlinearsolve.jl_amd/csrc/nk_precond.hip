@@ -579,6 +579,11 @@ extern "C" int nk_precond_amg_info(nk_precond *P, int *levels, int cap, int64_t 
     NK_TRY(nk_amg_level_info(P->amg, l, sizes ? sizes + l : nullptr, nnzs ? nnzs + l : nullptr, lmax ? lmax + l : nullptr));
   return NK_OK;
 }
+extern "C" int nk_precond_amg_matching(nk_precond *P, int *matching) {
+  NK_REQUIRE(P && P->kind == NK_PRECOND_AMG && P->amg && matching, "not an AMG preconditioner");
+  *matching = nk_amg_matching(P->amg);
+  return NK_OK;
+}
 extern "C" int nk_precond_amg_aggregates(nk_precond *P, int level, int32_t *agg, int64_t count) {
   NK_REQUIRE(P && P->kind == NK_PRECOND_AMG && P->amg && agg, "not an AMG preconditioner");
   const int32_t *h = nk_amg_aggregates(P->amg, level);

@@ -742,6 +742,69 @@ def jacobi_preconditioner(A):
 #     two; 1.8 is the measured optimum on the 5-point Laplacian and the Brusselator) — x += ω·T x_c.
 # A fixed linear operator (fixed degree, fixed hierarchy), so it serves plain GMRES on either side. New values on the same
 # pattern (a new Jacobian) refresh the numbers — Galerkin sums, D⁻¹, λmax, the coarse inverse — and keep the aggregates.
+#
+# Two matchings: "greedy" (the sequential pass above — the device's HOST set-up: several ranks, NK_AMG_SETUP=host) and
+# "handshake" (round 5, the device-side set-up, the default on one rank): every unmatched row names its best unmatched
+# neighbour — largest s_ij among s_ij ≥ θ·max_k s_ik, ties by a key that both ends of an edge compute alike — and two rows
+# that name each other are paired; AMG_HS_ROUNDS rounds, what is left stays a singleton. The tie-break key of the edge
+# a < b, d = b − a: [d (variant 1: far first) or 2³¹ − 1 − d (variant 0: near first)] ≫ [⌊a / d⌋ even first] ≫ [a 32-bit hash
+# of (a, b)]: on a lexicographically numbered grid with equal couplings ⌊a / d⌋ is the position along the grid line, so whole
+# lines pair up in ONE round and the aggregates come out as regular as the greedy pass's. A level that variant 0 does not
+# coarsen by 2^passes within 2 % is coarsened with both variants and keeps the one with fewer aggregates (ties: variant 0) —
+# near-first reproduces the greedy aggregates on even-sized and periodic grids, far-first keeps the pairs aligned on odd-sized ones.
+AMG_HS_ROUNDS = 8
+
+
+def amg_edge_hash(a, b):
+    a = np.asarray(a).astype(np.uint32)
+    b = np.asarray(b).astype(np.uint32)
+    h = (a * np.uint32(0x9E3779B1)) ^ (b * np.uint32(0x85EBCA77))
+    h = h ^ (h >> np.uint32(16))
+    h = h * np.uint32(0x7FEB352D)
+    h = h ^ (h >> np.uint32(15))
+    h = h * np.uint32(0x846CA68B)
+    h = h ^ (h >> np.uint32(16))
+    return h
+
+
+def amg_handshake_pass(rp, ci, v, theta, variant=0, rounds=AMG_HS_ROUNDS):
+    """one pairwise pass by handshaking: (cid, nc) — aggregates numbered in the order of their smallest row"""
+    n = len(rp) - 1
+    rp, ci = np.asarray(rp, dtype=np.int64), np.asarray(ci, dtype=np.int64)
+    row = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    off = ci != row
+    diag = np.zeros(n)
+    np.add.at(diag, row[~off], v[~off])
+    sg = np.where(diag < 0, -1.0, 1.0)
+    s = -v * sg[row]
+    smax = np.zeros(n)
+    np.maximum.at(smax, row[off], s[off])
+    cand = off & (s > 0) & (s >= theta * smax[row])
+    a, b = np.minimum(row, ci), np.maximum(row, ci)
+    d = np.maximum(b - a, 1)
+    k2 = d if variant == 1 else (np.int64(0x7FFFFFFF) - d)
+    key = (k2.astype(np.uint64) << np.uint64(33)) | ((np.uint64(1) - ((a // d) & 1).astype(np.uint64)) << np.uint64(32)) \
+        | amg_edge_hash(a, b).astype(np.uint64)
+    match = -np.ones(n, dtype=np.int64)
+    me = np.arange(n, dtype=np.int64)
+    for _ in range(rounds):
+        ok = cand & (match[row] < 0) & (match[ci] < 0)
+        idx = np.nonzero(ok)[0]
+        if len(idx) == 0:
+            break
+        o = idx[np.lexsort((ci[idx], key[idx], s[idx], row[idx]))]      # per row: ascending (s, key, column) — the last one is named
+        last = np.ones(len(o), dtype=bool)
+        last[:-1] = row[o][1:] != row[o][:-1]
+        best = -np.ones(n, dtype=np.int64)
+        best[row[o][last]] = ci[o][last]
+        mutual = (best >= 0) & (best[np.maximum(best, 0)] == me)
+        match[mutual] = best[mutual]
+    rep = (match < 0) | (me < match)
+    num = np.cumsum(rep) - 1
+    cid = np.where(rep, num, num[np.maximum(match, 0)])
+    return cid.astype(np.int64), int(rep.sum())
+
+
 def amg_pairwise_pass(rp, ci, v, theta):
     n = len(rp) - 1
     cid = -np.ones(n, dtype=np.int64)
@@ -794,21 +857,36 @@ def amg_galerkin(rp, ci, v, cid, nc):
 
 
 class AggregationAMG:
-    def __init__(self, A, nu=2, passes=2, theta=0.25, overcorrection=1.8, cheb_ratio=4.0, coarse_max=128, max_levels=24):
+    def __init__(self, A, nu=2, passes=2, theta=0.25, overcorrection=1.8, cheb_ratio=4.0, coarse_max=128, max_levels=24,
+                 matching="handshake"):
         A = sp.csr_matrix(A)
         A.sort_indices()
         self.nu, self.passes, self.theta, self.omega = int(nu), int(passes), float(theta), float(overcorrection)
         self.ratio, self.coarse_max = float(cheb_ratio), int(coarse_max)
+        self.matching = matching
         self.levels = []      # dicts: rp, ci (pattern), agg (row → coarse row), nc, emap (fine entry → coarse entry)
         rp, ci, v = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
+
+        def coarsen(passfn):
+            agg = np.arange(len(rp) - 1, dtype=np.int64)
+            crp, cci, cv, nc = rp, ci, v, len(rp) - 1
+            for p_ in range(self.passes):
+                cid, nc = passfn(crp, cci, cv, self.theta)
+                if p_ + 1 < self.passes:
+                    crp, cci, cv, _e = amg_galerkin(crp, cci, cv, cid, nc)
+                agg = cid[agg]
+            return agg, nc
+
         while len(rp) - 1 > self.coarse_max and len(self.levels) < max_levels:
             n = len(rp) - 1
-            agg = np.arange(n, dtype=np.int64)
-            crp, cci, cv = rp, ci, v
-            for _ in range(self.passes):
-                cid, nc = amg_pairwise_pass(crp, cci, cv, self.theta)
-                crp, cci, cv, _e = amg_galerkin(crp, cci, cv, cid, nc)
-                agg = cid[agg]
+            if matching == "greedy":
+                agg, nc = coarsen(amg_pairwise_pass)
+            else:
+                agg, nc = coarsen(lambda *a: amg_handshake_pass(*a, variant=0))
+                if nc * (1 << self.passes) > n + n // 50:      # not (nearly) a full coarsening: try the other tie-break
+                    agg1, nc1 = coarsen(lambda *a: amg_handshake_pass(*a, variant=1))
+                    if nc1 < nc:
+                        agg, nc = agg1, nc1
             if nc > 0.8 * n:
                 break
             nrp, nci, nv, emap = amg_galerkin(rp, ci, v, agg, nc)   # one-stage sums: what a value refresh recomputes
