@@ -250,14 +250,19 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
                                                         int nv, const int *__restrict__ d_nv,
                                                         const double *__restrict__ h, double sign,
                                                         double *__restrict__ w, double *__restrict__ partials,
-                                                        const int *d_skip, const double *__restrict__ sc, int overwrite) {
+                                                        const int *d_skip, const double *__restrict__ sc, int overwrite,
+                                                        const double *__restrict__ uo, double *__restrict__ un, double usign,
+                                                        double *__restrict__ upartials) {
+  // (un != nullptr — the fused Newton update — is only launched without a skip flag: the update must happen)
   SKIP_GUARD(d_skip);
   __shared__ double sm[4];
   if (d_nv) nv = *d_nv;
   const int64_t npair = n >> 1;
   const int64_t stride = (int64_t)gridDim.x * NK_BLOCK;
   double2 *w2 = reinterpret_cast<double2 *>(w);
-  double ss = 0.0;
+  const double2 *uo2 = reinterpret_cast<const double2 *>(uo);
+  double2 *un2 = reinterpret_cast<double2 *>(un);
+  double ss = 0.0, us = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; i < npair; i += stride) {
     double2 a = overwrite ? make_double2(0.0, 0.0) : w2[i];
     int j = 0;
@@ -280,28 +285,51 @@ __global__ __launch_bounds__(NK_BLOCK) void k_multiaxpy(int64_t n, const double 
     }
     w2[i] = a;
     ss += a.x * a.x + a.y * a.y;
+    if (un) {   // u_new = u_old + usign·x, ‖u_new − u_old‖² (k_newton_update's arithmetic)
+      const double2 u = uo2[i];
+      double2 r;
+      r.x = u.x + usign * a.x; r.y = u.y + usign * a.y;
+      un2[i] = r;
+      const double dx = r.x - u.x, dy = r.y - u.y;
+      us += dx * dx;
+      us += dy * dy;
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double a = overwrite ? 0.0 : w[n - 1];
     for (int j = 0; j < nv; ++j) a += sign * h[j] * (sc ? sc[j] : 1.0) * V[(size_t)j * ldv + n - 1];
     w[n - 1] = a;
     ss += a * a;
+    if (un) {
+      const double u = uo[n - 1], r = u + usign * a, d = r - u;
+      un[n - 1] = r;
+      us += d * d;
+    }
   }
   if (partials) {
     const double s = block_sum(ss, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
   }
+  if (upartials) {
+    if (partials) __syncthreads();
+    const double s = block_sum(us, sm);
+    if (threadIdx.x == 0) upartials[blockIdx.x] = s;
+  }
 }
 
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq, const int *d_skip, const int *d_nv,
-                      const double *d_scales, bool overwrite) {
+                      const double *d_scales, bool overwrite, nk_fused_update *fu) {
   const int grid = nk_grid_for(n >> 1, NK_BLOCK * 2, NK_MAX_RED_BLOCKS);
+  NK_REQUIRE(!fu || (d_skip == nullptr && d_sumsq == nullptr), "internal: a fused update rides in an unconditional, plain multiaxpy");
   {
-    nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2));
+    nk_prof_scope prof_(ctx, NK_K_MULTIAXPY, 8.0 * (double)n * (nv + 2 + (fu ? 2 : 0)));
     NK_LAUNCH(ctx, k_multiaxpy, dim3(grid), dim3(NK_BLOCK), n, V, ldv, nv, d_nv, d_h, sign,
-                       w, d_sumsq ? ctx->d_partials_ss : nullptr, d_skip, d_scales, overwrite ? 1 : 0);
+                       w, d_sumsq ? ctx->d_partials_ss : nullptr, d_skip, d_scales, overwrite ? 1 : 0,
+                       fu ? fu->u_old : (const double *)nullptr, fu ? fu->u_new : (double *)nullptr, fu ? fu->usign : 0.0,
+                       fu ? fu->partials : (double *)nullptr);
   }
+  if (fu) { fu->grid = grid; fu->done = true; }
   if (d_sumsq == NK_SUMSQ_PARTIALS_ONLY) {  // consumer (k_givens) reduces ctx->d_partials[0..grid) itself
     ctx->last_red_grid = grid;
     NK_HIP(hipGetLastError());
@@ -858,9 +886,10 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_inf2(const double *__restri
     }
   }
 }
-int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n) {
-  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
-  NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
+int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
+                       int have_partials) {
+  const int grid = have_partials > 0 ? have_partials : nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+  if (have_partials <= 0) NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
   NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
             (double *)nullptr, (uint64_t *)nullptr, (uint64_t)0);
   NK_HIP(hipGetLastError());
@@ -870,11 +899,11 @@ __global__ __launch_bounds__(NK_BLOCK) void k_publish(const double *__restrict__
                                                       uint64_t seq);
 // the same, with the 2–3 results delivered to the host (`h_out`): on one rank the stage-2 launch publishes them itself
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
-                               double *h_out, const std::function<int()> &before_wait) {
+                               double *h_out, const std::function<int()> &before_wait, int have_partials) {
   const int count = extra_partials ? 3 : 2;
   static const bool legacy = getenv("NK_FETCH_MEMCPY") != nullptr || getenv("NK_NORMS_SEPARATE_PUBLISH") != nullptr;
   if (!nk_ctx_is_single(ctx) || legacy) {
-    NK_TRY(nk_blas_norms_inf2(ctx, n, x, d_out, extra_partials, extra_n));
+    NK_TRY(nk_blas_norms_inf2(ctx, n, x, d_out, extra_partials, extra_n, have_partials));
     if (legacy) return nk_scalars_to_host(ctx, d_out, count, h_out);
     // several ranks: the publish is a launch of its own; work the caller wants in the queue behind it goes in before the wait
     const uint64_t seq = ++ctx->seq;
@@ -886,9 +915,9 @@ int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *
     for (int i = 0; i < count; ++i) h_out[i] = ctx->h_pinned[i];
     return NK_OK;
   }
-  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+  const int grid = have_partials > 0 ? have_partials : nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
   const uint64_t seq = ++ctx->seq;
-  NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
+  if (have_partials <= 0) NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
   NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
             ctx->h_pinned_dev, ctx->h_seq_dev, seq);
   NK_HIP(hipGetLastError());

@@ -1598,6 +1598,18 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   }
   return rc;
 }
+void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, double usign, double *partials) {
+  G->fu = nk_fused_update{};
+  G->fu.u_old = u_old; G->fu.u_new = u_new; G->fu.usign = usign; G->fu.partials = partials;
+  G->fu.armed = true;
+}
+bool nk_gmres_take_fused_update(nk_gmres *G, int *grid) {
+  const bool done = G->fu.armed && G->fu.done;
+  if (grid) *grid = G->fu.grid;
+  G->fu.armed = false;
+  G->fu.done = false;
+  return done;
+}
 static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol, int maxiter,
                             int fixed_iters, nk_gmres_info *info) {
   nk_ctx *ctx = G->ctx;
@@ -1671,7 +1683,10 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
   int first = 1;
   int total_iters = 0;
   volatile nk_gmres_pub *pub = G->h_pub;
+  static const bool fused_update_off = getenv("NK_FUSED_UPDATE") && atoi(getenv("NK_FUSED_UPDATE")) == 0;   // A/B switch
+  G->fu.done = false;
   for (;;) {
+    G->fu.done = false;   // (a further cycle moves x again: an update fused into an earlier one is stale)
     if (!have_ss) NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
     have_ss = false;
     const uint64_t seq = ++G->cycle_seq;
@@ -1755,7 +1770,10 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
                 (const uint64_t *)(ctx->peer.on ? nk_peer_err_ptr(ctx) : nullptr),
                 G->ortho == NK_ORTHO_SSTEP ? nk_ss_take_last_block(G) : nk_ss_fix{});
     if (!G->prec_kind) {
-      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero));
+      // the Newton driver's update rides in this pass when the solve is ONE cycle from a zero guess (whatever its outcome: the
+      // update is out of place, a failed solve's is never looked at)
+      nk_fused_update *fu = (G->fu.armed && x_is_zero && cap <= m && !fused_update_off) ? &G->fu : nullptr;
+      NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, d_x, nullptr, nullptr, &G->d_ctl->k, G->d_s, x_is_zero, fu));
     } else {
       NK_TRY(nk_blas_multiaxpy(ctx, n, m, G->V, ldv, G->d_y, 1.0, G->r, nullptr, nullptr, &G->d_ctl->k, G->d_s, true));
       NK_TRY(prec_apply(G, G->r, G->z, nullptr));

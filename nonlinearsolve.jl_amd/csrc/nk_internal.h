@@ -358,6 +358,7 @@ int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, d
 int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out);
 int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi);
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
+int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out);
 // forget what the problem was linearised at: the caller wrote new contents into a buffer it may have been keyed on
 static inline void nk_problem_invalidate(nk_problem *P) { P->d_u_lin = nullptr; P->d_u_linJ = nullptr; }
 int nk_csr_clone_pattern(nk_csr *A, nk_csr **out);  // same pattern and partition, own values (collective on several ranks)
@@ -377,10 +378,20 @@ int nk_blas_norm_inf(nk_ctx *ctx, int64_t n, const double *x, double *d_out);
 // d_scales (nullable): per-column scale s_j of a lazily-normalised basis; h_j = s_j (ṽ_j·w), coefficient h_j s_j
 int nk_blas_multidot(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *w,
                      double *d_h, bool with_self, const int *d_skip, const double *d_scales);
+// a Newton update riding in the pass that forms the linear solve's x: u_new = u_old + usign·w_new (out of place), the
+// partial sums of (u_new − u_old)² per workgroup → partials[0 .. *grid_out) (k_newton_update's arithmetic)
+struct nk_fused_update {
+  const double *u_old = nullptr;
+  double *u_new = nullptr;
+  double usign = -1.0;
+  double *partials = nullptr;
+  int grid = 0;            // out: workgroups = partial sums written
+  bool armed = false, done = false;
+};
 int nk_blas_multiaxpy(nk_ctx *ctx, int64_t n, int nv, const double *V, int64_t ldv, const double *d_h,
                       double sign, double *w, double *d_sumsq /*nullable*/, const int *d_skip,
                       const int *d_nv /*nullable: device count overrides nv*/, const double *d_scales,
-                      bool overwrite = false /* w = sign·V h instead of w += … */);
+                      bool overwrite = false /* w = sign·V h instead of w += … */, nk_fused_update *fu = nullptr);
 constexpr int NK_MR_MAX = 6;  // inner products per nk_blas_multi_reduce launch
 int nk_blas_multi_reduce(nk_ctx *ctx, int64_t n, int ndots, const double *const *xs, const double *const *ys,
                          const double *amax, const double *extra_partials, int extra_slots, int extra_n, double *d_out);
@@ -389,7 +400,8 @@ int nk_blas_reduce_one(nk_ctx *ctx, const double *partials, int nblk, double *d_
 int nk_blas_copy_sumsq(nk_ctx *ctx, int64_t n, const double *x, double *y, double *d_out);
 // d_out[0] = max|x| (NaN-propagating), d_out[1] = Σ x²; optional third slot: Σ of `extra_partials[0..extra_n)` (per-block
 // partial sums another kernel left behind) — one stage-2 launch and one fetch for the Newton driver's three norms
-int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n);
+int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
+                       int have_partials = 0);
 #define NK_SUMSQ_PARTIALS_ONLY ((double *)(uintptr_t)1)  // multiaxpy: leave ‖w‖² partials in ctx->d_partials_ss
 // DCGS2 pass A: correct the pending column V[:,k] by −Σ a_j ṽ_j, turn V[:,k+1] (= s_k·A·pending) into the true next
 // vector by −Σ b_j ṽ_j − b_k·corrected, and return d_h[0..k] = s_j·(ṽ_j·w) over the corrected basis
@@ -453,6 +465,7 @@ struct nk_gmres {
   int m = 30, ortho = NK_ORTHO_CGS2;
   double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
   double *x0_keep = nullptr;   // the warm start of a solve that runs on a resident matrix-powers plan (restored if a launch is torn)
+  nk_fused_update fu;          // armed by the Newton driver for ONE solve (nk_gmres_arm_fused_update)
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
@@ -601,12 +614,17 @@ int nk_csr_alloc_values(nk_csr *A, double **out);   // a zero-padded value array
 bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
 void nk_csr_commit_pending_bounds(nk_csr *A);   // the caller's reducing kernel is enqueued: the partials are no longer pending
 int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
+// (have_partials > 0: stage 1 has run inside the kernel that produced x — ctx->d_partials holds its have_partials workgroups' results)
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
-                               double *h_out, const std::function<int()> &before_wait = nullptr);
+                               double *h_out, const std::function<int()> &before_wait = nullptr, int have_partials = 0);
 // the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
 int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved);
+// The NEXT solve's last pass (x = V y) also forms u_new = u_old + usign·x and the partial sums of ‖u_new − u_old‖² — if that solve
+// is a single cycle from a zero guess without a right preconditioner. nk_gmres_take_fused_update: whether it happened (disarms).
+void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, double usign, double *partials);
+bool nk_gmres_take_fused_update(nk_gmres *G, int *grid);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
 int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting);   // sweep A's own grid (read-only: one workgroup per CU)

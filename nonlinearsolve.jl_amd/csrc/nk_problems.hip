@@ -64,6 +64,39 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual(int64_t ns, int64_t
   const int64_t jl = k / ns, i = k - jl * ns;
   f[k] = c_lap * bratu_lap(u, lo, hi, ns, nl, i, jl, k) - c_exp * exp(u[k]);
 }
+// The residual and, in the same pass, the per-workgroup partial results of its norms — max |f| in partials[0 .. grid), Σ f² in
+// partials[grid .. 2 grid) — with k_absmax_sumsq's assignment of entries to threads and its order of combination: the bits of
+// ‖f‖∞ and ‖f‖₂ are those of the two-launch form (nk_blas.hip). One pass over f less per Newton step.
+__global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual_norms(int64_t ns, int64_t nl, double c_lap, double c_exp,
+                                                                   const double *__restrict__ u, const double *__restrict__ lo,
+                                                                   const double *__restrict__ hi, double *__restrict__ f,
+                                                                   double *__restrict__ partials) {
+  __shared__ double sm[8];
+  double m = 0.0, s = 0.0;
+  const int64_t n = ns * nl, stride = (int64_t)gridDim.x * NK_BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; k < n; k += stride) {
+    const int64_t jl = k / ns, i = k - jl * ns;
+    const double v = c_lap * bratu_lap(u, lo, hi, ns, nl, i, jl, k) - c_exp * exp(u[k]);
+    f[k] = v;
+    const double av = fabs(v);
+    m = (m != m || av != av) ? __builtin_nan("") : (m > av ? m : av);
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double mo = __shfl_xor(m, o, 64);
+    m = (m != m || mo != mo) ? __builtin_nan("") : (m > mo ? m : mo);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; sm[4 + (threadIdx.x >> 6)] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    auto nmax = [](double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); };
+    partials[blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+    partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  }
+}
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_diag(int64_t n, double c_exp, const double *__restrict__ u,
                                                          double *__restrict__ d) {
   const int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x;
@@ -512,6 +545,25 @@ extern "C" int nk_problem_set_params(nk_problem *P, const double *params, int np
 }
 
 // ---------------------------------------------------------------------------- device-level operations
+// f(u) and the stage-1 partials of ‖f‖∞, ‖f‖₂² in ONE launch, where the problem has such a kernel: *grid_out = the number of
+// workgroups (partials laid out as k_absmax_sumsq leaves them), 0 = not available (nothing was launched).
+int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out) {
+  static const bool off = getenv("NK_FUSED_RESIDUAL_NORMS") && atoi(getenv("NK_FUSED_RESIDUAL_NORMS")) == 0;   // A/B switch
+  *grid_out = 0;
+  nk_ctx *ctx = P->ctx;
+  const int64_t n = P->n_local;
+  if (off || n == 0 || P->kind != NK_PROBLEM_BRATU2D) return NK_OK;
+  const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);   // (k_absmax_sumsq's grid: nk_blas_norms_inf2)
+  nk_prof_scope prof_(ctx, NK_K_RESIDUAL, 16.0 * (double)n);
+  const double *lo, *hi;
+  NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
+  halo_lines(P, 1, false, &lo, &hi);
+  NK_LAUNCH(ctx, k_bratu_residual_norms, dim3(grid), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->c_lap, P->c_exp, d_u, lo, hi, d_f,
+            partials);
+  NK_HIP(hipGetLastError());
+  *grid_out = grid;
+  return NK_OK;
+}
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f) {
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;

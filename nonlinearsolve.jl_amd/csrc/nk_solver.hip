@@ -265,9 +265,9 @@ static double *spare_u(nk_solver *S) {
 }
 // ‖fu‖∞ and ‖fu‖₂² of the current residual (+ optionally the stall norm's partial sums) → ONE stage-2 launch, one fetch
 static int residual_norms(nk_solver *S, const double *stall_partials, int stall_n, double *step_norm,
-                          const std::function<int()> &before_wait = nullptr) {
+                          const std::function<int()> &before_wait = nullptr, int have_partials = 0) {
   double v[3] = {0, 0, 0};
-  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v, before_wait));
+  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v, before_wait, have_partials));
   S->fnorm_inf = v[0];
   S->fnorm2 = sqrt(v[1]);
   if (step_norm) *step_norm = sqrt(v[2]);
@@ -1720,8 +1720,13 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
   double duJJdu = NAN;
   // plain Newton step: the update takes x of J x = fu as it is (u − x), sparing the δu = −x pass
   const bool fold_sign = !is_tr(S) && !S->o.linesearch;
+  // plain Newton through GMRES: u_new = u − x is formed by the pass that forms x (nk_gmres_arm_fused_update)
+  const bool fuse_update = fold_sign && !direct(S) && !is_pt(S) && !normal_form(S) && S->G != nullptr;
+  if (fuse_update) nk_gmres_arm_fused_update(S->G, S->u, spare_u(S), -1.0, ctx->d_partials_ss);
   if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu, new_jacobian, &have_JTfu));
   else NK_TRY(newton_descent(S, S->du, &ok, new_jacobian, !fold_sign));
+  int fused_grid = 0;
+  const bool update_fused = fuse_update && nk_gmres_take_fused_update(S->G, &fused_grid) && ok;
   if (!ok) {
     if (new_jacobian) {
       S->retcode = NK_RET_INTERNAL_LINEAR_SOLVE_FAILED;
@@ -1766,9 +1771,9 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       }
       if (alpha != 1.0) NK_TRY(nk_blas_lincomb(ctx, n, alpha, S->du, 0.0, S->du, S->du));  // δu ← α δu, then u += δu
     }
-    const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
+    const int grid = update_fused ? fused_grid : nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
     double *un = spare_u(S);
-    {
+    if (!update_fused) {
       nk_prof_scope prof_(ctx, NK_K_NEWTON_UPDATE, 24.0 * (double)n);
       NK_LAUNCH(ctx, k_newton_update, dim3(grid), dim3(NK_BLOCK), n, fold_sign ? -1.0 : 1.0, (const double *)S->du,
                 (const double *)S->u, un, ctx->d_partials_ss);
@@ -1781,11 +1786,14 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       S->fu_deferred = true;
       return NK_OK;
     }
-    NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
+    int norm_grid = 0;   // (> 0: the residual kernel has left the norms' stage-1 partials in ctx->d_partials)
+    NK_TRY(nk_problem_residual_norms_dev(S->P, S->u, S->fu, ctx->d_partials, &norm_grid));
+    if (norm_grid == 0) NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
     S->stats.nf++;
     // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch — and behind the kernels that produce them, before the host waits, the next step's
     // Jacobian values (speculate_J)
-    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm, [S]() -> int { return speculate_J(S, S->u, S->u_version); }));
+    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm, [S]() -> int { return speculate_J(S, S->u, S->u_version); },
+                          norm_grid));
     if (S->o.store_trace) {
       NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
       double v;

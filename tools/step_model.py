@@ -29,8 +29,11 @@ def spmv_bytes(n, nnz):
     return 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
 
 
-def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True):
+def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True,
+                  fused_tail=True):
     """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order.
+    fused_tail (round 5): the Newton update u_new = u − x rides in the pass that forms x = V y (k_multiaxpy), and the residual
+    kernel leaves the stage-1 partials of its own norms — no k_newton_update, no k_absmax_sumsq launch.
     deferred (round 5, the default with the implicit second pass): a block's second factorisation rides in the NEXT block's scalar
     launch (k_ss_job), the previous block's Hessenberg columns in workgroup 0 of this block's sweep B, and the cycle's last scalar
     launch also back-substitutes — three k_ss_job launches per two-block cycle where rounds 3–4 had four k_ss_reduce_factor,
@@ -71,10 +74,14 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
         add("k_ss_job", 0)                                      # the cycle's last launch: reduce, factor, Hessenberg columns, y
     else:
         add("k_backsolve", 0)
-    add("k_multiaxpy", 8.0 * n * (m + 2))                       # x = V y: m + 1 columns read, x written
-    add("k_newton_update", 24.0 * n)
-    add("k_bratu_residual", 16.0 * n)
-    add("k_absmax_sumsq", 8.0 * n)
+    if fused_tail:
+        add("k_multiaxpy", 8.0 * n * (m + 4))                   # x = V y (m + 1 columns read, x written) + u read, u_new written
+        add("k_bratu_residual_norms", 16.0 * n)                 # f(u_new) and the partials of ‖f‖∞, ‖f‖₂²
+    else:
+        add("k_multiaxpy", 8.0 * n * (m + 2))                   # x = V y: m + 1 columns read, x written
+        add("k_newton_update", 24.0 * n)
+        add("k_bratu_residual", 16.0 * n)
+        add("k_absmax_sumsq", 8.0 * n)
     add("k_reduce_inf2", 0)
     return L
 
