@@ -771,7 +771,12 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
   const bool hw = FUSE && gstream > 1 && njob == 0;
   const int nwk = gstream - (hw ? 1 : 0), me = (int)blockIdx.x - (hw ? 1 : 0);
   const int tpw = (ntiles + nwk - 1) / nwk;
-  const int tile0 = me >= 0 ? me * tpw : 0, tile1 = me >= 0 ? min(tile0 + tpw, ntiles) : 0;
+  int tile0 = me >= 0 ? me * tpw : 0, tile1 = me >= 0 ? min(tile0 + tpw, ntiles) : 0;
+  if (njob > 0) {   // workgroups given up to a hosted job: ⌊tiles/nwk⌋ or one more each, so that none of the rest idles
+    const int base = ntiles / nwk, rem = ntiles % nwk;
+    tile0 = me * base + min(me, rem);
+    tile1 = tile0 + base + (me < rem ? 1 : 0);
+  }
   auto process = [&](double (&vr)[NVR], double (&w)[S], int tile, bool valid, auto &&mid) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const bool ok = valid && r < n;
