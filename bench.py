@@ -177,7 +177,8 @@ def bytes_per_step(args, n, nnz, newton_basis, resident_powers):
         return step_model.step_bytes(n, nnz, arnoldi=args.arnoldi, s=s, matfree=args.matfree, resident_powers=resident_powers,
                                      newton_basis=newton_basis, implicit=newton_basis and os.environ.get("NK_SS_IMPLICIT", "1") != "0",
                                      fused_tail=os.environ.get("NK_FUSED_UPDATE", "1") != "0" and
-                                     os.environ.get("NK_FUSED_RESIDUAL_NORMS", "1") != "0")
+                                     os.environ.get("NK_FUSED_RESIDUAL_NORMS", "1") != "0" and
+                                     os.environ.get("NK_PRELOADED_RHS", "1") != "0")
     b_op = 24.0 * n if args.matfree else step_model.spmv_bytes(n, nnz)
     m = args.arnoldi
     krylov = sum(b_op + 8.0 * n * (k + 2) + 8.0 * n * (k + 4) for k in range(m))    # delayed CGS2: two sweeps per column

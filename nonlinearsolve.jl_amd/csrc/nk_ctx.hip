@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 
@@ -532,6 +533,43 @@ extern "C" int nk_comm_unique_id(char id_out[128]) {
   memcpy(id_out, id.internal, 128);
   return NK_OK;
 }
+// Do several ranks run on one device? Every rank contributes a hash of its device's PCI bus id (and host name) in its own slot
+// of a vector that is summed over the ranks; equal entries = a shared device. Collective; the verdict is the same on every rank.
+// Why it matters: (1) two processes whose persistent kernels wait for each other (the resident matrix-powers kernel over the
+// peer arenas) each need the whole device — on one device they only advance when the scheduler preempts one for the other, or
+// not at all; (2) measured on this pool (profiles/r05_m_shared_device.txt): with two processes time-slicing one MI355X, 9 of 41
+// two-rank runs whose sweep B was k_ss_block_mm<15, 16> (the one sweep whose workgroups hold more than 64 KB of LDS: 65.8 KB, and
+// the longest kernel of the cycle) ended with a residual off by 3 – 40 % or hung in the base transport, whatever the transport;
+// with the ≤ 64 KB substitution form of that sweep 0 of 38 did (3 took the breakdown fallback and agreed to 1e-12). The same
+// kernel in a process that has the device to itself is bit-reproducible run after run. A preempted wavefront's state is
+// apparently not always restored on this pool; nothing a kernel can do about — so the form most exposed is not used there.
+static int comm_detect_shared_device(nk_ctx *ctx) {
+  ctx->device_shared = false;
+  if (ctx->nranks <= 1) return NK_OK;
+  if (const char *e = getenv("NK_DEVICE_SHARED")) { ctx->device_shared = atoi(e) != 0; return NK_OK; }   // (override, both ways)
+  char bus[64] = {0}, host[256] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device) != hipSuccess) { (void)hipGetLastError(); return NK_OK; }
+  gethostname(host, sizeof(host) - 1);
+  uint64_t h = 1469598103934665603ull;
+  for (const char *p = host; *p; ++p) h = (h ^ (unsigned char)*p) * 1099511628211ull;
+  for (const char *p = bus; *p; ++p) h = (h ^ (unsigned char)*p) * 1099511628211ull;
+  const double mine = (double)(h >> 12);   // 52 bits: exact in a double, and a sum with zeros keeps it exact
+  const int P = ctx->nranks;
+  std::vector<double> tab((size_t)P, 0.0);
+  tab[ctx->rank] = mine;
+  double *d = nullptr;
+  NK_TRY(nk_dev_alloc(&d, (size_t)P));
+  NK_HIP(hipMemcpy(d, tab.data(), (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+  int st = comm_allreduce_base(ctx, d, P, 0);
+  if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
+  if (st == NK_OK && hipMemcpy(tab.data(), d, (size_t)P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = NK_E_HIP;
+  hipFree(d);
+  NK_TRY(st);
+  for (int a = 0; a < P; ++a)
+    for (int b = a + 1; b < P; ++b)
+      if (tab[a] == tab[b]) ctx->device_shared = true;
+  return NK_OK;
+}
 extern "C" int nk_ctx_comm_init_rccl(nk_ctx *ctx, int nranks, int rank, const char id[128]) {
   NK_REQUIRE(ctx && id, "NULL argument");
   NK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
@@ -544,7 +582,7 @@ extern "C" int nk_ctx_comm_init_rccl(nk_ctx *ctx, int nranks, int rank, const ch
   ctx->comm_kind = NK_COMM_RCCL;
   ctx->nranks = nranks;
   ctx->rank = rank;
-  return NK_OK;
+  return comm_detect_shared_device(ctx);
 }
 extern "C" int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, const nk_comm_callbacks *cb) {
   NK_REQUIRE(ctx && cb && cb->allreduce && cb->alltoallv, "NULL argument / callback");
@@ -554,7 +592,7 @@ extern "C" int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, con
   ctx->comm_kind = NK_COMM_CALLBACKS;
   ctx->nranks = nranks;
   ctx->rank = rank;
-  return NK_OK;
+  return comm_detect_shared_device(ctx);
 }
 extern "C" int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank) {
   NK_REQUIRE(ctx, "ctx is NULL");

@@ -1598,6 +1598,15 @@ int nk_gmres_solve_dev(nk_gmres *G, const double *d_b, double *d_x, int use_x0, 
   }
   return rc;
 }
+static bool gmres_can_preload(const nk_gmres *G) {
+  static const bool off = (getenv("NK_PRELOADED_RHS") && atoi(getenv("NK_PRELOADED_RHS")) == 0) ||
+                          (getenv("NK_SS_FUSED_BEGIN") && atoi(getenv("NK_SS_FUSED_BEGIN")) == 0) || getenv("NK_GMRES_GRAPH");
+  return !off && nk_ctx_is_single(G->ctx) && G->ortho == NK_ORTHO_SSTEP && !G->lprec_kind && !G->normal && G->V != nullptr;
+}
+double *nk_gmres_rhs_column(nk_gmres *G) { return gmres_can_preload(G) ? G->V : nullptr; }
+void nk_gmres_preloaded_rhs(nk_gmres *G, const double *d_b, const double *ss_partials, int grid) {
+  G->pre.b = d_b; G->pre.ss = ss_partials; G->pre.grid = grid;
+}
 void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, double usign, double *partials) {
   G->fu = nk_fused_update{};
   G->fu.u_old = u_old; G->fu.u_new = u_new; G->fu.usign = usign; G->fu.partials = partials;
@@ -1649,8 +1658,11 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
   // ‖b‖² in one pass, and the first solution update WRITES x = V y (no memset of x)
   bool have_ss = false, x_is_zero = false;
   static const bool fused_begin_off = getenv("NK_SS_FUSED_BEGIN") && atoi(getenv("NK_SS_FUSED_BEGIN")) == 0;   // A/B switch
-  bool ss_from_partials = false;   // ‖b‖² is still per-workgroup partial sums in ctx->d_partials
+  bool ss_from_partials = false;   // ‖b‖² is still per-workgroup partial sums (in ctx->d_partials, or where the producer of b left them)
+  const double *ss_partials = ctx->d_partials;
   int ss_grid = 0;
+  const auto pre = G->pre;
+  G->pre = {};   // (one solve)
   // with a left preconditioner every residual that enters the basis is Pl⁻¹(b − A x): the norms of the solve are preconditioned
   auto residual_to_v0 = [&]() -> int {   // column 0 ← Pl⁻¹ (b − A x), x in the original space
     NK_TRY(op_apply_raw(G, d_x, G->r, nullptr, nullptr));
@@ -1668,6 +1680,11 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
     if (!fused_begin_off && nk_ctx_is_single(ctx) && G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
       // the s-step form's begin kernel reduces the partial sums itself (one rank)
       ss_from_partials = true;
+      if (pre.b == d_b && pre.grid > 0 && gmres_can_preload(G)) {   // b is in column 0 already (nk_gmres_preloaded_rhs)
+        ss_partials = pre.ss;
+        ss_grid = pre.grid;
+        return NK_OK;
+      }
       return nk_blas_copy_sumsq_stage1(ctx, n, d_b, G->V, &ss_grid);
     }
     return nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss);
@@ -1692,10 +1709,10 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
     const uint64_t seq = ++G->cycle_seq;
     if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
       NK_TRY(nk_ss_begin_cycle(G, atol, rtol, fixed_iters > 0 ? 1 : 0, first, seq,
-                               ss_from_partials ? (const double *)ctx->d_partials : nullptr, ss_grid));
+                               ss_from_partials ? ss_partials : nullptr, ss_grid));
     } else {
       if (ss_from_partials)   // (a breakdown switched the solve to the column form between rhs → column 0 and this cycle)
-        NK_TRY(nk_blas_reduce_slots_allreduce(ctx, ctx->d_partials, ss_grid, 1, G->d_ss, nullptr));
+        NK_TRY(nk_blas_reduce_slots_allreduce(ctx, ss_partials, ss_grid, 1, G->d_ss, nullptr));
       NK_LAUNCH(ctx, k_gmres_begin, dim3(1), dim3(64), G->d_ctl, G->d_ss, atol, rtol,
                 fixed_iters > 0 ? 1 : 0, first, G->d_g, G->d_s, m, G->h_pub_dev, seq);
     }

@@ -138,6 +138,9 @@ struct nk_ctx {
   hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;
   int deterministic = 1;
   int num_cus = 256;
+  // several ranks of this communicator run on ONE device (processes time-slicing a GPU: development boxes, CI): forms that need
+  // every workgroup of a launch resident at once, or more than 64 KB of LDS per workgroup, are not used then (nk_ctx.hip)
+  bool device_shared = false;
   // communicator
   int comm_kind = NK_COMM_NONE, nranks = 1, rank = 0;
   void *rccl_comm = nullptr;
@@ -358,7 +361,8 @@ int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, d
 int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out);
 int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi);
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
-int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out);
+int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out,
+                                  double *f_copy = nullptr, double *ss_copy = nullptr);
 // forget what the problem was linearised at: the caller wrote new contents into a buffer it may have been keyed on
 static inline void nk_problem_invalidate(nk_problem *P) { P->d_u_lin = nullptr; P->d_u_linJ = nullptr; }
 int nk_csr_clone_pattern(nk_csr *A, nk_csr **out);  // same pattern and partition, own values (collective on several ranks)
@@ -466,6 +470,7 @@ struct nk_gmres {
   double *V = nullptr, *w = nullptr, *z = nullptr, *r = nullptr;
   double *x0_keep = nullptr;   // the warm start of a solve that runs on a resident matrix-powers plan (restored if a launch is torn)
   nk_fused_update fu;          // armed by the Newton driver for ONE solve (nk_gmres_arm_fused_update)
+  struct { const double *b = nullptr, *ss = nullptr; int grid = 0; } pre;   // nk_gmres_preloaded_rhs (one solve)
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
@@ -624,6 +629,12 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
 // The NEXT solve's last pass (x = V y) also forms u_new = u_old + usign·x and the partial sums of ‖u_new − u_old‖² — if that solve
 // is a single cycle from a zero guess without a right preconditioner. nk_gmres_take_fused_update: whether it happened (disarms).
 void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, double usign, double *partials);
+// Column 0 of the basis already holds b, and ss_partials[0 .. grid) sum to ‖b‖² (the kernel that produced b stored it twice):
+// the NEXT solve — if its right-hand side is this b, from a zero guess, in the s-step form on one rank without a left
+// preconditioner — skips the pass that copies b there. nk_gmres_rhs_column: where that kernel writes; NULL if this object's
+// next solve could not use it anyway.
+double *nk_gmres_rhs_column(nk_gmres *G);
+void nk_gmres_preloaded_rhs(nk_gmres *G, const double *d_b, const double *ss_partials, int grid);
 bool nk_gmres_take_fused_update(nk_gmres *G, int *grid);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);

@@ -685,7 +685,8 @@ static int pw_plan_ranks(nk_csr *A) {
   const int64_t n = A->nrows;
   const int nh = (int)A->halo_gcols.size();
   std::vector<int32_t> hvl(nh > 0 ? nh : 1, 0), vcol;
-  bool ok = pw_enabled() && ctx->peer.on && n >= PW_T && A->nnz >= 1;
+  // (ranks sharing a device: each rank's kernel wants every CU while it waits for the other's — not there; nk_ctx.hip)
+  bool ok = pw_enabled() && ctx->peer.on && !ctx->device_shared && n >= PW_T && A->nnz >= 1;
   static const bool ranks_off = getenv("NK_PW_RANKS") && atoi(getenv("NK_PW_RANKS")) == 0;   // A/B switch
   ok = ok && !ranks_off;
   for (int h = 0; h < nh && ok; ++h) {

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual(int64_t ns, int64_t
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual_norms(int64_t ns, int64_t nl, double c_lap, double c_exp,
                                                                    const double *__restrict__ u, const double *__restrict__ lo,
                                                                    const double *__restrict__ hi, double *__restrict__ f,
-                                                                   double *__restrict__ partials) {
+                                                                   double *__restrict__ partials, double *__restrict__ f_copy,
+                                                                   double *__restrict__ ss_copy) {
+  // f_copy / ss_copy (nullable): f once more — into column 0 of the Krylov basis the next linear solve starts from — and the
+  // Σ f² partials once more, where that solve's first kernel finds ‖b‖² (nk_gmres_preloaded_rhs)
   __shared__ double sm[8];
   double m = 0.0, s = 0.0;
   const int64_t n = ns * nl, stride = (int64_t)gridDim.x * NK_BLOCK;
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual_norms(int64_t ns, i
     const int64_t jl = k / ns, i = k - jl * ns;
     const double v = c_lap * bratu_lap(u, lo, hi, ns, nl, i, jl, k) - c_exp * exp(u[k]);
     f[k] = v;
+    if (f_copy) f_copy[k] = v;
     const double av = fabs(v);
     m = (m != m || av != av) ? __builtin_nan("") : (m > av ? m : av);
     s += v * v;
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual_norms(int64_t ns, i
     auto nmax = [](double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); };
     partials[blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
     partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+    if (ss_copy) ss_copy[blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
   }
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_diag(int64_t n, double c_exp, const double *__restrict__ u,
@@ -547,19 +552,20 @@ extern "C" int nk_problem_set_params(nk_problem *P, const double *params, int np
 // ---------------------------------------------------------------------------- device-level operations
 // f(u) and the stage-1 partials of ‖f‖∞, ‖f‖₂² in ONE launch, where the problem has such a kernel: *grid_out = the number of
 // workgroups (partials laid out as k_absmax_sumsq leaves them), 0 = not available (nothing was launched).
-int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out) {
+int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out, double *f_copy,
+                                  double *ss_copy) {
   static const bool off = getenv("NK_FUSED_RESIDUAL_NORMS") && atoi(getenv("NK_FUSED_RESIDUAL_NORMS")) == 0;   // A/B switch
   *grid_out = 0;
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
   if (off || n == 0 || P->kind != NK_PROBLEM_BRATU2D) return NK_OK;
   const int grid = nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);   // (k_absmax_sumsq's grid: nk_blas_norms_inf2)
-  nk_prof_scope prof_(ctx, NK_K_RESIDUAL, 16.0 * (double)n);
+  nk_prof_scope prof_(ctx, NK_K_RESIDUAL, (f_copy ? 24.0 : 16.0) * (double)n);
   const double *lo, *hi;
   NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
   halo_lines(P, 1, false, &lo, &hi);
   NK_LAUNCH(ctx, k_bratu_residual_norms, dim3(grid), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->c_lap, P->c_exp, d_u, lo, hi, d_f,
-            partials);
+            partials, f_copy, ss_copy);
   NK_HIP(hipGetLastError());
   *grid_out = grid;
   return NK_OK;

@@ -72,6 +72,13 @@ struct nk_solver {
   // trip. The live J is untouched until the next step takes the set (refresh_J); a solve that terminates never sees it.
   bool spec_valid = false;
   uint64_t spec_version = 0, spec_params = 0;
+  // the step's last residual kernel also wrote f into column 0 of the Krylov basis and its Σ f² partials into d_rhs_ss: the next
+  // step's linear solve starts from them if nothing has moved since (nk_gmres_preloaded_rhs)
+  double *d_rhs_ss = nullptr;
+  bool pre_valid = false;
+  uint64_t pre_uver = 0, pre_params = 0;
+  const double *pre_fu = nullptr;
+  int pre_grid = 0;
   const double *spec_u = nullptr;               // the iterate the set was filled at
   nk_csr_valstate spec_state{};                 // the filled set (valid) / the spare buffers (not valid)
   nk_precs_fn precs = nullptr;
@@ -669,6 +676,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
                     S->Jdu, S->JTfu, S->c1, S->c2, S->tr_du, S->stage, S->stage2, S->lm_dtd, S->lm_diag, S->lm_v,
                     S->lm_a, S->lm_vcache, S->lm_rhs, S->pt_mass};
   for (double *b : bufs) hipFree(b);
+  hipFree(S->d_rhs_ss);
   hipFree(S->spec_state.d_val);     // (whichever value set is the spare one now; the live one belongs to J)
   hipFree(S->spec_state.d_gersh);
   nk_gmres_destroy(S->G);
@@ -800,6 +808,9 @@ static int newton_descent(nk_solver *S, double *du_out, bool *ok, bool new_jacob
     NK_TRY(nk_gmres_set_normal_form(S->G, 1));
     rhs = S->JTfu;
   }
+  if (S->pre_valid && S->pre_uver == S->u_version && S->pre_fu == rhs && S->pre_params == S->P->params_version)
+    nk_gmres_preloaded_rhs(S->G, rhs, S->d_rhs_ss, S->pre_grid);
+  S->pre_valid = false;
   NK_TRY(nk_gmres_solve_dev(S->G, rhs, du_out, 0, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters,
                             S->o.gmres_fixed_iters, &info));
   S->last_gmres_iters = info.iters;
@@ -1787,7 +1798,14 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
       return NK_OK;
     }
     int norm_grid = 0;   // (> 0: the residual kernel has left the norms' stage-1 partials in ctx->d_partials)
-    NK_TRY(nk_problem_residual_norms_dev(S->P, S->u, S->fu, ctx->d_partials, &norm_grid));
+    // … and, for the next step's linear solve (plain Newton: its right-hand side is this f), f in column 0 of the Krylov basis
+    double *v0 = (fold_sign && !direct(S) && !is_pt(S) && !normal_form(S) && S->G != nullptr) ? nk_gmres_rhs_column(S->G) : nullptr;
+    if (v0 != nullptr && S->d_rhs_ss == nullptr) NK_TRY(nk_dev_alloc(&S->d_rhs_ss, (size_t)NK_MAX_RED_BLOCKS));
+    NK_TRY(nk_problem_residual_norms_dev(S->P, S->u, S->fu, ctx->d_partials, &norm_grid, v0, v0 ? S->d_rhs_ss : nullptr));
+    S->pre_valid = norm_grid > 0 && v0 != nullptr;
+    if (S->pre_valid) {
+      S->pre_uver = S->u_version; S->pre_params = S->P->params_version; S->pre_fu = S->fu; S->pre_grid = norm_grid;
+    }
     if (norm_grid == 0) NK_TRY(nk_problem_residual_dev(S->P, S->u, S->fu));
     S->stats.nf++;
     // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch — and behind the kernels that produce them, before the host waits, the next step's

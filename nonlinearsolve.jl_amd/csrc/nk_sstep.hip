@@ -1226,7 +1226,9 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   int g = grid + (hjp ? hjv.host_wgs : 0);
   if constexpr (S == 15) {
     static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);   // A/B switch
-    if (mode == 1 && mm_on && (k == 1 || k == 16) && (occ_out || (int64_t)S * ldv * 8 < ((int64_t)1 << 32) - 8)) {
+    // (ranks time-slicing one device: no workgroup above 64 KB of LDS — nk_ctx.hip::comm_detect_shared_device)
+    if (mode == 1 && mm_on && !(ctx->device_shared && k == 16) && (k == 1 || k == 16) &&
+        (occ_out || (int64_t)S * ldv * 8 < ((int64_t)1 << 32) - 8)) {
       const size_t tile_b = (size_t)(k + S + 1) * SS_P * sizeof(double);   // the tile + the spare column
       // tap: workgroup 0 hosts the previous block's Hessenberg work (hk, hs); its workspace overlays the tile it does not use
       const bool hostB = tap != nullptr && !occ_out;
@@ -2347,7 +2349,8 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       }
       // where the pending block's Hessenberg columns are derived: in workgroup 0 of this block's sweep B when nothing can stop
       // the cycle early (fixed work) and that sweep has the hosting form; else in the job itself (the verdict arrives before sweep B)
-      const bool host_b = !host_a && dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) && (hess_where < 0 ? fixed_work : hess_where == 1);
+      const bool host_b = !host_a && dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) && !(ctx->device_shared && k == 16) &&
+                          (hess_where < 0 ? fixed_work : hess_where == 1);
       {
         ss_job j = jb;
         j.part0 = W->part; j.nblk0 = grid_a; j.nslots0 = nslots; j.k0 = k; j.sb0 = sb;

@@ -568,7 +568,8 @@ def test_rccl_entry_points_world1():
 # ----------------------------------------------------------------------------- the resident matrix-powers kernel on several ranks
 def _powers_worker(rank, world, port, q, ns, pw_ranks):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NK_PW_RANKS=pw_ranks)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NK_PW_RANKS=pw_ranks,
+                      NK_DEVICE_SHARED="0")   # (the ranks DO share this GPU: at these sizes all their workgroups fit on it together)
     import hashlib
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -475,13 +475,13 @@ _SWITCH_CODE = (
 @pytest.mark.parametrize("env", [dict(NK_SS_DEFER="0"), dict(NK_SS_DEFER_HESS="0"), dict(NK_SS_DEFER_HESS="1"),
                                  dict(NK_SS_TAIL_BACK="0"), dict(NK_SS_HOST_B="0"), dict(NK_SS_IMPLICIT="0"),
                                  dict(NK_SS_FUSED="0"), dict(NK_SS_HOST_A="0"), dict(NK_SS_HOST_A_WGS="2"),
-                                 dict(NK_FUSED_UPDATE="0", NK_FUSED_RESIDUAL_NORMS="0")])
+                                 dict(NK_FUSED_UPDATE="0", NK_FUSED_RESIDUAL_NORMS="0"), dict(NK_PRELOADED_RHS="0")])
 def test_every_form_behind_an_ab_switch_reaches_the_same_iterates(env):
     """The s-step cycle's forms that the defaults do not take — the second factorisation in a launch of its own (round 4's cycle),
     the Hessenberg work inside the scalar launch / hosted by sweep B whatever the protocol, the back-substitution as a launch of
     its own, the explicit third sweep, the unfused scalar launches, the first block closed by a launch of its own instead of by
     workgroups of the second block's sweep A (and, at this size, the reverse: two hosted workgroups where the default grid is too
-    small to give any up), the Newton update and the residual's norms as launches of their own — are the same arithmetic in another order: four Newton steps
+    small to give any up), the Newton update and the residual's norms as launches of their own, the right-hand side copied into the basis by a pass of its own — are the same arithmetic in another order: four Newton steps
     (fixed work at 96², and GMRES to a tight tolerance at 24² — tight and small so that the linear solves are converged, not cut
     off at the iteration cap: two restarted solves cut off there differ by what rounding does to ten restart cycles) leave iterates
     equal to the default's to rounding."""

@@ -41,7 +41,7 @@ def test_a_timeline_of_the_current_dispatch_is_committed():
     Round 4's tracked kernel statistics lagged HEAD by three kernel commits (Weak #6)."""
     model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15)]
     assert "k_ss_job" in model and "k_backsolve" not in model       # round 5's dispatch
-    assert "k_newton_update" not in model and "k_bratu_residual_norms" in model
+    assert "k_newton_update" not in model and "k_bratu_residual_norms" in model and "k_copy_sumsq" not in model
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]_*step_timeline.md")))
     assert any(_timeline_kernels(p) == model for p in paths), \
         "no committed profiles/r05_*step_timeline.md matches the current dispatch: rerun tools/gpu_r05_evidence.sh and copy it"
@@ -65,9 +65,10 @@ def test_byte_counts_of_the_headline_step():
     hbm_i, alg_i = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, fused_tail=False)     # no sweep C for the first block either
     assert hbm_i == hbm_r - 8 * N * 31 and alg_i == alg_r - 8 * N * 31
     assert (hbm_i, alg_i) == step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, deferred=False, fused_tail=False)   # same bytes
-    # round 5's tail: x is not read back for the update (−8 n), f is not read back for its norms (−8 n)
+    # round 5's tail: x is not read back for the update (−8 n), f is not read back for its norms (−8 n) nor for the copy into
+    # the basis (−16 n for that pass, + 8 n for the second store of f)
     hbm_f, alg_f = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True)
-    assert hbm_f == hbm_i - 16 * N and alg_f == alg_i - 16 * N
+    assert hbm_f == hbm_i - 24 * N and alg_f == alg_i - 24 * N
 
 
 def test_canonical_names():

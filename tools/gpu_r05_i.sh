@@ -6,9 +6,10 @@ O=gpurun_out/$TAG; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_solvers.py tests/test_gpu_sstep.py tests/test_gpu_fullsize.py tests/test_gpu_linesearch.py tests/test_gpu_multirank.py -q -x < /dev/null > $O/pytest_core.log 2>&1; tail -8 $O/pytest_core.log
 B="--cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --steps 200 --warmup 20 --no-profile-pass"
 for rep in 1 2 3; do
+NK_PRELOADED_RHS=0 timeout 200 python bench.py $B < /dev/null > $O/bench_nopre_$rep.json 2> /dev/null
 timeout 200 python bench.py $B < /dev/null > $O/bench_default_$rep.json 2> $O/bench_default.err
-NK_FUSED_UPDATE=0 timeout 200 python bench.py $B < /dev/null > $O/bench_noupd_$rep.json 2> /dev/null
-NK_FUSED_RESIDUAL_NORMS=0 timeout 200 python bench.py $B < /dev/null > $O/bench_nonorms_$rep.json 2> /dev/null
+
+
 NK_FUSED_UPDATE=0 NK_FUSED_RESIDUAL_NORMS=0 timeout 200 python bench.py $B < /dev/null > $O/bench_neither_$rep.json 2> /dev/null
 done
 timeout 200 python bench.py $B --matfree < /dev/null > $O/bench_matfree.json 2> /dev/null
