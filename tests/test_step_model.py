@@ -31,7 +31,8 @@ def test_model_lists_exactly_the_launches_of_the_committed_timeline(path):
     assert ks, path
     resident, implicit, deferred = "k_spmv_powers" in ks, "k_ss_block<C>" not in ks, "k_ss_job" in ks
     model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15, resident_powers=resident, implicit=implicit,
-                                                            deferred=deferred, fused_tail="k_newton_update" not in ks)]
+                                                            deferred=deferred, fused_tail="k_newton_update" not in ks,
+                                                            preloaded_rhs="k_copy_sumsq" not in ks)]
     assert ks == model, f"{os.path.basename(path)}: the step launches\n{ks}\nthe model charges for\n{model}"
 
 

@@ -30,7 +30,7 @@ def spmv_bytes(n, nnz):
 
 
 def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True,
-                  fused_tail=True):
+                  fused_tail=True, preloaded_rhs=True):
     """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order.
     fused_tail (round 5): the Newton update u_new = u − x rides in the pass that forms x = V y (k_multiaxpy), and the residual
     kernel leaves the stage-1 partials of its own norms and a second copy of f in column 0 of the Krylov basis — no
@@ -48,8 +48,9 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
 
     if not matfree:
         add("k_bratu_jac", 8.0 * nnz + 8.0 * n)                 # u in, values out (the Gershgorin partials ride along)
-    if not fused_tail:
-        add("k_copy_sumsq", 16.0 * n)                           # b → column 0, ‖b‖² (fused tail: the residual kernel left both)
+    preloaded_rhs = preloaded_rhs and fused_tail
+    if not preloaded_rhs:
+        add("k_copy_sumsq", 16.0 * n)                           # b → column 0, ‖b‖² (preloaded: the residual kernel left both)
     add("k_ss_cycle_begin", 0)
     b_op = 24.0 * n if matfree else spmv_bytes(n, nnz)
     blocks = sstep_blocks(m, s)
@@ -78,7 +79,8 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
         add("k_backsolve", 0)
     if fused_tail:
         add("k_multiaxpy", 8.0 * n * (m + 4))                   # x = V y (m + 1 columns read, x written) + u read, u_new written
-        add("k_bratu_residual_norms", 24.0 * n)                 # f(u_new) — twice: fu and column 0 of the next solve's basis — and the partials of ‖f‖∞, ‖f‖₂²
+        # f(u_new) and the partials of ‖f‖∞, ‖f‖₂² — preloaded_rhs: f stored twice (fu and column 0 of the next solve's basis)
+        add("k_bratu_residual_norms", (24.0 if preloaded_rhs else 16.0) * n)
     else:
         add("k_multiaxpy", 8.0 * n * (m + 2))                   # x = V y: m + 1 columns read, x written
         add("k_newton_update", 24.0 * n)
