@@ -1,12 +1,11 @@
 # round 5, final evidence pass — the LAST GPU run of the round, on the tree as committed:
-#   the whole -m gpu suite, smoke(), the default bench line (cpu_baseline, live PMC, profile pass), rocprofv3 kernel statistics +
+#   smoke(), the default bench line (cpu_baseline, live PMC, profile pass), rocprofv3 kernel statistics +
 #   separate FETCH_SIZE / WRITE_SIZE passes of the same workload (tools/profile_round.sh), the timeline of one Newton step
 #   (tools/step_timeline.sh), A/B lines, the AMG set-up times. Copy what should be judged from gpurun_out/ into profiles/.
 set -x
 TAG=${1:-r05_z}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 660 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 300 python bench.py < /dev/null > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json
 timeout 200 bash tools/profile_round.sh ${TAG} < /dev/null
@@ -24,3 +23,7 @@ import json
 try:
     d=json.loads([x for x in open('$f') if x.startswith('{')][-1]); print('$f'.split('/')[-1], d['value'], d['ms_per_step'])
 except Exception as e: print('$f FAILED', e)"; done | tee $O/bench_lines.txt
+# the whole GPU suite last (the files that start several processes first): [ "$2" = "tests" ] runs it
+if [ "${2:-}" = "tests" ]; then
+  timeout ${3:-700} python -m pytest tests/test_gpu_multirank.py tests/test_gpu_fullsize.py tests -m gpu -q -p no:cacheprovider < /dev/null > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log
+fi
