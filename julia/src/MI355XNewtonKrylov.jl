@@ -170,7 +170,7 @@ bratu2d(n; λ = 6.0, scale = 0.0, kw...) = DeviceProblem(2, Float64[n, λ, scale
 brusselator2d(N; A = 3.4, B = 1.0, α = 10.0, dx = 1 / (N - 1), kw...) = DeviceProblem(3, Float64[N, A, B, α, dx]; kw...)
 
 # ------------------------------------------------------------------ preconditioner objects (what `precs(A, p)` may return)
-"""`DeviceILU0(A::DeviceCSR; ordering = :multicolor)` / `DeviceJacobi(A)`: nk_precond objects — usable as `Pl` or `Pr` of
+"""`DeviceILU0(A::DeviceCSR; ordering = :multicolor)` / `DeviceJacobi(A)` / `DeviceILUT(A; τ)` / `DeviceAMG(A; …)`: nk_precond objects — usable as `Pl` or `Pr` of
 `MI355XGMRES` without a host round trip per application, and as `ldiv!(y, P, x)` on host or resident vectors."""
 mutable struct DevicePreconditioner
     ptr::Ptr{Cvoid}
@@ -186,6 +186,38 @@ end
 function DeviceJacobi(A::DeviceCSR)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     nkcheck(@ccall libnk.nk_precond_create_jacobi(A.ptr::Ptr{Cvoid}, out::Ptr{Ptr{Cvoid}})::Cint)
+    p = DevicePreconditioner(out[], A)
+    finalizer(x -> @ccall(libnk.nk_precond_destroy(x.ptr::Ptr{Cvoid})::Cint), p)
+    return p
+end
+"""`DeviceILUT(A::DeviceCSR; τ)`: threshold ILU with fill — the tutorial's `IncompleteLU.ilu(W, τ = 50.0)`
+(docs/src/tutorials/large_systems.md:252-260): Crout ILU(τ), factorised on the host for every `update!` (the pattern depends on the
+numbers), applied on the device by level-scheduled triangular solves."""
+function DeviceILUT(A::DeviceCSR; τ::Real)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    nkcheck(@ccall libnk.nk_precond_create_ilut(A.ptr::Ptr{Cvoid}, Float64(τ)::Cdouble, out::Ptr{Ptr{Cvoid}})::Cint)
+    p = DevicePreconditioner(out[], A)
+    finalizer(x -> @ccall(libnk.nk_precond_destroy(x.ptr::Ptr{Cvoid})::Cint), p)
+    return p
+end
+# nk_amg_params (include/mi355x_nk.h): four 32-bit integers, three doubles; zero fields take the library's defaults
+struct AMGParams
+    nu::Int32
+    passes::Int32
+    coarse_max::Int32
+    matching::Int32      # 0 automatic, 1 sequential pairwise pass (host set-up), 2 handshaking (device set-up)
+    theta::Float64
+    overcorrection::Float64
+    cheb_ratio::Float64
+end
+"""`DeviceAMG(A::DeviceCSR; nu, passes, theta, overcorrection, cheb_ratio, coarse_max, matching)`: aggregation algebraic multigrid
+built from the matrix alone, its hierarchy set up on the device — the slot of `aspreconditioner(ruge_stuben(W))`
+(large_systems.md:276-316); `update!` refreshes every number for the matrix's current values and keeps the aggregates."""
+function DeviceAMG(A::DeviceCSR; nu::Integer = 0, passes::Integer = 0, coarse_max::Integer = 0, matching::Integer = 0,
+                   theta::Real = 0.0, overcorrection::Real = 0.0, cheb_ratio::Real = 0.0)
+    prm = Ref(AMGParams(nu, passes, coarse_max, matching, theta, overcorrection, cheb_ratio))
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    nkcheck(@ccall libnk.nk_precond_create_amg(A.ptr::Ptr{Cvoid}, prm::Ptr{Cvoid}, out::Ptr{Ptr{Cvoid}})::Cint)
     p = DevicePreconditioner(out[], A)
     finalizer(x -> @ccall(libnk.nk_precond_destroy(x.ptr::Ptr{Cvoid})::Cint), p)
     return p
@@ -592,6 +624,6 @@ end
 # callback contract (nk_matvec_fn proper).
 
 export Ctx, DeviceVector, DeviceCSR, DeviceProblem, bratu2d, brusselator2d, mi355x_function, MI355XGMRES,
-    MI355XNewtonKrylovAlg, EnsembleKernel, vectorized_solve, DevicePreconditioner, DeviceILU0, DeviceJacobi, update!, update_values!
+    MI355XNewtonKrylovAlg, EnsembleKernel, vectorized_solve, DevicePreconditioner, DeviceILU0, DeviceILUT, DeviceAMG, DeviceJacobi, update!, update_values!
 
 end # module
