@@ -550,7 +550,7 @@ static int amg_handshake_pass_dev(nk_ctx *ctx, amg_arena &ar, const amg_dcsr &F,
 // their own (kept by the level), else arena memory.
 struct amg_plan { int32_t nc = 0, nnzc = 0; int32_t *crp = nullptr, *cci = nullptr, *gptr = nullptr, *gidx = nullptr; };
 static int amg_galerkin_plan_dev(nk_ctx *ctx, amg_arena &ar, const amg_dcsr &F, const int32_t *cid, const int32_t *mem, int W, int32_t nc,
-                                 bool persist, amg_plan *out) {
+                                 bool persist, amg_plan *out, int32_t **persist_gptr = nullptr, int32_t **persist_gidx = nullptr) {
   int32_t *len, *kptr, *cnt, *crp;
   uint64_t *keys;
   NK_TRY(ar.get(&len, (size_t)nc + 1)); NK_TRY(ar.get(&kptr, (size_t)nc + 1)); NK_TRY(ar.get(&cnt, (size_t)nc + 1));
@@ -561,11 +561,12 @@ static int amg_galerkin_plan_dev(nk_ctx *ctx, amg_arena &ar, const amg_dcsr &F, 
   NK_TRY(amg_scan(ctx, ar, cnt, crp, (int64_t)nc + 1));
   int32_t nnzc = 0;
   NK_TRY(amg_fetch_int(ctx, crp + nc, &nnzc));
-  int32_t *cci, *gptr, *gidx;
+  int32_t *cci, *gptr = nullptr, *gidx = nullptr;
   NK_TRY(ar.get(&cci, (size_t)nnzc + 1));
-  if (persist) {
-    NK_TRY(nk_dev_alloc(&gptr, (size_t)nnzc + 2));
-    NK_TRY(nk_dev_alloc(&gidx, (size_t)F.nnz + 1));
+  if (persist) {   // (the caller's level owns them from the moment they exist: nk_amg_destroy frees what a failed set-up leaves)
+    NK_TRY(nk_dev_alloc(persist_gptr, (size_t)nnzc + 2));
+    NK_TRY(nk_dev_alloc(persist_gidx, (size_t)F.nnz + 1));
+    gptr = *persist_gptr; gidx = *persist_gidx;
   } else {
     NK_TRY(ar.get(&gptr, (size_t)nnzc + 2)); NK_TRY(ar.get(&gidx, (size_t)F.nnz + 1));
   }
@@ -647,9 +648,8 @@ static int amg_setup_device(nk_amg *M, const std::function<void(const char *)> &
     lap("  matching");
     if ((double)nc > 0.8 * (double)F.n) break;   // coarsening stalled: this level is the coarsest
     amg_plan pl;
-    NK_TRY(amg_galerkin_plan_dev(ctx, ar, F, agg, mem, W, nc, true, &pl));
     amg_level &L = M->lv[l];
-    L.d_gptr = pl.gptr; L.d_gidx = pl.gidx;
+    NK_TRY(amg_galerkin_plan_dev(ctx, ar, F, agg, mem, W, nc, true, &pl, &L.d_gptr, &L.d_gidx));
     L.nc = nc;
     // the aggregates: row → coarse row, coarse row → its rows
     NK_TRY(nk_dev_alloc(&L.d_agg, (size_t)F.n + 1));

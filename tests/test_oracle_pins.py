@@ -1056,3 +1056,46 @@ def test_ilut_restatement_is_pinned_by_its_defining_properties():
     x = rng.standard_normal(n)
     errs = [np.linalg.norm(R.ilut_preconditioner(A, tau)(A @ x) - x) for tau in (0.3, 0.05, 0.0)]
     assert errs[2] <= 1e-10 and errs[1] <= errs[0]
+
+
+def test_amg_handshake_matching_is_pinned_by_its_defining_properties():
+    """The device set-up's matching (oracle.amg_handshake_pass; csrc/nk_amg.hip::amg_setup_device) — no reference arithmetic to pin
+    it on (AlgebraicMultigrid.jl is [EXT]), so it is pinned on what defines it: (1) a pass is a MATCHING (aggregates of one or two
+    rows, numbered by their smallest row, every pair an edge of the matrix seen from both ends; an even-sized grid with equal
+    couplings pairs up completely in either tie-break variant); (2) on even-sized and periodic lexicographic grids the hierarchy is
+    the sequential rule's (same sizes, integer-identical aggregates), on an odd-sized grid within 5 % of it; (3) the V-cycle built
+    on it is a fixed linear operator that converges like the sequential one's."""
+    pb = R.Bratu2D(16)
+    A = sp.csr_matrix(pb.jac(np.zeros(pb.n)))
+    A.sort_indices()
+    rp, ci, v = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data
+    for variant in (0, 1):
+        cid, nc = R.amg_handshake_pass(rp, ci, v, 0.25, variant=variant)
+        counts = np.bincount(cid, minlength=nc)
+        assert cid.min() == 0 and cid.max() == nc - 1 and counts.max() <= 2 and counts.min() >= 1
+        first = np.full(nc, pb.n)
+        np.minimum.at(first, cid, np.arange(pb.n))
+        assert np.all(np.diff(first) > 0)                         # numbered by their smallest row
+        for I in np.nonzero(counts == 2)[0]:
+            i, j = np.nonzero(cid == I)[0]
+            assert A[i, j] != 0.0 and A[j, i] != 0.0              # a pair is an edge, seen from both ends
+        assert nc == pb.n // 2                                    # an even grid: whole lines pair up, no singletons
+    for prob, u in ((R.Bratu2D(16), None), (R.Bratu2D(24), 0.3), (R.Brusselator2D(8), None)):
+        n = prob.n
+        J = sp.csr_matrix(prob.jac(np.full(n, u) if u is not None else (prob.u0() if hasattr(prob, "u0") else np.zeros(n))))
+        J.sort_indices()
+        H, G = R.AggregationAMG(J, matching="handshake"), R.AggregationAMG(J, matching="greedy")
+        assert H.sizes() == G.sizes()
+        for a, b in zip(H.levels, G.levels):
+            assert np.array_equal(a["agg"], b["agg"])
+    pb = R.Bratu2D(21)                                            # odd-sized: the far-first variant keeps the pairs aligned
+    J = sp.csr_matrix(pb.jac(np.zeros(pb.n)))
+    J.sort_indices()
+    H, G = R.AggregationAMG(J, matching="handshake"), R.AggregationAMG(J, matching="greedy")
+    assert abs(H.sizes()[1] - G.sizes()[1]) <= 0.05 * G.sizes()[1]
+    b = np.random.default_rng(0).standard_normal(pb.n)
+    c = np.random.default_rng(1).standard_normal(pb.n)
+    assert np.linalg.norm(H(b + 2.0 * c) - (H(b) + 2.0 * H(c))) <= 1e-12 * np.linalg.norm(H(b))
+    _, ih = R.gmres(lambda z: J @ z, b, restart=30, rtol=1e-8, itmax=200, M=H)
+    _, ig = R.gmres(lambda z: J @ z, b, restart=30, rtol=1e-8, itmax=200, M=G)
+    assert ih.converged and ig.converged and ih.iters <= ig.iters + 4
