@@ -542,7 +542,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "unknowns_global": n_global, "unknowns_per_gpu": n_local, "lambda": 6.0,
                        "arnoldi_steps_per_newton_step": args.arnoldi, "ortho": args.ortho if args.ortho != "sstep" else "sstep_%s_%s" % (args.sstep or "auto", args.sstep_basis),
-                       "parallelism": f"row-range x{world}", "comm": comm, "comm_selfcheck": selfchecks, "halo_overlap": overlap},
+                       "parallelism": f"row-range x{world}", "comm": comm, "comm_selfcheck": selfchecks, "halo_overlap": overlap,
+                       # several ranks on ONE device (a code-path run, not a rate: DESIGN §7)
+                       "ranks_share_a_device": bool(ctx.comm_device_shared()) if world > 1 else False},
             "roofline": roof, "roofline_spmv": roof_spmv, "roofline_step": roof_step, "kernels": ksum, "cpu_baseline": cpu, "time_to_tolerance": ttt, "weak_scaling": weak,
             # against the best SUSTAINED figure the CPU leg produced (the median of its samples or a validation run; scan samples
             # can be bursts a container's CPU quota does not sustain and are reported, not used)

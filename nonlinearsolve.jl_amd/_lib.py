@@ -122,6 +122,7 @@ SIGNATURES = {
     "nk_ctx_comm_init_rccl": (_I, [_P, _I, _I, C.c_char_p]),
     "nk_ctx_comm_init_callbacks": (_I, [_P, _I, _I, C.POINTER(CommCallbacks)]),
     "nk_ctx_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "nk_ctx_comm_device_shared": (_I, [_P, C.POINTER(_I)]),
     "nk_ctx_comm_peer_handle": (_I, [_P, _L, C.c_char_p]),
     "nk_ctx_comm_enable_peer": (_I, [_P, C.c_char_p]),
     "nk_ctx_comm_peer_status": (_I, [_P, C.POINTER(_I), C.POINTER(_L)]),

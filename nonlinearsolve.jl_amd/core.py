@@ -149,6 +149,12 @@ class Context:
         check(L.lib().nk_ctx_comm_info(self._h, C.byref(k), C.byref(n), C.byref(r)))
         return k.value, n.value, r.value
 
+    def comm_device_shared(self) -> bool:
+        """several ranks of the communicator run on one device (processes time-slicing a GPU)"""
+        s = C.c_int(0)
+        check(L.lib().nk_ctx_comm_device_shared(self._h, C.byref(s)))
+        return bool(s.value)
+
     def close(self):
         if self._h:
             L.lib().nk_ctx_destroy(self._h)

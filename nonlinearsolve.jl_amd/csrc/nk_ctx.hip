@@ -594,6 +594,11 @@ extern "C" int nk_ctx_comm_init_callbacks(nk_ctx *ctx, int nranks, int rank, con
   ctx->rank = rank;
   return comm_detect_shared_device(ctx);
 }
+extern "C" int nk_ctx_comm_device_shared(nk_ctx *ctx, int *shared) {
+  NK_REQUIRE(ctx && shared, "NULL argument");
+  *shared = ctx->device_shared ? 1 : 0;
+  return NK_OK;
+}
 extern "C" int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank) {
   NK_REQUIRE(ctx, "ctx is NULL");
   if (kind) *kind = ctx->comm_kind;
