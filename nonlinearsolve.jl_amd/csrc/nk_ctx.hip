@@ -548,12 +548,15 @@ static int comm_detect_shared_device(nk_ctx *ctx) {
   if (ctx->nranks <= 1) return NK_OK;
   if (const char *e = getenv("NK_DEVICE_SHARED")) { ctx->device_shared = atoi(e) != 0; return NK_OK; }   // (override, both ways)
   char bus[64] = {0}, host[256] = {0};
-  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device) != hipSuccess) { (void)hipGetLastError(); return NK_OK; }
+  const bool have_id = hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device) == hipSuccess;
+  if (!have_id) (void)hipGetLastError();
   gethostname(host, sizeof(host) - 1);
   uint64_t h = 1469598103934665603ull;
   for (const char *p = host; *p; ++p) h = (h ^ (unsigned char)*p) * 1099511628211ull;
   for (const char *p = bus; *p; ++p) h = (h ^ (unsigned char)*p) * 1099511628211ull;
-  const double mine = (double)(h >> 12);   // 52 bits: exact in a double, and a sum with zeros keeps it exact
+  // 52 bits: exact in a double, and a sum with zeros keeps it exact. (A rank that cannot name its device still takes part in the
+  //  collective, with a value no other rank can have.)
+  const double mine = have_id ? (double)(h >> 12) : 0.5 + (double)ctx->rank;
   const int P = ctx->nranks;
   std::vector<double> tab((size_t)P, 0.0);
   tab[ctx->rank] = mine;
