@@ -13,6 +13,12 @@
 // HBM traffic per power: the 8 n bytes of the new column. Row sums are formed exactly as the streaming kernel forms them
 // (products rounded, added in CSR order from 0.0, same epilogue), so the columns are BIT-IDENTICAL to s streaming launches.
 //
+// The hand-off is written for gfx950 and says so: boundary rows leave as `sc1` stores (RELAXED agent-scope atomics → write-through
+// past the XCD's L2), the wavefront drains them with `s_waitcnt vmcnt(0)` (on gfx9 vmcnt counts stores as well as loads), a barrier,
+// then the RELAXED agent-scope flag store; the reader polls with `sc1` loads and reads the rows with `sc1` loads. That is a
+// release / acquire pair spelled out instruction by instruction: a compiler-emitted agent-scope release would write back the whole
+// L2 (`buffer_wbl2`) once per power and band — measured in rounds 3–5 as the slow form (MI355X_MICROARCH.md, hand-off forms) —, so
+// the contract is tied to this target, checked by tests that compare every word under uneven load (tests/test_gpu_powers.py).
 // Eligibility (host, once per pattern — nk_csr_powers_plan): one rank, no halo; rows ≤ #CUs × 1024 × RPT_max; every row ≤ W
 // entries; every column of band b inside [first row of b − 1024, last row of b + 1024]. Everything else keeps the streaming
 // kernel. All workgroups must be resident at once (grid ≤ #CUs, one per CU by its LDS footprint); every wait is bounded by a
