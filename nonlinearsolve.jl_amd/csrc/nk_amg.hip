@@ -19,7 +19,6 @@
 // CPU restatement: oracle/reference_restatement.py::AggregationAMG (same aggregates, V-cycle equal to 1e-12 relative).
 #include "nk_internal.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -505,13 +504,54 @@ struct amg_arena {
   }
 };
 static inline dim3 amg_g1(int64_t n) { return dim3((unsigned)((n + NK_BLOCK - 1) / NK_BLOCK > 0 ? (n + NK_BLOCK - 1) / NK_BLOCK : 1)); }
-// out[0 .. n) = exclusive prefix sums of in[0 .. n) (n includes the caller's trailing zero: out[n − 1] is the total)
+// out[0 .. n) = exclusive prefix sums of in[0 .. n) (n includes the caller's trailing zero: out[n − 1] is the total).
+// An in-tree scan (no vendor primitive in the shipped path): a workgroup scans 2048 entries — eight per thread in registers, the
+// wavefront's 64 thread sums by a shuffle ladder, the four wavefront sums through LDS — and leaves its total; the totals are
+// scanned by the same routine (two levels serve 4 M entries, three 8 G) and added back. in == out is allowed.
+constexpr int AMG_SCAN_PER = 8, AMG_SCAN_TILE = NK_BLOCK * AMG_SCAN_PER;
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_scan_tile(const int32_t *in, int32_t *out, int64_t n,
+                                                            int32_t *__restrict__ totals) {
+  __shared__ int32_t s_w[NK_BLOCK / 64];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * AMG_SCAN_TILE + (int64_t)t * AMG_SCAN_PER;
+  int32_t v[AMG_SCAN_PER];
+#pragma unroll
+  for (int q = 0; q < AMG_SCAN_PER; ++q) v[q] = (base + q < n) ? in[base + q] : 0;
+  int32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < AMG_SCAN_PER; ++q) { const int32_t x = v[q]; v[q] = mine; mine += x; }   // exclusive within the thread
+  int32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  int32_t off = incl - mine;
+  for (int w = 0; w < wv; ++w) off += s_w[w];
+#pragma unroll
+  for (int q = 0; q < AMG_SCAN_PER; ++q)
+    if (base + q < n) out[base + q] = v[q] + off;
+  if (totals != nullptr && t == NK_BLOCK - 1) totals[blockIdx.x] = off + mine;
+}
+__global__ __launch_bounds__(NK_BLOCK) void k_amg_scan_add(int32_t *__restrict__ out, int64_t n, const int32_t *__restrict__ offs) {
+  const int32_t o = offs[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * AMG_SCAN_TILE;
+  for (int q = threadIdx.x; q < AMG_SCAN_TILE; q += NK_BLOCK)
+    if (base + q < n) out[base + q] += o;
+}
 static int amg_scan(nk_ctx *ctx, amg_arena &ar, const int32_t *in, int32_t *out, int64_t n) {
-  size_t bytes = 0;
-  NK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
-  char *tmp = nullptr;
-  NK_TRY(ar.get(&tmp, bytes + 256));
-  NK_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, ctx->stream));
+  if (n <= 0) return NK_OK;
+  const int64_t nb = (n + AMG_SCAN_TILE - 1) / AMG_SCAN_TILE;
+  int32_t *totals = nullptr;
+  if (nb > 1) NK_TRY(ar.get(&totals, (size_t)nb));
+  hipLaunchKernelGGL(k_amg_scan_tile, dim3((unsigned)nb), dim3(NK_BLOCK), 0, ctx->stream, in, out, n, totals);
+  if (nb > 1) {
+    NK_TRY(amg_scan(ctx, ar, totals, totals, nb));
+    hipLaunchKernelGGL(k_amg_scan_add, dim3((unsigned)nb), dim3(NK_BLOCK), 0, ctx->stream, out, n, (const int32_t *)totals);
+  }
+  NK_HIP(hipGetLastError());
   return NK_OK;
 }
 static int amg_fetch_int(nk_ctx *ctx, const int32_t *d, int32_t *h) {

@@ -75,13 +75,16 @@ __global__ __launch_bounds__(NK_BLOCK) void k_spmv_stream(
   const int b = REMAP ? xcd_remap(blockIdx.x, nblk) : (int)blockIdx.x;
   if (HALO && xc.segs != nullptr) {  // (uniform per workgroup; runs even when the cycle is done: flags stay in step)
     if ((int)blockIdx.x < xc.nsegs) {
-      const nk_peer_seg sg = xc.segs[blockIdx.x];
-      double *dst = sg.dst[xc.seq & 1];
-      const int32_t *idx = xc.send_idx + sg.send_off;
-      for (int64_t i = threadIdx.x; i < sg.send_cnt; i += NK_BLOCK) dst[i] = x[idx[i]];
+      // (fields read through the pointer: a by-value copy of the segment indexed by the sequence's parity lands in private memory
+      //  — 56 B of scratch per lane in every HALO instance — and turns `dst` into a generic pointer, its stores into FLAT ones)
+      const nk_peer_seg *__restrict__ sg = xc.segs + blockIdx.x;
+      double *__restrict__ dst = (xc.seq & 1) ? sg->dst[1] : sg->dst[0];
+      const int64_t send_cnt = sg->send_cnt;
+      const int32_t *idx = xc.send_idx + sg->send_off;
+      for (int64_t i = threadIdx.x; i < send_cnt; i += NK_BLOCK) dst[i] = x[idx[i]];
       __threadfence_system();
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(sg.flag_remote, xc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) __hip_atomic_store(sg->flag_remote, xc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (b >= xc.wait_from) {
       if ((int)threadIdx.x < xc.nsegs) {

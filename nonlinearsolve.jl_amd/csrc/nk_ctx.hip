@@ -300,15 +300,16 @@ __global__ __launch_bounds__(NK_BLOCK) void k_peer_allreduce(char *const *map, i
 // and then waits for that neighbour's flag over here. Every workgroup pushes before it waits, so no cycle can form.
 __global__ __launch_bounds__(NK_BLOCK) void k_peer_halo_xchg(const nk_peer_seg *segs, const int32_t *__restrict__ send_idx,
                                                              const double *__restrict__ x, uint64_t seq, uint64_t *err) {
-  const nk_peer_seg sg = segs[blockIdx.x];
-  double *dst = sg.dst[seq & 1];
-  const int32_t *idx = send_idx + sg.send_off;
-  for (int64_t i = threadIdx.x; i < sg.send_cnt; i += NK_BLOCK) dst[i] = x[idx[i]];
+  const nk_peer_seg *__restrict__ sg = segs + blockIdx.x;   // (through the pointer: a by-value copy indexed by the parity is private memory)
+  double *__restrict__ dst = (seq & 1) ? sg->dst[1] : sg->dst[0];
+  const int64_t send_cnt = sg->send_cnt;
+  const int32_t *idx = send_idx + sg->send_off;
+  for (int64_t i = threadIdx.x; i < send_cnt; i += NK_BLOCK) dst[i] = x[idx[i]];
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_store(sg.flag_remote, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    peer_wait_ge(sg.flag_local, seq, err);
+    __hip_atomic_store(sg->flag_remote, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    peer_wait_ge(sg->flag_local, seq, err);
   }
 }
 
