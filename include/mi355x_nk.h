@@ -358,8 +358,9 @@ int nk_ctx_comm_peer_selftest(nk_ctx *ctx, int *ok);
 int nk_ctx_comm_peer_disable(nk_ctx *ctx);   /* before any problem / matrix was created on the context */
 int nk_ctx_comm_info(nk_ctx *ctx, int *kind, int *nranks, int *rank);
 /* *shared = 1 if several ranks of the communicator run on ONE device (found out collectively when the communicator was set up,
- * from the devices' PCI bus ids; NK_DEVICE_SHARED=0/1 overrides): such ranks do not use the forms that need a whole device each —
- * the resident matrix-powers kernel on ranks, workgroups above 64 KB of LDS. One process per GPU: 0. */
+ * from the devices' PCI bus ids; NK_DEVICE_SHARED=0/1, set alike on every rank, overrides): such ranks do not use the one form that
+ * needs a whole device per rank — the resident matrix-powers kernel on ranks. One process per GPU: 0.
+ * nk_ctx_comm_init_rccl / nk_ctx_comm_init_callbacks are COLLECTIVE for this reason (one small all-reduce through the transport). */
 int nk_ctx_comm_device_shared(nk_ctx *ctx, int *shared);
 
 /* contiguous row-range partition used everywhere: rank r owns [r*n/P, (r+1)*n/P) rounded down to a

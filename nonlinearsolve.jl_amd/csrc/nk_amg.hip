@@ -677,7 +677,7 @@ static int amg_setup_device(nk_amg *M, const std::function<void(const char *)> &
     NK_TRY(amg_coarsen_dev(ctx, ar, F, prm, 0, &agg, &mem, &nc, d_fail));
     if (l == 0) {
       int fail = 0;
-      NK_HIP(hipMemcpy(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost));
+      NK_HIP(nk_memcpy(ctx, &fail, d_fail, sizeof(int), hipMemcpyDeviceToHost));
       NK_REQUIRE(!fail, "AMG: the columns of some row are not sorted / unique");
     }
     if ((int64_t)nc * W > F.n + F.n / 50) {   // not (nearly) a full coarsening: the other tie-break may align the pairs better
@@ -750,9 +750,9 @@ void nk_amg_destroy(nk_amg *M) {
   delete M;
 }
 template <class T>
-static int upload(T **dst, const std::vector<T> &src) {
+static int upload(nk_ctx *ctx, T **dst, const std::vector<T> &src) {
   NK_TRY(nk_dev_alloc(dst, src.size() + 1));
-  if (!src.empty()) NK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!src.empty()) NK_HIP(nk_memcpy(ctx, *dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
   return NK_OK;
 }
 int nk_amg_create(nk_csr *A, const nk_amg_params *prm, nk_amg **out) {
@@ -805,7 +805,7 @@ int nk_amg_create(nk_csr *A, const nk_amg_params *prm, nk_amg **out) {
     H.n = n;
     std::vector<double> vals((size_t)A->nnz);
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    if (A->nnz) NK_HIP(hipMemcpy(vals.data(), A->d_val, A->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (A->nnz) NK_HIP(nk_memcpy(ctx, vals.data(), A->d_val, A->nnz * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<int32_t> src0;
     if (!has_halo) {   // the whole matrix: its pattern and values as they are
       H.rp.assign(A->h_rowptr.begin(), A->h_rowptr.end());
@@ -896,14 +896,14 @@ int nk_amg_create(nk_csr *A, const nk_amg_params *prm, nk_amg **out) {
           std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
           for (int64_t k = 0; k < L.nnz; ++k) gidx[fill[emap[k]]++] = (int32_t)k;
         }
-        NK_TRY(upload(&L.d_agg, agg));
-        NK_TRY(upload(&L.d_aggptr, aptr));
-        NK_TRY(upload(&L.d_aggmem, amem));
-        NK_TRY(upload(&L.d_gptr, gptr));
-        NK_TRY(upload(&L.d_gidx, gidx));
+        NK_TRY(upload(M->ctx, &L.d_agg, agg));
+        NK_TRY(upload(M->ctx, &L.d_aggptr, aptr));
+        NK_TRY(upload(M->ctx, &L.d_aggmem, amem));
+        NK_TRY(upload(M->ctx, &L.d_gptr, gptr));
+        NK_TRY(upload(M->ctx, &L.d_gidx, gidx));
       }
     }
-    if (has_halo) NK_TRY(upload(&M->d_src0, src0));
+    if (has_halo) NK_TRY(upload(M->ctx, &M->d_src0, src0));
     lap("device objects");
   }
   const int nlev = (int)M->lv.size();
@@ -913,7 +913,7 @@ int nk_amg_create(nk_csr *A, const nk_amg_params *prm, nk_amg **out) {
   M->lpart_stride = 1024;
   M->nparts.assign(nlev, 0);
   for (int l = 0; l < nlev; ++l) M->nparts[l] = M->lv[l].n > 0 ? nk_grid_for(M->lv[l].n, NK_BLOCK, M->lpart_stride) : 0;
-  NK_TRY(upload(&M->d_nparts, M->nparts));
+  NK_TRY(upload(M->ctx, &M->d_nparts, M->nparts));
   NK_TRY(nk_dev_alloc(&M->d_lpart, (size_t)nlev * M->lpart_stride));
   NK_TRY(nk_dev_alloc(&M->d_lmax, (size_t)nlev + 1));
   NK_TRY(nk_dev_alloc(&M->d_fail, (size_t)2));
@@ -1062,7 +1062,7 @@ const int32_t *nk_amg_aggregates(const nk_amg *Mc, int l) {
   amg_level &L = M->lv[l];
   if (L.h_agg.empty() && L.n > 0 && L.d_agg) {   // (device set-up: the map has not been to the host yet)
     L.h_agg.resize((size_t)L.n);
-    if (hipMemcpy(L.h_agg.data(), L.d_agg, (size_t)L.n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    if (nk_memcpy(M->ctx, L.h_agg.data(), L.d_agg, (size_t)L.n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
   }
   return L.h_agg.data();
 }

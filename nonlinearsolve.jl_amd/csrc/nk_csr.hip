@@ -239,8 +239,8 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   NK_TRY(nk_dev_alloc(&A->d_rowptr, (size_t)nrows + 1));
   NK_TRY(nk_dev_alloc(&A->d_col, (size_t)nnz + SPMV_TILE_MAX));  // padded: the tile phase reads whole tiles
   NK_TRY(nk_dev_alloc(&A->d_val, (size_t)nnz + SPMV_TILE_MAX));
-  NK_HIP(hipMemset(A->d_col + nnz, 0, SPMV_TILE_MAX * sizeof(int32_t)));
-  NK_HIP(hipMemset(A->d_val + nnz, 0, SPMV_TILE_MAX * sizeof(double)));
+  NK_HIP(nk_memset(ctx, A->d_col + nnz, 0, SPMV_TILE_MAX * sizeof(int32_t)));
+  NK_HIP(nk_memset(ctx, A->d_val + nnz, 0, SPMV_TILE_MAX * sizeof(double)));
   // block descriptors, those that read no halo column first: with halo overlap the SpMV launches the two groups
   // separately (interior while the exchange is in flight, boundary after it); on one rank every block is interior
   std::vector<int32_t> desc(4 * (size_t)A->nblocks);
@@ -276,17 +276,17 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
     }
     if (fits) {
       NK_HIP(hipMalloc((void **)&A->d_col16, ((size_t)nnz + SPMV_TILE_MAX) * sizeof(int16_t)));
-      NK_HIP(hipMemset(A->d_col16, 0, ((size_t)nnz + SPMV_TILE_MAX) * sizeof(int16_t)));
-      NK_HIP(hipMemcpy(A->d_col16, c16.data(), (size_t)nnz * sizeof(int16_t), hipMemcpyHostToDevice));
+      NK_HIP(nk_memset(ctx, A->d_col16, 0, ((size_t)nnz + SPMV_TILE_MAX) * sizeof(int16_t)));
+      NK_HIP(nk_memcpy(ctx, A->d_col16, c16.data(), (size_t)nnz * sizeof(int16_t), hipMemcpyHostToDevice));
       A->n16 = A->nblocks_interior;
     }
   }
   NK_TRY(nk_dev_alloc(&A->d_rowblocks, desc.size() + 4));
-  NK_HIP(hipMemcpy(A->d_rowptr, rowptr.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (nnz) NK_HIP(hipMemcpy(A->d_col, A->h_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (!desc.empty()) NK_HIP(hipMemcpy(A->d_rowblocks, desc.data(), desc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (vals_host && nnz) NK_HIP(hipMemcpy(A->d_val, vals_host, nnz * sizeof(double), hipMemcpyHostToDevice));
-  else if (nnz) NK_HIP(hipMemset(A->d_val, 0, nnz * sizeof(double)));
+  NK_HIP(nk_memcpy(ctx, A->d_rowptr, rowptr.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nnz) NK_HIP(nk_memcpy(ctx, A->d_col, A->h_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!desc.empty()) NK_HIP(nk_memcpy(ctx, A->d_rowblocks, desc.data(), desc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (vals_host && nnz) NK_HIP(nk_memcpy(ctx, A->d_val, vals_host, nnz * sizeof(double), hipMemcpyHostToDevice));
+  else if (nnz) NK_HIP(nk_memset(ctx, A->d_val, 0, nnz * sizeof(double)));
 
   // ---- halo plan (collective): tell every owner which of its entries we need
   if (ctx->nranks > 1 && !local_only) {
@@ -297,10 +297,10 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
     if (ctx->rank == P - 1) hb[P] = (double)(row_begin + nrows);
     double *d_tmp = nullptr;
     NK_TRY(nk_dev_alloc(&d_tmp, (size_t)P * P + P + 1));
-    NK_HIP(hipMemcpy(d_tmp, hb.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, d_tmp, hb.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice));
     NK_TRY(nk_comm_allreduce(ctx, d_tmp, P + 1, 0));
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_HIP(hipMemcpy(hb.data(), d_tmp, (P + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    NK_HIP(nk_memcpy(ctx, hb.data(), d_tmp, (P + 1) * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<int64_t> begin(P + 1);
     for (int p = 0; p <= P; ++p) begin[p] = (int64_t)hb[p];
     // 2. needs per owner
@@ -316,10 +316,10 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
     // 3. exchange counts: P×P matrix, row = requester, col = owner
     std::vector<double> cnt((size_t)P * P, 0.0);
     for (int p = 0; p < P; ++p) cnt[(size_t)ctx->rank * P + p] = (double)need[p].size();
-    NK_HIP(hipMemcpy(d_tmp, cnt.data(), (size_t)P * P * sizeof(double), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, d_tmp, cnt.data(), (size_t)P * P * sizeof(double), hipMemcpyHostToDevice));
     NK_TRY(nk_comm_allreduce(ctx, d_tmp, P * P, 0));
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_HIP(hipMemcpy(cnt.data(), d_tmp, (size_t)P * P * sizeof(double), hipMemcpyDeviceToHost));
+    NK_HIP(nk_memcpy(ctx, cnt.data(), d_tmp, (size_t)P * P * sizeof(double), hipMemcpyDeviceToHost));
     hipFree(d_tmp);
     // 4. exchange index lists (int64 global ids) — what I need from p ↔ what p needs from me
     std::vector<int64_t> soff(P, 0), sbytes(P, 0), roff(P, 0), rbytes(P, 0);
@@ -338,11 +338,11 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
     NK_TRY(nk_dev_alloc(&d_s, sendflat.size() + 1));
     NK_TRY(nk_dev_alloc(&d_r, (size_t)rtotal + 1));
     if (!sendflat.empty())
-      NK_HIP(hipMemcpy(d_s, sendflat.data(), sendflat.size() * 8, hipMemcpyHostToDevice));
+      NK_HIP(nk_memcpy(ctx, d_s, sendflat.data(), sendflat.size() * 8, hipMemcpyHostToDevice));
     NK_TRY(nk_comm_alltoallv(ctx, d_s, soff.data(), sbytes.data(), d_r, roff.data(), rbytes.data()));
     NK_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> wanted((size_t)rtotal);
-    if (rtotal) NK_HIP(hipMemcpy(wanted.data(), d_r, (size_t)rtotal * 8, hipMemcpyDeviceToHost));
+    if (rtotal) NK_HIP(nk_memcpy(ctx, wanted.data(), d_r, (size_t)rtotal * 8, hipMemcpyDeviceToHost));
     hipFree(d_s);
     hipFree(d_r);
     std::vector<std::vector<int32_t>> send_idx(P);
@@ -384,13 +384,13 @@ extern "C" int nk_csr_create(nk_ctx *ctx, int64_t nrows_local, int64_t n_global,
   const void *rp = rowptr, *ci = colind;
   const double *vv = vals;
   if (memspace == NK_DEVICE) {
-    NK_HIP(hipMemcpy(hrp.data(), rowptr, hrp.size(), hipMemcpyDeviceToHost));
-    if (nnz) NK_HIP(hipMemcpy(hci.data(), colind, hci.size(), hipMemcpyDeviceToHost));
+    NK_HIP(nk_memcpy(ctx, hrp.data(), rowptr, hrp.size(), hipMemcpyDeviceToHost));
+    if (nnz) NK_HIP(nk_memcpy(ctx, hci.data(), colind, hci.size(), hipMemcpyDeviceToHost));
     rp = hrp.data();
     ci = hci.data();
     if (vals) {
       hv.resize(nnz);
-      if (nnz) NK_HIP(hipMemcpy(hv.data(), vals, nnz * sizeof(double), hipMemcpyDeviceToHost));
+      if (nnz) NK_HIP(nk_memcpy(ctx, hv.data(), vals, nnz * sizeof(double), hipMemcpyDeviceToHost));
       vv = hv.data();
     }
   }
@@ -461,7 +461,7 @@ extern "C" int nk_csr_create_from_csc_rows(nk_ctx *ctx, int64_t n, int64_t nnz, 
         if (rv[k] >= lo && rv[k] < hi) src[fill2[rv[k] - lo]++] = (int32_t)k;
     A->csc_nnz = nnz;
     if (nnz < (1ll << 31) && nk_dev_alloc(&A->d_csc_src, (size_t)nloc + 1) == NK_OK && nloc > 0)
-      NK_HIP(hipMemcpy(A->d_csc_src, src.data(), nloc * sizeof(int32_t), hipMemcpyHostToDevice));
+      NK_HIP(nk_memcpy(ctx, A->d_csc_src, src.data(), nloc * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   return NK_OK;
 }
@@ -760,7 +760,7 @@ void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v) {
 }
 int nk_csr_alloc_values(nk_csr *A, double **out) {
   NK_TRY(nk_dev_alloc(out, (size_t)A->nnz + SPMV_TILE_MAX));
-  NK_HIP(hipMemset(*out, 0, ((size_t)A->nnz + SPMV_TILE_MAX) * sizeof(double)));
+  NK_HIP(nk_memset(A->ctx, *out, 0, ((size_t)A->nnz + SPMV_TILE_MAX) * sizeof(double)));
   return NK_OK;
 }
 int nk_csr_clone_pattern(nk_csr *A, nk_csr **out) {
@@ -805,7 +805,7 @@ static int build_transpose(nk_csr *A) {
     }
   NK_TRY(nk_csr_create_local(A->ctx, nt, nt, 0, rp, gc, nullptr, &A->T, true));
   NK_TRY(nk_dev_alloc(&A->d_tperm, (size_t)nnz));
-  if (nnz) NK_HIP(hipMemcpy(A->d_tperm, perm.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nnz) NK_HIP(nk_memcpy(A->ctx, A->d_tperm, perm.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
   if (nh) {
     NK_TRY(nk_dev_alloc(&A->d_tz, (size_t)nt + 1));
     NK_TRY(nk_dev_alloc(&A->d_trecv, (size_t)A->halo.n_send + 1));
@@ -906,7 +906,7 @@ int nk_csr_add_to_diagonal_dev(nk_csr *A, double sigma, const double *d_m) {
       pos[r] = found;
     }
     NK_TRY(nk_dev_alloc(&A->d_diagpos, (size_t)A->nrows + 1));
-    if (A->nrows) NK_HIP(hipMemcpy(A->d_diagpos, pos.data(), A->nrows * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (A->nrows) NK_HIP(nk_memcpy(A->ctx, A->d_diagpos, pos.data(), A->nrows * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (A->nrows)
     NK_LAUNCH(A->ctx, k_add_diag, dim3((unsigned)((A->nrows + NK_BLOCK - 1) / NK_BLOCK)), dim3(NK_BLOCK), A->nrows,
@@ -998,10 +998,10 @@ int nk_normal_plan_create(nk_csr *J, nk_normal_plan **out) {
   NK_TRY(nk_dev_alloc(&Pn->d_pa, np + 1));
   NK_TRY(nk_dev_alloc(&Pn->d_pb, np + 1));
   NK_TRY(nk_dev_alloc(&Pn->d_diagrow, nnzN + 1));
-  NK_HIP(hipMemcpy(Pn->d_ptr, ptr.data(), (nnzN + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (np) NK_HIP(hipMemcpy(Pn->d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (np) NK_HIP(hipMemcpy(Pn->d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
-  NK_HIP(hipMemcpy(Pn->d_diagrow, diagrow.data(), nnzN * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, Pn->d_ptr, ptr.data(), (nnzN + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (np) NK_HIP(nk_memcpy(ctx, Pn->d_pa, pa.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (np) NK_HIP(nk_memcpy(ctx, Pn->d_pb, pb.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, Pn->d_diagrow, diagrow.data(), nnzN * sizeof(int32_t), hipMemcpyHostToDevice));
   *out = guard.release();
   return NK_OK;
 }

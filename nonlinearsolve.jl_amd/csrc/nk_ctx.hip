@@ -88,6 +88,7 @@ extern "C" int nk_ctx_destroy(nk_ctx *ctx) {
   nk_peer_destroy(ctx);
   hipFree(ctx->d_partials);
   hipFree(ctx->d_partials_ss);
+  hipFree(ctx->audit.d_slots);
   hipFree(ctx->d_scal);
   hipHostFree(ctx->h_pinned);
   if (ctx->comm_stream) {
@@ -363,12 +364,12 @@ extern "C" int nk_ctx_comm_peer_handle(nk_ctx *ctx, int64_t arena_bytes, char ha
     }
   }
   pr.arena = (char *)a;
-  NK_HIP(hipMemset(pr.arena, 0, NK_PEER_HDR_BYTES));
+  NK_HIP(nk_memset(ctx, pr.arena, 0, NK_PEER_HDR_BYTES));
   {  // the bound of every device-side wait (a rank stalled by a host callback, a JIT, a first kernel load): NK_PEER_TIMEOUT_MS
     const char *e = getenv("NK_PEER_TIMEOUT_MS");
     const double ms = e ? atof(e) : 5000.0;
     const uint64_t ticks = (uint64_t)((ms > 1.0 ? ms : 1.0) * 1e5);
-    NK_HIP(hipMemcpy(pr.arena + offsetof(nk_peer_hdr, timeout_ticks), &ticks, sizeof(ticks), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, pr.arena + offsetof(nk_peer_hdr, timeout_ticks), &ticks, sizeof(ticks), hipMemcpyHostToDevice));
   }
   NK_HIP(hipDeviceSynchronize());
   pr.bump = NK_PEER_HDR_BYTES;
@@ -405,9 +406,9 @@ extern "C" int nk_ctx_comm_enable_peer(nk_ctx *ctx, const char *handles) {
     pr.map[p] = (char *)q;
   }
   NK_TRY(nk_dev_alloc(&pr.d_map, (size_t)NK_PEER_MAX_RANKS));
-  NK_HIP(hipMemcpy(pr.d_map, pr.map, sizeof(char *) * NK_PEER_MAX_RANKS, hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, pr.d_map, pr.map, sizeof(char *) * NK_PEER_MAX_RANKS, hipMemcpyHostToDevice));
   NK_TRY(nk_dev_alloc(&pr.d_ticket, (size_t)4));
-  NK_HIP(hipMemset(pr.d_ticket, 0, 4 * sizeof(unsigned int)));
+  NK_HIP(nk_memset(ctx, pr.d_ticket, 0, 4 * sizeof(unsigned int)));
   pr.on = true;
   return NK_OK;
 }
@@ -431,11 +432,11 @@ extern "C" int nk_ctx_comm_peer_selftest(nk_ctx *ctx, int *ok) {
   int bad = 0;
   for (int round = 0; round < 4 && !bad; ++round) {
     for (int i = 0; i < cnt; ++i) h[i] = (double)(me + 1) * (round + 1) + 0.25 * i;
-    NK_HIP(hipMemcpy(d, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, d, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
     int st = nk_comm_allreduce_mixed(ctx, d, cnt, 8, 16);  // elements 8..15 with max, the others with +
     if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
     if (st != NK_OK) { bad = 1; break; }
-    NK_HIP(hipMemcpy(h.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    NK_HIP(nk_memcpy(ctx, h.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < cnt; ++i) {
       const double sum = (double)(round + 1) * P * (P + 1) / 2.0 + 0.25 * i * P, mx = (double)P * (round + 1) + 0.25 * i;
       if (h[i] != ((i >= 8 && i < 16) ? mx : sum)) bad = 1;
@@ -446,10 +447,10 @@ extern "C" int nk_ctx_comm_peer_selftest(nk_ctx *ctx, int *ok) {
   NK_TRY(nk_ctx_comm_peer_status(ctx, &en, &errs));
   if (errs != 0) bad = 1;
   double flag = bad ? 1.0 : 0.0;
-  NK_HIP(hipMemcpy(d, &flag, sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, d, &flag, sizeof(double), hipMemcpyHostToDevice));
   int st = comm_allreduce_base(ctx, d, 1, 1);
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
-  if (st == NK_OK) NK_HIP(hipMemcpy(&flag, d, sizeof(double), hipMemcpyDeviceToHost));
+  if (st == NK_OK) NK_HIP(nk_memcpy(ctx, &flag, d, sizeof(double), hipMemcpyDeviceToHost));
   hipFree(d);
   NK_TRY(st);
   if (flag != 0.0) ctx->peer.on = false;
@@ -465,7 +466,7 @@ extern "C" int nk_ctx_comm_peer_status(nk_ctx *ctx, int *enabled, int64_t *error
     if (ctx->peer.arena) {
       uint64_t e = 0;
       NK_HIP(hipStreamSynchronize(ctx->stream));
-      NK_HIP(hipMemcpy(&e, ctx->peer.arena + offsetof(nk_peer_hdr, err), sizeof(e), hipMemcpyDeviceToHost));
+      NK_HIP(nk_memcpy(ctx, &e, ctx->peer.arena + offsetof(nk_peer_hdr, err), sizeof(e), hipMemcpyDeviceToHost));
       *errors = (int64_t)e;
     }
   }
@@ -536,18 +537,14 @@ extern "C" int nk_comm_unique_id(char id_out[128]) {
 }
 // Do several ranks run on one device? Every rank contributes a hash of its device's PCI bus id (and host name) in its own slot
 // of a vector that is summed over the ranks; equal entries = a shared device. Collective; the verdict is the same on every rank.
-// Why it matters: (1) two processes whose persistent kernels wait for each other (the resident matrix-powers kernel over the
-// peer arenas) each need the whole device — on one device they only advance when the scheduler preempts one for the other, or
-// not at all; (2) measured on this pool (profiles/r05_m_shared_device.txt): with two processes time-slicing one MI355X, 9 of 41
-// two-rank runs whose sweep B was k_ss_block_mm<15, 16> (the one sweep whose workgroups hold more than 64 KB of LDS: 65.8 KB, and
-// the longest kernel of the cycle) ended with a residual off by 3 – 40 % or hung in the base transport, whatever the transport;
-// with the ≤ 64 KB substitution form of that sweep 0 of 38 did (3 took the breakdown fallback and agreed to 1e-12). The same
-// kernel in a process that has the device to itself is bit-reproducible run after run. A preempted wavefront's state is
-// apparently not always restored on this pool; nothing a kernel can do about — so the form most exposed is not used there.
+// Why it matters: two processes whose persistent kernels wait for each other (the resident matrix-powers kernel over the peer
+// arenas) each need the whole device — on one device they only advance when the scheduler happens to run both, or not at all.
+// That form is not used there. (Round 5 also kept sweep B's matrix-core form away from such ranks, blaming wrong results of
+// two-process runs on preemption; round 6 found the cause in the product — a write-after-read race between the wavefronts of
+// the Gram block's factorisation, ss_factor in nk_sstep.hip — and that restriction is gone: profiles/r06_a_shared_device_root_cause.md.)
 static int comm_detect_shared_device(nk_ctx *ctx) {
   ctx->device_shared = false;
   if (ctx->nranks <= 1) return NK_OK;
-  if (const char *e = getenv("NK_DEVICE_SHARED")) { ctx->device_shared = atoi(e) != 0; return NK_OK; }   // (override, both ways)
   char bus[64] = {0}, host[256] = {0};
   const bool have_id = hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device) == hipSuccess;
   if (!have_id) (void)hipGetLastError();
@@ -563,15 +560,18 @@ static int comm_detect_shared_device(nk_ctx *ctx) {
   tab[ctx->rank] = mine;
   double *d = nullptr;
   NK_TRY(nk_dev_alloc(&d, (size_t)P));
-  NK_HIP(hipMemcpy(d, tab.data(), (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, d, tab.data(), (size_t)P * sizeof(double), hipMemcpyHostToDevice));
   int st = comm_allreduce_base(ctx, d, P, 0);
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
-  if (st == NK_OK && hipMemcpy(tab.data(), d, (size_t)P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = NK_E_HIP;
+  if (st == NK_OK && nk_memcpy(ctx, tab.data(), d, (size_t)P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = NK_E_HIP;
   hipFree(d);
   NK_TRY(st);
   for (int a = 0; a < P; ++a)
     for (int b = a + 1; b < P; ++b)
       if (tab[a] == tab[b]) ctx->device_shared = true;
+  // the override (both ways) is read BEHIND the collective: a rank that has it set still takes part, the others do not hang
+  // (it must be set alike on every rank to mean anything — the forms it gates are collective decisions)
+  if (const char *e = getenv("NK_DEVICE_SHARED")) ctx->device_shared = atoi(e) != 0;
   return NK_OK;
 }
 extern "C" int nk_ctx_comm_init_rccl(nk_ctx *ctx, int nranks, int rank, const char id[128]) {
@@ -715,10 +715,10 @@ static int halo_setup_peer(nk_ctx *ctx, nk_halo *H) {
   for (int p = 0; p < P; ++p) row[3 + p] = (double)H->recv_off[p];
   double *d_tab = nullptr;
   NK_TRY(nk_dev_alloc(&d_tab, tab.size()));
-  NK_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   int st = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
-  if (st == NK_OK) NK_HIP(hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (st == NK_OK) NK_HIP(nk_memcpy(ctx, tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
   hipFree(d_tab);
   NK_TRY(st);
   bool fits = true;
@@ -750,13 +750,13 @@ static int halo_setup_peer(nk_ctx *ctx, nk_halo *H) {
   H->nsegs = (int)segs.size();
   if (H->nsegs) {
     NK_HIP(hipMalloc((void **)&H->d_segs, segs.size() * sizeof(nk_peer_seg)));
-    NK_HIP(hipMemcpy(H->d_segs, segs.data(), segs.size() * sizeof(nk_peer_seg), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, H->d_segs, segs.data(), segs.size() * sizeof(nk_peer_seg), hipMemcpyHostToDevice));
   }
   NK_HIP(hipStreamSynchronize(ctx->stream));
   // nobody may push into a receive area before its owner has zeroed the flags: one more collective as a barrier
   double *d_one = nullptr;
   NK_TRY(nk_dev_alloc(&d_one, (size_t)1));
-  NK_HIP(hipMemset(d_one, 0, sizeof(double)));
+  NK_HIP(nk_memset(ctx, d_one, 0, sizeof(double)));
   st = comm_allreduce_base(ctx, d_one, 1, 0);
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
   hipFree(d_one);
@@ -778,10 +778,10 @@ int nk_peer_powers_setup(nk_ctx *ctx, bool eligible, nk_peer_powers *out, bool *
   tab[(size_t)me * 2 + 1] = (eligible && pr.on && off + NEED <= pr.arena_bytes) ? 0.0 : 1.0;
   double *d_tab = nullptr;
   NK_TRY(nk_dev_alloc(&d_tab, tab.size()));
-  NK_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   int st = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
-  if (st == NK_OK) NK_HIP(hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (st == NK_OK) NK_HIP(nk_memcpy(ctx, tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
   hipFree(d_tab);
   NK_TRY(st);
   for (int p = 0; p < P; ++p)
@@ -806,7 +806,7 @@ int nk_peer_powers_setup(nk_ctx *ctx, bool eligible, nk_peer_powers *out, bool *
   // nobody may push into an area before its owner has zeroed the flags: one more collective as a barrier
   double *d_one = nullptr;
   NK_TRY(nk_dev_alloc(&d_one, (size_t)1));
-  NK_HIP(hipMemset(d_one, 0, sizeof(double)));
+  NK_HIP(nk_memset(ctx, d_one, 0, sizeof(double)));
   st = comm_allreduce_base(ctx, d_one, 1, 0);
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
   hipFree(d_one);
@@ -846,7 +846,7 @@ int nk_halo_setup(nk_ctx *ctx, nk_halo *H, const std::vector<std::vector<int32_t
   }
   NK_TRY(nk_dev_alloc(&H->d_send_idx, (size_t)so));
   NK_TRY(nk_dev_alloc(&H->d_send, (size_t)so));
-  if (so) NK_HIP(hipMemcpy(H->d_send_idx, flat.data(), so * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (so) NK_HIP(nk_memcpy(ctx, H->d_send_idx, flat.data(), so * sizeof(int32_t), hipMemcpyHostToDevice));
   if (ctx->peer.on && P > 1) return halo_setup_peer(ctx, H);  // (collective, like every halo set-up on several ranks)
   NK_TRY(nk_dev_alloc(&H->d_recv, (size_t)ro));
   return NK_OK;
@@ -862,10 +862,10 @@ int nk_halo_build_from_needs(nk_ctx *ctx, int64_t my_begin, int64_t my_count, co
   double *d_tmp = nullptr;
   NK_TRY(nk_dev_alloc(&d_tmp, (size_t)P * P + P + 1));
   auto tmp_guard = nk_make_guard(d_tmp, [](double *q) { hipFree(q); });
-  NK_HIP(hipMemcpy(d_tmp, hb.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, d_tmp, hb.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice));
   NK_TRY(comm_allreduce_base(ctx, d_tmp, P + 1, 0));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  NK_HIP(hipMemcpy(hb.data(), d_tmp, (P + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  NK_HIP(nk_memcpy(ctx, hb.data(), d_tmp, (P + 1) * sizeof(double), hipMemcpyDeviceToHost));
   std::vector<int64_t> begin(P + 1);
   for (int p = 0; p <= P; ++p) begin[p] = (int64_t)hb[p];
   // 2. needs per owner
@@ -879,10 +879,10 @@ int nk_halo_build_from_needs(nk_ctx *ctx, int64_t my_begin, int64_t my_count, co
   // 3. counts: P×P matrix, row = requester, col = owner
   std::vector<double> cnt((size_t)P * P, 0.0);
   for (int p = 0; p < P; ++p) cnt[(size_t)ctx->rank * P + p] = (double)need[p].size();
-  NK_HIP(hipMemcpy(d_tmp, cnt.data(), (size_t)P * P * sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, d_tmp, cnt.data(), (size_t)P * P * sizeof(double), hipMemcpyHostToDevice));
   NK_TRY(comm_allreduce_base(ctx, d_tmp, P * P, 0));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  NK_HIP(hipMemcpy(cnt.data(), d_tmp, (size_t)P * P * sizeof(double), hipMemcpyDeviceToHost));
+  NK_HIP(nk_memcpy(ctx, cnt.data(), d_tmp, (size_t)P * P * sizeof(double), hipMemcpyDeviceToHost));
   // 4. index lists (int64 global ids): what I need from p ↔ what p needs from me
   std::vector<int64_t> soff(P, 0), sbytes(P, 0), roff(P, 0), rbytes(P, 0), sendflat;
   int64_t rtotal = 0;
@@ -900,11 +900,11 @@ int nk_halo_build_from_needs(nk_ctx *ctx, int64_t my_begin, int64_t my_count, co
   auto s_guard = nk_make_guard(d_s, [](int64_t *q) { hipFree(q); });
   NK_TRY(nk_dev_alloc(&d_r, (size_t)rtotal + 1));
   auto r_guard = nk_make_guard(d_r, [](int64_t *q) { hipFree(q); });
-  if (!sendflat.empty()) NK_HIP(hipMemcpy(d_s, sendflat.data(), sendflat.size() * 8, hipMemcpyHostToDevice));
+  if (!sendflat.empty()) NK_HIP(nk_memcpy(ctx, d_s, sendflat.data(), sendflat.size() * 8, hipMemcpyHostToDevice));
   NK_TRY(nk_comm_alltoallv(ctx, d_s, soff.data(), sbytes.data(), d_r, roff.data(), rbytes.data()));
   NK_HIP(hipStreamSynchronize(ctx->stream));
   std::vector<int64_t> wanted((size_t)rtotal);
-  if (rtotal) NK_HIP(hipMemcpy(wanted.data(), d_r, (size_t)rtotal * 8, hipMemcpyDeviceToHost));
+  if (rtotal) NK_HIP(nk_memcpy(ctx, wanted.data(), d_r, (size_t)rtotal * 8, hipMemcpyDeviceToHost));
   std::vector<std::vector<int32_t>> send_idx(P);
   std::vector<int64_t> recv_cnt(P, 0);
   for (int p = 0; p < P; ++p) {
@@ -990,4 +990,56 @@ void nk_halo_free(nk_halo *H) {
   H->d_send_idx = nullptr;
   H->d_send = H->d_recv = nullptr;
   H->n_send = H->n_recv = 0;
+}
+
+// ----------------------------------------------------------------------------- development: the audit log (nk_internal.h)
+__global__ __launch_bounds__(256) void k_audit_hash(const uint64_t *__restrict__ p, size_t n, uint64_t *__restrict__ out) {
+  __shared__ uint64_t sa[256], sb[256];
+  uint64_t a = 0, b = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const uint64_t w = p[i];
+    a += w * (2 * (uint64_t)i + 1);                       // position-dependent, order-independent
+    b ^= (w << (i & 31)) | (w >> (64 - (i & 31) - 1) >> 1);
+  }
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 1; t < 256; ++t) { a += sa[t]; b ^= sb[t]; }
+    *out = a ^ (b * 0x9e3779b97f4a7c15ull);
+  }
+}
+int nk_audit(nk_ctx *ctx, int tag, const void *p, size_t nwords64) {
+  nk_audit_log &A = ctx->audit;
+  if (!A.on || p == nullptr) return NK_OK;
+  if (A.count >= A.cap) return NK_OK;
+  hipLaunchKernelGGL(k_audit_hash, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)p, nwords64, A.d_slots + A.count);
+  A.tags.push_back(tag);
+  A.count++;
+  return NK_OK;
+}
+extern "C" int nk_debug_audit_enable(nk_ctx *ctx, int on) {
+  NK_REQUIRE(ctx, "NULL argument");
+  nk_audit_log &A = ctx->audit;
+  if (on && !A.d_slots) {
+    A.cap = 1 << 16;
+    NK_TRY(nk_dev_alloc(&A.d_slots, (size_t)A.cap));
+  }
+  A.on = on != 0;
+  A.count = 0;
+  A.tags.clear();
+  return NK_OK;
+}
+// copies the log out (tags and hashes) and clears it
+extern "C" int nk_debug_audit_fetch(nk_ctx *ctx, int *tags, unsigned long long *hashes, int cap, int *count) {
+  NK_REQUIRE(ctx && count, "NULL argument");
+  nk_audit_log &A = ctx->audit;
+  const int n = A.count < cap ? A.count : cap;
+  if (n > 0) {
+    NK_HIP(nk_memcpy(ctx, hashes, A.d_slots, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) tags[i] = A.tags[i];
+  }
+  *count = n;
+  A.count = 0;
+  A.tags.clear();
+  return NK_OK;
 }

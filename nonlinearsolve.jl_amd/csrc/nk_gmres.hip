@@ -744,9 +744,9 @@ extern "C" int nk_gmres_create(nk_ctx *ctx, int64_t n_local, int restart_m, int 
     const char *e = getenv("NK_GMRES_RUN_AHEAD");
     G->run_ahead = e ? atoi(e) : 4;
   }
-  NK_HIP(hipMemset(G->d_ctl, 0, sizeof(nk_gmres_ctl)));
-  NK_HIP(hipMemset(G->V, 0, (size_t)G->ldv * (m + 1) * sizeof(double)));
-  NK_HIP(hipMemset(G->d_s, 0, (NK_MAX_NV + 2) * sizeof(double)));
+  NK_HIP(nk_memset(ctx, G->d_ctl, 0, sizeof(nk_gmres_ctl)));
+  NK_HIP(nk_memset(ctx, G->V, 0, (size_t)G->ldv * (m + 1) * sizeof(double)));
+  NK_HIP(nk_memset(ctx, G->d_s, 0, (NK_MAX_NV + 2) * sizeof(double)));
   *out = guard.release();
   return NK_OK;
 }

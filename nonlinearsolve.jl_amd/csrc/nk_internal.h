@@ -126,7 +126,16 @@ __device__ __forceinline__ unsigned long long nk_peer_timeout(const uint64_t *er
 }
 uint64_t *nk_peer_err_ptr(nk_ctx *ctx);  // the arena's time-out counter (device pointer)  // claims the next sequence number if the fast path applies
 
+// development: content hashes of device buffers at named points of a solve (nk_audit; tools/shared_device_probe.py --audit) —
+// two runs of a deterministic path must produce the same sequence; the first entry that differs names the kernel whose output did
+struct nk_audit_log {
+  bool on = false;
+  uint64_t *d_slots = nullptr;
+  int cap = 0, count = 0;
+  std::vector<int> tags;
+};
 struct nk_ctx {
+  nk_audit_log audit;
   nk_prof prof;
   nk_peer peer;
   int device = 0;
@@ -176,6 +185,7 @@ static inline int nk_spin_wait(nk_ctx *ctx, Pred ready, const char *what) {
   }
 }
 
+int nk_audit(nk_ctx *ctx, int tag, const void *p, size_t nwords64);   // (no-op unless the log is on)
 // true when no collective has to be issued (1 rank and not in the NK_FORCE_COLLECTIVES test mode)
 bool nk_ctx_is_single(const nk_ctx *ctx);
 // Profiling: inside an nk_prof_scope every launch goes through hipExtLaunchKernelGGL with its own start/stop
@@ -671,6 +681,19 @@ int nk_bandlu_factor(nk_bandlu *B, nk_csr *A, int *ok);
 int nk_bandlu_solve(nk_bandlu *B, const double *d_b, double *d_x);
 
 // ----------------------------------------------------------------------------- misc helpers
+// The library's "synchronous" memsets and copies, ORDERED ON THE CONTEXT'S STREAM. hipMemset / hipMemcpy run on the null stream:
+// a caller's stream created with hipStreamNonBlocking (PyTorch's, AMDGPU.jl's) is not ordered against it, and hipMemset of device
+// memory does not block the host — a buffer zeroed at allocation time was still being zeroed while the first kernel on the
+// context's stream filled it (round 6: the spare Jacobian value set of the speculative fill, found by running a context on a
+// non-default stream — tools/shared_device_probe.py --mode threads). nk_memset: asynchronous, in stream order. nk_memcpy: in
+// stream order and complete on return (the host side may be a temporary).
+static inline hipError_t nk_memset(const nk_ctx *ctx, void *p, int v, size_t bytes) {
+  return hipMemsetAsync(p, v, bytes, ctx->stream);
+}
+static inline hipError_t nk_memcpy(const nk_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
 template <typename T>
 static inline int nk_dev_alloc(T **p, size_t count) {
   *p = nullptr;

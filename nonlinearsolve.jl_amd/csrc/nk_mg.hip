@@ -446,10 +446,10 @@ int nk_mg_create(nk_problem *P, int nu, int coarse_max, nk_mg **out) {
       NK_TRY(nk_dev_alloc(&L.pw1, (size_t)nf));
       NK_TRY(nk_dev_alloc(&L.rlo, (size_t)nc));
       NK_TRY(nk_dev_alloc(&L.rw, (size_t)nc * 5));
-      NK_HIP(hipMemcpy(L.pI0, I0.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
-      NK_HIP(hipMemcpy(L.pw1, w1.data(), nf * sizeof(double), hipMemcpyHostToDevice));
-      NK_HIP(hipMemcpy(L.rlo, lo.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
-      NK_HIP(hipMemcpy(L.rw, w.data(), (size_t)nc * 5 * sizeof(double), hipMemcpyHostToDevice));
+      NK_HIP(nk_memcpy(ctx, L.pI0, I0.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
+      NK_HIP(nk_memcpy(ctx, L.pw1, w1.data(), nf * sizeof(double), hipMemcpyHostToDevice));
+      NK_HIP(nk_memcpy(ctx, L.rlo, lo.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice));
+      NK_HIP(nk_memcpy(ctx, L.rw, w.data(), (size_t)nc * 5 * sizeof(double), hipMemcpyHostToDevice));
       hI0.back() = I0;
       hlo.back() = lo;
     }

@@ -599,12 +599,12 @@ static int pw_dispatch_seg(nk_ctx *ctx, int rps, int w, int seg, const pw_args &
   NK_FAIL(NK_E_INVALID, "internal: no segmented matrix-powers kernel for %d slices × %d slots × %d segments", rps, w, seg);
 }
 
-static int pw_plan_new(int rpt, int w, int nb, nk_powers_plan **out) {
+static int pw_plan_new(nk_ctx *ctx, int rpt, int w, int nb, nk_powers_plan **out) {
   nk_powers_plan *P = new nk_powers_plan();
   auto guard = nk_make_guard(P, [](nk_powers_plan *p) { nk_powers_plan_destroy(p); });
   P->rpt = rpt; P->w = w; P->nb = nb;
   NK_TRY(nk_dev_alloc(&P->d_flags, (size_t)nb * PW_FLAG_STRIDE));
-  NK_HIP(hipMemset(P->d_flags, 0, (size_t)nb * PW_FLAG_STRIDE * sizeof(uint64_t)));
+  NK_HIP(nk_memset(ctx, P->d_flags, 0, (size_t)nb * PW_FLAG_STRIDE * sizeof(uint64_t)));
   NK_HIP(hipHostMalloc((void **)&P->h_err, 2 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
   NK_HIP(hipHostGetDevicePointer((void **)&P->h_err_dev, P->h_err, 0));
   P->h_err[0] = 0;
@@ -717,11 +717,11 @@ static int pw_plan_ranks(nk_csr *A) {
   bool all = false;
   NK_TRY(nk_peer_powers_setup(ctx, ok, &pp, &all));
   if (!all) return NK_OK;
-  NK_TRY(pw_plan_new(L.rpt, L.w, L.nb, &A->pw));
+  NK_TRY(pw_plan_new(A->ctx, L.rpt, L.w, L.nb, &A->pw));
   A->pw->peer = true;
   A->pw->pp = pp;
   NK_HIP(hipMalloc((void **)&A->pw->d_halo_vl, hvl.size() * sizeof(int32_t)));
-  NK_HIP(hipMemcpy(A->pw->d_halo_vl, hvl.data(), hvl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, A->pw->d_halo_vl, hvl.data(), hvl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return NK_OK;
 }
 static int pw_plan(nk_csr *A) {
@@ -738,7 +738,7 @@ static int pw_plan(nk_csr *A) {
     if (L.kind == 1) NK_TRY(pw_dispatch(ctx, L.rpt, L.w, probe, true, &occ));
     else NK_TRY(pw_dispatch_seg(ctx, L.rpt, L.w, L.seg, probe, true, &occ));
     if (occ >= 1 && L.nb <= ctx->num_cus * occ) {
-      NK_TRY(pw_plan_new(L.rpt, L.w, L.nb, &A->pw));
+      NK_TRY(pw_plan_new(A->ctx, L.rpt, L.w, L.nb, &A->pw));
       if (L.kind == 2) { A->pw->seg = L.seg; A->pw->ring = L.ring; A->pw->seg_len = (int)L.M; }
       return NK_OK;
     }
@@ -819,7 +819,7 @@ static int pw_problem_plan(nk_problem *P) {
   int occ = 0;
   NK_TRY(pw_dispatch(ctx, rpt, 5, probe, true, &occ, 1));
   if (occ < 1 || nb > ctx->num_cus * occ) return NK_OK;
-  return pw_plan_new(rpt, 5, nb, &P->pw);
+  return pw_plan_new(P->ctx, rpt, 5, nb, &P->pw);
 }
 bool nk_problem_powers_ready(nk_problem *P) {
   if (!P->pw_tried && pw_problem_plan(P) != NK_OK) return false;
@@ -863,13 +863,13 @@ extern "C" int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy,
   else {
     NK_TRY(nk_dev_alloc(&dx, (size_t)n));
     if (nk_dev_alloc(&dY, (size_t)ldy * s) != NK_OK) { cleanup(); return NK_E_NOMEM; }
-    NK_HIP(hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, dx, x, n * sizeof(double), hipMemcpyHostToDevice));
   }
   if (nk_dev_alloc(&dsc, (size_t)s + 1) != NK_OK) { cleanup(); return NK_E_NOMEM; }
   std::vector<double> hs((size_t)s + 1, 0.0);
   hs[0] = scale;
   if (theta) for (int p = 0; p < s; ++p) hs[1 + p] = theta[p];
-  hipMemcpy(dsc, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice);
+  nk_memcpy(ctx, dsc, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice);
   nk_csr_powers_rearm(A);
   const bool res = nk_csr_powers_ready(A);
   bool res_used = res;
@@ -893,7 +893,7 @@ extern "C" int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy,
     if (rc == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { nk_set_error("stream error in nk_csr_powers"); rc = NK_E_HIP; }
   }
   if (rc == NK_OK && memspace != NK_DEVICE)
-    if (hipMemcpy(Y, dY, (size_t)ldy * s * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = NK_E_HIP;
+    if (nk_memcpy(ctx, Y, dY, (size_t)ldy * s * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = NK_E_HIP;
   cleanup();
   if (resident) *resident = res_used ? 1 : 0;
   return rc;

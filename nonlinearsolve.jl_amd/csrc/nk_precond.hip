@@ -181,9 +181,9 @@ __global__ __launch_bounds__(NK_BLOCK) void k_ilu_gather_values(int64_t nnzp, co
 
 // ----------------------------------------------------------------------------- ILU(0): symbolic phase (host)
 template <typename T>
-static int upload(T **dst, const std::vector<T> &v) {
+static int upload(nk_ctx *ctx, T **dst, const std::vector<T> &v) {
   NK_TRY(nk_dev_alloc(dst, v.size() + 1));
-  if (!v.empty()) NK_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!v.empty()) NK_HIP(nk_memcpy(ctx, *dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return NK_OK;
 }
 // greedy distance-1 colouring of the symmetrised pattern in natural order (smallest free colour); rows are then ordered by
@@ -310,18 +310,18 @@ static int ilu_symbolic(nk_precond *P) {
   P->chainL = chain_pays(P->h_ptrL);
   P->chainU = chain_pays(P->h_ptrU);
   if (P->ordering != NK_ILU_MULTICOLOR) P->ncolors = 0;
-  if (P->ordering == NK_ILU_MULTICOLOR) NK_TRY(upload(&P->d_perm, perm));
-  NK_TRY(upload(&P->d_rp, rp));
-  NK_TRY(upload(&P->d_ci, ci));
-  NK_TRY(upload(&P->d_dg, dg));
-  NK_TRY(upload(&P->d_src, src));
-  NK_TRY(upload(&P->d_planptr, planptr));
-  NK_TRY(upload(&P->d_planq, planq));
-  NK_TRY(upload(&P->d_plans, plans));
-  NK_TRY(upload(&P->d_rowsL, rowsL));
-  NK_TRY(upload(&P->d_ptrL, P->h_ptrL));
-  NK_TRY(upload(&P->d_rowsU, rowsU));
-  NK_TRY(upload(&P->d_ptrU, P->h_ptrU));
+  if (P->ordering == NK_ILU_MULTICOLOR) NK_TRY(upload(P->ctx, &P->d_perm, perm));
+  NK_TRY(upload(P->ctx, &P->d_rp, rp));
+  NK_TRY(upload(P->ctx, &P->d_ci, ci));
+  NK_TRY(upload(P->ctx, &P->d_dg, dg));
+  NK_TRY(upload(P->ctx, &P->d_src, src));
+  NK_TRY(upload(P->ctx, &P->d_planptr, planptr));
+  NK_TRY(upload(P->ctx, &P->d_planq, planq));
+  NK_TRY(upload(P->ctx, &P->d_plans, plans));
+  NK_TRY(upload(P->ctx, &P->d_rowsL, rowsL));
+  NK_TRY(upload(P->ctx, &P->d_ptrL, P->h_ptrL));
+  NK_TRY(upload(P->ctx, &P->d_rowsU, rowsU));
+  NK_TRY(upload(P->ctx, &P->d_ptrU, P->h_ptrU));
   NK_TRY(nk_dev_alloc(&P->d_lu, (size_t)P->nnzp + 1));
   NK_TRY(nk_dev_alloc(&P->d_y, (size_t)n + 1));
   NK_TRY(nk_dev_alloc(&P->d_z, (size_t)n + 1));
@@ -496,14 +496,14 @@ static int ilut_update(nk_precond *P) {
   hipFree(P->d_rowsL); hipFree(P->d_ptrL); hipFree(P->d_rowsU); hipFree(P->d_ptrU);
   P->d_rp = P->d_ci = P->d_dg = P->d_rowsL = P->d_ptrL = P->d_rowsU = P->d_ptrU = nullptr;
   P->d_lu = nullptr;
-  NK_TRY(upload(&P->d_rp, rp));
-  NK_TRY(upload(&P->d_ci, ci));
-  NK_TRY(upload(&P->d_dg, dg));
-  NK_TRY(upload(&P->d_rowsL, rowsL));
-  NK_TRY(upload(&P->d_ptrL, P->h_ptrL));
-  NK_TRY(upload(&P->d_rowsU, rowsU));
-  NK_TRY(upload(&P->d_ptrU, P->h_ptrU));
-  NK_TRY(upload(&P->d_lu, lu));
+  NK_TRY(upload(P->ctx, &P->d_rp, rp));
+  NK_TRY(upload(P->ctx, &P->d_ci, ci));
+  NK_TRY(upload(P->ctx, &P->d_dg, dg));
+  NK_TRY(upload(P->ctx, &P->d_rowsL, rowsL));
+  NK_TRY(upload(P->ctx, &P->d_ptrL, P->h_ptrL));
+  NK_TRY(upload(P->ctx, &P->d_rowsU, rowsU));
+  NK_TRY(upload(P->ctx, &P->d_ptrU, P->h_ptrU));
+  NK_TRY(upload(P->ctx, &P->d_lu, lu));
   if (!P->d_y) NK_TRY(nk_dev_alloc(&P->d_y, (size_t)n + 1));
   if (!P->d_z) NK_TRY(nk_dev_alloc(&P->d_z, (size_t)n + 1));
   P->factored = true;
@@ -528,7 +528,7 @@ static int precond_new(nk_csr *A, int kind, nk_precond **out, nk_precond **Pp) {
   P->A = A;
   P->n = A->nrows;
   if (nk_dev_alloc(&P->d_fail, (size_t)2) != NK_OK) { delete P; NK_FAIL(NK_E_NOMEM, "out of device memory"); }
-  hipMemset(P->d_fail, 0, 2 * sizeof(int));
+  nk_memset(P->ctx, P->d_fail, 0, 2 * sizeof(int));
   *Pp = P;
   return NK_OK;
 }
@@ -739,11 +739,11 @@ extern "C" int nk_precond_ilu0_factors(nk_precond *P, int64_t *nnz, int32_t *row
   NK_HIP(hipSetDevice(P->ctx->device));
   NK_HIP(hipStreamSynchronize(P->ctx->stream));
   if (nnz) *nnz = P->nnzp;
-  if (rowptr) NK_HIP(hipMemcpy(rowptr, P->d_rp, (P->n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (col) NK_HIP(hipMemcpy(col, P->d_ci, P->nnzp * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (val) NK_HIP(hipMemcpy(val, P->d_lu, P->nnzp * sizeof(double), hipMemcpyDeviceToHost));
+  if (rowptr) NK_HIP(nk_memcpy(P->ctx, rowptr, P->d_rp, (P->n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (col) NK_HIP(nk_memcpy(P->ctx, col, P->d_ci, P->nnzp * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (val) NK_HIP(nk_memcpy(P->ctx, val, P->d_lu, P->nnzp * sizeof(double), hipMemcpyDeviceToHost));
   if (perm) {
-    if (P->d_perm) NK_HIP(hipMemcpy(perm, P->d_perm, P->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (P->d_perm) NK_HIP(nk_memcpy(P->ctx, perm, P->d_perm, P->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     else for (int64_t i = 0; i < P->n; ++i) perm[i] = (int32_t)i;
   }
   return NK_OK;

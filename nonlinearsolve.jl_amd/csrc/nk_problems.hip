@@ -882,8 +882,8 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
     nk_csr *Jc = *out;
     NK_TRY(nk_dev_alloc(&Jc->d_role, role.size()));
     NK_TRY(nk_dev_alloc(&Jc->d_node, node.size()));
-    NK_HIP(hipMemcpy(Jc->d_role, role.data(), role.size(), hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(Jc->d_node, node.data(), node.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, Jc->d_role, role.data(), role.size(), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, Jc->d_node, node.data(), node.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     (void)nn;
     return NK_OK;
   }
@@ -1139,8 +1139,8 @@ static int csr_ensure_coloring(nk_problem *P, nk_csr *J) {
   NK_TRY(nk_dev_alloc(&J->d_nnzcolor, (size_t)J->nnz + 1));
   NK_TRY(nk_dev_alloc(&J->d_seed, (size_t)n + 1));
   NK_TRY(nk_dev_alloc(&J->d_B, (size_t)n + 1));
-  if (n) NK_HIP(hipMemcpy(J->d_color, color_loc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (J->nnz) NK_HIP(hipMemcpy(J->d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n) NK_HIP(nk_memcpy(J->ctx, J->d_color, color_loc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (J->nnz) NK_HIP(nk_memcpy(J->ctx, J->d_nnzcolor, nnzcolor.data(), J->nnz * sizeof(int32_t), hipMemcpyHostToDevice));
   J->ncolors = ncolors;
   return NK_OK;
 }

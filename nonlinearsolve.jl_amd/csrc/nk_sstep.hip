@@ -322,11 +322,21 @@ __device__ bool ss_factor(int k, int sb, const double *__restrict__ red, const d
     }
     if (a > p && b >= a) {
       val = __builtin_fma(-(f0a * ss_rcp(d0)), f0b, val);
-      if (a > p + 1) val = __builtin_fma(-(f1a * ss_rcp(d1)), f1b, val);
-      F[a * SS_FP + b] = val;
+      if (a > p + 1) {   // rows ≥ p + 2: nobody reads them before the barrier
+        val = __builtin_fma(-(f1a * ss_rcp(d1)), f1b, val);
+        F[a * SS_FP + b] = val;
+      }
     }
     __syncthreads();
+    // Row p + 1 — final after pivot p — is READ by every thread in the interval above (d1r, f1ar, f1br: its values BEFORE pivot p),
+    // so its owners store it BEHIND the barrier: the next interval reads rows p + 2 and p + 3 only. (Round 5 stored it in front of
+    // the barrier: a write-after-read race between wavefronts — harmless while the four wavefronts run in step, i.e. alone on
+    // the device; beside another process's kernels a delayed wavefront read the updated row and applied pivot p twice: the
+    // "Cholesky breakdowns a deterministic algorithm cannot hit" and the silently wrong Gram factors of
+    // profiles/r05_m_shared_device.txt, found by tools/shared_device_probe.py --audit, profiles/r06_a_shared_device_root_cause.md.)
+    if (a == p + 1 && b >= a) F[a * SS_FP + b] = val;
   }
+  __syncthreads();   // (row 15's store in front of the diagonal reads below)
   // R = D^½ U (upper; zero below the diagonal). The sweeps apply R⁻¹ by forward substitution, row by row of the tile
   // (q_c = (w_c − Σ_{cc<c} q_cc R_cc,c) / R_cc: the same 120 multiply-adds as a product with an explicit inverse, whose
   // 16 dependent steps were the longest phase of this routine): `Ri` carries R in that form — reciprocal diagonal.
@@ -1226,8 +1236,7 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   int g = grid + (hjp ? hjv.host_wgs : 0);
   if constexpr (S == 15) {
     static const bool mm_on = !(getenv("NK_SS_MM") && atoi(getenv("NK_SS_MM")) == 0);   // A/B switch
-    // (ranks time-slicing one device: no workgroup above 64 KB of LDS — nk_ctx.hip::comm_detect_shared_device)
-    if (mode == 1 && mm_on && !(ctx->device_shared && k == 16) && (k == 1 || k == 16) &&
+    if (mode == 1 && mm_on && (k == 1 || k == 16) &&
         (occ_out || (int64_t)S * ldv * 8 < ((int64_t)1 << 32) - 8)) {
       const size_t tile_b = (size_t)(k + S + 1) * SS_P * sizeof(double);   // the tile + the spare column
       // tap: workgroup 0 hosts the previous block's Hessenberg work (hk, hs); its workspace overlays the tile it does not use
@@ -1768,7 +1777,8 @@ extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
   static unsigned long long *d_st = nullptr;
   if (enable && !d_st) {
     if (hipMalloc(&d_st, 48 * sizeof(unsigned long long)) != hipSuccess) return NK_E_NOMEM;
-    hipMemset(d_st, 0, 48 * sizeof(unsigned long long));
+    hipMemset(d_st, 0, 48 * sizeof(unsigned long long));   // (development hook: the caller synchronises the device)
+    hipDeviceSynchronize();
     hipMemcpyToSymbol(HIP_SYMBOL(g_ss_stamp), &d_st, sizeof(d_st));
   }
   if (!enable && d_st) {
@@ -1796,18 +1806,18 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
   NK_TRY(nk_dev_alloc(&dV, nv));
   NK_TRY(nk_dev_alloc(&dc, (size_t)k * s + s * s + 1));
   NK_TRY(nk_dev_alloc(&dp, nslots * grid + 1));
-  NK_HIP(hipMemcpy(dV, V_host, nv * sizeof(double), hipMemcpyHostToDevice));
+  NK_HIP(nk_memcpy(ctx, dV, V_host, nv * sizeof(double), hipMemcpyHostToDevice));
   if (coef_host) {  // [U ; R] as the caller wrote them → R with a reciprocal diagonal, as the sweeps take it
     std::vector<double> hc(coef_host, coef_host + (size_t)k * s + (size_t)s * s);
     for (int c = 0; c < s; ++c) hc[(size_t)k * s + (size_t)c * s + c] = 1.0 / hc[(size_t)k * s + (size_t)c * s + c];
-    NK_HIP(hipMemcpy(dc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
+    NK_HIP(nk_memcpy(ctx, dc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  NK_HIP(hipMemcpy(V_host, dV, nv * sizeof(double), hipMemcpyDeviceToHost));
+  NK_HIP(nk_memcpy(ctx, V_host, dV, nv * sizeof(double), hipMemcpyDeviceToHost));
   if (mode != 2 && gram_out) {
     std::vector<double> hp(nslots * grid);
-    NK_HIP(hipMemcpy(hp.data(), dp, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    NK_HIP(nk_memcpy(ctx, hp.data(), dp, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t e = 0; e < nslots; ++e) {
       double a = 0.0;
       for (int b = 0; b < grid; ++b) a += hp[e * grid + b];
@@ -2017,13 +2027,13 @@ static int ss_workspace(nk_gmres *G) {
   NK_TRY(nk_dev_alloc(&W->Wi, (size_t)SS_SS * W->nblk_slots));
   NK_TRY(nk_dev_alloc(&W->D, W->c2_stride * W->nblk_slots));
   NK_TRY(nk_dev_alloc(&W->ticket, (size_t)2));
-  NK_HIP(hipMemset(W->ticket, 0, 2 * sizeof(unsigned int)));
+  NK_HIP(nk_memset(G->ctx, W->ticket, 0, 2 * sizeof(unsigned int)));
   NK_TRY(nk_dev_alloc(&W->H, (size_t)(m + 2 + SS_SMAX) * m));
   NK_TRY(nk_dev_alloc(&W->scal, (size_t)SS_TH + SS_SMAX));
   NK_TRY(nk_dev_alloc(&W->ival, (size_t)2));
   NK_TRY(nk_dev_alloc(&W->nodes, (size_t)SS_SMAX));
-  NK_HIP(hipMemset(W->scal, 0, (SS_TH + SS_SMAX) * sizeof(double)));
-  NK_HIP(hipMemset(W->H, 0, (size_t)(m + 2 + SS_SMAX) * m * sizeof(double)));
+  NK_HIP(nk_memset(G->ctx, W->scal, 0, (SS_TH + SS_SMAX) * sizeof(double)));
+  NK_HIP(nk_memset(G->ctx, W->H, 0, (size_t)(m + 2 + SS_SMAX) * m * sizeof(double)));
   G->ss = guard.release();
   return NK_OK;
 }
@@ -2300,6 +2310,8 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
                                W->newton ? W->scal + SS_TH + j : nullptr));
     const int grid = nk_ss_grid(ctx, n, k, sb);
     const int nslots = (k + sb) * sb;
+    if (ctx->audit.on)   // (development) the block's new columns as the operator left them
+      for (int j = 0; j < sb; ++j) nk_audit(ctx, 100 + k - 1 + j, Wk + (size_t)j * ldv, (size_t)n);
     // fused: the block's scalar work rides in the stage-2 reduction (its last workgroup factors the reduced block and leaves
     // the update coefficients for the next sweep's scalar loads) and in sweep C (workgroup 0: the Hessenberg columns) — one
     // rank, or several on peer-mapped arenas (the reduction is then the all-reduce as well). Other transports and the
@@ -2349,7 +2361,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       }
       // where the pending block's Hessenberg columns are derived: in workgroup 0 of this block's sweep B when nothing can stop
       // the cycle early (fixed work) and that sweep has the hosting form; else in the job itself (the verdict arrives before sweep B)
-      const bool host_b = !host_a && dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) && !(ctx->device_shared && k == 16) &&
+      const bool host_b = !host_a && dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) &&
                           (hess_where < 0 ? fixed_work : hess_where == 1);
       {
         ss_job j = jb;
@@ -2407,10 +2419,15 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         }
         NK_TRY(ss_launch_job(ctx, j, ta, ta));
       } else {
+        if (ctx->audit.on) {
+          nk_audit(ctx, 1000 * (pass + 1) + 10 * blk + 1, W->part, (size_t)nslots * grid);            // the sweep's partial Gram blocks
+          if (pass == 1) for (int j = 0; j < sb; ++j) nk_audit(ctx, 200 + k + j, Wk + (size_t)j * ldv, (size_t)n);   // … and updated columns
+        }
         {
           nk_prof_scope prof_(ctx, NK_K_REDUCE_SMALL, 8.0 * nslots * grid);
           NK_TRY(nk_blas_reduce_slots_allreduce(ctx, W->part, grid, nslots, W->red, done));  // (k + s)·s values, one message
         }
+        if (ctx->audit.on) nk_audit(ctx, 1000 * (pass + 1) + 10 * blk + 2, W->red, (size_t)nslots);   // the reduced (all-reduced) block
         const size_t lds = (ss_ws_doubles(k, sb, pass == 1) + ss_fixc_doubles(ta.fix)) * sizeof(double);
         if (pass == 0) {
           if (lds > 64 * 1024)
@@ -2420,6 +2437,12 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
           if (lds > 64 * 1024)
             NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_tail2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hipLaunchKernelGGL(k_ss_tail2, dim3(1), dim3(256), lds, ctx->stream, k, sb, W->coef, ta);
+        }
+        if (ctx->audit.on) {   // what the tail left: the next sweep's coefficients, the factors, the control block
+          nk_audit(ctx, 1000 * (pass + 1) + 10 * blk + 3, W->coef, (size_t)k * sb + (size_t)sb * sb);
+          nk_audit(ctx, 1000 * (pass + 1) + 10 * blk + 4, pass == 0 ? ta.C1 : ta.C2, (size_t)k * sb);
+          nk_audit(ctx, 1000 * (pass + 1) + 10 * blk + 5, pass == 0 ? ta.R1 : ta.R2, (size_t)sb * sb);
+          nk_audit(ctx, 1000 * (pass + 1) + 10 * blk + 6, G->d_ctl, sizeof(nk_gmres_ctl) / 8);
         }
       }
     }

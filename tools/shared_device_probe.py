@@ -12,6 +12,7 @@ the histogram of ‖F‖∞ after the steps as hex floats: a deterministic path 
 Environment switches (NK_*) are passed through; `--env K=V` sets one for the workers only.
 Output: one JSON line per mode with the histogram, the all-reduce counts and the trials that raised / hung."""
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -37,6 +38,12 @@ def _trials(nls, torch, ctx, args, tag, sync=None):
     faulthandler.enable()
     prob, u0, cache = _make(nls, torch, ctx, args.grid, args)
     vals, ars, errs = [], [], []
+    audit_ref = []
+    if args.audit:
+        from nonlinearsolve_jl_amd import _lib as L
+        L.lib().nk_debug_audit_enable.restype = C.c_int
+        L.lib().nk_debug_audit_enable.argtypes = [C.c_void_p, C.c_int]
+        assert L.lib().nk_debug_audit_enable(ctx._h, 1) == 0
     for tr in range(args.trials):
         try:
             if sync is not None:
@@ -45,10 +52,21 @@ def _trials(nls, torch, ctx, args, tag, sync=None):
             cache.reinit(u0=u0)
             a0 = int(cache.stats.allreduces)
             trace = []
-            for _ in range(args.steps):
+            for st_i in range(args.steps):
                 cache.step()
                 if args.detail:
                     trace.append(float(cache.fnorm_inf).hex())
+                if args.audit:
+                    log = _audit_fetch(ctx)
+                    if tr == 0:
+                        audit_ref.append(log)
+                    elif [e for e in log if e[0] % 10 != 6] != [e for e in audit_ref[st_i] if e[0] % 10 != 6]:   # (…6: the control block, which carries stale fields)
+                        ref = audit_ref[st_i]
+                        first = next((i for i in range(min(len(log), len(ref))) if log[i] != ref[i] and log[i][0] % 10 != 6), min(len(log), len(ref)))
+                        print(f"[probe {tag}] AUDIT trial {tr} step {st_i}: {len(log)} entries (reference {len(ref)}); first difference at "
+                              f"entry {first}: {log[first] if first < len(log) else None} vs {ref[first] if first < len(ref) else None}; "
+                              f"tags around: {[t for t, _ in log[max(0, first - 3):first + 4]]}", file=sys.stderr, flush=True)
+                        audit_ref[st_i] = log   # (the path may have changed for good: a block-size cap after a breakdown)
             faulthandler.cancel_dump_traceback_later()
             vals.append(float(cache.fnorm_inf).hex())
             ars.append(int(cache.stats.allreduces) - a0)
@@ -64,6 +82,19 @@ def _trials(nls, torch, ctx, args, tag, sync=None):
         pass
     cache.close()
     return {"tag": tag, "values": vals, "allreduces": ars, "errors": errs, "sstep_state": st}
+
+
+def _audit_fetch(ctx):
+    from nonlinearsolve_jl_amd import _lib as L
+    f = L.lib().nk_debug_audit_fetch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    cap = 1 << 16
+    tags = (C.c_int * cap)()
+    hs = (C.c_ulonglong * cap)()
+    n = C.c_int(0)
+    assert f(ctx._h, tags, hs, cap, C.byref(n)) == 0
+    return [(int(tags[i]), int(hs[i])) for i in range(n.value)]
 
 
 def _summary(res):
@@ -287,6 +318,7 @@ def main():
     ap.add_argument("--timeout", type=float, default=240.0)
     ap.add_argument("--env", action="append", default=[])
     ap.add_argument("--label", default="")
+    ap.add_argument("--audit", action="store_true", help="content hashes at named points of every step (nk_audit): the first point where a trial differs from trial 0")
     ap.add_argument("--detail", action="store_true", help="per-trial, per-step residual norms on stderr")
     ap.add_argument("--stall-dump", type=float, default=45.0, help="seconds after which a stalled trial dumps its Python stacks")
     args = ap.parse_args()
