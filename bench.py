@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--step-events", action="store_true", help="development: one event record per step INSIDE the timed region (the form of rounds 3-5)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling run")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance extras")
     ap.add_argument("--no-spmv-hbm", action="store_true", help="skip the HBM-resident SpMV measurement (Bratu 4096², ≈ 10 s)")
@@ -143,29 +144,59 @@ def live_pmc_traffic(args, kname):
                      f"{time.perf_counter() - t0:.0f} s), (2·F + W)·1024")
 
 
+STEP_EVENTS = False
+
+
 def timed_steps(cache, steps, barrier, dist, world, backend, torch):
-    """EXACTLY `steps` steps between two barriers + synchronisations (the contract's clock), max over the ranks. Inside the timed
-    region an event is recorded on the library's stream after every step (no synchronisation: ≈ 1 µs each): the distribution of
-    the per-step times — median, p10, p90 — is reported next to the mean the contract asks for."""
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    """EXACTLY `steps` steps between two barriers + synchronisations (the contract's clock), max over the ranks. Nothing but the
+    steps is inside the timed region."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if STEP_EVENTS else None
+    host = []
+    gc_mode = os.environ.get("BENCH_GC", "1")
+    if gc_mode == "1":     # the interpreter's cyclic collector stays out of the timed region
+        import gc
+        gc.collect()
+        gc.disable()
     barrier()
     t0 = time.perf_counter()
-    evs[0].record()
     for i in range(steps):
         cache.step()
-        evs[i + 1].record()
+        if evs:
+            evs[i].record()
+        host.append(time.perf_counter())
+    t_loop = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
-    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
-    if per:
-        q = lambda f: per[min(len(per) - 1, int(f * len(per)))]  # noqa: E731
-        STEP_STATS.update(n=steps, median_ms=round(q(0.5), 4), p10_ms=round(q(0.1), 4), p90_ms=round(q(0.9), 4),
-                          min_ms=round(per[0], 4), max_ms=round(per[-1], 4))
+    STEP_STATS.update(closing_barrier_ms=round((t0 + dt - t_loop) * 1e3, 3))
+    if gc_mode == "1":
+        gc.enable()
+    hs = sorted(b - a for a, b in zip([t0] + host[:-1], host))
+    if hs:
+        STEP_STATS.update(host_median_ms=round(hs[len(hs) // 2] * 1e3, 4), host_max_ms=round(hs[-1] * 1e3, 4),
+                          host_p99_ms=round(hs[min(len(hs) - 1, int(0.99 * len(hs)))] * 1e3, 4), host_mean_ms=round(sum(hs) / len(hs) * 1e3, 4))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def step_time_distribution(cache, steps, barrier, torch):
+    """A pass of its own, NOT the contract's clock: an event recorded on the library's stream after every step (no
+    synchronisation — but every record is a marker packet between two steps' kernels, a few µs of idle device each, which is why
+    round 6 took the events out of the timed region): median, p10, p90 of the per-step times."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    evs[0].record()
+    for i in range(steps):
+        cache.step()
+        evs[i + 1].record()
+    barrier()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    if per:
+        q = lambda f: per[min(len(per) - 1, int(f * len(per)))]  # noqa: E731
+        STEP_STATS.update(n=steps, mean_ms=round(sum(per) / len(per), 4), median_ms=round(q(0.5), 4), p10_ms=round(q(0.1), 4), p90_ms=round(q(0.9), 4),
+                          min_ms=round(per[0], 4), max_ms=round(per[-1], 4), measured="in a pass of its own (one event per step)")
 
 
 def bytes_per_step(args, n, nnz, newton_basis, resident_powers):
@@ -318,6 +349,8 @@ def main():
         # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
         return prob, nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)
 
+    global STEP_EVENTS
+    STEP_EVENTS = args.step_events
     ns = args.n or {"c3": 1024, "c4": 4096, "c5": 512}[args.workload]
     prob, cache = make_cache(args.workload, ns)
     n_local, n_global = prob.device_problem.n_local, prob.device_problem.n_global
@@ -327,6 +360,7 @@ def main():
     steps_per_s = args.steps / dt
     stats = cache.stats
     fnorm = cache.fnorm_inf
+    step_time_distribution(cache, min(args.steps, 200), barrier, torch)
 
     # ---- second, instrumented pass of the same K steps: HIP events on the launch stream around every
     # kernel family (not part of `value`)

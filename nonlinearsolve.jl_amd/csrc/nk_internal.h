@@ -1,9 +1,11 @@
 // Internal declarations of libmi355x_nk.so (gfx950 only). Not part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <functional>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -167,13 +169,25 @@ struct nk_ctx {
   nk_stats stats{};
 };
 
-// Host side of "a kernel publishes into coherent pinned memory, the host polls": spins on `ready`, checking every few
-// thousand polls that the stream is still alive (a faulted or drained stream must not leave the host spinning).
+// Host side of "a kernel publishes into coherent pinned memory, the host polls": spins on `ready`, checking that the stream
+// is still alive (a faulted or drained stream must not leave the host spinning) — by the CLOCK, first after 2 ms and every
+// 2 ms from then on: hipStreamQuery on a busy stream makes the runtime put a marker (a barrier packet with a completion
+// signal) behind the last kernel enqueued, 6 µs of idle device in front of the next one; a poll count (round 5: every 16 384
+// polls ≈ 0.2 ms) put that marker into every Newton step whose linear solve outlasted it.
 template <class Pred>
 static inline int nk_spin_wait(nk_ctx *ctx, Pred ready, const char *what) {
+  static const long legacy_polls = getenv("NK_SPIN_QUERY_POLLS") ? atol(getenv("NK_SPIN_QUERY_POLLS")) : 0;   // A/B: round 5's form
+  auto next_check = std::chrono::steady_clock::time_point{};
   for (uint64_t it = 1;; ++it) {
     if (ready()) return NK_OK;
-    if ((it & 0x3fff) == 0) {
+    bool check = false;
+    if (legacy_polls > 0) check = (it % (uint64_t)legacy_polls) == 0;
+    else if ((it & 0x3ff) == 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (next_check == std::chrono::steady_clock::time_point{}) next_check = now + std::chrono::milliseconds(2);
+      else if (now >= next_check) { check = true; next_check = now + std::chrono::milliseconds(2); }
+    }
+    if (check) {
       const hipError_t e = hipStreamQuery(ctx->stream);
       if (e == hipSuccess) {
         if (ready()) return NK_OK;
@@ -481,6 +495,10 @@ struct nk_gmres {
   double *x0_keep = nullptr;   // the warm start of a solve that runs on a resident matrix-powers plan (restored if a launch is torn)
   nk_fused_update fu;          // armed by the Newton driver for ONE solve (nk_gmres_arm_fused_update)
   struct { const double *b = nullptr, *ss = nullptr; int grid = 0; } pre;   // nk_gmres_preloaded_rhs (one solve)
+  // nk_gmres_solve_head: the begin kernel and the first block's operator applications of the NEXT solve are in the queue
+  // already — for exactly these arguments and this set of operator values
+  struct { bool valid = false; const double *b = nullptr, *val = nullptr; double atol = 0.0, rtol = 0.0;
+           int maxiter = 0, fixed_iters = 0; uint64_t seq = 0; } head;
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
@@ -627,6 +645,7 @@ void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v);
 int nk_csr_alloc_values(nk_csr *A, double **out);   // a zero-padded value array of A's size (freed with hipFree)
 // fill kernels' Gershgorin partials not reduced yet: hands them to a caller that reduces them into *dst in its own kernel
 bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
+void nk_csr_invalidate_bounds(nk_csr *A);   // the bounds word no longer belongs to the live values (recomputed on demand)
 void nk_csr_commit_pending_bounds(nk_csr *A);   // the caller's reducing kernel is enqueued: the partials are no longer pending
 int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
 // (have_partials > 0: stage 1 has run inside the kernel that produced x — ctx->d_partials holds its have_partials workgroups' results)
@@ -635,7 +654,8 @@ int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *
 // the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
-int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved);
+// part: 0 the whole cycle; 1 the HEAD only — the first block's operator applications (nk_gmres_solve_head); 2 everything but those
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved, int part = 0);
 // The NEXT solve's last pass (x = V y) also forms u_new = u_old + usign·x and the partial sums of ‖u_new − u_old‖² — if that solve
 // is a single cycle from a zero guess without a right preconditioner. nk_gmres_take_fused_update: whether it happened (disarms).
 void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, double usign, double *partials);
@@ -645,6 +665,15 @@ void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, 
 // next solve could not use it anyway.
 double *nk_gmres_rhs_column(nk_gmres *G);
 void nk_gmres_preloaded_rhs(nk_gmres *G, const double *d_b, const double *ss_partials, int grid);
+// The first launches of the NEXT solve enqueued ahead of the caller's host round trip (the Newton driver: behind the kernels
+// that produce the step's norms, before it waits for them): the cycle's begin kernel and the first block's operator
+// applications — when that solve will be the fixed-work, single-cycle, zero-guess s-step solve on one rank whose right-hand
+// side d_b sits in column 0 already (nk_gmres_preloaded_rhs) and whose operator is the CSR matrix with the values it holds NOW.
+// *done: whether anything was enqueued. nk_gmres_solve_dev takes the launches over when its arguments and the operator's value
+// array are the same, and otherwise starts from scratch (the head touched the basis and the control block only);
+// nk_gmres_drop_head forgets it (every nk_gmres_set_* does).
+int nk_gmres_solve_head(nk_gmres *G, const double *d_b, double atol, double rtol, int maxiter, int fixed_iters, bool *done);
+void nk_gmres_drop_head(nk_gmres *G);
 bool nk_gmres_take_fused_update(nk_gmres *G, int *grid);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);

@@ -1955,6 +1955,7 @@ __global__ void k_ss_force_fail(nk_gmres_ctl *ctl, nk_gmres_pub *pub, uint64_t s
   ss_pub_progress(pub, seq, ctl->k, 1);
 }
 extern "C" int nk_gmres_debug_force_breakdown(nk_gmres *G, int cycle) {
+  if (G) G->head.valid = false;   // (a head enqueued for the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->ss_force_break_cycle = cycle;
   return NK_OK;
@@ -2224,7 +2225,9 @@ static bool ss_a_can_host_job(nk_ctx *ctx, int k, int s) {
 // sweep B (the fixed-work protocol: off the critical path). The cycle's last block is closed by one launch that reduces,
 // factors, derives the Hessenberg columns and back-substitutes without leaving the workgroup. Per GMRES(30) cycle of two blocks:
 // 3 scalar launches instead of 6 (4 × k_ss_reduce_factor, k_ss_hess, k_backsolve), 3 all-reduces instead of 4 on several ranks.
-int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved) {
+// part = 1 enqueues the HEAD of the cycle only — the first block's operator applications, ahead of the solve proper
+// (nk_gmres_solve_head) —, part = 2 everything but those.
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved, int part) {
   nk_ctx *ctx = G->ctx;
   if (backsolved) *backsolved = false;
   NK_TRY(ss_workspace(G));
@@ -2281,7 +2284,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     if (with_back && backsolved) *backsolved = true;
     return NK_OK;
   };
-  if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
+  if (part != 1 && G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
   int prev_sb = s;
@@ -2302,12 +2305,14 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     double *Wk = G->V + (size_t)k * ldv;
     // the block's basis vectors: (A − θ_j I) applied s times (right-preconditioned operator), scaled by 1/σ — in one launch
     // with the matrix held on the chip where that applies (nk_powers.hip), else one operator launch per column
-    bool powers = false;
-    NK_TRY(nk_gmres_op_powers(G, G->V + (size_t)(k - 1) * ldv, Wk, ldv, sb, done, W->scal, W->newton ? W->scal + SS_TH : nullptr,
-                              &powers));
+    bool powers = part == 2 && k == 1;   // (in the queue already: the cycle's head)
+    if (!powers)
+      NK_TRY(nk_gmres_op_powers(G, G->V + (size_t)(k - 1) * ldv, Wk, ldv, sb, done, W->scal, W->newton ? W->scal + SS_TH : nullptr,
+                                &powers));
     for (int j = 0; j < sb && !powers; ++j)
       NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1),
                                W->newton ? W->scal + SS_TH + j : nullptr));
+    if (part == 1) return NK_OK;
     const int grid = nk_ss_grid(ctx, n, k, sb);
     const int nslots = (k + sb) * sb;
     if (ctx->audit.on)   // (development) the block's new columns as the operator left them
