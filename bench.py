@@ -67,7 +67,6 @@ def parse_args():
     ap.add_argument("--matfree", action="store_true", help="bench the matrix-free JVP operator instead of CSR")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--step-events", action="store_true", help="development: one event record per step INSIDE the timed region (the form of rounds 3-5)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling run")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance extras")
     ap.add_argument("--no-spmv-hbm", action="store_true", help="skip the HBM-resident SpMV measurement (Bratu 4096², ≈ 10 s)")
@@ -144,32 +143,26 @@ def live_pmc_traffic(args, kname):
                      f"{time.perf_counter() - t0:.0f} s), (2·F + W)·1024")
 
 
-STEP_EVENTS = False
-
-
 def timed_steps(cache, steps, barrier, dist, world, backend, torch):
     """EXACTLY `steps` steps between two barriers + synchronisations (the contract's clock), max over the ranks. Nothing but the
-    steps is inside the timed region."""
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if STEP_EVENTS else None
+    steps is inside the timed region — no event records (marker packets between the steps' kernels: they moved to
+    step_time_distribution in round 6), and not the interpreter's cyclic garbage collector either: a full collection of the
+    torch / scipy object graph takes ≈ 46 ms and, once the events were gone, fired inside the closing barrier of every run
+    (profiles/r06_c_host_gaps_head_and_powers_handoff.md §3)."""
+    import gc
     host = []
-    gc_mode = os.environ.get("BENCH_GC", "1")
-    if gc_mode == "1":     # the interpreter's cyclic collector stays out of the timed region
-        import gc
-        gc.collect()
-        gc.disable()
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         cache.step()
-        if evs:
-            evs[i].record()
         host.append(time.perf_counter())
     t_loop = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     STEP_STATS.update(closing_barrier_ms=round((t0 + dt - t_loop) * 1e3, 3))
-    if gc_mode == "1":
-        gc.enable()
     hs = sorted(b - a for a, b in zip([t0] + host[:-1], host))
     if hs:
         STEP_STATS.update(host_median_ms=round(hs[len(hs) // 2] * 1e3, 4), host_max_ms=round(hs[-1] * 1e3, 4),
@@ -349,8 +342,6 @@ def main():
         # abstol tiny and maxiters huge: every step does the full fixed work, nothing terminates early
         return prob, nls.init(prob, alg, abstol=1e-300, maxiters=10 ** 9)
 
-    global STEP_EVENTS
-    STEP_EVENTS = args.step_events
     ns = args.n or {"c3": 1024, "c4": 4096, "c5": 512}[args.workload]
     prob, cache = make_cache(args.workload, ns)
     n_local, n_global = prob.device_problem.n_local, prob.device_problem.n_global

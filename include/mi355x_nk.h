@@ -404,7 +404,10 @@ int nk_spmv_t(nk_csr *A, const double *x, double *y, int memspace);
  * (*resident = 1, csrc/nk_powers.hip) — also a matrix made of two equal segments that is banded segment by segment (the
  * (i, j, species) ordering of a two-species system, docs/src/tutorials/large_systems.md) and / or whose bands close to a ring
  * (periodic boundaries); any other matrix takes s streaming SpMV launches. The columns are bit-identical either way.
- * NK_SPMV_POWERS=0 disables the resident kernel. */
+ * NK_SPMV_POWERS=0 disables the resident kernel.
+ * Several ranks: whether the resident kernel applies is decided ONCE per matrix by all ranks together — the first nk_csr_powers
+ * or s-step linear solve on a row-partitioned matrix is COLLECTIVE (two small all-reduces through the communicator); every rank
+ * must reach it, also a rank whose share would not qualify. */
 int nk_csr_powers(nk_csr *A, const double *x, double *Y, int64_t ldy, int s, const double *theta, double scale, int memspace,
                   int *resident);
 /* Which form of the resident kernel a CSR PATTERN (global column ids, one rank) fits on a device with num_cus compute units —

@@ -861,30 +861,9 @@ __global__ __launch_bounds__(NK_BLOCK) void k_reduce_inf2(const double *__restri
                                                           const double *__restrict__ extra, int extra_n,
                                                           double *__restrict__ out, double *h_dst, uint64_t *h_seq, uint64_t seq) {
   __shared__ double sm[12];
-  double m = -__builtin_inf(), s = 0.0, e = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += NK_BLOCK) { m = nanmax(m, partials[i]); s += partials[nblk + i]; }
-  for (int i = threadIdx.x; i < extra_n; i += NK_BLOCK) e += extra[i];
-  m = wave_nanmax(m);
-  s = wave_sum(s);
-  e = wave_sum(e);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sm[w] = m; sm[4 + w] = s; sm[8 + w] = e; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double o0 = nanmax(nanmax(sm[0], sm[1]), nanmax(sm[2], sm[3]));
-    const double o1 = (sm[4] + sm[5]) + (sm[6] + sm[7]);
-    const double o2 = (sm[8] + sm[9]) + (sm[10] + sm[11]);
-    out[0] = o0;
-    out[1] = o1;
-    if (extra != nullptr) out[2] = o2;
-    if (h_dst != nullptr) {
-      h_dst[0] = o0;
-      h_dst[1] = o1;
-      if (extra != nullptr) h_dst[2] = o2;
-      __threadfence_system();
-      __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  nk_fold_norms f;
+  f.partials = partials; f.nblk = nblk; f.extra = extra; f.extra_n = extra_n; f.out = out; f.h_dst = h_dst; f.h_seq = h_seq; f.seq = seq;
+  nk_reduce_inf2_body(f, sm);
 }
 int nk_blas_norms_inf2(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
                        int have_partials) {
@@ -899,7 +878,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_publish(const double *__restrict__
                                                       uint64_t seq);
 // the same, with the 2–3 results delivered to the host (`h_out`): on one rank the stage-2 launch publishes them itself
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
-                               double *h_out, const std::function<int()> &before_wait, int have_partials) {
+                               double *h_out, const std::function<int()> &before_wait, int have_partials,
+                               const std::function<int(const nk_fold_norms &, bool *)> &fold_into) {
   const int count = extra_partials ? 3 : 2;
   static const bool legacy = getenv("NK_FETCH_MEMCPY") != nullptr || getenv("NK_NORMS_SEPARATE_PUBLISH") != nullptr;
   if (!nk_ctx_is_single(ctx) || legacy) {
@@ -918,8 +898,17 @@ int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *
   const int grid = have_partials > 0 ? have_partials : nk_grid_for(n, NK_BLOCK * 4, NK_MAX_RED_BLOCKS);
   const uint64_t seq = ++ctx->seq;
   if (have_partials <= 0) NK_LAUNCH(ctx, k_absmax_sumsq, dim3(grid), dim3(NK_BLOCK), n, x, ctx->d_partials);
-  NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
-            ctx->h_pinned_dev, ctx->h_seq_dev, seq);
+  bool folded = false;
+  static const bool fold_off = getenv("NK_FOLD_NORMS") && atoi(getenv("NK_FOLD_NORMS")) == 0;   // A/B switch
+  if (fold_into && have_partials > 0 && !fold_off) {
+    nk_fold_norms f;
+    f.partials = ctx->d_partials; f.nblk = grid; f.extra = extra_partials; f.extra_n = extra_n; f.out = d_out;
+    f.h_dst = ctx->h_pinned_dev; f.h_seq = ctx->h_seq_dev; f.seq = seq;
+    NK_TRY(fold_into(f, &folded));
+  }
+  if (!folded)
+    NK_LAUNCH(ctx, k_reduce_inf2, dim3(1), dim3(NK_BLOCK), (const double *)ctx->d_partials, grid, extra_partials, extra_n, d_out,
+              ctx->h_pinned_dev, ctx->h_seq_dev, seq);
   NK_HIP(hipGetLastError());
   if (before_wait) NK_TRY(before_wait());   // (the host's round trip for these scalars then overlaps with that work)
   volatile uint64_t *hs = ctx->h_seq;

@@ -289,6 +289,7 @@ int nk_csr_create_local(nk_ctx *ctx, int64_t nrows, int64_t n_global, int64_t ro
   else if (nnz) NK_HIP(nk_memset(ctx, A->d_val, 0, nnz * sizeof(double)));
 
   // ---- halo plan (collective): tell every owner which of its entries we need
+  A->local_only = local_only;
   if (ctx->nranks > 1 && !local_only) {
     const int P = ctx->nranks;
     // 1. everyone learns all row ranges: all-reduce a zero vector with our begin in slot `rank`
@@ -663,7 +664,6 @@ bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, doubl
   return true;
 }
 void nk_csr_commit_pending_bounds(nk_csr *A) { A->bounds_pending = false; }
-void nk_csr_invalidate_bounds(nk_csr *A) { A->bounds_valid = false; A->bounds_pending = false; }
 int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2, const double **where) {
   nk_ctx *ctx = A->ctx;
   NK_REQUIRE(A->nblocks > 0, "Gershgorin bounds of an empty matrix");

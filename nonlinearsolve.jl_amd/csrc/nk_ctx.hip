@@ -715,11 +715,14 @@ static int halo_setup_peer(nk_ctx *ctx, nk_halo *H) {
   for (int p = 0; p < P; ++p) row[3 + p] = (double)H->recv_off[p];
   double *d_tab = nullptr;
   NK_TRY(nk_dev_alloc(&d_tab, tab.size()));
-  NK_HIP(nk_memcpy(ctx, d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-  int st = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
+  int st = NK_OK;   // (every exit below frees d_tab; a failed copy still takes part in the collective with what it has)
+  if (nk_memcpy(ctx, d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) st = NK_E_HIP;
+  const int st_ar = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
+  if (st == NK_OK) st = st_ar;
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
-  if (st == NK_OK) NK_HIP(nk_memcpy(ctx, tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (st == NK_OK && nk_memcpy(ctx, tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = NK_E_HIP;
   hipFree(d_tab);
+  if (st == NK_E_HIP) nk_set_error("peer set-up: a copy of the negotiation table failed");
   NK_TRY(st);
   bool fits = true;
   for (int p = 0; p < P; ++p) fits = fits && tab[(size_t)p * (P + 3) + 2] == 0.0;
@@ -778,11 +781,14 @@ int nk_peer_powers_setup(nk_ctx *ctx, bool eligible, nk_peer_powers *out, bool *
   tab[(size_t)me * 2 + 1] = (eligible && pr.on && off + NEED <= pr.arena_bytes) ? 0.0 : 1.0;
   double *d_tab = nullptr;
   NK_TRY(nk_dev_alloc(&d_tab, tab.size()));
-  NK_HIP(nk_memcpy(ctx, d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-  int st = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
+  int st = NK_OK;   // (every exit below frees d_tab; a failed copy still takes part in the collective with what it has)
+  if (nk_memcpy(ctx, d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) st = NK_E_HIP;
+  const int st_ar = comm_allreduce_base(ctx, d_tab, (int)tab.size(), 0);
+  if (st == NK_OK) st = st_ar;
   if (st == NK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = NK_E_HIP;
-  if (st == NK_OK) NK_HIP(nk_memcpy(ctx, tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (st == NK_OK && nk_memcpy(ctx, tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = NK_E_HIP;
   hipFree(d_tab);
+  if (st == NK_E_HIP) nk_set_error("peer set-up: a copy of the negotiation table failed");
   NK_TRY(st);
   for (int p = 0; p < P; ++p)
     if (tab[(size_t)p * 2 + 1] != 0.0) return NK_OK;   // somebody cannot: nobody does

@@ -172,28 +172,25 @@ struct nk_ctx {
 // Host side of "a kernel publishes into coherent pinned memory, the host polls": spins on `ready`, checking that the stream
 // is still alive (a faulted or drained stream must not leave the host spinning) — by the CLOCK, first after 2 ms and every
 // 2 ms from then on: hipStreamQuery on a busy stream makes the runtime put a marker (a barrier packet with a completion
-// signal) behind the last kernel enqueued, 6 µs of idle device in front of the next one; a poll count (round 5: every 16 384
-// polls ≈ 0.2 ms) put that marker into every Newton step whose linear solve outlasted it.
+// signal) behind the last kernel enqueued; a poll count (round 5: every 16 384 polls ≈ 0.2 ms) put one into every Newton step
+// whose linear solve outlasted it. (No measurable effect on the step time: profiles/r06_c_host_gaps_head_and_powers_handoff.md.)
 template <class Pred>
 static inline int nk_spin_wait(nk_ctx *ctx, Pred ready, const char *what) {
-  static const long legacy_polls = getenv("NK_SPIN_QUERY_POLLS") ? atol(getenv("NK_SPIN_QUERY_POLLS")) : 0;   // A/B: round 5's form
   auto next_check = std::chrono::steady_clock::time_point{};
   for (uint64_t it = 1;; ++it) {
     if (ready()) return NK_OK;
-    bool check = false;
-    if (legacy_polls > 0) check = (it % (uint64_t)legacy_polls) == 0;
-    else if ((it & 0x3ff) == 0) {
+    if ((it & 0x3ff) == 0) {
       const auto now = std::chrono::steady_clock::now();
       if (next_check == std::chrono::steady_clock::time_point{}) next_check = now + std::chrono::milliseconds(2);
-      else if (now >= next_check) { check = true; next_check = now + std::chrono::milliseconds(2); }
-    }
-    if (check) {
-      const hipError_t e = hipStreamQuery(ctx->stream);
-      if (e == hipSuccess) {
-        if (ready()) return NK_OK;
-        NK_FAIL(NK_E_HIP, "the stream drained but %s never arrived", what);
+      else if (now >= next_check) {
+        next_check = now + std::chrono::milliseconds(2);
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) {
+          if (ready()) return NK_OK;
+          NK_FAIL(NK_E_HIP, "the stream drained but %s never arrived", what);
+        }
+        if (e != hipErrorNotReady) NK_FAIL(NK_E_HIP, "stream error while waiting for %s: %s", what, hipGetErrorString(e));
       }
-      if (e != hipErrorNotReady) NK_FAIL(NK_E_HIP, "stream error while waiting for %s: %s", what, hipGetErrorString(e));
     }
     __builtin_ia32_pause();
   }
@@ -317,6 +314,7 @@ struct nk_csr {
   // resident matrix-powers kernel (nk_powers.hip): built on first use; NULL = the matrix is not eligible
   struct nk_powers_plan *pw = nullptr;
   bool pw_tried = false;
+  bool local_only = false;   // created without a global partition (helper matrices): nothing about it is collective
 };
 // s operator applications in one launch with the matrix held in registers (nk_powers.hip):
 //   Y[:, p] = os_p·(A Y[:, p−1] − θ_p Y[:, p−1]),  Y[:, −1] = x0,  os_0 = *d_scal_first, os_p = *d_scal_rest (NULL = 1), θ NULL = 0
@@ -395,7 +393,22 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
                        const double *d_out_scale = nullptr, const struct nk_spmv_epi *epi = nullptr);
 int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
 int nk_problem_spectrum_interval_dev(nk_problem *P, const double *d_u, double *d_out2);  // Bratu: {−lo, hi} of the stencil's discs
-int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J);
+// `fold` (optional): the stage-2 reduction of a residual kernel's norm partials — max |f|, Σ f², optionally a second sum — and
+// their delivery to the host ride in workgroup 0 of the fill kernel instead of in a launch of their own (k_reduce_inf2): the
+// Newton driver's speculative fill of the NEXT Jacobian sits directly behind the residual kernel, and its first workgroup has the
+// norms out ≈ 3 µs into the launch while the others write the matrix. *folded: whether this problem's fill kernel took it (the
+// Bratu fill on one rank does; otherwise the caller launches the reduction itself).
+struct nk_fold_norms {
+  const double *partials = nullptr;   // [nblk] maxima, then [nblk] sums (k_absmax_sumsq's layout)
+  int nblk = 0;
+  const double *extra = nullptr;      // [extra_n] further partial sums (nullable)
+  int extra_n = 0;
+  double *out = nullptr, *h_dst = nullptr;   // device scalars; coherent pinned host copy (nullable)
+  uint64_t *h_seq = nullptr;
+  uint64_t seq = 0;
+};
+int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const nk_fold_norms *fold = nullptr,
+                              bool *folded = nullptr);
 int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J);  // ncolors JVPs + decompression
 
 // ----------------------------------------------------------------------------- BLAS-1 launchers (device)
@@ -495,10 +508,6 @@ struct nk_gmres {
   double *x0_keep = nullptr;   // the warm start of a solve that runs on a resident matrix-powers plan (restored if a launch is torn)
   nk_fused_update fu;          // armed by the Newton driver for ONE solve (nk_gmres_arm_fused_update)
   struct { const double *b = nullptr, *ss = nullptr; int grid = 0; } pre;   // nk_gmres_preloaded_rhs (one solve)
-  // nk_gmres_solve_head: the begin kernel and the first block's operator applications of the NEXT solve are in the queue
-  // already — for exactly these arguments and this set of operator values
-  struct { bool valid = false; const double *b = nullptr, *val = nullptr; double atol = 0.0, rtol = 0.0;
-           int maxiter = 0, fixed_iters = 0; uint64_t seq = 0; } head;
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
@@ -598,6 +607,38 @@ int nk_ss_block_width(int want);
 // start of a restart cycle (thread 0 of k_gmres_begin / of the s-step form's k_ss_cycle_begin): β = ‖r₀‖ from its square,
 // tolerance of a new solve, flags, the first column's scale, the right-hand side of the small least-squares problem
 #ifdef __HIPCC__
+// stage 2 of the norms [max |·| (NaN-propagating), Σ, Σ]: ONE 256-thread workgroup, fixed order — k_reduce_inf2 (nk_blas.hip) as a
+// launch of its own, workgroup 0 of a fill kernel when folded (nk_fold_norms): the same arithmetic either way
+__device__ __forceinline__ double nk_nanmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
+__device__ __forceinline__ void nk_reduce_inf2_body(const nk_fold_norms &f, double *sm /* [12] shared */) {
+  double m = -__builtin_inf(), s = 0.0, e = 0.0;
+  for (int i = threadIdx.x; i < f.nblk; i += NK_BLOCK) { m = nk_nanmax(m, f.partials[i]); s += f.partials[f.nblk + i]; }
+  for (int i = threadIdx.x; i < f.extra_n; i += NK_BLOCK) e += f.extra[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = nk_nanmax(m, __shfl_xor(m, o, 64));
+    s += __shfl_xor(s, o, 64);
+    e += __shfl_xor(e, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w] = m; sm[4 + w] = s; sm[8 + w] = e; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double o0 = nk_nanmax(nk_nanmax(sm[0], sm[1]), nk_nanmax(sm[2], sm[3]));
+    const double o1 = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+    const double o2 = (sm[8] + sm[9]) + (sm[10] + sm[11]);
+    f.out[0] = o0;
+    f.out[1] = o1;
+    if (f.extra != nullptr) f.out[2] = o2;
+    if (f.h_dst != nullptr) {
+      f.h_dst[0] = o0;
+      f.h_dst[1] = o1;
+      if (f.extra != nullptr) f.h_dst[2] = o2;
+      __threadfence_system();
+      __hip_atomic_store(f.h_seq, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 __device__ __forceinline__ void nk_gmres_begin_body(nk_gmres_ctl *ctl, double ss, double atol, double rtol, int fixed, int first,
                                                     double *g, double *s, int m, nk_gmres_pub *pub, uint64_t seq) {
   const double beta = sqrt(ss);
@@ -645,17 +686,19 @@ void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v);
 int nk_csr_alloc_values(nk_csr *A, double **out);   // a zero-padded value array of A's size (freed with hipFree)
 // fill kernels' Gershgorin partials not reduced yet: hands them to a caller that reduces them into *dst in its own kernel
 bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
-void nk_csr_invalidate_bounds(nk_csr *A);   // the bounds word no longer belongs to the live values (recomputed on demand)
 void nk_csr_commit_pending_bounds(nk_csr *A);   // the caller's reducing kernel is enqueued: the partials are no longer pending
 int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
 // (have_partials > 0: stage 1 has run inside the kernel that produced x — ctx->d_partials holds its have_partials workgroups' results)
+// fold_into (optional, one rank, have_partials > 0): called INSTEAD of launching the stage-2 reduction, with what a kernel of the
+// caller's needs to perform it in its first workgroup (nk_fold_norms); it returns whether such a kernel was enqueued — if not the
+// reduction is launched as usual. Either way before_wait runs next, then the wait.
 int nk_blas_norms_inf2_to_host(nk_ctx *ctx, int64_t n, const double *x, double *d_out, const double *extra_partials, int extra_n,
-                               double *h_out, const std::function<int()> &before_wait = nullptr, int have_partials = 0);
+                               double *h_out, const std::function<int()> &before_wait = nullptr, int have_partials = 0,
+                               const std::function<int(const nk_fold_norms &, bool *)> &fold_into = nullptr);
 // the cycle's last s-step block as k_backsolve needs it (sb = 0: nothing to adapt); resets the record
 nk_ss_fix nk_ss_take_last_block(nk_gmres *G);
 int nk_ss_block_size(const nk_gmres *G);   // the block size in effect
-// part: 0 the whole cycle; 1 the HEAD only — the first block's operator applications (nk_gmres_solve_head); 2 everything but those
-int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved, int part = 0);
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved);
 // The NEXT solve's last pass (x = V y) also forms u_new = u_old + usign·x and the partial sums of ‖u_new − u_old‖² — if that solve
 // is a single cycle from a zero guess without a right preconditioner. nk_gmres_take_fused_update: whether it happened (disarms).
 void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, double usign, double *partials);
@@ -665,15 +708,6 @@ void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, 
 // next solve could not use it anyway.
 double *nk_gmres_rhs_column(nk_gmres *G);
 void nk_gmres_preloaded_rhs(nk_gmres *G, const double *d_b, const double *ss_partials, int grid);
-// The first launches of the NEXT solve enqueued ahead of the caller's host round trip (the Newton driver: behind the kernels
-// that produce the step's norms, before it waits for them): the cycle's begin kernel and the first block's operator
-// applications — when that solve will be the fixed-work, single-cycle, zero-guess s-step solve on one rank whose right-hand
-// side d_b sits in column 0 already (nk_gmres_preloaded_rhs) and whose operator is the CSR matrix with the values it holds NOW.
-// *done: whether anything was enqueued. nk_gmres_solve_dev takes the launches over when its arguments and the operator's value
-// array are the same, and otherwise starts from scratch (the head touched the basis and the control block only);
-// nk_gmres_drop_head forgets it (every nk_gmres_set_* does).
-int nk_gmres_solve_head(nk_gmres *G, const double *d_b, double atol, double rtol, int maxiter, int fixed_iters, bool *done);
-void nk_gmres_drop_head(nk_gmres *G);
 bool nk_gmres_take_fused_update(nk_gmres *G, int *grid);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);

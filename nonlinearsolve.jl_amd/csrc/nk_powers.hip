@@ -46,9 +46,6 @@ struct pw_args {
   uint64_t *flags;
   uint64_t base;   // band b has published power p ⇔ flags[b] ≥ base + p + 1 (base grows with every launch: no reset)
   uint64_t *err;   // [0] time-outs (sticky), [1] bound of a wait in ticks of the 100 MHz wall clock
-  // GRAN = true: the boundary slices change hands as 16-byte {value, tag} granules (pw_gran), tag = base + p + 1 —
-  // gran[parity of p][band][0: its first slice, 1: its last][PW_T]
-  struct pw_gran *gran;
   // GEN = 1: the matrix is not stored — the 5-point Bratu Jacobian c_lap·Δ_h − diag(d) on an ns × ns grid, rows lexicographic
   int ns;
   double c_lap;
@@ -70,15 +67,6 @@ struct pw_args {
     int ebuf;                            // buffer pair of this launch: (epoch & 1)·2 — a neighbour is never two launches ahead
   } pr;
 };
-
-// One row of a boundary slice on its way to the neighbour band: the value and the tag of the power it belongs to, written by
-// ONE 16-byte write-through store and read by one 16-byte `sc1` load — the reader needs no flag, no drain on the writer's side
-// and no second round trip: it polls the granule itself until the tag is the power it waits for (MI355X_MICROARCH.md,
-// hand-off price list: "handoff-1to1, data-tagged granules" against "handoff-flag" at 1.7 – 1.9 × its price). 16-byte `sc1`
-// accesses are observed untorn on gfx950 (the guide's R2) — and the tests compare every word under uneven load.
-struct __attribute__((aligned(16))) pw_gran { double v; uint64_t tag; };
-typedef unsigned int pw_u4 __attribute__((ext_vector_type(4)));
-constexpr int PW_AUX_SC1 = 16;   // cache-policy bits of the raw buffer intrinsics on gfx940+: 1 = sc0, 2 = nt, 16 = sc1
 
 // development: phase time stamps of every band's wavefront 0 (100 MHz wall clock), builds with -DNK_PW_STAMPS only (make stamps;
 // tools/pw_stamps.py): [band][power][PW_NST]
@@ -150,7 +138,7 @@ __device__ __forceinline__ constexpr int pw_slice(int q) {
   return q == 0 ? 0 : (q == 1 ? RPT - 1 : q - 1);
 }
 
-template <int RPT, int W, int GEN, bool PEER = false, bool GRAN = false>
+template <int RPT, int W, int GEN, bool PEER = false>
 __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
   if (a.d_skip != nullptr && *a.d_skip != 0) return;   // (the flag is replicated: every rank takes the same branch)
   extern __shared__ double pw_x[];
@@ -275,10 +263,6 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
   }
 
   const bool shifted = a.theta != nullptr;
-  // GRAN: the granule areas as buffer resources (16-byte `sc1` stores / loads the compiler counts in vmcnt like any other)
-  // (one resource over both parities' areas; the parity picks the scalar offset)
-  const unsigned gbytes = GRAN ? (unsigned)((size_t)a.nb * 2 * PW_T * sizeof(pw_gran)) : 0u;
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)a.gran, 0, (int)(2u * gbytes), 0x00020000);
   for (int p = 0; p < a.s; ++p) {
     const double *xin = (p & 1) ? xb : xa;
     double *xout = (p & 1) ? xa : xb;
@@ -300,23 +284,10 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
       }
       double out = shifted ? sum - th * xin[PW_HALO + lr] : sum;
       out = osp ? os * out : out;
-      if constexpr (GRAN) {
-        if (q < NBND && pub && !((a.variant & 256) && b == 0)) {   // rows a neighbour band reads: {value, tag}, one 16-byte write-through store
-          const unsigned long long vb = (unsigned long long)__double_as_longlong(r < a.nrows ? out : 0.0), tg = a.base + (uint64_t)p + 1;
-          pw_u4 g;
-          g.x = (unsigned)vb; g.y = (unsigned)(vb >> 32); g.z = (unsigned)tg; g.w = (unsigned)(tg >> 32);
-          __builtin_amdgcn_raw_buffer_store_b128(g, grs, (int)(((b * 2 + q) * PW_T + t) * sizeof(pw_gran)), (p & 1) ? (int)gbytes : 0, PW_AUX_SC1);
-        }
-        if (r < a.nrows) {
-          xout[PW_HALO + lr] = out;
-          ycol[r] = out;
-        }
-      } else {
       if (r < a.nrows) {
         xout[PW_HALO + lr] = out;
         if (q < NBND) pw_store_sc1(ycol + r, out);   // rows a neighbour band reads: write-through
         else ycol[r] = out;
-      }
       }
       if (PEER && pub) {   // … and the slice a neighbour RANK reads: into its receive area (buffer ebuf + (p + 1) mod 2)
         const size_t boff = (size_t)(a.pr.ebuf + ((p + 1) & 1)) * PW_T + t;
@@ -324,7 +295,7 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
         if (pdn && i == RPT - 1) pw_store_sys(a.pr.push_dn + boff, out);
       }
       if (q == NBND - 1) PW_STAMP(p, 1);   // boundary slices computed, their stores issued
-      if (!GRAN && pub && (a.variant & 255) == 0 && q == NBND - 1) {   // publish as early as possible: behind the boundary slices
+      if (pub && (a.variant & 255) == 0 && q == NBND - 1) {   // publish as early as possible: behind the boundary slices
         if (PEER && (pup || pdn)) __threadfence_system();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PW_STAMP(p, 2);                      // … drained
@@ -341,49 +312,6 @@ __global__ __launch_bounds__(PW_T) void k_spmv_powers(const pw_args a) {
     }
     PW_STAMP(p, 4);                          // interior slices computed, their stores issued
     if (!pub) break;
-    if constexpr (GRAN) {
-      // ---- the neighbours' boundary rows of power p: every lane polls ITS two granules until they carry this power's tag.
-      // (several ranks: the slices of a neighbour RANK keep the flag form below — PEER instances are not built with GRAN)
-      static_assert(!(GRAN && PEER), "the granule hand-off is the one-rank form");
-      const uint64_t want = a.base + (uint64_t)p + 1;
-      const bool nu = b > 0, nd = b + 1 < a.nb;
-      const int ou = (int)((((b - 1) * 2 + (NBND - 1)) * PW_T + t) * sizeof(pw_gran));   // band b − 1's last slice
-      const int od = (int)((((b + 1) * 2 + 0) * PW_T + t) * sizeof(pw_gran));            // band b + 1's first slice
-      double hu = 0.0, hd = 0.0;
-      bool gotu = !nu, gotd = !nd;
-      unsigned long long t0 = 0;
-      for (unsigned it = 0; !(gotu && gotd); ++it) {
-        pw_u4 gu = {0u, 0u, 0u, 0u}, gd = {0u, 0u, 0u, 0u};
-        if (!gotu) gu = __builtin_amdgcn_raw_buffer_load_b128(grs, ou, (p & 1) ? (int)gbytes : 0, PW_AUX_SC1);
-        if (!gotd) gd = __builtin_amdgcn_raw_buffer_load_b128(grs, od, (p & 1) ? (int)gbytes : 0, PW_AUX_SC1);
-        if (!gotu && (((uint64_t)gu.w << 32) | gu.z) == want) {
-          hu = __longlong_as_double((long long)(((uint64_t)gu.y << 32) | gu.x));
-          gotu = true;
-        }
-        if (!gotd && (((uint64_t)gd.w << 32) | gd.z) == want) {
-          hd = __longlong_as_double((long long)(((uint64_t)gd.y << 32) | gd.x));
-          gotd = true;
-        }
-        if (gotu && gotd) break;
-        asm volatile("" ::: "memory");   // (the next trip's loads are new loads)
-        __builtin_amdgcn_s_sleep(1);
-        if ((it & 63u) == 63u) {          // bounded like every wait of this kernel
-          if (t0 == 0) t0 = wall_clock64();
-          if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > a.err[1]) {
-            __hip_atomic_store(a.err, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s_abort = 1;
-            break;
-          }
-        }
-      }
-      PW_STAMP(p, 7);                        // this wavefront's granules are in
-      xout[t] = hu;
-      xout[PW_HALO + RB + t] = hd;
-      __syncthreads();
-      PW_STAMP(p, 9);
-      if (s_abort) return;
-      continue;
-    }
     if ((a.variant & 255) != 0) {   // publish behind the whole band: the interior rows overlap the boundary rows' write-through
       if (PEER && (pup || pdn)) __threadfence_system();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -573,7 +501,6 @@ struct nk_powers_plan {
   int rpt = 0, w = 0, nb = 0;
   int seg = 0, ring = 0, seg_len = 0;   // seg > 0: k_spmv_powers_seg<rpt, w, seg> (rpt slices per segment and band)
   uint64_t *d_flags = nullptr;
-  pw_gran *d_gran = nullptr;   // the granule hand-off's areas: [2 parities][nb][2 slices][PW_T] (one rank, plain bands)
   uint64_t *h_err = nullptr, *h_err_dev = nullptr;   // pinned, coherent: {time-outs, bound in ticks}
   uint64_t epoch = 0;
   bool broken = false;
@@ -586,7 +513,6 @@ struct nk_powers_plan {
 void nk_powers_plan_destroy(nk_powers_plan *P) {
   if (!P) return;
   hipFree(P->d_flags);
-  hipFree(P->d_gran);
   hipFree(P->d_halo_vl);
   if (P->h_err) hipHostFree(P->h_err);
   delete P;
@@ -613,11 +539,6 @@ static int pw_variant() {
   for (long x : stalls) stall = stall || (x > 0 && launches == x);
   return (v & 255) | (stall ? 256 : 0);
 }
-// the boundary slices change hands as data-tagged 16-byte granules (one rank, plain bands) instead of payload → drain → flag
-static bool pw_granules() {
-  static const bool on = getenv("NK_PW_GRAN") && atoi(getenv("NK_PW_GRAN")) != 0;   // A/B switch (measured slower: profiles/r06_c_*)
-  return on;
-}
 static bool pw_enabled() {
   static const bool on = !(getenv("NK_SPMV_POWERS") && atoi(getenv("NK_SPMV_POWERS")) == 0);
   return on;
@@ -625,15 +546,15 @@ static bool pw_enabled() {
 
 // (the LDS limit is an attribute of the function ON A DEVICE: set on every call — a process-wide "done" flag left a second
 //  context on another GPU at the default 64 KB)
-template <int RPT, int W, int GEN, bool PEER = false, bool GRAN = false>
+template <int RPT, int W, int GEN, bool PEER = false>
 static int pw_launch(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
   constexpr size_t lds_x = (size_t)2 * (PW_T * RPT + 2 * PW_HALO) * sizeof(double), lds_m = (W > 8 || GEN == 1) ? 0 : (size_t)PW_T * W * 12;
   constexpr size_t lds = lds_x > lds_m ? lds_x : lds_m;
   if (lds > 64 * 1024)
-    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN, PEER, GRAN>),
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN, PEER>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (query) {
-    NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers<RPT, W, GEN, PEER, GRAN>, PW_T, lds));
+    NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_spmv_powers<RPT, W, GEN, PEER>, PW_T, lds));
     return NK_OK;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -642,14 +563,14 @@ static int pw_launch(nk_ctx *ctx, const pw_args &a, bool query, int *occ) {
   // stays the safety net). Measured: profiles/r05_*_powers_coop_ab.txt.
   static const bool coop = getenv("NK_PW_COOP") && atoi(getenv("NK_PW_COOP")) != 0;
   if (ctx->prof.on && nk_prof_next(ctx, &e0, &e1))
-    hipExtLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER, GRAN>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, e0, e1, 0, a);
   else if (coop) {
     pw_args ac = a;
     void *args[] = {(void *)&ac};
-    NK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN, PEER, GRAN>), dim3(a.nb), dim3(PW_T), args,
+    NK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), args,
                                       (unsigned int)lds, ctx->stream));
   } else
-    hipLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER, GRAN>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_spmv_powers<RPT, W, GEN, PEER>), dim3(a.nb), dim3(PW_T), lds, ctx->stream, a);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
@@ -662,10 +583,7 @@ static int pw_dispatch(nk_ctx *ctx, int rpt, int w, const pw_args &a, bool query
 #undef PW_PEER
     NK_FAIL(NK_E_INVALID, "internal: no matrix-powers kernel for %d rows per thread × %d entries per row", rpt, w);
   }
-  // (the occupancy query is made with an empty argument block: it asks about the form the plan WILL launch)
-  const bool gran = query ? pw_granules() : a.gran != nullptr;
-#define PW_CASE(R, WW, G) if (rpt == R && w == WW && gen == G) return gran ? pw_launch<R, WW, G, false, true>(ctx, a, query, occ) \
-                                                                            : pw_launch<R, WW, G, false, false>(ctx, a, query, occ)
+#define PW_CASE(R, WW, G) if (rpt == R && w == WW && gen == G) return pw_launch<R, WW, G>(ctx, a, query, occ)
   PW_CASE(1, 5, 1); PW_CASE(2, 5, 1); PW_CASE(4, 5, 1); PW_CASE(6, 5, 1);
   PW_CASE(1, 5, 0); PW_CASE(2, 5, 0); PW_CASE(4, 5, 0); PW_CASE(6, 5, 0);
   PW_CASE(1, 8, 0); PW_CASE(2, 8, 0);
@@ -707,18 +625,12 @@ static int pw_dispatch_seg(nk_ctx *ctx, int rps, int w, int seg, const pw_args &
   NK_FAIL(NK_E_INVALID, "internal: no segmented matrix-powers kernel for %d slices × %d slots × %d segments", rps, w, seg);
 }
 
-static int pw_plan_new(nk_ctx *ctx, int rpt, int w, int nb, nk_powers_plan **out, bool gran = false) {
+static int pw_plan_new(nk_ctx *ctx, int rpt, int w, int nb, nk_powers_plan **out) {
   nk_powers_plan *P = new nk_powers_plan();
   auto guard = nk_make_guard(P, [](nk_powers_plan *p) { nk_powers_plan_destroy(p); });
   P->rpt = rpt; P->w = w; P->nb = nb;
   NK_TRY(nk_dev_alloc(&P->d_flags, (size_t)nb * PW_FLAG_STRIDE));
   NK_HIP(nk_memset(ctx, P->d_flags, 0, (size_t)nb * PW_FLAG_STRIDE * sizeof(uint64_t)));
-  if (gran && pw_granules()) {   // (tags of zero: below every launch's base)
-    const size_t gb = (size_t)2 * nb * 2 * PW_T * sizeof(pw_gran);
-    NK_REQUIRE(gb < ((size_t)1 << 31), "internal: the matrix-powers granule area exceeds a buffer resource");
-    NK_HIP(hipMalloc((void **)&P->d_gran, gb));
-    NK_HIP(nk_memset(ctx, P->d_gran, 0, gb));
-  }
   NK_HIP(hipHostMalloc((void **)&P->h_err, 2 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
   NK_HIP(hipHostGetDevicePointer((void **)&P->h_err_dev, P->h_err, 0));
   P->h_err[0] = 0;
@@ -842,6 +754,7 @@ static int pw_plan(nk_csr *A) {
   if (A->pw_tried) return NK_OK;
   A->pw_tried = true;
   nk_ctx *ctx = A->ctx;
+  if (ctx->nranks > 1 && A->local_only) return NK_OK;   // (a rank-local helper matrix: no collective decision to take part in)
   if (ctx->nranks > 1) return pw_plan_ranks(A);
   if (!pw_enabled() || !A->halo_gcols.empty() || A->nrows < 1 || A->nnz < 1) return NK_OK;
   pw_args probe{};
@@ -852,7 +765,7 @@ static int pw_plan(nk_csr *A) {
     if (L.kind == 1) NK_TRY(pw_dispatch(ctx, L.rpt, L.w, probe, true, &occ));
     else NK_TRY(pw_dispatch_seg(ctx, L.rpt, L.w, L.seg, probe, true, &occ));
     if (occ >= 1 && L.nb <= ctx->num_cus * occ) {
-      NK_TRY(pw_plan_new(A->ctx, L.rpt, L.w, L.nb, &A->pw, L.kind == 1));
+      NK_TRY(pw_plan_new(A->ctx, L.rpt, L.w, L.nb, &A->pw));
       if (L.kind == 2) { A->pw->seg = L.seg; A->pw->ring = L.ring; A->pw->seg_len = (int)L.M; }
       return NK_OK;
     }
@@ -895,7 +808,6 @@ int nk_csr_powers_dev(nk_csr *A, const double *d_x0, double *d_Y, int64_t ldy, i
   a.x0 = d_x0; a.Y = d_Y; a.ldy = ldy;
   a.scal_first = d_scal_first; a.scal_rest = d_scal_rest; a.theta = d_theta; a.d_skip = d_skip;
   a.flags = P->d_flags; a.base = (++P->epoch) << 8; a.err = P->h_err_dev;
-  a.gran = (P->seg > 0 || P->peer) ? nullptr : P->d_gran;
   ctx->stats.op_applies += s;
   nk_prof_scope prof_(ctx, NK_K_POWERS,
                       (double)s * (12.0 * (double)A->nnz + 4.0 * (double)(A->nrows + 1) + 16.0 * (double)A->nrows));
@@ -934,7 +846,7 @@ static int pw_problem_plan(nk_problem *P) {
   int occ = 0;
   NK_TRY(pw_dispatch(ctx, rpt, 5, probe, true, &occ, 1));
   if (occ < 1 || nb > ctx->num_cus * occ) return NK_OK;
-  return pw_plan_new(P->ctx, rpt, 5, nb, &P->pw, true);
+  return pw_plan_new(P->ctx, rpt, 5, nb, &P->pw);
 }
 bool nk_problem_powers_ready(nk_problem *P) {
   if (!P->pw_tried && pw_problem_plan(P) != NK_OK) return false;
@@ -958,7 +870,6 @@ int nk_problem_powers_dev(nk_problem *P, const double *d_u, const double *d_x0, 
   a.x0 = d_x0; a.Y = d_Y; a.ldy = ldy;
   a.scal_first = d_scal_first; a.scal_rest = d_scal_rest; a.theta = d_theta; a.d_skip = d_skip;
   a.flags = Q->d_flags; a.base = (++Q->epoch) << 8; a.err = Q->h_err_dev;
-  a.gran = Q->d_gran;
   a.ns = (int)P->ns; a.c_lap = P->c_lap; a.diag = P->d_diag;
   ctx->stats.op_applies += s;
   nk_prof_scope prof_(ctx, NK_K_POWERS, (double)s * 24.0 * (double)P->n_local);

@@ -378,15 +378,15 @@ static int ilut_update(nk_precond *P) {
   for (int64_t k = 0; k < n; ++k) {
     // ---- row k of U
     idx.clear();
-    bool has_diag = false;
+    // (a row without a stored diagonal entry starts from 0 there: fill may still create the pivot, as in the reference's ilu —
+    //  if it does not, the zero-pivot test below reports the row)
+    mark[k] = 1; idx.push_back((int32_t)k); wz[k] = 0.0;
     for (int32_t p = rp0[k]; p < rp0[k + 1]; ++p) {
       const int32_t j = ci0[p];
       if (j < k || j >= n) continue;
       if (!mark[j]) { mark[j] = 1; idx.push_back(j); wz[j] = 0.0; }
       wz[j] += av[p];
-      if (j == k) has_diag = true;
     }
-    NK_REQUIRE(has_diag, "ILU(τ): row %lld has no stored diagonal entry", (long long)k);
     for (const ent &l : Lrow[k]) {             // ascending i (the columns were finished in that order)
       const int32_t i = l.idx;
       const std::vector<ent> &ur = Urow[i];

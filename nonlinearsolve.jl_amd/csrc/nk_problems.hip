@@ -201,11 +201,20 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jvp_tile(int ns, int nl, dou
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, int64_t j0, double c_lap,
                                                         double c_exp, const double *__restrict__ u,
                                                         const int32_t *__restrict__ rowptr,
-                                                        double *__restrict__ vals, double *__restrict__ gpart) {
+                                                        double *__restrict__ vals, double *__restrict__ gpart,
+                                                        const nk_fold_norms fold) {
   __shared__ double sv[5 * NK_BLOCK];
   __shared__ double sg[8];
   __shared__ int32_t s_p0, s_p1;
-  const int64_t n = ns * nl, r0 = (int64_t)blockIdx.x * NK_BLOCK;
+  // fold.partials != nullptr: workgroup 0 fills nothing — it reduces a residual kernel's norm partials and hands them to the host
+  // (nk_fold_norms); the rows then belong to workgroups 1 … (the grid is one larger)
+  const int fb = fold.partials != nullptr ? 1 : 0;
+  if (fb && blockIdx.x == 0) {
+    nk_reduce_inf2_body(fold, sv);
+    return;
+  }
+  const int bid = (int)blockIdx.x - fb, nbl = (int)gridDim.x - fb;
+  const int64_t n = ns * nl, r0 = (int64_t)bid * NK_BLOCK;
   const int64_t k = r0 + threadIdx.x;
   const int64_t rlast = (r0 + NK_BLOCK < n ? r0 + NK_BLOCK : n);
   if (threadIdx.x == 0) { s_p0 = rowptr[r0]; s_p1 = rowptr[rlast]; }
@@ -249,8 +258,8 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, 
     if ((threadIdx.x & 63) == 0) { sg[threadIdx.x >> 6] = mlo; sg[4 + (threadIdx.x >> 6)] = mhi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      gpart[blockIdx.x] = fmax(fmax(sg[0], sg[1]), fmax(sg[2], sg[3]));
-      gpart[gridDim.x + blockIdx.x] = fmax(fmax(sg[4], sg[5]), fmax(sg[6], sg[7]));
+      gpart[bid] = fmax(fmax(sg[0], sg[1]), fmax(sg[2], sg[3]));
+      gpart[nbl + bid] = fmax(fmax(sg[4], sg[5]), fmax(sg[6], sg[7]));
     }
   }
 }
@@ -895,9 +904,10 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
   NK_FAIL(NK_E_INVALID, "bad problem kind");
 }
 
-int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
+int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const nk_fold_norms *fold, bool *folded) {
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
+  if (folded) *folded = false;
   J->t_values_stale = true; J->bounds_valid = false; J->bounds_pending = false;
   if (n == 0) return NK_OK;
   nk_prof_scope prof_(ctx, NK_K_JACFILL, 8.0 * (double)J->nnz + 8.0 * (double)n);
@@ -921,8 +931,10 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J) {
         }
         gpart = J->d_gersh;
       }
-      NK_LAUNCH(ctx, k_bratu_jac, dim3(g), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->j0, P->c_lap, P->c_exp, d_u, J->d_rowptr,
-                J->d_val, gpart);
+      const bool take_fold = fold != nullptr && folded != nullptr && fold->partials != nullptr && ctx->nranks == 1;
+      NK_LAUNCH(ctx, k_bratu_jac, dim3(g + (take_fold ? 1 : 0)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->j0, P->c_lap, P->c_exp, d_u,
+                J->d_rowptr, J->d_val, gpart, take_fold ? *fold : nk_fold_norms{});
+      if (take_fold) *folded = true;
       if (gpart) NK_TRY(nk_csr_bounds_from_partials(J, gpart, g));
       break;
     }

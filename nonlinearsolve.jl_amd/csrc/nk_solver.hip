@@ -71,10 +71,6 @@ struct nk_solver {
   // second value set while the host waits for this step's norms — the queue is not empty during the termination test's round
   // trip. The live J is untouched until the next step takes the set (refresh_J); a solve that terminates never sees it.
   bool spec_valid = false;
-  hipEvent_t retire_ev[2] = {nullptr, nullptr};   // retire_launch_records
-  int retire_idx = 0;
-  bool retired_this_step = false;   // retire_launch_records has run in this step (where the host waits anyway)
-  bool head_enqueued = false;   // … and the head of the next step's linear solve is in the queue behind it (speculate_head)
   uint64_t spec_version = 0, spec_params = 0;
   // the step's last residual kernel also wrote f into column 0 of the Krylov basis and its Σ f² partials into d_rhs_ss: the next
   // step's linear solve starts from them if nothing has moved since (nk_gmres_preloaded_rhs)
@@ -276,9 +272,11 @@ static double *spare_u(nk_solver *S) {
 }
 // ‖fu‖∞ and ‖fu‖₂² of the current residual (+ optionally the stall norm's partial sums) → ONE stage-2 launch, one fetch
 static int residual_norms(nk_solver *S, const double *stall_partials, int stall_n, double *step_norm,
-                          const std::function<int()> &before_wait = nullptr, int have_partials = 0) {
+                          const std::function<int()> &before_wait = nullptr, int have_partials = 0,
+                          const std::function<int(const nk_fold_norms &, bool *)> &fold_into = nullptr) {
   double v[3] = {0, 0, 0};
-  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v, before_wait, have_partials));
+  NK_TRY(nk_blas_norms_inf2_to_host(S->ctx, S->n, S->fu, slot(S, 0), stall_partials, stall_n, v, before_wait, have_partials,
+                                    fold_into));
   S->fnorm_inf = v[0];
   S->fnorm2 = sqrt(v[1]);
   if (step_norm) *step_norm = sqrt(v[2]);
@@ -295,8 +293,10 @@ static bool speculation_allowed(const nk_solver *S) {
 }
 // J(u) of the iterate just formed into the spare value set (enqueued behind the step's last kernels, before the host waits)
 // (`version`: the iterate's version at which the set may be taken)
-static int speculate_J(nk_solver *S, const double *u_at, uint64_t version) {
+// (fold / folded: the stage-2 reduction of the step's norms rides in the fill kernel's first workgroup — nk_fold_norms)
+static int speculate_J(nk_solver *S, const double *u_at, uint64_t version, const nk_fold_norms *fold = nullptr, bool *folded = nullptr) {
   S->spec_valid = false;
+  if (folded) *folded = false;
   if (!speculation_allowed(S)) return NK_OK;
   nk_csr *J = S->J;
   if (!S->spec_state.d_val) NK_TRY(nk_csr_alloc_values(J, &S->spec_state.d_val));
@@ -304,7 +304,7 @@ static int speculate_J(nk_solver *S, const double *u_at, uint64_t version) {
   nk_csr_valstate spare = S->spec_state;
   spare.t_values_stale = true; spare.bounds_valid = false; spare.bounds_pending = false;
   nk_csr_set_valstate(J, spare);
-  const int rc = nk_problem_jac_values_dev(S->P, u_at, J);
+  const int rc = nk_problem_jac_values_dev(S->P, u_at, J, fold, folded);
   S->spec_state = nk_csr_get_valstate(J);       // (the fill may have grown the partials buffer)
   nk_csr_set_valstate(J, live);
   if (rc != NK_OK) return rc;
@@ -314,39 +314,6 @@ static int speculate_J(nk_solver *S, const double *u_at, uint64_t version) {
   S->spec_params = S->P->params_version;
   return NK_OK;
 }
-// … and, behind that fill, the HEAD of the next step's linear solve (nk_gmres_solve_head: the cycle's begin kernel and the first
-// block's operator applications, on the value set just filled): when the host comes back from its round trip for the norms and
-// enters the next step, the device is busy with work of that step already — the round trip moves off the critical path (round 5:
-// ≈ 18 µs of idle device per step). If the termination check stops the solve, the head was for nothing and touched nothing but
-// the Krylov workspace (drop_head).
-static bool head_allowed(const nk_solver *S) {
-  return speculation_allowed(S) && S->o.forcing != NK_FORCING_EISENSTAT_WALKER2 && S->o.cheb_degree <= 0 && S->o.mg_nu <= 0 &&
-         !S->o.precond_kind && !S->o.store_trace && S->G != nullptr && S->G->op_kind == 1 && S->G->A == S->J &&
-         S->o.gmres_fixed_iters > 0 && S->nsteps + 2 <= S->o.maxiters;
-}
-static int speculate_head(nk_solver *S) {
-  S->head_enqueued = false;
-  if (!S->spec_valid || !S->pre_valid || !head_allowed(S)) return NK_OK;
-  nk_csr *J = S->J;
-  const nk_csr_valstate live = nk_csr_get_valstate(J);
-  nk_csr_set_valstate(J, S->spec_state);
-  nk_gmres_preloaded_rhs(S->G, S->fu, S->d_rhs_ss, S->pre_grid);
-  bool done = false;
-  const int rc = nk_gmres_solve_head(S->G, S->fu, S->lin_abstol, S->lin_reltol, S->o.gmres_maxiters, S->o.gmres_fixed_iters, &done);
-  S->spec_state = nk_csr_get_valstate(J);   // (the begin kernel has taken the fill's Gershgorin partials)
-  nk_csr_set_valstate(J, live);
-  if (rc != NK_OK) return rc;
-  S->head_enqueued = done;
-  return NK_OK;
-}
-static void drop_head(nk_solver *S) {
-  if (!S->head_enqueued) return;
-  S->head_enqueued = false;
-  nk_gmres_drop_head(S->G);
-  // the head's begin kernel reduced the SPARE set's Gershgorin bounds into the matrix's bounds word: the live set's are gone
-  if (S->J) nk_csr_invalidate_bounds(S->J);
-  S->spec_valid = false;
-}
 static int refresh_J(nk_solver *S) {
   if (S->spec_valid && S->spec_version == S->u_version && S->spec_u == S->u && S->spec_params == S->P->params_version &&
       speculation_allowed(S)) {
@@ -355,9 +322,7 @@ static int refresh_J(nk_solver *S) {
     nk_csr_set_valstate(S->J, S->spec_state);
     S->spec_state = live;
     S->spec_valid = false;
-    S->head_enqueued = false;   // (nk_gmres_solve_dev takes it over — or starts from scratch if anything about the solve differs)
   } else {
-    drop_head(S);
     S->spec_valid = false;
     if (S->o.jac_colored && S->P->kind != NK_PROBLEM_USER) NK_TRY(nk_problem_jac_colored_dev(S->P, S->u, S->J));
     else NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
@@ -716,7 +681,6 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
                     S->lm_a, S->lm_vcache, S->lm_rhs, S->pt_mass};
   for (double *b : bufs) hipFree(b);
   hipFree(S->d_rhs_ss);
-  for (hipEvent_t e : S->retire_ev) if (e) hipEventDestroy(e);
   hipFree(S->spec_state.d_val);     // (whichever value set is the spare one now; the live one belongs to J)
   hipFree(S->spec_state.d_gersh);
   nk_gmres_destroy(S->G);
@@ -1578,7 +1542,6 @@ static void lm_callback(nk_solver *S) {
 }
 static int check_and_update(nk_solver *S, double step_norm);
 static int internal_step(nk_solver *S, int recompute, bool evaluate_residual);
-static void retire_launch_records(nk_solver *S);
 // the rest of step! (FirstOrder/src/solve.jl:365-462) for LevenbergMarquardt: GeodesicAcceleration.solve!
 // (geodesic_acceleration.jl:98-136), LevenbergMarquardtTrustRegionCache solve! (levenberg_marquardt.jl:247-268)
 static int lm_step(nk_solver *S, bool new_jacobian, bool evaluate_residual) {
@@ -1762,7 +1725,6 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     if (!direct(S)) NK_TRY(refresh_precs(S));
   } else {
     new_jacobian = false;
-    drop_head(S);
     S->spec_valid = false;   // (a value set filled ahead is only ever taken by the step that follows its fill)
   }
   if (is_lm(S)) return lm_step(S, new_jacobian, evaluate_residual);
@@ -1775,6 +1737,9 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
   const bool fold_sign = !is_tr(S) && !S->o.linesearch;
   // plain Newton through GMRES: u_new = u − x is formed by the pass that forms x (nk_gmres_arm_fused_update)
   const bool fuse_update = fold_sign && !direct(S) && !is_pt(S) && !normal_form(S) && S->G != nullptr;
+  // (armed for THIS descent only: an error exit below must not leave the object armed with pointers into the u pool — a later
+  //  zero-guess, single-cycle solve on the same object would write a u buffer)
+  struct fu_guard_t { nk_gmres *g; ~fu_guard_t() { if (g) (void)nk_gmres_take_fused_update(g, nullptr); } } fu_guard{fuse_update ? S->G : nullptr};
   if (fuse_update) nk_gmres_arm_fused_update(S->G, S->u, spare_u(S), -1.0, ctx->d_partials_ss);
   if (is_tr(S)) NK_TRY(dogleg(S, &ok, &duJJdu, new_jacobian, &have_JTfu));
   else NK_TRY(newton_descent(S, S->du, &ok, new_jacobian, !fold_sign));
@@ -1852,13 +1817,18 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     S->stats.nf++;
     // ‖f‖∞, ‖f‖₂, ‖u − u_prev‖₂: one fetch — and behind the kernels that produce them, before the host waits, the next step's
     // Jacobian values (speculate_J)
-    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm, [S]() -> int {
-      NK_TRY(speculate_J(S, S->u, S->u_version));
-      NK_TRY(speculate_head(S));
-      retire_launch_records(S);   // (the host is about to wait for the norms: the query's host time is free here)
-      S->retired_this_step = true;
-      return NK_OK;
-    }, norm_grid));
+    // (where the fill kernel can carry the norms' stage-2 reduction — fold_into — the fill is enqueued by THAT call, in place of
+    //  k_reduce_inf2; otherwise behind it, by before_wait)
+    bool spec_done = false;
+    std::function<int(const nk_fold_norms &, bool *)> fold_into;
+    if (speculation_allowed(S) && S->P->kind == NK_PROBLEM_BRATU2D && nk_ctx_is_single(ctx))   // (the fill kernel that can carry it)
+      fold_into = [S, &spec_done](const nk_fold_norms &f, bool *folded) -> int {
+        spec_done = true;
+        return speculate_J(S, S->u, S->u_version, &f, folded);
+      };
+    NK_TRY(residual_norms(S, ctx->d_partials_ss, grid, &step_norm,
+                          [S, &spec_done]() -> int { return spec_done ? NK_OK : speculate_J(S, S->u, S->u_version); }, norm_grid,
+                          fold_into));
     if (S->o.store_trace) {
       NK_TRY(nk_blas_sumsq(ctx, n, S->du, slot(S, 0)));
       double v;
@@ -1867,7 +1837,6 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     }
   }
   NK_TRY(check_and_update(S, step_norm));
-  if (S->force_stop) drop_head(S);
   if (S->o.store_trace) {
     nk_trace_entry e;
     memset(&e, 0, sizeof(e));
@@ -1891,34 +1860,13 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
 }
 
 // CommonSolve.step!(cache; recompute_jacobian, evaluate_residual) (Base/src/solve.jl:835-859)
-// A Newton step never synchronises with the stream (its scalars arrive through pinned memory), so the runtime never learns that
-// the step's launches have completed: it keeps a record per launch until somebody asks — and the caller's first
-// hipStreamSynchronize / hipDeviceSynchronize then pays for ALL of them at once (measured: 38 ms behind 300 steps = 4 800
-// launches, 8 µs per launch, 25 % of the steps' own time — profiles/r06_d_*). One status query per step lets the runtime retire
-// what has completed while the host has nothing else to do; it costs the device nothing measurable (same profile).
-static void retire_launch_records(nk_solver *S) {
-  static const int mode = getenv("NK_STEP_RETIRE") ? atoi(getenv("NK_STEP_RETIRE")) : 1;   // A/B switch: 0 off, 1 event (no timing), 2 event (timing), 3 status query
-  if (mode == 0) return;
-  if (mode == 3) { (void)hipStreamQuery(S->ctx->stream); return; }
-  if (!S->retire_ev[0]) {
-    for (int i = 0; i < 2; ++i)
-      if (hipEventCreateWithFlags(&S->retire_ev[i], mode == 2 ? hipEventDefault : hipEventDisableTiming) != hipSuccess) {
-        S->retire_ev[i] = nullptr;
-        (void)hipGetLastError();
-        return;
-      }
-  }
-  (void)hipEventRecord(S->retire_ev[S->retire_idx ^= 1], S->ctx->stream);
-}
 extern "C" int nk_solver_step_ex(nk_solver *S, int recompute_jacobian, int evaluate_residual) {
   NK_REQUIRE(S, "NULL argument");
   NK_REQUIRE(recompute_jacobian >= -1 && recompute_jacobian <= 1, "recompute_jacobian must be -1 (nothing), 0 or 1");
   NK_HIP(hipSetDevice(S->ctx->device));
   if (S->force_stop || S->nsteps >= S->o.maxiters) return NK_OK;
   const auto t0 = std::chrono::steady_clock::now();
-  S->retired_this_step = false;
   NK_TRY(internal_step(S, recompute_jacobian, evaluate_residual != 0));
-  if (!S->retired_this_step) retire_launch_records(S);
   S->stats.nsteps++;
   S->nsteps++;
   if (S->o.maxtime > 0.0) {

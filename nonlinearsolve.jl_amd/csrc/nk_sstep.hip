@@ -1073,6 +1073,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
     for (int c = 0; c < S; ++c) {
       const double qv = sX[(k + c) * SS_P + t];
       const unsigned off = ok ? (unsigned)c * ldvb + rbyte : 0xFFFFFFFFu;
+      // (non-temporal hints measured in round 6 — `nt` on these stores −1.6 %, on the loads of the k read-only columns −0.9 %,
+      //  both −2.3 % in Newton steps/s: profiles/r06_h_nt_hints_ab.txt — the basis is re-read from the Infinity Cache by the next launch)
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u2, qv), wrs, (int)off, 0, 0);
     }
     // Gram block [V Q]ᵀQ: 64 rows per wavefront, 4 per instruction
@@ -1293,14 +1295,9 @@ static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, dou
   switch (s) {
     case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 3: return ss_launch_s<3>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 5: return ss_launch_s<5>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 7: return ss_launch_s<7>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 10: return ss_launch_s<10>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 12: return ss_launch_s<12>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
     default: NK_FAIL(NK_E_INVALID, "internal: no s-step sweep for a block of %d columns", s);
   }
@@ -1332,11 +1329,12 @@ int nk_ss_sweep_occupancy(nk_ctx *ctx, int mode, int k, int s) {
   return c;
 }
 // widths the sweeps are compiled for; any other block is cut into these (the last block of a cycle, odd block sizes)
-int nk_ss_block_width(int want) {
+int nk_ss_block_width(int want) {   // (round 6: 3, 5, 7, 10 and 12 left the list — 45 % of the sweep instantiations for ragged tails only)
   if (want >= 15) return 15;
-  if (want >= 12) return 12;
-  if (want >= 10) return 10;
-  return want > 8 ? 8 : want;
+  if (want >= 8) return 8;
+  if (want >= 6) return 6;
+  if (want >= 4) return 4;
+  return want >= 2 ? 2 : 1;
 }
 
 // ----------------------------------------------------------------------------- the scalar work of the block scheme: one launch
@@ -1955,7 +1953,6 @@ __global__ void k_ss_force_fail(nk_gmres_ctl *ctl, nk_gmres_pub *pub, uint64_t s
   ss_pub_progress(pub, seq, ctl->k, 1);
 }
 extern "C" int nk_gmres_debug_force_breakdown(nk_gmres *G, int cycle) {
-  if (G) G->head.valid = false;   // (a head enqueued for the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->ss_force_break_cycle = cycle;
   return NK_OK;
@@ -2225,9 +2222,7 @@ static bool ss_a_can_host_job(nk_ctx *ctx, int k, int s) {
 // sweep B (the fixed-work protocol: off the critical path). The cycle's last block is closed by one launch that reduces,
 // factors, derives the Hessenberg columns and back-substitutes without leaving the workgroup. Per GMRES(30) cycle of two blocks:
 // 3 scalar launches instead of 6 (4 × k_ss_reduce_factor, k_ss_hess, k_backsolve), 3 all-reduces instead of 4 on several ranks.
-// part = 1 enqueues the HEAD of the cycle only — the first block's operator applications, ahead of the solve proper
-// (nk_gmres_solve_head) —, part = 2 everything but those.
-int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved, int part) {
+int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_progress, bool *backsolved) {
   nk_ctx *ctx = G->ctx;
   if (backsolved) *backsolved = false;
   NK_TRY(ss_workspace(G));
@@ -2284,7 +2279,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     if (with_back && backsolved) *backsolved = true;
     return NK_OK;
   };
-  if (part != 1 && G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
+  if (G->ss_force_break_cycle >= 0 && G->ss_force_break_cycle == G->ss_cycle_idx)
     NK_LAUNCH(ctx, k_ss_force_fail, dim3(1), dim3(64), G->d_ctl, G->h_pub_dev, G->cycle_seq);
   int k = 1;  // orthonormal columns so far (column 0 = r₀, un-normalised, scale s[0])
   int prev_sb = s;
@@ -2305,14 +2300,12 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
     double *Wk = G->V + (size_t)k * ldv;
     // the block's basis vectors: (A − θ_j I) applied s times (right-preconditioned operator), scaled by 1/σ — in one launch
     // with the matrix held on the chip where that applies (nk_powers.hip), else one operator launch per column
-    bool powers = part == 2 && k == 1;   // (in the queue already: the cycle's head)
-    if (!powers)
-      NK_TRY(nk_gmres_op_powers(G, G->V + (size_t)(k - 1) * ldv, Wk, ldv, sb, done, W->scal, W->newton ? W->scal + SS_TH : nullptr,
-                                &powers));
+    bool powers = false;
+    NK_TRY(nk_gmres_op_powers(G, G->V + (size_t)(k - 1) * ldv, Wk, ldv, sb, done, W->scal, W->newton ? W->scal + SS_TH : nullptr,
+                              &powers));
     for (int j = 0; j < sb && !powers; ++j)
       NK_TRY(nk_gmres_op_apply(G, G->V + (size_t)(k - 1 + j) * ldv, Wk + (size_t)j * ldv, done, W->scal + (j == 0 ? 0 : 1),
                                W->newton ? W->scal + SS_TH + j : nullptr));
-    if (part == 1) return NK_OK;
     const int grid = nk_ss_grid(ctx, n, k, sb);
     const int nslots = (k + sb) * sb;
     if (ctx->audit.on)   // (development) the block's new columns as the operator left them

@@ -986,9 +986,10 @@ void orc_leja_nodes(int s, double *out) {
 /* block widths the device's sweeps are compiled for (csrc/nk_sstep.hip::nk_ss_block_width) */
 static int ss_block_width(int want) {
   if (want >= 15) return 15;
-  if (want >= 12) return 12;
-  if (want >= 10) return 10;
-  return want > 8 ? 8 : want;
+  if (want >= 8) return 8;
+  if (want >= 6) return 6;
+  if (want >= 4) return 4;
+  return want >= 2 ? 2 : 1;
 }
 /* basis: 0 = monomial X_j = A X_{j−1}; 1 = Newton X_j = (A − θ_j I) X_{j−1} / σ with θ = Leja-ordered Chebyshev points of
  * the Gershgorin interval of J (CSR: the discs of the assembled rows; matrix-free: [−max d, 8c − min d], d = c_exp·eᵘ) and

@@ -994,11 +994,13 @@ def sstep_block_width(want):
     """widths the device's sweeps are compiled for (csrc/nk_sstep.hip::nk_ss_block_width); other blocks are cut into these"""
     if want >= 15:
         return 15
-    if want >= 12:
-        return 12
-    if want >= 10:
-        return 10
-    return 8 if want > 8 else want
+    if want >= 8:
+        return 8
+    if want >= 6:
+        return 6
+    if want >= 4:
+        return 4
+    return 2 if want >= 2 else 1
 
 
 def gmres_sstep(matvec: Callable, b, atol=0.0, rtol=1e-8, restart=30, itmax=300, fixed_iters=0, s=6,

@@ -883,7 +883,7 @@ def test_c_oracle_newton_basis_equals_python_restatement_and_column_form():
         n = ns * ns
         for use_csr in (True, False):
             u1, f1, _ = CO.bratu_newton_fast(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30)
-            for s_ in (6, 10, 12, 15):
+            for s_ in (4, 6, 8, 15):   # (widths the sweeps are compiled for)
                 u2, f2, _ = CO.bratu_newton_fast_sstep(ns, 6.0, 0.0, np.zeros(n), 4, use_csr=use_csr, m=30, s=s_, basis="newton")
                 assert np.max(np.abs(u1 - u2)) <= 1e-10 and np.allclose(f1, f2, rtol=1e-7)
             c = R.init(R.Bratu2D(ns, 6.0), R.NewtonRaphson(linsolve=R.KrylovJL_GMRES(fixed_iters=30, maxiters=30,

@@ -17,7 +17,7 @@ def sstep_blocks(arnoldi, s):
     out, k = [], 1
     while k - 1 < arnoldi:
         w = min(s, arnoldi - (k - 1))
-        w = 15 if w >= 15 else 12 if w >= 12 else 10 if w >= 10 else min(w, 8)
+        w = 15 if w >= 15 else 8 if w >= 8 else 6 if w >= 6 else 4 if w >= 4 else 2 if w >= 2 else 1
         if k + w > 48 and w > 8:
             w = 8
         out.append((k, w))
@@ -30,8 +30,10 @@ def spmv_bytes(n, nnz):
 
 
 def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True,
-                  fused_tail=True, preloaded_rhs=True):
+                  fused_tail=True, preloaded_rhs=True, folded_norms=True):
     """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order.
+    folded_norms (round 6): the stage-2 reduction of the step's norms and their delivery to the host ride in workgroup 0 of the
+    NEXT Jacobian's fill kernel (k_bratu_jac, enqueued directly behind the residual kernel) — no k_reduce_inf2 launch.
     fused_tail (round 5): the Newton update u_new = u − x rides in the pass that forms x = V y (k_multiaxpy), and the residual
     kernel leaves the stage-1 partials of its own norms and a second copy of f in column 0 of the Krylov basis — no
     k_newton_update, no k_absmax_sumsq, no k_copy_sumsq launch.
@@ -86,7 +88,8 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
         add("k_newton_update", 24.0 * n)
         add("k_bratu_residual", 16.0 * n)
         add("k_absmax_sumsq", 8.0 * n)
-    add("k_reduce_inf2", 0)
+    if not (folded_norms and fused_tail and not matfree):
+        add("k_reduce_inf2", 0)
     return L
 
 

@@ -10,35 +10,23 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-MIMIC = int(os.environ.get("PROBE_MIMIC", "0"))   # bisecting bench.py's set-up: 1 + torch.distributed, 2 + set_device, 3 + own Context, 4 + algorithm arguments
-if MIMIC >= 1:
-    import torch.distributed as dist  # noqa: F401
-if MIMIC >= 2:
-    torch.cuda.set_device(0)
 import nonlinearsolve_jl_amd as nls
 
-if MIMIC >= 3:
-    ctx = nls.Context(device=0)
-    nls.set_default_context(ctx)
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 prob = nls.NonlinearProblem(nls.Bratu2D(ns, 6.0))
 prob.u0 = torch.zeros(ns * ns, dtype=torch.float64, device="cuda")
-if MIMIC >= 4:
-    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho="sstep", sstep=0, sstep_basis="auto", fixed_iters=30), concrete_jac=True)
-else:
-    alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30), concrete_jac=True)
+alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(fixed_iters=30, maxiters=30), concrete_jac=True)
 cache = nls.init(prob, alg, abstol=1e-300, maxiters=10**9)
 for _ in range(20):
     cache.step()
-if MIMIC < 5:
-    torch.cuda.synchronize()
+torch.cuda.synchronize()
 two = [torch.cuda.Event(enable_timing=False) for _ in range(2)]
 stream = torch.cuda.current_stream()
 
 
 def run(label, between):
-    fresh = [torch.cuda.Event(enable_timing=True) for _ in range(steps)] if MIMIC < 6 else None
+    fresh = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -51,12 +39,8 @@ def run(label, between):
                           contract_ms_per_step=round((t2 - t0) / steps * 1e3, 4))), flush=True)
 
 
-for rep in range(1 if MIMIC else 2):
+for rep in range(2):
     run("nothing between the steps", lambda i, ev: None)
-    if MIMIC >= 5:
-        run("nothing between the steps (again)", lambda i, ev: None)
-        run("nothing between the steps (third)", lambda i, ev: None)
-        break
     run("a NEW timing event recorded per step", lambda i, ev: ev[i].record())
     run("one of TWO no-timing events re-recorded per step", lambda i, ev: two[i & 1].record())
     run("stream.query() per step", lambda i, ev: stream.query())
