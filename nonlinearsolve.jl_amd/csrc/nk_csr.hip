@@ -664,6 +664,11 @@ bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, doubl
   return true;
 }
 void nk_csr_commit_pending_bounds(nk_csr *A) { A->bounds_pending = false; }
+void nk_csr_invalidate_bounds(nk_csr *A) { A->bounds_valid = false; A->bounds_pending = false; }
+double *nk_csr_bounds_word(nk_csr *A) {
+  if (!A->d_bounds && nk_dev_alloc(&A->d_bounds, (size_t)2) != NK_OK) return nullptr;
+  return A->d_bounds;
+}
 int nk_csr_gershgorin_dev(nk_csr *A, double *d_out2, const double **where) {
   nk_ctx *ctx = A->ctx;
   NK_REQUIRE(A->nblocks > 0, "Gershgorin bounds of an empty matrix");

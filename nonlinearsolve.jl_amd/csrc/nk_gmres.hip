@@ -770,12 +770,14 @@ extern "C" int nk_gmres_destroy(nk_gmres *G) {
   return NK_OK;
 }
 extern "C" int nk_gmres_set_block_size(nk_gmres *G, int s) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   NK_REQUIRE(s >= 0 && s <= 16, "s-step block size %d outside 0..16 (0 = automatic)", s);
   G->ss_s = s;
   return NK_OK;
 }
 extern "C" int nk_gmres_set_operator_csr(nk_gmres *G, nk_csr *A) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G && A, "NULL argument");
   NK_REQUIRE(A->nrows == G->n, "operator size %lld != GMRES size %lld", (long long)A->nrows, (long long)G->n);
   G->op_kind = 1;
@@ -783,6 +785,7 @@ extern "C" int nk_gmres_set_operator_csr(nk_gmres *G, nk_csr *A) {
   return NK_OK;
 }
 extern "C" int nk_gmres_set_operator_jvp(nk_gmres *G, nk_problem *P, const double *u, int memspace) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G && P && u, "NULL argument");
   NK_REQUIRE(P->n_local == G->n, "problem size %lld != GMRES size %lld", (long long)P->n_local, (long long)G->n);
   NK_HIP(hipSetDevice(G->ctx->device));
@@ -798,6 +801,7 @@ extern "C" int nk_gmres_set_operator_jvp(nk_gmres *G, nk_problem *P, const doubl
   return nk_problem_jvp_prepare(P, G->d_u);
 }
 extern "C" int nk_gmres_set_operator_fn(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G && fn, "NULL argument");
   G->op_kind = 3;
   G->fn = fn;
@@ -818,16 +822,19 @@ static int host_callback(nk_gmres *G, nk_matvec_fn fn, void *user, const double 
   return NK_OK;
 }
 extern "C" int nk_gmres_set_operator_fn_host(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_TRY(nk_gmres_set_operator_fn(G, fn, user));
   G->fn_host = true;
   return NK_OK;
 }
 extern "C" int nk_gmres_set_right_preconditioner_host(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_TRY(nk_gmres_set_right_preconditioner(G, fn, user));
   G->prec_host = fn != nullptr;
   return NK_OK;
 }
 extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->prec = fn;
   G->prec_user = user;
@@ -839,6 +846,7 @@ extern "C" int nk_gmres_set_right_preconditioner(nk_gmres *G, nk_matvec_fn fn, v
 }
 
 extern "C" int nk_gmres_set_left_preconditioner(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   NK_HIP(hipSetDevice(G->ctx->device));
   G->lprec = fn;
@@ -850,12 +858,14 @@ extern "C" int nk_gmres_set_left_preconditioner(nk_gmres *G, nk_matvec_fn fn, vo
   return NK_OK;
 }
 extern "C" int nk_gmres_set_left_preconditioner_host(nk_gmres *G, nk_matvec_fn fn, void *user) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_TRY(nk_gmres_set_left_preconditioner(G, fn, user));
   G->lprec_host = fn != nullptr;
   return NK_OK;
 }
 // a built-in preconditioner object (nk_precond.hip) on either side; NULL removes what sits on that side
 extern "C" int nk_gmres_set_preconditioner(nk_gmres *G, int side, nk_precond *P) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   NK_REQUIRE(side == NK_SIDE_LEFT || side == NK_SIDE_RIGHT, "bad preconditioner side %d", side);
   NK_REQUIRE(!P || nk_precond_size(P) == G->n, "preconditioner size %lld != GMRES size %lld",
@@ -878,6 +888,7 @@ extern "C" int nk_gmres_set_preconditioner(nk_gmres *G, int side, nk_precond *P)
 }
 
 extern "C" int nk_gmres_set_normal_form(nk_gmres *G, int on) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   NK_HIP(hipSetDevice(G->ctx->device));
   if (on && !G->nrm_tmp) NK_TRY(nk_dev_alloc(&G->nrm_tmp, (size_t)G->ldv));
@@ -886,6 +897,7 @@ extern "C" int nk_gmres_set_normal_form(nk_gmres *G, int on) {
 }
 
 extern "C" int nk_gmres_set_normal_form_damping(nk_gmres *G, const double *d_diag, double lambda) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->nrm_diag = d_diag;
   G->nrm_lambda = d_diag ? lambda : 0.0;
@@ -903,11 +915,13 @@ __global__ __launch_bounds__(NK_BLOCK) void k_add_diag_scale(int64_t n, double l
 }
 
 extern "C" int nk_gmres_set_shift(nk_gmres *G, double sigma) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->shift = sigma;
   return NK_OK;
 }
 extern "C" int nk_gmres_set_shift_weights(nk_gmres *G, const double *d_m) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->d_shift_w = d_m;  // borrowed device vector (local rows); NULL = identity
   return NK_OK;
@@ -1141,6 +1155,7 @@ static int estimate_lambda(nk_gmres *G, double *lambda) {
 
 extern "C" int nk_gmres_set_chebyshev_preconditioner(nk_gmres *G, int degree, double lambda_min, double lambda_max,
                                                      double ratio) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   NK_REQUIRE(G->op_kind != 0, "set the operator before the preconditioner");
   if (degree <= 0) {
@@ -1179,6 +1194,7 @@ extern "C" int nk_gmres_get_chebyshev_interval(nk_gmres *G, double *lambda_min, 
 // afterwards only re-linearises it at `u` — call it again for every new Jacobian, like `precs(A, p)`.
 extern "C" int nk_gmres_set_multigrid_preconditioner(nk_gmres *G, nk_problem *P, const double *u, int memspace, int nu,
                                                      int coarse_max) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   if (nu <= 0 || !P) {  // remove
     G->prec_kind = G->rprec_obj ? 4 : (G->prec ? 1 : 0);
@@ -1333,6 +1349,7 @@ int nk_gmres_spectrum_interval_dev(nk_gmres *G, double *d_out2, const double **w
   return NK_OK;
 }
 extern "C" int nk_gmres_set_spectrum_interval(nk_gmres *G, double lo, double hi) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   if (lo == 0.0 && hi == 0.0) { G->ss_ival_user = false; return NK_OK; }
   NK_REQUIRE(lo < hi && lo == lo && hi == hi && !std::isinf(lo) && !std::isinf(hi), "spectrum interval needs finite lo < hi");
@@ -1342,6 +1359,7 @@ extern "C" int nk_gmres_set_spectrum_interval(nk_gmres *G, double lo, double hi)
   return NK_OK;
 }
 extern "C" int nk_gmres_set_sstep_basis(nk_gmres *G, int basis) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   NK_REQUIRE(basis == NK_SS_BASIS_AUTO || basis == NK_SS_BASIS_MONOMIAL || basis == NK_SS_BASIS_NEWTON, "bad s-step basis %d", basis);
   G->ss_basis = basis;
@@ -1619,17 +1637,53 @@ bool nk_gmres_take_fused_update(nk_gmres *G, int *grid) {
   G->fu.done = false;
   return done;
 }
+void nk_gmres_drop_ahead(nk_gmres *G) { G->ahead.valid = false; }
+static bool gmres_graph_wanted() {
+  static const bool want_graph = getenv("NK_GMRES_GRAPH") && atoi(getenv("NK_GMRES_GRAPH")) != 0;
+  return want_graph;
+}
+int nk_gmres_begin_ahead(nk_gmres *G, const double *d_b, const double *ss_partials, int ss_grid, const double *bpart, int bnblk,
+                         double atol, double rtol, int maxiter, int fixed_iters, nk_ss_begin_args *out, bool *done) {
+  static const bool off = getenv("NK_BEGIN_AHEAD") && atoi(getenv("NK_BEGIN_AHEAD")) == 0;   // A/B switch
+  nk_ctx *ctx = G->ctx;
+  *done = false;
+  G->ahead.valid = false;
+  // exactly the solve whose begin needs nothing the host learns in between: fixed work in ONE cycle from a zero guess, the s-step
+  // form on one rank with b in column 0, a CSR operator with the Newton basis on its own Gershgorin bounds, no preconditioner
+  if (off || !(fixed_iters > 0 && fixed_iters <= G->m) || G->op_kind != 1 || !G->A || G->prec_kind || G->lprec_kind || G->normal ||
+      G->shift != 0.0 || G->ortho != NK_ORTHO_SSTEP || !nk_ss_eligible(G) || !gmres_can_preload(G) || ss_partials == nullptr ||
+      ss_grid <= 0 || bpart == nullptr || bnblk <= 0 || G->ss_basis == NK_SS_BASIS_MONOMIAL || G->ss_ival_user ||
+      G->ss_force_break_cycle >= 0 || ctx->audit.on || gmres_graph_wanted())
+    return NK_OK;
+  double *dst = nk_csr_bounds_word(G->A);
+  if (dst == nullptr) return NK_OK;
+  NK_TRY(nk_ss_prepare_ahead(G, bpart, bnblk, dst));
+  const uint64_t seq = ++G->cycle_seq;
+  NK_TRY(nk_ss_begin_args_for(G, atol, rtol, 1, 1, seq, ss_partials, ss_grid, out));
+  G->ahead.valid = true;
+  G->ahead.b = d_b; G->ahead.val = nullptr;   // (the caller names the value array once its fill is enqueued: nk_gmres_ahead_values)
+  G->ahead.atol = atol; G->ahead.rtol = rtol; G->ahead.maxiter = maxiter; G->ahead.fixed_iters = fixed_iters; G->ahead.seq = seq;
+  *done = true;
+  return NK_OK;
+}
+void nk_gmres_ahead_values(nk_gmres *G, const double *d_val) { G->ahead.val = d_val; }
 static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use_x0, double atol, double rtol, int maxiter,
                             int fixed_iters, nk_gmres_info *info) {
   nk_ctx *ctx = G->ctx;
   const int64_t n = G->n, ldv = G->ldv;
   const int m = G->m;
   NK_REQUIRE(G->op_kind != 0, "GMRES has no operator");
+  // this very solve's cycle begin has run already (nk_gmres_begin_ahead): same right-hand side, tolerances and work, same values
+  const bool ahead = G->ahead.valid && !use_x0 && G->ahead.b == d_b && G->ahead.atol == atol && G->ahead.rtol == rtol &&
+                     G->ahead.maxiter == maxiter && G->ahead.fixed_iters == fixed_iters && G->op_kind == 1 && G->A &&
+                     G->ahead.val != nullptr && nk_csr_get_valstate(G->A).d_val == G->ahead.val && G->ortho == NK_ORTHO_SSTEP &&
+                     !G->prec_kind && !G->lprec_kind && !G->normal && G->ahead.seq == G->cycle_seq && G->pre.b == d_b;
+  G->ahead.valid = false;
   // the arena's time-out counter is cumulative per CONTEXT: a solver object created after a time-out (or used after another
   // object's solve saw one) starts from what the context has already reported — not from zero
   if (ctx->peer.on && ctx->peer_err_reported > G->peer_err_seen) G->peer_err_seen = ctx->peer_err_reported;
   {
-    static const bool want_graph = getenv("NK_GMRES_GRAPH") && atoi(getenv("NK_GMRES_GRAPH")) != 0;
+    const bool want_graph = gmres_graph_wanted();
     if (want_graph && fixed_iters > 0 && fixed_iters <= m && !use_x0 && nk_ctx_is_single(ctx) && !ctx->prof.on &&
         !G->prec_kind && !G->lprec_kind && !G->normal && G->op_kind != 3 && use_dcgs2r(G) && !G->graph_broken) {
       bool used = false;
@@ -1651,7 +1705,7 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
   if (G->ortho == NK_ORTHO_SSTEP && G->ss_s == 0 &&
       ((fixed_iters <= 0 && (G->prec_kind || G->lprec_kind)) || G->normal))
     G->ortho = NK_ORTHO_DCGS2;
-  if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) NK_TRY(nk_ss_prepare(G));
+  if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G) && !ahead) NK_TRY(nk_ss_prepare(G));
   nk_gmres_info inf;
   memset(&inf, 0, sizeof(inf));
   // r0 = b − A x0, written straight into column 0 of the basis (un-normalised); zero initial guess: b → column 0 and
@@ -1689,7 +1743,10 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
     }
     return nk_blas_copy_sumsq(ctx, n, d_b, G->V, G->d_ss);
   };
-  if (!use_x0) {
+  if (ahead) {           // column 0, ‖b‖² and the cycle's begin: done (nk_gmres_begin_ahead)
+    have_ss = true;
+    x_is_zero = true;
+  } else if (!use_x0) {
     NK_TRY(rhs_to_v0());
     have_ss = true;
     x_is_zero = true;
@@ -1706,8 +1763,10 @@ static int gmres_solve_once(nk_gmres *G, const double *d_b, double *d_x, int use
     G->fu.done = false;   // (a further cycle moves x again: an update fused into an earlier one is stale)
     if (!have_ss) NK_TRY(nk_blas_sumsq(ctx, n, G->V, G->d_ss));
     have_ss = false;
-    const uint64_t seq = ++G->cycle_seq;
-    if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
+    const bool begun = ahead && first == 1;   // this cycle's begin has run ahead of the solve
+    const uint64_t seq = begun ? G->cycle_seq : ++G->cycle_seq;
+    if (begun) {
+    } else if (G->ortho == NK_ORTHO_SSTEP && nk_ss_eligible(G)) {
       NK_TRY(nk_ss_begin_cycle(G, atol, rtol, fixed_iters > 0 ? 1 : 0, first, seq,
                                ss_from_partials ? ss_partials : nullptr, ss_grid));
     } else {

@@ -383,8 +383,10 @@ int nk_problem_create_bratu_replicated(nk_ctx *ctx, int64_t ns, double lambda, d
 int nk_problem_create_brus_replicated(nk_ctx *ctx, const double *params5, nk_problem **out);
 int nk_problem_ghost_lines(nk_problem *P, const double *d_v, const double **lo, const double **hi);
 int nk_problem_residual_dev(nk_problem *P, const double *d_u, double *d_f);
+// gpart (nullable, 2·NK_MAX_RED_BLOCKS doubles, one rank): the Gershgorin partials {max −lo, max hi} per workgroup of J(d_u) —
+// the numbers the fill kernel's own discs give (same expressions), here before that kernel has run
 int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out,
-                                  double *f_copy = nullptr, double *ss_copy = nullptr);
+                                  double *f_copy = nullptr, double *ss_copy = nullptr, double *gpart = nullptr);
 // forget what the problem was linearised at: the caller wrote new contents into a buffer it may have been keyed on
 static inline void nk_problem_invalidate(nk_problem *P) { P->d_u_lin = nullptr; P->d_u_linJ = nullptr; }
 int nk_csr_clone_pattern(nk_csr *A, nk_csr **out);  // same pattern and partition, own values (collective on several ranks)
@@ -393,6 +395,22 @@ int nk_problem_jvp_dev(nk_problem *P, const double *d_u, const double *d_v, doub
                        const double *d_out_scale = nullptr, const struct nk_spmv_epi *epi = nullptr);
 int nk_problem_vjp_dev(nk_problem *P, const double *d_u, const double *d_v, double *d_vj);
 int nk_problem_spectrum_interval_dev(nk_problem *P, const double *d_u, double *d_out2);  // Bratu: {−lo, hi} of the stencil's discs
+// the s-step cycle's begin (nk_sstep.hip: k_ss_cycle_begin — or, round 6, workgroup 0 of the Newton driver's speculative Jacobian
+// fill, behind the norms' reduction: nk_gmres_begin_ahead): the stage-2 sum of ‖b‖² (k_reduce_sum's order), the max-reduction of a
+// fill kernel's Gershgorin partials, the GMRES begin, the shifts and scales of the block basis
+struct nk_gmres_ctl;
+struct nk_gmres_pub;
+constexpr int NK_SS_SMAX = 16;   // widest block
+constexpr int NK_SS_TH = 8;      // scal[NK_SS_TH + j] = θ_j; scal[0..5): first-application scale, 1/σ, σ, carried σ estimate, Newton flag
+struct nk_ss_begin_args {
+  nk_gmres_ctl *ctl;               // nullptr: nothing to do (the folded form's "no begin")
+  double *d_ss, *g, *s, *scal, *ival;
+  const double *ss_part, *bpart, *nodes;
+  nk_gmres_pub *pub;
+  uint64_t seq;
+  double atol, rtol;
+  int fixed, first, m, ss_grid, bnblk, ns, newton;
+};
 // `fold` (optional): the stage-2 reduction of a residual kernel's norm partials — max |f|, Σ f², optionally a second sum — and
 // their delivery to the host ride in workgroup 0 of the fill kernel instead of in a launch of their own (k_reduce_inf2): the
 // Newton driver's speculative fill of the NEXT Jacobian sits directly behind the residual kernel, and its first workgroup has the
@@ -407,8 +425,11 @@ struct nk_fold_norms {
   uint64_t *h_seq = nullptr;
   uint64_t seq = 0;
 };
+// `begin` (optional, with `fold`): behind that reduction the same workgroup runs the NEXT linear solve's cycle begin
+// (nk_ss_begin_body) — its inputs exist when the fill kernel starts (the residual kernel left Σ f² and, for the Bratu stencil,
+// the Gershgorin partials of the very Jacobian this launch fills: nk_problem_residual_norms_dev's gpart).
 int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const nk_fold_norms *fold = nullptr,
-                              bool *folded = nullptr);
+                              bool *folded = nullptr, const nk_ss_begin_args *begin = nullptr);
 int nk_problem_jac_colored_dev(nk_problem *P, const double *d_u, nk_csr *J);  // ncolors JVPs + decompression
 
 // ----------------------------------------------------------------------------- BLAS-1 launchers (device)
@@ -508,6 +529,10 @@ struct nk_gmres {
   double *x0_keep = nullptr;   // the warm start of a solve that runs on a resident matrix-powers plan (restored if a launch is torn)
   nk_fused_update fu;          // armed by the Newton driver for ONE solve (nk_gmres_arm_fused_update)
   struct { const double *b = nullptr, *ss = nullptr; int grid = 0; } pre;   // nk_gmres_preloaded_rhs (one solve)
+  // nk_gmres_begin_ahead: the NEXT solve's cycle begin is in the queue already (inside a kernel of the caller's) — for exactly
+  // these arguments and this set of operator values
+  struct { bool valid = false; const double *b = nullptr, *val = nullptr; double atol = 0.0, rtol = 0.0;
+           int maxiter = 0, fixed_iters = 0; uint64_t seq = 0; } ahead;
   double *d_Hraw = nullptr, *d_ca = nullptr, *d_cb = nullptr;  // DCGS2: un-rotated Hessenberg, pass-A coefficients
   double *d_tprev = nullptr, *d_red = nullptr;                 // DCGS2-1R: first-projection part of the open column, reduced dots
   double *d_h = nullptr, *d_h2 = nullptr, *d_R = nullptr, *d_cs = nullptr, *d_sn = nullptr,
@@ -666,6 +691,87 @@ __device__ __forceinline__ void nk_gmres_begin_body(nk_gmres_ctl *ctl, double ss
   if (pub != nullptr)
     __hip_atomic_store(&pub->progress, (seq << 16) | (uint64_t)(ctl->done ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// (ONE 256-thread workgroup; sm: 16 doubles of LDS)
+__device__ __forceinline__ void nk_ss_begin_body(const nk_ss_begin_args &a, double *sm) {
+  double *sh_ch = sm + 12;   // centre, half width, Newton basis in effect
+  const int t = threadIdx.x, wv = t >> 6;
+  // (requested before the reductions: a lone thread's loads behind its own stores cost a round trip each — the 15 shifts alone
+  //  were 7 of this launch's 12 µs)
+  const double node_t = (t < NK_SS_SMAX) ? a.nodes[t] : 0.0;
+  const double sigma_old = (t == 0) ? a.scal[3] : 0.0;
+  double v = 0.0, blo = -INFINITY, bhi = -INFINITY;
+  if (a.ss_part != nullptr)
+    for (int i = t; i < a.ss_grid; i += 256) v += a.ss_part[i];
+  if (a.bpart != nullptr) {
+    for (int base = 0; base < a.bnblk; base += 2048) {   // sixteen loads in flight per lane (a rolled loop: one round trip each)
+      double x[8], y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + t + 256 * j, ic = i < a.bnblk ? i : a.bnblk - 1;   // (clamped: max is idempotent)
+        x[j] = a.bpart[ic];
+        y[j] = a.bpart[a.bnblk + ic];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { blo = fmax(blo, x[j]); bhi = fmax(bhi, y[j]); }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o, 64);
+    blo = fmax(blo, __shfl_xor(blo, o, 64));
+    bhi = fmax(bhi, __shfl_xor(bhi, o, 64));
+  }
+  if ((t & 63) == 0) { sm[wv] = v; sm[4 + wv] = blo; sm[8 + wv] = bhi; }
+  __syncthreads();
+  if (t == 0) {
+  double ss;
+  if (a.ss_part != nullptr) {
+    ss = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    *a.d_ss = ss;
+  } else {
+    ss = *a.d_ss;
+  }
+  double lo_neg = 0.0, hi = 0.0;
+  if (a.newton) {
+    if (a.bpart != nullptr) {
+      lo_neg = fmax(fmax(sm[4], sm[5]), fmax(sm[6], sm[7]));
+      hi = fmax(fmax(sm[8], sm[9]), fmax(sm[10], sm[11]));
+      a.ival[0] = lo_neg;
+      a.ival[1] = hi;
+    } else {
+      lo_neg = a.ival[0];
+      hi = a.ival[1];
+    }
+  }
+  nk_gmres_begin_body(a.ctl, ss, a.atol, a.rtol, a.fixed, a.first, a.g, a.s, a.m, a.pub, a.seq);
+  double *scal = a.scal;
+  double sigma = sigma_old;
+  double newton = 0.0, c = 0.0, h = 0.0;
+  if (a.newton) {
+    const double lo = -lo_neg;
+    c = 0.5 * (lo + hi);
+    h = 0.5 * (hi - lo);
+    if (h > 0.0 && !isinf(h) && c == c && !isinf(c)) {
+      sigma = exp2(rint(log2(0.5 * h)));
+      newton = 1.0;
+    }
+  }
+  sh_ch[0] = c; sh_ch[1] = h; sh_ch[2] = newton;
+  if (!(sigma > 0.0) || isinf(sigma)) sigma = 1.0;
+  scal[4] = newton;
+  scal[3] = sigma;
+  scal[2] = sigma;
+  scal[1] = 1.0 / sigma;
+  {  // s[0] as nk_gmres_begin_body has just stored it (recomputed: reading it back is a memory round trip)
+    const double beta = sqrt(ss);
+    const bool bad = !(beta == beta) || isinf(beta);
+    scal[0] = ((beta > 0.0 && !bad) ? 1.0 / beta : 0.0) / sigma;
+  }
+  }
+  __syncthreads();
+  if (t < NK_SS_SMAX)   // the shifts, one lane each
+    a.scal[NK_SS_TH + t] = (sh_ch[2] != 0.0 && t < a.ns) ? sh_ch[0] + sh_ch[1] * node_t : 0.0;
+}
 #endif
 // s-step form: the cycle's begin kernel (gmres begin + the block basis' shifts and scales; on one rank also the stage-2
 // reductions of ‖b‖² and of the Jacobian fill's Gershgorin partials, which are launches of their own otherwise)
@@ -686,6 +792,8 @@ void nk_csr_set_valstate(nk_csr *A, const nk_csr_valstate &v);
 int nk_csr_alloc_values(nk_csr *A, double **out);   // a zero-padded value array of A's size (freed with hipFree)
 // fill kernels' Gershgorin partials not reduced yet: hands them to a caller that reduces them into *dst in its own kernel
 bool nk_csr_take_pending_bounds(nk_csr *A, const double **part, int *nblk, double **dst);
+double *nk_csr_bounds_word(nk_csr *A);         // {−lo, hi} of the matrix's Gershgorin bounds (device; allocated on first use; NULL on failure)
+void nk_csr_invalidate_bounds(nk_csr *A);     // the bounds word no longer belongs to the live values (recomputed on demand)
 void nk_csr_commit_pending_bounds(nk_csr *A);   // the caller's reducing kernel is enqueued: the partials are no longer pending
 int nk_blas_copy_sumsq_stage1(nk_ctx *ctx, int64_t n, const double *x, double *y, int *grid_out);
 // (have_partials > 0: stage 1 has run inside the kernel that produced x — ctx->d_partials holds its have_partials workgroups' results)
@@ -708,6 +816,21 @@ void nk_gmres_arm_fused_update(nk_gmres *G, const double *u_old, double *u_new, 
 // next solve could not use it anyway.
 double *nk_gmres_rhs_column(nk_gmres *G);
 void nk_gmres_preloaded_rhs(nk_gmres *G, const double *d_b, const double *ss_partials, int grid);
+// The NEXT solve's cycle begin (k_ss_cycle_begin's work) handed to a kernel of the caller's instead of being launched: fills
+// *out for nk_ss_begin_body when that solve will be the fixed-work, single-cycle, zero-guess s-step solve on one rank with a
+// CSR operator and the Newton basis, its right-hand side d_b in column 0 already (nk_gmres_preloaded_rhs), ‖b‖² as the partial
+// sums ss_partials[0 .. ss_grid), the operator's Gershgorin partials {max −lo, max hi} in bpart[0 .. 2·bnblk) — *done says
+// whether. The caller must enqueue a kernel that runs nk_ss_begin_body(*out) behind the producers of those partials, on the
+// operator values the solve will see. nk_gmres_solve_dev skips its begin when its arguments and the operator's value array are
+// the ones recorded here, and otherwise starts from scratch; nk_gmres_drop_ahead forgets the record (every nk_gmres_set_* does).
+int nk_gmres_begin_ahead(nk_gmres *G, const double *d_b, const double *ss_partials, int ss_grid, const double *bpart, int bnblk,
+                         double atol, double rtol, int maxiter, int fixed_iters, nk_ss_begin_args *out, bool *done);
+void nk_gmres_drop_ahead(nk_gmres *G);
+void nk_gmres_ahead_values(nk_gmres *G, const double *d_val);   // the value array the begin's bounds belong to (set once its fill is enqueued)
+// (nk_sstep.hip) the begin's argument block for this object's workspace; first: 1 a new solve
+int nk_ss_prepare_ahead(nk_gmres *G, const double *bpart, int bnblk, double *dst);
+int nk_ss_begin_args_for(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
+                         int ss_grid, nk_ss_begin_args *out);
 bool nk_gmres_take_fused_update(nk_gmres *G, int *grid);
 void nk_ss_destroy(struct nk_sstep *W);
 int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);

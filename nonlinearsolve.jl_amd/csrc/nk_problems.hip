@@ -71,15 +71,28 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual_norms(int64_t ns, i
                                                                    const double *__restrict__ u, const double *__restrict__ lo,
                                                                    const double *__restrict__ hi, double *__restrict__ f,
                                                                    double *__restrict__ partials, double *__restrict__ f_copy,
-                                                                   double *__restrict__ ss_copy) {
+                                                                   double *__restrict__ ss_copy, double *__restrict__ gpart) {
   // f_copy / ss_copy (nullable): f once more — into column 0 of the Krylov basis the next linear solve starts from — and the
   // Σ f² partials once more, where that solve's first kernel finds ‖b‖² (nk_gmres_preloaded_rhs)
-  __shared__ double sm[8];
-  double m = 0.0, s = 0.0;
+  // gpart (nullable; one rank: jl is the global grid line): the Gershgorin partials of J(u) — centre 4 c_lap − c_exp·eᵘ, radius =
+  // the |off-diagonals| added in CSR order —, exactly k_bratu_jac's expressions: {max −(d − r), max (d + r)} per workgroup
+  __shared__ double sm[16];
+  double m = 0.0, s = 0.0, mlo = -INFINITY, mhi = -INFINITY;
   const int64_t n = ns * nl, stride = (int64_t)gridDim.x * NK_BLOCK;
   for (int64_t k = (int64_t)blockIdx.x * NK_BLOCK + threadIdx.x; k < n; k += stride) {
     const int64_t jl = k / ns, i = k - jl * ns;
-    const double v = c_lap * bratu_lap(u, lo, hi, ns, nl, i, jl, k) - c_exp * exp(u[k]);
+    const double eu = exp(u[k]);
+    const double v = c_lap * bratu_lap(u, lo, hi, ns, nl, i, jl, k) - c_exp * eu;
+    if (gpart != nullptr) {
+      const double d = 4.0 * c_lap - c_exp * eu;
+      double rad = 0.0;
+      if (jl > 0) rad += c_lap;
+      if (i > 0) rad += c_lap;
+      if (i < ns - 1) rad += c_lap;
+      if (jl < ns - 1) rad += c_lap;
+      mlo = fmax(mlo, -(d - rad));
+      mhi = fmax(mhi, d + rad);
+    }
     f[k] = v;
     if (f_copy) f_copy[k] = v;
     const double av = fabs(v);
@@ -100,6 +113,16 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_residual_norms(int64_t ns, i
     partials[blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
     partials[gridDim.x + blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     if (ss_copy) ss_copy[blockIdx.x] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  }
+  if (gpart != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mlo = fmax(mlo, __shfl_xor(mlo, o, 64)); mhi = fmax(mhi, __shfl_xor(mhi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sm[8 + (threadIdx.x >> 6)] = mlo; sm[12 + (threadIdx.x >> 6)] = mhi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      gpart[blockIdx.x] = fmax(fmax(sm[8], sm[9]), fmax(sm[10], sm[11]));
+      gpart[gridDim.x + blockIdx.x] = fmax(fmax(sm[12], sm[13]), fmax(sm[14], sm[15]));
+    }
   }
 }
 __global__ __launch_bounds__(NK_BLOCK) void k_bratu_diag(int64_t n, double c_exp, const double *__restrict__ u,
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, 
                                                         double c_exp, const double *__restrict__ u,
                                                         const int32_t *__restrict__ rowptr,
                                                         double *__restrict__ vals, double *__restrict__ gpart,
-                                                        const nk_fold_norms fold) {
+                                                        const nk_fold_norms fold, const nk_ss_begin_args beg) {
   __shared__ double sv[5 * NK_BLOCK];
   __shared__ double sg[8];
   __shared__ int32_t s_p0, s_p1;
@@ -211,6 +234,10 @@ __global__ __launch_bounds__(NK_BLOCK) void k_bratu_jac(int64_t ns, int64_t nl, 
   const int fb = fold.partials != nullptr ? 1 : 0;
   if (fb && blockIdx.x == 0) {
     nk_reduce_inf2_body(fold, sv);
+    if (beg.ctl != nullptr) {   // … and the next linear solve's cycle begin (nk_gmres_begin_ahead)
+      __syncthreads();
+      nk_ss_begin_body(beg, sv + 16);
+    }
     return;
   }
   const int bid = (int)blockIdx.x - fb, nbl = (int)gridDim.x - fb;
@@ -562,7 +589,7 @@ extern "C" int nk_problem_set_params(nk_problem *P, const double *params, int np
 // f(u) and the stage-1 partials of ‖f‖∞, ‖f‖₂² in ONE launch, where the problem has such a kernel: *grid_out = the number of
 // workgroups (partials laid out as k_absmax_sumsq leaves them), 0 = not available (nothing was launched).
 int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f, double *partials, int *grid_out, double *f_copy,
-                                  double *ss_copy) {
+                                  double *ss_copy, double *gpart) {
   static const bool off = getenv("NK_FUSED_RESIDUAL_NORMS") && atoi(getenv("NK_FUSED_RESIDUAL_NORMS")) == 0;   // A/B switch
   *grid_out = 0;
   nk_ctx *ctx = P->ctx;
@@ -573,8 +600,10 @@ int nk_problem_residual_norms_dev(nk_problem *P, const double *d_u, double *d_f,
   const double *lo, *hi;
   NK_TRY(nk_halo_exchange(ctx, &P->halo, d_u));
   halo_lines(P, 1, false, &lo, &hi);
+  // (the discs' radii depend on the GLOBAL position of a row: one rank with the whole grid only)
+  const bool whole = ctx->nranks == 1 && P->j0 == 0 && P->j1 == P->ns && !P->replicated;
   NK_LAUNCH(ctx, k_bratu_residual_norms, dim3(grid), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->c_lap, P->c_exp, d_u, lo, hi, d_f,
-            partials, f_copy, ss_copy);
+            partials, f_copy, ss_copy, whole ? gpart : (double *)nullptr);
   NK_HIP(hipGetLastError());
   *grid_out = grid;
   return NK_OK;
@@ -904,7 +933,8 @@ extern "C" int nk_problem_jac_csr(nk_problem *P, nk_csr **out) {
   NK_FAIL(NK_E_INVALID, "bad problem kind");
 }
 
-int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const nk_fold_norms *fold, bool *folded) {
+int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const nk_fold_norms *fold, bool *folded,
+                              const nk_ss_begin_args *begin) {
   nk_ctx *ctx = P->ctx;
   const int64_t n = P->n_local;
   if (folded) *folded = false;
@@ -921,7 +951,14 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const
       // every linear solve); several ranks: the bounds are all-reduced, computed on demand
       const int g = grid1(n);
       double *gpart = nullptr;
-      if (ctx->nranks == 1 && J->nblocks > 0) {
+      const bool take_fold = fold != nullptr && folded != nullptr && fold->partials != nullptr && ctx->nranks == 1;
+      const bool begin_rides = take_fold && begin != nullptr && begin->ctl != nullptr;
+      if (begin_rides) {
+        // the cycle begin in this launch's first workgroup reduces the bounds of THIS Jacobian (from the residual kernel's
+        // partials) into the matrix's bounds word: nothing pending, nothing for this kernel to compute
+        NK_REQUIRE(begin->ival != nullptr && begin->ival == nk_csr_bounds_word(J), "internal: a cycle begin folded into the fill must reduce into the matrix's bounds word");
+        J->bounds_valid = true;
+      } else if (ctx->nranks == 1 && J->nblocks > 0) {
         if (!J->d_gersh || J->gersh_cap < 2 * g) {
           hipFree(J->d_gersh);
           J->d_gersh = nullptr;
@@ -931,9 +968,9 @@ int nk_problem_jac_values_dev(nk_problem *P, const double *d_u, nk_csr *J, const
         }
         gpart = J->d_gersh;
       }
-      const bool take_fold = fold != nullptr && folded != nullptr && fold->partials != nullptr && ctx->nranks == 1;
       NK_LAUNCH(ctx, k_bratu_jac, dim3(g + (take_fold ? 1 : 0)), dim3(NK_BLOCK), P->ns, P->j1 - P->j0, P->j0, P->c_lap, P->c_exp, d_u,
-                J->d_rowptr, J->d_val, gpart, take_fold ? *fold : nk_fold_norms{});
+                J->d_rowptr, J->d_val, gpart, take_fold ? *fold : nk_fold_norms{},
+                begin_rides ? *begin : nk_ss_begin_args{});
       if (take_fold) *folded = true;
       if (gpart) NK_TRY(nk_csr_bounds_from_partials(J, gpart, g));
       break;

@@ -71,6 +71,8 @@ struct nk_solver {
   // second value set while the host waits for this step's norms — the queue is not empty during the termination test's round
   // trip. The live J is untouched until the next step takes the set (refresh_J); a solve that terminates never sees it.
   bool spec_valid = false;
+  bool begun_ahead = false;     // … and the next linear solve's cycle begin rode in that fill's first workgroup (speculate_J)
+  double *d_rhs_gersh = nullptr;   // the residual kernel's Gershgorin partials of J(u_new) (what that begin reduces)
   uint64_t spec_version = 0, spec_params = 0;
   // the step's last residual kernel also wrote f into column 0 of the Krylov basis and its Σ f² partials into d_rhs_ss: the next
   // step's linear solve starts from them if nothing has moved since (nk_gmres_preloaded_rhs)
@@ -79,6 +81,7 @@ struct nk_solver {
   uint64_t pre_uver = 0, pre_params = 0;
   const double *pre_fu = nullptr;
   int pre_grid = 0;
+  int rhs_gersh_grid = 0;      // > 0: d_rhs_gersh holds the Gershgorin partials of J at the iterate the residual was taken at
   const double *spec_u = nullptr;               // the iterate the set was filled at
   nk_csr_valstate spec_state{};                 // the filled set (valid) / the spare buffers (not valid)
   nk_precs_fn precs = nullptr;
@@ -294,8 +297,17 @@ static bool speculation_allowed(const nk_solver *S) {
 // J(u) of the iterate just formed into the spare value set (enqueued behind the step's last kernels, before the host waits)
 // (`version`: the iterate's version at which the set may be taken)
 // (fold / folded: the stage-2 reduction of the step's norms rides in the fill kernel's first workgroup — nk_fold_norms)
+// The next step's linear solve may have its cycle begin run in that fill's first workgroup as well (nk_gmres_begin_ahead): one
+// launch less on the step's critical path. Only where nothing the host learns in between can change the begin: no forcing (the
+// tolerance of the next solve is this one's), no preconditioner that is rebuilt per Jacobian, fixed work, not the last step.
+static bool begin_ahead_allowed(const nk_solver *S) {
+  return speculation_allowed(S) && S->o.forcing != NK_FORCING_EISENSTAT_WALKER2 && S->o.cheb_degree <= 0 && S->o.mg_nu <= 0 &&
+         !S->o.precond_kind && !S->o.store_trace && S->G != nullptr && S->G->op_kind == 1 && S->G->A == S->J &&
+         S->o.gmres_fixed_iters > 0 && S->nsteps + 2 <= S->o.maxiters && S->pre_valid && S->rhs_gersh_grid > 0;
+}
 static int speculate_J(nk_solver *S, const double *u_at, uint64_t version, const nk_fold_norms *fold = nullptr, bool *folded = nullptr) {
   S->spec_valid = false;
+  S->begun_ahead = false;
   if (folded) *folded = false;
   if (!speculation_allowed(S)) return NK_OK;
   nk_csr *J = S->J;
@@ -304,7 +316,22 @@ static int speculate_J(nk_solver *S, const double *u_at, uint64_t version, const
   nk_csr_valstate spare = S->spec_state;
   spare.t_values_stale = true; spare.bounds_valid = false; spare.bounds_pending = false;
   nk_csr_set_valstate(J, spare);
-  const int rc = nk_problem_jac_values_dev(S->P, u_at, J, fold, folded);
+  nk_ss_begin_args beg{};
+  bool begin_rides = false;
+  if (fold != nullptr && begin_ahead_allowed(S)) {
+    const int brc = nk_gmres_begin_ahead(S->G, S->fu, S->d_rhs_ss, S->pre_grid, S->d_rhs_gersh, S->rhs_gersh_grid, S->lin_abstol,
+                                         S->lin_reltol, S->o.gmres_maxiters, S->o.gmres_fixed_iters, &beg, &begin_rides);
+    if (brc != NK_OK) { nk_csr_set_valstate(J, live); return brc; }
+  }
+  const int rc = nk_problem_jac_values_dev(S->P, u_at, J, fold, folded, begin_rides ? &beg : nullptr);
+  if (begin_rides) {
+    if (rc == NK_OK && folded && *folded) {
+      nk_gmres_ahead_values(S->G, nk_csr_get_valstate(J).d_val);
+      S->begun_ahead = true;
+    } else {
+      nk_gmres_drop_ahead(S->G);
+    }
+  }
   S->spec_state = nk_csr_get_valstate(J);       // (the fill may have grown the partials buffer)
   nk_csr_set_valstate(J, live);
   if (rc != NK_OK) return rc;
@@ -314,6 +341,15 @@ static int speculate_J(nk_solver *S, const double *u_at, uint64_t version, const
   S->spec_params = S->P->params_version;
   return NK_OK;
 }
+// a begin that ran ahead for a solve that will not take it: forgotten — and, because it reduced the SPARE value set's bounds into
+// the matrix's bounds word, the live set's bounds are recomputed on demand
+static void drop_begun_ahead(nk_solver *S) {
+  if (!S->begun_ahead) return;
+  S->begun_ahead = false;
+  nk_gmres_drop_ahead(S->G);
+  if (S->J) nk_csr_invalidate_bounds(S->J);
+  S->spec_valid = false;
+}
 static int refresh_J(nk_solver *S) {
   if (S->spec_valid && S->spec_version == S->u_version && S->spec_u == S->u && S->spec_params == S->P->params_version &&
       speculation_allowed(S)) {
@@ -322,7 +358,9 @@ static int refresh_J(nk_solver *S) {
     nk_csr_set_valstate(S->J, S->spec_state);
     S->spec_state = live;
     S->spec_valid = false;
+    S->begun_ahead = false;   // (nk_gmres_solve_dev skips its begin — or starts from scratch if anything about the solve differs)
   } else {
+    drop_begun_ahead(S);
     S->spec_valid = false;
     if (S->o.jac_colored && S->P->kind != NK_PROBLEM_USER) NK_TRY(nk_problem_jac_colored_dev(S->P, S->u, S->J));
     else NK_TRY(nk_problem_jac_values_dev(S->P, S->u, S->J));
@@ -681,6 +719,7 @@ extern "C" int nk_solver_destroy(nk_solver *S) {
                     S->lm_a, S->lm_vcache, S->lm_rhs, S->pt_mass};
   for (double *b : bufs) hipFree(b);
   hipFree(S->d_rhs_ss);
+  hipFree(S->d_rhs_gersh);
   hipFree(S->spec_state.d_val);     // (whichever value set is the spare one now; the live one belongs to J)
   hipFree(S->spec_state.d_gersh);
   nk_gmres_destroy(S->G);
@@ -1725,6 +1764,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     if (!direct(S)) NK_TRY(refresh_precs(S));
   } else {
     new_jacobian = false;
+    drop_begun_ahead(S);
     S->spec_valid = false;   // (a value set filled ahead is only ever taken by the step that follows its fill)
   }
   if (is_lm(S)) return lm_step(S, new_jacobian, evaluate_residual);
@@ -1808,7 +1848,13 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     // … and, for the next step's linear solve (plain Newton: its right-hand side is this f), f in column 0 of the Krylov basis
     double *v0 = (fold_sign && !direct(S) && !is_pt(S) && !normal_form(S) && S->G != nullptr) ? nk_gmres_rhs_column(S->G) : nullptr;
     if (v0 != nullptr && S->d_rhs_ss == nullptr) NK_TRY(nk_dev_alloc(&S->d_rhs_ss, (size_t)NK_MAX_RED_BLOCKS));
-    NK_TRY(nk_problem_residual_norms_dev(S->P, S->u, S->fu, ctx->d_partials, &norm_grid, v0, v0 ? S->d_rhs_ss : nullptr));
+    // (… and, for a cycle begin that may run ahead of the next solve, the Gershgorin partials of J(u_new): the Bratu residual kernel
+    //  evaluates the exponential the discs' centres need anyway)
+    const bool want_gersh = v0 != nullptr && S->P->kind == NK_PROBLEM_BRATU2D && nk_ctx_is_single(ctx) && speculation_allowed(S);
+    if (want_gersh && S->d_rhs_gersh == nullptr) NK_TRY(nk_dev_alloc(&S->d_rhs_gersh, (size_t)2 * NK_MAX_RED_BLOCKS));
+    NK_TRY(nk_problem_residual_norms_dev(S->P, S->u, S->fu, ctx->d_partials, &norm_grid, v0, v0 ? S->d_rhs_ss : nullptr,
+                                         want_gersh ? S->d_rhs_gersh : nullptr));
+    S->rhs_gersh_grid = (want_gersh && norm_grid > 0 && S->P->j0 == 0 && S->P->j1 == S->P->ns && !S->P->replicated) ? norm_grid : 0;
     S->pre_valid = norm_grid > 0 && v0 != nullptr;
     if (S->pre_valid) {
       S->pre_uver = S->u_version; S->pre_params = S->P->params_version; S->pre_fu = S->fu; S->pre_grid = norm_grid;
@@ -1837,6 +1883,7 @@ static int internal_step(nk_solver *S, int recompute /*-1 nothing, 0 false, 1 tr
     }
   }
   NK_TRY(check_and_update(S, step_norm));
+  if (S->force_stop) drop_begun_ahead(S);
   if (S->o.store_trace) {
     nk_trace_entry e;
     memset(&e, 0, sizeof(e));

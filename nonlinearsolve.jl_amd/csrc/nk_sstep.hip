@@ -33,8 +33,8 @@
 constexpr int SS_R = 256;        // rows per tile = threads per workgroup
 constexpr int SS_P = SS_R + 1;   // LDS pitch in doubles (odd)
 constexpr int SS_MTMAX = 5;      // Gram tiles of 16 rows: k + s ≤ 80
-constexpr int SS_SMAX = 16;      // one 16-wide matrix-core tile of new columns
-constexpr int SS_TH = 8;         // scal[SS_TH + j] = θ_j; scal[0..5): first-application scale, 1/σ, σ, carried σ estimate, Newton flag
+constexpr int SS_SMAX = NK_SS_SMAX;   // one 16-wide matrix-core tile of new columns
+constexpr int SS_TH = NK_SS_TH;   // scal[SS_TH + j] = θ_j; scal[0..5): first-application scale, 1/σ, σ, carried σ estimate, Newton flag
 constexpr int SS_MAX_WG_PER_CU = 4;
 typedef double ss_d4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ss_u2 __attribute__((ext_vector_type(2)));
@@ -1851,95 +1851,10 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
 //    first operator application. newton: `ival` = {−lo, hi} bounds the spectrum; θ_j = c + h·t_j with t the Leja-ordered
 //    Chebyshev points of [−1, 1] and σ = the interval's capacity h/2 rounded to a power of two (exact in binary floating point;
 //    the basis polynomials then stay O(1) on the interval). Degenerate bounds fall back to the monomial basis: θ = 0, σ ≈ ‖A v₁‖.
-struct ss_begin_args {
-  nk_gmres_ctl *ctl;
-  double *d_ss, *g, *s, *scal, *ival;
-  const double *ss_part, *bpart, *nodes;
-  nk_gmres_pub *pub;
-  uint64_t seq;
-  double atol, rtol;
-  int fixed, first, m, ss_grid, bnblk, ns, newton;
-};
+typedef nk_ss_begin_args ss_begin_args;
 __global__ __launch_bounds__(256) void k_ss_cycle_begin(const ss_begin_args a) {
-  __shared__ double sm[12];
-  __shared__ double sh_ch[3];   // centre, half width, Newton basis in effect
-  const int t = threadIdx.x, wv = t >> 6;
-  // (requested before the reductions: a lone thread's loads behind its own stores cost a round trip each — the 15 shifts alone
-  //  were 7 of this launch's 12 µs)
-  const double node_t = (t < SS_SMAX) ? a.nodes[t] : 0.0;
-  const double sigma_old = (t == 0) ? a.scal[3] : 0.0;
-  double v = 0.0, blo = -INFINITY, bhi = -INFINITY;
-  if (a.ss_part != nullptr)
-    for (int i = t; i < a.ss_grid; i += 256) v += a.ss_part[i];
-  if (a.bpart != nullptr) {
-    for (int base = 0; base < a.bnblk; base += 2048) {   // sixteen loads in flight per lane (a rolled loop: one round trip each)
-      double x[8], y[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = base + t + 256 * j, ic = i < a.bnblk ? i : a.bnblk - 1;   // (clamped: max is idempotent)
-        x[j] = a.bpart[ic];
-        y[j] = a.bpart[a.bnblk + ic];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { blo = fmax(blo, x[j]); bhi = fmax(bhi, y[j]); }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    v += __shfl_xor(v, o, 64);
-    blo = fmax(blo, __shfl_xor(blo, o, 64));
-    bhi = fmax(bhi, __shfl_xor(bhi, o, 64));
-  }
-  if ((t & 63) == 0) { sm[wv] = v; sm[4 + wv] = blo; sm[8 + wv] = bhi; }
-  __syncthreads();
-  if (t == 0) {
-  double ss;
-  if (a.ss_part != nullptr) {
-    ss = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-    *a.d_ss = ss;
-  } else {
-    ss = *a.d_ss;
-  }
-  double lo_neg = 0.0, hi = 0.0;
-  if (a.newton) {
-    if (a.bpart != nullptr) {
-      lo_neg = fmax(fmax(sm[4], sm[5]), fmax(sm[6], sm[7]));
-      hi = fmax(fmax(sm[8], sm[9]), fmax(sm[10], sm[11]));
-      a.ival[0] = lo_neg;
-      a.ival[1] = hi;
-    } else {
-      lo_neg = a.ival[0];
-      hi = a.ival[1];
-    }
-  }
-  nk_gmres_begin_body(a.ctl, ss, a.atol, a.rtol, a.fixed, a.first, a.g, a.s, a.m, a.pub, a.seq);
-  double *scal = a.scal;
-  double sigma = sigma_old;
-  double newton = 0.0, c = 0.0, h = 0.0;
-  if (a.newton) {
-    const double lo = -lo_neg;
-    c = 0.5 * (lo + hi);
-    h = 0.5 * (hi - lo);
-    if (h > 0.0 && !isinf(h) && c == c && !isinf(c)) {
-      sigma = exp2(rint(log2(0.5 * h)));
-      newton = 1.0;
-    }
-  }
-  sh_ch[0] = c; sh_ch[1] = h; sh_ch[2] = newton;
-  if (!(sigma > 0.0) || isinf(sigma)) sigma = 1.0;
-  scal[4] = newton;
-  scal[3] = sigma;
-  scal[2] = sigma;
-  scal[1] = 1.0 / sigma;
-  {  // s[0] as nk_gmres_begin_body has just stored it (recomputed: reading it back is a memory round trip)
-    const double beta = sqrt(ss);
-    const bool bad = !(beta == beta) || isinf(beta);
-    scal[0] = ((beta > 0.0 && !bad) ? 1.0 / beta : 0.0) / sigma;
-  }
-  }
-  __syncthreads();
-  if (t < SS_SMAX)   // the shifts, one lane each
-    a.scal[SS_TH + t] = (sh_ch[2] != 0.0 && t < a.ns) ? sh_ch[0] + sh_ch[1] * node_t : 0.0;
+  __shared__ double sm[16];
+  nk_ss_begin_body(a, sm);
 }
 
 // development hook (not in the public header): the first block of restart cycle `cycle` of the next solves reports a
@@ -1953,6 +1868,7 @@ __global__ void k_ss_force_fail(nk_gmres_ctl *ctl, nk_gmres_pub *pub, uint64_t s
   ss_pub_progress(pub, seq, ctl->k, 1);
 }
 extern "C" int nk_gmres_debug_force_breakdown(nk_gmres *G, int cycle) {
+  if (G) G->ahead.valid = false;   // (a cycle begin run ahead of the next solve belongs to the old setting)
   NK_REQUIRE(G, "NULL argument");
   G->ss_force_break_cycle = cycle;
   return NK_OK;
@@ -2102,9 +2018,10 @@ nk_ss_fix nk_ss_take_last_block(nk_gmres *G) {
   return fx;
 }
 
-// The cycle's begin kernel (k_ss_cycle_begin). ss_partials: ‖b‖² as per-workgroup partial sums (one rank), else G->d_ss holds it.
-int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
-                      int ss_grid) {
+// The cycle begin's argument block (k_ss_cycle_begin / nk_ss_begin_body) for this object's workspace. ss_partials: ‖b‖² as
+// per-workgroup partial sums (one rank), else G->d_ss holds it. nk_ss_prepare (or nk_ss_prepare_ahead) has chosen the basis.
+int nk_ss_begin_args_for(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
+                         int ss_grid, nk_ss_begin_args *out) {
   nk_ctx *ctx = G->ctx;
   NK_TRY(ss_workspace(G));
   nk_sstep *W = G->ss;
@@ -2122,10 +2039,30 @@ int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int firs
   a.ss_part = ss_partials; a.bpart = W->newton ? W->bpart : nullptr; a.nodes = W->nodes;
   a.pub = G->h_pub_dev; a.seq = seq; a.atol = atol; a.rtol = rtol;
   a.fixed = fixed; a.first = first; a.m = G->m; a.ss_grid = ss_grid; a.bnblk = W->bnblk; a.ns = s; a.newton = W->newton ? 1 : 0;
+  *out = a;
+  return NK_OK;
+}
+// The cycle's begin as a launch of its own.
+int nk_ss_begin_cycle(nk_gmres *G, double atol, double rtol, int fixed, int first, uint64_t seq, const double *ss_partials,
+                      int ss_grid) {
+  nk_ctx *ctx = G->ctx;
+  ss_begin_args a;
+  NK_TRY(nk_ss_begin_args_for(G, atol, rtol, fixed, first, seq, ss_partials, ss_grid, &a));
   NK_LAUNCH(ctx, k_ss_cycle_begin, dim3(1), dim3(256), a);
   NK_HIP(hipGetLastError());
   if (a.bpart != nullptr && G->op_kind == 1 && G->A) nk_csr_commit_pending_bounds(G->A);
-  W->bpart = nullptr;   // (reduced by this launch; later cycles of the solve read the bounds where it left them)
+  G->ss->bpart = nullptr;   // (reduced by this launch; later cycles of the solve read the bounds where it left them)
+  return NK_OK;
+}
+// nk_ss_prepare for a solve whose begin is handed to a kernel of the caller's (nk_gmres_begin_ahead): the Newton basis on the
+// Gershgorin partials the caller names, reduced by that begin into `dst` (the matrix's bounds word)
+int nk_ss_prepare_ahead(nk_gmres *G, const double *bpart, int bnblk, double *dst) {
+  NK_TRY(ss_workspace(G));
+  nk_sstep *W = G->ss;
+  W->bpart = bpart;
+  W->bnblk = bnblk;
+  W->ival_use = dst;
+  W->newton = true;
   return NK_OK;
 }
 

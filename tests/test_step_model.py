@@ -32,7 +32,8 @@ def test_model_lists_exactly_the_launches_of_the_committed_timeline(path):
     resident, implicit, deferred = "k_spmv_powers" in ks, "k_ss_block<C>" not in ks, "k_ss_job" in ks
     model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15, resident_powers=resident, implicit=implicit,
                                                             deferred=deferred, fused_tail="k_newton_update" not in ks,
-                                                            preloaded_rhs="k_copy_sumsq" not in ks, folded_norms="k_reduce_inf2" not in ks)]
+                                                            preloaded_rhs="k_copy_sumsq" not in ks, folded_norms="k_reduce_inf2" not in ks,
+                                                            begin_ahead="k_ss_cycle_begin" not in ks)]
     assert ks == model, f"{os.path.basename(path)}: the step launches\n{ks}\nthe model charges for\n{model}"
 
 
@@ -43,7 +44,7 @@ def test_a_timeline_of_the_current_dispatch_is_committed():
     model = [nm for nm, _h, _a in step_model.step_launches(N, NNZ, arnoldi=30, s=15)]
     assert "k_ss_job" in model and "k_backsolve" not in model       # round 5's dispatch
     assert "k_newton_update" not in model and "k_bratu_residual_norms" in model and "k_copy_sumsq" not in model
-    assert "k_reduce_inf2" not in model                            # round 6: the norms' stage 2 rides in the next fill kernel
+    assert "k_reduce_inf2" not in model and "k_ss_cycle_begin" not in model   # round 6: both ride in the next fill kernel
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]_*step_timeline.md")))
     assert any(_timeline_kernels(p) == model for p in paths), \
         "no committed profiles/r05_*step_timeline.md matches the current dispatch: rerun tools/gpu_r05_evidence.sh and copy it"

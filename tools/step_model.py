@@ -30,10 +30,12 @@ def spmv_bytes(n, nnz):
 
 
 def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True,
-                  fused_tail=True, preloaded_rhs=True, folded_norms=True):
+                  fused_tail=True, preloaded_rhs=True, folded_norms=True, begin_ahead=True):
     """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order.
     folded_norms (round 6): the stage-2 reduction of the step's norms and their delivery to the host ride in workgroup 0 of the
     NEXT Jacobian's fill kernel (k_bratu_jac, enqueued directly behind the residual kernel) — no k_reduce_inf2 launch.
+    begin_ahead (round 6, with folded_norms): the linear solve's cycle begin rides there as well (its inputs — Σ f² and the
+    Gershgorin partials of the new Jacobian — are left by the residual kernel) — no k_ss_cycle_begin launch.
     fused_tail (round 5): the Newton update u_new = u − x rides in the pass that forms x = V y (k_multiaxpy), and the residual
     kernel leaves the stage-1 partials of its own norms and a second copy of f in column 0 of the Krylov basis — no
     k_newton_update, no k_absmax_sumsq, no k_copy_sumsq launch.
@@ -53,7 +55,10 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
     preloaded_rhs = preloaded_rhs and fused_tail
     if not preloaded_rhs:
         add("k_copy_sumsq", 16.0 * n)                           # b → column 0, ‖b‖² (preloaded: the residual kernel left both)
-    add("k_ss_cycle_begin", 0)
+    folded_norms = folded_norms and fused_tail and not matfree
+    begin_ahead = begin_ahead and folded_norms and preloaded_rhs and newton_basis
+    if not begin_ahead:
+        add("k_ss_cycle_begin", 0)
     b_op = 24.0 * n if matfree else spmv_bytes(n, nnz)
     blocks = sstep_blocks(m, s)
     for bi, (k, w) in enumerate(blocks):
@@ -88,7 +93,7 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
         add("k_newton_update", 24.0 * n)
         add("k_bratu_residual", 16.0 * n)
         add("k_absmax_sumsq", 8.0 * n)
-    if not (folded_norms and fused_tail and not matfree):
+    if not folded_norms:
         add("k_reduce_inf2", 0)
     return L
 
