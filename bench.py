@@ -28,8 +28,10 @@ step (config C5) — both row-partitioned over N ranks as well. A weak-scaling r
 
 Extra objects on the JSON line: `roofline` (the time-dominant kernel family of the step — the CSR SpMV — HIP-event timed on
 the launch stream in a second, instrumented pass of the same K steps; `traffic` from the newest PMC summary under profiles/),
-`roofline_step` (bytes every kernel of the step must move ÷ ms_per_step), `step_time_stats` (median / p10 / p90 of the per-step
-times from one event per step inside the timed region), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
+`roofline_step` (bytes every kernel of the step must move ÷ ms_per_step), `step_time_stats` (the host's per-step loop times of the
+timed region, the time of its closing barrier, and median / p10 / p90 of the per-step device times from one event per step in a
+pass of its own — round 6 took the events, which are marker packets between the steps' kernels, and the interpreter's garbage
+collector out of the timed region), `kernels` (every kernel family of the step), `cpu_baseline` (the oracle's
 tuned C/OpenMP restatements of the same step — delayed CGS2 and the Newton-basis s-step form, median of 5 sustained samples
 each at a thread count chosen by sustained samples; value = the faster — next to the box's STREAM triad, its CSR SpMV rate and
 a single-thread figure), `config.comm_selfcheck` for N > 1 (tools/multi_gpu_selfcheck.py's verdict on the negotiated transport).

@@ -837,7 +837,7 @@ int nk_ss_grid(nk_ctx *ctx, int64_t n, int k, int s);
 int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting);   // sweep A's own grid (read-only: one workgroup per CU)
 struct ss_tail_args;
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk = 0, int hs = 0);
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk = 0, int hs = 0, int flags = 0 /* 1: sweep B stores nothing */);
 int nk_blas_reduce_slots(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 int nk_blas_reduce_slots_allreduce(nk_ctx *ctx, const double *partials, int nblk, int nslots, double *d_out, const int *d_skip);
 

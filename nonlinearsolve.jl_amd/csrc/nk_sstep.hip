@@ -674,6 +674,7 @@ struct ss_job {
   int k0, sb0, k1, sb1;   // [0]: this block (first pass); [1]: the pending block (second pass)
   int mode, m;
   double *red, *coef;
+  double *coefn;              // SSJ_F1, nullable: U once more without the column scales (the coefficients on the NORMALISED stored columns)
   const int *d_skip;
   unsigned int *ticket;
   nk_gmres_ctl *ctl;          // (what both blocks' argument sets share)
@@ -936,7 +937,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
 // HOST: workgroup 0 streams no tiles — it derives the Hessenberg columns, rotations and stopping test of the PREVIOUS block
 // (hk, hs), whose second factorisation was deferred into the launch in front of this sweep (its workspace overlays the tile);
 // the other workgroups share the tiles evenly (⌊tiles/(grid − 1)⌋ or one more).
-template <int S, int KC, bool HOST>
+// NOSTORE (round 6): the cycle's LAST block. Its updated columns are read once more only — by x = [V Q] y — and that product can
+// be taken from the columns as the matrix powers left them: Q₁ = (X − V U) N, so Q₁ b = X (N b) − V (U N b) — one more entry
+// (U, R₁) in the back-substitution's list of blocks (nk_ss_cycle). The sweep then writes nothing: the update lives in the LDS tile
+// for the Gram block and is gone with the tile — 8 n S bytes less per cycle, and a read-only stream.
+template <int S, int KC, bool HOST, bool NOSTORE = false>
 __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restrict__ V, int64_t ldv,
                                                       const double *__restrict__ coef, double *__restrict__ partials,
                                                       const int *d_skip, int ntiles, int *mark, ss_tail_args hta, int hk, int hs) {
@@ -1069,6 +1074,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
     // branch around the stores, behind which the wait-count pass no longer knows how many operations follow a register set's
     // loads and waits for the stores it has just issued at the top of the next tile.
     const unsigned rbyte = (unsigned)r * 8u;
+    if constexpr (!NOSTORE) {
 #pragma unroll
     for (int c = 0; c < S; ++c) {
       const double qv = sX[(k + c) * SS_P + t];
@@ -1076,6 +1082,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
       // (non-temporal hints measured in round 6 — `nt` on these stores −1.6 %, on the loads of the k read-only columns −0.9 %,
       //  both −2.3 % in Newton steps/s: profiles/r06_h_nt_hints_ab.txt — the basis is re-read from the Infinity Cache by the next launch)
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ss_u2, qv), wrs, (int)off, 0, 0);
+    }
+    } else {
+      (void)rbyte; (void)ldvb; (void)wrs;
+      // a row without data (ragged last tile, phantom tile) must not reach the Gram block: the product wrote T-combinations of
+      // zeros = zeros there already (the staged values of such a row are zero)
     }
     // Gram block [V Q]ᵀQ: 64 rows per wavefront, 4 per instruction
 #pragma unroll
@@ -1184,7 +1195,7 @@ int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting) {
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
                        const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out = nullptr, int hk = 0,
-                       int hs = 0, const ss_job *hjp = nullptr) {
+                       int hs = 0, const ss_job *hjp = nullptr, int flags = 0) {
   const int ntiles = (int)((n + SS_R - 1) / SS_R);
   const int cls = ss_class(k, S);
   // "fused": a sweep whose workgroup 0 derives a block's Hessenberg columns while the others stream (its LDS: the scalar
@@ -1246,20 +1257,23 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
       NK_REQUIRE(!hostB || g > 1, "internal: a hosting sweep B needs a second workgroup");
       const size_t ws_b = hostB ? ss_ws_doubles(hk, hs, true) * sizeof(double) : 0;
       const size_t lds = tile_b > ws_b ? tile_b : ws_b;
-#define SS_MM(KCC, HST)                                                                                                   \
+#define SS_MM(KCC, HST, NST)                                                                                              \
   do {                                                                                                                    \
     if (lds > 64 * 1024)                                                                                                  \
-      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_mm<S, KCC, HST>),                             \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_mm<S, KCC, HST, NST>),                        \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
     if (occ_out) {                                                                                                        \
-      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_mm<S, KCC, HST>, SS_R, lds));               \
-    } else if (ev) hipExtLaunchKernelGGL((k_ss_block_mm<S, KCC, HST>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
+      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_mm<S, KCC, HST, NST>, SS_R, lds));          \
+    } else if (ev) hipExtLaunchKernelGGL((k_ss_block_mm<S, KCC, HST, NST>), dim3(g), dim3(SS_R), lds, ctx->stream, e0, e1, 0, n, V, \
                                          ldv, coef, partials, d_skip, ntiles, mark, ta, hk, hs);                          \
-    else hipLaunchKernelGGL((k_ss_block_mm<S, KCC, HST>), dim3(g), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials, \
+    else hipLaunchKernelGGL((k_ss_block_mm<S, KCC, HST, NST>), dim3(g), dim3(SS_R), lds, ctx->stream, n, V, ldv, coef, partials, \
                             d_skip, ntiles, mark, ta, hk, hs);                                                            \
   } while (0)
-      if (hostB) { if (k == 1) SS_MM(1, true); else SS_MM(16, true); }
-      else { if (k == 1) SS_MM(1, false); else SS_MM(16, false); }
+      const bool nostore = (flags & 1) != 0;   // (the cycle's last block: nk_ss_cycle)
+      if (hostB && nostore) { NK_REQUIRE(k == 16, "internal: no hosting sweep B behind one column that stores nothing"); SS_MM(16, true, true); }
+      else if (hostB) { if (k == 1) SS_MM(1, true, false); else SS_MM(16, true, false); }
+      else if (nostore) { if (k == 1) SS_MM(1, false, true); else SS_MM(16, false, true); }
+      else { if (k == 1) SS_MM(1, false, false); else SS_MM(16, false, false); }
 #undef SS_MM
       NK_HIP(hipGetLastError());
       return NK_OK;
@@ -1267,6 +1281,7 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   }
   static const bool kc_on = !(getenv("NK_SS_KCONST") && atoi(getenv("NK_SS_KCONST")) == 0);   // A/B switch
   NK_REQUIRE(!(mode == 1 && tap != nullptr), "internal: sweep B of this shape (k = %d, s = %d) cannot host a Hessenberg workgroup", k, S);
+  NK_REQUIRE((flags & 1) == 0, "internal: sweep B of this shape (k = %d, s = %d) has no form that stores nothing", k, S);
   if (mode == 0) SS_GO(false, true);        // sweep A: Gram only
   else if (mode == 1) SS_GO(true, true);    // sweep B: update, then Gram of the result
   else {                                    // sweep C: update only — no LDS tile
@@ -1288,23 +1303,23 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
 // mode 0/1/2 = sweep A/B/C over V[:, 0..k) and the s columns behind them; tap != nullptr: the fused forms of B and C
 static int ss_sweep_dispatch(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
                              const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out, int hk = 0, int hs = 0,
-                             const ss_job *hjp = nullptr) {
+                             const ss_job *hjp = nullptr, int flags = 0) {
   NK_REQUIRE(s >= 1 && s <= SS_SMAX && k >= 0 && k + s <= 16 * SS_MTMAX, "s-step sweep: s in 1..%d, k + s ≤ %d", SS_SMAX,
              16 * SS_MTMAX);
   NK_REQUIRE(ss_lds_bytes(k, s, true) <= 160 * 1024, "s-step sweep: %d columns do not fit the LDS tile", k + s);
   switch (s) {
-    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
-    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp);
+    case 1: return ss_launch_s<1>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp, flags);
+    case 2: return ss_launch_s<2>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp, flags);
+    case 4: return ss_launch_s<4>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp, flags);
+    case 6: return ss_launch_s<6>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp, flags);
+    case 8: return ss_launch_s<8>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp, flags);
+    case 15: return ss_launch_s<15>(ctx, mode, n, k, V, ldv, coef, partials, d_skip, grid, tap, mark, occ_out, hk, hs, hjp, flags);
     default: NK_FAIL(NK_E_INVALID, "internal: no s-step sweep for a block of %d columns", s);
   }
 }
 int nk_ss_sweep(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V, int64_t ldv, const double *coef, double *partials,
-                const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk, int hs) {
-  return ss_sweep_dispatch(ctx, mode, n, k, s, V, ldv, coef, partials, d_skip, grid, tap, mark, nullptr, hk, hs);
+                const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int hk, int hs, int flags) {
+  return ss_sweep_dispatch(ctx, mode, n, k, s, V, ldv, coef, partials, d_skip, grid, tap, mark, nullptr, hk, hs, nullptr, flags);
 }
 // sweep A of a block whose last `hj.host_wgs` workgroups are the scalar launch that closes the previous block (ss_a_can_host_job)
 static int ss_sweep_a_hosting_job(nk_ctx *ctx, int64_t n, int k, int s, double *V, int64_t ldv, double *partials, const int *d_skip,
@@ -1734,6 +1749,11 @@ __device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args 
     if (alive) {
       for (int e = t; e < j.k0 * j.sb0; e += SS_R) j.coef[e] = w0.U[e];
       if (t < j.sb0 * j.sb0) j.coef[(size_t)j.k0 * j.sb0 + t] = w0.Ri[t];
+      if (j.coefn != nullptr)   // (a sweep B that stores nothing: the back-substitution takes the update off the coefficients instead)
+        for (int e = t; e < j.k0 * j.sb0; e += SS_R) {
+          const double scr = s_sc[e / j.sb0];
+          j.coefn[e] = scr != 0.0 ? w0.U[e] / scr : 0.0;
+        }
       ss_keep_pass1(j.k0, j.sb0, w0, ta0, red0);
       if (t == 0) ta0.scal[0] = 1.0 / ta0.scal[2];   // (this block's powers have run; the next block's start from a unit column)
     }
@@ -1900,6 +1920,7 @@ extern "C" int nk_ss_leja_nodes(int s, double *out) {
 // ============================================================================= one restart cycle, s columns at a time
 struct nk_sstep {
   int s = 0, grid = 0;
+  double *coefn = nullptr;   // the last block's update coefficients on the normalised stored columns (a sweep B that stores nothing)
   double *part = nullptr, *part2 = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
   double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup), one slot per block
   double *Wi = nullptr, *D = nullptr;        // R₂⁻¹ and C₂R₂⁻¹ of the blocks left at their first pass (same slots)
@@ -1915,7 +1936,7 @@ struct nk_sstep {
 };
 void nk_ss_destroy(nk_sstep *W) {
   if (!W) return;
-  hipFree(W->part); hipFree(W->part2); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
+  hipFree(W->part); hipFree(W->part2); hipFree(W->red); hipFree(W->coef); hipFree(W->coefn); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
   hipFree(W->ival); hipFree(W->nodes); hipFree(W->C2); hipFree(W->R2); hipFree(W->ticket); hipFree(W->Wi); hipFree(W->D);
   delete W;
 }
@@ -1930,6 +1951,7 @@ static int ss_workspace(nk_gmres *G) {
   NK_TRY(nk_dev_alloc(&W->part2, nslots * W->grid + 1));   // sweep B's partial blocks while their reduction is deferred
   NK_TRY(nk_dev_alloc(&W->red, 2 * nslots + 1));   // (a launch may reduce two partial blocks)
   NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
+  NK_TRY(nk_dev_alloc(&W->coefn, nslots + 64));
   // the factors of both passes, one slot per block of a cycle: blocks left at their first pass need pass 2's until the
   // back-substitution, and a block's Hessenberg columns (which need pass 1's) may be derived while the next block is under way
   W->c2_stride = nslots + 1;
@@ -2205,12 +2227,30 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   std::memset(&dp, 0, sizeof(dp));
   // closes the pending block in a launch of its own: second factorisation, Wi / D, Hessenberg columns — and, at the cycle's end,
   // the back-substitution
+  // the cycle's last block with a sweep B that stores nothing (k_ss_block_mm<…, NOSTORE>): its stored columns stay as the matrix
+  // powers left them, X, and Q₁ = (X − V_stored U) R₁⁻¹ enters x = [V Q] y through ONE MORE entry of the back-substitution's
+  // list — (U on the normalised stored columns, R₁) for the same columns, applied behind all the others (index 0: the list is
+  // walked last entry first), when every coefficient is on stored columns
+  struct { bool on; int k0, sb; const double *U, *R1; } raw;
+  std::memset(&raw, 0, sizeof(raw));
   auto close_pending = [&](bool with_back) -> int {
     ss_job j = jb;
     j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
     j.mode = SSJ_F2 | SSJ_PREP | SSJ_HESS | (with_back ? SSJ_BACK : 0);
     j.cfix = dp.ta.fix;
-    if (with_back) j.bfx = G->ss_fix;
+    NK_REQUIRE(!raw.on || with_back, "internal: a block whose sweep B stored nothing needs the back-substitution of its cycle's last launch");
+    if (with_back) {
+      j.bfx = G->ss_fix;
+      if (raw.on) {
+        nk_ss_fix &b = j.bfx;
+        NK_REQUIRE(b.n < NK_SS_NFIX, "internal: no room for the stored-nothing block in the back-substitution's list");
+        for (int q = b.n; q > 0; --q) {
+          b.k0[q] = b.k0[q - 1]; b.sb[q] = b.sb[q - 1]; b.C2[q] = b.C2[q - 1]; b.R2[q] = b.R2[q - 1]; b.Wi[q] = b.Wi[q - 1]; b.D[q] = b.D[q - 1];
+        }
+        b.k0[0] = raw.k0; b.sb[0] = raw.sb; b.C2[0] = raw.U; b.R2[0] = raw.R1; b.Wi[0] = nullptr; b.D[0] = nullptr;
+        b.n++;
+      }
+    }
     NK_TRY(ss_launch_job(ctx, j, dp.ta, dp.ta));
     dp.on = false;
     if (with_back && backsolved) *backsolved = true;
@@ -2298,11 +2338,17 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       // the cycle early (fixed work) and that sweep has the hosting form; else in the job itself (the verdict arrives before sweep B)
       const bool host_b = !host_a && dp.on && grid > 1 && ss_b_can_host(ldv, k, sb) &&
                           (hess_where < 0 ? fixed_work : hess_where == 1);
+      // the last block's sweep B stores nothing where the matrix-core form runs it, the cycle's last scalar launch
+      // back-substitutes, the list has room and nothing else wants the columns (development audit)
+      static const bool nostore_off = getenv("NK_SS_NOSTORE") && atoi(getenv("NK_SS_NOSTORE")) == 0;   // A/B switch
+      const bool raw_last = last_block && !nostore_off && !(host_b && k != 16) && ss_b_can_host(ldv, k, sb) && !tail_back_off &&
+                            backsolved != nullptr && G->ss_fix.n + 2 <= NK_SS_NFIX && !ctx->audit.on;
       {
         ss_job j = jb;
         j.part0 = W->part; j.nblk0 = grid_a; j.nslots0 = nslots; j.k0 = k; j.sb0 = sb;
         j.mode = SSJ_F1;
         j.cfix = ta.fix;
+        j.coefn = raw_last ? W->coefn : nullptr;
         if (dp.on && !host_a) {
           j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
           j.mode |= SSJ_F2 | SSJ_PREP | (host_b ? 0 : SSJ_HESS);
@@ -2310,12 +2356,13 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         NK_TRY(ss_launch_job(ctx, j, ta, (dp.on && !host_a) ? dp.ta : ta));
       }
       {
-        nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + 2 * sb));
+        nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + (raw_last ? 1 : 2) * sb));
         ss_tail_args hta = dp.ta;
         hta.Wi = nullptr; hta.D = nullptr;   // (prepared by the job already)
         NK_TRY(nk_ss_sweep(ctx, 1, n, k, sb, G->V, ldv, W->coef, W->part2, done, grid, host_b ? &hta : nullptr, nullptr,
-                           host_b ? dp.k : 0, host_b ? dp.sb : 0));
+                           host_b ? dp.k : 0, host_b ? dp.sb : 0, raw_last ? 1 : 0));
       }
+      if (raw_last) { raw.on = true; raw.k0 = k; raw.sb = sb; raw.U = W->coefn; raw.R1 = ta.R1; }
       dp.on = true; dp.k = k; dp.sb = sb; dp.grid = grid; dp.ta = ta;
       {
         nk_ss_fix &fx = G->ss_fix;

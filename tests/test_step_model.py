@@ -65,13 +65,16 @@ def test_byte_counts_of_the_headline_step():
     assert alg_r == alg_s                        # the algorithmic figure does not depend on how the operator is executed
     per_block = 12 * NNZ + 4 * (N + 1) + 8 * N + 8 * N * 15
     assert hbm_r == hbm_s - 30 * spmv + 2 * per_block
-    hbm_i, alg_i = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, fused_tail=False)     # no sweep C for the first block either
+    hbm_i, alg_i = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, fused_tail=False, last_block_unstored=False)     # no sweep C for the first block either
     assert hbm_i == hbm_r - 8 * N * 31 and alg_i == alg_r - 8 * N * 31
     assert (hbm_i, alg_i) == step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, deferred=False, fused_tail=False)   # same bytes
     # round 5's tail: x is not read back for the update (−8 n), f is not read back for its norms (−8 n) nor for the copy into
     # the basis (−16 n for that pass, + 8 n for the second store of f)
-    hbm_f, alg_f = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True)
+    hbm_f, alg_f = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True, last_block_unstored=False)
     assert hbm_f == hbm_i - 24 * N and alg_f == alg_i - 24 * N
+    # round 6: sweep B of the cycle's last block stores nothing (−8 n · 15)
+    hbm_u, alg_u = step_model.step_bytes(N, NNZ, resident_powers=True, implicit=True)
+    assert hbm_u == hbm_f - 8 * N * 15 and alg_u == alg_f - 8 * N * 15
 
 
 def test_canonical_names():

@@ -30,10 +30,13 @@ def spmv_bytes(n, nnz):
 
 
 def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True, newton_basis=True, implicit=True, deferred=True,
-                  fused_tail=True, preloaded_rhs=True, folded_norms=True, begin_ahead=True):
+                  fused_tail=True, preloaded_rhs=True, folded_norms=True, begin_ahead=True, last_block_unstored=True):
     """[(kernel name prefix, hbm bytes, algorithmic bytes)] in launch order.
     folded_norms (round 6): the stage-2 reduction of the step's norms and their delivery to the host ride in workgroup 0 of the
     NEXT Jacobian's fill kernel (k_bratu_jac, enqueued directly behind the residual kernel) — no k_reduce_inf2 launch.
+    last_block_unstored (round 6, with deferred): sweep B of the cycle's LAST block stores nothing (its columns are read once more
+    only, by x = V y, and enter that product as the matrix powers left them — one more entry in the back-substitution's list):
+    8 n w bytes less, for the launch and for the algorithm.
     begin_ahead (round 6, with folded_norms): the linear solve's cycle begin rides there as well (its inputs — Σ f² and the
     Gershgorin partials of the new Jacobian — are left by the residual kernel) — no k_ss_cycle_begin launch.
     fused_tail (round 5): the Newton update u_new = u − x rides in the pass that forms x = V y (k_multiaxpy), and the residual
@@ -70,7 +73,8 @@ def step_launches(n, nnz, arnoldi=30, s=15, matfree=False, resident_powers=True,
                 add("k_bratu_jvp" if matfree else "k_spmv_stream", b_op)
         add("k_ss_block<A>", 8.0 * n * (k + w))                 # Gram of [V X]ᵀX: k + w columns read
         add("k_ss_job" if deferred else "k_ss_reduce_factor", 0)
-        add("k_ss_block<B>", 8.0 * n * (k + 2 * w))             # update (k + w read, w written) + Gram of the result
+        unstored = last_block_unstored and deferred and newton_basis and bi + 1 == len(blocks) and w == 15 and k in (1, 16)
+        add("k_ss_block<B>", 8.0 * n * (k + (1 if unstored else 2) * w))   # update (k + w read, w written — or not) + Gram of the result
         if deferred:
             continue                                            # (its reduction rides in the next scalar launch)
         add("k_ss_reduce_factor", 0)
