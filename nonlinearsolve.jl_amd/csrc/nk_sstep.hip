@@ -1058,16 +1058,37 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
     prefetch(vr, w, next);
     __builtin_amdgcn_sched_barrier(0);
     // the update: 16 rows per instruction group, the result back into the X columns of the same rows
+    // REGGRAM (k = 16, round 6): the Gram block takes the updated rows straight from the update's accumulator. The product leaves
+    // lane (q4, li) with Q[row0 + q4 + 4 r][li], r = 0 … 3 — which is exactly the B operand of a Gram instruction whose four rows
+    // are {q4 + 4 r}, and (the A and B lane maps of 16x16x4 coincide) the A operand of the QᵀQ tile for the same rows; the sum
+    // over rows does not care how the rows are grouped four at a time. Only the V tile's A operand comes from the LDS tile. No
+    // write-back of Q for the Gram phase (its transposed ds_writes were the sweep's only bank conflicts: 12 % of its LDS cycles,
+    // profiles/r06_p_sweeps_sq_counters.md), no re-read of Q: 48 LDS instructions per wavefront and tile less, and the 64 matrix
+    // instructions of a tile in one run.
+    constexpr bool REGGRAM = (KC == 16);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       ss_d4 q = ss_d4{0.0, 0.0, 0.0, 0.0};
-      double a[NKS];
+      double a[NKS], va[4];
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) a[ks] = pu[ks][g * 16];
+      if constexpr (REGGRAM) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) va[rr] = pa[0][g * 16 + 4 * rr];   // V[row0 + q4 + 4 rr][li]
+      }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) q = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], tb[ks], q, 0, 0, 0);
+      if constexpr (!REGGRAM || !NOSTORE) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) pq[g * 16 + 4 * rr] = q[rr];
+        for (int rr = 0; rr < 4; ++rr) pq[g * 16 + 4 * rr] = q[rr];
+      }
+      if constexpr (REGGRAM) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[rr], q[rr], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[rr], q[rr], acc[1], 0, 0, 0);
+        }
+      }
     }
     // the updated columns leave through the row-per-thread layout (coalesced). Buffer stores: a lane without a row (ragged last
     // tile, the phantom tile of an odd count) carries an out-of-range offset and the hardware drops it — `if (ok) store` is a
@@ -1089,6 +1110,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
       // zeros = zeros there already (the staged values of such a row are zero)
     }
     // Gram block [V Q]ᵀQ: 64 rows per wavefront, 4 per instruction
+    if constexpr (!REGGRAM) {
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4) {
       double bb[4], aa[NT][4];
@@ -1103,6 +1125,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[mt][u], bb[u], acc[mt], 0, 0, 0);
       }
+    }
     }
   };
   auto pair = [&](int tile) __attribute__((always_inline)) {
