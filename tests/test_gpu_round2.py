@@ -460,3 +460,44 @@ def test_speculative_jacobian_fill_is_invisible(nls, dev):
     assert s1.retcode == "Success" == R.RETCODE_NAMES[ref.retcode] and s1.stats.nsteps == ref.stats.nsteps
     assert s1.stats.njacs == ref.stats.njacs and np.max(np.abs(np.asarray(s1.u) - ref.u)) <= 1e-9
     cache.close()
+
+
+_AHEAD_CODE = (
+    "import numpy as np, hashlib, nonlinearsolve_jl_amd as nls\n"
+    "ns = 48\n"
+    "alg = nls.NewtonRaphson(linsolve=nls.KrylovJL_GMRES(gmres_restart=30, maxiters=30, ortho='sstep', fixed_iters=30), concrete_jac=True)\n"
+    "cache = nls.init(nls.NonlinearProblem(nls.Bratu2D(ns, 6.0)), alg, abstol=1e-9, maxiters=50)\n"
+    "out = []\n"
+    "def h():\n"
+    "    u = cache.u\n"
+    "    out.append(hashlib.sha256(np.asarray(u.cpu() if hasattr(u, 'cpu') else u).tobytes()).hexdigest()[:16])\n"
+    "for _ in range(2): cache.step(); h()\n"
+    "cache.prob.device_problem.set_params([ns, 3.0, 0.0])      # the begin that ran ahead was for lambda = 6: must not be taken\n"
+    "cache.step(); h()\n"
+    "G = nls.GMRES(ns * ns, restart=30)                          # (an unrelated object: nothing to do with the cache's)\n"
+    "s = nls.solve_(cache); h()                                  # terminates with a begin ahead in the queue: dropped\n"
+    "out.append(s.retcode + str(s.stats.nsteps))\n"
+    "cache.prob.device_problem.set_params([ns, 6.0, 0.0])\n"
+    "nls.reinit_(cache, np.zeros(ns * ns))\n"
+    "s = nls.solve_(cache); h()\n"
+    "out.append(s.retcode + str(s.stats.nsteps) + ' ' + str(s.stats.gmres_iters))\n"
+    "print('TRACE', ' '.join(out))\n")
+
+
+def test_cycle_begin_run_ahead_is_invisible():
+    """The next linear solve's cycle begin rides in the speculative Jacobian fill (csrc/nk_solver.hip: speculate_J →
+    nk_gmres_begin_ahead). Whatever happens between the fill and the solve — nothing, a parameter change (the fill and the begin
+    were for the old parameters), a termination with the begin still in the queue, a reinit! — the iterates are those of the
+    form that launches the begin with the solve (NK_BEGIN_AHEAD=0): the same arithmetic, the same bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tr = {}
+    for name, env in (("ahead", {}), ("launched", dict(NK_BEGIN_AHEAD="0")), ("round5", dict(NK_BEGIN_AHEAD="0", NK_FOLD_NORMS="0"))):
+        r = subprocess.run([sys.executable, "-c", _AHEAD_CODE], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                           cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        tr[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("TRACE")][-1]
+    assert tr["ahead"] == tr["launched"] == tr["round5"], tr
+    assert "Success" in tr["ahead"]
