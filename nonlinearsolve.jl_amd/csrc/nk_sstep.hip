@@ -428,7 +428,7 @@ __device__ __forceinline__ double ss_readlane(double v, int lane) {
 // control block — for the same workgroup's back-substitution, which must not read them back through the cache.
 __device__ void ss_hessenberg(int k, int sb, const ss_ws &w, const ss_tail_args &ta, bool loaded = false, double *sR = nullptr,
                               int LK = 0, bool raise_pad1 = false, double *verdict = nullptr) {
-  const int t = threadIdx.x, nt = SS_R;
+  const int t = threadIdx.x;
   const int K = k + sb, ko = k - 1, m = ta.m;                // ko old Hessenberg columns / rotations
   double *F = w.F, *NC = w.NC, *Hs = w.Hs, *scs = w.scs, *ssn = w.ssn, *sg = w.sg;
   if (!loaded) ss_hess_load(k, sb, w, ta);
