@@ -674,7 +674,7 @@ struct ss_job {
   int k0, sb0, k1, sb1;   // [0]: this block (first pass); [1]: the pending block (second pass)
   int mode, m;
   double *red, *coef;
-  double *coefn;              // SSJ_F1, nullable: U once more without the column scales (the coefficients on the NORMALISED stored columns)
+  int raw_last;               // SSJ_BACK: the pending block's sweep B stored nothing — its columns are the matrix powers' X (below)
   const int *d_skip;
   unsigned int *ticket;
   nk_gmres_ctl *ctl;          // (what both blocks' argument sets share)
@@ -1772,11 +1772,6 @@ __device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args 
     if (alive) {
       for (int e = t; e < j.k0 * j.sb0; e += SS_R) j.coef[e] = w0.U[e];
       if (t < j.sb0 * j.sb0) j.coef[(size_t)j.k0 * j.sb0 + t] = w0.Ri[t];
-      if (j.coefn != nullptr)   // (a sweep B that stores nothing: the back-substitution takes the update off the coefficients instead)
-        for (int e = t; e < j.k0 * j.sb0; e += SS_R) {
-          const double scr = s_sc[e / j.sb0];
-          j.coefn[e] = scr != 0.0 ? w0.U[e] / scr : 0.0;
-        }
       ss_keep_pass1(j.k0, j.sb0, w0, ta0, red0);
       if (t == 0) ta0.scal[0] = 1.0 / ta0.scal[2];   // (this block's powers have run; the next block's start from a unit column)
     }
@@ -1792,10 +1787,19 @@ __device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args 
       }
       ss_publish_outcome(j.pub, j.seq, j.peer_err, (int)vd[0], (int)vd[1], (int)vd[2], vd[4], vd[3]);
     }
-    if (alive && f2 && t == 0) {   // the pending block's (C₂, R₂): in LDS already
+    if (alive && f2 && t == 0) {   // the pending block's factors: in LDS already
       const int q = j.bfx.n - 1;
-      s_bc.oD[q] = w1.o0;
-      s_bc.oWi[q] = w1.o0 + ss_ws_off(j.k1, j.sb1).Rm;
+      if (j.raw_last && hs) {
+        // its sweep B stored nothing: the block's columns in memory are the matrix powers' X = V_true C + Q R, with C = C₁ + C₂R₁ and
+        // R = R₂R₁ — the coordinates the Hessenberg recovery has just formed (F: C in rows 0 … k − 1, R in rows k …). The same
+        // operation as for a block left at its first pass, Q y = X (R⁻¹ y) − V_true (C R⁻¹ y), with (C, R) in place of (C₂, R₂)
+        const int oF = w1.o0 + ss_ws_off(j.k1, j.sb1).F;
+        s_bc.oD[q] = oF;
+        s_bc.oWi[q] = oF + j.k1 * j.sb1;
+      } else {   // (C₂, R₂): the stored columns are the first pass's Q₁
+        s_bc.oD[q] = w1.o0;
+        s_bc.oWi[q] = w1.o0 + ss_ws_off(j.k1, j.sb1).Rm;
+      }
     }
     __syncthreads();
     SS_STAMP(14);
@@ -1943,7 +1947,6 @@ extern "C" int nk_ss_leja_nodes(int s, double *out) {
 // ============================================================================= one restart cycle, s columns at a time
 struct nk_sstep {
   int s = 0, grid = 0;
-  double *coefn = nullptr;   // the last block's update coefficients on the normalised stored columns (a sweep B that stores nothing)
   double *part = nullptr, *part2 = nullptr, *red = nullptr, *coef = nullptr, *C1 = nullptr, *R1 = nullptr, *H = nullptr, *scal = nullptr;
   double *C2 = nullptr, *R2 = nullptr;       // pass 2's factors (for sweep C's Hessenberg workgroup), one slot per block
   double *Wi = nullptr, *D = nullptr;        // R₂⁻¹ and C₂R₂⁻¹ of the blocks left at their first pass (same slots)
@@ -1959,7 +1962,7 @@ struct nk_sstep {
 };
 void nk_ss_destroy(nk_sstep *W) {
   if (!W) return;
-  hipFree(W->part); hipFree(W->part2); hipFree(W->red); hipFree(W->coef); hipFree(W->coefn); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
+  hipFree(W->part); hipFree(W->part2); hipFree(W->red); hipFree(W->coef); hipFree(W->C1); hipFree(W->R1); hipFree(W->H); hipFree(W->scal);
   hipFree(W->ival); hipFree(W->nodes); hipFree(W->C2); hipFree(W->R2); hipFree(W->ticket); hipFree(W->Wi); hipFree(W->D);
   delete W;
 }
@@ -1974,7 +1977,6 @@ static int ss_workspace(nk_gmres *G) {
   NK_TRY(nk_dev_alloc(&W->part2, nslots * W->grid + 1));   // sweep B's partial blocks while their reduction is deferred
   NK_TRY(nk_dev_alloc(&W->red, 2 * nslots + 1));   // (a launch may reduce two partial blocks)
   NK_TRY(nk_dev_alloc(&W->coef, nslots + 64));
-  NK_TRY(nk_dev_alloc(&W->coefn, nslots + 64));
   // the factors of both passes, one slot per block of a cycle: blocks left at their first pass need pass 2's until the
   // back-substitution, and a block's Hessenberg columns (which need pass 1's) may be derived while the next block is under way
   W->c2_stride = nslots + 1;
@@ -2250,29 +2252,19 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
   std::memset(&dp, 0, sizeof(dp));
   // closes the pending block in a launch of its own: second factorisation, Wi / D, Hessenberg columns — and, at the cycle's end,
   // the back-substitution
-  // the cycle's last block with a sweep B that stores nothing (k_ss_block_mm<…, NOSTORE>): its stored columns stay as the matrix
-  // powers left them, X, and Q₁ = (X − V_stored U) R₁⁻¹ enters x = [V Q] y through ONE MORE entry of the back-substitution's
-  // list — (U on the normalised stored columns, R₁) for the same columns, applied behind all the others (index 0: the list is
-  // walked last entry first), when every coefficient is on stored columns
-  struct { bool on; int k0, sb; const double *U, *R1; } raw;
-  std::memset(&raw, 0, sizeof(raw));
+  // the cycle's last block with a sweep B that stores nothing (k_ss_block_mm<…, NOSTORE>): its columns in memory stay as the matrix
+  // powers left them, X; the back-substitution of the cycle's last launch takes the block's COMBINED factors (C, R) — which the
+  // Hessenberg recovery forms anyway — where it takes (C₂, R₂) for a block whose first-pass columns were stored (ss_job.raw_last)
+  bool raw_on = false;
   auto close_pending = [&](bool with_back) -> int {
     ss_job j = jb;
     j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
     j.mode = SSJ_F2 | SSJ_PREP | SSJ_HESS | (with_back ? SSJ_BACK : 0);
     j.cfix = dp.ta.fix;
-    NK_REQUIRE(!raw.on || with_back, "internal: a block whose sweep B stored nothing needs the back-substitution of its cycle's last launch");
+    NK_REQUIRE(!raw_on || with_back, "internal: a block whose sweep B stored nothing needs the back-substitution of its cycle's last launch");
     if (with_back) {
       j.bfx = G->ss_fix;
-      if (raw.on) {
-        nk_ss_fix &b = j.bfx;
-        NK_REQUIRE(b.n < NK_SS_NFIX, "internal: no room for the stored-nothing block in the back-substitution's list");
-        for (int q = b.n; q > 0; --q) {
-          b.k0[q] = b.k0[q - 1]; b.sb[q] = b.sb[q - 1]; b.C2[q] = b.C2[q - 1]; b.R2[q] = b.R2[q - 1]; b.Wi[q] = b.Wi[q - 1]; b.D[q] = b.D[q - 1];
-        }
-        b.k0[0] = raw.k0; b.sb[0] = raw.sb; b.C2[0] = raw.U; b.R2[0] = raw.R1; b.Wi[0] = nullptr; b.D[0] = nullptr;
-        b.n++;
-      }
+      j.raw_last = raw_on ? 1 : 0;
     }
     NK_TRY(ss_launch_job(ctx, j, dp.ta, dp.ta));
     dp.on = false;
@@ -2365,13 +2357,12 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
       // back-substitutes, the list has room and nothing else wants the columns (development audit)
       static const bool nostore_off = getenv("NK_SS_NOSTORE") && atoi(getenv("NK_SS_NOSTORE")) == 0;   // A/B switch
       const bool raw_last = last_block && !nostore_off && !(host_b && k != 16) && ss_b_can_host(ldv, k, sb) && !tail_back_off &&
-                            backsolved != nullptr && G->ss_fix.n + 2 <= NK_SS_NFIX && !ctx->audit.on;
+                            backsolved != nullptr && !ctx->audit.on;
       {
         ss_job j = jb;
         j.part0 = W->part; j.nblk0 = grid_a; j.nslots0 = nslots; j.k0 = k; j.sb0 = sb;
         j.mode = SSJ_F1;
         j.cfix = ta.fix;
-        j.coefn = raw_last ? W->coefn : nullptr;
         if (dp.on && !host_a) {
           j.part1 = W->part2; j.nblk1 = dp.grid; j.nslots1 = (dp.k + dp.sb) * dp.sb; j.k1 = dp.k; j.sb1 = dp.sb;
           j.mode |= SSJ_F2 | SSJ_PREP | (host_b ? 0 : SSJ_HESS);
@@ -2385,7 +2376,7 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         NK_TRY(nk_ss_sweep(ctx, 1, n, k, sb, G->V, ldv, W->coef, W->part2, done, grid, host_b ? &hta : nullptr, nullptr,
                            host_b ? dp.k : 0, host_b ? dp.sb : 0, raw_last ? 1 : 0));
       }
-      if (raw_last) { raw.on = true; raw.k0 = k; raw.sb = sb; raw.U = W->coefn; raw.R1 = ta.R1; }
+      if (raw_last) raw_on = true;
       dp.on = true; dp.k = k; dp.sb = sb; dp.grid = grid; dp.ta = ta;
       {
         nk_ss_fix &fx = G->ss_fix;
