@@ -923,6 +923,49 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
   }
 }
 
+// T = [−U N ; N], N = R⁻¹ (upper triangular; `coef` = U (k × S) then R with a reciprocal diagonal), formed in LDS scratch at sX by
+// the whole workgroup; returns each lane's share as matrix-core B operands: tb[ks] = T[4 ks + q4][li] (rows ≥ k + S and column
+// S … 15 zero). Ends with a barrier (the scratch overlays the tile).
+template <int S, int KC>
+__device__ __forceinline__ void ss_mm_form_t(const double *__restrict__ coef, double *sX, double (&tb)[(KC + S + 3) / 4]) {
+  constexpr int k = KC, K = KC + S, NKS = (K + 3) / 4;
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, q4 = lane >> 4;
+  double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + 256;
+  for (int e = t; e < k * S + S * S; e += SS_R) sX[e] = coef[e];
+  __syncthreads();
+  if (t < S) {   // row t of N: n R = e_t by forward substitution (R's diagonal arrives as reciprocals)
+    double nr[S];
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      double a = (c == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int c2 = 0; c2 < c; ++c2) a = __builtin_fma(-nr[c2], sR[c2 * S + c], a);
+      nr[c] = (c < t) ? 0.0 : a * sR[c * S + c];
+    }
+#pragma unroll
+    for (int c = 0; c < S; ++c) sN[t * 16 + c] = nr[c];
+  }
+  __syncthreads();
+  for (int e = t; e < 4 * NKS * 16; e += SS_R) {
+    const int j = e >> 4, c = e & 15;
+    double v = 0.0;
+    if (c < S) {
+      if (j < k) {
+        double a = 0.0;
+        for (int c2 = 0; c2 <= c; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
+        v = -a;
+      } else if (j < K) {
+        v = sN[(j - k) * 16 + c];
+      }
+    }
+    sT[e] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) tb[ks] = sT[(4 * ks + q4) * 16 + li];
+  __syncthreads();
+}
+
 // Sweep B of the default cycle's shapes with the UPDATE on the matrix cores as well (round 4). X ← (X − V U) R⁻¹ is one
 // product of the tile [V X] (256 rows × (k + S) columns, already staged in LDS for the Gram block) with the (k + S) × S matrix
 //     T = [ −U N ; N ],  N = R⁻¹ (upper triangular, formed once per workgroup from the reduction's U and R),
@@ -941,6 +984,12 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
 // be taken from the columns as the matrix powers left them: Q₁ = (X − V U) N, so Q₁ b = X (N b) − V (U N b) — one more entry
 // (U, R₁) in the back-substitution's list of blocks (nk_ss_cycle). The sweep then writes nothing: the update lives in the LDS tile
 // for the Gram block and is gone with the tile — 8 n S bytes less per cycle, and a read-only stream.
+// development (tools/gpu_sweep_decomposition.sh): NK_SS_EXP = 1 — the loop without its matrix instructions (loads and staging only);
+// 2 — without its loads (the first two tiles' registers staged again and again); 3 — without loads and staging; 4 — also without
+// the operands' LDS reads (the matrix instructions and their accumulator copies alone). Timing builds: the results are meaningless.
+#ifndef NK_SS_EXP
+#define NK_SS_EXP 0
+#endif
 template <int S, int KC, bool HOST, bool NOSTORE = false>
 __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restrict__ V, int64_t ldv,
                                                       const double *__restrict__ coef, double *__restrict__ partials,
@@ -1048,15 +1097,22 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   auto process = [&](double (&vr)[KC], double (&w)[S], int tile, bool valid, int next) __attribute__((always_inline)) {
     const int64_t r = (int64_t)tile * SS_R + t;
     const bool ok = valid && r < n;
+#if NK_SS_EXP < 3
 #pragma unroll
     for (int j = 0; j < KC; ++j) sX[j * SS_P + t] = ok ? vr[j] : 0.0;
 #pragma unroll
     for (int c = 0; c < S; ++c) sX[(k + c) * SS_P + t] = ok ? w[c] : 0.0;
+#endif
     // the set is staged: request it again for the tile after next (past the end: the last tile once more, a cache hit) — every
     // load then has two tiles' time to land. (sched_barrier: the machine scheduler otherwise sinks the loads to their uses.)
     __builtin_amdgcn_sched_barrier(0);
+#if NK_SS_EXP < 2
     prefetch(vr, w, next);
+#endif
     __builtin_amdgcn_sched_barrier(0);
+#if NK_SS_EXP == 1
+    return;
+#endif
     // the update: 16 rows per instruction group, the result back into the X columns of the same rows
     // REGGRAM (k = 16, round 6): the Gram block takes the updated rows straight from the update's accumulator. The product leaves
     // lane (q4, li) with Q[row0 + q4 + 4 r][li], r = 0 … 3 — which is exactly the B operand of a Gram instruction whose four rows
@@ -1071,11 +1127,19 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
       ss_d4 q = ss_d4{0.0, 0.0, 0.0, 0.0};
       double a[NKS], va[4];
 #pragma unroll
+#if NK_SS_EXP == 4
+      for (int ks = 0; ks < NKS; ++ks) a[ks] = vr[ks % KC];
+      if constexpr (REGGRAM) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) va[rr] = w[rr];
+      }
+#else
       for (int ks = 0; ks < NKS; ++ks) a[ks] = pu[ks][g * 16];
       if constexpr (REGGRAM) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) va[rr] = pa[0][g * 16 + 4 * rr];   // V[row0 + q4 + 4 rr][li]
       }
+#endif
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) q = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], tb[ks], q, 0, 0, 0);
       if constexpr (!REGGRAM || !NOSTORE) {
@@ -1135,6 +1199,159 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   // (first pair peeled: at the loop header the outstanding-load state of the entry edge then equals the back edge's, and the
   //  waits inside the loop are the steady state's vmcnt(46 … 61) instead of the prologue's vmcnt(31 …))
   if (tile0 < tile1) {
+    pair(tile0);
+    for (int tile = tile0 + 2; tile < tile1; tile += 2) pair(tile);
+  }
+  __syncthreads();   // (the scratch overlays rows the other wavefronts may still be reading)
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) sX[((wv * NT + mt) * 4 + rr) * 64 + lane] = acc[mt][rr];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    const int rr = t >> 6, ln = t & 63;
+    const int mrow = mt * 16 + (ln >> 4) + 4 * rr, ncol = ln & 15;
+    if (mrow < K && ncol < S) {
+      const int e = (mt * 4 + rr) * 64 + ln;
+      const double sum = (sX[e] + sX[NT * 256 + e]) + (sX[2 * NT * 256 + e] + sX[3 * NT * 256 + e]);
+      partials[(size_t)(mrow * S + ncol) * gridDim.x + blockIdx.x] = sum;
+    }
+  }
+}
+
+
+// Sweep B of the cycle's LAST block behind 16 columns — the read-only form (round 6). k_ss_block_mm<15, 16, ·, true> stores nothing
+// but still stages all 31 columns through the LDS tile (31 ds_write_b64 + 62 v_cndmask per wavefront and tile) and reads the
+// update's operands back from it (32 of its 48 ds_read_b64): taken apart on the device (profiles/r06_s_sweep_decomposition.txt),
+// its loop costs 29.7 µs for the matrix instructions alone, 38.5 with the operands' LDS reads, 53.6 with the staging — more than
+// the 42.5 µs its loads take: the sweep was bound by LDS traffic and instruction issue, not by HBM. Here
+//  * every lane loads its operands of the UPDATE product straight from global memory in the matrix instruction's own layout: lane
+//    (li, q4) takes rows 2 li, 2 li + 1 of a 32-row block of column 4 ks + q4 — one 16-byte buffer load (a wavefront's load covers
+//    4 columns × 256 contiguous bytes; 16 loads per register set instead of 31). The even rows of a block are one 16-row group of the
+//    product, the odd rows another: the update is row-wise and the Gram block a sum over rows, so the order of rows inside a tile
+//    is free as long as both Gram operands use the same one;
+//  * only the 16 basis columns go to LDS (8 ds_write_b128 per wavefront and tile), for the Gram block's Vᵀ Q operand, which wants
+//    them row-major: one ds_read_b128 delivers a row pair = the operand of the even AND the odd group (8 per tile instead of 48
+//    ds_read_b64). Pitch 258 doubles: 16-byte aligned columns, an odd number of 16-byte units (conflict-free both ways);
+//  * the updated rows go from the product's accumulator into the Gram instructions (as in k_ss_block_mm since REGGRAM);
+//  * raw buffer loads: a column's offset rides in the scalar offset, the lane's in one VGPR for the whole kernel (no 64-bit
+//    address arithmetic in the loop), a prefetch past the workgroup's last tile goes through a descriptor of zero records (returns
+//    zeros, moves nothing), rows past n are masked in the ragged tile only (a wave-uniform branch around selects).
+// Needs (k + S)·ldv·8 < 2³², ldv even and a 16-byte aligned basis; otherwise the launcher takes k_ss_block_mm.
+constexpr int SS_P2 = SS_R + 2;
+typedef double ss_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ss_u4 __attribute__((ext_vector_type(4)));
+template <int S, int KC, bool HOST>
+__global__ __launch_bounds__(SS_R) void k_ss_block_ro(int64_t n, const double *__restrict__ V, int64_t ldv,
+                                                      const double *__restrict__ coef, double *__restrict__ partials,
+                                                      const int *d_skip, int ntiles, int *mark, ss_tail_args hta, int hk, int hs) {
+  static_assert(S == 15 && KC == 16, "the default cycle's second block");
+  {
+    const int dskip = (d_skip != nullptr) ? *d_skip : 0;
+    if (mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *mark = dskip;
+    if (dskip) return;
+  }
+  extern __shared__ ss_d2 sX2[];   // (16-byte aligned)
+  double *sX = reinterpret_cast<double *>(sX2);
+  constexpr int K = KC + S, NT = 2, NKS = 8;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, q4 = lane >> 4;
+  if (HOST && blockIdx.x == 0) {
+    for (int e = t; e < K * S; e += SS_R) partials[(size_t)e * gridDim.x] = 0.0;
+    ss_hess_block(hk, hs, sX, hta, true);
+    return;
+  }
+  const int nwk = (int)gridDim.x - (HOST ? 1 : 0), me = (int)blockIdx.x - (HOST ? 1 : 0);
+  const int tpw = (ntiles + nwk - 1) / nwk;
+  const int tq = ntiles / nwk, tr = ntiles - tq * nwk;
+  const int tile0 = HOST ? me * tq + min(me, tr) : me * tpw;
+  const int tile1 = HOST ? tile0 + tq + (me < tr ? 1 : 0) : min(tile0 + tpw, ntiles);
+  // x[gp][ks]: rows (2 li, 2 li + 1) of the wavefront's 32-row block gp, column 4 ks + q4 (column 31 does not exist: past the
+  // descriptor's records — zeros against T's zero row). Block gp of wavefront wv = rows 128 gp + 32 wv … of the tile: the four
+  // wavefronts' loads of one (gp, ks) cover 1 KB of each column in one piece
+  ss_d2 xa[2][NKS], xb[2][NKS];
+  const unsigned nrec = (unsigned)((((int64_t)(K - 1)) * ldv + n) * 8);
+  const unsigned voff = (unsigned)(((int64_t)q4 * ldv + 32 * wv + 2 * li) * 8);
+  const unsigned colb = (unsigned)(ldv * 32);   // four columns, in bytes
+  auto prefetch = [&](ss_d2 (&x)[2][NKS], int gp, int tile) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, tile < 0 ? 0 : (int)nrec, 0x00020000);
+    const unsigned tb0 = (unsigned)(tile < 0 ? 0 : tile) * (unsigned)(SS_R * 8) + (unsigned)gp * 1024u;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      x[gp][ks] = __builtin_bit_cast(ss_d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(tb0 + (unsigned)ks * colb), 0));
+  };
+  if (tile0 < tile1) {   // both register sets are in flight while T is formed
+    prefetch(xa, 0, tile0);
+    prefetch(xa, 1, tile0);
+    prefetch(xb, 0, tile0 + 1 < tile1 ? tile0 + 1 : -1);
+    prefetch(xb, 1, tile0 + 1 < tile1 ? tile0 + 1 : -1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double tb[NKS];
+  ss_mm_form_t<S, KC>(coef, sX, tb);
+  ss_d4 acc[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
+  // staging: the row pair of basis column 4 ks + q4 (ks < 4); Gram operand: rows 2 q4 + 8 rr (+ 1) of column li
+  ss_d2 *pst = reinterpret_cast<ss_d2 *>(sX + q4 * SS_P2 + 32 * wv + 2 * li);
+  const ss_d2 *pva = reinterpret_cast<const ss_d2 *>(sX + li * SS_P2 + 32 * wv + 2 * q4);
+  auto process = [&](ss_d2 (&x)[2][NKS], int tile, bool valid, int next) __attribute__((always_inline)) {
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) pst[(4 * ks * SS_P2 + 128 * gp) / 2] = x[gp][ks];
+    }
+    // rows of this tile that exist (a tile without data arrived as zeros: nothing to mask)
+    const int64_t rv64 = n - (int64_t)tile * SS_R;
+    const int rv = __builtin_amdgcn_readfirstlane(valid ? (rv64 > SS_R ? SS_R : (rv64 < 0 ? 0 : (int)rv64)) : SS_R);
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      ss_d4 qe = ss_d4{0.0, 0.0, 0.0, 0.0}, qo = ss_d4{0.0, 0.0, 0.0, 0.0};   // the even rows' group, the odd rows' group
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#if NK_SS_EXP == 1
+        qe[ks & 3] += x[gp][ks].x; qo[ks & 3] += x[gp][ks].y;   // (the loads stay alive)
+#else
+        qe = __builtin_amdgcn_mfma_f64_16x16x4f64(x[gp][ks].x, tb[ks], qe, 0, 0, 0);
+        qo = __builtin_amdgcn_mfma_f64_16x16x4f64(x[gp][ks].y, tb[ks], qo, 0, 0, 0);
+#endif
+      }
+      ss_d2 va[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) va[rr] = pva[(128 * gp + 8 * rr) / 2];
+      // the registers are consumed: request them again for the tile after next
+      __builtin_amdgcn_sched_barrier(0);
+#if NK_SS_EXP < 2
+      prefetch(x, gp, next);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if (rv < SS_R) {   // the ragged tile: product lane (li, q4), entry rr is row 128 gp + 32 wv + 2 (q4 + 4 rr) (+ 1) of the tile
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = 128 * gp + 32 * wv + 2 * q4 + 8 * rr;
+          if (r >= rv) { qe[rr] = 0.0; va[rr].x = 0.0; }
+          if (r + 1 >= rv) { qo[rr] = 0.0; va[rr].y = 0.0; }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+#if NK_SS_EXP == 1
+        acc[0][rr] += va[rr].x + qe[rr]; acc[1][rr] += va[rr].y + qo[rr];
+#else
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[rr].x, qe[rr], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qe[rr], qe[rr], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[rr].y, qo[rr], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qo[rr], qo[rr], acc[1], 0, 0, 0);
+#endif
+      }
+    }
+  };
+  auto pair = [&](int tile) __attribute__((always_inline)) {
+    process(xa, tile, true, tile + 2 < tile1 ? tile + 2 : -1);
+    process(xb, tile + 1, tile + 1 < tile1, tile + 3 < tile1 ? tile + 3 : -1);
+  };
+  if (tile0 < tile1) {   // (first pair peeled: the loop's waits are then the steady state's)
     pair(tile0);
     for (int tile = tile0 + 2; tile < tile1; tile += 2) pair(tile);
   }
@@ -1293,7 +1510,30 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
                             d_skip, ntiles, mark, ta, hk, hs);                                                            \
   } while (0)
       const bool nostore = (flags & 1) != 0;   // (the cycle's last block: nk_ss_cycle)
-      if (hostB && nostore) { NK_REQUIRE(k == 16, "internal: no hosting sweep B behind one column that stores nothing"); SS_MM(16, true, true); }
+      // the read-only form behind 16 columns (k_ss_block_ro): 32-bit byte offsets over the whole basis, 16-byte row pairs
+      static const bool ro_on = !(getenv("NK_SS_RO") && atoi(getenv("NK_SS_RO")) == 0);   // A/B switch
+      const bool ro = nostore && k == 16 && ro_on && (occ_out || ((int64_t)(k + S) * ldv * 8 < ((int64_t)1 << 32) - 8 &&
+                                                                   (ldv & 1) == 0 && ((uintptr_t)V & 15) == 0));
+      if (ro) {
+        const size_t tile_r = (size_t)16 * SS_P2 * sizeof(double), red_r = (size_t)4 * 2 * 256 * sizeof(double);
+        size_t lds_r = tile_r > red_r ? tile_r : red_r;
+        if (ws_b > lds_r) lds_r = ws_b;
+#define SS_RO(HST)                                                                                                        \
+  do {                                                                                                                    \
+    if (lds_r > 64 * 1024)                                                                                                \
+      NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ss_block_ro<S, 16, HST>),                              \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                                \
+    if (occ_out) {                                                                                                        \
+      NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ_out, k_ss_block_ro<S, 16, HST>, SS_R, lds_r));              \
+    } else if (ev) hipExtLaunchKernelGGL((k_ss_block_ro<S, 16, HST>), dim3(g), dim3(SS_R), lds_r, ctx->stream, e0, e1, 0, n, V, \
+                                         ldv, coef, partials, d_skip, ntiles, mark, ta, hk, hs);                          \
+    else hipLaunchKernelGGL((k_ss_block_ro<S, 16, HST>), dim3(g), dim3(SS_R), lds_r, ctx->stream, n, V, ldv, coef, partials, \
+                            d_skip, ntiles, mark, ta, hk, hs);                                                            \
+  } while (0)
+        if (hostB) SS_RO(true); else SS_RO(false);
+#undef SS_RO
+      }
+      else if (hostB && nostore) { NK_REQUIRE(k == 16, "internal: no hosting sweep B behind one column that stores nothing"); SS_MM(16, true, true); }
       else if (hostB) { if (k == 1) SS_MM(1, true, false); else SS_MM(16, true, false); }
       else if (nostore) { if (k == 1) SS_MM(1, false, true); else SS_MM(16, false, true); }
       else { if (k == 1) SS_MM(1, false, false); else SS_MM(16, false, false); }
@@ -1841,9 +2081,10 @@ extern "C" int nk_ss_debug_stamps(int enable, unsigned long long *out5) {
 // Runs one sweep on caller data: V (n × (k+s), column-major, leading dimension n, HOST), coef = [U ; R] (k·s + s·s, HOST; the
 // sweep computes X ← (X − V U) R⁻¹); returns the
 // updated columns, the reduced Gram block ((k+s) × s, row-major) and the average kernel time over `iters` launches.
-extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, double *V_host, const double *coef_host,
+extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode_in, int64_t n, int k, int s, double *V_host, const double *coef_host,
                                 double *gram_out, int iters, double *avg_us) {
   NK_REQUIRE(ctx && V_host, "NULL argument");
+  const int mode = mode_in == 3 ? 1 : mode_in, flags = mode_in == 3 ? 1 : 0;   // (3: the sweep B that stores nothing — the Gram block only)
   NK_HIP(hipSetDevice(ctx->device));
   double *dV = nullptr, *dc = nullptr, *dp = nullptr;
   const int grid = mode == 0 ? nk_ss_grid_a(ctx, n, k, s, false) : nk_ss_grid(ctx, n, k, s);
@@ -1857,7 +2098,7 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
     for (int c = 0; c < s; ++c) hc[(size_t)k * s + (size_t)c * s + c] = 1.0 / hc[(size_t)k * s + (size_t)c * s + c];
     NK_HIP(nk_memcpy(ctx, dc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr));
+  NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr, 0, 0, flags));
   NK_HIP(hipStreamSynchronize(ctx->stream));
   NK_HIP(nk_memcpy(ctx, V_host, dV, nv * sizeof(double), hipMemcpyDeviceToHost));
   if (mode != 2 && gram_out) {
@@ -1874,7 +2115,7 @@ extern "C" int nk_ss_sweep_test(nk_ctx *ctx, int mode, int64_t n, int k, int s, 
     NK_HIP(hipEventCreate(&e0));
     NK_HIP(hipEventCreate(&e1));
     NK_HIP(hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters; ++i) NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr));
+    for (int i = 0; i < iters; ++i) NK_TRY(nk_ss_sweep(ctx, mode, n, k, s, dV, n, dc, dp, nullptr, grid, nullptr, nullptr, 0, 0, flags));
     NK_HIP(hipEventRecord(e1, ctx->stream));
     NK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

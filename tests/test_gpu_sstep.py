@@ -48,6 +48,34 @@ def test_block_sweeps_match_numpy(nls, n, k, s):
         _sweep(nls, mode, n, k, s, rng)
 
 
+@pytest.mark.parametrize("n,k", [(4096, 16), (70002, 16), (70001, 16), (300, 16), (65538, 16), (2, 16), (1 << 20, 16), (262144 + 64 + 6, 16),
+                                 (100000, 1), (5001, 1)])
+def test_sweep_b_that_stores_nothing(nls, n, k):
+    """The cycle's last block: sweep B leaves the columns as the matrix powers wrote them and returns the Gram block of the update
+    it formed in registers. Behind 16 columns with an even leading dimension that is the read-only kernel (operands loaded in the
+    matrix instruction's layout, rows of a tile in a different order, only the basis columns staged in LDS): full tiles, ragged
+    tiles inside a wavefront's row pair block and between wavefronts, fewer rows than a wavefront; an odd leading dimension and
+    the block behind one column take the staging kernel."""
+    from nonlinearsolve_jl_amd import _lib as L
+    f = L.lib().nk_ss_sweep_test
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                  C.POINTER(C.c_double)]
+    rng = np.random.default_rng(n + k)
+    s = 15
+    V = np.asfortranarray(rng.standard_normal((n, k + s)))
+    U = rng.standard_normal((k, s)) * 0.1
+    Rup = np.triu(rng.standard_normal((s, s))) * 0.3 + 2 * np.eye(s)
+    coef = np.concatenate([U.ravel(), Rup.ravel()])
+    V0, gram, us = V.copy(), np.zeros((k + s, s)), C.c_double(0)
+    assert f(nls.default_context()._h, 3, n, k, s, V.ctypes.data, coef.ctypes.data, gram.ctypes.data, 0, C.byref(us)) == 0, \
+        L.lib().nk_last_error()
+    assert np.array_equal(V, V0)
+    Wn = (V0[:, k:] - V0[:, :k] @ U) @ np.linalg.inv(Rup)
+    gref = np.concatenate([V0[:, :k], Wn], axis=1).T @ Wn
+    assert np.max(np.abs(gram - gref)) <= 1e-12 * np.max(np.abs(gref))
+
+
 @pytest.mark.parametrize("k", [1, 16, 7])
 def test_update_sweep_with_an_ill_conditioned_factor(nls, k):
     """X ← (X − V U) R⁻¹ with κ(R) = 1e5 (pivot ratio 1e-10: two decades above the rank-loss bar): the matrix-core form of the
