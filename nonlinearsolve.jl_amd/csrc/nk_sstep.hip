@@ -925,13 +925,18 @@ __global__ __launch_bounds__(SS_R) void k_ss_block(int64_t n, int k_rt, double *
 
 // T = [−U N ; N], N = R⁻¹ (upper triangular; `coef` = U (k × S) then R with a reciprocal diagonal), formed in LDS scratch at sX by
 // the whole workgroup; returns each lane's share as matrix-core B operands: tb[ks] = T[4 ks + q4][li] (rows ≥ k + S and column
-// S … 15 zero). Ends with a barrier (the scratch overlays the tile).
+// S … 15 zero). Ends with a barrier (the scratch overlays the tile). (c0, c1) = coef[t], coef[t + 256] — requested by the caller
+// BEFORE its first tiles: vector memory returns in order, and behind two tiles per workgroup of a grid that has just started
+// (63 MB on the chip) the coefficients arrived ≈ 6 µs late, the matrix pipe idle until T was formed
+// (profiles/r06_u_sweep_b_prologue.txt).
 template <int S, int KC>
-__device__ __forceinline__ void ss_mm_form_t(const double *__restrict__ coef, double *sX, double (&tb)[(KC + S + 3) / 4]) {
+__device__ __forceinline__ void ss_mm_form_t(double c0, double c1, double *sX, double (&tb)[(KC + S + 3) / 4]) {
   constexpr int k = KC, K = KC + S, NKS = (K + 3) / 4;
+  static_assert(k * S + S * S <= 2 * SS_R, "two coefficients per thread");
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, q4 = lane >> 4;
   double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + 256;
-  for (int e = t; e < k * S + S * S; e += SS_R) sX[e] = coef[e];
+  sX[t] = c0;
+  if (t + SS_R < k * S + S * S) sX[t + SS_R] = c1;
   __syncthreads();
   if (t < S) {   // row t of N: n R = e_t by forward substitution (R's diagonal arrives as reciprocals)
     double nr[S];
@@ -1027,6 +1032,11 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
 #pragma unroll
     for (int j = 0; j < KC; ++j) vrx[j] = V[(size_t)j * cs + rc];
   };
+  // (the coefficients are requested in front of the tiles: vector memory returns in order — ss_mm_form_t)
+  constexpr int NCOEF = KC * S + S * S;
+  static_assert(NCOEF <= 2 * SS_R, "two coefficients per thread");
+  const double cf0 = coef[t < NCOEF ? t : 0], cf1 = coef[t + SS_R < NCOEF ? t + SS_R : 0];
+  __builtin_amdgcn_sched_barrier(0);
   if (tile0 < tile1) {   // both register sets are in flight while T is formed
     prefetch(vr, w, tile0);
     prefetch(vr2, w2, tile0 + 1 < tile1 ? tile0 + 1 : -1);
@@ -1036,7 +1046,8 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   double tb[NKS];
   {
     double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + 256;
-    for (int e = t; e < k * S + S * S; e += SS_R) sX[e] = coef[e];
+    sX[t] = cf0;
+    if (t + SS_R < NCOEF) sX[t + SS_R] = cf1;
     __syncthreads();
     if (t < S) {   // row t of N: n R = e_t by forward substitution (R's diagonal arrives as reciprocals)
       double nr[S];
@@ -1281,6 +1292,9 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_ro(int64_t n, const double *_
     for (int ks = 0; ks < NKS; ++ks)
       x[gp][ks] = __builtin_bit_cast(ss_d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(tb0 + (unsigned)ks * colb), 0));
   };
+  constexpr int NCOEF = KC * S + S * S;
+  const double cf0 = coef[t < NCOEF ? t : 0], cf1 = coef[t + SS_R < NCOEF ? t + SS_R : 0];   // (in front of the tiles: ss_mm_form_t)
+  __builtin_amdgcn_sched_barrier(0);
   if (tile0 < tile1) {   // both register sets are in flight while T is formed
     prefetch(xa, 0, tile0);
     prefetch(xa, 1, tile0);
@@ -1289,7 +1303,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_ro(int64_t n, const double *_
   }
   __builtin_amdgcn_sched_barrier(0);
   double tb[NKS];
-  ss_mm_form_t<S, KC>(coef, sX, tb);
+  ss_mm_form_t<S, KC>(cf0, cf1, sX, tb);
   ss_d4 acc[NT];
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
@@ -1432,6 +1446,12 @@ int nk_ss_grid_a(nk_ctx *ctx, int64_t n, int k, int s, bool hosting) {
   return ctx->num_cus + (hosting ? host_extra : 0);
 }
 
+// Sweep B that stores nothing takes the read-only kernel (k_ss_block_ro): behind 16 columns, 32-bit byte offsets over the whole
+// basis, 16-byte row pairs
+static bool ss_b_is_read_only(const double *V, int64_t ldv, int k, int s) {
+  static const bool ro_on = !(getenv("NK_SS_RO") && atoi(getenv("NK_SS_RO")) == 0);   // A/B switch
+  return ro_on && k == 16 && s == 15 && (int64_t)(k + s) * ldv * 8 < ((int64_t)1 << 32) - 8 && (ldv & 1) == 0 && ((uintptr_t)V & 15) == 0;
+}
 template <int S>
 static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64_t ldv, const double *coef, double *partials,
                        const int *d_skip, int grid, const ss_tail_args *tap, int *mark, int *occ_out = nullptr, int hk = 0,
@@ -1511,9 +1531,7 @@ static int ss_launch_s(nk_ctx *ctx, int mode, int64_t n, int k, double *V, int64
   } while (0)
       const bool nostore = (flags & 1) != 0;   // (the cycle's last block: nk_ss_cycle)
       // the read-only form behind 16 columns (k_ss_block_ro): 32-bit byte offsets over the whole basis, 16-byte row pairs
-      static const bool ro_on = !(getenv("NK_SS_RO") && atoi(getenv("NK_SS_RO")) == 0);   // A/B switch
-      const bool ro = nostore && k == 16 && ro_on && (occ_out || ((int64_t)(k + S) * ldv * 8 < ((int64_t)1 << 32) - 8 &&
-                                                                   (ldv & 1) == 0 && ((uintptr_t)V & 15) == 0));
+      const bool ro = nostore && (occ_out ? k == 16 : ss_b_is_read_only(V, ldv, k, S));
       if (ro) {
         const size_t tile_r = (size_t)16 * SS_P2 * sizeof(double), red_r = (size_t)4 * 2 * 256 * sizeof(double);
         size_t lds_r = tile_r > red_r ? tile_r : red_r;
@@ -2610,15 +2628,22 @@ int nk_ss_cycle(nk_gmres *G, int steps, const std::function<bool(int)> &wait_pro
         }
         NK_TRY(ss_launch_job(ctx, j, ta, (dp.on && !host_a) ? dp.ta : ta));
       }
+      // the read-only sweep runs ONE workgroup per CU where the tiles allow (as the read-only sweeps A do: stand-alone 52 → 48 µs
+      // at 1024² — half the prologues and partial sums, one wavefront per SIMD on the matrix pipe)
+      static const bool ro_grid_off = getenv("NK_SS_RO_GRID") && atoi(getenv("NK_SS_RO_GRID")) == 0;   // A/B switch
+      int grid_b = grid;
+      if (raw_last && !host_b && !ro_grid_off && ss_b_is_read_only(G->V, ldv, k, sb) && (n + SS_R - 1) / SS_R >= 2 * (int64_t)ctx->num_cus &&
+          grid > ctx->num_cus)
+        grid_b = ctx->num_cus;
       {
         nk_prof_scope prof_(ctx, NK_K_MULTIDOT, 8.0 * (double)n * (k + (raw_last ? 1 : 2) * sb));
         ss_tail_args hta = dp.ta;
         hta.Wi = nullptr; hta.D = nullptr;   // (prepared by the job already)
-        NK_TRY(nk_ss_sweep(ctx, 1, n, k, sb, G->V, ldv, W->coef, W->part2, done, grid, host_b ? &hta : nullptr, nullptr,
+        NK_TRY(nk_ss_sweep(ctx, 1, n, k, sb, G->V, ldv, W->coef, W->part2, done, grid_b, host_b ? &hta : nullptr, nullptr,
                            host_b ? dp.k : 0, host_b ? dp.sb : 0, raw_last ? 1 : 0));
       }
       if (raw_last) raw_on = true;
-      dp.on = true; dp.k = k; dp.sb = sb; dp.grid = grid; dp.ta = ta;
+      dp.on = true; dp.k = k; dp.sb = sb; dp.grid = grid_b; dp.ta = ta;
       {
         nk_ss_fix &fx = G->ss_fix;
         NK_REQUIRE(fx.n < NK_SS_NFIX, "internal: too many s-step blocks left at their first pass");
