@@ -372,8 +372,8 @@ def main():
     FAMILY = {"spmv": ("k_spmv_stream", r"k_spmv_stream<"),
               "spmv_powers": ("k_spmv_powers", r"k_spmv_powers<"),
               "jvp": ("k_bratu_jvp", r"k_bratu_jvp"),
-              "multidot": ("k_ss_block<S, false, true, …> + k_ss_block_mm<S, k> (s-step sweeps A and B: Gram blocks — and B's update — on the FP64 matrix cores)"
-                           if args.ortho == "sstep" else "k_dcgs2r_dots", r"(k_ss_block<\d+, (true|false), true|k_ss_block_mm<)" if args.ortho == "sstep" else r"k_dcgs2r_dots"),
+              "multidot": ("k_ss_block<S, false, true, …> + k_ss_block_mm<S, k> / k_ss_block_ro<S, k> (s-step sweeps A and B: Gram blocks — and B's update — on the FP64 matrix cores)"
+                           if args.ortho == "sstep" else "k_dcgs2r_dots", r"(k_ss_block<\d+, (true|false), true|k_ss_block_mm<|k_ss_block_ro<)" if args.ortho == "sstep" else r"k_dcgs2r_dots"),
               "multiaxpy": ("k_ss_block<S, true, false, …> + k_multiaxpy (sweep C, x = V y)" if args.ortho == "sstep" else "k_dcgs2r_axpy_tail",
                             r"(k_ss_block<\d+, true, false|k_multiaxpy)" if args.ortho == "sstep" else r"k_dcgs2r_axpy")}
     roof = None

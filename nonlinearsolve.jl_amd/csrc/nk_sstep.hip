@@ -956,8 +956,9 @@ __device__ __forceinline__ void ss_mm_form_t(double c0, double c1, double *sX, d
     double v = 0.0;
     if (c < S) {
       if (j < k) {
-        double a = 0.0;
-        for (int c2 = 0; c2 <= c; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
+        double a = 0.0;   // (all S terms, unrolled — N is upper triangular, the terms past c are exact zeros: one LDS latency, not c)
+#pragma unroll
+        for (int c2 = 0; c2 < S; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
         v = -a;
       } else if (j < K) {
         v = sN[(j - k) * 16 + c];
@@ -1067,8 +1068,9 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
       double v = 0.0;
       if (c < S) {
         if (j < k) {
-          double a = 0.0;
-          for (int c2 = 0; c2 <= c; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
+          double a = 0.0;   // (all S terms, unrolled — N is upper triangular, the terms past c are exact zeros: one LDS latency, not c)
+#pragma unroll
+          for (int c2 = 0; c2 < S; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
           v = -a;
         } else if (j < K) {
           v = sN[(j - k) * 16 + c];

@@ -504,7 +504,8 @@ _SWITCH_CODE = (
                                  dict(NK_SS_TAIL_BACK="0"), dict(NK_SS_HOST_B="0"), dict(NK_SS_IMPLICIT="0"),
                                  dict(NK_SS_FUSED="0"), dict(NK_SS_HOST_A="0"), dict(NK_SS_HOST_A_WGS="2"),
                                  dict(NK_FUSED_UPDATE="0", NK_FUSED_RESIDUAL_NORMS="0"), dict(NK_PRELOADED_RHS="0"),
-                                 dict(NK_SS_NOSTORE="0"), dict(NK_BEGIN_AHEAD="0"), dict(NK_FOLD_NORMS="0")])   # (round 6's three)
+                                 dict(NK_SS_NOSTORE="0"), dict(NK_BEGIN_AHEAD="0"), dict(NK_FOLD_NORMS="0"),
+                                 dict(NK_SS_RO="0"), dict(NK_SS_RO_GRID="0")])   # (round 6's five)
 def test_every_form_behind_an_ab_switch_reaches_the_same_iterates(env):
     """The s-step cycle's forms that the defaults do not take — the second factorisation in a launch of its own (round 4's cycle),
     the Hessenberg work inside the scalar launch / hosted by sweep B whatever the protocol, the back-substitution as a launch of

@@ -112,8 +112,8 @@ def canonical(kernel_name):
     import re
     nm = re.sub(r"^void ", "", kernel_name)
     nm = re.sub(r"\(.*$", "", nm)
-    if nm.startswith("k_ss_block_mm<"):   # sweep B of the default cycle's shapes: update and Gram block on the matrix cores
-        return "k_ss_block<B>"
+    if nm.startswith("k_ss_block_mm<") or nm.startswith("k_ss_block_ro<"):   # sweep B of the default cycle's shapes: update and Gram
+        return "k_ss_block<B>"                                                 # block on the matrix cores (_ro: the last block's, read-only)
     if nm.startswith("k_ss_block<"):
         f = [x.strip() for x in nm[len("k_ss_block<"):].rstrip(">").split(",")]
         upd, gram = f[1] in ("true", "1"), f[2] in ("true", "1")
