@@ -16,6 +16,7 @@ B="--cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --steps 300 --warmup 20 --no
 timeout 100 python bench.py $B --matfree < /dev/null > $O/bench_matfree.json 2> /dev/null
 timeout 100 python bench.py $B --workload c5 < /dev/null > $O/bench_c5.json 2> /dev/null
 NK_SS_NOSTORE=0 timeout 100 python bench.py $B < /dev/null > $O/bench_last_block_stored.json 2> /dev/null
+NK_SS_RO=0 NK_SS_RO_GRID=0 timeout 100 python bench.py $B < /dev/null > $O/bench_last_block_staging_kernel.json 2> /dev/null
 NK_SS_NOSTORE=0 NK_BEGIN_AHEAD=0 NK_FOLD_NORMS=0 timeout 100 python bench.py $B < /dev/null > $O/bench_round5_dispatch.json 2> /dev/null
 timeout 100 python bench.py $B < /dev/null > $O/bench_quick_default.json 2> /dev/null
 timeout 100 python bench.py --workload c4 --steps 10 --warmup 2 --cpu-seconds 0 --no-ttt --no-spmv-hbm --pmc off --no-profile-pass < /dev/null > $O/bench_c4size_1gpu.json 2> /dev/null
