@@ -2068,7 +2068,7 @@ __device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args 
   }
 #ifdef NK_SS_STAMPS
   if (t == 0 && g_ss_stamp != nullptr) {
-    const int bank = bk ? 2 : ((f1 && f2) ? 1 : 0);
+    const int bank = bk ? 2 : (((f1 && f2) || j.host_wgs > 0) ? 1 : 0);   // (1: both factorisations — or the job a sweep A hosts)
     for (int i = 0; i < 16; ++i) g_ss_stamp[16 * bank + i] = s_ss_stamps[i];
   }
 #endif

@@ -25,7 +25,7 @@ for _ in range(3):
     cache.step()
     f(1, out)
     v = list(out)
-    for bank, what in enumerate(("first block", "second block", "cycle's last launch")):
+    for bank, what in enumerate(("first block", "second block / the job hosted by sweep A", "cycle's last launch")):
         b = v[16 * bank:16 * bank + 16]
         if b[0] == 0:
             continue
