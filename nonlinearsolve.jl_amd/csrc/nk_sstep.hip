@@ -2045,7 +2045,6 @@ __device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args 
       if (!(alive && hs)) {   // (a failure inside this launch: the columns closed before this block count, x stays as it is)
         vd[0] = (double)j.ctl->k; vd[1] = 0.0; vd[2] = alive ? (double)j.ctl->failed : 2.0; vd[3] = j.ctl->rnorm;
       }
-      ss_publish_outcome(j.pub, j.seq, j.peer_err, (int)vd[0], (int)vd[1], (int)vd[2], vd[4], vd[3]);
     }
     if (alive && f2 && t == 0) {   // the pending block's factors: in LDS already
       const int q = j.bfx.n - 1;
@@ -2064,6 +2063,9 @@ __device__ __forceinline__ void ss_job_body(const ss_job &j, const ss_tail_args 
     __syncthreads();
     SS_STAMP(14);
     ss_backsolve((int)vd[0], (int)vd[2], (int)L.sR, L.LK, (alive && hs) ? w1.o0 + ss_ws_off(j.k1, j.sb1).sg : (int)L.sg, (int)L.rdv, j.y, j.m, bc3, lds3);
+    // the outcome goes to the host from the LAST wavefront, which has left the back-substitution behind its parallel phase: the
+    // system-scope fence (≈ 1.2 µs) runs beside the first wavefront's dependent chain instead of in front of it
+    if (t == SS_R - 1) ss_publish_outcome(j.pub, j.seq, j.peer_err, (int)vd[0], (int)vd[1], (int)vd[2], vd[4], vd[3]);
     SS_STAMP(15);
   }
 #ifdef NK_SS_STAMPS
