@@ -49,6 +49,7 @@ def test_block_sweeps_match_numpy(nls, n, k, s):
 
 
 @pytest.mark.parametrize("n,k", [(4096, 16), (70002, 16), (70001, 16), (300, 16), (65538, 16), (2, 16), (1 << 20, 16), (262144 + 64 + 6, 16),
+                                 (254, 16), (256, 16), (258, 16), (32, 16), (34, 16), (130, 16), (131072 + 128 + 30, 16), (7 * 256 * 256 + 98, 16),
                                  (100000, 1), (5001, 1)])
 def test_sweep_b_that_stores_nothing(nls, n, k):
     """The cycle's last block: sweep B leaves the columns as the matrix powers wrote them and returns the Gram block of the update
