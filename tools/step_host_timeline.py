@@ -22,7 +22,7 @@ def main():
             if "Launch" in r["Function"]:
                 api[r.get("Correlation_Id")] = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"])
     kern.sort()
-    starts = [i for i, r in enumerate(kern) if r[2].startswith("k_bratu_jac")]
+    starts = [i for i, r in enumerate(kern) if r[2].startswith(("k_bratu_jac", "k_bratu_residual_jac"))]
     if len(starts) < 4:
         print("no steps found")
         return

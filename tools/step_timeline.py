@@ -17,7 +17,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
     # a Newton step starts with the Jacobian fill (k_bratu_jac); take the last but one complete step
-    starts = [i for i, r in enumerate(rows) if r[2].startswith("k_bratu_jac")]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith(("k_bratu_jac", "k_bratu_residual_jac"))]
     if len(starts) < 4:
         print("no steps found")
         return
