@@ -1045,44 +1045,7 @@ __global__ __launch_bounds__(SS_R) void k_ss_block_mm(int64_t n, double *__restr
   __builtin_amdgcn_sched_barrier(0);
   // ---- T = [−U N ; N] in LDS (the tile is not in use yet), then each lane's share of it as matrix-core B operands
   double tb[NKS];
-  {
-    double *sU = sX, *sR = sU + k * S, *sN = sR + S * S, *sT = sN + 256;
-    sX[t] = cf0;
-    if (t + SS_R < NCOEF) sX[t + SS_R] = cf1;
-    __syncthreads();
-    if (t < S) {   // row t of N: n R = e_t by forward substitution (R's diagonal arrives as reciprocals)
-      double nr[S];
-#pragma unroll
-      for (int c = 0; c < S; ++c) {
-        double a = (c == t) ? 1.0 : 0.0;
-#pragma unroll
-        for (int c2 = 0; c2 < c; ++c2) a = __builtin_fma(-nr[c2], sR[c2 * S + c], a);
-        nr[c] = (c < t) ? 0.0 : a * sR[c * S + c];
-      }
-#pragma unroll
-      for (int c = 0; c < S; ++c) sN[t * 16 + c] = nr[c];
-    }
-    __syncthreads();
-    for (int e = t; e < 4 * NKS * 16; e += SS_R) {
-      const int j = e >> 4, c = e & 15;
-      double v = 0.0;
-      if (c < S) {
-        if (j < k) {
-          double a = 0.0;   // (all S terms, unrolled — N is upper triangular, the terms past c are exact zeros: one LDS latency, not c)
-#pragma unroll
-          for (int c2 = 0; c2 < S; ++c2) a = __builtin_fma(sU[j * S + c2], sN[c2 * 16 + c], a);
-          v = -a;
-        } else if (j < K) {
-          v = sN[(j - k) * 16 + c];
-        }
-      }
-      sT[e] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) tb[ks] = sT[(4 * ks + q4) * 16 + li];
-    __syncthreads();   // (the scratch overlays the tile)
-  }
+  ss_mm_form_t<S, KC>(cf0, cf1, sX, tb);
   ss_d4 acc[NT];
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) acc[mt] = ss_d4{0.0, 0.0, 0.0, 0.0};
